@@ -1,0 +1,402 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ by EXECUTING THE REFERENCE'S OWN PYTHON.
+
+Run in the build container only (needs /root/reference):
+
+    python tests/golden/make_golden.py
+
+The reference (traveller59/second.pytorch) cannot be imported as-is here: numba and spconv
+are absent.  This script therefore installs *execution shims* --
+they contain no algorithm, they only let the reference's unmodified source run:
+
+  * ``numba.jit/njit``         -> identity decorators (the jitted helpers run as plain Python);
+  * ``numba.cuda``             -> a tiny SIMT emulator: ``kernel[grid, block, stream](*args)``
+                                  runs one Python thread per CUDA thread of a block, with
+                                  ``cuda.syncthreads()`` = ``threading.Barrier``,
+                                  ``cuda.shared.array`` = one numpy array per block,
+                                  ``cuda.local.array`` = fresh numpy array,
+                                  ``cuda.blockIdx/threadIdx`` = thread-local proxies.
+                                  So ``rotate_nms_gpu``, ``nms_gpu``, ``rotate_iou_gpu_eval``
+                                  (second/core/non_max_suppression/nms_gpu.py) execute verbatim.
+  * ``spconv``, ``cv2``, ``torchvision.models.resnet`` -> empty stand-ins (import only).
+
+Arithmetic caveat (documented in DESIGN.md): under the shim, fp32 scalars follow numpy
+(NEP 50) promotion, numba would promote a few intermediates to fp64; both are within
+1e-6 of each other, tests use 2e-5 absolute on IoU values and exact match on keep lists.
+
+Outputs (all small .npz):
+  rotate_iou.npz        boxes/qboxes -> iou for criterion -1,0,1,2   (rotate_iou_gpu_eval)
+  rotate_nms.npz        dets, thresholds -> keep lists                (rotate_nms_gpu)
+  nms_axis_aligned.npz  dets -> keep (nms_gpu, '+1' convention) and nms_jit ('>=' eps)
+  standup.npz           center_to_corner_box2d / corner_to_standup_nd / iou_jit(eps=0)
+  voxel_coords.npz      simplevis._points_to_bevmap_reverse_kernel: per-point voxel ids
+  torch_modules.npz     SimpleVoxel, second_box_decode, limit_period, PointPillarsScatter,
+                        PillarFeatureNet, RPNV2 (small) forward on seeded inputs + weights
+"""
+import collections
+import collections.abc
+import contextlib
+import os
+import sys
+import threading
+import types
+
+import numpy as np
+
+REF = os.environ.get("SECOND_REFERENCE", "/root/reference")
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+# --------------------------------------------------------------------------- shims
+class _Idx:
+    def __init__(self, tls, name):
+        self._tls, self._name = tls, name
+
+    def _get(self, i):
+        return getattr(self._tls, self._name)[i]
+
+    x = property(lambda s: s._get(0))
+    y = property(lambda s: s._get(1))
+    z = property(lambda s: s._get(2))
+
+
+class _DevArray(np.ndarray):
+    def copy_to_host(self, ary=None, stream=None):
+        if ary is None:
+            return np.array(self)
+        ary[...] = np.asarray(self).reshape(ary.shape)
+        return ary
+
+
+class _Stream:
+    @contextlib.contextmanager
+    def auto_synchronize(self):
+        yield self
+
+    def synchronize(self):
+        pass
+
+
+class _Kernel:
+    def __init__(self, fn, tls):
+        self.fn, self.tls = fn, tls
+        self.__name__ = getattr(fn, "__name__", "kernel")
+
+    def __call__(self, *a, **k):  # device function call
+        return self.fn(*a, **k)
+
+    def __getitem__(self, cfg):
+        grid, block = cfg[0], cfg[1]
+        grid = tuple(grid) if isinstance(grid, (tuple, list)) else (grid,)
+        grid = grid + (1,) * (3 - len(grid))
+        nthr = int(block) if not isinstance(block, (tuple, list)) else int(np.prod(block))
+
+        def launch(*args):
+            for bz in range(grid[2]):
+                for by in range(grid[1]):
+                    for bx in range(grid[0]):
+                        self._run_block((bx, by, bz), nthr, args)
+        return launch
+
+    def _run_block(self, bidx, nthr, args):
+        barrier = threading.Barrier(nthr)
+        shared = {}
+        lock = threading.Lock()
+        errors = []
+
+        def body(t):
+            tls = self.tls
+            tls.blockIdx, tls.threadIdx = bidx, (t, 0, 0)
+            tls.barrier, tls.shared, tls.shared_ctr, tls.lock = barrier, shared, 0, lock
+            try:
+                self.fn(*args)
+            except BaseException as e:  # pragma: no cover
+                errors.append(e)
+                barrier.abort()
+        ths = [threading.Thread(target=body, args=(t,)) for t in range(nthr)]
+        [t.start() for t in ths]
+        [t.join() for t in ths]
+        if errors:
+            raise errors[0]
+
+
+def install_shims():
+    collections.Iterable = collections.abc.Iterable  # torchplus/train/optim.py:1 on py>=3.10
+    tls = threading.local()
+
+    def passthrough(*dargs, **dkw):
+        if len(dargs) == 1 and callable(dargs[0]) and not dkw:
+            return dargs[0]
+        return lambda f: f
+
+    numba = types.ModuleType("numba")
+    numba.jit = numba.njit = passthrough
+    for n in ("float32", "float64", "int32", "int64"):
+        setattr(numba, n, getattr(np, n))
+    numba.prange = range
+    cuda = types.ModuleType("numba.cuda")
+
+    def cuda_jit(*dargs, **dkw):
+        if len(dargs) == 1 and callable(dargs[0]) and not dkw:
+            return _Kernel(dargs[0], tls)
+        return lambda f: _Kernel(f, tls)
+
+    cuda.jit = cuda_jit
+    cuda.blockIdx = _Idx(tls, "blockIdx")
+    cuda.threadIdx = _Idx(tls, "threadIdx")
+    cuda.syncthreads = lambda: tls.barrier.wait()
+    cuda.local = types.SimpleNamespace(array=lambda shape, dtype=np.float32: np.zeros(shape, dtype))
+
+    def shared_array(shape, dtype=np.float32):
+        key = tls.shared_ctr
+        tls.shared_ctr += 1
+        with tls.lock:
+            if key not in tls.shared:
+                tls.shared[key] = np.zeros(shape, dtype)
+            return tls.shared[key]
+
+    cuda.shared = types.SimpleNamespace(array=shared_array)
+    cuda.to_device = lambda a, stream=None: np.array(a).view(_DevArray)
+    cuda.stream = lambda: _Stream()
+    cuda.select_device = lambda i: None
+    numba.cuda = cuda
+    sys.modules["numba"], sys.modules["numba.cuda"] = numba, cuda
+
+    def absent(name):
+        def f(*a, **k):
+            raise RuntimeError(f"{name} belongs to the absent spconv dependency")
+        return f
+
+    spconv = types.ModuleType("spconv")
+    utils = types.ModuleType("spconv.utils")
+    for n in ("non_max_suppression", "non_max_suppression_cpu", "rotate_non_max_suppression_cpu",
+              "rbbox_iou", "rbbox_intersection", "VoxelGeneratorV2", "points_to_voxel"):
+        setattr(utils, n, absent(n))
+    import torch
+
+    class _SparseModule(torch.nn.Module):
+        pass
+
+    spconv.SparseModule = _SparseModule
+    spconv.utils = utils
+    sys.modules["spconv"], sys.modules["spconv.utils"] = spconv, utils
+    cv2 = types.ModuleType("cv2")
+    cv2.__getattr__ = lambda name: 0  # constants used as default args at import time
+    sys.modules["cv2"] = cv2
+    tv = types.ModuleType("torchvision")
+    tvm = types.ModuleType("torchvision.models")
+    tvr = types.ModuleType("torchvision.models.resnet")
+    tv.models, tvm.resnet = tvm, tvr
+    sys.modules.update({"torchvision": tv, "torchvision.models": tvm, "torchvision.models.resnet": tvr})
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+
+
+# --------------------------------------------------------------------------- inputs
+def random_rboxes(rng, n, extent=12.0):
+    """(x, y, w, l, r) boxes that overlap often."""
+    xy = rng.uniform(0, extent, (n, 2))
+    wl = rng.uniform(0.8, 4.5, (n, 2))
+    r = rng.uniform(-np.pi, np.pi, (n, 1))
+    return np.concatenate([xy, wl, r], 1).astype(np.float32)
+
+
+def special_rbox_pairs():
+    a = [[0, 0, 1, 1, 0], [0, 0, 1, 1, 0], [0, 0, 1, 1, 0], [0, 0, 2, 4, 0.3], [5, 5, 2, 3, 1.0],
+         [0, 0, 1, 1, 0], [1, 1, 3.9, 1.6, 1.57], [0, 0, 2, 2, 0]]
+    b = [[0, 0, 1, 1, 0], [0.5, 0, 1, 1, 0], [0, 0, 1, 1, np.pi / 4], [0.5, 0.2, 2, 4, -0.4],
+         [50, 50, 2, 3, 1.0], [1.0, 0, 1, 1, 0], [1.2, 0.9, 3.9, 1.6, 0.0], [0, 0, 1, 1, 0.5]]
+    return np.array(a, np.float32), np.array(b, np.float32)
+
+
+# --------------------------------------------------------------------------- generators
+def gen_rotate_iou():
+    import importlib
+    nms_gpu = importlib.import_module('second.core.non_max_suppression.nms_gpu')
+    rng = np.random.default_rng(1)
+    boxes = random_rboxes(rng, 40)
+    qboxes = random_rboxes(rng, 30)
+    sa, sb = special_rbox_pairs()
+    out = {"boxes": boxes, "qboxes": qboxes, "special_a": sa, "special_b": sb}
+    for crit in (-1, 0, 1, 2):
+        out[f"iou_c{crit}"] = nms_gpu.rotate_iou_gpu_eval(boxes, qboxes, crit)
+    out["iou_plain"] = nms_gpu.rotate_iou_gpu(boxes, qboxes)
+    out["special_iou"] = np.array(
+        [nms_gpu.rotate_iou_gpu_eval(sa[i:i + 1], sb[i:i + 1], -1)[0, 0] for i in range(len(sa))], np.float32)
+    np.savez_compressed(os.path.join(OUT, "rotate_iou.npz"), **out)
+    print("rotate_iou: special", out["special_iou"])
+
+
+def gen_rotate_nms():
+    import importlib
+    nms_gpu = importlib.import_module('second.core.non_max_suppression.nms_gpu')
+    rng = np.random.default_rng(2)
+    out = {}
+    for tag, n, ext in (("a", 100, 14.0), ("b", 70, 40.0), ("c", 1, 5.0), ("d", 65, 6.0)):
+        b = random_rboxes(rng, n, ext)
+        scores = rng.permutation(n).astype(np.float32) / n + 0.001  # distinct scores
+        dets = np.concatenate([b, scores[:, None]], 1).astype(np.float32)
+        out[f"dets_{tag}"] = dets
+        for thr in (0.01, 0.3):
+            keep = nms_gpu.rotate_nms_gpu(dets, thr)
+            out[f"keep_{tag}_{thr}"] = np.array(keep, np.int64)
+            print(f"rotate_nms {tag} thr={thr}: keep {len(keep)}/{n}")
+    np.savez_compressed(os.path.join(OUT, "rotate_nms.npz"), **out)
+
+
+def gen_nms_axis_aligned():
+    import importlib
+    nms_gpu = importlib.import_module('second.core.non_max_suppression.nms_gpu')
+    nms_cpu = importlib.import_module('second.core.non_max_suppression.nms_cpu')
+    rng = np.random.default_rng(3)
+    n = 150
+    xy = rng.uniform(0, 60, (n, 2))
+    wh = rng.uniform(2, 25, (n, 2))
+    scores = rng.permutation(n).astype(np.float32) / n + 0.001
+    dets = np.concatenate([xy, xy + wh, scores[:, None]], 1).astype(np.float32)
+    out = {"dets": dets}
+    for thr in (0.1, 0.5):
+        out[f"keep_gpu_{thr}"] = np.array(nms_gpu.nms_gpu(dets, thr), np.int64)
+        out[f"keep_jit_eps0_{thr}"] = np.array(nms_cpu.nms_jit(dets, thr, 0.0), np.int64)
+        out[f"keep_jit_eps1_{thr}"] = np.array(nms_cpu.nms_jit(dets, thr, 1.0), np.int64)
+        print("nms aa", thr, len(out[f"keep_gpu_{thr}"]), len(out[f"keep_jit_eps0_{thr}"]))
+    np.savez_compressed(os.path.join(OUT, "nms_axis_aligned.npz"), **out)
+
+
+def gen_standup():
+    from second.core import box_np_ops
+    rng = np.random.default_rng(4)
+    dets = random_rboxes(rng, 50)
+    corners = box_np_ops.center_to_corner_box2d(dets[:, :2], dets[:, 2:4], dets[:, 4])
+    standup = box_np_ops.corner_to_standup_nd(corners)
+    iou = box_np_ops.iou_jit(standup, standup, eps=0.0)
+    np.savez_compressed(os.path.join(OUT, "standup.npz"), dets=dets, corners=corners.astype(np.float32),
+                        standup=standup.astype(np.float32), standup_iou=iou.astype(np.float32))
+    print("standup: corners", corners.shape, corners.dtype)
+
+
+def gen_voxel_coords():
+    """second/utils/simplevis.py:8-60 is the in-repo copy of spconv's points_to_voxel loop."""
+    from second.utils import simplevis
+    rng = np.random.default_rng(5)
+    out = {}
+    cases = {
+        "kitti": dict(voxel_size=[0.05, 0.05, 0.1], rng_=[0, -40, -3, 70.4, 40, 1], n=3000, cap=40000),
+        "coarse_cap": dict(voxel_size=[0.4, 0.4, 0.5], rng_=[0, -8, -3, 16, 8, 1], n=2500, cap=300),
+    }
+    for tag, c in cases.items():
+        vs = np.array(c["voxel_size"], np.float32)
+        pr = np.array(c["rng_"], np.float32)
+        lo, hi = pr[:3] - 1.0, pr[3:] + 1.0  # some points out of range
+        pts = rng.uniform(lo, hi, (c["n"], 3)).astype(np.float32)
+        # put points exactly on voxel borders / range bounds (fp32 division edge cases)
+        k = c["n"] // 10
+        cells = rng.integers(0, 40, (k, 3)).astype(np.float32)
+        pts[:k] = pr[:3] + cells * vs
+        pts[k] = pr[3:]            # upper bound: must be dropped
+        pts[k + 1] = pr[:3]        # lower bound: kept
+        pts = np.concatenate([pts, rng.uniform(0, 1, (c["n"], 1)).astype(np.float32)], 1)
+        # duplicates so that some voxels hold several points
+        pts[-200:] = pts[100:300]
+        grid = np.round((pr[3:] - pr[:3]) / vs).astype(np.int32)
+        lookup = -np.ones(tuple(grid[::-1]), np.int32)
+        bev = np.zeros((int(grid[2]) + 2, int(grid[1]), int(grid[0])), np.float32)
+        lowers = np.linspace(pr[2], pr[5], int(grid[2]), endpoint=False).astype(np.float32)
+        simplevis._points_to_bevmap_reverse_kernel(pts, vs, pr, lookup, bev, lowers, False, c["cap"])
+        zyx = np.argwhere(lookup >= 0)
+        vid = lookup[lookup >= 0]
+        order = np.argsort(vid)
+        out[f"{tag}_points"] = pts
+        out[f"{tag}_voxel_size"] = vs
+        out[f"{tag}_range"] = pr
+        out[f"{tag}_cap"] = np.int64(c["cap"])
+        out[f"{tag}_coors"] = zyx[order].astype(np.int32)   # voxel id order, (z,y,x)
+        out[f"{tag}_density"] = bev[-1].copy()               # points counted per (y,x) column
+        print("voxel", tag, "grid", grid, "voxels", len(vid))
+    np.savez_compressed(os.path.join(OUT, "voxel_coords.npz"), **out)
+
+
+def gen_torch_modules():
+    import torch
+    from second.pytorch.models import voxel_encoder, pointpillars, rpn
+    from second.pytorch.core import box_torch_ops
+    torch.manual_seed(0)
+    out = {}
+    # SimpleVoxel (voxel_encoder.py:207-225)
+    vox = torch.rand(64, 5, 4)
+    npts = torch.randint(1, 6, (64,), dtype=torch.int32)
+    for i in range(64):
+        vox[i, npts[i]:] = 0
+    sv = voxel_encoder.SimpleVoxel(num_input_features=4)
+    out["sv_voxels"], out["sv_num_points"] = vox.numpy(), npts.numpy()
+    out["sv_out"] = sv(vox, npts, None).numpy()
+    # second_box_decode / limit_period (box_torch_ops.py:56-101,370-371)
+    enc = torch.randn(200, 7) * 0.3
+    anchors = torch.cat([torch.rand(200, 3) * 40, torch.rand(200, 3) * 3 + 0.5, torch.rand(200, 1) * 3], 1)
+    out["dec_enc"], out["dec_anchors"] = enc.numpy(), anchors.numpy()
+    out["dec_out"] = box_torch_ops.second_box_decode(enc, anchors).numpy()
+    val = torch.randn(100) * 6
+    out["lp_val"] = val.numpy()
+    out["lp_out"] = box_torch_ops.limit_period(val, 1.0, np.pi).numpy()
+    # PointPillarsScatter (pointpillars.py:444-476)
+    ny, nx, c, bsz = 12, 10, 8, 2
+    coords = []
+    for b in range(bsz):
+        cells = torch.randperm(ny * nx)[:30]
+        coords.append(torch.stack([torch.full_like(cells, b), torch.zeros_like(cells), cells // nx, cells % nx], 1))
+    coords = torch.cat(coords).int()
+    feats = torch.randn(coords.shape[0], c)
+    sc = pointpillars.PointPillarsScatter(output_shape=[bsz, 1, ny, nx, c], num_input_features=c)
+    out["ps_feats"], out["ps_coords"] = feats.numpy(), coords.numpy()
+    out["ps_out"] = sc(feats, coords, bsz).numpy()
+    # PillarFeatureNet (pointpillars.py:150-237), eval-mode BN with random stats
+    pfn = pointpillars.PillarFeatureNet(num_input_features=4, use_norm=True, num_filters=(16,),
+                                        voxel_size=(0.25, 0.25, 8), pc_range=(-50, -50, -5, 50, 50, 3))
+    bn = pfn.pfn_layers[0].norm
+    bn.running_mean.uniform_(-0.1, 0.1)
+    bn.running_var.uniform_(0.5, 1.5)
+    bn.weight.data.uniform_(0.5, 1.5)
+    bn.bias.data.uniform_(-0.2, 0.2)
+    pfn.eval()
+    P, T = 40, 10
+    pv = torch.rand(P, T, 4) * 4 - 2
+    pn = torch.randint(1, T + 1, (P,), dtype=torch.int32)
+    for i in range(P):
+        pv[i, pn[i]:] = 0
+    pc = torch.stack([torch.zeros(P), torch.zeros(P), torch.randint(0, 400, (P,)).float(),
+                      torch.randint(0, 400, (P,)).float()], 1).int()
+    with torch.no_grad():
+        out["pfn_out"] = pfn(pv, pn, pc).numpy()
+    out["pfn_voxels"], out["pfn_num_points"], out["pfn_coords"] = pv.numpy(), pn.numpy(), pc.numpy()
+    for k, v in pfn.state_dict().items():
+        out["pfn_sd." + k] = v.numpy()
+    # RPNV2 (rpn.py:468-497 + RPNBase :334-420), small width so the fixture stays small
+    net = rpn.RPNV2(use_norm=True, num_class=1, layer_nums=(2,), layer_strides=(1,), num_filters=(16,),
+                    upsample_strides=(1,), num_upsample_filters=(16,), num_input_features=16,
+                    num_anchor_per_loc=2, encode_background_as_zeros=True, use_direction_classifier=True,
+                    box_code_size=7, num_direction_bins=2)
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.uniform_(-0.1, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.uniform_(-0.2, 0.2)
+    net.eval()
+    x = torch.randn(2, 16, 12, 10)
+    with torch.no_grad():
+        r = net(x)
+    out["rpn_in"] = x.numpy()
+    for k in ("box_preds", "cls_preds", "dir_cls_preds"):
+        out["rpn_" + k] = r[k].numpy()
+    for k, v in net.state_dict().items():
+        out["rpn_sd." + k] = v.numpy()
+    np.savez_compressed(os.path.join(OUT, "torch_modules.npz"), **out)
+    print("torch modules: rpn box_preds", out["rpn_box_preds"].shape)
+
+
+if __name__ == "__main__":
+    install_shims()
+    which = sys.argv[1:] or ["rotate_iou", "rotate_nms", "nms_axis_aligned", "standup", "voxel_coords",
+                             "torch_modules"]
+    for w in which:
+        globals()["gen_" + w]()
