@@ -1,0 +1,158 @@
+/*
+ * second_hip.h -- C ABI of libsecond_hip.so: the MI355X (gfx950) implementation of the SECOND hot path.
+ *
+ * This is the drop-in boundary of the project.  The reference reaches this
+ * arithmetic through the `spconv` Python package (pybind11 / torch custom ops of traveller59/spconv
+ * v1.x, absent from /root/reference) and through numba.cuda kernels; each entry point below names the
+ * reference interface it replaces.  Host code binds it with ctypes (second.pytorch_amd/second_amd/
+ * runtime.py); INTEGRATION.md shows the binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name starts with h_ (small host arrays read at call time);
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued asynchronously on it, no function
+ *     synchronises the host, allocates or frees memory;
+ *   - scratch memory is caller-provided: query `*_workspace_bytes`, pass a buffer at least that large;
+ *   - return value: 0 = ok, negative = error (SEC_E_*); never throws;
+ *   - dtype codes: SEC_F32 / SEC_F16 / SEC_BF16; index tensors are int32; coordinates are (b, z, y, x).
+ */
+#ifndef SECOND_HIP_H
+#define SECOND_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SEC_OK 0
+#define SEC_E_INVALID -1   /* bad argument */
+#define SEC_E_WORKSPACE -2 /* workspace too small */
+#define SEC_E_UNSUPPORTED -3
+#define SEC_E_LAUNCH -4    /* hipGetLastError() != hipSuccess after a launch */
+
+#define SEC_F32 0
+#define SEC_F16 1
+#define SEC_BF16 2
+
+#define SEC_ABI_VERSION 1
+int sec_abi_version(void);
+/* last HIP error string seen by this library (thread-unsafe convenience for diagnostics) */
+const char *sec_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * points_to_voxel  -- replaces spconv.utils.VoxelGeneratorV2.generate / generate_multi_gpu
+ *   (called at second/data/preprocess.py:301-316; built at second/builder/voxel_builder.py:23-32)
+ *   and, batched, the coordinate padding of merge_second_batch (second/data/preprocess.py:44-50).
+ *
+ * `batch` clouds are concatenated in `points` [num_points, num_features]; cloud b owns rows
+ * [point_offsets[b], point_offsets[b+1]).  Semantics per cloud = the sequential reference loop
+ * (second/utils/simplevis.py:31-50): voxel numbering in first-occurrence order, the first
+ * `max_points` points of a voxel kept in arrival order, at most `max_voxels` voxels
+ * (cap_mode 0 = `break` at the cap, 1 = `continue`).
+ * Outputs are compact: cloud b's voxels are rows [voxel_offsets[b], voxel_offsets[b+1]).
+ *   voxels [batch*max_voxels, max_points, num_features] (zero padded), coors [.,4] = (b,z,y,x),
+ *   num_points_per_voxel [.], voxel_offsets [batch+1];
+ *   mean (optional, may be NULL) [., mean_features] = SimpleVoxel.forward
+ *   (second/pytorch/models/voxel_encoder.py:220-225) fused as an epilogue.
+ * --------------------------------------------------------------------------------------------- */
+size_t sec_voxelize_workspace_bytes(int num_points, int batch, int max_voxels, int max_points);
+int sec_voxelize_f32(const float *points, const int *point_offsets, int num_points, int num_features,
+                     int batch, const float *h_range6, const float *h_voxel_size3, int max_points,
+                     int max_voxels, int cap_mode, float *voxels, int *coors,
+                     int *num_points_per_voxel, int *voxel_offsets, float *mean, int mean_features,
+                     void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Rulebooks -- replace spconv.ops.get_indice_pairs (torch.ops.spconv.get_indice_pairs; CPU oracle
+ * semantics of spconv include/spconv/indice.h).
+ *
+ * Besides spconv's pair lists (`pairs` [K,2,n_in] -1 padded, `pair_num` [K]; canonical order =
+ * ascending input row within an offset) the builders emit the OUTPUT-MAJOR GATHER TABLE
+ * `nbr_out` [n_out, K]: nbr_out[o][k] = input row feeding output o through kernel offset k, or -1,
+ * which is what sec_indice_conv_fwd consumes, and the INPUT-MAJOR table `nbr_in` [n_in, K]
+ * (nbr_in[j][k] = output row or -1) which the backward pass consumes.
+ * --------------------------------------------------------------------------------------------- */
+size_t sec_rulebook_workspace_bytes(int n_in, int kvol, int max_out_per_in);
+
+/* SubMConv3d: outputs == inputs.  nbr_in may be NULL (it is the mirror of nbr_out). pairs/pair_num may be NULL. */
+int sec_rulebook_subm3d(const int *indices, int n_in, int batch, const int *h_shape3,
+                        const int *h_ksize3, const int *h_dilation3, int *nbr_out, int *pairs,
+                        int *pair_num, void *workspace, size_t workspace_bytes, void *stream);
+
+/* SparseConv3d, step 1: discover the active outputs in first-touch order (oracle numbering).
+ *   out_indices [out_cap,4]; num_out (device int) receives the count (may exceed out_cap only if the
+ *   caller under-sized it: then SEC_E_INVALID is reported by step 2). State is kept in `workspace`. */
+int sec_rulebook_conv3d_build(const int *indices, int n_in, int batch, const int *h_in_shape3,
+                              const int *h_out_shape3, const int *h_ksize3, const int *h_stride3,
+                              const int *h_padding3, const int *h_dilation3, int *out_indices,
+                              int out_cap, int *num_out, void *workspace, size_t workspace_bytes,
+                              void *stream);
+/* step 2: fill the tables. nbr_out has `nbr_out_rows` rows (>= number of outputs; rows are -1 filled). */
+int sec_rulebook_conv3d_tables(int n_in, const int *h_ksize3, const int *h_stride3, int *nbr_out,
+                               int nbr_out_rows, int *nbr_in, int *pairs, int *pair_num,
+                               void *workspace, size_t workspace_bytes, void *stream);
+void sec_conv_output_shape(const int *h_in_shape3, const int *h_ksize3, const int *h_stride3,
+                           const int *h_padding3, const int *h_dilation3, int *h_out_shape3);
+
+/* ---------------------------------------------------------------------------------------------
+ * indice_conv -- replaces spconv.ops.indice_conv / indice_subm_conv (torch.ops.spconv.indice_conv_*;
+ * spconv_ops.h indiceConv):  out[o,:] = sum_k feat[nbr_out[o][k],:] @ W[k]  (fp32 accumulate)
+ * followed by the optional fused epilogue  y = relu?( y * scale[c] + shift[c] )  (folded BatchNorm1d +
+ * ReLU of second/pytorch/models/middle.py:146-191; bias is a shift with scale = 1).
+ *   weight: spconv layout [kD,kH,kW,Cin,Cout] == [K,Cin,Cout], dtype = feature dtype.
+ *   packed_weight: result of sec_pack_conv_weight for the MFMA path, or NULL (generic path).
+ *   num_out_dev: optional device int overriding n_out (static-capacity, sync-free pipelines).
+ * --------------------------------------------------------------------------------------------- */
+size_t sec_packed_weight_bytes(int kvol, int cin, int cout, int dtype);
+int sec_pack_conv_weight(const void *weight, int kvol, int cin, int cout, int dtype, void *packed,
+                         void *stream);
+int sec_indice_conv_fwd(const void *features, int n_in, int cin, const void *weight,
+                        const void *packed_weight, int kvol, int cout, const int *nbr_out, int n_out,
+                        const int *num_out_dev, const float *scale, const float *shift, int relu,
+                        void *out, int dtype, int out_dtype, void *stream);
+/* backward (spconv_ops.h indiceConvBackward): dfeat[j,:] = sum_k dout[nbr_in[j][k],:] @ W[k]^T ;
+ * dW[k] = sum_o feat[nbr_out[o][k],:]^T dout[o,:].  fp32 gradients for weights, feature dtype for dfeat. */
+int sec_indice_conv_bwd(const void *features, int n_in, int cin, const void *weight, int kvol, int cout,
+                        const int *nbr_out, const int *nbr_in, int n_out, const void *dout,
+                        void *dfeat, float *dweight, int dtype, void *stream);
+
+/* SparseConvTensor.dense() (spconv/__init__.py; consumed at second/pytorch/models/middle.py:206-210).
+ * Scatter rows into a zero-initialised dense tensor with arbitrary element strides so the same kernel
+ * writes NCDHW-contiguous or the channels-last [B, C*D, H, W] layout the RPN consumes.
+ * The function clears `out_elems` elements first. */
+int sec_sparse_to_dense(const void *features, const int *indices, int n, int c, const int *num_dev,
+                        void *out, size_t out_elems, int64_t stride_b, int64_t stride_c,
+                        int64_t stride_z, int64_t stride_y, int64_t stride_x, int dtype, void *stream);
+
+/* PointPillarsScatter.forward (second/pytorch/models/pointpillars.py:444-476): coords (b,z,y,x),
+ * canvas [B, C, ny, nx] (strides given in elements), cleared first. */
+int sec_pillar_scatter(const void *features, const int *coords, int p, int c, void *out,
+                       size_t out_elems, int64_t stride_b, int64_t stride_c, int64_t stride_y,
+                       int64_t stride_x, int dtype, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Rotated IoU / NMS -- replace the numba.cuda kernels of second/core/non_max_suppression/nms_gpu.py
+ * (rotate_iou_kernel_eval :564-602, rotate_nms_kernel :404-437, nms_kernel :70-101, nms_postprocess
+ * :109-126) and the CPU path rotate_nms_cc (nms_cpu.py:17-28 -> spconv rotate_non_max_suppression_cpu).
+ * --------------------------------------------------------------------------------------------- */
+/* iou[n,k] for boxes [N,5], qboxes [K,5] (x,y,w,l,r); criterion -1 IoU, 0 inter/area(q), 1 inter/area(box), 2 inter */
+int sec_rotate_iou_f32(const float *boxes, int n, const float *qboxes, int k, int criterion,
+                       float *iou, void *stream);
+/* Batched greedy NMS on boxes ALREADY SORTED by descending score.
+ *   dets [batch, max_n, stride] (first 5 columns x,y,w,l,r  -- or x1,y1,x2,y2 for the axis-aligned kind);
+ *   counts [batch] device ints (boxes per item, <= max_n <= 4096).
+ *   kind 0 rotated, 1 axis-aligned.  semantics 0 = numba.cuda spec (IoU > thr; axis-aligned uses the
+ *   '+1' convention), 1 = CPU path (rotated: standup-IoU pre-filter then IoU >= thr; axis-aligned:
+ *   eps convention, >= thr).
+ *   keep [batch, max_n] receives kept positions (ascending), num_keep [batch] their count (capped at post_max, <=0 = no cap).
+ *   workspace: sec_nms_workspace_bytes(batch, max_n). */
+size_t sec_nms_workspace_bytes(int batch, int max_n);
+int sec_nms_sorted_f32(const float *dets, const int *counts, int batch, int max_n, int stride,
+                       float thresh, int kind, int semantics, float eps, int post_max, int *keep,
+                       int *num_keep, void *workspace, size_t workspace_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SECOND_HIP_H */

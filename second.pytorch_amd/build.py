@@ -1,0 +1,36 @@
+"""Build libsecond_hip.so (all HIP kernels + the C ABI) for gfx950 with hipcc, in-tree.
+
+    python second.pytorch_amd/build.py [--force]
+
+hipcc cross-compiles without a GPU.  The library lands in second.pytorch_amd/lib/ (git-ignored, but it
+travels to the GPU box with the gpurun snapshot).
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = [os.path.join(HERE, "csrc", f) for f in
+       ("common.hip", "voxelize.hip", "rulebook.hip", "indice_conv.hip", "scatter.hip", "nms.hip")]
+HDR = [os.path.join(HERE, "csrc", "common.hpp"), os.path.join(HERE, "..", "include", "second_hip.h")]
+OUT = os.path.join(HERE, "lib", "libsecond_hip.so")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+         "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
+
+
+def build(force=False, verbose=True):
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    if not force and os.path.exists(OUT):
+        newest = max(os.path.getmtime(p) for p in SRC + HDR)
+        if os.path.getmtime(OUT) >= newest:
+            return OUT
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, *FLAGS, "-o", OUT, *SRC]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,112 @@
+// Shared device/host helpers for libsecond_hip.so (gfx950 / CDNA4 only: wave64, 256 CUs).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/second_hip.h"
+
+#define SEC_API extern "C" __attribute__((visibility("default")))
+
+namespace sec {
+
+constexpr int kWave = 64;          // CDNA wavefront
+constexpr int kBlock = 256;        // default workgroup: 4 waves, one per SIMD
+constexpr int kEmptyI32 = 0x7f7f7f7f;               // hipMemsetAsync(…, 0x7f) pattern: > any row index
+constexpr unsigned long long kEmptyKey = ~0ull;     // hipMemsetAsync(…, 0xff) pattern
+
+void set_last_error(hipError_t e);
+inline int check_launch() {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_last_error(e); return SEC_E_LAUNCH; }
+    return SEC_OK;
+}
+inline int hip_ok(hipError_t e) {
+    if (e != hipSuccess) { set_last_error(e); return SEC_E_LAUNCH; }
+    return SEC_OK;
+}
+
+inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+inline int div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
+inline uint32_t next_pow2(uint32_t v) {
+    uint32_t p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+// bump allocator over the caller-provided workspace
+struct Arena {
+    char *base;
+    size_t used, cap;
+    Arena(void *p, size_t c) : base((char *)p), used(0), cap(c) {}
+    template <typename T> T *take(size_t n) {
+        size_t off = align_up(used);
+        used = off + n * sizeof(T);
+        return (T *)(base + off);
+    }
+    bool ok() const { return used <= cap; }
+};
+
+// ---------------------------------------------------------------- hashing (open addressing, linear probe)
+__device__ __forceinline__ uint32_t hash64(unsigned long long k) {
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdull;
+    k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull;
+    k ^= k >> 33;
+    return (uint32_t)k;
+}
+// returns the slot holding `key`, inserting it if absent
+__device__ __forceinline__ uint32_t hash_insert(unsigned long long *keys, uint32_t mask, unsigned long long key) {
+    uint32_t s = hash64(key) & mask;
+    while (true) {
+        unsigned long long prev = atomicCAS(&keys[s], kEmptyKey, key);
+        if (prev == kEmptyKey || prev == key) return s;
+        s = (s + 1) & mask;
+    }
+}
+// returns slot or -1
+__device__ __forceinline__ int hash_find(const unsigned long long *keys, uint32_t mask, unsigned long long key) {
+    uint32_t s = hash64(key) & mask;
+    while (true) {
+        unsigned long long cur = keys[s];
+        if (cur == key) return (int)s;
+        if (cur == kEmptyKey) return -1;
+        s = (s + 1) & mask;
+    }
+}
+
+// ---------------------------------------------------------------- wave / block scans (wave64)
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_inclusive_scan(int v) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int t = __shfl_up(v, d, 64);
+        if (lane_id() >= d) v += t;
+    }
+    return v;
+}
+// exclusive scan across a 256-thread block; returns exclusive prefix, *total = block sum. smem: >= 4 ints
+__device__ __forceinline__ int block_exclusive_scan(int v, int *smem, int *total) {
+    int inc = wave_inclusive_scan(v);
+    int w = threadIdx.x >> 6;
+    if (lane_id() == 63) smem[w] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < kBlock / 64; ++i) {
+        int s = smem[i];
+        if (i < w) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
+// device-wide exclusive scan of int32 (three launches; n up to ~2^31). Scratch: scan_scratch_ints(n) ints.
+constexpr int kScanItems = 8;                      // per thread
+constexpr int kScanTile = kBlock * kScanItems;     // 2048 per block
+inline size_t scan_scratch_ints(long long n) { return (size_t)div_up(n, kScanTile) + 8; }
+int exclusive_scan_i32(const int *in, int *out, long long n, int *total_out, int *scratch, hipStream_t st);
+
+}  // namespace sec

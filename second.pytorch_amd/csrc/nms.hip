@@ -1,0 +1,316 @@
+// Rotated-box IoU and greedy NMS on gfx950, replacing the numba.cuda kernels of
+// second/core/non_max_suppression/nms_gpu.py (rotate_iou_kernel_eval :564-602, rotate_nms_kernel :404-437,
+// nms_kernel :70-101, host nms_postprocess :109-126) and the CPU round trip of box_torch_ops.rotate_nms
+// (second/pytorch/core/box_torch_ops.py:492-515 -> nms_cpu.py:17-28).
+//
+// Wave64 mapping: a 64-box column tile sits in LDS, the 64 lanes of a wave are the 64 columns, so the
+// 64-bit suppression word of a row is ONE __ballot (the reference builds it bit by bit in a 64-iteration
+// per-thread loop).  The greedy reduce runs on-device in a single wave (lane w holds removal word w), so
+// kept indices never leave the GPU.  The fp32 polygon-clipping arithmetic follows nms_gpu.py:166-401
+// operation for operation (compiled with -ffp-contract=off).
+#include "common.hpp"
+
+namespace sec {
+
+__device__ __forceinline__ float tri_area(const float *a, const float *b, const float *c) {
+    return ((a[0] - c[0]) * (b[1] - c[1]) - (a[1] - c[1]) * (b[0] - c[0])) / 2.0f;
+}
+
+__device__ __forceinline__ void box_corners(float *c, const float *b) {  // nms_gpu.py:353-376
+    float ac = cosf(b[4]), as = sinf(b[4]);
+    float cx = b[0], cy = b[1], xd = b[2], yd = b[3];
+    float xs[4] = {-xd / 2, -xd / 2, xd / 2, xd / 2};
+    float ys[4] = {-yd / 2, yd / 2, yd / 2, -yd / 2};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        c[2 * i] = ac * xs[i] + as * ys[i] + cx;
+        c[2 * i + 1] = -as * xs[i] + ac * ys[i] + cy;
+    }
+}
+
+__device__ __forceinline__ bool pt_in_quad(float x, float y, const float *c) {  // nms_gpu.py:308-325
+    float ab0 = c[2] - c[0], ab1 = c[3] - c[1];
+    float ad0 = c[6] - c[0], ad1 = c[7] - c[1];
+    float ap0 = x - c[0], ap1 = y - c[1];
+    float abab = ab0 * ab0 + ab1 * ab1;
+    float abap = ab0 * ap0 + ab1 * ap1;
+    float adad = ad0 * ad0 + ad1 * ad1;
+    float adap = ad0 * ap0 + ad1 * ap1;
+    const float eps = -1e-6f;
+    return abab - abap >= eps && abap >= eps && adad - adap >= eps && adap >= eps;
+}
+
+__device__ __forceinline__ bool seg_intersect(const float *p1, const float *p2, int i, int j, float *t) {  // :222-264
+    float A0 = p1[2 * i], A1 = p1[2 * i + 1];
+    float B0 = p1[2 * ((i + 1) & 3)], B1 = p1[2 * ((i + 1) & 3) + 1];
+    float C0 = p2[2 * j], C1 = p2[2 * j + 1];
+    float D0 = p2[2 * ((j + 1) & 3)], D1 = p2[2 * ((j + 1) & 3) + 1];
+    float BA0 = B0 - A0, BA1 = B1 - A1, DA0 = D0 - A0, CA0 = C0 - A0, DA1 = D1 - A1, CA1 = C1 - A1;
+    bool acd = DA1 * CA0 > CA1 * DA0;
+    bool bcd = (D1 - B1) * (C0 - B0) > (C1 - B1) * (D0 - B0);
+    if (acd != bcd) {
+        bool abc = CA1 * BA0 > BA1 * CA0;
+        bool abd = DA1 * BA0 > BA1 * DA0;
+        if (abc != abd) {
+            float DC0 = D0 - C0, DC1 = D1 - C1;
+            float ABBA = A0 * B1 - B0 * A1;
+            float CDDC = C0 * D1 - D0 * C1;
+            float DH = BA1 * DC0 - BA0 * DC1;
+            float Dx = ABBA * DC0 - BA0 * CDDC;
+            float Dy = ABBA * DC1 - BA1 * CDDC;
+            t[0] = Dx / DH;
+            t[1] = Dy / DH;
+            return true;
+        }
+    }
+    return false;
+}
+
+// intersection area of two quads given by their corners (nms_gpu.py:329-350,172-219,379-393)
+__device__ float quad_inter(const float *c1, const float *c2) {
+    float pts[48];
+    int n = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (pt_in_quad(c1[2 * i], c1[2 * i + 1], c2)) { pts[2 * n] = c1[2 * i]; pts[2 * n + 1] = c1[2 * i + 1]; ++n; }
+        if (pt_in_quad(c2[2 * i], c2[2 * i + 1], c1)) { pts[2 * n] = c2[2 * i]; pts[2 * n + 1] = c2[2 * i + 1]; ++n; }
+    }
+    float t[2];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j)
+            if (seg_intersect(c1, c2, i, j, t)) { pts[2 * n] = t[0]; pts[2 * n + 1] = t[1]; ++n; }
+    if (n > 8) n = 8;
+    if (n < 3) return 0.0f;
+    // angular sort about the centroid (insertion sort on the reference's key)
+    float cx = 0.0f, cy = 0.0f;
+    for (int i = 0; i < n; ++i) { cx += pts[2 * i]; cy += pts[2 * i + 1]; }
+    cx /= (float)n;
+    cy /= (float)n;
+    float vs[8];
+    for (int i = 0; i < n; ++i) {
+        float vx = pts[2 * i] - cx, vy = pts[2 * i + 1] - cy;
+        float d = sqrtf(vx * vx + vy * vy);
+        vx = vx / d;
+        vy = vy / d;
+        if (vy < 0) vx = -2 - vx;
+        vs[i] = vx;
+    }
+    for (int i = 1; i < n; ++i) {
+        if (vs[i - 1] > vs[i]) {
+            float temp = vs[i], tx = pts[2 * i], ty = pts[2 * i + 1];
+            int j = i;
+            while (j > 0 && vs[j - 1] > temp) {
+                vs[j] = vs[j - 1];
+                pts[2 * j] = pts[2 * j - 2];
+                pts[2 * j + 1] = pts[2 * j - 1];
+                --j;
+            }
+            vs[j] = temp;
+            pts[2 * j] = tx;
+            pts[2 * j + 1] = ty;
+        }
+    }
+    float s = 0.0f;
+    for (int i = 0; i < n - 2; ++i) s += fabsf(tri_area(pts, pts + 2 * i + 2, pts + 2 * i + 4));
+    return s;
+}
+
+struct Standup { float x0, y0, x1, y1; };
+__device__ __forceinline__ Standup standup_of(const float *c) {
+    Standup s{c[0], c[1], c[0], c[1]};
+#pragma unroll
+    for (int i = 1; i < 4; ++i) {
+        s.x0 = fminf(s.x0, c[2 * i]); s.x1 = fmaxf(s.x1, c[2 * i]);
+        s.y0 = fminf(s.y0, c[2 * i + 1]); s.y1 = fmaxf(s.y1, c[2 * i + 1]);
+    }
+    return s;
+}
+// far apart => the clipper finds no vertex => intersection exactly 0 (margin covers its 1e-6 tolerances)
+__device__ __forceinline__ bool far_apart(const Standup &a, const Standup &b) {
+    const float m = 1e-3f;
+    return a.x0 > b.x1 + m || b.x0 > a.x1 + m || a.y0 > b.y1 + m || b.y0 > a.y1 + m;
+}
+
+// ---------------------------------------------------------------- IoU matrix (rotate_iou_gpu_eval)
+__global__ __launch_bounds__(kBlock) void k_rotate_iou(const float *__restrict__ boxes, int N,
+                                                      const float *__restrict__ qboxes, int K, int criterion,
+                                                      float *__restrict__ iou) {
+    __shared__ float qc[64][9];   // corners of the 64 query boxes of this column tile (+1 pad)
+    __shared__ float qa[64];
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int kq = blockIdx.y * 64 + lane;
+    if (w == 0 && kq < K) {
+        float c[8];
+        box_corners(c, qboxes + (size_t)kq * 5);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) qc[lane][i] = c[i];
+        qa[lane] = qboxes[(size_t)kq * 5 + 2] * qboxes[(size_t)kq * 5 + 3];
+    }
+    __syncthreads();
+    float c1[8];
+    float a1 = 0.0f;
+    if (kq < K) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) c1[i] = qc[lane][i];
+        a1 = qa[lane];
+    }
+    for (int rr = 0; rr < 16; ++rr) {
+        int n = blockIdx.x * 64 + w * 16 + rr;
+        if (n >= N) break;
+        if (kq >= K) continue;
+        float c2[8];
+        box_corners(c2, boxes + (size_t)n * 5);
+        float a2 = boxes[(size_t)n * 5 + 2] * boxes[(size_t)n * 5 + 3];
+        float in = far_apart(standup_of(c1), standup_of(c2)) ? 0.0f : quad_inter(c1, c2);
+        float v;
+        if (criterion == -1) v = in / (a1 + a2 - in);
+        else if (criterion == 0) v = in / a1;
+        else if (criterion == 1) v = in / a2;
+        else v = in;
+        iou[(size_t)n * K + kq] = v;
+    }
+}
+
+// ---------------------------------------------------------------- suppression bit matrix
+// grid (col_block, row_block, batch); only col_block >= row_block is computed.
+__global__ __launch_bounds__(kBlock) void k_nms_mask(const float *__restrict__ dets, const int *__restrict__ counts,
+                                                    int max_n, int stride, float thresh, int kind, int semantics,
+                                                    float eps, int words, unsigned long long *__restrict__ mask) {
+    int cb = blockIdx.x, rb = blockIdx.y, b = blockIdx.z;
+    if (cb < rb) return;
+    int n = counts[b];
+    if (n > max_n) n = max_n;
+    if (rb * 64 >= n || cb * 64 >= n) return;
+    __shared__ float cc[64][9];
+    __shared__ float ca[64];
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const float *base = dets + (size_t)b * max_n * stride;
+    int col = cb * 64 + lane;
+    if (w == 0 && col < n) {
+        const float *d = base + (size_t)col * stride;
+        if (kind == 0) {
+            float c[8];
+            box_corners(c, d);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) cc[lane][i] = c[i];
+            ca[lane] = d[2] * d[3];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) cc[lane][i] = d[i];
+        }
+    }
+    __syncthreads();
+    float c2[8];
+    float a2 = 0.0f;
+    if (col < n) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) c2[i] = cc[lane][i];
+        a2 = ca[lane];
+    }
+    for (int rr = 0; rr < 16; ++rr) {
+        int row = rb * 64 + w * 16 + rr;
+        if (row >= n) break;
+        bool sup = false;
+        if (col < n && col > row) {
+            const float *d = base + (size_t)row * stride;
+            if (kind == 0) {
+                float c1[8];
+                box_corners(c1, d);
+                float a1 = d[2] * d[3];
+                Standup s1 = standup_of(c1), s2 = standup_of(c2);
+                if (!far_apart(s1, s2)) {
+                    bool consider = true;
+                    if (semantics == 1) {  // CPU path: standup IoU (eps = 0) must be > 0 (nms_cpu.py:25, A.6)
+                        float iw = fminf(s1.x1, s2.x1) - fmaxf(s1.x0, s2.x0);
+                        float ih = fminf(s1.y1, s2.y1) - fmaxf(s1.y0, s2.y0);
+                        consider = iw > 0.0f && ih > 0.0f;
+                        if (consider) {
+                            float ua = (s1.x1 - s1.x0) * (s1.y1 - s1.y0) + (s2.x1 - s2.x0) * (s2.y1 - s2.y0) - iw * ih;
+                            consider = iw * ih / ua > 0.0f;
+                        }
+                    }
+                    if (consider) {
+                        float in = quad_inter(c1, c2);
+                        float v = in / (a1 + a2 - in);
+                        sup = semantics == 1 ? v >= thresh : v > thresh;
+                    }
+                } else if (semantics == 1) {
+                    sup = false;
+                } else {
+                    sup = 0.0f > thresh;  // IoU is exactly 0
+                }
+            } else {
+                float e = semantics == 0 ? 1.0f : eps;
+                float wv = fmaxf(fminf(d[2], c2[2]) - fmaxf(d[0], c2[0]) + e, 0.0f);
+                float hv = fmaxf(fminf(d[3], c2[3]) - fmaxf(d[1], c2[1]) + e, 0.0f);
+                float in = wv * hv;
+                float sa = (d[2] - d[0] + e) * (d[3] - d[1] + e);
+                float sb = (c2[2] - c2[0] + e) * (c2[3] - c2[1] + e);
+                float v = in / (sa + sb - in);
+                sup = semantics == 0 ? v > thresh : v >= thresh;
+            }
+        }
+        unsigned long long word = __ballot(sup);
+        if (lane == 0) mask[((size_t)b * max_n + row) * words + cb] = word;
+    }
+}
+
+// greedy reduce (nms_postprocess): one wave per batch item, lane w owns removal word w
+__global__ __launch_bounds__(64) void k_nms_reduce(const unsigned long long *__restrict__ mask,
+                                                  const int *__restrict__ counts, int max_n, int words, int post_max,
+                                                  int *__restrict__ keep, int *__restrict__ num_keep) {
+    int b = blockIdx.x, lane = threadIdx.x;
+    int n = counts[b];
+    if (n > max_n) n = max_n;
+    int nwords = (n + 63) >> 6;
+    unsigned long long remv = 0ull;
+    const unsigned long long *mb = mask + (size_t)b * max_n * words;
+    int nk = 0;
+    unsigned long long nxt = (n > 0 && lane < nwords) ? mb[lane] : 0ull;
+    for (int i = 0; i < n; ++i) {
+        unsigned long long cur = nxt;
+        if (i + 1 < n) nxt = lane < nwords ? mb[(size_t)(i + 1) * words + lane] : 0ull;  // independent of remv
+        unsigned long long word = __shfl(remv, i >> 6, 64);
+        if (!((word >> (i & 63)) & 1ull)) {
+            if (lane == 0) keep[(size_t)b * max_n + nk] = i;
+            ++nk;
+            if (post_max > 0 && nk >= post_max) break;
+            if (lane >= (i >> 6)) remv |= cur;
+        }
+    }
+    if (lane == 0) num_keep[b] = nk;
+}
+
+}  // namespace sec
+
+using namespace sec;
+
+SEC_API int sec_rotate_iou_f32(const float *boxes, int n, const float *qboxes, int k, int criterion, float *iou,
+                               void *stream) {
+    if (n < 0 || k < 0 || (n > 0 && k > 0 && (!boxes || !qboxes || !iou))) return SEC_E_INVALID;
+    if (n == 0 || k == 0) return SEC_OK;
+    hipLaunchKernelGGL(k_rotate_iou, dim3(div_up(n, 64), div_up(k, 64)), dim3(kBlock), 0, (hipStream_t)stream, boxes, n,
+                       qboxes, k, criterion, iou);
+    return check_launch();
+}
+
+SEC_API size_t sec_nms_workspace_bytes(int batch, int max_n) {
+    if (batch <= 0 || max_n <= 0) return 0;
+    return align_up((size_t)batch * max_n * ((max_n + 63) / 64) * sizeof(unsigned long long));
+}
+
+SEC_API int sec_nms_sorted_f32(const float *dets, const int *counts, int batch, int max_n, int stride, float thresh,
+                               int kind, int semantics, float eps, int post_max, int *keep, int *num_keep,
+                               void *workspace, size_t workspace_bytes, void *stream) {
+    if (!dets || !counts || !keep || !num_keep || batch <= 0 || max_n <= 0 || max_n > 4096 ||
+        stride < (kind == 0 ? 5 : 4) || kind < 0 || kind > 1 || semantics < 0 || semantics > 1)
+        return SEC_E_INVALID;
+    if (!workspace || workspace_bytes < sec_nms_workspace_bytes(batch, max_n)) return SEC_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    int words = (max_n + 63) / 64;
+    unsigned long long *mask = (unsigned long long *)workspace;
+    hipLaunchKernelGGL(k_nms_mask, dim3(words, words, batch), dim3(kBlock), 0, st, dets, counts, max_n, stride, thresh,
+                       kind, semantics, eps, words, mask);
+    hipLaunchKernelGGL(k_nms_reduce, dim3(batch), dim3(64), 0, st, mask, counts, max_n, words, post_max, keep, num_keep);
+    return check_launch();
+}

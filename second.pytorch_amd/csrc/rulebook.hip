@@ -1,0 +1,335 @@
+// Sparse-convolution rulebooks on gfx950 (reference: spconv.ops.get_indice_pairs, CPU semantics of
+// spconv include/spconv/indice.h + geometry.h -- SURVEY.md Appendix A.4; caller side
+// second/pytorch/models/middle.py:146-189).
+//
+// The reference's GPU kernels number outputs by a device sort and append pairs in atomic-arrival order
+// (nondeterministic).  Here everything is deterministic and equal to the sequential CPU algorithm:
+//   * coordinates live in an open-addressing hash table (400 KB for a KITTI frame: L2 resident) instead of
+//     the reference's dense 369 MB-per-sample grid;
+//   * SubM: one lookup per (site, kernel offset) writes the output-major gather table nbr_out[N][K];
+//   * strided conv: every (input, offset) candidate inserts its output cell with atomicMin(token),
+//     token = input*K + offset = position in the sequential loop, so "first touch" numbering is the rank
+//     of the winning token, obtained with a flag + exclusive scan (no sort);
+//   * spconv-format pair lists are produced by wave-ballot/prefix-sum compaction of the table columns
+//     (ascending input row inside each offset == the CPU order).
+#include "common.hpp"
+
+namespace sec {
+
+constexpr int kMaxKvol = 128;
+
+struct RbGeom {
+    int in_shape[3], out_shape[3], ksize[3], stride[3], pad[3], dil[3];
+    int kvol, n_in, batch;
+    uint32_t mask;
+};
+
+__device__ __forceinline__ unsigned long long cell_key(int b, int z, int y, int x, const int *shape) {
+    unsigned long long vol = (unsigned long long)shape[0] * shape[1] * shape[2];
+    return (unsigned long long)b * vol + ((unsigned long long)z * shape[1] + y) * shape[2] + x;
+}
+
+__global__ __launch_bounds__(kBlock) void k_rb_hash_rows(const int *__restrict__ indices, RbGeom g,
+                                                        unsigned long long *__restrict__ keys,
+                                                        int *__restrict__ vals) {
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= g.n_in) return;
+    int4 c = *reinterpret_cast<const int4 *>(indices + (size_t)i * 4);
+    uint32_t s = hash_insert(keys, g.mask, cell_key(c.x, c.y, c.z, c.w, g.in_shape));
+    vals[s] = i;
+}
+
+// nbr_out[o][k] = row of the site at coord(o) + (k - centre) * dilation, or -1
+__global__ __launch_bounds__(kBlock) void k_subm_nbr(const int *__restrict__ indices, RbGeom g,
+                                                    const unsigned long long *__restrict__ keys,
+                                                    const int *__restrict__ vals, int *__restrict__ nbr) {
+    long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= (long long)g.n_in * g.kvol) return;
+    int o = (int)(t / g.kvol), k = (int)(t % g.kvol);
+    int kx = k % g.ksize[2], ky = (k / g.ksize[2]) % g.ksize[1], kz = k / (g.ksize[2] * g.ksize[1]);
+    int4 c = *reinterpret_cast<const int4 *>(indices + (size_t)o * 4);
+    int z = c.y + (kz - g.ksize[0] / 2) * g.dil[0];
+    int y = c.z + (ky - g.ksize[1] / 2) * g.dil[1];
+    int x = c.w + (kx - g.ksize[2] / 2) * g.dil[2];
+    int r = -1;
+    if (z >= 0 && z < g.in_shape[0] && y >= 0 && y < g.in_shape[1] && x >= 0 && x < g.in_shape[2]) {
+        int s = hash_find(keys, g.mask, cell_key(c.x, z, y, x, g.in_shape));
+        if (s >= 0) r = vals[s];
+    }
+    nbr[t] = r;
+}
+
+// ---- strided / regular sparse conv -------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_conv_cand(const int *__restrict__ indices, RbGeom g,
+                                                     unsigned long long *__restrict__ keys,
+                                                     int *__restrict__ vals, int *__restrict__ cand_slot) {
+    long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= (long long)g.n_in * g.kvol) return;
+    int j = (int)(t / g.kvol), k = (int)(t % g.kvol);
+    int kk[3] = {k / (g.ksize[2] * g.ksize[1]), (k / g.ksize[2]) % g.ksize[1], k % g.ksize[2]};
+    int4 c = *reinterpret_cast<const int4 *>(indices + (size_t)j * 4);
+    int in[3] = {c.y, c.z, c.w}, out[3];
+    bool ok = true;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        int num = in[d] + g.pad[d] - kk[d] * g.dil[d];
+        if (num < 0 || num % g.stride[d] != 0) ok = false;
+        out[d] = num / g.stride[d];
+        if (out[d] >= g.out_shape[d]) ok = false;
+    }
+    int s = -1;
+    if (ok) {
+        s = (int)hash_insert(keys, g.mask, cell_key(c.x, out[0], out[1], out[2], g.out_shape));
+        atomicMin(&vals[s], (int)t);  // token = j*K + k: order of the sequential reference loop
+    }
+    cand_slot[t] = s;
+}
+
+__global__ __launch_bounds__(kBlock) void k_conv_flag(const int *__restrict__ cand_slot,
+                                                     const int *__restrict__ vals, long long n,
+                                                     int *__restrict__ flag) {
+    long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= n) return;
+    int s = cand_slot[t];
+    flag[t] = (s >= 0 && vals[s] == (int)t) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(kBlock) void k_conv_assign(const int *__restrict__ cand_slot,
+                                                       const int *__restrict__ vals,
+                                                       const unsigned long long *__restrict__ keys,
+                                                       const int *__restrict__ rank, RbGeom g,
+                                                       int *__restrict__ orank, int *__restrict__ out_indices,
+                                                       int out_cap) {
+    long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= (long long)g.n_in * g.kvol) return;
+    int s = cand_slot[t];
+    if (s < 0 || vals[s] != (int)t) return;
+    int r = rank[t];
+    orank[s] = r;
+    if (r < out_cap) {
+        unsigned long long vol = (unsigned long long)g.out_shape[0] * g.out_shape[1] * g.out_shape[2];
+        unsigned long long key = keys[s];
+        int b = (int)(key / vol);
+        unsigned long long lin = key - (unsigned long long)b * vol;
+        int x = (int)(lin % g.out_shape[2]);
+        unsigned long long q = lin / g.out_shape[2];
+        int4 c = make_int4(b, (int)(q / g.out_shape[1]), (int)(q % g.out_shape[1]), x);
+        *reinterpret_cast<int4 *>(out_indices + (size_t)r * 4) = c;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_conv_tables(const int *__restrict__ cand_slot,
+                                                       const int *__restrict__ orank, long long n, int kvol,
+                                                       int *__restrict__ nbr_in, int *__restrict__ nbr_out,
+                                                       int nbr_out_rows) {
+    long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= n) return;
+    int s = cand_slot[t];
+    int o = s >= 0 ? orank[s] : -1;
+    nbr_in[t] = o;
+    if (o >= 0 && o < nbr_out_rows) nbr_out[(size_t)o * kvol + (int)(t % kvol)] = (int)(t / kvol);
+}
+
+// ---- spconv-format pair lists by ballot/prefix compaction of table columns -----------------------
+// table is input-major [n][K]; pair list k = rows j (ascending) with table[j][col(k)] >= 0,
+// col(k) = K-1-k when `mirror` (SubM: nbr_in is the mirror image of nbr_out), else k.
+template <bool WRITE>
+__global__ __launch_bounds__(kBlock) void k_pairs(const int *__restrict__ table, int n, int kvol, int mirror,
+                                                 int nblocks, int *__restrict__ blk, int *__restrict__ pairs,
+                                                 int *__restrict__ pair_num) {
+    __shared__ int wcnt[4 * kMaxKvol];
+    int j = blockIdx.x * kBlock + threadIdx.x;
+    int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int *row = table + (size_t)j * kvol;
+    if (!WRITE) {
+        for (int k = 0; k < kvol; ++k) {
+            int v = j < n ? row[mirror ? kvol - 1 - k : k] : -1;
+            unsigned long long m = __ballot(v >= 0);
+            if (lane == 0) wcnt[w * kvol + k] = __popcll(m);
+        }
+        __syncthreads();
+        for (int k = threadIdx.x; k < kvol; k += kBlock)
+            blk[(size_t)k * nblocks + blockIdx.x] = wcnt[k] + wcnt[kvol + k] + wcnt[2 * kvol + k] + wcnt[3 * kvol + k];
+    } else {
+        // pass 1: per-wave counts (again), pass 2: positions
+        for (int k = 0; k < kvol; ++k) {
+            int v = j < n ? row[mirror ? kvol - 1 - k : k] : -1;
+            unsigned long long m = __ballot(v >= 0);
+            if (lane == 0) wcnt[w * kvol + k] = __popcll(m);
+        }
+        __syncthreads();
+        for (int k = 0; k < kvol; ++k) {
+            int v = j < n ? row[mirror ? kvol - 1 - k : k] : -1;
+            unsigned long long m = __ballot(v >= 0);
+            if (v >= 0) {
+                int pos = blk[(size_t)k * nblocks + blockIdx.x] - blk[(size_t)k * nblocks];
+                for (int ww = 0; ww < w; ++ww) pos += wcnt[ww * kvol + k];
+                pos += __popcll(m & ((1ull << lane) - 1ull));
+                pairs[((size_t)k * 2 + 0) * n + pos] = j;
+                pairs[((size_t)k * 2 + 1) * n + pos] = v;
+            }
+        }
+        if (blockIdx.x == 0)
+            for (int k = threadIdx.x; k < kvol; k += kBlock)
+                pair_num[k] = blk[(size_t)(k + 1) * nblocks] - blk[(size_t)k * nblocks];
+    }
+}
+
+static int emit_pairs(const int *table, int n, int kvol, int mirror, int *blk, int *scan_scratch, int *pairs,
+                      int *pair_num, hipStream_t st) {
+    int rc;
+    if (n == 0) return hip_ok(hipMemsetAsync(pair_num, 0, kvol * sizeof(int), st));
+    if ((rc = hip_ok(hipMemsetAsync(pairs, 0xff, (size_t)kvol * 2 * n * sizeof(int), st)))) return rc;
+    int nblocks = div_up(n, kBlock);
+    hipLaunchKernelGGL(k_pairs<false>, dim3(nblocks), dim3(kBlock), 0, st, table, n, kvol, mirror, nblocks, blk,
+                       (int *)nullptr, (int *)nullptr);
+    long long cnt = (long long)kvol * nblocks;
+    if ((rc = exclusive_scan_i32(blk, blk, cnt, blk + cnt, scan_scratch, st))) return rc;
+    hipLaunchKernelGGL(k_pairs<true>, dim3(nblocks), dim3(kBlock), 0, st, table, n, kvol, mirror, nblocks, blk,
+                       pairs, pair_num);
+    return check_launch();
+}
+
+struct RbWorkspace {
+    unsigned long long *keys;
+    int *vals, *orank, *cand_slot, *rank, *scan, *blk, *scan2, *mirror_tbl;
+    uint32_t table;
+    size_t bytes;
+};
+
+static RbWorkspace carve_rb(void *ws, size_t cap, int n_in, int kvol, int max_out_per_in) {
+    RbWorkspace w;
+    Arena a(ws, cap);
+    size_t entries = (size_t)(n_in > 0 ? n_in : 1) * (size_t)(max_out_per_in > 0 ? max_out_per_in : 1);
+    w.table = next_pow2((uint32_t)(entries * 2 > 1024 ? entries * 2 : 1024));
+    w.keys = a.take<unsigned long long>(w.table);
+    w.vals = a.take<int>(w.table);
+    w.orank = a.take<int>(w.table);
+    long long nk = (long long)n_in * kvol;
+    w.cand_slot = a.take<int>(nk);
+    w.rank = a.take<int>(nk);
+    w.scan = a.take<int>(scan_scratch_ints(nk));
+    long long nblk = (long long)kvol * div_up(n_in > 0 ? n_in : 1, kBlock);
+    w.blk = a.take<int>(nblk + 1);
+    w.scan2 = a.take<int>(scan_scratch_ints(nblk));
+    w.bytes = align_up(a.used);
+    return w;
+}
+
+static int fill_geom(RbGeom &g, const int *in_shape, const int *out_shape, const int *ksize, const int *stride,
+                     const int *pad, const int *dil, int n_in, int batch) {
+    g.kvol = 1;
+    for (int d = 0; d < 3; ++d) {
+        g.in_shape[d] = in_shape[d];
+        g.out_shape[d] = out_shape ? out_shape[d] : in_shape[d];
+        g.ksize[d] = ksize[d];
+        g.stride[d] = stride ? stride[d] : 1;
+        g.pad[d] = pad ? pad[d] : 0;
+        g.dil[d] = dil ? dil[d] : 1;
+        if (g.ksize[d] <= 0 || g.stride[d] <= 0 || g.dil[d] <= 0 || g.in_shape[d] <= 0 || g.out_shape[d] <= 0)
+            return SEC_E_INVALID;
+        g.kvol *= ksize[d];
+    }
+    if (g.kvol > kMaxKvol) return SEC_E_UNSUPPORTED;
+    g.n_in = n_in;
+    g.batch = batch;
+    return SEC_OK;
+}
+
+static int max_out_per_in(const int *ksize, const int *stride) {
+    int c = 1;
+    for (int d = 0; d < 3; ++d) c *= (ksize[d] + stride[d] - 1) / stride[d];
+    return c;
+}
+
+}  // namespace sec
+
+using namespace sec;
+
+SEC_API size_t sec_rulebook_workspace_bytes(int n_in, int kvol, int max_out_per_in) {
+    if (n_in < 0 || kvol <= 0) return 0;
+    return carve_rb(nullptr, 0, n_in, kvol, max_out_per_in).bytes;
+}
+
+SEC_API void sec_conv_output_shape(const int *in_shape, const int *ksize, const int *stride, const int *pad,
+                                   const int *dil, int *out_shape) {
+    for (int d = 0; d < 3; ++d)
+        out_shape[d] = (in_shape[d] + 2 * pad[d] - dil[d] * (ksize[d] - 1) - 1) / stride[d] + 1;
+}
+
+SEC_API int sec_rulebook_subm3d(const int *indices, int n_in, int batch, const int *h_shape3, const int *h_ksize3,
+                                const int *h_dilation3, int *nbr_out, int *pairs, int *pair_num, void *workspace,
+                                size_t workspace_bytes, void *stream) {
+    if (n_in < 0 || batch <= 0 || !h_shape3 || !h_ksize3 || (n_in > 0 && !nbr_out) || (pairs && !pair_num)) return SEC_E_INVALID;
+    RbGeom g;
+    int rc = fill_geom(g, h_shape3, nullptr, h_ksize3, nullptr, nullptr, h_dilation3, n_in, batch);
+    if (rc) return rc;
+    for (int d = 0; d < 3; ++d)
+        if (g.ksize[d] % 2 == 0) return SEC_E_UNSUPPORTED;  // submanifold kernels are odd (spconv asserts the same)
+    hipStream_t st = (hipStream_t)stream;
+    RbWorkspace w = carve_rb(workspace, workspace_bytes, n_in, g.kvol, 1);
+    if (!workspace || w.bytes > workspace_bytes) return SEC_E_WORKSPACE;
+    g.mask = w.table - 1;
+    if (n_in == 0) {
+        if (pair_num) return hip_ok(hipMemsetAsync(pair_num, 0, g.kvol * sizeof(int), st));
+        return SEC_OK;
+    }
+    if ((rc = hip_ok(hipMemsetAsync(w.keys, 0xff, (size_t)w.table * sizeof(unsigned long long), st)))) return rc;
+    hipLaunchKernelGGL(k_rb_hash_rows, dim3(div_up(n_in, kBlock)), dim3(kBlock), 0, st, indices, g, w.keys, w.vals);
+    long long nk = (long long)n_in * g.kvol;
+    hipLaunchKernelGGL(k_subm_nbr, dim3(div_up(nk, kBlock)), dim3(kBlock), 0, st, indices, g, w.keys, w.vals, nbr_out);
+    if ((rc = check_launch())) return rc;
+    if (pairs) return emit_pairs(nbr_out, n_in, g.kvol, /*mirror=*/1, w.blk, w.scan2, pairs, pair_num, st);
+    return SEC_OK;
+}
+
+SEC_API int sec_rulebook_conv3d_build(const int *indices, int n_in, int batch, const int *h_in_shape3,
+                                      const int *h_out_shape3, const int *h_ksize3, const int *h_stride3,
+                                      const int *h_padding3, const int *h_dilation3, int *out_indices, int out_cap,
+                                      int *num_out, void *workspace, size_t workspace_bytes, void *stream) {
+    if (n_in < 0 || batch <= 0 || !h_in_shape3 || !h_out_shape3 || !h_ksize3 || !h_stride3 || !h_padding3 ||
+        !out_indices || !num_out || out_cap < 0)
+        return SEC_E_INVALID;
+    RbGeom g;
+    int rc = fill_geom(g, h_in_shape3, h_out_shape3, h_ksize3, h_stride3, h_padding3, h_dilation3, n_in, batch);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    RbWorkspace w = carve_rb(workspace, workspace_bytes, n_in, g.kvol, max_out_per_in(g.ksize, g.stride));
+    if (!workspace || w.bytes > workspace_bytes) return SEC_E_WORKSPACE;
+    g.mask = w.table - 1;
+    long long nk = (long long)n_in * g.kvol;
+    if (nk == 0) return hip_ok(hipMemsetAsync(num_out, 0, sizeof(int), st));
+    if ((rc = hip_ok(hipMemsetAsync(w.keys, 0xff, (size_t)w.table * sizeof(unsigned long long), st)))) return rc;
+    if ((rc = hip_ok(hipMemsetAsync(w.vals, 0x7f, (size_t)w.table * sizeof(int), st)))) return rc;
+    int nb = div_up(nk, kBlock);
+    hipLaunchKernelGGL(k_conv_cand, dim3(nb), dim3(kBlock), 0, st, indices, g, w.keys, w.vals, w.cand_slot);
+    hipLaunchKernelGGL(k_conv_flag, dim3(nb), dim3(kBlock), 0, st, w.cand_slot, w.vals, nk, w.rank);
+    if ((rc = exclusive_scan_i32(w.rank, w.rank, nk, num_out, w.scan, st))) return rc;
+    hipLaunchKernelGGL(k_conv_assign, dim3(nb), dim3(kBlock), 0, st, w.cand_slot, w.vals, w.keys, w.rank, g, w.orank,
+                       out_indices, out_cap);
+    return check_launch();
+}
+
+SEC_API int sec_rulebook_conv3d_tables(int n_in, const int *h_ksize3, const int *h_stride3, int *nbr_out,
+                                       int nbr_out_rows, int *nbr_in, int *pairs, int *pair_num, void *workspace,
+                                       size_t workspace_bytes, void *stream) {
+    if (n_in < 0 || !h_ksize3 || !h_stride3 || (nbr_out_rows > 0 && !nbr_out) || (n_in > 0 && !nbr_in) || nbr_out_rows < 0 ||
+        (pairs && !pair_num))
+        return SEC_E_INVALID;
+    int kvol = h_ksize3[0] * h_ksize3[1] * h_ksize3[2];
+    if (kvol <= 0 || kvol > kMaxKvol) return SEC_E_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    RbWorkspace w = carve_rb(workspace, workspace_bytes, n_in, kvol, max_out_per_in(h_ksize3, h_stride3));
+    if (!workspace || w.bytes > workspace_bytes) return SEC_E_WORKSPACE;
+    int rc;
+    if (nbr_out_rows > 0)
+        if ((rc = hip_ok(hipMemsetAsync(nbr_out, 0xff, (size_t)nbr_out_rows * kvol * sizeof(int), st)))) return rc;
+    long long nk = (long long)n_in * kvol;
+    if (nk > 0) {
+        hipLaunchKernelGGL(k_conv_tables, dim3(div_up(nk, kBlock)), dim3(kBlock), 0, st, w.cand_slot, w.orank, nk, kvol,
+                           nbr_in, nbr_out, nbr_out_rows);
+        if ((rc = check_launch())) return rc;
+    }
+    if (pairs) return emit_pairs(nbr_in, n_in, kvol, /*mirror=*/0, w.blk, w.scan2, pairs, pair_num, st);
+    return SEC_OK;
+}

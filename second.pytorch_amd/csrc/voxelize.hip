@@ -1,0 +1,278 @@
+// points_to_voxel on gfx950: a deterministic, sort-free parallel restatement of the sequential
+// hard-voxelisation loop (reference: spconv VoxelGeneratorV2.generate, called at
+// second/data/preprocess.py:301-316; in-repo copy of the loop: second/utils/simplevis.py:31-50).
+//
+// Sequential semantics to reproduce bit-exactly (per cloud):
+//   voxel id   = order of first occurrence of the voxel among the points,
+//   slot       = order of arrival of the point inside its voxel, first `max_points` kept,
+//   cap        = at most `max_voxels` voxels (`break` or `continue` at the cap).
+// Parallel formulation (all clouds of a batch in one pass, HBM/L2-bound integer work):
+//   1. hash insert  key=(cloud, linear cell) -> atomicMin(point index)      [first point of each voxel]
+//   2. flag first points, device-wide exclusive scan -> voxel rank = sequential voxel id
+//   3. per voxel, the `max_points` smallest point indices via an atomicMin cascade
+//      (position t keeps the min of everything that reaches it and forwards the loser, so position t
+//       ends up holding the (t+1)-th smallest index regardless of interleaving)
+//   4. voxel-major fill (coalesced stores) + optional SimpleVoxel mean epilogue.
+#include "common.hpp"
+
+namespace sec {
+
+struct VoxParams {
+    float lo[3], vs[3];
+    int grid[3];  // x, y, z
+    int num_points, num_features, batch, max_points, max_voxels, cap_mode;
+    uint32_t table_mask;
+};
+
+__device__ __forceinline__ int frame_of(const int *__restrict__ offs, int batch, int i) {
+    int lo = 0, hi = batch;  // find b with offs[b] <= i < offs[b+1]
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (offs[mid] <= i) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(kBlock) void k_vox_hash(const float *__restrict__ points,
+                                                    const int *__restrict__ offs, VoxParams p,
+                                                    unsigned long long *__restrict__ keys,
+                                                    int *__restrict__ vals, int *__restrict__ pslot) {
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= p.num_points) return;
+    const float *pt = points + (size_t)i * p.num_features;
+    int c[3];
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        // fp32 IEEE subtract + correctly rounded divide + floor, exactly like the reference loop
+        float q = floorf(__fdiv_rn(__fsub_rn(pt[j], p.lo[j]), p.vs[j]));
+        if (!(q >= 0.0f) || !(q < (float)p.grid[j])) ok = false;
+        c[j] = (int)q;
+    }
+    if (!ok) { pslot[i] = -1; return; }
+    int b = frame_of(offs, p.batch, i);
+    unsigned long long vol = (unsigned long long)p.grid[0] * p.grid[1] * p.grid[2];
+    unsigned long long lin = ((unsigned long long)c[2] * p.grid[1] + c[1]) * p.grid[0] + c[0];
+    uint32_t s = hash_insert(keys, p.table_mask, (unsigned long long)b * vol + lin);
+    atomicMin(&vals[s], i);
+    pslot[i] = (int)s;
+}
+
+__global__ __launch_bounds__(kBlock) void k_vox_flag(const int *__restrict__ pslot,
+                                                    const int *__restrict__ vals, int n,
+                                                    int *__restrict__ flag) {
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    int s = pslot[i];
+    flag[i] = (s >= 0 && vals[s] == i) ? 1 : 0;
+}
+
+// one thread: per-cloud voxel counts (capped) -> voxel_offsets; rank base per cloud; reset break markers
+__global__ void k_vox_frames(const int *__restrict__ offs, const int *__restrict__ rank,
+                             const int *__restrict__ total, VoxParams p, int *__restrict__ base,
+                             int *__restrict__ break_idx, int *__restrict__ voxel_offsets) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int tot = *total;
+    int acc = 0;
+    voxel_offsets[0] = 0;
+    int prev = offs[0] < p.num_points ? rank[offs[0]] : tot;
+    base[0] = prev;
+    for (int b = 0; b < p.batch; ++b) {
+        int o = offs[b + 1];
+        int nxt = o < p.num_points ? rank[o] : tot;
+        base[b + 1] = nxt;
+        int cnt = nxt - prev;
+        if (cnt > p.max_voxels) cnt = p.max_voxels;
+        acc += cnt;
+        voxel_offsets[b + 1] = acc;
+        break_idx[b] = 0x7fffffff;
+        prev = nxt;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_vox_assign(const int *__restrict__ offs,
+                                                      const int *__restrict__ pslot,
+                                                      const int *__restrict__ vals,
+                                                      const unsigned long long *__restrict__ keys,
+                                                      const int *__restrict__ rank,
+                                                      const int *__restrict__ base,
+                                                      const int *__restrict__ voxel_offsets, VoxParams p,
+                                                      int *__restrict__ svid, int *__restrict__ break_idx,
+                                                      int *__restrict__ coors) {
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= p.num_points) return;
+    int s = pslot[i];
+    if (s < 0 || vals[s] != i) return;  // only the first point of a voxel acts
+    int b = frame_of(offs, p.batch, i);
+    int r = rank[i] - base[b];
+    if (r < p.max_voxels) {
+        int vid = voxel_offsets[b] + r;
+        svid[s] = vid;
+        unsigned long long vol = (unsigned long long)p.grid[0] * p.grid[1] * p.grid[2];
+        unsigned long long lin = keys[s] - (unsigned long long)b * vol;
+        int x = (int)(lin % p.grid[0]);
+        unsigned long long t = lin / p.grid[0];
+        int y = (int)(t % p.grid[1]);
+        int z = (int)(t / p.grid[1]);
+        int4 c = make_int4(b, z, y, x);
+        *reinterpret_cast<int4 *>(coors + (size_t)vid * 4) = c;
+    } else {
+        svid[s] = -1;
+        if (r == p.max_voxels && p.cap_mode == 0) break_idx[b] = i;  // sequential loop `break`s here
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_vox_cascade(const int *__restrict__ offs,
+                                                       const int *__restrict__ pslot,
+                                                       const int *__restrict__ svid,
+                                                       const int *__restrict__ break_idx, VoxParams p,
+                                                       int *__restrict__ count, int *__restrict__ slot_idx) {
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= p.num_points) return;
+    int s = pslot[i];
+    if (s < 0) return;
+    int vid = svid[s];
+    if (vid < 0) return;
+    if (p.cap_mode == 0) {
+        int b = frame_of(offs, p.batch, i);
+        if (i >= break_idx[b]) return;
+    }
+    atomicAdd(&count[vid], 1);
+    int v = i;
+    int *row = slot_idx + (size_t)vid * p.max_points;
+    for (int t = 0; t < p.max_points; ++t) {
+        int old = atomicMin(&row[t], v);
+        if (old == kEmptyI32) break;
+        v = old > v ? old : v;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_vox_fill(const float *__restrict__ points,
+                                                    const int *__restrict__ voxel_offsets,
+                                                    const int *__restrict__ count,
+                                                    const int *__restrict__ slot_idx, VoxParams p,
+                                                    float *__restrict__ voxels,
+                                                    int *__restrict__ num_points_per_voxel) {
+    long long g = (long long)blockIdx.x * kBlock + threadIdx.x;  // (vid, t)
+    int total = voxel_offsets[p.batch];
+    int vid = (int)(g / p.max_points);
+    int t = (int)(g % p.max_points);
+    if (vid >= total) return;
+    int n = count[vid];
+    if (n > p.max_points) n = p.max_points;
+    if (t == 0) num_points_per_voxel[vid] = n;
+    float *dst = voxels + (size_t)g * p.num_features;
+    if (t < n) {
+        const float *src = points + (size_t)slot_idx[g] * p.num_features;
+        for (int f = 0; f < p.num_features; ++f) dst[f] = src[f];
+    } else {
+        for (int f = 0; f < p.num_features; ++f) dst[f] = 0.0f;
+    }
+}
+
+// SimpleVoxel.forward (second/pytorch/models/voxel_encoder.py:220-225): sum over slots / num_points
+__global__ __launch_bounds__(kBlock) void k_vox_mean(const float *__restrict__ voxels,
+                                                    const int *__restrict__ voxel_offsets,
+                                                    const int *__restrict__ num_points_per_voxel,
+                                                    VoxParams p, int mean_features,
+                                                    float *__restrict__ mean) {
+    long long g = (long long)blockIdx.x * kBlock + threadIdx.x;  // (vid, f)
+    int vid = (int)(g / mean_features);
+    int f = (int)(g % mean_features);
+    if (vid >= voxel_offsets[p.batch]) return;
+    const float *src = voxels + (size_t)vid * p.max_points * p.num_features + f;
+    float s = 0.0f;
+    for (int t = 0; t < p.max_points; ++t) s = __fadd_rn(s, src[(size_t)t * p.num_features]);
+    mean[g] = __fdiv_rn(s, (float)num_points_per_voxel[vid]);
+}
+
+struct VoxWorkspace {
+    unsigned long long *keys;
+    int *vals, *svid, *pslot, *rank, *scan, *base, *break_idx, *total, *count, *slot_idx;
+    uint32_t table;
+    size_t bytes;
+};
+
+static VoxWorkspace carve_vox(void *ws, size_t cap, int n, int batch, int max_voxels, int max_points) {
+    VoxWorkspace w;
+    Arena a(ws, cap);
+    w.table = next_pow2((uint32_t)(n > 512 ? 2 * (size_t)n : 1024));
+    w.keys = a.take<unsigned long long>(w.table);
+    w.vals = a.take<int>(w.table);
+    w.svid = a.take<int>(w.table);
+    w.pslot = a.take<int>(n);
+    w.rank = a.take<int>(n);
+    w.scan = a.take<int>(scan_scratch_ints(n));
+    w.base = a.take<int>(batch + 1);
+    w.break_idx = a.take<int>(batch);
+    w.total = a.take<int>(1);
+    w.count = a.take<int>((size_t)batch * max_voxels);
+    w.slot_idx = a.take<int>((size_t)batch * max_voxels * max_points);
+    w.bytes = align_up(a.used);
+    return w;
+}
+
+}  // namespace sec
+
+using namespace sec;
+
+SEC_API size_t sec_voxelize_workspace_bytes(int num_points, int batch, int max_voxels, int max_points) {
+    if (num_points < 0 || batch <= 0 || max_voxels <= 0 || max_points <= 0) return 0;
+    return carve_vox(nullptr, 0, num_points, batch, max_voxels, max_points).bytes;
+}
+
+SEC_API int sec_voxelize_f32(const float *points, const int *point_offsets, int num_points,
+                             int num_features, int batch, const float *h_range6,
+                             const float *h_voxel_size3, int max_points, int max_voxels, int cap_mode,
+                             float *voxels, int *coors, int *num_points_per_voxel, int *voxel_offsets,
+                             float *mean, int mean_features, void *workspace, size_t workspace_bytes,
+                             void *stream) {
+    if (num_points < 0 || num_features < 3 || batch <= 0 || max_points <= 0 || max_voxels <= 0 ||
+        !h_range6 || !h_voxel_size3 || !voxels || !coors || !num_points_per_voxel || !voxel_offsets ||
+        (mean && (mean_features <= 0 || mean_features > num_features)))
+        return SEC_E_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    VoxWorkspace w = carve_vox(workspace, workspace_bytes, num_points, batch, max_voxels, max_points);
+    if (!workspace || w.bytes > workspace_bytes) return SEC_E_WORKSPACE;
+    VoxParams p;
+    for (int j = 0; j < 3; ++j) {
+        p.lo[j] = h_range6[j];
+        p.vs[j] = h_voxel_size3[j];
+        // grid = round-half-even((max - min) / size) in fp32 (np.round), second/utils/simplevis.py:26-29
+        p.grid[j] = (int)__builtin_rintf((h_range6[3 + j] - h_range6[j]) / h_voxel_size3[j]);
+        if (p.grid[j] <= 0) return SEC_E_INVALID;
+    }
+    p.num_points = num_points; p.num_features = num_features; p.batch = batch;
+    p.max_points = max_points; p.max_voxels = max_voxels; p.cap_mode = cap_mode;
+    p.table_mask = w.table - 1;
+
+    int rc;
+    if ((rc = hip_ok(hipMemsetAsync(w.keys, 0xff, (size_t)w.table * sizeof(unsigned long long), st)))) return rc;
+    if ((rc = hip_ok(hipMemsetAsync(w.vals, 0x7f, (size_t)w.table * sizeof(int), st)))) return rc;
+    if ((rc = hip_ok(hipMemsetAsync(w.count, 0, (size_t)batch * max_voxels * sizeof(int), st)))) return rc;
+    if ((rc = hip_ok(hipMemsetAsync(w.slot_idx, 0x7f, (size_t)batch * max_voxels * max_points * sizeof(int), st)))) return rc;
+    int nb = div_up(num_points > 0 ? num_points : 1, kBlock);
+    if (num_points > 0) {
+        hipLaunchKernelGGL(k_vox_hash, dim3(nb), dim3(kBlock), 0, st, points, point_offsets, p, w.keys, w.vals, w.pslot);
+        hipLaunchKernelGGL(k_vox_flag, dim3(nb), dim3(kBlock), 0, st, w.pslot, w.vals, num_points, w.rank);
+    }
+    if ((rc = exclusive_scan_i32(w.rank, w.rank, num_points, w.total, w.scan, st))) return rc;
+    hipLaunchKernelGGL(k_vox_frames, dim3(1), dim3(64), 0, st, point_offsets, w.rank, w.total, p, w.base,
+                       w.break_idx, voxel_offsets);
+    if (num_points > 0) {
+        hipLaunchKernelGGL(k_vox_assign, dim3(nb), dim3(kBlock), 0, st, point_offsets, w.pslot, w.vals, w.keys,
+                           w.rank, w.base, voxel_offsets, p, w.svid, w.break_idx, coors);
+        hipLaunchKernelGGL(k_vox_cascade, dim3(nb), dim3(kBlock), 0, st, point_offsets, w.pslot, w.svid,
+                           w.break_idx, p, w.count, w.slot_idx);
+    }
+    long long cap = (long long)batch * max_voxels;
+    long long bound = num_points < cap ? num_points : cap;  // #voxels <= #points
+    if (bound > 0) {
+        hipLaunchKernelGGL(k_vox_fill, dim3(div_up(bound * max_points, kBlock)), dim3(kBlock), 0, st, points,
+                           voxel_offsets, w.count, w.slot_idx, p, voxels, num_points_per_voxel);
+        if (mean)
+            hipLaunchKernelGGL(k_vox_mean, dim3(div_up(bound * mean_features, kBlock)), dim3(kBlock), 0, st,
+                               voxels, voxel_offsets, num_points_per_voxel, p, mean_features, mean);
+    }
+    return check_launch();
+}

@@ -1,0 +1,238 @@
+"""Tensor-level wrappers over the C ABI (include/second_hip.h).
+
+torch here is plumbing only: it owns device memory and the current HIP stream.  Each function cites
+the reference interface its kernel replaces (see the header for file:line).
+"""
+import numpy as np
+import torch
+
+from . import runtime as rt
+
+
+# ----------------------------------------------------------------------------- voxelisation
+def voxelize(points, point_offsets, point_cloud_range, voxel_size, max_points, max_voxels,
+             cap_mode="break", mean_features=0, sync=True):
+    """Batched points_to_voxel (spconv VoxelGeneratorV2.generate; second/data/preprocess.py:301-316).
+
+    points [N,F] float32 cuda (clouds concatenated), point_offsets [B+1] int32 cuda.
+    Returns dict(voxels, coordinates [M,4]=(b,z,y,x), num_points_per_voxel, voxel_offsets [B+1], mean?).
+    With ``sync=True`` the outputs are sliced to the total voxel count (one D2H of B+1 ints);
+    with ``sync=False`` they keep capacity B*max_voxels and only rows < voxel_offsets[B] are defined.
+    """
+    rt.require_gpu(points, point_offsets)
+    assert points.dtype == torch.float32 and points.dim() == 2 and points.is_contiguous()
+    assert point_offsets.dtype == torch.int32
+    n, f = points.shape
+    batch = point_offsets.numel() - 1
+    dev = points.device
+    cap = batch * max_voxels
+    rows = min(cap, max(n, 1))
+    voxels = torch.empty((rows, max_points, f), dtype=torch.float32, device=dev)
+    coors = torch.empty((rows, 4), dtype=torch.int32, device=dev)
+    npv = torch.empty((rows,), dtype=torch.int32, device=dev)
+    voff = torch.empty((batch + 1,), dtype=torch.int32, device=dev)
+    mean = torch.empty((rows, mean_features), dtype=torch.float32, device=dev) if mean_features else None
+    l = rt.lib()
+    ws_bytes = l.sec_voxelize_workspace_bytes(n, batch, max_voxels, max_points)
+    ws = rt.workspace(ws_bytes, dev)
+    rc = l.sec_voxelize_f32(rt.ptr(points), rt.ptr(point_offsets), n, f, batch, rt.f_arr(point_cloud_range),
+                            rt.f_arr(voxel_size), int(max_points), int(max_voxels),
+                            {"break": 0, "continue": 1}[cap_mode], rt.ptr(voxels), rt.ptr(coors), rt.ptr(npv),
+                            rt.ptr(voff), rt.ptr(mean), int(mean_features), rt.ptr(ws), ws.numel(), rt.stream())
+    rt.check(rc, "sec_voxelize_f32")
+    out = {"voxels": voxels, "coordinates": coors, "num_points_per_voxel": npv, "voxel_offsets": voff}
+    if mean is not None:
+        out["mean"] = mean
+    if sync:
+        total = int(voff[-1].item())
+        for k in ("voxels", "coordinates", "num_points_per_voxel", "mean"):
+            if k in out:
+                out[k] = out[k][:total]
+        out["voxel_num"] = total
+    return out
+
+
+# ----------------------------------------------------------------------------- rulebooks
+def conv_output_shape(in_shape, ksize, stride, padding, dilation):
+    import ctypes
+    out = (ctypes.c_int * 3)()
+    rt.lib().sec_conv_output_shape(rt.i3(in_shape), rt.i3(ksize), rt.i3(stride), rt.i3(padding), rt.i3(dilation), out)
+    return [int(v) for v in out]
+
+
+def _kvol(ksize):
+    return int(np.prod([int(k) for k in ((ksize,) * 3 if isinstance(ksize, int) else ksize)]))
+
+
+def rulebook_subm(indices, batch_size, spatial_shape, ksize=3, dilation=1, want_pairs=False):
+    """SubMConv3d rulebook (spconv.ops.get_indice_pairs(subm=True)).  indices [N,4] int32 (b,z,y,x)."""
+    rt.require_gpu(indices)
+    assert indices.dtype == torch.int32 and indices.is_contiguous()
+    n = indices.shape[0]
+    k = _kvol(ksize)
+    dev = indices.device
+    nbr = torch.empty((n, k), dtype=torch.int32, device=dev)
+    pairs = torch.empty((k, 2, n), dtype=torch.int32, device=dev) if want_pairs else None
+    pair_num = torch.zeros((k,), dtype=torch.int32, device=dev) if want_pairs else None
+    l = rt.lib()
+    ws = rt.workspace(l.sec_rulebook_workspace_bytes(n, k, 1), dev)
+    rc = l.sec_rulebook_subm3d(rt.ptr(indices), n, int(batch_size), rt.i3(spatial_shape), rt.i3(ksize),
+                               rt.i3(dilation), rt.ptr(nbr), rt.ptr(pairs), rt.ptr(pair_num), rt.ptr(ws),
+                               ws.numel(), rt.stream())
+    rt.check(rc, "sec_rulebook_subm3d")
+    return {"nbr_out": nbr, "nbr_in": None, "pairs": pairs, "pair_num": pair_num, "out_indices": indices,
+            "num_out": n, "out_shape": [int(s) for s in spatial_shape]}
+
+
+def rulebook_conv(indices, batch_size, spatial_shape, ksize, stride, padding, dilation=1, want_pairs=False):
+    """SparseConv3d rulebook (spconv.ops.get_indice_pairs(subm=False)), first-touch output numbering.
+    One D2H sync (the active-output count), like the reference's numActOut."""
+    rt.require_gpu(indices)
+    assert indices.dtype == torch.int32 and indices.is_contiguous()
+    n = indices.shape[0]
+    ks, st = rt.i3(ksize), rt.i3(stride)
+    k = _kvol(ksize)
+    dev = indices.device
+    out_shape = conv_output_shape(spatial_shape, ksize, stride, padding, dilation)
+    per_in = int(np.prod([(ks[d] + st[d] - 1) // st[d] for d in range(3)]))
+    cap = max(1, min(n * per_in, int(batch_size) * int(np.prod(out_shape))))
+    out_idx = torch.empty((cap, 4), dtype=torch.int32, device=dev)
+    num_out = torch.zeros((1,), dtype=torch.int32, device=dev)
+    l = rt.lib()
+    ws = rt.workspace(l.sec_rulebook_workspace_bytes(n, k, per_in), dev)
+    rc = l.sec_rulebook_conv3d_build(rt.ptr(indices), n, int(batch_size), rt.i3(spatial_shape), rt.i3(out_shape), ks,
+                                     st, rt.i3(padding), rt.i3(dilation), rt.ptr(out_idx), cap, rt.ptr(num_out),
+                                     rt.ptr(ws), ws.numel(), rt.stream())
+    rt.check(rc, "sec_rulebook_conv3d_build")
+    m = int(num_out.item())
+    nbr_out = torch.empty((m, k), dtype=torch.int32, device=dev)
+    nbr_in = torch.empty((n, k), dtype=torch.int32, device=dev)
+    pairs = torch.empty((k, 2, n), dtype=torch.int32, device=dev) if want_pairs else None
+    pair_num = torch.zeros((k,), dtype=torch.int32, device=dev) if want_pairs else None
+    rc = l.sec_rulebook_conv3d_tables(n, ks, st, rt.ptr(nbr_out), m, rt.ptr(nbr_in), rt.ptr(pairs), rt.ptr(pair_num),
+                                      rt.ptr(ws), ws.numel(), rt.stream())
+    rt.check(rc, "sec_rulebook_conv3d_tables")
+    return {"nbr_out": nbr_out, "nbr_in": nbr_in, "pairs": pairs, "pair_num": pair_num,
+            "out_indices": out_idx[:m], "num_out": m, "out_shape": out_shape}
+
+
+# ----------------------------------------------------------------------------- indice_conv
+def pack_weight(weight):
+    """Fragment-order copy of a [kD,kH,kW,Cin,Cout] weight for the MFMA path; None when not applicable."""
+    rt.require_gpu(weight)
+    cin, cout = weight.shape[-2], weight.shape[-1]
+    k = weight.numel() // (cin * cout)
+    if weight.dtype == torch.float32:
+        return None
+    code = rt.dtype_code(weight.dtype)
+    l = rt.lib()
+    nbytes = l.sec_packed_weight_bytes(k, cin, cout, code)
+    if nbytes == 0:
+        return None
+    packed = torch.empty((nbytes // 2,), dtype=weight.dtype, device=weight.device)
+    rt.check(l.sec_pack_conv_weight(rt.ptr(weight.contiguous()), k, cin, cout, code, rt.ptr(packed), rt.stream()),
+             "sec_pack_conv_weight")
+    return packed
+
+
+def indice_conv(features, weight, nbr_out, num_out, packed=None, scale=None, shift=None, relu=False,
+                out_dtype=None, num_out_dev=None):
+    """out[o] = sum_k features[nbr_out[o][k]] @ W[k], optional fused scale/shift/ReLU epilogue
+    (spconv.ops.indice_conv / indice_subm_conv)."""
+    rt.require_gpu(features, weight, nbr_out)
+    assert features.is_contiguous() and weight.is_contiguous() and nbr_out.is_contiguous()
+    assert features.dtype == weight.dtype, (features.dtype, weight.dtype)
+    cin, cout = weight.shape[-2], weight.shape[-1]
+    k = weight.numel() // (cin * cout)
+    assert features.shape[1] == cin and nbr_out.shape[1] == k
+    out_dtype = out_dtype or features.dtype
+    out = torch.empty((num_out, cout), dtype=out_dtype, device=features.device)
+    for t in (scale, shift):
+        assert t is None or (t.dtype == torch.float32 and t.is_cuda and t.numel() == cout)
+    rc = rt.lib().sec_indice_conv_fwd(rt.ptr(features), features.shape[0], cin, rt.ptr(weight), rt.ptr(packed), k, cout,
+                                      rt.ptr(nbr_out), int(num_out), rt.ptr(num_out_dev), rt.ptr(scale), rt.ptr(shift),
+                                      int(bool(relu)), rt.ptr(out), rt.dtype_code(features.dtype),
+                                      rt.dtype_code(out_dtype), rt.stream())
+    rt.check(rc, "sec_indice_conv_fwd")
+    return out
+
+
+def indice_conv_backward(features, weight, nbr_out, nbr_in, dout, need_dfeat=True, need_dweight=True):
+    """(dfeat, dweight) of indice_conv (spconv.ops.indice_conv_backward). nbr_in None => SubM mirror."""
+    rt.require_gpu(features, weight, nbr_out, dout)
+    cin, cout = weight.shape[-2], weight.shape[-1]
+    k = weight.numel() // (cin * cout)
+    dout = dout.contiguous()
+    dfeat = torch.empty_like(features) if need_dfeat else None
+    dw = torch.empty(weight.shape, dtype=torch.float32, device=weight.device) if need_dweight else None
+    rc = rt.lib().sec_indice_conv_bwd(rt.ptr(features), features.shape[0], cin, rt.ptr(weight), k, cout, rt.ptr(nbr_out),
+                                      rt.ptr(nbr_in), dout.shape[0], rt.ptr(dout), rt.ptr(dfeat), rt.ptr(dw),
+                                      rt.dtype_code(features.dtype), rt.stream())
+    rt.check(rc, "sec_indice_conv_bwd")
+    return dfeat, (dw.to(weight.dtype) if dw is not None else None)
+
+
+# ----------------------------------------------------------------------------- scatters
+def sparse_to_dense(features, indices, batch_size, spatial_shape, channels_last_2d=False, num_dev=None):
+    """SparseConvTensor.dense().  Default: [B,C,D,H,W] contiguous.  ``channels_last_2d``: a
+    [B, C*D, H, W] tensor in torch.channels_last memory format (what the RPN consumes) -- same values as
+    dense().view(B, C*D, H, W) (second/pytorch/models/middle.py:206-210), no permute copy."""
+    rt.require_gpu(features, indices)
+    n, c = features.shape
+    d, h, w = [int(s) for s in spatial_shape]
+    b = int(batch_size)
+    if channels_last_2d:
+        out = torch.empty((b, c * d, h, w), dtype=features.dtype, device=features.device,
+                          memory_format=torch.channels_last)
+        sb, sc2, sy, sx = out.stride()
+        strides = (sb, sc2 * d, sc2, sy, sx)  # channel index = c*D + z
+    else:
+        out = torch.empty((b, c, d, h, w), dtype=features.dtype, device=features.device)
+        strides = out.stride()
+    rc = rt.lib().sec_sparse_to_dense(rt.ptr(features.contiguous()), rt.ptr(indices), n, c, rt.ptr(num_dev), rt.ptr(out),
+                                      out.numel(), *[int(s) for s in strides], rt.dtype_code(features.dtype), rt.stream())
+    rt.check(rc, "sec_sparse_to_dense")
+    return out
+
+
+def pillar_scatter(features, coords, batch_size, ny, nx, channels_last=False):
+    """PointPillarsScatter.forward (second/pytorch/models/pointpillars.py:444-476) as one launch."""
+    rt.require_gpu(features, coords)
+    p, c = features.shape
+    fmt = torch.channels_last if channels_last else torch.contiguous_format
+    out = torch.empty((int(batch_size), c, int(ny), int(nx)), dtype=features.dtype, device=features.device,
+                      memory_format=fmt)
+    sb, sc, sy, sx = out.stride()
+    rc = rt.lib().sec_pillar_scatter(rt.ptr(features.contiguous()), rt.ptr(coords), p, c, rt.ptr(out), out.numel(),
+                                     int(sb), int(sc), int(sy), int(sx), rt.dtype_code(features.dtype), rt.stream())
+    rt.check(rc, "sec_pillar_scatter")
+    return out
+
+
+# ----------------------------------------------------------------------------- IoU / NMS
+def rotate_iou(boxes, qboxes, criterion=-1):
+    """[N,K] rotated IoU (nms_gpu.py rotate_iou_gpu_eval)."""
+    rt.require_gpu(boxes, qboxes)
+    boxes, qboxes = boxes.float().contiguous(), qboxes.float().contiguous()
+    n, k = boxes.shape[0], qboxes.shape[0]
+    out = torch.zeros((n, k), dtype=torch.float32, device=boxes.device)
+    rt.check(rt.lib().sec_rotate_iou_f32(rt.ptr(boxes), n, rt.ptr(qboxes), k, int(criterion), rt.ptr(out), rt.stream()),
+             "sec_rotate_iou_f32")
+    return out
+
+
+def nms_sorted(dets, counts, thresh, kind="rotate", semantics="numba", eps=1.0, post_max=0):
+    """Greedy NMS of score-sorted boxes. dets [B,max_n,stride] float32, counts [B] int32 (device).
+    Returns (keep [B,max_n] int32 positions, num_keep [B] int32), all on device, no host sync."""
+    rt.require_gpu(dets, counts)
+    assert dets.dtype == torch.float32 and dets.dim() == 3 and dets.is_contiguous() and counts.dtype == torch.int32
+    b, max_n, stride = dets.shape
+    keep = torch.empty((b, max_n), dtype=torch.int32, device=dets.device)
+    num_keep = torch.empty((b,), dtype=torch.int32, device=dets.device)
+    l = rt.lib()
+    ws = rt.workspace(l.sec_nms_workspace_bytes(b, max_n), dets.device)
+    rc = l.sec_nms_sorted_f32(rt.ptr(dets), rt.ptr(counts), b, max_n, stride, float(thresh),
+                              {"rotate": 0, "axis_aligned": 1}[kind], {"numba": 0, "cpu": 1}[semantics], float(eps),
+                              int(post_max or 0), rt.ptr(keep), rt.ptr(num_keep), rt.ptr(ws), ws.numel(), rt.stream())
+    rt.check(rc, "sec_nms_sorted_f32")
+    return keep, num_keep

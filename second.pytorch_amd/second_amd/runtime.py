@@ -1,0 +1,113 @@
+"""ctypes binding of libsecond_hip.so (C ABI: include/second_hip.h).
+
+Fails loudly: no library -> RuntimeError at first use; no silent CPU path anywhere.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libsecond_hip.so")
+
+SEC_F32, SEC_F16, SEC_BF16 = 0, 1, 2
+_DTYPES = {torch.float32: SEC_F32, torch.float16: SEC_F16, torch.bfloat16: SEC_BF16}
+_ERRORS = {-1: "SEC_E_INVALID (bad argument)", -2: "SEC_E_WORKSPACE (workspace too small)",
+           -3: "SEC_E_UNSUPPORTED", -4: "SEC_E_LAUNCH (HIP error)"}
+
+# every symbol include/second_hip.h declares (checked by tests/test_capi_symbols.py)
+SYMBOLS = [
+    "sec_abi_version", "sec_last_error", "sec_voxelize_workspace_bytes", "sec_voxelize_f32",
+    "sec_rulebook_workspace_bytes", "sec_rulebook_subm3d", "sec_rulebook_conv3d_build",
+    "sec_rulebook_conv3d_tables", "sec_conv_output_shape", "sec_packed_weight_bytes",
+    "sec_pack_conv_weight", "sec_indice_conv_fwd", "sec_indice_conv_bwd", "sec_sparse_to_dense",
+    "sec_pillar_scatter", "sec_rotate_iou_f32", "sec_nms_workspace_bytes", "sec_nms_sorted_f32",
+]
+
+_lib = None
+
+
+class SecondHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library.  Raises if it has not been built (python second.pytorch_amd/build.py)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SecondHipError(
+                f"{LIB_PATH} is missing: build it with `python second.pytorch_amd/build.py` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        l = ctypes.CDLL(LIB_PATH)
+        for name in ("sec_voxelize_workspace_bytes", "sec_rulebook_workspace_bytes",
+                     "sec_packed_weight_bytes", "sec_nms_workspace_bytes"):
+            getattr(l, name).restype = ctypes.c_size_t
+        l.sec_last_error.restype = ctypes.c_char_p
+        l.sec_conv_output_shape.restype = None
+        vp, ci, cf, sz, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_int64
+        l.sec_voxelize_workspace_bytes.argtypes = [ci, ci, ci, ci]
+        l.sec_voxelize_f32.argtypes = [vp, vp, ci, ci, ci, vp, vp, ci, ci, ci, vp, vp, vp, vp, vp, ci, vp, sz, vp]
+        l.sec_rulebook_workspace_bytes.argtypes = [ci, ci, ci]
+        l.sec_rulebook_subm3d.argtypes = [vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, sz, vp]
+        l.sec_rulebook_conv3d_build.argtypes = [vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, ci, vp, vp, sz, vp]
+        l.sec_rulebook_conv3d_tables.argtypes = [ci, vp, vp, vp, ci, vp, vp, vp, vp, sz, vp]
+        l.sec_conv_output_shape.argtypes = [vp] * 6
+        l.sec_packed_weight_bytes.argtypes = [ci, ci, ci, ci]
+        l.sec_pack_conv_weight.argtypes = [vp, ci, ci, ci, ci, vp, vp]
+        l.sec_indice_conv_fwd.argtypes = [vp, ci, ci, vp, vp, ci, ci, vp, ci, vp, vp, vp, ci, vp, ci, ci, vp]
+        l.sec_indice_conv_bwd.argtypes = [vp, ci, ci, vp, ci, ci, vp, vp, ci, vp, vp, vp, ci, vp]
+        l.sec_sparse_to_dense.argtypes = [vp, vp, ci, ci, vp, vp, sz, i64, i64, i64, i64, i64, ci, vp]
+        l.sec_pillar_scatter.argtypes = [vp, vp, ci, ci, vp, sz, i64, i64, i64, i64, ci, vp]
+        l.sec_rotate_iou_f32.argtypes = [vp, ci, vp, ci, ci, vp, vp]
+        l.sec_nms_workspace_bytes.argtypes = [ci, ci]
+        l.sec_nms_sorted_f32.argtypes = [vp, vp, ci, ci, ci, cf, ci, ci, cf, ci, vp, vp, vp, sz, vp]
+        _lib = l
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        detail = lib().sec_last_error().decode() if rc == -4 else ""
+        raise SecondHipError(f"{what} failed: {_ERRORS.get(rc, rc)} {detail}")
+
+
+def dtype_code(dt):
+    try:
+        return _DTYPES[dt]
+    except KeyError:
+        raise SecondHipError(f"unsupported feature dtype {dt}") from None
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise SecondHipError(
+                "second_amd ops run on the GPU only (got a CPU tensor); there is no CPU fallback")
+
+
+def ptr(t):
+    if t is None:
+        return ctypes.c_void_p(0)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def i3(v):
+    if isinstance(v, int):
+        v = (v, v, v)
+    v = [int(x) for x in v]
+    assert len(v) == 3, v
+    return (ctypes.c_int * 3)(*v)
+
+
+def f_arr(v):
+    v = [float(x) for x in v]
+    return (ctypes.c_float * len(v))(*v)
+
+
+def workspace(nbytes, device):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)

@@ -1,0 +1,125 @@
+"""spconv.SubMConv3d / SparseConv3d (spconv/conv.py upstream; used at
+second/pytorch/models/middle.py:146-189 and resnet.py:10-29).  Leaf nn.Modules with Parameters
+``weight`` [kD,kH,kW,Cin,Cout] and ``bias`` [Cout] so .tckpt checkpoints interchange."""
+import math
+
+import torch
+from torch import nn
+from torch.nn import init
+
+from second_amd import ops as _ops
+from . import functional as Fsp
+from .modules import SparseModule
+from .tensor import Rulebook, SparseConvTensor
+
+
+def _triple(v):
+    if isinstance(v, (list, tuple)):
+        assert len(v) == 3, v
+        return [int(x) for x in v]
+    return [int(v)] * 3
+
+
+class SparseConvolution(SparseModule):
+    def __init__(self, ndim, in_channels, out_channels, kernel_size=3, stride=1, padding=0, dilation=1, groups=1,
+                 bias=True, subm=False, output_padding=0, transposed=False, inverse=False, indice_key=None):
+        super().__init__()
+        assert ndim == 3, "only 3-D sparse convolutions are on the SECOND hot path"
+        assert groups == 1 and not transposed and not inverse, "unused by the reference (SURVEY 2.2)"
+        self.ndim, self.in_channels, self.out_channels = ndim, in_channels, out_channels
+        self.kernel_size, self.stride = _triple(kernel_size), _triple(stride)
+        self.padding, self.dilation = _triple(padding), _triple(dilation)
+        self.conv1x1 = all(k == 1 for k in self.kernel_size)
+        self.subm, self.indice_key = subm, indice_key
+        self.weight = nn.Parameter(torch.empty(*self.kernel_size, in_channels, out_channels))
+        if bias:
+            self.bias = nn.Parameter(torch.empty(out_channels))
+        else:
+            self.register_parameter("bias", None)
+        self._packed = None
+        self._packed_key = None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        fan_in = self.in_channels * self.kernel_size[0] * self.kernel_size[1] * self.kernel_size[2]
+        bound = math.sqrt(6.0 / ((1 + 5) * fan_in))  # kaiming_uniform_(a=sqrt(5))
+        init.uniform_(self.weight, -bound, bound)
+        if self.bias is not None:
+            b = 1 / math.sqrt(fan_in)
+            init.uniform_(self.bias, -b, b)
+
+    def extra_repr(self):
+        return (f"{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, stride={self.stride}, "
+                f"padding={self.padding}, subm={self.subm}, indice_key={self.indice_key}")
+
+    # -- rulebook ---------------------------------------------------------------------------------
+    def _rulebook(self, x):
+        rb = x.find_indice_pair(self.indice_key)
+        if rb is not None and self.subm:
+            return rb
+        indices = x.indices.contiguous()
+        if self.subm:
+            r = _ops.rulebook_subm(indices, x.batch_size, x.spatial_shape, self.kernel_size, self.dilation)
+        else:
+            r = _ops.rulebook_conv(indices, x.batch_size, x.spatial_shape, self.kernel_size, self.stride, self.padding,
+                                   self.dilation)
+        rb = Rulebook(r["out_indices"], indices, r["nbr_out"], r["nbr_in"], r["num_out"], x.spatial_shape,
+                      r["out_shape"], self.subm)
+        if self.indice_key is not None:
+            x.indice_dict[self.indice_key] = rb
+        return rb
+
+    def packed_weight(self):
+        w = self.weight
+        key = (w._version, w.dtype, w.device, w.data_ptr())
+        if self._packed_key != key:
+            self._packed = _ops.pack_weight(w.detach().contiguous()) if w.is_cuda else None
+            self._packed_key = key
+        return self._packed
+
+    def _wrap(self, x, feats, rb):
+        out = SparseConvTensor(feats, rb.out_indices, rb.out_shape, x.batch_size, x.grid)
+        out.indice_dict = x.indice_dict
+        return out
+
+    # -- forward ----------------------------------------------------------------------------------
+    def forward(self, x):
+        assert isinstance(x, SparseConvTensor)
+        if self.conv1x1 and not self.subm and all(s == 1 for s in self.stride) and all(p == 0 for p in self.padding):
+            feats = torch.mm(x.features, self.weight.view(self.in_channels, self.out_channels))
+            if self.bias is not None:
+                feats = feats + self.bias
+            out = SparseConvTensor(feats, x.indices, x.spatial_shape, x.batch_size, x.grid)
+            out.indice_dict = x.indice_dict
+            return out
+        rb = self._rulebook(x)
+        feats = Fsp.indice_conv(x.features, self.weight.to(x.features.dtype), rb, self.packed_weight()
+                                if self.weight.dtype == x.features.dtype else None)
+        if self.bias is not None:
+            feats = feats + self.bias.to(feats.dtype)
+        return self._wrap(x, feats, rb)
+
+    def forward_fused(self, x, scale, shift, relu):
+        """Inference: conv + per-channel scale/shift (folded BatchNorm1d, bias) + ReLU in ONE launch."""
+        rb = self._rulebook(x)
+        w = self.weight.detach()
+        packed = self.packed_weight()
+        if w.dtype != x.features.dtype:
+            w, packed = w.to(x.features.dtype), None
+        feats = _ops.indice_conv(x.features.contiguous(), w.contiguous(), rb.nbr_out, rb.num_out, packed=packed,
+                                 scale=scale, shift=shift, relu=relu)
+        return self._wrap(x, feats, rb)
+
+
+class SubMConv3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 indice_key=None):
+        super().__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias, True,
+                         indice_key=indice_key)
+
+
+class SparseConv3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 indice_key=None):
+        super().__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias,
+                         indice_key=indice_key)

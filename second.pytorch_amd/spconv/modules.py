@@ -1,0 +1,100 @@
+"""spconv.SparseModule / SparseSequential (spconv/modules.py upstream; second/pytorch/models/middle.py:145)."""
+from collections import OrderedDict
+
+import torch
+from torch import nn
+
+
+class SparseModule(nn.Module):
+    """Marker base class: modules that take and return a SparseConvTensor."""
+
+
+def _is_sparse(m):
+    return isinstance(m, SparseModule)
+
+
+class SparseSequential(SparseModule):
+    """nn.Sequential that applies SparseModules to the tensor and plain modules to ``.features``.
+
+    Inference peephole (API unchanged): ``SparseConvolution -> BatchNorm1d [-> ReLU]`` runs as ONE fused
+    launch with the BatchNorm folded into a per-channel scale/shift epilogue (``fuse_inference``)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        if len(args) == 1 and isinstance(args[0], OrderedDict):
+            for key, module in args[0].items():
+                self.add_module(key, module)
+        else:
+            for idx, module in enumerate(args):
+                self.add_module(str(idx), module)
+        for name, module in kwargs.items():
+            if name in self._modules:
+                raise ValueError("name exists.")
+            self.add_module(name, module)
+        self.fuse_inference = True
+        self._fold_cache = {}
+
+    def __getitem__(self, idx):
+        if not (-len(self) <= idx < len(self)):
+            raise IndexError(f"index {idx} is out of range")
+        if idx < 0:
+            idx += len(self)
+        return list(self._modules.values())[idx]
+
+    def __len__(self):
+        return len(self._modules)
+
+    def add(self, module, name=None):
+        if name is None:
+            name = str(len(self._modules))
+            if name in self._modules:
+                raise KeyError("name exists")
+        self.add_module(name, module)
+
+    def _folded(self, conv, bn):
+        key = (id(conv), id(bn), bn.weight._version if bn.weight is not None else 0,
+               bn.bias._version if bn.bias is not None else 0, bn.running_mean._version, bn.running_var._version,
+               conv.bias._version if conv.bias is not None else -1, bn.running_mean.device)
+        hit = self._fold_cache.get(id(conv))
+        if hit is not None and hit[0] == key:
+            return hit[1], hit[2]
+        with torch.no_grad():
+            var = bn.running_var.float()
+            scale = torch.rsqrt(var + bn.eps)
+            if bn.weight is not None:
+                scale = scale * bn.weight.float()
+            shift = -bn.running_mean.float() * scale
+            if bn.bias is not None:
+                shift = shift + bn.bias.float()
+            if conv.bias is not None:
+                shift = shift + conv.bias.float() * scale
+            scale, shift = scale.contiguous(), shift.contiguous()
+        self._fold_cache[id(conv)] = (key, scale, shift)
+        return scale, shift
+
+    def forward(self, input):
+        from .conv import SparseConvolution
+        from .tensor import SparseConvTensor
+        mods = list(self._modules.values())
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if (self.fuse_inference and not self.training and isinstance(m, SparseConvolution) and not m.conv1x1
+                    and isinstance(input, SparseConvTensor) and input.features.is_cuda
+                    and not torch.is_grad_enabled()
+                    and i + 1 < len(mods) and isinstance(mods[i + 1], nn.BatchNorm1d)
+                    and mods[i + 1].track_running_stats and not mods[i + 1].training):
+                relu = i + 2 < len(mods) and isinstance(mods[i + 2], nn.ReLU)
+                scale, shift = self._folded(m, mods[i + 1])
+                input = m.forward_fused(input, scale, shift, relu)
+                i += 3 if relu else 2
+                continue
+            if _is_sparse(m):
+                input = m(input)
+            elif isinstance(input, SparseConvTensor):
+                if input.indices.shape[0] != 0:
+                    input.features = m(input.features)
+            else:
+                input = m(input)
+            i += 1
+        return input

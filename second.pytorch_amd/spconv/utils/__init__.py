@@ -1,0 +1,152 @@
+"""spconv.utils (spconv/utils/__init__.py upstream): VoxelGeneratorV2, points_to_voxel and the numpy-facing
+NMS helpers the reference imports (second/builder/voxel_builder.py:23-32, second/data/preprocess.py:301-316,
+second/core/non_max_suppression/nms_gpu.py:8,16, nms_cpu.py:5-6,14,27).
+
+The arithmetic runs on the MI355X through libsecond_hip.so: numpy arrays are staged to the GPU and back
+(that is what the upstream `non_max_suppression` did too).  GPU required; no CPU path.
+NOTE: HIP contexts do not survive fork(); use a `spawn` DataLoader context or voxelise in the main process
+(`VoxelGeneratorV2.generate_device`) when driving the reference's training loop.
+"""
+import numpy as np
+import torch
+
+from second_amd import ops as _ops
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        from second_amd.runtime import SecondHipError
+        raise SecondHipError("spconv.utils needs a GPU: the MI355X path has no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+class VoxelGeneratorV2:
+    def __init__(self, voxel_size, point_cloud_range, max_num_points, max_voxels=20000, full_mean=False,
+                 block_filtering=False, block_factor=0, block_size=0, height_threshold=0.0,
+                 height_high_threshold=3.0, max_voxels_mode="break"):
+        assert full_mean is False, "full_mean is asserted off upstream and unused by every config"
+        point_cloud_range = np.array(point_cloud_range, dtype=np.float32)
+        voxel_size = np.array(voxel_size, dtype=np.float32)
+        grid_size = (point_cloud_range[3:] - point_cloud_range[:3]) / voxel_size
+        grid_size = np.round(grid_size).astype(np.int64)
+        self._voxel_size = voxel_size
+        self._point_cloud_range = point_cloud_range
+        self._max_num_points = int(max_num_points)
+        self._max_voxels = int(max_voxels)
+        self._grid_size = grid_size
+        self._full_mean = full_mean
+        self._block_filtering = block_filtering
+        self._block_factor, self._block_size = block_factor, block_size
+        self._height_threshold, self._height_high_threshold = height_threshold, height_high_threshold
+        self._mode = max_voxels_mode
+        if block_filtering:
+            raise NotImplementedError("block_filtering (nuscenes/all.fhd.config:9-12) is a later SURVEY 8a row (a4)")
+
+    # -- device-resident path (no host round trip): points [N,F] cuda float32, offsets [B+1] cuda int32
+    def generate_device(self, points, point_offsets, max_voxels=None, mean_features=0, sync=True):
+        return _ops.voxelize(points, point_offsets, self._point_cloud_range.tolist(), self._voxel_size.tolist(),
+                             self._max_num_points, int(max_voxels or self._max_voxels), self._mode,
+                             mean_features=mean_features, sync=sync)
+
+    def _run(self, points, max_voxels):
+        dev = _dev()
+        pts = torch.from_numpy(np.ascontiguousarray(points, dtype=np.float32)).to(dev)
+        offs = torch.tensor([0, pts.shape[0]], dtype=torch.int32, device=dev)
+        return self.generate_device(pts, offs, max_voxels)
+
+    def generate(self, points, max_voxels=None):
+        r = self._run(points, max_voxels)
+        n = r["voxel_num"]
+        voxels = r["voxels"].cpu().numpy()
+        npv = r["num_points_per_voxel"].cpu().numpy()
+        mask = (np.arange(self._max_num_points)[None, :] < npv[:, None]).astype(np.float32)[..., None]
+        return {"voxels": voxels, "coordinates": r["coordinates"][:, 1:].cpu().numpy(),
+                "num_points_per_voxel": npv, "voxel_point_mask": mask, "voxel_num": n}
+
+    def generate_multi_gpu(self, points, max_voxels=None):
+        mv = int(max_voxels or self._max_voxels)
+        res = self.generate(points, mv)
+        n = res["voxel_num"]
+        f = points.shape[1]
+        out = {"voxels": np.zeros((mv, self._max_num_points, f), np.float32),
+               "coordinates": np.zeros((mv, 3), np.int32),
+               "num_points_per_voxel": np.zeros((mv,), np.int32),
+               "voxel_point_mask": np.zeros((mv, self._max_num_points, 1), np.float32), "voxel_num": n}
+        for k in ("voxels", "coordinates", "num_points_per_voxel", "voxel_point_mask"):
+            out[k][:n] = res[k]
+        return out
+
+    @property
+    def voxel_size(self):
+        return self._voxel_size
+
+    @property
+    def max_num_points_per_voxel(self):
+        return self._max_num_points
+
+    @property
+    def point_cloud_range(self):
+        return self._point_cloud_range
+
+    @property
+    def grid_size(self):
+        return self._grid_size
+
+
+VoxelGenerator = VoxelGeneratorV2
+
+
+def points_to_voxel(points, voxel_size, coors_range, coor_to_voxelidx=None, max_points=35, max_voxels=20000,
+                    full_mean=False, block_filtering=True, block_factor=1, block_size=8, height_threshold=0.2,
+                    pad_output=False):
+    gen = VoxelGeneratorV2(voxel_size, coors_range, max_points, max_voxels)
+    return gen.generate_multi_gpu(points, max_voxels) if pad_output else gen.generate(points, max_voxels)
+
+
+# ----------------------------------------------------------------------------- NMS helpers (numpy facing)
+def non_max_suppression(sorted_dets, keep_out, thresh, device_id=0):
+    """spconv's CUDA NMS (src/utils/nms.cu) signature: boxes [N,5] (x1,y1,x2,y2,score) sorted by score,
+    writes kept positions into keep_out, returns their count ('+1' convention, IoU > thresh)."""
+    dev = torch.device("cuda", device_id)
+    n = sorted_dets.shape[0]
+    if n == 0:
+        return 0
+    d = torch.from_numpy(np.ascontiguousarray(sorted_dets, np.float32)).to(dev).unsqueeze(0)
+    cnt = torch.tensor([n], dtype=torch.int32, device=dev)
+    keep, num = _chunked_nms(d, cnt, thresh, "axis_aligned", "numba", 1.0)
+    k = int(num[0].item())
+    keep_out[:k] = keep[0, :k].cpu().numpy()
+    return k
+
+
+def _chunked_nms(dets, counts, thresh, kind, semantics, eps, post_max=0):
+    assert dets.shape[1] <= 4096, "sec_nms_sorted_f32 handles up to 4096 boxes per item"
+    return _ops.nms_sorted(dets.contiguous(), counts, thresh, kind, semantics, eps, post_max)
+
+
+def non_max_suppression_cpu(dets, order, thresh, eps=0.0):
+    """greedy NMS with the eps convention, IoU >= thresh (nms_cpu.py:11-14); returns original indices."""
+    dev = _dev()
+    order = np.asarray(order)
+    n = dets.shape[0]
+    if n == 0:
+        return []
+    d = torch.from_numpy(np.ascontiguousarray(dets[order], np.float32)).to(dev).unsqueeze(0)
+    cnt = torch.tensor([n], dtype=torch.int32, device=dev)
+    keep, num = _chunked_nms(d, cnt, thresh, "axis_aligned", "cpu", eps)
+    k = int(num[0].item())
+    return order[keep[0, :k].cpu().numpy()].tolist()
+
+
+def _nms_tensor(boxes, scores, pre_max_size, post_max_size, thresh, eps):
+    dev = _dev()
+    scores, boxes = scores.to(dev).float(), boxes.to(dev).float()
+    if pre_max_size is not None and pre_max_size > 0:
+        scores, idx = torch.topk(scores, min(pre_max_size, scores.shape[0]))
+    else:
+        scores, idx = torch.sort(scores, descending=True)
+    d = torch.cat([boxes[idx], scores[:, None]], 1).unsqueeze(0).contiguous()
+    cnt = torch.tensor([d.shape[1]], dtype=torch.int32, device=dev)
+    keep, num = _chunked_nms(d, cnt, thresh, "axis_aligned", "cpu", eps,
+                             post_max_size if post_max_size and post_max_size > 0 else 0)
+    return idx[keep[0, :int(num[0].item())].long()]

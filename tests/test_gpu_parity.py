@@ -1,0 +1,370 @@
+"""-m gpu parity tests: HIP path (through the C ABI) vs the CPU oracle and the golden fixtures.
+Bit-exact for voxel indices, rulebooks and NMS keep lists; <= 1e-4 relative for features (BASELINE.json)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle as orc  # noqa: E402  (test infrastructure only)
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from second_amd import ops
+    return ops
+
+
+@pytest.fixture(scope="module")
+def syn():
+    from second_amd import synthetic
+    return synthetic
+
+
+# ------------------------------------------------------------------ voxelisation
+def _check_voxelize(ops, clouds, vs, rng_, max_points, max_voxels, cap_mode):
+    from second_amd.synthetic import batch_clouds
+    pts, offs = batch_clouds(clouds)
+    res = ops.voxelize(dev(pts), dev(offs), rng_, vs, max_points, max_voxels, cap_mode, mean_features=pts.shape[1])
+    voff = res["voxel_offsets"].cpu().numpy()
+    for b, c in enumerate(clouds):
+        ref = orc.points_to_voxel(c, vs, rng_, max_points, max_voxels, cap_mode)
+        lo, hi = voff[b], voff[b + 1]
+        assert hi - lo == ref["voxel_num"], (b, hi - lo, ref["voxel_num"])
+        co = res["coordinates"][lo:hi].cpu().numpy()
+        assert (co[:, 0] == b).all()
+        np.testing.assert_array_equal(co[:, 1:], ref["coordinates"])
+        np.testing.assert_array_equal(res["num_points_per_voxel"][lo:hi].cpu().numpy(), ref["num_points_per_voxel"])
+        np.testing.assert_array_equal(res["voxels"][lo:hi].cpu().numpy(), ref["voxels"])
+        if ref["voxel_num"]:
+            mean = orc.simple_voxel_mean(ref["voxels"], ref["num_points_per_voxel"], c.shape[1])
+            np.testing.assert_allclose(res["mean"][lo:hi].cpu().numpy(), mean, rtol=1e-6, atol=1e-7)
+    return res
+
+
+@pytest.mark.parametrize("tag", ["kitti", "coarse_cap"])
+@pytest.mark.parametrize("cap_mode", ["break", "continue"])
+def test_voxelize_golden_clouds(ops, golden, tag, cap_mode):
+    g = golden("voxel_coords")
+    pts, vs, rng_, cap = g[f"{tag}_points"], g[f"{tag}_voxel_size"], g[f"{tag}_range"], int(g[f"{tag}_cap"])
+    res = _check_voxelize(ops, [pts], vs, rng_, 5, cap, cap_mode)
+    if cap_mode == "break":  # fixture produced by the reference's own loop (simplevis.py:8-60)
+        np.testing.assert_array_equal(res["coordinates"][:, 1:].cpu().numpy(), g[f"{tag}_coors"])
+
+
+def test_voxelize_batched_ragged_and_edge_cases(ops, golden, syn):
+    g = golden("voxel_coords")
+    vs, rng_ = g["coarse_cap_voxel_size"], g["coarse_cap_range"]
+    p = g["coarse_cap_points"]
+    empty = np.zeros((0, 4), np.float32)
+    outside = p[:50] + 1000.0
+    one = p[5:6]
+    nan = p[:20].copy()
+    nan[3, 0] = np.nan
+    nan[4, 1] = np.inf
+    clouds = [p[:700], empty, outside, one, p[700:], nan]
+    for cap_mode in ("break", "continue"):
+        _check_voxelize(ops, clouds, vs, rng_, 3, 120, cap_mode)   # cap hit in some clouds
+        _check_voxelize(ops, clouds, vs, rng_, 1, 100000, cap_mode)  # max_points 1, cap never hit
+    # many points in few voxels: the atomicMin cascade must keep the first max_points arrivals in order
+    rs = np.random.default_rng(0)
+    dense = np.concatenate([rs.uniform([0, -8, -3], [1.2, -6.8, -2], (5000, 3)), rs.uniform(0, 1, (5000, 1))], 1)
+    _check_voxelize(ops, [dense.astype(np.float32)], vs, rng_, 60, 1000, "break")
+
+
+def test_voxelize_car_fhd_batch8(ops, syn):
+    clouds = [syn.syn_kitti_cloud(s) for s in range(8)]
+    res = _check_voxelize(ops, clouds, syn.CAR_FHD_VOXEL, syn.CAR_FHD_RANGE, 5, 40000, "break")
+    assert res["voxel_num"] == 8 * 16000
+    # size-independent properties: one voxel per distinct cell, every stored point lies in its voxel
+    co = res["coordinates"].long()
+    lin = ((co[:, 0] * 41 + co[:, 1]) * 1600 + co[:, 2]) * 1408 + co[:, 3]
+    assert torch.unique(lin).numel() == lin.numel()
+    v = res["voxels"][:, 0, :3]
+    lo = torch.tensor(syn.CAR_FHD_RANGE[:3], device="cuda")
+    cell = torch.floor((v - lo) / torch.tensor(syn.CAR_FHD_VOXEL, device="cuda")).long()
+    assert (cell[:, 0] == co[:, 3]).all() and (cell[:, 1] == co[:, 2]).all() and (cell[:, 2] == co[:, 1]).all()
+
+
+# ------------------------------------------------------------------ rulebooks
+def _random_indices(rng, batch, shape, n):
+    idx = []
+    for b in range(batch):
+        lin = rng.choice(int(np.prod(shape)), size=n, replace=False)
+        z, y, x = np.unravel_index(lin, shape)
+        idx.append(np.stack([np.full_like(z, b), z, y, x], 1))
+    idx = np.concatenate(idx).astype(np.int32)
+    rng.shuffle(idx)
+    return idx
+
+
+def _tables_from_pairs(pairs, pair_num, n_in, n_out):
+    K = pairs.shape[0]
+    nbr_out = -np.ones((n_out, K), np.int32)
+    nbr_in = -np.ones((n_in, K), np.int32)
+    for k in range(K):
+        i, o = pairs[k, 0, :pair_num[k]], pairs[k, 1, :pair_num[k]]
+        nbr_out[o, k] = i
+        nbr_in[i, k] = o
+    return nbr_out, nbr_in
+
+
+@pytest.mark.parametrize("ksize", [3, (3, 1, 1), (1, 3, 3), 5])
+def test_rulebook_subm_bit_exact(ops, ksize):
+    rng = np.random.default_rng(0)
+    shape = (9, 20, 17)
+    idx = _random_indices(rng, 3, shape, 400)
+    rb = ops.rulebook_subm(dev(idx), 3, shape, ksize, 1, want_pairs=True)
+    _, pairs, pair_num = orc.rulebook_subm(idx, 3, shape, ksize)
+    np.testing.assert_array_equal(rb["pair_num"].cpu().numpy(), pair_num)
+    np.testing.assert_array_equal(rb["pairs"].cpu().numpy(), pairs)
+    nbr_out, _ = _tables_from_pairs(pairs, pair_num, len(idx), len(idx))
+    np.testing.assert_array_equal(rb["nbr_out"].cpu().numpy(), nbr_out)
+
+
+@pytest.mark.parametrize("ksize,stride,padding", [
+    (3, 2, 1), (3, 2, (0, 1, 1)), ((3, 1, 1), (2, 1, 1), 0), (3, 1, 0), (2, 2, 0), (3, 1, 1), (3, 3, 1)])
+def test_rulebook_conv_bit_exact(ops, ksize, stride, padding):
+    rng = np.random.default_rng(1)
+    shape = (11, 24, 19)
+    idx = _random_indices(rng, 2, shape, 500)
+    rb = ops.rulebook_conv(dev(idx), 2, shape, ksize, stride, padding, 1, want_pairs=True)
+    out_idx, pairs, pair_num, out_shape = orc.rulebook_conv(idx, 2, shape, ksize, stride, padding)
+    assert rb["out_shape"] == out_shape.tolist()
+    assert rb["num_out"] == len(out_idx)
+    np.testing.assert_array_equal(rb["out_indices"].cpu().numpy(), out_idx)
+    np.testing.assert_array_equal(rb["pair_num"].cpu().numpy(), pair_num)
+    np.testing.assert_array_equal(rb["pairs"].cpu().numpy(), pairs)
+    nbr_out, nbr_in = _tables_from_pairs(pairs, pair_num, len(idx), len(out_idx))
+    np.testing.assert_array_equal(rb["nbr_out"].cpu().numpy(), nbr_out)
+    np.testing.assert_array_equal(rb["nbr_in"].cpu().numpy(), nbr_in)
+
+
+def test_rulebook_empty_and_single(ops):
+    e = torch.zeros((0, 4), dtype=torch.int32, device="cuda")
+    rb = ops.rulebook_subm(e, 1, (5, 5, 5), 3, 1, want_pairs=True)
+    assert rb["pair_num"].sum().item() == 0
+    rb = ops.rulebook_conv(e, 1, (5, 5, 5), 3, 2, 1, 1, want_pairs=True)
+    assert rb["num_out"] == 0 and rb["pair_num"].sum().item() == 0
+    one = dev(np.array([[0, 1, 1, 1]], np.int32))
+    rb = ops.rulebook_conv(one, 1, (5, 5, 5), 3, 2, 1, 1, want_pairs=True)
+    assert rb["num_out"] == 8
+    assert rb["out_indices"][0].tolist() == [0, 1, 1, 1] and rb["out_indices"][-1].tolist() == [0, 0, 0, 0]
+
+
+def test_rulebook_car_fhd_stack(ops, syn):
+    """The four SubM + four strided rulebooks of SpMiddleFHD (middle.py:146-189) on a real-size frame pair."""
+    clouds = [syn.syn_kitti_cloud(s) for s in range(2)]
+    coors = []
+    for b, c in enumerate(clouds):
+        r = orc.points_to_voxel(c, syn.CAR_FHD_VOXEL, syn.CAR_FHD_RANGE, 5, 40000)
+        coors.append(np.concatenate([np.full((r["voxel_num"], 1), b, np.int32), r["coordinates"]], 1))
+    idx = np.concatenate(coors).astype(np.int32)
+    shape = [41, 1600, 1408]
+    for ks, st, pd in ((3, 2, 1), (3, 2, 1), (3, 2, (0, 1, 1)), ((3, 1, 1), (2, 1, 1), 0)):
+        rb = ops.rulebook_subm(dev(idx), 2, shape, 3, 1, want_pairs=True)
+        _, pairs, pair_num = orc.rulebook_subm(idx, 2, shape, 3)
+        np.testing.assert_array_equal(rb["pair_num"].cpu().numpy(), pair_num)
+        np.testing.assert_array_equal(rb["pairs"].cpu().numpy(), pairs)
+        rb = ops.rulebook_conv(dev(idx), 2, shape, ks, st, pd, 1, want_pairs=True)
+        out_idx, pairs, pair_num, out_shape = orc.rulebook_conv(idx, 2, shape, ks, st, pd)
+        np.testing.assert_array_equal(rb["out_indices"].cpu().numpy(), out_idx)
+        np.testing.assert_array_equal(rb["pairs"].cpu().numpy(), pairs)
+        idx, shape = out_idx, out_shape.tolist()
+    assert shape == [2, 200, 176]
+
+
+# ------------------------------------------------------------------ indice_conv
+CONV_SHAPES = [(4, 16), (16, 16), (16, 32), (32, 32), (32, 64), (64, 64), (5, 7), (64, 128)]
+
+
+def _conv_case(rng, cin, cout, subm):
+    shape = (8, 30, 28)
+    idx = _random_indices(rng, 2, shape, 900)
+    if subm:
+        _, pairs, pair_num = orc.rulebook_subm(idx, 2, shape, 3)
+        n_out = len(idx)
+    else:
+        out_idx, pairs, pair_num, _ = orc.rulebook_conv(idx, 2, shape, 3, 2, 1)
+        n_out = len(out_idx)
+    feat = rng.standard_normal((len(idx), cin)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, 3, cin, cout)) / np.sqrt(27 * cin)).astype(np.float32)
+    nbr_out, nbr_in = _tables_from_pairs(pairs, pair_num, len(idx), n_out)
+    return feat, w, pairs, pair_num, nbr_out, nbr_in, n_out
+
+
+@pytest.mark.parametrize("cin,cout", CONV_SHAPES)
+@pytest.mark.parametrize("subm", [True, False])
+def test_indice_conv_fp32(ops, cin, cout, subm):
+    rng = np.random.default_rng(cin * 131 + cout)
+    feat, w, pairs, pair_num, nbr_out, _, n_out = _conv_case(rng, cin, cout, subm)
+    ref = orc.indice_conv(feat, w, pairs, pair_num, n_out, acc64=True)
+    out = ops.indice_conv(dev(feat), dev(w), dev(nbr_out), n_out).cpu().numpy()
+    np.testing.assert_allclose(out, ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("cin,cout", CONV_SHAPES)
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_indice_conv_half_mfma(ops, cin, cout, dtype):
+    """bf16/f16 inputs, fp32 accumulate: vs the fp32 oracle on the SAME rounded inputs, <= 1e-4 relative."""
+    rng = np.random.default_rng(cin * 17 + cout)
+    feat, w, pairs, pair_num, nbr_out, _, n_out = _conv_case(rng, cin, cout, True)
+    f_t, w_t = dev(feat, dtype), dev(w, dtype)
+    ref = orc.indice_conv(f_t.float().cpu().numpy(), w_t.float().cpu().numpy(), pairs, pair_num, n_out, acc64=True)
+    packed = ops.pack_weight(w_t)
+    assert (packed is not None) == (cin % 16 == 0)
+    scale = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+    shift = rng.uniform(-0.2, 0.2, cout).astype(np.float32)
+    out32 = ops.indice_conv(f_t, w_t, dev(nbr_out), n_out, packed=packed, out_dtype=torch.float32).cpu().numpy()
+    np.testing.assert_allclose(out32, ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max())
+    # generic path on the same inputs must agree too (cross-check of the MFMA fragment layouts)
+    gen = ops.indice_conv(f_t, w_t, dev(nbr_out), n_out, packed=None, out_dtype=torch.float32).cpu().numpy()
+    np.testing.assert_allclose(out32, gen, rtol=1e-4, atol=1e-4 * np.abs(ref).max())
+    # fused epilogue + low-precision store: within one rounding of the fp32 result
+    fused = ops.indice_conv(f_t, w_t, dev(nbr_out), n_out, packed=packed, scale=dev(scale), shift=dev(shift), relu=True)
+    assert fused.dtype == dtype
+    ref_f = torch.from_numpy(np.maximum(ref * scale + shift, 0)).to(dtype).float().numpy()
+    tol = 2 ** -7 if dtype == torch.bfloat16 else 2 ** -10
+    np.testing.assert_allclose(fused.float().cpu().numpy(), ref_f, rtol=tol, atol=tol * np.abs(ref_f).max())
+
+
+def test_indice_conv_asymmetric_identity(ops):
+    """A = one-hot rows, asymmetric B: catches transposed MFMA operand / output layouts."""
+    cin = cout = 64
+    n = 70
+    nbr = -np.ones((n, 27), np.int32)
+    nbr[:, 13] = np.arange(n)
+    feat = np.zeros((n, cin), np.float32)
+    feat[np.arange(n), np.arange(n) % cin] = 1.0
+    w = np.zeros((27, cin, cout), np.float32)
+    w[13] = np.arange(cin * cout, dtype=np.float32).reshape(cin, cout) / 64.0  # exact in bf16? use small ints
+    w[13] = (np.arange(cin)[:, None] * 2 + np.arange(cout)[None, :] % 2).astype(np.float32)
+    f_t, w_t = dev(feat, torch.bfloat16), dev(w.reshape(3, 3, 3, cin, cout), torch.bfloat16)
+    out = ops.indice_conv(f_t, w_t, dev(nbr), n, packed=ops.pack_weight(w_t), out_dtype=torch.float32).cpu().numpy()
+    np.testing.assert_array_equal(out, w[13][np.arange(n) % cin])
+
+
+@pytest.mark.parametrize("subm", [True, False])
+def test_indice_conv_backward(ops, subm):
+    rng = np.random.default_rng(5)
+    feat, w, pairs, pair_num, nbr_out, nbr_in, n_out = _conv_case(rng, 16, 32, subm)
+    dout = rng.standard_normal((n_out, 32)).astype(np.float32)
+    dfeat_ref, dw_ref = orc.indice_conv_backward(feat, w, pairs, pair_num, dout)
+    dfeat, dw = ops.indice_conv_backward(dev(feat), dev(w), dev(nbr_out), None if subm else dev(nbr_in), dev(dout))
+    np.testing.assert_allclose(dfeat.cpu().numpy(), dfeat_ref, rtol=1e-4, atol=1e-4 * np.abs(dfeat_ref).max())
+    np.testing.assert_allclose(dw.cpu().numpy(), dw_ref, rtol=1e-4, atol=1e-4 * np.abs(dw_ref).max())
+
+
+def test_indice_conv_car_fhd_layer(ops, syn):
+    """Full-size subm2-like layer (64->64) on a synthetic frame: bf16 MFMA vs oracle."""
+    c = syn.syn_kitti_cloud(0)
+    r = orc.points_to_voxel(c, syn.CAR_FHD_VOXEL, syn.CAR_FHD_RANGE, 5, 40000)
+    idx = np.concatenate([np.zeros((r["voxel_num"], 1), np.int32), r["coordinates"]], 1)
+    _, pairs, pair_num = orc.rulebook_subm(idx, 1, [41, 1600, 1408], 3)
+    rng = np.random.default_rng(0)
+    feat = rng.standard_normal((len(idx), 64)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, 3, 64, 64)) / 40).astype(np.float32)
+    f_t, w_t = dev(feat, torch.bfloat16), dev(w, torch.bfloat16)
+    rb = ops.rulebook_subm(dev(idx), 1, [41, 1600, 1408], 3)
+    out = ops.indice_conv(f_t, w_t, rb["nbr_out"], len(idx), packed=ops.pack_weight(w_t), out_dtype=torch.float32)
+    ref = orc.indice_conv(f_t.float().cpu().numpy(), w_t.float().cpu().numpy(), pairs, pair_num, len(idx))
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max())
+
+
+# ------------------------------------------------------------------ scatters
+def test_sparse_to_dense(ops):
+    rng = np.random.default_rng(7)
+    shape = (2, 20, 18)
+    idx = _random_indices(rng, 3, shape, 100)
+    feat = rng.standard_normal((len(idx), 64)).astype(np.float32)
+    ref = orc.sparse_to_dense(feat, idx, 3, shape)
+    out = ops.sparse_to_dense(dev(feat), dev(idx), 3, shape)
+    np.testing.assert_array_equal(out.cpu().numpy(), ref)
+    cl = ops.sparse_to_dense(dev(feat, torch.bfloat16), dev(idx), 3, shape, channels_last_2d=True)
+    assert cl.shape == (3, 128, 20, 18) and cl.is_contiguous(memory_format=torch.channels_last)
+    ref_bf = torch.from_numpy(ref).to(torch.bfloat16).view(3, 128, 20, 18)
+    assert torch.equal(cl.cpu(), ref_bf)
+
+
+def test_pillar_scatter_golden(ops, golden):
+    g = golden("torch_modules")
+    b, c, ny, nx = g["ps_out"].shape
+    out = ops.pillar_scatter(dev(g["ps_feats"]), dev(g["ps_coords"]), b, ny, nx)
+    np.testing.assert_array_equal(out.cpu().numpy(), g["ps_out"])
+
+
+# ------------------------------------------------------------------ IoU / NMS
+def test_rotate_iou_golden(ops, golden):
+    g = golden("rotate_iou")
+    for crit in (-1, 0, 1, 2):
+        out = ops.rotate_iou(dev(g["boxes"]), dev(g["qboxes"]), crit).cpu().numpy()
+        np.testing.assert_allclose(out, g[f"iou_c{crit}"], atol=2e-5, rtol=1e-5)
+    sp = np.array([ops.rotate_iou(dev(g["special_a"][i:i + 1]), dev(g["special_b"][i:i + 1]))[0, 0].item()
+                   for i in range(len(g["special_a"]))])
+    np.testing.assert_allclose(sp, g["special_iou"], atol=2e-5)
+
+
+def _nms_call(ops, dets_sorted_list, thr, kind, semantics, eps=1.0, post_max=0):
+    b = len(dets_sorted_list)
+    max_n = max(1, max(len(d) for d in dets_sorted_list))
+    stride = dets_sorted_list[0].shape[1]
+    buf = np.zeros((b, max_n, stride), np.float32)
+    for i, d in enumerate(dets_sorted_list):
+        buf[i, :len(d)] = d
+    counts = np.array([len(d) for d in dets_sorted_list], np.int32)
+    keep, num = ops.nms_sorted(dev(buf), dev(counts), thr, kind, semantics, eps, post_max)
+    keep, num = keep.cpu().numpy(), num.cpu().numpy()
+    return [keep[i, :num[i]] for i in range(b)]
+
+
+@pytest.mark.parametrize("thr", [0.01, 0.3])
+def test_rotate_nms_golden_batched(ops, golden, thr):
+    g = golden("rotate_nms")
+    tags = ["a", "b", "c", "d"]
+    orders = [g[f"dets_{t}"][:, 5].argsort()[::-1] for t in tags]
+    sorted_dets = [g[f"dets_{t}"][o] for t, o in zip(tags, orders)]
+    for sem in ("numba", "cpu"):
+        keeps = _nms_call(ops, sorted_dets, thr, "rotate", sem)
+        for t, o, k in zip(tags, orders, keeps):
+            np.testing.assert_array_equal(o[k], g[f"keep_{t}_{thr}"])
+
+
+def test_rotate_nms_1000_boxes_vs_oracle(ops):
+    rng = np.random.default_rng(11)
+    n = 1000
+    dets = np.concatenate([rng.uniform(0, 70, (n, 1)), rng.uniform(-40, 40, (n, 1)), rng.uniform(1.4, 1.8, (n, 1)),
+                           rng.uniform(3.5, 4.3, (n, 1)), rng.uniform(-3.2, 3.2, (n, 1)),
+                           np.sort(rng.uniform(0.3, 1, (n, 1)), 0)[::-1]], 1).astype(np.float32)
+    for sem in ("numba", "cpu"):
+        for post in (0, 100):
+            k = _nms_call(ops, [dets, dets[:333]], 0.01, "rotate", sem, post_max=post)
+            r0 = orc.rotate_nms_sorted(dets, 0.01, sem)
+            r1 = orc.rotate_nms_sorted(dets[:333], 0.01, sem)
+            np.testing.assert_array_equal(k[0], r0[:post] if post else r0)
+            np.testing.assert_array_equal(k[1], r1[:post] if post else r1)
+
+
+@pytest.mark.parametrize("thr", [0.1, 0.5])
+def test_axis_aligned_nms_golden(ops, golden, thr):
+    g = golden("nms_axis_aligned")
+    dets = g["dets"]
+    order = dets[:, 4].argsort()[::-1]
+    k = _nms_call(ops, [dets[order]], thr, "axis_aligned", "numba")[0]
+    np.testing.assert_array_equal(order[k], g[f"keep_gpu_{thr}"])
+    k = _nms_call(ops, [dets[order]], thr, "axis_aligned", "cpu", eps=0.0)[0]
+    np.testing.assert_array_equal(order[k], g[f"keep_jit_eps0_{thr}"])
+    k = _nms_call(ops, [dets[order]], thr, "axis_aligned", "cpu", eps=1.0)[0]
+    np.testing.assert_array_equal(order[k], g[f"keep_jit_eps1_{thr}"])
+
+
+def test_cpu_tensors_are_rejected(ops):
+    from second_amd.runtime import SecondHipError
+    with pytest.raises(SecondHipError):
+        ops.rulebook_subm(torch.zeros((1, 4), dtype=torch.int32), 1, (3, 3, 3))
