@@ -1,0 +1,258 @@
+#!/usr/bin/env python3
+"""Headline benchmark: frames/s of the car.fhd VoxelNet forward (BASELINE.json configs[1]).
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+One *step* = one pass of the whole hot path over one batch of 8 synthetic KITTI clouds that are already
+resident in HBM: points_to_voxel (+SimpleVoxel mean) -> 14 sparse conv layers (rulebooks + fused
+indice_conv) -> dense -> RPNV2 (bf16, MIOpen) -> decode / top-k / rotated NMS, detections left on the device.
+Per-frame data parallel: every rank runs its own batch, no data-path collective ("weak" scaling).
+
+Prints ONE JSON line on rank 0 with, besides the contract fields,
+  roofline     -- the SubMConv3d 64->64 gather-GEMM-scatter kernel (the kernel BASELINE.json's metric names):
+                  algorithmic bytes per launch / mean launch duration measured with HIP events on the launch
+                  stream inside the timed region, against the 8 TB/s HBM peak;
+  cpu_baseline -- the same forward on the host cores through the CPU oracle (kind "port"), rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "second.pytorch_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured-achievable)
+BATCH = 8
+
+
+class ConvTimer:
+    """HIP-event pairs around selected sec_indice_conv_fwd launches (same stream as the launch)."""
+
+    def __init__(self, select):
+        self.select, self.records, self.enabled = select, [], False
+
+    def begin(self, meta):
+        if not self.enabled or not self.select(meta):
+            return None
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(torch.cuda.current_stream())
+        return (e0, e1, meta)
+
+    def end(self, token):
+        token[1].record(torch.cuda.current_stream())
+        self.records.append(token)
+
+
+def build_inputs(rank, device):
+    from second_amd import synthetic as syn
+    clouds = [syn.syn_kitti_cloud(rank * BATCH + s) for s in range(BATCH)]
+    pts, offs = syn.batch_clouds(clouds)
+    return clouds, torch.from_numpy(pts).to(device), torch.from_numpy(offs).to(device)
+
+
+def build_detector(device, dtype):
+    from second_amd.models import SecondDetector, CAR_FHD
+    torch.manual_seed(0)
+    det = SecondDetector(CAR_FHD)
+    g = torch.Generator().manual_seed(1)
+    for m in det.modules():  # BN in eval mode with non-trivial statistics so that folding is exercised
+        if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+            m.running_mean.copy_(torch.empty_like(m.running_mean).uniform_(-0.1, 0.1, generator=g))
+            m.running_var.copy_(torch.empty_like(m.running_var).uniform_(0.5, 1.5, generator=g))
+    det.eval()
+    cpu_state = {k: v.clone() for k, v in det.state_dict().items()}
+    det = det.to(device)
+    if dtype != torch.float32:
+        det.prepare_inference(dtype)
+    return det, cpu_state
+
+
+# ------------------------------------------------------------------------------------------ CPU baseline
+def cpu_baseline(cpu_state, clouds, budget_s=20.0):
+    """The same forward on the host through the oracle ("port"): single-threaded oracle for voxelise /
+    rulebook / indice_conv / NMS (like the reference's worker-side C++), torch CPU (all cores) for the RPN."""
+    from oracle import oracle as orc
+    from second_amd.models import SecondDetector, CAR_FHD, decode_boxes
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    det = SecondDetector(CAR_FHD)
+    det.load_state_dict(cpu_state)
+    det.eval()
+    cfg = CAR_FHD
+    seq = list(det.middle_feature_extractor.middle_conv.children())
+    anchors = det.anchors
+
+    def one(cloud):
+        v = orc.points_to_voxel(cloud, cfg["voxel_size"], cfg["point_cloud_range"], cfg["max_points_per_voxel"], cfg["max_voxels"])
+        feat = orc.simple_voxel_mean(v["voxels"], v["num_points_per_voxel"], 4)
+        idx = np.concatenate([np.zeros((v["voxel_num"], 1), np.int32), v["coordinates"]], 1)
+        shape = det.middle_feature_extractor.sparse_shape
+        cache = {}
+        i = 0
+        while i < len(seq):
+            conv, bn = seq[i], seq[i + 1]
+            if conv.subm:
+                if conv.indice_key not in cache:
+                    cache[conv.indice_key] = orc.rulebook_subm(idx, 1, shape, conv.kernel_size)
+                out_idx, pairs, num = cache[conv.indice_key]
+                n_out = len(idx)
+            else:
+                out_idx, pairs, num, oshape = orc.rulebook_conv(idx, 1, shape, conv.kernel_size, conv.stride, conv.padding)
+                n_out = len(out_idx)
+            y = orc.indice_conv(feat, conv.weight.detach().numpy(), pairs, num, n_out, acc64=False)
+            scale = (bn.weight / torch.sqrt(bn.running_var + bn.eps)).detach().numpy()
+            shift = (bn.bias - bn.running_mean * torch.from_numpy(scale)).detach().numpy()
+            feat = np.maximum(y * scale + shift, 0).astype(np.float32)
+            if not conv.subm:
+                idx, shape = out_idx, [int(s) for s in oshape]
+            i += 3
+        dense = orc.sparse_to_dense(feat, idx, 1, shape)
+        x = torch.from_numpy(dense).view(1, -1, shape[1], shape[2])
+        with torch.no_grad():
+            preds = det.rpn(x)
+            cls = torch.sigmoid(preds["cls_preds"].reshape(-1))
+            keep = cls >= cfg["nms_score_threshold"]
+            sc, ix = torch.topk(cls[keep], min(cfg["nms_pre_max_size"], int(keep.sum())))
+            sel = torch.nonzero(keep).squeeze(1)[ix]
+            boxes = decode_boxes(preds["box_preds"].reshape(-1, 7)[sel], anchors[sel])
+            dets = torch.cat([boxes[:, [0, 1, 3, 4, 6]], sc[:, None]], 1).numpy()
+        k = orc.rotate_nms_sorted(dets, cfg["nms_iou_threshold"], "cpu")[:cfg["nms_post_max_size"]]
+        return len(k)
+
+    t0 = time.perf_counter()
+    n = 0
+    while n < len(clouds) and (n < 1 or time.perf_counter() - t0 < budget_s):
+        one(clouds[n])
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(n / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{n} synthetic KITTI frame(s) (17k pts, 16k voxels), fp32; oracle (1 thread) for voxelise/"
+                      f"rulebook/indice_conv/NMS + torch CPU ({cores} threads) for the RPN; {dt:.1f} s"}
+
+
+# ------------------------------------------------------------------------------------------ main
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stages", action="store_true", help="also print per-stage timings to stderr")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (use gpurun)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.dtype]
+
+    from second_amd import ops
+    clouds, points, offsets = build_inputs(rank, device)
+    det, cpu_state = build_detector(device, dtype)
+
+    timer = ConvTimer(lambda m: m["cin"] == 64 and m["cout"] == 64 and m["kvol"] == 27 and m["n_in"] == m["n_out"]
+                      and m["n_out"] > 30000)  # the three subm2 layers (64->64 on the 11x400x352 grid)
+    ops.set_conv_profiler(timer)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            out = det.forward_points(points, offsets)
+        barrier()
+        timer.enabled = True
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = det.forward_points(points, offsets)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        timer.enabled = False
+
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # roofline of the SubMConv3d 64->64 kernel: algorithmic bytes / mean measured launch time
+    roof = None
+    if timer.records:
+        ms = [e0.elapsed_time(e1) for e0, e1, _ in timer.records]
+        meta = timer.records[0][2]
+        s = 2 if meta["dtype"] != torch.float32 else 4
+        pairs = int((meta["nbr_out"] >= 0).sum().item())
+        b_alg = s * (pairs * meta["cin"] + meta["n_out"] * meta["cout"]) + 8 * pairs + s * meta["kvol"] * meta["cin"] * meta["cout"]
+        t_mean = float(np.mean(ms)) * 1e-3
+        ach = b_alg / t_mean / 1e9
+        roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                "kernel": "k_conv_mfma<bf16,64,64> (SubMConv3d subm2, batch 8)" if meta["mfma"] else "k_conv_generic",
+                "launch_us": round(t_mean * 1e6, 2), "launches_timed": len(ms), "alg_bytes_per_launch": b_alg,
+                "rows": meta["n_out"], "pairs": pairs, "frac_of_6.29TBs_measured_peak": round(ach / 6290.0, 4)}
+
+    if args.stages and rank == 0:
+        stage_times(det, points, offsets)
+
+    if rank == 0:
+        frames = BATCH * args.steps * world
+        res = {
+            "metric": "frames/sec VoxelNet fwd (car.fhd, ~16k active voxels)", "value": round(frames / elapsed, 2),
+            "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "car.fhd.config VoxelNet forward (voxelise+VFE+SpMiddleFHD+RPNV2+rotated NMS), "
+                                   "inference, batch=8 synthetic KITTI clouds/GPU (17000 pts, 16000 voxels each), "
+                                   "random-init weights, inputs resident in HBM",
+                       "frames_per_step_per_gpu": BATCH, "parallelism": f"frame-dp{world}"},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(cpu_state, clouds)
+        det_count = int(out["valid"].sum().item())
+        res["detections_last_step"] = det_count
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def stage_times(det, points, offsets, iters=20):
+    """The reference's own stage boundaries (voxelnet.py:325-336,371-374), sync-bracketed like its timers."""
+    import torch
+    bs = offsets.numel() - 1
+
+    def timeit(fn):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            r = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / iters * 1e3, r
+    with torch.no_grad():
+        t_vox, vox = timeit(lambda: det.voxel_generator.generate_device(points, offsets, mean_features=4))
+        dt = det._infer_dtype
+        feats = vox["mean"].to(dt) if dt is not None else vox["mean"]
+        t_mid, spatial = timeit(lambda: det.middle_feature_extractor(feats, vox["coordinates"], bs, channels_last=dt is not None))
+        t_rpn, preds = timeit(lambda: det.rpn(spatial))
+        t_pred, _ = timeit(lambda: det.predict_device(preds, bs))
+    print(json.dumps({"stage_ms_per_batch8": {"voxelize+vfe": round(t_vox, 3), "middle": round(t_mid, 3),
+                                              "rpn": round(t_rpn, 3), "predict": round(t_pred, 3)}}), file=sys.stderr)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,338 @@
+"""Host-side mirror of the reference's VoxelNet forward for the configurations BASELINE.json names.
+
+The GPU box has no /root/reference, so bench.py / smoke() / -m gpu tests cannot import the reference's
+model code; this module restates the network *topology* (never the code) with the same module names,
+parameter shapes and state_dict keys as second/pytorch/models/{voxelnet,middle,rpn,voxel_encoder}.py, so a
+reference ``.tckpt`` loads into it and the unmodified reference model (running over our drop-in ``spconv``)
+produces the same numbers (tests/test_dropin_reference.py checks that in the build container).
+
+    SimpleVoxel      voxel_encoder.py:207-225   (fused into the voxeliser's epilogue on the native path)
+    SpMiddleFHD      middle.py:111-210          (spconv.SubMConv3d / SparseConv3d stack)
+    RPNV2            rpn.py:202-420,468-497     (dense 2-D convs: torch/MIOpen bf16 channels-last)
+    predict          voxelnet.py:377-645        (decode -> score filter -> top-k -> rotated NMS -> direction fix)
+"""
+import math
+
+import numpy as np
+import torch
+from torch import nn
+import torch.nn.functional as F
+
+import spconv
+from . import ops
+
+
+# ------------------------------------------------------------------------------------------ config
+CAR_FHD = dict(
+    name="car.fhd",
+    point_cloud_range=[0, -40, -3, 70.4, 40, 1], voxel_size=[0.05, 0.05, 0.1], max_points_per_voxel=5,
+    max_voxels=40000, num_point_features=4,
+    middle="SpMiddleFHD", middle_in=4,
+    rpn=dict(layer_nums=[5], layer_strides=[1], num_filters=[128], upsample_strides=[1],
+             num_upsample_filters=[128], num_input_features=128),
+    downsample_factor=8,
+    anchor_sizes=[[1.6, 3.9, 1.56]], anchor_ranges=[[0, -40.0, -1.00, 70.4, 40.0, -1.00]], rotations=[0, 1.57],
+    num_class=1, num_direction_bins=2, direction_offset=0.0, direction_limit_offset=1.0,
+    nms_score_threshold=0.3, nms_pre_max_size=1000, nms_post_max_size=100, nms_iou_threshold=0.01,
+    use_rotate_nms=True, post_center_range=[0, -40, -2.2, 70.4, 40, 0.8],
+)  # second/configs/car.fhd.config
+
+
+def grid_size_of(cfg):
+    r = np.array(cfg["point_cloud_range"], np.float32)
+    v = np.array(cfg["voxel_size"], np.float32)
+    return np.round((r[3:] - r[:3]) / v).astype(np.int64)  # (x, y, z)
+
+
+def generate_anchors(cfg, feature_map_size):
+    """[A*D*H*W, 7] anchors ordered (anchor, z, y, x) like target_assigner.generate_anchors
+    (second/core/target_assigner.py:169-207 over box_np_ops.create_anchors_3d_range :606-638)."""
+    d, h, w = feature_map_size
+    out = []
+    for size, rng in zip(cfg["anchor_sizes"], cfg["anchor_ranges"]):
+        rng = np.array(rng, np.float32)
+        zc = np.linspace(rng[2], rng[5], d, dtype=np.float32)
+        yc = np.linspace(rng[1], rng[4], h, dtype=np.float32)
+        xc = np.linspace(rng[0], rng[3], w, dtype=np.float32)
+        rots = np.array(cfg["rotations"], np.float32)
+        a = np.zeros((len(rots), d, h, w, 7), np.float32)
+        a[..., 0] = xc[None, None, None, :]
+        a[..., 1] = yc[None, None, :, None]
+        a[..., 2] = zc[None, :, None, None]
+        a[..., 3:6] = np.array(size, np.float32)
+        a[..., 6] = rots[:, None, None, None]
+        out.append(a.reshape(-1, 7))
+    return np.concatenate(out, 0)
+
+
+# ------------------------------------------------------------------------------------------ modules
+class SimpleVoxel(nn.Module):
+    def __init__(self, num_input_features=4):
+        super().__init__()
+        self.num_input_features = num_input_features
+
+    def forward(self, features, num_voxels, coors=None):
+        s = features[:, :, :self.num_input_features].sum(dim=1)
+        return (s / num_voxels.type_as(features).view(-1, 1)).contiguous()
+
+
+def _bn1d(c):
+    return nn.BatchNorm1d(c, eps=1e-3, momentum=0.01)
+
+
+def _bn2d(c):
+    return nn.BatchNorm2d(c, eps=1e-3, momentum=0.01)
+
+
+class SpMiddleFHD(nn.Module):
+    """14 sparse conv layers; channel plan 4-16-16-32-32-32-64-...-64; state_dict keys
+    ``middle_conv.<i>.weight`` as in the reference."""
+
+    def __init__(self, output_shape, num_input_features=4):
+        super().__init__()
+        self.sparse_shape = [int(output_shape[1]) + 1, int(output_shape[2]), int(output_shape[3])]
+        sub = lambda i, o, key: spconv.SubMConv3d(i, o, 3, bias=False, indice_key=key)
+        down = lambda i, o, k, s, p: spconv.SparseConv3d(i, o, k, s, padding=p, bias=False)
+        layers = []
+
+        def add(conv, c):
+            layers.extend([conv, _bn1d(c), nn.ReLU()])
+        add(sub(num_input_features, 16, "subm0"), 16)
+        add(sub(16, 16, "subm0"), 16)
+        add(down(16, 32, 3, 2, 1), 32)
+        add(sub(32, 32, "subm1"), 32)
+        add(sub(32, 32, "subm1"), 32)
+        add(down(32, 64, 3, 2, 1), 64)
+        for _ in range(3):
+            add(sub(64, 64, "subm2"), 64)
+        add(down(64, 64, 3, 2, [0, 1, 1]), 64)
+        for _ in range(3):
+            add(sub(64, 64, "subm3"), 64)
+        add(down(64, 64, (3, 1, 1), (2, 1, 1), 0), 64)
+        self.middle_conv = spconv.SparseSequential(*layers)
+
+    def forward(self, voxel_features, coors, batch_size, channels_last=False):
+        x = spconv.SparseConvTensor(voxel_features, coors.int(), self.sparse_shape, batch_size)
+        x = self.middle_conv(x)
+        if channels_last:
+            return x.dense_channels_last_2d()
+        d = x.dense()
+        n, c, dd, h, w = d.shape
+        return d.view(n, c * dd, h, w)
+
+
+class RPNV2(nn.Module):
+    """ZeroPad+Conv3x3+BN+ReLU, layer_num x (Conv3x3+BN+ReLU) per block; deconv (or strided conv) per
+    block; three 1x1 heads.  Keys: blocks.<b>.<i>, deblocks.<b>.<i>, conv_cls, conv_box, conv_dir_cls."""
+
+    def __init__(self, num_class=1, layer_nums=(5,), layer_strides=(1,), num_filters=(128,), upsample_strides=(1,),
+                 num_upsample_filters=(128,), num_input_features=128, num_anchor_per_loc=2, box_code_size=7,
+                 num_direction_bins=2, use_direction_classifier=True):
+        super().__init__()
+        self._num_anchor_per_loc, self._num_class = num_anchor_per_loc, num_class
+        self._box_code_size, self._num_direction_bins = box_code_size, num_direction_bins
+        self._use_direction_classifier = use_direction_classifier
+        self._upsample_start_idx = len(layer_nums) - len(upsample_strides)
+        blocks, deblocks = [], []
+        cin = num_input_features
+        for i, n in enumerate(layer_nums):
+            planes = num_filters[i]
+            mods = [nn.ZeroPad2d(1), nn.Conv2d(cin, planes, 3, stride=layer_strides[i], bias=False), _bn2d(planes), nn.ReLU()]
+            for _ in range(n):
+                mods += [nn.Conv2d(planes, planes, 3, padding=1, bias=False), _bn2d(planes), nn.ReLU()]
+            blocks.append(nn.Sequential(*mods))
+            if i - self._upsample_start_idx >= 0:
+                s = upsample_strides[i - self._upsample_start_idx]
+                cup = num_upsample_filters[i - self._upsample_start_idx]
+                if s >= 1:
+                    s = int(round(s))
+                    up = nn.ConvTranspose2d(planes, cup, s, stride=s, bias=False)
+                else:
+                    s = int(round(1 / s))
+                    up = nn.Conv2d(planes, cup, s, stride=s, bias=False)
+                deblocks.append(nn.Sequential(up, _bn2d(cup), nn.ReLU()))
+            cin = planes
+        self.blocks, self.deblocks = nn.ModuleList(blocks), nn.ModuleList(deblocks)
+        final = sum(num_upsample_filters) if len(num_upsample_filters) else cin
+        self.conv_cls = nn.Conv2d(final, num_anchor_per_loc * num_class, 1)
+        self.conv_box = nn.Conv2d(final, num_anchor_per_loc * box_code_size, 1)
+        if use_direction_classifier:
+            self.conv_dir_cls = nn.Conv2d(final, num_anchor_per_loc * num_direction_bins, 1)
+
+    def forward(self, x):
+        ups = []
+        for i, blk in enumerate(self.blocks):
+            x = blk(x)
+            if i - self._upsample_start_idx >= 0:
+                ups.append(self.deblocks[i - self._upsample_start_idx](x))
+        if ups:
+            x = torch.cat(ups, dim=1) if len(ups) > 1 else ups[0]
+        a = self._num_anchor_per_loc
+
+        def head(conv, code):
+            y = conv(x)
+            h, w = y.shape[2:]
+            return y.view(-1, a, code, h, w).permute(0, 1, 3, 4, 2).contiguous()
+        ret = {"box_preds": head(self.conv_box, self._box_code_size), "cls_preds": head(self.conv_cls, self._num_class)}
+        if self._use_direction_classifier:
+            ret["dir_cls_preds"] = head(self.conv_dir_cls, self._num_direction_bins)
+        return ret
+
+
+def fold_conv_bn_(seq):
+    """In place: fold every (Conv2d|ConvTranspose2d, BatchNorm2d) pair of an nn.Sequential (eval mode)."""
+    mods = list(seq.children())
+    out = []
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.BatchNorm2d):
+            bn = mods[i + 1]
+            scale = bn.weight.float() * torch.rsqrt(bn.running_var.float() + bn.eps)
+            shift = bn.bias.float() - bn.running_mean.float() * scale
+            w = m.weight.float()
+            if isinstance(m, nn.ConvTranspose2d):
+                w = w * scale.view(1, -1, 1, 1)
+            else:
+                w = w * scale.view(-1, 1, 1, 1)
+            b = shift if m.bias is None else m.bias.float() * scale + shift
+            m.weight = nn.Parameter(w.to(m.weight.dtype), requires_grad=False)
+            m.bias = nn.Parameter(b.to(m.weight.dtype), requires_grad=False)
+            out.append(m)
+            i += 2
+        else:
+            out.append(m)
+            i += 1
+    return nn.Sequential(*out)
+
+
+# ------------------------------------------------------------------------------------------ detector
+def limit_period(val, offset, period):
+    return val - torch.floor(val / period + offset) * period
+
+
+class SecondDetector(nn.Module):
+    """VoxelNet mirror.  ``forward(example)`` accepts the reference's example dict
+    (voxels, num_points, coordinates, anchors; voxelnet.py:339-375) and returns the reference's list of
+    prediction dicts; ``forward_points`` is the device-resident fast path (raw clouds in, detections out,
+    no host sync until the caller reads the result)."""
+
+    def __init__(self, cfg=CAR_FHD):
+        super().__init__()
+        self.cfg = cfg
+        gs = grid_size_of(cfg)
+        self.grid_size = gs
+        dense_shape = [1] + gs[::-1].tolist() + [64]
+        self.voxel_feature_extractor = SimpleVoxel(cfg["num_point_features"])
+        self.middle_feature_extractor = SpMiddleFHD(dense_shape, cfg["middle_in"])
+        a_per_loc = len(cfg["rotations"]) * len(cfg["anchor_sizes"])
+        self.rpn = RPNV2(num_class=cfg["num_class"], num_anchor_per_loc=a_per_loc, num_direction_bins=cfg["num_direction_bins"],
+                         **cfg["rpn"])
+        self.register_buffer("global_step", torch.LongTensor(1).zero_())
+        fm = [1, int(gs[1]) // cfg["downsample_factor"], int(gs[0]) // cfg["downsample_factor"]]
+        self.feature_map_size = fm
+        self.register_buffer("anchors", torch.from_numpy(generate_anchors(cfg, fm)), persistent=False)
+        self._infer_dtype = None
+        self.voxel_generator = spconv.utils.VoxelGeneratorV2(cfg["voxel_size"], cfg["point_cloud_range"],
+                                                            cfg["max_points_per_voxel"], cfg["max_voxels"])
+
+    # -- inference preparation: bf16 channels-last RPN with folded BN; sparse stack in bf16 (BN folded at run time)
+    def prepare_inference(self, dtype=torch.bfloat16):
+        self.eval()
+        self.rpn.blocks = nn.ModuleList([fold_conv_bn_(b) for b in self.rpn.blocks])
+        self.rpn.deblocks = nn.ModuleList([fold_conv_bn_(b) for b in self.rpn.deblocks])
+        self.rpn.to(dtype).to(memory_format=torch.channels_last)
+        for m in self.middle_feature_extractor.modules():
+            if isinstance(m, spconv.SparseConvolution):
+                m.weight.data = m.weight.data.to(dtype)
+        self._infer_dtype = dtype
+        return self
+
+    # -- stages ------------------------------------------------------------------------------------
+    def network_forward(self, voxel_features, coors, batch_size):
+        dt = self._infer_dtype
+        if dt is not None:
+            spatial = self.middle_feature_extractor(voxel_features.to(dt), coors, batch_size, channels_last=True)
+        else:
+            spatial = self.middle_feature_extractor(voxel_features, coors, batch_size)
+        return self.rpn(spatial)
+
+    def forward(self, example):
+        voxels, num_points, coors = example["voxels"], example["num_points"], example["coordinates"]
+        batch_size = example["anchors"].shape[0]
+        feats = self.voxel_feature_extractor(voxels, num_points, coors)
+        preds = self.network_forward(feats, coors, batch_size)
+        with torch.no_grad():
+            return self.predict(preds, example["anchors"].view(batch_size, -1, 7))
+
+    def forward_points(self, points, point_offsets):
+        """points [N,4] cuda float32 (clouds concatenated), point_offsets [B+1] cuda int32."""
+        batch_size = point_offsets.numel() - 1
+        vox = self.voxel_generator.generate_device(points, point_offsets, mean_features=self.cfg["num_point_features"])
+        preds = self.network_forward(vox["mean"], vox["coordinates"], batch_size)
+        return self.predict_device(preds, batch_size)
+
+    # -- post-processing -----------------------------------------------------------------------------
+    def _select(self, preds, batch_size, anchors):
+        """score filter + top-k + decode of the selected boxes, all on device, fixed shapes."""
+        cfg = self.cfg
+        cls = preds["cls_preds"].reshape(batch_size, -1).float()            # num_class == 1
+        box = preds["box_preds"].reshape(batch_size, -1, 7)
+        scores = torch.sigmoid(cls)
+        k = min(cfg["nms_pre_max_size"], scores.shape[1])
+        masked = torch.where(scores >= cfg["nms_score_threshold"], scores, torch.full_like(scores, -1.0))
+        top_scores, top_idx = torch.topk(masked, k, dim=1)
+        counts = (top_scores >= cfg["nms_score_threshold"]).sum(1).to(torch.int32)
+        enc = torch.gather(box, 1, top_idx.unsqueeze(-1).expand(-1, -1, 7)).float()
+        anc = anchors[top_idx] if anchors.dim() == 2 else torch.gather(anchors, 1, top_idx.unsqueeze(-1).expand(-1, -1, 7))
+        dec = decode_boxes(enc, anc)
+        if "dir_cls_preds" in preds:
+            d = preds["dir_cls_preds"].reshape(batch_size, -1, cfg["num_direction_bins"])
+            d = torch.gather(d, 1, top_idx.unsqueeze(-1).expand(-1, -1, cfg["num_direction_bins"]))
+            dir_labels = torch.max(d, dim=-1)[1]
+        else:
+            dir_labels = None
+        return dec, top_scores, counts, dir_labels
+
+    def predict_device(self, preds, batch_size, anchors=None):
+        """-> dict of padded device tensors: boxes [B,P,7], scores [B,P], labels [B,P], valid [B,P] (bool)."""
+        cfg = self.cfg
+        anchors = self.anchors if anchors is None else anchors
+        dec, top_scores, counts, dir_labels = self._select(preds, batch_size, anchors)
+        dets = torch.cat([dec[..., [0, 1, 3, 4, 6]], top_scores.unsqueeze(-1)], -1).contiguous()
+        if cfg["use_rotate_nms"]:
+            keep, num_keep = ops.nms_sorted(dets, counts, cfg["nms_iou_threshold"], "rotate", "cpu",
+                                            post_max=cfg["nms_post_max_size"])
+        else:
+            raise NotImplementedError("axis-aligned predict path (nuscenes all.fhd) comes with SURVEY row a19 wiring")
+        p = min(cfg["nms_post_max_size"], keep.shape[1])
+        sel = keep[:, :p].long().clamp_(min=0, max=dets.shape[1] - 1)
+        valid = torch.arange(p, device=keep.device).unsqueeze(0) < num_keep.unsqueeze(1)
+        boxes = torch.gather(dec, 1, sel.unsqueeze(-1).expand(-1, -1, 7))
+        scores = torch.gather(top_scores, 1, sel)
+        if dir_labels is not None:
+            dl = torch.gather(dir_labels, 1, sel)
+            period = 2 * math.pi / cfg["num_direction_bins"]
+            rot = limit_period(boxes[..., 6] - cfg["direction_offset"], cfg["direction_limit_offset"], period)
+            boxes[..., 6] = rot + cfg["direction_offset"] + period * dl.to(boxes.dtype)
+        r = torch.tensor(cfg["post_center_range"], device=boxes.device, dtype=boxes.dtype)
+        valid = valid & (boxes[..., :3] >= r[:3]).all(-1) & (boxes[..., :3] <= r[3:]).all(-1)
+        return {"boxes": boxes, "scores": scores, "labels": torch.zeros_like(sel), "valid": valid}
+
+    def predict(self, preds, anchors):
+        out = self.predict_device(preds, anchors.shape[0], anchors)
+        res = []
+        for b in range(anchors.shape[0]):
+            m = out["valid"][b]
+            res.append({"box3d_lidar": out["boxes"][b][m], "scores": out["scores"][b][m],
+                        "label_preds": out["labels"][b][m], "metadata": None})
+        return res
+
+
+def decode_boxes(enc, anc):
+    """GroundBox3dCoder.decode (second_box_decode, second/pytorch/core/box_torch_ops.py:56-101)."""
+    xa, ya, za, wa, la, ha, ra = anc.unbind(-1)
+    xt, yt, zt, wt, lt, ht, rt = enc.unbind(-1)
+    diag = torch.sqrt(la * la + wa * wa)
+    return torch.stack([xt * diag + xa, yt * diag + ya, zt * ha + za, torch.exp(wt) * wa, torch.exp(lt) * la,
+                        torch.exp(ht) * ha, rt + ra], -1)

@@ -117,6 +117,16 @@ def rulebook_conv(indices, batch_size, spatial_shape, ksize, stride, padding, di
 
 
 # ----------------------------------------------------------------------------- indice_conv
+_conv_profiler = None
+
+
+def set_conv_profiler(profiler):
+    """Measurement hook (bench.py): ``profiler.begin(meta) -> token`` / ``profiler.end(token)`` bracket the
+    sec_indice_conv_fwd launch on the current stream.  None disables it."""
+    global _conv_profiler
+    _conv_profiler = profiler
+
+
 def pack_weight(weight):
     """Fragment-order copy of a [kD,kH,kW,Cin,Cout] weight for the MFMA path; None when not applicable."""
     rt.require_gpu(weight)
@@ -149,10 +159,17 @@ def indice_conv(features, weight, nbr_out, num_out, packed=None, scale=None, shi
     out = torch.empty((num_out, cout), dtype=out_dtype, device=features.device)
     for t in (scale, shift):
         assert t is None or (t.dtype == torch.float32 and t.is_cuda and t.numel() == cout)
+    token = None
+    if _conv_profiler is not None:
+        token = _conv_profiler.begin({"cin": cin, "cout": cout, "kvol": k, "n_in": features.shape[0],
+                                      "n_out": int(num_out), "dtype": features.dtype, "nbr_out": nbr_out,
+                                      "mfma": packed is not None})
     rc = rt.lib().sec_indice_conv_fwd(rt.ptr(features), features.shape[0], cin, rt.ptr(weight), rt.ptr(packed), k, cout,
                                       rt.ptr(nbr_out), int(num_out), rt.ptr(num_out_dev), rt.ptr(scale), rt.ptr(shift),
                                       int(bool(relu)), rt.ptr(out), rt.dtype_code(features.dtype),
                                       rt.dtype_code(out_dtype), rt.stream())
+    if token is not None:
+        _conv_profiler.end(token)
     rt.check(rc, "sec_indice_conv_fwd")
     return out
 
