@@ -144,6 +144,9 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--mode", default="graph", choices=["graph", "static", "eager"],
+                    help="graph: static-capacity forward captured in a hipGraph (default); static: same, eager "
+                         "launches; eager: the dynamic-shape drop-in path (host syncs per strided layer)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stages", action="store_true", help="also print per-stage timings to stderr")
     args = ap.parse_args()
@@ -174,15 +177,34 @@ def main():
         torch.cuda.synchronize()
 
     with torch.no_grad():
+        if args.mode != "eager":
+            det.calibrate(points, offsets)
+        if args.mode == "graph":
+            replay, out = det.make_graphed(points, offsets)
+            step = replay
+        elif args.mode == "static":
+            step = lambda: det.forward_points(points, offsets, static=True)
+        else:
+            step = lambda: det.forward_points(points, offsets)
         for _ in range(args.warmup):
-            out = det.forward_points(points, offsets)
+            r = step()
         barrier()
-        timer.enabled = True
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            out = det.forward_points(points, offsets)
+            r = step()
         barrier()
         elapsed = time.perf_counter() - t0
+        if args.mode != "graph":
+            out = r
+        if args.mode != "eager":
+            det.check_overflow()
+        # per-kernel timing of the SubMConv3d kernel: HIP events on the launch stream around each launch,
+        # in eager launches of the very same static forward right after the timed region (events cannot be
+        # timed inside a captured graph); the rocprofv3 summary under profiles/ cross-checks it.
+        timer.enabled = True
+        for _ in range(min(args.steps, 10)):
+            det.forward_points(points, offsets, static=args.mode != "eager")
+        torch.cuda.synchronize()
         timer.enabled = False
 
     if world > 1:
@@ -196,7 +218,9 @@ def main():
         ms = [e0.elapsed_time(e1) for e0, e1, _ in timer.records]
         meta = timer.records[0][2]
         s = 2 if meta["dtype"] != torch.float32 else 4
-        pairs = int((meta["nbr_out"] >= 0).sum().item())
+        rows = int(meta["num_out_dev"][0].item()) if meta.get("num_out_dev") is not None else meta["n_out"]
+        pairs = int((meta["nbr_out"][:rows] >= 0).sum().item())
+        meta = dict(meta, n_out=rows)
         b_alg = s * (pairs * meta["cin"] + meta["n_out"] * meta["cout"]) + 8 * pairs + s * meta["kvol"] * meta["cin"] * meta["cout"]
         t_mean = float(np.mean(ms)) * 1e-3
         ach = b_alg / t_mean / 1e9
@@ -219,7 +243,7 @@ def main():
             "config": {"workload": "car.fhd.config VoxelNet forward (voxelise+VFE+SpMiddleFHD+RPNV2+rotated NMS), "
                                    "inference, batch=8 synthetic KITTI clouds/GPU (17000 pts, 16000 voxels each), "
                                    "random-init weights, inputs resident in HBM",
-                       "frames_per_step_per_gpu": BATCH, "parallelism": f"frame-dp{world}"},
+                       "frames_per_step_per_gpu": BATCH, "parallelism": f"frame-dp{world}", "launch_mode": args.mode},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -73,25 +73,38 @@ int sec_voxelize_f32(const float *points, const int *point_offsets, int num_poin
  * which is what sec_indice_conv_fwd consumes, and the INPUT-MAJOR table `nbr_in` [n_in, K]
  * (nbr_in[j][k] = output row or -1) which the backward pass consumes.
  * --------------------------------------------------------------------------------------------- */
+/* max_out_per_in sizes the output hash table (2 * n_in * max_out_per_in slots).  The exact bound is
+ * prod(ceil(k/s)) (8 for k3 s2); the same value must be passed as `out_per_in_hint` (0 = exact bound) to
+ * both conv3d calls.  A smaller hint saves memset traffic; if the data then needs more slots the build
+ * reports num_out[1] = INT_MAX (overflow) instead of hanging. */
 size_t sec_rulebook_workspace_bytes(int n_in, int kvol, int max_out_per_in);
 
-/* SubMConv3d: outputs == inputs.  nbr_in may be NULL (it is the mirror of nbr_out). pairs/pair_num may be NULL. */
-int sec_rulebook_subm3d(const int *indices, int n_in, int batch, const int *h_shape3,
-                        const int *h_ksize3, const int *h_dilation3, int *nbr_out, int *pairs,
-                        int *pair_num, void *workspace, size_t workspace_bytes, void *stream);
+/* Static-capacity mode: every builder takes an optional device int `n_in_dev`; buffers are sized for
+ * `n_in` rows, only the first *n_in_dev are live.  With the device-side counts of the voxeliser
+ * (voxel_offsets[batch]) and of sec_rulebook_conv3d_build (num_out) a whole forward pass needs no host
+ * synchronisation and can be captured in a hipGraph. */
+
+/* SubMConv3d: outputs == inputs.  pairs/pair_num may be NULL (and must be in static-capacity mode). */
+int sec_rulebook_subm3d(const int *indices, int n_in, const int *n_in_dev, int batch,
+                        const int *h_shape3, const int *h_ksize3, const int *h_dilation3, int *nbr_out,
+                        int *pairs, int *pair_num, void *workspace, size_t workspace_bytes,
+                        void *stream);
 
 /* SparseConv3d, step 1: discover the active outputs in first-touch order (oracle numbering).
- *   out_indices [out_cap,4]; num_out (device int) receives the count (may exceed out_cap only if the
- *   caller under-sized it: then SEC_E_INVALID is reported by step 2). State is kept in `workspace`. */
-int sec_rulebook_conv3d_build(const int *indices, int n_in, int batch, const int *h_in_shape3,
+ *   out_indices [out_cap,4]; num_out = device int[2]: [0] live outputs clamped to out_cap (feed it to the
+ *   next layer as n_in_dev / num_out_dev), [1] the raw count (raw > out_cap == capacity overflow, to be
+ *   checked by the caller whenever it next synchronises). State is kept in `workspace`. */
+int sec_rulebook_conv3d_build(const int *indices, int n_in, const int *n_in_dev, int batch,
+                              const int *h_in_shape3,
                               const int *h_out_shape3, const int *h_ksize3, const int *h_stride3,
                               const int *h_padding3, const int *h_dilation3, int *out_indices,
-                              int out_cap, int *num_out, void *workspace, size_t workspace_bytes,
-                              void *stream);
+                              int out_cap, int *num_out, int out_per_in_hint, void *workspace,
+                              size_t workspace_bytes, void *stream);
 /* step 2: fill the tables. nbr_out has `nbr_out_rows` rows (>= number of outputs; rows are -1 filled). */
-int sec_rulebook_conv3d_tables(int n_in, const int *h_ksize3, const int *h_stride3, int *nbr_out,
-                               int nbr_out_rows, int *nbr_in, int *pairs, int *pair_num,
-                               void *workspace, size_t workspace_bytes, void *stream);
+int sec_rulebook_conv3d_tables(int n_in, const int *h_ksize3, const int *h_stride3,
+                               int out_per_in_hint, int *nbr_out, int nbr_out_rows, int *nbr_in,
+                               int *pairs, int *pair_num, void *workspace, size_t workspace_bytes,
+                               void *stream);
 void sec_conv_output_shape(const int *h_in_shape3, const int *h_ksize3, const int *h_stride3,
                            const int *h_padding3, const int *h_dilation3, int *h_out_shape3);
 

@@ -64,6 +64,17 @@ __device__ __forceinline__ uint32_t hash_insert(unsigned long long *keys, uint32
         s = (s + 1) & mask;
     }
 }
+// bounded variant: gives up (-1) after `mask + 1` probes, i.e. when the table is full -- a sync-free
+// pipeline with under-estimated capacity must degrade into a reported overflow, never into a hang
+__device__ __forceinline__ int hash_insert_bounded(unsigned long long *keys, uint32_t mask, unsigned long long key) {
+    uint32_t s = hash64(key) & mask;
+    for (uint32_t probes = 0; probes <= mask; ++probes) {
+        unsigned long long prev = atomicCAS(&keys[s], kEmptyKey, key);
+        if (prev == kEmptyKey || prev == key) return (int)s;
+        s = (s + 1) & mask;
+    }
+    return -1;
+}
 // returns slot or -1
 __device__ __forceinline__ int hash_find(const unsigned long long *keys, uint32_t mask, unsigned long long key) {
     uint32_t s = hash64(key) & mask;

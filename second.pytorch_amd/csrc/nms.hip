@@ -172,7 +172,9 @@ __global__ __launch_bounds__(kBlock) void k_rotate_iou(const float *__restrict__
 }
 
 // ---------------------------------------------------------------- suppression bit matrix
-// grid (col_block, row_block, batch); only col_block >= row_block is computed.
+// grid (col_block, row_block, batch); only col_block >= row_block is computed.  Corners / areas of the 64
+// row boxes and the 64 column boxes are computed once per tile into LDS (the reference recomputes sin/cos
+// per pair); lanes are columns, a wave walks 16 rows, each row's 64-bit word is one __ballot.
 __global__ __launch_bounds__(kBlock) void k_nms_mask(const float *__restrict__ dets, const int *__restrict__ counts,
                                                     int max_n, int stride, float thresh, int kind, int semantics,
                                                     float eps, int words, unsigned long long *__restrict__ mask) {
@@ -181,43 +183,48 @@ __global__ __launch_bounds__(kBlock) void k_nms_mask(const float *__restrict__ d
     int n = counts[b];
     if (n > max_n) n = max_n;
     if (rb * 64 >= n || cb * 64 >= n) return;
-    __shared__ float cc[64][9];
-    __shared__ float ca[64];
+    __shared__ float tile[2][64][10];  // [0] = column boxes, [1] = row boxes: 8 corner floats (or x1,y1,x2,y2), area
     int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const float *base = dets + (size_t)b * max_n * stride;
-    int col = cb * 64 + lane;
-    if (w == 0 && col < n) {
-        const float *d = base + (size_t)col * stride;
-        if (kind == 0) {
-            float c[8];
-            box_corners(c, d);
+    if (w < 2) {
+        int idx = (w == 0 ? cb : rb) * 64 + lane;
+        if (idx < n) {
+            const float *d = base + (size_t)idx * stride;
+            if (kind == 0) {
+                float c[8];
+                box_corners(c, d);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) cc[lane][i] = c[i];
-            ca[lane] = d[2] * d[3];
-        } else {
+                for (int i = 0; i < 8; ++i) tile[w][lane][i] = c[i];
+                tile[w][lane][8] = d[2] * d[3];
+            } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) cc[lane][i] = d[i];
+                for (int i = 0; i < 4; ++i) tile[w][lane][i] = d[i];
+            }
         }
     }
     __syncthreads();
+    int col = cb * 64 + lane;
     float c2[8];
     float a2 = 0.0f;
+    Standup s2{0, 0, 0, 0};
     if (col < n) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) c2[i] = cc[lane][i];
-        a2 = ca[lane];
+        for (int i = 0; i < 8; ++i) c2[i] = tile[0][lane][i];
+        a2 = tile[0][lane][8];
+        if (kind == 0) s2 = standup_of(c2);
     }
     for (int rr = 0; rr < 16; ++rr) {
-        int row = rb * 64 + w * 16 + rr;
+        int rl = w * 16 + rr;
+        int row = rb * 64 + rl;
         if (row >= n) break;
         bool sup = false;
         if (col < n && col > row) {
-            const float *d = base + (size_t)row * stride;
+            float c1[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) c1[i] = tile[1][rl][i];  // wave-uniform address: LDS broadcast
             if (kind == 0) {
-                float c1[8];
-                box_corners(c1, d);
-                float a1 = d[2] * d[3];
-                Standup s1 = standup_of(c1), s2 = standup_of(c2);
+                float a1 = tile[1][rl][8];
+                Standup s1 = standup_of(c1);
                 if (!far_apart(s1, s2)) {
                     bool consider = true;
                     if (semantics == 1) {  // CPU path: standup IoU (eps = 0) must be > 0 (nms_cpu.py:25, A.6)
@@ -234,17 +241,15 @@ __global__ __launch_bounds__(kBlock) void k_nms_mask(const float *__restrict__ d
                         float v = in / (a1 + a2 - in);
                         sup = semantics == 1 ? v >= thresh : v > thresh;
                     }
-                } else if (semantics == 1) {
-                    sup = false;
-                } else {
+                } else if (semantics == 0) {
                     sup = 0.0f > thresh;  // IoU is exactly 0
                 }
             } else {
                 float e = semantics == 0 ? 1.0f : eps;
-                float wv = fmaxf(fminf(d[2], c2[2]) - fmaxf(d[0], c2[0]) + e, 0.0f);
-                float hv = fmaxf(fminf(d[3], c2[3]) - fmaxf(d[1], c2[1]) + e, 0.0f);
+                float wv = fmaxf(fminf(c1[2], c2[2]) - fmaxf(c1[0], c2[0]) + e, 0.0f);
+                float hv = fmaxf(fminf(c1[3], c2[3]) - fmaxf(c1[1], c2[1]) + e, 0.0f);
                 float in = wv * hv;
-                float sa = (d[2] - d[0] + e) * (d[3] - d[1] + e);
+                float sa = (c1[2] - c1[0] + e) * (c1[3] - c1[1] + e);
                 float sb = (c2[2] - c2[0] + e) * (c2[3] - c2[1] + e);
                 float v = in / (sa + sb - in);
                 sup = semantics == 0 ? v > thresh : v >= thresh;
@@ -255,7 +260,16 @@ __global__ __launch_bounds__(kBlock) void k_nms_mask(const float *__restrict__ d
     }
 }
 
-// greedy reduce (nms_postprocess): one wave per batch item, lane w owns removal word w
+__device__ __forceinline__ unsigned long long wave_or64(unsigned long long v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v |= __shfl_xor(v, d, 64);
+    return v;
+}
+
+// Greedy reduce (host loop nms_postprocess, nms_gpu.py:109-126) on-device, one wave per batch item.
+// Lane w owns removal word w.  Per 64-box block: (1) the intra-block chain is resolved on scalar state
+// with the 64 diagonal words (one per lane, read with v_readlane), (2) the kept rows' words for the later
+// blocks are OR-reduced across the wave and merged into the owners' removal words.
 __global__ __launch_bounds__(64) void k_nms_reduce(const unsigned long long *__restrict__ mask,
                                                   const int *__restrict__ counts, int max_n, int words, int post_max,
                                                   int *__restrict__ keep, int *__restrict__ num_keep) {
@@ -265,17 +279,32 @@ __global__ __launch_bounds__(64) void k_nms_reduce(const unsigned long long *__r
     int nwords = (n + 63) >> 6;
     unsigned long long remv = 0ull;
     const unsigned long long *mb = mask + (size_t)b * max_n * words;
+    int *kp = keep + (size_t)b * max_n;
     int nk = 0;
-    unsigned long long nxt = (n > 0 && lane < nwords) ? mb[lane] : 0ull;
-    for (int i = 0; i < n; ++i) {
-        unsigned long long cur = nxt;
-        if (i + 1 < n) nxt = lane < nwords ? mb[(size_t)(i + 1) * words + lane] : 0ull;  // independent of remv
-        unsigned long long word = __shfl(remv, i >> 6, 64);
-        if (!((word >> (i & 63)) & 1ull)) {
-            if (lane == 0) keep[(size_t)b * max_n + nk] = i;
-            ++nk;
-            if (post_max > 0 && nk >= post_max) break;
-            if (lane >= (i >> 6)) remv |= cur;
+    for (int c = 0; c < nwords; ++c) {
+        int base = c * 64;
+        int cnt = n - base < 64 ? n - base : 64;
+        unsigned long long diag = lane < cnt ? mb[(size_t)(base + lane) * words + c] : 0ull;
+        unsigned rlo = __builtin_amdgcn_readlane((unsigned)remv, c), rhi = __builtin_amdgcn_readlane((unsigned)(remv >> 32), c);
+        unsigned long long alive = ~(((unsigned long long)rhi << 32) | rlo);
+        if (cnt < 64) alive &= (1ull << cnt) - 1ull;
+        unsigned long long kept = 0ull;
+        int room = post_max > 0 ? post_max - nk : 0x7fffffff;
+        while (alive && room > 0) {
+            int i = __builtin_amdgcn_readfirstlane(__builtin_ctzll(alive));
+            kept |= 1ull << i;
+            --room;
+            unsigned dlo = __builtin_amdgcn_readlane((unsigned)diag, i), dhi = __builtin_amdgcn_readlane((unsigned)(diag >> 32), i);
+            alive &= ~((1ull << i) | (((unsigned long long)dhi << 32) | dlo));
+        }
+        bool mine = (kept >> lane) & 1ull;
+        if (mine) kp[nk + __popcll(kept & ((1ull << lane) - 1ull))] = base + lane;
+        nk += __popcll(kept);
+        if (post_max > 0 && nk >= post_max) break;
+        for (int w = c + 1; w < nwords; ++w) {
+            unsigned long long v = mine ? mb[(size_t)(base + lane) * words + w] : 0ull;
+            v = wave_or64(v);
+            if (lane == w) remv |= v;
         }
     }
     if (lane == 0) num_keep[b] = nk;

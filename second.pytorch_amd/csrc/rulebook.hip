@@ -29,11 +29,20 @@ __device__ __forceinline__ unsigned long long cell_key(int b, int z, int y, int 
     return (unsigned long long)b * vol + ((unsigned long long)z * shape[1] + y) * shape[2] + x;
 }
 
+// Every kernel takes an optional device-side row count `n_dev` (static-capacity, sync-free pipelines):
+// buffers are sized for g.n_in rows, only the first *n_dev are live.
+__device__ __forceinline__ int live_rows(const RbGeom &g, const int *n_dev) {
+    if (!n_dev) return g.n_in;
+    int n = *n_dev;
+    return n < g.n_in ? n : g.n_in;
+}
+
 __global__ __launch_bounds__(kBlock) void k_rb_hash_rows(const int *__restrict__ indices, RbGeom g,
+                                                        const int *__restrict__ n_dev,
                                                         unsigned long long *__restrict__ keys,
                                                         int *__restrict__ vals) {
     int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= g.n_in) return;
+    if (i >= live_rows(g, n_dev)) return;
     int4 c = *reinterpret_cast<const int4 *>(indices + (size_t)i * 4);
     uint32_t s = hash_insert(keys, g.mask, cell_key(c.x, c.y, c.z, c.w, g.in_shape));
     vals[s] = i;
@@ -41,10 +50,11 @@ __global__ __launch_bounds__(kBlock) void k_rb_hash_rows(const int *__restrict__
 
 // nbr_out[o][k] = row of the site at coord(o) + (k - centre) * dilation, or -1
 __global__ __launch_bounds__(kBlock) void k_subm_nbr(const int *__restrict__ indices, RbGeom g,
+                                                    const int *__restrict__ n_dev,
                                                     const unsigned long long *__restrict__ keys,
                                                     const int *__restrict__ vals, int *__restrict__ nbr) {
     long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
-    if (t >= (long long)g.n_in * g.kvol) return;
+    if (t >= (long long)live_rows(g, n_dev) * g.kvol) return;
     int o = (int)(t / g.kvol), k = (int)(t % g.kvol);
     int kx = k % g.ksize[2], ky = (k / g.ksize[2]) % g.ksize[1], kz = k / (g.ksize[2] * g.ksize[1]);
     int4 c = *reinterpret_cast<const int4 *>(indices + (size_t)o * 4);
@@ -61,11 +71,14 @@ __global__ __launch_bounds__(kBlock) void k_subm_nbr(const int *__restrict__ ind
 
 // ---- strided / regular sparse conv -------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_conv_cand(const int *__restrict__ indices, RbGeom g,
+                                                     const int *__restrict__ n_dev,
                                                      unsigned long long *__restrict__ keys,
-                                                     int *__restrict__ vals, int *__restrict__ cand_slot) {
+                                                     int *__restrict__ vals, int *__restrict__ cand_slot,
+                                                     int *__restrict__ overflow) {
     long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (t >= (long long)g.n_in * g.kvol) return;
     int j = (int)(t / g.kvol), k = (int)(t % g.kvol);
+    if (j >= live_rows(g, n_dev)) { cand_slot[t] = -1; return; }
     int kk[3] = {k / (g.ksize[2] * g.ksize[1]), (k / g.ksize[2]) % g.ksize[1], k % g.ksize[2]};
     int4 c = *reinterpret_cast<const int4 *>(indices + (size_t)j * 4);
     int in[3] = {c.y, c.z, c.w}, out[3];
@@ -79,8 +92,9 @@ __global__ __launch_bounds__(kBlock) void k_conv_cand(const int *__restrict__ in
     }
     int s = -1;
     if (ok) {
-        s = (int)hash_insert(keys, g.mask, cell_key(c.x, out[0], out[1], out[2], g.out_shape));
-        atomicMin(&vals[s], (int)t);  // token = j*K + k: order of the sequential reference loop
+        s = hash_insert_bounded(keys, g.mask, cell_key(c.x, out[0], out[1], out[2], g.out_shape));
+        if (s >= 0) atomicMin(&vals[s], (int)t);  // token = j*K + k: order of the sequential reference loop
+        else atomicOr(overflow, 1);               // table sized from a too-small hint: reported, not hung
     }
     cand_slot[t] = s;
 }
@@ -99,8 +113,14 @@ __global__ __launch_bounds__(kBlock) void k_conv_assign(const int *__restrict__ 
                                                        const unsigned long long *__restrict__ keys,
                                                        const int *__restrict__ rank, RbGeom g,
                                                        int *__restrict__ orank, int *__restrict__ out_indices,
-                                                       int out_cap) {
+                                                       int out_cap, int *__restrict__ num_out,
+                                                       const int *__restrict__ overflow) {
     long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (t == 0) {  // num_out[0] = live outputs (clamped to the capacity), num_out[1] = raw count (overflow check)
+        int tot = num_out[0];
+        num_out[1] = *overflow ? 0x7fffffff : tot;
+        if (tot > out_cap) num_out[0] = out_cap;
+    }
     if (t >= (long long)g.n_in * g.kvol) return;
     int s = cand_slot[t];
     if (s < 0 || vals[s] != (int)t) return;
@@ -192,7 +212,7 @@ static int emit_pairs(const int *table, int n, int kvol, int mirror, int *blk, i
 
 struct RbWorkspace {
     unsigned long long *keys;
-    int *vals, *orank, *cand_slot, *rank, *scan, *blk, *scan2, *mirror_tbl;
+    int *vals, *orank, *cand_slot, *rank, *scan, *blk, *scan2, *overflow;
     uint32_t table;
     size_t bytes;
 };
@@ -212,6 +232,7 @@ static RbWorkspace carve_rb(void *ws, size_t cap, int n_in, int kvol, int max_ou
     long long nblk = (long long)kvol * div_up(n_in > 0 ? n_in : 1, kBlock);
     w.blk = a.take<int>(nblk + 1);
     w.scan2 = a.take<int>(scan_scratch_ints(nblk));
+    w.overflow = a.take<int>(1);
     w.bytes = align_up(a.used);
     return w;
 }
@@ -236,10 +257,10 @@ static int fill_geom(RbGeom &g, const int *in_shape, const int *out_shape, const
     return SEC_OK;
 }
 
-static int max_out_per_in(const int *ksize, const int *stride) {
+static int max_out_per_in(const int *ksize, const int *stride, int hint) {
     int c = 1;
     for (int d = 0; d < 3; ++d) c *= (ksize[d] + stride[d] - 1) / stride[d];
-    return c;
+    return (hint > 0 && hint < c) ? hint : c;
 }
 
 }  // namespace sec
@@ -257,9 +278,10 @@ SEC_API void sec_conv_output_shape(const int *in_shape, const int *ksize, const 
         out_shape[d] = (in_shape[d] + 2 * pad[d] - dil[d] * (ksize[d] - 1) - 1) / stride[d] + 1;
 }
 
-SEC_API int sec_rulebook_subm3d(const int *indices, int n_in, int batch, const int *h_shape3, const int *h_ksize3,
-                                const int *h_dilation3, int *nbr_out, int *pairs, int *pair_num, void *workspace,
-                                size_t workspace_bytes, void *stream) {
+SEC_API int sec_rulebook_subm3d(const int *indices, int n_in, const int *n_in_dev, int batch, const int *h_shape3,
+                                const int *h_ksize3, const int *h_dilation3, int *nbr_out, int *pairs, int *pair_num,
+                                void *workspace, size_t workspace_bytes, void *stream) {
+    if (n_in_dev && pairs) return SEC_E_UNSUPPORTED;  // pair lists are an eager-API feature
     if (n_in < 0 || batch <= 0 || !h_shape3 || !h_ksize3 || (n_in > 0 && !nbr_out) || (pairs && !pair_num)) return SEC_E_INVALID;
     RbGeom g;
     int rc = fill_geom(g, h_shape3, nullptr, h_ksize3, nullptr, nullptr, h_dilation3, n_in, batch);
@@ -275,18 +297,19 @@ SEC_API int sec_rulebook_subm3d(const int *indices, int n_in, int batch, const i
         return SEC_OK;
     }
     if ((rc = hip_ok(hipMemsetAsync(w.keys, 0xff, (size_t)w.table * sizeof(unsigned long long), st)))) return rc;
-    hipLaunchKernelGGL(k_rb_hash_rows, dim3(div_up(n_in, kBlock)), dim3(kBlock), 0, st, indices, g, w.keys, w.vals);
+    hipLaunchKernelGGL(k_rb_hash_rows, dim3(div_up(n_in, kBlock)), dim3(kBlock), 0, st, indices, g, n_in_dev, w.keys, w.vals);
     long long nk = (long long)n_in * g.kvol;
-    hipLaunchKernelGGL(k_subm_nbr, dim3(div_up(nk, kBlock)), dim3(kBlock), 0, st, indices, g, w.keys, w.vals, nbr_out);
+    hipLaunchKernelGGL(k_subm_nbr, dim3(div_up(nk, kBlock)), dim3(kBlock), 0, st, indices, g, n_in_dev, w.keys, w.vals, nbr_out);
     if ((rc = check_launch())) return rc;
     if (pairs) return emit_pairs(nbr_out, n_in, g.kvol, /*mirror=*/1, w.blk, w.scan2, pairs, pair_num, st);
     return SEC_OK;
 }
 
-SEC_API int sec_rulebook_conv3d_build(const int *indices, int n_in, int batch, const int *h_in_shape3,
+SEC_API int sec_rulebook_conv3d_build(const int *indices, int n_in, const int *n_in_dev, int batch, const int *h_in_shape3,
                                       const int *h_out_shape3, const int *h_ksize3, const int *h_stride3,
                                       const int *h_padding3, const int *h_dilation3, int *out_indices, int out_cap,
-                                      int *num_out, void *workspace, size_t workspace_bytes, void *stream) {
+                                      int *num_out, int out_per_in_hint, void *workspace, size_t workspace_bytes,
+                                      void *stream) {
     if (n_in < 0 || batch <= 0 || !h_in_shape3 || !h_out_shape3 || !h_ksize3 || !h_stride3 || !h_padding3 ||
         !out_indices || !num_out || out_cap < 0)
         return SEC_E_INVALID;
@@ -294,32 +317,33 @@ SEC_API int sec_rulebook_conv3d_build(const int *indices, int n_in, int batch, c
     int rc = fill_geom(g, h_in_shape3, h_out_shape3, h_ksize3, h_stride3, h_padding3, h_dilation3, n_in, batch);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    RbWorkspace w = carve_rb(workspace, workspace_bytes, n_in, g.kvol, max_out_per_in(g.ksize, g.stride));
+    RbWorkspace w = carve_rb(workspace, workspace_bytes, n_in, g.kvol, max_out_per_in(g.ksize, g.stride, out_per_in_hint));
     if (!workspace || w.bytes > workspace_bytes) return SEC_E_WORKSPACE;
     g.mask = w.table - 1;
     long long nk = (long long)n_in * g.kvol;
-    if (nk == 0) return hip_ok(hipMemsetAsync(num_out, 0, sizeof(int), st));
+    if (nk == 0) return hip_ok(hipMemsetAsync(num_out, 0, 2 * sizeof(int), st));
     if ((rc = hip_ok(hipMemsetAsync(w.keys, 0xff, (size_t)w.table * sizeof(unsigned long long), st)))) return rc;
     if ((rc = hip_ok(hipMemsetAsync(w.vals, 0x7f, (size_t)w.table * sizeof(int), st)))) return rc;
+    if ((rc = hip_ok(hipMemsetAsync(w.overflow, 0, sizeof(int), st)))) return rc;
     int nb = div_up(nk, kBlock);
-    hipLaunchKernelGGL(k_conv_cand, dim3(nb), dim3(kBlock), 0, st, indices, g, w.keys, w.vals, w.cand_slot);
+    hipLaunchKernelGGL(k_conv_cand, dim3(nb), dim3(kBlock), 0, st, indices, g, n_in_dev, w.keys, w.vals, w.cand_slot, w.overflow);
     hipLaunchKernelGGL(k_conv_flag, dim3(nb), dim3(kBlock), 0, st, w.cand_slot, w.vals, nk, w.rank);
     if ((rc = exclusive_scan_i32(w.rank, w.rank, nk, num_out, w.scan, st))) return rc;
     hipLaunchKernelGGL(k_conv_assign, dim3(nb), dim3(kBlock), 0, st, w.cand_slot, w.vals, w.keys, w.rank, g, w.orank,
-                       out_indices, out_cap);
+                       out_indices, out_cap, num_out, w.overflow);
     return check_launch();
 }
 
-SEC_API int sec_rulebook_conv3d_tables(int n_in, const int *h_ksize3, const int *h_stride3, int *nbr_out,
-                                       int nbr_out_rows, int *nbr_in, int *pairs, int *pair_num, void *workspace,
-                                       size_t workspace_bytes, void *stream) {
+SEC_API int sec_rulebook_conv3d_tables(int n_in, const int *h_ksize3, const int *h_stride3, int out_per_in_hint,
+                                       int *nbr_out, int nbr_out_rows, int *nbr_in, int *pairs, int *pair_num,
+                                       void *workspace, size_t workspace_bytes, void *stream) {
     if (n_in < 0 || !h_ksize3 || !h_stride3 || (nbr_out_rows > 0 && !nbr_out) || (n_in > 0 && !nbr_in) || nbr_out_rows < 0 ||
         (pairs && !pair_num))
         return SEC_E_INVALID;
     int kvol = h_ksize3[0] * h_ksize3[1] * h_ksize3[2];
     if (kvol <= 0 || kvol > kMaxKvol) return SEC_E_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    RbWorkspace w = carve_rb(workspace, workspace_bytes, n_in, kvol, max_out_per_in(h_ksize3, h_stride3));
+    RbWorkspace w = carve_rb(workspace, workspace_bytes, n_in, kvol, max_out_per_in(h_ksize3, h_stride3, out_per_in_hint));
     if (!workspace || w.bytes > workspace_bytes) return SEC_E_WORKSPACE;
     int rc;
     if (nbr_out_rows > 0)

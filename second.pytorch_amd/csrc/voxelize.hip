@@ -39,6 +39,7 @@ __global__ __launch_bounds__(kBlock) void k_vox_hash(const float *__restrict__ p
                                                     int *__restrict__ vals, int *__restrict__ pslot) {
     int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= p.num_points) return;
+    if (i >= offs[p.batch]) { pslot[i] = -1; return; }  // capacity rows beyond the live point count
     const float *pt = points + (size_t)i * p.num_features;
     int c[3];
     bool ok = true;

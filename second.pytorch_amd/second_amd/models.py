@@ -111,9 +111,11 @@ class SpMiddleFHD(nn.Module):
         add(down(64, 64, (3, 1, 1), (2, 1, 1), 0), 64)
         self.middle_conv = spconv.SparseSequential(*layers)
 
-    def forward(self, voxel_features, coors, batch_size, channels_last=False):
-        x = spconv.SparseConvTensor(voxel_features, coors.int(), self.sparse_shape, batch_size)
+    def forward(self, voxel_features, coors, batch_size, channels_last=False, num_active_dev=None):
+        x = spconv.SparseConvTensor(voxel_features, coors.int(), self.sparse_shape, batch_size,
+                                    num_active_dev=num_active_dev)
         x = self.middle_conv(x)
+        self.last_overflow_checks = x.overflow_checks
         if channels_last:
             return x.dense_channels_last_2d()
         d = x.dense()
@@ -232,6 +234,9 @@ class SecondDetector(nn.Module):
         fm = [1, int(gs[1]) // cfg["downsample_factor"], int(gs[0]) // cfg["downsample_factor"]]
         self.feature_map_size = fm
         self.register_buffer("anchors", torch.from_numpy(generate_anchors(cfg, fm)), persistent=False)
+        self.register_buffer("_arange_p", torch.arange(cfg["nms_post_max_size"], dtype=torch.int32), persistent=False)
+        self.register_buffer("post_center_range", torch.tensor(cfg["post_center_range"], dtype=torch.float32),
+                             persistent=False)
         self._infer_dtype = None
         self.voxel_generator = spconv.utils.VoxelGeneratorV2(cfg["voxel_size"], cfg["point_cloud_range"],
                                                             cfg["max_points_per_voxel"], cfg["max_voxels"])
@@ -249,12 +254,13 @@ class SecondDetector(nn.Module):
         return self
 
     # -- stages ------------------------------------------------------------------------------------
-    def network_forward(self, voxel_features, coors, batch_size):
+    def network_forward(self, voxel_features, coors, batch_size, num_active_dev=None):
         dt = self._infer_dtype
         if dt is not None:
-            spatial = self.middle_feature_extractor(voxel_features.to(dt), coors, batch_size, channels_last=True)
+            spatial = self.middle_feature_extractor(voxel_features.to(dt), coors, batch_size, channels_last=True,
+                                                    num_active_dev=num_active_dev)
         else:
-            spatial = self.middle_feature_extractor(voxel_features, coors, batch_size)
+            spatial = self.middle_feature_extractor(voxel_features, coors, batch_size, num_active_dev=num_active_dev)
         return self.rpn(spatial)
 
     def forward(self, example):
@@ -265,12 +271,56 @@ class SecondDetector(nn.Module):
         with torch.no_grad():
             return self.predict(preds, example["anchors"].view(batch_size, -1, 7))
 
-    def forward_points(self, points, point_offsets):
-        """points [N,4] cuda float32 (clouds concatenated), point_offsets [B+1] cuda int32."""
+    def forward_points(self, points, point_offsets, static=False):
+        """points [N,4] cuda float32 (clouds concatenated), point_offsets [B+1] cuda int32.
+
+        ``static=True``: static-capacity, sync-free pipeline (every buffer sized for N rows, live counts stay
+        on the device) -- hipGraph-capturable; call :meth:`check_overflow` whenever the host next syncs."""
         batch_size = point_offsets.numel() - 1
-        vox = self.voxel_generator.generate_device(points, point_offsets, mean_features=self.cfg["num_point_features"])
-        preds = self.network_forward(vox["mean"], vox["coordinates"], batch_size)
+        nf = self.cfg["num_point_features"]
+        if not static:
+            vox = self.voxel_generator.generate_device(points, point_offsets, mean_features=nf)
+            preds = self.network_forward(vox["mean"], vox["coordinates"], batch_size)
+        else:
+            vox = self.voxel_generator.generate_device(points, point_offsets, mean_features=nf, sync=False)
+            preds = self.network_forward(vox["mean"], vox["coordinates"], batch_size,
+                                         num_active_dev=vox["voxel_offsets"][batch_size:])
         return self.predict_device(preds, batch_size)
+
+    def calibrate(self, points, point_offsets, margin=1.25):
+        """Size the static-capacity buffers of the strided layers from one eager forward of representative
+        clouds (live outputs x margin, rounded up to 256 rows), like a static-shape inference engine profile.
+        Data that later exceeds a capacity is reported by :meth:`check_overflow`."""
+        with torch.no_grad():
+            self.forward_points(points, point_offsets)
+        caps = []
+        for m in self.middle_feature_extractor.modules():
+            if isinstance(m, spconv.SparseConvolution) and not m.subm and m.last_num_out is not None:
+                m.static_out_rows = int(-(-int(m.last_num_out * margin) // 256) * 256)
+                caps.append(m.static_out_rows)
+        return caps
+
+    def check_overflow(self):
+        """Raise if a strided layer of the last static forward produced more outputs than its capacity."""
+        for num, cap in getattr(self.middle_feature_extractor, "last_overflow_checks", []):
+            raw = int(num[1].item())
+            if raw > cap:
+                raise RuntimeError(f"static-capacity overflow: a strided sparse conv produced {raw} outputs, capacity {cap}")
+
+    def make_graphed(self, points, point_offsets, warmup=3):
+        """Capture the static forward into a hipGraph.  Returns (replay_fn, outputs); new clouds are fed by
+        copying into ``points`` / ``point_offsets`` (any point count <= capacity) before calling replay_fn."""
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s), torch.no_grad():
+            for _ in range(warmup):
+                self.forward_points(points, point_offsets, static=True)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(graph):
+            out = self.forward_points(points, point_offsets, static=True)
+        return graph.replay, out
 
     # -- post-processing -----------------------------------------------------------------------------
     def _select(self, preds, batch_size, anchors):
@@ -299,7 +349,9 @@ class SecondDetector(nn.Module):
         cfg = self.cfg
         anchors = self.anchors if anchors is None else anchors
         dec, top_scores, counts, dir_labels = self._select(preds, batch_size, anchors)
-        dets = torch.cat([dec[..., [0, 1, 3, 4, 6]], top_scores.unsqueeze(-1)], -1).contiguous()
+        # (x, y, w, l, r, score): boxes_for_nms = box[:, [0, 1, 3, 4, 6]] (voxelnet.py:570); slices, not index
+        # lists, so that nothing is staged from the host (hipGraph capture)
+        dets = torch.cat([dec[..., 0:2], dec[..., 3:5], dec[..., 6:7], top_scores.unsqueeze(-1)], -1).contiguous()
         if cfg["use_rotate_nms"]:
             keep, num_keep = ops.nms_sorted(dets, counts, cfg["nms_iou_threshold"], "rotate", "cpu",
                                             post_max=cfg["nms_post_max_size"])
@@ -307,7 +359,7 @@ class SecondDetector(nn.Module):
             raise NotImplementedError("axis-aligned predict path (nuscenes all.fhd) comes with SURVEY row a19 wiring")
         p = min(cfg["nms_post_max_size"], keep.shape[1])
         sel = keep[:, :p].long().clamp_(min=0, max=dets.shape[1] - 1)
-        valid = torch.arange(p, device=keep.device).unsqueeze(0) < num_keep.unsqueeze(1)
+        valid = self._arange_p[:p].unsqueeze(0) < num_keep.unsqueeze(1)
         boxes = torch.gather(dec, 1, sel.unsqueeze(-1).expand(-1, -1, 7))
         scores = torch.gather(top_scores, 1, sel)
         if dir_labels is not None:
@@ -315,7 +367,7 @@ class SecondDetector(nn.Module):
             period = 2 * math.pi / cfg["num_direction_bins"]
             rot = limit_period(boxes[..., 6] - cfg["direction_offset"], cfg["direction_limit_offset"], period)
             boxes[..., 6] = rot + cfg["direction_offset"] + period * dl.to(boxes.dtype)
-        r = torch.tensor(cfg["post_center_range"], device=boxes.device, dtype=boxes.dtype)
+        r = self.post_center_range
         valid = valid & (boxes[..., :3] >= r[:3]).all(-1) & (boxes[..., :3] <= r[3:]).all(-1)
         return {"boxes": boxes, "scores": scores, "labels": torch.zeros_like(sel), "valid": valid}
 

@@ -64,8 +64,9 @@ def _kvol(ksize):
     return int(np.prod([int(k) for k in ((ksize,) * 3 if isinstance(ksize, int) else ksize)]))
 
 
-def rulebook_subm(indices, batch_size, spatial_shape, ksize=3, dilation=1, want_pairs=False):
-    """SubMConv3d rulebook (spconv.ops.get_indice_pairs(subm=True)).  indices [N,4] int32 (b,z,y,x)."""
+def rulebook_subm(indices, batch_size, spatial_shape, ksize=3, dilation=1, want_pairs=False, n_dev=None):
+    """SubMConv3d rulebook (spconv.ops.get_indice_pairs(subm=True)).  indices [N,4] int32 (b,z,y,x).
+    ``n_dev`` (device int32[1]) switches to static-capacity mode: only the first n_dev rows are live."""
     rt.require_gpu(indices)
     assert indices.dtype == torch.int32 and indices.is_contiguous()
     n = indices.shape[0]
@@ -76,17 +77,21 @@ def rulebook_subm(indices, batch_size, spatial_shape, ksize=3, dilation=1, want_
     pair_num = torch.zeros((k,), dtype=torch.int32, device=dev) if want_pairs else None
     l = rt.lib()
     ws = rt.workspace(l.sec_rulebook_workspace_bytes(n, k, 1), dev)
-    rc = l.sec_rulebook_subm3d(rt.ptr(indices), n, int(batch_size), rt.i3(spatial_shape), rt.i3(ksize),
+    rc = l.sec_rulebook_subm3d(rt.ptr(indices), n, rt.ptr(n_dev), int(batch_size), rt.i3(spatial_shape), rt.i3(ksize),
                                rt.i3(dilation), rt.ptr(nbr), rt.ptr(pairs), rt.ptr(pair_num), rt.ptr(ws),
                                ws.numel(), rt.stream())
     rt.check(rc, "sec_rulebook_subm3d")
     return {"nbr_out": nbr, "nbr_in": None, "pairs": pairs, "pair_num": pair_num, "out_indices": indices,
-            "num_out": n, "out_shape": [int(s) for s in spatial_shape]}
+            "num_out": n, "num_out_dev": n_dev, "out_shape": [int(s) for s in spatial_shape]}
 
 
-def rulebook_conv(indices, batch_size, spatial_shape, ksize, stride, padding, dilation=1, want_pairs=False):
+def rulebook_conv(indices, batch_size, spatial_shape, ksize, stride, padding, dilation=1, want_pairs=False,
+                  n_dev=None, out_cap=None, out_per_in_hint=0):
     """SparseConv3d rulebook (spconv.ops.get_indice_pairs(subm=False)), first-touch output numbering.
-    One D2H sync (the active-output count), like the reference's numActOut."""
+
+    Eager mode (default): one D2H sync for the active-output count, like the reference's numActOut.
+    Static-capacity mode (``out_cap`` given, optional ``n_dev``): no sync; tables are sized ``out_cap`` rows,
+    ``num_out_dev`` int32[2] = (live outputs clamped to out_cap, raw count for the overflow check)."""
     rt.require_gpu(indices)
     assert indices.dtype == torch.int32 and indices.is_contiguous()
     n = indices.shape[0]
@@ -95,25 +100,28 @@ def rulebook_conv(indices, batch_size, spatial_shape, ksize, stride, padding, di
     dev = indices.device
     out_shape = conv_output_shape(spatial_shape, ksize, stride, padding, dilation)
     per_in = int(np.prod([(ks[d] + st[d] - 1) // st[d] for d in range(3)]))
-    cap = max(1, min(n * per_in, int(batch_size) * int(np.prod(out_shape))))
+    hint = int(out_per_in_hint) if 0 < int(out_per_in_hint) < per_in else 0
+    static = out_cap is not None
+    cap = int(out_cap) if static else max(1, min(n * per_in, int(batch_size) * int(np.prod(out_shape))))
     out_idx = torch.empty((cap, 4), dtype=torch.int32, device=dev)
-    num_out = torch.zeros((1,), dtype=torch.int32, device=dev)
+    num_out = torch.zeros((2,), dtype=torch.int32, device=dev)
     l = rt.lib()
-    ws = rt.workspace(l.sec_rulebook_workspace_bytes(n, k, per_in), dev)
-    rc = l.sec_rulebook_conv3d_build(rt.ptr(indices), n, int(batch_size), rt.i3(spatial_shape), rt.i3(out_shape), ks,
-                                     st, rt.i3(padding), rt.i3(dilation), rt.ptr(out_idx), cap, rt.ptr(num_out),
-                                     rt.ptr(ws), ws.numel(), rt.stream())
+    ws = rt.workspace(l.sec_rulebook_workspace_bytes(n, k, hint or per_in), dev)
+    rc = l.sec_rulebook_conv3d_build(rt.ptr(indices), n, rt.ptr(n_dev), int(batch_size), rt.i3(spatial_shape),
+                                     rt.i3(out_shape), ks, st, rt.i3(padding), rt.i3(dilation), rt.ptr(out_idx), cap,
+                                     rt.ptr(num_out), hint, rt.ptr(ws), ws.numel(), rt.stream())
     rt.check(rc, "sec_rulebook_conv3d_build")
-    m = int(num_out.item())
+    m = cap if static else int(num_out[0].item())
     nbr_out = torch.empty((m, k), dtype=torch.int32, device=dev)
     nbr_in = torch.empty((n, k), dtype=torch.int32, device=dev)
     pairs = torch.empty((k, 2, n), dtype=torch.int32, device=dev) if want_pairs else None
     pair_num = torch.zeros((k,), dtype=torch.int32, device=dev) if want_pairs else None
-    rc = l.sec_rulebook_conv3d_tables(n, ks, st, rt.ptr(nbr_out), m, rt.ptr(nbr_in), rt.ptr(pairs), rt.ptr(pair_num),
-                                      rt.ptr(ws), ws.numel(), rt.stream())
+    rc = l.sec_rulebook_conv3d_tables(n, ks, st, hint, rt.ptr(nbr_out), m, rt.ptr(nbr_in), rt.ptr(pairs),
+                                      rt.ptr(pair_num), rt.ptr(ws), ws.numel(), rt.stream())
     rt.check(rc, "sec_rulebook_conv3d_tables")
     return {"nbr_out": nbr_out, "nbr_in": nbr_in, "pairs": pairs, "pair_num": pair_num,
-            "out_indices": out_idx[:m], "num_out": m, "out_shape": out_shape}
+            "out_indices": out_idx[:m], "num_out": m, "num_out_dev": num_out if static else None,
+            "out_shape": out_shape}
 
 
 # ----------------------------------------------------------------------------- indice_conv
@@ -163,7 +171,7 @@ def indice_conv(features, weight, nbr_out, num_out, packed=None, scale=None, shi
     if _conv_profiler is not None:
         token = _conv_profiler.begin({"cin": cin, "cout": cout, "kvol": k, "n_in": features.shape[0],
                                       "n_out": int(num_out), "dtype": features.dtype, "nbr_out": nbr_out,
-                                      "mfma": packed is not None})
+                                      "mfma": packed is not None, "num_out_dev": num_out_dev})
     rc = rt.lib().sec_indice_conv_fwd(rt.ptr(features), features.shape[0], cin, rt.ptr(weight), rt.ptr(packed), k, cout,
                                       rt.ptr(nbr_out), int(num_out), rt.ptr(num_out_dev), rt.ptr(scale), rt.ptr(shift),
                                       int(bool(relu)), rt.ptr(out), rt.dtype_code(features.dtype),

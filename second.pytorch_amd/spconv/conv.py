@@ -38,6 +38,11 @@ class SparseConvolution(SparseModule):
             self.register_parameter("bias", None)
         self._packed = None
         self._packed_key = None
+        # static-capacity mode (see SparseConvTensor.num_active_dev): rows reserved for this layer's output.
+        # Default = growth x input capacity; `static_out_rows` (e.g. from SecondDetector.calibrate) overrides.
+        self.static_growth = 2.0
+        self.static_out_rows = None
+        self.last_num_out = None
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -58,15 +63,23 @@ class SparseConvolution(SparseModule):
         if rb is not None and self.subm:
             return rb
         indices = x.indices.contiguous()
+        nd = x.num_active_dev
         if self.subm:
-            r = _ops.rulebook_subm(indices, x.batch_size, x.spatial_shape, self.kernel_size, self.dilation)
+            r = _ops.rulebook_subm(indices, x.batch_size, x.spatial_shape, self.kernel_size, self.dilation, n_dev=nd)
+        elif nd is not None:  # static capacity: no host sync, overflow is reported through num_out_dev[1]
+            cap = self.static_out_rows or int(indices.shape[0] * self.static_growth)
+            hint = max(1, -(-cap // max(indices.shape[0], 1)))
+            r = _ops.rulebook_conv(indices, x.batch_size, x.spatial_shape, self.kernel_size, self.stride, self.padding,
+                                   self.dilation, n_dev=nd, out_cap=cap, out_per_in_hint=hint)
         else:
             r = _ops.rulebook_conv(indices, x.batch_size, x.spatial_shape, self.kernel_size, self.stride, self.padding,
                                    self.dilation)
         rb = Rulebook(r["out_indices"], indices, r["nbr_out"], r["nbr_in"], r["num_out"], x.spatial_shape,
-                      r["out_shape"], self.subm)
+                      r["out_shape"], self.subm, num_out_dev=r["num_out_dev"])
         if self.indice_key is not None:
             x.indice_dict[self.indice_key] = rb
+        if nd is None:
+            self.last_num_out = rb.num_out
         return rb
 
     def packed_weight(self):
@@ -78,7 +91,10 @@ class SparseConvolution(SparseModule):
         return self._packed
 
     def _wrap(self, x, feats, rb):
-        out = SparseConvTensor(feats, rb.out_indices, rb.out_shape, x.batch_size, x.grid)
+        out = SparseConvTensor(feats, rb.out_indices, rb.out_shape, x.batch_size, x.grid, rb.num_out_dev)
+        out.overflow_checks = getattr(x, "overflow_checks", [])
+        if rb.num_out_dev is not None and not rb.subm:
+            out.overflow_checks = out.overflow_checks + [(rb.num_out_dev, rb.out_indices.shape[0])]
         out.indice_dict = x.indice_dict
         return out
 
@@ -107,7 +123,7 @@ class SparseConvolution(SparseModule):
         if w.dtype != x.features.dtype:
             w, packed = w.to(x.features.dtype), None
         feats = _ops.indice_conv(x.features.contiguous(), w.contiguous(), rb.nbr_out, rb.num_out, packed=packed,
-                                 scale=scale, shift=shift, relu=relu)
+                                 scale=scale, shift=shift, relu=relu, num_out_dev=rb.num_out_dev)
         return self._wrap(x, feats, rb)
 
 

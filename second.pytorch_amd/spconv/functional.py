@@ -10,7 +10,7 @@ class IndiceConvFunction(torch.autograd.Function):
         ctx.rulebook = rulebook
         ctx.save_for_backward(features, weight)
         return _ops.indice_conv(features.contiguous(), weight.contiguous(), rulebook.nbr_out, rulebook.num_out,
-                                packed=packed)
+                                packed=packed, num_out_dev=rulebook.num_out_dev)
 
     @staticmethod
     def backward(ctx, grad_out):

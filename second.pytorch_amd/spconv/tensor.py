@@ -11,7 +11,8 @@ class Rulebook:
     Holds the gather tables our kernels consume and (lazily) spconv's pair lists."""
 
     def __init__(self, out_indices, in_indices, nbr_out, nbr_in, num_out, in_shape, out_shape, subm,
-                 pairs=None, pair_num=None):
+                 pairs=None, pair_num=None, num_out_dev=None):
+        self.num_out_dev = num_out_dev  # static-capacity mode: device count of live output rows
         self.out_indices, self.in_indices = out_indices, in_indices
         self.nbr_out, self.nbr_in = nbr_out, nbr_in
         self.num_out, self.in_shape, self.out_shape, self.subm = num_out, in_shape, out_shape, subm
@@ -23,8 +24,14 @@ class Rulebook:
 
 
 class SparseConvTensor:
-    def __init__(self, features, indices, spatial_shape, batch_size, grid=None):
-        """features [N,C]; indices [N,4] int32 (batch, z, y, x); spatial_shape (z,y,x)."""
+    def __init__(self, features, indices, spatial_shape, batch_size, grid=None, num_active_dev=None):
+        """features [N,C]; indices [N,4] int32 (batch, z, y, x); spatial_shape (z,y,x).
+
+        ``num_active_dev`` (extension, device int32[>=1]): static-capacity mode -- the tensors are sized for
+        a capacity, only the first num_active_dev[0] rows are live; every layer then runs without host
+        synchronisation (hipGraph-capturable).  None = the reference's dynamic-shape behaviour."""
+        self.num_active_dev = num_active_dev
+        self.overflow_checks = []  # [(device int32[2] = (clamped, raw), capacity)] of strided layers upstream
         self.features = features
         self.indices = indices
         if self.indices.dtype != torch.int32:
@@ -44,7 +51,8 @@ class SparseConvTensor:
         return self.indice_dict.get(key)
 
     def dense(self, channels_first=True):
-        out = _ops.sparse_to_dense(self.features, self.indices.contiguous(), self.batch_size, self.spatial_shape)
+        out = _ops.sparse_to_dense(self.features, self.indices.contiguous(), self.batch_size, self.spatial_shape,
+                                   num_dev=self.num_active_dev)
         if not channels_first:
             return out.permute(0, 2, 3, 4, 1).contiguous()
         return out
@@ -53,7 +61,7 @@ class SparseConvTensor:
         """[B, C*D, H, W] in channels_last memory format == dense().view(B, C*D, H, W) values
         (the RPN input of second/pytorch/models/middle.py:206-210) without the permute copy."""
         return _ops.sparse_to_dense(self.features, self.indices.contiguous(), self.batch_size, self.spatial_shape,
-                                    channels_last_2d=True)
+                                    channels_last_2d=True, num_dev=self.num_active_dev)
 
     @property
     def sparity(self):

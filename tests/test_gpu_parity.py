@@ -368,3 +368,51 @@ def test_cpu_tensors_are_rejected(ops):
     from second_amd.runtime import SecondHipError
     with pytest.raises(SecondHipError):
         ops.rulebook_subm(torch.zeros((1, 4), dtype=torch.int32), 1, (3, 3, 3))
+
+
+# ------------------------------------------------------------------ static-capacity (sync-free) pipeline
+def test_static_capacity_rulebooks_match_eager(ops, syn):
+    c = syn.syn_kitti_cloud(1, num_points=6000, num_voxels=5000)
+    r = orc.points_to_voxel(c, syn.CAR_FHD_VOXEL, syn.CAR_FHD_RANGE, 5, 40000)
+    idx = np.concatenate([np.zeros((r["voxel_num"], 1), np.int32), r["coordinates"]], 1)
+    n = len(idx)
+    cap = n + 777
+    padded = np.concatenate([idx, np.full((cap - n, 4), 12345, np.int32)])  # garbage rows beyond the live count
+    n_dev = dev(np.array([n], np.int32))
+    shape = [41, 1600, 1408]
+    e = ops.rulebook_subm(dev(idx), 1, shape, 3)
+    s = ops.rulebook_subm(dev(padded), 1, shape, 3, n_dev=n_dev)
+    assert torch.equal(e["nbr_out"], s["nbr_out"][:n])
+    e = ops.rulebook_conv(dev(idx), 1, shape, 3, 2, 1)
+    s = ops.rulebook_conv(dev(padded), 1, shape, 3, 2, 1, n_dev=n_dev, out_cap=4 * cap, out_per_in_hint=4)
+    m = e["num_out"]
+    assert s["num_out_dev"].tolist() == [m, m]
+    assert torch.equal(e["out_indices"], s["out_indices"][:m])
+    assert torch.equal(e["nbr_out"], s["nbr_out"][:m])
+    assert torch.equal(e["nbr_in"], s["nbr_in"][:n])
+    # capacity overflow is reported, never a hang or an out-of-bounds write
+    s = ops.rulebook_conv(dev(padded), 1, shape, 3, 2, 1, n_dev=n_dev, out_cap=100, out_per_in_hint=2)
+    assert s["num_out_dev"][0].item() == 100 and s["num_out_dev"][1].item() == m
+    s = ops.rulebook_conv(dev(padded[:64]), 1, shape, 3, 2, 1, out_cap=64, out_per_in_hint=1)
+    assert s["num_out_dev"][1].item() >= 64
+
+
+def test_detector_static_and_graph_match_eager(syn):
+    from second_amd.models import SecondDetector, CAR_FHD
+    torch.manual_seed(0)
+    det = SecondDetector(CAR_FHD).cuda().prepare_inference(torch.bfloat16)
+    clouds = [syn.syn_kitti_cloud(s, num_points=9000, num_voxels=8000) for s in range(2)]
+    pts, offs = syn.batch_clouds(clouds)
+    pts, offs = dev(pts), dev(offs)
+    with torch.no_grad():
+        e = det.forward_points(pts, offs)
+        s = det.forward_points(pts, offs, static=True)   # default growth-factor capacities
+        det.check_overflow()
+        det.calibrate(pts, offs)                          # profile-sized capacities
+        replay, g = det.make_graphed(pts, offs)
+        replay()
+        torch.cuda.synchronize()
+    for k in ("boxes", "scores", "valid"):
+        assert torch.equal(e[k], s[k]), k
+        assert torch.equal(e[k], g[k]), k
+    assert e["valid"].any()
