@@ -416,3 +416,18 @@ def test_detector_static_and_graph_match_eager(syn):
         assert torch.equal(e[k], s[k]), k
         assert torch.equal(e[k], g[k]), k
     assert e["valid"].any()
+
+
+def test_rpn_mirror_matches_reference_golden(golden):
+    """RPNV2 mirror vs outputs of the reference's own RPNV2 module (fixture, fp32)."""
+    from second_amd.models import RPNV2
+    g = golden("torch_modules")
+    net = RPNV2(num_class=1, layer_nums=(2,), layer_strides=(1,), num_filters=(16,), upsample_strides=(1,),
+                num_upsample_filters=(16,), num_input_features=16)
+    sd = {k[len("rpn_sd."):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("rpn_sd.")}
+    net.load_state_dict(sd)
+    net = net.cuda().eval()
+    with torch.no_grad():
+        r = net(dev(g["rpn_in"]))
+    for k in ("box_preds", "cls_preds", "dir_cls_preds"):
+        np.testing.assert_allclose(r[k].cpu().numpy(), g["rpn_" + k], rtol=1e-4, atol=1e-5)
