@@ -1,0 +1,192 @@
+"""Import shims that let the UNMODIFIED reference (traveller59/second.pytorch, v1.6.0-alpha, a 2019 code
+base) import on python 3.10 / torch 2.10 / numpy 2 / protobuf 7 with this repo's drop-in ``spconv``.
+
+    from second_amd import compat
+    compat.install("/path/to/second.pytorch")      # then: import second.pytorch.train
+
+Nothing here contains hot-path arithmetic: only stand-ins for optional third-party imports the reference
+performs at module import time and a loader for its protoc-3.x era ``*_pb2.py`` files.
+"""
+import collections
+import collections.abc
+import glob
+import importlib
+import os
+import re
+import sys
+import types
+
+
+def _missing(name):
+    try:
+        importlib.import_module(name)
+        return False
+    except Exception:
+        return True
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    def _getattr(attr):
+        if attr.startswith("__"):
+            raise AttributeError(attr)
+        return _Placeholder(f"{name}.{attr}")
+    m.__getattr__ = _getattr
+    sys.modules[name] = m
+    return m
+
+
+class _Placeholder:
+    """Import-time placeholder: usable as a default argument / attribute, fails loudly when called."""
+
+    def __init__(self, name):
+        self._name = name
+
+    def __call__(self, *a, **k):
+        raise ImportError(f"{self._name} is not available in this environment (second_amd.compat placeholder)")
+
+    def __getattr__(self, attr):
+        if attr.startswith("__"):
+            raise AttributeError(attr)
+        return _Placeholder(f"{self._name}.{attr}")
+
+
+def _install_numba():
+    """numba.jit/njit as identity decorators: the reference's CPU helpers (anchors, target assignment, box math)
+    then run as plain Python/numpy; its numba.cuda kernels are replaced by libsecond_hip (never called)."""
+    import numpy as np
+
+    def passthrough(*dargs, **dkw):
+        if len(dargs) == 1 and callable(dargs[0]) and not dkw:
+            return dargs[0]
+        return lambda f: f
+
+    numba = _stub("numba", jit=passthrough, njit=passthrough, prange=range, float32=np.float32, float64=np.float64,
+                  int32=np.int32, int64=np.int64)
+    cuda = _stub("numba.cuda", jit=passthrough)
+    numba.cuda = cuda
+
+
+def _install_fire():
+    def Fire(component=None, *a, **k):
+        import inspect
+        argv = sys.argv[1:]
+        if not argv:
+            return component
+        fn = getattr(sys.modules["__main__"], argv[0]) if not callable(component) else component
+        kwargs = {}
+        for tok in argv[1:]:
+            if tok.startswith("--") and "=" in tok:
+                key, val = tok[2:].split("=", 1)
+                try:
+                    import ast
+                    val = ast.literal_eval(val)
+                except Exception:
+                    pass
+                kwargs[key] = val
+        return fn(**kwargs)
+    _stub("fire", Fire=Fire)
+
+
+def _install_tensorboardx():
+    class SummaryWriter:
+        def __init__(self, *a, **k):
+            pass
+
+        def __getattr__(self, name):
+            return lambda *a, **k: None
+    _stub("tensorboardX", SummaryWriter=SummaryWriter)
+
+
+def _install_torchvision():
+    import torch
+
+    class _Block(torch.nn.Module):
+        expansion = 1
+    tv = _stub("torchvision")
+    tvm = _stub("torchvision.models")
+    tvr = _stub("torchvision.models.resnet", BasicBlock=_Block, Bottleneck=_Block)
+    tv.models, tvm.resnet = tvm, tvr
+
+
+def load_protos(reference_root):
+    """Rebuild second/protos/*_pb2 message classes from the serialized descriptors embedded in the generated
+    files (they cannot be imported under protobuf >= 4) and install them as ``second.protos.<x>_pb2``."""
+    from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
+    proto_dir = os.path.join(reference_root, "second", "protos")
+    files = {}
+    for path in sorted(glob.glob(os.path.join(proto_dir, "*_pb2.py"))):
+        src = open(path).read()
+        m = re.search(r"serialized_pb=_b\('((?:[^'\\]|\\.)*)'\)", src, re.S)
+        if not m:
+            continue
+        blob = eval("b'" + m.group(1) + "'")  # the literal the generated file itself would evaluate
+        fdp = descriptor_pb2.FileDescriptorProto()
+        fdp.ParseFromString(blob)
+        files[fdp.name] = (fdp, os.path.basename(path)[:-3])
+    pool = descriptor_pool.DescriptorPool()
+    done = set()
+
+    def add(name):
+        if name in done:
+            return
+        fdp, _ = files[name]
+        for dep in fdp.dependency:
+            add(dep)
+        pool.Add(fdp)
+        done.add(name)
+    for name in files:
+        add(name)
+    import second  # the reference package (namespace for second.protos)
+    pkg = importlib.import_module("second.protos")
+    for name, (fdp, modname) in files.items():
+        mod = types.ModuleType(f"second.protos.{modname}")
+        fd = pool.FindFileByName(name)
+        mod.DESCRIPTOR = fd
+        for msg_name, desc in fd.message_types_by_name.items():
+            setattr(mod, msg_name, message_factory.GetMessageClass(desc))
+        for enum_name, enum in fd.enum_types_by_name.items():
+            setattr(mod, enum_name, enum)
+            for v in enum.values:
+                setattr(mod, v.name, v.number)
+        sys.modules[mod.__name__] = mod
+        setattr(pkg, modname, mod)
+    return sorted(m for _, m in files.values())
+
+
+def install(reference_root=None, spconv_path=None):
+    """Make ``import second...`` / ``import torchplus`` work.  Idempotent."""
+    collections.Iterable = collections.abc.Iterable      # torchplus/train/optim.py:1, fastai_optim.py:1
+    import torch  # noqa: F401  (before any stand-in module exists: torch introspects sys.modules at import)
+    import numpy as np
+    if not getattr(np.meshgrid, "_second_amd_list", False):
+        _meshgrid = np.meshgrid
+
+        def meshgrid(*a, **k):   # numpy >= 2 returns a tuple; box_np_ops.py:626-629 assigns into the result
+            return list(_meshgrid(*a, **k))
+        meshgrid._second_amd_list = True
+        np.meshgrid = meshgrid
+    for alias, typ in (("float", float), ("int", int), ("bool", bool)):  # removed numpy aliases used by 2019 code
+        if not hasattr(np, alias):
+            setattr(np, alias, typ)
+    here = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    spconv_path = spconv_path or here
+    if spconv_path not in sys.path:
+        sys.path.insert(0, spconv_path)
+    if _missing("numba"):
+        _install_numba()
+    if _missing("fire"):
+        _install_fire()
+    if _missing("tensorboardX"):
+        _install_tensorboardx()
+    if _missing("torchvision"):
+        _install_torchvision()
+    for name in ("cv2", "skimage", "skimage.io", "seaborn", "shapely", "shapely.geometry", "pyquaternion"):
+        if _missing(name):
+            _stub(name)
+    if reference_root:
+        if reference_root not in sys.path:
+            sys.path.append(reference_root)
+        return load_protos(reference_root)
+    return []

@@ -150,3 +150,46 @@ def _nms_tensor(boxes, scores, pre_max_size, post_max_size, thresh, eps):
     keep, num = _chunked_nms(d, cnt, thresh, "axis_aligned", "cpu", eps,
                              post_max_size if post_max_size and post_max_size > 0 else 0)
     return idx[keep[0, :int(num[0].item())].long()]
+
+
+def _corners_to_rbox(corners):
+    """[N,4,2] corners in box_np_ops.center_to_corner_box2d order ((-,-),(-,+),(+,+),(+,-) rotated clockwise)
+    -> [N,5] (x, y, w, l, r).  Inverse of second/core/box_np_ops.py:405-425."""
+    c = np.asarray(corners, np.float32).reshape(-1, 4, 2)
+    ctr = c.mean(1)
+    ex, ey = c[:, 3] - c[:, 0], c[:, 1] - c[:, 0]
+    w, l = np.linalg.norm(ex, axis=1), np.linalg.norm(ey, axis=1)
+    r = np.arctan2(-ex[:, 1], ex[:, 0])
+    return np.concatenate([ctr, w[:, None], l[:, None], r[:, None]], 1).astype(np.float32)
+
+
+def rotate_non_max_suppression_cpu(box_corners, order, standup_iou, thresh):
+    """spconv's CPU rotated NMS (called by rotate_nms_cc, second/core/non_max_suppression/nms_cpu.py:17-28):
+    greedy over `order`, pairs with standup IoU <= 0 skipped, suppress at IoU >= thresh.  Runs on the MI355X
+    (the standup matrix is recomputed on the device; the argument is accepted for signature parity)."""
+    dev = _dev()
+    order = np.asarray(order)
+    n = len(order)
+    if n == 0:
+        return []
+    boxes = _corners_to_rbox(box_corners)[order]
+    d = torch.from_numpy(np.ascontiguousarray(boxes)).to(dev).unsqueeze(0)
+    cnt = torch.tensor([n], dtype=torch.int32, device=dev)
+    keep, num = _chunked_nms(d, cnt, thresh, "rotate", "cpu", 0.0)
+    return order[keep[0, :int(num[0].item())].cpu().numpy()].tolist()
+
+
+def rbbox_iou(box_corners, qbox_corners, standup_iou, standup_thresh):
+    """[N,K] rotated IoU where standup_iou > standup_thresh else 0 (second/core/box_np_ops.py:10-21)."""
+    dev = _dev()
+    iou = _ops.rotate_iou(torch.from_numpy(_corners_to_rbox(box_corners)).to(dev),
+                          torch.from_numpy(_corners_to_rbox(qbox_corners)).to(dev), -1).cpu().numpy()
+    return np.where(np.asarray(standup_iou) > standup_thresh, iou, 0).astype(np.asarray(box_corners).dtype)
+
+
+def rbbox_intersection(box_corners, qbox_corners, standup_iou, standup_thresh):
+    """[N,K] rotated intersection / area(box) (second/core/box_np_ops.py:23-34 -> spconv rbbox_intersection)."""
+    dev = _dev()
+    inter = _ops.rotate_iou(torch.from_numpy(_corners_to_rbox(box_corners)).to(dev),
+                            torch.from_numpy(_corners_to_rbox(qbox_corners)).to(dev), 1).cpu().numpy()
+    return np.where(np.asarray(standup_iou) > standup_thresh, inter, 0).astype(np.asarray(box_corners).dtype)
