@@ -144,6 +144,11 @@ int sec_pillar_scatter(const void *features, const int *coords, int p, int c, vo
                        size_t out_elems, int64_t stride_b, int64_t stride_c, int64_t stride_y,
                        int64_t stride_x, int dtype, void *stream);
 
+/* Dense RPN helper (second/pytorch/models/rpn.py:486-497: Conv2d -> BatchNorm2d -> ReLU): in-place
+ * y = relu?(x + bias[c]) on a channels-last [pixels, channels] activation (bias = folded BatchNorm). */
+int sec_bias_act_nhwc(void *x, const float *bias, size_t pixels, int channels, int relu, int dtype,
+                      void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Rotated IoU / NMS -- replace the numba.cuda kernels of second/core/non_max_suppression/nms_gpu.py
  * (rotate_iou_kernel_eval :564-602, rotate_nms_kernel :404-437, nms_kernel :70-101, nms_postprocess

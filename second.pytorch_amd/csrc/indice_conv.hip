@@ -15,6 +15,7 @@
 // the whole wave is skipped.  The kernel is bounded by the gather (HBM/L2 bytes), not by MFMA:
 // see DESIGN.md for the roofline arithmetic.
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace sec {
 
@@ -181,10 +182,678 @@ __global__ __launch_bounds__(kBlock) void k_conv_mfma(const T *__restrict__ feat
         }
 }
 
+// Split-K variant: the NW waves of a workgroup share ONE 32-row output tile and split the kernel offsets
+// (wave w takes offsets w, w+NW, ...).  Versus one-wave-per-tile this puts NW times more waves in flight and
+// shortens every wave's serial gather->MFMA chain NW-fold (the layer is latency-bound: ~440 workgroups of a
+// batch-8 subm2 layer leave a 256-CU chip at < 2 waves/SIMD otherwise).  Partial accumulators are reduced
+// through LDS in the MFMA register layout ([wave][reg][lane]: conflict-free), each wave finishing and
+// storing 1/NW of the tile's registers.
+// XCD-aware tile order (guide T1): workgroup b runs on XCD b % 8, so give XCD x the CONTIGUOUS tile range
+// [x * n/8, (x+1) * n/8): with spatially ordered rows every XCD's L2 then holds one slab of the feature matrix.
+__device__ __forceinline__ int xcd_tile(int b, int n, int swz) {
+    if (!swz) return b;
+    int per = (n + 7) / 8;
+    int t = (b % 8) * per + b / 8;
+    return t;   // may be >= n for the padded tail: callers bounds-check rows
+}
+
+__device__ long long *g_timeline = nullptr;
+
+static int conv_swizzle() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("SEC_CONV_XCD"); v = e ? atoi(e) : 1; }
+    return v;
+}
+  // profiling aid (tools/conv_microbench.py --timeline); null in production
+
+template <typename T, typename OT, int CIN, int COUT, int NW>
+__global__ __launch_bounds__(NW * 64) void k_conv_mfma_sk(const T *__restrict__ feat, const T *__restrict__ packed,
+                                                        const int *__restrict__ nbr, int n_out,
+                                                        const int *__restrict__ num_out_dev, int kvol,
+                                                        const float *__restrict__ scale, const float *__restrict__ shift,
+                                                        int relu, OT *__restrict__ out) {
+    long long *tl = g_timeline;
+    long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    if (tl) t0 = clock64();
+    constexpr int KS = CIN / 16, NT = (COUT + 31) / 32, NREG = NT * 16;
+    static_assert(NREG % NW == 0, "registers must split evenly over the waves");
+    __shared__ float red[NW][NREG][64];
+    if (num_out_dev) n_out = *num_out_dev;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const long long base = (long long)xcd_tile(blockIdx.x, gridDim.x, relu & 0x10000) * 32;
+    if (base >= n_out) return;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+
+    const long long row = base + r;
+    const bool valid = row < n_out;
+    const int *nrow = nbr + (size_t)(valid ? row : 0) * kvol;
+    const uint4 *wp = reinterpret_cast<const uint4 *>(packed) + lane;
+
+    if (tl) t1 = clock64();
+    const int ablate = (relu >> 8) & 0xff;  // debug/profiling only (SEC_CONV_ABLATE): bit0 gather row 0, bit1 one W block, bit2 no MFMA
+    int idx = (valid && w < kvol) ? nrow[w] : -1;
+    for (int k = w; k < kvol; k += NW) {
+        int cur = idx;
+        if (k + NW < kvol) idx = valid ? nrow[k + NW] : -1;  // prefetch this wave's next offset
+        if (__ballot(cur >= 0) == 0ull) continue;
+        if ((ablate & 1) && cur >= 0) cur = 0;
+        uint4 a[KS];
+        const uint4 *src = reinterpret_cast<const uint4 *>(feat + (size_t)(cur >= 0 ? cur : 0) * CIN) + h;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (cur >= 0) v = src[s * 2];
+            a[s] = v;
+        }
+        const uint4 *wk = wp + (size_t)((ablate & 2) ? 0 : k) * KS * NT * 64;
+        if (ablate & 4) {
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    uint4 b = wk[(s * NT + t) * 64];
+                    acc[t][0] += __uint_as_float(a[s].x ^ b.x);
+                }
+            continue;
+        }
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = Mfma<T>::run(a[s], wk[(s * NT + t) * 64], acc[t]);
+    }
+    relu &= 0xff;
+    if (tl) t2 = clock64();
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) red[w][t * 16 + i][lane] = acc[t][i];
+    __syncthreads();
+    if (tl) t3 = clock64();
+    constexpr int PER = NREG / NW;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int reg = w * PER + j;
+        float v = 0.0f;
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) v += red[ww][reg][lane];
+        const int t = reg >> 4, i = reg & 15;
+        const int col = t * 32 + r;
+        const long long orow = base + (i & 3) + 8 * (i >> 2) + 4 * h;
+        if (col < COUT && orow < n_out) out[(size_t)orow * COUT + col] = Cvt<OT>::from(epilogue(v, scale, shift, col, relu));
+    }
+    if (tl && lane == 0) {
+        long long *rec = tl + ((size_t)blockIdx.x * NW + w) * 6;
+        rec[0] = t0; rec[1] = t1; rec[2] = t2; rec[3] = t3; rec[4] = clock64();
+        rec[5] = __builtin_amdgcn_s_getreg((4 << 11) | 20);  // HW_REG_XCC_ID etc. (informative only)
+    }
+}
+
+// First layer of SpMiddleFHD (Cin = 4, middle.py:146): one thread per output row, all COUT channels in
+// registers, the 27 x 4 x COUT weight block broadcast from LDS, 8-byte (4 x bf16) gathers.
+template <typename T, typename OT, int COUT>
+__global__ __launch_bounds__(kBlock) void k_conv_c4(const T *__restrict__ feat, const T *__restrict__ w,
+                                                   const int *__restrict__ nbr, int n_out,
+                                                   const int *__restrict__ num_out_dev, int kvol,
+                                                   const float *__restrict__ scale, const float *__restrict__ shift,
+                                                   int relu, OT *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];  // [kvol][4][COUT]
+    if (num_out_dev) n_out = *num_out_dev;
+    for (int e = threadIdx.x; e < kvol * 4 * COUT; e += kBlock) wl[e] = Cvt<T>::to(w[e]);
+    __syncthreads();
+    long long o = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (o >= n_out) return;
+    float acc[COUT];
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) acc[c] = 0.0f;
+    const int *row = nbr + (size_t)o * kvol;
+    for (int k = 0; k < kvol; ++k) {
+        int idx = row[k];
+        if (idx < 0) continue;
+        float f[4];
+        if (sizeof(T) == 2) {
+            uint2 v = *reinterpret_cast<const uint2 *>(feat + (size_t)idx * 4);
+            const T *pv = reinterpret_cast<const T *>(&v);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) f[c] = Cvt<T>::to(pv[c]);
+        } else {
+            float4 v = *reinterpret_cast<const float4 *>(feat + (size_t)idx * 4);
+            f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+        }
+        const float *wk = wl + k * 4 * COUT;
+#pragma unroll
+        for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+            for (int c = 0; c < COUT; ++c) acc[c] = fmaf(f[ci], wk[ci * COUT + c], acc[c]);
+    }
+    OT *dst = out + (size_t)o * COUT;
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) dst[c] = Cvt<OT>::from(epilogue(acc[c], scale, shift, c, relu));
+}
+
+// Lock-step variant: the 4 waves of a workgroup own 4 x 32 consecutive rows and walk the offsets together,
+// so W[k] (the dominant L2 traffic of the one-wave-per-tile kernels: every wave re-reads all K weight blocks)
+// is fetched ONCE per workgroup and double-buffered in LDS; the next offset's weights and gathered rows are
+// in flight while the current offset's MFMAs run; one barrier per offset.  KVOL is a template constant so
+// the neighbour indices of all offsets live in registers (no dependent index->gather chain).
+template <typename T, typename OT, int CIN, int COUT, int KVOL>
+__global__ __launch_bounds__(kBlock) void k_conv_mfma_lds(const T *__restrict__ feat, const T *__restrict__ packed,
+                                                         const int *__restrict__ nbr, int n_out,
+                                                         const int *__restrict__ num_out_dev,
+                                                         const float *__restrict__ scale, const float *__restrict__ shift,
+                                                         int relu, OT *__restrict__ out) {
+    constexpr int KS = CIN / 16, NT = (COUT + 31) / 32, ENT = KS * NT * 64;   // uint4 entries of one W[k]
+    constexpr int PER = (ENT + kBlock - 1) / kBlock;
+    __shared__ uint4 wbuf[2][ENT];
+    if (num_out_dev) n_out = *num_out_dev;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const long long base = (long long)blockIdx.x * 128 + w * 32;
+    if ((long long)blockIdx.x * 128 >= n_out) return;
+    const long long row = base + r;
+    const bool valid = row < n_out;
+
+    int idxs[KVOL];
+    {
+        const int *nrow = nbr + (size_t)(valid ? row : 0) * KVOL;
+#pragma unroll
+        for (int k = 0; k < KVOL; ++k) idxs[k] = valid ? nrow[k] : -1;
+    }
+    const uint4 *wsrc = reinterpret_cast<const uint4 *>(packed);
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        int e = tid + j * kBlock;
+        if (e < ENT) wbuf[0][e] = wsrc[e];
+    }
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+
+    uint4 a_cur[KS], a_nxt[KS];
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(feat + (size_t)(idxs[0] >= 0 ? idxs[0] : 0) * CIN) + h;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) a_cur[s] = idxs[0] >= 0 ? src[s * 2] : make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < KVOL; ++k) {
+        uint4 wn[PER];
+        if (k + 1 < KVOL) {
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                int e = tid + j * kBlock;
+                if (e < ENT) wn[j] = wsrc[(size_t)(k + 1) * ENT + e];
+            }
+            const int ni = idxs[k + 1];
+            const uint4 *src = reinterpret_cast<const uint4 *>(feat + (size_t)(ni >= 0 ? ni : 0) * CIN) + h;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) a_nxt[s] = ni >= 0 ? src[s * 2] : make_uint4(0, 0, 0, 0);
+        }
+        if (__ballot(idxs[k] >= 0) != 0ull) {
+            const uint4 *wb = wbuf[k & 1] + lane;
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = Mfma<T>::run(a_cur[s], wb[(s * NT + t) * 64], acc[t]);
+        }
+        if (k + 1 < KVOL) {
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                int e = tid + j * kBlock;
+                if (e < ENT) wbuf[(k + 1) & 1][e] = wn[j];
+            }
+#pragma unroll
+            for (int s = 0; s < KS; ++s) a_cur[s] = a_nxt[s];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        int col = t * 32 + r;
+        if (col >= COUT) continue;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            long long orow = base + (i & 3) + 8 * (i >> 2) + 4 * h;
+            if (orow < n_out) out[(size_t)orow * COUT + col] = Cvt<OT>::from(epilogue(acc[t][i], scale, shift, col, relu));
+        }
+    }
+}
+
+// Lock-step variant 2: like k_conv_mfma_lds, but (a) the tile's neighbour table is staged in LDS (no
+// 27-register index array), (b) gathered rows are prefetched TWO offsets ahead through a 3-deep register ring,
+// (c) the next W block is loaded before the gathers are issued so that waiting for it leaves them in flight.
+template <typename T, typename OT, int CIN, int COUT, int KVOL>
+__global__ __launch_bounds__(kBlock) void k_conv_mfma_lds2(const T *__restrict__ feat, const T *__restrict__ packed,
+                                                          const int *__restrict__ nbr, int n_out,
+                                                          const int *__restrict__ num_out_dev,
+                                                          const float *__restrict__ scale, const float *__restrict__ shift,
+                                                          int relu, OT *__restrict__ out) {
+    constexpr int KS = CIN / 16, NT = (COUT + 31) / 32, ENT = KS * NT * 64;
+    constexpr int PER = (ENT + kBlock - 1) / kBlock;
+    __shared__ uint4 wbuf[2][ENT];
+    __shared__ int nidx[128 * KVOL];
+    if (num_out_dev) n_out = *num_out_dev;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const long long tile = (long long)blockIdx.x * 128;
+    if (tile >= n_out) return;
+    const long long base = tile + w * 32;
+    {
+        long long lim = (n_out - tile) * KVOL;  // ints of live rows in this tile
+        const int *src = nbr + (size_t)tile * KVOL;
+        for (int e = tid; e < 128 * KVOL; e += kBlock) nidx[e] = e < lim ? src[e] : -1;
+    }
+    const uint4 *wsrc = reinterpret_cast<const uint4 *>(packed);
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        int e = tid + j * kBlock;
+        if (e < ENT) wbuf[0][e] = wsrc[e];
+    }
+    __syncthreads();
+    const int *myidx = nidx + (w * 32 + r) * KVOL;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+    uint4 a[3][KS];
+    auto gather = [&](int k, uint4 *dst) {
+        const int ni = myidx[k];
+        const uint4 *src = reinterpret_cast<const uint4 *>(feat + (size_t)(ni >= 0 ? ni : 0) * CIN) + h;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) dst[s] = ni >= 0 ? src[s * 2] : make_uint4(0, 0, 0, 0);
+    };
+    gather(0, a[0]);
+    if (KVOL > 1) gather(1, a[1]);
+#pragma unroll
+    for (int k = 0; k < KVOL; ++k) {
+        uint4 wn[PER];
+        if (k + 1 < KVOL) {
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                int e = tid + j * kBlock;
+                if (e < ENT) wn[j] = wsrc[(size_t)(k + 1) * ENT + e];
+            }
+        }
+        if (k + 2 < KVOL) gather(k + 2, a[(k + 2) % 3]);
+        if (__ballot(myidx[k] >= 0) != 0ull) {
+            const uint4 *wb = wbuf[k & 1] + lane;
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = Mfma<T>::run(a[k % 3][s], wb[(s * NT + t) * 64], acc[t]);
+        }
+        if (k + 1 < KVOL) {
+#pragma unroll
+            for (int j = 0; j < PER; ++j) {
+                int e = tid + j * kBlock;
+                if (e < ENT) wbuf[(k + 1) & 1][e] = wn[j];
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        int col = t * 32 + r;
+        if (col >= COUT) continue;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            long long orow = base + (i & 3) + 8 * (i >> 2) + 4 * h;
+            if (orow < n_out) out[(size_t)orow * COUT + col] = Cvt<OT>::from(epilogue(acc[t][i], scale, shift, col, relu));
+        }
+    }
+}
+
+// Split-K with MT row tiles per workgroup (halves / quarters the weight traffic per row) and a pairwise LDS
+// reduction (2 slots): waves 1,3 -> 0,2 ; wave 2 -> 0 ; wave 0 stores.
+template <typename T, typename OT, int CIN, int COUT, int MT>
+__global__ __launch_bounds__(kBlock) void k_conv_mfma_skm(const T *__restrict__ feat, const T *__restrict__ packed,
+                                                         const int *__restrict__ nbr, int n_out,
+                                                         const int *__restrict__ num_out_dev, int kvol,
+                                                         const float *__restrict__ scale, const float *__restrict__ shift,
+                                                         int relu, OT *__restrict__ out) {
+    constexpr int KS = CIN / 16, NT = (COUT + 31) / 32, NREG = MT * NT * 16, NW = 4;
+    __shared__ float red[2][NREG][64];
+    if (num_out_dev) n_out = *num_out_dev;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const long long base = (long long)blockIdx.x * (32 * MT);
+    if (base >= n_out) return;
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[m][t][i] = 0.0f;
+    const int *nrow[MT];
+    bool valid[MT];
+    int idx[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        long long row = base + m * 32 + r;
+        valid[m] = row < n_out;
+        nrow[m] = nbr + (size_t)(valid[m] ? row : 0) * kvol;
+        idx[m] = (valid[m] && w < kvol) ? nrow[m][w] : -1;
+    }
+    const uint4 *wp = reinterpret_cast<const uint4 *>(packed) + lane;
+    for (int k = w; k < kvol; k += NW) {
+        int cur[MT];
+        bool any = false;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            cur[m] = idx[m];
+            any |= cur[m] >= 0;
+            if (k + NW < kvol) idx[m] = valid[m] ? nrow[m][k + NW] : -1;
+        }
+        if (__ballot(any) == 0ull) continue;
+        uint4 a[MT][KS];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(feat + (size_t)(cur[m] >= 0 ? cur[m] : 0) * CIN) + h;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) a[m][s] = cur[m] >= 0 ? src[s * 2] : make_uint4(0, 0, 0, 0);
+        }
+        const uint4 *wk = wp + (size_t)k * KS * NT * 64;
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                uint4 b = wk[(s * NT + t) * 64];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) acc[m][t] = Mfma<T>::run(a[m][s], b, acc[m][t]);
+            }
+    }
+    // pairwise reduction in the MFMA register layout
+    if (w & 1) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) red[w >> 1][(m * NT + t) * 16 + i][lane] = acc[m][t][i];
+    }
+    __syncthreads();
+    if (!(w & 1)) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[m][t][i] += red[w >> 1][(m * NT + t) * 16 + i][lane];
+    }
+    __syncthreads();
+    if (w == 2) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) red[0][(m * NT + t) * 16 + i][lane] = acc[m][t][i];
+    }
+    __syncthreads();
+    if (w != 0) return;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            int col = t * 32 + r;
+            if (col >= COUT) continue;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                float v = acc[m][t][i] + red[0][(m * NT + t) * 16 + i][lane];
+                long long orow = base + m * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (orow < n_out) out[(size_t)orow * COUT + col] = Cvt<OT>::from(epilogue(v, scale, shift, col, relu));
+            }
+        }
+}
+
+// Weights-resident variant: a 16-wave workgroup first copies ONE 32-column slice of ALL KVOL weight blocks into
+// LDS (27 x Cin x 32 bf16 = 110 KB for Cin = 64: only possible with CDNA4's 160 KB LDS), then every wave
+// computes one 32-row x 32-column output tile with the B fragments coming from LDS (ds_read_b128) and the
+// gathered A rows prefetched DEPTH offsets ahead through a register ring.  No weight bytes cross the vector
+// memory pipe in the main loop (they were 5x the gather bytes), so the registers they occupied buy prefetch
+// depth instead; grid = (row groups of 512, Cout/32 column slices).
+template <typename T, typename OT, int CIN, int COUT, int KVOL>
+__global__ __launch_bounds__(1024) void k_conv_wlds(const T *__restrict__ feat, const T *__restrict__ packed,
+                                                   const int *__restrict__ nbr, int n_out,
+                                                   const int *__restrict__ num_out_dev,
+                                                   const float *__restrict__ scale, const float *__restrict__ shift,
+                                                   int relu, OT *__restrict__ out) {
+    constexpr int KS = CIN / 16, NT = (COUT + 31) / 32, ENT = KVOL * KS * 64, DEPTH = 3;
+    extern __shared__ __attribute__((aligned(16))) uint4 wlds_smem[];   // [KVOL][KS][64 lanes]
+    uint4 *wl = wlds_smem;
+    if (num_out_dev) n_out = *num_out_dev;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int t = blockIdx.y;
+    const long long tile0 = (long long)xcd_tile(blockIdx.x, gridDim.x, relu & 0x10000) * 512;
+    relu &= 0xff;
+    if (tile0 >= n_out) return;
+    const long long base = tile0 + w * 32;
+    const long long row = base + r;
+    const bool valid = row < n_out;
+
+    const uint4 *wsrc = reinterpret_cast<const uint4 *>(packed);
+    for (int e = tid; e < ENT; e += 1024) {
+        int ks = e >> 6, l = e & 63;                      // ks = k*KS + s
+        wl[e] = wsrc[((size_t)ks * NT + t) * 64 + l];
+    }
+    int idxs[KVOL];
+    {
+        const int *nrow = nbr + (size_t)(valid ? row : 0) * KVOL;
+#pragma unroll
+        for (int k = 0; k < KVOL; ++k) idxs[k] = valid ? nrow[k] : -1;
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    uint4 a[DEPTH][KS];
+    auto gather = [&](int k, uint4 *dst) {
+        const int ni = idxs[k];
+        const uint4 *src = reinterpret_cast<const uint4 *>(feat + (size_t)(ni >= 0 ? ni : 0) * CIN) + h;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) dst[s] = ni >= 0 ? src[s * 2] : make_uint4(0, 0, 0, 0);
+    };
+#pragma unroll
+    for (int k = 0; k < DEPTH - 1 && k < KVOL; ++k) gather(k, a[k]);
+    __syncthreads();
+    if (base < n_out) {
+#pragma unroll
+        for (int k = 0; k < KVOL; ++k) {
+            if (k + DEPTH - 1 < KVOL) gather(k + DEPTH - 1, a[(k + DEPTH - 1) % DEPTH]);
+            if (__ballot(idxs[k] >= 0) != 0ull) {
+                const uint4 *wb = wl + (k * KS) * 64 + lane;
+#pragma unroll
+                for (int s = 0; s < KS; ++s) acc = Mfma<T>::run(a[k % DEPTH][s], wb[s * 64], acc);
+            }
+        }
+        const int col = t * 32 + r;
+        if (col < COUT) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                long long orow = base + (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (orow < n_out) out[(size_t)orow * COUT + col] = Cvt<OT>::from(epilogue(acc[i], scale, shift, col, relu));
+            }
+        }
+    }
+}
+
+// Weights-resident + full-line gathers: as k_conv_wlds, but every gather instruction fetches WHOLE input rows
+// (Cin = 64: 8 lanes x 16 B = one 128-byte line per row, 8 rows per instruction) instead of the MFMA-fragment
+// shape (32 rows x 32 B per instruction = 4 line touches per row), and the rows are transposed into the
+// fragment layout through a 4 KB per-wave LDS staging tile with an XOR swizzle (conflict-free ds_read_b128).
+// Fragment-shaped loads were measured to keep the texture-address unit ~2x busier at identical traffic.
+template <typename T, typename OT, int CIN, int COUT, int KVOL>
+__global__ __launch_bounds__(512) void k_conv_wlds_fl(const T *__restrict__ feat, const T *__restrict__ packed,
+                                                     const int *__restrict__ nbr, int n_out,
+                                                     const int *__restrict__ num_out_dev,
+                                                     const float *__restrict__ scale, const float *__restrict__ shift,
+                                                     int relu, OT *__restrict__ out) {
+    constexpr int KS = CIN / 16, NT = (COUT + 31) / 32, ENT = KVOL * KS * 64, DEPTH = 3, NWAVE = 8;
+    constexpr int CH = CIN / 8;          // 16-byte chunks per row
+    constexpr int RPI = 64 / CH;         // rows fetched per gather instruction
+    constexpr int NI = 32 / RPI;         // gather instructions per 32-row tile (== KS)
+    extern __shared__ __attribute__((aligned(16))) uint4 wlds_fl_smem[];
+    uint4 *wl = wlds_fl_smem;                      // [KVOL][KS][64]
+    if (num_out_dev) n_out = *num_out_dev;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    uint4 *stage = wlds_fl_smem + ENT + w * (32 * CH);   // this wave's [32 rows][CH] staging tile
+    const int r = lane & 31, h = lane >> 5;
+    const int t = blockIdx.y;
+    if ((long long)blockIdx.x * (32 * NWAVE) >= n_out) return;
+    const long long base = (long long)blockIdx.x * (32 * NWAVE) + w * 32;
+    const long long row = base + r;
+    const bool valid = row < n_out;
+
+    const uint4 *wsrc = reinterpret_cast<const uint4 *>(packed);
+    for (int e = tid; e < ENT; e += 64 * NWAVE) {
+        int ks = e >> 6, l = e & 63;
+        wl[e] = wsrc[((size_t)ks * NT + t) * 64 + l];
+    }
+    int idxs[KVOL];
+    {
+        const int *nrow = nbr + (size_t)(valid ? row : 0) * KVOL;
+#pragma unroll
+        for (int k = 0; k < KVOL; ++k) idxs[k] = valid ? nrow[k] : -1;
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    const int lrow = lane / CH, lch = lane % CH;   // full-line mapping: instruction j fetches rows lrow + j*RPI
+    uint4 a[DEPTH][NI];
+    auto gather = [&](int k, uint4 *dst) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int ni = __shfl(idxs[k], lrow + j * RPI, 64);
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (ni >= 0) v = reinterpret_cast<const uint4 *>(feat + (size_t)ni * CIN)[lch];
+            dst[j] = v;
+        }
+    };
+#pragma unroll
+    for (int k = 0; k < DEPTH - 1 && k < KVOL; ++k) gather(k, a[k]);
+    __syncthreads();
+    if (base < n_out) {
+#pragma unroll
+        for (int k = 0; k < KVOL; ++k) {
+            if (k + DEPTH - 1 < KVOL) gather(k + DEPTH - 1, a[(k + DEPTH - 1) % DEPTH]);
+            if (__ballot(idxs[k] >= 0) != 0ull) {
+#pragma unroll
+                for (int j = 0; j < NI; ++j) {
+                    const int rr = lrow + j * RPI;
+                    stage[rr * CH + (lch ^ (rr & (CH - 1)))] = a[k % DEPTH][j];
+                }
+                const uint4 *wb = wl + (k * KS) * 64 + lane;
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    uint4 af = stage[r * CH + ((2 * s + h) ^ (r & (CH - 1)))];
+                    acc = Mfma<T>::run(af, wb[s * 64], acc);
+                }
+            }
+        }
+        const int col = t * 32 + r;
+        if (col < COUT) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                long long orow = base + (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (orow < n_out) out[(size_t)orow * COUT + col] = Cvt<OT>::from(epilogue(acc[i], scale, shift, col, relu));
+            }
+        }
+    }
+}
+
+template <typename T, typename OT, int CIN, int COUT>
+static void launch_wlds_fl(const void *feat, const void *packed, const int *nbr, int n_out, const int *num_out_dev,
+                           const float *scale, const float *shift, int relu, void *out, hipStream_t st) {
+    constexpr int KVOL = 27;
+    constexpr size_t lds = ((size_t)KVOL * (CIN / 16) * 64 + 8 * 32 * (CIN / 8)) * 16;
+    static bool configured = false;
+    auto fn = k_conv_wlds_fl<T, OT, CIN, COUT, KVOL>;
+    if (!configured) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        configured = true;
+    }
+    hipLaunchKernelGGL(fn, dim3(div_up(n_out, 256), (COUT + 31) / 32), dim3(512), lds, st, (const T *)feat,
+                       (const T *)packed, nbr, n_out, num_out_dev, scale, shift, relu, (OT *)out);
+}
+
+template <typename T, typename OT, int CIN, int COUT>
+static void launch_wlds(const void *feat, const void *packed, const int *nbr, int n_out, const int *num_out_dev,
+                        const float *scale, const float *shift, int relu, void *out, hipStream_t st) {
+    constexpr int KVOL = 27;
+    constexpr size_t lds = (size_t)KVOL * (CIN / 16) * 64 * 16;
+    static bool configured = false;
+    auto fn = k_conv_wlds<T, OT, CIN, COUT, KVOL>;
+    if (!configured) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        configured = true;
+    }
+    hipLaunchKernelGGL(fn, dim3((div_up(n_out, 512) + 7) / 8 * 8, (COUT + 31) / 32), dim3(1024), lds, st, (const T *)feat,
+                       (const T *)packed, nbr, n_out, num_out_dev, scale, shift, relu | (conv_swizzle() << 16), (OT *)out);
+}
+
+static int conv_ablate() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("SEC_CONV_ABLATE"); v = e ? atoi(e) : 0; }
+    return v;
+}
+
+static int conv_variant() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("SEC_CONV_VARIANT");
+        v = e ? atoi(e) : 1;  // 0 = one wave per 32-row tile, 1 = split-K over 4 waves, 2 = lock-step + W in LDS (kvol 27)
+    }
+    return v;
+}
+
 template <typename T, typename OT, int CIN, int COUT>
 static void launch_mfma(const void *feat, const void *packed, const int *nbr, int n_out, const int *num_out_dev,
                         int kvol, const float *scale, const float *shift, int relu, void *out, hipStream_t st) {
     constexpr int MT = 1;
+    if (conv_variant() == 2 && kvol == 27) {
+        hipLaunchKernelGGL((k_conv_mfma_lds<T, OT, CIN, COUT, 27>), dim3(div_up(n_out, 128)), dim3(kBlock), 0, st,
+                           (const T *)feat, (const T *)packed, nbr, n_out, num_out_dev, scale, shift, relu, (OT *)out);
+        return;
+    }
+    if (conv_variant() == 7 && kvol == 27 && CIN <= 64 && CIN >= 32) {
+        launch_wlds_fl<T, OT, CIN, COUT>(feat, packed, nbr, n_out, num_out_dev, scale, shift, relu, out, st);
+        return;
+    }
+    if ((conv_variant() == 6 || conv_variant() == 7) && kvol == 27 && CIN <= 64) {
+        launch_wlds<T, OT, CIN, COUT>(feat, packed, nbr, n_out, num_out_dev, scale, shift, relu, out, st);
+        return;
+    }
+    if (conv_variant() == 3 && kvol == 27) {
+        hipLaunchKernelGGL((k_conv_mfma_lds2<T, OT, CIN, COUT, 27>), dim3(div_up(n_out, 128)), dim3(kBlock), 0, st,
+                           (const T *)feat, (const T *)packed, nbr, n_out, num_out_dev, scale, shift, relu, (OT *)out);
+        return;
+    }
+    if (conv_variant() == 4 || conv_variant() == 5) {
+        if (conv_variant() == 4)
+            hipLaunchKernelGGL((k_conv_mfma_skm<T, OT, CIN, COUT, 2>), dim3(div_up(n_out, 64)), dim3(kBlock), 0, st,
+                               (const T *)feat, (const T *)packed, nbr, n_out, num_out_dev, kvol, scale, shift, relu, (OT *)out);
+        else
+            hipLaunchKernelGGL((k_conv_mfma_skm<T, OT, CIN, COUT, 1>), dim3(div_up(n_out, 32)), dim3(kBlock), 0, st,
+                               (const T *)feat, (const T *)packed, nbr, n_out, num_out_dev, kvol, scale, shift, relu, (OT *)out);
+        return;
+    }
+    if (conv_variant() >= 1) {
+        constexpr int NW = 4;
+        hipLaunchKernelGGL((k_conv_mfma_sk<T, OT, CIN, COUT, NW>), dim3((div_up(n_out, 32) + 7) / 8 * 8), dim3(NW * 64), 0, st,
+                           (const T *)feat, (const T *)packed, nbr, n_out, num_out_dev, kvol, scale, shift,
+                           relu | (conv_ablate() << 8) | (conv_swizzle() << 16), (OT *)out);
+        return;
+    }
     int rows_per_block = (kBlock / 64) * 32 * MT;
     hipLaunchKernelGGL((k_conv_mfma<T, OT, CIN, COUT, MT>), dim3(div_up(n_out, rows_per_block)), dim3(kBlock), 0, st,
                        (const T *)feat, (const T *)packed, nbr, n_out, num_out_dev, kvol, scale, shift, relu, (OT *)out);
@@ -209,6 +878,11 @@ template <typename T, typename OT>
 static void launch_generic(const void *feat, const void *w, const int *nbr, int n_out, const int *num_out_dev, int cin,
                            int cout, int kvol, const float *scale, const float *shift, int relu, void *out,
                            hipStream_t st) {
+    if (cin == 4 && cout == 16 && kvol * 4 * 16 * sizeof(float) <= 48 * 1024) {
+        hipLaunchKernelGGL((k_conv_c4<T, OT, 16>), dim3(div_up(n_out, kBlock)), dim3(kBlock), kvol * 4 * 16 * sizeof(float), st,
+                           (const T *)feat, (const T *)w, nbr, n_out, num_out_dev, kvol, scale, shift, relu, (OT *)out);
+        return;
+    }
     long long total = (long long)n_out * cout;
     int blocks = div_up(total, kBlock);
     if (blocks > 256 * 64) blocks = 256 * 64;
@@ -263,6 +937,10 @@ static size_t elt_size(int dtype) { return dtype == SEC_F32 ? 4 : 2; }
 }  // namespace sec
 
 using namespace sec;
+
+extern "C" __attribute__((visibility("default"))) int sec__debug_timeline(long long *buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(sec::g_timeline), &buf, sizeof(buf)) == hipSuccess ? 0 : -4;
+}
 
 SEC_API size_t sec_packed_weight_bytes(int kvol, int cin, int cout, int dtype) {
     if (dtype == SEC_F32 || cin % 16 != 0 || kvol <= 0 || cout <= 0) return 0;

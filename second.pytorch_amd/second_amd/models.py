@@ -208,6 +208,66 @@ def fold_conv_bn_(seq):
     return nn.Sequential(*out)
 
 
+class RPNInference(nn.Module):
+    """Inference form of a single-block RPNV2: BatchNorm2d folded into the conv weights (scale) and a float32
+    bias, every conv issued bias-free through MIOpen followed by ONE fused in-place bias+ReLU pass
+    (sec_bias_act_nhwc), ZeroPad2d merged into the conv padding, the stride-1 1x1 ConvTranspose2d rewritten as
+    a 1x1 conv, the three 1x1 heads merged into one conv (output channels padded to a multiple of 8).
+    Same arithmetic as RPNV2.forward (rpn.py:314-331,393-420) up to bf16 rounding of the folded weights."""
+
+    def __init__(self, rpn, dtype):
+        super().__init__()
+        assert len(rpn.blocks) == 1 and len(rpn.deblocks) == 1
+        self.a, self.codes = rpn._num_anchor_per_loc, (rpn._box_code_size, rpn._num_class, rpn._num_direction_bins)
+        layers, pad = [], 0
+        mods = list(rpn.blocks[0].children()) + list(rpn.deblocks[0].children())
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, nn.ZeroPad2d):
+                pad = m.padding[0]
+            elif isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+                bn = mods[i + 1]
+                assert isinstance(bn, nn.BatchNorm2d) and m.bias is None
+                scale = bn.weight.float() * torch.rsqrt(bn.running_var.float() + bn.eps)
+                bias = bn.bias.float() - bn.running_mean.float() * scale
+                w = m.weight.detach().float()
+                if isinstance(m, nn.ConvTranspose2d):
+                    assert m.kernel_size == (1, 1) and m.stride == (1, 1)
+                    w = w.permute(1, 0, 2, 3)
+                    stride, padding = [1, 1], [0, 0]
+                else:
+                    stride, padding = list(m.stride), [m.padding[0] + pad, m.padding[1] + pad]
+                w = (w * scale.view(-1, 1, 1, 1)).to(dtype).contiguous(memory_format=torch.channels_last)
+                layers.append((w, bias.detach().contiguous(), stride, padding))
+                pad = 0
+                i += 1
+            i += 1
+        self.ws = nn.ParameterList([nn.Parameter(w, requires_grad=False) for w, _, _, _ in layers])
+        self.bs = nn.ParameterList([nn.Parameter(b, requires_grad=False) for _, b, _, _ in layers])
+        self.cfgs = [(s, p) for _, _, s, p in layers]
+        heads = [rpn.conv_box, rpn.conv_cls] + ([rpn.conv_dir_cls] if rpn._use_direction_classifier else [])
+        self.splits = [h.out_channels for h in heads]
+        tot = sum(self.splits)
+        padc = (-tot) % 8
+        hw = torch.cat([h.weight.detach().float() for h in heads] + [torch.zeros(padc, heads[0].in_channels, 1, 1, device=heads[0].weight.device)], 0)
+        hb = torch.cat([h.bias.detach().float() for h in heads] + [torch.zeros(padc, device=heads[0].weight.device)], 0)
+        self.head_w = nn.Parameter(hw.to(dtype).contiguous(memory_format=torch.channels_last), requires_grad=False)
+        self.head_b = nn.Parameter(hb.contiguous(), requires_grad=False)
+
+    def forward(self, x):
+        for w, b, (s, p) in zip(self.ws, self.bs, self.cfgs):
+            x = ops.bias_act_(F.conv2d(x, w, None, s, p), b, relu=True)
+        y = ops.bias_act_(F.conv2d(x, self.head_w, None), self.head_b, relu=False)
+        n, _, h, wd = y.shape
+        ret, c0 = {}, 0
+        for name, sz, code in zip(["box_preds", "cls_preds", "dir_cls_preds"], self.splits, self.codes):
+            o = y[:, c0:c0 + sz]
+            c0 += sz
+            ret[name] = o.reshape(n, self.a, code, h, wd).permute(0, 1, 3, 4, 2).contiguous()
+        return ret
+
+
 # ------------------------------------------------------------------------------------------ detector
 def limit_period(val, offset, period):
     return val - torch.floor(val / period + offset) * period
@@ -247,9 +307,12 @@ class SecondDetector(nn.Module):
         # 3x3 conv for bf16 NHWC on gfx950 (naive fallback kernel) vs 0.14 ms unfused -- not an option; the
         # fused dense path is the hand-written MFMA conv.
         self.eval()
-        self.rpn.blocks = nn.ModuleList([fold_conv_bn_(b) for b in self.rpn.blocks])
-        self.rpn.deblocks = nn.ModuleList([fold_conv_bn_(b) for b in self.rpn.deblocks])
-        self.rpn.to(dtype).to(memory_format=torch.channels_last)
+        if len(self.rpn.blocks) == 1 and len(self.rpn.deblocks) == 1 and next(self.parameters()).is_cuda:
+            self.rpn = RPNInference(self.rpn, dtype)
+        else:
+            self.rpn.blocks = nn.ModuleList([fold_conv_bn_(b) for b in self.rpn.blocks])
+            self.rpn.deblocks = nn.ModuleList([fold_conv_bn_(b) for b in self.rpn.deblocks])
+            self.rpn.to(dtype).to(memory_format=torch.channels_last)
         for m in self.middle_feature_extractor.modules():
             if isinstance(m, spconv.SparseConvolution):
                 m.weight.data = m.weight.data.to(dtype)
@@ -361,8 +424,8 @@ class SecondDetector(nn.Module):
         else:
             raise NotImplementedError("axis-aligned predict path (nuscenes all.fhd) comes with SURVEY row a19 wiring")
         p = min(cfg["nms_post_max_size"], keep.shape[1])
-        sel = keep[:, :p].long().clamp_(min=0, max=dets.shape[1] - 1)
         valid = self._arange_p[:p].unsqueeze(0) < num_keep.unsqueeze(1)
+        sel = torch.where(valid, keep[:, :p], torch.zeros_like(keep[:, :p])).long()   # slots past num_keep are undefined
         boxes = torch.gather(dec, 1, sel.unsqueeze(-1).expand(-1, -1, 7))
         scores = torch.gather(top_scores, 1, sel)
         if dir_labels is not None:

@@ -171,7 +171,10 @@ def indice_conv(features, weight, nbr_out, num_out, packed=None, scale=None, shi
     if _conv_profiler is not None:
         token = _conv_profiler.begin({"cin": cin, "cout": cout, "kvol": k, "n_in": features.shape[0],
                                       "n_out": int(num_out), "dtype": features.dtype, "nbr_out": nbr_out,
-                                      "mfma": packed is not None, "num_out_dev": num_out_dev})
+                                      "mfma": packed is not None, "num_out_dev": num_out_dev,
+                                      "args": {"pos": (features, weight, nbr_out, num_out),
+                                               "kw": dict(packed=packed, scale=scale, shift=shift, relu=relu,
+                                                          out_dtype=out_dtype, num_out_dev=num_out_dev)}})
     rc = rt.lib().sec_indice_conv_fwd(rt.ptr(features), features.shape[0], cin, rt.ptr(weight), rt.ptr(packed), k, cout,
                                       rt.ptr(nbr_out), int(num_out), rt.ptr(num_out_dev), rt.ptr(scale), rt.ptr(shift),
                                       int(bool(relu)), rt.ptr(out), rt.dtype_code(features.dtype),
@@ -232,6 +235,24 @@ def pillar_scatter(features, coords, batch_size, ny, nx, channels_last=False):
                                      int(sb), int(sc), int(sy), int(sx), rt.dtype_code(features.dtype), rt.stream())
     rt.check(rc, "sec_pillar_scatter")
     return out
+
+
+def bias_act_(x, bias, relu=True):
+    """In place y = relu?(x + bias[c]) on a channels-last activation [B,C,H,W] (or [P,C]); bias float32 [C].
+    The folded-BatchNorm bias + ReLU that follows every RPN conv (rpn.py:486-497), one pass."""
+    rt.require_gpu(x, bias)
+    assert bias.dtype == torch.float32 and bias.is_contiguous()
+    if x.dim() == 4:
+        assert x.is_contiguous(memory_format=torch.channels_last), "bias_act_ expects channels_last"
+        c = x.shape[1]
+    else:
+        assert x.is_contiguous()
+        c = x.shape[-1]
+    assert bias.numel() == c
+    rc = rt.lib().sec_bias_act_nhwc(rt.ptr(x), rt.ptr(bias), x.numel() // c, c, int(bool(relu)), rt.dtype_code(x.dtype),
+                                    rt.stream())
+    rt.check(rc, "sec_bias_act_nhwc")
+    return x
 
 
 # ----------------------------------------------------------------------------- IoU / NMS

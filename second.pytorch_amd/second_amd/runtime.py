@@ -21,7 +21,7 @@ SYMBOLS = [
     "sec_rulebook_workspace_bytes", "sec_rulebook_subm3d", "sec_rulebook_conv3d_build",
     "sec_rulebook_conv3d_tables", "sec_conv_output_shape", "sec_packed_weight_bytes",
     "sec_pack_conv_weight", "sec_indice_conv_fwd", "sec_indice_conv_bwd", "sec_sparse_to_dense",
-    "sec_pillar_scatter", "sec_rotate_iou_f32", "sec_nms_workspace_bytes", "sec_nms_sorted_f32",
+    "sec_pillar_scatter", "sec_bias_act_nhwc", "sec_rotate_iou_f32", "sec_nms_workspace_bytes", "sec_nms_sorted_f32",
 ]
 
 _lib = None
@@ -59,6 +59,7 @@ def lib():
         l.sec_indice_conv_bwd.argtypes = [vp, ci, ci, vp, ci, ci, vp, vp, ci, vp, vp, vp, ci, vp]
         l.sec_sparse_to_dense.argtypes = [vp, vp, ci, ci, vp, vp, sz, i64, i64, i64, i64, i64, ci, vp]
         l.sec_pillar_scatter.argtypes = [vp, vp, ci, ci, vp, sz, i64, i64, i64, i64, ci, vp]
+        l.sec_bias_act_nhwc.argtypes = [vp, vp, sz, ci, ci, ci, vp]
         l.sec_rotate_iou_f32.argtypes = [vp, ci, vp, ci, ci, vp, vp]
         l.sec_nms_workspace_bytes.argtypes = [ci, ci]
         l.sec_nms_sorted_f32.argtypes = [vp, vp, ci, ci, ci, cf, ci, ci, cf, ci, vp, vp, vp, sz, vp]
