@@ -144,6 +144,27 @@ int sec_pillar_scatter(const void *features, const int *coords, int p, int c, vo
                        size_t out_elems, int64_t stride_b, int64_t stride_c, int64_t stride_y,
                        int64_t stride_x, int dtype, void *stream);
 
+/* PillarFeatureNet.forward with a single PFNLayer in eval mode (second/pytorch/models/pointpillars.py:
+ * 203-237, 51-65; config nuscenes/all.pp.largea.config:10-15): point decoration (cluster / pillar-centre
+ * offsets), Linear(F+5 -> C, no bias; weight_t = weight^T [F+5, C]), folded BatchNorm1d (scale, shift), ReLU,
+ * max over the max_points slots -- one launch.  voxels [P, max_points, 4] fp32, coords [P,4] (b,z,y,x). */
+int sec_pfn_fwd(const float *voxels, const int *num_points, const int *coords, int num_pillars,
+                const int *num_dev, int max_points, int num_features, const float *weight_t,
+                const float *scale, const float *shift, int channels, float vx, float vy,
+                float x_offset, float y_offset, void *out, int out_dtype, void *stream);
+
+/* Block filtering of points_to_voxel_3d_with_filtering (spconv point2voxel.h; enabled by
+ * second/configs/nuscenes/all.fhd.config:9-12): keep a voxel iff the z-span of the stored points inside the
+ * block_size x block_size block window around it lies in (height_threshold, height_high_threshold); the
+ * voxel arrays are compacted in order.  Input = output layout of sec_voxelize_f32 (coors (b,z,y,x)). */
+size_t sec_block_filter_workspace_bytes(int rows, int batch, int grid_x, int grid_y, int block_factor);
+int sec_voxel_block_filter_f32(const float *voxels, const int *coors, const int *num_points,
+                               const int *voxel_offsets, int rows, int batch, int max_points,
+                               int num_features, int grid_x, int grid_y, int block_factor, int block_size,
+                               float height_threshold, float height_high_threshold, float *out_voxels,
+                               int *out_coors, int *out_num_points, int *out_offsets, void *workspace,
+                               size_t workspace_bytes, void *stream);
+
 /* Dense RPN helper (second/pytorch/models/rpn.py:486-497: Conv2d -> BatchNorm2d -> ReLU): in-place
  * y = relu?(x + bias[c]) on a channels-last [pixels, channels] activation (bias = folded BatchNorm). */
 int sec_bias_act_nhwc(void *x, const float *bias, size_t pixels, int channels, int relu, int dtype,

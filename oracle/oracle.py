@@ -227,3 +227,28 @@ def box_decode(encodings, anchors):
     out = np.zeros_like(enc)
     lib().orc_box_decode(_fp(enc), _fp(anc), enc.shape[0], _fp(out))
     return out
+
+
+def pfn_forward(voxels, num_points, coords, weight_t, scale, shift, vx, vy, x_offset, y_offset):
+    """orc_pfn_fwd: weight_t [F+5, C] (= PFNLayer.linear.weight.T), scale/shift = folded eval BatchNorm1d."""
+    voxels, num_points, coords = _f(voxels), _i(num_points), _i(coords)
+    p, t, f = voxels.shape
+    weight_t, scale, shift = _f(weight_t), _f(scale), _f(shift)
+    c = weight_t.shape[1]
+    out = np.zeros((p, c), np.float32)
+    cf = ctypes.c_float
+    lib().orc_pfn_fwd(_fp(voxels), _ip(num_points), _ip(coords), p, t, f, _fp(weight_t), _fp(scale), _fp(shift), c,
+                      cf(vx), cf(vy), cf(x_offset), cf(y_offset), _fp(out))
+    return out
+
+
+def block_filter(voxels, coors, num_points, grid_size_xy, block_factor, block_size, height_threshold,
+                 height_high_threshold=3.0):
+    """orc_block_filter -> bool mask [V] (coors are (z,y,x))."""
+    voxels, coors, num_points = _f(voxels), _i(coors), _i(num_points)
+    v, t, f = voxels.shape
+    keep = np.zeros((v,), np.uint8)
+    lib().orc_block_filter(_fp(voxels), _ip(coors), _ip(num_points), v, t, f, int(grid_size_xy[0]), int(grid_size_xy[1]),
+                           int(block_factor), int(block_size), ctypes.c_float(height_threshold),
+                           ctypes.c_float(height_high_threshold), keep.ctypes.data_as(ctypes.POINTER(ctypes.c_ubyte)))
+    return keep.astype(bool)

@@ -644,3 +644,102 @@ ORC_API void orc_box_decode(const float *enc, const float *anchors, int N, float
         g[6] = t[6] + a[6];
     }
 }
+
+/* ------------------------------------------------------------------------ */
+/* a20: PillarFeatureNet.forward with ONE PFNLayer (last_layer=True) in eval  */
+/* mode (second/pytorch/models/pointpillars.py:203-237 + PFNLayer :51-65):    */
+/* decorate each point with (xyz - mean of the pillar's points) and           */
+/* (xy - pillar centre), zero the padded slots, Linear(F+5 -> C, no bias),    */
+/* BatchNorm1d folded to scale/shift, ReLU, max over ALL T slots (padded      */
+/* slots contribute relu(shift), as in the reference).                        */
+/* voxels [P,T,F], coords [P,4] (b,z,y,x), W [F+5, C] (= linear.weight^T).    */
+/* ------------------------------------------------------------------------ */
+ORC_API void orc_pfn_fwd(const float *voxels, const int *num_points, const int *coords, int P, int T,
+                         int F, const float *W, const float *scale, const float *shift, int C,
+                         float vx, float vy, float x_offset, float y_offset, float *out)
+{
+    const int IN = F + 5;
+    float *feat = (float *)malloc((size_t)IN * sizeof(float));
+    for (int p = 0; p < P; ++p) {
+        const float *v = voxels + (size_t)p * T * F;
+        int n = num_points[p];
+        float mean[3];
+        for (int j = 0; j < 3; ++j) {
+            float s = 0.0f;
+            for (int t = 0; t < T; ++t) s += v[(size_t)t * F + j];
+            mean[j] = s / (float)n;
+        }
+        float cx = (float)coords[p * 4 + 3] * vx + x_offset;
+        float cy = (float)coords[p * 4 + 2] * vy + y_offset;
+        float *o = out + (size_t)p * C;
+        for (int c = 0; c < C; ++c) o[c] = -INFINITY;
+        for (int t = 0; t < T; ++t) {
+            const float *pt = v + (size_t)t * F;
+            if (t < n) {
+                for (int j = 0; j < F; ++j) feat[j] = pt[j];
+                for (int j = 0; j < 3; ++j) feat[F + j] = pt[j] - mean[j];
+                feat[F + 3] = pt[0] - cx;
+                feat[F + 4] = pt[1] - cy;
+            } else {
+                for (int j = 0; j < IN; ++j) feat[j] = 0.0f;
+            }
+            for (int c = 0; c < C; ++c) {
+                float y = 0.0f;
+                for (int j = 0; j < IN; ++j) y += feat[j] * W[(size_t)j * C + c];
+                y = y * scale[c] + shift[c];
+                if (y < 0.0f) y = 0.0f;
+                if (y > o[c]) o[c] = y;
+            }
+        }
+    }
+    free(feat);
+}
+
+/* ------------------------------------------------------------------------ */
+/* a4: block filtering of points_to_voxel_3d_with_filtering (SURVEY A.2,      */
+/* spconv point2voxel.h [recall, constants UNVERIFIED]; enabled by            */
+/* second/configs/nuscenes/all.fhd.config:9-12).  Given the voxelisation      */
+/* result, build per-(y,x)-block min/max of the z of the STORED points, then  */
+/* keep voxel v iff the height span over the block_size x block_size window   */
+/* around its block lies in (height_threshold, height_high_threshold).        */
+/* Returns the number of kept voxels; keep[v] in {0,1}.                       */
+/* ------------------------------------------------------------------------ */
+ORC_API int orc_block_filter(const float *voxels, const int *coors /*[V,3] z,y,x*/, const int *num_points,
+                             int V, int T, int F, int grid_x, int grid_y, int block_factor, int block_size,
+                             float height_threshold, float height_high_threshold, unsigned char *keep)
+{
+    const int bx = (grid_x + block_factor - 1) / block_factor, by = (grid_y + block_factor - 1) / block_factor;
+    float *mins = (float *)malloc((size_t)bx * by * sizeof(float));
+    float *maxs = (float *)malloc((size_t)bx * by * sizeof(float));
+    for (int i = 0; i < bx * by; ++i) { mins[i] = 99999999.0f; maxs[i] = -99999999.0f; }
+    for (int v = 0; v < V; ++v) {
+        int cy = coors[v * 3 + 1] / block_factor, cx = coors[v * 3 + 2] / block_factor;
+        for (int t = 0; t < num_points[v] && t < T; ++t) {
+            float z = voxels[((size_t)v * T + t) * F + 2];
+            if (z < mins[cy * bx + cx]) mins[cy * bx + cx] = z;
+            if (z > maxs[cy * bx + cx]) maxs[cy * bx + cx] = z;
+        }
+    }
+    int kept = 0;
+    for (int v = 0; v < V; ++v) {
+        int cy = coors[v * 3 + 1] / block_factor, cx = coors[v * 3 + 2] / block_factor;
+        int y0 = cy - block_size / 2, y1 = cy + block_size - block_size / 2;
+        int x0 = cx - block_size / 2, x1 = cx + block_size - block_size / 2;
+        if (y0 < 0) y0 = 0;
+        if (x0 < 0) x0 = 0;
+        if (y1 > by) y1 = by;
+        if (x1 > bx) x1 = bx;
+        float hmin = 99999999.0f, hmax = -99999999.0f;
+        for (int y = y0; y < y1; ++y)
+            for (int x = x0; x < x1; ++x) {
+                if (mins[y * bx + x] < hmin) hmin = mins[y * bx + x];
+                if (maxs[y * bx + x] > hmax) hmax = maxs[y * bx + x];
+            }
+        float span = hmax - hmin;
+        keep[v] = (span > height_threshold && span < height_high_threshold) ? 1 : 0;
+        kept += keep[v];
+    }
+    free(mins);
+    free(maxs);
+    return kept;
+}

@@ -38,6 +38,28 @@ CAR_FHD = dict(
 )  # second/configs/car.fhd.config
 
 
+ALL_PP_LARGEA = dict(
+    name="nuscenes/all.pp.largea",
+    point_cloud_range=[-50, -50, -10, 50, 50, 10], voxel_size=[0.25, 0.25, 20], max_points_per_voxel=60,
+    max_voxels=30000, num_point_features=4,
+    vfe="PillarFeatureNet", vfe_filters=[64], middle="PointPillarsScatter", middle_in=64,
+    rpn=dict(layer_nums=[3, 5, 5], layer_strides=[2, 2, 2], num_filters=[64, 128, 256],
+             upsample_strides=[0.25, 0.5, 1], num_upsample_filters=[128, 128, 128], num_input_features=64),
+    downsample_factor=8,
+    # anchored classes (car, bus, construction_vehicle, trailer x2 sizes, truck); the other five are `no_anchor`
+    anchor_sizes=[[1.95017717, 4.60718145, 1.72270761], [2.94046906, 11.1885991, 3.47030982],
+                  [2.73050468, 6.38352896, 3.13312415], [3, 15, 3.8], [2, 3, 3.8], [2.4560939, 6.73778078, 2.73004906]],
+    anchor_ranges=[[-50, -50, -0.93897414, 50, 50, -0.93897414], [-50, -50, -0.0715754, 50, 50, -0.0715754],
+                   [-50, -50, -0.08168083, 50, 50, -0.08168083], [-50, -50, 0.22228277, 50, 50, 0.22228277],
+                   [-50, -50, 0.22228277, 50, 50, 0.22228277], [-50, -50, -0.37937912, 50, 50, -0.37937912]],
+    anchor_groups=[[0], [1], [2], [3, 4], [5]],   # sizes belonging to one anchor generator (class)
+    rotations=[0, 1.57],
+    num_class=10, num_direction_bins=2, direction_offset=0.78, direction_limit_offset=0.0,
+    nms_score_threshold=0.05, nms_pre_max_size=1000, nms_post_max_size=300, nms_iou_threshold=0.5,
+    use_rotate_nms=False, post_center_range=[-59.6, -59.6, -10, 59.6, 59.6, 10],
+)  # second/configs/nuscenes/all.pp.largea.config
+
+
 def grid_size_of(cfg):
     r = np.array(cfg["point_cloud_range"], np.float32)
     v = np.array(cfg["voxel_size"], np.float32)
@@ -49,18 +71,20 @@ def generate_anchors(cfg, feature_map_size):
     (second/core/target_assigner.py:169-207 over box_np_ops.create_anchors_3d_range :606-638)."""
     d, h, w = feature_map_size
     out = []
-    for size, rng in zip(cfg["anchor_sizes"], cfg["anchor_ranges"]):
-        rng = np.array(rng, np.float32)
+    groups = cfg.get("anchor_groups") or [[i] for i in range(len(cfg["anchor_sizes"]))]
+    rots = np.array(cfg["rotations"], np.float32)
+    for grp in groups:   # one anchor generator: (size, rotation) major, then z, y, x
+        rng = np.array(cfg["anchor_ranges"][grp[0]], np.float32)
         zc = np.linspace(rng[2], rng[5], d, dtype=np.float32)
         yc = np.linspace(rng[1], rng[4], h, dtype=np.float32)
         xc = np.linspace(rng[0], rng[3], w, dtype=np.float32)
-        rots = np.array(cfg["rotations"], np.float32)
-        a = np.zeros((len(rots), d, h, w, 7), np.float32)
-        a[..., 0] = xc[None, None, None, :]
-        a[..., 1] = yc[None, None, :, None]
-        a[..., 2] = zc[None, :, None, None]
-        a[..., 3:6] = np.array(size, np.float32)
-        a[..., 6] = rots[:, None, None, None]
+        a = np.zeros((len(grp), len(rots), d, h, w, 7), np.float32)
+        a[..., 0] = xc[None, None, None, None, :]
+        a[..., 1] = yc[None, None, None, :, None]
+        a[..., 2] = zc[None, None, :, None, None]
+        for si, sz in enumerate(grp):
+            a[si, ..., 3:6] = np.array(cfg["anchor_sizes"][sz], np.float32)
+        a[..., 6] = rots[None, :, None, None, None]
         out.append(a.reshape(-1, 7))
     return np.concatenate(out, 0)
 
@@ -74,6 +98,61 @@ class SimpleVoxel(nn.Module):
     def forward(self, features, num_voxels, coors=None):
         s = features[:, :, :self.num_input_features].sum(dim=1)
         return (s / num_voxels.type_as(features).view(-1, 1)).contiguous()
+
+
+class PFNLayer(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.linear = nn.Linear(cin, cout, bias=False)
+        self.norm = nn.BatchNorm1d(cout, eps=1e-3, momentum=0.01)
+
+
+class PillarFeatureNet(nn.Module):
+    """One-layer PillarFeatureNet (pointpillars.py:150-237); keys pfn_layers.0.{linear,norm}.  Inference on the
+    GPU runs the fused sec_pfn_fwd kernel; the torch formulation below serves training (autograd) and CPU tests."""
+
+    def __init__(self, num_input_features=4, num_filters=(64,), voxel_size=(0.2, 0.2, 4), pc_range=(0, -40, -3, 70.4, 40, 1)):
+        super().__init__()
+        assert len(num_filters) == 1, "the shipped PointPillars configs use a single PFN layer"
+        self.pfn_layers = nn.ModuleList([PFNLayer(num_input_features + 5, num_filters[0])])
+        self.vx, self.vy = voxel_size[0], voxel_size[1]
+        self.x_offset, self.y_offset = self.vx / 2 + pc_range[0], self.vy / 2 + pc_range[1]
+
+    def folded(self):
+        l = self.pfn_layers[0]
+        scale = (l.norm.weight * torch.rsqrt(l.norm.running_var + l.norm.eps)).float()
+        shift = (l.norm.bias - l.norm.running_mean * scale).float()
+        return l.linear.weight.detach().t().contiguous().float(), scale.detach().contiguous(), shift.detach().contiguous()
+
+    def forward(self, features, num_voxels, coors, out_dtype=None, num_dev=None):
+        l = self.pfn_layers[0]
+        if features.is_cuda and not self.training and not torch.is_grad_enabled():
+            wt, scale, shift = self.folded()
+            return ops.pfn_forward(features.float().contiguous(), num_voxels.int(), coors.int(), wt, scale, shift, self.vx,
+                                   self.vy, self.x_offset, self.y_offset, out_dtype=out_dtype, num_dev=num_dev)
+        n = num_voxels.to(features.dtype).view(-1, 1, 1)
+        xyz = features[:, :, :3]
+        mean = xyz.sum(1, keepdim=True) / n
+        cx = coors[:, 3].to(features.dtype).view(-1, 1) * self.vx + self.x_offset
+        cy = coors[:, 2].to(features.dtype).view(-1, 1) * self.vy + self.y_offset
+        dec = torch.cat([features, xyz - mean, (features[:, :, 0] - cx).unsqueeze(-1), (features[:, :, 1] - cy).unsqueeze(-1)], -1)
+        t = features.shape[1]
+        mask = (torch.arange(t, device=features.device).view(1, -1) < num_voxels.view(-1, 1)).to(features.dtype)
+        x = l.linear(dec * mask.unsqueeze(-1))
+        x = F.relu(l.norm(x.permute(0, 2, 1)).permute(0, 2, 1))
+        return x.max(dim=1)[0]
+
+
+class PointPillarsScatter(nn.Module):
+    """pointpillars.py:420-476: pillars -> [B, C, ny, nx] pseudo image, one launch (sec_pillar_scatter)."""
+
+    def __init__(self, output_shape, num_input_features=64):
+        super().__init__()
+        self.ny, self.nx, self.nchannels = int(output_shape[2]), int(output_shape[3]), num_input_features
+
+    def forward(self, voxel_features, coords, batch_size, channels_last=False):
+        return ops.pillar_scatter(voxel_features.contiguous(), coords.int().contiguous(), batch_size, self.ny, self.nx,
+                                  channels_last=channels_last)
 
 
 def _bn1d(c):
@@ -285,8 +364,14 @@ class SecondDetector(nn.Module):
         gs = grid_size_of(cfg)
         self.grid_size = gs
         dense_shape = [1] + gs[::-1].tolist() + [64]
-        self.voxel_feature_extractor = SimpleVoxel(cfg["num_point_features"])
-        self.middle_feature_extractor = SpMiddleFHD(dense_shape, cfg["middle_in"])
+        self.pillars = cfg.get("vfe") == "PillarFeatureNet"
+        if self.pillars:
+            self.voxel_feature_extractor = PillarFeatureNet(cfg["num_point_features"], cfg["vfe_filters"], cfg["voxel_size"],
+                                                           cfg["point_cloud_range"])
+            self.middle_feature_extractor = PointPillarsScatter(dense_shape, cfg["middle_in"])
+        else:
+            self.voxel_feature_extractor = SimpleVoxel(cfg["num_point_features"])
+            self.middle_feature_extractor = SpMiddleFHD(dense_shape, cfg["middle_in"])
         a_per_loc = len(cfg["rotations"]) * len(cfg["anchor_sizes"])
         self.rpn = RPNV2(num_class=cfg["num_class"], num_anchor_per_loc=a_per_loc, num_direction_bins=cfg["num_direction_bins"],
                          **cfg["rpn"])
@@ -307,7 +392,8 @@ class SecondDetector(nn.Module):
         # 3x3 conv for bf16 NHWC on gfx950 (naive fallback kernel) vs 0.14 ms unfused -- not an option; the
         # fused dense path is the hand-written MFMA conv.
         self.eval()
-        if len(self.rpn.blocks) == 1 and len(self.rpn.deblocks) == 1 and next(self.parameters()).is_cuda:
+        if (isinstance(self.rpn, RPNV2) and len(self.rpn.blocks) == 1 and len(self.rpn.deblocks) == 1
+                and next(self.parameters()).is_cuda):
             self.rpn = RPNInference(self.rpn, dtype)
         else:
             self.rpn.blocks = nn.ModuleList([fold_conv_bn_(b) for b in self.rpn.blocks])
@@ -322,6 +408,10 @@ class SecondDetector(nn.Module):
     # -- stages ------------------------------------------------------------------------------------
     def network_forward(self, voxel_features, coors, batch_size, num_active_dev=None):
         dt = self._infer_dtype
+        if self.pillars:
+            spatial = self.middle_feature_extractor(voxel_features if dt is None else voxel_features.to(dt), coors,
+                                                    batch_size, channels_last=dt is not None)
+            return self.rpn(spatial)
         if dt is not None:
             spatial = self.middle_feature_extractor(voxel_features.to(dt), coors, batch_size, channels_last=True,
                                                     num_active_dev=num_active_dev)
@@ -332,7 +422,8 @@ class SecondDetector(nn.Module):
     def forward(self, example):
         voxels, num_points, coors = example["voxels"], example["num_points"], example["coordinates"]
         batch_size = example["anchors"].shape[0]
-        feats = self.voxel_feature_extractor(voxels, num_points, coors)
+        with torch.no_grad():
+            feats = self.voxel_feature_extractor(voxels, num_points, coors)
         preds = self.network_forward(feats, coors, batch_size)
         with torch.no_grad():
             return self.predict(preds, example["anchors"].view(batch_size, -1, 7))
@@ -344,6 +435,12 @@ class SecondDetector(nn.Module):
         on the device) -- hipGraph-capturable; call :meth:`check_overflow` whenever the host next syncs."""
         batch_size = point_offsets.numel() - 1
         nf = self.cfg["num_point_features"]
+        if self.pillars:
+            vox = self.voxel_generator.generate_device(points, point_offsets)
+            feats = self.voxel_feature_extractor(vox["voxels"], vox["num_points_per_voxel"], vox["coordinates"],
+                                                 out_dtype=self._infer_dtype)
+            preds = self.network_forward(feats, vox["coordinates"], batch_size)
+            return self.predict_device(preds, batch_size)
         if not static:
             vox = self.voxel_generator.generate_device(points, point_offsets, mean_features=nf)
             preds = self.network_forward(vox["mean"], vox["coordinates"], batch_size)
@@ -392,9 +489,13 @@ class SecondDetector(nn.Module):
     def _select(self, preds, batch_size, anchors):
         """score filter + top-k + decode of the selected boxes, all on device, fixed shapes."""
         cfg = self.cfg
-        cls = preds["cls_preds"].reshape(batch_size, -1).float()            # num_class == 1
+        nc = cfg["num_class"]
         box = preds["box_preds"].reshape(batch_size, -1, 7)
-        scores = torch.sigmoid(cls)
+        if nc == 1:
+            scores = torch.sigmoid(preds["cls_preds"].reshape(batch_size, -1).float())
+            labels = None
+        else:   # class-agnostic selection: best class per anchor (voxelnet.py:545-553)
+            scores, labels = torch.sigmoid(preds["cls_preds"].reshape(batch_size, -1, nc).float()).max(-1)
         k = min(cfg["nms_pre_max_size"], scores.shape[1])
         masked = torch.where(scores >= cfg["nms_score_threshold"], scores, torch.full_like(scores, -1.0))
         top_scores, top_idx = torch.topk(masked, k, dim=1)
@@ -408,21 +509,29 @@ class SecondDetector(nn.Module):
             dir_labels = torch.max(d, dim=-1)[1]
         else:
             dir_labels = None
-        return dec, top_scores, counts, dir_labels
+        top_labels = torch.gather(labels, 1, top_idx) if labels is not None else torch.zeros_like(top_idx)
+        return dec, top_scores, counts, dir_labels, top_labels
 
     def predict_device(self, preds, batch_size, anchors=None):
         """-> dict of padded device tensors: boxes [B,P,7], scores [B,P], labels [B,P], valid [B,P] (bool)."""
         cfg = self.cfg
         anchors = self.anchors if anchors is None else anchors
-        dec, top_scores, counts, dir_labels = self._select(preds, batch_size, anchors)
-        # (x, y, w, l, r, score): boxes_for_nms = box[:, [0, 1, 3, 4, 6]] (voxelnet.py:570); slices, not index
-        # lists, so that nothing is staged from the host (hipGraph capture)
-        dets = torch.cat([dec[..., 0:2], dec[..., 3:5], dec[..., 6:7], top_scores.unsqueeze(-1)], -1).contiguous()
+        dec, top_scores, counts, dir_labels, top_labels = self._select(preds, batch_size, anchors)
         if cfg["use_rotate_nms"]:
+            # (x, y, w, l, r, score): boxes_for_nms = box[:, [0, 1, 3, 4, 6]] (voxelnet.py:570); slices, not index
+            # lists, so that nothing is staged from the host (hipGraph capture)
+            dets = torch.cat([dec[..., 0:2], dec[..., 3:5], dec[..., 6:7], top_scores.unsqueeze(-1)], -1).contiguous()
             keep, num_keep = ops.nms_sorted(dets, counts, cfg["nms_iou_threshold"], "rotate", "cpu",
                                             post_max=cfg["nms_post_max_size"])
         else:
-            raise NotImplementedError("axis-aligned predict path (nuscenes all.fhd) comes with SURVEY row a19 wiring")
+            # standup boxes of the rotated BEV rectangles (voxelnet.py:571-576 -> center_to_corner_box2d +
+            # corner_to_standup_nd), then nms -> nms_gpu_cc -> spconv non_max_suppression ('+1', IoU > thr)
+            hx, hy, ang = dec[..., 3] * 0.5, dec[..., 4] * 0.5, dec[..., 6]
+            cs, sn = torch.cos(ang).abs(), torch.sin(ang).abs()
+            ex, ey = hx * cs + hy * sn, hx * sn + hy * cs
+            dets = torch.stack([dec[..., 0] - ex, dec[..., 1] - ey, dec[..., 0] + ex, dec[..., 1] + ey, top_scores], -1).contiguous()
+            keep, num_keep = ops.nms_sorted(dets, counts, cfg["nms_iou_threshold"], "axis_aligned", "numba",
+                                            post_max=cfg["nms_post_max_size"])
         p = min(cfg["nms_post_max_size"], keep.shape[1])
         valid = self._arange_p[:p].unsqueeze(0) < num_keep.unsqueeze(1)
         sel = torch.where(valid, keep[:, :p], torch.zeros_like(keep[:, :p])).long()   # slots past num_keep are undefined
@@ -435,7 +544,7 @@ class SecondDetector(nn.Module):
             boxes[..., 6] = rot + cfg["direction_offset"] + period * dl.to(boxes.dtype)
         r = self.post_center_range
         valid = valid & (boxes[..., :3] >= r[:3]).all(-1) & (boxes[..., :3] <= r[3:]).all(-1)
-        return {"boxes": boxes, "scores": scores, "labels": torch.zeros_like(sel), "valid": valid}
+        return {"boxes": boxes, "scores": scores, "labels": torch.gather(top_labels, 1, sel), "valid": valid}
 
     def predict(self, preds, anchors):
         out = self.predict_device(preds, anchors.shape[0], anchors)

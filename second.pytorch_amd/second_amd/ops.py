@@ -237,6 +237,53 @@ def pillar_scatter(features, coords, batch_size, ny, nx, channels_last=False):
     return out
 
 
+def pfn_forward(voxels, num_points, coords, weight_t, scale, shift, vx, vy, x_offset, y_offset, out_dtype=None,
+                num_dev=None):
+    """Fused PillarFeatureNet (one PFNLayer, eval): decorate -> Linear(9,C) -> folded BN -> ReLU -> max over points
+    (second/pytorch/models/pointpillars.py:203-237,51-65).  voxels [P,T,4] fp32, coords [P,4] (b,z,y,x),
+    weight_t [9,C] = linear.weight.T, scale/shift fp32 [C]."""
+    rt.require_gpu(voxels, num_points, coords, weight_t, scale, shift)
+    assert voxels.dtype == torch.float32 and voxels.is_contiguous() and coords.dtype == torch.int32
+    p, t, f = voxels.shape
+    c = weight_t.shape[1]
+    assert weight_t.shape[0] == f + 5 and weight_t.dtype == torch.float32 and weight_t.is_contiguous()
+    out_dtype = out_dtype or torch.float32
+    out = torch.empty((p, c), dtype=out_dtype, device=voxels.device)
+    rc = rt.lib().sec_pfn_fwd(rt.ptr(voxels), rt.ptr(num_points), rt.ptr(coords.contiguous()), p, rt.ptr(num_dev), t, f,
+                              rt.ptr(weight_t), rt.ptr(scale), rt.ptr(shift), c, float(vx), float(vy), float(x_offset),
+                              float(y_offset), rt.ptr(out), rt.dtype_code(out_dtype), rt.stream())
+    rt.check(rc, "sec_pfn_fwd")
+    return out
+
+
+def voxel_block_filter(vox, grid_size_xy, block_factor, block_size, height_threshold, height_high_threshold=3.0,
+                       sync=True):
+    """Block filtering of points_to_voxel_3d_with_filtering on the output dict of :func:`voxelize`
+    (which must have been produced with sync=False or sync=True, any); returns a dict of the same layout."""
+    voxels, coors, npv, voff = vox["voxels"], vox["coordinates"], vox["num_points_per_voxel"], vox["voxel_offsets"]
+    rt.require_gpu(voxels, coors, npv, voff)
+    rows, t, f = voxels.shape
+    batch = voff.numel() - 1
+    dev = voxels.device
+    ov, oc, on = torch.empty_like(voxels), torch.empty_like(coors), torch.empty_like(npv)
+    ooff = torch.empty_like(voff)
+    l = rt.lib()
+    ws = rt.workspace(l.sec_block_filter_workspace_bytes(rows, batch, int(grid_size_xy[0]), int(grid_size_xy[1]),
+                                                         int(block_factor)), dev)
+    rc = l.sec_voxel_block_filter_f32(rt.ptr(voxels), rt.ptr(coors), rt.ptr(npv), rt.ptr(voff), rows, batch, t, f,
+                                      int(grid_size_xy[0]), int(grid_size_xy[1]), int(block_factor), int(block_size),
+                                      float(height_threshold), float(height_high_threshold), rt.ptr(ov), rt.ptr(oc),
+                                      rt.ptr(on), rt.ptr(ooff), rt.ptr(ws), ws.numel(), rt.stream())
+    rt.check(rc, "sec_voxel_block_filter_f32")
+    out = {"voxels": ov, "coordinates": oc, "num_points_per_voxel": on, "voxel_offsets": ooff}
+    if sync:
+        total = int(ooff[-1].item())
+        for k in ("voxels", "coordinates", "num_points_per_voxel"):
+            out[k] = out[k][:total]
+        out["voxel_num"] = total
+    return out
+
+
 def bias_act_(x, bias, relu=True):
     """In place y = relu?(x + bias[c]) on a channels-last activation [B,C,H,W] (or [P,C]); bias float32 [C].
     The folded-BatchNorm bias + ReLU that follows every RPN conv (rpn.py:486-497), one pass."""

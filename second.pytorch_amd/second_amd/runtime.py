@@ -21,7 +21,8 @@ SYMBOLS = [
     "sec_rulebook_workspace_bytes", "sec_rulebook_subm3d", "sec_rulebook_conv3d_build",
     "sec_rulebook_conv3d_tables", "sec_conv_output_shape", "sec_packed_weight_bytes",
     "sec_pack_conv_weight", "sec_indice_conv_fwd", "sec_indice_conv_bwd", "sec_sparse_to_dense",
-    "sec_pillar_scatter", "sec_bias_act_nhwc", "sec_rotate_iou_f32", "sec_nms_workspace_bytes", "sec_nms_sorted_f32",
+    "sec_pillar_scatter", "sec_pfn_fwd", "sec_block_filter_workspace_bytes",
+    "sec_voxel_block_filter_f32", "sec_bias_act_nhwc", "sec_rotate_iou_f32", "sec_nms_workspace_bytes", "sec_nms_sorted_f32",
 ]
 
 _lib = None
@@ -41,7 +42,7 @@ def lib():
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
         l = ctypes.CDLL(LIB_PATH)
         for name in ("sec_voxelize_workspace_bytes", "sec_rulebook_workspace_bytes",
-                     "sec_packed_weight_bytes", "sec_nms_workspace_bytes"):
+                     "sec_packed_weight_bytes", "sec_nms_workspace_bytes", "sec_block_filter_workspace_bytes"):
             getattr(l, name).restype = ctypes.c_size_t
         l.sec_last_error.restype = ctypes.c_char_p
         l.sec_conv_output_shape.restype = None
@@ -59,6 +60,9 @@ def lib():
         l.sec_indice_conv_bwd.argtypes = [vp, ci, ci, vp, ci, ci, vp, vp, ci, vp, vp, vp, ci, vp]
         l.sec_sparse_to_dense.argtypes = [vp, vp, ci, ci, vp, vp, sz, i64, i64, i64, i64, i64, ci, vp]
         l.sec_pillar_scatter.argtypes = [vp, vp, ci, ci, vp, sz, i64, i64, i64, i64, ci, vp]
+        l.sec_pfn_fwd.argtypes = [vp, vp, vp, ci, vp, ci, ci, vp, vp, vp, ci, cf, cf, cf, cf, vp, ci, vp]
+        l.sec_block_filter_workspace_bytes.argtypes = [ci, ci, ci, ci, ci]
+        l.sec_voxel_block_filter_f32.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, cf, cf, vp, vp, vp, vp, vp, sz, vp]
         l.sec_bias_act_nhwc.argtypes = [vp, vp, sz, ci, ci, ci, vp]
         l.sec_rotate_iou_f32.argtypes = [vp, ci, vp, ci, ci, vp, vp]
         l.sec_nms_workspace_bytes.argtypes = [ci, ci]

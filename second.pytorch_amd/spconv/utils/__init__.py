@@ -40,13 +40,23 @@ class VoxelGeneratorV2:
         self._height_threshold, self._height_high_threshold = height_threshold, height_high_threshold
         self._mode = max_voxels_mode
         if block_filtering:
-            raise NotImplementedError("block_filtering (nuscenes/all.fhd.config:9-12) is a later SURVEY 8a row (a4)")
+            assert block_factor > 0 and block_size > 0, "block_filtering needs block_factor / block_size"
 
     # -- device-resident path (no host round trip): points [N,F] cuda float32, offsets [B+1] cuda int32
     def generate_device(self, points, point_offsets, max_voxels=None, mean_features=0, sync=True):
-        return _ops.voxelize(points, point_offsets, self._point_cloud_range.tolist(), self._voxel_size.tolist(),
-                             self._max_num_points, int(max_voxels or self._max_voxels), self._mode,
-                             mean_features=mean_features, sync=sync)
+        if not self._block_filtering:
+            return _ops.voxelize(points, point_offsets, self._point_cloud_range.tolist(), self._voxel_size.tolist(),
+                                 self._max_num_points, int(max_voxels or self._max_voxels), self._mode,
+                                 mean_features=mean_features, sync=sync)
+        # points_to_voxel_3d_with_filtering: voxelise, then drop flat (ground-only) neighbourhoods
+        vox = _ops.voxelize(points, point_offsets, self._point_cloud_range.tolist(), self._voxel_size.tolist(),
+                            self._max_num_points, int(max_voxels or self._max_voxels), self._mode, sync=False)
+        out = _ops.voxel_block_filter(vox, self._grid_size[:2].tolist(), self._block_factor, self._block_size,
+                                      self._height_threshold, self._height_high_threshold, sync=sync)
+        if mean_features:
+            v = out["voxels"][:, :, :mean_features].sum(1)
+            out["mean"] = v / out["num_points_per_voxel"].clamp(min=1).to(v.dtype).unsqueeze(1)
+        return out
 
     def _run(self, points, max_voxels):
         dev = _dev()
@@ -107,7 +117,9 @@ def points_to_voxel(points, voxel_size, coors_range, coor_to_voxelidx=None, max_
 def non_max_suppression(sorted_dets, keep_out, thresh, device_id=0):
     """spconv's CUDA NMS (src/utils/nms.cu) signature: boxes [N,5] (x1,y1,x2,y2,score) sorted by score,
     writes kept positions into keep_out, returns their count ('+1' convention, IoU > thresh)."""
-    dev = torch.device("cuda", device_id)
+    dev = _dev()
+    if dev.type == "cuda":
+        dev = torch.device("cuda", device_id)
     n = sorted_dets.shape[0]
     if n == 0:
         return 0

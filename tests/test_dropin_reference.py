@@ -121,3 +121,59 @@ def test_api_surface_used_by_reference():
     for kw in ("voxel_size", "point_cloud_range", "max_num_points", "max_voxels", "full_mean", "block_filtering",
                "block_factor", "block_size", "height_threshold"):
         assert kw in sig
+
+
+def test_reference_pointpillars_over_our_stack(ref):
+    """BASELINE config 4 (nuscenes/all.pp.largea): the unmodified reference VoxelNet (PillarFeatureNet +
+    PointPillarsScatter + 3-block RPNV2 + class-agnostic axis-aligned NMS) vs our mirror, same weights."""
+    import oracle_backend
+    from google.protobuf import text_format
+    from second.protos import pipeline_pb2
+    from second_amd import synthetic as syn
+    from second_amd.models import SecondDetector, ALL_PP_LARGEA
+    train, _ = ref
+    cfg = pipeline_pb2.TrainEvalPipelineConfig()
+    text_format.Merge(open(os.path.join(REF, "second/configs/nuscenes/all.pp.largea.config")).read(), cfg)
+    model_cfg = cfg.model.second
+    for cs in model_cfg.target_assigner.class_settings:
+        cs.nms_pre_max_size = 200
+    torch.manual_seed(0)
+    with oracle_backend.installed():
+        net = train.build_network(model_cfg).eval()
+        g = torch.Generator().manual_seed(1)
+        for m in net.modules():
+            if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+                m.running_mean.copy_(torch.empty_like(m.running_mean).uniform_(-0.1, 0.1, generator=g))
+                m.running_var.copy_(torch.empty_like(m.running_var).uniform_(0.5, 1.5, generator=g))
+        cloud = syn.syn_nusc_cloud(0, num_points=20000, point_cloud_range=(-50, -50, -5, 50, 50, 3))
+        vox = net.voxel_generator.generate(cloud, 30000)
+        fm = [1, 50, 50]
+        anchors = net.target_assigner.generate_anchors(fm)["anchors"].reshape(1, -1, 7)
+        example = {"voxels": vox["voxels"], "num_points": vox["num_points_per_voxel"],
+                   "coordinates": np.pad(vox["coordinates"], ((0, 0), (1, 0)), mode="constant", constant_values=0),
+                   "anchors": anchors}
+        ex = train.example_convert_to_torch(example, torch.float32, torch.device("cpu"))
+        with torch.no_grad():
+            ref_preds = net.network_forward(ex["voxels"], ex["num_points"], ex["coordinates"], 1)
+        det = SecondDetector(dict(ALL_PP_LARGEA, nms_pre_max_size=200)).eval()
+        missing = det.load_state_dict({k: v for k, v in net.state_dict().items() if k in det.state_dict()})
+        assert not missing.missing_keys
+        assert det.anchors.shape == (anchors.shape[1], 7)
+        np.testing.assert_allclose(det.anchors.numpy(), anchors[0], rtol=0, atol=1e-5)
+        with torch.no_grad():
+            feats = det.voxel_feature_extractor(ex["voxels"], ex["num_points"], ex["coordinates"])
+            ours_preds = det.network_forward(feats, ex["coordinates"], 1)
+        for k in ("box_preds", "cls_preds", "dir_cls_preds"):
+            np.testing.assert_allclose(ours_preds[k].numpy(), ref_preds[k].numpy(), rtol=1e-3, atol=1e-4)
+        gen = torch.Generator().manual_seed(3)
+        fake = {k: v.clone() for k, v in ref_preds.items()}
+        fake["cls_preds"] = torch.randn(fake["cls_preds"].shape, generator=gen) * 0.8 - 3.2
+        fake["box_preds"] = torch.randn(fake["box_preds"].shape, generator=gen) * 0.2
+        fake["dir_cls_preds"] = torch.randn(fake["dir_cls_preds"].shape, generator=gen)
+        with torch.no_grad():
+            r = net.predict(ex, {k: v.clone() for k, v in fake.items()})[0]
+            o = det.predict(fake, ex["anchors"].view(1, -1, 7))[0]
+    assert r["scores"].shape[0] > 5
+    np.testing.assert_allclose(o["scores"].numpy(), r["scores"].numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(o["box3d_lidar"].numpy(), r["box3d_lidar"].numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_array_equal(o["label_preds"].numpy(), r["label_preds"].numpy())

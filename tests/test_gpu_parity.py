@@ -456,3 +456,75 @@ def test_rpn_inference_form_matches_module(golden):
         np.testing.assert_allclose(f32[k].cpu().numpy(), ref[k].cpu().numpy(), rtol=1e-3, atol=1e-4)
         err = (bf[k].float() - ref[k]).abs().max().item() / ref[k].abs().max().item()
         assert err < 3e-2, (k, err)
+
+
+# ------------------------------------------------------------------ PointPillars front end / block filter
+def test_pfn_kernel_matches_reference_module_and_oracle(ops, golden):
+    g = golden("torch_modules")
+    W = g["pfn_sd.pfn_layers.0.linear.weight"]
+    bw, bb, rm, rv = [g["pfn_sd.pfn_layers.0.norm." + k] for k in ("weight", "bias", "running_mean", "running_var")]
+    scale = bw / np.sqrt(rv + 1e-3)
+    shift = bb - rm * scale
+    out = ops.pfn_forward(dev(g["pfn_voxels"]), dev(g["pfn_num_points"]), dev(g["pfn_coords"]), dev(W.T.copy()),
+                          dev(scale), dev(shift), 0.25, 0.25, 0.125 - 50, 0.125 - 50)
+    np.testing.assert_allclose(out.cpu().numpy(), g["pfn_out"], rtol=1e-4, atol=1e-5)   # the reference's own module
+    rng = np.random.default_rng(0)
+    P, T, C = 3000, 60, 64
+    vox = rng.uniform(-3, 3, (P, T, 4)).astype(np.float32)
+    n = rng.integers(1, T + 1, P).astype(np.int32)
+    n[:10] = T
+    for i in range(P):
+        vox[i, n[i]:] = 0
+    coords = np.stack([rng.integers(0, 4, P), np.zeros(P, int), rng.integers(0, 400, P), rng.integers(0, 400, P)], 1).astype(np.int32)
+    Wt = (rng.standard_normal((9, C)) / 3).astype(np.float32)
+    sc, sh = rng.uniform(0.5, 1.5, C).astype(np.float32), rng.uniform(-0.3, 0.3, C).astype(np.float32)
+    ref = orc.pfn_forward(vox, n, coords, Wt, sc, sh, 0.25, 0.25, -49.875, -49.875)
+    out = ops.pfn_forward(dev(vox), dev(n), dev(coords), dev(Wt), dev(sc), dev(sh), 0.25, 0.25, -49.875, -49.875)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-4, atol=1e-4)
+
+
+def test_block_filter_vs_oracle(ops):
+    rng = np.random.default_rng(1)
+    rng_, vs = [-10, -10, -3, 10, 10, 1], [0.1, 0.1, 0.2]
+    clouds = []
+    for b in range(3):   # flat ground + a few tall clusters
+        ground = np.concatenate([rng.uniform(-10, 10, (4000, 2)), rng.normal(-1.7, 0.02, (4000, 1))], 1)
+        tall = np.concatenate([rng.normal(0, 0.4, (1500, 2)) + rng.uniform(-8, 8, (1, 2)), rng.uniform(-1.7, 0.5, (1500, 1))], 1)
+        pts = np.concatenate([ground, tall])
+        rng.shuffle(pts)
+        clouds.append(np.concatenate([pts, rng.uniform(0, 1, (len(pts), 1))], 1).astype(np.float32))
+    from second_amd.synthetic import batch_clouds
+    pts, offs = batch_clouds(clouds)
+    vox = ops.voxelize(dev(pts), dev(offs), rng_, vs, 2, 20000, sync=False)
+    out = ops.voxel_block_filter(vox, [200, 200], 1, 8, 0.2, 3.0)
+    ooff = out["voxel_offsets"].cpu().numpy()
+    kept_any = False
+    for b, c in enumerate(clouds):
+        r = orc.points_to_voxel(c, vs, rng_, 2, 20000)
+        keep = orc.block_filter(r["voxels"], r["coordinates"], r["num_points_per_voxel"], [200, 200], 1, 8, 0.2, 3.0)
+        lo, hi = ooff[b], ooff[b + 1]
+        assert hi - lo == keep.sum(), (b, hi - lo, keep.sum())
+        np.testing.assert_array_equal(out["coordinates"][lo:hi, 1:].cpu().numpy(), r["coordinates"][keep])
+        np.testing.assert_array_equal(out["voxels"][lo:hi].cpu().numpy(), r["voxels"][keep])
+        np.testing.assert_array_equal(out["num_points_per_voxel"][lo:hi].cpu().numpy(), r["num_points_per_voxel"][keep])
+        kept_any |= 0 < keep.sum() < len(keep)
+    assert kept_any
+
+
+def test_pointpillars_detector_runs_fused_equals_module_path(syn):
+    from second_amd.models import SecondDetector, ALL_PP_LARGEA
+    torch.manual_seed(0)
+    det = SecondDetector(ALL_PP_LARGEA).cuda().eval()
+    cloud = syn.syn_nusc_cloud(0, num_points=60000, point_cloud_range=(-50, -50, -5, 50, 50, 3))
+    pts, offs = syn.batch_clouds([cloud, cloud[::3]])
+    pts, offs = dev(pts), dev(offs)
+    with torch.no_grad():
+        out = det.forward_points(pts, offs)                    # fused PFN kernel + scatter kernel, fp32
+        vox = det.voxel_generator.generate_device(pts, offs)
+    with torch.enable_grad():                                  # torch formulation of the PFN (training path)
+        feats_t = det.voxel_feature_extractor(vox["voxels"], vox["num_points_per_voxel"], vox["coordinates"])
+    with torch.no_grad():
+        feats_k = det.voxel_feature_extractor(vox["voxels"], vox["num_points_per_voxel"], vox["coordinates"])
+    np.testing.assert_allclose(feats_k.cpu().numpy(), feats_t.detach().cpu().numpy(), rtol=1e-4, atol=1e-4)
+    assert out["boxes"].shape[0] == 2 and out["valid"].any()
+    assert int(out["labels"].max()) < 10
