@@ -170,6 +170,17 @@ int sec_voxel_block_filter_f32(const float *voxels, const int *coors, const int 
 int sec_bias_act_nhwc(void *x, const float *bias, size_t pixels, int channels, int relu, int dtype,
                       void *stream);
 
+/* Dense conv2d of the RPN (second/pytorch/models/rpn.py:468-497 blocks, :275-285 1x1 deconv, :386-391 heads):
+ * channels-last [B,H,W,Cin] bf16/f16, implicit GEMM on MFMA with bias (folded BatchNorm2d) + ReLU fused.
+ * weight [Cout,Cin,k,k] (torch layout) is re-packed once by sec_conv2d_pack_weight.  Cin, Cout multiples of 64.
+ * Output [B,Ho,Wo,Cout] with Ho = (H + 2 pad - k) / stride + 1. */
+size_t sec_conv2d_packed_weight_bytes(int cout, int cin, int ksize, int dtype);
+int sec_conv2d_pack_weight(const void *weight, int cout, int cin, int ksize, int dtype, void *packed,
+                           void *stream);
+int sec_conv2d_nhwc(const void *x, int batch, int h, int w, int cin, const void *packed_weight,
+                    const float *bias, int cout, int ksize, int stride, int pad, int relu, void *y,
+                    int dtype, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Rotated IoU / NMS -- replace the numba.cuda kernels of second/core/non_max_suppression/nms_gpu.py
  * (rotate_iou_kernel_eval :564-602, rotate_nms_kernel :404-437, nms_kernel :70-101, nms_postprocess

@@ -189,12 +189,26 @@ class SpMiddleFHD(nn.Module):
             add(sub(64, 64, "subm3"), 64)
         add(down(64, 64, (3, 1, 1), (2, 1, 1), 0), 64)
         self.middle_conv = spconv.SparseSequential(*layers)
+        import os
+        self.overlap_rulebooks = os.environ.get("SEC_OVERLAP_RULEBOOKS", "0") == "1"  # measured: no gain under hipGraph replay
+        self._side_stream = None
 
     def forward(self, voxel_features, coors, batch_size, channels_last=False, num_active_dev=None):
         x = spconv.SparseConvTensor(voxel_features, coors.int(), self.sparse_shape, batch_size,
                                     num_active_dev=num_active_dev)
+        side = None
+        if num_active_dev is not None and self.overlap_rulebooks:
+            # static pipeline: all 8 rulebooks on a side stream, overlapped with the conv layers (fork / join)
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream()
+            side = self._side_stream
+            x.planned = self.middle_conv.plan_rulebooks(x, side)
         x = self.middle_conv(x)
-        self.last_overflow_checks = x.overflow_checks
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
+            self.last_overflow_checks = self.middle_conv._planned_overflow
+        else:
+            self.last_overflow_checks = x.overflow_checks
         if channels_last:
             return x.dense_channels_last_2d()
         d = x.dense()
@@ -333,11 +347,35 @@ class RPNInference(nn.Module):
         hb = torch.cat([h.bias.detach().float() for h in heads] + [torch.zeros(padc, device=heads[0].weight.device)], 0)
         self.head_w = nn.Parameter(hw.to(dtype).contiguous(memory_format=torch.channels_last), requires_grad=False)
         self.head_b = nn.Parameter(hb.contiguous(), requires_grad=False)
+        # hand-written MFMA conv (sec_conv2d_nhwc, bias + ReLU fused) when shapes allow; SEC_RPN_BACKEND=miopen
+        # keeps the phase-1 path (MIOpen conv + one fused bias/ReLU pass) for A/B measurements
+        import os
+        self.use_hip = os.environ.get("SEC_RPN_BACKEND", "hip") == "hip" and dtype in (torch.bfloat16, torch.float16)
+        self.packed, self.head_packed = [], None
+        if self.use_hip:
+            for w in self.ws:
+                pk = ops.conv2d_pack_weight(w.detach().contiguous())
+                if pk is None:
+                    self.use_hip = False
+                    break
+                self.packed.append(pk)
+        if self.use_hip:
+            cpad = (-hw.shape[0]) % 64
+            hw64 = torch.cat([hw, torch.zeros(cpad, *hw.shape[1:], device=hw.device)], 0).to(dtype).contiguous()
+            self.head_cout = hw64.shape[0]
+            self.head_packed = ops.conv2d_pack_weight(hw64)
+            self.head_b64 = torch.cat([hb, torch.zeros(cpad, device=hb.device)]).contiguous()
+            self.use_hip = self.head_packed is not None
 
     def forward(self, x):
-        for w, b, (s, p) in zip(self.ws, self.bs, self.cfgs):
-            x = ops.bias_act_(F.conv2d(x, w, None, s, p), b, relu=True)
-        y = ops.bias_act_(F.conv2d(x, self.head_w, None), self.head_b, relu=False)
+        if self.use_hip:
+            for w, pk, b, (s, p) in zip(self.ws, self.packed, self.bs, self.cfgs):
+                x = ops.conv2d_nhwc(x, pk, b, w.shape[0], w.shape[2], s[0], p[0], relu=True)
+            y = ops.conv2d_nhwc(x, self.head_packed, self.head_b64, self.head_cout, 1, 1, 0, relu=False)
+        else:
+            for w, b, (s, p) in zip(self.ws, self.bs, self.cfgs):
+                x = ops.bias_act_(F.conv2d(x, w, None, s, p), b, relu=True)
+            y = ops.bias_act_(F.conv2d(x, self.head_w, None), self.head_b, relu=False)
         n, _, h, wd = y.shape
         ret, c0 = {}, 0
         for name, sz, code in zip(["box_preds", "cls_preds", "dir_cls_preds"], self.splits, self.codes):

@@ -302,6 +302,36 @@ def bias_act_(x, bias, relu=True):
     return x
 
 
+def conv2d_pack_weight(weight):
+    """[Cout,Cin,k,k] (torch layout, bf16/f16) -> MFMA slab order for :func:`conv2d_nhwc`; None if unsupported."""
+    rt.require_gpu(weight)
+    cout, cin, kh, kw = weight.shape
+    if weight.dtype == torch.float32 or kh != kw:
+        return None
+    l = rt.lib()
+    nbytes = l.sec_conv2d_packed_weight_bytes(cout, cin, kh, rt.dtype_code(weight.dtype))
+    if nbytes == 0:
+        return None
+    packed = torch.empty((nbytes // 2,), dtype=weight.dtype, device=weight.device)
+    rt.check(l.sec_conv2d_pack_weight(rt.ptr(weight.contiguous()), cout, cin, kh, rt.dtype_code(weight.dtype), rt.ptr(packed),
+                                      rt.stream()), "sec_conv2d_pack_weight")
+    return packed
+
+
+def conv2d_nhwc(x, packed, bias, cout, ksize, stride=1, pad=0, relu=False):
+    """Dense conv2d + bias + ReLU in one launch (hand-written MFMA implicit GEMM).  x: [B,Cin,H,W] in
+    torch.channels_last memory format (bf16/f16); returns [B,Cout,Ho,Wo] channels_last."""
+    rt.require_gpu(x, packed)
+    assert x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)
+    b, cin, h, w = x.shape
+    ho, wo = (h + 2 * pad - ksize) // stride + 1, (w + 2 * pad - ksize) // stride + 1
+    y = torch.empty((b, cout, ho, wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    rc = rt.lib().sec_conv2d_nhwc(rt.ptr(x), b, h, w, cin, rt.ptr(packed), rt.ptr(bias), cout, ksize, stride, pad,
+                                  int(bool(relu)), rt.ptr(y), rt.dtype_code(x.dtype), rt.stream())
+    rt.check(rc, "sec_conv2d_nhwc")
+    return y
+
+
 # ----------------------------------------------------------------------------- IoU / NMS
 def rotate_iou(boxes, qboxes, criterion=-1):
     """[N,K] rotated IoU (nms_gpu.py rotate_iou_gpu_eval)."""

@@ -22,7 +22,8 @@ SYMBOLS = [
     "sec_rulebook_conv3d_tables", "sec_conv_output_shape", "sec_packed_weight_bytes",
     "sec_pack_conv_weight", "sec_indice_conv_fwd", "sec_indice_conv_bwd", "sec_sparse_to_dense",
     "sec_pillar_scatter", "sec_pfn_fwd", "sec_block_filter_workspace_bytes",
-    "sec_voxel_block_filter_f32", "sec_bias_act_nhwc", "sec_rotate_iou_f32", "sec_nms_workspace_bytes", "sec_nms_sorted_f32",
+    "sec_voxel_block_filter_f32", "sec_bias_act_nhwc", "sec_conv2d_packed_weight_bytes",
+    "sec_conv2d_pack_weight", "sec_conv2d_nhwc", "sec_rotate_iou_f32", "sec_nms_workspace_bytes", "sec_nms_sorted_f32",
 ]
 
 _lib = None
@@ -42,7 +43,8 @@ def lib():
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
         l = ctypes.CDLL(LIB_PATH)
         for name in ("sec_voxelize_workspace_bytes", "sec_rulebook_workspace_bytes",
-                     "sec_packed_weight_bytes", "sec_nms_workspace_bytes", "sec_block_filter_workspace_bytes"):
+                     "sec_packed_weight_bytes", "sec_nms_workspace_bytes", "sec_block_filter_workspace_bytes",
+                     "sec_conv2d_packed_weight_bytes"):
             getattr(l, name).restype = ctypes.c_size_t
         l.sec_last_error.restype = ctypes.c_char_p
         l.sec_conv_output_shape.restype = None
@@ -64,6 +66,9 @@ def lib():
         l.sec_block_filter_workspace_bytes.argtypes = [ci, ci, ci, ci, ci]
         l.sec_voxel_block_filter_f32.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, cf, cf, vp, vp, vp, vp, vp, sz, vp]
         l.sec_bias_act_nhwc.argtypes = [vp, vp, sz, ci, ci, ci, vp]
+        l.sec_conv2d_packed_weight_bytes.argtypes = [ci, ci, ci, ci]
+        l.sec_conv2d_pack_weight.argtypes = [vp, ci, ci, ci, ci, vp, vp]
+        l.sec_conv2d_nhwc.argtypes = [vp, ci, ci, ci, ci, vp, vp, ci, ci, ci, ci, ci, vp, ci, vp]
         l.sec_rotate_iou_f32.argtypes = [vp, ci, vp, ci, ci, vp, vp]
         l.sec_nms_workspace_bytes.argtypes = [ci, ci]
         l.sec_nms_sorted_f32.argtypes = [vp, vp, ci, ci, ci, cf, ci, ci, cf, ci, vp, vp, vp, sz, vp]

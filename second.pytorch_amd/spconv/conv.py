@@ -59,6 +59,12 @@ class SparseConvolution(SparseModule):
 
     # -- rulebook ---------------------------------------------------------------------------------
     def _rulebook(self, x):
+        planned = getattr(x, "planned", None)
+        if planned is not None and id(self) in planned:      # built ahead of time on a side stream (plan_rulebooks)
+            rb, event = planned[id(self)]
+            if event is not None:
+                torch.cuda.current_stream().wait_event(event)
+            return rb
         rb = x.find_indice_pair(self.indice_key)
         if rb is not None and self.subm:
             return rb
@@ -92,6 +98,7 @@ class SparseConvolution(SparseModule):
 
     def _wrap(self, x, feats, rb):
         out = SparseConvTensor(feats, rb.out_indices, rb.out_shape, x.batch_size, x.grid, rb.num_out_dev)
+        out.planned = getattr(x, "planned", None)
         out.overflow_checks = getattr(x, "overflow_checks", [])
         if rb.num_out_dev is not None and not rb.subm:
             out.overflow_checks = out.overflow_checks + [(rb.num_out_dev, rb.out_indices.shape[0])]

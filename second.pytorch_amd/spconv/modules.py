@@ -51,6 +51,38 @@ class SparseSequential(SparseModule):
                 raise KeyError("name exists")
         self.add_module(name, module)
 
+    def plan_rulebooks(self, x, stream):
+        """Build the rulebooks of EVERY sparse conv of this sequence on `stream`, ahead of the feature
+        computation: rulebooks depend on coordinates only, so the (latency-bound) hash / scan kernels of all
+        layers overlap with the conv kernels of the layers before them.  Returns {id(conv): (Rulebook, event)};
+        assign it to ``x.planned`` before calling forward.  Static-capacity tensors only (no host syncs)."""
+        from .conv import SparseConvolution
+        from .tensor import SparseConvTensor
+        assert x.num_active_dev is not None, "plan_rulebooks needs a static-capacity SparseConvTensor"
+        main = torch.cuda.current_stream()
+        stream.wait_stream(main)
+        plans = {}
+        with torch.cuda.stream(stream):
+            cur = SparseConvTensor(None, x.indices, x.spatial_shape, x.batch_size, None, x.num_active_dev)
+            cur.indice_dict = x.indice_dict
+            for m in self._modules.values():
+                if not isinstance(m, SparseConvolution) or m.conv1x1:
+                    continue
+                rb = m._rulebook(cur)
+                ev = torch.cuda.Event()
+                ev.record(stream)
+                for t in (rb.nbr_out, rb.nbr_in, rb.out_indices, rb.num_out_dev):
+                    if t is not None:
+                        t.record_stream(main)
+                plans[id(m)] = (rb, ev)
+                if not m.subm:
+                    nxt = SparseConvTensor(None, rb.out_indices, rb.out_shape, x.batch_size, None, rb.num_out_dev)
+                    nxt.indice_dict = cur.indice_dict
+                    nxt.overflow_checks = cur.overflow_checks + [(rb.num_out_dev, rb.out_indices.shape[0])]
+                    cur = nxt
+            self._planned_overflow = cur.overflow_checks
+        return plans
+
     def _folded(self, conv, bn):
         key = (id(conv), id(bn), bn.weight._version if bn.weight is not None else 0,
                bn.bias._version if bn.bias is not None else 0, bn.running_mean._version, bn.running_var._version,

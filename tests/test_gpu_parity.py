@@ -528,3 +528,23 @@ def test_pointpillars_detector_runs_fused_equals_module_path(syn):
     np.testing.assert_allclose(feats_k.cpu().numpy(), feats_t.detach().cpu().numpy(), rtol=1e-4, atol=1e-4)
     assert out["boxes"].shape[0] == 2 and out["valid"].any()
     assert int(out["labels"].max()) < 10
+
+
+@pytest.mark.parametrize("cin,cout,k,stride,pad,hw", [(128, 128, 3, 1, 1, (200, 176)), (64, 64, 3, 2, 1, (37, 29)),
+                                                     (128, 256, 3, 2, 1, (50, 50)), (128, 64, 1, 1, 0, (33, 17)),
+                                                     (64, 128, 3, 1, 1, (9, 7))])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_conv2d_nhwc_mfma_vs_torch(ops, cin, cout, k, stride, pad, hw, dtype):
+    torch.manual_seed(cin + cout + k)
+    b = 2
+    x = torch.randn(b, cin, *hw, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(cout, cin, k, k, device="cuda") / (cin * k * k) ** 0.5).to(dtype)
+    bias = torch.randn(cout, device="cuda")
+    ref = torch.relu(torch.nn.functional.conv2d(x.float(), w.float(), bias, stride, pad))
+    out = ops.conv2d_nhwc(x, ops.conv2d_pack_weight(w), bias, cout, k, stride, pad, relu=True)
+    assert out.shape == ref.shape and out.is_contiguous(memory_format=torch.channels_last)
+    tol = 2 ** -7 if dtype == torch.bfloat16 else 2 ** -9
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref.cpu().numpy(), rtol=tol, atol=tol * ref.abs().max().item())
+    nob = ops.conv2d_nhwc(x, ops.conv2d_pack_weight(w), None, cout, k, stride, pad, relu=False)
+    ref2 = torch.nn.functional.conv2d(x.float(), w.float(), None, stride, pad)
+    np.testing.assert_allclose(nob.float().cpu().numpy(), ref2.cpu().numpy(), rtol=tol, atol=tol * ref2.abs().max().item())
