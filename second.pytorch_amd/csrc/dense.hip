@@ -308,16 +308,149 @@ __global__ __launch_bounds__(kBlock) void k_conv2d_nhwc_dma(const T *__restrict_
     }
 }
 
+// Halo-tile variant for the 3x3 / stride 1 / pad 1 layers (all six 128->128 layers of the car.fhd RPN): the
+// implicit-GEMM kernels above re-fetch every input pixel once per tap (9x); here a workgroup owns a 16 x 16 output
+// tile, brings the (16+2)^2 input halo into LDS ONCE (all Cin channels: 18*18*Cin*2 B = 83 KB for Cin = 128 --
+// CDNA4's 160 KB LDS makes this possible) and then only streams the nine 3x3 weight slabs (double-buffered LDS-DMA).
+// 8 waves as 4 (pixel quarters) x 2 (cout halves), each 64 px x 64 cout on MFMA 32x32x16.
+template <typename T, int CIN, int TH>
+__global__ __launch_bounds__(TH * 32) void k_conv2d_halo(const T *__restrict__ x, const T *__restrict__ wpk,
+                                                    const float *__restrict__ bias, T *__restrict__ y, Conv2dParams p,
+                                                    int tiles_y, int tiles_x) {
+    constexpr int TW = 16, HW_ = TW + 2, HPIX = (TH + 2) * (TW + 2);   // TH = 16: 324 halo pixels, 8 waves; TH = 8: 180, 4 waves
+    constexpr int NWV = TH / 2, PQ = TH / 4;       // waves; pixel quarters (64 px = 4 tile rows each)
+    constexpr int CH = CIN / 8;                    // 16-byte chunks per pixel (16 for Cin = 128)
+    constexpr int HENT = HPIX * CH;                // uint4 entries of the halo
+    constexpr int BN = 128, CC = CIN / 64, NIT = 9 * CC;
+    extern __shared__ __attribute__((aligned(16))) uint4 halo_smem[];
+    uint4 *hal = halo_smem;                        // [HPIX][CH], chunk index XOR-swizzled with (pixel & (CH-1))
+    uint4 *sB = halo_smem + HENT;                  // [2][8 * BN]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int wm = wv % PQ, wn = wv / PQ;
+    // XCD-aware tile order
+    const int per = gridDim.x / 8;
+    const int tile = (blockIdx.x % 8) * per + blockIdx.x / 8;
+    const int ntile = p.batch * tiles_y * tiles_x;
+    if (tile >= ntile) return;
+    const int b = tile / (tiles_y * tiles_x);
+    const int trem = tile - b * tiles_y * tiles_x;
+    const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
+    const int n0 = blockIdx.y * BN;
+    const int cin8 = CIN / 8;
+    const uint4 *x4 = reinterpret_cast<const uint4 *>(x);
+    const uint4 *w4 = reinterpret_cast<const uint4 *>(wpk);
+    const uint4 *zero16 = w4 + (size_t)9 * cin8 * p.cout;
+
+    // halo DMA: instruction i fills entries [i*64, i*64+64); HENT is a multiple of 64 for CIN in {64, 128}
+    for (int i = wv; i < (HENT + 63) / 64; i += NWV) {
+        const int e = i * 64 + lane;
+        if (e >= HENT) break;
+        const int hp = e / CH, slot = e - hp * CH;
+        const int hy = hp / HW_, hx = hp - hy * HW_;
+        const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+        const bool ok = iy >= 0 && iy < p.h && ix >= 0 && ix < p.w;
+        const uint4 *src = ok ? x4 + (((long long)b * p.h + iy) * p.w + ix) * cin8 + (slot ^ (hp & (CH - 1))) : zero16;
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)&hal[i * 64], 16, 0, 0);
+    }
+    auto issue_b = [&](int it, int buf) {
+        const int tap = it / CC, cc = it - tap * CC;
+#pragma unroll
+        for (int j = 0; j < 16 / NWV; ++j) {
+            const int e = (j * NWV + wv) * 64 + lane, ch = e / BN, n = e - ch * BN;
+            const uint4 *src = w4 + ((size_t)tap * cin8 + cc * 8 + ch) * p.cout + n0 + n;
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)&sB[buf * (8 * BN) + (j * NWV + wv) * 64], 16, 0, 0);
+        }
+    };
+    f32x16d acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][c][i] = 0.0f;
+    // halo pixel (top-left tap) of this lane's two A rows: wave quarter wm = 4 tile rows, m-tile mt = 2 rows
+    int hp0[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int q = mt * 32 + r;
+        hp0[mt] = (wm * 4 + (q >> 4)) * HW_ + (q & 15);
+    }
+    issue_b(0, 0);
+    __syncthreads();
+    for (int it = 0; it < NIT; ++it) {
+        const int buf = it & 1;
+        if (it + 1 < NIT) issue_b(it + 1, buf ^ 1);
+        const int tap = it / CC, cc = it - tap * CC;
+        const int dy = tap / 3, dx = tap - dy * 3;
+        const uint4 *bb = sB + buf * (8 * BN);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            uint4 af[2], bf[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int hp = hp0[mt] + dy * HW_ + dx;
+                af[mt] = hal[hp * CH + ((cc * 8 + s * 2 + hh) ^ (hp & (CH - 1)))];
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) bf[nt] = bb[(s * 2 + hh) * BN + wn * 64 + nt * 32 + r];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = MfmaD<T>::run(af[mt], bf[nt], acc[mt][nt]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int co = n0 + wn * 64 + nt * 32 + r;
+        const float bv = bias ? bias[co] : 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int q = mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;       // pixel inside the wave's 64
+                const int oy = y0 + wm * 4 + (q >> 4), ox = x0 + (q & 15);
+                if (oy < p.h && ox < p.w) {
+                    float v = acc[mt][nt][i] + bv;
+                    if (p.relu) v = v > 0.0f ? v : 0.0f;
+                    y[(((size_t)b * p.h + oy) * p.w + ox) * p.cout + co] = from_f<T>(v);
+                }
+            }
+    }
+}
+
+template <typename T, int CIN, int TH>
+static int launch_conv2d_halo(const void *x, const void *wpk, const float *bias, void *y, const Conv2dParams &p, hipStream_t st) {
+    constexpr size_t lds = ((size_t)(TH + 2) * 18 * (CIN / 8) + 2 * 8 * 128) * 16;
+    static bool configured = false;
+    auto fn = k_conv2d_halo<T, CIN, TH>;
+    if (!configured) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        configured = true;
+    }
+    const int ty = div_up(p.h, TH), tx = div_up(p.w, 16);
+    const int gx = (p.batch * ty * tx + 7) / 8 * 8;
+    hipLaunchKernelGGL(fn, dim3(gx, p.cout / 128), dim3(TH * 32), lds, st, (const T *)x, (const T *)wpk, bias, (T *)y, p, ty, tx);
+    return check_launch();
+}
+
 static int conv2d_variant() {
     static int v = -1;
-    if (v < 0) { const char *e = getenv("SEC_CONV2D_VARIANT"); v = e ? atoi(e) : 1; }  // 0 register staged, 1 LDS-DMA
+    if (v < 0) { const char *e = getenv("SEC_CONV2D_VARIANT"); v = e ? atoi(e) : 3; }  // 0 register staged, 1 LDS-DMA implicit GEMM, 2/3 halo tile 16x16 / 8x16 (3x3 s1 p1 layers)
     return v;
 }
 
 template <typename T>
 static int launch_conv2d(const void *x, const void *wpk, const float *bias, void *y, const Conv2dParams &p, hipStream_t st) {
     dim3 block(kBlock);
-    if (conv2d_variant() == 1) {
+    if ((conv2d_variant() == 2 || conv2d_variant() == 3) && p.ksize == 3 && p.stride == 1 && p.pad == 1 &&
+        p.cout % 128 == 0 && (p.cin == 128 || p.cin == 64)) {
+        if (conv2d_variant() == 2)
+            return p.cin == 128 ? launch_conv2d_halo<T, 128, 16>(x, wpk, bias, y, p, st) : launch_conv2d_halo<T, 64, 16>(x, wpk, bias, y, p, st);
+        return p.cin == 128 ? launch_conv2d_halo<T, 128, 8>(x, wpk, bias, y, p, st) : launch_conv2d_halo<T, 64, 8>(x, wpk, bias, y, p, st);
+    }
+    if (conv2d_variant() >= 1) {
         const int gx = (div_up(p.m, 128) + 7) / 8 * 8;   // multiple of 8 for the XCD-aware tile order
         if (p.cout % 128 == 0)
             hipLaunchKernelGGL((k_conv2d_nhwc_dma<T, 128>), dim3(gx, p.cout / 128), block, 0, st, (const T *)x,
