@@ -202,6 +202,32 @@ int sec_nms_sorted_f32(const float *dets, const int *counts, int batch, int max_
                        float thresh, int kind, int semantics, float eps, int post_max, int *keep,
                        int *num_keep, void *workspace, size_t workspace_bytes, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Post-processing of VoxelNet.predict (second/pytorch/models/voxelnet.py:377-645) without leaving the device.
+ * RPN outputs are addressed in place through element strides of a [B, A, H, W, C] view (h_*_strides5 =
+ * {sb, sa, sy, sx, sc}); anchor n = (a*H + y)*W + x as in target_assigner.generate_anchors.
+ *   select  : best class per anchor (num_class > 1), top-k by score (k <= 1024) sorted descending;
+ *             counts[b] = entries with sigmoid score >= score_thr (voxelnet.py:545-569, box_torch_ops.py:497-501)
+ *   decode  : second_box_decode (box_torch_ops.py:56-101) of the selected anchors -> decoded [B,k,7];
+ *             dets [B,k,6] = NMS rows (rotate: x,y,w,l,r,score ; else standup x1,y1,x2,y2,score,0); direction argmax
+ *   finalize: gather of the NMS survivors (keep / num_keep of sec_nms_sorted_f32), direction fix
+ *             (voxelnet.py:598-607), post_center_range mask (:611-621) -> boxes [B,post_max,7], scores, labels, valid
+ * --------------------------------------------------------------------------------------------- */
+int sec_predict_select(const void *cls, const int64_t *h_cls_strides5, int batch, int anchors_per_loc,
+                       int h, int w, int num_class, int k, float score_thr,
+                       unsigned *key_scratch /* batch * anchors_per_loc * h * w words */, int *top_idx,
+                       float *top_score, int *top_label, int *counts, int dtype, void *stream);
+int sec_predict_decode(const void *box, const int64_t *h_box_strides5, const void *dir,
+                       const int64_t *h_dir_strides5, int num_dir_bins, int batch, int anchors_per_loc,
+                       int h, int w, int k, const float *anchors, const int *top_idx,
+                       const float *top_score, int rotate, float *decoded, float *dets, int *dir_label,
+                       int dtype, void *stream);
+int sec_predict_finalize(const float *decoded, const float *top_score, const int *top_label,
+                         const int *dir_label, const int *keep, const int *num_keep, int batch, int k,
+                         int post_max, int use_direction, float dir_offset, float dir_limit_offset,
+                         int num_dir_bins, const float *range6, float *boxes, float *scores, int *labels,
+                         unsigned char *valid, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,350 @@
+// Device-resident post-processing of VoxelNet.predict (second/pytorch/models/voxelnet.py:377-645):
+//   sec_predict_select   : best class per anchor, score threshold, top-k by score, sorted descending
+//                          (torch.sigmoid / max / masked_select / topk of voxelnet.py:545-569 and
+//                          box_torch_ops.py:497-501) -- one workgroup per frame: 8-bit radix select over
+//                          order-preserving keys, ordered tie handling, bitonic sort of the k survivors in LDS;
+//   sec_predict_decode   : gather + second_box_decode (box_torch_ops.py:56-101) of the selected anchors, NMS input
+//                          rows (rotated (x,y,w,l,r,score) or standup (x1,y1,x2,y2,score)), direction argmax;
+//   sec_predict_finalize : gather of the NMS survivors, direction fix (limit_period, voxelnet.py:598-607),
+//                          post_center_range mask (:611-621).
+// The reference runs ~60 tiny torch kernels plus a GPU->CPU->GPU round trip here; these three launches plus the
+// two NMS launches keep everything on the device with fixed shapes (hipGraph friendly).
+// Tensors are addressed as logit(b, anchor n = (a, y, x), c) = base[b*sb + a*sa + y*sy + x*sx + c*sc] so the RPN head
+// output is consumed in place (no permute / contiguous copies).
+#include "common.hpp"
+
+namespace sec {
+
+struct View5 {          // element strides of a [B, A, H, W, C] view
+    long long sb, sa, sy, sx, sc;
+};
+struct PredGeom {
+    int batch, A, H, W, nc;   // anchors per location, feature map, classes
+};
+
+template <typename T> __device__ __forceinline__ float ldf(const T *p);
+template <> __device__ __forceinline__ float ldf(const float *p) { return *p; }
+template <> __device__ __forceinline__ float ldf(const __hip_bfloat16 *p) { return __bfloat162float(*p); }
+template <> __device__ __forceinline__ float ldf(const __half *p) { return __half2float(*p); }
+
+__device__ __forceinline__ unsigned f2key(float f) {   // order-preserving float -> uint
+    unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(unsigned k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+template <typename T>
+__device__ __forceinline__ unsigned anchor_key(const T *cls, const View5 &v, const PredGeom &g, int b, int n, int *label) {
+    int x = n % g.W;
+    int t = n / g.W;
+    int y = t % g.H;
+    int a = t / g.H;
+    const T *p = cls + b * v.sb + a * v.sa + y * v.sy + x * v.sx;
+    float best = ldf(p);
+    int lab = 0;
+    for (int c = 1; c < g.nc; ++c) {
+        float f = ldf(p + c * v.sc);
+        if (f > best) { best = f; lab = c; }
+    }
+    if (label) *label = lab;
+    return f2key(best);
+}
+
+constexpr int kSelThreads = 1024;
+
+// pass 0 (whole chip): compact, coalesced key array (the RPN head is channels-last: one anchor's logit per 128-byte
+// pixel row, far too scattered to be re-read by the single workgroup that owns a frame in the select kernel)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_predict_keys(const T *__restrict__ cls, View5 v, PredGeom g,
+                                                        unsigned *__restrict__ keys) {
+    const int N = g.A * g.H * g.W;
+    long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= (long long)g.batch * N) return;
+    keys[t] = anchor_key(cls, v, g, (int)(t / N), (int)(t % N), nullptr);
+}
+
+// one workgroup per frame
+template <typename T>
+__global__ __launch_bounds__(kSelThreads) void k_predict_select(const T *__restrict__ cls, View5 v, PredGeom g, int K,
+                                                                float score_thr, const unsigned *__restrict__ keys,
+                                                                int *__restrict__ top_idx,
+                                                                float *__restrict__ top_score, int *__restrict__ top_label,
+                                                                int *__restrict__ counts) {
+    __shared__ unsigned hist[256];
+    __shared__ unsigned ckey[kSelThreads];
+    __shared__ int cidx[kSelThreads];
+    __shared__ int wsum[kSelThreads / 64];
+    __shared__ unsigned s_prefix, s_need;
+    __shared__ int s_cnt, s_eqbase;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int N = g.A * g.H * g.W;
+    const unsigned *fk = keys + (size_t)b * N;
+    if (K > kSelThreads) K = kSelThreads;
+    if (K > N) K = N;
+    // ---- radix select of the K-th largest key (4 x 8 bits, MSB first)
+    unsigned prefix = 0, mask = 0, need = K;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        for (int i = tid; i < 256; i += kSelThreads) hist[i] = 0;
+        __syncthreads();
+        for (int n0 = 0; n0 < N; n0 += kSelThreads) {
+            int n = n0 + tid;
+            bool act = false;
+            unsigned d = 0;
+            if (n < N) {
+                unsigned key = fk[n];
+                act = (key & mask) == prefix;
+                d = (key >> shift) & 255u;
+            }
+            // wave-aggregated histogram update (a uniform digit costs one LDS atomic per wave, not 64)
+            unsigned long long todo = __ballot(act);
+            while (todo) {
+                int leader = __ffsll((long long)todo) - 1;
+                unsigned d0 = __shfl(d, leader, 64);
+                unsigned long long same = __ballot(act && d == d0) & todo;
+                if (lane == leader) atomicAdd(&hist[d0], (unsigned)__popcll(same));
+                todo &= ~same;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned acc = 0;
+            int bin = 255;
+            for (; bin > 0; --bin) {
+                if (acc + hist[bin] >= need) break;
+                acc += hist[bin];
+            }
+            s_prefix = prefix | ((unsigned)bin << shift);
+            s_need = need - acc;     // how many still to take inside this bin
+        }
+        __syncthreads();
+        prefix = s_prefix;
+        need = s_need;
+        mask |= 255u << shift;
+        __syncthreads();
+    }
+    const unsigned T_key = prefix;   // K-th largest key; take all keys > T and the first `need` (by index) equal to T
+    // ---- ordered compaction into LDS
+    if (tid == 0) { s_cnt = 0; s_eqbase = 0; }
+    ckey[tid] = 0u;
+    cidx[tid] = 0x7fffffff;
+    __syncthreads();
+    for (int n0 = 0; n0 < N; n0 += kSelThreads) {
+        int n = n0 + tid;
+        unsigned key = 0;
+        bool gt = false, eq = false;
+        if (n < N) {
+            key = fk[n];
+            gt = key > T_key;
+            eq = key == T_key;
+        }
+        // rank among the equal keys of this chunk, in index order
+        unsigned long long em = __ballot(eq);
+        int wcnt = __popcll(em);
+        if (lane == 0) wsum[wv] = wcnt;
+        __syncthreads();
+        int ebase = s_eqbase;
+        for (int w2 = 0; w2 < wv; ++w2) ebase += wsum[w2];
+        int erank = ebase + __popcll(em & ((1ull << lane) - 1ull));
+        bool take = gt || (eq && erank < (int)need);
+        if (take) {
+            int pos = atomicAdd(&s_cnt, 1);
+            if (pos < kSelThreads) { ckey[pos] = key; cidx[pos] = n; }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int tot = 0;
+            for (int w2 = 0; w2 < kSelThreads / 64; ++w2) tot += wsum[w2];
+            s_eqbase += tot;
+        }
+        __syncthreads();
+    }
+    // ---- bitonic sort of the (key desc, idx asc) pairs; unused slots hold key 0 / idx INT_MAX and sink to the end
+    for (int size = 2; size <= kSelThreads; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            int partner = tid ^ stride;
+            if (partner > tid) {
+                unsigned ka = ckey[tid], kb = ckey[partner];
+                int ia = cidx[tid], ib = cidx[partner];
+                bool a_first = ka > kb || (ka == kb && ia < ib);       // a should precede b in descending order
+                bool up = (tid & size) == 0;                            // this run is sorted "descending-first"
+                if (up ? !a_first : a_first) {
+                    ckey[tid] = kb; ckey[partner] = ka;
+                    cidx[tid] = ib; cidx[partner] = ia;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // ---- outputs
+    if (tid < K) {
+        int n = cidx[tid];
+        float sc = sigmoidf_(key2f(ckey[tid]));
+        int lab = 0;
+        if (g.nc > 1 && n < N) anchor_key(cls, v, g, b, n, &lab);
+        top_idx[(size_t)b * K + tid] = n < N ? n : 0;
+        top_score[(size_t)b * K + tid] = sc;
+        top_label[(size_t)b * K + tid] = lab;
+    }
+    // number of selected anchors with score >= threshold (a prefix of the sorted list)
+    bool ok = tid < K && cidx[tid] < N && sigmoidf_(key2f(ckey[tid])) >= score_thr;
+    unsigned long long m = __ballot(ok);
+    if (lane == 0) wsum[wv] = __popcll(m);
+    __syncthreads();
+    if (tid == 0) {
+        int tot = 0;
+        for (int w2 = 0; w2 < kSelThreads / 64; ++w2) tot += wsum[w2];
+        counts[b] = tot;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_predict_decode(const T *__restrict__ box, View5 vb, const T *__restrict__ dir,
+                                                          View5 vd, int ndir, PredGeom g, int K,
+                                                          const float *__restrict__ anchors, const int *__restrict__ top_idx,
+                                                          const float *__restrict__ top_score, int rotate,
+                                                          float *__restrict__ dec, float *__restrict__ dets,
+                                                          int *__restrict__ dir_label) {
+    int t = blockIdx.x * kBlock + threadIdx.x;
+    if (t >= g.batch * K) return;
+    int b = t / K;
+    int n = top_idx[t];
+    int x = n % g.W;
+    int q = n / g.W;
+    int y = q % g.H;
+    int a = q / g.H;
+    const T *pb = box + b * vb.sb + a * vb.sa + y * vb.sy + x * vb.sx;
+    float e[7];
+#pragma unroll
+    for (int c = 0; c < 7; ++c) e[c] = ldf(pb + c * vb.sc);
+    const float *an = anchors + (size_t)n * 7;
+    float xa = an[0], ya = an[1], za = an[2], wa = an[3], la = an[4], ha = an[5], ra = an[6];
+    float diag = sqrtf(__fadd_rn(__fmul_rn(la, la), __fmul_rn(wa, wa)));
+    float o[7];
+    o[0] = __fadd_rn(__fmul_rn(e[0], diag), xa);
+    o[1] = __fadd_rn(__fmul_rn(e[1], diag), ya);
+    o[2] = __fadd_rn(__fmul_rn(e[2], ha), za);
+    o[3] = __fmul_rn(expf(e[3]), wa);
+    o[4] = __fmul_rn(expf(e[4]), la);
+    o[5] = __fmul_rn(expf(e[5]), ha);
+    o[6] = __fadd_rn(e[6], ra);
+#pragma unroll
+    for (int c = 0; c < 7; ++c) dec[(size_t)t * 7 + c] = o[c];
+    float *d = dets + (size_t)t * 6;
+    if (rotate) {        // boxes_for_nms = box[:, [0, 1, 3, 4, 6]] + score
+        d[0] = o[0]; d[1] = o[1]; d[2] = o[3]; d[3] = o[4]; d[4] = o[6]; d[5] = top_score[t];
+    } else {             // standup box of the rotated BEV rectangle (center_to_corner_box2d + corner_to_standup_nd)
+        float hx = o[3] * 0.5f, hy = o[4] * 0.5f;
+        float cs = fabsf(cosf(o[6])), sn = fabsf(sinf(o[6]));
+        float ex = hx * cs + hy * sn, ey = hx * sn + hy * cs;
+        d[0] = o[0] - ex; d[1] = o[1] - ey; d[2] = o[0] + ex; d[3] = o[1] + ey; d[4] = top_score[t]; d[5] = 0.0f;
+    }
+    int dl = 0;
+    if (dir) {
+        const T *pd = dir + b * vd.sb + a * vd.sa + y * vd.sy + x * vd.sx;
+        float best = ldf(pd);
+        for (int c = 1; c < ndir; ++c) {
+            float f = ldf(pd + c * vd.sc);
+            if (f > best) { best = f; dl = c; }
+        }
+    }
+    dir_label[t] = dl;
+}
+
+__global__ __launch_bounds__(kBlock) void k_predict_finalize(const float *__restrict__ dec, const float *__restrict__ top_score,
+                                                            const int *__restrict__ top_label, const int *__restrict__ dir_label,
+                                                            const int *__restrict__ keep, const int *__restrict__ num_keep,
+                                                            int batch, int K, int P, int use_dir, float dir_offset,
+                                                            float dir_limit_offset, float period, const float *__restrict__ range6,
+                                                            float *__restrict__ boxes, float *__restrict__ scores,
+                                                            int *__restrict__ labels, unsigned char *__restrict__ valid) {
+    int t = blockIdx.x * kBlock + threadIdx.x;
+    if (t >= batch * P) return;
+    int b = t / P, j = t - b * P;
+    bool ok = j < num_keep[b];
+    int sel = ok ? keep[(size_t)b * K + j] : 0;
+    const float *s = dec + ((size_t)b * K + sel) * 7;
+    float o[7];
+#pragma unroll
+    for (int c = 0; c < 7; ++c) o[c] = s[c];
+    if (use_dir) {   // limit_period(rot - offset, limit_offset, period) + offset + period * dir_label
+        float val = __fsub_rn(o[6], dir_offset);
+        float rot = __fsub_rn(val, __fmul_rn(floorf(__fadd_rn(__fdiv_rn(val, period), dir_limit_offset)), period));
+        o[6] = __fadd_rn(__fadd_rn(rot, dir_offset), __fmul_rn(period, (float)dir_label[(size_t)b * K + sel]));
+    }
+    if (range6)
+        ok = ok && o[0] >= range6[0] && o[1] >= range6[1] && o[2] >= range6[2] && o[0] <= range6[3] && o[1] <= range6[4] &&
+             o[2] <= range6[5];
+#pragma unroll
+    for (int c = 0; c < 7; ++c) boxes[(size_t)t * 7 + c] = o[c];
+    scores[t] = top_score[(size_t)b * K + sel];
+    labels[t] = top_label[(size_t)b * K + sel];
+    valid[t] = ok ? 1 : 0;
+}
+
+}  // namespace sec
+
+using namespace sec;
+
+static View5 mkview(const int64_t *s) { return View5{s[0], s[1], s[2], s[3], s[4]}; }
+
+SEC_API int sec_predict_select(const void *cls, const int64_t *h_cls_strides5, int batch, int anchors_per_loc, int h, int w,
+                               int num_class, int k, float score_thr, unsigned *key_scratch, int *top_idx, float *top_score,
+                               int *top_label, int *counts, int dtype, void *stream) {
+    if (!key_scratch) return SEC_E_WORKSPACE;
+    if (!cls || !h_cls_strides5 || batch <= 0 || anchors_per_loc <= 0 || h <= 0 || w <= 0 || num_class <= 0 || k <= 0 ||
+        k > kSelThreads || !top_idx || !top_score || !top_label || !counts)
+        return SEC_E_INVALID;
+    PredGeom g{batch, anchors_per_loc, h, w, num_class};
+    View5 v = mkview(h_cls_strides5);
+    hipStream_t st = (hipStream_t)stream;
+    const long long total = (long long)batch * anchors_per_loc * h * w;
+#define SEC_SEL(T)                                                                                                              \
+    do {                                                                                                                        \
+        hipLaunchKernelGGL(k_predict_keys<T>, dim3(div_up(total, kBlock)), dim3(kBlock), 0, st, (const T *)cls, v, g, key_scratch); \
+        hipLaunchKernelGGL(k_predict_select<T>, dim3(batch), dim3(kSelThreads), 0, st, (const T *)cls, v, g, k, score_thr,       \
+                           key_scratch, top_idx, top_score, top_label, counts);                                                  \
+    } while (0)
+    if (dtype == SEC_F32) SEC_SEL(float);
+    else if (dtype == SEC_BF16) SEC_SEL(__hip_bfloat16);
+    else if (dtype == SEC_F16) SEC_SEL(__half);
+    else return SEC_E_UNSUPPORTED;
+#undef SEC_SEL
+    return check_launch();
+}
+
+SEC_API int sec_predict_decode(const void *box, const int64_t *h_box_strides5, const void *dir, const int64_t *h_dir_strides5,
+                               int num_dir_bins, int batch, int anchors_per_loc, int h, int w, int k, const float *anchors,
+                               const int *top_idx, const float *top_score, int rotate, float *decoded, float *dets,
+                               int *dir_label, int dtype, void *stream) {
+    if (!box || !h_box_strides5 || batch <= 0 || k <= 0 || !anchors || !top_idx || !top_score || !decoded || !dets || !dir_label)
+        return SEC_E_INVALID;
+    PredGeom g{batch, anchors_per_loc, h, w, 1};
+    View5 vb = mkview(h_box_strides5), vd = dir ? mkview(h_dir_strides5) : View5{0, 0, 0, 0, 0};
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(div_up((long long)batch * k, kBlock));
+#define SEC_DEC(T) hipLaunchKernelGGL(k_predict_decode<T>, grid, dim3(kBlock), 0, st, (const T *)box, vb, (const T *)dir, vd, \
+                                      num_dir_bins, g, k, anchors, top_idx, top_score, rotate, decoded, dets, dir_label)
+    if (dtype == SEC_F32) SEC_DEC(float);
+    else if (dtype == SEC_BF16) SEC_DEC(__hip_bfloat16);
+    else if (dtype == SEC_F16) SEC_DEC(__half);
+    else return SEC_E_UNSUPPORTED;
+#undef SEC_DEC
+    return check_launch();
+}
+
+SEC_API int sec_predict_finalize(const float *decoded, const float *top_score, const int *top_label, const int *dir_label,
+                                 const int *keep, const int *num_keep, int batch, int k, int post_max, int use_direction,
+                                 float dir_offset, float dir_limit_offset, int num_dir_bins, const float *range6,
+                                 float *boxes, float *scores, int *labels, unsigned char *valid, void *stream) {
+    if (!decoded || !top_score || !top_label || !keep || !num_keep || batch <= 0 || k <= 0 || post_max <= 0 || post_max > k ||
+        !boxes || !scores || !labels || !valid || (use_direction && (!dir_label || num_dir_bins <= 0)))
+        return SEC_E_INVALID;
+    float period = use_direction ? 6.283185307179586f / (float)num_dir_bins : 0.0f;
+    hipLaunchKernelGGL(k_predict_finalize, dim3(div_up((long long)batch * post_max, kBlock)), dim3(kBlock), 0, (hipStream_t)stream,
+                       decoded, top_score, top_label, dir_label, keep, num_keep, batch, k, post_max, use_direction, dir_offset,
+                       dir_limit_offset, period, range6, boxes, scores, labels, valid);
+    return check_launch();
+}

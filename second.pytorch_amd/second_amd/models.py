@@ -350,6 +350,7 @@ class RPNInference(nn.Module):
         # hand-written MFMA conv (sec_conv2d_nhwc, bias + ReLU fused) when shapes allow; SEC_RPN_BACKEND=miopen
         # keeps the phase-1 path (MIOpen conv + one fused bias/ReLU pass) for A/B measurements
         import os
+        self.return_views = True   # the fused predict kernels read the head output in place through strides
         self.use_hip = os.environ.get("SEC_RPN_BACKEND", "hip") == "hip" and dtype in (torch.bfloat16, torch.float16)
         self.packed, self.head_packed = [], None
         if self.use_hip:
@@ -381,7 +382,8 @@ class RPNInference(nn.Module):
         for name, sz, code in zip(["box_preds", "cls_preds", "dir_cls_preds"], self.splits, self.codes):
             o = y[:, c0:c0 + sz]
             c0 += sz
-            ret[name] = o.reshape(n, self.a, code, h, wd).permute(0, 1, 3, 4, 2).contiguous()
+            o = o.reshape(n, self.a, code, h, wd).permute(0, 1, 3, 4, 2)   # [B,A,H,W,code] view of the head output
+            ret[name] = o if self.return_views else o.contiguous()
         return ret
 
 
@@ -421,6 +423,7 @@ class SecondDetector(nn.Module):
         self.register_buffer("post_center_range", torch.tensor(cfg["post_center_range"], dtype=torch.float32),
                              persistent=False)
         self._infer_dtype = None
+        self.fused_predict = True
         self.voxel_generator = spconv.utils.VoxelGeneratorV2(cfg["voxel_size"], cfg["point_cloud_range"],
                                                             cfg["max_points_per_voxel"], cfg["max_voxels"])
 
@@ -554,6 +557,8 @@ class SecondDetector(nn.Module):
         """-> dict of padded device tensors: boxes [B,P,7], scores [B,P], labels [B,P], valid [B,P] (bool)."""
         cfg = self.cfg
         anchors = self.anchors if anchors is None else anchors
+        if preds["cls_preds"].is_cuda and self.fused_predict:
+            return self._predict_fused(preds, batch_size, anchors)
         dec, top_scores, counts, dir_labels, top_labels = self._select(preds, batch_size, anchors)
         if cfg["use_rotate_nms"]:
             # (x, y, w, l, r, score): boxes_for_nms = box[:, [0, 1, 3, 4, 6]] (voxelnet.py:570); slices, not index
@@ -583,6 +588,33 @@ class SecondDetector(nn.Module):
         r = self.post_center_range
         valid = valid & (boxes[..., :3] >= r[:3]).all(-1) & (boxes[..., :3] <= r[3:]).all(-1)
         return {"boxes": boxes, "scores": scores, "labels": torch.gather(top_labels, 1, sel), "valid": valid}
+
+    def _predict_fused(self, preds, batch_size, anchors):
+        """select -> decode -> NMS -> finalize: five launches, no host sync, no torch glue."""
+        cfg = self.cfg
+        a_per_loc = len(cfg["rotations"]) * len(cfg["anchor_sizes"])
+        _, h, w = self.feature_map_size
+
+        def view5(t, code):
+            if t.dim() == 5:
+                return t
+            return t.reshape(batch_size, a_per_loc, h, w, code)
+        cls = view5(preds["cls_preds"], cfg["num_class"])
+        box = view5(preds["box_preds"], 7)
+        dirp = view5(preds["dir_cls_preds"], cfg["num_direction_bins"]) if "dir_cls_preds" in preds else None
+        if anchors.dim() == 3:
+            anchors = anchors[0]
+        anchors = anchors.float().contiguous()
+        top_idx, top_score, top_label, counts = ops.predict_select(cls, cfg["nms_pre_max_size"], cfg["nms_score_threshold"])
+        dec, dets, dlab = ops.predict_decode(box, dirp, anchors, top_idx, top_score, rotate=cfg["use_rotate_nms"])
+        if cfg["use_rotate_nms"]:
+            keep, num_keep = ops.nms_sorted(dets, counts, cfg["nms_iou_threshold"], "rotate", "cpu", post_max=cfg["nms_post_max_size"])
+        else:
+            keep, num_keep = ops.nms_sorted(dets, counts, cfg["nms_iou_threshold"], "axis_aligned", "numba",
+                                            post_max=cfg["nms_post_max_size"])
+        return ops.predict_finalize(dec, top_score, top_label, dlab, keep, num_keep, cfg["nms_post_max_size"],
+                                    dirp is not None, cfg["direction_offset"], cfg["direction_limit_offset"],
+                                    cfg["num_direction_bins"], self.post_center_range)
 
     def predict(self, preds, anchors):
         out = self.predict_device(preds, anchors.shape[0], anchors)

@@ -359,3 +359,69 @@ def nms_sorted(dets, counts, thresh, kind="rotate", semantics="numba", eps=1.0, 
                               int(post_max or 0), rt.ptr(keep), rt.ptr(num_keep), rt.ptr(ws), ws.numel(), rt.stream())
     rt.check(rc, "sec_nms_sorted_f32")
     return keep, num_keep
+
+
+# ----------------------------------------------------------------------------- fused predict (voxelnet.py:377-645)
+def _strides5(t):
+    import ctypes
+    assert t.dim() == 5
+    return (ctypes.c_int64 * 5)(*[int(x) for x in t.stride()])
+
+
+def predict_select(cls, k, score_thr):
+    """cls: [B, A, H, W, num_class] view (any strides).  -> (top_idx [B,k] int32 anchor ids sorted by descending
+    score, top_score [B,k] sigmoid scores, top_label [B,k], counts [B] = entries with score >= score_thr)."""
+    rt.require_gpu(cls)
+    b, a, h, w, nc = cls.shape
+    k = min(int(k), a * h * w, 1024)
+    dev = cls.device
+    top_idx = torch.empty((b, k), dtype=torch.int32, device=dev)
+    top_score = torch.empty((b, k), dtype=torch.float32, device=dev)
+    top_label = torch.empty((b, k), dtype=torch.int32, device=dev)
+    counts = torch.empty((b,), dtype=torch.int32, device=dev)
+    keys = torch.empty((b * a * h * w,), dtype=torch.int32, device=dev)
+    rc = rt.lib().sec_predict_select(rt.ptr(cls), _strides5(cls), b, a, h, w, nc, k, float(score_thr), rt.ptr(keys), rt.ptr(top_idx),
+                                     rt.ptr(top_score), rt.ptr(top_label), rt.ptr(counts), rt.dtype_code(cls.dtype), rt.stream())
+    rt.check(rc, "sec_predict_select")
+    return top_idx, top_score, top_label, counts
+
+
+def predict_decode(box, dir_cls, anchors, top_idx, top_score, rotate=True):
+    """box: [B,A,H,W,7] view, dir_cls: [B,A,H,W,bins] view or None, anchors [A*H*W,7] fp32.
+    -> (decoded [B,k,7] fp32, dets [B,k,6] fp32 NMS rows, dir_label [B,k] int32)."""
+    rt.require_gpu(box, anchors, top_idx, top_score)
+    b, a, h, w, code = box.shape
+    assert code == 7 and anchors.dtype == torch.float32 and anchors.is_contiguous() and anchors.shape == (a * h * w, 7)
+    k = top_idx.shape[1]
+    dev = box.device
+    dec = torch.empty((b, k, 7), dtype=torch.float32, device=dev)
+    dets = torch.empty((b, k, 6), dtype=torch.float32, device=dev)
+    dlab = torch.empty((b, k), dtype=torch.int32, device=dev)
+    if dir_cls is not None:
+        assert dir_cls.dtype == box.dtype
+    rc = rt.lib().sec_predict_decode(rt.ptr(box), _strides5(box), rt.ptr(dir_cls),
+                                     _strides5(dir_cls) if dir_cls is not None else None,
+                                     dir_cls.shape[-1] if dir_cls is not None else 0, b, a, h, w, k, rt.ptr(anchors),
+                                     rt.ptr(top_idx), rt.ptr(top_score), int(bool(rotate)), rt.ptr(dec), rt.ptr(dets),
+                                     rt.ptr(dlab), rt.dtype_code(box.dtype), rt.stream())
+    rt.check(rc, "sec_predict_decode")
+    return dec, dets, dlab
+
+
+def predict_finalize(dec, top_score, top_label, dir_label, keep, num_keep, post_max, use_direction, dir_offset,
+                     dir_limit_offset, num_dir_bins, range6):
+    """-> dict(boxes [B,P,7], scores [B,P], labels [B,P] int32, valid [B,P] bool)."""
+    rt.require_gpu(dec, keep, num_keep)
+    b, k, _ = dec.shape
+    p = min(int(post_max), k)
+    dev = dec.device
+    boxes = torch.empty((b, p, 7), dtype=torch.float32, device=dev)
+    scores = torch.empty((b, p), dtype=torch.float32, device=dev)
+    labels = torch.empty((b, p), dtype=torch.int32, device=dev)
+    valid = torch.empty((b, p), dtype=torch.uint8, device=dev)
+    rc = rt.lib().sec_predict_finalize(rt.ptr(dec), rt.ptr(top_score), rt.ptr(top_label), rt.ptr(dir_label), rt.ptr(keep),
+                                       rt.ptr(num_keep), b, k, p, int(bool(use_direction)), float(dir_offset),
+                                       float(dir_limit_offset), int(num_dir_bins), rt.ptr(range6), rt.ptr(boxes),
+                                       rt.ptr(scores), rt.ptr(labels), rt.ptr(valid), rt.stream())
+    rt.check(rc, "sec_predict_finalize")
+    return {"boxes": boxes, "scores": scores, "labels": labels, "valid": valid.bool()}

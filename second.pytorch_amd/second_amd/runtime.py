@@ -24,6 +24,7 @@ SYMBOLS = [
     "sec_pillar_scatter", "sec_pfn_fwd", "sec_block_filter_workspace_bytes",
     "sec_voxel_block_filter_f32", "sec_bias_act_nhwc", "sec_conv2d_packed_weight_bytes",
     "sec_conv2d_pack_weight", "sec_conv2d_nhwc", "sec_rotate_iou_f32", "sec_nms_workspace_bytes", "sec_nms_sorted_f32",
+    "sec_predict_select", "sec_predict_decode", "sec_predict_finalize",
 ]
 
 _lib = None
@@ -72,6 +73,9 @@ def lib():
         l.sec_rotate_iou_f32.argtypes = [vp, ci, vp, ci, ci, vp, vp]
         l.sec_nms_workspace_bytes.argtypes = [ci, ci]
         l.sec_nms_sorted_f32.argtypes = [vp, vp, ci, ci, ci, cf, ci, ci, cf, ci, vp, vp, vp, sz, vp]
+        l.sec_predict_select.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, cf, vp, vp, vp, vp, vp, ci, vp]
+        l.sec_predict_decode.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, ci, vp, vp, vp, ci, vp]
+        l.sec_predict_finalize.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, cf, ci, vp, vp, vp, vp, vp, vp]
         _lib = l
     return _lib
 

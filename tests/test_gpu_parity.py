@@ -548,3 +548,41 @@ def test_conv2d_nhwc_mfma_vs_torch(ops, cin, cout, k, stride, pad, hw, dtype):
     nob = ops.conv2d_nhwc(x, ops.conv2d_pack_weight(w), None, cout, k, stride, pad, relu=False)
     ref2 = torch.nn.functional.conv2d(x.float(), w.float(), None, stride, pad)
     np.testing.assert_allclose(nob.float().cpu().numpy(), ref2.cpu().numpy(), rtol=tol, atol=tol * ref2.abs().max().item())
+
+
+@pytest.mark.parametrize("cfg_name", ["car.fhd", "pp"])
+def test_fused_predict_matches_torch_formulation(cfg_name):
+    """select / decode / NMS / finalize kernels vs the torch restatement of voxelnet.py:377-645 (distinct scores)."""
+    from second_amd.models import SecondDetector, CAR_FHD, ALL_PP_LARGEA
+    cfg = CAR_FHD if cfg_name == "car.fhd" else ALL_PP_LARGEA
+    det = SecondDetector(cfg).cuda().eval()
+    a = det.rpn._num_anchor_per_loc
+    _, h, w = det.feature_map_size
+    b, nc = 3, cfg["num_class"]
+    g = torch.Generator(device="cuda").manual_seed(0)
+    preds = {"cls_preds": torch.randn(b, a, h, w, nc, device="cuda", generator=g) * 0.8 - (1.0 if nc == 1 else 3.0),
+             "box_preds": torch.randn(b, a, h, w, 7, device="cuda", generator=g) * 0.2,
+             "dir_cls_preds": torch.randn(b, a, h, w, 2, device="cuda", generator=g)}
+    with torch.no_grad():
+        det.fused_predict = False
+        ref = det.predict_device({k: v.clone() for k, v in preds.items()}, b)
+        det.fused_predict = True
+        out = det.predict_device(preds, b)
+        # strided (non-contiguous) views of a packed head tensor, bf16
+        packed = torch.cat([preds["box_preds"].permute(0, 1, 4, 2, 3).reshape(b, a * 7, h, w),
+                            preds["cls_preds"].permute(0, 1, 4, 2, 3).reshape(b, a * nc, h, w),
+                            preds["dir_cls_preds"].permute(0, 1, 4, 2, 3).reshape(b, a * 2, h, w)], 1)
+        packed = packed.bfloat16().contiguous(memory_format=torch.channels_last)
+        c0, views = 0, {}
+        for name, code in (("box_preds", 7), ("cls_preds", nc), ("dir_cls_preds", 2)):
+            views[name] = packed[:, c0:c0 + a * code].reshape(b, a, code, h, w).permute(0, 1, 3, 4, 2)
+            c0 += a * code
+        out_v = det.predict_device(views, b)
+        det.fused_predict = False
+        ref_v = det.predict_device({k: v.float().contiguous() for k, v in views.items()}, b)
+    for o, r in ((out, ref), (out_v, ref_v)):
+        assert torch.equal(o["valid"], r["valid"]) and o["valid"].any()
+        m = r["valid"]
+        np.testing.assert_allclose(o["scores"][m].cpu().numpy(), r["scores"][m].cpu().numpy(), rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(o["boxes"][m].cpu().numpy(), r["boxes"][m].cpu().numpy(), rtol=1e-5, atol=1e-5)
+        assert torch.equal(o["labels"][m].long(), r["labels"][m].long())
