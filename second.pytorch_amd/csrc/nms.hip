@@ -172,9 +172,14 @@ __global__ __launch_bounds__(kBlock) void k_rotate_iou(const float *__restrict__
 }
 
 // ---------------------------------------------------------------- suppression bit matrix
-// grid (col_block, row_block, batch); only col_block >= row_block is computed.  Corners / areas of the 64
-// row boxes and the 64 column boxes are computed once per tile into LDS (the reference recomputes sin/cos
-// per pair); lanes are columns, a wave walks 16 rows, each row's 64-bit word is one __ballot.
+// grid (col_block, row_block, batch); only col_block >= row_block is computed.  Two phases per 64 x 64 tile:
+//   A. every thread screens 16 (row, col) pairs with the cheap standup test (corners / standup boxes of the 128
+//      boxes of the tile are computed once into LDS); survivors are appended to an LDS queue with one wave-level
+//      atomic per ballot;
+//   B. the queue is processed densely -- one polygon clip per thread -- and hits are OR-ed into the tile's 64
+//      suppression words (LDS atomics).
+// The reference (and a lanes-are-columns mapping) runs the ~1000-instruction clipper for all 64 lanes whenever a
+// single pair of the wave overlaps; with ~1 % of the pairs overlapping that wastes > 95 % of the lanes.
 __global__ __launch_bounds__(kBlock) void k_nms_mask(const float *__restrict__ dets, const int *__restrict__ counts,
                                                     int max_n, int stride, float thresh, int kind, int semantics,
                                                     float eps, int words, unsigned long long *__restrict__ mask) {
@@ -183,9 +188,15 @@ __global__ __launch_bounds__(kBlock) void k_nms_mask(const float *__restrict__ d
     int n = counts[b];
     if (n > max_n) n = max_n;
     if (rb * 64 >= n || cb * 64 >= n) return;
-    __shared__ float tile[2][64][10];  // [0] = column boxes, [1] = row boxes: 8 corner floats (or x1,y1,x2,y2), area
-    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __shared__ float tile[2][64][10];              // [0] column boxes, [1] row boxes: 8 corner floats (or x1,y1,x2,y2), area
+    __shared__ Standup su[2][64];
+    __shared__ unsigned long long sup_words[64];
+    __shared__ unsigned short queue[64 * 64];
+    __shared__ int qcount;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const float *base = dets + (size_t)b * max_n * stride;
+    if (tid == 0) qcount = 0;
+    if (tid < 64) sup_words[tid] = 0ull;
     if (w < 2) {
         int idx = (w == 0 ? cb : rb) * 64 + lane;
         if (idx < n) {
@@ -196,6 +207,7 @@ __global__ __launch_bounds__(kBlock) void k_nms_mask(const float *__restrict__ d
 #pragma unroll
                 for (int i = 0; i < 8; ++i) tile[w][lane][i] = c[i];
                 tile[w][lane][8] = d[2] * d[3];
+                su[w][lane] = standup_of(c);
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) tile[w][lane][i] = d[i];
@@ -203,48 +215,31 @@ __global__ __launch_bounds__(kBlock) void k_nms_mask(const float *__restrict__ d
         }
     }
     __syncthreads();
-    int col = cb * 64 + lane;
-    float c2[8];
-    float a2 = 0.0f;
-    Standup s2{0, 0, 0, 0};
-    if (col < n) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) c2[i] = tile[0][lane][i];
-        a2 = tile[0][lane][8];
-        if (kind == 0) s2 = standup_of(c2);
-    }
-    for (int rr = 0; rr < 16; ++rr) {
-        int rl = w * 16 + rr;
-        int row = rb * 64 + rl;
-        if (row >= n) break;
-        bool sup = false;
-        if (col < n && col > row) {
-            float c1[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) c1[i] = tile[1][rl][i];  // wave-uniform address: LDS broadcast
+    // ---- phase A: screen
+#pragma unroll 1
+    for (int it = 0; it < 16; ++it) {
+        const int rl = it * 4 + w, cl = lane;      // a wave = one row of the tile x 64 columns
+        const int row = rb * 64 + rl, col = cb * 64 + cl;
+        bool cand = false;
+        if (row < n && col < n && col > row) {
             if (kind == 0) {
-                float a1 = tile[1][rl][8];
-                Standup s1 = standup_of(c1);
+                const Standup s1 = su[1][rl], s2 = su[0][cl];
                 if (!far_apart(s1, s2)) {
-                    bool consider = true;
-                    if (semantics == 1) {  // CPU path: standup IoU (eps = 0) must be > 0 (nms_cpu.py:25, A.6)
+                    cand = true;
+                    if (semantics == 1) {          // CPU path: standup IoU (eps = 0) must be > 0 (nms_cpu.py:25, A.6)
                         float iw = fminf(s1.x1, s2.x1) - fmaxf(s1.x0, s2.x0);
                         float ih = fminf(s1.y1, s2.y1) - fmaxf(s1.y0, s2.y0);
-                        consider = iw > 0.0f && ih > 0.0f;
-                        if (consider) {
+                        cand = iw > 0.0f && ih > 0.0f;
+                        if (cand) {
                             float ua = (s1.x1 - s1.x0) * (s1.y1 - s1.y0) + (s2.x1 - s2.x0) * (s2.y1 - s2.y0) - iw * ih;
-                            consider = iw * ih / ua > 0.0f;
+                            cand = iw * ih / ua > 0.0f;
                         }
                     }
-                    if (consider) {
-                        float in = quad_inter(c1, c2);
-                        float v = in / (a1 + a2 - in);
-                        sup = semantics == 1 ? v >= thresh : v > thresh;
-                    }
-                } else if (semantics == 0) {
-                    sup = 0.0f > thresh;  // IoU is exactly 0
+                } else if (semantics == 0 && 0.0f > thresh) {
+                    atomicOr(&sup_words[rl], 1ull << cl);   // IoU is exactly 0 and the threshold is negative
                 }
             } else {
+                const float *c1 = tile[1][rl], *c2 = tile[0][cl];
                 float e = semantics == 0 ? 1.0f : eps;
                 float wv = fmaxf(fminf(c1[2], c2[2]) - fmaxf(c1[0], c2[0]) + e, 0.0f);
                 float hv = fmaxf(fminf(c1[3], c2[3]) - fmaxf(c1[1], c2[1]) + e, 0.0f);
@@ -252,12 +247,31 @@ __global__ __launch_bounds__(kBlock) void k_nms_mask(const float *__restrict__ d
                 float sa = (c1[2] - c1[0] + e) * (c1[3] - c1[1] + e);
                 float sb = (c2[2] - c2[0] + e) * (c2[3] - c2[1] + e);
                 float v = in / (sa + sb - in);
-                sup = semantics == 0 ? v > thresh : v >= thresh;
+                if (semantics == 0 ? v > thresh : v >= thresh) atomicOr(&sup_words[rl], 1ull << cl);
             }
         }
-        unsigned long long word = __ballot(sup);
-        if (lane == 0) mask[((size_t)b * max_n + row) * words + cb] = word;
+        unsigned long long m = __ballot(cand);
+        if (m) {
+            int qbase = 0;
+            if (lane == 0) qbase = atomicAdd(&qcount, __popcll(m));
+            qbase = __shfl(qbase, 0, 64);
+            if (cand) queue[qbase + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)((rl << 8) | cl);
+        }
     }
+    __syncthreads();
+    // ---- phase B: dense polygon clipping of the survivors
+    const int qn = qcount;
+    for (int q = tid; q < qn; q += kBlock) {
+        const int rl = queue[q] >> 8, cl = queue[q] & 255;
+        float c1[8], c2[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { c1[i] = tile[1][rl][i]; c2[i] = tile[0][cl][i]; }
+        float in = quad_inter(c1, c2);
+        float v = in / (tile[1][rl][8] + tile[0][cl][8] - in);
+        if (semantics == 1 ? v >= thresh : v > thresh) atomicOr(&sup_words[rl], 1ull << cl);
+    }
+    __syncthreads();
+    if (tid < 64 && rb * 64 + tid < n) mask[((size_t)b * max_n + rb * 64 + tid) * words + cb] = sup_words[tid];
 }
 
 __device__ __forceinline__ unsigned long long wave_or64(unsigned long long v) {

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(kBlock) void k_predict_keys(const T *__restrict__ c
 }
 
 // one workgroup per frame
-template <typename T>
+template <typename T, bool KEY16>
 __global__ __launch_bounds__(kSelThreads) void k_predict_select(const T *__restrict__ cls, View5 v, PredGeom g, int K,
                                                                 float score_thr, const unsigned *__restrict__ keys,
                                                                 int *__restrict__ top_idx,
@@ -84,28 +84,35 @@ __global__ __launch_bounds__(kSelThreads) void k_predict_select(const T *__restr
     const unsigned *fk = keys + (size_t)b * N;
     if (K > kSelThreads) K = kSelThreads;
     if (K > N) K = N;
-    // ---- radix select of the K-th largest key (4 x 8 bits, MSB first)
+    // ---- radix select of the K-th largest key (8 bits per pass, MSB first).  bf16 logits only carry 16 key bits
+    //      (the low half of the fp32 pattern is zero): two passes instead of four.
+    constexpr int UNR = 8;                       // independent key loads in flight per thread
+    const int first_shift = 24, last_shift = sizeof(T) == 2 && KEY16 ? 16 : 0;
     unsigned prefix = 0, mask = 0, need = K;
-    for (int shift = 24; shift >= 0; shift -= 8) {
+    for (int shift = first_shift; shift >= last_shift; shift -= 8) {
         for (int i = tid; i < 256; i += kSelThreads) hist[i] = 0;
         __syncthreads();
-        for (int n0 = 0; n0 < N; n0 += kSelThreads) {
-            int n = n0 + tid;
-            bool act = false;
-            unsigned d = 0;
-            if (n < N) {
-                unsigned key = fk[n];
-                act = (key & mask) == prefix;
-                d = (key >> shift) & 255u;
+        for (int n0 = 0; n0 < N; n0 += kSelThreads * UNR) {
+            unsigned kk[UNR];
+#pragma unroll
+            for (int j = 0; j < UNR; ++j) {
+                int n = n0 + j * kSelThreads + tid;
+                kk[j] = n < N ? fk[n] : 0u;
             }
-            // wave-aggregated histogram update (a uniform digit costs one LDS atomic per wave, not 64)
-            unsigned long long todo = __ballot(act);
-            while (todo) {
-                int leader = __ffsll((long long)todo) - 1;
-                unsigned d0 = __shfl(d, leader, 64);
-                unsigned long long same = __ballot(act && d == d0) & todo;
-                if (lane == leader) atomicAdd(&hist[d0], (unsigned)__popcll(same));
-                todo &= ~same;
+#pragma unroll
+            for (int j = 0; j < UNR; ++j) {
+                int n = n0 + j * kSelThreads + tid;
+                bool act = n < N && (kk[j] & mask) == prefix;
+                unsigned d = (kk[j] >> shift) & 255u;
+                // wave-aggregated histogram update (a uniform digit costs one LDS atomic per wave, not 64)
+                unsigned long long todo = __ballot(act);
+                while (todo) {
+                    int leader = __ffsll((long long)todo) - 1;
+                    unsigned d0 = __shfl(d, leader, 64);
+                    unsigned long long same = __ballot(act && d == d0) & todo;
+                    if (lane == leader) atomicAdd(&hist[d0], (unsigned)__popcll(same));
+                    todo &= ~same;
+                }
             }
         }
         __syncthreads();
@@ -131,36 +138,41 @@ __global__ __launch_bounds__(kSelThreads) void k_predict_select(const T *__restr
     ckey[tid] = 0u;
     cidx[tid] = 0x7fffffff;
     __syncthreads();
-    for (int n0 = 0; n0 < N; n0 += kSelThreads) {
-        int n = n0 + tid;
-        unsigned key = 0;
-        bool gt = false, eq = false;
-        if (n < N) {
-            key = fk[n];
-            gt = key > T_key;
-            eq = key == T_key;
+    for (int n0 = 0; n0 < N; n0 += kSelThreads * UNR) {
+        unsigned kk[UNR];
+#pragma unroll
+        for (int j = 0; j < UNR; ++j) {
+            int n = n0 + j * kSelThreads + tid;
+            kk[j] = n < N ? fk[n] : 0u;
         }
-        // rank among the equal keys of this chunk, in index order
-        unsigned long long em = __ballot(eq);
-        int wcnt = __popcll(em);
-        if (lane == 0) wsum[wv] = wcnt;
-        __syncthreads();
-        int ebase = s_eqbase;
-        for (int w2 = 0; w2 < wv; ++w2) ebase += wsum[w2];
-        int erank = ebase + __popcll(em & ((1ull << lane) - 1ull));
-        bool take = gt || (eq && erank < (int)need);
-        if (take) {
-            int pos = atomicAdd(&s_cnt, 1);
-            if (pos < kSelThreads) { ckey[pos] = key; cidx[pos] = n; }
+#pragma unroll
+        for (int j = 0; j < UNR; ++j) {
+            int n = n0 + j * kSelThreads + tid;
+            unsigned key = kk[j];
+            bool gt = n < N && key > T_key, eq = n < N && key == T_key;
+            unsigned long long em = __ballot(eq);
+            if (__syncthreads_or(eq)) {          // chunks without a tie candidate (almost all) skip the ordered ranking
+                if (lane == 0) wsum[wv] = __popcll(em);
+                __syncthreads();
+                int ebase = s_eqbase;
+                for (int w2 = 0; w2 < wv; ++w2) ebase += wsum[w2];
+                int erank = ebase + __popcll(em & ((1ull << lane) - 1ull));
+                eq = eq && erank < (int)need;
+                __syncthreads();
+                if (tid == 0) {
+                    int tot = 0;
+                    for (int w2 = 0; w2 < kSelThreads / 64; ++w2) tot += wsum[w2];
+                    s_eqbase += tot;
+                }
+                __syncthreads();
+            }
+            if (gt || eq) {
+                int pos = atomicAdd(&s_cnt, 1);
+                if (pos < kSelThreads) { ckey[pos] = key; cidx[pos] = n; }
+            }
         }
-        __syncthreads();
-        if (tid == 0) {
-            int tot = 0;
-            for (int w2 = 0; w2 < kSelThreads / 64; ++w2) tot += wsum[w2];
-            s_eqbase += tot;
-        }
-        __syncthreads();
     }
+    __syncthreads();
     // ---- bitonic sort of the (key desc, idx asc) pairs; unused slots hold key 0 / idx INT_MAX and sink to the end
     for (int size = 2; size <= kSelThreads; size <<= 1) {
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
@@ -301,15 +313,15 @@ SEC_API int sec_predict_select(const void *cls, const int64_t *h_cls_strides5, i
     View5 v = mkview(h_cls_strides5);
     hipStream_t st = (hipStream_t)stream;
     const long long total = (long long)batch * anchors_per_loc * h * w;
-#define SEC_SEL(T)                                                                                                              \
+#define SEC_SEL(T, K16)                                                                                                         \
     do {                                                                                                                        \
         hipLaunchKernelGGL(k_predict_keys<T>, dim3(div_up(total, kBlock)), dim3(kBlock), 0, st, (const T *)cls, v, g, key_scratch); \
-        hipLaunchKernelGGL(k_predict_select<T>, dim3(batch), dim3(kSelThreads), 0, st, (const T *)cls, v, g, k, score_thr,       \
+        hipLaunchKernelGGL((k_predict_select<T, K16>), dim3(batch), dim3(kSelThreads), 0, st, (const T *)cls, v, g, k, score_thr, \
                            key_scratch, top_idx, top_score, top_label, counts);                                                  \
     } while (0)
-    if (dtype == SEC_F32) SEC_SEL(float);
-    else if (dtype == SEC_BF16) SEC_SEL(__hip_bfloat16);
-    else if (dtype == SEC_F16) SEC_SEL(__half);
+    if (dtype == SEC_F32) SEC_SEL(float, false);
+    else if (dtype == SEC_BF16) SEC_SEL(__hip_bfloat16, true);
+    else if (dtype == SEC_F16) SEC_SEL(__half, false);
     else return SEC_E_UNSUPPORTED;
 #undef SEC_SEL
     return check_launch();
