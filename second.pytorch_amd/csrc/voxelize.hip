@@ -59,6 +59,15 @@ __global__ __launch_bounds__(kBlock) void k_vox_hash(const float *__restrict__ p
     pslot[i] = (int)s;
 }
 
+__global__ __launch_bounds__(kBlock) void k_vox_init(unsigned long long *__restrict__ keys, int *__restrict__ vals, long long table,
+                                                    int *__restrict__ count, long long rows, int *__restrict__ slot_idx,
+                                                    long long slots) {
+    long long stride = (long long)gridDim.x * kBlock;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < table; i += stride) { keys[i] = kEmptyKey; vals[i] = kEmptyI32; }
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < rows; i += stride) count[i] = 0;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < slots; i += stride) slot_idx[i] = kEmptyI32;
+}
+
 __global__ __launch_bounds__(kBlock) void k_vox_flag(const int *__restrict__ pslot,
                                                     const int *__restrict__ vals, int n,
                                                     int *__restrict__ flag) {
@@ -248,10 +257,14 @@ SEC_API int sec_voxelize_f32(const float *points, const int *point_offsets, int 
     p.table_mask = w.table - 1;
 
     int rc;
-    if ((rc = hip_ok(hipMemsetAsync(w.keys, 0xff, (size_t)w.table * sizeof(unsigned long long), st)))) return rc;
-    if ((rc = hip_ok(hipMemsetAsync(w.vals, 0x7f, (size_t)w.table * sizeof(int), st)))) return rc;
-    if ((rc = hip_ok(hipMemsetAsync(w.count, 0, (size_t)batch * max_voxels * sizeof(int), st)))) return rc;
-    if ((rc = hip_ok(hipMemsetAsync(w.slot_idx, 0x7f, (size_t)batch * max_voxels * max_points * sizeof(int), st)))) return rc;
+    {   // one init launch instead of four memset nodes; only the rows that can be live (#voxels <= #points) are touched
+        long long cap_rows = (long long)batch * max_voxels;
+        if (cap_rows > num_points) cap_rows = num_points > 0 ? num_points : 1;
+        int blocks = div_up((long long)w.table, kBlock);
+        if (blocks > 256 * 8) blocks = 256 * 8;
+        hipLaunchKernelGGL(k_vox_init, dim3(blocks), dim3(kBlock), 0, st, w.keys, w.vals, (long long)w.table, w.count, cap_rows,
+                           w.slot_idx, cap_rows * max_points);
+    }
     int nb = div_up(num_points > 0 ? num_points : 1, kBlock);
     if (num_points > 0) {
         hipLaunchKernelGGL(k_vox_hash, dim3(nb), dim3(kBlock), 0, st, points, point_offsets, p, w.keys, w.vals, w.pslot);
