@@ -313,12 +313,13 @@ __global__ __launch_bounds__(kBlock) void k_conv2d_nhwc_dma(const T *__restrict_
 // tile, brings the (16+2)^2 input halo into LDS ONCE (all Cin channels: 18*18*Cin*2 B = 83 KB for Cin = 128 --
 // CDNA4's 160 KB LDS makes this possible) and then only streams the nine 3x3 weight slabs (double-buffered LDS-DMA).
 // 8 waves as 4 (pixel quarters) x 2 (cout halves), each 64 px x 64 cout on MFMA 32x32x16.
-template <typename T, int CIN, int TH>
-__global__ __launch_bounds__(TH * 32) void k_conv2d_halo(const T *__restrict__ x, const T *__restrict__ wpk,
+template <typename T, int CIN, int TH, int NQ>
+__global__ __launch_bounds__(TH * 16 * NQ) void k_conv2d_halo(const T *__restrict__ x, const T *__restrict__ wpk,
                                                     const float *__restrict__ bias, T *__restrict__ y, Conv2dParams p,
                                                     int tiles_y, int tiles_x) {
     constexpr int TW = 16, HW_ = TW + 2, HPIX = (TH + 2) * (TW + 2);   // TH = 16: 324 halo pixels, 8 waves; TH = 8: 180, 4 waves
-    constexpr int NWV = TH / 2, PQ = TH / 4;       // waves; pixel quarters (64 px = 4 tile rows each)
+    constexpr int PQ = TH / 4, NWV = PQ * NQ;      // pixel groups (64 px = 4 tile rows each) x NQ cout groups = waves
+    constexpr int NTW = 128 / (NQ * 32);           // 32-wide cout tiles per wave
     constexpr int CH = CIN / 8;                    // 16-byte chunks per pixel (16 for Cin = 128)
     constexpr int HENT = HPIX * CH;                // uint4 entries of the halo
     constexpr int BN = 128, CC = CIN / 64, NIT = 9 * CC;
@@ -362,11 +363,11 @@ __global__ __launch_bounds__(TH * 32) void k_conv2d_halo(const T *__restrict__ x
             __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)&sB[buf * (8 * BN) + (j * NWV + wv) * 64], 16, 0, 0);
         }
     };
-    f32x16d acc[2][2];
+    f32x16d acc[2][NTW];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+        for (int c = 0; c < NTW; ++c)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[a][c][i] = 0.0f;
     // halo pixel (top-left tap) of this lane's two A rows: wave quarter wm = 4 tile rows, m-tile mt = 2 rows
@@ -386,24 +387,24 @@ __global__ __launch_bounds__(TH * 32) void k_conv2d_halo(const T *__restrict__ x
         const uint4 *bb = sB + buf * (8 * BN);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            uint4 af[2], bf[2];
+            uint4 af[2], bf[NTW];
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 const int hp = hp0[mt] + dy * HW_ + dx;
                 af[mt] = hal[hp * CH + ((cc * 8 + s * 2 + hh) ^ (hp & (CH - 1)))];
             }
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) bf[nt] = bb[(s * 2 + hh) * BN + wn * 64 + nt * 32 + r];
+            for (int nt = 0; nt < NTW; ++nt) bf[nt] = bb[(s * 2 + hh) * BN + wn * (BN / NQ) + nt * 32 + r];
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = MfmaD<T>::run(af[mt], bf[nt], acc[mt][nt]);
+                for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = MfmaD<T>::run(af[mt], bf[nt], acc[mt][nt]);
         }
         __syncthreads();
     }
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int co = n0 + wn * 64 + nt * 32 + r;
+    for (int nt = 0; nt < NTW; ++nt) {
+        const int co = n0 + wn * (BN / NQ) + nt * 32 + r;
         const float bv = bias ? bias[co] : 0.0f;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
@@ -420,35 +421,37 @@ __global__ __launch_bounds__(TH * 32) void k_conv2d_halo(const T *__restrict__ x
     }
 }
 
-template <typename T, int CIN, int TH>
+template <typename T, int CIN, int TH, int NQ>
 static int launch_conv2d_halo(const void *x, const void *wpk, const float *bias, void *y, const Conv2dParams &p, hipStream_t st) {
     constexpr size_t lds = ((size_t)(TH + 2) * 18 * (CIN / 8) + 2 * 8 * 128) * 16;
     static bool configured = false;
-    auto fn = k_conv2d_halo<T, CIN, TH>;
+    auto fn = k_conv2d_halo<T, CIN, TH, NQ>;
     if (!configured) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         configured = true;
     }
     const int ty = div_up(p.h, TH), tx = div_up(p.w, 16);
     const int gx = (p.batch * ty * tx + 7) / 8 * 8;
-    hipLaunchKernelGGL(fn, dim3(gx, p.cout / 128), dim3(TH * 32), lds, st, (const T *)x, (const T *)wpk, bias, (T *)y, p, ty, tx);
+    hipLaunchKernelGGL(fn, dim3(gx, p.cout / 128), dim3(TH * 16 * NQ), lds, st, (const T *)x, (const T *)wpk, bias, (T *)y, p, ty, tx);
     return check_launch();
 }
 
 static int conv2d_variant() {
     static int v = -1;
-    if (v < 0) { const char *e = getenv("SEC_CONV2D_VARIANT"); v = e ? atoi(e) : 3; }  // 0 register staged, 1 LDS-DMA implicit GEMM, 2/3 halo tile 16x16 / 8x16 (3x3 s1 p1 layers)
+    if (v < 0) { const char *e = getenv("SEC_CONV2D_VARIANT"); v = e ? atoi(e) : 4; }  // 0 register staged, 1 LDS-DMA implicit GEMM, 2/3/4 halo tile 16x16 / 8x16 / 8x16 with 8 waves
     return v;
 }
 
 template <typename T>
 static int launch_conv2d(const void *x, const void *wpk, const float *bias, void *y, const Conv2dParams &p, hipStream_t st) {
     dim3 block(kBlock);
-    if ((conv2d_variant() == 2 || conv2d_variant() == 3) && p.ksize == 3 && p.stride == 1 && p.pad == 1 &&
+    if (conv2d_variant() >= 2 && conv2d_variant() <= 4 && p.ksize == 3 && p.stride == 1 && p.pad == 1 &&
         p.cout % 128 == 0 && (p.cin == 128 || p.cin == 64)) {
         if (conv2d_variant() == 2)
-            return p.cin == 128 ? launch_conv2d_halo<T, 128, 16>(x, wpk, bias, y, p, st) : launch_conv2d_halo<T, 64, 16>(x, wpk, bias, y, p, st);
-        return p.cin == 128 ? launch_conv2d_halo<T, 128, 8>(x, wpk, bias, y, p, st) : launch_conv2d_halo<T, 64, 8>(x, wpk, bias, y, p, st);
+            return p.cin == 128 ? launch_conv2d_halo<T, 128, 16, 2>(x, wpk, bias, y, p, st) : launch_conv2d_halo<T, 64, 16, 2>(x, wpk, bias, y, p, st);
+        if (conv2d_variant() == 4)   // 8 waves on a 16x8 tile: 64 px x 32 cout per wave, 4 waves / SIMD at 2 workgroups per CU
+            return p.cin == 128 ? launch_conv2d_halo<T, 128, 8, 4>(x, wpk, bias, y, p, st) : launch_conv2d_halo<T, 64, 8, 4>(x, wpk, bias, y, p, st);
+        return p.cin == 128 ? launch_conv2d_halo<T, 128, 8, 2>(x, wpk, bias, y, p, st) : launch_conv2d_halo<T, 64, 8, 2>(x, wpk, bias, y, p, st);
     }
     if (conv2d_variant() >= 1) {
         const int gx = (div_up(p.m, 128) + 7) / 8 * 8;   // multiple of 8 for the XCD-aware tile order

@@ -148,15 +148,20 @@ __global__ __launch_bounds__(kBlock) void k_conv_cand(const int *__restrict__ in
 // per input row: how many of its candidates are the FIRST touch of their output cell (scan over n_in counts
 // instead of n_in * K flags: 27x less scan traffic)
 __global__ __launch_bounds__(kBlock) void k_conv_count(const int *__restrict__ cand_slot, const int *__restrict__ vals,
-                                                      int n_in, int kvol, int *__restrict__ count) {
+                                                      int n_in, int kvol, int *__restrict__ count,
+                                                      unsigned *__restrict__ first_mask) {
     int j = blockIdx.x * kBlock + threadIdx.x;
     if (j >= n_in) return;
     int c = 0;
+    unsigned m = 0;   // bit k = candidate (j, k) is a first touch (kvol <= 32; larger kernels recount in k_conv_assign)
     for (int k = 0; k < kvol; ++k) {
         int s = cand_slot[(size_t)j * kvol + k];
-        c += (s >= 0 && vals[s] == j * kvol + k) ? 1 : 0;
+        bool f = s >= 0 && vals[s] == j * kvol + k;
+        c += f ? 1 : 0;
+        if (f && k < 32) m |= 1u << k;
     }
     count[j] = c;
+    first_mask[j] = m;
 }
 
 __global__ __launch_bounds__(kBlock) void k_conv_assign(const int *__restrict__ cand_slot,
@@ -165,7 +170,8 @@ __global__ __launch_bounds__(kBlock) void k_conv_assign(const int *__restrict__ 
                                                        const int *__restrict__ rank, RbGeom g,
                                                        int *__restrict__ orank, int *__restrict__ out_indices,
                                                        int out_cap, int *__restrict__ num_out,
-                                                       const int *__restrict__ overflow) {
+                                                       const int *__restrict__ overflow,
+                                                       const unsigned *__restrict__ first_mask) {
     long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (t == 0) {  // num_out[0] = live outputs (clamped to the capacity), num_out[1] = raw count (overflow check)
         int tot = num_out[0];
@@ -178,9 +184,13 @@ __global__ __launch_bounds__(kBlock) void k_conv_assign(const int *__restrict__ 
     // rank = first touches of earlier rows (scan) + first touches of this row at smaller offsets
     const int j = (int)(t / g.kvol), k = (int)(t % g.kvol);
     int r = rank[j];
-    for (int k2 = 0; k2 < k; ++k2) {
-        int s2 = cand_slot[(size_t)j * g.kvol + k2];
-        r += (s2 >= 0 && vals[s2] == j * g.kvol + k2) ? 1 : 0;
+    if (g.kvol <= 32) {
+        r += __popc(first_mask[j] & ((1u << k) - 1u));
+    } else {
+        for (int k2 = 0; k2 < k; ++k2) {
+            int s2 = cand_slot[(size_t)j * g.kvol + k2];
+            r += (s2 >= 0 && vals[s2] == j * g.kvol + k2) ? 1 : 0;
+        }
     }
     orank[s] = r;
     if (r < out_cap) {
@@ -270,6 +280,7 @@ static int emit_pairs(const int *table, int n, int kvol, int mirror, int *blk, i
 struct RbWorkspace {
     unsigned long long *keys;
     int *vals, *orank, *cand_slot, *rank, *scan, *blk, *scan2, *overflow;
+    unsigned *first_mask;
     uint32_t table;
     size_t bytes;
 };
@@ -290,6 +301,7 @@ static RbWorkspace carve_rb(void *ws, size_t cap, int n_in, int kvol, int max_ou
     w.blk = a.take<int>(nblk + 1);
     w.scan2 = a.take<int>(scan_scratch_ints(nblk));
     w.overflow = a.take<int>(1);
+    w.first_mask = a.take<unsigned>(n_in > 0 ? n_in : 1);
     w.bytes = align_up(a.used);
     return w;
 }
@@ -383,10 +395,10 @@ SEC_API int sec_rulebook_conv3d_build(const int *indices, int n_in, const int *n
     rb_init(w.keys, w.table, kEmptyKey, w.vals, w.table, kEmptyI32, w.overflow, 1, 0, st);
     int nb = div_up(nk, kBlock);
     hipLaunchKernelGGL(k_conv_cand, dim3(nb), dim3(kBlock), 0, st, indices, g, n_in_dev, w.keys, w.vals, w.cand_slot, w.overflow);
-    hipLaunchKernelGGL(k_conv_count, dim3(div_up(n_in, kBlock)), dim3(kBlock), 0, st, w.cand_slot, w.vals, n_in, g.kvol, w.rank);
+    hipLaunchKernelGGL(k_conv_count, dim3(div_up(n_in, kBlock)), dim3(kBlock), 0, st, w.cand_slot, w.vals, n_in, g.kvol, w.rank, w.first_mask);
     if ((rc = exclusive_scan_i32(w.rank, w.rank, n_in, num_out, w.scan, st))) return rc;
     hipLaunchKernelGGL(k_conv_assign, dim3(nb), dim3(kBlock), 0, st, w.cand_slot, w.vals, w.keys, w.rank, g, w.orank,
-                       out_indices, out_cap, num_out, w.overflow);
+                       out_indices, out_cap, num_out, w.overflow, w.first_mask);
     return check_launch();
 }
 
