@@ -61,7 +61,40 @@ __global__ __launch_bounds__(kBlock) void k_scan_apply(const int *__restrict__ i
     }
 }
 
+// single-workgroup scan (1024 threads, each a contiguous run): one launch instead of three for small n
+constexpr int kSoloThreads = 1024;
+__global__ __launch_bounds__(kSoloThreads) void k_scan_solo(const int *__restrict__ in, int *__restrict__ out, int n,
+                                                           int *__restrict__ total_out) {
+    __shared__ int wtot[kSoloThreads / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int per = (n + kSoloThreads - 1) / kSoloThreads;
+    const int lo = tid * per, hi = lo + per < n ? lo + per : n;
+    int s = 0;
+    for (int i = lo; i < hi; ++i) s += in[i];
+    int inc = wave_inclusive_scan(s);
+    if (lane == 63) wtot[wv] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < kSoloThreads / 64; ++i) {
+        int v = wtot[i];
+        if (i < wv) base += v;
+        tot += v;
+    }
+    int run = base + inc - s;
+    for (int i = lo; i < hi; ++i) {
+        int v = in[i];
+        out[i] = run;
+        run += v;
+    }
+    if (tid == 0 && total_out) *total_out = tot;
+}
+
 int exclusive_scan_i32(const int *in, int *out, long long n, int *total_out, int *scratch, hipStream_t st) {
+    if (n > 0 && n <= 16 * 1024) {   // tiny scans only: a thread-contiguous run is uncoalesced, 128-element runs cost more than 3 launches
+        hipLaunchKernelGGL(k_scan_solo, dim3(1), dim3(kSoloThreads), 0, st, in, out, (int)n, total_out);
+        return check_launch();
+    }
     if (n <= 0) {
         if (total_out) return hip_ok(hipMemsetAsync(total_out, 0, sizeof(int), st));
         return SEC_OK;

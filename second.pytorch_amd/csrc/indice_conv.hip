@@ -294,6 +294,59 @@ __global__ __launch_bounds__(NW * 64) void k_conv_mfma_sk(const T *__restrict__ 
     }
 }
 
+// Split-K + cout-sliced variant: grid.y selects a 32-column slice of the output, so a wave carries 16 accumulator
+// registers and 4*KS weight registers per offset instead of NT times that -- more waves per SIMD (the layer is
+// latency bound) at the price of gathering the rows once per slice.
+template <typename T, typename OT, int CIN, int COUT, int NW>
+__global__ __launch_bounds__(NW * 64) void k_conv_mfma_sks(const T *__restrict__ feat, const T *__restrict__ packed,
+                                                         const int *__restrict__ nbr, int n_out,
+                                                         const int *__restrict__ num_out_dev, int kvol,
+                                                         const float *__restrict__ scale, const float *__restrict__ shift,
+                                                         int relu, OT *__restrict__ out) {
+    constexpr int KS = CIN / 16, NT = (COUT + 31) / 32;
+    __shared__ float red[NW][16][64];
+    if (num_out_dev) n_out = *num_out_dev;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int t = blockIdx.y;
+    const long long base = (long long)xcd_tile(blockIdx.x, gridDim.x, 1) * 32;
+    if (base >= n_out) return;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    const long long row = base + r;
+    const bool valid = row < n_out;
+    const int *nrow = nbr + (size_t)(valid ? row : 0) * kvol;
+    const uint4 *wp = reinterpret_cast<const uint4 *>(packed) + lane;
+    int idx = (valid && w < kvol) ? nrow[w] : -1;
+    for (int k = w; k < kvol; k += NW) {
+        const int cur = idx;
+        if (k + NW < kvol) idx = valid ? nrow[k + NW] : -1;
+        if (__ballot(cur >= 0) == 0ull) continue;
+        uint4 a[KS];
+        const uint4 *src = reinterpret_cast<const uint4 *>(feat + (size_t)(cur >= 0 ? cur : 0) * CIN) + h;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) a[s] = cur >= 0 ? src[s * 2] : make_uint4(0, 0, 0, 0);
+        const uint4 *wk = wp + (size_t)k * KS * NT * 64;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) acc = Mfma<T>::run(a[s], wk[(s * NT + t) * 64], acc);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) red[w][i][lane] = acc[i];
+    __syncthreads();
+    constexpr int PER = 16 / NW;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int i = w * PER + j;
+        float v = 0.0f;
+#pragma unroll
+        for (int ww = 0; ww < NW; ++ww) v += red[ww][i][lane];
+        const int col = t * 32 + r;
+        const long long orow = base + (i & 3) + 8 * (i >> 2) + 4 * h;
+        if (col < COUT && orow < n_out) out[(size_t)orow * COUT + col] = Cvt<OT>::from(epilogue(v, scale, shift, col, relu));
+    }
+}
+
 // First layer of SpMiddleFHD (Cin = 4, middle.py:146): one thread per output row, all COUT channels in
 // registers, the 27 x 4 x COUT weight block broadcast from LDS, 8-byte (4 x bf16) gathers.
 template <typename T, typename OT, int COUT>
@@ -831,6 +884,12 @@ static void launch_mfma(const void *feat, const void *packed, const int *nbr, in
     }
     if ((conv_variant() == 6 || conv_variant() == 7) && kvol == 27 && CIN <= 64) {
         launch_wlds<T, OT, CIN, COUT>(feat, packed, nbr, n_out, num_out_dev, scale, shift, relu, out, st);
+        return;
+    }
+    if (conv_variant() == 8 || (conv_variant() == 1 && COUT <= 32)) {   // single 32-column slice: leaner split-K kernel
+        hipLaunchKernelGGL((k_conv_mfma_sks<T, OT, CIN, COUT, 4>), dim3((div_up(n_out, 32) + 7) / 8 * 8, (COUT + 31) / 32),
+                           dim3(256), 0, st, (const T *)feat, (const T *)packed, nbr, n_out, num_out_dev, kvol, scale, shift,
+                           relu, (OT *)out);
         return;
     }
     if (conv_variant() == 3 && kvol == 27) {

@@ -104,14 +104,19 @@ __global__ __launch_bounds__(kSelThreads) void k_predict_select(const T *__restr
                 int n = n0 + j * kSelThreads + tid;
                 bool act = n < N && (kk[j] & mask) == prefix;
                 unsigned d = (kk[j] >> shift) & 255u;
-                // wave-aggregated histogram update (a uniform digit costs one LDS atomic per wave, not 64)
-                unsigned long long todo = __ballot(act);
-                while (todo) {
-                    int leader = __ffsll((long long)todo) - 1;
-                    unsigned d0 = __shfl(d, leader, 64);
-                    unsigned long long same = __ballot(act && d == d0) & todo;
-                    if (lane == leader) atomicAdd(&hist[d0], (unsigned)__popcll(same));
-                    todo &= ~same;
+                if (shift == first_shift) {
+                    // sign/exponent byte: a handful of distinct values -> wave-aggregated update (a uniform digit
+                    // costs one LDS atomic per wave instead of a 64-way conflict)
+                    unsigned long long todo = __ballot(act);
+                    while (todo) {
+                        int leader = __ffsll((long long)todo) - 1;
+                        unsigned d0 = __shfl(d, leader, 64);
+                        unsigned long long same = __ballot(act && d == d0) & todo;
+                        if (lane == leader) atomicAdd(&hist[d0], (unsigned)__popcll(same));
+                        todo &= ~same;
+                    }
+                } else if (act) {
+                    atomicAdd(&hist[d], 1u);      // mantissa bytes are well spread and only the prefix matches are active
                 }
             }
         }
