@@ -436,6 +436,99 @@ static int launch_conv2d_halo(const void *x, const void *wpk, const float *bias,
     return check_launch();
 }
 
+// 1x1 convolutions (the ConvTranspose2d(k=1) "deconv" and the merged heads of the RPN, rpn.py:275-285,386-391) are
+// memory bound: the generic implicit-GEMM kernel re-fetches the whole [Cin x BN] weight block for every 128-pixel
+// tile (as many bytes as the activations it reads).  Here the weight block (Cin = 128: two 16 KB slabs) stays
+// RESIDENT in LDS while the workgroup streams TPW consecutive pixel tiles through a double-buffered A slab.
+template <typename T, int BN, int TPW>
+__global__ __launch_bounds__(kBlock) void k_conv1x1_nhwc(const T *__restrict__ x, const T *__restrict__ wpk,
+                                                        const float *__restrict__ bias, T *__restrict__ y, Conv2dParams p) {
+    constexpr int BM = 128, NTW = BN / 64, CC = 2;   // Cin == 128
+    constexpr int PERB = BN * 8 / kBlock;
+    __shared__ uint4 sA[2][BM * 8];
+    __shared__ uint4 sB[CC][8 * BN];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int wm = wv & 1, wn = wv >> 1;
+    const int n0 = blockIdx.y * BN;
+    const int cin8 = p.cin / 8;
+    const uint4 *x4 = reinterpret_cast<const uint4 *>(x);
+    const uint4 *w4 = reinterpret_cast<const uint4 *>(wpk);
+    const uint4 *zero16 = w4 + (size_t)cin8 * p.cout;
+    const long long tile0 = (long long)blockIdx.x * TPW;
+    const long long ntiles = (p.m + BM - 1) / BM;
+    if (tile0 >= ntiles) return;
+    const int nt_local = (int)((ntiles - tile0 < TPW) ? ntiles - tile0 : TPW);
+    const int slot = lane & 7;
+    auto issue_a = [&](int it, int buf) {           // it = local_tile * CC + cc ; 1x1: pixel p reads input pixel p
+        const long long m0 = (tile0 + it / CC) * BM;
+        const int cc = it % CC;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int pl = (j * 4 + wv) * 8 + (lane >> 3);
+            const long long pix = m0 + pl;
+            const uint4 *src = pix < p.m ? x4 + pix * cin8 + cc * 8 + (slot ^ (pl & 7)) : zero16;
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)&sA[buf][(j * 4 + wv) * 64], 16, 0, 0);
+        }
+    };
+#pragma unroll
+    for (int cc = 0; cc < CC; ++cc)
+#pragma unroll
+        for (int j = 0; j < PERB; ++j) {
+            const int e = (j * 4 + wv) * 64 + lane, ch = e / BN, n = e - ch * BN;
+            const uint4 *src = w4 + ((size_t)cc * 8 + ch) * p.cout + n0 + n;
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)&sB[cc][(j * 4 + wv) * 64], 16, 0, 0);
+        }
+    issue_a(0, 0);
+    __syncthreads();
+    f32x16d acc[2][NTW];
+    const int NIT = nt_local * CC;
+    for (int it = 0; it < NIT; ++it) {
+        const int buf = it & 1, cc = it % CC;
+        if (cc == 0) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < NTW; ++b)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
+        }
+        if (it + 1 < NIT) issue_a(it + 1, buf ^ 1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            uint4 af[2], bf[NTW];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) af[mt] = sA[buf][(wm * 64 + mt * 32 + r) * 8 + ((s * 2 + hh) ^ (r & 7))];
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) bf[nt] = sB[cc][(s * 2 + hh) * BN + wn * (BN / 2) + nt * 32 + r];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = MfmaD<T>::run(af[mt], bf[nt], acc[mt][nt]);
+        }
+        if (cc == CC - 1) {
+            const long long m0 = (tile0 + it / CC) * BM;
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                const int co = n0 + wn * (BN / 2) + nt * 32 + r;
+                const float bv = bias ? bias[co] : 0.0f;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const long long pix = m0 + wm * 64 + mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+                        if (pix < p.m) {
+                            float v = acc[mt][nt][i] + bv;
+                            if (p.relu) v = v > 0.0f ? v : 0.0f;
+                            y[(size_t)pix * p.cout + co] = from_f<T>(v);
+                        }
+                    }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 static int conv2d_variant() {
     static int v = -1;
     if (v < 0) { const char *e = getenv("SEC_CONV2D_VARIANT"); v = e ? atoi(e) : 4; }  // 0 register staged, 1 LDS-DMA implicit GEMM, 2/3/4 halo tile 16x16 / 8x16 / 8x16 with 8 waves
@@ -452,6 +545,17 @@ static int launch_conv2d(const void *x, const void *wpk, const float *bias, void
         if (conv2d_variant() == 4)   // 8 waves on a 16x8 tile: 64 px x 32 cout per wave, 4 waves / SIMD at 2 workgroups per CU
             return p.cin == 128 ? launch_conv2d_halo<T, 128, 8, 4>(x, wpk, bias, y, p, st) : launch_conv2d_halo<T, 64, 8, 4>(x, wpk, bias, y, p, st);
         return p.cin == 128 ? launch_conv2d_halo<T, 128, 8, 2>(x, wpk, bias, y, p, st) : launch_conv2d_halo<T, 64, 8, 2>(x, wpk, bias, y, p, st);
+    }
+    if (conv2d_variant() >= 1 && p.ksize == 1 && p.stride == 1 && p.pad == 0 && p.cin == 128) {
+        constexpr int TPW = 4;
+        const int gx1 = div_up(div_up(p.m, 128), TPW);
+        if (p.cout % 128 == 0)
+            hipLaunchKernelGGL((k_conv1x1_nhwc<T, 128, TPW>), dim3(gx1, p.cout / 128), block, 0, st, (const T *)x, (const T *)wpk,
+                               bias, (T *)y, p);
+        else
+            hipLaunchKernelGGL((k_conv1x1_nhwc<T, 64, TPW>), dim3(gx1, p.cout / 64), block, 0, st, (const T *)x, (const T *)wpk,
+                               bias, (T *)y, p);
+        return check_launch();
     }
     if (conv2d_variant() >= 1) {
         const int gx = (div_up(p.m, 128) + 7) / 8 * 8;   // multiple of 8 for the XCD-aware tile order

@@ -206,8 +206,11 @@ static int conv_swizzle() {
 }
   // profiling aid (tools/conv_microbench.py --timeline); null in production
 
+#ifndef SEC_SK_MIN_WAVES
+#define SEC_SK_MIN_WAVES 5
+#endif
 template <typename T, typename OT, int CIN, int COUT, int NW>
-__global__ __launch_bounds__(NW * 64) void k_conv_mfma_sk(const T *__restrict__ feat, const T *__restrict__ packed,
+__global__ __launch_bounds__(NW * 64, SEC_SK_MIN_WAVES) void k_conv_mfma_sk(const T *__restrict__ feat, const T *__restrict__ packed,
                                                         const int *__restrict__ nbr, int n_out,
                                                         const int *__restrict__ num_out_dev, int kvol,
                                                         const float *__restrict__ scale, const float *__restrict__ shift,
@@ -217,7 +220,7 @@ __global__ __launch_bounds__(NW * 64) void k_conv_mfma_sk(const T *__restrict__ 
     if (tl) t0 = clock64();
     constexpr int KS = CIN / 16, NT = (COUT + 31) / 32, NREG = NT * 16;
     static_assert(NREG % NW == 0, "registers must split evenly over the waves");
-    __shared__ float red[NW][NREG][64];
+    __shared__ float red[2][NREG][64];
     if (num_out_dev) n_out = *num_out_dev;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -269,19 +272,36 @@ __global__ __launch_bounds__(NW * 64) void k_conv_mfma_sk(const T *__restrict__ 
     }
     relu &= 0xff;
     if (tl) t2 = clock64();
+    // pairwise LDS reduction in the MFMA register layout (2 slots = 16 KB instead of NW slots: LDS no longer caps
+    // the occupancy): waves 1,3 -> 0,2 ; wave 2 -> 0 ; then waves 0..NW-1 each finish 1/NW of the registers
+    static_assert(NW == 4, "pairwise reduction is written for 4 waves");
+    if (w & 1) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) red[w][t * 16 + i][lane] = acc[t][i];
+            for (int i = 0; i < 16; ++i) red[w >> 1][t * 16 + i][lane] = acc[t][i];
+    }
+    __syncthreads();
+    if (!(w & 1)) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[t][i] += red[w >> 1][t * 16 + i][lane];
+    }
+    __syncthreads();
+    if (w == 0 || w == 2) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) red[w >> 1][t * 16 + i][lane] = acc[t][i];
+    }
     __syncthreads();
     if (tl) t3 = clock64();
     constexpr int PER = NREG / NW;
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
         const int reg = w * PER + j;
-        float v = 0.0f;
-#pragma unroll
-        for (int ww = 0; ww < NW; ++ww) v += red[ww][reg][lane];
+        const float v = red[0][reg][lane] + red[1][reg][lane];
         const int t = reg >> 4, i = reg & 15;
         const int col = t * 32 + r;
         const long long orow = base + (i & 3) + 8 * (i >> 2) + 4 * h;
