@@ -138,6 +138,13 @@ int sec_sparse_to_dense(const void *features, const int *indices, int n, int c, 
                         void *out, size_t out_elems, int64_t stride_b, int64_t stride_c,
                         int64_t stride_z, int64_t stride_y, int64_t stride_x, int dtype, void *stream);
 
+/* Adjoint of sec_sparse_to_dense -- rows[i,:] = dense[indices[i]] -- i.e. the backward of
+ * SparseConvTensor.dense() (upstream gets it from autograd through scatter_nd, spconv/__init__.py) and of
+ * PointPillarsScatter (pointpillars.py:444-476) with stride_z = 0. */
+int sec_dense_to_sparse(const void *dense, const int *indices, int n, int c, void *rows,
+                        int64_t stride_b, int64_t stride_c, int64_t stride_z, int64_t stride_y,
+                        int64_t stride_x, int dtype, void *stream);
+
 /* PointPillarsScatter.forward (second/pytorch/models/pointpillars.py:444-476): coords (b,z,y,x),
  * canvas [B, C, ny, nx] (strides given in elements), cleared first. */
 int sec_pillar_scatter(const void *features, const int *coords, int p, int c, void *out,

@@ -22,6 +22,30 @@ __global__ __launch_bounds__(kBlock) void k_scatter_rows(const T *__restrict__ f
     }
 }
 
+// adjoint of k_scatter_rows: rows[i, ch] = dense[idx[i]] (the backward of SparseConvTensor.dense())
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_gather_rows(const T *__restrict__ dense, const int *__restrict__ idx, int n,
+                                                       int c, T *__restrict__ rows, long long sb, long long sc,
+                                                       long long sz, long long sy, long long sx) {
+    long long total = (long long)n * c;
+    for (long long g = (long long)blockIdx.x * kBlock + threadIdx.x; g < total; g += (long long)gridDim.x * kBlock) {
+        int i = (int)(g / c), ch = (int)(g % c);
+        int4 q = *reinterpret_cast<const int4 *>(idx + (size_t)i * 4);
+        rows[g] = dense[q.x * sb + ch * sc + q.y * sz + q.z * sy + q.w * sx];
+    }
+}
+
+template <typename T>
+static int run_gather(const void *dense, const int *idx, int n, int c, void *rows, long long sb, long long sc,
+                      long long sz, long long sy, long long sx, hipStream_t st) {
+    if (n == 0) return SEC_OK;
+    int blocks = div_up((long long)n * c, kBlock);
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(k_gather_rows<T>, dim3(blocks), dim3(kBlock), 0, st, (const T *)dense, idx, n, c, (T *)rows, sb, sc,
+                       sz, sy, sx);
+    return check_launch();
+}
+
 template <typename T>
 static int run_scatter(const void *feat, const int *idx, int n, const int *num_dev, int c, void *out, size_t out_elems,
                        long long sb, long long sc, long long sz, long long sy, long long sx, hipStream_t st) {
@@ -48,6 +72,18 @@ SEC_API int sec_sparse_to_dense(const void *features, const int *indices, int n,
         return run_scatter<float>(features, indices, n, num_dev, c, out, out_elems, stride_b, stride_c, stride_z, stride_y, stride_x, st);
     if (dtype == SEC_F16 || dtype == SEC_BF16)  // pure byte movement: both are 16-bit
         return run_scatter<unsigned short>(features, indices, n, num_dev, c, out, out_elems, stride_b, stride_c, stride_z, stride_y, stride_x, st);
+    return SEC_E_UNSUPPORTED;
+}
+
+SEC_API int sec_dense_to_sparse(const void *dense, const int *indices, int n, int c, void *rows, int64_t stride_b,
+                                int64_t stride_c, int64_t stride_z, int64_t stride_y, int64_t stride_x, int dtype,
+                                void *stream) {
+    if (n < 0 || c <= 0 || (n > 0 && (!dense || !indices || !rows))) return SEC_E_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SEC_F32)
+        return run_gather<float>(dense, indices, n, c, rows, stride_b, stride_c, stride_z, stride_y, stride_x, st);
+    if (dtype == SEC_F16 || dtype == SEC_BF16)
+        return run_gather<unsigned short>(dense, indices, n, c, rows, stride_b, stride_c, stride_z, stride_y, stride_x, st);
     return SEC_E_UNSUPPORTED;
 }
 

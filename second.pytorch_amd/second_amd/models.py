@@ -60,6 +60,38 @@ ALL_PP_LARGEA = dict(
 )  # second/configs/nuscenes/all.pp.largea.config
 
 
+ALL_FHD_NUSC = dict(
+    name="nuscenes/all.fhd",
+    point_cloud_range=[-49.6, -49.6, -5, 49.6, 49.6, 3], voxel_size=[0.05, 0.05, 0.2], max_points_per_voxel=1,
+    max_voxels=90000, num_point_features=4,
+    block_filtering=dict(block_factor=1, block_size=8, height_threshold=0.2),   # ground-block filter
+    middle="SpMiddleFHD", middle_in=4,
+    rpn=dict(layer_nums=[5], layer_strides=[1], num_filters=[128], upsample_strides=[0.5],   # 0.5 = stride-2 conv
+             num_upsample_filters=[128], num_input_features=128),
+    downsample_factor=16,
+    # car, bicycle, bus, construction_vehicle, motorcycle, pedestrian, traffic_cone, trailer (2 sizes), truck, barrier
+    anchor_sizes=[[1.95017719, 4.60718155, 1.72270763], [0.6005891, 1.68452156, 1.27192199],
+                  [2.94046903, 11.18859863, 3.47030973], [2.73050475, 6.38352919, 3.13312411],
+                  [0.76279479, 2.09973788, 1.44403028], [0.66344887, 0.72564369, 1.75748074],
+                  [0.39694518, 0.40359262, 1.06232154], [3.0, 15.0, 3.8], [2.0, 3.0, 3.8],
+                  [2.45609379, 6.73778057, 2.73004913], [2.49008846, 0.48578221, 0.98297065]],
+    anchor_ranges=[[-49.6, -49.6, z, 49.6, 49.6, z] for z in
+                   (-0.93897414, -1.03743017, -0.0715754, -0.08168083, -0.99194854, -0.73911035, -1.27868915,
+                    0.22228277, 0.22228277, -0.37937912, -1.27247965)],
+    anchor_groups=[[0], [1], [2], [3], [4], [5], [6], [7, 8], [9], [10]],
+    rotations=[0, 1.57], group_rotations={5: [0], 6: [0]},   # pedestrian / traffic_cone: one rotation
+    num_class=10, num_direction_bins=2, direction_offset=0.78, direction_limit_offset=0.0,
+    nms_score_threshold=0.05, nms_pre_max_size=1000, nms_post_max_size=300, nms_iou_threshold=0.5,
+    use_rotate_nms=False, post_center_range=[-59.6, -59.6, -10, 59.6, 59.6, 10],
+)  # second/configs/nuscenes/all.fhd.config
+
+
+def anchors_per_location(cfg):
+    """target_assigner.num_anchors_per_location (target_assigner.py:249-254): sum over generators of sizes x rotations."""
+    groups = cfg.get("anchor_groups") or [[i] for i in range(len(cfg["anchor_sizes"]))]
+    return sum(len(g) * len(cfg.get("group_rotations", {}).get(gi, cfg["rotations"])) for gi, g in enumerate(groups))
+
+
 def grid_size_of(cfg):
     r = np.array(cfg["point_cloud_range"], np.float32)
     v = np.array(cfg["voxel_size"], np.float32)
@@ -72,8 +104,8 @@ def generate_anchors(cfg, feature_map_size):
     d, h, w = feature_map_size
     out = []
     groups = cfg.get("anchor_groups") or [[i] for i in range(len(cfg["anchor_sizes"]))]
-    rots = np.array(cfg["rotations"], np.float32)
-    for grp in groups:   # one anchor generator: (size, rotation) major, then z, y, x
+    for gi, grp in enumerate(groups):   # one anchor generator: (size, rotation) major, then z, y, x
+        rots = np.array(cfg.get("group_rotations", {}).get(gi, cfg["rotations"]), np.float32)
         rng = np.array(cfg["anchor_ranges"][grp[0]], np.float32)
         zc = np.linspace(rng[2], rng[5], d, dtype=np.float32)
         yc = np.linspace(rng[1], rng[4], h, dtype=np.float32)
@@ -151,6 +183,10 @@ class PointPillarsScatter(nn.Module):
         self.ny, self.nx, self.nchannels = int(output_shape[2]), int(output_shape[3]), num_input_features
 
     def forward(self, voxel_features, coords, batch_size, channels_last=False):
+        if torch.is_grad_enabled() and voxel_features.requires_grad:   # training: differentiable scatter
+            from spconv.functional import PillarScatterFunction
+            return PillarScatterFunction.apply(voxel_features.contiguous(), coords.int().contiguous(), batch_size,
+                                               self.ny, self.nx)
         return ops.pillar_scatter(voxel_features.contiguous(), coords.int().contiguous(), batch_size, self.ny, self.nx,
                                   channels_last=channels_last)
 
@@ -412,7 +448,7 @@ class SecondDetector(nn.Module):
         else:
             self.voxel_feature_extractor = SimpleVoxel(cfg["num_point_features"])
             self.middle_feature_extractor = SpMiddleFHD(dense_shape, cfg["middle_in"])
-        a_per_loc = len(cfg["rotations"]) * len(cfg["anchor_sizes"])
+        a_per_loc = anchors_per_location(cfg)
         self.rpn = RPNV2(num_class=cfg["num_class"], num_anchor_per_loc=a_per_loc, num_direction_bins=cfg["num_direction_bins"],
                          **cfg["rpn"])
         self.register_buffer("global_step", torch.LongTensor(1).zero_())
@@ -424,8 +460,10 @@ class SecondDetector(nn.Module):
                              persistent=False)
         self._infer_dtype = None
         self.fused_predict = True
+        bf = cfg.get("block_filtering")
         self.voxel_generator = spconv.utils.VoxelGeneratorV2(cfg["voxel_size"], cfg["point_cloud_range"],
-                                                            cfg["max_points_per_voxel"], cfg["max_voxels"])
+                                                            cfg["max_points_per_voxel"], cfg["max_voxels"],
+                                                            **(dict(bf, block_filtering=True) if bf else {}))
 
     # -- inference preparation: bf16 channels-last RPN with folded BN; sparse stack in bf16 (BN folded at run time)
     def prepare_inference(self, dtype=torch.bfloat16):
@@ -592,7 +630,7 @@ class SecondDetector(nn.Module):
     def _predict_fused(self, preds, batch_size, anchors):
         """select -> decode -> NMS -> finalize: five launches, no host sync, no torch glue."""
         cfg = self.cfg
-        a_per_loc = len(cfg["rotations"]) * len(cfg["anchor_sizes"])
+        a_per_loc = anchors_per_location(cfg)
         _, h, w = self.feature_map_size
 
         def view5(t, code):

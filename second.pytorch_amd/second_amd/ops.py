@@ -223,6 +223,24 @@ def sparse_to_dense(features, indices, batch_size, spatial_shape, channels_last_
     return out
 
 
+def dense_to_sparse(dense, indices):
+    """rows[i,:] = dense[b_i, :, (z_i,) y_i, x_i]: the adjoint of :func:`sparse_to_dense` ([B,C,D,H,W]) and of
+    :func:`pillar_scatter` ([B,C,H,W], z ignored) -- what autograd needs for their backward."""
+    rt.require_gpu(dense, indices)
+    n = indices.shape[0]
+    c = dense.shape[1]
+    rows = torch.empty((n, c), dtype=dense.dtype, device=dense.device)
+    st = [int(v) for v in dense.stride()]
+    if dense.dim() == 5:
+        sb, sc, sz, sy, sx = st
+    else:
+        (sb, sc, sy, sx), sz = st, 0
+    rc = rt.lib().sec_dense_to_sparse(rt.ptr(dense), rt.ptr(indices.contiguous()), n, c, rt.ptr(rows), sb, sc, sz, sy, sx,
+                                      rt.dtype_code(dense.dtype), rt.stream())
+    rt.check(rc, "sec_dense_to_sparse")
+    return rows
+
+
 def pillar_scatter(features, coords, batch_size, ny, nx, channels_last=False):
     """PointPillarsScatter.forward (second/pytorch/models/pointpillars.py:444-476) as one launch."""
     rt.require_gpu(features, coords)

@@ -26,3 +26,31 @@ def indice_conv(features, weight, rulebook, packed=None):
 
 
 indice_subm_conv = indice_conv
+
+
+class SparseToDenseFunction(torch.autograd.Function):
+    """dense() with a gradient (upstream: scatter_nd under autograd, spconv/__init__.py SparseConvTensor.dense)."""
+
+    @staticmethod
+    def forward(ctx, features, indices, batch_size, spatial_shape):
+        ctx.save_for_backward(indices)
+        return _ops.sparse_to_dense(features, indices, batch_size, spatial_shape)
+
+    @staticmethod
+    def backward(ctx, grad):
+        (indices,) = ctx.saved_tensors
+        return _ops.dense_to_sparse(grad, indices), None, None, None
+
+
+class PillarScatterFunction(torch.autograd.Function):
+    """PointPillarsScatter with a gradient (pointpillars.py:444-476 relies on index assignment under autograd)."""
+
+    @staticmethod
+    def forward(ctx, features, coords, batch_size, ny, nx):
+        ctx.save_for_backward(coords)
+        return _ops.pillar_scatter(features, coords, batch_size, ny, nx)
+
+    @staticmethod
+    def backward(ctx, grad):
+        (coords,) = ctx.saved_tensors
+        return _ops.dense_to_sparse(grad, coords), None, None, None, None

@@ -52,8 +52,12 @@ class SparseConvTensor:
         return self.indice_dict.get(key)
 
     def dense(self, channels_first=True):
-        out = _ops.sparse_to_dense(self.features, self.indices.contiguous(), self.batch_size, self.spatial_shape,
-                                   num_dev=self.num_active_dev)
+        if torch.is_grad_enabled() and self.features.requires_grad:   # training: differentiable scatter
+            from .functional import SparseToDenseFunction
+            out = SparseToDenseFunction.apply(self.features, self.indices.contiguous(), self.batch_size, self.spatial_shape)
+        else:
+            out = _ops.sparse_to_dense(self.features, self.indices.contiguous(), self.batch_size, self.spatial_shape,
+                                       num_dev=self.num_active_dev)
         if not channels_first:
             return out.permute(0, 2, 3, 4, 1).contiguous()
         return out

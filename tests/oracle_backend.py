@@ -62,6 +62,23 @@ def voxelize(points, point_offsets, point_cloud_range, voxel_size, max_points, m
     return res
 
 
+def voxel_block_filter(vox, grid_size_xy, block_factor, block_size, height_threshold, height_high_threshold=3.0,
+                       sync=True):
+    voff = _np(vox["voxel_offsets"])
+    outs = {"voxels": [], "coordinates": [], "num_points_per_voxel": []}
+    ooff = [0]
+    for b in range(len(voff) - 1):
+        sl = slice(int(voff[b]), int(voff[b + 1]))
+        v, c, n = _np(vox["voxels"])[sl], _np(vox["coordinates"])[sl], _np(vox["num_points_per_voxel"])[sl]
+        keep = orc.block_filter(v, c[:, 1:], n, grid_size_xy, block_factor, block_size, height_threshold, height_high_threshold)
+        outs["voxels"].append(v[keep]); outs["coordinates"].append(c[keep]); outs["num_points_per_voxel"].append(n[keep])
+        ooff.append(ooff[-1] + int(keep.sum()))
+    res = {k: torch.from_numpy(np.concatenate(v)) for k, v in outs.items()}
+    res["voxel_offsets"] = torch.tensor(ooff, dtype=torch.int32)
+    res["voxel_num"] = ooff[-1]
+    return res
+
+
 def rulebook_subm(indices, batch_size, spatial_shape, ksize=3, dilation=1, want_pairs=False, n_dev=None):
     idx = _np(indices)
     _, pairs, num = orc.rulebook_subm(idx, batch_size, spatial_shape, ksize, dilation)
@@ -115,6 +132,13 @@ def pillar_scatter(features, coords, batch_size, ny, nx, channels_last=False):
     return torch.from_numpy(orc.pillar_scatter(_np(features.float()), _np(coords), batch_size, ny, nx)).to(features.dtype)
 
 
+def dense_to_sparse(dense, indices):
+    idx = indices.long()
+    if dense.dim() == 5:
+        return dense[idx[:, 0], :, idx[:, 1], idx[:, 2], idx[:, 3]].contiguous()
+    return dense[idx[:, 0], :, idx[:, 2], idx[:, 3]].contiguous()
+
+
 def rotate_iou(boxes, qboxes, criterion=-1):
     return torch.from_numpy(orc.rotate_iou(_np(boxes), _np(qboxes), criterion))
 
@@ -137,7 +161,7 @@ def nms_sorted(dets, counts, thresh, kind="rotate", semantics="numba", eps=1.0, 
 
 
 _NAMES = ["voxelize", "rulebook_subm", "rulebook_conv", "pack_weight", "indice_conv", "indice_conv_backward",
-          "sparse_to_dense", "pillar_scatter", "rotate_iou", "nms_sorted"]
+          "sparse_to_dense", "pillar_scatter", "rotate_iou", "nms_sorted", "voxel_block_filter", "dense_to_sparse"]
 
 
 @contextlib.contextmanager

@@ -177,3 +177,51 @@ def test_reference_pointpillars_over_our_stack(ref):
     np.testing.assert_allclose(o["scores"].numpy(), r["scores"].numpy(), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(o["box3d_lidar"].numpy(), r["box3d_lidar"].numpy(), rtol=1e-4, atol=1e-4)
     np.testing.assert_array_equal(o["label_preds"].numpy(), r["label_preds"].numpy())
+
+
+def test_reference_nuscenes_fhd_over_our_stack(ref):
+    """BASELINE config 5 (nuscenes/all.fhd): block-filtered voxels (max 1 point), SpMiddleFHD on a
+    1984x1984x40 grid, RPNV2 whose "upsample" is a stride-2 conv, 22 anchors per location."""
+    import oracle_backend
+    from google.protobuf import text_format
+    from second.protos import pipeline_pb2
+    from second_amd import synthetic as syn
+    from second_amd.models import SecondDetector, ALL_FHD_NUSC
+    train, _ = ref
+    cfg = pipeline_pb2.TrainEvalPipelineConfig()
+    text_format.Merge(open(os.path.join(REF, "second/configs/nuscenes/all.fhd.config")).read(), cfg)
+    model_cfg = cfg.model.second
+    torch.manual_seed(0)
+    with oracle_backend.installed():
+        net = train.build_network(model_cfg).eval()
+        g = torch.Generator().manual_seed(1)
+        for m in net.modules():
+            if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+                m.running_mean.copy_(torch.empty_like(m.running_mean).uniform_(-0.1, 0.1, generator=g))
+                m.running_var.copy_(torch.empty_like(m.running_var).uniform_(0.5, 1.5, generator=g))
+        vg = net.voxel_generator
+        assert vg.grid_size.tolist() == [1984, 1984, 40]
+        cloud = syn.syn_nusc_cloud(0, num_points=6000, point_cloud_range=(-49.6, -49.6, -5, 49.6, 49.6, 3))
+        vox = vg.generate(cloud, 90000)
+        det = SecondDetector(ALL_FHD_NUSC).eval()
+        ours_vox = det.voxel_generator.generate(cloud, 90000)
+        for k in ("voxels", "coordinates", "num_points_per_voxel"):
+            np.testing.assert_array_equal(ours_vox[k], vox[k])
+        assert 0 < vox["voxel_num"] < 6000          # the block filter removed something
+        fm = [1, 124, 124]
+        anchors = net.target_assigner.generate_anchors(fm)["anchors"].reshape(1, -1, 7)
+        example = {"voxels": vox["voxels"], "num_points": vox["num_points_per_voxel"],
+                   "coordinates": np.pad(vox["coordinates"], ((0, 0), (1, 0)), mode="constant", constant_values=0),
+                   "anchors": anchors}
+        ex = train.example_convert_to_torch(example, torch.float32, torch.device("cpu"))
+        with torch.no_grad():
+            ref_preds = net.network_forward(ex["voxels"], ex["num_points"], ex["coordinates"], 1)
+        missing = det.load_state_dict({k: v for k, v in net.state_dict().items() if k in det.state_dict()})
+        assert not missing.missing_keys
+        assert det.anchors.shape == (anchors.shape[1], 7) and det.feature_map_size == fm
+        np.testing.assert_allclose(det.anchors.numpy(), anchors[0], rtol=0, atol=1e-5)
+        with torch.no_grad():
+            feats = det.voxel_feature_extractor(ex["voxels"], ex["num_points"], ex["coordinates"])
+            ours_preds = det.network_forward(feats, ex["coordinates"], 1)
+        for k in ("box_preds", "cls_preds", "dir_cls_preds"):
+            np.testing.assert_allclose(ours_preds[k].numpy(), ref_preds[k].numpy(), rtol=1e-3, atol=1e-4)

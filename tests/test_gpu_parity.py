@@ -551,11 +551,11 @@ def test_conv2d_nhwc_mfma_vs_torch(ops, cin, cout, k, stride, pad, hw, dtype):
     np.testing.assert_allclose(nob.float().cpu().numpy(), ref2.cpu().numpy(), rtol=tol, atol=tol * ref2.abs().max().item())
 
 
-@pytest.mark.parametrize("cfg_name", ["car.fhd", "pp"])
+@pytest.mark.parametrize("cfg_name", ["car.fhd", "pp", "nusc.fhd"])
 def test_fused_predict_matches_torch_formulation(cfg_name):
     """select / decode / NMS / finalize kernels vs the torch restatement of voxelnet.py:377-645 (distinct scores)."""
-    from second_amd.models import SecondDetector, CAR_FHD, ALL_PP_LARGEA
-    cfg = CAR_FHD if cfg_name == "car.fhd" else ALL_PP_LARGEA
+    from second_amd.models import SecondDetector, CAR_FHD, ALL_PP_LARGEA, ALL_FHD_NUSC
+    cfg = {"car.fhd": CAR_FHD, "pp": ALL_PP_LARGEA, "nusc.fhd": ALL_FHD_NUSC}[cfg_name]
     det = SecondDetector(cfg).cuda().eval()
     a = det.rpn._num_anchor_per_loc
     _, h, w = det.feature_map_size
@@ -587,3 +587,79 @@ def test_fused_predict_matches_torch_formulation(cfg_name):
         np.testing.assert_allclose(o["scores"][m].cpu().numpy(), r["scores"][m].cpu().numpy(), rtol=1e-6, atol=1e-7)
         np.testing.assert_allclose(o["boxes"][m].cpu().numpy(), r["boxes"][m].cpu().numpy(), rtol=1e-5, atol=1e-5)
         assert torch.equal(o["labels"][m].long(), r["labels"][m].long())
+
+
+def test_nuscenes_fhd_detector_static_and_graph_match_eager(syn):
+    """BASELINE config 5 on the device path: block-filtered voxels -> SpMiddleFHD (1984x1984x40) -> RPN with a
+    stride-2 "upsample" conv -> 10-class axis-aligned NMS; eager == static-capacity == hipGraph replay."""
+    from second_amd.models import SecondDetector, ALL_FHD_NUSC
+    torch.manual_seed(0)
+    det = SecondDetector(ALL_FHD_NUSC).cuda().prepare_inference(torch.bfloat16)
+    assert type(det.rpn).__name__ == "RPNInference" and det.rpn.use_hip
+    clouds = [syn.syn_nusc_cloud(s, num_points=30000, point_cloud_range=(-49.6, -49.6, -5, 49.6, 49.6, 3)) for s in range(2)]
+    pts, offs = syn.batch_clouds(clouds)
+    pts, offs = dev(pts), dev(offs)
+    with torch.no_grad():
+        e = det.forward_points(pts, offs)
+        det.calibrate(pts, offs)
+        s = det.forward_points(pts, offs, static=True)
+        det.check_overflow()
+        replay, g = det.make_graphed(pts, offs)
+        replay()
+        torch.cuda.synchronize()
+    assert e["boxes"].shape[:2] == (2, 300)
+    for other in (s, g):
+        assert torch.equal(e["valid"], other["valid"])
+        m = e["valid"]
+        assert torch.equal(e["scores"][m], other["scores"][m])
+        assert torch.equal(e["boxes"][m], other["boxes"][m])
+        assert torch.equal(e["labels"][m], other["labels"][m])
+
+
+def test_sparse_sequential_training_step_vs_oracle(ops):
+    """Training path through the drop-in modules (train-mode BatchNorm1d, autograd through IndiceConvFunction,
+    rulebook reuse via indice_key): loss.backward() on the GPU vs the same modules over the CPU oracle."""
+    import copy
+    import spconv
+    import oracle_backend
+    torch.manual_seed(0)
+    rng = np.random.RandomState(0)
+    shape = [9, 24, 20]
+    n = 700
+    flat = rng.choice(2 * shape[0] * shape[1] * shape[2], n, replace=False)
+    b, r = np.divmod(flat, shape[0] * shape[1] * shape[2])
+    z, r = np.divmod(r, shape[1] * shape[2])
+    y, x = np.divmod(r, shape[2])
+    idx = np.stack([b, z, y, x], 1).astype(np.int32)
+    idx = idx[np.argsort(b, kind="stable")]
+    feats = rng.randn(n, 16).astype(np.float32)
+
+    def bn(c):
+        return torch.nn.BatchNorm1d(c, eps=1e-3, momentum=0.01)
+    net = spconv.SparseSequential(
+        spconv.SubMConv3d(16, 32, 3, bias=False, indice_key="subm0"), bn(32), torch.nn.ReLU(),
+        spconv.SubMConv3d(32, 32, 3, bias=False, indice_key="subm0"), bn(32), torch.nn.ReLU(),
+        spconv.SparseConv3d(32, 64, 3, 2, padding=1, bias=False), bn(64), torch.nn.ReLU(),
+        spconv.SparseConv3d(64, 64, (3, 1, 1), (2, 1, 1), bias=True), torch.nn.ReLU())
+    net_cpu = copy.deepcopy(net)
+
+    def step(model, device):
+        model.train()
+        f = torch.from_numpy(feats).to(device).requires_grad_(True)
+        t = spconv.SparseConvTensor(f, torch.from_numpy(idx).to(device), shape, 2)
+        out = model(t).dense()
+        w = torch.linspace(-1, 1, out.numel(), device=device).view_as(out)
+        loss = (out * w).sum() + (out ** 2).mean()
+        loss.backward()
+        grads = {k: p.grad.detach().cpu().numpy() for k, p in model.named_parameters()}
+        return loss.item(), f.grad.cpu().numpy(), grads, {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}
+
+    loss_g, df_g, grads_g, state_g = step(net.cuda(), "cuda")
+    with oracle_backend.installed():
+        loss_c, df_c, grads_c, state_c = step(net_cpu, "cpu")
+    assert abs(loss_g - loss_c) <= 1e-4 * max(1.0, abs(loss_c))
+    np.testing.assert_allclose(df_g, df_c, rtol=1e-3, atol=1e-4 * np.abs(df_c).max())
+    for k in grads_c:
+        np.testing.assert_allclose(grads_g[k], grads_c[k], rtol=1e-3, atol=2e-4 * np.abs(grads_c[k]).max(), err_msg=k)
+    for k in state_c:   # BatchNorm running statistics updated identically
+        np.testing.assert_allclose(state_g[k], state_c[k], rtol=1e-4, atol=1e-5, err_msg=k)
