@@ -73,8 +73,9 @@ int sec_voxelize_f32(const float *points, const int *point_offsets, int num_poin
  * which is what sec_indice_conv_fwd consumes, and the INPUT-MAJOR table `nbr_in` [n_in, K]
  * (nbr_in[j][k] = output row or -1) which the backward pass consumes.
  * --------------------------------------------------------------------------------------------- */
-/* max_out_per_in sizes the output hash table (2 * n_in * max_out_per_in slots).  The exact bound is
- * prod(ceil(k/s)) (8 for k3 s2); the same value must be passed as `out_per_in_hint` (0 = exact bound) to
+/* max_out_per_in sizes the output hash table (2 * n_in * max_out_per_in slots).  The exact bound is the number
+ * of kernel offsets that can reach an output from one input: prod over dims of the largest residue class of
+ * {k*dil mod stride} (= prod(ceil(k/s)) for dil 1; 8 for k3 s2); the same value must be passed as `out_per_in_hint` (0 = exact bound) to
  * both conv3d calls.  A smaller hint saves memset traffic; if the data then needs more slots the build
  * reports num_out[1] = INT_MAX (overflow) instead of hanging. */
 size_t sec_rulebook_workspace_bytes(int n_in, int kvol, int max_out_per_in);
@@ -91,6 +92,7 @@ int sec_rulebook_subm3d(const int *indices, int n_in, const int *n_in_dev, int b
                         void *stream);
 
 /* SparseConv3d, step 1: discover the active outputs in first-touch order (oracle numbering).
+ *   A dim with both stride > 1 and dilation > 1 returns SEC_E_UNSUPPORTED (no SECOND config has one).
  *   out_indices [out_cap,4]; num_out = device int[2]: [0] live outputs clamped to out_cap (feed it to the
  *   next layer as n_in_dev / num_out_dev), [1] the raw count (raw > out_cap == capacity overflow, to be
  *   checked by the caller whenever it next synchronises). State is kept in `workspace`. */
@@ -100,11 +102,12 @@ int sec_rulebook_conv3d_build(const int *indices, int n_in, const int *n_in_dev,
                               const int *h_padding3, const int *h_dilation3, int *out_indices,
                               int out_cap, int *num_out, int out_per_in_hint, void *workspace,
                               size_t workspace_bytes, void *stream);
-/* step 2: fill the tables. nbr_out has `nbr_out_rows` rows (>= number of outputs; rows are -1 filled). */
+/* step 2: fill the tables. nbr_out has `nbr_out_rows` rows (>= number of outputs; rows are -1 filled).
+ * nbr_in may be NULL when neither the backward pass nor the pair lists are wanted (inference). */
 int sec_rulebook_conv3d_tables(int n_in, const int *h_ksize3, const int *h_stride3,
-                               int out_per_in_hint, int *nbr_out, int nbr_out_rows, int *nbr_in,
-                               int *pairs, int *pair_num, void *workspace, size_t workspace_bytes,
-                               void *stream);
+                               const int *h_dilation3, int out_per_in_hint, int *nbr_out,
+                               int nbr_out_rows, int *nbr_in, int *pairs, int *pair_num,
+                               void *workspace, size_t workspace_bytes, void *stream);
 void sec_conv_output_shape(const int *h_in_shape3, const int *h_ksize3, const int *h_stride3,
                            const int *h_padding3, const int *h_dilation3, int *h_out_shape3);
 
@@ -187,6 +190,15 @@ int sec_conv2d_pack_weight(const void *weight, int cout, int cin, int ksize, int
 int sec_conv2d_nhwc(const void *x, int batch, int h, int w, int cin, const void *packed_weight,
                     const float *bias, int cout, int ksize, int stride, int pad, int relu, void *y,
                     int dtype, void *stream);
+
+/* Fused tail of the RPN at inference: y = W2 * act(W1 * x + bias1) + bias2 over `pixels` channels-last pixels with
+ * 128 input and 128 intermediate channels -- the 1x1/stride-1 ConvTranspose2d deblock with folded BatchNorm + ReLU
+ * (second/pytorch/models/rpn.py:275-285) followed by the merged conv_box / conv_cls / conv_dir_cls 1x1 heads
+ * (rpn.py:386-391, 412-420).  cout2 in {64, 128}; weights from sec_conv2d_pack_weight (ksize 1); bias2 may be NULL.
+ * The intermediate never reaches HBM. */
+int sec_conv1x1_chain_nhwc(const void *x, long long pixels, const void *packed_w1, const float *bias1,
+                           int relu1, const void *packed_w2, const float *bias2, int cout2, void *y,
+                           int dtype, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Rotated IoU / NMS -- replace the numba.cuda kernels of second/core/non_max_suppression/nms_gpu.py

@@ -2,6 +2,8 @@
 // through MIOpen in phase 1; the per-channel bias (folded BatchNorm2d) + ReLU that follows every conv is ONE
 // in-place pass here instead of MIOpen's separate bias tensor-op plus a ReLU kernel (3 passes -> 1).
 #include "common.hpp"
+#include <stdio.h>
+#include <stdlib.h>
 #include <stdlib.h>
 
 namespace sec {
@@ -65,6 +67,49 @@ template <> struct MfmaD<__half> {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8d, a), __builtin_bit_cast(f16x8d, b), c, 0, 0, 0);
     }
 };
+
+
+// Transposed-accumulator epilogue.  With the MFMA operands swapped (weights as the first operand) the 32x32 result
+// tile is D^T: a lane owns ONE pixel (lane & 31) and, per group g = i >> 2, four CONSECUTIVE output channels
+// 8g + 4*(lane >> 5) + (i & 3).  The two half-waves exchange one group each so that every lane ends up with eight
+// consecutive channels of its pixel: two 16-byte stores per tile instead of sixteen 2-byte scatters.
+template <typename T> __device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
+    T t[4] = {from_f<T>(a), from_f<T>(b), from_f<T>(c), from_f<T>(d)};
+    uint2 u;
+    __builtin_memcpy(&u, t, 8);
+    return u;
+}
+template <typename T, bool HAS_BIAS>
+__device__ __forceinline__ void store_tile_tb(const f32x16d &acc, const float *__restrict__ bias, int c0, int relu,
+                                              T *__restrict__ ypix, bool ok, int hh) {
+    uint2 pk[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int c = c0 + 8 * g + 4 * hh;
+        float4 bv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (HAS_BIAS) bv = *reinterpret_cast<const float4 *>(bias + c);
+        float v[4] = {acc[4 * g] + bv.x, acc[4 * g + 1] + bv.y, acc[4 * g + 2] + bv.z, acc[4 * g + 3] + bv.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = relu ? (v[j] > 0.0f ? v[j] : 0.0f) : v[j];
+        pk[g] = pack4<T>(v[0], v[1], v[2], v[3]);
+    }
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+        const uint2 keep = hh ? pk[2 * pr + 1] : pk[2 * pr];
+        const uint2 send = hh ? pk[2 * pr] : pk[2 * pr + 1];
+        uint2 recv;
+        recv.x = (unsigned)__shfl_xor((int)send.x, 32, 64);
+        recv.y = (unsigned)__shfl_xor((int)send.y, 32, 64);
+        const uint4 out = hh ? make_uint4(recv.x, recv.y, keep.x, keep.y) : make_uint4(keep.x, keep.y, recv.x, recv.y);
+        if (ok) *reinterpret_cast<uint4 *>(ypix + c0 + 8 * (2 * pr + hh)) = out;
+    }
+}
+template <typename T>
+__device__ __forceinline__ void store_tile_t(const f32x16d &acc, const float *__restrict__ bias, int c0, int relu,
+                                             T *__restrict__ ypix, bool ok, int hh) {
+    if (bias) store_tile_tb<T, true>(acc, bias, c0, relu, ypix, ok, hh);
+    else store_tile_tb<T, false>(acc, bias, c0, relu, ypix, ok, hh);
+}
 
 struct Conv2dParams {
     int batch, h, w, cin, cout, ho, wo, ksize, stride, pad, relu;
@@ -398,26 +443,19 @@ __global__ __launch_bounds__(TH * 16 * NQ) void k_conv2d_halo(const T *__restric
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = MfmaD<T>::run(af[mt], bf[nt], acc[mt][nt]);
+                for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = MfmaD<T>::run(bf[nt], af[mt], acc[mt][nt]);   // D^T: see store_tile_t
         }
         __syncthreads();
     }
 #pragma unroll
-    for (int nt = 0; nt < NTW; ++nt) {
-        const int co = n0 + wn * (BN / NQ) + nt * 32 + r;
-        const float bv = bias ? bias[co] : 0.0f;
+    for (int mt = 0; mt < 2; ++mt) {
+        const int q = mt * 32 + r;                                         // this lane's pixel inside the wave's 64
+        const int oy = y0 + wm * 4 + (q >> 4), ox = x0 + (q & 15);
+        const bool ok = oy < p.h && ox < p.w;
+        T *ypix = y + (((size_t)b * p.h + oy) * p.w + ox) * p.cout;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int q = mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;       // pixel inside the wave's 64
-                const int oy = y0 + wm * 4 + (q >> 4), ox = x0 + (q & 15);
-                if (oy < p.h && ox < p.w) {
-                    float v = acc[mt][nt][i] + bv;
-                    if (p.relu) v = v > 0.0f ? v : 0.0f;
-                    y[(((size_t)b * p.h + oy) * p.w + ox) * p.cout + co] = from_f<T>(v);
-                }
-            }
+        for (int nt = 0; nt < NTW; ++nt)
+            store_tile_t<T>(acc[mt][nt], bias, n0 + wn * (BN / NQ) + nt * 32, p.relu, ypix, ok, hh);
     }
 }
 
@@ -433,6 +471,329 @@ static int launch_conv2d_halo(const void *x, const void *wpk, const float *bias,
     const int ty = div_up(p.h, TH), tx = div_up(p.w, 16);
     const int gx = (p.batch * ty * tx + 7) / 8 * 8;
     hipLaunchKernelGGL(fn, dim3(gx, p.cout / 128), dim3(TH * 16 * NQ), lds, st, (const T *)x, (const T *)wpk, bias, (T *)y, p, ty, tx);
+    return check_launch();
+}
+
+
+// ---- software-pipelined halo kernel -------------------------------------------------------------------------
+// k_conv2d_halo above double-buffers the weight slabs, but the compiler cannot tell the LDS-DMA destination from
+// the slab being read (one dynamic LDS array) and puts s_waitcnt vmcnt(0) in front of the first ds_read of every
+// iteration: the "prefetch" is waited for before the MFMAs it was meant to hide behind.  Here the iteration body is
+// a function whose LDS pointers are __restrict__ (inlining turns that into alias scopes, which the waitcnt pass
+// honours), the slabs form an NB-deep ring filled DIST = NB-1 iterations ahead, and the only waits are the counted
+// s_waitcnt vmcnt(n) + LDS-only barrier written out below.  KS = input channels per slab (64: 16 KB, 32: 8 KB).
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// XOR key of a halo pixel's 16-byte chunks.  ds_read_b128 is served in groups of 16 lanes that must hit 16 distinct
+// 16-B slots of the 256-B bank row; a group's lanes are 8 + 8 pixels of two ADJACENT tile rows at complementary
+// columns ({0-3,12-15} and {4-11}), so keying on the halo COLUMN makes them distinct (keying on the linear halo index,
+// as k_conv2d_halo does, shifts the second row by HW_ - 16 = 2 and collides two slots).  Cin = 64 keeps the old key.
+template <int CH, int HW_, bool COLKEY> __device__ __forceinline__ int halo_key(int hp) {
+    return (COLKEY && CH == 16) ? ((hp % HW_) & 15) : (hp & (CH - 1));
+}
+
+template <typename T, int CH, int HW_, int BN, int NTW, int NQ, int NWV, int KS, bool COLKEY, bool FPIPE>
+__device__ __forceinline__ void halo_step(const uint4 *__restrict__ hal, const uint4 *__restrict__ bb,
+                                          uint4 *__restrict__ bnext, const uint4 *__restrict__ wnext, int cout,
+                                          const int (&hp0)[2], int dy, int dx, int kc, int wn, int wv, int lane,
+                                          f32x16d (&acc)[2][NTW]) {
+    constexpr int SLAB = (KS / 8) * BN;            // uint4 entries per slab
+    const int r = lane & 31, hh = lane >> 5;
+    if (wnext) {
+#pragma unroll
+        for (int j = 0; j < SLAB / 64 / NWV; ++j) {
+            const int e = (j * NWV + wv) * 64 + lane, ch = e / BN, n = e - ch * BN;
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(wnext + (size_t)ch * cout + n), (lds_ptr_t)&bnext[(j * NWV + wv) * 64], 16, 0, 0);
+        }
+    }
+    // fragment loads run one k-step ahead of the MFMAs that consume them (register double buffer)
+    int hoff[2], key[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int hp = hp0[mt] + dy * HW_ + dx;
+        hoff[mt] = hp * CH;
+        key[mt] = halo_key<CH, HW_, COLKEY>(hp);
+    }
+    if (!FPIPE) {
+#pragma unroll
+        for (int s = 0; s < KS / 16; ++s) {
+            uint4 a1[2], b1[NTW];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) a1[mt] = hal[hoff[mt] + ((kc * (KS / 8) + s * 2 + hh) ^ key[mt])];
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) b1[nt] = bb[(s * 2 + hh) * BN + wn * (BN / NQ) + nt * 32 + r];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = MfmaD<T>::run(b1[nt], a1[mt], acc[mt][nt]);
+        }
+        return;
+    }
+    uint4 af[2][2], bf[2][NTW];
+    auto load_frag = [&](int s, int w) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) af[w][mt] = hal[hoff[mt] + ((kc * (KS / 8) + s * 2 + hh) ^ key[mt])];
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) bf[w][nt] = bb[(s * 2 + hh) * BN + wn * (BN / NQ) + nt * 32 + r];
+    };
+    load_frag(0, 0);
+#pragma unroll
+    for (int s = 0; s < KS / 16; ++s) {
+        if (s + 1 < KS / 16) load_frag(s + 1, (s + 1) & 1);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt)
+                acc[mt][nt] = MfmaD<T>::run(bf[s & 1][nt], af[s & 1][mt], acc[mt][nt]);   // D^T: see store_tile_t
+    }
+}
+
+template <typename T, int CIN, int TH, int NQ, int KS, int NB, bool COLKEY, bool FPIPE>
+__global__ __launch_bounds__(TH * 16 * NQ) void k_conv2d_halo_pipe(const T *__restrict__ x, const T *__restrict__ wpk,
+                                                                   const float *__restrict__ bias, T *__restrict__ y,
+                                                                   Conv2dParams p, int tiles_y, int tiles_x) {
+    constexpr int TW = 16, HW_ = TW + 2, HPIX = (TH + 2) * (TW + 2);
+    constexpr int PQ = TH / 4, NWV = PQ * NQ;
+    constexpr int NTW = 128 / (NQ * 32);
+    constexpr int CH = CIN / 8, HENT = HPIX * CH;
+    constexpr int BN = 128, KC = CIN / KS, NIT = 9 * KC, SLAB = (KS / 8) * BN, DIST = NB - 1;
+    constexpr int L = SLAB / 64 / NWV;             // DMA instructions per wave per slab
+    static_assert(SLAB % (64 * NWV) == 0 && NIT > DIST, "slab must split evenly over the waves");
+    extern __shared__ __attribute__((aligned(16))) uint4 halo_smem[];
+    uint4 *hal = halo_smem;
+    uint4 *ring = halo_smem + HENT;                // [NB][SLAB]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int wm = wv % PQ, wn = wv / PQ;
+    const int per = gridDim.x / 8;
+    const int tile = (blockIdx.x % 8) * per + blockIdx.x / 8;    // XCD-aware tile order
+    const int ntile = p.batch * tiles_y * tiles_x;
+    if (tile >= ntile) return;
+    const int b = tile / (tiles_y * tiles_x);
+    const int trem = tile - b * tiles_y * tiles_x;
+    const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
+    const int n0 = blockIdx.y * BN;
+    constexpr int cin8 = CIN / 8;
+    const uint4 *x4 = reinterpret_cast<const uint4 *>(x);
+    const uint4 *w4 = reinterpret_cast<const uint4 *>(wpk);
+    const uint4 *zero16 = w4 + (size_t)9 * cin8 * p.cout;
+    auto slab_src = [&](int it) {                  // first entry of slab `it` = (tap, kc): [tap][cin8][cout] uint4
+        const int tap = it / KC, kc = it - tap * KC;
+        return w4 + ((size_t)tap * cin8 + kc * (KS / 8)) * p.cout + n0;
+    };
+    for (int i = wv; i < (HENT + 63) / 64; i += NWV) {
+        const int e = i * 64 + lane;
+        if (e >= HENT) break;
+        const int hp = e / CH, slot = e - hp * CH;
+        const int hy = hp / HW_, hx = hp - hy * HW_;
+        const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+        const bool ok = iy >= 0 && iy < p.h && ix >= 0 && ix < p.w;
+        const uint4 *src = ok ? x4 + (((long long)b * p.h + iy) * p.w + ix) * cin8 + (slot ^ halo_key<CH, HW_, COLKEY>(hp)) : zero16;
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)&hal[i * 64], 16, 0, 0);
+    }
+#pragma unroll
+    for (int d = 0; d < DIST; ++d) {
+        const uint4 *src = slab_src(d);
+#pragma unroll
+        for (int j = 0; j < L; ++j) {
+            const int e = (j * NWV + wv) * 64 + lane, ch = e / BN, n = e - ch * BN;
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + (size_t)ch * p.cout + n), (lds_ptr_t)&ring[d * SLAB + (j * NWV + wv) * 64], 16, 0, 0);
+        }
+    }
+    f32x16d acc[2][NTW];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < NTW; ++c)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][c][i] = 0.0f;
+    int hp0[2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int q = mt * 32 + r;
+        hp0[mt] = (wm * 4 + (q >> 4)) * HW_ + (q & 15);
+    }
+    // halo + slab 0 must have landed; slabs 1 .. DIST-1 (the youngest (DIST-1)*L DMAs of this wave) may still fly
+    wait_vmcnt<(DIST - 1) * L>();
+    lds_barrier();
+    int slot = 0, tap = 0, kc = 0;
+    for (int it = 0; it < NIT; ++it) {
+        const int dy = tap / 3, dx = tap - dy * 3;
+        int nslot = slot + DIST;
+        if (nslot >= NB) nslot -= NB;
+        const bool more = it + DIST < NIT;
+        halo_step<T, CH, HW_, BN, NTW, NQ, NWV, KS, COLKEY, FPIPE>(hal, ring + slot * SLAB, ring + nslot * SLAB,
+                                                     more ? slab_src(it + DIST) : nullptr, p.cout, hp0, dy, dx, kc, wn, wv,
+                                                     lane, acc);
+        // slab it+1 must be complete in every wave before anyone reads it; younger slabs stay in flight
+        if (more) wait_vmcnt<(DIST - 1) * L>();
+        else wait_vmcnt<0>();
+        lds_barrier();
+        if (++slot == NB) slot = 0;
+        if (++kc == KC) { kc = 0; ++tap; }
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int q = mt * 32 + r;
+        const int oy = y0 + wm * 4 + (q >> 4), ox = x0 + (q & 15);
+        const bool ok = oy < p.h && ox < p.w;
+        T *ypix = y + (((size_t)b * p.h + oy) * p.w + ox) * p.cout;
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+            store_tile_t<T>(acc[mt][nt], bias, n0 + wn * (BN / NQ) + nt * 32, p.relu, ypix, ok, hh);
+    }
+}
+
+template <typename T, int CIN, int TH, int NQ, int KS, int NB, bool COLKEY, bool FPIPE>
+static int launch_conv2d_halo_pipe(const void *x, const void *wpk, const float *bias, void *y, const Conv2dParams &p, hipStream_t st) {
+    constexpr size_t lds = ((size_t)(TH + 2) * 18 * (CIN / 8) + (size_t)NB * (KS / 8) * 128) * 16;
+    static bool configured = false;
+    auto fn = k_conv2d_halo_pipe<T, CIN, TH, NQ, KS, NB, COLKEY, FPIPE>;
+    if (!configured) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        configured = true;
+    }
+    const int ty = div_up(p.h, TH), tx = div_up(p.w, 16);
+    const int gx = (p.batch * ty * tx + 7) / 8 * 8;
+    hipLaunchKernelGGL(fn, dim3(gx, p.cout / 128), dim3(TH * 16 * NQ), lds, st, (const T *)x, (const T *)wpk, bias, (T *)y, p, ty, tx);
+    return check_launch();
+}
+
+
+// ---- halo kernel with register-resident weights ----------------------------------------------------------------
+// PMC on the LDS-slab kernels (profiles/r01_g_pmc_conv2d.txt): MFMA pipe 38 % busy, waves parked 48 % of their
+// cycles (one s_barrier per 16 KB weight slab keeps all eight waves in lock-step) and only 12 of 16 wave slots
+// filled on average (2200 tiles over 512 workgroup slots = 4.3 rounds).  Here the weights never touch LDS: a
+// wave owns ALL 128 pixels of the 8 x 16 tile for 32 output channels, so no two waves of a workgroup need the same
+// B fragment and each streams its own from L2 (1 KB coalesced per k-step, prefetched one iteration ahead in VGPRs).
+// LDS holds only the halo (46 KB -> 3 workgroups per CU, 2200 / 768 = 2.9 rounds), the main loop has no barrier,
+// and LDS traffic drops to one conflict-free ds_read_b128 per MFMA.
+template <typename T, int CIN, int TH>
+__global__ __launch_bounds__(256, 3) void k_conv2d_halo_reg(const T *__restrict__ x, const T *__restrict__ wpk,
+                                                            const float *__restrict__ bias, T *__restrict__ y,
+                                                            Conv2dParams p, int tiles_y, int tiles_x, int per_xcd) {
+    constexpr int TW = 16, HW_ = TW + 2, HPIX = (TH + 2) * (TW + 2);
+    constexpr int MT = TH * TW / 32;               // 32-pixel m-tiles per wave (4 for an 8 x 16 tile)
+    constexpr int CH = CIN / 8, HENT = HPIX * CH;
+    constexpr int KC = CIN / 64, NIT = 9 * KC;
+    extern __shared__ __attribute__((aligned(16))) uint4 halo_smem[];
+    uint4 *hal = halo_smem;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int ntile = p.batch * tiles_y * tiles_x;
+    // XCD-aware tile order: workgroup b runs on XCD b % 8 and takes tile b / 8 of that XCD's contiguous range.
+    // (A persistent form -- 3 resident workgroups per CU striding through the range, next halo DMA overlapped with
+    // the epilogue -- was measured 5 % SLOWER: its extra live state spills at the 168-VGPR budget.)
+    const int xcd = blockIdx.x % 8, local = blockIdx.x / 8;
+    const int n0 = blockIdx.y * 128 + wv * 32;     // this wave's 32 output channels
+    constexpr int cin8 = CIN / 8;
+    const uint4 *x4 = reinterpret_cast<const uint4 *>(x);
+    const uint4 *w4 = reinterpret_cast<const uint4 *>(wpk);
+    const uint4 *zero16 = w4 + (size_t)9 * cin8 * p.cout;
+    auto issue_halo = [&](int tile) {
+        const int b = tile / (tiles_y * tiles_x);
+        const int trem = tile - b * tiles_y * tiles_x;
+        const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
+        for (int i = wv; i < (HENT + 63) / 64; i += 4) {
+            const int e = i * 64 + lane;
+            if (e >= HENT) break;
+            const int hp = e / CH, slot = e - hp * CH;
+            const int hy = hp / HW_, hx = hp - hy * HW_;
+            const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+            const bool ok = iy >= 0 && iy < p.h && ix >= 0 && ix < p.w;
+            const uint4 *src = ok ? x4 + (((long long)b * p.h + iy) * p.w + ix) * cin8 + (slot ^ halo_key<CH, HW_, true>(hp)) : zero16;
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)&hal[i * 64], 16, 0, 0);
+        }
+    };
+    // B fragment of k-step s of slab `it` = (tap, kc): packed weights are [tap][cin8][cout] uint4
+    const uint4 *wlane = w4 + (size_t)hh * p.cout + n0 + r;
+    auto load_b = [&](int it, uint4 (&dst)[4]) {
+        const uint4 *src = wlane + (size_t)it * 8 * p.cout;     // it * 8 chunks == (tap * cin8 + kc * 8) because KC * 8 == cin8
+#pragma unroll
+        for (int s = 0; s < 4; ++s) dst[s] = src[(size_t)s * 2 * p.cout];
+    };
+    int hp0[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int q = mt * 32 + r;
+        hp0[mt] = (q >> 4) * HW_ + (q & 15);
+    }
+    auto load_a = [&](int tap_, int kc_, int s, uint4 (&dst)[MT]) {
+        const int dy = tap_ / 3, dx = tap_ - dy * 3;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int hp = hp0[mt] + dy * HW_ + dx;
+            dst[mt] = hal[hp * CH + ((kc_ * 8 + s * 2 + hh) ^ halo_key<CH, HW_, true>(hp))];
+        }
+    };
+    const int tile = xcd * per_xcd + local;
+    if (local >= per_xcd || tile >= ntile) return;
+    issue_halo(tile);
+    {
+        const int b = tile / (tiles_y * tiles_x);
+        const int trem = tile - b * tiles_y * tiles_x;
+        const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
+        uint4 bq[2][4];
+        load_b(0, bq[0]);
+        f32x16d acc[MT];
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][i] = 0.0f;
+        __syncthreads();                            // halo landed
+        // A fragments run one whole k-step (MT MFMAs = 128 cycles of matrix pipe) ahead of their use, across iterations
+        uint4 af[2][MT];
+        int tap = 0, kc = 0;
+        load_a(0, 0, 0, af[0]);
+#pragma unroll 2
+        for (int it = 0; it < NIT; ++it) {
+            const int cur = it & 1;
+            if (it + 1 < NIT) load_b(it + 1, bq[cur ^ 1]);
+            int ntap = tap, nkc = kc + 1;
+            if (nkc == KC) { nkc = 0; ++ntap; }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                if (s < 3) load_a(tap, kc, s + 1, af[(s + 1) & 1]);
+                else if (it + 1 < NIT) load_a(ntap, nkc, 0, af[0]);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt] = MfmaD<T>::run(bq[cur][s], af[s & 1][mt], acc[mt]);   // D^T: see store_tile_t
+            }
+            tap = ntap;
+            kc = nkc;
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int q = mt * 32 + r;
+            const int oy = y0 + (q >> 4), ox = x0 + (q & 15);
+            const bool ok = oy < p.h && ox < p.w;
+            T *ypix = y + (((size_t)b * p.h + oy) * p.w + ox) * p.cout;
+            store_tile_t<T>(acc[mt], bias, n0, p.relu, ypix, ok, hh);
+        }
+    }
+}
+
+template <typename T, int CIN, int TH>
+static int launch_conv2d_halo_reg(const void *x, const void *wpk, const float *bias, void *y, const Conv2dParams &p, hipStream_t st) {
+    constexpr size_t lds = (size_t)(TH + 2) * 18 * (CIN / 8) * 16;
+    static bool configured = false;
+    auto fn = k_conv2d_halo_reg<T, CIN, TH>;
+    if (!configured) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        configured = true;
+        if (getenv("SEC_DEBUG_OCCUPANCY")) {
+            int nb = -1;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(fn), 256, lds);
+            hipFuncAttributes fa;
+            (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(fn));
+            fprintf(stderr, "[sec] k_conv2d_halo_reg: occupancy API %d blocks/CU, lds %zu, regs %d, static lds %zu, scratch %zu\n", nb, lds,
+                    fa.numRegs, fa.sharedSizeBytes, fa.localSizeBytes);
+        }
+    }
+    const int ty = div_up(p.h, TH), tx = div_up(p.w, 16);
+    const int per_xcd = div_up(p.batch * ty * tx, 8);
+    const int gx = per_xcd * 8;
+    hipLaunchKernelGGL(fn, dim3(gx, p.cout / 128), dim3(256), lds, st, (const T *)x, (const T *)wpk, bias, (T *)y, p, ty, tx, per_xcd);
     return check_launch();
 }
 
@@ -504,40 +865,165 @@ __global__ __launch_bounds__(kBlock) void k_conv1x1_nhwc(const T *__restrict__ x
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = MfmaD<T>::run(af[mt], bf[nt], acc[mt][nt]);
+                for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = MfmaD<T>::run(bf[nt], af[mt], acc[mt][nt]);   // D^T: see store_tile_t
         }
         if (cc == CC - 1) {
             const long long m0 = (tile0 + it / CC) * BM;
 #pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) {
-                const int co = n0 + wn * (BN / 2) + nt * 32 + r;
-                const float bv = bias ? bias[co] : 0.0f;
+            for (int mt = 0; mt < 2; ++mt) {
+                const long long pix = m0 + wm * 64 + mt * 32 + r;
+                T *ypix = y + (size_t)pix * p.cout;
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const long long pix = m0 + wm * 64 + mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-                        if (pix < p.m) {
-                            float v = acc[mt][nt][i] + bv;
-                            if (p.relu) v = v > 0.0f ? v : 0.0f;
-                            y[(size_t)pix * p.cout + co] = from_f<T>(v);
-                        }
-                    }
+                for (int nt = 0; nt < NTW; ++nt)
+                    store_tile_t<T>(acc[mt][nt], bias, n0 + wn * (BN / 2) + nt * 32, p.relu, ypix, pix < p.m, hh);
             }
         }
         __syncthreads();
     }
 }
 
+
+// ---- fused 1x1 chain: y = W2 * relu(W1 * x + b1) + b2 ------------------------------------------------------------
+// The RPN tail is two back-to-back 1x1 convolutions -- the ConvTranspose2d(k=1,s=1) "deblock" (128 -> 128, BN, ReLU;
+// rpn.py:275-285) and the merged box/cls/dir heads (128 -> 64 padded; rpn.py:386-391) -- and nothing else reads the
+// deblock output at inference.  Run separately they move 72 MB in + 72 MB out + 72 MB in + 36 MB out; fused, the
+// 128-channel intermediate lives only in LDS: 72 MB in, 36 MB out.  One workgroup = one 128-pixel tile; weights are
+// never staged (each wave streams its own B fragments from L2, as in k_conv2d_halo_reg); the x tile and then the
+// intermediate share one 32 KB LDS buffer, so five workgroups fit a CU's LDS and three its registers.
+template <typename T, int NT2>    // NT2 = 32-wide cout tiles per wave in the second GEMM: cout2 = 64 * NT2
+__global__ __launch_bounds__(256, 3) void k_conv1x1_chain(const T *__restrict__ x, const T *__restrict__ w1pk,
+                                                          const float *__restrict__ b1, const T *__restrict__ w2pk,
+                                                          const float *__restrict__ b2, T *__restrict__ y, long long m,
+                                                          int relu1) {
+    constexpr int BM = 128, C = 128, CH = C / 8, N2 = 64 * NT2;
+    __shared__ uint4 tile[BM * CH];                 // [pixel][16-byte chunk ^ (pixel & 15)]: x, then relu(W1 x + b1)
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const long long m0 = (long long)blockIdx.x * BM;
+    const uint4 *x4 = reinterpret_cast<const uint4 *>(x);
+    const uint4 *w1 = reinterpret_cast<const uint4 *>(w1pk);
+    const uint4 *w2 = reinterpret_cast<const uint4 *>(w2pk);
+    const uint4 *zero16 = w1 + (size_t)CH * C;
+#pragma unroll
+    for (int j = 0; j < BM * CH / 64 / 4; ++j) {
+        const int e = (j * 4 + wv) * 64 + lane, px = e / CH, slot = e - px * CH;
+        const uint4 *src = m0 + px < m ? x4 + (m0 + px) * CH + (slot ^ (px & 15)) : zero16;
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)&tile[(j * 4 + wv) * 64], 16, 0, 0);
+    }
+    // GEMM 1: this wave = all 128 pixels x mid channels [32 wv, 32 wv + 32)
+    uint4 bq[8];
+    {
+        const uint4 *wl = w1 + (size_t)hh * C + wv * 32 + r;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) bq[s] = wl[(size_t)s * 2 * C];
+    }
+    f32x16d acc[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[a][i] = 0.0f;
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int px = mt * 32 + r;
+            acc[mt] = MfmaD<T>::run(bq[s], tile[px * CH + ((s * 2 + hh) ^ (px & 15))], acc[mt]);   // D^T: see store_tile_t
+        }
+    // second-GEMM weights: wave = 64 pixels (wm) x N2 / 2 couts (wn); issued now, needed after the two barriers
+    const int wm = wv & 1, wn = wv >> 1;
+    uint4 cq[8][NT2];
+    {
+        const uint4 *wl = w2 + (size_t)hh * N2 + wn * (N2 / 2) + r;
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int nt = 0; nt < NT2; ++nt) cq[s][nt] = wl[(size_t)s * 2 * N2 + nt * 32];
+    }
+    lds_barrier();                                  // every wave has read all of x
+    {   // intermediate -> LDS (bias, ReLU, 16-bit): lane owns pixel mt*32 + r, channels 32 wv + 8 g + 4 hh + (0..3)
+        unsigned char *tb = reinterpret_cast<unsigned char *>(tile);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int px = mt * 32 + r;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = wv * 32 + 8 * g + 4 * hh;
+                const float4 bv = *reinterpret_cast<const float4 *>(b1 + c);
+                float v[4] = {acc[mt][4 * g] + bv.x, acc[mt][4 * g + 1] + bv.y, acc[mt][4 * g + 2] + bv.z, acc[mt][4 * g + 3] + bv.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = relu1 ? (v[j] > 0.0f ? v[j] : 0.0f) : v[j];
+                *reinterpret_cast<uint2 *>(tb + ((size_t)px * CH + ((wv * 4 + g) ^ (px & 15))) * 16 + hh * 8) = pack4<T>(v[0], v[1], v[2], v[3]);
+            }
+        }
+    }
+    lds_barrier();
+    f32x16d acc2[2][NT2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < NT2; ++c)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc2[a][c][i] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int px = wm * 64 + mt * 32 + r;
+            const uint4 af = tile[px * CH + ((s * 2 + hh) ^ (px & 15))];
+#pragma unroll
+            for (int nt = 0; nt < NT2; ++nt) acc2[mt][nt] = MfmaD<T>::run(cq[s][nt], af, acc2[mt][nt]);
+        }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const long long pix = m0 + wm * 64 + mt * 32 + r;
+        T *ypix = y + (size_t)pix * N2;
+#pragma unroll
+        for (int nt = 0; nt < NT2; ++nt)
+            store_tile_t<T>(acc2[mt][nt], b2, wn * (N2 / 2) + nt * 32, 0, ypix, pix < m, hh);
+    }
+}
+
+template <typename T>
+static int launch_conv1x1_chain(const void *x, long long m, const void *w1, const float *b1, const void *w2, const float *b2,
+                                int cout2, int relu1, void *y, hipStream_t st) {
+    const int blocks = div_up(m, 128);
+    if (cout2 == 64)
+        hipLaunchKernelGGL((k_conv1x1_chain<T, 1>), dim3(blocks), dim3(256), 0, st, (const T *)x, (const T *)w1, b1, (const T *)w2, b2,
+                           (T *)y, m, relu1);
+    else
+        hipLaunchKernelGGL((k_conv1x1_chain<T, 2>), dim3(blocks), dim3(256), 0, st, (const T *)x, (const T *)w1, b1, (const T *)w2, b2,
+                           (T *)y, m, relu1);
+    return check_launch();
+}
+
 static int conv2d_variant() {
     static int v = -1;
-    if (v < 0) { const char *e = getenv("SEC_CONV2D_VARIANT"); v = e ? atoi(e) : 4; }  // 0 register staged, 1 LDS-DMA implicit GEMM, 2/3/4 halo tile 16x16 / 8x16 / 8x16 with 8 waves
+    if (v < 0) { const char *e = getenv("SEC_CONV2D_VARIANT"); v = e ? atoi(e) : 13; }  // 0 register staged, 1 LDS-DMA implicit GEMM, 2/3/4 halo tile 16x16 / 8x16 / 8x16 with 8 waves
     return v;
 }
 
 template <typename T>
 static int launch_conv2d(const void *x, const void *wpk, const float *bias, void *y, const Conv2dParams &p, hipStream_t st) {
     dim3 block(kBlock);
+    if (conv2d_variant() == 13 && p.ksize == 3 && p.stride == 1 && p.pad == 1 && p.cout % 128 == 0 && (p.cin == 128 || p.cin == 64))
+        return p.cin == 128 ? launch_conv2d_halo_reg<T, 128, 8>(x, wpk, bias, y, p, st) : launch_conv2d_halo_reg<T, 64, 8>(x, wpk, bias, y, p, st);
+    if (conv2d_variant() >= 5 && conv2d_variant() <= 12 && p.ksize == 3 && p.stride == 1 && p.pad == 1 && p.cout % 128 == 0 &&
+        (p.cin == 128 || p.cin == 64)) {
+        // 8 waves / 16 KB slabs / ring 2 with: 5 linear key   10 column key   11 fragment pipelining   12 both
+        // 8: 4 waves (64 px x 64 cout per wave), column key
+#define SEC_HALO_PIPE(NQ_, KS_, NB_, CK_, FP_)                                                                  \
+    return p.cin == 128 ? launch_conv2d_halo_pipe<T, 128, 8, NQ_, KS_, NB_, CK_, FP_>(x, wpk, bias, y, p, st)   \
+                        : launch_conv2d_halo_pipe<T, 64, 8, NQ_, KS_, NB_, CK_, FP_>(x, wpk, bias, y, p, st)
+        switch (conv2d_variant()) {
+        case 5: SEC_HALO_PIPE(4, 64, 2, false, false);
+        case 8: SEC_HALO_PIPE(2, 64, 2, true, false);
+        case 10: SEC_HALO_PIPE(4, 64, 2, true, false);
+        case 11: SEC_HALO_PIPE(4, 64, 2, false, true);
+        default: SEC_HALO_PIPE(4, 64, 2, true, true);
+        }
+#undef SEC_HALO_PIPE
+    }
     if (conv2d_variant() >= 2 && conv2d_variant() <= 4 && p.ksize == 3 && p.stride == 1 && p.pad == 1 &&
         p.cout % 128 == 0 && (p.cin == 128 || p.cin == 64)) {
         if (conv2d_variant() == 2)
@@ -613,6 +1099,17 @@ SEC_API int sec_conv2d_nhwc(const void *x, int batch, int h, int w, int cin, con
     hipStream_t st = (hipStream_t)stream;
     if (dtype == SEC_BF16) return launch_conv2d<__hip_bfloat16>(x, packed_weight, bias, y, p, st);
     return launch_conv2d<__half>(x, packed_weight, bias, y, p, st);
+}
+
+SEC_API int sec_conv1x1_chain_nhwc(const void *x, long long pixels, const void *packed_w1, const float *bias1, int relu1,
+                                   const void *packed_w2, const float *bias2, int cout2, void *y, int dtype, void *stream) {
+    if (!x || !packed_w1 || !packed_w2 || !bias1 || !y || pixels < 0) return SEC_E_INVALID;
+    if ((cout2 != 64 && cout2 != 128) || (dtype != SEC_BF16 && dtype != SEC_F16)) return SEC_E_UNSUPPORTED;
+    if (pixels == 0) return SEC_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SEC_BF16)
+        return launch_conv1x1_chain<__hip_bfloat16>(x, pixels, packed_w1, bias1, packed_w2, bias2, cout2, relu1, y, st);
+    return launch_conv1x1_chain<__half>(x, pixels, packed_w1, bias1, packed_w2, bias2, cout2, relu1, y, st);
 }
 
 SEC_API int sec_bias_act_nhwc(void *x, const float *bias, size_t pixels, int channels, int relu, int dtype, void *stream) {

@@ -21,6 +21,7 @@ constexpr int kMaxKvol = 128;
 struct RbGeom {
     int in_shape[3], out_shape[3], ksize[3], stride[3], pad[3], dil[3];
     int kvol, n_in, batch;
+    int cand[3], ncand;   // strided conv: max kernel offsets per dim that can hit an output, and their product
     uint32_t mask;
 };
 
@@ -116,55 +117,74 @@ __global__ __launch_bounds__(kBlock) void k_subm_nbr_sym(const int *__restrict__
 }
 
 // ---- strided / regular sparse conv -------------------------------------------------------------
+// An input row reaches an output only through the kernel offsets k_d with k_d*dil_d == i_d + pad_d (mod stride_d):
+// at most cand[d] = ceil(ksize/stride) of them per dim for dil = 1 (8 of 27 for the 3x3x3 stride-2 layers).  Candidate
+// slot c = (cz, cy, cx) enumerates the cz-th / cy-th / cx-th such offset, so offsets grow with c and "earlier
+// in the sequential reference loop" == "smaller c" inside a row.
+__device__ __forceinline__ bool cand_offset(const RbGeom &g, int d, int in, int c, int *k_out, int *o_out) {
+    int seen = 0;
+    for (int k = 0; k < g.ksize[d]; ++k) {
+        int num = in + g.pad[d] - k * g.dil[d];
+        if (num % g.stride[d] != 0) continue;
+        if (seen++ == c) {
+            int o = num / g.stride[d];
+            *k_out = k;
+            *o_out = o;
+            return num >= 0 && o < g.out_shape[d];
+        }
+    }
+    return false;
+}
+
 __global__ __launch_bounds__(kBlock) void k_conv_cand(const int *__restrict__ indices, RbGeom g,
                                                      const int *__restrict__ n_dev,
                                                      unsigned long long *__restrict__ keys,
                                                      int *__restrict__ vals, int *__restrict__ cand_slot,
-                                                     int *__restrict__ overflow) {
+                                                     unsigned char *__restrict__ cand_k, int *__restrict__ overflow) {
     long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
-    if (t >= (long long)g.n_in * g.kvol) return;
-    int j = (int)(t / g.kvol), k = (int)(t % g.kvol);
+    if (t >= (long long)g.n_in * g.ncand) return;
+    int j = (int)(t / g.ncand), c = (int)(t % g.ncand);
     if (j >= live_rows(g, n_dev)) { cand_slot[t] = -1; return; }
-    int kk[3] = {k / (g.ksize[2] * g.ksize[1]), (k / g.ksize[2]) % g.ksize[1], k % g.ksize[2]};
-    int4 c = *reinterpret_cast<const int4 *>(indices + (size_t)j * 4);
-    int in[3] = {c.y, c.z, c.w}, out[3];
+    int cc[3] = {c / (g.cand[2] * g.cand[1]), (c / g.cand[2]) % g.cand[1], c % g.cand[2]};
+    int4 q = *reinterpret_cast<const int4 *>(indices + (size_t)j * 4);
+    int in[3] = {q.y, q.z, q.w}, out[3], kk[3];
     bool ok = true;
 #pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        int num = in[d] + g.pad[d] - kk[d] * g.dil[d];
-        if (num < 0 || num % g.stride[d] != 0) ok = false;
-        out[d] = num / g.stride[d];
-        if (out[d] >= g.out_shape[d]) ok = false;
-    }
+    for (int d = 0; d < 3; ++d) ok &= cand_offset(g, d, in[d], cc[d], &kk[d], &out[d]);
     int s = -1;
     if (ok) {
-        s = hash_insert_bounded(keys, g.mask, cell_key(c.x, out[0], out[1], out[2], g.out_shape));
-        if (s >= 0) atomicMin(&vals[s], (int)t);  // token = j*K + k: order of the sequential reference loop
-        else atomicOr(overflow, 1);               // table sized from a too-small hint: reported, not hung
+        int k = (kk[0] * g.ksize[1] + kk[1]) * g.ksize[2] + kk[2];
+        s = hash_insert_bounded(keys, g.mask, cell_key(q.x, out[0], out[1], out[2], g.out_shape));
+        if (s >= 0) atomicMin(&vals[s], j * g.kvol + k);  // token = position in the sequential reference loop
+        else atomicOr(overflow, 1);                        // table sized from a too-small hint: reported, not hung
+        cand_k[t] = (unsigned char)k;
     }
     cand_slot[t] = s;
 }
 
 // per input row: how many of its candidates are the FIRST touch of their output cell (scan over n_in counts
-// instead of n_in * K flags: 27x less scan traffic)
-__global__ __launch_bounds__(kBlock) void k_conv_count(const int *__restrict__ cand_slot, const int *__restrict__ vals,
-                                                      int n_in, int kvol, int *__restrict__ count,
-                                                      unsigned *__restrict__ first_mask) {
+// instead of per-candidate flags)
+__global__ __launch_bounds__(kBlock) void k_conv_count(const int *__restrict__ cand_slot,
+                                                      const unsigned char *__restrict__ cand_k,
+                                                      const int *__restrict__ vals, int n_in, int kvol, int ncand,
+                                                      int *__restrict__ count, unsigned *__restrict__ first_mask) {
     int j = blockIdx.x * kBlock + threadIdx.x;
     if (j >= n_in) return;
-    int c = 0;
-    unsigned m = 0;   // bit k = candidate (j, k) is a first touch (kvol <= 32; larger kernels recount in k_conv_assign)
-    for (int k = 0; k < kvol; ++k) {
-        int s = cand_slot[(size_t)j * kvol + k];
-        bool f = s >= 0 && vals[s] == j * kvol + k;
-        c += f ? 1 : 0;
-        if (f && k < 32) m |= 1u << k;
+    int cnt = 0;
+    unsigned m = 0;   // bit c = candidate (j, c) is a first touch (ncand <= 32; larger ones recount in k_conv_assign)
+    for (int c = 0; c < ncand; ++c) {
+        size_t t = (size_t)j * ncand + c;
+        int s = cand_slot[t];
+        bool f = s >= 0 && vals[s] == j * kvol + (int)cand_k[t];
+        cnt += f ? 1 : 0;
+        if (f && c < 32) m |= 1u << c;
     }
-    count[j] = c;
+    count[j] = cnt;
     first_mask[j] = m;
 }
 
 __global__ __launch_bounds__(kBlock) void k_conv_assign(const int *__restrict__ cand_slot,
+                                                       const unsigned char *__restrict__ cand_k,
                                                        const int *__restrict__ vals,
                                                        const unsigned long long *__restrict__ keys,
                                                        const int *__restrict__ rank, RbGeom g,
@@ -178,18 +198,19 @@ __global__ __launch_bounds__(kBlock) void k_conv_assign(const int *__restrict__ 
         num_out[1] = *overflow ? 0x7fffffff : tot;
         if (tot > out_cap) num_out[0] = out_cap;
     }
-    if (t >= (long long)g.n_in * g.kvol) return;
+    if (t >= (long long)g.n_in * g.ncand) return;
     int s = cand_slot[t];
-    if (s < 0 || vals[s] != (int)t) return;
+    const int j = (int)(t / g.ncand), c = (int)(t % g.ncand);
+    if (s < 0 || vals[s] != j * g.kvol + (int)cand_k[t]) return;
     // rank = first touches of earlier rows (scan) + first touches of this row at smaller offsets
-    const int j = (int)(t / g.kvol), k = (int)(t % g.kvol);
     int r = rank[j];
-    if (g.kvol <= 32) {
-        r += __popc(first_mask[j] & ((1u << k) - 1u));
+    if (g.ncand <= 32) {
+        r += __popc(first_mask[j] & ((1u << c) - 1u));
     } else {
-        for (int k2 = 0; k2 < k; ++k2) {
-            int s2 = cand_slot[(size_t)j * g.kvol + k2];
-            r += (s2 >= 0 && vals[s2] == j * g.kvol + k2) ? 1 : 0;
+        for (int c2 = 0; c2 < c; ++c2) {
+            size_t t2 = (size_t)j * g.ncand + c2;
+            int s2 = cand_slot[t2];
+            r += (s2 >= 0 && vals[s2] == j * g.kvol + (int)cand_k[t2]) ? 1 : 0;
         }
     }
     orank[s] = r;
@@ -200,21 +221,24 @@ __global__ __launch_bounds__(kBlock) void k_conv_assign(const int *__restrict__ 
         unsigned long long lin = key - (unsigned long long)b * vol;
         int x = (int)(lin % g.out_shape[2]);
         unsigned long long q = lin / g.out_shape[2];
-        int4 c = make_int4(b, (int)(q / g.out_shape[1]), (int)(q % g.out_shape[1]), x);
-        *reinterpret_cast<int4 *>(out_indices + (size_t)r * 4) = c;
+        int4 c4 = make_int4(b, (int)(q / g.out_shape[1]), (int)(q % g.out_shape[1]), x);
+        *reinterpret_cast<int4 *>(out_indices + (size_t)r * 4) = c4;
     }
 }
 
+// nbr_out[o][k] = j (pre-filled with -1); nbr_in[j][k] = o only when requested (backward / pair lists; pre-filled too)
 __global__ __launch_bounds__(kBlock) void k_conv_tables(const int *__restrict__ cand_slot,
-                                                       const int *__restrict__ orank, long long n, int kvol,
+                                                       const unsigned char *__restrict__ cand_k,
+                                                       const int *__restrict__ orank, long long n, int kvol, int ncand,
                                                        int *__restrict__ nbr_in, int *__restrict__ nbr_out,
                                                        int nbr_out_rows) {
     long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (t >= n) return;
     int s = cand_slot[t];
-    int o = s >= 0 ? orank[s] : -1;
-    nbr_in[t] = o;
-    if (o >= 0 && o < nbr_out_rows) nbr_out[(size_t)o * kvol + (int)(t % kvol)] = (int)(t / kvol);
+    if (s < 0) return;
+    int o = orank[s], k = cand_k[t], j = (int)(t / ncand);
+    if (nbr_in) nbr_in[(size_t)j * kvol + k] = o;
+    if (o < nbr_out_rows) nbr_out[(size_t)o * kvol + k] = j;
 }
 
 // ---- spconv-format pair lists by ballot/prefix compaction of table columns -----------------------
@@ -281,6 +305,7 @@ struct RbWorkspace {
     unsigned long long *keys;
     int *vals, *orank, *cand_slot, *rank, *scan, *blk, *scan2, *overflow;
     unsigned *first_mask;
+    unsigned char *cand_k;
     uint32_t table;
     size_t bytes;
 };
@@ -302,6 +327,7 @@ static RbWorkspace carve_rb(void *ws, size_t cap, int n_in, int kvol, int max_ou
     w.scan2 = a.take<int>(scan_scratch_ints(nblk));
     w.overflow = a.take<int>(1);
     w.first_mask = a.take<unsigned>(n_in > 0 ? n_in : 1);
+    w.cand_k = a.take<unsigned char>(nk > 0 ? nk : 1);
     w.bytes = align_up(a.used);
     return w;
 }
@@ -323,14 +349,21 @@ static int fill_geom(RbGeom &g, const int *in_shape, const int *out_shape, const
     if (g.kvol > kMaxKvol) return SEC_E_UNSUPPORTED;
     g.n_in = n_in;
     g.batch = batch;
+    g.ncand = 1;
+    for (int d = 0; d < 3; ++d) {   // most kernel offsets of one residue class mod stride
+        int best = 0;
+        for (int r = 0; r < g.stride[d]; ++r) {
+            int c = 0;
+            for (int k = 0; k < g.ksize[d]; ++k) c += (k * g.dil[d]) % g.stride[d] == r;
+            if (c > best) best = c;
+        }
+        g.cand[d] = best;
+        g.ncand *= best;
+    }
     return SEC_OK;
 }
 
-static int max_out_per_in(const int *ksize, const int *stride, int hint) {
-    int c = 1;
-    for (int d = 0; d < 3; ++d) c *= (ksize[d] + stride[d] - 1) / stride[d];
-    return (hint > 0 && hint < c) ? hint : c;
-}
+static int max_out_per_in(const RbGeom &g, int hint) { return (hint > 0 && hint < g.ncand) ? hint : g.ncand; }
 
 }  // namespace sec
 
@@ -386,40 +419,50 @@ SEC_API int sec_rulebook_conv3d_build(const int *indices, int n_in, const int *n
     RbGeom g;
     int rc = fill_geom(g, h_in_shape3, h_out_shape3, h_ksize3, h_stride3, h_padding3, h_dilation3, n_in, batch);
     if (rc) return rc;
+    // stride > 1 together with dilation > 1 in the same dim: upstream getValidOutPos steps the outputs by `dilation`
+    // and floors the offset division there, which no SECOND config exercises -- refused rather than guessed
+    for (int d = 0; d < 3; ++d)
+        if (g.stride[d] > 1 && g.dil[d] > 1) return SEC_E_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    RbWorkspace w = carve_rb(workspace, workspace_bytes, n_in, g.kvol, max_out_per_in(g.ksize, g.stride, out_per_in_hint));
+    RbWorkspace w = carve_rb(workspace, workspace_bytes, n_in, g.kvol, max_out_per_in(g, out_per_in_hint));
     if (!workspace || w.bytes > workspace_bytes) return SEC_E_WORKSPACE;
     g.mask = w.table - 1;
-    long long nk = (long long)n_in * g.kvol;
-    if (nk == 0) return hip_ok(hipMemsetAsync(num_out, 0, 2 * sizeof(int), st));
+    long long nc = (long long)n_in * g.ncand;
+    if (nc == 0) return hip_ok(hipMemsetAsync(num_out, 0, 2 * sizeof(int), st));
     rb_init(w.keys, w.table, kEmptyKey, w.vals, w.table, kEmptyI32, w.overflow, 1, 0, st);
-    int nb = div_up(nk, kBlock);
-    hipLaunchKernelGGL(k_conv_cand, dim3(nb), dim3(kBlock), 0, st, indices, g, n_in_dev, w.keys, w.vals, w.cand_slot, w.overflow);
-    hipLaunchKernelGGL(k_conv_count, dim3(div_up(n_in, kBlock)), dim3(kBlock), 0, st, w.cand_slot, w.vals, n_in, g.kvol, w.rank, w.first_mask);
+    int nb = div_up(nc, kBlock);
+    hipLaunchKernelGGL(k_conv_cand, dim3(nb), dim3(kBlock), 0, st, indices, g, n_in_dev, w.keys, w.vals, w.cand_slot,
+                       w.cand_k, w.overflow);
+    hipLaunchKernelGGL(k_conv_count, dim3(div_up(n_in, kBlock)), dim3(kBlock), 0, st, w.cand_slot, w.cand_k, w.vals, n_in,
+                       g.kvol, g.ncand, w.rank, w.first_mask);
     if ((rc = exclusive_scan_i32(w.rank, w.rank, n_in, num_out, w.scan, st))) return rc;
-    hipLaunchKernelGGL(k_conv_assign, dim3(nb), dim3(kBlock), 0, st, w.cand_slot, w.vals, w.keys, w.rank, g, w.orank,
-                       out_indices, out_cap, num_out, w.overflow, w.first_mask);
+    hipLaunchKernelGGL(k_conv_assign, dim3(nb), dim3(kBlock), 0, st, w.cand_slot, w.cand_k, w.vals, w.keys, w.rank, g,
+                       w.orank, out_indices, out_cap, num_out, w.overflow, w.first_mask);
     return check_launch();
 }
 
-SEC_API int sec_rulebook_conv3d_tables(int n_in, const int *h_ksize3, const int *h_stride3, int out_per_in_hint,
-                                       int *nbr_out, int nbr_out_rows, int *nbr_in, int *pairs, int *pair_num,
-                                       void *workspace, size_t workspace_bytes, void *stream) {
-    if (n_in < 0 || !h_ksize3 || !h_stride3 || (nbr_out_rows > 0 && !nbr_out) || (n_in > 0 && !nbr_in) || nbr_out_rows < 0 ||
-        (pairs && !pair_num))
+SEC_API int sec_rulebook_conv3d_tables(int n_in, const int *h_ksize3, const int *h_stride3, const int *h_dilation3,
+                                       int out_per_in_hint, int *nbr_out, int nbr_out_rows, int *nbr_in, int *pairs,
+                                       int *pair_num, void *workspace, size_t workspace_bytes, void *stream) {
+    if (n_in < 0 || !h_ksize3 || !h_stride3 || (nbr_out_rows > 0 && !nbr_out) || nbr_out_rows < 0 ||
+        (pairs && (!pair_num || !nbr_in)))
         return SEC_E_INVALID;
-    int kvol = h_ksize3[0] * h_ksize3[1] * h_ksize3[2];
-    if (kvol <= 0 || kvol > kMaxKvol) return SEC_E_UNSUPPORTED;
+    RbGeom g;
+    const int ones[3] = {1, 1, 1};
+    int rc = fill_geom(g, ones, ones, h_ksize3, h_stride3, nullptr, h_dilation3, n_in, 1);   // shapes unused here
+    if (rc) return rc;
+    const int kvol = g.kvol;
     hipStream_t st = (hipStream_t)stream;
-    RbWorkspace w = carve_rb(workspace, workspace_bytes, n_in, kvol, max_out_per_in(h_ksize3, h_stride3, out_per_in_hint));
+    RbWorkspace w = carve_rb(workspace, workspace_bytes, n_in, kvol, max_out_per_in(g, out_per_in_hint));
     if (!workspace || w.bytes > workspace_bytes) return SEC_E_WORKSPACE;
-    int rc;
-    if (nbr_out_rows > 0)
-        if ((rc = hip_ok(hipMemsetAsync(nbr_out, 0xff, (size_t)nbr_out_rows * kvol * sizeof(int), st)))) return rc;
-    long long nk = (long long)n_in * kvol;
-    if (nk > 0) {
-        hipLaunchKernelGGL(k_conv_tables, dim3(div_up(nk, kBlock)), dim3(kBlock), 0, st, w.cand_slot, w.orank, nk, kvol,
-                           nbr_in, nbr_out, nbr_out_rows);
+    // one fill launch for both tables (nbr_in only when the caller wants it: backward / pair lists)
+    long long n_out_words = (long long)nbr_out_rows * kvol, n_in_words = nbr_in ? (long long)n_in * kvol : 0;
+    if (n_out_words + n_in_words > 0)
+        rb_init(nullptr, 0, 0, nbr_out, n_out_words, -1, nbr_in, n_in_words, -1, st);
+    long long nc = (long long)n_in * g.ncand;
+    if (nc > 0) {
+        hipLaunchKernelGGL(k_conv_tables, dim3(div_up(nc, kBlock)), dim3(kBlock), 0, st, w.cand_slot, w.cand_k, w.orank, nc,
+                           kvol, g.ncand, nbr_in, nbr_out, nbr_out_rows);
         if ((rc = check_launch())) return rc;
     }
     if (pairs) return emit_pairs(nbr_in, n_in, kvol, /*mirror=*/0, w.blk, w.scan2, pairs, pair_num, st);

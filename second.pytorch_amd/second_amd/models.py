@@ -403,12 +403,20 @@ class RPNInference(nn.Module):
             self.head_packed = ops.conv2d_pack_weight(hw64)
             self.head_b64 = torch.cat([hb, torch.zeros(cpad, device=hb.device)]).contiguous()
             self.use_hip = self.head_packed is not None
+        # deblock (1x1, stride 1, 128 -> 128) + heads (<= 128 padded channels) run as ONE kernel (sec_conv1x1_chain_nhwc)
+        wl = self.ws[-1]
+        self.chain_tail = (self.use_hip and tuple(wl.shape) == (128, 128, 1, 1) and self.cfgs[-1] == ([1, 1], [0, 0])
+                           and self.head_cout in (64, 128) and os.environ.get("SEC_RPN_CHAIN", "1") == "1")
 
     def forward(self, x):
         if self.use_hip:
-            for w, pk, b, (s, p) in zip(self.ws, self.packed, self.bs, self.cfgs):
+            n_sep = len(self.ws) - 1 if self.chain_tail else len(self.ws)
+            for w, pk, b, (s, p) in list(zip(self.ws, self.packed, self.bs, self.cfgs))[:n_sep]:
                 x = ops.conv2d_nhwc(x, pk, b, w.shape[0], w.shape[2], s[0], p[0], relu=True)
-            y = ops.conv2d_nhwc(x, self.head_packed, self.head_b64, self.head_cout, 1, 1, 0, relu=False)
+            if self.chain_tail:
+                y = ops.conv1x1_chain(x, self.packed[-1], self.bs[-1], self.head_packed, self.head_b64, self.head_cout)
+            else:
+                y = ops.conv2d_nhwc(x, self.head_packed, self.head_b64, self.head_cout, 1, 1, 0, relu=False)
         else:
             for w, b, (s, p) in zip(self.ws, self.bs, self.cfgs):
                 x = ops.bias_act_(F.conv2d(x, w, None, s, p), b, relu=True)

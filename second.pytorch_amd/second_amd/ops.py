@@ -85,8 +85,16 @@ def rulebook_subm(indices, batch_size, spatial_shape, ksize=3, dilation=1, want_
             "num_out": n, "num_out_dev": n_dev, "out_shape": [int(s) for s in spatial_shape]}
 
 
+def _out_per_in(ks, st, dl):
+    """Kernel offsets that can reach an output from one input (see sec_rulebook_workspace_bytes)."""
+    tot = 1
+    for d in range(3):
+        tot *= max(sum(1 for k in range(ks[d]) if (k * dl[d]) % st[d] == r) for r in range(st[d]))
+    return tot
+
+
 def rulebook_conv(indices, batch_size, spatial_shape, ksize, stride, padding, dilation=1, want_pairs=False,
-                  n_dev=None, out_cap=None, out_per_in_hint=0):
+                  n_dev=None, out_cap=None, out_per_in_hint=0, want_nbr_in=True):
     """SparseConv3d rulebook (spconv.ops.get_indice_pairs(subm=False)), first-touch output numbering.
 
     Eager mode (default): one D2H sync for the active-output count, like the reference's numActOut.
@@ -99,7 +107,8 @@ def rulebook_conv(indices, batch_size, spatial_shape, ksize, stride, padding, di
     k = _kvol(ksize)
     dev = indices.device
     out_shape = conv_output_shape(spatial_shape, ksize, stride, padding, dilation)
-    per_in = int(np.prod([(ks[d] + st[d] - 1) // st[d] for d in range(3)]))
+    dl = rt.i3(dilation)
+    per_in = _out_per_in(ks, st, dl)
     hint = int(out_per_in_hint) if 0 < int(out_per_in_hint) < per_in else 0
     static = out_cap is not None
     cap = int(out_cap) if static else max(1, min(n * per_in, int(batch_size) * int(np.prod(out_shape))))
@@ -113,10 +122,10 @@ def rulebook_conv(indices, batch_size, spatial_shape, ksize, stride, padding, di
     rt.check(rc, "sec_rulebook_conv3d_build")
     m = cap if static else int(num_out[0].item())
     nbr_out = torch.empty((m, k), dtype=torch.int32, device=dev)
-    nbr_in = torch.empty((n, k), dtype=torch.int32, device=dev)
+    nbr_in = torch.empty((n, k), dtype=torch.int32, device=dev) if (want_nbr_in or want_pairs) else None
     pairs = torch.empty((k, 2, n), dtype=torch.int32, device=dev) if want_pairs else None
     pair_num = torch.zeros((k,), dtype=torch.int32, device=dev) if want_pairs else None
-    rc = l.sec_rulebook_conv3d_tables(n, ks, st, hint, rt.ptr(nbr_out), m, rt.ptr(nbr_in), rt.ptr(pairs),
+    rc = l.sec_rulebook_conv3d_tables(n, ks, st, dl, hint, rt.ptr(nbr_out), m, rt.ptr(nbr_in), rt.ptr(pairs),
                                       rt.ptr(pair_num), rt.ptr(ws), ws.numel(), rt.stream())
     rt.check(rc, "sec_rulebook_conv3d_tables")
     return {"nbr_out": nbr_out, "nbr_in": nbr_in, "pairs": pairs, "pair_num": pair_num,
@@ -351,6 +360,20 @@ def conv2d_nhwc(x, packed, bias, cout, ksize, stride=1, pad=0, relu=False):
 
 
 # ----------------------------------------------------------------------------- IoU / NMS
+def conv1x1_chain(x, packed_w1, bias1, packed_w2, bias2, cout2, relu1=True):
+    """y = W2 * act(W1 * x + bias1) + bias2 for two back-to-back 1x1 convs on a channels_last [B,128,H,W] tensor
+    (the RPN deblock + merged heads, rpn.py:275-285,386-391); the 128-channel intermediate stays in LDS."""
+    rt.require_gpu(x, packed_w1, packed_w2, bias1)
+    assert x.dim() == 4 and x.shape[1] == 128 and x.is_contiguous(memory_format=torch.channels_last)
+    b, _, h, w = x.shape
+    y = torch.empty((b, int(cout2), h, w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    rc = rt.lib().sec_conv1x1_chain_nhwc(rt.ptr(x), b * h * w, rt.ptr(packed_w1), rt.ptr(bias1), int(bool(relu1)),
+                                         rt.ptr(packed_w2), rt.ptr(bias2), int(cout2), rt.ptr(y), rt.dtype_code(x.dtype),
+                                         rt.stream())
+    rt.check(rc, "sec_conv1x1_chain_nhwc")
+    return y
+
+
 def rotate_iou(boxes, qboxes, criterion=-1):
     """[N,K] rotated IoU (nms_gpu.py rotate_iou_gpu_eval)."""
     rt.require_gpu(boxes, qboxes)

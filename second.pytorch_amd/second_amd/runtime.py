@@ -23,7 +23,7 @@ SYMBOLS = [
     "sec_pack_conv_weight", "sec_indice_conv_fwd", "sec_indice_conv_bwd", "sec_sparse_to_dense", "sec_dense_to_sparse",
     "sec_pillar_scatter", "sec_pfn_fwd", "sec_block_filter_workspace_bytes",
     "sec_voxel_block_filter_f32", "sec_bias_act_nhwc", "sec_conv2d_packed_weight_bytes",
-    "sec_conv2d_pack_weight", "sec_conv2d_nhwc", "sec_rotate_iou_f32", "sec_nms_workspace_bytes", "sec_nms_sorted_f32",
+    "sec_conv2d_pack_weight", "sec_conv2d_nhwc", "sec_conv1x1_chain_nhwc", "sec_rotate_iou_f32", "sec_nms_workspace_bytes", "sec_nms_sorted_f32",
     "sec_predict_select", "sec_predict_decode", "sec_predict_finalize",
 ]
 
@@ -55,7 +55,7 @@ def lib():
         l.sec_rulebook_workspace_bytes.argtypes = [ci, ci, ci]
         l.sec_rulebook_subm3d.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, sz, vp]
         l.sec_rulebook_conv3d_build.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, vp, ci, vp, sz, vp]
-        l.sec_rulebook_conv3d_tables.argtypes = [ci, vp, vp, ci, vp, ci, vp, vp, vp, vp, sz, vp]
+        l.sec_rulebook_conv3d_tables.argtypes = [ci, vp, vp, vp, ci, vp, ci, vp, vp, vp, vp, sz, vp]
         l.sec_conv_output_shape.argtypes = [vp] * 6
         l.sec_packed_weight_bytes.argtypes = [ci, ci, ci, ci]
         l.sec_pack_conv_weight.argtypes = [vp, ci, ci, ci, ci, vp, vp]
@@ -71,6 +71,7 @@ def lib():
         l.sec_conv2d_packed_weight_bytes.argtypes = [ci, ci, ci, ci]
         l.sec_conv2d_pack_weight.argtypes = [vp, ci, ci, ci, ci, vp, vp]
         l.sec_conv2d_nhwc.argtypes = [vp, ci, ci, ci, ci, vp, vp, ci, ci, ci, ci, ci, vp, ci, vp]
+        l.sec_conv1x1_chain_nhwc.argtypes = [vp, ctypes.c_longlong, vp, vp, ci, vp, vp, ci, vp, ci, vp]
         l.sec_rotate_iou_f32.argtypes = [vp, ci, vp, ci, ci, vp, vp]
         l.sec_nms_workspace_bytes.argtypes = [ci, ci]
         l.sec_nms_sorted_f32.argtypes = [vp, vp, ci, ci, ci, cf, ci, ci, cf, ci, vp, vp, vp, sz, vp]

@@ -76,10 +76,11 @@ class SparseConvolution(SparseModule):
             cap = self.static_out_rows or int(indices.shape[0] * self.static_growth)
             hint = max(1, -(-cap // max(indices.shape[0], 1)))
             r = _ops.rulebook_conv(indices, x.batch_size, x.spatial_shape, self.kernel_size, self.stride, self.padding,
-                                   self.dilation, n_dev=nd, out_cap=cap, out_per_in_hint=hint)
+                                   self.dilation, n_dev=nd, out_cap=cap, out_per_in_hint=hint,
+                                   want_nbr_in=torch.is_grad_enabled())
         else:
             r = _ops.rulebook_conv(indices, x.batch_size, x.spatial_shape, self.kernel_size, self.stride, self.padding,
-                                   self.dilation)
+                                   self.dilation, want_nbr_in=torch.is_grad_enabled())
         rb = Rulebook(r["out_indices"], indices, r["nbr_out"], r["nbr_in"], r["num_out"], x.spatial_shape,
                       r["out_shape"], self.subm, num_out_dev=r["num_out_dev"])
         if self.indice_key is not None:

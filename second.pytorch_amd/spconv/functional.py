@@ -16,6 +16,9 @@ class IndiceConvFunction(torch.autograd.Function):
     def backward(ctx, grad_out):
         features, weight = ctx.saved_tensors
         rb = ctx.rulebook
+        if not rb.subm and rb.nbr_in is None:
+            raise RuntimeError("this rulebook was built with autograd disabled (no input-major table); rebuild it "
+                               "under torch.enable_grad() to back-propagate through a strided sparse conv")
         dfeat, dw = _ops.indice_conv_backward(features.contiguous(), weight.contiguous(), rb.nbr_out, rb.nbr_in,
                                               grad_out.contiguous(), ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         return dfeat, dw, None, None

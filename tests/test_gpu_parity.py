@@ -129,14 +129,18 @@ def test_rulebook_subm_bit_exact(ops, ksize):
     np.testing.assert_array_equal(rb["nbr_out"].cpu().numpy(), nbr_out)
 
 
-@pytest.mark.parametrize("ksize,stride,padding", [
-    (3, 2, 1), (3, 2, (0, 1, 1)), ((3, 1, 1), (2, 1, 1), 0), (3, 1, 0), (2, 2, 0), (3, 1, 1), (3, 3, 1)])
-def test_rulebook_conv_bit_exact(ops, ksize, stride, padding):
+@pytest.mark.parametrize("ksize,stride,padding,dilation", [
+    (3, 2, 1, 1), (3, 2, (0, 1, 1), 1), ((3, 1, 1), (2, 1, 1), 0, 1), (3, 1, 0, 1), (2, 2, 0, 1), (3, 1, 1, 1), (3, 3, 1, 1),
+    (3, 1, 2, 2), (3, (2, 1, 1), 1, (1, 2, 2)), (5, 2, 2, 1), (4, 2, 1, 1)])
+def test_rulebook_conv_bit_exact(ops, ksize, stride, padding, dilation):
     rng = np.random.default_rng(1)
     shape = (11, 24, 19)
     idx = _random_indices(rng, 2, shape, 500)
-    rb = ops.rulebook_conv(dev(idx), 2, shape, ksize, stride, padding, 1, want_pairs=True)
-    out_idx, pairs, pair_num, out_shape = orc.rulebook_conv(idx, 2, shape, ksize, stride, padding)
+    rb = ops.rulebook_conv(dev(idx), 2, shape, ksize, stride, padding, dilation, want_pairs=True)
+    out_idx, pairs, pair_num, out_shape = orc.rulebook_conv(idx, 2, shape, ksize, stride, padding, dilation)
+    lean = ops.rulebook_conv(dev(idx), 2, shape, ksize, stride, padding, dilation, want_nbr_in=False)   # inference form
+    assert lean["nbr_in"] is None and torch.equal(lean["nbr_out"], rb["nbr_out"])
+    assert torch.equal(lean["out_indices"], rb["out_indices"])
     assert rb["out_shape"] == out_shape.tolist()
     assert rb["num_out"] == len(out_idx)
     np.testing.assert_array_equal(rb["out_indices"].cpu().numpy(), out_idx)
@@ -145,6 +149,13 @@ def test_rulebook_conv_bit_exact(ops, ksize, stride, padding):
     nbr_out, nbr_in = _tables_from_pairs(pairs, pair_num, len(idx), len(out_idx))
     np.testing.assert_array_equal(rb["nbr_out"].cpu().numpy(), nbr_out)
     np.testing.assert_array_equal(rb["nbr_in"].cpu().numpy(), nbr_in)
+
+
+def test_rulebook_conv_stride_with_dilation_is_refused(ops):
+    from second_amd.runtime import SecondHipError
+    idx = _random_indices(np.random.default_rng(2), 1, (11, 24, 19), 50)
+    with pytest.raises(SecondHipError):
+        ops.rulebook_conv(dev(idx), 1, (11, 24, 19), 3, 2, 2, 2)
 
 
 def test_rulebook_empty_and_single(ops):
@@ -663,3 +674,25 @@ def test_sparse_sequential_training_step_vs_oracle(ops):
         np.testing.assert_allclose(grads_g[k], grads_c[k], rtol=1e-3, atol=2e-4 * np.abs(grads_c[k]).max(), err_msg=k)
     for k in state_c:   # BatchNorm running statistics updated identically
         np.testing.assert_allclose(state_g[k], state_c[k], rtol=1e-4, atol=1e-5, err_msg=k)
+
+
+@pytest.mark.parametrize("cout2", [64, 128])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_conv1x1_chain_vs_torch(ops, cout2, dtype):
+    """Fused deblock + heads kernel vs two torch 1x1 convs (the intermediate rounded to the 16-bit type, as the
+    unfused path stores it)."""
+    torch.manual_seed(cout2)
+    b, hw = 2, (37, 29)                                  # 2146 pixels: not a multiple of the 128-pixel tile
+    x = torch.randn(b, 128, *hw, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)
+    w1 = (torch.randn(128, 128, 1, 1, device="cuda") / 128 ** 0.5).to(dtype)
+    w2 = (torch.randn(cout2, 128, 1, 1, device="cuda") / 128 ** 0.5).to(dtype)
+    b1, b2 = torch.randn(128, device="cuda"), torch.randn(cout2, device="cuda")
+    h = torch.relu(torch.nn.functional.conv2d(x.float(), w1.float(), b1)).to(dtype).float()
+    ref = torch.nn.functional.conv2d(h, w2.float(), b2)
+    out = ops.conv1x1_chain(x, ops.conv2d_pack_weight(w1), b1, ops.conv2d_pack_weight(w2), b2, cout2)
+    assert out.shape == ref.shape and out.is_contiguous(memory_format=torch.channels_last)
+    tol = 2 ** -7 if dtype == torch.bfloat16 else 2 ** -9
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref.cpu().numpy(), rtol=tol, atol=tol * ref.abs().max().item())
+    sep = ops.conv2d_nhwc(ops.conv2d_nhwc(x, ops.conv2d_pack_weight(w1), b1, 128, 1, 1, 0, relu=True),
+                          ops.conv2d_pack_weight(w2), b2, cout2, 1, 1, 0, relu=False)
+    np.testing.assert_allclose(out.float().cpu().numpy(), sep.float().cpu().numpy(), rtol=tol, atol=tol * ref.abs().max().item())

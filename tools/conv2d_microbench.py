@@ -14,8 +14,9 @@ x = x.bfloat16().contiguous(memory_format=torch.channels_last)
 w = (torch.randn(128, 128, 3, 3, device="cuda") / 34).bfloat16()
 b = torch.randn(128, device="cuda")
 pk = ops.conv2d_pack_weight(w)
-def bench(fn, n=100):
-    for _ in range(300): fn()          # ~0.1 s of warm-up: the first launches of a process run at idle clocks
+WARM, N = int(os.environ.get("WARM", "300")), int(os.environ.get("ITERS", "100"))
+def bench(fn, n=N):
+    for _ in range(WARM): fn()          # ~0.1 s of warm-up: the first launches of a process run at idle clocks
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
