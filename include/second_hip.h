@@ -91,6 +91,17 @@ int sec_rulebook_subm3d(const int *indices, int n_in, const int *n_in_dev, int b
                         int *pairs, int *pair_num, void *workspace, size_t workspace_bytes,
                         void *stream);
 
+/* SubMConv3d on the OUTPUT sites of a strided conv whose rulebook was just built: the strided build's hash table
+ * (output cell -> output row) is still in `conv_workspace`, so this layer skips re-hashing its sites (the
+ * subm1/subm2/subm3 groups of SpMiddleFHD each follow a SparseConv3d, middle.py:152-188).  `indices` must be the
+ * out_indices of that build, the conv_* arguments the ones given to sec_rulebook_conv3d_build / _tables, and
+ * the workspace must not have been reused in between.  Same nbr_out as sec_rulebook_subm3d. */
+int sec_rulebook_subm3d_after_conv(const int *indices, int n_in, const int *n_in_dev, int batch,
+                                   const int *h_shape3, const int *h_ksize3, const int *h_dilation3,
+                                   int *nbr_out, const void *conv_workspace, size_t conv_workspace_bytes,
+                                   int conv_n_in, const int *h_conv_ksize3, const int *h_conv_stride3,
+                                   const int *h_conv_dilation3, int conv_out_per_in_hint, void *stream);
+
 /* SparseConv3d, step 1: discover the active outputs in first-touch order (oracle numbering).
  *   A dim with both stride > 1 and dilation > 1 returns SEC_E_UNSUPPORTED (no SECOND config has one).
  *   out_indices [out_cap,4]; num_out = device int[2]: [0] live outputs clamped to out_cap (feed it to the

@@ -114,6 +114,57 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int *smem, int *total
     return base + inc - v;
 }
 
+// ---------------------------------------------------------------- single-pass grid scan (decoupled look-back)
+// A producer kernel that already visits every element scans in place instead of writing flags for three more
+// launches.  Tiles are handed out by an atomic ticket (a spinning tile only waits on tiles that are already running);
+// a workgroup publishes its aggregate, then one wave inspects up to 64 predecessors per step until it meets an
+// inclusive prefix.  status[t] = flag << 32 | value (1 = aggregate, 2 = inclusive prefix, 0 = not yet); the ticket and
+// the status words must be zero at launch (the init kernel of the same pipeline clears them).
+constexpr unsigned long long kScanAgg = 1ull << 32, kScanIncl = 2ull << 32;
+inline size_t scan_ctl_words(long long n) { return 4 + 2 * (size_t)div_up(n > 0 ? n : 1, kBlock); }   // [ticket,-,-,-,status...]
+__device__ __forceinline__ int scan_take_tile(int *ticket, int *s_tile) {
+    if (threadIdx.x == 0) *s_tile = atomicAdd(ticket, 1);
+    __syncthreads();
+    return *s_tile;
+}
+// every thread of the 256-thread block calls this with its value; returns the exclusive prefix over the whole grid
+// in tile order; the last tile stores the grand total.  smem: >= 5 ints.
+__device__ __forceinline__ int scan_lookback(int v, int tile, int ntiles, unsigned long long *status, int *smem,
+                                             int *total_out) {
+    int total;
+    const int ex = block_exclusive_scan(v, smem, &total);
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        if (lane == 0)
+            __hip_atomic_store(&status[tile], (tile == 0 ? kScanIncl : kScanAgg) | (unsigned)total, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        int prefix = 0;
+        for (int look = tile - 1; look >= 0; look -= 64) {
+            const int idx = look - lane;
+            unsigned long long sv = kScanIncl;                // before the first tile: inclusive prefix 0
+            if (idx >= 0) {
+                while (((sv = __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) == 0)
+                    __builtin_amdgcn_s_sleep(1);
+            }
+            const unsigned long long incl = __ballot((sv >> 32) == 2);
+            const int stop = incl ? __ffsll((long long)incl) - 1 : 64;   // nearest predecessor holding an inclusive prefix
+            int part = lane <= stop ? (int)(unsigned)sv : 0;
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d, 64);
+            prefix += part;
+            if (incl) break;
+        }
+        if (lane == 0) {
+            if (tile > 0)
+                __hip_atomic_store(&status[tile], kScanIncl | (unsigned)(prefix + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            smem[4] = prefix;
+            if (tile == ntiles - 1 && total_out) *total_out = prefix + total;
+        }
+    }
+    __syncthreads();
+    return smem[4] + ex;
+}
+
 // device-wide exclusive scan of int32 (three launches; n up to ~2^31). Scratch: scan_scratch_ints(n) ints.
 constexpr int kScanItems = 8;                      // per thread
 constexpr int kScanTile = kBlock * kScanItems;     // 2048 per block

@@ -110,8 +110,10 @@ __global__ __launch_bounds__(kBlock) void k_subm_nbr_sym(const int *__restrict__
         int s = hash_find(keys, g.mask, cell_key(c.x, z, y, x, g.in_shape));
         if (s >= 0) {
             int j = vals[s];
-            nbr[(size_t)o * g.kvol + k] = j;
-            nbr[(size_t)j * g.kvol + (g.kvol - 1 - k)] = o;
+            if ((unsigned)j < (unsigned)g.n_in) {   // a table inherited from an overflowed strided build may rank past the capacity
+                nbr[(size_t)o * g.kvol + k] = j;
+                nbr[(size_t)j * g.kvol + (g.kvol - 1 - k)] = o;
+            }
         }
     }
 }
@@ -162,25 +164,33 @@ __global__ __launch_bounds__(kBlock) void k_conv_cand(const int *__restrict__ in
     cand_slot[t] = s;
 }
 
-// per input row: how many of its candidates are the FIRST touch of their output cell (scan over n_in counts
-// instead of per-candidate flags)
-__global__ __launch_bounds__(kBlock) void k_conv_count(const int *__restrict__ cand_slot,
-                                                      const unsigned char *__restrict__ cand_k,
-                                                      const int *__restrict__ vals, int n_in, int kvol, int ncand,
-                                                      int *__restrict__ count, unsigned *__restrict__ first_mask) {
-    int j = blockIdx.x * kBlock + threadIdx.x;
-    if (j >= n_in) return;
+// Per input row: how many of its candidates are the FIRST touch of their output cell, and -- in the same launch -- the
+// exclusive prefix sum of those counts over the rows (rank of the row's first new output) by the single-pass scan of
+// common.hpp: replaces a count kernel + three scan launches.
+__global__ __launch_bounds__(kBlock) void k_conv_count_scan(const int *__restrict__ cand_slot,
+                                                           const unsigned char *__restrict__ cand_k,
+                                                           const int *__restrict__ vals, int n_in, int kvol, int ncand,
+                                                           int *__restrict__ rank, unsigned *__restrict__ first_mask,
+                                                           unsigned long long *__restrict__ status,
+                                                           int *__restrict__ ticket, int *__restrict__ total_out) {
+    __shared__ int smem[5];
+    __shared__ int s_tile;
+    const int tile = scan_take_tile(ticket, &s_tile);
+    const int j = tile * kBlock + threadIdx.x;
     int cnt = 0;
     unsigned m = 0;   // bit c = candidate (j, c) is a first touch (ncand <= 32; larger ones recount in k_conv_assign)
-    for (int c = 0; c < ncand; ++c) {
-        size_t t = (size_t)j * ncand + c;
-        int s = cand_slot[t];
-        bool f = s >= 0 && vals[s] == j * kvol + (int)cand_k[t];
-        cnt += f ? 1 : 0;
-        if (f && c < 32) m |= 1u << c;
+    if (j < n_in) {
+        for (int c = 0; c < ncand; ++c) {
+            size_t t = (size_t)j * ncand + c;
+            int s = cand_slot[t];
+            bool f = s >= 0 && vals[s] == j * kvol + (int)cand_k[t];
+            cnt += f ? 1 : 0;
+            if (f && c < 32) m |= 1u << c;
+        }
+        first_mask[j] = m;
     }
-    count[j] = cnt;
-    first_mask[j] = m;
+    const int ex = scan_lookback(cnt, tile, (int)gridDim.x, status, smem, total_out);
+    if (j < n_in) rank[j] = ex;
 }
 
 __global__ __launch_bounds__(kBlock) void k_conv_assign(const int *__restrict__ cand_slot,
@@ -303,7 +313,9 @@ static int emit_pairs(const int *table, int n, int kvol, int mirror, int *blk, i
 
 struct RbWorkspace {
     unsigned long long *keys;
-    int *vals, *orank, *cand_slot, *rank, *scan, *blk, *scan2, *overflow;
+    int *vals, *orank, *cand_slot, *rank, *scan, *blk, *scan2, *overflow, *ticket;
+    unsigned long long *status;
+    long long ctl_words;
     unsigned *first_mask;
     unsigned char *cand_k;
     uint32_t table;
@@ -325,7 +337,11 @@ static RbWorkspace carve_rb(void *ws, size_t cap, int n_in, int kvol, int max_ou
     long long nblk = (long long)kvol * div_up(n_in > 0 ? n_in : 1, kBlock);
     w.blk = a.take<int>(nblk + 1);
     w.scan2 = a.take<int>(scan_scratch_ints(nblk));
-    w.overflow = a.take<int>(1);
+    // control block cleared by one k_rb_init region: [ticket, overflow, -, -, status[tiles] (64-bit)]
+    w.ctl_words = (long long)scan_ctl_words(n_in);
+    w.ticket = a.take<int>(w.ctl_words);
+    w.overflow = w.ticket + 1;
+    w.status = reinterpret_cast<unsigned long long *>(w.ticket + 4);
     w.first_mask = a.take<unsigned>(n_in > 0 ? n_in : 1);
     w.cand_k = a.take<unsigned char>(nk > 0 ? nk : 1);
     w.bytes = align_up(a.used);
@@ -408,6 +424,34 @@ SEC_API int sec_rulebook_subm3d(const int *indices, int n_in, const int *n_in_de
     return SEC_OK;
 }
 
+SEC_API int sec_rulebook_subm3d_after_conv(const int *indices, int n_in, const int *n_in_dev, int batch, const int *h_shape3,
+                                           const int *h_ksize3, const int *h_dilation3, int *nbr_out,
+                                           const void *conv_workspace, size_t conv_workspace_bytes, int conv_n_in,
+                                           const int *h_conv_ksize3, const int *h_conv_stride3, const int *h_conv_dilation3,
+                                           int conv_out_per_in_hint, void *stream) {
+    if (n_in < 0 || batch <= 0 || !h_shape3 || !h_ksize3 || (n_in > 0 && !nbr_out) || !conv_workspace || !h_conv_ksize3 ||
+        !h_conv_stride3)
+        return SEC_E_INVALID;
+    RbGeom g, cg;
+    int rc = fill_geom(g, h_shape3, nullptr, h_ksize3, nullptr, nullptr, h_dilation3, n_in, batch);
+    if (rc) return rc;
+    for (int d = 0; d < 3; ++d)
+        if (g.ksize[d] % 2 == 0) return SEC_E_UNSUPPORTED;
+    const int ones[3] = {1, 1, 1};
+    if ((rc = fill_geom(cg, ones, ones, h_conv_ksize3, h_conv_stride3, nullptr, h_conv_dilation3, conv_n_in, 1))) return rc;
+    RbWorkspace w = carve_rb(const_cast<void *>(conv_workspace), conv_workspace_bytes, conv_n_in, cg.kvol,
+                             max_out_per_in(cg, conv_out_per_in_hint));
+    if (w.bytes > conv_workspace_bytes) return SEC_E_WORKSPACE;
+    if (n_in == 0) return SEC_OK;
+    g.mask = w.table - 1;
+    hipStream_t st = (hipStream_t)stream;
+    rb_init(nullptr, 0, 0, nbr_out, (long long)n_in * g.kvol, -1, nullptr, 0, 0, st);
+    long long nh = (long long)n_in * (g.kvol / 2 + 1);
+    // the strided build's table maps output cell -> slot and orank[slot] = output row: exactly this layer's site lookup
+    hipLaunchKernelGGL(k_subm_nbr_sym, dim3(div_up(nh, kBlock)), dim3(kBlock), 0, st, indices, g, n_in_dev, w.keys, w.orank, nbr_out);
+    return check_launch();
+}
+
 SEC_API int sec_rulebook_conv3d_build(const int *indices, int n_in, const int *n_in_dev, int batch, const int *h_in_shape3,
                                       const int *h_out_shape3, const int *h_ksize3, const int *h_stride3,
                                       const int *h_padding3, const int *h_dilation3, int *out_indices, int out_cap,
@@ -429,13 +473,12 @@ SEC_API int sec_rulebook_conv3d_build(const int *indices, int n_in, const int *n
     g.mask = w.table - 1;
     long long nc = (long long)n_in * g.ncand;
     if (nc == 0) return hip_ok(hipMemsetAsync(num_out, 0, 2 * sizeof(int), st));
-    rb_init(w.keys, w.table, kEmptyKey, w.vals, w.table, kEmptyI32, w.overflow, 1, 0, st);
+    rb_init(w.keys, w.table, kEmptyKey, w.vals, w.table, kEmptyI32, w.ticket, w.ctl_words, 0, st);
     int nb = div_up(nc, kBlock);
     hipLaunchKernelGGL(k_conv_cand, dim3(nb), dim3(kBlock), 0, st, indices, g, n_in_dev, w.keys, w.vals, w.cand_slot,
                        w.cand_k, w.overflow);
-    hipLaunchKernelGGL(k_conv_count, dim3(div_up(n_in, kBlock)), dim3(kBlock), 0, st, w.cand_slot, w.cand_k, w.vals, n_in,
-                       g.kvol, g.ncand, w.rank, w.first_mask);
-    if ((rc = exclusive_scan_i32(w.rank, w.rank, n_in, num_out, w.scan, st))) return rc;
+    hipLaunchKernelGGL(k_conv_count_scan, dim3(div_up(n_in, kBlock)), dim3(kBlock), 0, st, w.cand_slot, w.cand_k, w.vals, n_in,
+                       g.kvol, g.ncand, w.rank, w.first_mask, w.status, w.ticket, num_out);
     hipLaunchKernelGGL(k_conv_assign, dim3(nb), dim3(kBlock), 0, st, w.cand_slot, w.cand_k, w.vals, w.keys, w.rank, g,
                        w.orank, out_indices, out_cap, num_out, w.overflow, w.first_mask);
     return check_launch();

@@ -61,20 +61,30 @@ __global__ __launch_bounds__(kBlock) void k_vox_hash(const float *__restrict__ p
 
 __global__ __launch_bounds__(kBlock) void k_vox_init(unsigned long long *__restrict__ keys, int *__restrict__ vals, long long table,
                                                     int *__restrict__ count, long long rows, int *__restrict__ slot_idx,
-                                                    long long slots) {
+                                                    long long slots, int *__restrict__ ctl, long long ctl_words) {
     long long stride = (long long)gridDim.x * kBlock;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < ctl_words; i += stride) ctl[i] = 0;
     for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < table; i += stride) { keys[i] = kEmptyKey; vals[i] = kEmptyI32; }
     for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < rows; i += stride) count[i] = 0;
     for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < slots; i += stride) slot_idx[i] = kEmptyI32;
 }
 
-__global__ __launch_bounds__(kBlock) void k_vox_flag(const int *__restrict__ pslot,
-                                                    const int *__restrict__ vals, int n,
-                                                    int *__restrict__ flag) {
-    int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    int s = pslot[i];
-    flag[i] = (s >= 0 && vals[s] == i) ? 1 : 0;
+// rank[i] = number of voxel-creating points before point i (exclusive scan of the first-touch flags), in one launch
+// (single-pass scan of common.hpp); *total = number of voxels over all clouds
+__global__ __launch_bounds__(kBlock) void k_vox_flag_scan(const int *__restrict__ pslot, const int *__restrict__ vals, int n,
+                                                         int *__restrict__ rank, unsigned long long *__restrict__ status,
+                                                         int *__restrict__ ticket, int *__restrict__ total) {
+    __shared__ int smem[5];
+    __shared__ int s_tile;
+    const int tile = scan_take_tile(ticket, &s_tile);
+    const int i = tile * kBlock + threadIdx.x;
+    int f = 0;
+    if (i < n) {
+        int s = pslot[i];
+        f = (s >= 0 && vals[s] == i) ? 1 : 0;
+    }
+    const int ex = scan_lookback(f, tile, (int)gridDim.x, status, smem, total);
+    if (i < n) rank[i] = ex;
 }
 
 // one thread: per-cloud voxel counts (capped) -> voxel_offsets; rank base per cloud; reset break markers
@@ -198,7 +208,7 @@ __global__ __launch_bounds__(kBlock) void k_vox_mean(const float *__restrict__ v
 
 struct VoxWorkspace {
     unsigned long long *keys;
-    int *vals, *svid, *pslot, *rank, *scan, *base, *break_idx, *total, *count, *slot_idx;
+    int *vals, *svid, *pslot, *rank, *ctl, *base, *break_idx, *total, *count, *slot_idx;
     uint32_t table;
     size_t bytes;
 };
@@ -212,7 +222,7 @@ static VoxWorkspace carve_vox(void *ws, size_t cap, int n, int batch, int max_vo
     w.svid = a.take<int>(w.table);
     w.pslot = a.take<int>(n);
     w.rank = a.take<int>(n);
-    w.scan = a.take<int>(scan_scratch_ints(n));
+    w.ctl = a.take<int>(scan_ctl_words(n));   // ticket + tile status of the single-pass scan
     w.base = a.take<int>(batch + 1);
     w.break_idx = a.take<int>(batch);
     w.total = a.take<int>(1);
@@ -263,14 +273,14 @@ SEC_API int sec_voxelize_f32(const float *points, const int *point_offsets, int 
         int blocks = div_up((long long)w.table, kBlock);
         if (blocks > 256 * 8) blocks = 256 * 8;
         hipLaunchKernelGGL(k_vox_init, dim3(blocks), dim3(kBlock), 0, st, w.keys, w.vals, (long long)w.table, w.count, cap_rows,
-                           w.slot_idx, cap_rows * max_points);
+                           w.slot_idx, cap_rows * max_points, w.ctl, (long long)scan_ctl_words(num_points));
     }
     int nb = div_up(num_points > 0 ? num_points : 1, kBlock);
     if (num_points > 0) {
         hipLaunchKernelGGL(k_vox_hash, dim3(nb), dim3(kBlock), 0, st, points, point_offsets, p, w.keys, w.vals, w.pslot);
-        hipLaunchKernelGGL(k_vox_flag, dim3(nb), dim3(kBlock), 0, st, w.pslot, w.vals, num_points, w.rank);
-    }
-    if ((rc = exclusive_scan_i32(w.rank, w.rank, num_points, w.total, w.scan, st))) return rc;
+        hipLaunchKernelGGL(k_vox_flag_scan, dim3(nb), dim3(kBlock), 0, st, w.pslot, w.vals, num_points, w.rank,
+                           reinterpret_cast<unsigned long long *>(w.ctl + 4), w.ctl, w.total);
+    } else if ((rc = hip_ok(hipMemsetAsync(w.total, 0, sizeof(int), st)))) return rc;
     hipLaunchKernelGGL(k_vox_frames, dim3(1), dim3(64), 0, st, point_offsets, w.rank, w.total, p, w.base,
                        w.break_idx, voxel_offsets);
     if (num_points > 0) {

@@ -64,14 +64,25 @@ def _kvol(ksize):
     return int(np.prod([int(k) for k in ((ksize,) * 3 if isinstance(ksize, int) else ksize)]))
 
 
-def rulebook_subm(indices, batch_size, spatial_shape, ksize=3, dilation=1, want_pairs=False, n_dev=None):
+def rulebook_subm(indices, batch_size, spatial_shape, ksize=3, dilation=1, want_pairs=False, n_dev=None, site_table=None):
     """SubMConv3d rulebook (spconv.ops.get_indice_pairs(subm=True)).  indices [N,4] int32 (b,z,y,x).
-    ``n_dev`` (device int32[1]) switches to static-capacity mode: only the first n_dev rows are live."""
+    ``n_dev`` (device int32[1]) switches to static-capacity mode: only the first n_dev rows are live.
+    ``site_table``: the ``site_table`` entry of the :func:`rulebook_conv` result whose out_indices these are -- its
+    hash table is reused instead of re-hashing the sites."""
     rt.require_gpu(indices)
     assert indices.dtype == torch.int32 and indices.is_contiguous()
     n = indices.shape[0]
     k = _kvol(ksize)
     dev = indices.device
+    if site_table is not None and not want_pairs and n > 0:
+        ws, cn, cks, cst, cdl, chint = site_table
+        nbr = torch.empty((n, k), dtype=torch.int32, device=dev)
+        rc = rt.lib().sec_rulebook_subm3d_after_conv(rt.ptr(indices), n, rt.ptr(n_dev), int(batch_size), rt.i3(spatial_shape),
+                                                     rt.i3(ksize), rt.i3(dilation), rt.ptr(nbr), rt.ptr(ws), ws.numel(), int(cn),
+                                                     cks, cst, cdl, int(chint), rt.stream())
+        rt.check(rc, "sec_rulebook_subm3d_after_conv")
+        return {"nbr_out": nbr, "nbr_in": None, "pairs": None, "pair_num": None, "out_indices": indices,
+                "num_out": n, "num_out_dev": n_dev, "out_shape": [int(s) for s in spatial_shape]}
     nbr = torch.empty((n, k), dtype=torch.int32, device=dev)
     pairs = torch.empty((k, 2, n), dtype=torch.int32, device=dev) if want_pairs else None
     pair_num = torch.zeros((k,), dtype=torch.int32, device=dev) if want_pairs else None
@@ -113,7 +124,7 @@ def rulebook_conv(indices, batch_size, spatial_shape, ksize, stride, padding, di
     static = out_cap is not None
     cap = int(out_cap) if static else max(1, min(n * per_in, int(batch_size) * int(np.prod(out_shape))))
     out_idx = torch.empty((cap, 4), dtype=torch.int32, device=dev)
-    num_out = torch.zeros((2,), dtype=torch.int32, device=dev)
+    num_out = torch.empty((2,), dtype=torch.int32, device=dev)   # both words are written by the build
     l = rt.lib()
     ws = rt.workspace(l.sec_rulebook_workspace_bytes(n, k, hint or per_in), dev)
     rc = l.sec_rulebook_conv3d_build(rt.ptr(indices), n, rt.ptr(n_dev), int(batch_size), rt.i3(spatial_shape),
@@ -130,7 +141,7 @@ def rulebook_conv(indices, batch_size, spatial_shape, ksize, stride, padding, di
     rt.check(rc, "sec_rulebook_conv3d_tables")
     return {"nbr_out": nbr_out, "nbr_in": nbr_in, "pairs": pairs, "pair_num": pair_num,
             "out_indices": out_idx[:m], "num_out": m, "num_out_dev": num_out if static else None,
-            "out_shape": out_shape}
+            "out_shape": out_shape, "site_table": (ws, n, ks, st, dl, hint) if n > 0 else None}
 
 
 # ----------------------------------------------------------------------------- indice_conv

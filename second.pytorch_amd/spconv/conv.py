@@ -71,7 +71,12 @@ class SparseConvolution(SparseModule):
         indices = x.indices.contiguous()
         nd = x.num_active_dev
         if self.subm:
-            r = _ops.rulebook_subm(indices, x.batch_size, x.spatial_shape, self.kernel_size, self.dilation, n_dev=nd)
+            # sites produced by a strided conv: its output hash table is still around -> no re-hash (one use only)
+            tbl = x.__dict__.pop("site_table", None)
+            if tbl is not None and tbl[0] != (indices.data_ptr(), indices.shape[0]):
+                tbl = None
+            r = _ops.rulebook_subm(indices, x.batch_size, x.spatial_shape, self.kernel_size, self.dilation, n_dev=nd,
+                                   site_table=tbl[1] if tbl else None)
         elif nd is not None:  # static capacity: no host sync, overflow is reported through num_out_dev[1]
             cap = self.static_out_rows or int(indices.shape[0] * self.static_growth)
             hint = max(1, -(-cap // max(indices.shape[0], 1)))
@@ -83,6 +88,8 @@ class SparseConvolution(SparseModule):
                                    self.dilation, want_nbr_in=torch.is_grad_enabled())
         rb = Rulebook(r["out_indices"], indices, r["nbr_out"], r["nbr_in"], r["num_out"], x.spatial_shape,
                       r["out_shape"], self.subm, num_out_dev=r["num_out_dev"])
+        if r.get("site_table") is not None:
+            rb._site_table = ((r["out_indices"].data_ptr(), r["out_indices"].shape[0]), r["site_table"])
         if self.indice_key is not None:
             x.indice_dict[self.indice_key] = rb
         if nd is None:
@@ -104,6 +111,8 @@ class SparseConvolution(SparseModule):
         if rb.num_out_dev is not None and not rb.subm:
             out.overflow_checks = out.overflow_checks + [(rb.num_out_dev, rb.out_indices.shape[0])]
         out.indice_dict = x.indice_dict
+        if not rb.subm:
+            out.site_table = rb.__dict__.pop("_site_table", None)   # handed to the next SubM rulebook build, then dropped
         return out
 
     # -- forward ----------------------------------------------------------------------------------

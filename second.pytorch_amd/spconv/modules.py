@@ -79,6 +79,7 @@ class SparseSequential(SparseModule):
                     nxt = SparseConvTensor(None, rb.out_indices, rb.out_shape, x.batch_size, None, rb.num_out_dev)
                     nxt.indice_dict = cur.indice_dict
                     nxt.overflow_checks = cur.overflow_checks + [(rb.num_out_dev, rb.out_indices.shape[0])]
+                    nxt.site_table = rb.__dict__.pop("_site_table", None)
                     cur = nxt
             self._planned_overflow = cur.overflow_checks
         return plans

@@ -79,7 +79,7 @@ def voxel_block_filter(vox, grid_size_xy, block_factor, block_size, height_thres
     return res
 
 
-def rulebook_subm(indices, batch_size, spatial_shape, ksize=3, dilation=1, want_pairs=False, n_dev=None):
+def rulebook_subm(indices, batch_size, spatial_shape, ksize=3, dilation=1, want_pairs=False, n_dev=None, **kw):
     idx = _np(indices)
     _, pairs, num = orc.rulebook_subm(idx, batch_size, spatial_shape, ksize, dilation)
     nbr_out, _ = _tables(pairs, num, len(idx), len(idx))

@@ -141,6 +141,10 @@ def test_rulebook_conv_bit_exact(ops, ksize, stride, padding, dilation):
     lean = ops.rulebook_conv(dev(idx), 2, shape, ksize, stride, padding, dilation, want_nbr_in=False)   # inference form
     assert lean["nbr_in"] is None and torch.equal(lean["nbr_out"], rb["nbr_out"])
     assert torch.equal(lean["out_indices"], rb["out_indices"])
+    # SubM rulebook on the outputs, reusing the strided build's hash table == the stand-alone build
+    sub_reuse = ops.rulebook_subm(lean["out_indices"], 2, lean["out_shape"], 3, 1, site_table=lean["site_table"])
+    sub_plain = ops.rulebook_subm(lean["out_indices"].clone(), 2, lean["out_shape"], 3, 1)
+    assert torch.equal(sub_reuse["nbr_out"], sub_plain["nbr_out"])
     assert rb["out_shape"] == out_shape.tolist()
     assert rb["num_out"] == len(out_idx)
     np.testing.assert_array_equal(rb["out_indices"].cpu().numpy(), out_idx)
