@@ -244,7 +244,7 @@ def main():
         ach = b_alg / t_mean / 1e9
         roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-                "kernel": "k_conv_mfma_sk<bf16,64,64> (SubMConv3d subm2, batch 8)" if meta["mfma"] else "k_conv_generic",
+                "kernel": "k_conv_rows<bf16,64,64,27> (SubMConv3d subm2, batch 8)" if meta["mfma"] else "k_conv_generic",
                 "launch_us": round(t_mean * 1e6, 2), "launches_timed": 100, "alg_bytes_per_launch": b_alg,
                 "rows": meta["n_out"], "pairs": pairs, "frac_of_6.29TBs_measured_peak": round(ach / 6290.0, 4)}
 

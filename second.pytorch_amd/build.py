@@ -25,7 +25,8 @@ def build(force=False, verbose=True):
         if os.path.getmtime(OUT) >= newest:
             return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, *FLAGS, "-o", OUT, *SRC]
+    extra = os.environ.get("SEC_EXTRA_HIPCC_FLAGS", "").split()   # e.g. -DSEC_CONV_ABLATIONS for profiling builds
+    cmd = [hipcc, *FLAGS, *extra, "-o", OUT, *SRC]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

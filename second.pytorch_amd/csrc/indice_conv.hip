@@ -16,6 +16,7 @@
 // see DESIGN.md for the roofline arithmetic.
 #include "common.hpp"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace sec {
 
@@ -874,6 +875,182 @@ static void launch_wlds(const void *feat, const void *packed, const int *nbr, in
                        (const T *)packed, nbr, n_out, num_out_dev, scale, shift, relu | (conv_swizzle() << 16), (OT *)out);
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Row-split kernel with LDS-staged operands (SEC_CONV_VARIANT=9).
+// The split-K kernel above moves 5x more weight bytes than feature bytes through the vector L1 (every 32-row tile
+// re-fetches all kvol weight blocks: 380 MB of B against 76 MB of gathered A for the 64->64 SubM layer) and gathers
+// rows as 32-byte fragments of 32 different cache lines per instruction.  Here a workgroup owns 128 output rows
+// (one 32-row tile per wave), all waves walk the kernel offsets together so ONE copy of W[k] serves 128 rows
+// (LDS-DMA, ring of 3), and each wave gathers its neighbour rows with LDS-DMA in full 128-byte lines (8 lanes per
+// row, 8 rows per instruction) into a private ring of 3 -- operands are fetched two offsets ahead of their use.
+// Ordering is explicit (counted s_waitcnt vmcnt + one LDS barrier per offset); the step body takes __restrict__ LDS
+// pointers so the compiler does not put vmcnt(0) in front of every ds_read (see k_conv2d_halo_pipe in dense.hip).
+typedef __attribute__((address_space(3))) void *lds_ptr_c;
+typedef const __attribute__((address_space(1))) void *glb_ptr_c;
+template <int N> __device__ __forceinline__ void cwait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void clds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <typename T, int CIN, int COUT>
+struct RowsCfg {
+    static constexpr int KS = CIN / 16, NT = COUT / 32;
+    static constexpr int LPR = CIN / 8;            // 16-byte chunks (= DMA lanes) per feature row
+    static constexpr int RPI = 64 / LPR;           // rows per DMA instruction
+    static constexpr int ND = 32 / RPI;            // DMA instructions per 32-row tile
+    static constexpr int BPIECES = KS * NT;        // 1 KB pieces of one packed W[k]
+    static constexpr int NBW = BPIECES >= 4 ? BPIECES / 4 : 1;   // pieces copied by each wave
+    static constexpr int L = ND + NBW + 1;         // vector-memory ops per wave per offset (A DMAs, B DMAs, index load)
+    static constexpr int ASLOT = 32 * LPR, BSLOT = BPIECES * 64;   // uint4 entries
+    static constexpr int RING = 3;
+};
+
+// swizzle key of a row's 16-byte chunks: makes the 16 lanes of every ds_read_b128 group hit 16 distinct bank slots
+template <int LPR> __device__ __forceinline__ int row_key(int r) { return (r / (16 / LPR)) & (LPR - 1); }
+
+// ABL (profiling builds of the same kernel, -DSEC_CONV_ABLATIONS + SEC_CONV_VARIANT 91..96): 1 no gather DMA, 2 no weight
+// DMA, 4 no MFMA, 8 no per-offset barrier, 16 gathers all read row 0.
+// The LDS pointers are __restrict__: after inlining they carry alias scopes, without which the compiler puts
+// s_waitcnt vmcnt(0) in front of every ds_read that follows an LDS-DMA.
+template <typename T, int CIN, int COUT, int ABL>
+__device__ __forceinline__ void rows_compute(const uint4 *__restrict__ a_cur, const uint4 *__restrict__ b_cur, int idx_cur,
+                                             int lane, f32x16 (&acc)[COUT / 32]) {
+    using C = RowsCfg<T, CIN, COUT>;
+    const int r = lane & 31, h = lane >> 5;
+    const bool have = idx_cur >= 0;                 // lanes r and r + 32 hold the same row's index
+    const int key = row_key<C::LPR>(r);
+    // all fragments of the offset first (KS + KS*NT ds_read_b128 in flight together), then the MFMAs back to back
+    uint4 af[C::KS], bf[C::KS * C::NT];
+#pragma unroll
+    for (int s = 0; s < C::KS; ++s) af[s] = a_cur[r * C::LPR + ((s * 2 + h) ^ key)];
+#pragma unroll
+    for (int i = 0; i < C::KS * C::NT; ++i) bf[i] = b_cur[i * 64 + lane];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < C::KS; ++s) {
+        const uint4 a = have ? af[s] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < C::NT; ++t) {
+            if (ABL & 4) acc[t][0] += __uint_as_float(a.x ^ bf[s * C::NT + t].x);
+            else acc[t] = Mfma<T>::run(bf[s * C::NT + t], a, acc[t]);   // D^T
+        }
+    }
+}
+
+template <typename T, int CIN, int COUT, int KVOL, int ABL>
+__global__ __launch_bounds__(kBlock) void k_conv_rows(const T *__restrict__ feat, const T *__restrict__ packed,
+                                                     const int *__restrict__ nbr, int n_out,
+                                                     const int *__restrict__ num_out_dev,
+                                                     const float *__restrict__ scale, const float *__restrict__ shift,
+                                                     int relu, T *__restrict__ out) {
+    using C = RowsCfg<T, CIN, COUT>;
+    extern __shared__ __attribute__((aligned(16))) uint4 rows_smem[];
+    uint4 *bring = rows_smem;                                    // [RING][BSLOT]   shared by the four waves
+    if (num_out_dev) n_out = *num_out_dev;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint4 *aring = rows_smem + C::RING * C::BSLOT + w * C::RING * C::ASLOT;   // [RING][ASLOT] private to this wave
+    const int r = lane & 31, h = lane >> 5;
+    const long long base = (long long)blockIdx.x * 128 + w * 32;
+    if ((long long)blockIdx.x * 128 >= n_out) return;
+    const long long row = base + r;
+    const bool valid = row < n_out;
+    const uint4 *wp = reinterpret_cast<const uint4 *>(packed);
+    // the row's whole neighbour list, once, up front (the table is row-major: a per-offset load inside the loop is a
+    // 32-cache-line gather whose latency then sits on the critical path of every offset)
+    int idx[KVOL];
+    {
+        const int *nrow = nbr + (size_t)(valid ? row : 0) * KVOL;
+#pragma unroll
+        for (int k = 0; k < KVOL; ++k) idx[k] = valid ? nrow[k] : -1;
+    }
+    f32x16 acc[C::NT];
+#pragma unroll
+    for (int t = 0; t < C::NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+    auto issue = [&](int k) {        // operands of offset k -> ring slot k % RING (k is a compile-time constant after unrolling)
+        const int sl = k % C::RING;
+        if (!(ABL & 1)) {
+            int src_row[C::ND];
+#pragma unroll
+            for (int g = 0; g < C::ND; ++g) {
+                src_row[g] = __shfl(idx[k], g * C::RPI + lane / C::LPR, 64);
+                if (ABL & 16) src_row[g] = 0;
+            }
+#pragma unroll
+            for (int g = 0; g < C::ND; ++g) {
+                const int rr = g * C::RPI + lane / C::LPR, slot = lane % C::LPR;
+                // rows without a neighbour fetch row 0 (their fragment is zeroed when it is read): every lane stays active so
+                // the instruction count, and with it the s_waitcnt vmcnt(n) bookkeeping, is fixed.  (Masking those lanes off
+                // was measured 6 % slower: the exec save/restore around each DMA costs more than the 16-byte fetches.)
+                const uint4 *src = reinterpret_cast<const uint4 *>(feat + (size_t)(src_row[g] >= 0 ? src_row[g] : 0) * CIN) + (slot ^ row_key<C::LPR>(rr));
+                __builtin_amdgcn_global_load_lds((glb_ptr_c)src, (lds_ptr_c)&aring[sl * C::ASLOT + g * 64], 16, 0, 0);
+            }
+        }
+        if (!(ABL & 2)) {
+#pragma unroll
+            for (int j = 0; j < C::NBW; ++j) {
+                const int piece = (w * C::NBW + j) % C::BPIECES;
+                __builtin_amdgcn_global_load_lds((glb_ptr_c)(wp + (size_t)k * C::BSLOT + piece * 64 + lane),
+                                                 (lds_ptr_c)&bring[sl * C::BSLOT + piece * 64], 16, 0, 0);
+            }
+        }
+    };
+    constexpr int PEND = ((ABL & 1) ? 0 : C::ND) + ((ABL & 2) ? 0 : C::NBW);   // DMAs per wave per offset
+    issue(0);
+    if (KVOL > 1) issue(1);
+    // software pipeline, distance 2: iteration k computes offset k while k+1 is in flight and k+2 is being issued
+#pragma unroll
+    for (int k = 0; k < KVOL; ++k) {
+        // this wave's DMAs of offset k have landed once only those of offset k+1 are outstanding ...
+        if (k + 1 < KVOL) cwait_vmcnt<PEND>();
+        else cwait_vmcnt<0>();
+        if (!(ABL & 8)) clds_barrier();                      // ... and so have the other waves' pieces of W[k]
+        if (k + 2 < KVOL) issue(k + 2);                      // into the slot every wave finished reading before this barrier
+        __builtin_amdgcn_sched_barrier(0);                   // keep the prefetch ahead of the MFMAs it is meant to overlap
+        rows_compute<T, CIN, COUT, ABL>(aring + (k % C::RING) * C::ASLOT, bring + (k % C::RING) * C::BSLOT, idx[k], lane, acc);
+    }
+    // epilogue (D^T layout): lane owns row `r`, channels t*32 + 8g + 4h + (0..3); half-waves swap a group -> 16-byte stores
+    T *orow = out + (size_t)row * COUT;
+#pragma unroll
+    for (int t = 0; t < C::NT; ++t) {
+        uint2 pk[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c = t * 32 + 8 * g + 4 * h;
+            T v4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v4[j] = Cvt<T>::from(epilogue(acc[t][4 * g + j], scale, shift, c + j, relu));
+            __builtin_memcpy(&pk[g], v4, 8);
+        }
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            const uint2 keep = h ? pk[2 * pr + 1] : pk[2 * pr];
+            const uint2 send = h ? pk[2 * pr] : pk[2 * pr + 1];
+            uint2 recv;
+            recv.x = (unsigned)__shfl_xor((int)send.x, 32, 64);
+            recv.y = (unsigned)__shfl_xor((int)send.y, 32, 64);
+            const uint4 o = h ? make_uint4(recv.x, recv.y, keep.x, keep.y) : make_uint4(keep.x, keep.y, recv.x, recv.y);
+            if (valid) *reinterpret_cast<uint4 *>(orow + t * 32 + 8 * (2 * pr + h)) = o;
+        }
+    }
+}
+
+template <typename T, int CIN, int COUT, int ABL>
+static void launch_rows(const void *feat, const void *packed, const int *nbr, int n_out, const int *num_out_dev, int kvol,
+                        const float *scale, const float *shift, int relu, void *out, hipStream_t st) {
+    constexpr int KVOL = 27;   // dispatched for 3x3x3 layers only
+    using C = RowsCfg<T, CIN, COUT>;
+    constexpr size_t lds = (size_t)C::RING * (C::BSLOT + 4 * C::ASLOT) * 16;
+    static bool configured = false;
+    auto fn = k_conv_rows<T, CIN, COUT, KVOL, ABL>;
+    if (!configured) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        configured = true;
+    }
+    hipLaunchKernelGGL(fn, dim3(div_up(n_out, 128)), dim3(kBlock), lds, st, (const T *)feat, (const T *)packed, nbr, n_out,
+                       num_out_dev, scale, shift, relu, (T *)out);
+}
+
 static int conv_ablate() {
     static int v = -1;
     if (v < 0) { const char *e = getenv("SEC_CONV_ABLATE"); v = e ? atoi(e) : 0; }
@@ -893,6 +1070,27 @@ template <typename T, typename OT, int CIN, int COUT>
 static void launch_mfma(const void *feat, const void *packed, const int *nbr, int n_out, const int *num_out_dev,
                         int kvol, const float *scale, const float *shift, int relu, void *out, hipStream_t st) {
     constexpr int MT = 1;
+    if constexpr (std::is_same<T, OT>::value && (CIN == 64 || CIN == 32) && (COUT == 64 || COUT == 32)) {
+        // default for the large 64 -> 64 3x3x3 layers (subm2 of car.fhd: 33 us vs 36 us split-K); smaller row counts leave the
+        // row-split kernel's 27-offset chain exposed (subm3: 23.6 vs 16.8 us) and stay on split-K
+        if (((conv_variant() == 1 && CIN == 64 && COUT == 64 && n_out >= 32768) || conv_variant() == 9) && kvol == 27 && feat) {
+            launch_rows<T, CIN, COUT, 0>(feat, packed, nbr, n_out, num_out_dev, kvol, scale, shift, relu, out, st);
+            return;
+        }
+#ifdef SEC_CONV_ABLATIONS
+        if (conv_variant() >= 91 && conv_variant() <= 96 && kvol == 27 && feat && CIN == 64 && COUT == 64) {
+            switch (conv_variant()) {
+            case 91: launch_rows<T, CIN, COUT, 1>(feat, packed, nbr, n_out, num_out_dev, kvol, scale, shift, relu, out, st); break;
+            case 92: launch_rows<T, CIN, COUT, 2>(feat, packed, nbr, n_out, num_out_dev, kvol, scale, shift, relu, out, st); break;
+            case 93: launch_rows<T, CIN, COUT, 4>(feat, packed, nbr, n_out, num_out_dev, kvol, scale, shift, relu, out, st); break;
+            case 94: launch_rows<T, CIN, COUT, 8>(feat, packed, nbr, n_out, num_out_dev, kvol, scale, shift, relu, out, st); break;
+            case 95: launch_rows<T, CIN, COUT, 16>(feat, packed, nbr, n_out, num_out_dev, kvol, scale, shift, relu, out, st); break;
+            default: launch_rows<T, CIN, COUT, 3>(feat, packed, nbr, n_out, num_out_dev, kvol, scale, shift, relu, out, st); break;
+            }
+            return;
+        }
+#endif
+    }
     if (conv_variant() == 2 && kvol == 27) {
         hipLaunchKernelGGL((k_conv_mfma_lds<T, OT, CIN, COUT, 27>), dim3(div_up(n_out, 128)), dim3(kBlock), 0, st,
                            (const T *)feat, (const T *)packed, nbr, n_out, num_out_dev, scale, shift, relu, (OT *)out);
