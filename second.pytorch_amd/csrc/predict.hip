@@ -66,6 +66,18 @@ __global__ __launch_bounds__(kBlock) void k_predict_keys(const T *__restrict__ c
     keys[t] = anchor_key(cls, v, g, (int)(t / N), (int)(t % N), nullptr);
 }
 
+// 16-bit form for 16-bit logits (the low half of such a key is implied by its sign bit): half the bytes, and two
+// consecutive anchors' keys arrive in one dword load in k_predict_select_reg.  Frame stride `ns` is N rounded up to even.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_predict_keys16(const T *__restrict__ cls, View5 v, PredGeom g, int ns,
+                                                          unsigned short *__restrict__ keys) {
+    const int N = g.A * g.H * g.W;
+    long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= (long long)g.batch * ns) return;
+    const int b = (int)(t / ns), n = (int)(t % ns);
+    keys[t] = n < N ? (unsigned short)(anchor_key(cls, v, g, b, n, nullptr) >> 16) : (unsigned short)0;
+}
+
 // one workgroup per frame
 template <typename T, bool KEY16>
 __global__ __launch_bounds__(kSelThreads) void k_predict_select(const T *__restrict__ cls, View5 v, PredGeom g, int K,
@@ -217,6 +229,141 @@ __global__ __launch_bounds__(kSelThreads) void k_predict_select(const T *__restr
     }
 }
 
+
+// ---- register-resident select (frames of up to 1024 * KPT anchors: car.fhd has 70400) ----------------------------------
+// k_predict_select walks the frame's key array three times (two radix passes + compaction, 9 dependent load rounds each),
+// re-synchronises the workgroup once per 1024 keys to rank ties, and finishes with a 55-barrier bitonic sort.  Here every
+// thread loads its KPT keys ONCE (wave-contiguous segments, so "first by index" among equal keys is a prefix over waves),
+// the radix passes, tie ranking and compaction run out of registers, and the sort does its in-wave steps with shuffles
+// (10 LDS exchange steps instead of 55).  Same outputs as k_predict_select.
+template <typename T, int KP>     // 16-bit logits only (bf16); KP = key PAIRS (dwords) per thread
+__global__ __launch_bounds__(kSelThreads) void k_predict_select_reg(const T *__restrict__ cls, View5 v, PredGeom g, int K,
+                                                                    float score_thr, const unsigned short *__restrict__ keys,
+                                                                    int ns, int *__restrict__ top_idx,
+                                                                    float *__restrict__ top_score, int *__restrict__ top_label,
+                                                                    int *__restrict__ counts) {
+    __shared__ unsigned ckey[kSelThreads];
+    __shared__ int cidx[kSelThreads];
+    __shared__ int wsum[kSelThreads / 64];
+    __shared__ int wred[2][kSelThreads / 64];
+    __shared__ int s_cnt;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int N = g.A * g.H * g.W;
+    const unsigned *fk2 = reinterpret_cast<const unsigned *>(keys + (size_t)b * ns);   // ns is even: dword aligned
+    if (K > kSelThreads) K = kSelThreads;
+    if (K > N) K = N;
+    const int n_base = wv * (KP * 128) + lane * 2;    // pair i of this thread = anchors n_base + 128 i and + 1
+    unsigned k2[KP];                                  // low half: even anchor's key, high half: the odd one's
+#pragma unroll
+    for (int i = 0; i < KP; ++i) {
+        const int n = n_base + i * 128;
+        k2[i] = n < ns ? fk2[n >> 1] : 0u;
+    }
+    // K-th largest 16-bit key by bisection on its bits: 16 counting sweeps over the registers (no histogram, no atomics);
+    // out-of-range slots hold key 0 and are never counted because every probe is >= 1
+    auto count_ge = [&](unsigned t, int it) -> int {
+        int c = 0;
+#pragma unroll
+        for (int i = 0; i < KP; ++i) c += ((k2[i] & 0xffffu) >= t ? 1 : 0) + ((k2[i] >> 16) >= t ? 1 : 0);
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d, 64);
+        if (lane == 0) wred[it & 1][wv] = c;
+        __syncthreads();
+        int tot = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < kSelThreads / 64; ++w2) tot += wred[it & 1][w2];
+        return tot;
+    };
+    unsigned cand = 0;
+    int it = 0;
+    for (int bit = 15; bit >= 0; --bit, ++it) {
+        const unsigned t = cand | (1u << bit);
+        if (count_ge(t, it) >= K) cand = t;
+    }
+    const unsigned prefix = cand;
+    const unsigned need = cand == 0xffffu ? (unsigned)K : (unsigned)(K - count_ge(cand + 1, it));
+    const unsigned T_key = prefix;   // K-th largest (16-bit) key; take all keys > T and the first `need` (by index) equal to T
+    // ties: a wave's keys are a contiguous index range (pair i, lane, half = ascending anchor index), so its first tie
+    // ranks after all ties of the waves before it
+    int my_eq = 0;
+#pragma unroll
+    for (int i = 0; i < KP; ++i)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+            my_eq += __popcll(__ballot(n_base + i * 128 + hf < N && ((k2[i] >> (hf * 16)) & 0xffffu) == T_key));
+    if (tid == 0) s_cnt = 0;
+    if (lane == 0) wsum[wv] = my_eq;
+    ckey[tid] = 0u;
+    cidx[tid] = 0x7fffffff;
+    __syncthreads();
+    int erun = 0;
+    for (int w2 = 0; w2 < wv; ++w2) erun += wsum[w2];
+    const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int i = 0; i < KP; ++i) {
+        const int n = n_base + i * 128;
+        const unsigned ka = k2[i] & 0xffffu, kb = k2[i] >> 16;
+        const bool eqa = n < N && ka == T_key, eqb = n + 1 < N && kb == T_key;
+        const unsigned long long ma = __ballot(eqa), mb = __ballot(eqb);
+        const int before = erun + __popcll(ma & lt) + __popcll(mb & lt);
+        erun += __popcll(ma) + __popcll(mb);
+        const bool ta = (n < N && ka > T_key) || (eqa && before < (int)need);
+        const bool tb = (n + 1 < N && kb > T_key) || (eqb && before + (eqa ? 1 : 0) < (int)need);
+        // full key: f2key of a 16-bit float has low half 0 (non-negative input) or 0xffff (negative input)
+        if (ta) {
+            const int pos = atomicAdd(&s_cnt, 1);
+            if (pos < kSelThreads) { ckey[pos] = (ka << 16) | ((ka & 0x8000u) ? 0u : 0xffffu); cidx[pos] = n; }
+        }
+        if (tb) {
+            const int pos = atomicAdd(&s_cnt, 1);
+            if (pos < kSelThreads) { ckey[pos] = (kb << 16) | ((kb & 0x8000u) ? 0u : 0xffffu); cidx[pos] = n + 1; }
+        }
+    }
+    __syncthreads();
+    // ---- bitonic sort of (key desc, idx asc); strides < 64 stay inside the wave (shuffles), the rest go through LDS
+    unsigned mk = ckey[tid];
+    int mi = cidx[tid];
+    for (int size = 2; size <= kSelThreads; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            unsigned ok_;
+            int oi;
+            if (stride >= 64) {
+                __syncthreads();
+                ckey[tid] = mk; cidx[tid] = mi;
+                __syncthreads();
+                ok_ = ckey[tid ^ stride]; oi = cidx[tid ^ stride];
+            } else {
+                ok_ = (unsigned)__shfl_xor((int)mk, stride, 64);
+                oi = __shfl_xor(mi, stride, 64);
+            }
+            const bool lower = (tid & stride) == 0;                    // this thread holds the first slot of the pair
+            const bool mine_first = mk > ok_ || (mk == ok_ && mi < oi);   // my element precedes the partner's (descending)
+            const bool up = (tid & size) == 0;                         // this run is sorted descending-first
+            const bool keep_mine = (lower == up) ? mine_first : !mine_first;
+            if (!keep_mine) { mk = ok_; mi = oi; }
+        }
+    }
+    // ---- outputs
+    if (tid < K) {
+        float sc = sigmoidf_(key2f(mk));
+        int lab = 0;
+        if (g.nc > 1 && mi < N) anchor_key(cls, v, g, b, mi, &lab);
+        top_idx[(size_t)b * K + tid] = mi < N ? mi : 0;
+        top_score[(size_t)b * K + tid] = sc;
+        top_label[(size_t)b * K + tid] = lab;
+    }
+    const bool ok = tid < K && mi < N && sigmoidf_(key2f(mk)) >= score_thr;
+    const unsigned long long m = __ballot(ok);
+    __syncthreads();
+    if (lane == 0) wsum[wv] = __popcll(m);
+    __syncthreads();
+    if (tid == 0) {
+        int tot = 0;
+        for (int w2 = 0; w2 < kSelThreads / 64; ++w2) tot += wsum[w2];
+        counts[b] = tot;
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_predict_decode(const T *__restrict__ box, View5 vb, const T *__restrict__ dir,
                                                           View5 vd, int ndir, PredGeom g, int K,
@@ -321,9 +468,19 @@ SEC_API int sec_predict_select(const void *cls, const int64_t *h_cls_strides5, i
 #define SEC_SEL(T, K16)                                                                                                         \
     do {                                                                                                                        \
         hipLaunchKernelGGL(k_predict_keys<T>, dim3(div_up(total, kBlock)), dim3(kBlock), 0, st, (const T *)cls, v, g, key_scratch); \
-        hipLaunchKernelGGL((k_predict_select<T, K16>), dim3(batch), dim3(kSelThreads), 0, st, (const T *)cls, v, g, k, score_thr, \
-                           key_scratch, top_idx, top_score, top_label, counts);                                                  \
+            hipLaunchKernelGGL((k_predict_select<T, K16>), dim3(batch), dim3(kSelThreads), 0, st, (const T *)cls, v, g, k,        \
+                               score_thr, key_scratch, top_idx, top_score, top_label, counts);                                   \
     } while (0)
+    const long long nfr = (long long)anchors_per_loc * h * w;
+    if (dtype == SEC_BF16 && nfr <= (long long)kSelThreads * 72) {   // register-resident select on 16-bit keys
+        using T = __hip_bfloat16;
+        const int ns = (int)((nfr + 1) & ~1ll);
+        hipLaunchKernelGGL(k_predict_keys16<T>, dim3(div_up((long long)batch * ns, kBlock)), dim3(kBlock), 0, st, (const T *)cls, v, g, ns,
+                           reinterpret_cast<unsigned short *>(key_scratch));
+        hipLaunchKernelGGL((k_predict_select_reg<T, 36>), dim3(batch), dim3(kSelThreads), 0, st, (const T *)cls, v, g, k, score_thr,
+                           reinterpret_cast<const unsigned short *>(key_scratch), ns, top_idx, top_score, top_label, counts);
+        return check_launch();
+    }
     if (dtype == SEC_F32) SEC_SEL(float, false);
     else if (dtype == SEC_BF16) SEC_SEL(__hip_bfloat16, true);
     else if (dtype == SEC_F16) SEC_SEL(__half, false);
