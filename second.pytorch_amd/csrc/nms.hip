@@ -282,8 +282,8 @@ __device__ __forceinline__ unsigned long long wave_or64(unsigned long long v) {
 
 // Greedy reduce (host loop nms_postprocess, nms_gpu.py:109-126) on-device, one wave per batch item.
 // Lane w owns removal word w.  Per 64-box block: (1) the intra-block chain is resolved on scalar state
-// with the 64 diagonal words (one per lane, read with v_readlane), (2) the kept rows' words for the later
-// blocks are OR-reduced across the wave and merged into the owners' removal words.
+// with the 64 diagonal words (one per lane, read with v_readlane), (2) each kept row is read once (its words for
+// the later blocks, one per lane) and OR-ed into the owners' removal words.
 __global__ __launch_bounds__(64) void k_nms_reduce(const unsigned long long *__restrict__ mask,
                                                   const int *__restrict__ counts, int max_n, int words, int post_max,
                                                   int *__restrict__ keep, int *__restrict__ num_keep) {
@@ -315,14 +315,26 @@ __global__ __launch_bounds__(64) void k_nms_reduce(const unsigned long long *__r
         if (mine) kp[nk + __popcll(kept & ((1ull << lane) - 1ull))] = base + lane;
         nk += __popcll(kept);
         if (post_max > 0 && nk >= post_max) break;
-        for (int w = c + 1; w < nwords; ++w) {
-            unsigned long long v = mine ? mb[(size_t)(base + lane) * words + w] : 0ull;
-            v = wave_or64(v);
-            if (lane == w) remv |= v;
+        // lane w (> c) merges the kept rows' word w into its removal word: one coalesced 8-byte-per-lane row load per KEPT
+        // box (a handful per block), four in flight, instead of a wave-wide OR-reduction per later word
+        const bool owner = lane > c && lane < nwords;
+        unsigned long long todo = kept;
+        while (todo) {
+            int i4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                i4[u] = todo ? __builtin_amdgcn_readfirstlane(__builtin_ctzll(todo)) : -1;
+                if (todo) todo &= todo - 1ull;
+            }
+            unsigned long long v4[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v4[u] = (owner && i4[u] >= 0) ? mb[(size_t)(base + i4[u]) * words + lane] : 0ull;
+            remv |= (v4[0] | v4[1]) | (v4[2] | v4[3]);
         }
     }
     if (lane == 0) num_keep[b] = nk;
 }
+
 
 }  // namespace sec
 

@@ -54,6 +54,7 @@ __device__ __forceinline__ unsigned anchor_key(const T *cls, const View5 &v, con
 }
 
 constexpr int kSelThreads = 1024;
+constexpr int kCandCap = 2048;      // k_predict_select_reg: keys kept in LDS once that few remain above the bisection bound
 
 // pass 0 (whole chip): compact, coalesced key array (the RPN head is channels-last: one anchor's logit per 128-byte
 // pixel row, far too scattered to be re-read by the single workgroup that owns a frame in the select kernel)
@@ -247,11 +248,20 @@ __global__ __launch_bounds__(kSelThreads) void k_predict_select_reg(const T *__r
     __shared__ int wsum[kSelThreads / 64];
     __shared__ int wred[2][kSelThreads / 64];
     __shared__ int s_cnt;
+    __shared__ unsigned short cand_key[kCandCap];
+    __shared__ int cand_idx[kCandCap];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int N = g.A * g.H * g.W;
     const unsigned *fk2 = reinterpret_cast<const unsigned *>(keys + (size_t)b * ns);   // ns is even: dword aligned
     if (K > kSelThreads) K = kSelThreads;
     if (K > N) K = N;
+#ifdef SEC_SELECT_TIMING
+    long long tstamp[8]; int tsi = 0;
+#define SEC_TS() do { __syncthreads(); tstamp[tsi++] = clock64(); } while (0)
+#else
+#define SEC_TS() do {} while (0)
+#endif
+    SEC_TS();
     const int n_base = wv * (KP * 128) + lane * 2;    // pair i of this thread = anchors n_base + 128 i and + 1
     unsigned k2[KP];                                  // low half: even anchor's key, high half: the odd one's
 #pragma unroll
@@ -259,12 +269,13 @@ __global__ __launch_bounds__(kSelThreads) void k_predict_select_reg(const T *__r
         const int n = n_base + i * 128;
         k2[i] = n < ns ? fk2[n >> 1] : 0u;
     }
-    // K-th largest 16-bit key by bisection on its bits: 16 counting sweeps over the registers (no histogram, no atomics);
-    // out-of-range slots hold key 0 and are never counted because every probe is >= 1
-    auto count_ge = [&](unsigned t, int it) -> int {
-        int c = 0;
-#pragma unroll
-        for (int i = 0; i < KP; ++i) c += ((k2[i] & 0xffffu) >= t ? 1 : 0) + ((k2[i] >> 16) >= t ? 1 : 0);
+    SEC_TS();
+    // K-th largest 16-bit key by bisection on its bits, MSB first (no histogram, no atomics).  Counting sweeps run over
+    // all registers only while more than CAND_CAP keys lie at or above the current lower bound; then those few are
+    // compacted into LDS (two per thread) and the remaining bits are resolved on them.  Out-of-range slots hold key 0
+    // and are never counted because every probe is >= 1.
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    auto block_sum = [&](int c, int it) -> int {
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d, 64);
         if (lane == 0) wred[it & 1][wv] = c;
@@ -274,13 +285,76 @@ __global__ __launch_bounds__(kSelThreads) void k_predict_select_reg(const T *__r
         for (int w2 = 0; w2 < kSelThreads / 64; ++w2) tot += wred[it & 1][w2];
         return tot;
     };
+    auto count_ge = [&](unsigned t, int it) -> int {
+        // packed 16-bit arithmetic, three VALU ops per key pair: min(1, sat(k - (t - 1))) is 1 exactly when k >= t
+        const us2 tm1 = {(unsigned short)(t - 1), (unsigned short)(t - 1)}, one = {1, 1};
+        us2 acc2 = {0, 0};
+#pragma unroll
+        for (int i = 0; i < KP; ++i)
+            acc2 += __builtin_elementwise_min(__builtin_elementwise_sub_sat(__builtin_bit_cast(us2, k2[i]), tm1), one);
+        return block_sum((int)acc2.x + (int)acc2.y, it);
+    };
     unsigned cand = 0;
-    int it = 0;
-    for (int bit = 15; bit >= 0; --bit, ++it) {
+    int it = 0, bit = 15, above = N;                  // above = number of keys >= cand
+    for (; bit >= 0 && above > kCandCap; --bit, ++it) {
         const unsigned t = cand | (1u << bit);
-        if (count_ge(t, it) >= K) cand = t;
+        const int c = count_ge(t, it);
+        if (c >= K) { cand = t; above = c; }
+    }
+    bool sorted_ready = false;                        // the sort buffer already holds every key >= T (ties included)
+    ckey[tid] = 0u;
+    cidx[tid] = 0x7fffffff;
+    if (bit >= 0) {
+        if (tid == 0) s_cnt = 0;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < KP; ++i)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const unsigned kj = (k2[i] >> (hf * 16)) & 0xffffu;
+                const int n = n_base + i * 128 + hf;
+                if (n < N && kj >= cand) {
+                    const int pos = atomicAdd(&s_cnt, 1);
+                    if (pos < kCandCap) { cand_key[pos] = (unsigned short)kj; cand_idx[pos] = n; }
+                }
+            }
+        __syncthreads();
+        const int m = s_cnt < kCandCap ? s_cnt : kCandCap;
+        unsigned c2[kCandCap / kSelThreads];
+        int ci[kCandCap / kSelThreads];
+#pragma unroll
+        for (int u = 0; u < kCandCap / kSelThreads; ++u) {
+            const int p = tid + u * kSelThreads;
+            c2[u] = p < m ? (unsigned)cand_key[p] : 0u;
+            ci[u] = p < m ? cand_idx[p] : 0x7fffffff;
+        }
+        auto count_ge_c = [&](unsigned t, int it2) -> int {
+            int c = 0;
+#pragma unroll
+            for (int u = 0; u < kCandCap / kSelThreads; ++u) c += c2[u] >= t ? 1 : 0;
+            return block_sum(c, it2);
+        };
+        for (; bit >= 0; --bit, ++it) {
+            const unsigned t = cand | (1u << bit);
+            const int c = count_ge_c(t, it);
+            if (c >= K) { cand = t; above = c; }
+        }
+        if (above <= kSelThreads && cand > 0) {       // everything at or above T fits the sort buffer: the sort ranks the ties
+            if (tid == 0) s_cnt = 0;
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < kCandCap / kSelThreads; ++u)
+                if (c2[u] >= cand) {
+                    const int pos = atomicAdd(&s_cnt, 1);
+                    ckey[pos] = (c2[u] << 16) | ((c2[u] & 0x8000u) ? 0u : 0xffffu);
+                    cidx[pos] = ci[u];
+                }
+            sorted_ready = true;
+        }
     }
     const unsigned prefix = cand;
+    SEC_TS();
+    if (!sorted_ready) {
     const unsigned need = cand == 0xffffu ? (unsigned)K : (unsigned)(K - count_ge(cand + 1, it));
     const unsigned T_key = prefix;   // K-th largest (16-bit) key; take all keys > T and the first `need` (by index) equal to T
     // ties: a wave's keys are a contiguous index range (pair i, lane, half = ascending anchor index), so its first tie
@@ -293,8 +367,6 @@ __global__ __launch_bounds__(kSelThreads) void k_predict_select_reg(const T *__r
             my_eq += __popcll(__ballot(n_base + i * 128 + hf < N && ((k2[i] >> (hf * 16)) & 0xffffu) == T_key));
     if (tid == 0) s_cnt = 0;
     if (lane == 0) wsum[wv] = my_eq;
-    ckey[tid] = 0u;
-    cidx[tid] = 0x7fffffff;
     __syncthreads();
     int erun = 0;
     for (int w2 = 0; w2 < wv; ++w2) erun += wsum[w2];
@@ -319,7 +391,9 @@ __global__ __launch_bounds__(kSelThreads) void k_predict_select_reg(const T *__r
             if (pos < kSelThreads) { ckey[pos] = (kb << 16) | ((kb & 0x8000u) ? 0u : 0xffffu); cidx[pos] = n + 1; }
         }
     }
+    }   // !sorted_ready
     __syncthreads();
+    SEC_TS();
     // ---- bitonic sort of (key desc, idx asc); strides < 64 stay inside the wave (shuffles), the rest go through LDS
     unsigned mk = ckey[tid];
     int mi = cidx[tid];
@@ -343,6 +417,7 @@ __global__ __launch_bounds__(kSelThreads) void k_predict_select_reg(const T *__r
             if (!keep_mine) { mk = ok_; mi = oi; }
         }
     }
+    SEC_TS();
     // ---- outputs
     if (tid < K) {
         float sc = sigmoidf_(key2f(mk));
@@ -362,6 +437,13 @@ __global__ __launch_bounds__(kSelThreads) void k_predict_select_reg(const T *__r
         for (int w2 = 0; w2 < kSelThreads / 64; ++w2) tot += wsum[w2];
         counts[b] = tot;
     }
+#ifdef SEC_SELECT_TIMING
+    SEC_TS();
+    if (b == 0 && tid == 0)
+        printf("[select_reg] load %lld  bisect %lld  compact %lld  sort %lld  out %lld  (clock64 ticks)\n", tstamp[1] - tstamp[0],
+               tstamp[2] - tstamp[1], tstamp[3] - tstamp[2], tstamp[4] - tstamp[3], tstamp[5] - tstamp[4]);
+#endif
+#undef SEC_TS
 }
 
 template <typename T>
