@@ -242,8 +242,18 @@ def main():
         b_alg = s * (pairs * meta["cin"] + meta["n_out"] * meta["cout"]) + 8 * pairs + s * meta["kvol"] * meta["cin"] * meta["cout"]
         t_mean = t_kernel
         ach = b_alg / t_mean / 1e9
+        # HBM-side bytes per launch from the committed PMC passes of this kernel on this (seeded, deterministic)
+        # workload -- profiles/r01_k_traffic.json says how they were collected; null if the shapes do not match
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_k_traffic.json")) as f:
+                tj = json.load(f)
+            if tj["rows"] == meta["n_out"] and tj["pairs"] == pairs and meta["mfma"]:
+                traffic = tj["traffic_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "kernel": "k_conv_rows<bf16,64,64,27> (SubMConv3d subm2, batch 8)" if meta["mfma"] else "k_conv_generic",
                 "launch_us": round(t_mean * 1e6, 2), "launches_timed": 100, "alg_bytes_per_launch": b_alg,
                 "rows": meta["n_out"], "pairs": pairs, "frac_of_6.29TBs_measured_peak": round(ach / 6290.0, 4)}
