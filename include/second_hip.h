@@ -139,10 +139,14 @@ int sec_indice_conv_fwd(const void *features, int n_in, int cin, const void *wei
                         const int *num_out_dev, const float *scale, const float *shift, int relu,
                         void *out, int dtype, int out_dtype, void *stream);
 /* backward (spconv_ops.h indiceConvBackward): dfeat[j,:] = sum_k dout[nbr_in[j][k],:] @ W[k]^T ;
- * dW[k] = sum_o feat[nbr_out[o][k],:]^T dout[o,:].  fp32 gradients for weights, feature dtype for dfeat. */
+ * dW[k] = sum_o feat[nbr_out[o][k],:]^T dout[o,:].  fp32 gradients for weights, feature dtype for dfeat.
+ * For 16-bit dtypes dfeat runs on the MFMA forward kernels over re-packed transposed weights, which live in
+ * `workspace` (sec_indice_conv_bwd_workspace_bytes; NULL / too small selects the slower generic kernel). */
+size_t sec_indice_conv_bwd_workspace_bytes(int kvol, int cin, int cout, int dtype);
 int sec_indice_conv_bwd(const void *features, int n_in, int cin, const void *weight, int kvol, int cout,
                         const int *nbr_out, const int *nbr_in, int n_out, const void *dout,
-                        void *dfeat, float *dweight, int dtype, void *stream);
+                        void *dfeat, float *dweight, int dtype, void *workspace, size_t workspace_bytes,
+                        void *stream);
 
 /* SparseConvTensor.dense() (spconv/__init__.py; consumed at second/pytorch/models/middle.py:206-210).
  * Scatter rows into a zero-initialised dense tensor with arbitrary element strides so the same kernel

@@ -1152,6 +1152,11 @@ static bool dispatch_mfma(int cin, int cout, const void *feat, const void *packe
 }
 
 template <typename T, typename OT>
+static bool launch_tiled(const void *feat, const void *w, const int *nbr, int n_out, const int *num_out_dev, int cin, int cout,
+                         int kvol, int w_t, int mirror, const float *scale, const float *shift, int relu, void *out,
+                         hipStream_t st);
+
+template <typename T, typename OT>
 static void launch_generic(const void *feat, const void *w, const int *nbr, int n_out, const int *num_out_dev, int cin,
                            int cout, int kvol, const float *scale, const float *shift, int relu, void *out,
                            hipStream_t st) {
@@ -1160,6 +1165,7 @@ static void launch_generic(const void *feat, const void *w, const int *nbr, int 
                            (const T *)feat, (const T *)w, nbr, n_out, num_out_dev, kvol, scale, shift, relu, (OT *)out);
         return;
     }
+    if (launch_tiled<T, OT>(feat, w, nbr, n_out, num_out_dev, cin, cout, kvol, 0, 0, scale, shift, relu, out, st)) return;
     long long total = (long long)n_out * cout;
     int blocks = div_up(total, kBlock);
     if (blocks > 256 * 64) blocks = 256 * 64;
@@ -1167,7 +1173,102 @@ static void launch_generic(const void *feat, const void *w, const int *nbr, int 
                        n_out, num_out_dev, cin, cout, kvol, scale, shift, relu, (OT *)out);
 }
 
-// ------------------------------------------------------------------ backward (correctness-first VALU kernels)
+
+// ------------------------------------------------------------------ register-tiled VALU path (fp32 training / inference)
+// Output stationary like the MFMA kernels, for dtypes without a matrix-core path here (fp32) and as the dgrad of fp32
+// training: a workgroup owns ROWS output rows x all COUT channels, walks the offsets, stages the gathered input rows
+// (transposed: [ci][row], fp32) and W[k] ([ci][co]) in LDS, and every thread keeps a 4 row x 4 channel block in registers:
+// two 16-byte LDS reads per 16 FMAs, versus two global loads per FMA in k_conv_generic (27x faster on the subm2 layer).
+// The per-element accumulation order (offsets outer, input channels inner, fmaf) is that of k_conv_generic and of the
+// oracle, so fp32 results are unchanged.  w_t: read W[k] transposed (dgrad: Cin/Cout already swapped by the caller);
+// mirror: use offset K-1-k's weights (SubM dgrad through nbr_out).
+template <typename T, typename OT, int CIN, int COUT>
+__global__ __launch_bounds__(kBlock) void k_conv_tiled(const T *__restrict__ feat, const T *__restrict__ w,
+                                                      const int *__restrict__ nbr, int n_out,
+                                                      const int *__restrict__ num_out_dev, int kvol, int w_t, int mirror,
+                                                      const float *__restrict__ scale, const float *__restrict__ shift,
+                                                      int relu, OT *__restrict__ out) {
+    constexpr int CT = COUT / 4;                  // threads across the channels
+    constexpr int ROWS = (kBlock / CT) * 4;       // 64 rows for COUT = 64, 128 for 32, 256 for 16
+    __shared__ float sA[CIN][ROWS + 4];           // gathered inputs, transposed
+    __shared__ float sW[CIN][COUT + 4];
+    __shared__ int s_idx[ROWS];
+    if (num_out_dev) n_out = *num_out_dev;
+    const int tid = threadIdx.x;
+    const long long base = (long long)blockIdx.x * ROWS;
+    if (base >= n_out) return;
+    const int r0 = (tid / CT) * 4, c0 = (tid % CT) * 4;
+    float acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = 0.0f;
+    for (int k = 0; k < kvol; ++k) {
+        for (int r = tid; r < ROWS; r += kBlock) s_idx[r] = base + r < n_out ? nbr[(size_t)(base + r) * kvol + k] : -1;
+        __syncthreads();
+        {   // W[k] (or its transpose / mirror) -> sW[ci][co]
+            const T *wk = w + (size_t)(mirror ? kvol - 1 - k : k) * CIN * COUT;
+            for (int e = tid; e < CIN * COUT; e += kBlock) {
+                const int ci = e / COUT, co = e - ci * COUT;
+                sW[ci][co] = Cvt<T>::to(w_t ? wk[(size_t)co * CIN + ci] : wk[e]);   // w_t: stored [co][ci] per offset
+            }
+        }
+        // gathered rows -> sA[ci][row]; rows without a neighbour contribute exact zeros
+        for (int e = tid; e < ROWS * (CIN / 4); e += kBlock) {
+            const int r = e / (CIN / 4), c4 = (e - r * (CIN / 4)) * 4;
+            const int idx = s_idx[r];
+            float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (idx >= 0) {
+                const T *src = feat + (size_t)idx * CIN + c4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = Cvt<T>::to(src[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sA[c4 + j][r] = v[j];
+        }
+        __syncthreads();
+        const bool any = s_idx[r0] >= 0 || s_idx[r0 + 1] >= 0 || s_idx[r0 + 2] >= 0 || s_idx[r0 + 3] >= 0;
+        if (any) {
+#pragma unroll 8
+            for (int ci = 0; ci < CIN; ++ci) {
+                const float4 a4 = *reinterpret_cast<const float4 *>(&sA[ci][r0]);
+                const float4 w4 = *reinterpret_cast<const float4 *>(&sW[ci][c0]);
+                const float aa[4] = {a4.x, a4.y, a4.z, a4.w}, ww[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) acc[a][b] = fmaf(aa[a], ww[b], acc[a][b]);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const long long row = base + r0 + a;
+        if (row < n_out)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                out[(size_t)row * COUT + c0 + b] = Cvt<OT>::from(epilogue(acc[a][b], scale, shift, c0 + b, relu));
+    }
+}
+
+template <typename T, typename OT>
+static bool launch_tiled(const void *feat, const void *w, const int *nbr, int n_out, const int *num_out_dev, int cin, int cout,
+                         int kvol, int w_t, int mirror, const float *scale, const float *shift, int relu, void *out,
+                         hipStream_t st) {
+#define SEC_TL(CI, CO)                                                                                                   \
+    if (cin == CI && cout == CO) {                                                                                       \
+        constexpr int ROWS = (kBlock / (CO / 4)) * 4;                                                                    \
+        hipLaunchKernelGGL((k_conv_tiled<T, OT, CI, CO>), dim3(div_up(n_out, ROWS)), dim3(kBlock), 0, st, (const T *)feat,   \
+                           (const T *)w, nbr, n_out, num_out_dev, kvol, w_t, mirror, scale, shift, relu, (OT *)out);      \
+        return true;                                                                                                     \
+    }
+    SEC_TL(16, 16) SEC_TL(16, 32) SEC_TL(32, 16) SEC_TL(32, 32) SEC_TL(32, 64) SEC_TL(64, 32) SEC_TL(64, 64)
+#undef SEC_TL
+    return false;
+}
+
+// ------------------------------------------------------------------ backward: generic fallbacks
 // dfeat[j][ci] = sum_k sum_co dout[tbl[j][col(k)]][co] * W[k][ci][co]
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_conv_dgrad(const T *__restrict__ dout, const T *__restrict__ w,
@@ -1207,6 +1308,132 @@ __global__ __launch_bounds__(kBlock) void k_conv_wgrad(const T *__restrict__ fea
         }
         if (acc != 0.0f) atomicAdd(&dw[((size_t)k * cin + ci) * cout + co], acc);
     }
+}
+
+
+// ---- backward ----------------------------------------------------------------------------------------------------------
+// dgrad is the forward operator with the roles swapped: dfeat[j,:] = sum_k dout[tbl[j][k], :] @ W[k]^T with tbl = nbr_in
+// (strided conv) or, for SubM, nbr_out itself read through mirrored offsets (nbr_in[j][k] == nbr_out[j][K-1-k]).  So for
+// 16-bit dtypes the weights are re-packed transposed (and offset-mirrored for SubM) into the caller's workspace and the
+// MFMA forward kernels run unchanged with Cin <-> Cout swapped.
+// packed element ((((k*KS + s)*NT + t)*64 + lane)*8 + e) = Wt[k][s*16 + (lane>>5)*8 + e][t*32 + (lane&31)],
+// Wt[k][co][ci] = W[mirror ? K-1-k : k][ci][co]      (KS = Cout/16, NT = ceil(Cin/32))
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_pack_weight_t(const T *__restrict__ w, int kvol, int cin, int cout, int mirror,
+                                                         T *__restrict__ packed) {
+    int ks = cout / 16, nt = (cin + 31) / 32;
+    long long total = (long long)kvol * ks * nt * 64 * 8;
+    long long g = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (g >= total) return;
+    int e = (int)(g & 7), lane = (int)((g >> 3) & 63);
+    long long q = g >> 9;
+    int t = (int)(q % nt);
+    q /= nt;
+    int sidx = (int)(q % ks);
+    int k = (int)(q / ks);
+    int co = sidx * 16 + (lane >> 5) * 8 + e, ci = t * 32 + (lane & 31);
+    int km = mirror ? kvol - 1 - k : k;
+    packed[g] = ci < cin ? w[((size_t)km * cin + ci) * cout + co] : Cvt<T>::from(0.0f);
+}
+
+// wgrad: dW[k][ci][co] = sum over the pairs (i, o) of offset k of feat[i][ci] * dout[o][co].
+// One workgroup = one offset x one chunk of output rows.  The chunk's pairs are compacted 32 at a time into LDS (fp32,
+// gathered feature row next to its dout row); every thread keeps a 4 x 4 (ci x co) block of the Cin x Cout result in
+// registers and consumes the staged rows with two 16-byte LDS reads per 16 FMAs; chunks combine with fp32 atomics.
+template <typename T, int CIN, int COUT>
+__global__ __launch_bounds__(kBlock) void k_conv_wgrad_tiled(const T *__restrict__ feat, const T *__restrict__ dout,
+                                                            const int *__restrict__ nbr, int n_out, int kvol,
+                                                            int rows_per_chunk, float *__restrict__ dw) {
+    constexpr int SUB = 32;                                   // pairs staged per step
+    constexpr int TILES = (CIN / 4) * (COUT / 4);             // 4x4 register blocks
+    constexpr int TPT = (TILES + kBlock - 1) / kBlock;        // blocks per thread (1 for 64x64)
+    __shared__ float sF[SUB][CIN + 4], sD[SUB][COUT + 4];
+    __shared__ int s_src[SUB], s_dst[SUB], s_n;
+    const int k = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const int o0 = blockIdx.x * rows_per_chunk;
+    const int o1 = o0 + rows_per_chunk < n_out ? o0 + rows_per_chunk : n_out;
+    float acc[TPT][4][4];
+#pragma unroll
+    for (int u = 0; u < TPT; ++u)
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[u][a][b] = 0.0f;
+    for (int ob = o0; ob < o1; ob += SUB) {
+        if (tid < 64) {                                       // wave 0 compacts the valid pairs of these SUB rows
+            const int o = ob + lane;
+            const int idx = (lane < SUB && o < o1) ? nbr[(size_t)o * kvol + k] : -1;
+            const unsigned long long m = __ballot(idx >= 0);
+            if (idx >= 0) {
+                const int pos = __popcll(m & ((1ull << lane) - 1ull));
+                s_src[pos] = idx;
+                s_dst[pos] = o;
+            }
+            if (lane == 0) s_n = __popcll(m);
+        }
+        __syncthreads();
+        const int np = s_n;
+        for (int e = tid; e < np * (CIN / 4); e += kBlock) {      // 4 channels per thread per step
+            const int p = e / (CIN / 4), c4 = (e - p * (CIN / 4)) * 4;
+            const T *src = feat + (size_t)s_src[p] * CIN + c4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sF[p][c4 + j] = Cvt<T>::to(src[j]);
+        }
+        for (int e = tid; e < np * (COUT / 4); e += kBlock) {
+            const int p = e / (COUT / 4), c4 = (e - p * (COUT / 4)) * 4;
+            const T *src = dout + (size_t)s_dst[p] * COUT + c4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sD[p][c4 + j] = Cvt<T>::to(src[j]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < TPT; ++u) {
+            const int tile = tid + u * kBlock;
+            if (tile < TILES) {
+                const int ci0 = (tile / (COUT / 4)) * 4, co0 = (tile % (COUT / 4)) * 4;
+                for (int p = 0; p < np; ++p) {
+                    const float4 f = *reinterpret_cast<const float4 *>(&sF[p][ci0]);
+                    const float4 d = *reinterpret_cast<const float4 *>(&sD[p][co0]);
+                    const float fa[4] = {f.x, f.y, f.z, f.w}, da[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) acc[u][a][b] = fmaf(fa[a], da[b], acc[u][a][b]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int u = 0; u < TPT; ++u) {
+        const int tile = tid + u * kBlock;
+        if (tile < TILES) {
+            const int ci0 = (tile / (COUT / 4)) * 4, co0 = (tile % (COUT / 4)) * 4;
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    if (acc[u][a][b] != 0.0f) atomicAdd(&dw[((size_t)k * CIN + ci0 + a) * COUT + co0 + b], acc[u][a][b]);
+        }
+    }
+}
+
+template <typename T>
+static bool launch_wgrad_tiled(const void *feat, const void *dout, const int *nbr, int n_out, int cin, int cout, int kvol,
+                               float *dw, hipStream_t st) {
+    // large chunks keep the fp32 atomics few; at least ~2 workgroups per CU overall
+    int chunk = 8192;
+    while (chunk > 512 && (long long)div_up(n_out, chunk) * kvol < 512) chunk >>= 1;
+    dim3 grid(div_up(n_out, chunk), kvol);
+#define SEC_WG(CI, CO)                                                                                                    \
+    if (cin == CI && cout == CO) {                                                                                        \
+        hipLaunchKernelGGL((k_conv_wgrad_tiled<T, CI, CO>), grid, dim3(kBlock), 0, st, (const T *)feat, (const T *)dout, nbr,  \
+                           n_out, kvol, chunk, dw);                                                                       \
+        return true;                                                                                                      \
+    }
+    SEC_WG(4, 16) SEC_WG(16, 16) SEC_WG(16, 32) SEC_WG(32, 32) SEC_WG(32, 64) SEC_WG(64, 64) SEC_WG(64, 128) SEC_WG(128, 128)
+#undef SEC_WG
+    return false;
 }
 
 static size_t elt_size(int dtype) { return dtype == SEC_F32 ? 4 : 2; }
@@ -1271,19 +1498,36 @@ SEC_API int sec_indice_conv_fwd(const void *features, int n_in, int cin, const v
 
 template <typename T>
 static int run_bwd(const void *features, int n_in, int cin, const void *weight, int kvol, int cout, const int *nbr_out,
-                   const int *nbr_in, int n_out, const void *dout, void *dfeat, float *dweight, hipStream_t st) {
+                   const int *nbr_in, int n_out, const void *dout, void *dfeat, float *dweight, void *workspace,
+                   size_t workspace_bytes, int dtype, hipStream_t st) {
     int rc;
     if (dfeat && n_in > 0) {
-        long long total = (long long)n_in * cin;
-        int blocks = div_up(total, kBlock);
-        if (blocks > 256 * 64) blocks = 256 * 64;
         const int *tbl = nbr_in ? nbr_in : nbr_out;  // SubM: nbr_in is the mirror image of nbr_out
-        hipLaunchKernelGGL(k_conv_dgrad<T>, dim3(blocks), dim3(kBlock), 0, st, (const T *)dout, (const T *)weight, tbl,
-                           nbr_in ? 0 : 1, n_in, cin, cout, kvol, (T *)dfeat);
+        bool done = false;
+        if constexpr (!std::is_same<T, float>::value) {
+            // MFMA path: forward kernels on (dout, Wt) with Cin <-> Cout swapped
+            const size_t need = sec_packed_weight_bytes(kvol, cout, cin, dtype);
+            if (need > 0 && workspace && workspace_bytes >= need && n_out > 0) {
+                long long total = (long long)kvol * cout * ((cin + 31) / 32) * 32;
+                hipLaunchKernelGGL(k_pack_weight_t<T>, dim3(div_up(total, kBlock)), dim3(kBlock), 0, st, (const T *)weight, kvol, cin,
+                                   cout, nbr_in ? 0 : 1, (T *)workspace);
+                done = dispatch_mfma<T, T>(cout, cin, dout, workspace, tbl, n_in, nullptr, kvol, nullptr, nullptr, 0, dfeat, st);
+            }
+        }
+        if (!done)   // register-tiled VALU forward on (dout, W^T): Cin <-> Cout swapped, weights read transposed in place
+            done = launch_tiled<T, T>(dout, weight, tbl, n_in, nullptr, cout, cin, kvol, 1, nbr_in ? 0 : 1, nullptr, nullptr, 0,
+                                      dfeat, st);
+        if (!done) {
+            long long total = (long long)n_in * cin;
+            int blocks = div_up(total, kBlock);
+            if (blocks > 256 * 64) blocks = 256 * 64;
+            hipLaunchKernelGGL(k_conv_dgrad<T>, dim3(blocks), dim3(kBlock), 0, st, (const T *)dout, (const T *)weight, tbl,
+                               nbr_in ? 0 : 1, n_in, cin, cout, kvol, (T *)dfeat);
+        }
     }
     if (dweight) {
         if ((rc = hip_ok(hipMemsetAsync(dweight, 0, (size_t)kvol * cin * cout * sizeof(float), st)))) return rc;
-        if (n_out > 0) {
+        if (n_out > 0 && !launch_wgrad_tiled<T>(features, dout, nbr_out, n_out, cin, cout, kvol, dweight, st)) {
             int rows_per_chunk = 512;
             hipLaunchKernelGGL(k_conv_wgrad<T>, dim3(div_up(n_out, rows_per_chunk), kvol), dim3(kBlock), 0, st,
                                (const T *)features, (const T *)dout, nbr_out, n_out, cin, cout, kvol, rows_per_chunk, dweight);
@@ -1292,14 +1536,18 @@ static int run_bwd(const void *features, int n_in, int cin, const void *weight, 
     return check_launch();
 }
 
+SEC_API size_t sec_indice_conv_bwd_workspace_bytes(int kvol, int cin, int cout, int dtype) {
+    return sec_packed_weight_bytes(kvol, cout, cin, dtype);   // the transposed packed weights of the MFMA dgrad (0 for fp32)
+}
+
 SEC_API int sec_indice_conv_bwd(const void *features, int n_in, int cin, const void *weight, int kvol, int cout,
                                 const int *nbr_out, const int *nbr_in, int n_out, const void *dout, void *dfeat,
-                                float *dweight, int dtype, void *stream) {
+                                float *dweight, int dtype, void *workspace, size_t workspace_bytes, void *stream) {
     if (n_in < 0 || n_out < 0 || cin <= 0 || cout <= 0 || kvol <= 0 || !weight || !nbr_out || !dout) return SEC_E_INVALID;
     if (!nbr_in && n_in != n_out) return SEC_E_INVALID;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == SEC_F32) return run_bwd<float>(features, n_in, cin, weight, kvol, cout, nbr_out, nbr_in, n_out, dout, dfeat, dweight, st);
-    if (dtype == SEC_F16) return run_bwd<__half>(features, n_in, cin, weight, kvol, cout, nbr_out, nbr_in, n_out, dout, dfeat, dweight, st);
-    if (dtype == SEC_BF16) return run_bwd<__hip_bfloat16>(features, n_in, cin, weight, kvol, cout, nbr_out, nbr_in, n_out, dout, dfeat, dweight, st);
+    if (dtype == SEC_F32) return run_bwd<float>(features, n_in, cin, weight, kvol, cout, nbr_out, nbr_in, n_out, dout, dfeat, dweight, workspace, workspace_bytes, dtype, st);
+    if (dtype == SEC_F16) return run_bwd<__half>(features, n_in, cin, weight, kvol, cout, nbr_out, nbr_in, n_out, dout, dfeat, dweight, workspace, workspace_bytes, dtype, st);
+    if (dtype == SEC_BF16) return run_bwd<__hip_bfloat16>(features, n_in, cin, weight, kvol, cout, nbr_out, nbr_in, n_out, dout, dfeat, dweight, workspace, workspace_bytes, dtype, st);
     return SEC_E_UNSUPPORTED;
 }

@@ -213,9 +213,11 @@ def indice_conv_backward(features, weight, nbr_out, nbr_in, dout, need_dfeat=Tru
     dout = dout.contiguous()
     dfeat = torch.empty_like(features) if need_dfeat else None
     dw = torch.empty(weight.shape, dtype=torch.float32, device=weight.device) if need_dweight else None
-    rc = rt.lib().sec_indice_conv_bwd(rt.ptr(features), features.shape[0], cin, rt.ptr(weight), k, cout, rt.ptr(nbr_out),
-                                      rt.ptr(nbr_in), dout.shape[0], rt.ptr(dout), rt.ptr(dfeat), rt.ptr(dw),
-                                      rt.dtype_code(features.dtype), rt.stream())
+    l = rt.lib()
+    ws = rt.workspace(l.sec_indice_conv_bwd_workspace_bytes(k, cin, cout, rt.dtype_code(features.dtype)), features.device)
+    rc = l.sec_indice_conv_bwd(rt.ptr(features), features.shape[0], cin, rt.ptr(weight), k, cout, rt.ptr(nbr_out),
+                               rt.ptr(nbr_in), dout.shape[0], rt.ptr(dout), rt.ptr(dfeat), rt.ptr(dw),
+                               rt.dtype_code(features.dtype), rt.ptr(ws), ws.numel(), rt.stream())
     rt.check(rc, "sec_indice_conv_bwd")
     return dfeat, (dw.to(weight.dtype) if dw is not None else None)
 

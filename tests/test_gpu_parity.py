@@ -277,6 +277,28 @@ def test_indice_conv_backward(ops, subm):
     np.testing.assert_allclose(dw.cpu().numpy(), dw_ref, rtol=1e-4, atol=1e-4 * np.abs(dw_ref).max())
 
 
+@pytest.mark.parametrize("cin,cout", [(16, 16), (16, 32), (32, 64), (64, 64), (4, 16)])
+@pytest.mark.parametrize("subm", [True, False])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+def test_indice_conv_backward_shapes_and_dtypes(ops, cin, cout, subm, dtype):
+    """dgrad on the MFMA forward kernels (16-bit dtypes: transposed, offset-mirrored packed weights) and the
+    register-tiled wgrad, vs the fp32 oracle on the same (rounded) operands."""
+    if subm and cin != cout:
+        pytest.skip("SubM backward needs the mirrored table: same sites in and out, any channel counts are fine "
+                    "but keep the matrix of cases small")
+    rng = np.random.default_rng(cin * 100 + cout)
+    feat, w, pairs, pair_num, nbr_out, nbr_in, n_out = _conv_case(rng, cin, cout, subm)
+    dout = rng.standard_normal((n_out, cout)).astype(np.float32)
+    rnd = lambda a: torch.from_numpy(a).to(dtype).float().numpy()
+    feat, w, dout = rnd(feat), rnd(w), rnd(dout)
+    dfeat_ref, dw_ref = orc.indice_conv_backward(feat, w, pairs, pair_num, dout)
+    dfeat, dw = ops.indice_conv_backward(dev(feat).to(dtype), dev(w).to(dtype), dev(nbr_out), None if subm else dev(nbr_in),
+                                         dev(dout).to(dtype))
+    tol = {torch.float32: 1e-4, torch.float16: 2 ** -9, torch.bfloat16: 2 ** -7}[dtype]
+    np.testing.assert_allclose(dfeat.float().cpu().numpy(), dfeat_ref, rtol=tol, atol=tol * np.abs(dfeat_ref).max())
+    np.testing.assert_allclose(dw.float().cpu().numpy(), dw_ref, rtol=tol, atol=tol * np.abs(dw_ref).max())
+
+
 def test_indice_conv_car_fhd_layer(ops, syn):
     """Full-size subm2-like layer (64->64) on a synthetic frame: bf16 MFMA vs oracle."""
     c = syn.syn_kitti_cloud(0)

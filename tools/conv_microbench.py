@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--sorted", action="store_true", help="spatially sorted clouds (rows in (z,y,x) order per frame)")
     ap.add_argument("--timeline", action="store_true", help="per-wave clock64 timeline of the split-K kernel")
+    ap.add_argument("--backward", action="store_true", help="also time sec_indice_conv_bwd (dgrad + wgrad), bf16 and fp32")
     args = ap.parse_args()
     dev = torch.device("cuda")
     clouds = [syn.syn_kitti_cloud(s) for s in range(args.batch)]
@@ -57,6 +58,19 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / args.iters
+    if args.backward:
+        for dt in (torch.bfloat16, torch.float32):
+            f, ww, do = feat.to(dt), w.to(dt), torch.randn(n, c, device=dev).to(dt)
+            for need in ((True, False), (False, True)):
+                for _ in range(3):
+                    ops.indice_conv_backward(f, ww, rb["nbr_out"], None, do, *need)
+                torch.cuda.synchronize()
+                e0.record()
+                for _ in range(10):
+                    ops.indice_conv_backward(f, ww, rb["nbr_out"], None, do, *need)
+                e1.record()
+                torch.cuda.synchronize()
+                print(f"backward {'dgrad' if need[0] else 'wgrad'} {dt}: {e0.elapsed_time(e1) * 100:.1f} us")
     if args.timeline:
         import ctypes
         from second_amd import runtime as rt
