@@ -64,8 +64,32 @@ def time_kernel(call, reps=100):
     return e0.elapsed_time(e1) * 1e-3 / reps
 
 
+# Other BASELINE configs (parity-test cases; timed only on request with --workload, never the default line):
+#   nusc.pp  = nuscenes/all.pp.largea (PointPillars), nusc.fhd = nuscenes/all.fhd (block-filtered voxels, 10 classes)
+WORKLOADS = {
+    "car.fhd": dict(cfg="CAR_FHD", batch=8, metric="frames/sec VoxelNet fwd (car.fhd, ~16k active voxels)",
+                    desc="car.fhd.config VoxelNet forward (voxelise+VFE+SpMiddleFHD+RPNV2+rotated NMS), inference, "
+                         "batch=8 synthetic KITTI clouds/GPU (17000 pts, 16000 voxels each), random-init weights, "
+                         "inputs resident in HBM"),
+    "nusc.pp": dict(cfg="ALL_PP_LARGEA", batch=4, metric="frames/sec VoxelNet fwd (nuscenes/all.pp.largea)",
+                    desc="nuscenes/all.pp.largea VoxelNet forward (voxelise+PillarFeatureNet+scatter+RPNV2 3 blocks+"
+                         "axis-aligned NMS), inference, batch=4 synthetic 10-sweep NuScenes clouds/GPU (<= 120k pts), "
+                         "random-init weights, inputs resident in HBM"),
+    "nusc.fhd": dict(cfg="ALL_FHD_NUSC", batch=4, metric="frames/sec VoxelNet fwd (nuscenes/all.fhd)",
+                     desc="nuscenes/all.fhd VoxelNet forward (block-filtered voxelise+SpMiddleFHD on 1984x1984x40+RPNV2+"
+                          "axis-aligned NMS), inference, batch=4 synthetic 10-sweep NuScenes clouds/GPU (<= 120k pts), "
+                          "random-init weights, inputs resident in HBM"),
+}
+WL = WORKLOADS["car.fhd"]
+
+
 def build_inputs(rank, device, order="shuffle"):
     from second_amd import synthetic as syn
+    if WL["cfg"] != "CAR_FHD":
+        rng = (-50, -50, -5, 50, 50, 3) if WL["cfg"] == "ALL_PP_LARGEA" else (-49.6, -49.6, -5, 49.6, 49.6, 3)
+        clouds = [syn.syn_nusc_cloud(rank * BATCH + s, num_points=120000, point_cloud_range=rng) for s in range(WL["batch"])]
+        pts, offs = syn.batch_clouds(clouds)
+        return clouds, torch.from_numpy(pts).to(device), torch.from_numpy(offs).to(device)
     clouds = [syn.syn_kitti_cloud(rank * BATCH + s) for s in range(BATCH)]
     if order == "sorted":   # experiment: points in spatial (z, y, x) order instead of the shuffled order of SURVEY 8d
         clouds = [c[np.lexsort((c[:, 0], c[:, 1], c[:, 2]))] for c in clouds]
@@ -74,9 +98,10 @@ def build_inputs(rank, device, order="shuffle"):
 
 
 def build_detector(device, dtype):
-    from second_amd.models import SecondDetector, CAR_FHD
+    from second_amd import models
+    from second_amd.models import SecondDetector
     torch.manual_seed(0)
-    det = SecondDetector(CAR_FHD)
+    det = SecondDetector(getattr(models, WL["cfg"]))
     g = torch.Generator().manual_seed(1)
     for m in det.modules():  # BN in eval mode with non-trivial statistics so that folding is exercised
         if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
@@ -166,7 +191,13 @@ def main():
     ap.add_argument("--point-order", default="shuffle", choices=["shuffle", "sorted"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stages", action="store_true", help="also print per-stage timings to stderr")
+    ap.add_argument("--workload", default="car.fhd", choices=sorted(WORKLOADS),
+                    help="car.fhd (default, the BASELINE metric) or another BASELINE config for a side measurement")
     args = ap.parse_args()
+    global WL
+    WL = WORKLOADS[args.workload]
+    if args.workload != "car.fhd":
+        args.no_cpu_baseline = True
 
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
@@ -262,16 +293,14 @@ def main():
         stage_times(det, points, offsets)
 
     if rank == 0:
-        frames = BATCH * args.steps * world
+        frames = WL["batch"] * args.steps * world
         res = {
-            "metric": "frames/sec VoxelNet fwd (car.fhd, ~16k active voxels)", "value": round(frames / elapsed, 2),
+            "metric": WL["metric"], "value": round(frames / elapsed, 2),
             "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "car.fhd.config VoxelNet forward (voxelise+VFE+SpMiddleFHD+RPNV2+rotated NMS), "
-                                   "inference, batch=8 synthetic KITTI clouds/GPU (17000 pts, 16000 voxels each), "
-                                   "random-init weights, inputs resident in HBM",
-                       "frames_per_step_per_gpu": BATCH, "parallelism": f"frame-dp{world}", "launch_mode": args.mode},
+            "config": {"workload": WL["desc"],
+                       "frames_per_step_per_gpu": WL["batch"], "parallelism": f"frame-dp{world}", "launch_mode": args.mode},
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

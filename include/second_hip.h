@@ -164,9 +164,10 @@ int sec_dense_to_sparse(const void *dense, const int *indices, int n, int c, voi
                         int64_t stride_x, int dtype, void *stream);
 
 /* PointPillarsScatter.forward (second/pytorch/models/pointpillars.py:444-476): coords (b,z,y,x),
- * canvas [B, C, ny, nx] (strides given in elements), cleared first. */
-int sec_pillar_scatter(const void *features, const int *coords, int p, int c, void *out,
-                       size_t out_elems, int64_t stride_b, int64_t stride_c, int64_t stride_y,
+ * canvas [B, C, ny, nx] (strides given in elements), cleared first.  num_dev (optional device int): only the
+ * first *num_dev pillars are live (static-capacity pipelines). */
+int sec_pillar_scatter(const void *features, const int *coords, int p, int c, const int *num_dev,
+                       void *out, size_t out_elems, int64_t stride_b, int64_t stride_c, int64_t stride_y,
                        int64_t stride_x, int dtype, void *stream);
 
 /* PillarFeatureNet.forward with a single PFNLayer in eval mode (second/pytorch/models/pointpillars.py:

@@ -87,10 +87,10 @@ SEC_API int sec_dense_to_sparse(const void *dense, const int *indices, int n, in
     return SEC_E_UNSUPPORTED;
 }
 
-SEC_API int sec_pillar_scatter(const void *features, const int *coords, int p, int c, void *out, size_t out_elems,
-                               int64_t stride_b, int64_t stride_c, int64_t stride_y, int64_t stride_x, int dtype,
-                               void *stream) {
+SEC_API int sec_pillar_scatter(const void *features, const int *coords, int p, int c, const int *num_dev, void *out,
+                               size_t out_elems, int64_t stride_b, int64_t stride_c, int64_t stride_y, int64_t stride_x,
+                               int dtype, void *stream) {
     // coords are (b, z, y, x) with z == 0 for pillars; the reference ignores z (pointpillars.py:462)
-    return sec_sparse_to_dense(features, coords, p, c, nullptr, out, out_elems, stride_b, stride_c, 0, stride_y, stride_x,
+    return sec_sparse_to_dense(features, coords, p, c, num_dev, out, out_elems, stride_b, stride_c, 0, stride_y, stride_x,
                                dtype, stream);
 }

@@ -182,13 +182,13 @@ class PointPillarsScatter(nn.Module):
         super().__init__()
         self.ny, self.nx, self.nchannels = int(output_shape[2]), int(output_shape[3]), num_input_features
 
-    def forward(self, voxel_features, coords, batch_size, channels_last=False):
+    def forward(self, voxel_features, coords, batch_size, channels_last=False, num_dev=None):
         if torch.is_grad_enabled() and voxel_features.requires_grad:   # training: differentiable scatter
             from spconv.functional import PillarScatterFunction
             return PillarScatterFunction.apply(voxel_features.contiguous(), coords.int().contiguous(), batch_size,
                                                self.ny, self.nx)
         return ops.pillar_scatter(voxel_features.contiguous(), coords.int().contiguous(), batch_size, self.ny, self.nx,
-                                  channels_last=channels_last)
+                                  channels_last=channels_last, num_dev=num_dev)
 
 
 def _bn1d(c):
@@ -497,7 +497,7 @@ class SecondDetector(nn.Module):
         dt = self._infer_dtype
         if self.pillars:
             spatial = self.middle_feature_extractor(voxel_features if dt is None else voxel_features.to(dt), coors,
-                                                    batch_size, channels_last=dt is not None)
+                                                    batch_size, channels_last=dt is not None, num_dev=num_active_dev)
             return self.rpn(spatial)
         if dt is not None:
             spatial = self.middle_feature_extractor(voxel_features.to(dt), coors, batch_size, channels_last=True,
@@ -523,10 +523,11 @@ class SecondDetector(nn.Module):
         batch_size = point_offsets.numel() - 1
         nf = self.cfg["num_point_features"]
         if self.pillars:
-            vox = self.voxel_generator.generate_device(points, point_offsets)
+            vox = self.voxel_generator.generate_device(points, point_offsets, sync=not static)
+            nd = vox["voxel_offsets"][batch_size:] if static else None    # device count of live pillars
             feats = self.voxel_feature_extractor(vox["voxels"], vox["num_points_per_voxel"], vox["coordinates"],
-                                                 out_dtype=self._infer_dtype)
-            preds = self.network_forward(feats, vox["coordinates"], batch_size)
+                                                 out_dtype=self._infer_dtype, num_dev=nd)
+            preds = self.network_forward(feats, vox["coordinates"], batch_size, num_active_dev=nd)
             return self.predict_device(preds, batch_size)
         if not static:
             vox = self.voxel_generator.generate_device(points, point_offsets, mean_features=nf)
@@ -568,7 +569,8 @@ class SecondDetector(nn.Module):
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(graph):
+        # thread_local: a RCCL watchdog / other host thread touching the runtime must not invalidate the capture
+        with torch.no_grad(), torch.cuda.graph(graph, capture_error_mode="thread_local"):
             out = self.forward_points(points, point_offsets, static=True)
         return graph.replay, out
 

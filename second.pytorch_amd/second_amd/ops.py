@@ -263,7 +263,7 @@ def dense_to_sparse(dense, indices):
     return rows
 
 
-def pillar_scatter(features, coords, batch_size, ny, nx, channels_last=False):
+def pillar_scatter(features, coords, batch_size, ny, nx, channels_last=False, num_dev=None):
     """PointPillarsScatter.forward (second/pytorch/models/pointpillars.py:444-476) as one launch."""
     rt.require_gpu(features, coords)
     p, c = features.shape
@@ -271,7 +271,7 @@ def pillar_scatter(features, coords, batch_size, ny, nx, channels_last=False):
     out = torch.empty((int(batch_size), c, int(ny), int(nx)), dtype=features.dtype, device=features.device,
                       memory_format=fmt)
     sb, sc, sy, sx = out.stride()
-    rc = rt.lib().sec_pillar_scatter(rt.ptr(features.contiguous()), rt.ptr(coords), p, c, rt.ptr(out), out.numel(),
+    rc = rt.lib().sec_pillar_scatter(rt.ptr(features.contiguous()), rt.ptr(coords), p, c, rt.ptr(num_dev), rt.ptr(out), out.numel(),
                                      int(sb), int(sc), int(sy), int(sx), rt.dtype_code(features.dtype), rt.stream())
     rt.check(rc, "sec_pillar_scatter")
     return out

@@ -65,7 +65,7 @@ def lib():
         l.sec_indice_conv_bwd_workspace_bytes.argtypes = [ci, ci, ci, ci]
         l.sec_sparse_to_dense.argtypes = [vp, vp, ci, ci, vp, vp, sz, i64, i64, i64, i64, i64, ci, vp]
         l.sec_dense_to_sparse.argtypes = [vp, vp, ci, ci, vp, i64, i64, i64, i64, i64, ci, vp]
-        l.sec_pillar_scatter.argtypes = [vp, vp, ci, ci, vp, sz, i64, i64, i64, i64, ci, vp]
+        l.sec_pillar_scatter.argtypes = [vp, vp, ci, ci, vp, vp, sz, i64, i64, i64, i64, ci, vp]
         l.sec_pfn_fwd.argtypes = [vp, vp, vp, ci, vp, ci, ci, vp, vp, vp, ci, cf, cf, cf, cf, vp, ci, vp]
         l.sec_block_filter_workspace_bytes.argtypes = [ci, ci, ci, ci, ci]
         l.sec_voxel_block_filter_f32.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, cf, cf, vp, vp, vp, vp, vp, sz, vp]

@@ -128,7 +128,7 @@ def sparse_to_dense(features, indices, batch_size, spatial_shape, channels_last_
     return d
 
 
-def pillar_scatter(features, coords, batch_size, ny, nx, channels_last=False):
+def pillar_scatter(features, coords, batch_size, ny, nx, channels_last=False, num_dev=None):
     return torch.from_numpy(orc.pillar_scatter(_np(features.float()), _np(coords), batch_size, ny, nx)).to(features.dtype)
 
 

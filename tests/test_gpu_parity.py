@@ -565,6 +565,16 @@ def test_pointpillars_detector_runs_fused_equals_module_path(syn):
     np.testing.assert_allclose(feats_k.cpu().numpy(), feats_t.detach().cpu().numpy(), rtol=1e-4, atol=1e-4)
     assert out["boxes"].shape[0] == 2 and out["valid"].any()
     assert int(out["labels"].max()) < 10
+    # static-capacity pillars (device-side pillar count) and its hipGraph replay == the eager path
+    with torch.no_grad():
+        st = det.forward_points(pts, offs, static=True)
+        replay, g = det.make_graphed(pts, offs)
+        replay()
+        torch.cuda.synchronize()
+    for other in (st, g):
+        assert torch.equal(out["valid"], other["valid"])
+        m = out["valid"]
+        assert torch.equal(out["scores"][m], other["scores"][m]) and torch.equal(out["boxes"][m], other["boxes"][m])
 
 
 @pytest.mark.parametrize("cin,cout,k,stride,pad,hw", [(128, 128, 3, 1, 1, (200, 176)), (64, 64, 3, 2, 1, (37, 29)),
