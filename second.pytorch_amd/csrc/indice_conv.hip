@@ -1468,11 +1468,10 @@ SEC_API int sec_indice_conv_fwd(const void *features, int n_in, int cin, const v
                                 int kvol, int cout, const int *nbr_out, int n_out, const int *num_out_dev,
                                 const float *scale, const float *shift, int relu, void *out, int dtype, int out_dtype,
                                 void *stream) {
-    if (n_in < 0 || n_out < 0 || cin <= 0 || cout <= 0 || kvol <= 0 || !weight || !nbr_out || !out ||
-        (n_in > 0 && !features))
-        return SEC_E_INVALID;
+    if (n_in < 0 || n_out < 0 || cin <= 0 || cout <= 0 || kvol <= 0 || !weight) return SEC_E_INVALID;
     if (dtype < 0 || dtype > 2 || (out_dtype != dtype && out_dtype != SEC_F32)) return SEC_E_UNSUPPORTED;
-    if (n_out == 0) return SEC_OK;
+    if (n_out == 0) return SEC_OK;                 // an empty batch: empty tensors carry null pointers
+    if (!nbr_out || !out || (n_in > 0 && !features)) return SEC_E_INVALID;
     hipStream_t st = (hipStream_t)stream;
     bool done = false;
     if (packed_weight && dtype != SEC_F32) {

@@ -732,3 +732,34 @@ def test_conv1x1_chain_vs_torch(ops, cout2, dtype):
     sep = ops.conv2d_nhwc(ops.conv2d_nhwc(x, ops.conv2d_pack_weight(w1), b1, 128, 1, 1, 0, relu=True),
                           ops.conv2d_pack_weight(w2), b2, cout2, 1, 1, 0, relu=False)
     np.testing.assert_allclose(out.float().cpu().numpy(), sep.float().cpu().numpy(), rtol=tol, atol=tol * ref.abs().max().item())
+
+
+def test_detector_empty_and_tiny_frames(syn):
+    """Ragged batch: an EMPTY frame between two real ones, and a frame with three points -- eager and static paths;
+    the real frames' detections do not depend on their neighbours (frames are independent)."""
+    from second_amd.models import SecondDetector, CAR_FHD
+    torch.manual_seed(0)
+    det = SecondDetector(CAR_FHD).cuda().prepare_inference(torch.bfloat16)
+    a, c = syn.syn_kitti_cloud(0, num_points=9000, num_voxels=8000), syn.syn_kitti_cloud(1, num_points=9000, num_voxels=8000)
+    empty = np.zeros((0, 4), np.float32)
+    tiny = a[:3].copy()
+
+    def run(clouds, static):
+        pts, offs = syn.batch_clouds(clouds)
+        with torch.no_grad():
+            out = det.forward_points(dev(pts), dev(offs), static=static)
+            if static:
+                det.check_overflow()
+        return {k: v.cpu() for k, v in out.items()}
+
+    ref = run([a, c], False)
+    for static in (False, True):
+        out = run([a, empty, c, tiny], static)
+        # (the empty frame may well "detect" something: an all-zero RPN input still passes through the biases)
+        for src, dst in ((0, 0), (1, 2)):
+            m = ref["valid"][src]
+            assert torch.equal(m, out["valid"][dst])
+            assert torch.equal(ref["scores"][src][m], out["scores"][dst][m])
+            assert torch.equal(ref["boxes"][src][m], out["boxes"][dst][m])
+    only_empty = run([empty], False)                         # must simply run
+    assert only_empty["valid"].shape[0] == 1
