@@ -26,7 +26,23 @@ def build(force=False, verbose=True):
             return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     extra = os.environ.get("SEC_EXTRA_HIPCC_FLAGS", "").split()   # e.g. -DSEC_CONV_ABLATIONS for profiling builds
-    cmd = [hipcc, *FLAGS, *extra, "-o", OUT, *SRC]
+    # one translation unit per source, compiled concurrently (indice_conv.hip / dense.hip dominate), then one link
+    from concurrent.futures import ThreadPoolExecutor
+    objdir = os.path.join(HERE, "lib", "obj")
+    os.makedirs(objdir, exist_ok=True)
+    cflags = [f for f in FLAGS if f != "-shared"]
+
+    def compile_one(src):
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        cmd = [hipcc, *cflags, *extra, "-c", "-o", obj, src]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(len(SRC), os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, SRC))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fvisibility=hidden", "-o", OUT, *objs]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -1091,6 +1091,7 @@ static void launch_mfma(const void *feat, const void *packed, const int *nbr, in
         }
 #endif
     }
+#ifdef SEC_CONV_EXPERIMENTS   // measured dead ends, compiled only for A/B builds
     if (conv_variant() == 2 && kvol == 27) {
         hipLaunchKernelGGL((k_conv_mfma_lds<T, OT, CIN, COUT, 27>), dim3(div_up(n_out, 128)), dim3(kBlock), 0, st,
                            (const T *)feat, (const T *)packed, nbr, n_out, num_out_dev, scale, shift, relu, (OT *)out);
@@ -1104,12 +1105,14 @@ static void launch_mfma(const void *feat, const void *packed, const int *nbr, in
         launch_wlds<T, OT, CIN, COUT>(feat, packed, nbr, n_out, num_out_dev, scale, shift, relu, out, st);
         return;
     }
+#endif
     if (conv_variant() == 8 || (conv_variant() == 1 && COUT <= 32)) {   // single 32-column slice: leaner split-K kernel
         hipLaunchKernelGGL((k_conv_mfma_sks<T, OT, CIN, COUT, 4>), dim3((div_up(n_out, 32) + 7) / 8 * 8, (COUT + 31) / 32),
                            dim3(256), 0, st, (const T *)feat, (const T *)packed, nbr, n_out, num_out_dev, kvol, scale, shift,
                            relu, (OT *)out);
         return;
     }
+#ifdef SEC_CONV_EXPERIMENTS
     if (conv_variant() == 3 && kvol == 27) {
         hipLaunchKernelGGL((k_conv_mfma_lds2<T, OT, CIN, COUT, 27>), dim3(div_up(n_out, 128)), dim3(kBlock), 0, st,
                            (const T *)feat, (const T *)packed, nbr, n_out, num_out_dev, scale, shift, relu, (OT *)out);
@@ -1124,6 +1127,7 @@ static void launch_mfma(const void *feat, const void *packed, const int *nbr, in
                                (const T *)feat, (const T *)packed, nbr, n_out, num_out_dev, kvol, scale, shift, relu, (OT *)out);
         return;
     }
+#endif
     if (conv_variant() >= 1) {
         constexpr int NW = 4;
         hipLaunchKernelGGL((k_conv_mfma_sk<T, OT, CIN, COUT, NW>), dim3((div_up(n_out, 32) + 7) / 8 * 8), dim3(NW * 64), 0, st,
