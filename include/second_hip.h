@@ -111,13 +111,17 @@ int sec_rulebook_conv3d_build(const int *indices, int n_in, const int *n_in_dev,
                               const int *h_in_shape3,
                               const int *h_out_shape3, const int *h_ksize3, const int *h_stride3,
                               const int *h_padding3, const int *h_dilation3, int *out_indices,
-                              int out_cap, int *num_out, int out_per_in_hint, void *workspace,
+                              int out_cap, int *num_out, int out_per_in_hint, int *prefill_nbr_out,
+                              int prefill_nbr_out_rows, int *prefill_nbr_in, void *workspace,
                               size_t workspace_bytes, void *stream);
-/* step 2: fill the tables. nbr_out has `nbr_out_rows` rows (>= number of outputs; rows are -1 filled).
+/* (build, continued) prefill_nbr_out / prefill_nbr_in: when the caller already owns the gather tables (static-capacity
+ * pipelines know their row counts before the build) the build's numbering launch also writes their -1 fill;
+ * pass prefilled = 1 to step 2 then.  NULL = step 2 fills them itself.
+ * step 2: fill the tables. nbr_out has `nbr_out_rows` rows (>= number of outputs; rows are -1 filled).
  * nbr_in may be NULL when neither the backward pass nor the pair lists are wanted (inference). */
 int sec_rulebook_conv3d_tables(int n_in, const int *h_ksize3, const int *h_stride3,
                                const int *h_dilation3, int out_per_in_hint, int *nbr_out,
-                               int nbr_out_rows, int *nbr_in, int *pairs, int *pair_num,
+                               int nbr_out_rows, int *nbr_in, int prefilled, int *pairs, int *pair_num,
                                void *workspace, size_t workspace_bytes, void *stream);
 void sec_conv_output_shape(const int *h_in_shape3, const int *h_ksize3, const int *h_stride3,
                            const int *h_padding3, const int *h_dilation3, int *h_out_shape3);

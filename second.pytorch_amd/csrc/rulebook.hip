@@ -193,6 +193,68 @@ __global__ __launch_bounds__(kBlock) void k_conv_count_scan(const int *__restric
     if (j < n_in) rank[j] = ex;
 }
 
+// ncand <= 32: count + scan + ASSIGN in one launch.  Once the look-back has given a row the rank of its first new output,
+// the row's own first-touch candidates (its mask bits) can be numbered on the spot: orank[slot] = rank + popcount of
+// the lower mask bits, out_indices[rank] = the cell decoded from the hash key.  The same launch pre-fills the gather
+// tables with -1 when the caller already has them (static-capacity pipelines), so a strided build is
+// init -> candidates -> this kernel -> tables: four launches instead of eight.
+__global__ __launch_bounds__(kBlock) void k_conv_count_scan_assign(const int *__restrict__ cand_slot,
+                                                                  const unsigned char *__restrict__ cand_k,
+                                                                  const int *__restrict__ vals,
+                                                                  const unsigned long long *__restrict__ keys, RbGeom g,
+                                                                  int *__restrict__ orank, int *__restrict__ out_indices,
+                                                                  int out_cap, unsigned long long *__restrict__ status,
+                                                                  int *__restrict__ ticket, int *__restrict__ num_out,
+                                                                  const int *__restrict__ overflow,
+                                                                  int *__restrict__ fill_a, long long fill_a_words,
+                                                                  int *__restrict__ fill_b, long long fill_b_words) {
+    __shared__ int smem[5];
+    __shared__ int s_tile;
+    {   // table pre-fill (independent of everything else in this launch)
+        const long long stride = (long long)gridDim.x * kBlock;
+        for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < fill_a_words; i += stride) fill_a[i] = -1;
+        for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < fill_b_words; i += stride) fill_b[i] = -1;
+    }
+    const int tile = scan_take_tile(ticket, &s_tile);
+    const int j = tile * kBlock + threadIdx.x;
+    const int n_in = g.n_in, ncand = g.ncand;
+    int cnt = 0;
+    unsigned m = 0;
+    if (j < n_in) {
+        for (int c = 0; c < ncand; ++c) {
+            const size_t t = (size_t)j * ncand + c;
+            const int s = cand_slot[t];
+            const bool f = s >= 0 && vals[s] == j * g.kvol + (int)cand_k[t];
+            cnt += f ? 1 : 0;
+            if (f) m |= 1u << c;
+        }
+    }
+    int r = scan_lookback(cnt, tile, (int)gridDim.x, status, smem, num_out);
+    if (tile == (int)gridDim.x - 1 && threadIdx.x == 0) {
+        // num_out[0] = live outputs (clamped to the capacity), num_out[1] = raw count (overflow check)
+        const int tot = num_out[0];
+        num_out[1] = *overflow ? 0x7fffffff : tot;
+        if (tot > out_cap) num_out[0] = out_cap;
+    }
+    const unsigned long long vol = (unsigned long long)g.out_shape[0] * g.out_shape[1] * g.out_shape[2];
+    while (m) {                                   // this row's first touches, in offset order
+        const int c = __ffs((int)m) - 1;
+        m &= m - 1u;
+        const int s = cand_slot[(size_t)j * ncand + c];
+        orank[s] = r;
+        if (r < out_cap) {
+            const unsigned long long key = keys[s];
+            const int b = (int)(key / vol);
+            const unsigned long long lin = key - (unsigned long long)b * vol;
+            const int x = (int)(lin % g.out_shape[2]);
+            const unsigned long long q = lin / g.out_shape[2];
+            *reinterpret_cast<int4 *>(out_indices + (size_t)r * 4) = make_int4(b, (int)(q / g.out_shape[1]), (int)(q % g.out_shape[1]), x);
+        }
+        ++r;
+    }
+}
+
+
 __global__ __launch_bounds__(kBlock) void k_conv_assign(const int *__restrict__ cand_slot,
                                                        const unsigned char *__restrict__ cand_k,
                                                        const int *__restrict__ vals,
@@ -455,10 +517,10 @@ SEC_API int sec_rulebook_subm3d_after_conv(const int *indices, int n_in, const i
 SEC_API int sec_rulebook_conv3d_build(const int *indices, int n_in, const int *n_in_dev, int batch, const int *h_in_shape3,
                                       const int *h_out_shape3, const int *h_ksize3, const int *h_stride3,
                                       const int *h_padding3, const int *h_dilation3, int *out_indices, int out_cap,
-                                      int *num_out, int out_per_in_hint, void *workspace, size_t workspace_bytes,
-                                      void *stream) {
+                                      int *num_out, int out_per_in_hint, int *prefill_nbr_out, int prefill_nbr_out_rows,
+                                      int *prefill_nbr_in, void *workspace, size_t workspace_bytes, void *stream) {
     if (n_in < 0 || batch <= 0 || !h_in_shape3 || !h_out_shape3 || !h_ksize3 || !h_stride3 || !h_padding3 ||
-        !out_indices || !num_out || out_cap < 0)
+        !out_indices || !num_out || out_cap < 0 || prefill_nbr_out_rows < 0)
         return SEC_E_INVALID;
     RbGeom g;
     int rc = fill_geom(g, h_in_shape3, h_out_shape3, h_ksize3, h_stride3, h_padding3, h_dilation3, n_in, batch);
@@ -472,11 +534,23 @@ SEC_API int sec_rulebook_conv3d_build(const int *indices, int n_in, const int *n
     if (!workspace || w.bytes > workspace_bytes) return SEC_E_WORKSPACE;
     g.mask = w.table - 1;
     long long nc = (long long)n_in * g.ncand;
-    if (nc == 0) return hip_ok(hipMemsetAsync(num_out, 0, 2 * sizeof(int), st));
+    const long long fill_a = prefill_nbr_out ? (long long)prefill_nbr_out_rows * g.kvol : 0;
+    const long long fill_b = prefill_nbr_in ? (long long)n_in * g.kvol : 0;
+    if (nc == 0) {
+        if (fill_a + fill_b > 0) rb_init(nullptr, 0, 0, prefill_nbr_out, fill_a, -1, prefill_nbr_in, fill_b, -1, st);
+        return hip_ok(hipMemsetAsync(num_out, 0, 2 * sizeof(int), st));
+    }
     rb_init(w.keys, w.table, kEmptyKey, w.vals, w.table, kEmptyI32, w.ticket, w.ctl_words, 0, st);
     int nb = div_up(nc, kBlock);
     hipLaunchKernelGGL(k_conv_cand, dim3(nb), dim3(kBlock), 0, st, indices, g, n_in_dev, w.keys, w.vals, w.cand_slot,
                        w.cand_k, w.overflow);
+    if (g.ncand <= 32) {
+        hipLaunchKernelGGL(k_conv_count_scan_assign, dim3(div_up(n_in, kBlock)), dim3(kBlock), 0, st, w.cand_slot, w.cand_k, w.vals,
+                           w.keys, g, w.orank, out_indices, out_cap, w.status, w.ticket, num_out, w.overflow, prefill_nbr_out,
+                           fill_a, prefill_nbr_in, fill_b);
+        return check_launch();
+    }
+    if (fill_a + fill_b > 0) rb_init(nullptr, 0, 0, prefill_nbr_out, fill_a, -1, prefill_nbr_in, fill_b, -1, st);
     hipLaunchKernelGGL(k_conv_count_scan, dim3(div_up(n_in, kBlock)), dim3(kBlock), 0, st, w.cand_slot, w.cand_k, w.vals, n_in,
                        g.kvol, g.ncand, w.rank, w.first_mask, w.status, w.ticket, num_out);
     hipLaunchKernelGGL(k_conv_assign, dim3(nb), dim3(kBlock), 0, st, w.cand_slot, w.cand_k, w.vals, w.keys, w.rank, g,
@@ -485,8 +559,8 @@ SEC_API int sec_rulebook_conv3d_build(const int *indices, int n_in, const int *n
 }
 
 SEC_API int sec_rulebook_conv3d_tables(int n_in, const int *h_ksize3, const int *h_stride3, const int *h_dilation3,
-                                       int out_per_in_hint, int *nbr_out, int nbr_out_rows, int *nbr_in, int *pairs,
-                                       int *pair_num, void *workspace, size_t workspace_bytes, void *stream) {
+                                       int out_per_in_hint, int *nbr_out, int nbr_out_rows, int *nbr_in, int prefilled,
+                                       int *pairs, int *pair_num, void *workspace, size_t workspace_bytes, void *stream) {
     if (n_in < 0 || !h_ksize3 || !h_stride3 || (nbr_out_rows > 0 && !nbr_out) || nbr_out_rows < 0 ||
         (pairs && (!pair_num || !nbr_in)))
         return SEC_E_INVALID;
@@ -500,7 +574,7 @@ SEC_API int sec_rulebook_conv3d_tables(int n_in, const int *h_ksize3, const int 
     if (!workspace || w.bytes > workspace_bytes) return SEC_E_WORKSPACE;
     // one fill launch for both tables (nbr_in only when the caller wants it: backward / pair lists)
     long long n_out_words = (long long)nbr_out_rows * kvol, n_in_words = nbr_in ? (long long)n_in * kvol : 0;
-    if (n_out_words + n_in_words > 0)
+    if (!prefilled && n_out_words + n_in_words > 0)   // prefilled: the build call already wrote the -1s (static pipelines)
         rb_init(nullptr, 0, 0, nbr_out, n_out_words, -1, nbr_in, n_in_words, -1, st);
     long long nc = (long long)n_in * g.ncand;
     if (nc > 0) {

@@ -127,16 +127,23 @@ def rulebook_conv(indices, batch_size, spatial_shape, ksize, stride, padding, di
     num_out = torch.empty((2,), dtype=torch.int32, device=dev)   # both words are written by the build
     l = rt.lib()
     ws = rt.workspace(l.sec_rulebook_workspace_bytes(n, k, hint or per_in), dev)
+    # static capacity: the table sizes are known before the build, whose numbering launch then also writes their -1 fill
+    pre_out = torch.empty((cap, k), dtype=torch.int32, device=dev) if static else None
+    pre_in = torch.empty((n, k), dtype=torch.int32, device=dev) if (static and (want_nbr_in or want_pairs)) else None
     rc = l.sec_rulebook_conv3d_build(rt.ptr(indices), n, rt.ptr(n_dev), int(batch_size), rt.i3(spatial_shape),
                                      rt.i3(out_shape), ks, st, rt.i3(padding), rt.i3(dilation), rt.ptr(out_idx), cap,
-                                     rt.ptr(num_out), hint, rt.ptr(ws), ws.numel(), rt.stream())
+                                     rt.ptr(num_out), hint, rt.ptr(pre_out), cap if static else 0, rt.ptr(pre_in), rt.ptr(ws),
+                                     ws.numel(), rt.stream())
     rt.check(rc, "sec_rulebook_conv3d_build")
     m = cap if static else int(num_out[0].item())
-    nbr_out = torch.empty((m, k), dtype=torch.int32, device=dev)
-    nbr_in = torch.empty((n, k), dtype=torch.int32, device=dev) if (want_nbr_in or want_pairs) else None
+    nbr_out = pre_out if static else torch.empty((m, k), dtype=torch.int32, device=dev)
+    if static:
+        nbr_in = pre_in
+    else:
+        nbr_in = torch.empty((n, k), dtype=torch.int32, device=dev) if (want_nbr_in or want_pairs) else None
     pairs = torch.empty((k, 2, n), dtype=torch.int32, device=dev) if want_pairs else None
     pair_num = torch.zeros((k,), dtype=torch.int32, device=dev) if want_pairs else None
-    rc = l.sec_rulebook_conv3d_tables(n, ks, st, dl, hint, rt.ptr(nbr_out), m, rt.ptr(nbr_in), rt.ptr(pairs),
+    rc = l.sec_rulebook_conv3d_tables(n, ks, st, dl, hint, rt.ptr(nbr_out), m, rt.ptr(nbr_in), 1 if static else 0, rt.ptr(pairs),
                                       rt.ptr(pair_num), rt.ptr(ws), ws.numel(), rt.stream())
     rt.check(rc, "sec_rulebook_conv3d_tables")
     return {"nbr_out": nbr_out, "nbr_in": nbr_in, "pairs": pairs, "pair_num": pair_num,
