@@ -69,8 +69,15 @@ __device__ __forceinline__ uint32_t hash_insert(unsigned long long *keys, uint32
 __device__ __forceinline__ int hash_insert_bounded(unsigned long long *keys, uint32_t mask, unsigned long long key) {
     uint32_t s = hash64(key) & mask;
     for (uint32_t probes = 0; probes <= mask; ++probes) {
-        unsigned long long prev = atomicCAS(&keys[s], kEmptyKey, key);
-        if (prev == kEmptyKey || prev == key) return (int)s;
+        // peek first (agent-scope load, L2): most candidates of a strided conv find their cell already inserted, and a
+        // returning compare-and-swap is a fabric round trip.  A slot only ever goes empty -> key, so a stale "empty"
+        // merely costs the CAS we would have issued anyway and a non-empty value is final.
+        unsigned long long cur = __hip_atomic_load(&keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == key) return (int)s;
+        if (cur == kEmptyKey) {
+            cur = atomicCAS(&keys[s], kEmptyKey, key);
+            if (cur == kEmptyKey || cur == key) return (int)s;
+        }
         s = (s + 1) & mask;
     }
     return -1;

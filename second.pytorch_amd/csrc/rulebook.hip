@@ -157,7 +157,8 @@ __global__ __launch_bounds__(kBlock) void k_conv_cand(const int *__restrict__ in
     if (ok) {
         int k = (kk[0] * g.ksize[1] + kk[1]) * g.ksize[2] + kk[2];
         s = hash_insert_bounded(keys, g.mask, cell_key(q.x, out[0], out[1], out[2], g.out_shape));
-        if (s >= 0) atomicMin(&vals[s], j * g.kvol + k);  // token = position in the sequential reference loop
+        if (s >= 0) atomicMin(&vals[s], j * g.kvol + k);  // token = position in the sequential reference loop (a peek before
+                                                          // this non-returning atomic was measured: no gain)
         else atomicOr(overflow, 1);                        // table sized from a too-small hint: reported, not hung
         cand_k[t] = (unsigned char)k;
     }
@@ -237,6 +238,7 @@ __global__ __launch_bounds__(kBlock) void k_conv_count_scan_assign(const int *__
         if (tot > out_cap) num_out[0] = out_cap;
     }
     const unsigned long long vol = (unsigned long long)g.out_shape[0] * g.out_shape[1] * g.out_shape[2];
+    const bool small = (vol * (unsigned long long)g.batch) >> 32 == 0;
     while (m) {                                   // this row's first touches, in offset order
         const int c = __ffs((int)m) - 1;
         m &= m - 1u;
@@ -244,11 +246,20 @@ __global__ __launch_bounds__(kBlock) void k_conv_count_scan_assign(const int *__
         orank[s] = r;
         if (r < out_cap) {
             const unsigned long long key = keys[s];
-            const int b = (int)(key / vol);
-            const unsigned long long lin = key - (unsigned long long)b * vol;
-            const int x = (int)(lin % g.out_shape[2]);
-            const unsigned long long q = lin / g.out_shape[2];
-            *reinterpret_cast<int4 *>(out_indices + (size_t)r * 4) = make_int4(b, (int)(q / g.out_shape[1]), (int)(q % g.out_shape[1]), x);
+            int4 c4;
+            if (small) {                          // the whole grid indexes in 32 bits: avoid the 64-bit divisions
+                const unsigned k32 = (unsigned)key, v32 = (unsigned)vol;
+                const unsigned b = k32 / v32, lin = k32 - b * v32;
+                const unsigned q = lin / (unsigned)g.out_shape[2];
+                c4 = make_int4((int)b, (int)(q / (unsigned)g.out_shape[1]), (int)(q % (unsigned)g.out_shape[1]),
+                               (int)(lin - q * (unsigned)g.out_shape[2]));
+            } else {
+                const int b = (int)(key / vol);
+                const unsigned long long lin = key - (unsigned long long)b * vol;
+                const unsigned long long q = lin / g.out_shape[2];
+                c4 = make_int4(b, (int)(q / g.out_shape[1]), (int)(q % g.out_shape[1]), (int)(lin % g.out_shape[2]));
+            }
+            *reinterpret_cast<int4 *>(out_indices + (size_t)r * 4) = c4;
         }
         ++r;
     }
