@@ -64,6 +64,35 @@ def time_kernel(call, reps=100):
     return e0.elapsed_time(e1) * 1e-3 / reps
 
 
+def time_rpn_conv(det, batch, reps=100):
+    """The RPN's 3x3 128->128 conv (k_conv2d_halo_reg, the largest single share of the step) re-issued `reps` times between
+    two HIP events on the launch stream, on an input of the live shape: achieved TFLOP/s against the dense bf16 MFMA peak."""
+    from second_amd import ops
+    rpn = det.rpn
+    if not getattr(rpn, "use_hip", False):
+        return None
+    _, h, w = det.feature_map_size
+    # post-ReLU-like activations (half zeros), as between the RPN layers
+    x = torch.relu(torch.randn(batch, 128, h, w, device="cuda")).to(rpn.ws[1].dtype).contiguous(memory_format=torch.channels_last)
+    wgt, pk, b = rpn.ws[1], rpn.packed[1], rpn.bs[1]
+    if tuple(wgt.shape) != (128, 128, 3, 3):
+        return None
+    fn = lambda: ops.conv2d_nhwc(x, pk, b, 128, 3, 1, 1, relu=True)
+    for _ in range(200):          # ~20 ms: the first launches after an idle gap run at low clocks
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(torch.cuda.current_stream())
+    for _ in range(reps):
+        fn()
+    e1.record(torch.cuda.current_stream())
+    torch.cuda.synchronize()
+    t = e0.elapsed_time(e1) * 1e-3 / reps
+    flop = 2.0 * batch * h * w * 128 * 128 * 9
+    return {"bound": "mfma", "achieved": round(flop / t / 1e12, 1), "peak": 2500.0, "unit": "TFLOP/s",
+            "frac": round(flop / t / 2.5e15, 4), "kernel": "k_conv2d_halo_reg<bf16,128> (RPN 3x3 128->128, 6 launches per step)",
+            "launch_us": round(t * 1e6, 2), "launches_timed": reps, "flop_per_launch": flop}
+
+
 # Other BASELINE configs (parity-test cases; timed only on request with --workload, never the default line):
 #   nusc.pp  = nuscenes/all.pp.largea (PointPillars), nusc.fhd = nuscenes/all.fhd (block-filtered voxels, 10 classes)
 WORKLOADS = {
@@ -256,6 +285,7 @@ def main():
         timer.enabled = False
         ops.set_conv_profiler(None)
         t_kernel = time_kernel(timer.call) if timer.call is not None else None
+        roof_mfma = time_rpn_conv(det, WL["batch"]) if args.dtype == "bf16" else None
 
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -302,6 +332,7 @@ def main():
             "config": {"workload": WL["desc"],
                        "frames_per_step_per_gpu": WL["batch"], "parallelism": f"frame-dp{world}", "launch_mode": args.mode},
             "roofline": roof,
+            "roofline_mfma": roof_mfma,     # second-largest consumer by kind: the dense RPN conv, MFMA bound
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cpu_state, clouds)
