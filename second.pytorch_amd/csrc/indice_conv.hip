@@ -41,6 +41,20 @@ __device__ __forceinline__ float epilogue(float v, const float *scale, const flo
     return v;
 }
 
+// four consecutive output channels of one row in one store (8 bytes for 16-bit outputs, 16 for fp32)
+template <typename OT> __device__ __forceinline__ void store4(OT *p, float a, float b, float c, float d) {
+    OT v[4] = {Cvt<OT>::from(a), Cvt<OT>::from(b), Cvt<OT>::from(c), Cvt<OT>::from(d)};
+    if constexpr (sizeof(OT) == 2) {
+        uint2 u;
+        __builtin_memcpy(&u, v, 8);
+        *reinterpret_cast<uint2 *>(p) = u;
+    } else {
+        float4 u;
+        __builtin_memcpy(&u, v, 16);
+        *reinterpret_cast<float4 *>(p) = u;
+    }
+}
+
 // ------------------------------------------------------------------ generic VALU path (any Cin/Cout/dtype)
 // one thread per (output row, output channel); fp32 fmaf chain in (k, ci) order.
 template <typename T, typename OT>
@@ -269,7 +283,7 @@ __global__ __launch_bounds__(NW * 64, SEC_SK_MIN_WAVES) void k_conv_mfma_sk(cons
 #pragma unroll
         for (int s = 0; s < KS; ++s)
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = Mfma<T>::run(a[s], wk[(s * NT + t) * 64], acc[t]);
+            for (int t = 0; t < NT; ++t) acc[t] = Mfma<T>::run(wk[(s * NT + t) * 64], a[s], acc[t]);   // D^T: lane = one row
     }
     relu &= 0xff;
     if (tl) t2 = clock64();
@@ -298,15 +312,21 @@ __global__ __launch_bounds__(NW * 64, SEC_SK_MIN_WAVES) void k_conv_mfma_sk(cons
     }
     __syncthreads();
     if (tl) t3 = clock64();
+    // transposed accumulators (weights were the first MFMA operand): a lane owns output row base + r and, per group of
+    // four registers, four CONSECUTIVE channels t*32 + 8g + 4h + (0..3): one 8-byte store instead of four 2-byte scatters
     constexpr int PER = NREG / NW;
+    static_assert(PER % 4 == 0, "registers are finished in groups of four");
 #pragma unroll
-    for (int j = 0; j < PER; ++j) {
-        const int reg = w * PER + j;
-        const float v = red[0][reg][lane] + red[1][reg][lane];
-        const int t = reg >> 4, i = reg & 15;
-        const int col = t * 32 + r;
-        const long long orow = base + (i & 3) + 8 * (i >> 2) + 4 * h;
-        if (col < COUT && orow < n_out) out[(size_t)orow * COUT + col] = Cvt<OT>::from(epilogue(v, scale, shift, col, relu));
+    for (int q = 0; q < PER / 4; ++q) {
+        const int reg0 = w * PER + q * 4;
+        const int t = reg0 >> 4, g = (reg0 & 15) >> 2;
+        const int c0 = t * 32 + 8 * g + 4 * h;
+        if (c0 < COUT) {
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = epilogue(red[0][reg0 + j][lane] + red[1][reg0 + j][lane], scale, shift, c0 + j, relu);
+            if (valid) store4<OT>(out + (size_t)row * COUT + c0, v[0], v[1], v[2], v[3]);
+        }
     }
     if (tl && lane == 0) {
         long long *rec = tl + ((size_t)blockIdx.x * NW + w) * 6;
@@ -350,21 +370,26 @@ __global__ __launch_bounds__(NW * 64) void k_conv_mfma_sks(const T *__restrict__
         for (int s = 0; s < KS; ++s) a[s] = cur >= 0 ? src[s * 2] : make_uint4(0, 0, 0, 0);
         const uint4 *wk = wp + (size_t)k * KS * NT * 64;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) acc = Mfma<T>::run(a[s], wk[(s * NT + t) * 64], acc);
+        for (int s = 0; s < KS; ++s) acc = Mfma<T>::run(wk[(s * NT + t) * 64], a[s], acc);   // D^T: lane = one row
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) red[w][i][lane] = acc[i];
     __syncthreads();
-    constexpr int PER = 16 / NW;
+    // wave w finishes register group g = w: channels t*32 + 8w + 4h + (0..3) of row base + r, one 8-byte store
+    static_assert(NW == 4, "one four-register group per wave");
+    {
+        const int c0 = t * 32 + 8 * w + 4 * h;
+        if (c0 < COUT) {
+            float v[4];
 #pragma unroll
-    for (int j = 0; j < PER; ++j) {
-        const int i = w * PER + j;
-        float v = 0.0f;
+            for (int j = 0; j < 4; ++j) {
+                float sum = 0.0f;
 #pragma unroll
-        for (int ww = 0; ww < NW; ++ww) v += red[ww][i][lane];
-        const int col = t * 32 + r;
-        const long long orow = base + (i & 3) + 8 * (i >> 2) + 4 * h;
-        if (col < COUT && orow < n_out) out[(size_t)orow * COUT + col] = Cvt<OT>::from(epilogue(v, scale, shift, col, relu));
+                for (int ww = 0; ww < NW; ++ww) sum += red[ww][w * 4 + j][lane];
+                v[j] = epilogue(sum, scale, shift, c0 + j, relu);
+            }
+            if (valid) store4<OT>(out + (size_t)row * COUT + c0, v[0], v[1], v[2], v[3]);
+        }
     }
 }
 
