@@ -67,52 +67,64 @@ __device__ __forceinline__ bool seg_intersect(const float *p1, const float *p2, 
 }
 
 // intersection area of two quads given by their corners (nms_gpu.py:329-350,172-219,379-393)
-__device__ float quad_inter(const float *c1, const float *c2) {
-    float pts[48];
+// The vertex list is indexed dynamically (append, insertion sort), which in registers means scratch memory -- a
+// global-memory round trip per access on the serial critical path of the few lanes that clip.  It lives in LDS instead:
+// `lp` points at this thread's column of a [24][blockDim] float array (16 vertex coordinates + 8 sort keys), element i
+// at lp[i * LSTR].  At most 8 vertices are ever used (the reference's int_pts holds 8), so later ones are counted but
+// not stored.
+template <int LSTR>
+__device__ float quad_inter(const float *c1, const float *c2, float *lp) {
+#define SEC_P(i) lp[(i) * LSTR]
+#define SEC_V(i) lp[(16 + (i)) * LSTR]
     int n = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        if (pt_in_quad(c1[2 * i], c1[2 * i + 1], c2)) { pts[2 * n] = c1[2 * i]; pts[2 * n + 1] = c1[2 * i + 1]; ++n; }
-        if (pt_in_quad(c2[2 * i], c2[2 * i + 1], c1)) { pts[2 * n] = c2[2 * i]; pts[2 * n + 1] = c2[2 * i + 1]; ++n; }
+        if (pt_in_quad(c1[2 * i], c1[2 * i + 1], c2)) { if (n < 8) { SEC_P(2 * n) = c1[2 * i]; SEC_P(2 * n + 1) = c1[2 * i + 1]; } ++n; }
+        if (pt_in_quad(c2[2 * i], c2[2 * i + 1], c1)) { if (n < 8) { SEC_P(2 * n) = c2[2 * i]; SEC_P(2 * n + 1) = c2[2 * i + 1]; } ++n; }
     }
     float t[2];
     for (int i = 0; i < 4; ++i)
         for (int j = 0; j < 4; ++j)
-            if (seg_intersect(c1, c2, i, j, t)) { pts[2 * n] = t[0]; pts[2 * n + 1] = t[1]; ++n; }
+            if (seg_intersect(c1, c2, i, j, t)) { if (n < 8) { SEC_P(2 * n) = t[0]; SEC_P(2 * n + 1) = t[1]; } ++n; }
     if (n > 8) n = 8;
     if (n < 3) return 0.0f;
     // angular sort about the centroid (insertion sort on the reference's key)
     float cx = 0.0f, cy = 0.0f;
-    for (int i = 0; i < n; ++i) { cx += pts[2 * i]; cy += pts[2 * i + 1]; }
+    for (int i = 0; i < n; ++i) { cx += SEC_P(2 * i); cy += SEC_P(2 * i + 1); }
     cx /= (float)n;
     cy /= (float)n;
-    float vs[8];
     for (int i = 0; i < n; ++i) {
-        float vx = pts[2 * i] - cx, vy = pts[2 * i + 1] - cy;
+        float vx = SEC_P(2 * i) - cx, vy = SEC_P(2 * i + 1) - cy;
         float d = sqrtf(vx * vx + vy * vy);
         vx = vx / d;
         vy = vy / d;
         if (vy < 0) vx = -2 - vx;
-        vs[i] = vx;
+        SEC_V(i) = vx;
     }
     for (int i = 1; i < n; ++i) {
-        if (vs[i - 1] > vs[i]) {
-            float temp = vs[i], tx = pts[2 * i], ty = pts[2 * i + 1];
+        if (SEC_V(i - 1) > SEC_V(i)) {
+            float temp = SEC_V(i), tx = SEC_P(2 * i), ty = SEC_P(2 * i + 1);
             int j = i;
-            while (j > 0 && vs[j - 1] > temp) {
-                vs[j] = vs[j - 1];
-                pts[2 * j] = pts[2 * j - 2];
-                pts[2 * j + 1] = pts[2 * j - 1];
+            while (j > 0 && SEC_V(j - 1) > temp) {
+                SEC_V(j) = SEC_V(j - 1);
+                SEC_P(2 * j) = SEC_P(2 * j - 2);
+                SEC_P(2 * j + 1) = SEC_P(2 * j - 1);
                 --j;
             }
-            vs[j] = temp;
-            pts[2 * j] = tx;
-            pts[2 * j + 1] = ty;
+            SEC_V(j) = temp;
+            SEC_P(2 * j) = tx;
+            SEC_P(2 * j + 1) = ty;
         }
     }
     float s = 0.0f;
-    for (int i = 0; i < n - 2; ++i) s += fabsf(tri_area(pts, pts + 2 * i + 2, pts + 2 * i + 4));
+    const float p0[2] = {SEC_P(0), SEC_P(1)};
+    for (int i = 0; i < n - 2; ++i) {
+        const float pa[2] = {SEC_P(2 * i + 2), SEC_P(2 * i + 3)}, pb[2] = {SEC_P(2 * i + 4), SEC_P(2 * i + 5)};
+        s += fabsf(tri_area(p0, pa, pb));
+    }
     return s;
+#undef SEC_P
+#undef SEC_V
 }
 
 struct Standup { float x0, y0, x1, y1; };
@@ -136,6 +148,7 @@ __global__ __launch_bounds__(kBlock) void k_rotate_iou(const float *__restrict__
                                                       const float *__restrict__ qboxes, int K, int criterion,
                                                       float *__restrict__ iou) {
     __shared__ float qc[64][9];   // corners of the 64 query boxes of this column tile (+1 pad)
+    __shared__ float clip_scratch[24][kBlock];   // per-thread vertex lists of the clipper
     __shared__ float qa[64];
     int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int kq = blockIdx.y * 64 + lane;
@@ -161,7 +174,7 @@ __global__ __launch_bounds__(kBlock) void k_rotate_iou(const float *__restrict__
         float c2[8];
         box_corners(c2, boxes + (size_t)n * 5);
         float a2 = boxes[(size_t)n * 5 + 2] * boxes[(size_t)n * 5 + 3];
-        float in = far_apart(standup_of(c1), standup_of(c2)) ? 0.0f : quad_inter(c1, c2);
+        float in = far_apart(standup_of(c1), standup_of(c2)) ? 0.0f : quad_inter<kBlock>(c1, c2, &clip_scratch[0][threadIdx.x]);
         float v;
         if (criterion == -1) v = in / (a1 + a2 - in);
         else if (criterion == 0) v = in / a1;
@@ -193,6 +206,7 @@ __global__ __launch_bounds__(kBlock) void k_nms_mask(const float *__restrict__ d
     __shared__ unsigned long long sup_words[64];
     __shared__ unsigned short queue[64 * 64];
     __shared__ int qcount;
+    __shared__ float clip_scratch[24][kBlock];   // per-thread vertex lists of the clipper
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const float *base = dets + (size_t)b * max_n * stride;
     if (tid == 0) qcount = 0;
@@ -266,7 +280,7 @@ __global__ __launch_bounds__(kBlock) void k_nms_mask(const float *__restrict__ d
         float c1[8], c2[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) { c1[i] = tile[1][rl][i]; c2[i] = tile[0][cl][i]; }
-        float in = quad_inter(c1, c2);
+        float in = quad_inter<kBlock>(c1, c2, &clip_scratch[0][tid]);
         float v = in / (tile[1][rl][8] + tile[0][cl][8] - in);
         if (semantics == 1 ? v >= thresh : v > thresh) atomicOr(&sup_words[rl], 1ull << cl);
     }
