@@ -670,7 +670,7 @@ static int launch_conv2d_halo_pipe(const void *x, const void *wpk, const float *
 // LDS holds only the halo (46 KB -> 3 workgroups per CU, 2200 / 768 = 2.9 rounds), the main loop has no barrier,
 // and LDS traffic drops to one conflict-free ds_read_b128 per MFMA.
 template <typename T, int CIN, int TH>
-__global__ __launch_bounds__(256, 3) void k_conv2d_halo_reg(const T *__restrict__ x, const T *__restrict__ wpk,
+__global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(const T *__restrict__ x, const T *__restrict__ wpk,
                                                             const float *__restrict__ bias, T *__restrict__ y,
                                                             Conv2dParams p, int tiles_y, int tiles_x, int per_xcd) {
     constexpr int TW = 16, HW_ = TW + 2, HPIX = (TH + 2) * (TW + 2);

@@ -225,7 +225,8 @@ static int conv_swizzle() {
 #define SEC_SK_MIN_WAVES 5
 #endif
 template <typename T, typename OT, int CIN, int COUT, int NW>
-__global__ __launch_bounds__(NW * 64, SEC_SK_MIN_WAVES) void k_conv_mfma_sk(const T *__restrict__ feat, const T *__restrict__ packed,
+__global__ __launch_bounds__(NW * 64, (CIN * COUT > 64 * 64) ? 2 : SEC_SK_MIN_WAVES) void k_conv_mfma_sk(   // wide shapes: registers over occupancy (no spills)
+    const T *__restrict__ feat, const T *__restrict__ packed,
                                                         const int *__restrict__ nbr, int n_out,
                                                         const int *__restrict__ num_out_dev, int kvol,
                                                         const float *__restrict__ scale, const float *__restrict__ shift,
