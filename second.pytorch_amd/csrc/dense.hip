@@ -997,6 +997,11 @@ static int launch_conv1x1_chain(const void *x, long long m, const void *w1, cons
     return check_launch();
 }
 
+#ifdef SEC_CONV2D_EXPERIMENTS
+constexpr bool kConv2dExperiments = true;
+#else
+constexpr bool kConv2dExperiments = false;   // default build: halo_reg (3x3 s1), 1x1 kernels, LDS-DMA implicit GEMM (everything else)
+#endif
 static int conv2d_variant() {
     static int v = -1;
     if (v < 0) { const char *e = getenv("SEC_CONV2D_VARIANT"); v = e ? atoi(e) : 13; }  // 0 register staged, 1 LDS-DMA implicit GEMM, 2/3/4 halo tile 16x16 / 8x16 / 8x16 with 8 waves
@@ -1008,6 +1013,7 @@ static int launch_conv2d(const void *x, const void *wpk, const float *bias, void
     dim3 block(kBlock);
     if (conv2d_variant() == 13 && p.ksize == 3 && p.stride == 1 && p.pad == 1 && p.cout % 128 == 0 && (p.cin == 128 || p.cin == 64))
         return p.cin == 128 ? launch_conv2d_halo_reg<T, 128, 8>(x, wpk, bias, y, p, st) : launch_conv2d_halo_reg<T, 64, 8>(x, wpk, bias, y, p, st);
+#ifdef SEC_CONV2D_EXPERIMENTS   // earlier 3x3 kernels (LDS weight slabs / rings), kept for A/B builds: DESIGN.md section 4
     if (conv2d_variant() >= 5 && conv2d_variant() <= 12 && p.ksize == 3 && p.stride == 1 && p.pad == 1 && p.cout % 128 == 0 &&
         (p.cin == 128 || p.cin == 64)) {
         // 8 waves / 16 KB slabs / ring 2 with: 5 linear key   10 column key   11 fragment pipelining   12 both
@@ -1032,6 +1038,7 @@ static int launch_conv2d(const void *x, const void *wpk, const float *bias, void
             return p.cin == 128 ? launch_conv2d_halo<T, 128, 8, 4>(x, wpk, bias, y, p, st) : launch_conv2d_halo<T, 64, 8, 4>(x, wpk, bias, y, p, st);
         return p.cin == 128 ? launch_conv2d_halo<T, 128, 8, 2>(x, wpk, bias, y, p, st) : launch_conv2d_halo<T, 64, 8, 2>(x, wpk, bias, y, p, st);
     }
+#endif
     if (conv2d_variant() >= 1 && p.ksize == 1 && p.stride == 1 && p.pad == 0 && p.cin == 128) {
         constexpr int TPW = 4;
         const int gx1 = div_up(div_up(p.m, 128), TPW);
@@ -1043,7 +1050,7 @@ static int launch_conv2d(const void *x, const void *wpk, const float *bias, void
                                bias, (T *)y, p);
         return check_launch();
     }
-    if (conv2d_variant() >= 1) {
+    if (conv2d_variant() >= 1 || !kConv2dExperiments) {
         const int gx = (div_up(p.m, 128) + 7) / 8 * 8;   // multiple of 8 for the XCD-aware tile order
         if (p.cout % 128 == 0)
             hipLaunchKernelGGL((k_conv2d_nhwc_dma<T, 128>), dim3(gx, p.cout / 128), block, 0, st, (const T *)x,
@@ -1053,6 +1060,7 @@ static int launch_conv2d(const void *x, const void *wpk, const float *bias, void
                                (const T *)wpk, bias, (T *)y, p);
         return check_launch();
     }
+#ifdef SEC_CONV2D_EXPERIMENTS
     if (p.cout % 128 == 0) {
         hipLaunchKernelGGL((k_conv2d_nhwc<T, 128>), dim3(div_up(p.m, 128), p.cout / 128), block, 0, st, (const T *)x,
                            (const T *)wpk, bias, (T *)y, p);
@@ -1060,6 +1068,7 @@ static int launch_conv2d(const void *x, const void *wpk, const float *bias, void
         hipLaunchKernelGGL((k_conv2d_nhwc<T, 64>), dim3(div_up(p.m, 128), p.cout / 64), block, 0, st, (const T *)x,
                            (const T *)wpk, bias, (T *)y, p);
     }
+#endif
     return check_launch();
 }
 

@@ -212,7 +212,14 @@ __device__ __forceinline__ int xcd_tile(int b, int n, int swz) {
     return t;   // may be >= n for the padded tail: callers bounds-check rows
 }
 
+#ifdef SEC_CONV_TIMELINE   // profiling builds only (tools/conv_microbench.py --timeline)
 __device__ long long *g_timeline = nullptr;
+#define SEC_TL_DECL long long *tl = g_timeline; long long t0 = 0, t1 = 0, t2 = 0, t3 = 0
+#define SEC_TL_STAMP(x) do { if (tl) x = clock64(); } while (0)
+#else
+#define SEC_TL_DECL
+#define SEC_TL_STAMP(x) do {} while (0)
+#endif
 
 static int conv_swizzle() {
     static int v = -1;
@@ -231,9 +238,8 @@ __global__ __launch_bounds__(NW * 64, (CIN * COUT > 64 * 64) ? 2 : SEC_SK_MIN_WA
                                                         const int *__restrict__ num_out_dev, int kvol,
                                                         const float *__restrict__ scale, const float *__restrict__ shift,
                                                         int relu, OT *__restrict__ out) {
-    long long *tl = g_timeline;
-    long long t0 = 0, t1 = 0, t2 = 0, t3 = 0;
-    if (tl) t0 = clock64();
+    SEC_TL_DECL;
+    SEC_TL_STAMP(t0);
     constexpr int KS = CIN / 16, NT = (COUT + 31) / 32, NREG = NT * 16;
     static_assert(NREG % NW == 0, "registers must split evenly over the waves");
     __shared__ float red[2][NREG][64];
@@ -254,7 +260,7 @@ __global__ __launch_bounds__(NW * 64, (CIN * COUT > 64 * 64) ? 2 : SEC_SK_MIN_WA
     const int *nrow = nbr + (size_t)(valid ? row : 0) * kvol;
     const uint4 *wp = reinterpret_cast<const uint4 *>(packed) + lane;
 
-    if (tl) t1 = clock64();
+    SEC_TL_STAMP(t1);
     const int ablate = (relu >> 8) & 0xff;  // debug/profiling only (SEC_CONV_ABLATE): bit0 gather row 0, bit1 one W block, bit2 no MFMA
     int idx = (valid && w < kvol) ? nrow[w] : -1;
     for (int k = w; k < kvol; k += NW) {
@@ -287,7 +293,7 @@ __global__ __launch_bounds__(NW * 64, (CIN * COUT > 64 * 64) ? 2 : SEC_SK_MIN_WA
             for (int t = 0; t < NT; ++t) acc[t] = Mfma<T>::run(wk[(s * NT + t) * 64], a[s], acc[t]);   // D^T: lane = one row
     }
     relu &= 0xff;
-    if (tl) t2 = clock64();
+    SEC_TL_STAMP(t2);
     // pairwise LDS reduction in the MFMA register layout (2 slots = 16 KB instead of NW slots: LDS no longer caps
     // the occupancy): waves 1,3 -> 0,2 ; wave 2 -> 0 ; then waves 0..NW-1 each finish 1/NW of the registers
     static_assert(NW == 4, "pairwise reduction is written for 4 waves");
@@ -312,7 +318,7 @@ __global__ __launch_bounds__(NW * 64, (CIN * COUT > 64 * 64) ? 2 : SEC_SK_MIN_WA
             for (int i = 0; i < 16; ++i) red[w >> 1][t * 16 + i][lane] = acc[t][i];
     }
     __syncthreads();
-    if (tl) t3 = clock64();
+    SEC_TL_STAMP(t3);
     // transposed accumulators (weights were the first MFMA operand): a lane owns output row base + r and, per group of
     // four registers, four CONSECUTIVE channels t*32 + 8g + 4h + (0..3): one 8-byte store instead of four 2-byte scatters
     constexpr int PER = NREG / NW;
@@ -329,11 +335,13 @@ __global__ __launch_bounds__(NW * 64, (CIN * COUT > 64 * 64) ? 2 : SEC_SK_MIN_WA
             if (valid) store4<OT>(out + (size_t)row * COUT + c0, v[0], v[1], v[2], v[3]);
         }
     }
+#ifdef SEC_CONV_TIMELINE
     if (tl && lane == 0) {
         long long *rec = tl + ((size_t)blockIdx.x * NW + w) * 6;
         rec[0] = t0; rec[1] = t1; rec[2] = t2; rec[3] = t3; rec[4] = clock64();
         rec[5] = __builtin_amdgcn_s_getreg((4 << 11) | 20);  // HW_REG_XCC_ID etc. (informative only)
     }
+#endif
 }
 
 // Split-K + cout-sliced variant: grid.y selects a 32-column slice of the output, so a wave carries 16 accumulator
@@ -1472,9 +1480,11 @@ static size_t elt_size(int dtype) { return dtype == SEC_F32 ? 4 : 2; }
 
 using namespace sec;
 
+#ifdef SEC_CONV_TIMELINE
 extern "C" __attribute__((visibility("default"))) int sec__debug_timeline(long long *buf) {
     return hipMemcpyToSymbol(HIP_SYMBOL(sec::g_timeline), &buf, sizeof(buf)) == hipSuccess ? 0 : -4;
 }
+#endif
 
 SEC_API size_t sec_packed_weight_bytes(int kvol, int cin, int cout, int dtype) {
     if (dtype == SEC_F32 || cin % 16 != 0 || kvol <= 0 || cout <= 0) return 0;

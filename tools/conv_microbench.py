@@ -23,7 +23,7 @@ def main():
     ap.add_argument("--layer", default="subm2")
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--sorted", action="store_true", help="spatially sorted clouds (rows in (z,y,x) order per frame)")
-    ap.add_argument("--timeline", action="store_true", help="per-wave clock64 timeline of the split-K kernel")
+    ap.add_argument("--timeline", action="store_true", help="per-wave clock64 timeline of the split-K kernel (needs a build with SEC_EXTRA_HIPCC_FLAGS=-DSEC_CONV_TIMELINE)")
     ap.add_argument("--backward", action="store_true", help="also time sec_indice_conv_bwd (dgrad + wgrad), bf16 and fp32")
     args = ap.parse_args()
     dev = torch.device("cuda")
