@@ -220,6 +220,9 @@ def main():
     ap.add_argument("--point-order", default="shuffle", choices=["shuffle", "sorted"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stages", action="store_true", help="also print per-stage timings to stderr")
+    ap.add_argument("--branches", type=int, default=2,
+                    help="graph mode: capture the batch as this many independent half-batch chains on separate streams of "
+                         "ONE hipGraph (latency-bound kernels overlap); 1 = a single chain")
     ap.add_argument("--workload", default="car.fhd", choices=sorted(WORKLOADS),
                     help="car.fhd (default, the BASELINE metric) or another BASELINE config for a side measurement")
     args = ap.parse_args()
@@ -257,7 +260,11 @@ def main():
         if args.mode != "eager":
             det.calibrate(points, offsets)
         if args.mode == "graph":
-            replay, out = det.make_graphed(points, offsets)
+            if args.branches > 1:
+                replay, outs, _ = det.make_graphed(points, offsets, branches=args.branches)
+                out = {"valid": torch.cat([o["valid"] for o in outs])}
+            else:
+                replay, out = det.make_graphed(points, offsets)
             step = replay
         elif args.mode == "static":
             step = lambda: det.forward_points(points, offsets, static=True)
@@ -280,7 +287,7 @@ def main():
         # the launch stream (events cannot be timed inside a captured graph; a single event pair around one
         # ~40 us launch would add ~10 us of launch gap).  profiles/ holds the rocprofv3 cross-check.
         timer.enabled = True
-        det.forward_points(points, offsets, static=args.mode != "eager")
+        det.forward_points(points, offsets)     # eager full batch: exact row counts whatever the graph's branch capacities
         torch.cuda.synchronize()
         timer.enabled = False
         ops.set_conv_profiler(None)
@@ -330,7 +337,8 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": WL["desc"],
-                       "frames_per_step_per_gpu": WL["batch"], "parallelism": f"frame-dp{world}", "launch_mode": args.mode},
+                       "frames_per_step_per_gpu": WL["batch"], "parallelism": f"frame-dp{world}", "launch_mode": args.mode,
+                       "graph_branches": args.branches if args.mode == "graph" else None},
             "roofline": roof,
             "roofline_mfma": roof_mfma,     # second-largest consumer by kind: the dense RPN conv, MFMA bound
         }

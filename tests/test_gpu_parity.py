@@ -763,3 +763,25 @@ def test_detector_empty_and_tiny_frames(syn):
             assert torch.equal(ref["boxes"][src][m], out["boxes"][dst][m])
     only_empty = run([empty], False)                         # must simply run
     assert only_empty["valid"].shape[0] == 1
+
+
+def test_detector_branched_graph_matches_eager(syn):
+    """make_graphed(branches=2): two half-batch chains on two streams of one hipGraph == the eager per-frame results."""
+    from second_amd.models import SecondDetector, CAR_FHD
+    torch.manual_seed(0)
+    det = SecondDetector(CAR_FHD).cuda().prepare_inference(torch.bfloat16)
+    clouds = [syn.syn_kitti_cloud(s, num_points=6000 + 700 * s, num_voxels=5000 + 500 * s) for s in range(5)]
+    pts, offs = syn.batch_clouds(clouds)
+    pts, offs = dev(pts), dev(offs)
+    with torch.no_grad():
+        e = det.forward_points(pts, offs)
+        replay, outs, parts = det.make_graphed(pts, offs, branches=2)
+        replay()
+        replay()
+        torch.cuda.synchronize()
+        det.check_overflow()
+    assert len(outs) == 2 and sum(o["valid"].shape[0] for o in outs) == 5
+    got = {k: torch.cat([o[k] for o in outs]) for k in ("valid", "scores", "boxes")}
+    assert torch.equal(e["valid"], got["valid"])
+    m = e["valid"]
+    assert torch.equal(e["scores"][m], got["scores"][m]) and torch.equal(e["boxes"][m], got["boxes"][m])
