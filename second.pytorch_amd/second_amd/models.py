@@ -235,9 +235,13 @@ class SpMiddleFHD(nn.Module):
         side = None
         if num_active_dev is not None and self.overlap_rulebooks:
             # static pipeline: all 8 rulebooks on a side stream, overlapped with the conv layers (fork / join)
+            # one side stream per launching stream: branches of a branched graph must not share it
             if self._side_stream is None:
-                self._side_stream = torch.cuda.Stream()
-            side = self._side_stream
+                self._side_stream = {}
+            key = torch.cuda.current_stream().cuda_stream
+            if key not in self._side_stream:
+                self._side_stream[key] = torch.cuda.Stream()
+            side = self._side_stream[key]
             x.planned = self.middle_conv.plan_rulebooks(x, side)
         x = self.middle_conv(x)
         if side is not None:
@@ -596,6 +600,9 @@ class SecondDetector(nn.Module):
         return replay, outs, parts
 
     def _capture(self, parts, warmup):
+        mfe = self.middle_feature_extractor
+        if len(parts) > 1 and getattr(mfe, "overlap_rulebooks", False):
+            mfe.overlap_rulebooks = False     # the (experimental) side-stream rulebook planner is a single-chain feature
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s), torch.no_grad():
