@@ -247,8 +247,9 @@ def main():
     clouds, points, offsets = build_inputs(rank, device, args.point_order)
     det, cpu_state = build_detector(device, dtype)
 
+    # first subm2 layer (64->64 SubM on the 11x400x352 grid): the largest 64->64 3x3x3 launch of the forward
     timer = ConvCapture(lambda m: m["cin"] == 64 and m["cout"] == 64 and m["kvol"] == 27 and m["n_in"] == m["n_out"]
-                        and m["n_out"] > 30000)  # first subm2 layer (64->64 on the 11x400x352 grid)
+                        and m["n_out"] > 20000)
     ops.set_conv_profiler(timer)
 
     def barrier():
@@ -261,7 +262,7 @@ def main():
             det.calibrate(points, offsets)
         if args.mode == "graph":
             if args.branches > 1:
-                replay, outs, _ = det.make_graphed(points, offsets, branches=args.branches)
+                replay, outs, graph_parts = det.make_graphed(points, offsets, branches=args.branches)
                 out = {"valid": torch.cat([o["valid"] for o in outs])}
             else:
                 replay, out = det.make_graphed(points, offsets)
@@ -286,12 +287,37 @@ def main():
         # right after the timed region, then re-issue that launch 100x back-to-back between two HIP events on
         # the launch stream (events cannot be timed inside a captured graph; a single event pair around one
         # ~40 us launch would add ~10 us of launch gap).  profiles/ holds the rocprofv3 cross-check.
+        # capture exactly the launch the timed region runs: with a branched graph that is the static forward of one branch
         timer.enabled = True
-        det.forward_points(points, offsets)     # eager full batch: exact row counts whatever the graph's branch capacities
+        if args.mode == "graph" and args.branches > 1:
+            det.forward_points(*graph_parts[0], static=True)
+            frames_in_launch = graph_parts[0][1].numel() - 1
+        else:
+            det.forward_points(points, offsets, static=args.mode != "eager")
+            frames_in_launch = WL["batch"]
         torch.cuda.synchronize()
         timer.enabled = False
-        ops.set_conv_profiler(None)
         t_kernel = time_kernel(timer.call) if timer.call is not None else None
+        # auxiliary: the same layer as ONE full-batch launch (what a single-chain graph, --branches 1, runs)
+        aux = None
+        if args.mode == "graph" and args.branches > 1 and timer.call is not None:
+            det.calibrate(points, offsets)
+            timer8 = ConvCapture(timer.select)
+            ops.set_conv_profiler(timer8)
+            timer8.enabled = True
+            det.forward_points(points, offsets, static=True)
+            torch.cuda.synchronize()
+            timer8.enabled = False
+            if timer8.call is not None:
+                m8 = timer8.call
+                rows8 = int(m8["num_out_dev"][0].item()) if m8.get("num_out_dev") is not None else m8["n_out"]
+                pairs8 = int((m8["nbr_out"][:rows8] >= 0).sum().item())
+                s8 = 2 if m8["dtype"] != torch.float32 else 4
+                b8 = s8 * (pairs8 * 64 + rows8 * 64) + 8 * pairs8 + s8 * 27 * 64 * 64
+                t8 = time_kernel(m8)
+                aux = {"frames": WL["batch"], "rows": rows8, "pairs": pairs8, "launch_us": round(t8 * 1e6, 2),
+                       "frac": round(b8 / t8 / 1e9 / HBM_PEAK_GBS, 4)}
+        ops.set_conv_profiler(None)
         roof_mfma = time_rpn_conv(det, WL["batch"]) if args.dtype == "bf16" else None
 
     if world > 1:
@@ -304,6 +330,7 @@ def main():
     if timer.call is not None:
         meta = timer.call
         s = 2 if meta["dtype"] != torch.float32 else 4
+        rows_kernel = meta["n_out"] >= 32768      # launch capacity decides the kernel (sec_indice_conv_fwd dispatch)
         rows = int(meta["num_out_dev"][0].item()) if meta.get("num_out_dev") is not None else meta["n_out"]
         pairs = int((meta["nbr_out"][:rows] >= 0).sum().item())
         meta = dict(meta, n_out=rows)
@@ -316,15 +343,18 @@ def main():
         try:
             with open(os.path.join(ROOT, "profiles", "r01_k_traffic.json")) as f:
                 tj = json.load(f)
-            if tj["rows"] == meta["n_out"] and tj["pairs"] == pairs and meta["mfma"]:
-                traffic = tj["traffic_bytes_per_launch"]
+            for ent in tj["entries"]:
+                if ent["rows"] == meta["n_out"] and ent["pairs"] == pairs and meta["mfma"] and rows_kernel:
+                    traffic = ent["traffic_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
         roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "kernel": "k_conv_rows<bf16,64,64,27> (SubMConv3d subm2, batch 8)" if meta["mfma"] else "k_conv_generic",
+                "kernel": (("k_conv_rows<bf16,64,64,27>" if rows_kernel else "k_conv_mfma_sk<bf16,64,64>") +
+                           f" (SubMConv3d subm2, {frames_in_launch} frames per launch)") if meta["mfma"] else "k_conv_generic",
                 "launch_us": round(t_mean * 1e6, 2), "launches_timed": 100, "alg_bytes_per_launch": b_alg,
-                "rows": meta["n_out"], "pairs": pairs, "frac_of_6.29TBs_measured_peak": round(ach / 6290.0, 4)}
+                "rows": meta["n_out"], "pairs": pairs, "frac_of_6.29TBs_measured_peak": round(ach / 6290.0, 4),
+                "same_layer_as_one_full_batch_launch": aux}
 
     if args.stages and rank == 0:
         stage_times(det, points, offsets)
