@@ -5,14 +5,17 @@
 
 One *step* = one pass of the whole hot path over one batch of 8 synthetic KITTI clouds that are already
 resident in HBM: points_to_voxel (+SimpleVoxel mean) -> 14 sparse conv layers (rulebooks + fused
-indice_conv) -> dense -> RPNV2 (bf16, MIOpen) -> decode / top-k / rotated NMS, detections left on the device.
+indice_conv) -> dense -> RPNV2 (bf16, hand-written MFMA convs) -> decode / top-k / rotated NMS, detections left on the device.
 Per-frame data parallel: every rank runs its own batch, no data-path collective ("weak" scaling).
+Default launch mode: ONE hipGraph replay per step; the batch is captured as two independent 4-frame chains on two
+streams of that graph (--branches 2), which overlaps the path's latency-bound kernels.
 
 Prints ONE JSON line on rank 0 with, besides the contract fields,
-  roofline     -- the SubMConv3d 64->64 gather-GEMM-scatter kernel (the kernel BASELINE.json's metric names):
-                  algorithmic bytes per launch / mean launch duration measured with HIP events on the launch
-                  stream inside the timed region, against the 8 TB/s HBM peak;
-  cpu_baseline -- the same forward on the host cores through the CPU oracle (kind "port"), rank 0, N=1 only.
+  roofline      -- the SubMConv3d 64->64 gather-GEMM kernel (the kernel BASELINE.json's metric names): algorithmic bytes
+                   per launch / mean launch duration (HIP events around 100 re-issues of the very launch the timed graph
+                   runs, right after the timed region), against the 8 TB/s HBM peak; `traffic` from committed PMC passes;
+  roofline_mfma -- the RPN 3x3 conv (largest share of the step, MFMA bound), timed the same way;
+  cpu_baseline  -- the same forward on the host cores through the CPU oracle (kind "port"), rank 0, N=1 only.
 """
 import argparse
 import json

@@ -8,7 +8,8 @@ produces the same numbers (tests/test_dropin_reference.py checks that in the bui
 
     SimpleVoxel      voxel_encoder.py:207-225   (fused into the voxeliser's epilogue on the native path)
     SpMiddleFHD      middle.py:111-210          (spconv.SubMConv3d / SparseConv3d stack)
-    RPNV2            rpn.py:202-420,468-497     (dense 2-D convs: torch/MIOpen bf16 channels-last)
+    RPNV2            rpn.py:202-420,468-497     (inference: hand-written MFMA convs, sec_conv2d_nhwc / sec_conv1x1_chain_nhwc;
+                                                 training and multi-block RPNs: torch convs)
     predict          voxelnet.py:377-645        (decode -> score filter -> top-k -> rotated NMS -> direction fix)
 """
 import math
@@ -343,9 +344,10 @@ def fold_conv_bn_(seq):
 
 class RPNInference(nn.Module):
     """Inference form of a single-block RPNV2: BatchNorm2d folded into the conv weights (scale) and a float32
-    bias, every conv issued bias-free through MIOpen followed by ONE fused in-place bias+ReLU pass
-    (sec_bias_act_nhwc), ZeroPad2d merged into the conv padding, the stride-1 1x1 ConvTranspose2d rewritten as
-    a 1x1 conv, the three 1x1 heads merged into one conv (output channels padded to a multiple of 8).
+    bias, ZeroPad2d merged into the conv padding, the stride-1 1x1 ConvTranspose2d rewritten as a 1x1 conv, the three
+    1x1 heads merged into one conv (output channels padded to a multiple of 64).  Every 3x3 conv runs on the
+    hand-written MFMA kernel with bias + ReLU fused (sec_conv2d_nhwc), the deblock + heads as one fused kernel
+    (sec_conv1x1_chain_nhwc); SEC_RPN_BACKEND=miopen keeps torch convs + one fused bias/ReLU pass for A/B runs.
     Same arithmetic as RPNV2.forward (rpn.py:314-331,393-420) up to bf16 rounding of the folded weights."""
 
     def __init__(self, rpn, dtype):
