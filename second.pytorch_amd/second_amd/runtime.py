@@ -9,6 +9,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libsecond_hip.so")
+LIB_PATH = os.environ.get("SEC_HIP_LIB", LIB_PATH)   # A/B builds: point at another libsecond_hip.so
 
 SEC_F32, SEC_F16, SEC_BF16 = 0, 1, 2
 _DTYPES = {torch.float32: SEC_F32, torch.float16: SEC_F16, torch.bfloat16: SEC_BF16}
