@@ -350,34 +350,57 @@ class RPNInference(nn.Module):
     (sec_conv1x1_chain_nhwc); SEC_RPN_BACKEND=miopen keeps torch convs + one fused bias/ReLU pass for A/B runs.
     Same arithmetic as RPNV2.forward (rpn.py:314-331,393-420) up to bf16 rounding of the folded weights."""
 
+    @staticmethod
+    def supports(rpn):
+        """Every deblock must be expressible as a plain conv: Conv2d(k = s, stride = s) ("upsample" stride < 1) or the
+        stride-1 1x1 ConvTranspose2d; a true k = s > 1 transposed conv (depth-to-space) keeps the torch path."""
+        for d in rpn.deblocks:
+            m = list(d.children())[0]
+            if isinstance(m, nn.ConvTranspose2d) and (m.kernel_size != (1, 1) or m.stride != (1, 1)):
+                return False
+        return len(rpn.blocks) >= 1 and len(rpn.deblocks) >= 1
+
     def __init__(self, rpn, dtype):
         super().__init__()
-        assert len(rpn.blocks) == 1 and len(rpn.deblocks) == 1
+        assert self.supports(rpn)
         self.a, self.codes = rpn._num_anchor_per_loc, (rpn._box_code_size, rpn._num_class, rpn._num_direction_bins)
-        layers, pad = [], 0
-        mods = list(rpn.blocks[0].children()) + list(rpn.deblocks[0].children())
-        i = 0
-        while i < len(mods):
-            m = mods[i]
-            if isinstance(m, nn.ZeroPad2d):
-                pad = m.padding[0]
-            elif isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
-                bn = mods[i + 1]
-                assert isinstance(bn, nn.BatchNorm2d) and m.bias is None
-                scale = bn.weight.float() * torch.rsqrt(bn.running_var.float() + bn.eps)
-                bias = bn.bias.float() - bn.running_mean.float() * scale
-                w = m.weight.detach().float()
-                if isinstance(m, nn.ConvTranspose2d):
-                    assert m.kernel_size == (1, 1) and m.stride == (1, 1)
-                    w = w.permute(1, 0, 2, 3)
-                    stride, padding = [1, 1], [0, 0]
-                else:
-                    stride, padding = list(m.stride), [m.padding[0] + pad, m.padding[1] + pad]
-                w = (w * scale.view(-1, 1, 1, 1)).to(dtype).contiguous(memory_format=torch.channels_last)
-                layers.append((w, bias.detach().contiguous(), stride, padding))
-                pad = 0
+
+        def fold(mods):
+            out, pad, i = [], 0, 0
+            while i < len(mods):
+                m = mods[i]
+                if isinstance(m, nn.ZeroPad2d):
+                    pad = m.padding[0]
+                elif isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+                    bn = mods[i + 1]
+                    assert isinstance(bn, nn.BatchNorm2d) and m.bias is None
+                    scale = bn.weight.float() * torch.rsqrt(bn.running_var.float() + bn.eps)
+                    bias = bn.bias.float() - bn.running_mean.float() * scale
+                    w = m.weight.detach().float()
+                    if isinstance(m, nn.ConvTranspose2d):
+                        w = w.permute(1, 0, 2, 3)
+                        stride, padding = [1, 1], [0, 0]
+                    else:
+                        stride, padding = list(m.stride), [m.padding[0] + pad, m.padding[1] + pad]
+                    w = (w * scale.view(-1, 1, 1, 1)).to(dtype).contiguous(memory_format=torch.channels_last)
+                    out.append((w, bias.detach().contiguous(), stride, padding))
+                    pad = 0
+                    i += 1
                 i += 1
-            i += 1
+            return out
+        # execution plan over a flat layer list: ("c", i) = conv layer i of a block, ("u", i) = deblock conv i whose output
+        # is one of the concatenated feature maps
+        layers, self.plan = [], []
+        up0 = rpn._upsample_start_idx
+        for bi, blk in enumerate(rpn.blocks):
+            for l in fold(list(blk.children())):
+                self.plan.append(("c", len(layers)))
+                layers.append(l)
+            if bi - up0 >= 0:
+                (l,) = fold(list(rpn.deblocks[bi - up0].children()))
+                self.plan.append(("u", len(layers)))
+                layers.append(l)
+        single = len(rpn.blocks) == 1
         self.ws = nn.ParameterList([nn.Parameter(w, requires_grad=False) for w, _, _, _ in layers])
         self.bs = nn.ParameterList([nn.Parameter(b, requires_grad=False) for _, b, _, _ in layers])
         self.cfgs = [(s, p) for _, _, s, p in layers]
@@ -411,22 +434,33 @@ class RPNInference(nn.Module):
             self.use_hip = self.head_packed is not None
         # deblock (1x1, stride 1, 128 -> 128) + heads (<= 128 padded channels) run as ONE kernel (sec_conv1x1_chain_nhwc)
         wl = self.ws[-1]
-        self.chain_tail = (self.use_hip and tuple(wl.shape) == (128, 128, 1, 1) and self.cfgs[-1] == ([1, 1], [0, 0])
+        self.chain_tail = (single and self.use_hip and tuple(wl.shape) == (128, 128, 1, 1) and self.cfgs[-1] == ([1, 1], [0, 0])
                            and self.head_cout in (64, 128) and os.environ.get("SEC_RPN_CHAIN", "1") == "1")
 
-    def forward(self, x):
+    def _conv(self, x, i):
+        w, b, (s, p) = self.ws[i], self.bs[i], self.cfgs[i]
         if self.use_hip:
-            n_sep = len(self.ws) - 1 if self.chain_tail else len(self.ws)
-            for w, pk, b, (s, p) in list(zip(self.ws, self.packed, self.bs, self.cfgs))[:n_sep]:
-                x = ops.conv2d_nhwc(x, pk, b, w.shape[0], w.shape[2], s[0], p[0], relu=True)
-            if self.chain_tail:
-                y = ops.conv1x1_chain(x, self.packed[-1], self.bs[-1], self.head_packed, self.head_b64, self.head_cout)
+            return ops.conv2d_nhwc(x, self.packed[i], b, w.shape[0], w.shape[2], s[0], p[0], relu=True)
+        return ops.bias_act_(F.conv2d(x, w, None, s, p), b, relu=True)
+
+    def forward(self, x):
+        ups = []
+        for kind, i in self.plan:
+            if kind == "c":
+                x = self._conv(x, i)
+            elif self.chain_tail:
+                ups.append(None)                     # single block: the deblock runs fused with the heads below
             else:
-                y = ops.conv2d_nhwc(x, self.head_packed, self.head_b64, self.head_cout, 1, 1, 0, relu=False)
+                ups.append(self._conv(x, i))
+        if self.chain_tail:
+            y = ops.conv1x1_chain(x, self.packed[-1], self.bs[-1], self.head_packed, self.head_b64, self.head_cout)
         else:
-            for w, b, (s, p) in zip(self.ws, self.bs, self.cfgs):
-                x = ops.bias_act_(F.conv2d(x, w, None, s, p), b, relu=True)
-            y = ops.bias_act_(F.conv2d(x, self.head_w, None), self.head_b, relu=False)
+            f = ups[0] if len(ups) == 1 else torch.cat(ups, dim=1)    # channels_last in, channels_last out
+            if self.use_hip:
+                y = ops.conv2d_nhwc(f.contiguous(memory_format=torch.channels_last), self.head_packed, self.head_b64,
+                                    self.head_cout, 1, 1, 0, relu=False)
+            else:
+                y = ops.bias_act_(F.conv2d(f, self.head_w, None), self.head_b, relu=False)
         n, _, h, wd = y.shape
         ret, c0 = {}, 0
         for name, sz, code in zip(["box_preds", "cls_preds", "dir_cls_preds"], self.splits, self.codes):
@@ -485,8 +519,7 @@ class SecondDetector(nn.Module):
         # 3x3 conv for bf16 NHWC on gfx950 (naive fallback kernel) vs 0.14 ms unfused -- not an option; the
         # fused dense path is the hand-written MFMA conv.
         self.eval()
-        if (isinstance(self.rpn, RPNV2) and len(self.rpn.blocks) == 1 and len(self.rpn.deblocks) == 1
-                and next(self.parameters()).is_cuda):
+        if isinstance(self.rpn, RPNV2) and RPNInference.supports(self.rpn) and next(self.parameters()).is_cuda:
             self.rpn = RPNInference(self.rpn, dtype)
         else:
             self.rpn.blocks = nn.ModuleList([fold_conv_bn_(b) for b in self.rpn.blocks])

@@ -495,6 +495,36 @@ def test_rpn_inference_form_matches_module(golden):
         assert err < 3e-2, (k, err)
 
 
+def test_rpn_inference_multi_block_pointpillars_shape():
+    """The 3-block RPN of nuscenes/all.pp.largea (strided first convs, k = s strided "upsample" convs, 1x1 deblock, 384-channel
+    concat, 228 -> 256 padded head channels) entirely on sec_conv2d_nhwc: bf16 kernels vs the fp32 module, and the fp32
+    folded form (torch convs) tight against it."""
+    from second_amd.models import RPNV2, RPNInference, ALL_PP_LARGEA, anchors_per_location
+    torch.manual_seed(0)
+    cfg = ALL_PP_LARGEA
+    net = RPNV2(num_class=cfg["num_class"], num_anchor_per_loc=anchors_per_location(cfg),
+                num_direction_bins=cfg["num_direction_bins"], **cfg["rpn"]).cuda().eval()
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.uniform_(-0.1, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.uniform_(-0.2, 0.2)
+    assert RPNInference.supports(net) and len(net.blocks) == 3
+    x = torch.randn(2, 64, 96, 80, device="cuda")
+    with torch.no_grad():
+        ref = net(x)
+        f32 = RPNInference(net, torch.float32)(x.contiguous(memory_format=torch.channels_last))
+        inf = RPNInference(net, torch.bfloat16)
+        assert inf.use_hip and not inf.chain_tail
+        bf = inf(x.bfloat16().contiguous(memory_format=torch.channels_last))
+    for k in ref:
+        assert f32[k].shape == ref[k].shape == bf[k].shape
+        np.testing.assert_allclose(f32[k].cpu().numpy(), ref[k].cpu().numpy(), rtol=2e-3, atol=2e-4)
+        err = (bf[k].float() - ref[k]).abs().max().item() / ref[k].abs().max().item()
+        assert err < 4e-2, (k, err)
+
+
 # ------------------------------------------------------------------ PointPillars front end / block filter
 def test_pfn_kernel_matches_reference_module_and_oracle(ops, golden):
     g = golden("torch_modules")
