@@ -224,9 +224,13 @@ def main():
     ap.add_argument("--point-order", default="shuffle", choices=["shuffle", "sorted"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stages", action="store_true", help="also print per-stage timings to stderr")
-    ap.add_argument("--branches", type=int, default=2,
-                    help="graph mode: capture the batch as this many independent half-batch chains on separate streams of "
-                         "ONE hipGraph (latency-bound kernels overlap); 1 = a single chain")
+    ap.add_argument("--inflight", type=int, default=3,
+                    help="graph mode: number of steps (graph replays, each a full pass over the batch with its own activation "
+                         "buffers) kept in flight on separate HIP streams; the latency-bound sparse stages of one step then "
+                         "overlap the MFMA-bound RPN of another.  1 = strictly one step at a time")
+    ap.add_argument("--branches", type=int, default=1,
+                    help="graph mode: capture the batch as this many independent frame-group chains on separate streams of "
+                         "ONE hipGraph (the single-step-latency variant of --inflight); 1 = a single chain")
     ap.add_argument("--workload", default="car.fhd", choices=sorted(WORKLOADS),
                     help="car.fhd (default, the BASELINE metric) or another BASELINE config for a side measurement")
     args = ap.parse_args()
@@ -265,12 +269,25 @@ def main():
         if args.mode != "eager":
             det.calibrate(points, offsets)
         if args.mode == "graph":
-            if args.branches > 1:
-                replay, outs, graph_parts = det.make_graphed(points, offsets, branches=args.branches)
-                out = {"valid": torch.cat([o["valid"] for o in outs])}
+            replays = []
+            for _ in range(max(1, args.inflight)):       # every in-flight step owns its graph and activation buffers
+                if args.branches > 1:
+                    replay, outs, graph_parts = det.make_graphed(points, offsets, branches=args.branches)
+                    out = {"valid": torch.cat([o["valid"] for o in outs])}
+                else:
+                    replay, out = det.make_graphed(points, offsets)
+                replays.append(replay)
+            if len(replays) == 1:
+                step = replays[0]
             else:
-                replay, out = det.make_graphed(points, offsets)
-            step = replay
+                lanes = [torch.cuda.Stream() for _ in replays]
+                counter = [0]
+
+                def step():
+                    k = counter[0] % len(replays)
+                    counter[0] += 1
+                    with torch.cuda.stream(lanes[k]):     # same-lane replays serialise; different lanes overlap
+                        replays[k]()
         elif args.mode == "static":
             step = lambda: det.forward_points(points, offsets, static=True)
         else:
@@ -283,6 +300,13 @@ def main():
             r = step()
         barrier()
         elapsed = time.perf_counter() - t0
+        latency_ms = None
+        if args.mode == "graph":   # one step alone, start to finish (what --inflight 1 would run back to back)
+            t1 = time.perf_counter()
+            for _ in range(20):
+                replays[0]()
+                torch.cuda.synchronize()
+            latency_ms = round((time.perf_counter() - t1) / 20 * 1e3, 4)
         if args.mode != "graph":
             out = r
         if args.mode != "eager":
@@ -372,7 +396,9 @@ def main():
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": WL["desc"],
                        "frames_per_step_per_gpu": WL["batch"], "parallelism": f"frame-dp{world}", "launch_mode": args.mode,
-                       "graph_branches": args.branches if args.mode == "graph" else None},
+                       "graph_branches": args.branches if args.mode == "graph" else None,
+                       "steps_in_flight": max(1, args.inflight) if args.mode == "graph" else 1,
+                       "single_step_latency_ms": latency_ms},
             "roofline": roof,
             "roofline_mfma": roof_mfma,     # second-largest consumer by kind: the dense RPN conv, MFMA bound
         }
