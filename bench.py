@@ -269,25 +269,13 @@ def main():
         if args.mode != "eager":
             det.calibrate(points, offsets)
         if args.mode == "graph":
-            replays = []
-            for _ in range(max(1, args.inflight)):       # every in-flight step owns its graph and activation buffers
-                if args.branches > 1:
-                    replay, outs, graph_parts = det.make_graphed(points, offsets, branches=args.branches)
-                    out = {"valid": torch.cat([o["valid"] for o in outs])}
-                else:
-                    replay, out = det.make_graphed(points, offsets)
-                replays.append(replay)
-            if len(replays) == 1:
-                step = replays[0]
-            else:
-                lanes = [torch.cuda.Stream() for _ in replays]
-                counter = [0]
-
-                def step():
-                    k = counter[0] % len(replays)
-                    counter[0] += 1
-                    with torch.cuda.stream(lanes[k]):     # same-lane replays serialise; different lanes overlap
-                        replays[k]()
+            from second_amd.models import InFlightRunner
+            runner = InFlightRunner(det, points, offsets, inflight=args.inflight, branches=args.branches)
+            graph_parts = runner.parts      # branches > 1: the roofline probe below times one branch's launch
+            replays = runner.replays
+            outs = runner.outputs[-1]
+            out = {"valid": torch.cat([o["valid"] for o in outs])} if args.branches > 1 else outs
+            step = runner.step
         elif args.mode == "static":
             step = lambda: det.forward_points(points, offsets, static=True)
         else:

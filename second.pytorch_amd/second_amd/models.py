@@ -762,6 +762,43 @@ class SecondDetector(nn.Module):
         return res
 
 
+class InFlightRunner:
+    """Serving loop with several steps in flight: ``inflight`` captured forwards (hipGraphs with their own activation
+    buffers, all reading the same resident input buffers) are replayed round-robin on their own HIP streams.  Replays on
+    one lane serialise, different lanes overlap -- the latency-bound sparse stages of one step run beside the MFMA-bound
+    RPN of another (car.fhd, batch 8: 5600 -> 7200 frames/s with three lanes; more lanes add nothing).
+
+    ``step()`` enqueues one full forward and returns (outputs, stream): the output tensors of that lane, valid once
+    ``stream`` has been synchronised (or after :meth:`synchronize`) and until the lane is stepped again."""
+
+    def __init__(self, det, points, point_offsets, inflight=3, branches=1):
+        self.det = det
+        self.replays, self.outputs, self.parts = [], [], None
+        for _ in range(max(1, int(inflight))):
+            if branches > 1:
+                replay, outs, self.parts = det.make_graphed(points, point_offsets, branches=branches)
+            else:
+                replay, outs = det.make_graphed(points, point_offsets)
+            self.replays.append(replay)
+            self.outputs.append(outs)
+        self.lanes = [torch.cuda.Stream() for _ in self.replays] if len(self.replays) > 1 else [None]
+        self._k = 0
+
+    def step(self):
+        k = self._k % len(self.replays)
+        self._k += 1
+        if self.lanes[k] is None:
+            self.replays[k]()
+            return self.outputs[k], torch.cuda.current_stream()
+        with torch.cuda.stream(self.lanes[k]):
+            self.replays[k]()
+        return self.outputs[k], self.lanes[k]
+
+    def synchronize(self):
+        torch.cuda.synchronize()
+        self.det.check_overflow()
+
+
 def decode_boxes(enc, anc):
     """GroundBox3dCoder.decode (second_box_decode, second/pytorch/core/box_torch_ops.py:56-101)."""
     xa, ya, za, wa, la, ha, ra = anc.unbind(-1)

@@ -817,10 +817,10 @@ def test_detector_branched_graph_matches_eager(syn):
     assert torch.equal(e["scores"][m], got["scores"][m]) and torch.equal(e["boxes"][m], got["boxes"][m])
 
 
-def test_detector_two_graphs_in_flight(syn):
-    """Two captured forwards with their own activation buffers replayed concurrently on two streams (the bench's
-    --inflight pipelining) leave each other's results intact and equal the eager path."""
-    from second_amd.models import SecondDetector, CAR_FHD
+def test_detector_steps_in_flight(syn):
+    """InFlightRunner: captured forwards with their own activation buffers replayed concurrently on separate streams (the
+    bench's --inflight pipelining) leave each other's results intact and equal the eager path."""
+    from second_amd.models import SecondDetector, CAR_FHD, InFlightRunner
     torch.manual_seed(0)
     det = SecondDetector(CAR_FHD).cuda().prepare_inference(torch.bfloat16)
     pts, offs = syn.batch_clouds([syn.syn_kitti_cloud(s, num_points=7000, num_voxels=6000) for s in range(3)])
@@ -828,17 +828,14 @@ def test_detector_two_graphs_in_flight(syn):
     with torch.no_grad():
         e = det.forward_points(pts, offs)
         det.calibrate(pts, offs)
-        (r1, o1), (r2, o2) = det.make_graphed(pts, offs), det.make_graphed(pts, offs)
-        s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
-        torch.cuda.synchronize()
-        for _ in range(4):
-            with torch.cuda.stream(s1):
-                r1()
-            with torch.cuda.stream(s2):
-                r2()
-        torch.cuda.synchronize()
-        det.check_overflow()
+        runner = InFlightRunner(det, pts, offs, inflight=3)
+        seen = []
+        for _ in range(7):
+            out, stream = runner.step()
+            seen.append(out)
+        runner.synchronize()
+    assert len({id(o) for o in seen}) == 3
     m = e["valid"]
-    for o in (o1, o2):
+    for o in runner.outputs:
         assert torch.equal(m, o["valid"])
         assert torch.equal(e["scores"][m], o["scores"][m]) and torch.equal(e["boxes"][m], o["boxes"][m])
