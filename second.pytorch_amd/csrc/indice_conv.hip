@@ -261,13 +261,11 @@ __global__ __launch_bounds__(NW * 64, (CIN * COUT > 64 * 64) ? 2 : SEC_SK_MIN_WA
     const uint4 *wp = reinterpret_cast<const uint4 *>(packed) + lane;
 
     SEC_TL_STAMP(t1);
-    const int ablate = (relu >> 8) & 0xff;  // debug/profiling only (SEC_CONV_ABLATE): bit0 gather row 0, bit1 one W block, bit2 no MFMA
     int idx = (valid && w < kvol) ? nrow[w] : -1;
     for (int k = w; k < kvol; k += NW) {
         int cur = idx;
         if (k + NW < kvol) idx = valid ? nrow[k + NW] : -1;  // prefetch this wave's next offset
         if (__ballot(cur >= 0) == 0ull) continue;
-        if ((ablate & 1) && cur >= 0) cur = 0;
         uint4 a[KS];
         const uint4 *src = reinterpret_cast<const uint4 *>(feat + (size_t)(cur >= 0 ? cur : 0) * CIN) + h;
 #pragma unroll
@@ -276,17 +274,7 @@ __global__ __launch_bounds__(NW * 64, (CIN * COUT > 64 * 64) ? 2 : SEC_SK_MIN_WA
             if (cur >= 0) v = src[s * 2];
             a[s] = v;
         }
-        const uint4 *wk = wp + (size_t)((ablate & 2) ? 0 : k) * KS * NT * 64;
-        if (ablate & 4) {
-#pragma unroll
-            for (int s = 0; s < KS; ++s)
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    uint4 b = wk[(s * NT + t) * 64];
-                    acc[t][0] += __uint_as_float(a[s].x ^ b.x);
-                }
-            continue;
-        }
+        const uint4 *wk = wp + (size_t)k * KS * NT * 64;
 #pragma unroll
         for (int s = 0; s < KS; ++s)
 #pragma unroll
@@ -1085,12 +1073,6 @@ static void launch_rows(const void *feat, const void *packed, const int *nbr, in
                        num_out_dev, scale, shift, relu, (T *)out);
 }
 
-static int conv_ablate() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("SEC_CONV_ABLATE"); v = e ? atoi(e) : 0; }
-    return v;
-}
-
 static int conv_variant() {
     static int v = -1;
     if (v < 0) {
@@ -1166,7 +1148,7 @@ static void launch_mfma(const void *feat, const void *packed, const int *nbr, in
         constexpr int NW = 4;
         hipLaunchKernelGGL((k_conv_mfma_sk<T, OT, CIN, COUT, NW>), dim3((div_up(n_out, 32) + 7) / 8 * 8), dim3(NW * 64), 0, st,
                            (const T *)feat, (const T *)packed, nbr, n_out, num_out_dev, kvol, scale, shift,
-                           relu | (conv_ablate() << 8) | (conv_swizzle() << 16), (OT *)out);
+                           relu | (conv_swizzle() << 16), (OT *)out);
         return;
     }
     int rows_per_block = (kBlock / 64) * 32 * MT;
