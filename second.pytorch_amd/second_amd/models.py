@@ -352,11 +352,13 @@ class RPNInference(nn.Module):
 
     @staticmethod
     def supports(rpn):
-        """Every deblock must be expressible as a plain conv: Conv2d(k = s, stride = s) ("upsample" stride < 1) or the
-        stride-1 1x1 ConvTranspose2d; a true k = s > 1 transposed conv (depth-to-space) keeps the torch path."""
+        """Every deblock must be expressible as a plain conv: Conv2d(k = s, stride = s) ("upsample" stride < 1), the
+        stride-1 1x1 ConvTranspose2d, or ConvTranspose2d(k = s, stride = s), which is a 1x1 conv to s*s*Cout channels
+        followed by a depth-to-space rearrangement."""
         for d in rpn.deblocks:
             m = list(d.children())[0]
-            if isinstance(m, nn.ConvTranspose2d) and (m.kernel_size != (1, 1) or m.stride != (1, 1)):
+            if isinstance(m, nn.ConvTranspose2d) and (m.kernel_size != m.stride or m.kernel_size[0] != m.kernel_size[1]
+                                                      or m.padding != (0, 0) or m.output_padding != (0, 0)):
                 return False
         return len(rpn.blocks) >= 1 and len(rpn.deblocks) >= 1
 
@@ -377,13 +379,18 @@ class RPNInference(nn.Module):
                     scale = bn.weight.float() * torch.rsqrt(bn.running_var.float() + bn.eps)
                     bias = bn.bias.float() - bn.running_mean.float() * scale
                     w = m.weight.detach().float()
+                    up = 1
                     if isinstance(m, nn.ConvTranspose2d):
-                        w = w.permute(1, 0, 2, 3)
+                        # [Cin, Cout, s, s] -> 1x1 conv with output channel (dy*s + dx)*Cout + co; depth-to-space afterwards
+                        up = m.kernel_size[0]
+                        w = (w * scale.view(1, -1, 1, 1)).permute(2, 3, 1, 0).reshape(up * up * w.shape[1], w.shape[0], 1, 1)
+                        bias = bias.repeat(up * up)
                         stride, padding = [1, 1], [0, 0]
                     else:
                         stride, padding = list(m.stride), [m.padding[0] + pad, m.padding[1] + pad]
-                    w = (w * scale.view(-1, 1, 1, 1)).to(dtype).contiguous(memory_format=torch.channels_last)
-                    out.append((w, bias.detach().contiguous(), stride, padding))
+                        w = w * scale.view(-1, 1, 1, 1)
+                    w = w.to(dtype).contiguous(memory_format=torch.channels_last)
+                    out.append((w, bias.detach().contiguous(), stride, padding, up))
                     pad = 0
                     i += 1
                 i += 1
@@ -401,9 +408,10 @@ class RPNInference(nn.Module):
                 self.plan.append(("u", len(layers)))
                 layers.append(l)
         single = len(rpn.blocks) == 1
-        self.ws = nn.ParameterList([nn.Parameter(w, requires_grad=False) for w, _, _, _ in layers])
-        self.bs = nn.ParameterList([nn.Parameter(b, requires_grad=False) for _, b, _, _ in layers])
-        self.cfgs = [(s, p) for _, _, s, p in layers]
+        self.ws = nn.ParameterList([nn.Parameter(w, requires_grad=False) for w, _, _, _, _ in layers])
+        self.bs = nn.ParameterList([nn.Parameter(b, requires_grad=False) for _, b, _, _, _ in layers])
+        self.cfgs = [(s, p) for _, _, s, p, _ in layers]
+        self.ups = [u for _, _, _, _, u in layers]      # depth-to-space factor after the conv (transposed deblocks)
         heads = [rpn.conv_box, rpn.conv_cls] + ([rpn.conv_dir_cls] if rpn._use_direction_classifier else [])
         self.splits = [h.out_channels for h in heads]
         tot = sum(self.splits)
@@ -435,13 +443,22 @@ class RPNInference(nn.Module):
         # deblock (1x1, stride 1, 128 -> 128) + heads (<= 128 padded channels) run as ONE kernel (sec_conv1x1_chain_nhwc)
         wl = self.ws[-1]
         self.chain_tail = (single and self.use_hip and tuple(wl.shape) == (128, 128, 1, 1) and self.cfgs[-1] == ([1, 1], [0, 0])
+                           and self.ups[-1] == 1
                            and self.head_cout in (64, 128) and os.environ.get("SEC_RPN_CHAIN", "1") == "1")
 
     def _conv(self, x, i):
         w, b, (s, p) = self.ws[i], self.bs[i], self.cfgs[i]
         if self.use_hip:
-            return ops.conv2d_nhwc(x, self.packed[i], b, w.shape[0], w.shape[2], s[0], p[0], relu=True)
-        return ops.bias_act_(F.conv2d(x, w, None, s, p), b, relu=True)
+            y = ops.conv2d_nhwc(x, self.packed[i], b, w.shape[0], w.shape[2], s[0], p[0], relu=True)
+        else:
+            y = ops.bias_act_(F.conv2d(x, w, None, s, p), b, relu=True)
+        u = self.ups[i]
+        if u > 1:   # depth-to-space of the channels-last result: [B,H,W,(dy,dx,co)] -> [B,H*u,W*u,co]
+            n, c, h, wd = y.shape
+            co = c // (u * u)
+            y = y.permute(0, 2, 3, 1).reshape(n, h, wd, u, u * co).permute(0, 1, 3, 2, 4).reshape(n, h * u, wd * u, co)
+            y = y.permute(0, 3, 1, 2)        # a channels_last [B,co,H*u,W*u] tensor
+        return y
 
     def forward(self, x):
         ups = []

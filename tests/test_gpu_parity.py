@@ -525,6 +525,36 @@ def test_rpn_inference_multi_block_pointpillars_shape():
         assert err < 4e-2, (k, err)
 
 
+def test_rpn_inference_transposed_deblocks_kitti_pointpillars_shape():
+    """KITTI PointPillars RPN (configs/pointpillars/car/xyres_16.config: upsample strides 1, 2, 4 = ConvTranspose2d with
+    k = s): each deblock runs as a 1x1 conv to s*s*Cout channels + depth-to-space; bf16 kernels and the fp32 folded form
+    against the fp32 module."""
+    from second_amd.models import RPNV2, RPNInference
+    torch.manual_seed(0)
+    net = RPNV2(num_class=1, layer_nums=(3, 5, 5), layer_strides=(2, 2, 2), num_filters=(64, 128, 256),
+                upsample_strides=(1, 2, 4), num_upsample_filters=(128, 128, 128), num_input_features=64,
+                num_anchor_per_loc=2).cuda().eval()
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.uniform_(-0.1, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.uniform_(-0.2, 0.2)
+    assert RPNInference.supports(net)
+    x = torch.randn(2, 64, 64, 48, device="cuda")
+    with torch.no_grad():
+        ref = net(x)
+        f32 = RPNInference(net, torch.float32)(x.contiguous(memory_format=torch.channels_last))
+        inf = RPNInference(net, torch.bfloat16)
+        assert inf.use_hip and inf.ups.count(1) == len(inf.ups) - 2 and sorted(u for u in inf.ups if u > 1) == [2, 4]
+        bf = inf(x.bfloat16().contiguous(memory_format=torch.channels_last))
+    for k in ref:
+        assert f32[k].shape == ref[k].shape == bf[k].shape
+        np.testing.assert_allclose(f32[k].cpu().numpy(), ref[k].cpu().numpy(), rtol=2e-3, atol=2e-4)
+        err = (bf[k].float() - ref[k]).abs().max().item() / ref[k].abs().max().item()
+        assert err < 4e-2, (k, err)
+
+
 # ------------------------------------------------------------------ PointPillars front end / block filter
 def test_pfn_kernel_matches_reference_module_and_oracle(ops, golden):
     g = golden("torch_modules")
