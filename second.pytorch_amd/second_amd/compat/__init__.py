@@ -190,3 +190,49 @@ def install(reference_root=None, spconv_path=None):
             sys.path.append(reference_root)
         return load_protos(reference_root)
     return []
+
+
+def accelerate_nms():
+    """Optional: replace ``second.pytorch.core.box_torch_ops.rotate_nms`` / ``nms`` (box_torch_ops.py:454-515) by
+    device-resident equivalents.  The originals copy the candidates to the host, run numba / spconv CPU code there and
+    copy the kept indices back -- once per sample and class (voxelnet.py:452-455,578-584).  Same signature, same
+    semantics (top-k pre-selection, `rotate_nms_cc` = standup pre-filter and IoU >= thr, `nms_gpu_cc` = +1 convention and
+    IoU > thr), same return value (LongTensor of kept indices into the inputs); the only host synchronisation left is the
+    size of the result.  CPU tensors keep the original path.  Call after :func:`install`; returns the patched module."""
+    import importlib
+    import torch
+    from .. import ops
+    bto = importlib.import_module("second.pytorch.core.box_torch_ops")
+    if getattr(bto, "_second_amd_accelerated", False):
+        return bto
+    orig = {"rotate_nms": bto.rotate_nms, "nms": bto.nms}
+
+    def _run(kind, semantics, boxes, scores, pre_max_size, post_max_size, iou_threshold):
+        n = scores.shape[0]
+        n_cand = n if pre_max_size is None else min(n, pre_max_size)
+        if not (boxes.is_cuda or bto._second_amd_force) or n_cand > 4096:   # sec_nms_sorted_f32 handles <= 4096 boxes
+            return orig[kind](boxes, scores, pre_max_size, post_max_size, iou_threshold)
+        if n == 0:
+            return torch.zeros([0]).long().to(boxes.device)
+        if pre_max_size is not None:
+            scores, indices = torch.topk(scores, k=min(n, pre_max_size))
+        else:
+            scores, indices = torch.sort(scores, descending=True)
+        dets = torch.cat([boxes[indices], scores.unsqueeze(-1)], dim=1).float().contiguous().unsqueeze(0)
+        counts = torch.full((1,), dets.shape[1], dtype=torch.int32, device=boxes.device)
+        keep, num = ops.nms_sorted(dets, counts, float(iou_threshold), "rotate" if kind == "rotate_nms" else "axis_aligned",
+                                   semantics, post_max=int(post_max_size or 0))
+        keep = keep[0, :int(num[0].item())].long()
+        return indices[keep]
+
+    def rotate_nms(rbboxes, scores, pre_max_size=None, post_max_size=None, iou_threshold=0.5):
+        return _run("rotate_nms", "cpu", rbboxes, scores, pre_max_size, post_max_size, iou_threshold)
+
+    def nms(bboxes, scores, pre_max_size=None, post_max_size=None, iou_threshold=0.5):
+        return _run("nms", "numba", bboxes, scores, pre_max_size, post_max_size, iou_threshold)
+
+    bto.rotate_nms, bto.nms = rotate_nms, nms
+    bto._second_amd_force = False      # tests: take the device formulation for CPU tensors too (oracle backend)
+    bto._second_amd_accelerated = True
+    bto._second_amd_original_nms = orig
+    return bto

@@ -225,3 +225,31 @@ def test_reference_nuscenes_fhd_over_our_stack(ref):
             ours_preds = det.network_forward(feats, ex["coordinates"], 1)
         for k in ("box_preds", "cls_preds", "dir_cls_preds"):
             np.testing.assert_allclose(ours_preds[k].numpy(), ref_preds[k].numpy(), rtol=1e-3, atol=1e-4)
+
+
+def test_accelerated_nms_patch_equals_reference_path(ref):
+    """compat.accelerate_nms(): the device-resident rotate_nms / nms replacements return what the reference's own
+    host round-trip functions return (same kept indices, same order) -- here both over the CPU oracle."""
+    import oracle_backend
+    from second_amd import compat
+    rng = np.random.default_rng(0)
+    n = 300
+    boxes = np.concatenate([rng.uniform(0, 40, (n, 2)), rng.uniform(1.5, 4.5, (n, 2)), rng.uniform(-3.14, 3.14, (n, 1))], 1)
+    scores = rng.permutation(n).astype(np.float32) / n           # distinct scores
+    rb, sc = torch.from_numpy(boxes.astype(np.float32)), torch.from_numpy(scores)
+    # axis-aligned boxes (x1, y1, x2, y2)
+    ab = torch.from_numpy(np.concatenate([boxes[:, :2] - boxes[:, 2:4] / 2, boxes[:, :2] + boxes[:, 2:4] / 2], 1).astype(np.float32))
+    with oracle_backend.installed():
+        bto = compat.accelerate_nms()
+        orig = bto._second_amd_original_nms
+        try:
+            bto._second_amd_force = True
+            for pre, post, thr in ((None, None, 0.3), (200, 50, 0.01), (1000, 100, 0.5)):
+                got = bto.rotate_nms(rb, sc, pre, post, thr)
+                want = orig["rotate_nms"](rb, sc, pre, post, thr)
+                assert got.dtype == torch.int64 and torch.equal(got, want) and len(got) > 3
+                got = bto.nms(ab, sc, pre, post, thr)
+                want = orig["nms"](ab, sc, pre, post, thr)
+                assert torch.equal(got, want) and len(got) > 3
+        finally:
+            bto._second_amd_force = False
