@@ -1438,13 +1438,121 @@ __global__ __launch_bounds__(kBlock) void k_conv_wgrad_tiled(const T *__restrict
     }
 }
 
+
+// MFMA wgrad for 16-bit dtypes.  dW[k] = F^T D with F = gathered feature rows [pairs x Cin], D = dout rows [pairs x Cout]:
+// the contraction runs over the PAIRS, so both MFMA operands need 8 consecutive pairs per lane for a fixed channel -- the
+// transpose of how rows lie in memory.  The compacted pairs of a 64-row step are therefore staged TRANSPOSED in LDS
+// (sFt[channel][pair], sDt[channel][pair], 16-bit), from where a fragment is one ds_read_b128.  The (Cin/32) x (Cout/32)
+// result tiles are spread over the 4 waves; with fewer than 4 tiles the waves split the 16-pair k-steps between them and
+// are summed by the final fp32 atomics.  Channel counts below 32 are zero padded in LDS.
+template <typename T, int CIN, int COUT>
+__global__ __launch_bounds__(kBlock) void k_conv_wgrad_mfma(const T *__restrict__ feat, const T *__restrict__ dout,
+                                                           const int *__restrict__ nbr, int n_out, int kvol,
+                                                           int rows_per_chunk, float *__restrict__ dw) {
+    constexpr int SUB = 64;                                    // rows scanned per step -> up to four 16-pair MFMA k-steps
+    constexpr int CI_T = (CIN + 31) / 32, CO_T = (COUT + 31) / 32, TILES = CI_T * CO_T;
+    static_assert(TILES <= 4 && 4 % TILES == 0, "tiles must divide the four waves");
+    constexpr int WPT = 4 / TILES;                             // waves sharing one tile (they split the k-steps)
+    constexpr int LD = SUB + 8;                                // row pitch in elements: 80 bytes, 16-byte aligned fragments
+    __shared__ __attribute__((aligned(16))) T sFt[CI_T * 32][LD], sDt[CO_T * 32][LD];
+    __shared__ int s_src[SUB], s_dst[SUB], s_n;
+    const int k = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int tile = wv / WPT, ksel = wv % WPT;
+    const int ti = tile / CO_T, tj = tile % CO_T;
+    const int o0 = blockIdx.x * rows_per_chunk;
+    const int o1 = o0 + rows_per_chunk < n_out ? o0 + rows_per_chunk : n_out;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    for (int e = tid; e < CI_T * 32 * LD; e += kBlock) (&sFt[0][0])[e] = Cvt<T>::from(0.0f);   // padding rows / columns stay zero
+    for (int e = tid; e < CO_T * 32 * LD; e += kBlock) (&sDt[0][0])[e] = Cvt<T>::from(0.0f);
+    int idx_next = (tid < 64 && o0 + lane < o1) ? nbr[(size_t)(o0 + lane) * kvol + k] : -1;
+    for (int ob = o0; ob < o1; ob += SUB) {
+        if (tid < 64) {                                        // wave 0 compacts the valid pairs of these SUB rows
+            const int o = ob + lane;
+            const int idx = idx_next;
+            const int on = o + SUB;                            // next step's neighbour indices: in flight during this step
+            idx_next = on < o1 ? nbr[(size_t)on * kvol + k] : -1;
+            const unsigned long long m = __ballot(idx >= 0);
+            if (idx >= 0) {
+                const int pos = __popcll(m & ((1ull << lane) - 1ull));
+                s_src[pos] = idx;
+                s_dst[pos] = o;
+            }
+            if (lane == 0) s_n = __popcll(m);
+        }
+        __syncthreads();
+        const int np = s_n;
+        if (np > 0) {
+            // transposed staging, 8 channels (one 16-byte load) per thread-step; pairs beyond np are written as zeros
+            for (int e = tid; e < SUB * (CIN / 8 > 0 ? CIN / 8 : 1); e += kBlock) {
+                const int p = e % SUB, c8 = (e / SUB) * 8;
+                T v[8];
+                if (p < np) {
+                    if constexpr (CIN % 8 == 0) {
+                        *reinterpret_cast<uint4 *>(v) = *reinterpret_cast<const uint4 *>(feat + (size_t)s_src[p] * CIN + c8);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] = c8 + j < CIN ? feat[(size_t)s_src[p] * CIN + c8 + j] : Cvt<T>::from(0.0f);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = Cvt<T>::from(0.0f);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (c8 + j < CIN) sFt[c8 + j][p] = v[j];
+            }
+            for (int e = tid; e < SUB * (COUT / 8); e += kBlock) {
+                const int p = e % SUB, c8 = (e / SUB) * 8;
+                T v[8];
+                if (p < np) *reinterpret_cast<uint4 *>(v) = *reinterpret_cast<const uint4 *>(dout + (size_t)s_dst[p] * COUT + c8);
+                else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = Cvt<T>::from(0.0f);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sDt[c8 + j][p] = v[j];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int ks = 0; ks < SUB / 16; ++ks) {
+                if (ks % WPT == ksel && ks * 16 < np) {
+                    const uint4 a = *reinterpret_cast<const uint4 *>(&sFt[ti * 32 + r][ks * 16 + h * 8]);   // A[ci][8 pairs]
+                    const uint4 b = *reinterpret_cast<const uint4 *>(&sDt[tj * 32 + r][ks * 16 + h * 8]);   // B[8 pairs][co]
+                    acc = Mfma<T>::run(a, b, acc);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // D layout: column (co) = lane & 31, rows (ci) = (i & 3) + 8 (i >> 2) + 4 h
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int ci = ti * 32 + (i & 3) + 8 * (i >> 2) + 4 * h, co = tj * 32 + r;
+        if (ci < CIN && co < COUT && acc[i] != 0.0f) atomicAdd(&dw[((size_t)k * CIN + ci) * COUT + co], acc[i]);
+    }
+}
+
 template <typename T>
 static bool launch_wgrad_tiled(const void *feat, const void *dout, const int *nbr, int n_out, int cin, int cout, int kvol,
                                float *dw, hipStream_t st) {
-    // large chunks keep the fp32 atomics few; at least ~2 workgroups per CU overall
+    // large chunks keep the fp32 atomics few, but every workgroup walks its chunk as a serial chain of gather steps:
+    // ~5 workgroups per CU measured best on subm2 (chunk 512/1024/2048/4096: 81/67/78/128 us bf16, 222/169/228/417 us fp32)
     int chunk = 8192;
-    while (chunk > 512 && (long long)div_up(n_out, chunk) * kvol < 512) chunk >>= 1;
+    while (chunk > 512 && (long long)div_up(n_out, chunk) * kvol < 1400) chunk >>= 1;
     dim3 grid(div_up(n_out, chunk), kvol);
+    if constexpr (!std::is_same<T, float>::value) {            // 16-bit dtypes: matrix cores
+#define SEC_WM(CI, CO)                                                                                                    \
+        if (cin == CI && cout == CO) {                                                                                    \
+            hipLaunchKernelGGL((k_conv_wgrad_mfma<T, CI, CO>), grid, dim3(kBlock), 0, st, (const T *)feat, (const T *)dout, nbr, \
+                               n_out, kvol, chunk, dw);                                                                   \
+            return true;                                                                                                  \
+        }
+        SEC_WM(16, 16) SEC_WM(16, 32) SEC_WM(32, 32) SEC_WM(32, 64) SEC_WM(64, 64)
+#undef SEC_WM
+    }
 #define SEC_WG(CI, CO)                                                                                                    \
     if (cin == CI && cout == CO) {                                                                                        \
         hipLaunchKernelGGL((k_conv_wgrad_tiled<T, CI, CO>), grid, dim3(kBlock), 0, st, (const T *)feat, (const T *)dout, nbr,  \
