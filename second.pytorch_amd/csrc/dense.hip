@@ -685,8 +685,9 @@ __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(con
     // XCD-aware tile order: workgroup b runs on XCD b % 8 and takes tile b / 8 of that XCD's contiguous range.
     // (A persistent form -- 3 resident workgroups per CU striding through the range, next halo DMA overlapped with
     // the epilogue -- was measured 5 % SLOWER: its extra live state spills at the 168-VGPR budget.)
-    // (A 12 x 16 tile -- B fragments reused over 6 m-tiles, 202 VGPRs, 2 workgroups per CU -- measured 3 % slower, 96 vs 93 us:
-    // the kernel is bound by resident waves per SIMD, not by the L2 -> VGPR weight stream.)
+    // (A 12 x 16 tile -- B fragments reused over 6 m-tiles, 202 VGPRs, 2 workgroups per CU -- measured 3 % slower, 96 vs 93 us;
+    // a 6 x 16 tile -- 3 m-tiles, 128 VGPRs, 4 workgroups per CU -- 6 % slower, 97 vs 92 us: 8 x 16 at 3 per CU is the optimum
+    // between weight-stream reuse and resident waves.)
     const int xcd = blockIdx.x % 8, local = blockIdx.x / 8;
     const int n0 = blockIdx.y * 128 + wv * 32;     // this wave's 32 output channels
     constexpr int cin8 = CIN / 8;
