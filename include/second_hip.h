@@ -203,7 +203,10 @@ int sec_bias_act_nhwc(void *x, const float *bias, size_t pixels, int channels, i
 /* Dense conv2d of the RPN (second/pytorch/models/rpn.py:468-497 blocks, :275-285 1x1 deconv, :386-391 heads):
  * channels-last [B,H,W,Cin] bf16/f16, implicit GEMM on MFMA with bias (folded BatchNorm2d) + ReLU fused.
  * weight [Cout,Cin,k,k] (torch layout) is re-packed once by sec_conv2d_pack_weight.  Cin, Cout multiples of 64.
- * Output [B,Ho,Wo,Cout] with Ho = (H + 2 pad - k) / stride + 1. */
+ * Output [B,Ho,Wo,Cout] with Ho = (H + 2 pad - k) / stride + 1.
+ * `relu` is a flag word: bit 0 = ReLU; bit 1 = the input is a scattered sparse tensor (the first RPN layer after
+ * SparseConvTensor.dense(), middle.py:206-210): the 3x3/s1 kernel then tests each input tile and writes act(bias)
+ * for all-zero ones without running the MFMA loop -- bit-identical results for finite weights. */
 size_t sec_conv2d_packed_weight_bytes(int cout, int cin, int ksize, int dtype);
 int sec_conv2d_pack_weight(const void *weight, int cout, int cin, int ksize, int dtype, void *packed,
                            void *stream);

@@ -113,6 +113,7 @@ __device__ __forceinline__ void store_tile_t(const f32x16d &acc, const float *__
 
 struct Conv2dParams {
     int batch, h, w, cin, cout, ho, wo, ksize, stride, pad, relu;
+    int zskip;    // input known to be mostly zero (scattered sparse voxels): all-zero halo tiles skip the MFMA loop
     long long m;  // batch * ho * wo
 };
 
@@ -745,12 +746,23 @@ __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(con
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[a][i] = 0.0f;
         __syncthreads();                            // halo landed
+        // First RPN layer: its input is the scattered sparse-middle output, most 10 x 18 halos hold nothing but zeros and
+        // the result is act(bias) exactly (0 * w accumulates to 0) -- one LDS sweep + a barrier decides, uniformly.
+        bool live = true;
+        if (p.zskip) {
+            unsigned nz = 0;
+            for (int e = tid; e < HENT; e += 256) {
+                const uint4 v = hal[e];
+                nz |= v.x | v.y | v.z | v.w;
+            }
+            live = __syncthreads_or((int)(nz != 0)) != 0;
+        }
         // A fragments run one whole k-step (MT MFMAs = 128 cycles of matrix pipe) ahead of their use, across iterations
         uint4 af[2][MT];
         int tap = 0, kc = 0;
-        load_a(0, 0, 0, af[0]);
+        if (live) load_a(0, 0, 0, af[0]);
 #pragma unroll 2
-        for (int it = 0; it < NIT; ++it) {
+        for (int it = 0; live && it < NIT; ++it) {
             const int cur = it & 1;
             if (it + 1 < NIT) load_b(it + 1, bq[cur ^ 1]);
             int ntap = tap, nkc = kc + 1;
@@ -1103,7 +1115,9 @@ SEC_API int sec_conv2d_nhwc(const void *x, int batch, int h, int w, int cin, con
     if (!x || !packed_weight || !y || batch <= 0 || h <= 0 || w <= 0 || ksize <= 0 || stride <= 0 || pad < 0) return SEC_E_INVALID;
     if (cin % 64 || cout % 64 || (dtype != SEC_BF16 && dtype != SEC_F16)) return SEC_E_UNSUPPORTED;
     Conv2dParams p;
-    p.batch = batch; p.h = h; p.w = w; p.cin = cin; p.cout = cout; p.ksize = ksize; p.stride = stride; p.pad = pad; p.relu = relu;
+    p.batch = batch; p.h = h; p.w = w; p.cin = cin; p.cout = cout; p.ksize = ksize; p.stride = stride; p.pad = pad;
+    p.relu = relu & 1;
+    p.zskip = (relu >> 1) & 1;
     p.ho = (h + 2 * pad - ksize) / stride + 1;
     p.wo = (w + 2 * pad - ksize) / stride + 1;
     if (p.ho <= 0 || p.wo <= 0) return SEC_E_INVALID;

@@ -442,14 +442,16 @@ class RPNInference(nn.Module):
             self.use_hip = self.head_packed is not None
         # deblock (1x1, stride 1, 128 -> 128) + heads (<= 128 padded channels) run as ONE kernel (sec_conv1x1_chain_nhwc)
         wl = self.ws[-1]
+        self.sparse_input = os.environ.get("SEC_RPN_ZSKIP", "1") == "1"   # forward()'s input comes from SparseConvTensor.dense()
         self.chain_tail = (single and self.use_hip and tuple(wl.shape) == (128, 128, 1, 1) and self.cfgs[-1] == ([1, 1], [0, 0])
                            and self.ups[-1] == 1
                            and self.head_cout in (64, 128) and os.environ.get("SEC_RPN_CHAIN", "1") == "1")
 
-    def _conv(self, x, i):
+    def _conv(self, x, i, sparse_input=False):
         w, b, (s, p) = self.ws[i], self.bs[i], self.cfgs[i]
         if self.use_hip:
-            y = ops.conv2d_nhwc(x, self.packed[i], b, w.shape[0], w.shape[2], s[0], p[0], relu=True)
+            y = ops.conv2d_nhwc(x, self.packed[i], b, w.shape[0], w.shape[2], s[0], p[0], relu=True,
+                                sparse_input=sparse_input)
         else:
             y = ops.bias_act_(F.conv2d(x, w, None, s, p), b, relu=True)
         u = self.ups[i]
@@ -462,9 +464,11 @@ class RPNInference(nn.Module):
 
     def forward(self, x):
         ups = []
+        first = self.sparse_input     # x is the scattered sparse-middle output: mostly empty tiles
         for kind, i in self.plan:
             if kind == "c":
-                x = self._conv(x, i)
+                x = self._conv(x, i, sparse_input=first)
+                first = False
             elif self.chain_tail:
                 ups.append(None)                     # single block: the deblock runs fused with the heads below
             else:

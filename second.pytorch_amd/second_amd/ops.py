@@ -365,16 +365,18 @@ def conv2d_pack_weight(weight):
     return packed
 
 
-def conv2d_nhwc(x, packed, bias, cout, ksize, stride=1, pad=0, relu=False):
+def conv2d_nhwc(x, packed, bias, cout, ksize, stride=1, pad=0, relu=False, sparse_input=False):
     """Dense conv2d + bias + ReLU in one launch (hand-written MFMA implicit GEMM).  x: [B,Cin,H,W] in
-    torch.channels_last memory format (bf16/f16); returns [B,Cout,Ho,Wo] channels_last."""
+    torch.channels_last memory format (bf16/f16); returns [B,Cout,Ho,Wo] channels_last.
+    ``sparse_input``: x is a scattered sparse tensor (mostly zero tiles), which the 3x3/s1 kernel may skip."""
     rt.require_gpu(x, packed)
     assert x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last)
     b, cin, h, w = x.shape
     ho, wo = (h + 2 * pad - ksize) // stride + 1, (w + 2 * pad - ksize) // stride + 1
     y = torch.empty((b, cout, ho, wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
     rc = rt.lib().sec_conv2d_nhwc(rt.ptr(x), b, h, w, cin, rt.ptr(packed), rt.ptr(bias), cout, ksize, stride, pad,
-                                  int(bool(relu)), rt.ptr(y), rt.dtype_code(x.dtype), rt.stream())
+                                  int(bool(relu)) | (2 if sparse_input else 0), rt.ptr(y), rt.dtype_code(x.dtype),
+                                  rt.stream())
     rt.check(rc, "sec_conv2d_nhwc")
     return y
 

@@ -658,6 +658,34 @@ def test_conv2d_nhwc_mfma_vs_torch(ops, cin, cout, k, stride, pad, hw, dtype):
     np.testing.assert_allclose(nob.float().cpu().numpy(), ref2.cpu().numpy(), rtol=tol, atol=tol * ref2.abs().max().item())
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("fill", ["clusters", "empty", "negzero"])
+def test_conv2d_sparse_input_tile_skip_is_bit_identical(ops, dtype, fill):
+    """Flag bit 1 of sec_conv2d_nhwc (first RPN layer, input = SparseConvTensor.dense()): all-zero 10x18 input halos write
+    act(bias) without the MFMA loop.  Must equal the unflagged launch bit for bit, also across tile borders, for an
+    entirely empty input and for -0.0 inputs (treated as live)."""
+    torch.manual_seed(5)
+    b, c, h, w = 2, 128, 50, 70                       # ragged against the 8 x 16 tile
+    x = torch.zeros(b, c, h, w, device="cuda")
+    if fill != "empty":
+        for (bi, y0, x0) in [(0, 0, 0), (0, 7, 15), (0, 8, 16), (1, 23, 47), (1, 49, 69), (1, 31, 32)]:   # tile corners / borders
+            x[bi, :, y0:y0 + 2, x0:x0 + 1] = torch.randn(c, min(2, h - y0), 1, device="cuda")
+    if fill == "negzero":
+        x[0, 3, 40, 5] = -0.0
+    x = x.to(dtype).contiguous(memory_format=torch.channels_last)
+    wgt = (torch.randn(128, c, 3, 3, device="cuda") / 34).to(dtype)
+    bias = torch.randn(128, device="cuda")
+    pk = ops.conv2d_pack_weight(wgt)
+    for relu in (True, False):
+        plain = ops.conv2d_nhwc(x, pk, bias, 128, 3, 1, 1, relu=relu)
+        skip = ops.conv2d_nhwc(x, pk, bias, 128, 3, 1, 1, relu=relu, sparse_input=True)
+        assert torch.equal(plain.view(torch.int16), skip.view(torch.int16))
+    ref = torch.relu(torch.nn.functional.conv2d(x.float(), wgt.float(), bias, 1, 1))
+    tol = 2 ** -7 if dtype == torch.bfloat16 else 2 ** -9
+    out = ops.conv2d_nhwc(x, pk, bias, 128, 3, 1, 1, relu=True, sparse_input=True)
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref.cpu().numpy(), rtol=tol, atol=tol * ref.abs().max().item())
+
+
 @pytest.mark.parametrize("cfg_name", ["car.fhd", "pp", "nusc.fhd"])
 def test_fused_predict_matches_torch_formulation(cfg_name):
     """select / decode / NMS / finalize kernels vs the torch restatement of voxelnet.py:377-645 (distinct scores)."""
