@@ -670,7 +670,13 @@ static int launch_conv2d_halo_pipe(const void *x, const void *wpk, const float *
 // B fragment and each streams its own from L2 (1 KB coalesced per k-step, prefetched one iteration ahead in VGPRs).
 // LDS holds only the halo (46 KB -> 3 workgroups per CU, 2200 / 768 = 2.9 rounds), the main loop has no barrier,
 // and LDS traffic drops to one conflict-free ds_read_b128 per MFMA.
-template <typename T, int CIN, int TH>
+// Cin = 128 runs the ROLL main loop (below): B fragments in an 8-deep ring loaded 7 k-steps ahead, and halo addresses built
+// from a per-lane base, a dx-only swizzle key and ds_read immediates.  The first version recomputed `hp % HW_` per m-tile and
+// tap -- ~125 VALU instructions per tap, a third of them quarter-rate 32-bit multiplies, against 32 MFMAs: 93 us -> 84 us
+// (1000 TFLOP/s) once they were gone.  Bounding runs on that shape: halos served from L2-resident tiles -2 us, epilogue
+// stores removed -5 us, MFMA loop removed 37 us (26 us of it the halo DMA at ~12 B/clk/CU when all CUs burst at once):
+// what is left is prologue / epilogue of the three lock-stepped workgroup rounds, not the loop.
+template <typename T, int CIN, int TH, bool ROLL = false>
 __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(const T *__restrict__ x, const T *__restrict__ wpk,
                                                             const float *__restrict__ bias, T *__restrict__ y,
                                                             Conv2dParams p, int tiles_y, int tiles_x, int per_xcd) {
@@ -739,7 +745,14 @@ __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(con
         const int trem = tile - b * tiles_y * tiles_x;
         const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
         uint4 bq[2][4];
-        load_b(0, bq[0]);
+        constexpr int RD = 8;
+        uint4 br[RD];                               // ROLL: ring of B fragments, each loaded RD - 1 k-steps ahead of its use
+        if constexpr (ROLL) {
+#pragma unroll
+            for (int f = 0; f < RD - 1; ++f) br[f] = wlane[(size_t)f * 2 * p.cout];
+        } else {
+            load_b(0, bq[0]);
+        }
         f32x16d acc[MT];
 #pragma unroll
         for (int a = 0; a < MT; ++a)
@@ -760,7 +773,50 @@ __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(con
         // A fragments run one whole k-step (MT MFMAs = 128 cycles of matrix pipe) ahead of their use, across iterations
         uint4 af[2][MT];
         int tap = 0, kc = 0;
-        if (live) load_a(0, 0, 0, af[0]);
+        if (live && !ROLL) load_a(0, 0, 0, af[0]);
+        if constexpr (ROLL) {
+            // Rolled over the kernel ROW dy, unrolled over its 3 taps x 8 k-steps (three turns of the 8-deep B ring; fragment g
+            // of the packed weights [tap][cin8][cout] sits at chunk 2 g).  The halo address of (pixel, tap, chunk) splits into
+            //   lane base + dy * row pitch            (one VGPR, updated per dy)
+            //   ^ chunk swizzle                        (key = halo column & 15 = ((r & 15) + dx) & 15: depends on dx only)
+            //   + (mt * 2 * HW_ + dx) * 256            (ds_read immediate)
+            // so a k-step costs two VALU address instructions instead of a `% HW_` per m-tile (quarter-rate multiplies that
+            // competed with the MFMA issue slots).
+            static_assert(!ROLL || (KC == 2 && CH == 16), "ring of 8 == k-steps per tap");
+            const char *halb = reinterpret_cast<const char *>(hal);
+            const int colr = r & 15;
+            unsigned kk[3];
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) kk[dx] = (unsigned)(hh ^ ((colr + dx) & 15)) << 4;
+            const unsigned base0 = (unsigned)((r >> 4) * HW_ + colr) * (CH * 16);
+            auto load_a2 = [&](unsigned bdy, int dx, int cidx, uint4 (&dst)[MT]) {
+                const unsigned a = bdy + (((unsigned)cidx << 4) ^ kk[dx]);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) dst[mt] = *reinterpret_cast<const uint4 *>(halb + a + (mt * 2 * HW_ + dx) * (CH * 16));
+            };
+            if (live) {
+                load_a2(base0, 0, 0, af[0]);
+#pragma unroll 1
+                for (int dy = 0; dy < 3; ++dy) {
+                    // unconditional prefetches (the last row re-reads its own first fragments): static wait counts, no branches
+                    const int dyn = dy < 2 ? dy + 1 : 2;
+                    const unsigned bdy = base0 + dy * (HW_ * CH * 16), bdn = base0 + dyn * (HW_ * CH * 16);
+                    const uint4 *wt = wlane + (size_t)dy * 48 * p.cout, *wn = wlane + (size_t)dyn * 48 * p.cout;
+#pragma unroll
+                    for (int j = 0; j < 24; ++j) {
+                        br[(j + 7) & 7] = j + 7 < 24 ? wt[(size_t)(j + 7) * 2 * p.cout] : wn[(size_t)(j + 7 - 24) * 2 * p.cout];
+                        if (j + 1 < 24) load_a2(bdy, (j + 1) / 8, ((j + 1) % 8) * 2, af[(j + 1) & 1]);
+                        else load_a2(bdn, 0, 0, af[0]);
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) acc[mt] = MfmaD<T>::run(br[j & 7], af[j & 1][mt], acc[mt]);
+                        // pins [B prefetch, 4 A reads, 4 MFMAs] per k-step: free scheduling sinks the loads towards their use
+                        // (126 VGPRs, 96 us instead of 84 us); a 3-deep A ring measured no gain
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+            live = false;                           // skip the two-stage loop below
+        }
 #pragma unroll 2
         for (int it = 0; live && it < NIT; ++it) {
             const int cur = it & 1;
@@ -788,11 +844,11 @@ __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(con
     }
 }
 
-template <typename T, int CIN, int TH>
+template <typename T, int CIN, int TH, bool ROLL = false>
 static int launch_conv2d_halo_reg(const void *x, const void *wpk, const float *bias, void *y, const Conv2dParams &p, hipStream_t st) {
     constexpr size_t lds = (size_t)(TH + 2) * 18 * (CIN / 8) * 16;
     static bool configured = false;
-    auto fn = k_conv2d_halo_reg<T, CIN, TH>;
+    auto fn = k_conv2d_halo_reg<T, CIN, TH, ROLL>;
     if (!configured) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         configured = true;
@@ -1026,8 +1082,10 @@ static int conv2d_variant() {
 template <typename T>
 static int launch_conv2d(const void *x, const void *wpk, const float *bias, void *y, const Conv2dParams &p, hipStream_t st) {
     dim3 block(kBlock);
+    if (conv2d_variant() == 14 && p.ksize == 3 && p.stride == 1 && p.pad == 1 && p.cout % 128 == 0 && p.cin == 128)
+        return launch_conv2d_halo_reg<T, 128, 8>(x, wpk, bias, y, p, st);   // A/B: the two-stage loop with per-m-tile halo addressing
     if (conv2d_variant() == 13 && p.ksize == 3 && p.stride == 1 && p.pad == 1 && p.cout % 128 == 0 && (p.cin == 128 || p.cin == 64))
-        return p.cin == 128 ? launch_conv2d_halo_reg<T, 128, 8>(x, wpk, bias, y, p, st) : launch_conv2d_halo_reg<T, 64, 8>(x, wpk, bias, y, p, st);
+        return p.cin == 128 ? launch_conv2d_halo_reg<T, 128, 8, true>(x, wpk, bias, y, p, st) : launch_conv2d_halo_reg<T, 64, 8>(x, wpk, bias, y, p, st);
 #ifdef SEC_CONV2D_EXPERIMENTS   // earlier 3x3 kernels (LDS weight slabs / rings), kept for A/B builds: DESIGN.md section 4
     if (conv2d_variant() >= 5 && conv2d_variant() <= 12 && p.ksize == 3 && p.stride == 1 && p.pad == 1 && p.cout % 128 == 0 &&
         (p.cin == 128 || p.cin == 64)) {
