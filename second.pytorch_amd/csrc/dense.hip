@@ -676,6 +676,9 @@ static int launch_conv2d_halo_pipe(const void *x, const void *wpk, const float *
 // (1000 TFLOP/s) once they were gone.  Bounding runs on that shape: halos served from L2-resident tiles -2 us, epilogue
 // stores removed -5 us, MFMA loop removed 37 us (26 us of it the halo DMA at ~12 B/clk/CU when all CUs burst at once):
 // what is left is prologue / epilogue of the three lock-stepped workgroup rounds, not the loop.
+// With the ROLL loop re-measured: persistent workgroups (96 per XCD striding through the tiles, next halo DMA issued before the
+// epilogue stores, B ring wrapping into the next tile; 159 VGPRs, no spills) 83.7 vs 83.2 us -- no gain; 12 x 16 tiles 89 us,
+// 4 x 16 tiles at 5 workgroups per CU 94 us.
 template <typename T, int CIN, int TH, bool ROLL = false>
 __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(const T *__restrict__ x, const T *__restrict__ wpk,
                                                             const float *__restrict__ bias, T *__restrict__ y,
