@@ -271,15 +271,17 @@ __global__ __launch_bounds__(kBlock) void k_conv2d_nhwc_dma(const T *__restrict_
     const uint4 *w4 = reinterpret_cast<const uint4 *>(wpk);
     const uint4 *zero16 = w4 + (size_t)p.ksize * p.ksize * cin8 * p.cout;   // appended by sec_conv2d_pack_weight
 
-    // DMA instruction j of wave wv fills LDS entries [(j*4 + wv)*64, +64): pixel (j*4+wv)*8 + lane/8, slot lane%8
+    // DMA instruction j of wave wv fills LDS entries [(j*4 + wv)*64, +64): pixel (j*4+wv)*8 + lane/8, slot lane%8.
+    // All per-lane address arithmetic happens once, here: inside the loop a source address is a per-lane pointer plus
+    // a wave-uniform (scalar) offset that advances with (tap, channel slab) -- the first version re-derived tap / dy / dx by
+    // division and multiplied 64-bit pixel indices per DMA, ~100 quarter-rate multiplies per 16 MFMAs.
     const int slot = lane & 7;
-    long long abase[4];
-    int iy0[4], ix0[4], srcchunk[4];
+    const uint4 *aptr[4];
+    int iy0[4], ix0[4];
     bool pval[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int pl = (j * 4 + wv) * 8 + (lane >> 3);
-        srcchunk[j] = slot ^ (pl & 7);
         long long pix = m0 + pl;
         pval[j] = pix < p.m;
         long long q = pval[j] ? pix : 0;
@@ -289,23 +291,36 @@ __global__ __launch_bounds__(kBlock) void k_conv2d_nhwc_dma(const T *__restrict_
         int b = (int)(q / p.ho);
         iy0[j] = oy * p.stride - p.pad;
         ix0[j] = ox * p.stride - p.pad;
-        abase[j] = ((long long)b * p.h + iy0[j]) * p.w + ix0[j];
+        aptr[j] = x4 + (((long long)b * p.h + iy0[j]) * p.w + ix0[j]) * cin8 + (slot ^ (pl & 7));
     }
-    auto issue = [&](int it, int buf) {
-        const int tap = it / CC, cc = it - tap * CC;
-        const int dy = tap / p.ksize, dx = tap - dy * p.ksize;
+    const uint4 *bptr[PERB];
+#pragma unroll
+    for (int j = 0; j < PERB; ++j) {
+        const int e = (j * 4 + wv) * 64 + lane, ch = e / BN, n = e - ch * BN;
+        bptr[j] = w4 + (size_t)ch * p.cout + n0 + n;
+    }
+    // wave-uniform state of the NEXT slab to issue: tap (dy, dx), channel slab cc and the two scalar offsets
+    int n_dy = 0, n_dx = 0, n_cc = 0;
+    long long n_aoff = 0, n_boff = 0;          // (dy * w + dx) * cin8 + cc * 8   and   (tap * cin8 + cc * 8) * cout
+    const long long b_step = (long long)8 * p.cout;
+    auto issue = [&](int buf) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int iy = iy0[j] + dy, ix = ix0[j] + dx;
+            const int iy = iy0[j] + n_dy, ix = ix0[j] + n_dx;
             const bool ok = pval[j] && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w;
-            const uint4 *src = ok ? x4 + (abase[j] + (long long)dy * p.w + dx) * cin8 + cc * 8 + srcchunk[j] : zero16;
+            const uint4 *src = ok ? aptr[j] + n_aoff : zero16;
             __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)&sA[buf][(j * 4 + wv) * 64], 16, 0, 0);
         }
 #pragma unroll
-        for (int j = 0; j < PERB; ++j) {
-            const int e = (j * 4 + wv) * 64 + lane, ch = e / BN, n = e - ch * BN;
-            const uint4 *src = w4 + ((size_t)tap * cin8 + cc * 8 + ch) * p.cout + n0 + n;
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)&sB[buf][(j * 4 + wv) * 64], 16, 0, 0);
+        for (int j = 0; j < PERB; ++j)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(bptr[j] + n_boff), (lds_ptr_t)&sB[buf][(j * 4 + wv) * 64], 16, 0, 0);
+        n_boff += b_step;                       // packed weights are [tap][cin8][cout]: consecutive slabs are contiguous
+        if (++n_cc == CC) {
+            n_cc = 0;
+            if (++n_dx == p.ksize) { n_dx = 0; ++n_dy; }
+            n_aoff = ((long long)n_dy * p.w + n_dx) * cin8;
+        } else {
+            n_aoff += 8;
         }
     };
 
@@ -317,11 +332,11 @@ __global__ __launch_bounds__(kBlock) void k_conv2d_nhwc_dma(const T *__restrict_
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
 
-    issue(0, 0);
+    issue(0);
     __syncthreads();   // hipcc drains the DMA (vmcnt(0)) before the barrier
     for (int it = 0; it < NIT; ++it) {
         const int buf = it & 1;
-        if (it + 1 < NIT) issue(it + 1, buf ^ 1);
+        if (it + 1 < NIT) issue(buf ^ 1);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             uint4 af[2], bf[NTW];
@@ -336,21 +351,25 @@ __global__ __launch_bounds__(kBlock) void k_conv2d_nhwc_dma(const T *__restrict_
         }
         __syncthreads();
     }
+    const size_t ldc = (size_t)p.cout;
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
         const int co = n0 + wn * (BN / 2) + nt * 32 + r;
         const float bv = bias ? bias[co] : 0.0f;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < 2; ++mt) {
+            const long long pix0 = m0 + wm * 64 + mt * 32 + 4 * hh;
+            T *yp = y + (size_t)pix0 * ldc + co;            // one 64-bit multiply per tile; the row offsets below are scalar
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const long long pix = m0 + wm * 64 + mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-                if (pix < p.m) {
+                const int ro = (i & 3) + 8 * (i >> 2);
+                if (pix0 + ro < p.m) {
                     float v = acc[mt][nt][i] + bv;
                     if (p.relu) v = v > 0.0f ? v : 0.0f;
-                    y[(size_t)pix * p.cout + co] = from_f<T>(v);
+                    yp[(size_t)ro * ldc] = from_f<T>(v);
                 }
             }
+        }
     }
 }
 
