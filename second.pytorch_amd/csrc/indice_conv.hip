@@ -958,6 +958,40 @@ __device__ __forceinline__ void rows_compute(const uint4 *__restrict__ a_cur, co
     }
 }
 
+// COMPACT form (ABL bit 32, SEC_CONV_VARIANT=10): the gathered rows of an offset sit in LDS in COMPACTED order -- row r of the
+// tile reads slot `pos` = number of valid rows below it -- so only ceil(valid / 8) gather DMAs are issued per offset.
+template <typename T, int CIN, int COUT>
+__device__ __forceinline__ void rows_compute_compact(const uint4 *__restrict__ a_cur, const uint4 *__restrict__ b_cur, int idx_cur,
+                                                     int pos, int lane, f32x16 (&acc)[COUT / 32]) {
+    using C = RowsCfg<T, CIN, COUT>;
+    const int h = lane >> 5;
+    const bool have = idx_cur >= 0;
+    const int key = row_key<C::LPR>(pos);
+    uint4 af[C::KS], bf[C::KS * C::NT];
+#pragma unroll
+    for (int s = 0; s < C::KS; ++s) af[s] = a_cur[pos * C::LPR + ((s * 2 + h) ^ key)];
+#pragma unroll
+    for (int i = 0; i < C::KS * C::NT; ++i) bf[i] = b_cur[i * 64 + lane];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < C::KS; ++s) {
+        const uint4 a = have ? af[s] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < C::NT; ++t) acc[t] = Mfma<T>::run(bf[s * C::NT + t], a, acc[t]);   // D^T
+    }
+}
+
+template <int NBW> __device__ __forceinline__ void cwait_after(int younger_gathers) {
+    // hand-counted wait with a data-dependent (wave-uniform) number of younger gather DMAs + NBW younger weight DMAs
+    switch (younger_gathers) {
+        case 0: cwait_vmcnt<NBW>(); break;
+        case 1: cwait_vmcnt<NBW + 1>(); break;
+        case 2: cwait_vmcnt<NBW + 2>(); break;
+        case 3: cwait_vmcnt<NBW + 3>(); break;
+        default: cwait_vmcnt<NBW + 4>(); break;
+    }
+}
+
 template <typename T, int CIN, int COUT, int KVOL, int ABL>
 __global__ __launch_bounds__(kBlock) void k_conv_rows(const T *__restrict__ feat, const T *__restrict__ packed,
                                                      const int *__restrict__ nbr, int n_out,
@@ -989,6 +1023,51 @@ __global__ __launch_bounds__(kBlock) void k_conv_rows(const T *__restrict__ feat
     for (int t = 0; t < C::NT; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+    if constexpr ((ABL & 32) != 0) {
+        static_assert(!(ABL & 32) || (C::ND <= 4 && C::RPI == 8), "compact gathers: 8 rows per DMA instruction");
+        const unsigned below = (1u << r) - 1u;
+        // per offset: mask of the tile's valid rows (wave-uniform), this row's compact slot, and the gather count
+        auto vmask = [&](int k) { return (unsigned)(__ballot(idx[k] >= 0) & 0xffffffffull); };
+        auto issue_c = [&](int k) {
+            const int sl = k % C::RING;
+            const unsigned m = vmask(k);
+            const int nv = __builtin_amdgcn_readfirstlane(__popc(m));
+            const int cnt = (nv + C::RPI - 1) / C::RPI;
+            const int pos = __popc(m & below);
+            // forward permute: valid rows send their neighbour index to lane `pos`, the others fill the tail (a full permutation)
+            const int dest = lane >= 32 ? lane : (idx[k] >= 0 ? pos : nv + (r - pos));
+            const int comp = __builtin_amdgcn_ds_permute(dest << 2, idx[k]);
+#pragma unroll
+            for (int g = 0; g < C::ND; ++g) {
+                if (g < cnt) {
+                    const int sidx = g * C::RPI + lane / C::LPR, slot = lane % C::LPR;
+                    const int srow = __shfl(comp, sidx, 64);
+                    const uint4 *src = reinterpret_cast<const uint4 *>(feat + (size_t)(srow >= 0 ? srow : 0) * CIN) + (slot ^ row_key<C::LPR>(sidx));
+                    __builtin_amdgcn_global_load_lds((glb_ptr_c)src, (lds_ptr_c)&aring[sl * C::ASLOT + g * 64], 16, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < C::NBW; ++j) {
+                const int piece = (w * C::NBW + j) % C::BPIECES;
+                __builtin_amdgcn_global_load_lds((glb_ptr_c)(wp + (size_t)k * C::BSLOT + piece * 64 + lane),
+                                                 (lds_ptr_c)&bring[sl * C::BSLOT + piece * 64], 16, 0, 0);
+            }
+            return cnt;
+        };
+        int cnt_next = 0;                     // gather DMAs of the offset after the one being waited for
+        issue_c(0);
+        if (KVOL > 1) cnt_next = issue_c(1);
+#pragma unroll
+        for (int k = 0; k < KVOL; ++k) {
+            if (k + 1 < KVOL) cwait_after<C::NBW>(cnt_next);
+            else cwait_vmcnt<0>();
+            clds_barrier();
+            if (k + 2 < KVOL) cnt_next = issue_c(k + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            rows_compute_compact<T, CIN, COUT>(aring + (k % C::RING) * C::ASLOT, bring + (k % C::RING) * C::BSLOT, idx[k],
+                                               __popc(vmask(k) & below), lane, acc);
+        }
+    }
     auto issue = [&](int k) {        // operands of offset k -> ring slot k % RING (k is a compile-time constant after unrolling)
         const int sl = k % C::RING;
         if (!(ABL & 1)) {
@@ -1018,6 +1097,7 @@ __global__ __launch_bounds__(kBlock) void k_conv_rows(const T *__restrict__ feat
         }
     };
     constexpr int PEND = ((ABL & 1) ? 0 : C::ND) + ((ABL & 2) ? 0 : C::NBW);   // DMAs per wave per offset
+    if constexpr ((ABL & 32) == 0) {
     issue(0);
     if (KVOL > 1) issue(1);
     // software pipeline, distance 2: iteration k computes offset k while k+1 is in flight and k+2 is being issued
@@ -1030,6 +1110,7 @@ __global__ __launch_bounds__(kBlock) void k_conv_rows(const T *__restrict__ feat
         if (k + 2 < KVOL) issue(k + 2);                      // into the slot every wave finished reading before this barrier
         __builtin_amdgcn_sched_barrier(0);                   // keep the prefetch ahead of the MFMAs it is meant to overlap
         rows_compute<T, CIN, COUT, ABL>(aring + (k % C::RING) * C::ASLOT, bring + (k % C::RING) * C::BSLOT, idx[k], lane, acc);
+    }
     }
     // epilogue (D^T layout): lane owns row `r`, channels t*32 + 8g + 4h + (0..3); half-waves swap a group -> 16-byte stores
     T *orow = out + (size_t)row * COUT;
@@ -1089,6 +1170,12 @@ static void launch_mfma(const void *feat, const void *packed, const int *nbr, in
     if constexpr (std::is_same<T, OT>::value && (CIN == 64 || CIN == 32) && (COUT == 64 || COUT == 32)) {
         // default for the large 64 -> 64 3x3x3 layers (subm2 of car.fhd: 33 us vs 36 us split-K); smaller row counts leave the
         // row-split kernel's 27-offset chain exposed (subm3: 23.6 vs 16.8 us) and stay on split-K
+        if constexpr (CIN == 64) {
+            if (conv_variant() == 10 && kvol == 27 && feat) {   // compacted gathers (not validated on hardware yet: DESIGN.md section 9)
+                launch_rows<T, CIN, COUT, 32>(feat, packed, nbr, n_out, num_out_dev, kvol, scale, shift, relu, out, st);
+                return;
+            }
+        }
         if (((conv_variant() == 1 && CIN == 64 && COUT == 64 && n_out >= 32768) || conv_variant() == 9) && kvol == 27 && feat) {
             launch_rows<T, CIN, COUT, 0>(feat, packed, nbr, n_out, num_out_dev, kvol, scale, shift, relu, out, st);
             return;
