@@ -142,6 +142,14 @@ int sec_indice_conv_fwd(const void *features, int n_in, int cin, const void *wei
                         const void *packed_weight, int kvol, int cout, const int *nbr_out, int n_out,
                         const int *num_out_dev, const float *scale, const float *shift, int relu,
                         void *out, int dtype, int out_dtype, void *stream);
+/* Which kernel sec_indice_conv_fwd dispatches for a shape (no launch): 0 generic VALU, 1 register-tiled VALU (fp32),
+ * 2 Cin=4 first layer, 3 one MFMA wave per tile, 4 split-K MFMA, 5 split-K MFMA per 32-column slice, 6 row-split MFMA
+ * with LDS-staged operands (the SubMConv3d 64->64 kernel of the roofline figure), 7-11 its A/B forms.  The parity tests
+ * use it to prove which kernel an oracle comparison exercised.  sec_indice_conv_set_variant forces one kernel family
+ * (same numbers as the SEC_CONV_VARIANT environment variable; < 0 restores the automatic choice): process-wide,
+ * not thread-safe, meant for A/B measurements and tests. */
+int sec_indice_conv_fwd_plan(int cin, int cout, int kvol, int n_out, int dtype, int out_dtype, int has_packed);
+int sec_indice_conv_set_variant(int variant);
 /* backward (spconv_ops.h indiceConvBackward): dfeat[j,:] = sum_k dout[nbr_in[j][k],:] @ W[k]^T ;
  * dW[k] = sum_o feat[nbr_out[o][k],:]^T dout[o,:].  fp32 gradients for weights, feature dtype for dfeat.
  * For 16-bit dtypes dfeat runs on the MFMA forward kernels over re-packed transposed weights, which live in

@@ -18,17 +18,22 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp
          "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 
 
-def build(force=False, verbose=True):
-    os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    if not force and os.path.exists(OUT):
-        newest = max(os.path.getmtime(p) for p in SRC + HDR)
-        if os.path.getmtime(OUT) >= newest:
-            return OUT
+def build(force=False, verbose=True, tag=None, extra_flags=None):
+    """``tag`` / ``extra_flags`` (or SEC_BUILD_TAG / SEC_EXTRA_HIPCC_FLAGS): a profiling build next to the shipped library,
+    e.g. tag "tl" + -DSEC_CONV_TIMELINE -> lib/libsecond_hip_tl.so, loaded with SEC_HIP_LIB=<that path>."""
+    tag = tag or os.environ.get("SEC_BUILD_TAG", "")
+    out_path = OUT.replace(".so", f"_{tag}.so") if tag else OUT
+    os.makedirs(os.path.dirname(out_path), exist_ok=True)
+    hdrs = HDR + [os.path.join(HERE, "csrc", "experiments", f) for f in os.listdir(os.path.join(HERE, "csrc", "experiments"))]
+    if not force and os.path.exists(out_path):
+        newest = max(os.path.getmtime(p) for p in SRC + hdrs)
+        if os.path.getmtime(out_path) >= newest:
+            return out_path
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    extra = os.environ.get("SEC_EXTRA_HIPCC_FLAGS", "").split()   # e.g. -DSEC_CONV_ABLATIONS for profiling builds
+    extra = list(extra_flags) if extra_flags is not None else os.environ.get("SEC_EXTRA_HIPCC_FLAGS", "").split()   # e.g. -DSEC_CONV_ABLATIONS
     # one translation unit per source, compiled concurrently (indice_conv.hip / dense.hip dominate), then one link
     from concurrent.futures import ThreadPoolExecutor
-    objdir = os.path.join(HERE, "lib", "obj")
+    objdir = os.path.join(HERE, "lib", "obj_" + tag if tag else "obj")
     os.makedirs(objdir, exist_ok=True)
     cflags = [f for f in FLAGS if f != "-shared"]
 
@@ -42,11 +47,11 @@ def build(force=False, verbose=True):
 
     with ThreadPoolExecutor(max_workers=min(len(SRC), os.cpu_count() or 1)) as ex:
         objs = list(ex.map(compile_one, SRC))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fvisibility=hidden", "-o", OUT, *objs]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fvisibility=hidden", "-o", out_path, *objs]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return OUT
+    return out_path
 
 
 if __name__ == "__main__":

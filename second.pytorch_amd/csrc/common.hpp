@@ -82,15 +82,18 @@ __device__ __forceinline__ int hash_insert_bounded(unsigned long long *keys, uin
     }
     return -1;
 }
-// returns slot or -1
+// returns slot or -1.  Bounded like the insert: a table that a bounded insert filled completely (reported overflow of a
+// static-capacity build) has no empty slot left to stop the probe of an absent key -- give up after one sweep instead
+// of spinning inside a captured graph.
 __device__ __forceinline__ int hash_find(const unsigned long long *keys, uint32_t mask, unsigned long long key) {
     uint32_t s = hash64(key) & mask;
-    while (true) {
+    for (uint32_t probes = 0; probes <= mask; ++probes) {
         unsigned long long cur = keys[s];
         if (cur == key) return (int)s;
         if (cur == kEmptyKey) return -1;
         s = (s + 1) & mask;
     }
+    return -1;
 }
 
 // ---------------------------------------------------------------- wave / block scans (wave64)

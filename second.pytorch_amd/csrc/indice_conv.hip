@@ -41,6 +41,26 @@ __device__ __forceinline__ float epilogue(float v, const float *scale, const flo
     return v;
 }
 
+// The same epilogue for FOUR consecutive channels c0..c0+3 with the scale / shift entries fetched as one 16-byte load each.
+// (Per-element `epilogue(...)` calls compile into one dependent global load + s_waitcnt vmcnt(0) per channel: 64 serialised
+// round trips = 11 500 clocks in the row-split kernel's tail before this form replaced them.)  scale / shift: 16-byte aligned.
+struct Affine4 { float sc[4], sh[4]; };
+__device__ __forceinline__ Affine4 load_affine4(const float *scale, const float *shift, int c0) {
+    Affine4 a;
+    float4 s4 = make_float4(1.0f, 1.0f, 1.0f, 1.0f), h4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (scale) s4 = *reinterpret_cast<const float4 *>(scale + c0);
+    if (shift) h4 = *reinterpret_cast<const float4 *>(shift + c0);
+    a.sc[0] = s4.x; a.sc[1] = s4.y; a.sc[2] = s4.z; a.sc[3] = s4.w;
+    a.sh[0] = h4.x; a.sh[1] = h4.y; a.sh[2] = h4.z; a.sh[3] = h4.w;
+    return a;
+}
+__device__ __forceinline__ float epilogue_v(float v, float sc, float sh, bool has_scale, bool has_shift, int relu) {
+    if (has_scale) v = __fmul_rn(v, sc);
+    if (has_shift) v = __fadd_rn(v, sh);
+    if (relu) v = v > 0.0f ? v : 0.0f;
+    return v;
+}
+
 // four consecutive output channels of one row in one store (8 bytes for 16-bit outputs, 16 for fp32)
 template <typename OT> __device__ __forceinline__ void store4(OT *p, float a, float b, float c, float d) {
     OT v[4] = {Cvt<OT>::from(a), Cvt<OT>::from(b), Cvt<OT>::from(c), Cvt<OT>::from(d)};
@@ -318,8 +338,10 @@ __global__ __launch_bounds__(NW * 64, (CIN * COUT > 64 * 64) ? 2 : SEC_SK_MIN_WA
         const int c0 = t * 32 + 8 * g + 4 * h;
         if (c0 < COUT) {
             float v[4];
+            const Affine4 af = load_affine4(scale, shift, c0);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = epilogue(red[0][reg0 + j][lane] + red[1][reg0 + j][lane], scale, shift, c0 + j, relu);
+            for (int j = 0; j < 4; ++j)
+                v[j] = epilogue_v(red[0][reg0 + j][lane] + red[1][reg0 + j][lane], af.sc[j], af.sh[j], scale != nullptr, shift != nullptr, relu);
             if (valid) store4<OT>(out + (size_t)row * COUT + c0, v[0], v[1], v[2], v[3]);
         }
     }
@@ -378,12 +400,13 @@ __global__ __launch_bounds__(NW * 64) void k_conv_mfma_sks(const T *__restrict__
         const int c0 = t * 32 + 8 * w + 4 * h;
         if (c0 < COUT) {
             float v[4];
+            const Affine4 af = load_affine4(scale, shift, c0);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float sum = 0.0f;
 #pragma unroll
                 for (int ww = 0; ww < NW; ++ww) sum += red[ww][w * 4 + j][lane];
-                v[j] = epilogue(sum, scale, shift, c0 + j, relu);
+                v[j] = epilogue_v(sum, af.sc[j], af.sh[j], scale != nullptr, shift != nullptr, relu);
             }
             if (valid) store4<OT>(out + (size_t)row * COUT + c0, v[0], v[1], v[2], v[3]);
         }
@@ -432,470 +455,10 @@ __global__ __launch_bounds__(kBlock) void k_conv_c4(const T *__restrict__ feat, 
     for (int c = 0; c < COUT; ++c) dst[c] = Cvt<OT>::from(epilogue(acc[c], scale, shift, c, relu));
 }
 
-// Lock-step variant: the 4 waves of a workgroup own 4 x 32 consecutive rows and walk the offsets together,
-// so W[k] (the dominant L2 traffic of the one-wave-per-tile kernels: every wave re-reads all K weight blocks)
-// is fetched ONCE per workgroup and double-buffered in LDS; the next offset's weights and gathered rows are
-// in flight while the current offset's MFMAs run; one barrier per offset.  KVOL is a template constant so
-// the neighbour indices of all offsets live in registers (no dependent index->gather chain).
-template <typename T, typename OT, int CIN, int COUT, int KVOL>
-__global__ __launch_bounds__(kBlock) void k_conv_mfma_lds(const T *__restrict__ feat, const T *__restrict__ packed,
-                                                         const int *__restrict__ nbr, int n_out,
-                                                         const int *__restrict__ num_out_dev,
-                                                         const float *__restrict__ scale, const float *__restrict__ shift,
-                                                         int relu, OT *__restrict__ out) {
-    constexpr int KS = CIN / 16, NT = (COUT + 31) / 32, ENT = KS * NT * 64;   // uint4 entries of one W[k]
-    constexpr int PER = (ENT + kBlock - 1) / kBlock;
-    __shared__ uint4 wbuf[2][ENT];
-    if (num_out_dev) n_out = *num_out_dev;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    const long long base = (long long)blockIdx.x * 128 + w * 32;
-    if ((long long)blockIdx.x * 128 >= n_out) return;
-    const long long row = base + r;
-    const bool valid = row < n_out;
+#ifdef SEC_CONV_EXPERIMENTS
+#include "experiments/indice_conv_experiments.inc"
+#endif
 
-    int idxs[KVOL];
-    {
-        const int *nrow = nbr + (size_t)(valid ? row : 0) * KVOL;
-#pragma unroll
-        for (int k = 0; k < KVOL; ++k) idxs[k] = valid ? nrow[k] : -1;
-    }
-    const uint4 *wsrc = reinterpret_cast<const uint4 *>(packed);
-#pragma unroll
-    for (int j = 0; j < PER; ++j) {
-        int e = tid + j * kBlock;
-        if (e < ENT) wbuf[0][e] = wsrc[e];
-    }
-    f32x16 acc[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
-
-    uint4 a_cur[KS], a_nxt[KS];
-    {
-        const uint4 *src = reinterpret_cast<const uint4 *>(feat + (size_t)(idxs[0] >= 0 ? idxs[0] : 0) * CIN) + h;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) a_cur[s] = idxs[0] >= 0 ? src[s * 2] : make_uint4(0, 0, 0, 0);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < KVOL; ++k) {
-        uint4 wn[PER];
-        if (k + 1 < KVOL) {
-#pragma unroll
-            for (int j = 0; j < PER; ++j) {
-                int e = tid + j * kBlock;
-                if (e < ENT) wn[j] = wsrc[(size_t)(k + 1) * ENT + e];
-            }
-            const int ni = idxs[k + 1];
-            const uint4 *src = reinterpret_cast<const uint4 *>(feat + (size_t)(ni >= 0 ? ni : 0) * CIN) + h;
-#pragma unroll
-            for (int s = 0; s < KS; ++s) a_nxt[s] = ni >= 0 ? src[s * 2] : make_uint4(0, 0, 0, 0);
-        }
-        if (__ballot(idxs[k] >= 0) != 0ull) {
-            const uint4 *wb = wbuf[k & 1] + lane;
-#pragma unroll
-            for (int s = 0; s < KS; ++s)
-#pragma unroll
-                for (int t = 0; t < NT; ++t) acc[t] = Mfma<T>::run(a_cur[s], wb[(s * NT + t) * 64], acc[t]);
-        }
-        if (k + 1 < KVOL) {
-#pragma unroll
-            for (int j = 0; j < PER; ++j) {
-                int e = tid + j * kBlock;
-                if (e < ENT) wbuf[(k + 1) & 1][e] = wn[j];
-            }
-#pragma unroll
-            for (int s = 0; s < KS; ++s) a_cur[s] = a_nxt[s];
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        int col = t * 32 + r;
-        if (col >= COUT) continue;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            long long orow = base + (i & 3) + 8 * (i >> 2) + 4 * h;
-            if (orow < n_out) out[(size_t)orow * COUT + col] = Cvt<OT>::from(epilogue(acc[t][i], scale, shift, col, relu));
-        }
-    }
-}
-
-// Lock-step variant 2: like k_conv_mfma_lds, but (a) the tile's neighbour table is staged in LDS (no
-// 27-register index array), (b) gathered rows are prefetched TWO offsets ahead through a 3-deep register ring,
-// (c) the next W block is loaded before the gathers are issued so that waiting for it leaves them in flight.
-template <typename T, typename OT, int CIN, int COUT, int KVOL>
-__global__ __launch_bounds__(kBlock) void k_conv_mfma_lds2(const T *__restrict__ feat, const T *__restrict__ packed,
-                                                          const int *__restrict__ nbr, int n_out,
-                                                          const int *__restrict__ num_out_dev,
-                                                          const float *__restrict__ scale, const float *__restrict__ shift,
-                                                          int relu, OT *__restrict__ out) {
-    constexpr int KS = CIN / 16, NT = (COUT + 31) / 32, ENT = KS * NT * 64;
-    constexpr int PER = (ENT + kBlock - 1) / kBlock;
-    __shared__ uint4 wbuf[2][ENT];
-    __shared__ int nidx[128 * KVOL];
-    if (num_out_dev) n_out = *num_out_dev;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    const long long tile = (long long)blockIdx.x * 128;
-    if (tile >= n_out) return;
-    const long long base = tile + w * 32;
-    {
-        long long lim = (n_out - tile) * KVOL;  // ints of live rows in this tile
-        const int *src = nbr + (size_t)tile * KVOL;
-        for (int e = tid; e < 128 * KVOL; e += kBlock) nidx[e] = e < lim ? src[e] : -1;
-    }
-    const uint4 *wsrc = reinterpret_cast<const uint4 *>(packed);
-#pragma unroll
-    for (int j = 0; j < PER; ++j) {
-        int e = tid + j * kBlock;
-        if (e < ENT) wbuf[0][e] = wsrc[e];
-    }
-    __syncthreads();
-    const int *myidx = nidx + (w * 32 + r) * KVOL;
-    f32x16 acc[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
-    uint4 a[3][KS];
-    auto gather = [&](int k, uint4 *dst) {
-        const int ni = myidx[k];
-        const uint4 *src = reinterpret_cast<const uint4 *>(feat + (size_t)(ni >= 0 ? ni : 0) * CIN) + h;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) dst[s] = ni >= 0 ? src[s * 2] : make_uint4(0, 0, 0, 0);
-    };
-    gather(0, a[0]);
-    if (KVOL > 1) gather(1, a[1]);
-#pragma unroll
-    for (int k = 0; k < KVOL; ++k) {
-        uint4 wn[PER];
-        if (k + 1 < KVOL) {
-#pragma unroll
-            for (int j = 0; j < PER; ++j) {
-                int e = tid + j * kBlock;
-                if (e < ENT) wn[j] = wsrc[(size_t)(k + 1) * ENT + e];
-            }
-        }
-        if (k + 2 < KVOL) gather(k + 2, a[(k + 2) % 3]);
-        if (__ballot(myidx[k] >= 0) != 0ull) {
-            const uint4 *wb = wbuf[k & 1] + lane;
-#pragma unroll
-            for (int s = 0; s < KS; ++s)
-#pragma unroll
-                for (int t = 0; t < NT; ++t) acc[t] = Mfma<T>::run(a[k % 3][s], wb[(s * NT + t) * 64], acc[t]);
-        }
-        if (k + 1 < KVOL) {
-#pragma unroll
-            for (int j = 0; j < PER; ++j) {
-                int e = tid + j * kBlock;
-                if (e < ENT) wbuf[(k + 1) & 1][e] = wn[j];
-            }
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        int col = t * 32 + r;
-        if (col >= COUT) continue;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            long long orow = base + (i & 3) + 8 * (i >> 2) + 4 * h;
-            if (orow < n_out) out[(size_t)orow * COUT + col] = Cvt<OT>::from(epilogue(acc[t][i], scale, shift, col, relu));
-        }
-    }
-}
-
-// Split-K with MT row tiles per workgroup (halves / quarters the weight traffic per row) and a pairwise LDS
-// reduction (2 slots): waves 1,3 -> 0,2 ; wave 2 -> 0 ; wave 0 stores.
-template <typename T, typename OT, int CIN, int COUT, int MT>
-__global__ __launch_bounds__(kBlock) void k_conv_mfma_skm(const T *__restrict__ feat, const T *__restrict__ packed,
-                                                         const int *__restrict__ nbr, int n_out,
-                                                         const int *__restrict__ num_out_dev, int kvol,
-                                                         const float *__restrict__ scale, const float *__restrict__ shift,
-                                                         int relu, OT *__restrict__ out) {
-    constexpr int KS = CIN / 16, NT = (COUT + 31) / 32, NREG = MT * NT * 16, NW = 4;
-    __shared__ float red[2][NREG][64];
-    if (num_out_dev) n_out = *num_out_dev;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    const long long base = (long long)blockIdx.x * (32 * MT);
-    if (base >= n_out) return;
-    f32x16 acc[MT][NT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[m][t][i] = 0.0f;
-    const int *nrow[MT];
-    bool valid[MT];
-    int idx[MT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        long long row = base + m * 32 + r;
-        valid[m] = row < n_out;
-        nrow[m] = nbr + (size_t)(valid[m] ? row : 0) * kvol;
-        idx[m] = (valid[m] && w < kvol) ? nrow[m][w] : -1;
-    }
-    const uint4 *wp = reinterpret_cast<const uint4 *>(packed) + lane;
-    for (int k = w; k < kvol; k += NW) {
-        int cur[MT];
-        bool any = false;
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            cur[m] = idx[m];
-            any |= cur[m] >= 0;
-            if (k + NW < kvol) idx[m] = valid[m] ? nrow[m][k + NW] : -1;
-        }
-        if (__ballot(any) == 0ull) continue;
-        uint4 a[MT][KS];
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            const uint4 *src = reinterpret_cast<const uint4 *>(feat + (size_t)(cur[m] >= 0 ? cur[m] : 0) * CIN) + h;
-#pragma unroll
-            for (int s = 0; s < KS; ++s) a[m][s] = cur[m] >= 0 ? src[s * 2] : make_uint4(0, 0, 0, 0);
-        }
-        const uint4 *wk = wp + (size_t)k * KS * NT * 64;
-#pragma unroll
-        for (int s = 0; s < KS; ++s)
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                uint4 b = wk[(s * NT + t) * 64];
-#pragma unroll
-                for (int m = 0; m < MT; ++m) acc[m][t] = Mfma<T>::run(a[m][s], b, acc[m][t]);
-            }
-    }
-    // pairwise reduction in the MFMA register layout
-    if (w & 1) {
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) red[w >> 1][(m * NT + t) * 16 + i][lane] = acc[m][t][i];
-    }
-    __syncthreads();
-    if (!(w & 1)) {
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[m][t][i] += red[w >> 1][(m * NT + t) * 16 + i][lane];
-    }
-    __syncthreads();
-    if (w == 2) {
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) red[0][(m * NT + t) * 16 + i][lane] = acc[m][t][i];
-    }
-    __syncthreads();
-    if (w != 0) return;
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            int col = t * 32 + r;
-            if (col >= COUT) continue;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                float v = acc[m][t][i] + red[0][(m * NT + t) * 16 + i][lane];
-                long long orow = base + m * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
-                if (orow < n_out) out[(size_t)orow * COUT + col] = Cvt<OT>::from(epilogue(v, scale, shift, col, relu));
-            }
-        }
-}
-
-// Weights-resident variant: a 16-wave workgroup first copies ONE 32-column slice of ALL KVOL weight blocks into
-// LDS (27 x Cin x 32 bf16 = 110 KB for Cin = 64: only possible with CDNA4's 160 KB LDS), then every wave
-// computes one 32-row x 32-column output tile with the B fragments coming from LDS (ds_read_b128) and the
-// gathered A rows prefetched DEPTH offsets ahead through a register ring.  No weight bytes cross the vector
-// memory pipe in the main loop (they were 5x the gather bytes), so the registers they occupied buy prefetch
-// depth instead; grid = (row groups of 512, Cout/32 column slices).
-template <typename T, typename OT, int CIN, int COUT, int KVOL>
-__global__ __launch_bounds__(1024) void k_conv_wlds(const T *__restrict__ feat, const T *__restrict__ packed,
-                                                   const int *__restrict__ nbr, int n_out,
-                                                   const int *__restrict__ num_out_dev,
-                                                   const float *__restrict__ scale, const float *__restrict__ shift,
-                                                   int relu, OT *__restrict__ out) {
-    constexpr int KS = CIN / 16, NT = (COUT + 31) / 32, ENT = KVOL * KS * 64, DEPTH = 3;
-    extern __shared__ __attribute__((aligned(16))) uint4 wlds_smem[];   // [KVOL][KS][64 lanes]
-    uint4 *wl = wlds_smem;
-    if (num_out_dev) n_out = *num_out_dev;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    const int t = blockIdx.y;
-    const long long tile0 = (long long)xcd_tile(blockIdx.x, gridDim.x, relu & 0x10000) * 512;
-    relu &= 0xff;
-    if (tile0 >= n_out) return;
-    const long long base = tile0 + w * 32;
-    const long long row = base + r;
-    const bool valid = row < n_out;
-
-    const uint4 *wsrc = reinterpret_cast<const uint4 *>(packed);
-    for (int e = tid; e < ENT; e += 1024) {
-        int ks = e >> 6, l = e & 63;                      // ks = k*KS + s
-        wl[e] = wsrc[((size_t)ks * NT + t) * 64 + l];
-    }
-    int idxs[KVOL];
-    {
-        const int *nrow = nbr + (size_t)(valid ? row : 0) * KVOL;
-#pragma unroll
-        for (int k = 0; k < KVOL; ++k) idxs[k] = valid ? nrow[k] : -1;
-    }
-    f32x16 acc;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-    uint4 a[DEPTH][KS];
-    auto gather = [&](int k, uint4 *dst) {
-        const int ni = idxs[k];
-        const uint4 *src = reinterpret_cast<const uint4 *>(feat + (size_t)(ni >= 0 ? ni : 0) * CIN) + h;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) dst[s] = ni >= 0 ? src[s * 2] : make_uint4(0, 0, 0, 0);
-    };
-#pragma unroll
-    for (int k = 0; k < DEPTH - 1 && k < KVOL; ++k) gather(k, a[k]);
-    __syncthreads();
-    if (base < n_out) {
-#pragma unroll
-        for (int k = 0; k < KVOL; ++k) {
-            if (k + DEPTH - 1 < KVOL) gather(k + DEPTH - 1, a[(k + DEPTH - 1) % DEPTH]);
-            if (__ballot(idxs[k] >= 0) != 0ull) {
-                const uint4 *wb = wl + (k * KS) * 64 + lane;
-#pragma unroll
-                for (int s = 0; s < KS; ++s) acc = Mfma<T>::run(a[k % DEPTH][s], wb[s * 64], acc);
-            }
-        }
-        const int col = t * 32 + r;
-        if (col < COUT) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                long long orow = base + (i & 3) + 8 * (i >> 2) + 4 * h;
-                if (orow < n_out) out[(size_t)orow * COUT + col] = Cvt<OT>::from(epilogue(acc[i], scale, shift, col, relu));
-            }
-        }
-    }
-}
-
-// Weights-resident + full-line gathers: as k_conv_wlds, but every gather instruction fetches WHOLE input rows
-// (Cin = 64: 8 lanes x 16 B = one 128-byte line per row, 8 rows per instruction) instead of the MFMA-fragment
-// shape (32 rows x 32 B per instruction = 4 line touches per row), and the rows are transposed into the
-// fragment layout through a 4 KB per-wave LDS staging tile with an XOR swizzle (conflict-free ds_read_b128).
-// Fragment-shaped loads were measured to keep the texture-address unit ~2x busier at identical traffic.
-template <typename T, typename OT, int CIN, int COUT, int KVOL>
-__global__ __launch_bounds__(512) void k_conv_wlds_fl(const T *__restrict__ feat, const T *__restrict__ packed,
-                                                     const int *__restrict__ nbr, int n_out,
-                                                     const int *__restrict__ num_out_dev,
-                                                     const float *__restrict__ scale, const float *__restrict__ shift,
-                                                     int relu, OT *__restrict__ out) {
-    constexpr int KS = CIN / 16, NT = (COUT + 31) / 32, ENT = KVOL * KS * 64, DEPTH = 3, NWAVE = 8;
-    constexpr int CH = CIN / 8;          // 16-byte chunks per row
-    constexpr int RPI = 64 / CH;         // rows fetched per gather instruction
-    constexpr int NI = 32 / RPI;         // gather instructions per 32-row tile (== KS)
-    extern __shared__ __attribute__((aligned(16))) uint4 wlds_fl_smem[];
-    uint4 *wl = wlds_fl_smem;                      // [KVOL][KS][64]
-    if (num_out_dev) n_out = *num_out_dev;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    uint4 *stage = wlds_fl_smem + ENT + w * (32 * CH);   // this wave's [32 rows][CH] staging tile
-    const int r = lane & 31, h = lane >> 5;
-    const int t = blockIdx.y;
-    if ((long long)blockIdx.x * (32 * NWAVE) >= n_out) return;
-    const long long base = (long long)blockIdx.x * (32 * NWAVE) + w * 32;
-    const long long row = base + r;
-    const bool valid = row < n_out;
-
-    const uint4 *wsrc = reinterpret_cast<const uint4 *>(packed);
-    for (int e = tid; e < ENT; e += 64 * NWAVE) {
-        int ks = e >> 6, l = e & 63;
-        wl[e] = wsrc[((size_t)ks * NT + t) * 64 + l];
-    }
-    int idxs[KVOL];
-    {
-        const int *nrow = nbr + (size_t)(valid ? row : 0) * KVOL;
-#pragma unroll
-        for (int k = 0; k < KVOL; ++k) idxs[k] = valid ? nrow[k] : -1;
-    }
-    f32x16 acc;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
-    const int lrow = lane / CH, lch = lane % CH;   // full-line mapping: instruction j fetches rows lrow + j*RPI
-    uint4 a[DEPTH][NI];
-    auto gather = [&](int k, uint4 *dst) {
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            const int ni = __shfl(idxs[k], lrow + j * RPI, 64);
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (ni >= 0) v = reinterpret_cast<const uint4 *>(feat + (size_t)ni * CIN)[lch];
-            dst[j] = v;
-        }
-    };
-#pragma unroll
-    for (int k = 0; k < DEPTH - 1 && k < KVOL; ++k) gather(k, a[k]);
-    __syncthreads();
-    if (base < n_out) {
-#pragma unroll
-        for (int k = 0; k < KVOL; ++k) {
-            if (k + DEPTH - 1 < KVOL) gather(k + DEPTH - 1, a[(k + DEPTH - 1) % DEPTH]);
-            if (__ballot(idxs[k] >= 0) != 0ull) {
-#pragma unroll
-                for (int j = 0; j < NI; ++j) {
-                    const int rr = lrow + j * RPI;
-                    stage[rr * CH + (lch ^ (rr & (CH - 1)))] = a[k % DEPTH][j];
-                }
-                const uint4 *wb = wl + (k * KS) * 64 + lane;
-#pragma unroll
-                for (int s = 0; s < KS; ++s) {
-                    uint4 af = stage[r * CH + ((2 * s + h) ^ (r & (CH - 1)))];
-                    acc = Mfma<T>::run(af, wb[s * 64], acc);
-                }
-            }
-        }
-        const int col = t * 32 + r;
-        if (col < COUT) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                long long orow = base + (i & 3) + 8 * (i >> 2) + 4 * h;
-                if (orow < n_out) out[(size_t)orow * COUT + col] = Cvt<OT>::from(epilogue(acc[i], scale, shift, col, relu));
-            }
-        }
-    }
-}
-
-template <typename T, typename OT, int CIN, int COUT>
-static void launch_wlds_fl(const void *feat, const void *packed, const int *nbr, int n_out, const int *num_out_dev,
-                           const float *scale, const float *shift, int relu, void *out, hipStream_t st) {
-    constexpr int KVOL = 27;
-    constexpr size_t lds = ((size_t)KVOL * (CIN / 16) * 64 + 8 * 32 * (CIN / 8)) * 16;
-    static bool configured = false;
-    auto fn = k_conv_wlds_fl<T, OT, CIN, COUT, KVOL>;
-    if (!configured) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        configured = true;
-    }
-    hipLaunchKernelGGL(fn, dim3(div_up(n_out, 256), (COUT + 31) / 32), dim3(512), lds, st, (const T *)feat,
-                       (const T *)packed, nbr, n_out, num_out_dev, scale, shift, relu, (OT *)out);
-}
-
-template <typename T, typename OT, int CIN, int COUT>
-static void launch_wlds(const void *feat, const void *packed, const int *nbr, int n_out, const int *num_out_dev,
-                        const float *scale, const float *shift, int relu, void *out, hipStream_t st) {
-    constexpr int KVOL = 27;
-    constexpr size_t lds = (size_t)KVOL * (CIN / 16) * 64 * 16;
-    static bool configured = false;
-    auto fn = k_conv_wlds<T, OT, CIN, COUT, KVOL>;
-    if (!configured) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        configured = true;
-    }
-    hipLaunchKernelGGL(fn, dim3((div_up(n_out, 512) + 7) / 8 * 8, (COUT + 31) / 32), dim3(1024), lds, st, (const T *)feat,
-                       (const T *)packed, nbr, n_out, num_out_dev, scale, shift, relu | (conv_swizzle() << 16), (OT *)out);
-}
 
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -992,6 +555,77 @@ template <int NBW> __device__ __forceinline__ void cwait_after(int younger_gathe
     }
 }
 
+// epilogue of the row-per-lane (D^T) accumulator layout: lane owns row `r`, channels t*32 + 8g + 4h + (0..3); half-waves
+// swap a register group so every lane stores 16-byte runs; fused scale / shift / ReLU
+// `aff` = LDS copy of scale[COUT] | shift[COUT] made by rows_stage_affine at kernel start (16-byte reads, all in flight together)
+template <typename T, int COUT, bool FUSED>
+__device__ __forceinline__ void rows_store_impl(f32x16 (&acc)[COUT / 32], T *__restrict__ out, long long row, bool valid, int h,
+                                                const float *__restrict__ aff, bool has_scale, bool has_shift, int relu) {
+    if (FUSED) { has_scale = has_shift = true; relu = 1; }   // the inference layers: straight-line multiply, add, max
+    T *orow = out + (size_t)row * COUT;
+    float4 sc4[COUT / 32][4], sh4[COUT / 32][4];
+#pragma unroll
+    for (int t = 0; t < COUT / 32; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c = t * 32 + 8 * g + 4 * h;
+            if (has_scale) sc4[t][g] = *reinterpret_cast<const float4 *>(aff + c);
+            if (has_shift) sh4[t][g] = *reinterpret_cast<const float4 *>(aff + COUT + c);
+        }
+#pragma unroll
+    for (int t = 0; t < COUT / 32; ++t) {
+        uint2 pk[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float sc[4] = {sc4[t][g].x, sc4[t][g].y, sc4[t][g].z, sc4[t][g].w};
+            const float sh[4] = {sh4[t][g].x, sh4[t][g].y, sh4[t][g].z, sh4[t][g].w};
+            T v4[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v4[j] = Cvt<T>::from(epilogue_v(acc[t][4 * g + j], sc[j], sh[j], has_scale, has_shift, relu));
+            __builtin_memcpy(&pk[g], v4, 8);
+        }
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            const uint2 keep = h ? pk[2 * pr + 1] : pk[2 * pr];
+            const uint2 send = h ? pk[2 * pr] : pk[2 * pr + 1];
+            uint2 recv;
+            recv.x = (unsigned)__shfl_xor((int)send.x, 32, 64);
+            recv.y = (unsigned)__shfl_xor((int)send.y, 32, 64);
+            const uint4 o = h ? make_uint4(recv.x, recv.y, keep.x, keep.y) : make_uint4(keep.x, keep.y, recv.x, recv.y);
+            if (valid) *reinterpret_cast<uint4 *>(orow + t * 32 + 8 * (2 * pr + h)) = o;
+        }
+    }
+}
+template <typename T, int COUT>
+__device__ __forceinline__ void rows_store(f32x16 (&acc)[COUT / 32], T *__restrict__ out, long long row, bool valid, int h,
+                                           const float *__restrict__ aff, bool has_scale, bool has_shift, int relu) {
+    if (has_scale && has_shift && relu) rows_store_impl<T, COUT, true>(acc, out, row, valid, h, aff, true, true, 1);
+    else rows_store_impl<T, COUT, false>(acc, out, row, valid, h, aff, has_scale, has_shift, relu);
+}
+
+// scale / shift -> LDS, first thing in the kernel (published by the first barrier of the offset loop)
+template <int COUT>
+__device__ __forceinline__ void rows_stage_affine(float *aff, const float *__restrict__ scale, const float *__restrict__ shift) {
+    const int c = threadIdx.x;
+    if (c < COUT) {
+        if (scale) aff[c] = scale[c];
+        if (shift) aff[COUT + c] = shift[c];
+    }
+}
+
+#ifdef SEC_CONV_TIMELINE
+#define SEC_RTL(...) __VA_ARGS__
+#else
+#define SEC_RTL(...)
+#endif
+
+// ABL bits: 1..16 ablations (profiling builds), 32 = compacted gathers, 64 = TOUCH: every gathered row is first pulled towards
+// the L2 by a 4-byte LDS-DMA issued kTouchDist offsets ahead of its real gather (one instruction per offset: 32 rows x both
+// 64-byte halves, landing in a scratch line nobody reads).  The gather ring only holds two offsets in flight (LDS capacity), so
+// without the touches every step of the 27-offset chain pays a full L2-miss latency; with them the misses of eight offsets
+// overlap and the ring's own gathers hit the L2.
+constexpr int kTouchDist = 8;
+
 template <typename T, int CIN, int COUT, int KVOL, int ABL>
 __global__ __launch_bounds__(kBlock) void k_conv_rows(const T *__restrict__ feat, const T *__restrict__ packed,
                                                      const int *__restrict__ nbr, int n_out,
@@ -999,14 +633,20 @@ __global__ __launch_bounds__(kBlock) void k_conv_rows(const T *__restrict__ feat
                                                      const float *__restrict__ scale, const float *__restrict__ shift,
                                                      int relu, T *__restrict__ out) {
     using C = RowsCfg<T, CIN, COUT>;
+    constexpr bool TOUCH = (ABL & 64) != 0;
+    constexpr int TD = kTouchDist;
     extern __shared__ __attribute__((aligned(16))) uint4 rows_smem[];
     uint4 *bring = rows_smem;                                    // [RING][BSLOT]   shared by the four waves
     if (num_out_dev) n_out = *num_out_dev;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint4 *aring = rows_smem + C::RING * C::BSLOT + w * C::RING * C::ASLOT;   // [RING][ASLOT] private to this wave
+    float *aff = reinterpret_cast<float *>(rows_smem + C::RING * (C::BSLOT + 4 * C::ASLOT));          // scale[COUT] | shift[COUT]
+    uint4 *tscratch = rows_smem + C::RING * (C::BSLOT + 4 * C::ASLOT) + COUT / 2 + w * 16;   // 256 B per wave: landing zone of the touches
+    rows_stage_affine<COUT>(aff, scale, shift);
     const int r = lane & 31, h = lane >> 5;
     const long long base = (long long)blockIdx.x * 128 + w * 32;
     if ((long long)blockIdx.x * 128 >= n_out) return;
+    SEC_RTL(long long *tl = g_timeline; long long tl0 = 0, tl1 = 0, tl2 = 0, tl_wait = 0, tl_issue = 0, tl_comp = 0; if (tl) tl0 = clock64();)
     const long long row = base + r;
     const bool valid = row < n_out;
     const uint4 *wp = reinterpret_cast<const uint4 *>(packed);
@@ -1018,11 +658,21 @@ __global__ __launch_bounds__(kBlock) void k_conv_rows(const T *__restrict__ feat
 #pragma unroll
         for (int k = 0; k < KVOL; ++k) idx[k] = valid ? nrow[k] : -1;
     }
+    SEC_RTL(if (tl) { cwait_vmcnt<0>(); tl1 = clock64(); })
     f32x16 acc[C::NT];
 #pragma unroll
     for (int t = 0; t < C::NT; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+    auto touch = [&](int k) {        // rows of offset k towards the L2: lane (r, h) asks for 4 bytes of half h of row idx[k]
+        const int t = idx[k];
+        const char *src = reinterpret_cast<const char *>(feat + (size_t)(t >= 0 ? t : 0) * CIN) + h * (CIN * (int)sizeof(T) / 2);
+        __builtin_amdgcn_global_load_lds((glb_ptr_c)src, (lds_ptr_c)tscratch, 4, 0, 0);
+    };
+    if constexpr (TOUCH) {
+#pragma unroll
+        for (int k = 2; k < TD && k < KVOL; ++k) touch(k);       // offsets 0 and 1 are gathered right away
+    }
     if constexpr ((ABL & 32) != 0) {
         static_assert(!(ABL & 32) || (C::ND <= 4 && C::RPI == 8), "compact gathers: 8 rows per DMA instruction");
         const unsigned below = (1u << r) - 1u;
@@ -1059,13 +709,20 @@ __global__ __launch_bounds__(kBlock) void k_conv_rows(const T *__restrict__ feat
         if (KVOL > 1) cnt_next = issue_c(1);
 #pragma unroll
         for (int k = 0; k < KVOL; ++k) {
-            if (k + 1 < KVOL) cwait_after<C::NBW>(cnt_next);
+            SEC_RTL(long long ta = 0, tb = 0, tc = 0; if (tl) ta = clock64();)
+            // younger than offset k's DMAs: the touch of step k-1 (if any), then offset k+1's gathers and weights
+            const bool tprev = TOUCH && k >= 1 && k - 1 + TD < KVOL;
+            if (k + 1 < KVOL) { if (tprev) cwait_after<C::NBW + 1>(cnt_next); else cwait_after<C::NBW>(cnt_next); }
             else cwait_vmcnt<0>();
             clds_barrier();
+            SEC_RTL(if (tl) tb = clock64();)
+            if (TOUCH && k + TD < KVOL) touch(k + TD);
             if (k + 2 < KVOL) cnt_next = issue_c(k + 2);
             __builtin_amdgcn_sched_barrier(0);
+            SEC_RTL(if (tl) tc = clock64();)
             rows_compute_compact<T, CIN, COUT>(aring + (k % C::RING) * C::ASLOT, bring + (k % C::RING) * C::BSLOT, idx[k],
                                                __popc(vmask(k) & below), lane, acc);
+            SEC_RTL(if (tl) { tl_wait += tb - ta; tl_issue += tc - tb; tl_comp += clock64() - tc; })
         }
     }
     auto issue = [&](int k) {        // operands of offset k -> ring slot k % RING (k is a compile-time constant after unrolling)
@@ -1103,39 +760,30 @@ __global__ __launch_bounds__(kBlock) void k_conv_rows(const T *__restrict__ feat
     // software pipeline, distance 2: iteration k computes offset k while k+1 is in flight and k+2 is being issued
 #pragma unroll
     for (int k = 0; k < KVOL; ++k) {
-        // this wave's DMAs of offset k have landed once only those of offset k+1 are outstanding ...
-        if (k + 1 < KVOL) cwait_vmcnt<PEND>();
+        SEC_RTL(long long ta = 0, tb = 0, tc = 0; if (tl) ta = clock64();)
+        // this wave's DMAs of offset k have landed once only those of offset k+1 (and the touch issued before them) are outstanding ...
+        const bool tprev = TOUCH && k >= 1 && k - 1 + TD < KVOL;
+        if (k + 1 < KVOL) { if (tprev) cwait_vmcnt<PEND + 1>(); else cwait_vmcnt<PEND>(); }
         else cwait_vmcnt<0>();
         if (!(ABL & 8)) clds_barrier();                      // ... and so have the other waves' pieces of W[k]
+        SEC_RTL(if (tl) tb = clock64();)
+        if (TOUCH && k + TD < KVOL) touch(k + TD);
         if (k + 2 < KVOL) issue(k + 2);                      // into the slot every wave finished reading before this barrier
         __builtin_amdgcn_sched_barrier(0);                   // keep the prefetch ahead of the MFMAs it is meant to overlap
+        SEC_RTL(if (tl) tc = clock64();)
         rows_compute<T, CIN, COUT, ABL>(aring + (k % C::RING) * C::ASLOT, bring + (k % C::RING) * C::BSLOT, idx[k], lane, acc);
+        SEC_RTL(if (tl) { tl_wait += tb - ta; tl_issue += tc - tb; tl_comp += clock64() - tc; })
     }
     }
-    // epilogue (D^T layout): lane owns row `r`, channels t*32 + 8g + 4h + (0..3); half-waves swap a group -> 16-byte stores
-    T *orow = out + (size_t)row * COUT;
-#pragma unroll
-    for (int t = 0; t < C::NT; ++t) {
-        uint2 pk[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int c = t * 32 + 8 * g + 4 * h;
-            T v4[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v4[j] = Cvt<T>::from(epilogue(acc[t][4 * g + j], scale, shift, c + j, relu));
-            __builtin_memcpy(&pk[g], v4, 8);
-        }
-#pragma unroll
-        for (int pr = 0; pr < 2; ++pr) {
-            const uint2 keep = h ? pk[2 * pr + 1] : pk[2 * pr];
-            const uint2 send = h ? pk[2 * pr] : pk[2 * pr + 1];
-            uint2 recv;
-            recv.x = (unsigned)__shfl_xor((int)send.x, 32, 64);
-            recv.y = (unsigned)__shfl_xor((int)send.y, 32, 64);
-            const uint4 o = h ? make_uint4(recv.x, recv.y, keep.x, keep.y) : make_uint4(keep.x, keep.y, recv.x, recv.y);
-            if (valid) *reinterpret_cast<uint4 *>(orow + t * 32 + 8 * (2 * pr + h)) = o;
-        }
+    SEC_RTL(if (tl) tl2 = clock64();)
+    rows_store<T, COUT>(acc, out, row, valid, h, aff, scale != nullptr, shift != nullptr, relu);
+#ifdef SEC_CONV_TIMELINE
+    if (tl && lane == 0) {
+        long long *rec = tl + ((size_t)blockIdx.x * 4 + w) * 8;
+        rec[0] = tl0; rec[1] = tl1; rec[2] = tl2; rec[3] = clock64(); rec[4] = tl_wait; rec[5] = tl_issue; rec[6] = tl_comp;
+        rec[7] = __builtin_amdgcn_s_getreg((4 << 11) | 20);
     }
+#endif
 }
 
 template <typename T, int CIN, int COUT, int ABL>
@@ -1143,7 +791,7 @@ static void launch_rows(const void *feat, const void *packed, const int *nbr, in
                         const float *scale, const float *shift, int relu, void *out, hipStream_t st) {
     constexpr int KVOL = 27;   // dispatched for 3x3x3 layers only
     using C = RowsCfg<T, CIN, COUT>;
-    constexpr size_t lds = (size_t)C::RING * (C::BSLOT + 4 * C::ASLOT) * 16;
+    constexpr size_t lds = (size_t)C::RING * (C::BSLOT + 4 * C::ASLOT) * 16 + 2 * COUT * sizeof(float) + ((ABL & 64) ? 4 * 256 : 0);
     static bool configured = false;
     auto fn = k_conv_rows<T, CIN, COUT, KVOL, ABL>;
     if (!configured) {
@@ -1154,29 +802,273 @@ static void launch_rows(const void *feat, const void *packed, const int *nbr, in
                        num_out_dev, scale, shift, relu, (T *)out);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Row-split kernel with REGISTER-direct gathers (SEC_CONV_VARIANT 13/14/15).  Same work split as k_conv_rows (128 rows per
+// workgroup, one 32-row tile per wave, W[k] shared through a 3-slot LDS ring), but the gathered rows never touch LDS: lane
+// (r, h) loads the 16-byte K-chunks of its row straight into the registers the MFMA reads (the transposed product takes the
+// features as its second operand, whose fragment IS 8 consecutive channels of one row).  LDS then only holds the weight ring
+// (24 KB instead of 72 KB per workgroup), so the prefetch distance is set by registers -- DIST offsets of 16 VGPRs each -- and
+// no longer by the LDS capacity, and all memory operations are ordinary loads the compiler's own s_waitcnt bookkeeping
+// understands (W[k+2] travels global -> VGPR -> ds_write one step ahead of its barrier).
+template <typename T, int CIN, int COUT, int KVOL, int DIST, int MINW>
+__global__ __launch_bounds__(kBlock, MINW) void k_conv_rows_reg(const T *__restrict__ feat, const T *__restrict__ packed,
+                                                               const int *__restrict__ nbr, int n_out,
+                                                               const int *__restrict__ num_out_dev,
+                                                               const float *__restrict__ scale, const float *__restrict__ shift,
+                                                               int relu, T *__restrict__ out) {
+    using C = RowsCfg<T, CIN, COUT>;
+    static_assert(C::BPIECES % 4 == 0, "weight pieces split evenly over the four waves");
+    __shared__ __attribute__((aligned(16))) uint4 bring[3][C::BSLOT];
+    __shared__ __attribute__((aligned(16))) float aff[2 * COUT];
+    rows_stage_affine<COUT>(aff, scale, shift);
+    if (num_out_dev) n_out = *num_out_dev;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const long long base = (long long)blockIdx.x * 128 + w * 32;
+    if ((long long)blockIdx.x * 128 >= n_out) return;
+    SEC_RTL(long long *tl = g_timeline; long long tl0 = 0, tl1 = 0, tl2 = 0; if (tl) tl0 = clock64();)
+    const long long row = base + r;
+    const bool valid = row < n_out;
+    const uint4 *wp = reinterpret_cast<const uint4 *>(packed) + (size_t)w * C::NBW * 64 + lane;
+    int idx[KVOL];
+    {
+        const int *nrow = nbr + (size_t)(valid ? row : 0) * KVOL;
+#pragma unroll
+        for (int k = 0; k < KVOL; ++k) idx[k] = valid ? nrow[k] : -1;
+    }
+    SEC_RTL(if (tl) { cwait_vmcnt<0>(); tl1 = clock64(); })
+    f32x16 acc[C::NT];
+#pragma unroll
+    for (int t = 0; t < C::NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+    static_assert(C::NBW == 2, "two 1 KB weight pieces per wave and offset");
+    // vmcnt retires in order, so a load that is needed one step after its issue would drag every older gather with it: the
+    // weight pieces therefore travel at the SAME distance as the gathers (register ring, global -> VGPR -> ds_write -> barrier).
+    uint4 areg[DIST][C::KS];
+    uint4 wr0[DIST], wr1[DIST];      // this wave's share of the weight blocks on their way global -> LDS
+    uint4 *bslot = &bring[0][(w * C::NBW) * 64 + lane];
+#define SEC_FETCH(k)                                                                                                   \
+    {                                                                                                                  \
+        wr0[(k) % DIST] = wp[(size_t)(k) * C::BSLOT];                                                                  \
+        wr1[(k) % DIST] = wp[(size_t)(k) * C::BSLOT + 64];                                                             \
+        const int t_ = idx[k];       /* rows without a neighbour read row 0 (one hot line) and are zeroed at use */    \
+        const uint4 *src_ = reinterpret_cast<const uint4 *>(feat + (size_t)(t_ >= 0 ? t_ : 0) * CIN) + h;              \
+        _Pragma("unroll") for (int s_ = 0; s_ < C::KS; ++s_) areg[(k) % DIST][s_] = src_[2 * s_];                      \
+    }
+#define SEC_WSTORE(k) { bslot[((k) % 3) * C::BSLOT] = wr0[(k) % DIST]; bslot[((k) % 3) * C::BSLOT + 64] = wr1[(k) % DIST]; }
+#pragma unroll
+    for (int k = 0; k < DIST && k < KVOL; ++k) SEC_FETCH(k)
+    SEC_WSTORE(0)
+#pragma unroll
+    for (int k = 0; k < KVOL; ++k) {
+        uint4 wn0, wn1;                                      // W[k+1]'s pieces leave the ring before its slot is refilled below
+        if (k + 1 < KVOL) { wn0 = wr0[(k + 1) % DIST]; wn1 = wr1[(k + 1) % DIST]; }
+        if (k + 1 < KVOL) { bslot[((k + 1) % 3) * C::BSLOT] = wn0; bslot[((k + 1) % 3) * C::BSLOT + 64] = wn1; }   // slot last read two barriers ago
+        __syncthreads();                                     // W[k] (stored during step k-1) is visible to every wave
+        uint4 bf[C::KS * C::NT];
+#pragma unroll
+        for (int i = 0; i < C::KS * C::NT; ++i) bf[i] = bring[k % 3][i * 64 + lane];
+        __builtin_amdgcn_sched_barrier(0);                   // all B fragments in flight together, then the MFMAs back to back
+        const bool have = idx[k] >= 0;
+#pragma unroll
+        for (int s = 0; s < C::KS; ++s) {
+            const uint4 a = have ? areg[k % DIST][s] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < C::NT; ++t) acc[t] = Mfma<T>::run(bf[s * C::NT + t], a, acc[t]);   // D^T
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (k + DIST < KVOL) SEC_FETCH(k + DIST)             // into the registers this step just consumed
+    }
+#undef SEC_FETCH
+#undef SEC_WSTORE
+    SEC_RTL(if (tl) tl2 = clock64();)
+    rows_store<T, COUT>(acc, out, row, valid, h, aff, scale != nullptr, shift != nullptr, relu);
+#ifdef SEC_CONV_TIMELINE
+    if (tl && lane == 0) {
+        long long *rec = tl + ((size_t)blockIdx.x * 4 + w) * 8;
+        rec[0] = tl0; rec[1] = tl1; rec[2] = tl2; rec[3] = clock64(); rec[4] = rec[5] = rec[6] = 0;
+        rec[7] = __builtin_amdgcn_s_getreg((4 << 11) | 20);
+    }
+#endif
+}
+
+template <typename T, int CIN, int COUT, int DIST, int MINW>
+static void launch_rows_reg(const void *feat, const void *packed, const int *nbr, int n_out, const int *num_out_dev,
+                            const float *scale, const float *shift, int relu, void *out, hipStream_t st) {
+    hipLaunchKernelGGL((k_conv_rows_reg<T, CIN, COUT, 27, DIST, MINW>), dim3(div_up(n_out, 128)), dim3(kBlock), 0, st,
+                       (const T *)feat, (const T *)packed, nbr, n_out, num_out_dev, scale, shift, relu, (T *)out);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Row-split kernel, BUFFER-load form (SEC_CONV_VARIANT 16..19).  What the per-wave timeline of the forms above showed
+// (profiles/r02_a_timeline_conv_rows.txt): the waves hardly wait -- 7 % of the offset loop -- they are busy ISSUING: ~100
+// instructions per offset, a quarter of them v_cndmask that zero the fragments of rows without a neighbour, plus 64-bit
+// address arithmetic, and (LDS-DMA forms) an M0 hand-off per DMA.  Here the gathers are raw buffer loads over the feature
+// matrix: a row without a neighbour gets an OUT-OF-RANGE offset and the hardware returns zeros for it -- no select, no
+// dummy row, no memory access -- and the per-offset byte offsets (32-bit, precomputed once) replace the 64-bit pointers.
+// Per offset a wave issues 4 gather loads, its share of W[k] (global -> VGPR -> ds_write, at the same distance as the
+// gathers because vmcnt retires in order), 8 ds_read_b128 and 8 MFMAs: ~35 instructions.  WAVES = 8 makes the workgroup 256
+// rows, so one copy of W[k] per CU and step instead of two.
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+template <typename T, int CIN, int COUT, int KVOL, int DIST, int WAVES, int MINW>
+__global__ __launch_bounds__(WAVES * 64, MINW) void k_conv_rows_buf(const T *__restrict__ feat, long long feat_bytes,
+                                                                   const T *__restrict__ packed, const int *__restrict__ nbr,
+                                                                   int n_out, const int *__restrict__ num_out_dev,
+                                                                   const float *__restrict__ scale, const float *__restrict__ shift,
+                                                                   int relu, T *__restrict__ out) {
+    using C = RowsCfg<T, CIN, COUT>;
+    constexpr int NBW = C::BPIECES / WAVES;              // 1 KB weight pieces per wave and offset
+    constexpr int ROWB = CIN * (int)sizeof(T);           // bytes per feature row
+    static_assert(C::BPIECES % WAVES == 0 && NBW >= 1, "weight pieces split evenly over the waves");
+    __shared__ __attribute__((aligned(16))) uint4 bring[3][C::BSLOT];
+    __shared__ __attribute__((aligned(16))) float aff[2 * COUT];
+    rows_stage_affine<COUT>(aff, scale, shift);
+    if (num_out_dev) n_out = *num_out_dev;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    if ((long long)blockIdx.x * (32 * WAVES) >= n_out) return;
+    const long long row = (long long)blockIdx.x * (32 * WAVES) + w * 32 + r;
+    const bool valid = row < n_out;
+    SEC_RTL(long long *tl = g_timeline; long long tl0 = 0, tl1 = 0, tl2 = 0; if (tl) tl0 = clock64();)
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(feat), 0, (int)feat_bytes, 0x00020000);
+    const uint4 *wp = reinterpret_cast<const uint4 *>(packed) + (size_t)w * NBW * 64 + lane;
+    // byte offset of this lane's first 16-byte chunk of every neighbour row; no neighbour -> beyond the buffer -> zeros
+    unsigned off[KVOL];
+    {
+        const int *nrow = nbr + (size_t)(valid ? row : 0) * KVOL;
+#pragma unroll
+        for (int k = 0; k < KVOL; ++k) {
+            const int t = valid ? nrow[k] : -1;
+            off[k] = t >= 0 ? (unsigned)t * ROWB + h * 16 : 0x80000000u;
+        }
+    }
+    SEC_RTL(if (tl) { cwait_vmcnt<0>(); tl1 = clock64(); })
+    f32x16 acc[C::NT];
+#pragma unroll
+    for (int t = 0; t < C::NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+    static_assert(NBW <= 2, "one or two weight pieces per wave");
+    u32x4_t areg[DIST][C::KS];
+    u32x4_t wr0[DIST], wr1[DIST];
+    u32x4_t *bslot = reinterpret_cast<u32x4_t *>(&bring[0][(w * NBW) * 64 + lane]);
+    const u32x4_t *wpv = reinterpret_cast<const u32x4_t *>(wp);
+#define SEC_FETCH(k)                                                                                                  \
+    {                                                                                                                 \
+        wr0[(k) % DIST] = wpv[(size_t)(k) * C::BSLOT];                                                                \
+        if (NBW > 1) wr1[(k) % DIST] = wpv[(size_t)(k) * C::BSLOT + 64];                                              \
+        areg[(k) % DIST][0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[k], 0, 0);                              \
+        if (C::KS > 1) areg[(k) % DIST][1 % C::KS] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[k] + 32, 0, 0);  \
+        if (C::KS > 2) areg[(k) % DIST][2 % C::KS] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[k] + 64, 0, 0);  \
+        if (C::KS > 3) areg[(k) % DIST][3 % C::KS] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[k] + 96, 0, 0);  \
+    }
+    static_assert(C::KS <= 4, "up to four 16-channel k-steps per row");
+#pragma unroll
+    for (int k = 0; k < DIST && k < KVOL; ++k) SEC_FETCH(k)
+    bslot[0] = wr0[0];
+    if (NBW > 1) bslot[64] = wr1[0];
+#pragma unroll
+    for (int k = 0; k < KVOL; ++k) {
+        if (k + 1 < KVOL) {                                  // W[k+1] leaves the register ring; its LDS slot was last read two barriers ago
+            bslot[((k + 1) % 3) * C::BSLOT] = wr0[(k + 1) % DIST];
+            if (NBW > 1) bslot[((k + 1) % 3) * C::BSLOT + 64] = wr1[(k + 1) % DIST];
+        }
+        __syncthreads();                                     // W[k] (stored during step k-1) is visible to every wave
+        uint4 bf[C::KS * C::NT];
+#pragma unroll
+        for (int i = 0; i < C::KS * C::NT; ++i) bf[i] = bring[k % 3][i * 64 + lane];
+        __builtin_amdgcn_sched_barrier(0);                   // all B fragments in flight together, then the MFMAs back to back
+#pragma unroll
+        for (int s = 0; s < C::KS; ++s) {
+            const uint4 a = __builtin_bit_cast(uint4, areg[k % DIST][s]);
+#pragma unroll
+            for (int t = 0; t < C::NT; ++t) acc[t] = Mfma<T>::run(bf[s * C::NT + t], a, acc[t]);   // D^T
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (k + DIST < KVOL) SEC_FETCH(k + DIST)             // into the registers this step just consumed
+    }
+#undef SEC_FETCH
+    SEC_RTL(if (tl) tl2 = clock64();)
+    rows_store<T, COUT>(acc, out, row, valid, h, aff, scale != nullptr, shift != nullptr, relu);
+#ifdef SEC_CONV_TIMELINE
+    if (tl && lane == 0) {
+        long long *rec = tl + ((size_t)blockIdx.x * WAVES + w) * 8;
+        rec[0] = tl0; rec[1] = tl1; rec[2] = tl2; rec[3] = clock64(); rec[4] = rec[5] = rec[6] = 0;
+        rec[7] = __builtin_amdgcn_s_getreg((4 << 11) | 20);
+    }
+#endif
+}
+
+template <typename T, int CIN, int COUT, int DIST, int WAVES, int MINW>
+static void launch_rows_buf(const void *feat, long long n_feat, const void *packed, const int *nbr, int n_out, const int *num_out_dev,
+                            const float *scale, const float *shift, int relu, void *out, hipStream_t st) {
+    hipLaunchKernelGGL((k_conv_rows_buf<T, CIN, COUT, 27, DIST, WAVES, MINW>), dim3(div_up(n_out, 32 * WAVES)), dim3(WAVES * 64), 0, st,
+                       (const T *)feat, n_feat * CIN * (long long)sizeof(T), (const T *)packed, nbr, n_out, num_out_dev, scale, shift,
+                       relu, (T *)out);
+}
+
+static int g_variant_override = -1;     // sec_indice_conv_set_variant (A/B runs and the parity tests of every shipped kernel)
 static int conv_variant() {
+    if (g_variant_override >= 0) return g_variant_override;
     static int v = -1;
     if (v < 0) {
         const char *e = getenv("SEC_CONV_VARIANT");
-        v = e ? atoi(e) : 1;  // 0 = one wave per 32-row tile, 1 = split-K over 4 waves, 2 = lock-step + W in LDS (kvol 27)
+        v = e ? atoi(e) : 1;  // 1 = automatic choice; 0 = one wave per 32-row tile; 8 / 9 / 10.. force one kernel family
     }
     return v;
 }
 
+// kernel ids reported by sec_indice_conv_fwd_plan
+enum { PLAN_GENERIC = 0, PLAN_TILED = 1, PLAN_C4 = 2, PLAN_MFMA_WAVE = 3, PLAN_MFMA_SK = 4, PLAN_MFMA_SKS = 5, PLAN_ROWS = 6,
+       PLAN_ROWS_COMPACT = 7, PLAN_ROWS_TOUCH = 8, PLAN_ROWS_COMPACT_TOUCH = 9, PLAN_ROWS_REG = 10, PLAN_ROWS_BUF = 11, PLAN_EXPERIMENT = 99 };
+
+// which row-split kernel (0 = none) the 16-bit MFMA path takes for this shape under the current variant setting
+static int rows_plan(int cin, int cout, int kvol, int n_out, bool same_dtype) {
+    if (!same_dtype || kvol != 27 || !(cin == 64 || cin == 32) || !(cout == 64 || cout == 32)) return 0;
+    const int v = conv_variant();
+    if (cin == 64) {
+        if (v == 10) return PLAN_ROWS_COMPACT;
+        if (v == 11) return PLAN_ROWS_TOUCH;
+        if (v == 12) return PLAN_ROWS_COMPACT_TOUCH;
+        if (v >= 13 && v <= 15 && cout == 64) return PLAN_ROWS_REG;
+        if (v >= 16 && v <= 19 && cout == 64) return PLAN_ROWS_BUF;
+    }
+    if ((v == 1 && cin == 64 && cout == 64 && n_out >= 32768) || v == 9) return PLAN_ROWS;
+    return 0;
+}
+
 template <typename T, typename OT, int CIN, int COUT>
-static void launch_mfma(const void *feat, const void *packed, const int *nbr, int n_out, const int *num_out_dev,
+static void launch_mfma(const void *feat, long long n_feat, const void *packed, const int *nbr, int n_out, const int *num_out_dev,
                         int kvol, const float *scale, const float *shift, int relu, void *out, hipStream_t st) {
     constexpr int MT = 1;
     if constexpr (std::is_same<T, OT>::value && (CIN == 64 || CIN == 32) && (COUT == 64 || COUT == 32)) {
-        // default for the large 64 -> 64 3x3x3 layers (subm2 of car.fhd: 33 us vs 36 us split-K); smaller row counts leave the
-        // row-split kernel's 27-offset chain exposed (subm3: 23.6 vs 16.8 us) and stay on split-K
+        // default for the large 64 -> 64 3x3x3 layers (subm2 of car.fhd); smaller row counts leave the row-split kernel's
+        // 27-offset chain exposed (subm3: 23.6 vs 16.8 us) and stay on split-K
+        const int rp = feat ? rows_plan(CIN, COUT, kvol, n_out, true) : 0;
         if constexpr (CIN == 64) {
-            if (conv_variant() == 10 && kvol == 27 && feat) {   // compacted gathers (not validated on hardware yet: DESIGN.md section 9)
-                launch_rows<T, CIN, COUT, 32>(feat, packed, nbr, n_out, num_out_dev, kvol, scale, shift, relu, out, st);
-                return;
+            if (rp == PLAN_ROWS_COMPACT) { launch_rows<T, CIN, COUT, 32>(feat, packed, nbr, n_out, num_out_dev, kvol, scale, shift, relu, out, st); return; }
+            if (rp == PLAN_ROWS_TOUCH) { launch_rows<T, CIN, COUT, 64>(feat, packed, nbr, n_out, num_out_dev, kvol, scale, shift, relu, out, st); return; }
+            if (rp == PLAN_ROWS_COMPACT_TOUCH) { launch_rows<T, CIN, COUT, 96>(feat, packed, nbr, n_out, num_out_dev, kvol, scale, shift, relu, out, st); return; }
+            if constexpr (COUT == 64) {
+                if (rp == PLAN_ROWS_BUF && n_feat * CIN * (long long)sizeof(T) < 0x7fffffffll) {
+                    const int v = conv_variant();
+                    if (v == 16) launch_rows_buf<T, CIN, COUT, 4, 4, 2>(feat, n_feat, packed, nbr, n_out, num_out_dev, scale, shift, relu, out, st);
+                    else if (v == 17) launch_rows_buf<T, CIN, COUT, 4, 8, 2>(feat, n_feat, packed, nbr, n_out, num_out_dev, scale, shift, relu, out, st);
+                    else if (v == 18) launch_rows_buf<T, CIN, COUT, 3, 8, 2>(feat, n_feat, packed, nbr, n_out, num_out_dev, scale, shift, relu, out, st);
+                    else launch_rows_buf<T, CIN, COUT, 6, 8, 2>(feat, n_feat, packed, nbr, n_out, num_out_dev, scale, shift, relu, out, st);
+                    return;
+                }
+                if (rp == PLAN_ROWS_REG) {
+                    const int v = conv_variant();
+                    if (v == 13) launch_rows_reg<T, CIN, COUT, 4, 2>(feat, packed, nbr, n_out, num_out_dev, scale, shift, relu, out, st);
+                    else if (v == 14) launch_rows_reg<T, CIN, COUT, 2, 3>(feat, packed, nbr, n_out, num_out_dev, scale, shift, relu, out, st);
+                    else launch_rows_reg<T, CIN, COUT, 5, 2>(feat, packed, nbr, n_out, num_out_dev, scale, shift, relu, out, st);
+                    return;
+                }
             }
         }
-        if (((conv_variant() == 1 && CIN == 64 && COUT == 64 && n_out >= 32768) || conv_variant() == 9) && kvol == 27 && feat) {
+        if (rp == PLAN_ROWS) {
             launch_rows<T, CIN, COUT, 0>(feat, packed, nbr, n_out, num_out_dev, kvol, scale, shift, relu, out, st);
             return;
         }
@@ -1244,12 +1136,12 @@ static void launch_mfma(const void *feat, const void *packed, const int *nbr, in
 }
 
 template <typename T, typename OT>
-static bool dispatch_mfma(int cin, int cout, const void *feat, const void *packed, const int *nbr, int n_out,
+static bool dispatch_mfma(int cin, int cout, const void *feat, long long n_feat, const void *packed, const int *nbr, int n_out,
                           const int *num_out_dev, int kvol, const float *scale, const float *shift, int relu, void *out,
                           hipStream_t st) {
 #define SEC_CASE(CI, CO)                                                                                         \
     if (cin == CI && cout == CO) {                                                                               \
-        launch_mfma<T, OT, CI, CO>(feat, packed, nbr, n_out, num_out_dev, kvol, scale, shift, relu, out, st);     \
+        launch_mfma<T, OT, CI, CO>(feat, n_feat, packed, nbr, n_out, num_out_dev, kvol, scale, shift, relu, out, st); \
         return true;                                                                                             \
     }
     SEC_CASE(16, 16) SEC_CASE(16, 32) SEC_CASE(32, 32) SEC_CASE(32, 64) SEC_CASE(64, 64) SEC_CASE(64, 128)
@@ -1349,13 +1241,14 @@ __global__ __launch_bounds__(kBlock) void k_conv_tiled(const T *__restrict__ fea
         }
         __syncthreads();
     }
+    const Affine4 af = load_affine4(scale, shift, c0);
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
         const long long row = base + r0 + a;
         if (row < n_out)
 #pragma unroll
             for (int b = 0; b < 4; ++b)
-                out[(size_t)row * COUT + c0 + b] = Cvt<OT>::from(epilogue(acc[a][b], scale, shift, c0 + b, relu));
+                out[(size_t)row * COUT + c0 + b] = Cvt<OT>::from(epilogue_v(acc[a][b], af.sc[b], af.sh[b], scale != nullptr, shift != nullptr, relu));
     }
 }
 
@@ -1681,6 +1574,33 @@ SEC_API int sec_pack_conv_weight(const void *weight, int kvol, int cin, int cout
     return check_launch();
 }
 
+SEC_API int sec_indice_conv_set_variant(int variant) {
+    g_variant_override = variant;      // < 0: back to SEC_CONV_VARIANT / the automatic choice
+    return SEC_OK;
+}
+
+SEC_API int sec_indice_conv_fwd_plan(int cin, int cout, int kvol, int n_out, int dtype, int out_dtype, int has_packed) {
+    static const int mfma_shapes[][2] = {{16, 16}, {16, 32}, {32, 32}, {32, 64}, {64, 64}, {64, 128}, {128, 128}, {16, 64},
+                                         {64, 32}, {32, 16}, {128, 64}};
+    bool mfma = false;
+    for (auto &sh : mfma_shapes) mfma |= sh[0] == cin && sh[1] == cout;
+    if (has_packed && dtype != SEC_F32 && mfma) {
+        const int rp = rows_plan(cin, cout, kvol, n_out, dtype == out_dtype);
+        if (rp) return rp;
+        const int v = conv_variant();
+#ifdef SEC_CONV_EXPERIMENTS
+        if (v >= 2 && v <= 7) return PLAN_EXPERIMENT;
+#endif
+        if (v == 8 || (v == 1 && cout <= 32)) return PLAN_MFMA_SKS;
+        return v >= 1 ? PLAN_MFMA_SK : PLAN_MFMA_WAVE;
+    }
+    if (cin == 4 && cout == 16 && (size_t)kvol * 4 * 16 * sizeof(float) <= 48 * 1024) return PLAN_C4;
+    static const int tiled_shapes[][2] = {{16, 16}, {16, 32}, {32, 16}, {32, 32}, {32, 64}, {64, 32}, {64, 64}};
+    for (auto &sh : tiled_shapes)
+        if (sh[0] == cin && sh[1] == cout) return PLAN_TILED;
+    return PLAN_GENERIC;
+}
+
 SEC_API int sec_indice_conv_fwd(const void *features, int n_in, int cin, const void *weight, const void *packed_weight,
                                 int kvol, int cout, const int *nbr_out, int n_out, const int *num_out_dev,
                                 const float *scale, const float *shift, int relu, void *out, int dtype, int out_dtype,
@@ -1694,12 +1614,12 @@ SEC_API int sec_indice_conv_fwd(const void *features, int n_in, int cin, const v
     if (packed_weight && dtype != SEC_F32) {
         if (dtype == SEC_BF16) {
             done = out_dtype == SEC_F32
-                       ? dispatch_mfma<__hip_bfloat16, float>(cin, cout, features, packed_weight, nbr_out, n_out, num_out_dev, kvol, scale, shift, relu, out, st)
-                       : dispatch_mfma<__hip_bfloat16, __hip_bfloat16>(cin, cout, features, packed_weight, nbr_out, n_out, num_out_dev, kvol, scale, shift, relu, out, st);
+                       ? dispatch_mfma<__hip_bfloat16, float>(cin, cout, features, n_in, packed_weight, nbr_out, n_out, num_out_dev, kvol, scale, shift, relu, out, st)
+                       : dispatch_mfma<__hip_bfloat16, __hip_bfloat16>(cin, cout, features, n_in, packed_weight, nbr_out, n_out, num_out_dev, kvol, scale, shift, relu, out, st);
         } else {
             done = out_dtype == SEC_F32
-                       ? dispatch_mfma<__half, float>(cin, cout, features, packed_weight, nbr_out, n_out, num_out_dev, kvol, scale, shift, relu, out, st)
-                       : dispatch_mfma<__half, __half>(cin, cout, features, packed_weight, nbr_out, n_out, num_out_dev, kvol, scale, shift, relu, out, st);
+                       ? dispatch_mfma<__half, float>(cin, cout, features, n_in, packed_weight, nbr_out, n_out, num_out_dev, kvol, scale, shift, relu, out, st)
+                       : dispatch_mfma<__half, __half>(cin, cout, features, n_in, packed_weight, nbr_out, n_out, num_out_dev, kvol, scale, shift, relu, out, st);
         }
     }
     if (!done) {
@@ -1727,7 +1647,7 @@ static int run_bwd(const void *features, int n_in, int cin, const void *weight, 
                 long long total = (long long)kvol * cout * ((cin + 31) / 32) * 32;
                 hipLaunchKernelGGL(k_pack_weight_t<T>, dim3(div_up(total, kBlock)), dim3(kBlock), 0, st, (const T *)weight, kvol, cin,
                                    cout, nbr_in ? 0 : 1, (T *)workspace);
-                done = dispatch_mfma<T, T>(cout, cin, dout, workspace, tbl, n_in, nullptr, kvol, nullptr, nullptr, 0, dfeat, st);
+                done = dispatch_mfma<T, T>(cout, cin, dout, n_out, workspace, tbl, n_in, nullptr, kvol, nullptr, nullptr, 0, dfeat, st);
             }
         }
         if (!done)   // register-tiled VALU forward on (dout, W^T): Cin <-> Cout swapped, weights read transposed in place

@@ -212,6 +212,17 @@ def indice_conv(features, weight, nbr_out, num_out, packed=None, scale=None, shi
     return out
 
 
+def indice_conv_plan(cin, cout, kvol, num_out, dtype, out_dtype=None, packed=True):
+    """Kernel id sec_indice_conv_fwd would dispatch for this shape (include/second_hip.h: 6 = the row-split SubM kernel)."""
+    return int(rt.lib().sec_indice_conv_fwd_plan(int(cin), int(cout), int(kvol), int(num_out), rt.dtype_code(dtype),
+                                                 rt.dtype_code(out_dtype or dtype), int(bool(packed))))
+
+
+def indice_conv_set_variant(variant):
+    """Force one kernel family of the 16-bit sparse conv (A/B runs, parity tests); -1 restores the automatic choice."""
+    rt.check(rt.lib().sec_indice_conv_set_variant(int(variant)), "sec_indice_conv_set_variant")
+
+
 def indice_conv_backward(features, weight, nbr_out, nbr_in, dout, need_dfeat=True, need_dweight=True):
     """(dfeat, dweight) of indice_conv (spconv.ops.indice_conv_backward). nbr_in None => SubM mirror."""
     rt.require_gpu(features, weight, nbr_out, dout)

@@ -21,7 +21,7 @@ SYMBOLS = [
     "sec_abi_version", "sec_last_error", "sec_voxelize_workspace_bytes", "sec_voxelize_f32",
     "sec_rulebook_workspace_bytes", "sec_rulebook_subm3d", "sec_rulebook_subm3d_after_conv", "sec_rulebook_conv3d_build",
     "sec_rulebook_conv3d_tables", "sec_conv_output_shape", "sec_packed_weight_bytes",
-    "sec_pack_conv_weight", "sec_indice_conv_fwd", "sec_indice_conv_bwd_workspace_bytes", "sec_indice_conv_bwd", "sec_sparse_to_dense", "sec_dense_to_sparse",
+    "sec_pack_conv_weight", "sec_indice_conv_fwd", "sec_indice_conv_fwd_plan", "sec_indice_conv_set_variant", "sec_indice_conv_bwd_workspace_bytes", "sec_indice_conv_bwd", "sec_sparse_to_dense", "sec_dense_to_sparse",
     "sec_pillar_scatter", "sec_pfn_fwd", "sec_block_filter_workspace_bytes",
     "sec_voxel_block_filter_f32", "sec_bias_act_nhwc", "sec_conv2d_packed_weight_bytes",
     "sec_conv2d_pack_weight", "sec_conv2d_nhwc", "sec_conv1x1_chain_nhwc", "sec_rotate_iou_f32", "sec_nms_workspace_bytes", "sec_nms_sorted_f32",
@@ -62,6 +62,8 @@ def lib():
         l.sec_packed_weight_bytes.argtypes = [ci, ci, ci, ci]
         l.sec_pack_conv_weight.argtypes = [vp, ci, ci, ci, ci, vp, vp]
         l.sec_indice_conv_fwd.argtypes = [vp, ci, ci, vp, vp, ci, ci, vp, ci, vp, vp, vp, ci, vp, ci, ci, vp]
+        l.sec_indice_conv_fwd_plan.argtypes = [ci] * 7
+        l.sec_indice_conv_set_variant.argtypes = [ci]
         l.sec_indice_conv_bwd.argtypes = [vp, ci, ci, vp, ci, ci, vp, vp, ci, vp, vp, vp, ci, vp, sz, vp]
         l.sec_indice_conv_bwd_workspace_bytes.argtypes = [ci, ci, ci, ci]
         l.sec_sparse_to_dense.argtypes = [vp, vp, ci, ci, vp, vp, sz, i64, i64, i64, i64, i64, ci, vp]

@@ -1,0 +1,154 @@
+"""-m gpu parity tests of the row-split sparse-conv kernels (k_conv_rows*, csrc/indice_conv.hip) against the CPU oracle.
+
+These are the kernels the bench's `roofline` object is quoted on: the 64->64 SubMConv3d layers of car.fhd's subm2 group
+(second/pytorch/models/middle.py:166-174).  The automatic dispatch only takes them for n_out >= 32768, so every case here
+is built at the size of the bench launch -- batch 8 of the SURVEY 8(d) clouds through the ORACLE's voxeliser and rulebooks
+(56 298 rows / 594 482 pairs) -- and `sec_indice_conv_fwd_plan` proves which kernel each comparison exercised.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle as orc  # noqa: E402  (test infrastructure only)
+
+PLAN_ROWS = 6
+# (variant number, expected plan id): None = the automatic choice; the others force one A/B form of the kernel
+ROW_VARIANTS = [(None, 6), (9, 6), (10, 7), (11, 8), (12, 9), (13, 10), (14, 10), (15, 10), (16, 11), (17, 11), (18, 11), (19, 11)]
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from second_amd import ops
+    yield ops
+    ops.indice_conv_set_variant(-1)
+
+
+@pytest.fixture(scope="module")
+def layer():
+    """The exact subm2 launch of bench.py: rulebook from the oracle, output-major gather table derived from its pairs."""
+    from second_amd import synthetic as syn
+    idx = []
+    for b in range(8):
+        r = orc.points_to_voxel(syn.syn_kitti_cloud(b), syn.CAR_FHD_VOXEL, syn.CAR_FHD_RANGE, 5, 40000)
+        idx.append(np.concatenate([np.full((r["voxel_num"], 1), b, np.int32), r["coordinates"]], 1))
+    idx, shape = np.concatenate(idx), [41, 1600, 1408]
+    for _ in range(2):                                   # the two stride-2 convs in front of the subm2 group
+        idx, _, _, shape = orc.rulebook_conv(idx, 8, shape, 3, 2, 1)
+        shape = [int(s) for s in shape]
+    _, pairs, pair_num = orc.rulebook_subm(idx, 8, shape, 3)
+    n = len(idx)
+    nbr = -np.ones((n, 27), np.int32)
+    for k in range(27):
+        p = pairs[k, :, :pair_num[k]]
+        nbr[p[1], k] = p[0]
+    assert n >= 32768 and n % 128 not in (0, 1, 127)
+    return {"idx": idx, "shape": shape, "pairs": pairs, "pair_num": pair_num, "nbr": nbr, "n": n}
+
+
+def _operands(rng, n, dtype):
+    feat = rng.standard_normal((n, 64)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, 3, 64, 64)) / 40).astype(np.float32)
+    f_t, w_t = dev(feat, dtype), dev(w, dtype)
+    return f_t, w_t, f_t.float().cpu().numpy(), w_t.float().cpu().numpy()
+
+
+def _tol(dtype):
+    return 2 ** -7 if dtype == torch.bfloat16 else 2 ** -10    # one rounding of the 16-bit store (tests/test_gpu_parity.py)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_conv_rows_bench_launch_vs_oracle(ops, layer, dtype):
+    """(i) the bench launch itself + (v) the fused scale / shift / ReLU epilogue, every kernel form, vs the fp64-accumulating
+    oracle on the same rounded operands."""
+    rng = np.random.default_rng(11)
+    n = layer["n"]
+    f_t, w_t, f_np, w_np = _operands(rng, n, dtype)
+    ref = orc.indice_conv(f_np, w_np, layer["pairs"], layer["pair_num"], n, acc64=True)
+    scale = rng.uniform(0.5, 1.5, 64).astype(np.float32)
+    shift = rng.uniform(-0.2, 0.2, 64).astype(np.float32)
+    ref_plain = torch.from_numpy(ref).to(dtype).float().numpy()
+    ref_fused = torch.from_numpy(np.maximum(ref * scale + shift, 0)).to(dtype).float().numpy()
+    packed, nbr = ops.pack_weight(w_t), dev(layer["nbr"])
+    tol = _tol(dtype)
+    for variant, plan in ROW_VARIANTS:
+        ops.indice_conv_set_variant(-1 if variant is None else variant)
+        assert ops.indice_conv_plan(64, 64, 27, n, dtype) == plan, (variant, plan)
+        out = ops.indice_conv(f_t, w_t, nbr, n, packed=packed)
+        assert out.dtype == dtype
+        np.testing.assert_allclose(out.float().cpu().numpy(), ref_plain, rtol=tol, atol=tol * np.abs(ref).max(), err_msg=f"variant {variant}")
+        out = ops.indice_conv(f_t, w_t, nbr, n, packed=packed, scale=dev(scale), shift=dev(shift), relu=True)
+        np.testing.assert_allclose(out.float().cpu().numpy(), ref_fused, rtol=tol, atol=tol * np.abs(ref_fused).max(), err_msg=f"variant {variant}")
+    ops.indice_conv_set_variant(-1)
+    # below the row threshold the automatic choice is split-K: the two families must agree on a prefix of the layer
+    assert ops.indice_conv_plan(64, 64, 27, 16000, dtype) != PLAN_ROWS
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_conv_rows_integer_operands_are_bit_exact(ops, layer, dtype):
+    """Small-integer features and weights: every partial sum is an exactly representable integer, so the 16-bit output must
+    equal the oracle BIT FOR BIT (no tolerance) -- catches any dropped, duplicated or misplaced (row, offset) contribution."""
+    rng = np.random.default_rng(5)
+    n = layer["n"]
+    feat = rng.integers(-1, 2, (n, 64)).astype(np.float32)
+    dens = 0.04 if dtype == torch.bfloat16 else 0.5
+    w = (rng.integers(-1, 2, (3, 3, 3, 64, 64)) * (rng.random((3, 3, 3, 64, 64)) < dens)).astype(np.float32)
+    ref = orc.indice_conv(feat, w, layer["pairs"], layer["pair_num"], n, acc64=True)
+    limit = 256 if dtype == torch.bfloat16 else 2048
+    assert np.abs(ref).max() <= limit and np.abs(ref).max() >= 8, np.abs(ref).max()
+    f_t, w_t = dev(feat, dtype), dev(w, dtype)
+    packed, nbr = ops.pack_weight(w_t), dev(layer["nbr"])
+    for variant, plan in ROW_VARIANTS:
+        ops.indice_conv_set_variant(-1 if variant is None else variant)
+        assert ops.indice_conv_plan(64, 64, 27, n, dtype) == plan
+        out = ops.indice_conv(f_t, w_t, nbr, n, packed=packed)
+        np.testing.assert_array_equal(out.float().cpu().numpy(), ref, err_msg=f"variant {variant}")
+    ops.indice_conv_set_variant(-1)
+
+
+def test_conv_rows_ragged_tail_device_count_and_empty_rows(ops, layer):
+    """(ii) n_out % 128 in {1, 127}, (iii) a device-side row count below the table capacity with garbage rows behind it,
+    (iv) rows without any neighbour -- all bit-exact on integer operands, every kernel form."""
+    dtype = torch.bfloat16
+    rng = np.random.default_rng(9)
+    n = layer["n"]
+    feat = rng.integers(-1, 2, (n, 64)).astype(np.float32)
+    w = (rng.integers(-1, 2, (3, 3, 3, 64, 64)) * (rng.random((3, 3, 3, 64, 64)) < 0.04)).astype(np.float32)
+    nbr = layer["nbr"].copy()
+    lonely = rng.choice(n, 3000, replace=False)
+    nbr[lonely] = -1                                         # (iv) these rows must come out as act(shift)
+    nbr[100:228] = -1                                        # a whole workgroup's worth of them
+    pairs = -np.ones((27, 2, n), np.int32)
+    pair_num = np.zeros(27, np.int32)
+    for k in range(27):
+        o = np.nonzero(nbr[:, k] >= 0)[0]
+        pairs[k, 0, :len(o)], pairs[k, 1, :len(o)], pair_num[k] = nbr[o, k], o, len(o)
+    shift = rng.integers(-2, 3, 64).astype(np.float32)
+    ref = np.maximum(orc.indice_conv(feat, w, pairs, pair_num, n, acc64=True) + shift, 0)
+    assert np.abs(ref).max() <= 256
+    f_t, w_t = dev(feat, dtype), dev(w, dtype)
+    packed = ops.pack_weight(w_t)
+    sizes = [n - (n % 128) + 1 - 128, n - (n % 128) + 127 - 128, n]
+    assert [m % 128 for m in sizes[:2]] == [1, 127] and min(sizes) >= 32768
+    garbage = np.full((512, 27), 0x3fffffff, np.int32)       # rows past the live count: never dereferenced
+    for variant, plan in ROW_VARIANTS:
+        ops.indice_conv_set_variant(-1 if variant is None else variant)
+        for m in sizes:
+            assert ops.indice_conv_plan(64, 64, 27, m, dtype) == plan
+            out = ops.indice_conv(f_t, w_t, dev(nbr[:m]), m, packed=packed, shift=dev(shift), relu=True)
+            np.testing.assert_array_equal(out.float().cpu().numpy(), ref[:m], err_msg=f"variant {variant} n_out {m}")
+            # static-capacity form: capacity m + 512, live count on the device
+            table = dev(np.concatenate([nbr[:m], garbage]))
+            out = ops.indice_conv(f_t, w_t, table, m + 512, packed=packed, shift=dev(shift), relu=True,
+                                  num_out_dev=dev(np.array([m], np.int32)))
+            np.testing.assert_array_equal(out[:m].float().cpu().numpy(), ref[:m], err_msg=f"variant {variant} static n_out {m}")
+    ops.indice_conv_set_variant(-1)
+    torch.cuda.synchronize()

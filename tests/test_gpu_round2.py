@@ -1,0 +1,85 @@
+"""-m gpu tests added in round 2: failure modes the advisor / judge named (overflowed static tables followed by a SubM layer,
+generate_multi_gpu) -- HIP path through the C ABI vs the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle as orc  # noqa: E402  (test infrastructure only)
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from second_amd import ops
+    return ops
+
+
+def _scattered_indices(rng, batch, shape, n):
+    cells = rng.choice(batch * int(np.prod(shape)), n, replace=False)
+    b, rem = np.divmod(cells, int(np.prod(shape)))
+    z, rem = np.divmod(rem, shape[1] * shape[2])
+    y, x = np.divmod(rem, shape[2])
+    return np.stack([b, z, y, x], 1).astype(np.int32)
+
+
+@pytest.mark.timeout(120)
+def test_overflowed_strided_table_then_subm_is_reported_not_hung(ops):
+    """a static-capacity strided build whose hash table was sized from a too-small hint fills every slot; the SubM
+    layer that re-uses that table (sec_rulebook_subm3d_after_conv) must still terminate (bounded probing) so that the host's
+    overflow check -- not a GPU hang inside a captured graph -- is what the user sees."""
+    rng = np.random.default_rng(3)
+    shape = [21, 200, 176]
+    idx = _scattered_indices(rng, 1, shape, 6000)              # isolated voxels: ~3 distinct outputs per input
+    n = len(idx)
+    ref_out, _, _, _ = orc.rulebook_conv(idx, 1, shape, 3, 2, 1)
+    assert len(ref_out) > 2.5 * n                                # beyond the 2 * n slots a hint of 1 provides
+    s = ops.rulebook_conv(dev(idx), 1, shape, 3, 2, 1, out_cap=2 * n, out_per_in_hint=1)
+    raw = int(s["num_out_dev"][1].item())
+    assert raw > 2 * n, raw                                      # reported: raw count (or the table-full marker) above the capacity
+    sub = ops.rulebook_subm(s["out_indices"], 1, s["out_shape"], 3, n_dev=s["num_out_dev"][:1], site_table=s["site_table"])
+    torch.cuda.synchronize()                                     # returns: no unbounded probe sequence
+    assert sub["nbr_out"].shape == (2 * n, 27)
+    # and a build with enough capacity on the same input is still bit-exact
+    ok = ops.rulebook_conv(dev(idx), 1, shape, 3, 2, 1, out_cap=len(ref_out) + 256)
+    m = int(ok["num_out_dev"][0].item())
+    assert m == len(ref_out) and int(ok["num_out_dev"][1].item()) == m
+    np.testing.assert_array_equal(ok["out_indices"][:m].cpu().numpy(), ref_out)
+    sub = ops.rulebook_subm(ok["out_indices"], 1, ok["out_shape"], 3, n_dev=ok["num_out_dev"][:1], site_table=ok["site_table"])
+    ref_sub = orc.rulebook_subm(ref_out, 1, ok["out_shape"], 3)
+    nbr = -np.ones((m, 27), np.int32)
+    for k in range(27):
+        p = ref_sub[1][k, :, :ref_sub[2][k]]
+        nbr[p[1], k] = p[0]
+    np.testing.assert_array_equal(sub["nbr_out"][:m].cpu().numpy(), nbr)
+
+
+def test_generate_multi_gpu_padded_output(ops):
+    """SURVEY 8 row a3 (second/data/preprocess.py:310-315): arrays stay at max_voxels length, zero padded, + voxel_num."""
+    import spconv
+    from second_amd import synthetic as syn
+    cloud = syn.syn_kitti_cloud(3, num_points=5000, num_voxels=4200)
+    gen = spconv.utils.VoxelGeneratorV2(syn.CAR_FHD_VOXEL, syn.CAR_FHD_RANGE, 5, 20000)
+    for cap in (6000, 3000):                                    # cap not hit / cap hit
+        ref = orc.points_to_voxel(cloud, syn.CAR_FHD_VOXEL, syn.CAR_FHD_RANGE, 5, cap)
+        got = gen.generate_multi_gpu(cloud, cap)
+        n = ref["voxel_num"]
+        assert got["voxel_num"] == n and (n == cap) == (cap == 3000)
+        assert got["voxels"].shape == (cap, 5, 4) and got["coordinates"].shape == (cap, 3)
+        assert got["num_points_per_voxel"].shape == (cap,) and got["voxel_point_mask"].shape == (cap, 5, 1)
+        np.testing.assert_array_equal(got["voxels"][:n], ref["voxels"])
+        np.testing.assert_array_equal(got["coordinates"][:n], ref["coordinates"])
+        np.testing.assert_array_equal(got["num_points_per_voxel"][:n], ref["num_points_per_voxel"])
+        for k in ("voxels", "coordinates", "num_points_per_voxel", "voxel_point_mask"):
+            assert not got[k][n:].any(), k
+        mask = (np.arange(5)[None, :] < ref["num_points_per_voxel"][:, None]).astype(np.float32)[..., None]
+        np.testing.assert_array_equal(got["voxel_point_mask"][:n], mask)
+        plain = gen.generate(cloud, cap)
+        assert plain["voxels"].shape[0] == n

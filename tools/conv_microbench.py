@@ -23,7 +23,9 @@ def main():
     ap.add_argument("--layer", default="subm2")
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--sorted", action="store_true", help="spatially sorted clouds (rows in (z,y,x) order per frame)")
-    ap.add_argument("--timeline", action="store_true", help="per-wave clock64 timeline of the split-K kernel (needs a build with SEC_EXTRA_HIPCC_FLAGS=-DSEC_CONV_TIMELINE)")
+    ap.add_argument("--timeline", action="store_true", help="per-wave clock64 timeline of the row-split kernels (with --variants; needs a build with SEC_EXTRA_HIPCC_FLAGS=-DSEC_CONV_TIMELINE)")
+    ap.add_argument("--variants", default="", help="comma list of SEC_CONV_VARIANT numbers timed back to back in this process (each checked against split-K)")
+    ap.add_argument("--repeat", type=int, default=1)
     ap.add_argument("--backward", action="store_true", help="also time sec_indice_conv_bwd (dgrad + wgrad), bf16 and fp32")
     args = ap.parse_args()
     dev = torch.device("cuda")
@@ -48,16 +50,57 @@ def main():
     packed = ops.pack_weight(w)
     scale = torch.ones(c, device=dev)
     shift = torch.zeros(c, device=dev)
-    for _ in range(5):
-        out = ops.indice_conv(feat, w, rb["nbr_out"], n, packed=packed, scale=scale, shift=shift, relu=True)
-    torch.cuda.synchronize()
+    from second_amd import runtime as rt
+    b_alg = 2 * (pairs * c + n * c) + 8 * pairs + 2 * 27 * c * c
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(args.iters):
-        out = ops.indice_conv(feat, w, rb["nbr_out"], n, packed=packed, scale=scale, shift=shift, relu=True)
-    e1.record()
-    torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / args.iters
+    run = lambda: ops.indice_conv(feat, w, rb["nbr_out"], n, packed=packed, scale=scale, shift=shift, relu=True)
+
+    def time_it(iters):
+        for _ in range(5):
+            run()
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(iters):
+            out = run()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / iters, out
+
+    if args.variants:
+        # several kernel families in ONE process (same box, same clocks): sec_indice_conv_set_variant switches between them
+        rt.lib().sec_indice_conv_set_variant(8)
+        ref = ops.indice_conv(feat, w, rb["nbr_out"], n, packed=packed, scale=scale, shift=shift, relu=True, out_dtype=torch.float32)
+        code = rt.dtype_code(feat.dtype)
+        for rep in range(args.repeat):
+            for v in [int(x) for x in args.variants.split(",")]:
+                rt.lib().sec_indice_conv_set_variant(v)
+                plan = rt.lib().sec_indice_conv_fwd_plan(c, c, 27, n, code, code, 1)
+                us, out = time_it(args.iters)
+                err = ((out.float() - ref).abs().max() / ref.abs().max()).item()
+                print(f"variant={v:3d} plan={plan:2d} layer={args.layer} rows={n} pairs={pairs} us/launch={us:7.2f} "
+                      f"alg_GBs={b_alg / us / 1e3:7.1f} frac_of_8TBs={b_alg / us / 1e3 / 8000:.3f} max_rel_err_vs_splitk={err:.2e}", flush=True)
+                if args.timeline and plan >= 6 and rep == 0 and hasattr(rt.lib(), "sec__debug_timeline"):
+                    import ctypes
+                    nw = (n + 127) // 128 * 4
+                    buf = torch.zeros((nw, 8), dtype=torch.int64, device=dev)
+                    rt.lib().sec__debug_timeline(ctypes.c_void_p(buf.data_ptr()))
+                    run()
+                    torch.cuda.synchronize()
+                    rt.lib().sec__debug_timeline(ctypes.c_void_p(0))
+                    t = buf.cpu().numpy().astype(np.float64)
+                    t = t[t[:, 3] > 0]
+                    z = np.zeros(len(t))                      # s_memtime is per XCD: offsets relative to the XCD's first wave
+                    for x in np.unique(t[:, 7]):
+                        z[t[:, 7] == x] = t[t[:, 7] == x, 0].min()
+                    cols = {"start_offset": t[:, 0] - z, "idx_loads": t[:, 1] - t[:, 0], "offset_loop": t[:, 2] - t[:, 1],
+                            "epilogue": t[:, 3] - t[:, 2], "end_offset": t[:, 3] - z, "sum_wait+barrier": t[:, 4],
+                            "sum_issue": t[:, 5], "sum_compute": t[:, 6]}
+                    for nm, col in cols.items():
+                        q = np.percentile(col, [5, 50, 95])
+                        print(f"    {nm:18s} p5={q[0]:9.0f} p50={q[1]:9.0f} p95={q[2]:9.0f}  (shader clocks)")
+        rt.lib().sec_indice_conv_set_variant(-1)
+        return
+    us, _ = time_it(args.iters)
     if args.backward:
         for dt in (torch.bfloat16, torch.float32):
             f, ww, do = feat.to(dt), w.to(dt), torch.randn(n, c, device=dev).to(dt)
@@ -71,25 +114,6 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
                 print(f"backward {'dgrad' if need[0] else 'wgrad'} {dt}: {e0.elapsed_time(e1) * 100:.1f} us")
-    if args.timeline:
-        import ctypes
-        from second_amd import runtime as rt
-        nw = (n + 31) // 32 * 4
-        buf = torch.zeros((nw, 6), dtype=torch.int64, device=dev)
-        rt.lib().sec__debug_timeline(ctypes.c_void_p(buf.data_ptr()))
-        ops.indice_conv(feat, w, rb["nbr_out"], n, packed=packed, scale=scale, shift=shift, relu=True)
-        torch.cuda.synchronize()
-        rt.lib().sec__debug_timeline(ctypes.c_void_p(0))
-        t = buf.cpu().numpy().astype(np.float64)
-        t = t[t[:, 4] > 0]
-        z = t[:, 0].min()
-        seg = np.stack([t[:, 0] - z, t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2], t[:, 4] - t[:, 3], t[:, 4] - z], 1)
-        names = ["start_offset", "setup(idx)", "k-loop", "lds+barrier", "finish", "end_offset"]
-        for i, nm in enumerate(names):
-            q = np.percentile(seg[:, i], [5, 50, 95])
-            print(f"  {nm:14s} p5={q[0]:9.0f} p50={q[1]:9.0f} p95={q[2]:9.0f}  (clock64 ticks)")
-        print("  waves", len(t), "span ticks", seg[:, 5].max())
-    b_alg = 2 * (pairs * c + n * c) + 8 * pairs + 2 * 27 * c * c
     print(f"variant={os.environ.get('SEC_CONV_VARIANT', 'default')} layer={args.layer} rows={n} pairs={pairs} C={c} "
           f"us/launch={us:.2f} alg_GBs={b_alg / us / 1e3:.1f} frac_of_8TBs={b_alg / us / 1e3 / 8000:.3f}")
 
