@@ -478,7 +478,7 @@ __device__ __forceinline__ void clds_barrier() { asm volatile("s_waitcnt lgkmcnt
 
 template <typename T, int CIN, int COUT>
 struct RowsCfg {
-    static constexpr int KS = CIN / 16, NT = COUT / 32;
+    static constexpr int KS = CIN / 16, NT = (COUT + 31) / 32;   // COUT = 16: one half-used 32-column tile (packed weights are padded)
     static constexpr int LPR = CIN / 8;            // 16-byte chunks (= DMA lanes) per feature row
     static constexpr int RPI = 64 / LPR;           // rows per DMA instruction
     static constexpr int ND = 32 / RPI;            // DMA instructions per 32-row tile
@@ -559,24 +559,26 @@ template <int NBW> __device__ __forceinline__ void cwait_after(int younger_gathe
 // swap a register group so every lane stores 16-byte runs; fused scale / shift / ReLU
 // `aff` = LDS copy of scale[COUT] | shift[COUT] made by rows_stage_affine at kernel start (16-byte reads, all in flight together)
 template <typename T, int COUT, bool FUSED>
-__device__ __forceinline__ void rows_store_impl(f32x16 (&acc)[COUT / 32], T *__restrict__ out, long long row, bool valid, int h,
+__device__ __forceinline__ void rows_store_impl(f32x16 (&acc)[(COUT + 31) / 32], T *__restrict__ out, long long row, bool valid, int h,
                                                 const float *__restrict__ aff, bool has_scale, bool has_shift, int relu) {
     if (FUSED) { has_scale = has_shift = true; relu = 1; }   // the inference layers: straight-line multiply, add, max
+    constexpr int NT = (COUT + 31) / 32, NG = COUT >= 32 ? 4 : COUT / 8;   // register groups of 4 that hold real channels
+    static_assert(COUT % 16 == 0, "whole 16-byte runs per half-wave pair");
     T *orow = out + (size_t)row * COUT;
-    float4 sc4[COUT / 32][4], sh4[COUT / 32][4];
+    float4 sc4[NT][NG], sh4[NT][NG];
 #pragma unroll
-    for (int t = 0; t < COUT / 32; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
+        for (int g = 0; g < NG; ++g) {
             const int c = t * 32 + 8 * g + 4 * h;
             if (has_scale) sc4[t][g] = *reinterpret_cast<const float4 *>(aff + c);
             if (has_shift) sh4[t][g] = *reinterpret_cast<const float4 *>(aff + COUT + c);
         }
 #pragma unroll
-    for (int t = 0; t < COUT / 32; ++t) {
-        uint2 pk[4];
+    for (int t = 0; t < NT; ++t) {
+        uint2 pk[NG];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
+        for (int g = 0; g < NG; ++g) {
             const float sc[4] = {sc4[t][g].x, sc4[t][g].y, sc4[t][g].z, sc4[t][g].w};
             const float sh[4] = {sh4[t][g].x, sh4[t][g].y, sh4[t][g].z, sh4[t][g].w};
             T v4[4];
@@ -585,7 +587,7 @@ __device__ __forceinline__ void rows_store_impl(f32x16 (&acc)[COUT / 32], T *__r
             __builtin_memcpy(&pk[g], v4, 8);
         }
 #pragma unroll
-        for (int pr = 0; pr < 2; ++pr) {
+        for (int pr = 0; pr < NG / 2; ++pr) {
             const uint2 keep = h ? pk[2 * pr + 1] : pk[2 * pr];
             const uint2 send = h ? pk[2 * pr] : pk[2 * pr + 1];
             uint2 recv;
@@ -597,7 +599,7 @@ __device__ __forceinline__ void rows_store_impl(f32x16 (&acc)[COUT / 32], T *__r
     }
 }
 template <typename T, int COUT>
-__device__ __forceinline__ void rows_store(f32x16 (&acc)[COUT / 32], T *__restrict__ out, long long row, bool valid, int h,
+__device__ __forceinline__ void rows_store(f32x16 (&acc)[(COUT + 31) / 32], T *__restrict__ out, long long row, bool valid, int h,
                                            const float *__restrict__ aff, bool has_scale, bool has_shift, int relu) {
     if (has_scale && has_shift && relu) rows_store_impl<T, COUT, true>(acc, out, row, valid, h, aff, true, true, 1);
     else rows_store_impl<T, COUT, false>(acc, out, row, valid, h, aff, has_scale, has_shift, relu);
@@ -911,19 +913,36 @@ static void launch_rows_reg(const void *feat, const void *packed, const int *nbr
 // gathers because vmcnt retires in order), 8 ds_read_b128 and 8 MFMAs: ~35 instructions.  WAVES = 8 makes the workgroup 256
 // rows, so one copy of W[k] per CU and step instead of two.
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-template <typename T, int CIN, int COUT, int KVOL, int DIST, int WAVES, int MINW>
+// FL bit 0: the tile's 32 x KVOL neighbour table arrives as four coalesced 16-byte loads per lane staged through LDS (instead
+//           of KVOL strided dword loads per lane, each a 32-cache-line gather: 27 x 8 waves of them kept the CU's address
+//           pipe busy for ~5000 clocks before the first offset);
+//    bit 1: the B fragments of offset k+1 are read from LDS while offset k's MFMAs run (register double buffer), so a wave's
+//           step no longer starts with an exposed LDS round trip.
+template <typename T, int CIN, int COUT, int KVOL, int DIST, int WAVES, int MINW, int FL>
 __global__ __launch_bounds__(WAVES * 64, MINW) void k_conv_rows_buf(const T *__restrict__ feat, long long feat_bytes,
                                                                    const T *__restrict__ packed, const int *__restrict__ nbr,
                                                                    int n_out, const int *__restrict__ num_out_dev,
                                                                    const float *__restrict__ scale, const float *__restrict__ shift,
                                                                    int relu, T *__restrict__ out) {
     using C = RowsCfg<T, CIN, COUT>;
-    constexpr int NBW = C::BPIECES / WAVES;              // 1 KB weight pieces per wave and offset
+    constexpr int NBW = (C::BPIECES + WAVES - 1) / WAVES;   // 1 KB weight pieces per wave and offset (narrow layers: duplicated)
     constexpr int ROWB = CIN * (int)sizeof(T);           // bytes per feature row
-    static_assert(C::BPIECES % WAVES == 0 && NBW >= 1, "weight pieces split evenly over the waves");
+    constexpr bool STAGE = (FL & 1) != 0, PIPE = (FL & 2) != 0;
+    // FL bit 5 (SKEW, 8-wave workgroups): every step ends in a workgroup barrier, so the two waves of a SIMD leave it together,
+    // want the MFMA pipe together, and the loser's later instructions (its next gathers) sit behind its queued MFMAs.  Waves
+    // 4..7 therefore issue their gathers BEFORE their MFMAs (one offset later than waves 0..3 would): while one wave of the
+    // SIMD multiplies, the other one issues loads, and vice versa.
+    constexpr bool SKEW = (FL & 32) != 0 && WAVES == 8 && PIPE;
+    const bool early = SKEW && __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8) != 0;
+    constexpr int TBL16 = 32 * KVOL / 4;                 // 16-byte pieces of one tile's neighbour table
+    static_assert(NBW >= 1 && NBW <= 2, "one or two weight pieces per wave");
+    static_assert(C::KS <= 4, "up to four 16-channel k-steps per row");
+    static_assert(!STAGE || (32 * KVOL) % 4 == 0, "tile table in whole 16-byte pieces");
     __shared__ __attribute__((aligned(16))) uint4 bring[3][C::BSLOT];
     __shared__ __attribute__((aligned(16))) float aff[2 * COUT];
+    __shared__ __attribute__((aligned(16))) u32x4_t stage[STAGE ? WAVES : 1][STAGE ? TBL16 : 1];
     rows_stage_affine<COUT>(aff, scale, shift);
+    const int n_cap = n_out;                             // rows the table holds (>= the live count of a static-capacity launch)
     if (num_out_dev) n_out = *num_out_dev;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -932,10 +951,30 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_conv_rows_buf(const T *__r
     const bool valid = row < n_out;
     SEC_RTL(long long *tl = g_timeline; long long tl0 = 0, tl1 = 0, tl2 = 0; if (tl) tl0 = clock64();)
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(feat), 0, (int)feat_bytes, 0x00020000);
-    const uint4 *wp = reinterpret_cast<const uint4 *>(packed) + (size_t)w * NBW * 64 + lane;
+    const int piece0 = (w * NBW) % C::BPIECES;           // waves beyond the last piece re-copy one (identical bytes, same slot)
+    const u32x4_t *wpv = reinterpret_cast<const u32x4_t *>(packed) + (size_t)piece0 * 64 + lane;
     // byte offset of this lane's first 16-byte chunk of every neighbour row; no neighbour -> beyond the buffer -> zeros
     unsigned off[KVOL];
-    {
+    if constexpr (STAGE) {
+        const long long tile_row0 = (long long)blockIdx.x * (32 * WAVES) + w * 32;
+        const long long tbl_bytes = (long long)n_cap * KVOL * 4;
+        const int *tile = nbr + tile_row0 * KVOL;
+        const long long left = tbl_bytes - tile_row0 * KVOL * 4;      // bytes of the table from this tile on (> 0 here)
+        const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<int *>(tile), 0, (int)(left < 32 * KVOL * 4 ? left : 32 * KVOL * 4), 0x00020000);
+#pragma unroll
+        for (int i = 0; i < (TBL16 + 63) / 64; ++i) {
+            const int p16 = i * 64 + lane;
+            if (p16 < TBL16) stage[w][p16] = __builtin_amdgcn_raw_buffer_load_b128(trs, p16 * 16, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int *mine = reinterpret_cast<const int *>(&stage[w][0]) + r * KVOL;
+#pragma unroll
+        for (int k = 0; k < KVOL; ++k) {
+            const int t = valid ? mine[k] : -1;
+            off[k] = t >= 0 ? (unsigned)t * ROWB + h * 16 : 0x80000000u;
+        }
+    } else {
         const int *nrow = nbr + (size_t)(valid ? row : 0) * KVOL;
 #pragma unroll
         for (int k = 0; k < KVOL; ++k) {
@@ -943,17 +982,29 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_conv_rows_buf(const T *__r
             off[k] = t >= 0 ? (unsigned)t * ROWB + h * 16 : 0x80000000u;
         }
     }
+#ifdef SEC_CONV_ABLATIONS   // timing-only forms (wrong results): where does the offset loop's time go?
+    if constexpr ((FL & 4) != 0) {          // no gather touches memory
+#pragma unroll
+        for (int k = 0; k < KVOL; ++k) off[k] = 0x80000000u;
+    }
+    if constexpr ((FL & 8) != 0) {          // every gather instruction touches 8 cache lines instead of 32
+#pragma unroll
+        for (int k = 0; k < KVOL; ++k) off[k] = (unsigned)__shfl((int)off[k], lane & ~3, 64);
+    }
+    if constexpr ((FL & 16) != 0) {         // all gathers hit one line
+#pragma unroll
+        for (int k = 0; k < KVOL; ++k) off[k] = h * 16;
+    }
+#endif
     SEC_RTL(if (tl) { cwait_vmcnt<0>(); tl1 = clock64(); })
     f32x16 acc[C::NT];
 #pragma unroll
     for (int t = 0; t < C::NT; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
-    static_assert(NBW <= 2, "one or two weight pieces per wave");
     u32x4_t areg[DIST][C::KS];
     u32x4_t wr0[DIST], wr1[DIST];
-    u32x4_t *bslot = reinterpret_cast<u32x4_t *>(&bring[0][(w * NBW) * 64 + lane]);
-    const u32x4_t *wpv = reinterpret_cast<const u32x4_t *>(wp);
+    u32x4_t *bslot = reinterpret_cast<u32x4_t *>(&bring[0][piece0 * 64 + lane]);
 #define SEC_FETCH(k)                                                                                                  \
     {                                                                                                                 \
         wr0[(k) % DIST] = wpv[(size_t)(k) * C::BSLOT];                                                                \
@@ -963,32 +1014,67 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_conv_rows_buf(const T *__r
         if (C::KS > 2) areg[(k) % DIST][2 % C::KS] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[k] + 64, 0, 0);  \
         if (C::KS > 3) areg[(k) % DIST][3 % C::KS] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[k] + 96, 0, 0);  \
     }
-    static_assert(C::KS <= 4, "up to four 16-channel k-steps per row");
+#define SEC_WPUT(k)                                                                                                   \
+    {                                                                                                                 \
+        bslot[((k) % 3) * C::BSLOT] = wr0[(k) % DIST];                                                                \
+        if (NBW > 1) bslot[((k) % 3) * C::BSLOT + 64] = wr1[(k) % DIST];                                              \
+    }
 #pragma unroll
     for (int k = 0; k < DIST && k < KVOL; ++k) SEC_FETCH(k)
-    bslot[0] = wr0[0];
-    if (NBW > 1) bslot[64] = wr1[0];
+    if constexpr (!PIPE) {
+        SEC_WPUT(0)
 #pragma unroll
-    for (int k = 0; k < KVOL; ++k) {
-        if (k + 1 < KVOL) {                                  // W[k+1] leaves the register ring; its LDS slot was last read two barriers ago
-            bslot[((k + 1) % 3) * C::BSLOT] = wr0[(k + 1) % DIST];
-            if (NBW > 1) bslot[((k + 1) % 3) * C::BSLOT + 64] = wr1[(k + 1) % DIST];
+        for (int k = 0; k < KVOL; ++k) {
+            if (k + 1 < KVOL) SEC_WPUT(k + 1)                // W[k+1] leaves the register ring; its LDS slot was last read two barriers ago
+            __syncthreads();                                 // W[k] (stored during step k-1) is visible to every wave
+            uint4 bf[C::KS * C::NT];
+#pragma unroll
+            for (int i = 0; i < C::KS * C::NT; ++i) bf[i] = bring[k % 3][i * 64 + lane];
+            __builtin_amdgcn_sched_barrier(0);               // all B fragments in flight together, then the MFMAs back to back
+#pragma unroll
+            for (int s = 0; s < C::KS; ++s) {
+                const uint4 a = __builtin_bit_cast(uint4, areg[k % DIST][s]);
+#pragma unroll
+                for (int t = 0; t < C::NT; ++t) acc[t] = Mfma<T>::run(bf[s * C::NT + t], a, acc[t]);   // D^T
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (k + DIST < KVOL) SEC_FETCH(k + DIST)         // into the registers this step just consumed
         }
-        __syncthreads();                                     // W[k] (stored during step k-1) is visible to every wave
-        uint4 bf[C::KS * C::NT];
+    } else {
+        static_assert(!PIPE || DIST >= 3, "W[k+2] must have left the ring before its registers are refilled");
+        // B fragments one offset ahead: step k stores W[k+2], the barrier publishes W[k+1], whose fragments are then read
+        // while the MFMAs of offset k run on the fragments read during step k-1
+        uint4 bf[2][C::KS * C::NT];
+        SEC_WPUT(0)
+        if (KVOL > 1) SEC_WPUT(1)
+        __syncthreads();
 #pragma unroll
-        for (int i = 0; i < C::KS * C::NT; ++i) bf[i] = bring[k % 3][i * 64 + lane];
-        __builtin_amdgcn_sched_barrier(0);                   // all B fragments in flight together, then the MFMAs back to back
+        for (int i = 0; i < C::KS * C::NT; ++i) bf[0][i] = bring[0][i * 64 + lane];
 #pragma unroll
-        for (int s = 0; s < C::KS; ++s) {
-            const uint4 a = __builtin_bit_cast(uint4, areg[k % DIST][s]);
+        for (int k = 0; k < KVOL; ++k) {
+            if (k + 2 < KVOL) SEC_WPUT(k + 2)                // slot (k+2)%3 held W[k-1]: its reads were issued before the last barrier
+            if (k + 1 < KVOL) {
+                __syncthreads();                             // W[k+1] (stored during step k-1) is visible
 #pragma unroll
-            for (int t = 0; t < C::NT; ++t) acc[t] = Mfma<T>::run(bf[s * C::NT + t], a, acc[t]);   // D^T
+                for (int i = 0; i < C::KS * C::NT; ++i) bf[(k + 1) & 1][i] = bring[(k + 1) % 3][i * 64 + lane];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (SKEW) {                            // waves 4..7 share their SIMDs with waves 0..3: see below
+                if (early && k >= 1 && k - 1 + DIST < KVOL) SEC_FETCH(k - 1 + DIST)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int s = 0; s < C::KS; ++s) {
+                const uint4 a = __builtin_bit_cast(uint4, areg[k % DIST][s]);
+#pragma unroll
+                for (int t = 0; t < C::NT; ++t) acc[t] = Mfma<T>::run(bf[k & 1][s * C::NT + t], a, acc[t]);   // D^T
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(SKEW && early) && k + DIST < KVOL) SEC_FETCH(k + DIST)
         }
-        __builtin_amdgcn_sched_barrier(0);
-        if (k + DIST < KVOL) SEC_FETCH(k + DIST)             // into the registers this step just consumed
     }
 #undef SEC_FETCH
+#undef SEC_WPUT
     SEC_RTL(if (tl) tl2 = clock64();)
     rows_store<T, COUT>(acc, out, row, valid, h, aff, scale != nullptr, shift != nullptr, relu);
 #ifdef SEC_CONV_TIMELINE
@@ -1000,10 +1086,10 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_conv_rows_buf(const T *__r
 #endif
 }
 
-template <typename T, int CIN, int COUT, int DIST, int WAVES, int MINW>
+template <typename T, int CIN, int COUT, int DIST, int WAVES, int MINW, int FL, int KVOL = 27>
 static void launch_rows_buf(const void *feat, long long n_feat, const void *packed, const int *nbr, int n_out, const int *num_out_dev,
                             const float *scale, const float *shift, int relu, void *out, hipStream_t st) {
-    hipLaunchKernelGGL((k_conv_rows_buf<T, CIN, COUT, 27, DIST, WAVES, MINW>), dim3(div_up(n_out, 32 * WAVES)), dim3(WAVES * 64), 0, st,
+    hipLaunchKernelGGL((k_conv_rows_buf<T, CIN, COUT, KVOL, DIST, WAVES, MINW, FL>), dim3(div_up(n_out, 32 * WAVES)), dim3(WAVES * 64), 0, st,
                        (const T *)feat, n_feat * CIN * (long long)sizeof(T), (const T *)packed, nbr, n_out, num_out_dev, scale, shift,
                        relu, (T *)out);
 }
@@ -1023,18 +1109,35 @@ static int conv_variant() {
 enum { PLAN_GENERIC = 0, PLAN_TILED = 1, PLAN_C4 = 2, PLAN_MFMA_WAVE = 3, PLAN_MFMA_SK = 4, PLAN_MFMA_SKS = 5, PLAN_ROWS = 6,
        PLAN_ROWS_COMPACT = 7, PLAN_ROWS_TOUCH = 8, PLAN_ROWS_COMPACT_TOUCH = 9, PLAN_ROWS_REG = 10, PLAN_ROWS_BUF = 11, PLAN_EXPERIMENT = 99 };
 
+// Row count from which the buffer-load row-split kernel replaces split-K in the automatic choice (SEC_CONV_ROWS_MIN; the
+// row-split chain of 27 offsets needs enough workgroups to fill the chip, split-K has a 4x shorter chain per wave)
+static int rows_min() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("SEC_CONV_ROWS_MIN"); v = e ? atoi(e) : 40000; }   // car.fhd batch 8: layers 1-8 (>= 56k rows) gain 25-30 %, the 23k-row layers lose
+    return v;
+}
+static bool buf_shape(int cin, int cout, int kvol) {
+    if (kvol == 3) return cin == 64 && cout == 64;
+    if (kvol != 27) return false;
+    return (cin == 16 && (cout == 16 || cout == 32)) || (cin == 32 && (cout == 32 || cout == 64)) || (cin == 64 && cout == 64);
+}
+
 // which row-split kernel (0 = none) the 16-bit MFMA path takes for this shape under the current variant setting
 static int rows_plan(int cin, int cout, int kvol, int n_out, bool same_dtype) {
-    if (!same_dtype || kvol != 27 || !(cin == 64 || cin == 32) || !(cout == 64 || cout == 32)) return 0;
+    if (!same_dtype) return 0;
     const int v = conv_variant();
+    if (buf_shape(cin, cout, kvol)) {
+        if (v == 22 || (v >= 16 && v <= 28 && cin == 64 && cout == 64 && kvol == 27)) return PLAN_ROWS_BUF;
+        if (v == 1 && n_out >= rows_min()) return PLAN_ROWS_BUF;
+    }
+    if (kvol != 27 || !(cin == 64 || cin == 32) || !(cout == 64 || cout == 32)) return 0;
     if (cin == 64) {
         if (v == 10) return PLAN_ROWS_COMPACT;
         if (v == 11) return PLAN_ROWS_TOUCH;
         if (v == 12) return PLAN_ROWS_COMPACT_TOUCH;
         if (v >= 13 && v <= 15 && cout == 64) return PLAN_ROWS_REG;
-        if (v >= 16 && v <= 19 && cout == 64) return PLAN_ROWS_BUF;
     }
-    if ((v == 1 && cin == 64 && cout == 64 && n_out >= 32768) || v == 9) return PLAN_ROWS;
+    if (v == 9) return PLAN_ROWS;
     return 0;
 }
 
@@ -1042,23 +1145,45 @@ template <typename T, typename OT, int CIN, int COUT>
 static void launch_mfma(const void *feat, long long n_feat, const void *packed, const int *nbr, int n_out, const int *num_out_dev,
                         int kvol, const float *scale, const float *shift, int relu, void *out, hipStream_t st) {
     constexpr int MT = 1;
+    if constexpr (std::is_same<T, OT>::value && CIN <= 64 && COUT <= 64 && (COUT >= CIN) ) {
+        const int rp = feat ? rows_plan(CIN, COUT, kvol, n_out, true) : 0;
+        if (rp == PLAN_ROWS_BUF && n_feat * CIN * (long long)sizeof(T) < 0x7fffffffll) {
+#define SEC_BUF(D, W, FLG, KV) launch_rows_buf<T, CIN, COUT, D, W, 2, FLG, KV>(feat, n_feat, packed, nbr, n_out, num_out_dev, scale, shift, relu, out, st)
+            if (kvol == 3) {
+                if constexpr (CIN == 64 && COUT == 64) { SEC_BUF(3, 8, 3, 3); return; }
+            } else {
+                if constexpr (CIN == 64 && COUT == 64) {
+                    switch (conv_variant()) {
+                    case 16: SEC_BUF(4, 4, 0, 27); return;
+                    case 17: SEC_BUF(4, 4, 1, 27); return;
+                    case 18: SEC_BUF(4, 4, 2, 27); return;
+                    case 19: SEC_BUF(4, 4, 3, 27); return;
+                    case 20: SEC_BUF(5, 4, 3, 27); return;
+                    case 21: SEC_BUF(5, 8, 3, 27); return;
+                    case 23: SEC_BUF(6, 4, 3, 27); return;
+                    case 27: SEC_BUF(5, 8, 3 + 32, 27); return;
+                    case 28: SEC_BUF(6, 8, 3 + 32, 27); return;
+#ifdef SEC_CONV_ABLATIONS
+                    case 24: SEC_BUF(4, 8, 3 + 4, 27); return;
+                    case 25: SEC_BUF(4, 8, 3 + 8, 27); return;
+                    case 26: SEC_BUF(4, 8, 3 + 16, 27); return;
+#endif
+                    default: break;
+                    }
+                }
+                SEC_BUF(4, 8, 3, 27);
+                return;
+            }
+#undef SEC_BUF
+        }
+    }
     if constexpr (std::is_same<T, OT>::value && (CIN == 64 || CIN == 32) && (COUT == 64 || COUT == 32)) {
-        // default for the large 64 -> 64 3x3x3 layers (subm2 of car.fhd); smaller row counts leave the row-split kernel's
-        // 27-offset chain exposed (subm3: 23.6 vs 16.8 us) and stay on split-K
         const int rp = feat ? rows_plan(CIN, COUT, kvol, n_out, true) : 0;
         if constexpr (CIN == 64) {
             if (rp == PLAN_ROWS_COMPACT) { launch_rows<T, CIN, COUT, 32>(feat, packed, nbr, n_out, num_out_dev, kvol, scale, shift, relu, out, st); return; }
             if (rp == PLAN_ROWS_TOUCH) { launch_rows<T, CIN, COUT, 64>(feat, packed, nbr, n_out, num_out_dev, kvol, scale, shift, relu, out, st); return; }
             if (rp == PLAN_ROWS_COMPACT_TOUCH) { launch_rows<T, CIN, COUT, 96>(feat, packed, nbr, n_out, num_out_dev, kvol, scale, shift, relu, out, st); return; }
             if constexpr (COUT == 64) {
-                if (rp == PLAN_ROWS_BUF && n_feat * CIN * (long long)sizeof(T) < 0x7fffffffll) {
-                    const int v = conv_variant();
-                    if (v == 16) launch_rows_buf<T, CIN, COUT, 4, 4, 2>(feat, n_feat, packed, nbr, n_out, num_out_dev, scale, shift, relu, out, st);
-                    else if (v == 17) launch_rows_buf<T, CIN, COUT, 4, 8, 2>(feat, n_feat, packed, nbr, n_out, num_out_dev, scale, shift, relu, out, st);
-                    else if (v == 18) launch_rows_buf<T, CIN, COUT, 3, 8, 2>(feat, n_feat, packed, nbr, n_out, num_out_dev, scale, shift, relu, out, st);
-                    else launch_rows_buf<T, CIN, COUT, 6, 8, 2>(feat, n_feat, packed, nbr, n_out, num_out_dev, scale, shift, relu, out, st);
-                    return;
-                }
                 if (rp == PLAN_ROWS_REG) {
                     const int v = conv_variant();
                     if (v == 13) launch_rows_reg<T, CIN, COUT, 4, 2>(feat, packed, nbr, n_out, num_out_dev, scale, shift, relu, out, st);
@@ -1101,7 +1226,7 @@ static void launch_mfma(const void *feat, long long n_feat, const void *packed, 
         return;
     }
 #endif
-    if (conv_variant() == 8 || (conv_variant() == 1 && COUT <= 32)) {   // single 32-column slice: leaner split-K kernel
+    if (conv_variant() == 8 || ((conv_variant() == 1 || conv_variant() == 29) && COUT <= 32)) {   // single 32-column slice: leaner split-K kernel (29 = the automatic choice without the row-split kernels)
         hipLaunchKernelGGL((k_conv_mfma_sks<T, OT, CIN, COUT, 4>), dim3((div_up(n_out, 32) + 7) / 8 * 8, (COUT + 31) / 32),
                            dim3(256), 0, st, (const T *)feat, (const T *)packed, nbr, n_out, num_out_dev, kvol, scale, shift,
                            relu, (OT *)out);
@@ -1591,7 +1716,7 @@ SEC_API int sec_indice_conv_fwd_plan(int cin, int cout, int kvol, int n_out, int
 #ifdef SEC_CONV_EXPERIMENTS
         if (v >= 2 && v <= 7) return PLAN_EXPERIMENT;
 #endif
-        if (v == 8 || (v == 1 && cout <= 32)) return PLAN_MFMA_SKS;
+        if (v == 8 || ((v == 1 || v == 29) && cout <= 32)) return PLAN_MFMA_SKS;
         return v >= 1 ? PLAN_MFMA_SK : PLAN_MFMA_WAVE;
     }
     if (cin == 4 && cout == 16 && (size_t)kvol * 4 * 16 * sizeof(float) <= 48 * 1024) return PLAN_C4;

@@ -6,10 +6,35 @@ the reference interface its kernel replaces (see the header for file:line).
 import numpy as np
 import torch
 
+import functools
+
 from . import runtime as rt
+
+# Measurement hook (bench.py's per-kernel roofline table): ``hook(name, fn, args, kwargs, result)`` is called after every traced
+# op so that the very same launch (same tensors, same tables) can be re-issued between two HIP events.  None = disabled.
+_op_hook = None
+
+
+def set_op_hook(hook):
+    global _op_hook
+    _op_hook = hook
+
+
+def _traced(name):
+    def deco(fn):
+        @functools.wraps(fn)
+        def wrapper(*args, **kwargs):
+            res = fn(*args, **kwargs)
+            if _op_hook is not None:
+                _op_hook(name, fn, args, kwargs, res)
+            return res
+        wrapper.__wrapped_op__ = fn
+        return wrapper
+    return deco
 
 
 # ----------------------------------------------------------------------------- voxelisation
+@_traced("voxelize")
 def voxelize(points, point_offsets, point_cloud_range, voxel_size, max_points, max_voxels,
              cap_mode="break", mean_features=0, sync=True):
     """Batched points_to_voxel (spconv VoxelGeneratorV2.generate; second/data/preprocess.py:301-316).
@@ -64,6 +89,7 @@ def _kvol(ksize):
     return int(np.prod([int(k) for k in ((ksize,) * 3 if isinstance(ksize, int) else ksize)]))
 
 
+@_traced("rulebook_subm")
 def rulebook_subm(indices, batch_size, spatial_shape, ksize=3, dilation=1, want_pairs=False, n_dev=None, site_table=None):
     """SubMConv3d rulebook (spconv.ops.get_indice_pairs(subm=True)).  indices [N,4] int32 (b,z,y,x).
     ``n_dev`` (device int32[1]) switches to static-capacity mode: only the first n_dev rows are live.
@@ -104,6 +130,7 @@ def _out_per_in(ks, st, dl):
     return tot
 
 
+@_traced("rulebook_conv")
 def rulebook_conv(indices, batch_size, spatial_shape, ksize, stride, padding, dilation=1, want_pairs=False,
                   n_dev=None, out_cap=None, out_per_in_hint=0, want_nbr_in=True):
     """SparseConv3d rulebook (spconv.ops.get_indice_pairs(subm=False)), first-touch output numbering.
@@ -180,6 +207,7 @@ def pack_weight(weight):
     return packed
 
 
+@_traced("indice_conv")
 def indice_conv(features, weight, nbr_out, num_out, packed=None, scale=None, shift=None, relu=False,
                 out_dtype=None, num_out_dev=None):
     """out[o] = sum_k features[nbr_out[o][k]] @ W[k], optional fused scale/shift/ReLU epilogue
@@ -241,6 +269,7 @@ def indice_conv_backward(features, weight, nbr_out, nbr_in, dout, need_dfeat=Tru
 
 
 # ----------------------------------------------------------------------------- scatters
+@_traced("sparse_to_dense")
 def sparse_to_dense(features, indices, batch_size, spatial_shape, channels_last_2d=False, num_dev=None):
     """SparseConvTensor.dense().  Default: [B,C,D,H,W] contiguous.  ``channels_last_2d``: a
     [B, C*D, H, W] tensor in torch.channels_last memory format (what the RPN consumes) -- same values as
@@ -281,6 +310,7 @@ def dense_to_sparse(dense, indices):
     return rows
 
 
+@_traced("pillar_scatter")
 def pillar_scatter(features, coords, batch_size, ny, nx, channels_last=False, num_dev=None):
     """PointPillarsScatter.forward (second/pytorch/models/pointpillars.py:444-476) as one launch."""
     rt.require_gpu(features, coords)
@@ -295,6 +325,7 @@ def pillar_scatter(features, coords, batch_size, ny, nx, channels_last=False, nu
     return out
 
 
+@_traced("pfn_forward")
 def pfn_forward(voxels, num_points, coords, weight_t, scale, shift, vx, vy, x_offset, y_offset, out_dtype=None,
                 num_dev=None):
     """Fused PillarFeatureNet (one PFNLayer, eval): decorate -> Linear(9,C) -> folded BN -> ReLU -> max over points
@@ -314,6 +345,7 @@ def pfn_forward(voxels, num_points, coords, weight_t, scale, shift, vx, vy, x_of
     return out
 
 
+@_traced("voxel_block_filter")
 def voxel_block_filter(vox, grid_size_xy, block_factor, block_size, height_threshold, height_high_threshold=3.0,
                        sync=True):
     """Block filtering of points_to_voxel_3d_with_filtering on the output dict of :func:`voxelize`
@@ -376,6 +408,7 @@ def conv2d_pack_weight(weight):
     return packed
 
 
+@_traced("conv2d_nhwc")
 def conv2d_nhwc(x, packed, bias, cout, ksize, stride=1, pad=0, relu=False, sparse_input=False):
     """Dense conv2d + bias + ReLU in one launch (hand-written MFMA implicit GEMM).  x: [B,Cin,H,W] in
     torch.channels_last memory format (bf16/f16); returns [B,Cout,Ho,Wo] channels_last.
@@ -393,6 +426,7 @@ def conv2d_nhwc(x, packed, bias, cout, ksize, stride=1, pad=0, relu=False, spars
 
 
 # ----------------------------------------------------------------------------- IoU / NMS
+@_traced("conv1x1_chain")
 def conv1x1_chain(x, packed_w1, bias1, packed_w2, bias2, cout2, relu1=True):
     """y = W2 * act(W1 * x + bias1) + bias2 for two back-to-back 1x1 convs on a channels_last [B,128,H,W] tensor
     (the RPN deblock + merged heads, rpn.py:275-285,386-391); the 128-channel intermediate stays in LDS."""
@@ -418,6 +452,7 @@ def rotate_iou(boxes, qboxes, criterion=-1):
     return out
 
 
+@_traced("nms_sorted")
 def nms_sorted(dets, counts, thresh, kind="rotate", semantics="numba", eps=1.0, post_max=0):
     """Greedy NMS of score-sorted boxes. dets [B,max_n,stride] float32, counts [B] int32 (device).
     Returns (keep [B,max_n] int32 positions, num_keep [B] int32), all on device, no host sync."""
@@ -442,6 +477,7 @@ def _strides5(t):
     return (ctypes.c_int64 * 5)(*[int(x) for x in t.stride()])
 
 
+@_traced("predict_select")
 def predict_select(cls, k, score_thr):
     """cls: [B, A, H, W, num_class] view (any strides).  -> (top_idx [B,k] int32 anchor ids sorted by descending
     score, top_score [B,k] sigmoid scores, top_label [B,k], counts [B] = entries with score >= score_thr)."""
@@ -460,6 +496,7 @@ def predict_select(cls, k, score_thr):
     return top_idx, top_score, top_label, counts
 
 
+@_traced("predict_decode")
 def predict_decode(box, dir_cls, anchors, top_idx, top_score, rotate=True):
     """box: [B,A,H,W,7] view, dir_cls: [B,A,H,W,bins] view or None, anchors [A*H*W,7] fp32.
     -> (decoded [B,k,7] fp32, dets [B,k,6] fp32 NMS rows, dir_label [B,k] int32)."""
@@ -482,6 +519,7 @@ def predict_decode(box, dir_cls, anchors, top_idx, top_score, rotate=True):
     return dec, dets, dlab
 
 
+@_traced("predict_finalize")
 def predict_finalize(dec, top_score, top_label, dir_label, keep, num_keep, post_max, use_direction, dir_offset,
                      dir_limit_offset, num_dir_bins, range6):
     """-> dict(boxes [B,P,7], scores [B,P], labels [B,P] int32, valid [B,P] bool)."""

@@ -1,8 +1,8 @@
 """-m gpu parity tests of the row-split sparse-conv kernels (k_conv_rows*, csrc/indice_conv.hip) against the CPU oracle.
 
 These are the kernels the bench's `roofline` object is quoted on: the 64->64 SubMConv3d layers of car.fhd's subm2 group
-(second/pytorch/models/middle.py:166-174).  The automatic dispatch only takes them for n_out >= 32768, so every case here
-is built at the size of the bench launch -- batch 8 of the SURVEY 8(d) clouds through the ORACLE's voxeliser and rulebooks
+(second/pytorch/models/middle.py:166-174).  Every case here
+is built at the size of the bench launch (the automatic dispatch takes the row-split kernel from 40 000 rows on) -- batch 8 of the SURVEY 8(d) clouds through the ORACLE's voxeliser and rulebooks
 (56 298 rows / 594 482 pairs) -- and `sec_indice_conv_fwd_plan` proves which kernel each comparison exercised.
 """
 import numpy as np
@@ -13,9 +13,9 @@ pytestmark = pytest.mark.gpu
 
 from oracle import oracle as orc  # noqa: E402  (test infrastructure only)
 
-PLAN_ROWS = 6
+PLAN_ROWS_BUF = 11
 # (variant number, expected plan id): None = the automatic choice; the others force one A/B form of the kernel
-ROW_VARIANTS = [(None, 6), (9, 6), (10, 7), (11, 8), (12, 9), (13, 10), (14, 10), (15, 10), (16, 11), (17, 11), (18, 11), (19, 11)]
+ROW_VARIANTS = [(None, 11), (9, 6), (10, 7), (11, 8), (12, 9), (13, 10), (14, 10), (15, 10), (16, 11), (17, 11), (18, 11), (19, 11), (20, 11), (21, 11), (22, 11), (23, 11), (27, 11), (28, 11)]
 
 
 def dev(a, dtype=None):
@@ -89,7 +89,7 @@ def test_conv_rows_bench_launch_vs_oracle(ops, layer, dtype):
         np.testing.assert_allclose(out.float().cpu().numpy(), ref_fused, rtol=tol, atol=tol * np.abs(ref_fused).max(), err_msg=f"variant {variant}")
     ops.indice_conv_set_variant(-1)
     # below the row threshold the automatic choice is split-K: the two families must agree on a prefix of the layer
-    assert ops.indice_conv_plan(64, 64, 27, 16000, dtype) != PLAN_ROWS
+    assert ops.indice_conv_plan(64, 64, 27, 16000, dtype) != PLAN_ROWS_BUF
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
@@ -152,3 +152,58 @@ def test_conv_rows_ragged_tail_device_count_and_empty_rows(ops, layer):
             np.testing.assert_array_equal(out[:m].float().cpu().numpy(), ref[:m], err_msg=f"variant {variant} static n_out {m}")
     ops.indice_conv_set_variant(-1)
     torch.cuda.synchronize()
+
+
+# ------------------------------------------------------------------ the buffer-load kernel on every layer shape of SpMiddleFHD
+BUF_SHAPES = [(16, 16, 3), (16, 32, 3), (32, 32, 3), (32, 64, 3), (64, 64, 3), (64, 64, (3, 1, 1))]
+
+
+@pytest.mark.parametrize("cin,cout,ksize", BUF_SHAPES)
+@pytest.mark.parametrize("subm", [True, False])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_conv_rows_buf_all_layer_shapes(ops, cin, cout, ksize, subm, dtype):
+    """SEC_CONV_VARIANT 22 forces k_conv_rows_buf for every (Cin, Cout, kernel) of middle.py:146-189, SubM and strided tables,
+    ragged row counts; integer operands -> bit-exact against the oracle, Gaussian operands -> within one 16-bit rounding."""
+    from test_gpu_parity import _random_indices, _tables_from_pairs
+    if subm and ksize != 3:
+        pytest.skip("the (3,1,1) kernel only occurs as a strided conv (middle.py:188)")
+    rng = np.random.default_rng(cin * 1000 + cout * 10 + int(subm))
+    shape = (9, 34, 30)
+    idx = _random_indices(rng, 3, shape, 2500)
+    if subm:
+        _, pairs, pair_num = orc.rulebook_subm(idx, 3, shape, ksize)
+        n_out = len(idx)
+    else:
+        stride = 2 if ksize == 3 else (2, 1, 1)
+        out_idx, pairs, pair_num, _ = orc.rulebook_conv(idx, 3, shape, ksize, stride, 1 if ksize == 3 else 0)
+        n_out = len(out_idx)
+    kvol = 27 if ksize == 3 else 3
+    nbr_out, _ = _tables_from_pairs(pairs, pair_num, len(idx), n_out)
+    assert n_out % 256 not in (0,) and n_out > 600
+    ops.indice_conv_set_variant(22)
+    try:
+        assert ops.indice_conv_plan(cin, cout, kvol, n_out, dtype) == 11
+        # integer operands: exact
+        feat = rng.integers(-1, 2, (len(idx), cin)).astype(np.float32)
+        dens = 0.08 if dtype == torch.bfloat16 else 0.5
+        w = (rng.integers(-1, 2, (kvol, cin, cout)) * (rng.random((kvol, cin, cout)) < dens)).astype(np.float32)
+        wk = w.reshape((3, 3, 3, cin, cout) if kvol == 27 else (3, 1, 1, cin, cout))
+        ref = orc.indice_conv(feat, wk, pairs, pair_num, n_out, acc64=True)
+        assert np.abs(ref).max() <= (256 if dtype == torch.bfloat16 else 2048)
+        f_t, w_t = dev(feat, dtype), dev(wk, dtype)
+        out = ops.indice_conv(f_t, w_t, dev(nbr_out), n_out, packed=ops.pack_weight(w_t))
+        assert out.dtype == dtype and out.shape == (n_out, cout)
+        np.testing.assert_array_equal(out.float().cpu().numpy(), ref)
+        # Gaussian operands + fused epilogue
+        feat = rng.standard_normal((len(idx), cin)).astype(np.float32)
+        wk = (rng.standard_normal(wk.shape) / np.sqrt(kvol * cin)).astype(np.float32)
+        f_t, w_t = dev(feat, dtype), dev(wk, dtype)
+        ref = orc.indice_conv(f_t.float().cpu().numpy(), w_t.float().cpu().numpy(), pairs, pair_num, n_out, acc64=True)
+        scale = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+        shift = rng.uniform(-0.2, 0.2, cout).astype(np.float32)
+        ref_f = torch.from_numpy(np.maximum(ref * scale + shift, 0)).to(dtype).float().numpy()
+        out = ops.indice_conv(f_t, w_t, dev(nbr_out), n_out, packed=ops.pack_weight(w_t), scale=dev(scale), shift=dev(shift), relu=True)
+        tol = _tol(dtype)
+        np.testing.assert_allclose(out.float().cpu().numpy(), ref_f, rtol=tol, atol=tol * np.abs(ref_f).max())
+    finally:
+        ops.indice_conv_set_variant(-1)

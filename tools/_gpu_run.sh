@@ -1,7 +1,21 @@
-mkdir -p gpurun_out/r2b
+mkdir -p gpurun_out/r2g
 export PYTHONUNBUFFERED=1
-timeout 900 python -m pytest tests/test_gpu_conv_rows.py tests/test_gpu_round2.py -q > gpurun_out/r2b/pytest_new.log 2>&1; echo "pytest_new rc=$?" >> gpurun_out/r2b/pytest_new.log
-timeout 300 python tools/conv_microbench.py --variants 8,1,9,13,16,17,18,19 --repeat 2 --iters 100 > gpurun_out/r2b/micro.log 2>&1
-SEC_HIP_LIB=$PWD/second.pytorch_amd/lib/libsecond_hip_tl.so timeout 300 python tools/conv_microbench.py --variants 9,13,16,17,19 --timeline --iters 20 > gpurun_out/r2b/timeline.log 2>&1
-timeout 600 python -m pytest tests/test_gpu_parity.py -q -x -k "indice_conv or sparse_sequential or detector" > gpurun_out/r2b/pytest_conv.log 2>&1; echo "rc=$?" >> gpurun_out/r2b/pytest_conv.log
-tail -5 gpurun_out/r2b/pytest_new.log; cat gpurun_out/r2b/micro.log; cat gpurun_out/r2b/timeline.log; tail -3 gpurun_out/r2b/pytest_conv.log
+timeout 1500 python -m pytest tests -m gpu -q -x > gpurun_out/r2g/pytest_all.log 2>&1; echo "pytest_all rc=$?" >> gpurun_out/r2g/pytest_all.log
+timeout 600 python bench.py > gpurun_out/r2g/bench.json 2> gpurun_out/r2g/bench.err
+timeout 300 python bench.py --inflight 1 --no-cpu-baseline --no-kernel-table > gpurun_out/r2g/bench_inflight1.json 2>> gpurun_out/r2g/bench.err
+cd /tmp && export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof1 -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 10 --inflight 1 --no-cpu-baseline --no-kernel-table > $GRAFT_REPO_ROOT/gpurun_out/r2g/rocprof_bench.log 2>&1
+find /tmp/prof1 -name "*kernel_stats*" -exec cp {} $GRAFT_REPO_ROOT/gpurun_out/r2g/ \;
+cd $GRAFT_REPO_ROOT
+tail -15 gpurun_out/r2g/pytest_all.log; python - <<'PY'
+import json
+for f in ("bench.json","bench_inflight1.json"):
+    try:
+        d=json.loads(open("gpurun_out/r2g/"+f).read().strip().splitlines()[-1])
+        k=d.pop("kernels",None)
+        print(f, json.dumps(d)[:3000])
+        if k:
+            for e in k: print("   ", e)
+    except Exception as ex: print(f, "ERR", ex)
+PY
+tail -5 gpurun_out/r2g/bench.err; ls gpurun_out/r2g

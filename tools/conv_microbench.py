@@ -17,6 +17,61 @@ import torch
 from second_amd import ops, synthetic as syn
 
 
+def all_layers(args, dev):
+    """Per-layer A/B over the whole car.fhd sparse stack (middle.py:146-189), bf16, fused scale/shift/ReLU epilogue."""
+    from second_amd import runtime as rt
+    clouds = [syn.syn_kitti_cloud(s) for s in range(args.batch)]
+    pts, offs = syn.batch_clouds(clouds)
+    vox = ops.voxelize(torch.from_numpy(pts).to(dev), torch.from_numpy(offs).to(dev), syn.CAR_FHD_RANGE, syn.CAR_FHD_VOXEL, 5, 40000)
+    idx, shape = vox["coordinates"].contiguous(), [41, 1600, 1408]
+    plan = [("subm", 4, 16), ("subm", 16, 16), ("down", 16, 32, 3, 2, 1), ("subm", 32, 32), ("subm", 32, 32), ("down", 32, 64, 3, 2, 1),
+            ("subm", 64, 64), ("subm", 64, 64), ("subm", 64, 64), ("down", 64, 64, 3, 2, (0, 1, 1)), ("subm", 64, 64), ("subm", 64, 64),
+            ("subm", 64, 64), ("down", 64, 64, (3, 1, 1), (2, 1, 1), 0)]
+    variants = [int(x) for x in (args.variants or "29,22").split(",")]
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    g = torch.Generator(device="cpu").manual_seed(0)
+    rb, total = None, {v: 0.0 for v in variants}
+    for li, spec in enumerate(plan):
+        kind, cin, cout = spec[:3]
+        if kind == "subm":
+            if rb is None or rb["kind"] != ("subm", idx.shape[0]):
+                rb = ops.rulebook_subm(idx, args.batch, shape, 3)
+                rb["kind"] = ("subm", idx.shape[0])
+            nbr, n_out, ks = rb["nbr_out"], idx.shape[0], (3, 3, 3)
+        else:
+            r = ops.rulebook_conv(idx, args.batch, shape, spec[3], spec[4], spec[5])
+            nbr, n_out = r["nbr_out"], r["num_out"]
+            ks = (spec[3],) * 3 if isinstance(spec[3], int) else spec[3]
+        n_in = idx.shape[0]
+        pairs = int((nbr >= 0).sum())
+        feat = torch.randn(n_in, cin, generator=g).to(dev).bfloat16()
+        w = (torch.randn(*ks, cin, cout, generator=g) / 30).to(dev).bfloat16()
+        packed = ops.pack_weight(w)
+        scale, shift = torch.ones(cout, device=dev), torch.zeros(cout, device=dev)
+        run = lambda: ops.indice_conv(feat, w, nbr, n_out, packed=packed, scale=scale, shift=shift, relu=True)
+        b_alg = 2 * (pairs * cin + n_out * cout) + 8 * pairs + 2 * int(np.prod(ks)) * cin * cout
+        line = f"layer {li:2d} {kind} {cin:2d}->{cout:2d} k{''.join(map(str, ks))} rows_in={n_in:6d} rows_out={n_out:6d} pairs={pairs:7d} B_alg={b_alg / 1e6:6.1f}MB |"
+        for v in variants:
+            rt.lib().sec_indice_conv_set_variant(v)
+            pl = rt.lib().sec_indice_conv_fwd_plan(cin, cout, int(np.prod(ks)), n_out, 2, 2, 1 if packed is not None else 0)
+            for _ in range(5):
+                run()
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(args.iters):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / args.iters
+            total[v] += us
+            line += f" v{v}(plan {pl}): {us:6.2f} us {b_alg / us / 1e3 / 8000:.3f}"
+        print(line, flush=True)
+        if kind == "down":
+            idx, shape, rb = r["out_indices"].contiguous(), r["out_shape"], None
+    print("sum over the 14 layers:", {v: round(t, 1) for v, t in total.items()}, "us")
+    rt.lib().sec_indice_conv_set_variant(-1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=50)
@@ -27,8 +82,11 @@ def main():
     ap.add_argument("--variants", default="", help="comma list of SEC_CONV_VARIANT numbers timed back to back in this process (each checked against split-K)")
     ap.add_argument("--repeat", type=int, default=1)
     ap.add_argument("--backward", action="store_true", help="also time sec_indice_conv_bwd (dgrad + wgrad), bf16 and fp32")
+    ap.add_argument("--all-layers", action="store_true", help="every conv layer of SpMiddleFHD at batch 8, each --variants entry per layer")
     args = ap.parse_args()
     dev = torch.device("cuda")
+    if args.all_layers:
+        return all_layers(args, dev)
     clouds = [syn.syn_kitti_cloud(s) for s in range(args.batch)]
     if args.sorted:
         clouds = [c[np.lexsort((c[:, 0], c[:, 1], c[:, 2]))] for c in clouds]
