@@ -1,21 +1,15 @@
-mkdir -p gpurun_out/r2g
+mkdir -p gpurun_out/r2h
 export PYTHONUNBUFFERED=1
-timeout 1500 python -m pytest tests -m gpu -q -x > gpurun_out/r2g/pytest_all.log 2>&1; echo "pytest_all rc=$?" >> gpurun_out/r2g/pytest_all.log
-timeout 600 python bench.py > gpurun_out/r2g/bench.json 2> gpurun_out/r2g/bench.err
-timeout 300 python bench.py --inflight 1 --no-cpu-baseline --no-kernel-table > gpurun_out/r2g/bench_inflight1.json 2>> gpurun_out/r2g/bench.err
+R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof1 -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 10 --inflight 1 --no-cpu-baseline --no-kernel-table > $GRAFT_REPO_ROOT/gpurun_out/r2g/rocprof_bench.log 2>&1
-find /tmp/prof1 -name "*kernel_stats*" -exec cp {} $GRAFT_REPO_ROOT/gpurun_out/r2g/ \;
-cd $GRAFT_REPO_ROOT
-tail -15 gpurun_out/r2g/pytest_all.log; python - <<'PY'
-import json
-for f in ("bench.json","bench_inflight1.json"):
-    try:
-        d=json.loads(open("gpurun_out/r2g/"+f).read().strip().splitlines()[-1])
-        k=d.pop("kernels",None)
-        print(f, json.dumps(d)[:3000])
-        if k:
-            for e in k: print("   ", e)
-    except Exception as ex: print(f, "ERR", ex)
-PY
-tail -5 gpurun_out/r2g/bench.err; ls gpurun_out/r2g
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof1 -o p -- python $R/bench.py --steps 50 --warmup 10 --inflight 1 --no-cpu-baseline --no-kernel-table > $R/gpurun_out/r2h/rocprof_bench.log 2>&1
+cp /tmp/prof1/p_results.db $R/gpurun_out/r2h/bench_inflight1.db
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof2 -o p -- python $R/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-kernel-table > $R/gpurun_out/r2h/rocprof_bench3.log 2>&1
+cp /tmp/prof2/p_results.db $R/gpurun_out/r2h/bench_inflight3.db
+for c in FETCH_SIZE WRITE_SIZE; do
+timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -o p -- python $R/tools/conv_microbench.py --layer subm2 --iters 20 > $R/gpurun_out/r2h/pmc_$c.log 2>&1
+mkdir -p $R/gpurun_out/r2h/pmc_$c; cp /tmp/pmc_$c/*.csv $R/gpurun_out/r2h/pmc_$c/ 2>/dev/null
+done
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_sq -o p -- python $R/tools/conv_microbench.py --layer subm2 --iters 20 > $R/gpurun_out/r2h/pmc_sq.log 2>&1
+mkdir -p $R/gpurun_out/r2h/pmc_sq; cp /tmp/pmc_sq/*.csv $R/gpurun_out/r2h/pmc_sq/ 2>/dev/null
+cd $R; ls -la gpurun_out/r2h gpurun_out/r2h/pmc_sq; tail -3 gpurun_out/r2h/pmc_sq.log
