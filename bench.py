@@ -223,7 +223,72 @@ WORKLOADS = {
                           "axis-aligned NMS), inference, batch=4 synthetic 10-sweep NuScenes clouds/GPU (<= 120k pts), "
                           "random-init weights, inputs resident in HBM"),
 }
+WORKLOADS["car.fhd.train"] = dict(cfg="CAR_FHD", batch=4, metric="samples/sec VoxelNet training step (car.fhd, batch 4/GPU)",
+                                  desc="car.fhd.config training step (voxelise + target assignment + SpMiddleFHD/RPNV2 forward, focal / "
+                                       "smooth-L1 / direction loss, backward, one flat-bucket gradient all-reduce, clip, AdamW), "
+                                       "batch=4 synthetic KITTI clouds/GPU (17000 pts, 16000 voxels, 12 ground-truth boxes each), "
+                                       "random-init weights, inputs resident in HBM")
 WL = WORKLOADS["car.fhd"]
+
+
+def train_bench(args, rank, local_rank, world, device):
+    """BASELINE config 3: DDP training, one process per GPU, ONE all-reduce of the flat gradient bucket per step (RCCL over
+    xGMI); weak scaling (batch 4 per GPU).  fp32 parameters and sparse stack (the reference's training precision), optional
+    bf16 autocast of the dense RPN (--dtype bf16)."""
+    import torch.distributed as dist
+    from second_amd import synthetic as syn
+    from second_amd.models import SecondDetector, CAR_FHD
+    from second_amd.training import DeviceTrainer
+    bs = WL["batch"]
+    clouds = [syn.syn_kitti_cloud(rank * bs + s) for s in range(bs)]
+    boxes = [syn.syn_kitti_boxes(rank * bs + s, 12) for s in range(bs)]
+    pts, offs = syn.batch_clouds(clouds)
+    gt = np.concatenate(boxes).astype(np.float32)
+    goffs = np.cumsum([0] + [len(b) for b in boxes]).astype(np.int32)
+    pts, offs, gt, goffs = (torch.from_numpy(a).to(device) for a in (pts, offs, gt, goffs))
+    torch.manual_seed(0)
+    det = SecondDetector(CAR_FHD).to(device)
+    amp = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": None}[args.dtype]
+    tr = DeviceTrainer(det, amp_dtype=amp)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        tr.step(pts, offs, gt, goffs)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out6 = tr.step(pts, offs, gt, goffs)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    # the gradient all-reduce alone (the only collective of the step): 20 back-to-back reductions of the live bucket
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        tr.bucket.allreduce(average=True)
+    e1.record()
+    torch.cuda.synchronize()
+    ar_us = e0.elapsed_time(e1) * 1e3 / 20
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        losses = tr.loss_dict()
+        res = {"metric": WL["metric"], "value": round(bs * args.steps * world / elapsed, 2), "unit": "samples/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "fp32" if amp is None else f"fp32 sparse stack + {args.dtype} autocast RPN", "data": "synthetic",
+               "config": {"workload": WL["desc"], "samples_per_step_per_gpu": bs, "parallelism": f"ddp{world}",
+                          "gradient_bucket_bytes": tr.bucket.numel * 4, "allreduce_us": round(ar_us, 1),
+                          "optimizer": "AdamW (adam + fixed weight decay 0.01, car.fhd.config:180-188)"},
+               "roofline": None, "cpu_baseline": None, "loss_last_step": {k: round(v, 5) for k, v in losses.items()}}
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
 
 
 def build_inputs(rank, device, order="shuffle"):
@@ -345,6 +410,10 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.dtype]
 
+    if args.workload == "car.fhd.train":
+        if args.dtype == "bf16" and "--dtype" not in " ".join(sys.argv):
+            args.dtype = "fp32"                     # training default: the reference's precision
+        return train_bench(args, rank, local_rank, world, device)
     from second_amd import ops
     clouds, points, offsets = build_inputs(rank, device, args.point_order)
     det, cpu_state = build_detector(device, dtype)

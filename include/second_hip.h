@@ -278,6 +278,35 @@ int sec_predict_finalize(const float *decoded, const float *top_score, const int
                          int num_dir_bins, const float *range6, float *boxes, float *scores, int *labels,
                          unsigned char *valid, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Training side: what the reference computes in DataLoader workers (numpy) and in ~40 torch kernels.
+ *
+ * sec_assign_targets_f32 -- replaces TargetAssigner.assign / assign_per_class -> create_target_np
+ *   (second/core/target_assigner.py:51-88, second/core/target_ops.py:29-229) for the configuration every shipped config
+ *   uses: NearestIouSimilarity (second/core/region_similarity.py:73-93), GroundBox3dCoder.encode
+ *   (second/core/box_np_ops.py:36-81), sample_positive_fraction = -1 (no sub-sampling), no anchor pruning.
+ *   anchors [n_anchor,7]; the ground truth of frame b is gt_boxes[gt_offsets[b] .. gt_offsets[b+1]) (x,y,z,w,l,h,r),
+ *   gt_classes (1-based, NULL = all 1), gt_importance (NULL = all 1).  Outputs per (frame, anchor): labels
+ *   (class / 0 background / -1 don't care), bbox_targets [.,7] (zeros for non-positives), importance.
+ * sec_second_loss_f32 -- replaces VoxelNet.loss (second/pytorch/models/voxelnet.py:239-312): SigmoidFocalClassificationLoss
+ *   + WeightedSmoothL1LocalizationLoss on the sin-difference encoding + direction WeightedSoftmaxClassificationLoss
+ *   (second/pytorch/core/losses.py:135-296,358-392), NormByNumPositives weighting (voxelnet.py:756-797).  One pass returns the
+ *   six scalars out6 = (loss, cls_loss_reduced, loc_loss_reduced, dir_loss_reduced, cls_pos_loss, cls_neg_loss) AND the
+ *   gradients of `loss` w.r.t. the head outputs (d_cls [B,N,num_class], d_box [B,N,7], d_dir [B,N,bins]).
+ *   h_params17 (host): alpha, gamma, sigma, pos_cls_weight, neg_cls_weight, classification_weight, localization_weight,
+ *   direction_loss_weight, direction_offset, sin_error_factor, code_weight[7].  Head tensors contiguous fp32.
+ * --------------------------------------------------------------------------------------------- */
+size_t sec_assign_targets_workspace_bytes(int batch, int n_anchor, int n_gt);
+int sec_assign_targets_f32(const float *anchors, int n_anchor, const float *gt_boxes, const int *gt_classes,
+                           const float *gt_importance, const int *gt_offsets, int n_gt, int batch,
+                           float matched_threshold, float unmatched_threshold, int *labels, float *bbox_targets,
+                           float *importance, void *workspace, size_t workspace_bytes, void *stream);
+size_t sec_second_loss_workspace_bytes(int batch, int n_anchor);
+int sec_second_loss_f32(const float *cls_preds, const float *box_preds, const float *dir_preds, const int *labels,
+                        const float *reg_targets, const float *anchors, const float *importance, int batch,
+                        int n_anchor, int num_class, int num_dir_bins, const float *h_params17, float *d_cls, float *d_box,
+                        float *d_dir, float *out6, void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

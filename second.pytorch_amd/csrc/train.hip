@@ -1,0 +1,361 @@
+// Training-side kernels of the SECOND path on gfx950:
+//
+//   sec_assign_targets_f32  -- anchor <-> ground-truth matching + box encoding.  Replaces the worker-side numpy of
+//                              second/core/target_ops.py:29-229 (create_target_np) with NearestIouSimilarity
+//                              (second/core/region_similarity.py:73-93 -> box_np_ops.rbbox2d_to_near_bbox :286-298 +
+//                              iou_jit(eps=0) :697-725) and GroundBox3dCoder.encode (box_np_ops.second_box_encode :36-81).
+//   sec_second_loss_f32     -- VoxelNet.loss (second/pytorch/models/voxelnet.py:239-312): sigmoid focal classification loss
+//                              (core/losses.py:236-296), smooth-L1 localisation loss on the sin-difference encoding
+//                              (losses.py:135-185, voxelnet.py:704-754), direction softmax cross-entropy (:814-829,
+//                              losses.py:358-392), NormByNumPositives weights (voxelnet.py:756-797) -- values AND the
+//                              gradients w.r.t. the three head outputs in one pass; deterministic two-stage reduction.
+//
+// Both are HBM-bound elementwise / small-reduction work: one thread per (frame, anchor), the frame's ground-truth boxes
+// staged in LDS.  fp32 throughout, operation order as in the numpy / torch originals (-ffp-contract=off).
+#include "common.hpp"
+
+namespace sec {
+
+constexpr int kMaxGtLds = 256;          // ground-truth boxes of one frame processed per LDS chunk
+
+__device__ __forceinline__ float limit_period_f(float v, float offset, float period) {
+    return __fsub_rn(v, __fmul_rn(floorf(__fadd_rn(__fdiv_rn(v, period), offset)), period));
+}
+
+// rbbox2d_to_near_bbox of (x, y, w, l, r): the axis-aligned box of the nearer of the "standing" / "lying" orientation
+__device__ __forceinline__ float4 near_bbox(float x, float y, float w, float l, float r) {
+    const float kPi = 3.14159274101257324f;
+    const float a = fabsf(limit_period_f(r, 0.5f, kPi));
+    const bool swap = a > 0.785398185253143311f;      // np.pi / 4 in fp32
+    const float dx = swap ? l : w, dy = swap ? w : l;
+    return make_float4(__fsub_rn(x, __fdiv_rn(dx, 2.0f)), __fsub_rn(y, __fdiv_rn(dy, 2.0f)), __fadd_rn(x, __fdiv_rn(dx, 2.0f)),
+                       __fadd_rn(y, __fdiv_rn(dy, 2.0f)));
+}
+
+// iou_jit(boxes = anchor, query = gt, eps = 0)
+__device__ __forceinline__ float iou_eps0(const float4 a, const float4 q) {
+    const float box_area = __fmul_rn(__fsub_rn(q.z, q.x), __fsub_rn(q.w, q.y));
+    const float iw = __fsub_rn(fminf(a.z, q.z), fmaxf(a.x, q.x));
+    if (!(iw > 0.0f)) return 0.0f;
+    const float ih = __fsub_rn(fminf(a.w, q.w), fmaxf(a.y, q.y));
+    if (!(ih > 0.0f)) return 0.0f;
+    const float ua = __fsub_rn(__fadd_rn(__fmul_rn(__fsub_rn(a.z, a.x), __fsub_rn(a.w, a.y)), box_area), __fmul_rn(iw, ih));
+    return __fdiv_rn(__fmul_rn(iw, ih), ua);
+}
+
+// pass 1: per (frame, anchor) best ground truth (first index on ties, like np.argmax) and, per ground truth, the best overlap
+// over all anchors (atomicMax on the float bits: overlaps are >= 0, so integer order == float order)
+__global__ __launch_bounds__(kBlock) void k_assign_max(const float *__restrict__ anchors, int n_anchor,
+                                                      const float *__restrict__ gt, const int *__restrict__ gt_offsets,
+                                                      float *__restrict__ a_max, int *__restrict__ a_arg,
+                                                      int *__restrict__ gt_max_bits) {
+    __shared__ float4 s_gt[kMaxGtLds];
+    const int b = blockIdx.y, a = blockIdx.x * kBlock + threadIdx.x;
+    const int g0 = gt_offsets[b], g1 = gt_offsets[b + 1];
+    float4 abv = make_float4(0, 0, 0, 0);
+    if (a < n_anchor) {
+        const float *p = anchors + (size_t)a * 7;
+        abv = near_bbox(p[0], p[1], p[3], p[4], p[6]);
+    }
+    float best = -1.0f;
+    int arg = -1;
+    for (int c0 = g0; c0 < g1; c0 += kMaxGtLds) {
+        const int cn = min(kMaxGtLds, g1 - c0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < cn; i += kBlock) {
+            const float *q = gt + (size_t)(c0 + i) * 7;
+            s_gt[i] = near_bbox(q[0], q[1], q[3], q[4], q[6]);
+        }
+        __syncthreads();
+        if (a < n_anchor) {
+            for (int i = 0; i < cn; ++i) {
+                const float v = iou_eps0(abv, s_gt[i]);
+                if (v > best) { best = v; arg = c0 + i - g0; }
+                if (v > 0.0f) atomicMax(&gt_max_bits[c0 + i], __float_as_int(v));
+            }
+        }
+    }
+    if (a < n_anchor) {
+        a_max[(size_t)b * n_anchor + a] = best;
+        a_arg[(size_t)b * n_anchor + a] = arg;
+    }
+}
+
+// pass 2: labels / box targets / importance of create_target_np (positive_fraction = None, no anchor pruning)
+__global__ __launch_bounds__(kBlock) void k_assign_write(const float *__restrict__ anchors, int n_anchor,
+                                                        const float *__restrict__ gt, const int *__restrict__ gt_classes,
+                                                        const float *__restrict__ gt_importance,
+                                                        const int *__restrict__ gt_offsets, const float *__restrict__ a_max,
+                                                        const int *__restrict__ a_arg, const int *__restrict__ gt_max_bits,
+                                                        float matched, float unmatched, int *__restrict__ labels,
+                                                        float *__restrict__ targets, float *__restrict__ importance) {
+    __shared__ float4 s_gt[kMaxGtLds];
+    __shared__ float s_gmax[kMaxGtLds];
+    const int b = blockIdx.y, a = blockIdx.x * kBlock + threadIdx.x;
+    const int g0 = gt_offsets[b], g1 = gt_offsets[b + 1];
+    const size_t o = (size_t)b * n_anchor + a;
+    float4 abv = make_float4(0, 0, 0, 0);
+    const float *p = anchors + (size_t)(a < n_anchor ? a : 0) * 7;
+    if (a < n_anchor) abv = near_bbox(p[0], p[1], p[3], p[4], p[6]);
+    bool force = false;                       // "anchors_with_max_overlap": ties with some ground truth's best overlap
+    for (int c0 = g0; c0 < g1; c0 += kMaxGtLds) {
+        const int cn = min(kMaxGtLds, g1 - c0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < cn; i += kBlock) {
+            const float *q = gt + (size_t)(c0 + i) * 7;
+            s_gt[i] = near_bbox(q[0], q[1], q[3], q[4], q[6]);
+            const float m = __int_as_float(gt_max_bits[c0 + i]);
+            s_gmax[i] = m == 0.0f ? -1.0f : m;       // a ground truth no anchor overlaps matches nothing
+        }
+        __syncthreads();
+        if (a < n_anchor)
+            for (int i = 0; i < cn; ++i) force |= iou_eps0(abv, s_gt[i]) == s_gmax[i];
+    }
+    if (a >= n_anchor) return;
+    int label = -1;
+    float imp = 1.0f;
+    float t[7] = {0, 0, 0, 0, 0, 0, 0};
+    if (g1 > g0) {
+        const float best = a_max[o];
+        const int arg = a_arg[o];
+        const bool pos = best >= matched;
+        if (best < unmatched) label = 0;
+        if (force || pos) label = gt_classes ? gt_classes[g0 + arg] : 1;
+        if (pos && gt_importance) imp = gt_importance[g0 + arg];
+        if (label > 0) {   // second_box_encode(gt[arg], anchor)
+            const float *q = gt + (size_t)(g0 + arg) * 7;
+            const float diag = sqrtf(__fadd_rn(__fmul_rn(p[4], p[4]), __fmul_rn(p[3], p[3])));
+            t[0] = __fdiv_rn(__fsub_rn(q[0], p[0]), diag);
+            t[1] = __fdiv_rn(__fsub_rn(q[1], p[1]), diag);
+            t[2] = __fdiv_rn(__fsub_rn(q[2], p[2]), p[5]);
+            t[3] = logf(__fdiv_rn(q[3], p[3]));
+            t[4] = logf(__fdiv_rn(q[4], p[4]));
+            t[5] = logf(__fdiv_rn(q[5], p[5]));
+            t[6] = __fsub_rn(q[6], p[6]);
+        }
+    } else {
+        label = 0;
+    }
+    labels[o] = label;
+    importance[o] = imp;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) targets[o * 7 + j] = t[j];
+}
+
+// ------------------------------------------------------------------------------------------------ loss
+struct LossParams {
+    int batch, n_anchor, num_class, num_bins;
+    float alpha, gamma, sigma, pos_w, neg_w, cls_w, loc_w, dir_w, dir_offset, sin_factor;
+    float code_w[7];
+};
+
+__global__ __launch_bounds__(kBlock) void k_loss_count(const int *__restrict__ labels, int n_anchor, float *__restrict__ cnt,
+                                                      const float *__restrict__ importance) {
+    // per frame: number of positives (weight normaliser) and sum of positive importance (direction weights)
+    __shared__ float s[2][kBlock / 64];
+    const int b = blockIdx.x;
+    float np_ = 0.0f, wi = 0.0f;
+    for (int a = threadIdx.x; a < n_anchor; a += kBlock) {
+        const bool pos = labels[(size_t)b * n_anchor + a] > 0;
+        np_ += pos ? 1.0f : 0.0f;
+        wi += pos ? importance[(size_t)b * n_anchor + a] : 0.0f;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { np_ += __shfl_xor(np_, d, 64); wi += __shfl_xor(wi, d, 64); }
+    if ((threadIdx.x & 63) == 0) { s[0][threadIdx.x >> 6] = np_; s[1][threadIdx.x >> 6] = wi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a0 = 0, a1 = 0;
+        for (int i = 0; i < kBlock / 64; ++i) { a0 += s[0][i]; a1 += s[1][i]; }
+        cnt[2 * b] = fmaxf(a0, 1.0f);
+        cnt[2 * b + 1] = fmaxf(a1, 1.0f);
+    }
+}
+
+// per (frame, anchor): the three loss terms and their gradients; per-block partial sums [nblocks][6] =
+// (cls, loc, dir, cls_pos, cls_neg, -).  cls_preds [B, N, num_class] etc. contiguous; gradients of the TOTAL loss
+// loc_w * loc / B + cls_w * cls / B + dir_w * dir / B.
+__global__ __launch_bounds__(kBlock) void k_loss_main(const float *__restrict__ cls, const float *__restrict__ box,
+                                                     const float *__restrict__ dirp, const int *__restrict__ labels,
+                                                     const float *__restrict__ reg, const float *__restrict__ anchors,
+                                                     const float *__restrict__ importance, const float *__restrict__ cnt,
+                                                     LossParams P, float *__restrict__ d_cls, float *__restrict__ d_box,
+                                                     float *__restrict__ d_dir, float *__restrict__ partial) {
+    const int b = blockIdx.y, a = blockIdx.x * kBlock + threadIdx.x;
+    float s_cls = 0, s_loc = 0, s_dir = 0, s_pos = 0, s_neg = 0;
+    if (a < P.n_anchor) {
+        const size_t o = (size_t)b * P.n_anchor + a;
+        const int label = labels[o];
+        const float imp = importance[o];
+        const float inv_b = 1.0f / (float)P.batch;
+        const float norm = cnt[2 * b];
+        const bool pos = label > 0, neg = label == 0;
+        // ---- classification (focal, background encoded as zeros): target one-hot over classes 1..num_class
+        const float wcls = ((neg ? P.neg_w : 0.0f) + (pos ? P.pos_w : 0.0f)) / norm * imp;
+        for (int c = 0; c < P.num_class; ++c) {
+            const float x = cls[o * P.num_class + c];
+            const float t = (label == c + 1) ? 1.0f : 0.0f;
+            const float ce = fmaxf(x, 0.0f) - x * t + log1pf(expf(-fabsf(x)));
+            const float p = 1.0f / (1.0f + expf(-x));
+            const float pt = t * p + (1.0f - t) * (1.0f - p);
+            const float om = 1.0f - pt;
+            const float mod = P.gamma == 2.0f ? om * om : (P.gamma == 0.0f ? 1.0f : powf(om, P.gamma));
+            const float at = t * P.alpha + (1.0f - t) * (1.0f - P.alpha);
+            const float l = mod * at * ce * wcls;
+            s_cls += l;
+            if (P.num_class == 1) { s_pos += pos ? l : 0.0f; s_neg += neg ? l : 0.0f; }
+            // d/dx: at * w * [ dmod/dx * ce + mod * (p - t) ],  dmod/dx = -gamma * om^(gamma-1) * dpt/dx,  dpt/dx = (2t-1) p (1-p)
+            const float dpt = (2.0f * t - 1.0f) * p * (1.0f - p);
+            const float dmod = P.gamma == 2.0f ? -2.0f * om * dpt : (P.gamma == 0.0f ? 0.0f : -P.gamma * powf(om, P.gamma - 1.0f) * dpt);
+            d_cls[o * P.num_class + c] = at * wcls * (dmod * ce + mod * (p - t)) * P.cls_w * inv_b;
+        }
+        // ---- localisation (smooth L1 on the sin-difference encoding), positives only
+        const float wreg = (pos ? 1.0f : 0.0f) / norm * imp;
+        const float s2 = P.sigma * P.sigma;
+        const float pr = box[o * 7 + 6] * P.sin_factor, tr = reg[o * 7 + 6] * P.sin_factor;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            float pv = box[o * 7 + j], tv = reg[o * 7 + j], dscale = 1.0f;
+            if (j == 6) {
+                pv = sinf(pr) * cosf(tr);
+                tv = cosf(pr) * sinf(tr);
+                dscale = (cosf(pr) * cosf(tr) + sinf(pr) * sinf(tr)) * P.sin_factor;     // both encodings depend on the prediction
+            }
+            const float diff = P.code_w[j] * (pv - tv);
+            const float ad = fabsf(diff);
+            const bool small = ad <= 1.0f / s2;
+            const float l = small ? 0.5f * (ad * P.sigma) * (ad * P.sigma) : ad - 0.5f / s2;
+            s_loc += l * wreg;
+            const float dl = small ? s2 * diff : (diff > 0.0f ? 1.0f : (diff < 0.0f ? -1.0f : 0.0f));
+            d_box[o * 7 + j] = dl * P.code_w[j] * dscale * wreg * P.loc_w * inv_b;
+        }
+        // ---- direction classifier (softmax cross-entropy on the heading bin of the ground truth)
+        if (P.num_bins > 0) {
+            const float kTwoPi = 6.28318548202514648f;
+            const float rot_gt = reg[o * 7 + 6] + anchors[(size_t)a * 7 + 6];
+            const float off = limit_period_f(rot_gt - P.dir_offset, 0.0f, kTwoPi);
+            int bin = (int)floorf(off / (kTwoPi / (float)P.num_bins));
+            bin = bin < 0 ? 0 : (bin > P.num_bins - 1 ? P.num_bins - 1 : bin);
+            const float wdir = (pos ? imp : 0.0f) / cnt[2 * b + 1];
+            float mx = -3.0e38f;
+            for (int c = 0; c < P.num_bins; ++c) mx = fmaxf(mx, dirp[o * P.num_bins + c]);
+            float se = 0.0f;
+            for (int c = 0; c < P.num_bins; ++c) se += expf(dirp[o * P.num_bins + c] - mx);
+            const float lse = mx + logf(se);
+            s_dir += (lse - dirp[o * P.num_bins + bin]) * wdir;
+            for (int c = 0; c < P.num_bins; ++c) {
+                const float sm = expf(dirp[o * P.num_bins + c] - lse);
+                d_dir[o * P.num_bins + c] = (sm - (c == bin ? 1.0f : 0.0f)) * wdir * P.dir_w * inv_b;
+            }
+        }
+    }
+    // block reduction -> partial[(b * gridDim.x + blockIdx.x)][6]
+    __shared__ float red[5][kBlock / 64];
+    float v[5] = {s_cls, s_loc, s_dir, s_pos, s_neg};
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) v[i] += __shfl_xor(v[i], d, 64);
+        if ((threadIdx.x & 63) == 0) red[i][threadIdx.x >> 6] = v[i];
+    }
+    __syncthreads();
+    if (threadIdx.x < 5) {
+        float acc = 0.0f;
+        for (int w = 0; w < kBlock / 64; ++w) acc += red[threadIdx.x][w];
+        partial[((size_t)b * gridDim.x + blockIdx.x) * 6 + threadIdx.x] = acc;
+    }
+}
+
+// out[0..5] = loss, cls_loss_reduced, loc_loss_reduced, dir_loss_reduced, cls_pos_loss, cls_neg_loss (fixed summation order)
+__global__ __launch_bounds__(kBlock) void k_loss_final(const float *__restrict__ partial, int nparts, LossParams P,
+                                                      float *__restrict__ out) {
+    __shared__ float red[5][kBlock];
+    float v[5] = {0, 0, 0, 0, 0};
+    for (int i = threadIdx.x; i < nparts; i += kBlock)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) v[j] += partial[(size_t)i * 6 + j];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) red[j][threadIdx.x] = v[j];
+    __syncthreads();
+    for (int s = kBlock / 2; s > 0; s >>= 1) {
+        if (threadIdx.x < s)
+#pragma unroll
+            for (int j = 0; j < 5; ++j) red[j][threadIdx.x] += red[j][threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float inv_b = 1.0f / (float)P.batch;
+        const float cls = red[0][0] * inv_b * P.cls_w, loc = red[1][0] * inv_b * P.loc_w, dir = red[2][0] * inv_b;
+        out[0] = loc + cls + dir * P.dir_w;
+        out[1] = cls;
+        out[2] = loc;
+        out[3] = dir;
+        out[4] = red[3][0] * inv_b / P.pos_w;
+        out[5] = red[4][0] * inv_b / P.neg_w;
+    }
+}
+
+}  // namespace sec
+
+using namespace sec;
+
+SEC_API size_t sec_assign_targets_workspace_bytes(int batch, int n_anchor, int n_gt) {
+    if (batch < 0 || n_anchor < 0 || n_gt < 0) return 0;
+    return align_up((size_t)batch * n_anchor * sizeof(float)) + align_up((size_t)batch * n_anchor * sizeof(int)) +
+           align_up((size_t)(n_gt > 0 ? n_gt : 1) * sizeof(int)) + 256;
+}
+
+SEC_API int sec_assign_targets_f32(const float *anchors, int n_anchor, const float *gt_boxes, const int *gt_classes,
+                                   const float *gt_importance, const int *gt_offsets, int n_gt, int batch,
+                                   float matched_threshold, float unmatched_threshold, int *labels, float *bbox_targets,
+                                   float *importance, void *workspace, size_t workspace_bytes, void *stream) {
+    if (n_anchor <= 0 || batch <= 0 || n_gt < 0 || !anchors || !gt_offsets || !labels || !bbox_targets || !importance ||
+        (n_gt > 0 && !gt_boxes))
+        return SEC_E_INVALID;
+    if (!workspace || workspace_bytes < sec_assign_targets_workspace_bytes(batch, n_anchor, n_gt)) return SEC_E_WORKSPACE;
+    Arena ar(workspace, workspace_bytes);
+    float *a_max = ar.take<float>((size_t)batch * n_anchor);
+    int *a_arg = ar.take<int>((size_t)batch * n_anchor);
+    int *gt_max = ar.take<int>(n_gt > 0 ? n_gt : 1);
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if ((rc = hip_ok(hipMemsetAsync(gt_max, 0, (size_t)(n_gt > 0 ? n_gt : 1) * sizeof(int), st)))) return rc;
+    dim3 grid(div_up(n_anchor, kBlock), batch);
+    hipLaunchKernelGGL(k_assign_max, grid, dim3(kBlock), 0, st, anchors, n_anchor, gt_boxes, gt_offsets, a_max, a_arg, gt_max);
+    hipLaunchKernelGGL(k_assign_write, grid, dim3(kBlock), 0, st, anchors, n_anchor, gt_boxes, gt_classes, gt_importance,
+                       gt_offsets, a_max, a_arg, gt_max, matched_threshold, unmatched_threshold, labels, bbox_targets, importance);
+    return check_launch();
+}
+
+SEC_API size_t sec_second_loss_workspace_bytes(int batch, int n_anchor) {
+    if (batch <= 0 || n_anchor <= 0) return 0;
+    return align_up((size_t)2 * batch * sizeof(float)) + align_up((size_t)batch * div_up(n_anchor, kBlock) * 6 * sizeof(float)) + 256;
+}
+
+SEC_API int sec_second_loss_f32(const float *cls_preds, const float *box_preds, const float *dir_preds, const int *labels,
+                                const float *reg_targets, const float *anchors, const float *importance, int batch,
+                                int n_anchor, int num_class, int num_dir_bins, const float *h_params17, float *d_cls, float *d_box,
+                                float *d_dir, float *out6, void *workspace, size_t workspace_bytes, void *stream) {
+    if (batch <= 0 || n_anchor <= 0 || num_class <= 0 || num_dir_bins < 0 || !cls_preds || !box_preds || !labels || !reg_targets ||
+        !anchors || !importance || !h_params17 || !d_cls || !d_box || !out6 || (num_dir_bins > 0 && (!dir_preds || !d_dir)))
+        return SEC_E_INVALID;
+    if (!workspace || workspace_bytes < sec_second_loss_workspace_bytes(batch, n_anchor)) return SEC_E_WORKSPACE;
+    LossParams P;
+    P.batch = batch; P.n_anchor = n_anchor; P.num_class = num_class; P.num_bins = num_dir_bins;
+    // h_params17: alpha, gamma, sigma, pos_cls_weight, neg_cls_weight, cls_loss_weight, loc_loss_weight, dir_loss_weight,
+    //             dir_offset, sin_error_factor, then (optional, else 1) nothing -- code weights follow in [10..16]
+    P.alpha = h_params17[0]; P.gamma = h_params17[1]; P.sigma = h_params17[2]; P.pos_w = h_params17[3]; P.neg_w = h_params17[4];
+    P.cls_w = h_params17[5]; P.loc_w = h_params17[6]; P.dir_w = h_params17[7]; P.dir_offset = h_params17[8];
+    P.sin_factor = h_params17[9];
+    for (int j = 0; j < 7; ++j) P.code_w[j] = h_params17[10 + j];
+    Arena ar(workspace, workspace_bytes);
+    float *cnt = ar.take<float>((size_t)2 * batch);
+    const int nb = div_up(n_anchor, kBlock);
+    float *partial = ar.take<float>((size_t)batch * nb * 6);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_loss_count, dim3(batch), dim3(kBlock), 0, st, labels, n_anchor, cnt, importance);
+    hipLaunchKernelGGL(k_loss_main, dim3(nb, batch), dim3(kBlock), 0, st, cls_preds, box_preds, dir_preds, labels, reg_targets,
+                       anchors, importance, cnt, P, d_cls, d_box, d_dir, partial);
+    hipLaunchKernelGGL(k_loss_final, dim3(1), dim3(kBlock), 0, st, partial, batch * nb, P, out6);
+    return check_launch();
+}

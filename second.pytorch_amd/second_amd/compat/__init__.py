@@ -155,8 +155,33 @@ def load_protos(reference_root):
     return sorted(m for _, m in files.values())
 
 
-def install(reference_root=None, spconv_path=None):
-    """Make ``import second...`` / ``import torchplus`` work.  Idempotent."""
+def spawn_dataloader_workers():
+    """``torch.utils.data.DataLoader(num_workers > 0)`` defaults to the ``spawn`` start method.
+
+    The reference forks its loader workers (second/pytorch/train.py:262-277, ``num_workers = 3``) and the workers call
+    ``spconv.utils.VoxelGeneratorV2.generate`` (second/data/preprocess.py:301-316).  Upstream that is a CPU loop; here it
+    runs on the MI355X, and a HIP context does not survive ``fork()`` ("Cannot re-initialize CUDA in forked subprocess").
+    Spawned workers import this package afresh and create their own context.  An explicit ``multiprocessing_context``
+    argument is left alone.  Idempotent."""
+    import torch.utils.data as tud
+    if getattr(tud.DataLoader, "_second_amd_spawn", False):
+        return
+    base = tud.DataLoader
+
+    class DataLoader(base):
+        _second_amd_spawn = True
+
+        def __init__(self, *a, **k):
+            if k.get("num_workers", 0) > 0 and k.get("multiprocessing_context") is None:
+                k["multiprocessing_context"] = "spawn"
+            super().__init__(*a, **k)
+    DataLoader.__name__, DataLoader.__qualname__ = base.__name__, base.__qualname__
+    tud.DataLoader = DataLoader
+
+
+def install(reference_root=None, spconv_path=None, spawn_workers=True):
+    """Make ``import second...`` / ``import torchplus`` work.  Idempotent.  ``spawn_workers``: see
+    :func:`spawn_dataloader_workers` (needed whenever the reference's DataLoader has worker processes)."""
     collections.Iterable = collections.abc.Iterable      # torchplus/train/optim.py:1, fastai_optim.py:1
     import torch  # noqa: F401  (before any stand-in module exists: torch introspects sys.modules at import)
     import numpy as np
@@ -185,6 +210,8 @@ def install(reference_root=None, spconv_path=None):
     for name in ("cv2", "skimage", "skimage.io", "seaborn", "shapely", "shapely.geometry", "pyquaternion"):
         if _missing(name):
             _stub(name)
+    if spawn_workers:
+        spawn_dataloader_workers()
     if reference_root:
         if reference_root not in sys.path:
             sys.path.append(reference_root)

@@ -58,24 +58,67 @@ def broadcast_parameters(module, src=0):
         off += n
 
 
+class GradBucket:
+    """ONE flat fp32 bucket holding the gradient of every trainable parameter, in parameter order, on every rank.
+
+    The bucket is laid out from ``requires_grad`` (identical on all ranks), never from which ``.grad`` happen to exist: a
+    parameter without a gradient on this rank this step (an empty shard, an unused head) contributes zeros, so the ranks
+    always reduce buffers of the same length and layout.  After :meth:`allreduce` every such parameter HAS a gradient (the
+    mean over ranks), and every ``p.grad`` is a view of the bucket -- later steps accumulate straight into it, so the
+    flatten / unflatten copies disappear."""
+
+    def __init__(self, module):
+        self.params = [p for p in module.parameters() if p.requires_grad]
+        self.numel = sum(p.numel() for p in self.params)
+        dev = self.params[0].device if self.params else torch.device("cpu")
+        self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        self.views = []
+        off = 0
+        for p in self.params:
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+
+    def pack(self):
+        for p, v in zip(self.params, self.views):
+            if p.grad is None:
+                v.zero_()
+            elif p.grad.data_ptr() != v.data_ptr():
+                v.copy_(p.grad)
+        return self.flat
+
+    def unpack(self):
+        for p, v in zip(self.params, self.views):
+            if p.dtype == torch.float32:
+                p.grad = v                    # a view of the bucket: the next backward accumulates into it in place
+            else:
+                if p.grad is None:
+                    p.grad = torch.empty_like(p)
+                p.grad.copy_(v)
+
+    def allreduce(self, average=True):
+        flat = self.pack()
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            if average:
+                flat /= dist.get_world_size()
+        self.unpack()
+        return self.numel * 4
+
+
 def allreduce_gradients(module, average=True):
-    """Average the gradients of all ranks with ONE all-reduce over a single flat bucket.
-    Call after backward(), before clip_grad_norm_/optimizer.step (cf. train.py:318-325)."""
+    """Average the gradients of all ranks with ONE all-reduce over a single flat bucket (see :class:`GradBucket` for the
+    layout rule).  Call after backward(), before clip_grad_norm_/optimizer.step (cf. train.py:318-325)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return 0
-    grads = [p.grad for p in module.parameters() if p.grad is not None]
-    if not grads:
+    bucket = getattr(module, "_sec_grad_bucket", None)
+    trainable = [p for p in module.parameters() if p.requires_grad]
+    if bucket is None or len(bucket.params) != len(trainable) or any(a is not b for a, b in zip(bucket.params, trainable)) or \
+            (trainable and bucket.flat.device != trainable[0].device):
+        bucket = GradBucket(module)
+        module._sec_grad_bucket = bucket
+    if bucket.numel == 0:
         return 0
-    flat = torch.cat([g.reshape(-1).float() for g in grads])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-    if average:
-        flat /= dist.get_world_size()
-    off = 0
-    for g in grads:
-        n = g.numel()
-        g.copy_(flat[off:off + n].view_as(g).to(g.dtype))
-        off += n
-    return flat.numel() * 4
+    return bucket.allreduce(average)
 
 
 def max_over_ranks(value, device=None):

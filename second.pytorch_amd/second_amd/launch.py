@@ -1,0 +1,197 @@
+"""One-process-per-GPU (DDP-style) launcher for the reference's UNMODIFIED training script.
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \\
+        -m second_amd.launch --reference-root /path/to/second.pytorch \\
+        train --config_path=second/configs/car.fhd.config --model_dir=/data/model
+
+The reference's only multi-GPU mechanism is single-process nn.DataParallel over padded batches
+(second/pytorch/train.py:203-206, second/data/preprocess.py:57-88).  ``train()`` offers no hook between
+``build_network`` and its loop and touches ``net.<attr>`` directly (train.py:178-186,285,297,326-329), so the model cannot be
+wrapped in DistributedDataParallel.  Instead every rank runs the reference's single-GPU path (``multi_gpu=False``) on its own
+GPU and this module patches five seams around it -- no file of the reference is edited:
+
+  1. device isolation   HIP_VISIBLE_DEVICES = LOCAL_RANK before torch touches the GPU: the reference hard-codes ``cuda:0``
+                        (train.py:29);
+  2. same start         ``torchplus.train.try_restore_latest_checkpoints`` is followed by a broadcast of rank 0's
+                        parameters and buffers (so a resumed run and a fresh one both start identical on all ranks);
+  3. gradient exchange  ``torch.nn.utils.clip_grad_norm_`` (train.py:323: the first thing after ``backward()``) first averages
+                        the gradients of all ranks with ONE RCCL all-reduce of a flat bucket (distributed.GradBucket);
+  4. data sharding      ``torch.utils.data.DataLoader`` with ``shuffle=True`` (the training loader, train.py:262-270) gets an
+                        epoch-advancing DistributedSampler; loaders with workers use the ``spawn`` start method, because the
+                        workers call ``spconv.utils.VoxelGeneratorV2.generate`` (second/data/preprocess.py:301-316), which
+                        runs on the GPU here, and a HIP context does not survive ``fork()``;
+  5. rank-0 side effects  checkpoints (``torchplus.train.save_models``), the model log (``SimpleModelLog``) and the periodic
+                        evaluation (``steps_per_eval``) happen on rank 0 only; the other ranks wait in the next all-reduce.
+
+BatchNorm statistics stay per rank, as in the reference (DataParallel replicas do not synchronise them either).
+"""
+import os
+import sys
+import time
+
+
+def _isolate_device():
+    """Must run before torch initialises the GPU runtime."""
+    lr = os.environ.get("LOCAL_RANK")
+    if lr is not None and os.environ.get("SEC_LAUNCH_NO_ISOLATION") != "1":
+        os.environ.setdefault("HIP_VISIBLE_DEVICES", lr)
+        os.environ.setdefault("CUDA_VISIBLE_DEVICES", lr)
+        os.environ["LOCAL_RANK_ORIGINAL"] = lr
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this driver
+
+
+class _NullLog:
+    """SimpleModelLog stand-in for ranks != 0 (second/utils/log_tool.py): same methods, no files."""
+
+    def __init__(self, *a, **k):
+        pass
+
+    def __getattr__(self, name):
+        return lambda *a, **k: None
+
+
+def patch_reference(train_module, rank, world, device=None, backend=None):
+    """Install seams 2-5 on an imported ``second.pytorch.train`` module.  Returns a dict of the originals (tests restore them)."""
+    import torch
+    import torch.distributed as dist
+    import torch.utils.data as tud
+    import torchplus.train as tpt
+    from . import distributed as D
+    T = train_module
+    saved = {"clip": torch.nn.utils.clip_grad_norm_, "DataLoader": tud.DataLoader, "restore": tpt.try_restore_latest_checkpoints,
+             "save_models": tpt.save_models, "SimpleModelLog": T.SimpleModelLog, "build_network": T.build_network,
+             "convert": T.example_convert_to_torch}
+    state = {"net": None, "allreduce_bytes": 0, "allreduce_calls": 0}
+
+    def build_network(*a, **k):
+        net = saved["build_network"](*a, **k)
+        state["net"] = net
+        return net
+
+    def restore(model_dir, objs, *a, **k):
+        r = saved["restore"](model_dir, objs, *a, **k)
+        for o in objs:                                   # the network (first call) -- optimizers restore from the same files
+            if isinstance(o, torch.nn.Module) and world > 1:
+                D.broadcast_parameters(o, 0)
+                for b in o.buffers():                    # global_step etc.
+                    if not b.is_floating_point():
+                        dist.broadcast(b.data, 0)
+        return r
+
+    def clip_grad_norm_(parameters, *a, **k):
+        net = state["net"]
+        if net is not None and world > 1:
+            state["allreduce_bytes"] = D.allreduce_gradients(net, average=True)
+            state["allreduce_calls"] += 1
+        return saved["clip"](parameters, *a, **k)
+
+    class EpochSampler(tud.distributed.DistributedSampler):
+        """the reference re-iterates the loader in a ``while True`` (train.py:291-293) without set_epoch: advance it here"""
+
+        def __iter__(self):
+            it = super().__iter__()
+            self.set_epoch(self.epoch + 1)
+            return it
+
+    def DataLoader(dataset, *a, **k):
+        if k.get("shuffle") and world > 1 and k.get("sampler") is None:
+            k["sampler"] = EpochSampler(dataset, num_replicas=world, rank=rank, shuffle=True)
+            k["shuffle"] = False
+        if k.get("num_workers", 0) > 0 and k.get("multiprocessing_context") is None:
+            k["multiprocessing_context"] = "spawn"       # the workers voxelise on the GPU: no fork after HIP initialisation
+        return saved["DataLoader"](dataset, *a, **k)
+
+    def save_models(*a, **k):
+        if rank == 0:
+            return saved["save_models"](*a, **k)
+
+    def convert(example, dtype=torch.float32, dev=None):
+        return saved["convert"](example, dtype, dev if dev is not None else device)
+
+    torch.nn.utils.clip_grad_norm_ = clip_grad_norm_
+    tud.DataLoader = DataLoader
+    tpt.try_restore_latest_checkpoints = restore
+    tpt.save_models = save_models
+    T.build_network = build_network
+    if device is not None:
+        T.example_convert_to_torch = convert
+    if rank != 0:
+        T.SimpleModelLog = _NullLog
+    saved["state"] = state
+    return saved
+
+
+def unpatch_reference(train_module, saved):
+    import torch
+    import torch.utils.data as tud
+    import torchplus.train as tpt
+    torch.nn.utils.clip_grad_norm_ = saved["clip"]
+    tud.DataLoader = saved["DataLoader"]
+    tpt.try_restore_latest_checkpoints = saved["restore"]
+    tpt.save_models = saved["save_models"]
+    train_module.SimpleModelLog = saved["SimpleModelLog"]
+    train_module.build_network = saved["build_network"]
+    train_module.example_convert_to_torch = saved["convert"]
+
+
+def load_config(train_module, config_path, rank):
+    """The pipeline config as an object (train() accepts one, train.py:150-158); ranks != 0 never reach the periodic
+    checkpoint + evaluation block (train.py:386-423)."""
+    from google.protobuf import text_format
+    from second.protos import pipeline_pb2
+    config = pipeline_pb2.TrainEvalPipelineConfig()
+    with open(config_path, "r") as f:
+        text_format.Merge(f.read(), config)
+    if rank != 0:
+        config.train_config.steps_per_eval = 2 ** 31 - 1
+    return config
+
+
+def run_train(reference_root, config_path, model_dir, backend=None, device=None, **train_kwargs):
+    """Everything ``main`` does after argument parsing; returns the patch state (all-reduce counters) for tests."""
+    from pathlib import Path
+    from . import compat, distributed as D
+    rank, local_rank, world = D.init_from_env(backend)
+    compat.install(reference_root)
+    import second.pytorch.train as T
+    saved = patch_reference(T, rank, world, device=device, backend=backend)
+    try:
+        config = load_config(T, config_path, rank)
+        if rank != 0:                                    # rank 0 creates (and checks) the model directory first
+            deadline = time.time() + 600
+            while not Path(model_dir).exists() and time.time() < deadline:
+                time.sleep(0.1)
+            train_kwargs["resume"] = True
+        T.train(config, model_dir, multi_gpu=False, **train_kwargs)
+    finally:
+        unpatch_reference(T, saved)
+    return saved["state"]
+
+
+def main(argv=None):
+    _isolate_device()
+    argv = list(sys.argv[1:] if argv is None else argv)
+    if len(argv) < 3 or argv[0] != "--reference-root" or argv[2] != "train":
+        print(__doc__)
+        raise SystemExit("usage: -m second_amd.launch --reference-root DIR train --config_path=... --model_dir=... [--key=value ...]")
+    reference_root = argv[1]
+    kwargs = {}
+    for tok in argv[3:]:
+        if not (tok.startswith("--") and "=" in tok):
+            raise SystemExit(f"expected --key=value, got {tok!r}")
+        key, val = tok[2:].split("=", 1)
+        try:
+            import ast
+            val = ast.literal_eval(val)
+        except (ValueError, SyntaxError):
+            pass
+        kwargs[key] = val
+    config_path, model_dir = kwargs.pop("config_path"), kwargs.pop("model_dir")
+    kwargs.pop("multi_gpu", None)
+    state = run_train(reference_root, config_path, model_dir, **kwargs)
+    if int(os.environ.get("RANK", 0)) == 0:
+        print(f"[second_amd.launch] {state['allreduce_calls']} gradient all-reduces of {state['allreduce_bytes']} bytes each")
+
+
+if __name__ == "__main__":
+    main()

@@ -537,3 +537,90 @@ def predict_finalize(dec, top_score, top_label, dir_label, keep, num_keep, post_
                                        rt.ptr(scores), rt.ptr(labels), rt.ptr(valid), rt.stream())
     rt.check(rc, "sec_predict_finalize")
     return {"boxes": boxes, "scores": scores, "labels": labels, "valid": valid.bool()}
+
+
+# ----------------------------------------------------------------------------- training: targets + loss
+@_traced("assign_targets")
+def assign_targets(anchors, gt_boxes, gt_offsets, matched_threshold, unmatched_threshold, gt_classes=None,
+                   gt_importance=None):
+    """TargetAssigner.assign -> create_target_np (second/core/target_ops.py:29-229) with NearestIouSimilarity and
+    GroundBox3dCoder.encode, for a whole batch on the device.  anchors [A,7] fp32; gt_boxes [G,7] fp32 (frames concatenated),
+    gt_offsets [B+1] int32.  -> labels [B,A] int32, bbox_targets [B,A,7] fp32, importance [B,A] fp32."""
+    rt.require_gpu(anchors, gt_boxes, gt_offsets)
+    assert anchors.dtype == torch.float32 and anchors.is_contiguous() and anchors.shape[1] == 7
+    assert gt_offsets.dtype == torch.int32
+    gt_boxes = gt_boxes.float().contiguous()
+    a, b, g = anchors.shape[0], gt_offsets.numel() - 1, gt_boxes.shape[0]
+    dev = anchors.device
+    labels = torch.empty((b, a), dtype=torch.int32, device=dev)
+    targets = torch.empty((b, a, 7), dtype=torch.float32, device=dev)
+    importance = torch.empty((b, a), dtype=torch.float32, device=dev)
+    l = rt.lib()
+    ws = rt.workspace(l.sec_assign_targets_workspace_bytes(b, a, g), dev)
+    rc = l.sec_assign_targets_f32(rt.ptr(anchors), a, rt.ptr(gt_boxes) if g else None, rt.ptr(gt_classes), rt.ptr(gt_importance),
+                                  rt.ptr(gt_offsets), g, b, float(matched_threshold), float(unmatched_threshold), rt.ptr(labels),
+                                  rt.ptr(targets), rt.ptr(importance), rt.ptr(ws), ws.numel(), rt.stream())
+    rt.check(rc, "sec_assign_targets_f32")
+    return labels, targets, importance
+
+
+LOSS_DEFAULTS = dict(alpha=0.25, gamma=2.0, sigma=3.0, pos_cls_weight=1.0, neg_cls_weight=1.0, classification_weight=1.0,
+                     localization_weight=2.0, direction_loss_weight=0.2, direction_offset=0.0, sin_error_factor=1.0,
+                     code_weights=(1.0,) * 7)   # second/configs/car.fhd.config:35-68
+
+
+@_traced("second_loss")
+def second_loss_raw(cls_preds, box_preds, dir_preds, labels, reg_targets, anchors, importance, **cfg):
+    """VoxelNet.loss (second/pytorch/models/voxelnet.py:239-312) values and head gradients in one fused pass.
+    cls_preds [B,N,C], box_preds [B,N,7], dir_preds [B,N,bins] or None: contiguous fp32.  -> (out6, d_cls, d_box, d_dir) with
+    out6 = (loss, cls_loss_reduced, loc_loss_reduced, dir_loss_reduced, cls_pos_loss, cls_neg_loss)."""
+    rt.require_gpu(cls_preds, box_preds, labels, reg_targets, anchors, importance)
+    p = dict(LOSS_DEFAULTS, **cfg)
+    for t in (cls_preds, box_preds, reg_targets, anchors, importance) + ((dir_preds,) if dir_preds is not None else ()):
+        assert t.dtype == torch.float32 and t.is_contiguous(), "second_loss takes contiguous fp32 tensors"
+    assert labels.dtype == torch.int32 and labels.is_contiguous()
+    b, n, nc = cls_preds.shape
+    bins = dir_preds.shape[-1] if dir_preds is not None else 0
+    dev = cls_preds.device
+    d_cls, d_box = torch.empty_like(cls_preds), torch.empty_like(box_preds)
+    d_dir = torch.empty_like(dir_preds) if dir_preds is not None else None
+    out6 = torch.empty((6,), dtype=torch.float32, device=dev)
+    params = rt.f_arr([p["alpha"], p["gamma"], p["sigma"], p["pos_cls_weight"], p["neg_cls_weight"], p["classification_weight"],
+                       p["localization_weight"], p["direction_loss_weight"], p["direction_offset"], p["sin_error_factor"],
+                       *p["code_weights"]])
+    l = rt.lib()
+    ws = rt.workspace(l.sec_second_loss_workspace_bytes(b, n), dev)
+    rc = l.sec_second_loss_f32(rt.ptr(cls_preds), rt.ptr(box_preds), rt.ptr(dir_preds), rt.ptr(labels), rt.ptr(reg_targets),
+                               rt.ptr(anchors), rt.ptr(importance), b, n, nc, bins, params, rt.ptr(d_cls), rt.ptr(d_box),
+                               rt.ptr(d_dir), rt.ptr(out6), rt.ptr(ws), ws.numel(), rt.stream())
+    rt.check(rc, "sec_second_loss_f32")
+    return out6, d_cls, d_box, d_dir
+
+
+class SecondLossFunction(torch.autograd.Function):
+    """loss = SecondLossFunction.apply(cls, box, dir, labels, reg_targets, anchors, importance, cfg_dict): the scalar training
+    loss of VoxelNet.loss; backward hands the gradients the forward pass already computed to autograd (scaled by grad_output)."""
+
+    @staticmethod
+    def forward(ctx, cls_preds, box_preds, dir_preds, labels, reg_targets, anchors, importance, cfg):
+        shapes = (cls_preds.shape, box_preds.shape, None if dir_preds is None else dir_preds.shape)
+        b = cls_preds.shape[0]
+        dts = (cls_preds.dtype, box_preds.dtype, None if dir_preds is None else dir_preds.dtype)
+        f = lambda t, k: t.reshape(b, -1, k).float().contiguous()
+        nc = cfg.get("num_class", 1)
+        out6, d_cls, d_box, d_dir = second_loss_raw(f(cls_preds, nc), f(box_preds, 7),
+                                                    None if dir_preds is None else f(dir_preds, cfg.get("num_direction_bins", 2)),
+                                                    labels, reg_targets, anchors, importance,
+                                                    **{k: v for k, v in cfg.items() if k in LOSS_DEFAULTS})
+        ctx.save_for_backward(d_cls, d_box, d_dir if d_dir is not None else d_cls.new_zeros(0))
+        ctx.meta = (shapes, dts)
+        ctx.mark_non_differentiable(out6)
+        return out6[0], out6
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_all):
+        d_cls, d_box, d_dir = ctx.saved_tensors
+        shapes, dts = ctx.meta
+        gd = None if shapes[2] is None else (d_dir * g_loss).reshape(shapes[2]).to(dts[2])
+        return ((d_cls * g_loss).reshape(shapes[0]).to(dts[0]), (d_box * g_loss).reshape(shapes[1]).to(dts[1]), gd,
+                None, None, None, None, None)

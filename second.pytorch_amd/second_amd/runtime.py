@@ -26,6 +26,7 @@ SYMBOLS = [
     "sec_voxel_block_filter_f32", "sec_bias_act_nhwc", "sec_conv2d_packed_weight_bytes",
     "sec_conv2d_pack_weight", "sec_conv2d_nhwc", "sec_conv1x1_chain_nhwc", "sec_rotate_iou_f32", "sec_nms_workspace_bytes", "sec_nms_sorted_f32",
     "sec_predict_select", "sec_predict_decode", "sec_predict_finalize",
+    "sec_assign_targets_workspace_bytes", "sec_assign_targets_f32", "sec_second_loss_workspace_bytes", "sec_second_loss_f32",
 ]
 
 _lib = None
@@ -46,7 +47,8 @@ def lib():
         l = ctypes.CDLL(LIB_PATH)
         for name in ("sec_voxelize_workspace_bytes", "sec_rulebook_workspace_bytes",
                      "sec_packed_weight_bytes", "sec_nms_workspace_bytes", "sec_block_filter_workspace_bytes",
-                     "sec_conv2d_packed_weight_bytes", "sec_indice_conv_bwd_workspace_bytes"):
+                     "sec_conv2d_packed_weight_bytes", "sec_indice_conv_bwd_workspace_bytes",
+                     "sec_assign_targets_workspace_bytes", "sec_second_loss_workspace_bytes"):
             getattr(l, name).restype = ctypes.c_size_t
         l.sec_last_error.restype = ctypes.c_char_p
         l.sec_conv_output_shape.restype = None
@@ -83,6 +85,10 @@ def lib():
         l.sec_predict_select.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, cf, vp, vp, vp, vp, vp, ci, vp]
         l.sec_predict_decode.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, ci, vp, vp, vp, ci, vp]
         l.sec_predict_finalize.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, cf, ci, vp, vp, vp, vp, vp, vp]
+        l.sec_assign_targets_workspace_bytes.argtypes = [ci, ci, ci]
+        l.sec_assign_targets_f32.argtypes = [vp, ci, vp, vp, vp, vp, ci, ci, cf, cf, vp, vp, vp, vp, sz, vp]
+        l.sec_second_loss_workspace_bytes.argtypes = [ci, ci]
+        l.sec_second_loss_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, sz, vp]
         _lib = l
     return _lib
 

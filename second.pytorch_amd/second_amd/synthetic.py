@@ -111,3 +111,15 @@ def syn_nusc_cloud(seed, num_points=300000, point_cloud_range=(-50, -50, -5, 50,
     if len(pts) > num_points:
         pts = pts[rng.choice(len(pts), num_points, replace=False)]
     return pts.astype(np.float32)
+
+
+def syn_kitti_boxes(seed, max_boxes=None):
+    """Ground truth of :func:`syn_kitti_cloud(seed)`: the boxes the ray caster placed, as SECOND lidar boxes
+    [n, 7] = (x, y, z_centre, w, l, h, r) with r = 0 (w along x, l along y: box_np_ops.rbbox2d_to_near_bbox convention)."""
+    rng = np.random.default_rng(seed)
+    n_box = 40
+    cx, cy = rng.uniform(5, 60, n_box), rng.uniform(-30, 30, n_box)
+    sx, sy, sz = rng.uniform(1.5, 4.5, n_box), rng.uniform(1.5, 4.5, n_box), rng.uniform(1.4, 3.0, n_box)
+    ground = -1.73
+    b = np.stack([cx, cy, ground + sz / 2, sx, sy, sz, np.zeros(n_box)], 1).astype(np.float32)
+    return b[:max_boxes] if max_boxes else b

@@ -1,0 +1,81 @@
+"""Device-resident training step of the SECOND path, one process per GPU (BASELINE configs 3 / 5).
+
+The reference trains through a worker-fed loop (second/pytorch/train.py:291-329): DataLoader workers voxelise and assign
+targets in numpy, ``example_convert_to_torch`` copies padded tensors to the device, ``VoxelNet.forward`` runs network +
+loss, then ``loss.backward()``, ``clip_grad_norm_(10)``, optimizer step; multi-GPU = single-process nn.DataParallel.
+
+Here the whole step stays on the GPU and every rank owns one GPU:
+
+    raw points + ground-truth boxes (HBM)
+      -> sec_voxelize_f32 (+ SimpleVoxel mean)                         [no worker-side numpy, no padded H2D copies]
+      -> SpMiddleFHD in train mode: rulebooks, sec_indice_conv_fwd, BatchNorm1d batch statistics, ReLU (autograd through
+         sec_indice_conv_bwd / sec_dense_to_sparse)
+      -> RPNV2 (torch convolutions, channels_last)                     [MIOpen backward; the hand-written conv is inference-only]
+      -> sec_assign_targets_f32 (anchor <-> ground truth, box encoding)
+      -> sec_second_loss_f32 (focal + smooth-L1 + direction loss, values and head gradients in one pass)
+      -> backward -> ONE all-reduce of the flat gradient bucket over RCCL/xGMI (distributed.GradBucket)
+      -> clip_grad_norm_(10) -> AdamW step.
+
+BatchNorm statistics stay per rank (the reference's DataParallel replicas never synchronise them either).
+"""
+import math
+
+import torch
+
+from . import distributed as D
+from . import ops
+
+
+class DeviceTrainer:
+    def __init__(self, det, lr=3e-3, weight_decay=0.01, max_grad_norm=10.0, matched_threshold=0.6, unmatched_threshold=0.45,
+                 loss_cfg=None, amp_dtype=None):
+        """det: SecondDetector on this rank's GPU (training mode is set here).  ``amp_dtype`` (torch.bfloat16 / float16):
+        autocast for the dense RPN convolutions; the sparse stack and the loss stay in the parameters' dtype."""
+        self.det = det.train()
+        self.cfg = det.cfg
+        self.max_grad_norm = float(max_grad_norm)
+        self.thresholds = (float(matched_threshold), float(unmatched_threshold))
+        self.loss_cfg = dict(ops.LOSS_DEFAULTS, direction_offset=self.cfg["direction_offset"], num_class=self.cfg["num_class"],
+                             num_direction_bins=self.cfg["num_direction_bins"], **(loss_cfg or {}))
+        self.amp_dtype = amp_dtype
+        D.broadcast_parameters(det, 0)
+        # the reference's adam_optimizer + fixed weight decay (car.fhd.config:180-188) -> AdamW
+        self.opt = torch.optim.AdamW([p for p in det.parameters() if p.requires_grad], lr=lr, weight_decay=weight_decay,
+                                     betas=(0.9, 0.99))
+        self.bucket = D.GradBucket(det)
+        self.steps = 0
+        self.last = {}
+
+    def forward_loss(self, points, point_offsets, gt_boxes, gt_offsets, gt_classes=None):
+        det, cfg = self.det, self.cfg
+        batch = point_offsets.numel() - 1
+        with torch.no_grad():
+            vox = det.voxel_generator.generate_device(points, point_offsets, mean_features=cfg["num_point_features"])
+            labels, reg_targets, importance = ops.assign_targets(det.anchors, gt_boxes, gt_offsets, *self.thresholds,
+                                                                 gt_classes=gt_classes)
+        if self.amp_dtype is not None:
+            spatial = det.middle_feature_extractor(vox["mean"], vox["coordinates"], batch)
+            with torch.autocast("cuda", dtype=self.amp_dtype):
+                preds = det.rpn(spatial.contiguous(memory_format=torch.channels_last))
+        else:
+            preds = det.network_forward(vox["mean"], vox["coordinates"], batch)
+        loss, out6 = ops.SecondLossFunction.apply(preds["cls_preds"], preds["box_preds"], preds.get("dir_cls_preds"), labels,
+                                                  reg_targets, det.anchors, importance, self.loss_cfg)
+        return loss, out6, labels
+
+    def step(self, points, point_offsets, gt_boxes, gt_offsets, gt_classes=None):
+        """One optimisation step on this rank's shard; returns the device tensor of the six loss scalars (no host sync)."""
+        loss, out6, _ = self.forward_loss(points, point_offsets, gt_boxes, gt_offsets, gt_classes)
+        loss.backward()
+        self.bucket.allreduce(average=True)                       # one flat bucket, zeros for parameters without a gradient
+        torch.nn.utils.clip_grad_norm_(self.bucket.params, self.max_grad_norm)
+        self.opt.step()
+        self.bucket.flat.zero_()                                  # p.grad are views of the bucket: zero_grad in one launch
+        self.steps += 1
+        self.last = {"out6": out6}
+        return out6
+
+    def loss_dict(self):
+        names = ("loss", "cls_loss_reduced", "loc_loss_reduced", "dir_loss_reduced", "cls_pos_loss", "cls_neg_loss")
+        v = self.last["out6"].tolist()
+        return {k: (x if math.isfinite(x) else float("nan")) for k, x in zip(names, v)}

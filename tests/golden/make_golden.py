@@ -32,6 +32,8 @@ Outputs (all small .npz):
   voxel_coords.npz      simplevis._points_to_bevmap_reverse_kernel: per-point voxel ids
   torch_modules.npz     SimpleVoxel, second_box_decode, limit_period, PointPillarsScatter,
                         PillarFeatureNet, RPNV2 (small) forward on seeded inputs + weights
+  train_targets_losses.npz  create_target_np (nearest-IoU matching + box encoding) and VoxelNet.loss
+                        (focal / smooth-L1 with sin difference / direction CE) with autograd gradients
 """
 import collections
 import collections.abc
@@ -394,9 +396,97 @@ def gen_torch_modules():
     print("torch modules: rpn box_preds", out["rpn_box_preds"].shape)
 
 
+def gen_train_targets_losses():
+    """Training-side fixtures: the reference's own target assignment (second/core/target_ops.py:29 create_target_np with
+    NearestIouSimilarity, region_similarity.py:73-93, and GroundBox3dCoder.encode = box_np_ops.second_box_encode) and its own
+    loss (second/pytorch/models/voxelnet.py:239-312 VoxelNet.loss -> create_loss / prepare_loss_weights /
+    get_direction_target over losses.py:135-296), executed on seeded inputs; gradients by autograd."""
+    import torch
+    if not getattr(np.meshgrid, "_as_list", False):            # numpy >= 2 returns a tuple; box_np_ops.py:626-629 assigns into it
+        _mg = np.meshgrid
+        np.meshgrid = lambda *a, **k: list(_mg(*a, **k))
+        np.meshgrid._as_list = True
+    from second.core import box_np_ops, region_similarity, target_ops
+    from second.pytorch.core import losses
+    from second.pytorch.models import voxelnet as V
+    rng = np.random.default_rng(11)
+    fm = [1, 50, 44]
+    anchors = box_np_ops.create_anchors_3d_range(fm, [0, -40.0, -1.0, 70.4, 40.0, -1.0], sizes=[1.6, 3.9, 1.56],
+                                                 rotations=[0, 1.57], dtype=np.float32).reshape(-1, 7)
+    sim = region_similarity.NearestIouSimilarity()
+
+    def similarity_fn(a, g):
+        return sim.compare(a[:, [0, 1, 3, 4, 6]], g[:, [0, 1, 3, 4, 6]])
+
+    def encode(boxes, anc):
+        return box_np_ops.second_box_encode(boxes, anc)
+    frames = []
+    pick = rng.choice(len(anchors), 14, replace=False)
+    g0 = anchors[pick].copy()
+    g0[:, :2] += rng.normal(0, 0.2, (14, 2)).astype(np.float32)
+    g0[:, 2] += rng.normal(0, 0.1, 14).astype(np.float32)
+    g0[:, 3:6] *= rng.uniform(0.85, 1.2, (14, 3)).astype(np.float32)
+    g0[:7, 6] += rng.normal(0, 0.15, 7).astype(np.float32)     # half of them roughly aligned with their anchor ...
+    g0[7:, 6] = rng.uniform(-np.pi, np.pi, 7).astype(np.float32)   # ... the others at any heading
+    g0[0] = anchors[pick[0]]                                   # one ground truth sits exactly on an anchor (IoU 1)
+    frames.append(g0.astype(np.float32))
+    frames.append(np.zeros((0, 7), np.float32))                # a frame without ground truth
+    g2 = anchors[rng.choice(len(anchors), 5, replace=False)].copy()
+    g2[:, :2] += rng.normal(0, 0.6, (5, 2)).astype(np.float32)
+    g2[:, 6] = rng.uniform(-np.pi, np.pi, 5).astype(np.float32)
+    g2[4, :2] = [500.0, 500.0]                                 # a box no anchor overlaps (the empty_gt_mask path)
+    frames.append(g2.astype(np.float32))
+    out = {"anchors": anchors, "feature_map_size": np.array(fm), "matched_threshold": np.float32(0.6),
+           "unmatched_threshold": np.float32(0.45)}
+    labels, targets, importance = [], [], []
+    for f, g in enumerate(frames):
+        r = target_ops.create_target_np(anchors, g, similarity_fn, encode, matched_threshold=0.6, unmatched_threshold=0.45,
+                                        gt_classes=np.ones(len(g), np.int32), positive_fraction=None, rpn_batch_size=512,
+                                        norm_by_num_examples=False, box_code_size=7)
+        out[f"gt_{f}"] = g
+        labels.append(r["labels"]); targets.append(r["bbox_targets"]); importance.append(r["importance"])
+    out["labels"], out["bbox_targets"], out["importance"] = np.stack(labels), np.stack(targets).astype(np.float32), np.stack(importance)
+    print("targets: positives per frame", [(l > 0).sum() for l in labels], "negatives", [(l == 0).sum() for l in labels])
+    # ---- loss (car.fhd settings: focal gamma 2 alpha 0.25, smooth-L1 sigma 3, sin-difference, direction classifier)
+    b, n = len(frames), len(anchors)
+    tg = torch.Generator().manual_seed(5)
+    cls = (torch.randn(b, n, 1, generator=tg) * 2 - 2).requires_grad_()
+    box = (torch.randn(b, n, 7, generator=tg) * 0.3).requires_grad_()
+    dirp = torch.randn(b, n, 2, generator=tg).requires_grad_()
+    lab = torch.from_numpy(out["labels"]).int()
+    reg = torch.from_numpy(out["bbox_targets"])
+    imp = torch.from_numpy(out["importance"])
+    cls_w, reg_w, cared = V.prepare_loss_weights(lab, pos_cls_weight=1.0, neg_cls_weight=1.0,
+                                                 loss_norm_type=V.LossNormType.NormByNumPositives, dtype=torch.float32)
+    cls_t = (lab * cared.type_as(lab)).unsqueeze(-1)
+    loc_ftor = losses.WeightedSmoothL1LocalizationLoss(sigma=3.0, code_weights=[1.0] * 7, codewise=True)
+    cls_ftor = losses.SigmoidFocalClassificationLoss(gamma=2.0, alpha=0.25)
+    dir_ftor = losses.WeightedSoftmaxClassificationLoss()
+    loc_loss, cls_loss = V.create_loss(loc_ftor, cls_ftor, box_preds=box, cls_preds=cls, cls_targets=cls_t, cls_weights=cls_w * imp,
+                                       reg_targets=reg, reg_weights=reg_w * imp, num_class=1, encode_rad_error_by_sin=True,
+                                       encode_background_as_zeros=True, box_code_size=7, sin_error_factor=1.0, num_direction_bins=2)
+    loc_red = loc_loss.sum() / b * 2.0
+    cls_red = cls_loss.sum() / b * 1.0
+    pos_l, neg_l = V._get_pos_neg_loss(cls_loss, lab)
+    anc_t = torch.from_numpy(anchors).unsqueeze(0).repeat(b, 1, 1)
+    dir_t = V.get_direction_target(anc_t, reg, dir_offset=0.0, num_bins=2)
+    w = (lab > 0).type_as(dirp) * imp
+    w = w / torch.clamp(w.sum(-1, keepdim=True), min=1.0)
+    dir_loss = dir_ftor(dirp, dir_t, weights=w).sum() / b
+    loss = loc_red + cls_red + dir_loss * 0.2
+    loss.backward()
+    out.update(cls_preds=cls.detach().numpy(), box_preds=box.detach().numpy(), dir_preds=dirp.detach().numpy(),
+               loss=np.float32(loss.item()), loc_loss_reduced=np.float32(loc_red.item()), cls_loss_reduced=np.float32(cls_red.item()),
+               dir_loss_reduced=np.float32(dir_loss.item()), cls_pos_loss=np.float32(pos_l.item()), cls_neg_loss=np.float32(neg_l.item()),
+               d_cls=cls.grad.numpy(), d_box=box.grad.numpy(), d_dir=dirp.grad.numpy(), dir_targets=dir_t.argmax(-1).numpy().astype(np.int32),
+               cls_loss=cls_loss.detach().numpy(), loc_loss=loc_loss.detach().numpy())
+    np.savez_compressed(os.path.join(OUT, "train_targets_losses.npz"), **out)
+    print("loss", loss.item(), "loc", loc_red.item(), "cls", cls_red.item(), "dir", dir_loss.item())
+
+
 if __name__ == "__main__":
     install_shims()
     which = sys.argv[1:] or ["rotate_iou", "rotate_nms", "nms_axis_aligned", "standup", "voxel_coords",
-                             "torch_modules"]
+                             "torch_modules", "train_targets_losses"]
     for w in which:
         globals()["gen_" + w]()

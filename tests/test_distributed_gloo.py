@@ -45,7 +45,23 @@ def _worker(rank, world, port, q):
     ((net(x) - y) ** 2).sum().backward()
     g_full = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
     tmax = D.max_over_ranks(float(rank + 1))
-    q.put((rank, same_after_bcast, torch.allclose(g_dist, g_full, rtol=1e-5, atol=1e-6), nbytes, tmax, (lo, hi)))
+    # a parameter without a gradient on ONE rank (unused head / empty shard) must not change the bucket layout
+    two = torch.nn.ModuleDict({"trunk": torch.nn.Linear(4, 4), "head_a": torch.nn.Linear(4, 1), "head_b": torch.nn.Linear(4, 1)})
+    D.broadcast_parameters(two, 0)
+    two.zero_grad(set_to_none=True)
+    xin = torch.ones(3, 4)
+    head = two["head_a"] if rank == 0 else two["head_b"]          # each rank exercises a different head
+    head(two["trunk"](xin)).sum().backward()
+    assert (two["head_b"].weight.grad is None) == (rank == 0)
+    D.allreduce_gradients(two, average=True)
+    ok_missing = all(p.grad is not None for p in two.parameters())
+    flat = torch.cat([p.grad.reshape(-1) for p in two.parameters()])
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    ok_missing = ok_missing and all(torch.equal(gathered[0], g_) for g_ in gathered)
+    # head_a only got a gradient on rank 0: its mean over 2 ranks is half of rank 0's local gradient (3 * trunk output / 2)
+    ok_missing = ok_missing and torch.allclose(two["head_a"].bias.grad, torch.tensor([1.5]))
+    q.put((rank, same_after_bcast, torch.allclose(g_dist, g_full, rtol=1e-5, atol=1e-6) and ok_missing, nbytes, tmax, (lo, hi)))
     dist.destroy_process_group()
 
 
