@@ -233,8 +233,8 @@ WL = WORKLOADS["car.fhd"]
 
 def train_bench(args, rank, local_rank, world, device):
     """BASELINE config 3: DDP training, one process per GPU, ONE all-reduce of the flat gradient bucket per step (RCCL over
-    xGMI); weak scaling (batch 4 per GPU).  fp32 parameters and sparse stack (the reference's training precision), optional
-    bf16 autocast of the dense RPN (--dtype bf16)."""
+    xGMI); weak scaling (batch 4 per GPU).  Default fp32 throughout (the reference's training precision); --dtype bf16 / fp16 =
+    16-bit features over fp32 master weights (BASELINE config 5 names fp16)."""
     import torch.distributed as dist
     from second_amd import synthetic as syn
     from second_amd.models import SecondDetector, CAR_FHD
@@ -280,7 +280,7 @@ def train_bench(args, rank, local_rank, world, device):
         res = {"metric": WL["metric"], "value": round(bs * args.steps * world / elapsed, 2), "unit": "samples/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "fp32" if amp is None else f"fp32 sparse stack + {args.dtype} autocast RPN", "data": "synthetic",
+               "dtype": "fp32" if amp is None else f"{args.dtype} features (sparse stack + RPN autocast) over fp32 master weights", "data": "synthetic",
                "config": {"workload": WL["desc"], "samples_per_step_per_gpu": bs, "parallelism": f"ddp{world}",
                           "gradient_bucket_bytes": tr.bucket.numel * 4, "allreduce_us": round(ar_us, 1),
                           "optimizer": "AdamW (adam + fixed weight decay 0.01, car.fhd.config:180-188)"},

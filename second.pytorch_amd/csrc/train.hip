@@ -149,13 +149,16 @@ struct LossParams {
     float code_w[7];
 };
 
-__global__ __launch_bounds__(kBlock) void k_loss_count(const int *__restrict__ labels, int n_anchor, float *__restrict__ cnt,
+constexpr int kCountChunks = 64;        // workgroups per frame of the positive count (deterministic: fixed chunks, fixed order)
+__global__ __launch_bounds__(kBlock) void k_loss_count(const int *__restrict__ labels, int n_anchor, float *__restrict__ part,
                                                       const float *__restrict__ importance) {
-    // per frame: number of positives (weight normaliser) and sum of positive importance (direction weights)
+    // per (frame, chunk): number of positives (weight normaliser) and sum of positive importance (direction weights)
     __shared__ float s[2][kBlock / 64];
-    const int b = blockIdx.x;
+    const int b = blockIdx.y, c = blockIdx.x;
+    const int per = (n_anchor + kCountChunks - 1) / kCountChunks;
+    const int lo = c * per, hi = min(n_anchor, lo + per);
     float np_ = 0.0f, wi = 0.0f;
-    for (int a = threadIdx.x; a < n_anchor; a += kBlock) {
+    for (int a = lo + threadIdx.x; a < hi; a += kBlock) {
         const bool pos = labels[(size_t)b * n_anchor + a] > 0;
         np_ += pos ? 1.0f : 0.0f;
         wi += pos ? importance[(size_t)b * n_anchor + a] : 0.0f;
@@ -167,8 +170,8 @@ __global__ __launch_bounds__(kBlock) void k_loss_count(const int *__restrict__ l
     if (threadIdx.x == 0) {
         float a0 = 0, a1 = 0;
         for (int i = 0; i < kBlock / 64; ++i) { a0 += s[0][i]; a1 += s[1][i]; }
-        cnt[2 * b] = fmaxf(a0, 1.0f);
-        cnt[2 * b + 1] = fmaxf(a1, 1.0f);
+        part[((size_t)b * kCountChunks + c) * 2] = a0;
+        part[((size_t)b * kCountChunks + c) * 2 + 1] = a1;
     }
 }
 
@@ -183,12 +186,19 @@ __global__ __launch_bounds__(kBlock) void k_loss_main(const float *__restrict__ 
                                                      float *__restrict__ d_dir, float *__restrict__ partial) {
     const int b = blockIdx.y, a = blockIdx.x * kBlock + threadIdx.x;
     float s_cls = 0, s_loc = 0, s_dir = 0, s_pos = 0, s_neg = 0;
+    __shared__ float s_norm[2];
+    if (threadIdx.x < 2) {                // the frame's normalisers: fixed-order sum of the chunk counts, clamped to >= 1
+        float acc = 0.0f;
+        for (int c = 0; c < kCountChunks; ++c) acc += cnt[((size_t)b * kCountChunks + c) * 2 + threadIdx.x];
+        s_norm[threadIdx.x] = fmaxf(acc, 1.0f);
+    }
+    __syncthreads();
     if (a < P.n_anchor) {
         const size_t o = (size_t)b * P.n_anchor + a;
         const int label = labels[o];
         const float imp = importance[o];
         const float inv_b = 1.0f / (float)P.batch;
-        const float norm = cnt[2 * b];
+        const float norm = s_norm[0];
         const bool pos = label > 0, neg = label == 0;
         // ---- classification (focal, background encoded as zeros): target one-hot over classes 1..num_class
         const float wcls = ((neg ? P.neg_w : 0.0f) + (pos ? P.pos_w : 0.0f)) / norm * imp;
@@ -236,7 +246,7 @@ __global__ __launch_bounds__(kBlock) void k_loss_main(const float *__restrict__ 
             const float off = limit_period_f(rot_gt - P.dir_offset, 0.0f, kTwoPi);
             int bin = (int)floorf(off / (kTwoPi / (float)P.num_bins));
             bin = bin < 0 ? 0 : (bin > P.num_bins - 1 ? P.num_bins - 1 : bin);
-            const float wdir = (pos ? imp : 0.0f) / cnt[2 * b + 1];
+            const float wdir = (pos ? imp : 0.0f) / s_norm[1];
             float mx = -3.0e38f;
             for (int c = 0; c < P.num_bins; ++c) mx = fmaxf(mx, dirp[o * P.num_bins + c]);
             float se = 0.0f;
@@ -329,7 +339,7 @@ SEC_API int sec_assign_targets_f32(const float *anchors, int n_anchor, const flo
 
 SEC_API size_t sec_second_loss_workspace_bytes(int batch, int n_anchor) {
     if (batch <= 0 || n_anchor <= 0) return 0;
-    return align_up((size_t)2 * batch * sizeof(float)) + align_up((size_t)batch * div_up(n_anchor, kBlock) * 6 * sizeof(float)) + 256;
+    return align_up((size_t)2 * batch * kCountChunks * sizeof(float)) + align_up((size_t)batch * div_up(n_anchor, kBlock) * 6 * sizeof(float)) + 256;
 }
 
 SEC_API int sec_second_loss_f32(const float *cls_preds, const float *box_preds, const float *dir_preds, const int *labels,
@@ -349,11 +359,11 @@ SEC_API int sec_second_loss_f32(const float *cls_preds, const float *box_preds, 
     P.sin_factor = h_params17[9];
     for (int j = 0; j < 7; ++j) P.code_w[j] = h_params17[10 + j];
     Arena ar(workspace, workspace_bytes);
-    float *cnt = ar.take<float>((size_t)2 * batch);
+    float *cnt = ar.take<float>((size_t)2 * batch * kCountChunks);
     const int nb = div_up(n_anchor, kBlock);
     float *partial = ar.take<float>((size_t)batch * nb * 6);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_loss_count, dim3(batch), dim3(kBlock), 0, st, labels, n_anchor, cnt, importance);
+    hipLaunchKernelGGL(k_loss_count, dim3(kCountChunks, batch), dim3(kBlock), 0, st, labels, n_anchor, cnt, importance);
     hipLaunchKernelGGL(k_loss_main, dim3(nb, batch), dim3(kBlock), 0, st, cls_preds, box_preds, dir_preds, labels, reg_targets,
                        anchors, importance, cnt, P, d_cls, d_box, d_dir, partial);
     hipLaunchKernelGGL(k_loss_final, dim3(1), dim3(kBlock), 0, st, partial, batch * nb, P, out6);

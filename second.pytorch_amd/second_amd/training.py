@@ -30,7 +30,8 @@ class DeviceTrainer:
     def __init__(self, det, lr=3e-3, weight_decay=0.01, max_grad_norm=10.0, matched_threshold=0.6, unmatched_threshold=0.45,
                  loss_cfg=None, amp_dtype=None):
         """det: SecondDetector on this rank's GPU (training mode is set here).  ``amp_dtype`` (torch.bfloat16 / float16):
-        autocast for the dense RPN convolutions; the sparse stack and the loss stay in the parameters' dtype."""
+        mixed precision -- 16-bit features in the sparse stack and the RPN over fp32 master weights; None = fp32 throughout
+        (the reference's default training precision)."""
         self.det = det.train()
         self.cfg = det.cfg
         self.max_grad_norm = float(max_grad_norm)
@@ -54,7 +55,9 @@ class DeviceTrainer:
             labels, reg_targets, importance = ops.assign_targets(det.anchors, gt_boxes, gt_offsets, *self.thresholds,
                                                                  gt_classes=gt_classes)
         if self.amp_dtype is not None:
-            spatial = det.middle_feature_extractor(vox["mean"], vox["coordinates"], batch)
+            # fp32 master weights; 16-bit features through the sparse stack (MFMA forward / dgrad / wgrad kernels) and,
+            # under autocast, through the dense RPN; BatchNorm statistics and the loss in fp32
+            spatial = det.middle_feature_extractor(vox["mean"].to(self.amp_dtype), vox["coordinates"], batch)
             with torch.autocast("cuda", dtype=self.amp_dtype):
                 preds = det.rpn(spatial.contiguous(memory_format=torch.channels_last))
         else:

@@ -126,8 +126,13 @@ class SparseConvolution(SparseModule):
             out.indice_dict = x.indice_dict
             return out
         rb = self._rulebook(x)
-        feats = Fsp.indice_conv(x.features, self.weight.to(x.features.dtype), rb, self.packed_weight()
-                                if self.weight.dtype == x.features.dtype else None)
+        if self.weight.dtype == x.features.dtype:
+            w, packed = self.weight, self.packed_weight()
+        else:
+            # mixed precision (fp32 master weights, 16-bit features): cast under autograd, pack the cast copy for the MFMA path
+            w = self.weight.to(x.features.dtype)
+            packed = _ops.pack_weight(w.detach().contiguous()) if w.is_cuda and w.dtype != torch.float32 else None
+        feats = Fsp.indice_conv(x.features, w, rb, packed)
         if self.bias is not None:
             feats = feats + self.bias.to(feats.dtype)
         return self._wrap(x, feats, rb)

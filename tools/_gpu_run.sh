@@ -1,15 +1,10 @@
-mkdir -p gpurun_out/r2h
+mkdir -p gpurun_out/r2j
 export PYTHONUNBUFFERED=1
-R=$GRAFT_REPO_ROOT
+timeout 900 python -m pytest tests/test_gpu_train.py tests/test_gpu_round2.py -q > gpurun_out/r2j/pytest_new.log 2>&1; echo "rc=$?" >> gpurun_out/r2j/pytest_new.log
+timeout 600 python bench.py --workload car.fhd.train --steps 20 --warmup 5 > gpurun_out/r2j/train_fp32.json 2> gpurun_out/r2j/train.err
+timeout 600 python bench.py --workload car.fhd.train --steps 20 --warmup 5 --dtype bf16 > gpurun_out/r2j/train_bf16.json 2>> gpurun_out/r2j/train.err
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof1 -o p -- python $R/bench.py --steps 50 --warmup 10 --inflight 1 --no-cpu-baseline --no-kernel-table > $R/gpurun_out/r2h/rocprof_bench.log 2>&1
-cp /tmp/prof1/p_results.db $R/gpurun_out/r2h/bench_inflight1.db
-timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof2 -o p -- python $R/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-kernel-table > $R/gpurun_out/r2h/rocprof_bench3.log 2>&1
-cp /tmp/prof2/p_results.db $R/gpurun_out/r2h/bench_inflight3.db
-for c in FETCH_SIZE WRITE_SIZE; do
-timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pmc_$c -o p -- python $R/tools/conv_microbench.py --layer subm2 --iters 20 > $R/gpurun_out/r2h/pmc_$c.log 2>&1
-mkdir -p $R/gpurun_out/r2h/pmc_$c; cp /tmp/pmc_$c/*.csv $R/gpurun_out/r2h/pmc_$c/ 2>/dev/null
-done
-timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_sq -o p -- python $R/tools/conv_microbench.py --layer subm2 --iters 20 > $R/gpurun_out/r2h/pmc_sq.log 2>&1
-mkdir -p $R/gpurun_out/r2h/pmc_sq; cp /tmp/pmc_sq/*.csv $R/gpurun_out/r2h/pmc_sq/ 2>/dev/null
-cd $R; ls -la gpurun_out/r2h gpurun_out/r2h/pmc_sq; tail -3 gpurun_out/r2h/pmc_sq.log
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof1 -o p -- python $GRAFT_REPO_ROOT/bench.py --workload car.fhd.train --steps 10 --warmup 3 --dtype bf16 > $GRAFT_REPO_ROOT/gpurun_out/r2j/rocprof_train.log 2>&1
+cp /tmp/prof1/p_results.db $GRAFT_REPO_ROOT/gpurun_out/r2j/train_bf16.db
+cd $GRAFT_REPO_ROOT
+tail -8 gpurun_out/r2j/pytest_new.log; cat gpurun_out/r2j/train_fp32.json gpurun_out/r2j/train_bf16.json | cut -c1-330; tail -5 gpurun_out/r2j/train.err
