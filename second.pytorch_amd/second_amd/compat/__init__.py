@@ -263,3 +263,35 @@ def accelerate_nms():
     bto._second_amd_accelerated = True
     bto._second_amd_original_nms = orig
     return bto
+
+
+def rotate_iou_gpu_eval(boxes, query_boxes, criterion=-1, device_id=0):
+    """Same signature and numpy-in / numpy-out contract as second/core/non_max_suppression/nms_gpu.py:604-640
+    (rotate_iou_gpu_eval, a numba.cuda kernel), on ``sec_rotate_iou_f32``: [N,5] x [K,5] (x, y, w, l, r) -> [N,K];
+    criterion -1 = IoU, 0 = intersection / area(box), 1 = intersection / area(query), 2 = intersection area."""
+    import numpy as np
+    import torch
+    from .. import ops
+    boxes = np.ascontiguousarray(boxes, dtype=np.float32)
+    query_boxes = np.ascontiguousarray(query_boxes, dtype=np.float32)
+    n, k = boxes.shape[0], query_boxes.shape[0]
+    if n == 0 or k == 0:
+        return np.zeros((n, k), dtype=np.float32)
+    dev = torch.device("cuda", device_id)
+    out = ops.rotate_iou(torch.from_numpy(boxes).to(dev), torch.from_numpy(query_boxes).to(dev), int(criterion))
+    return out.cpu().numpy().astype(boxes.dtype)
+
+
+def accelerate_eval():
+    """Route the KITTI evaluation's rotated-IoU calls to the MI355X: ``second/utils/eval.py:124`` (bev_box_overlap) and
+    ``:175`` (box3d_overlap) call ``rotate_iou_gpu_eval(boxes, qboxes, criterion)``, a numba.cuda kernel that cannot run
+    here; :func:`rotate_iou_gpu_eval` above replaces it (all four criteria; pinned on the original by
+    tests/golden/rotate_iou.npz).  Call after :func:`install`; returns the patched module."""
+    import importlib
+    ev = importlib.import_module("second.utils.eval")
+    if getattr(ev, "_second_amd_accelerated", False):
+        return ev
+    ev._second_amd_original_rotate_iou = ev.rotate_iou_gpu_eval
+    ev.rotate_iou_gpu_eval = rotate_iou_gpu_eval
+    ev._second_amd_accelerated = True
+    return ev

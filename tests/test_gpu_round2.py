@@ -124,3 +124,19 @@ def test_voxel_generator_inside_dataloader_workers_after_parent_initialised_the_
         np.testing.assert_array_equal(g["coordinates"], ref["coordinates"])
         np.testing.assert_array_equal(g["voxels"], ref["voxels"])
         np.testing.assert_array_equal(g["num_points"], ref["num_points_per_voxel"])
+
+
+def test_eval_rotate_iou_replacement_matches_the_numba_kernel(golden):
+    """second/utils/eval.py:124,175 call rotate_iou_gpu_eval (numba.cuda); compat.accelerate_eval() installs
+    second_amd.compat.rotate_iou_gpu_eval in its place: numpy in, numpy out, all four criteria, vs the fixture produced by
+    running the reference's own kernel (tests/golden/make_golden.py::gen_rotate_iou)."""
+    from second_amd.compat import rotate_iou_gpu_eval
+    g = golden("rotate_iou")
+    for crit in (-1, 0, 1, 2):
+        got = rotate_iou_gpu_eval(g["boxes"], g["qboxes"], crit)
+        assert isinstance(got, np.ndarray) and got.dtype == np.float32 and got.shape == (len(g["boxes"]), len(g["qboxes"]))
+        np.testing.assert_allclose(got, g[f"iou_c{crit}"], atol=2e-5)
+    assert rotate_iou_gpu_eval(np.zeros((0, 5), np.float32), g["qboxes"]).shape == (0, len(g["qboxes"]))
+    # float64 inputs (what eval.py passes) are accepted and come back in the input precision class of the kernel
+    got = rotate_iou_gpu_eval(g["boxes"].astype(np.float64), g["qboxes"].astype(np.float64), -1)
+    np.testing.assert_allclose(got, g["iou_c-1"], atol=2e-5)
