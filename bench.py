@@ -214,14 +214,16 @@ WORKLOADS = {
                     desc="car.fhd.config VoxelNet forward (voxelise+VFE+SpMiddleFHD+RPNV2+rotated NMS), inference, "
                          "batch=8 synthetic KITTI clouds/GPU (17000 pts, 16000 voxels each), random-init weights, "
                          "inputs resident in HBM"),
-    "nusc.pp": dict(cfg="ALL_PP_LARGEA", batch=4, metric="frames/sec VoxelNet fwd (nuscenes/all.pp.largea)",
+    # BASELINE configs 4 / 5 at their stated input sizes: ~300k points per 10-sweep cloud (SURVEY 8d SYN-NUSC); the live pillar /
+    # voxel counts of the run are reported in config.rows_per_frame
+    "nusc.pp": dict(cfg="ALL_PP_LARGEA", batch=4, points=300000, dtype="bf16", metric="frames/sec VoxelNet fwd (nuscenes/all.pp.largea)",
                     desc="nuscenes/all.pp.largea VoxelNet forward (voxelise+PillarFeatureNet+scatter+RPNV2 3 blocks+"
-                         "axis-aligned NMS), inference, batch=4 synthetic 10-sweep NuScenes clouds/GPU (<= 120k pts), "
+                         "axis-aligned NMS), inference, batch=4 synthetic 10-sweep NuScenes clouds/GPU (~300k pts each), "
                          "random-init weights, inputs resident in HBM"),
-    "nusc.fhd": dict(cfg="ALL_FHD_NUSC", batch=4, metric="frames/sec VoxelNet fwd (nuscenes/all.fhd)",
+    "nusc.fhd": dict(cfg="ALL_FHD_NUSC", batch=4, points=300000, dtype="fp16", metric="frames/sec VoxelNet fwd (nuscenes/all.fhd)",
                      desc="nuscenes/all.fhd VoxelNet forward (block-filtered voxelise+SpMiddleFHD on 1984x1984x40+RPNV2+"
-                          "axis-aligned NMS), inference, batch=4 synthetic 10-sweep NuScenes clouds/GPU (<= 120k pts), "
-                          "random-init weights, inputs resident in HBM"),
+                          "axis-aligned NMS), inference, fp16 (BASELINE config 5), batch=4 synthetic 10-sweep NuScenes clouds/GPU "
+                          "(~300k pts each), random-init weights, inputs resident in HBM"),
 }
 WORKLOADS["car.fhd.train"] = dict(cfg="CAR_FHD", batch=4, metric="samples/sec VoxelNet training step (car.fhd, batch 4/GPU)",
                                   desc="car.fhd.config training step (voxelise + target assignment + SpMiddleFHD/RPNV2 forward, focal / "
@@ -295,7 +297,7 @@ def build_inputs(rank, device, order="shuffle"):
     from second_amd import synthetic as syn
     if WL["cfg"] != "CAR_FHD":
         rng = (-50, -50, -5, 50, 50, 3) if WL["cfg"] == "ALL_PP_LARGEA" else (-49.6, -49.6, -5, 49.6, 49.6, 3)
-        clouds = [syn.syn_nusc_cloud(rank * BATCH + s, num_points=120000, point_cloud_range=rng) for s in range(WL["batch"])]
+        clouds = [syn.syn_nusc_cloud(rank * BATCH + s, num_points=WL["points"], point_cloud_range=rng) for s in range(WL["batch"])]
         pts, offs = syn.batch_clouds(clouds)
         return clouds, torch.from_numpy(pts).to(device), torch.from_numpy(offs).to(device)
     clouds = [syn.syn_kitti_cloud(rank * BATCH + s) for s in range(BATCH)]
@@ -393,6 +395,8 @@ def main():
     WL = WORKLOADS[args.workload]
     if args.workload != "car.fhd":
         args.no_cpu_baseline = True
+        if "dtype" in WL and "--dtype" not in " ".join(sys.argv):
+            args.dtype = WL["dtype"]
 
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
@@ -460,7 +464,9 @@ def main():
             latency_ms = round((time.perf_counter() - t1) / 20 * 1e3, 4)
         if args.mode != "graph":
             out = r
-        if args.mode != "eager":
+        if args.mode == "graph":
+            runner.synchronize()         # capacity-overflow counters of every lane
+        elif args.mode != "eager":
             det.check_overflow()
         # per-kernel timing of the SubMConv3d kernel: capture the launch arguments during one eager forward
         # right after the timed region, then re-issue that launch 100x back-to-back between two HIP events on
@@ -544,6 +550,11 @@ def main():
     if args.stages and rank == 0:
         stage_times(det, points, offsets)
 
+    rows_per_frame = None
+    if rank == 0:
+        with torch.no_grad():   # live voxel / pillar count of this input (what BASELINE quotes the configs on)
+            v_ = det.voxel_generator.generate_device(points, offsets)
+        rows_per_frame = int(v_["voxel_num"]) // WL["batch"]
     if rank == 0:
         frames = WL["batch"] * args.steps * world
         res = {
@@ -555,7 +566,8 @@ def main():
                        "frames_per_step_per_gpu": WL["batch"], "parallelism": f"frame-dp{world}", "launch_mode": args.mode,
                        "graph_branches": args.branches if args.mode == "graph" else None,
                        "steps_in_flight": max(1, args.inflight) if args.mode == "graph" else 1,
-                       "single_step_latency_ms": latency_ms},
+                       "single_step_latency_ms": latency_ms, "points_per_frame": int(points.shape[0]) // WL["batch"],
+                       "rows_per_frame": rows_per_frame},
             "roofline": roof,
             "roofline_mfma": roof_mfma,     # second-largest consumer by kind: the dense RPN conv, MFMA bound
             "kernels": ktable,              # per-launch table of one step (SURVEY 8d formulas)

@@ -622,7 +622,7 @@ class SecondDetector(nn.Module):
             if raw > cap:
                 raise RuntimeError(f"static-capacity overflow: a strided sparse conv produced {raw} outputs, capacity {cap}")
 
-    def make_graphed(self, points, point_offsets, warmup=3, branches=1):
+    def make_graphed(self, points, point_offsets, warmup=3, branches=1, parts=None):
         """Capture the static forward into a hipGraph.  Returns (replay_fn, outputs); new clouds are fed by
         copying into ``points`` / ``point_offsets`` (any point count <= capacity) before calling replay_fn.
 
@@ -633,15 +633,16 @@ class SecondDetector(nn.Module):
         the per-branch input buffers are the ones to refill."""
         if branches <= 1:
             return self._capture([(points, point_offsets)], warmup)[:2]
-        offs = point_offsets.cpu().tolist()
-        nfr = len(offs) - 1
-        branches = min(branches, nfr)
-        bounds = [round(i * nfr / branches) for i in range(branches + 1)]
-        parts = []
-        for lo, hi in zip(bounds[:-1], bounds[1:]):
-            pts = points[offs[lo]:offs[hi]].clone()
-            po = torch.tensor([o - offs[lo] for o in offs[lo:hi + 1]], dtype=torch.int32, device=points.device)
-            parts.append((pts, po))
+        if parts is None:      # (``parts``: input buffers of an earlier capture, re-used so that several graphs read the same ones)
+            offs = point_offsets.cpu().tolist()
+            nfr = len(offs) - 1
+            branches = min(branches, nfr)
+            bounds = [round(i * nfr / branches) for i in range(branches + 1)]
+            parts = []
+            for lo, hi in zip(bounds[:-1], bounds[1:]):
+                pts = points[offs[lo]:offs[hi]].clone()
+                po = torch.tensor([o - offs[lo] for o in offs[lo:hi + 1]], dtype=torch.int32, device=points.device)
+                parts.append((pts, po))
         # capacities: the largest any branch needs
         caps = None
         for pts, po in parts:
@@ -714,7 +715,9 @@ class SecondDetector(nn.Module):
         """-> dict of padded device tensors: boxes [B,P,7], scores [B,P], labels [B,P], valid [B,P] (bool)."""
         cfg = self.cfg
         anchors = self.anchors if anchors is None else anchors
-        if preds["cls_preds"].is_cuda and self.fused_predict:
+        if preds["cls_preds"].is_cuda and self.fused_predict and cfg["nms_pre_max_size"] <= 1024:
+            # (sec_predict_select ranks up to 1024 candidates per frame; larger nms_pre_max_size takes the torch.topk path
+            # below, which honours it -- never a silent truncation)
             return self._predict_fused(preds, batch_size, anchors)
         dec, top_scores, counts, dir_labels, top_labels = self._select(preds, batch_size, anchors)
         if cfg["use_rotate_nms"]:
@@ -785,7 +788,8 @@ class SecondDetector(nn.Module):
 
 class InFlightRunner:
     """Serving loop with several steps in flight: ``inflight`` captured forwards (hipGraphs with their own activation
-    buffers, all reading the same resident input buffers) are replayed round-robin on their own HIP streams.  Replays on
+    buffers, all reading the same resident input buffers -- ``points`` / ``point_offsets``, or ``self.parts`` with branches)
+    are replayed round-robin on their own HIP streams.  Replays on
     one lane serialise, different lanes overlap -- the latency-bound sparse stages of one step run beside the MFMA-bound
     RPN of another (car.fhd, batch 8: 5600 -> 7200 frames/s with three lanes; more lanes add nothing).
 
@@ -795,13 +799,16 @@ class InFlightRunner:
     def __init__(self, det, points, point_offsets, inflight=3, branches=1):
         self.det = det
         self.replays, self.outputs, self.parts = [], [], None
+        self._overflow = []                       # overflow counters of EVERY lane (each capture has its own rulebook buffers)
         for _ in range(max(1, int(inflight))):
             if branches > 1:
-                replay, outs, self.parts = det.make_graphed(points, point_offsets, branches=branches)
+                # the per-branch input buffers are created by the first lane and shared by all others: one place to refill
+                replay, outs, self.parts = det.make_graphed(points, point_offsets, branches=branches, parts=self.parts)
             else:
                 replay, outs = det.make_graphed(points, point_offsets)
             self.replays.append(replay)
             self.outputs.append(outs)
+            self._overflow += [c for lst in getattr(det, "_branch_overflow", []) for c in lst]
         self.lanes = [torch.cuda.Stream() for _ in self.replays] if len(self.replays) > 1 else [None]
         self._k = 0
 
@@ -817,7 +824,10 @@ class InFlightRunner:
 
     def synchronize(self):
         torch.cuda.synchronize()
-        self.det.check_overflow()
+        for num, cap in self._overflow:
+            raw = int(num[1].item())
+            if raw > cap:
+                raise RuntimeError(f"static-capacity overflow: a strided sparse conv produced {raw} outputs, capacity {cap}")
 
 
 def decode_boxes(enc, anc):

@@ -107,9 +107,13 @@ VoxelGenerator = VoxelGeneratorV2
 
 
 def points_to_voxel(points, voxel_size, coors_range, coor_to_voxelidx=None, max_points=35, max_voxels=20000,
-                    full_mean=False, block_filtering=True, block_factor=1, block_size=8, height_threshold=0.2,
+                    full_mean=False, block_filtering=False, block_factor=1, block_size=8, height_threshold=0.2,
                     pad_output=False):
-    gen = VoxelGeneratorV2(voxel_size, coors_range, max_points, max_voxels)
+    """Functional form (kittiviewer/viewer.py:389-395 is the only caller in the reference; it passes none of the filtering
+    arguments).  ``block_filtering`` etc. are forwarded to the generator; ``coor_to_voxelidx`` (upstream's dense scratch
+    grid) is accepted and ignored -- the device path hashes."""
+    gen = VoxelGeneratorV2(voxel_size, coors_range, max_points, max_voxels, full_mean=full_mean, block_filtering=block_filtering,
+                           block_factor=block_factor, block_size=block_size, height_threshold=height_threshold)
     return gen.generate_multi_gpu(points, max_voxels) if pad_output else gen.generate(points, max_voxels)
 
 
