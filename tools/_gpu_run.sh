@@ -1,10 +1,7 @@
-mkdir -p gpurun_out/r2j
+mkdir -p gpurun_out/r2k
 export PYTHONUNBUFFERED=1
-timeout 900 python -m pytest tests/test_gpu_train.py tests/test_gpu_round2.py -q > gpurun_out/r2j/pytest_new.log 2>&1; echo "rc=$?" >> gpurun_out/r2j/pytest_new.log
-timeout 600 python bench.py --workload car.fhd.train --steps 20 --warmup 5 > gpurun_out/r2j/train_fp32.json 2> gpurun_out/r2j/train.err
-timeout 600 python bench.py --workload car.fhd.train --steps 20 --warmup 5 --dtype bf16 > gpurun_out/r2j/train_bf16.json 2>> gpurun_out/r2j/train.err
-cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof1 -o p -- python $GRAFT_REPO_ROOT/bench.py --workload car.fhd.train --steps 10 --warmup 3 --dtype bf16 > $GRAFT_REPO_ROOT/gpurun_out/r2j/rocprof_train.log 2>&1
-cp /tmp/prof1/p_results.db $GRAFT_REPO_ROOT/gpurun_out/r2j/train_bf16.db
-cd $GRAFT_REPO_ROOT
-tail -8 gpurun_out/r2j/pytest_new.log; cat gpurun_out/r2j/train_fp32.json gpurun_out/r2j/train_bf16.json | cut -c1-330; tail -5 gpurun_out/r2j/train.err
+timeout 1500 python -m pytest tests -m gpu -q -x > gpurun_out/r2k/pytest_all.log 2>&1; echo "pytest_all rc=$?" >> gpurun_out/r2k/pytest_all.log
+timeout 600 python bench.py --workload nusc.pp --steps 50 --warmup 10 > gpurun_out/r2k/nusc_pp.json 2> gpurun_out/r2k/nusc.err
+timeout 600 python bench.py --workload nusc.fhd --steps 50 --warmup 10 > gpurun_out/r2k/nusc_fhd.json 2>> gpurun_out/r2k/nusc.err
+timeout 600 python bench.py --workload nusc.fhd --steps 50 --warmup 10 --inflight 1 > gpurun_out/r2k/nusc_fhd_1.json 2>> gpurun_out/r2k/nusc.err
+tail -12 gpurun_out/r2k/pytest_all.log; for f in nusc_pp nusc_fhd nusc_fhd_1; do cut -c1-1200 gpurun_out/r2k/$f.json; done; tail -20 gpurun_out/r2k/nusc.err
