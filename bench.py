@@ -103,7 +103,7 @@ def time_rpn_conv(det, batch, reps=100):
 
 
 PLAN_NAMES = {0: "k_conv_generic", 1: "k_conv_tiled", 2: "k_conv_c4", 3: "k_conv_mfma", 4: "k_conv_mfma_sk", 5: "k_conv_mfma_sks",
-              6: "k_conv_rows", 7: "k_conv_rows", 8: "k_conv_rows", 9: "k_conv_rows", 10: "k_conv_rows_reg", 11: "k_conv_rows_buf"}
+              6: "k_conv_rows", 7: "k_conv_rows", 8: "k_conv_rows", 9: "k_conv_rows", 10: "k_conv_rows_reg", 11: "k_conv_rows_buf", 12: "k_conv_c4_mfma"}
 
 
 def kernel_table(det, points, offsets, reps=30):

@@ -144,7 +144,8 @@ int sec_indice_conv_fwd(const void *features, int n_in, int cin, const void *wei
                         void *out, int dtype, int out_dtype, void *stream);
 /* Which kernel sec_indice_conv_fwd dispatches for a shape (no launch): 0 generic VALU, 1 register-tiled VALU (fp32),
  * 2 Cin=4 first layer, 3 one MFMA wave per tile, 4 split-K MFMA, 5 split-K MFMA per 32-column slice, 6 row-split MFMA
- * with LDS-staged operands (the SubMConv3d 64->64 kernel of the roofline figure), 7-11 its A/B forms.  The parity tests
+ * with LDS-staged operands, 7-10 its A/B forms, 11 the buffer-load row-split kernel (the SubMConv3d 64->64 kernel of the
+ * roofline figure), 12 the Cin=4 first layer on MFMA.  The parity tests
  * use it to prove which kernel an oracle comparison exercised.  sec_indice_conv_set_variant forces one kernel family
  * (same numbers as the SEC_CONV_VARIANT environment variable; < 0 restores the automatic choice): process-wide,
  * not thread-safe, meant for A/B measurements and tests. */

@@ -1094,6 +1094,78 @@ static void launch_rows_buf(const void *feat, long long n_feat, const void *pack
                        relu, (T *)out);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// First layer of SpMiddleFHD (Cin = 4 -> 16, 3x3x3; middle.py:146) on the matrix cores.  The whole receptive field of a
+// row is ONE K dimension: 27 neighbours x 4 channels = 108, padded to 112 = seven 16-deep MFMA steps.  Lane (r, h) feeds step s
+// with the 8-byte rows of neighbours 4s + 2h and 4s + 2h + 1 of output row r (raw buffer loads: no neighbour -> out-of-range
+// offset -> zeros); the 7 weight fragments (7 KB, packed by k_pack_weight_c4 in the matching K order) come straight from L2.
+// No LDS operands, no barrier, 14 gathers + 7 MFMAs per 32 rows (the thread-per-row VALU kernel: 1728 FMAs per row).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_pack_weight_c4(const T *__restrict__ w, int cout, T *__restrict__ packed) {
+    // element ((s * 64 + lane) * 8 + e) = W[kk][ci][c]:  K = s*16 + (lane>>5)*8 + e, kk = K / 4, ci = K % 4, c = lane & 31
+    const int g = blockIdx.x * kBlock + threadIdx.x;
+    if (g >= 7 * 64 * 8) return;
+    const int e = g & 7, lane = (g >> 3) & 63, s_ = g >> 9;
+    const int K = s_ * 16 + (lane >> 5) * 8 + e, kk = K >> 2, ci = K & 3, c = lane & 31;
+    packed[g] = (kk < 27 && c < cout) ? w[((size_t)kk * 4 + ci) * cout + c] : Cvt<T>::from(0.0f);
+}
+
+template <typename T, int COUT>
+__global__ __launch_bounds__(kBlock) void k_conv_c4_mfma(const T *__restrict__ feat, long long feat_bytes, const T *__restrict__ packed,
+                                                        const int *__restrict__ nbr, int n_out, const int *__restrict__ num_out_dev,
+                                                        const float *__restrict__ scale, const float *__restrict__ shift, int relu,
+                                                        T *__restrict__ out) {
+    constexpr int KVOL = 27, TBL16 = 32 * KVOL / 4;
+    __shared__ __attribute__((aligned(16))) u32x4_t stage[4][TBL16];
+    __shared__ __attribute__((aligned(16))) float aff[2 * COUT];
+    rows_stage_affine<COUT>(aff, scale, shift);
+    const int n_cap = n_out;
+    if (num_out_dev) n_out = *num_out_dev;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const long long tile_row0 = (long long)blockIdx.x * 128 + w * 32;
+    const long long row = tile_row0 + r;
+    const bool valid = row < n_out;
+    if (tile_row0 < n_out) {
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(feat), 0, (int)feat_bytes, 0x00020000);
+        const long long left = ((long long)n_cap - tile_row0) * KVOL * 4;
+        const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<int *>(nbr + tile_row0 * KVOL), 0, (int)(left < 32 * KVOL * 4 ? left : 32 * KVOL * 4), 0x00020000);
+#pragma unroll
+        for (int i = 0; i < (TBL16 + 63) / 64; ++i) {
+            const int p16 = i * 64 + lane;
+            if (p16 < TBL16) stage[w][p16] = __builtin_amdgcn_raw_buffer_load_b128(trs, p16 * 16, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int *mine = reinterpret_cast<const int *>(&stage[w][0]) + r * KVOL;
+        const u32x4_t *wp = reinterpret_cast<const u32x4_t *>(packed) + lane;
+        typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+        u32x4_t bfr[7];
+        u32x2_t lo[7], hi[7];
+#pragma unroll
+        for (int s = 0; s < 7; ++s) {
+            bfr[s] = wp[s * 64];
+            const int k0 = 4 * s + 2 * h, k1 = k0 + 1;
+            const int t0 = valid ? mine[k0] : -1;
+            const int t1 = (valid && k1 < KVOL) ? mine[k1 < KVOL ? k1 : 0] : -1;
+            lo[s] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, t0 >= 0 ? (unsigned)t0 * 8u : 0x80000000u, 0, 0);
+            hi[s] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, t1 >= 0 ? (unsigned)t1 * 8u : 0x80000000u, 0, 0);
+        }
+        f32x16 acc[1];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[0][i] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 7; ++s) {
+            const uint4 a = make_uint4(lo[s].x, lo[s].y, hi[s].x, hi[s].y);
+            acc[0] = Mfma<T>::run(__builtin_bit_cast(uint4, bfr[s]), a, acc[0]);   // D^T: lane owns row r
+        }
+        __syncthreads();                                     // the affine vectors staged above are visible
+        rows_store<T, COUT>(acc, out, row, valid, h, aff, scale != nullptr, shift != nullptr, relu);
+    } else {
+        __syncthreads();
+    }
+}
+
 static int g_variant_override = -1;     // sec_indice_conv_set_variant (A/B runs and the parity tests of every shipped kernel)
 static int conv_variant() {
     if (g_variant_override >= 0) return g_variant_override;
@@ -1107,7 +1179,7 @@ static int conv_variant() {
 
 // kernel ids reported by sec_indice_conv_fwd_plan
 enum { PLAN_GENERIC = 0, PLAN_TILED = 1, PLAN_C4 = 2, PLAN_MFMA_WAVE = 3, PLAN_MFMA_SK = 4, PLAN_MFMA_SKS = 5, PLAN_ROWS = 6,
-       PLAN_ROWS_COMPACT = 7, PLAN_ROWS_TOUCH = 8, PLAN_ROWS_COMPACT_TOUCH = 9, PLAN_ROWS_REG = 10, PLAN_ROWS_BUF = 11, PLAN_EXPERIMENT = 99 };
+       PLAN_ROWS_COMPACT = 7, PLAN_ROWS_TOUCH = 8, PLAN_ROWS_COMPACT_TOUCH = 9, PLAN_ROWS_REG = 10, PLAN_ROWS_BUF = 11, PLAN_C4_MFMA = 12, PLAN_EXPERIMENT = 99 };
 
 // Row count from which the buffer-load row-split kernel replaces split-K in the automatic choice (SEC_CONV_ROWS_MIN; the
 // row-split chain of 27 offsets needs enough workgroups to fill the chip, split-K has a 4x shorter chain per wave)
@@ -1682,6 +1754,7 @@ extern "C" __attribute__((visibility("default"))) int sec__debug_timeline(long l
 #endif
 
 SEC_API size_t sec_packed_weight_bytes(int kvol, int cin, int cout, int dtype) {
+    if (dtype != SEC_F32 && cin == 4 && cout == 16 && kvol == 27) return (size_t)7 * 64 * 8 * elt_size(dtype);   // k_conv_c4_mfma
     if (dtype == SEC_F32 || cin % 16 != 0 || kvol <= 0 || cout <= 0) return 0;
     return (size_t)kvol * cin * ((cout + 31) / 32) * 32 * elt_size(dtype);
 }
@@ -1689,6 +1762,15 @@ SEC_API size_t sec_packed_weight_bytes(int kvol, int cin, int cout, int dtype) {
 SEC_API int sec_pack_conv_weight(const void *weight, int kvol, int cin, int cout, int dtype, void *packed, void *stream) {
     if (!weight || !packed || sec_packed_weight_bytes(kvol, cin, cout, dtype) == 0) return SEC_E_INVALID;
     hipStream_t st = (hipStream_t)stream;
+    if (cin == 4) {
+        if (dtype == SEC_BF16)
+            hipLaunchKernelGGL(k_pack_weight_c4<__hip_bfloat16>, dim3(div_up(7 * 64 * 8, kBlock)), dim3(kBlock), 0, st,
+                               (const __hip_bfloat16 *)weight, cout, (__hip_bfloat16 *)packed);
+        else
+            hipLaunchKernelGGL(k_pack_weight_c4<__half>, dim3(div_up(7 * 64 * 8, kBlock)), dim3(kBlock), 0, st, (const __half *)weight, cout,
+                               (__half *)packed);
+        return check_launch();
+    }
     long long total = (long long)kvol * cin * ((cout + 31) / 32) * 32;
     if (dtype == SEC_BF16)
         hipLaunchKernelGGL(k_pack_weight<__hip_bfloat16>, dim3(div_up(total, kBlock)), dim3(kBlock), 0, st,
@@ -1719,6 +1801,7 @@ SEC_API int sec_indice_conv_fwd_plan(int cin, int cout, int kvol, int n_out, int
         if (v == 8 || ((v == 1 || v == 29) && cout <= 32)) return PLAN_MFMA_SKS;
         return v >= 1 ? PLAN_MFMA_SK : PLAN_MFMA_WAVE;
     }
+    if (has_packed && dtype != SEC_F32 && cin == 4 && cout == 16 && kvol == 27 && out_dtype == dtype && conv_variant() != 29) return PLAN_C4_MFMA;
     if (cin == 4 && cout == 16 && (size_t)kvol * 4 * 16 * sizeof(float) <= 48 * 1024) return PLAN_C4;
     static const int tiled_shapes[][2] = {{16, 16}, {16, 32}, {32, 16}, {32, 32}, {32, 64}, {64, 32}, {64, 64}};
     for (auto &sh : tiled_shapes)
@@ -1736,7 +1819,18 @@ SEC_API int sec_indice_conv_fwd(const void *features, int n_in, int cin, const v
     if (!nbr_out || !out || (n_in > 0 && !features)) return SEC_E_INVALID;
     hipStream_t st = (hipStream_t)stream;
     bool done = false;
-    if (packed_weight && dtype != SEC_F32) {
+    if (packed_weight && dtype != SEC_F32 && cin == 4 && cout == 16 && kvol == 27 && out_dtype == dtype && conv_variant() != 29 &&
+        (long long)n_in * 8 < 0x7fffffffll) {
+        const long long fb = (long long)n_in * 8;
+        if (dtype == SEC_BF16)
+            hipLaunchKernelGGL((k_conv_c4_mfma<__hip_bfloat16, 16>), dim3(div_up(n_out, 128)), dim3(kBlock), 0, st, (const __hip_bfloat16 *)features,
+                               fb, (const __hip_bfloat16 *)packed_weight, nbr_out, n_out, num_out_dev, scale, shift, relu, (__hip_bfloat16 *)out);
+        else
+            hipLaunchKernelGGL((k_conv_c4_mfma<__half, 16>), dim3(div_up(n_out, 128)), dim3(kBlock), 0, st, (const __half *)features, fb,
+                               (const __half *)packed_weight, nbr_out, n_out, num_out_dev, scale, shift, relu, (__half *)out);
+        return check_launch();
+    }
+    if (packed_weight && dtype != SEC_F32 && cin % 16 == 0) {
         if (dtype == SEC_BF16) {
             done = out_dtype == SEC_F32
                        ? dispatch_mfma<__hip_bfloat16, float>(cin, cout, features, n_in, packed_weight, nbr_out, n_out, num_out_dev, kvol, scale, shift, relu, out, st)

@@ -207,3 +207,43 @@ def test_conv_rows_buf_all_layer_shapes(ops, cin, cout, ksize, subm, dtype):
         np.testing.assert_allclose(out.float().cpu().numpy(), ref_f, rtol=tol, atol=tol * np.abs(ref_f).max())
     finally:
         ops.indice_conv_set_variant(-1)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_first_layer_c4_mfma_kernel(ops, dtype):
+    """middle.py:146 SubMConv3d(4, 16, 3): K = 27 x 4 folded into seven MFMA steps (k_conv_c4_mfma).  Bench-size row count (ragged),
+    integer operands bit-exact, Gaussian operands + fused epilogue within one 16-bit rounding, and agreement with the VALU kernel."""
+    from test_gpu_parity import _random_indices, _tables_from_pairs
+    rng = np.random.default_rng(4)
+    shape = (12, 60, 56)
+    idx = _random_indices(rng, 4, shape, 9000)                      # 36 000 rows: 282 workgroups, ragged last tile
+    _, pairs, pair_num = orc.rulebook_subm(idx, 4, shape, 3)
+    n = len(idx)
+    assert n % 128 != 0
+    nbr, _ = _tables_from_pairs(pairs, pair_num, n, n)
+    assert ops.indice_conv_plan(4, 16, 27, n, dtype) == 12
+    feat = rng.integers(-2, 3, (n, 4)).astype(np.float32)
+    w = rng.integers(-1, 2, (3, 3, 3, 4, 16)).astype(np.float32)
+    ref = orc.indice_conv(feat, w, pairs, pair_num, n, acc64=True)
+    assert np.abs(ref).max() <= 256
+    f_t, w_t = dev(feat, dtype), dev(w, dtype)
+    packed = ops.pack_weight(w_t)
+    assert packed is not None
+    out = ops.indice_conv(f_t, w_t, dev(nbr), n, packed=packed)
+    np.testing.assert_array_equal(out.float().cpu().numpy(), ref)
+    # static-capacity form
+    table = dev(np.concatenate([nbr, np.full((300, 27), 0x3fffffff, np.int32)]))
+    out = ops.indice_conv(f_t, w_t, table, n + 300, packed=packed, num_out_dev=dev(np.array([n], np.int32)))
+    np.testing.assert_array_equal(out[:n].float().cpu().numpy(), ref)
+    # Gaussian operands, fused epilogue; and the thread-per-row VALU kernel (no packed weights) on the same inputs
+    feat = rng.standard_normal((n, 4)).astype(np.float32) * 10
+    w = (rng.standard_normal((3, 3, 3, 4, 16)) / 10).astype(np.float32)
+    f_t, w_t = dev(feat, dtype), dev(w, dtype)
+    ref = orc.indice_conv(f_t.float().cpu().numpy(), w_t.float().cpu().numpy(), pairs, pair_num, n, acc64=True)
+    scale, shift = rng.uniform(0.5, 1.5, 16).astype(np.float32), rng.uniform(-0.2, 0.2, 16).astype(np.float32)
+    ref_f = torch.from_numpy(np.maximum(ref * scale + shift, 0)).to(dtype).float().numpy()
+    tol = _tol(dtype)
+    a = ops.indice_conv(f_t, w_t, dev(nbr), n, packed=ops.pack_weight(w_t), scale=dev(scale), shift=dev(shift), relu=True)
+    b = ops.indice_conv(f_t, w_t, dev(nbr), n, packed=None, scale=dev(scale), shift=dev(shift), relu=True)
+    np.testing.assert_allclose(a.float().cpu().numpy(), ref_f, rtol=tol, atol=tol * np.abs(ref_f).max())
+    np.testing.assert_allclose(b.float().cpu().numpy(), ref_f, rtol=tol, atol=tol * np.abs(ref_f).max())
