@@ -115,7 +115,13 @@ struct Conv2dParams {
     int batch, h, w, cin, cout, ho, wo, ksize, stride, pad, relu;
     int zskip;    // input known to be mostly zero (scattered sparse voxels): all-zero halo tiles skip the MFMA loop
     long long m;  // batch * ho * wo
+    int stagger;  // profiling builds (-DSEC_CONV_TIMELINE): start delay in clocks per resident-slot index
 };
+
+#ifdef SEC_CONV_TIMELINE
+__device__ long long *g_timeline2 = nullptr;
+__device__ int g_cu_resident[8 * 4096];     // profiling: workgroups currently resident per (XCC, HW_ID cu/sh/se)
+#endif
 
 // packed[((tap * cin/8 + chunk) * cout + n) * 8 + e] = w[n][chunk*8 + e][tap / ks][tap % ks]
 template <typename T>
@@ -761,6 +767,25 @@ __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(con
     };
     const int tile = xcd * per_xcd + local;
     if (local >= per_xcd || tile >= ntile) return;
+#ifdef SEC_CONV_TIMELINE
+    long long *tl = g_timeline2;
+    long long tl0 = 0, tl1 = 0, tl2 = 0;
+    if (p.stagger == -1) return;                                   // experiment: dispatch cost of the grid alone
+    if (p.stagger == -2) { issue_halo(tile); __syncthreads(); return; }   // ... plus the halo DMA
+    if (p.stagger > 0) {       // experiment: desynchronise the three workgroups a CU holds
+        const int slot = (blockIdx.x / 256) % 3;
+        const long long until = clock64() + (long long)slot * p.stagger;
+        while (clock64() < until) __builtin_amdgcn_s_sleep(8);
+    }
+    if (tl) tl0 = clock64();
+    int cu_key = 0, resident_at_start = 0;
+    if (tl && tid == 0) {
+        const unsigned hw = __builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4);      // HW_ID[15:0]: wave, simd, pipe, cu, sh, se
+        const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);     // XCC_ID[3:0]
+        cu_key = (int)((xcc & 7) * 4096 + ((hw >> 8) & 0xff));
+        resident_at_start = atomicAdd(&g_cu_resident[cu_key], 1);
+    }
+#endif
     issue_halo(tile);
     {
         const int b = tile / (tiles_y * tiles_x);
@@ -781,6 +806,9 @@ __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(con
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[a][i] = 0.0f;
         __syncthreads();                            // halo landed
+#ifdef SEC_CONV_TIMELINE
+        if (tl) tl1 = clock64();
+#endif
         // First RPN layer: its input is the scattered sparse-middle output, most 10 x 18 halos hold nothing but zeros and
         // the result is act(bias) exactly (0 * w accumulates to 0) -- one LDS sweep + a barrier decides, uniformly.
         bool live = true;
@@ -826,7 +854,11 @@ __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(con
                     const uint4 *wt = wlane + (size_t)dy * 48 * p.cout, *wn = wlane + (size_t)dyn * 48 * p.cout;
 #pragma unroll
                     for (int j = 0; j < 24; ++j) {
+#if defined(SEC_CONV2D_ABL) && SEC_CONV2D_ABL == 3
+                        br[(j + 7) & 7] = wlane[(size_t)((j + 7) & 1) * 2 * p.cout];   // ablation build: B fragments always from two hot lines
+#else
                         br[(j + 7) & 7] = j + 7 < 24 ? wt[(size_t)(j + 7) * 2 * p.cout] : wn[(size_t)(j + 7 - 24) * 2 * p.cout];
+#endif
                         if (j + 1 < 24) load_a2(bdy, (j + 1) / 8, ((j + 1) % 8) * 2, af[(j + 1) & 1]);
                         else load_a2(bdn, 0, 0, af[0]);
 #pragma unroll
@@ -855,6 +887,55 @@ __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(con
             tap = ntap;
             kc = nkc;
         }
+#ifdef SEC_CONV_TIMELINE
+        if (tl) tl2 = clock64();
+#endif
+        if constexpr (CIN == 128 && TH == 8) {
+            // Epilogue through LDS (the halo buffer is free now): the direct form stores 32-byte pieces of 32 different pixel rows
+            // per instruction -- every 256-byte row is completed by eight instructions of four waves -- and the per-workgroup
+            // timeline showed the store tail as long as the MFMA loop (13 500 of 37 400 clocks).  Here the waves drop their
+            // bias + ReLU'd 16-bit results into a [pixel][channel] tile in LDS (row pitch 272 B: conflict-free 16-byte writes),
+            // and after one barrier every instruction of the workgroup stores ONE 4 KB tile row (16 pixels x 256 B, contiguous).
+            constexpr int PITCH = 17;                       // uint4 per pixel row: 16 + 1 pad
+            __syncthreads();                                // every wave is done reading the halo
+            uint4 *ot = halo_smem;
+            float4 bv[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bv[g] = bias ? *reinterpret_cast<const float4 *>(bias + n0 + 8 * g + 4 * hh) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                uint2 pk[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float v[4] = {acc[mt][4 * g] + bv[g].x, acc[mt][4 * g + 1] + bv[g].y, acc[mt][4 * g + 2] + bv[g].z, acc[mt][4 * g + 3] + bv[g].w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = p.relu ? (v[j] > 0.0f ? v[j] : 0.0f) : v[j];
+                    pk[g] = pack4<T>(v[0], v[1], v[2], v[3]);
+                }
+                const int q = mt * 32 + r;
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    const uint2 keep = hh ? pk[2 * pr + 1] : pk[2 * pr];
+                    const uint2 send = hh ? pk[2 * pr] : pk[2 * pr + 1];
+                    uint2 recv;
+                    recv.x = (unsigned)__shfl_xor((int)send.x, 32, 64);
+                    recv.y = (unsigned)__shfl_xor((int)send.y, 32, 64);
+                    ot[q * PITCH + wv * 4 + 2 * pr + hh] = hh ? make_uint4(recv.x, recv.y, keep.x, keep.y) : make_uint4(keep.x, keep.y, recv.x, recv.y);
+                }
+            }
+            __syncthreads();
+            uint4 *y4 = reinterpret_cast<uint4 *>(y);
+#pragma unroll
+            for (int ty_ = 0; ty_ < TH; ++ty_) {            // one tile row (16 pixels x 16 chunks) per instruction
+                const int px = tid >> 4, ch = tid & 15;
+                const int oy = y0 + ty_, ox = x0 + px;
+                const uint4 v = ot[(ty_ * 16 + px) * PITCH + ch];
+#if defined(SEC_CONV2D_ABL) && SEC_CONV2D_ABL == 4
+                if (v.x != 0x12345678u) continue;                          // ablation build: no output stores
+#endif
+                if (oy < p.h && ox < p.w) y4[(((size_t)b * p.h + oy) * p.w + ox) * (p.cout / 8) + blockIdx.y * 16 + ch] = v;
+            }
+        } else {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int q = mt * 32 + r;
@@ -863,8 +944,22 @@ __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(con
             T *ypix = y + (((size_t)b * p.h + oy) * p.w + ox) * p.cout;
             store_tile_t<T>(acc[mt], bias, n0, p.relu, ypix, ok, hh);
         }
+        }
+#ifdef SEC_CONV_TIMELINE
+        if (tl && tid == 0 && blockIdx.y == 0) {
+            long long *rec = tl + (size_t)blockIdx.x * 4;
+            rec[0] = tl0; rec[1] = tl1; rec[2] = tl2 + ((long long)resident_at_start << 56); rec[3] = clock64();
+            atomicSub(&g_cu_resident[cu_key], 1);
+        }
+#endif
     }
 }
+
+#ifdef SEC_CONV_TIMELINE
+extern "C" __attribute__((visibility("default"))) int sec__debug_timeline2(long long *buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_timeline2), &buf, sizeof(buf)) == hipSuccess ? 0 : -4;
+}
+#endif
 
 template <typename T, int CIN, int TH, bool ROLL = false>
 static int launch_conv2d_halo_reg(const void *x, const void *wpk, const float *bias, void *y, const Conv2dParams &p, hipStream_t st) {
@@ -1198,6 +1293,7 @@ SEC_API int sec_conv2d_nhwc(const void *x, int batch, int h, int w, int cin, con
     p.batch = batch; p.h = h; p.w = w; p.cin = cin; p.cout = cout; p.ksize = ksize; p.stride = stride; p.pad = pad;
     p.relu = relu & 1;
     p.zskip = (relu >> 1) & 1;
+    { static int stg = -1; if (stg < 0) { const char *e = getenv("SEC_CONV2D_STAGGER"); stg = e ? atoi(e) : 0; } p.stagger = stg; }
     p.ho = (h + 2 * pad - ksize) / stride + 1;
     p.wo = (w + 2 * pad - ksize) / stride + 1;
     if (p.ho <= 0 || p.wo <= 0) return SEC_E_INVALID;
