@@ -462,7 +462,8 @@ __global__ __launch_bounds__(kBlock) void k_conv_c4(const T *__restrict__ feat, 
 
 
 // ------------------------------------------------------------------------------------------------------------------
-// Row-split kernel with LDS-staged operands (SEC_CONV_VARIANT=9).
+// Row-split kernels: shared configuration and epilogue.  (The first form, with LDS-staged operands -- SEC_CONV_VARIANT=9 -- now lives in
+// experiments/indice_conv_rows_ab.inc; its design notes follow because k_conv_rows_buf keeps the work split.)
 // The split-K kernel above moves 5x more weight bytes than feature bytes through the vector L1 (every 32-row tile
 // re-fetches all kvol weight blocks: 380 MB of B against 76 MB of gathered A for the 64->64 SubM layer) and gathers
 // rows as 32-byte fragments of 32 different cache lines per instruction.  Here a workgroup owns 128 output rows
@@ -488,72 +489,6 @@ struct RowsCfg {
     static constexpr int ASLOT = 32 * LPR, BSLOT = BPIECES * 64;   // uint4 entries
     static constexpr int RING = 3;
 };
-
-// swizzle key of a row's 16-byte chunks: makes the 16 lanes of every ds_read_b128 group hit 16 distinct bank slots
-template <int LPR> __device__ __forceinline__ int row_key(int r) { return (r / (16 / LPR)) & (LPR - 1); }
-
-// ABL (profiling builds of the same kernel, -DSEC_CONV_ABLATIONS + SEC_CONV_VARIANT 91..96): 1 no gather DMA, 2 no weight
-// DMA, 4 no MFMA, 8 no per-offset barrier, 16 gathers all read row 0.
-// The LDS pointers are __restrict__: after inlining they carry alias scopes, without which the compiler puts
-// s_waitcnt vmcnt(0) in front of every ds_read that follows an LDS-DMA.
-template <typename T, int CIN, int COUT, int ABL>
-__device__ __forceinline__ void rows_compute(const uint4 *__restrict__ a_cur, const uint4 *__restrict__ b_cur, int idx_cur,
-                                             int lane, f32x16 (&acc)[COUT / 32]) {
-    using C = RowsCfg<T, CIN, COUT>;
-    const int r = lane & 31, h = lane >> 5;
-    const bool have = idx_cur >= 0;                 // lanes r and r + 32 hold the same row's index
-    const int key = row_key<C::LPR>(r);
-    // all fragments of the offset first (KS + KS*NT ds_read_b128 in flight together), then the MFMAs back to back
-    uint4 af[C::KS], bf[C::KS * C::NT];
-#pragma unroll
-    for (int s = 0; s < C::KS; ++s) af[s] = a_cur[r * C::LPR + ((s * 2 + h) ^ key)];
-#pragma unroll
-    for (int i = 0; i < C::KS * C::NT; ++i) bf[i] = b_cur[i * 64 + lane];
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int s = 0; s < C::KS; ++s) {
-        const uint4 a = have ? af[s] : make_uint4(0, 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < C::NT; ++t) {
-            if (ABL & 4) acc[t][0] += __uint_as_float(a.x ^ bf[s * C::NT + t].x);
-            else acc[t] = Mfma<T>::run(bf[s * C::NT + t], a, acc[t]);   // D^T
-        }
-    }
-}
-
-// COMPACT form (ABL bit 32, SEC_CONV_VARIANT=10): the gathered rows of an offset sit in LDS in COMPACTED order -- row r of the
-// tile reads slot `pos` = number of valid rows below it -- so only ceil(valid / 8) gather DMAs are issued per offset.
-template <typename T, int CIN, int COUT>
-__device__ __forceinline__ void rows_compute_compact(const uint4 *__restrict__ a_cur, const uint4 *__restrict__ b_cur, int idx_cur,
-                                                     int pos, int lane, f32x16 (&acc)[COUT / 32]) {
-    using C = RowsCfg<T, CIN, COUT>;
-    const int h = lane >> 5;
-    const bool have = idx_cur >= 0;
-    const int key = row_key<C::LPR>(pos);
-    uint4 af[C::KS], bf[C::KS * C::NT];
-#pragma unroll
-    for (int s = 0; s < C::KS; ++s) af[s] = a_cur[pos * C::LPR + ((s * 2 + h) ^ key)];
-#pragma unroll
-    for (int i = 0; i < C::KS * C::NT; ++i) bf[i] = b_cur[i * 64 + lane];
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int s = 0; s < C::KS; ++s) {
-        const uint4 a = have ? af[s] : make_uint4(0, 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < C::NT; ++t) acc[t] = Mfma<T>::run(bf[s * C::NT + t], a, acc[t]);   // D^T
-    }
-}
-
-template <int NBW> __device__ __forceinline__ void cwait_after(int younger_gathers) {
-    // hand-counted wait with a data-dependent (wave-uniform) number of younger gather DMAs + NBW younger weight DMAs
-    switch (younger_gathers) {
-        case 0: cwait_vmcnt<NBW>(); break;
-        case 1: cwait_vmcnt<NBW + 1>(); break;
-        case 2: cwait_vmcnt<NBW + 2>(); break;
-        case 3: cwait_vmcnt<NBW + 3>(); break;
-        default: cwait_vmcnt<NBW + 4>(); break;
-    }
-}
 
 // epilogue of the row-per-lane (D^T) accumulator layout: lane owns row `r`, channels t*32 + 8g + 4h + (0..3); half-waves
 // swap a register group so every lane stores 16-byte runs; fused scale / shift / ReLU
@@ -621,286 +556,9 @@ __device__ __forceinline__ void rows_stage_affine(float *aff, const float *__res
 #define SEC_RTL(...)
 #endif
 
-// ABL bits: 1..16 ablations (profiling builds), 32 = compacted gathers, 64 = TOUCH: every gathered row is first pulled towards
-// the L2 by a 4-byte LDS-DMA issued kTouchDist offsets ahead of its real gather (one instruction per offset: 32 rows x both
-// 64-byte halves, landing in a scratch line nobody reads).  The gather ring only holds two offsets in flight (LDS capacity), so
-// without the touches every step of the 27-offset chain pays a full L2-miss latency; with them the misses of eight offsets
-// overlap and the ring's own gathers hit the L2.
-constexpr int kTouchDist = 8;
-
-template <typename T, int CIN, int COUT, int KVOL, int ABL>
-__global__ __launch_bounds__(kBlock) void k_conv_rows(const T *__restrict__ feat, const T *__restrict__ packed,
-                                                     const int *__restrict__ nbr, int n_out,
-                                                     const int *__restrict__ num_out_dev,
-                                                     const float *__restrict__ scale, const float *__restrict__ shift,
-                                                     int relu, T *__restrict__ out) {
-    using C = RowsCfg<T, CIN, COUT>;
-    constexpr bool TOUCH = (ABL & 64) != 0;
-    constexpr int TD = kTouchDist;
-    extern __shared__ __attribute__((aligned(16))) uint4 rows_smem[];
-    uint4 *bring = rows_smem;                                    // [RING][BSLOT]   shared by the four waves
-    if (num_out_dev) n_out = *num_out_dev;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    uint4 *aring = rows_smem + C::RING * C::BSLOT + w * C::RING * C::ASLOT;   // [RING][ASLOT] private to this wave
-    float *aff = reinterpret_cast<float *>(rows_smem + C::RING * (C::BSLOT + 4 * C::ASLOT));          // scale[COUT] | shift[COUT]
-    uint4 *tscratch = rows_smem + C::RING * (C::BSLOT + 4 * C::ASLOT) + COUT / 2 + w * 16;   // 256 B per wave: landing zone of the touches
-    rows_stage_affine<COUT>(aff, scale, shift);
-    const int r = lane & 31, h = lane >> 5;
-    const long long base = (long long)blockIdx.x * 128 + w * 32;
-    if ((long long)blockIdx.x * 128 >= n_out) return;
-    SEC_RTL(long long *tl = g_timeline; long long tl0 = 0, tl1 = 0, tl2 = 0, tl_wait = 0, tl_issue = 0, tl_comp = 0; if (tl) tl0 = clock64();)
-    const long long row = base + r;
-    const bool valid = row < n_out;
-    const uint4 *wp = reinterpret_cast<const uint4 *>(packed);
-    // the row's whole neighbour list, once, up front (the table is row-major: a per-offset load inside the loop is a
-    // 32-cache-line gather whose latency then sits on the critical path of every offset)
-    int idx[KVOL];
-    {
-        const int *nrow = nbr + (size_t)(valid ? row : 0) * KVOL;
-#pragma unroll
-        for (int k = 0; k < KVOL; ++k) idx[k] = valid ? nrow[k] : -1;
-    }
-    SEC_RTL(if (tl) { cwait_vmcnt<0>(); tl1 = clock64(); })
-    f32x16 acc[C::NT];
-#pragma unroll
-    for (int t = 0; t < C::NT; ++t)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
-    auto touch = [&](int k) {        // rows of offset k towards the L2: lane (r, h) asks for 4 bytes of half h of row idx[k]
-        const int t = idx[k];
-        const char *src = reinterpret_cast<const char *>(feat + (size_t)(t >= 0 ? t : 0) * CIN) + h * (CIN * (int)sizeof(T) / 2);
-        __builtin_amdgcn_global_load_lds((glb_ptr_c)src, (lds_ptr_c)tscratch, 4, 0, 0);
-    };
-    if constexpr (TOUCH) {
-#pragma unroll
-        for (int k = 2; k < TD && k < KVOL; ++k) touch(k);       // offsets 0 and 1 are gathered right away
-    }
-    if constexpr ((ABL & 32) != 0) {
-        static_assert(!(ABL & 32) || (C::ND <= 4 && C::RPI == 8), "compact gathers: 8 rows per DMA instruction");
-        const unsigned below = (1u << r) - 1u;
-        // per offset: mask of the tile's valid rows (wave-uniform), this row's compact slot, and the gather count
-        auto vmask = [&](int k) { return (unsigned)(__ballot(idx[k] >= 0) & 0xffffffffull); };
-        auto issue_c = [&](int k) {
-            const int sl = k % C::RING;
-            const unsigned m = vmask(k);
-            const int nv = __builtin_amdgcn_readfirstlane(__popc(m));
-            const int cnt = (nv + C::RPI - 1) / C::RPI;
-            const int pos = __popc(m & below);
-            // forward permute: valid rows send their neighbour index to lane `pos`, the others fill the tail (a full permutation)
-            const int dest = lane >= 32 ? lane : (idx[k] >= 0 ? pos : nv + (r - pos));
-            const int comp = __builtin_amdgcn_ds_permute(dest << 2, idx[k]);
-#pragma unroll
-            for (int g = 0; g < C::ND; ++g) {
-                if (g < cnt) {
-                    const int sidx = g * C::RPI + lane / C::LPR, slot = lane % C::LPR;
-                    const int srow = __shfl(comp, sidx, 64);
-                    const uint4 *src = reinterpret_cast<const uint4 *>(feat + (size_t)(srow >= 0 ? srow : 0) * CIN) + (slot ^ row_key<C::LPR>(sidx));
-                    __builtin_amdgcn_global_load_lds((glb_ptr_c)src, (lds_ptr_c)&aring[sl * C::ASLOT + g * 64], 16, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < C::NBW; ++j) {
-                const int piece = (w * C::NBW + j) % C::BPIECES;
-                __builtin_amdgcn_global_load_lds((glb_ptr_c)(wp + (size_t)k * C::BSLOT + piece * 64 + lane),
-                                                 (lds_ptr_c)&bring[sl * C::BSLOT + piece * 64], 16, 0, 0);
-            }
-            return cnt;
-        };
-        int cnt_next = 0;                     // gather DMAs of the offset after the one being waited for
-        issue_c(0);
-        if (KVOL > 1) cnt_next = issue_c(1);
-#pragma unroll
-        for (int k = 0; k < KVOL; ++k) {
-            SEC_RTL(long long ta = 0, tb = 0, tc = 0; if (tl) ta = clock64();)
-            // younger than offset k's DMAs: the touch of step k-1 (if any), then offset k+1's gathers and weights
-            const bool tprev = TOUCH && k >= 1 && k - 1 + TD < KVOL;
-            if (k + 1 < KVOL) { if (tprev) cwait_after<C::NBW + 1>(cnt_next); else cwait_after<C::NBW>(cnt_next); }
-            else cwait_vmcnt<0>();
-            clds_barrier();
-            SEC_RTL(if (tl) tb = clock64();)
-            if (TOUCH && k + TD < KVOL) touch(k + TD);
-            if (k + 2 < KVOL) cnt_next = issue_c(k + 2);
-            __builtin_amdgcn_sched_barrier(0);
-            SEC_RTL(if (tl) tc = clock64();)
-            rows_compute_compact<T, CIN, COUT>(aring + (k % C::RING) * C::ASLOT, bring + (k % C::RING) * C::BSLOT, idx[k],
-                                               __popc(vmask(k) & below), lane, acc);
-            SEC_RTL(if (tl) { tl_wait += tb - ta; tl_issue += tc - tb; tl_comp += clock64() - tc; })
-        }
-    }
-    auto issue = [&](int k) {        // operands of offset k -> ring slot k % RING (k is a compile-time constant after unrolling)
-        const int sl = k % C::RING;
-        if (!(ABL & 1)) {
-            int src_row[C::ND];
-#pragma unroll
-            for (int g = 0; g < C::ND; ++g) {
-                src_row[g] = __shfl(idx[k], g * C::RPI + lane / C::LPR, 64);
-                if (ABL & 16) src_row[g] = 0;
-            }
-#pragma unroll
-            for (int g = 0; g < C::ND; ++g) {
-                const int rr = g * C::RPI + lane / C::LPR, slot = lane % C::LPR;
-                // rows without a neighbour fetch row 0 (their fragment is zeroed when it is read): every lane stays active so
-                // the instruction count, and with it the s_waitcnt vmcnt(n) bookkeeping, is fixed.  (Masking those lanes off
-                // was measured 6 % slower: the exec save/restore around each DMA costs more than the 16-byte fetches.)
-                const uint4 *src = reinterpret_cast<const uint4 *>(feat + (size_t)(src_row[g] >= 0 ? src_row[g] : 0) * CIN) + (slot ^ row_key<C::LPR>(rr));
-                __builtin_amdgcn_global_load_lds((glb_ptr_c)src, (lds_ptr_c)&aring[sl * C::ASLOT + g * 64], 16, 0, 0);
-            }
-        }
-        if (!(ABL & 2)) {
-#pragma unroll
-            for (int j = 0; j < C::NBW; ++j) {
-                const int piece = (w * C::NBW + j) % C::BPIECES;
-                __builtin_amdgcn_global_load_lds((glb_ptr_c)(wp + (size_t)k * C::BSLOT + piece * 64 + lane),
-                                                 (lds_ptr_c)&bring[sl * C::BSLOT + piece * 64], 16, 0, 0);
-            }
-        }
-    };
-    constexpr int PEND = ((ABL & 1) ? 0 : C::ND) + ((ABL & 2) ? 0 : C::NBW);   // DMAs per wave per offset
-    if constexpr ((ABL & 32) == 0) {
-    issue(0);
-    if (KVOL > 1) issue(1);
-    // software pipeline, distance 2: iteration k computes offset k while k+1 is in flight and k+2 is being issued
-#pragma unroll
-    for (int k = 0; k < KVOL; ++k) {
-        SEC_RTL(long long ta = 0, tb = 0, tc = 0; if (tl) ta = clock64();)
-        // this wave's DMAs of offset k have landed once only those of offset k+1 (and the touch issued before them) are outstanding ...
-        const bool tprev = TOUCH && k >= 1 && k - 1 + TD < KVOL;
-        if (k + 1 < KVOL) { if (tprev) cwait_vmcnt<PEND + 1>(); else cwait_vmcnt<PEND>(); }
-        else cwait_vmcnt<0>();
-        if (!(ABL & 8)) clds_barrier();                      // ... and so have the other waves' pieces of W[k]
-        SEC_RTL(if (tl) tb = clock64();)
-        if (TOUCH && k + TD < KVOL) touch(k + TD);
-        if (k + 2 < KVOL) issue(k + 2);                      // into the slot every wave finished reading before this barrier
-        __builtin_amdgcn_sched_barrier(0);                   // keep the prefetch ahead of the MFMAs it is meant to overlap
-        SEC_RTL(if (tl) tc = clock64();)
-        rows_compute<T, CIN, COUT, ABL>(aring + (k % C::RING) * C::ASLOT, bring + (k % C::RING) * C::BSLOT, idx[k], lane, acc);
-        SEC_RTL(if (tl) { tl_wait += tb - ta; tl_issue += tc - tb; tl_comp += clock64() - tc; })
-    }
-    }
-    SEC_RTL(if (tl) tl2 = clock64();)
-    rows_store<T, COUT>(acc, out, row, valid, h, aff, scale != nullptr, shift != nullptr, relu);
-#ifdef SEC_CONV_TIMELINE
-    if (tl && lane == 0) {
-        long long *rec = tl + ((size_t)blockIdx.x * 4 + w) * 8;
-        rec[0] = tl0; rec[1] = tl1; rec[2] = tl2; rec[3] = clock64(); rec[4] = tl_wait; rec[5] = tl_issue; rec[6] = tl_comp;
-        rec[7] = __builtin_amdgcn_s_getreg((4 << 11) | 20);
-    }
+#ifdef SEC_CONV_EXPERIMENTS   // the LDS-DMA and register-direct row-split forms (SEC_CONV_VARIANT 9-15): measured, superseded
+#include "experiments/indice_conv_rows_ab.inc"
 #endif
-}
-
-template <typename T, int CIN, int COUT, int ABL>
-static void launch_rows(const void *feat, const void *packed, const int *nbr, int n_out, const int *num_out_dev, int kvol,
-                        const float *scale, const float *shift, int relu, void *out, hipStream_t st) {
-    constexpr int KVOL = 27;   // dispatched for 3x3x3 layers only
-    using C = RowsCfg<T, CIN, COUT>;
-    constexpr size_t lds = (size_t)C::RING * (C::BSLOT + 4 * C::ASLOT) * 16 + 2 * COUT * sizeof(float) + ((ABL & 64) ? 4 * 256 : 0);
-    static bool configured = false;
-    auto fn = k_conv_rows<T, CIN, COUT, KVOL, ABL>;
-    if (!configured) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        configured = true;
-    }
-    hipLaunchKernelGGL(fn, dim3(div_up(n_out, 128)), dim3(kBlock), lds, st, (const T *)feat, (const T *)packed, nbr, n_out,
-                       num_out_dev, scale, shift, relu, (T *)out);
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// Row-split kernel with REGISTER-direct gathers (SEC_CONV_VARIANT 13/14/15).  Same work split as k_conv_rows (128 rows per
-// workgroup, one 32-row tile per wave, W[k] shared through a 3-slot LDS ring), but the gathered rows never touch LDS: lane
-// (r, h) loads the 16-byte K-chunks of its row straight into the registers the MFMA reads (the transposed product takes the
-// features as its second operand, whose fragment IS 8 consecutive channels of one row).  LDS then only holds the weight ring
-// (24 KB instead of 72 KB per workgroup), so the prefetch distance is set by registers -- DIST offsets of 16 VGPRs each -- and
-// no longer by the LDS capacity, and all memory operations are ordinary loads the compiler's own s_waitcnt bookkeeping
-// understands (W[k+2] travels global -> VGPR -> ds_write one step ahead of its barrier).
-template <typename T, int CIN, int COUT, int KVOL, int DIST, int MINW>
-__global__ __launch_bounds__(kBlock, MINW) void k_conv_rows_reg(const T *__restrict__ feat, const T *__restrict__ packed,
-                                                               const int *__restrict__ nbr, int n_out,
-                                                               const int *__restrict__ num_out_dev,
-                                                               const float *__restrict__ scale, const float *__restrict__ shift,
-                                                               int relu, T *__restrict__ out) {
-    using C = RowsCfg<T, CIN, COUT>;
-    static_assert(C::BPIECES % 4 == 0, "weight pieces split evenly over the four waves");
-    __shared__ __attribute__((aligned(16))) uint4 bring[3][C::BSLOT];
-    __shared__ __attribute__((aligned(16))) float aff[2 * COUT];
-    rows_stage_affine<COUT>(aff, scale, shift);
-    if (num_out_dev) n_out = *num_out_dev;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    const long long base = (long long)blockIdx.x * 128 + w * 32;
-    if ((long long)blockIdx.x * 128 >= n_out) return;
-    SEC_RTL(long long *tl = g_timeline; long long tl0 = 0, tl1 = 0, tl2 = 0; if (tl) tl0 = clock64();)
-    const long long row = base + r;
-    const bool valid = row < n_out;
-    const uint4 *wp = reinterpret_cast<const uint4 *>(packed) + (size_t)w * C::NBW * 64 + lane;
-    int idx[KVOL];
-    {
-        const int *nrow = nbr + (size_t)(valid ? row : 0) * KVOL;
-#pragma unroll
-        for (int k = 0; k < KVOL; ++k) idx[k] = valid ? nrow[k] : -1;
-    }
-    SEC_RTL(if (tl) { cwait_vmcnt<0>(); tl1 = clock64(); })
-    f32x16 acc[C::NT];
-#pragma unroll
-    for (int t = 0; t < C::NT; ++t)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
-    static_assert(C::NBW == 2, "two 1 KB weight pieces per wave and offset");
-    // vmcnt retires in order, so a load that is needed one step after its issue would drag every older gather with it: the
-    // weight pieces therefore travel at the SAME distance as the gathers (register ring, global -> VGPR -> ds_write -> barrier).
-    uint4 areg[DIST][C::KS];
-    uint4 wr0[DIST], wr1[DIST];      // this wave's share of the weight blocks on their way global -> LDS
-    uint4 *bslot = &bring[0][(w * C::NBW) * 64 + lane];
-#define SEC_FETCH(k)                                                                                                   \
-    {                                                                                                                  \
-        wr0[(k) % DIST] = wp[(size_t)(k) * C::BSLOT];                                                                  \
-        wr1[(k) % DIST] = wp[(size_t)(k) * C::BSLOT + 64];                                                             \
-        const int t_ = idx[k];       /* rows without a neighbour read row 0 (one hot line) and are zeroed at use */    \
-        const uint4 *src_ = reinterpret_cast<const uint4 *>(feat + (size_t)(t_ >= 0 ? t_ : 0) * CIN) + h;              \
-        _Pragma("unroll") for (int s_ = 0; s_ < C::KS; ++s_) areg[(k) % DIST][s_] = src_[2 * s_];                      \
-    }
-#define SEC_WSTORE(k) { bslot[((k) % 3) * C::BSLOT] = wr0[(k) % DIST]; bslot[((k) % 3) * C::BSLOT + 64] = wr1[(k) % DIST]; }
-#pragma unroll
-    for (int k = 0; k < DIST && k < KVOL; ++k) SEC_FETCH(k)
-    SEC_WSTORE(0)
-#pragma unroll
-    for (int k = 0; k < KVOL; ++k) {
-        uint4 wn0, wn1;                                      // W[k+1]'s pieces leave the ring before its slot is refilled below
-        if (k + 1 < KVOL) { wn0 = wr0[(k + 1) % DIST]; wn1 = wr1[(k + 1) % DIST]; }
-        if (k + 1 < KVOL) { bslot[((k + 1) % 3) * C::BSLOT] = wn0; bslot[((k + 1) % 3) * C::BSLOT + 64] = wn1; }   // slot last read two barriers ago
-        __syncthreads();                                     // W[k] (stored during step k-1) is visible to every wave
-        uint4 bf[C::KS * C::NT];
-#pragma unroll
-        for (int i = 0; i < C::KS * C::NT; ++i) bf[i] = bring[k % 3][i * 64 + lane];
-        __builtin_amdgcn_sched_barrier(0);                   // all B fragments in flight together, then the MFMAs back to back
-        const bool have = idx[k] >= 0;
-#pragma unroll
-        for (int s = 0; s < C::KS; ++s) {
-            const uint4 a = have ? areg[k % DIST][s] : make_uint4(0, 0, 0, 0);
-#pragma unroll
-            for (int t = 0; t < C::NT; ++t) acc[t] = Mfma<T>::run(bf[s * C::NT + t], a, acc[t]);   // D^T
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (k + DIST < KVOL) SEC_FETCH(k + DIST)             // into the registers this step just consumed
-    }
-#undef SEC_FETCH
-#undef SEC_WSTORE
-    SEC_RTL(if (tl) tl2 = clock64();)
-    rows_store<T, COUT>(acc, out, row, valid, h, aff, scale != nullptr, shift != nullptr, relu);
-#ifdef SEC_CONV_TIMELINE
-    if (tl && lane == 0) {
-        long long *rec = tl + ((size_t)blockIdx.x * 4 + w) * 8;
-        rec[0] = tl0; rec[1] = tl1; rec[2] = tl2; rec[3] = clock64(); rec[4] = rec[5] = rec[6] = 0;
-        rec[7] = __builtin_amdgcn_s_getreg((4 << 11) | 20);
-    }
-#endif
-}
-
-template <typename T, int CIN, int COUT, int DIST, int MINW>
-static void launch_rows_reg(const void *feat, const void *packed, const int *nbr, int n_out, const int *num_out_dev,
-                            const float *scale, const float *shift, int relu, void *out, hipStream_t st) {
-    hipLaunchKernelGGL((k_conv_rows_reg<T, CIN, COUT, 27, DIST, MINW>), dim3(div_up(n_out, 128)), dim3(kBlock), 0, st,
-                       (const T *)feat, (const T *)packed, nbr, n_out, num_out_dev, scale, shift, relu, (T *)out);
-}
 
 // ------------------------------------------------------------------------------------------------------------------
 // Row-split kernel, BUFFER-load form (SEC_CONV_VARIANT 16..19).  What the per-wave timeline of the forms above showed
@@ -1202,6 +860,7 @@ static int rows_plan(int cin, int cout, int kvol, int n_out, bool same_dtype) {
         if (v == 22 || (v >= 16 && v <= 28 && cin == 64 && cout == 64 && kvol == 27)) return PLAN_ROWS_BUF;
         if (v == 1 && n_out >= rows_min()) return PLAN_ROWS_BUF;
     }
+#ifdef SEC_CONV_EXPERIMENTS
     if (kvol != 27 || !(cin == 64 || cin == 32) || !(cout == 64 || cout == 32)) return 0;
     if (cin == 64) {
         if (v == 10) return PLAN_ROWS_COMPACT;
@@ -1210,6 +869,7 @@ static int rows_plan(int cin, int cout, int kvol, int n_out, bool same_dtype) {
         if (v >= 13 && v <= 15 && cout == 64) return PLAN_ROWS_REG;
     }
     if (v == 9) return PLAN_ROWS;
+#endif
     return 0;
 }
 
@@ -1224,6 +884,7 @@ static void launch_mfma(const void *feat, long long n_feat, const void *packed, 
             if (kvol == 3) {
                 if constexpr (CIN == 64 && COUT == 64) { SEC_BUF(3, 8, 3, 3); return; }
             } else {
+#ifdef SEC_CONV_EXPERIMENTS   // A/B forms of the buffer-load kernel: prefetch distance, 4- or 8-wave workgroups, staging / pipelining off, skew
                 if constexpr (CIN == 64 && COUT == 64) {
                     switch (conv_variant()) {
                     case 16: SEC_BUF(4, 4, 0, 27); return;
@@ -1243,12 +904,14 @@ static void launch_mfma(const void *feat, long long n_feat, const void *packed, 
                     default: break;
                     }
                 }
+#endif
                 SEC_BUF(4, 8, 3, 27);
                 return;
             }
 #undef SEC_BUF
         }
     }
+#ifdef SEC_CONV_EXPERIMENTS
     if constexpr (std::is_same<T, OT>::value && (CIN == 64 || CIN == 32) && (COUT == 64 || COUT == 32)) {
         const int rp = feat ? rows_plan(CIN, COUT, kvol, n_out, true) : 0;
         if constexpr (CIN == 64) {
@@ -1283,6 +946,7 @@ static void launch_mfma(const void *feat, long long n_feat, const void *packed, 
         }
 #endif
     }
+#endif
 #ifdef SEC_CONV_EXPERIMENTS   // measured dead ends, compiled only for A/B builds
     if (conv_variant() == 2 && kvol == 27) {
         hipLaunchKernelGGL((k_conv_mfma_lds<T, OT, CIN, COUT, 27>), dim3(div_up(n_out, 128)), dim3(kBlock), 0, st,

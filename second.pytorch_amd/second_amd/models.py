@@ -227,7 +227,10 @@ class SpMiddleFHD(nn.Module):
         add(down(64, 64, (3, 1, 1), (2, 1, 1), 0), 64)
         self.middle_conv = spconv.SparseSequential(*layers)
         import os
-        self.overlap_rulebooks = os.environ.get("SEC_OVERLAP_RULEBOOKS", "0") == "1"  # measured: no gain under hipGraph replay
+        # rulebooks of all layers built ahead on side streams (graph branches): 1 = one side stream, 2 = strided chain and SubM
+        # builds on two streams.  Shortens one step's latency, costs throughput with several steps in flight
+        self.overlap_rulebooks = os.environ.get("SEC_OVERLAP_RULEBOOKS", "0") in ("1", "2")
+        self.overlap_rulebooks_split = os.environ.get("SEC_OVERLAP_RULEBOOKS", "0") == "2"
         self._side_stream = None
 
     def forward(self, voxel_features, coors, batch_size, channels_last=False, num_active_dev=None):
@@ -241,12 +244,13 @@ class SpMiddleFHD(nn.Module):
                 self._side_stream = {}
             key = torch.cuda.current_stream().cuda_stream
             if key not in self._side_stream:
-                self._side_stream[key] = torch.cuda.Stream()
-            side = self._side_stream[key]
-            x.planned = self.middle_conv.plan_rulebooks(x, side)
+                self._side_stream[key] = (torch.cuda.Stream(), torch.cuda.Stream())
+            side, side2 = self._side_stream[key]
+            x.planned = self.middle_conv.plan_rulebooks(x, side, side2 if self.overlap_rulebooks_split else None)
         x = self.middle_conv(x)
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.current_stream().wait_stream(side2)
             self.last_overflow_checks = self.middle_conv._planned_overflow
         else:
             self.last_overflow_checks = x.overflow_checks

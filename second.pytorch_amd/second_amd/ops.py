@@ -102,6 +102,7 @@ def rulebook_subm(indices, batch_size, spatial_shape, ksize=3, dilation=1, want_
     dev = indices.device
     if site_table is not None and not want_pairs and n > 0:
         ws, cn, cks, cst, cdl, chint = site_table
+        ws.record_stream(torch.cuda.current_stream())     # the strided build may have run (and allocated) on another stream
         nbr = torch.empty((n, k), dtype=torch.int32, device=dev)
         rc = rt.lib().sec_rulebook_subm3d_after_conv(rt.ptr(indices), n, rt.ptr(n_dev), int(batch_size), rt.i3(spatial_shape),
                                                      rt.i3(ksize), rt.i3(dilation), rt.ptr(nbr), rt.ptr(ws), ws.numel(), int(cn),

@@ -51,26 +51,35 @@ class SparseSequential(SparseModule):
                 raise KeyError("name exists")
         self.add_module(name, module)
 
-    def plan_rulebooks(self, x, stream):
-        """Build the rulebooks of EVERY sparse conv of this sequence on `stream`, ahead of the feature
-        computation: rulebooks depend on coordinates only, so the (latency-bound) hash / scan kernels of all
-        layers overlap with the conv kernels of the layers before them.  Returns {id(conv): (Rulebook, event)};
+    def plan_rulebooks(self, x, stream, stream2=None):
+        """Build the rulebooks of EVERY sparse conv of this sequence ahead of the feature computation: rulebooks depend on
+        coordinates only, so the (latency-bound) hash / scan kernels of all layers overlap with the conv kernels of the layers
+        before them.  The strided builds form a serial chain (each numbers the sites of the next level) and run on ``stream``;
+        the SubM builds hang off that chain -- each only needs the level's sites -- and run on ``stream2`` (default: the same
+        stream) as soon as the strided build that produced their sites is done.  Returns {id(conv): (Rulebook, event)};
         assign it to ``x.planned`` before calling forward.  Static-capacity tensors only (no host syncs)."""
         from .conv import SparseConvolution
         from .tensor import SparseConvTensor
         assert x.num_active_dev is not None, "plan_rulebooks needs a static-capacity SparseConvTensor"
         main = torch.cuda.current_stream()
         stream.wait_stream(main)
+        stream2 = stream2 or stream
+        if stream2 is not stream:
+            stream2.wait_stream(main)
         plans = {}
-        with torch.cuda.stream(stream):
-            cur = SparseConvTensor(None, x.indices, x.spatial_shape, x.batch_size, None, x.num_active_dev)
-            cur.indice_dict = x.indice_dict
-            for m in self._modules.values():
-                if not isinstance(m, SparseConvolution) or m.conv1x1:
-                    continue
+        cur = SparseConvTensor(None, x.indices, x.spatial_shape, x.batch_size, None, x.num_active_dev)
+        cur.indice_dict = x.indice_dict
+        level_ready = None                           # event: the current level's sites (and its hash table) exist
+        for m in self._modules.values():
+            if not isinstance(m, SparseConvolution) or m.conv1x1:
+                continue
+            st = stream2 if m.subm else stream
+            with torch.cuda.stream(st):
+                if m.subm and level_ready is not None and st is not stream:
+                    st.wait_event(level_ready)
                 rb = m._rulebook(cur)
                 ev = torch.cuda.Event()
-                ev.record(stream)
+                ev.record(st)
                 for t in (rb.nbr_out, rb.nbr_in, rb.out_indices, rb.num_out_dev):
                     if t is not None:
                         t.record_stream(main)
@@ -81,7 +90,9 @@ class SparseSequential(SparseModule):
                     nxt.overflow_checks = cur.overflow_checks + [(rb.num_out_dev, rb.out_indices.shape[0])]
                     nxt.site_table = rb.__dict__.pop("_site_table", None)
                     cur = nxt
-            self._planned_overflow = cur.overflow_checks
+                    level_ready = ev
+        self._planned_overflow = cur.overflow_checks
+        self._plan_streams = (stream, stream2)
         return plans
 
     def _folded(self, conv, bn):

@@ -39,7 +39,8 @@ def test_workspace_queries_are_host_only():
     assert l.sec_nms_workspace_bytes(8, 1000) == 8 * 1000 * 16 * 8
     assert l.sec_packed_weight_bytes(27, 64, 64, rt.SEC_BF16) == 27 * 64 * 64 * 2
     assert l.sec_packed_weight_bytes(27, 16, 16, rt.SEC_BF16) == 27 * 16 * 32 * 2  # Cout padded to 32 columns
-    assert l.sec_packed_weight_bytes(27, 4, 16, rt.SEC_BF16) == 0                  # Cin=4: generic path
+    assert l.sec_packed_weight_bytes(27, 4, 16, rt.SEC_BF16) == 7 * 64 * 8 * 2     # Cin=4 first layer: K = 27 x 4 padded to 7 MFMA steps
+    assert l.sec_packed_weight_bytes(27, 5, 7, rt.SEC_BF16) == 0                   # no MFMA layout: generic path
     out = (ctypes.c_int * 3)()
     l.sec_conv_output_shape(rt.i3([41, 1600, 1408]), rt.i3(3), rt.i3(2), rt.i3(1), rt.i3(1), out)
     assert list(out) == [21, 800, 704]

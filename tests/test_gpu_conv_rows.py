@@ -14,8 +14,12 @@ pytestmark = pytest.mark.gpu
 from oracle import oracle as orc  # noqa: E402  (test infrastructure only)
 
 PLAN_ROWS_BUF = 11
-# (variant number, expected plan id): None = the automatic choice; the others force one A/B form of the kernel
-ROW_VARIANTS = [(None, 11), (9, 6), (10, 7), (11, 8), (12, 9), (13, 10), (14, 10), (15, 10), (16, 11), (17, 11), (18, 11), (19, 11), (20, 11), (21, 11), (22, 11), (23, 11), (27, 11), (28, 11)]
+# (variant number, expected plan id): None = the automatic choice, 22 = the same kernel forced.  A library built with
+# -DSEC_CONV_EXPERIMENTS also carries the superseded row-split forms (9-15: LDS-DMA / register-direct gathers) and the A/B forms of
+# the buffer-load kernel (16-21, 23, 27, 28); they are run through the same comparisons when present.
+ROW_VARIANTS = [(None, 11), (22, 11)]
+EXPERIMENT_VARIANTS = [(9, 6), (10, 7), (11, 8), (12, 9), (13, 10), (14, 10), (15, 10), (16, 11), (17, 11), (18, 11), (19, 11),
+                       (20, 11), (21, 11), (23, 11), (27, 11), (28, 11)]
 
 
 def dev(a, dtype=None):
@@ -28,6 +32,10 @@ def dev(a, dtype=None):
 @pytest.fixture(scope="module")
 def ops():
     from second_amd import ops
+    ops.indice_conv_set_variant(9)                       # plan 6 only exists in experiment builds
+    if ops.indice_conv_plan(64, 64, 27, 50000, torch.bfloat16) == 6:
+        ROW_VARIANTS.extend(EXPERIMENT_VARIANTS)
+    ops.indice_conv_set_variant(-1)
     yield ops
     ops.indice_conv_set_variant(-1)
 
