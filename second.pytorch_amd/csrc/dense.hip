@@ -777,7 +777,8 @@ __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(con
         const long long until = clock64() + (long long)slot * p.stagger;
         while (clock64() < until) __builtin_amdgcn_s_sleep(8);
     }
-    if (tl) tl0 = clock64();
+    long long wl0 = 0;
+    if (tl) { tl0 = clock64(); wl0 = wall_clock64(); }
     int cu_key = 0, resident_at_start = 0;
     if (tl && tid == 0) {
         const unsigned hw = __builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4);      // HW_ID[15:0]: wave, simd, pipe, cu, sh, se
@@ -947,8 +948,9 @@ __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(con
         }
 #ifdef SEC_CONV_TIMELINE
         if (tl && tid == 0 && blockIdx.y == 0) {
-            long long *rec = tl + (size_t)blockIdx.x * 4;
+            long long *rec = tl + (size_t)blockIdx.x * 8;
             rec[0] = tl0; rec[1] = tl1; rec[2] = tl2 + ((long long)resident_at_start << 56); rec[3] = clock64();
+            rec[4] = wl0; rec[5] = wall_clock64(); rec[6] = cu_key;       // constant 100 MHz counter: real time, comparable across CUs
             atomicSub(&g_cu_resident[cu_key], 1);
         }
 #endif

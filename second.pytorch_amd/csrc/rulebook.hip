@@ -92,16 +92,19 @@ __global__ __launch_bounds__(kBlock) void k_subm_nbr(const int *__restrict__ ind
 // Symmetric form (odd kernels, any dilation): offset k and its mirror K-1-k describe the same pair of sites, so
 // only the lower half of the offsets is looked up; a hit (i, j) at k fills nbr[i][k] = j and nbr[j][K-1-k] = i.
 // The table must be pre-filled with -1; the centre column is the identity.
+template <bool K3>     // K3: 3x3x3 kernel (every SubM layer of the reference): constant divisors
 __global__ __launch_bounds__(kBlock) void k_subm_nbr_sym(const int *__restrict__ indices, RbGeom g,
                                                         const int *__restrict__ n_dev,
                                                         const unsigned long long *__restrict__ keys,
                                                         const int *__restrict__ vals, int *__restrict__ nbr) {
-    const int half = g.kvol / 2;                      // offsets 0..half-1 are looked up, `half` is the centre
+    if (K3) { g.kvol = 27; g.ksize[0] = g.ksize[1] = g.ksize[2] = 3; }
+    const int half = K3 ? 13 : g.kvol / 2;            // offsets 0..half-1 are looked up, `half` is the centre
     long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (t >= (long long)live_rows(g, n_dev) * (half + 1)) return;
     int o = (int)(t / (half + 1)), k = (int)(t % (half + 1));
     if (k == half) { nbr[(size_t)o * g.kvol + half] = o; return; }
-    int kx = k % g.ksize[2], ky = (k / g.ksize[2]) % g.ksize[1], kz = k / (g.ksize[2] * g.ksize[1]);
+    int kx = K3 ? k % 3 : k % g.ksize[2], ky = K3 ? (k / 3) % 3 : (k / g.ksize[2]) % g.ksize[1],
+        kz = K3 ? k / 9 : k / (g.ksize[2] * g.ksize[1]);
     int4 c = *reinterpret_cast<const int4 *>(indices + (size_t)o * 4);
     int z = c.y + (kz - g.ksize[0] / 2) * g.dil[0];
     int y = c.z + (ky - g.ksize[1] / 2) * g.dil[1];
@@ -138,24 +141,63 @@ __device__ __forceinline__ bool cand_offset(const RbGeom &g, int d, int in, int 
     return false;
 }
 
+// Compile-time geometries of the layers SECOND actually builds (middle.py:152-188): the generic kernels spend most of
+// their instructions on runtime integer divisions (t / ncand, c / cand, num % stride: ~40 VALU instructions each, several
+// per thread) and cannot unroll their per-candidate loops, so every candidate's two dependent loads are a round trip of
+// their own.  GEO 0 = any geometry (runtime), 1 = 3x3x3 stride 2 dilation 1, 2 = (3,1,1) stride (2,1,1) dilation 1.
+template <int GEO> struct Geo { static constexpr bool fixed = false; static constexpr int NCAND = 32, KVOL = 0; };
+template <> struct Geo<1> { static constexpr bool fixed = true; static constexpr int NCAND = 8, KVOL = 27, C1 = 2, C2 = 2, K1 = 3, K2 = 3; };
+template <> struct Geo<2> { static constexpr bool fixed = true; static constexpr int NCAND = 2, KVOL = 3, C1 = 1, C2 = 1, K1 = 1, K2 = 1; };
+static int geo_of(const RbGeom &g) {
+    bool d1 = g.dil[0] == 1 && g.dil[1] == 1 && g.dil[2] == 1;
+    if (d1 && g.ksize[0] == 3 && g.ksize[1] == 3 && g.ksize[2] == 3 && g.stride[0] == 2 && g.stride[1] == 2 && g.stride[2] == 2) return 1;
+    if (d1 && g.ksize[0] == 3 && g.ksize[1] == 1 && g.ksize[2] == 1 && g.stride[0] == 2 && g.stride[1] == 1 && g.stride[2] == 1) return 2;
+    return 0;
+}
+// c-th kernel offset of one dimension through which input coordinate `in` reaches an output (same enumeration order as
+// cand_offset): kernel 3 / stride 2: parity even -> k in {0, 2}, odd -> k = 1; kernel 1 / stride 1: k = 0.
+template <int KS, int ST>
+__device__ __forceinline__ bool cand_offset_fixed(int in, int pad, int out_dim, int c, int *k_out, int *o_out) {
+    if (KS == 1 && ST == 1) { *k_out = 0; *o_out = in + pad; return c == 0 && in + pad >= 0 && in + pad < out_dim; }
+    const int v = in + pad;
+    const int k = (v & 1) ? 1 : 2 * c;
+    if ((v & 1) && c > 0) return false;
+    const int num = v - k;
+    *k_out = k;
+    *o_out = num >> 1;
+    return num >= 0 && (num >> 1) < out_dim;
+}
+
+template <int GEO>
 __global__ __launch_bounds__(kBlock) void k_conv_cand(const int *__restrict__ indices, RbGeom g,
                                                      const int *__restrict__ n_dev,
                                                      unsigned long long *__restrict__ keys,
                                                      int *__restrict__ vals, int *__restrict__ cand_slot,
                                                      unsigned char *__restrict__ cand_k, int *__restrict__ overflow) {
+    using G = Geo<GEO>;
+    const int ncand = G::fixed ? G::NCAND : g.ncand;
     long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
-    if (t >= (long long)g.n_in * g.ncand) return;
-    int j = (int)(t / g.ncand), c = (int)(t % g.ncand);
+    if (t >= (long long)g.n_in * ncand) return;
+    int j = (int)(t / ncand), c = (int)(t % ncand);
     if (j >= live_rows(g, n_dev)) { cand_slot[t] = -1; return; }
-    int cc[3] = {c / (g.cand[2] * g.cand[1]), (c / g.cand[2]) % g.cand[1], c % g.cand[2]};
     int4 q = *reinterpret_cast<const int4 *>(indices + (size_t)j * 4);
     int in[3] = {q.y, q.z, q.w}, out[3], kk[3];
     bool ok = true;
+    int k = 0;
+    if constexpr (G::fixed) {
+        const int c0 = c / (G::C1 * G::C2), c1 = (c / G::C2) % G::C1, c2 = c % G::C2;
+        ok &= cand_offset_fixed<3, 2>(in[0], g.pad[0], g.out_shape[0], c0, &kk[0], &out[0]);
+        ok &= cand_offset_fixed<G::K1, G::K1 == 3 ? 2 : 1>(in[1], g.pad[1], g.out_shape[1], c1, &kk[1], &out[1]);
+        ok &= cand_offset_fixed<G::K2, G::K2 == 3 ? 2 : 1>(in[2], g.pad[2], g.out_shape[2], c2, &kk[2], &out[2]);
+        k = (kk[0] * G::K1 + kk[1]) * G::K2 + kk[2];
+    } else {
+        int cc[3] = {c / (g.cand[2] * g.cand[1]), (c / g.cand[2]) % g.cand[1], c % g.cand[2]};
 #pragma unroll
-    for (int d = 0; d < 3; ++d) ok &= cand_offset(g, d, in[d], cc[d], &kk[d], &out[d]);
+        for (int d = 0; d < 3; ++d) ok &= cand_offset(g, d, in[d], cc[d], &kk[d], &out[d]);
+        k = (kk[0] * g.ksize[1] + kk[1]) * g.ksize[2] + kk[2];
+    }
     int s = -1;
     if (ok) {
-        int k = (kk[0] * g.ksize[1] + kk[1]) * g.ksize[2] + kk[2];
         s = hash_insert_bounded(keys, g.mask, cell_key(q.x, out[0], out[1], out[2], g.out_shape));
         if (s >= 0) atomicMin(&vals[s], j * g.kvol + k);  // token = position in the sequential reference loop (a peek before
                                                           // this non-returning atomic was measured: no gain)
@@ -199,6 +241,7 @@ __global__ __launch_bounds__(kBlock) void k_conv_count_scan(const int *__restric
 // the lower mask bits, out_indices[rank] = the cell decoded from the hash key.  The same launch pre-fills the gather
 // tables with -1 when the caller already has them (static-capacity pipelines), so a strided build is
 // init -> candidates -> this kernel -> tables: four launches instead of eight.
+template <int GEO>
 __global__ __launch_bounds__(kBlock) void k_conv_count_scan_assign(const int *__restrict__ cand_slot,
                                                                   const unsigned char *__restrict__ cand_k,
                                                                   const int *__restrict__ vals,
@@ -216,18 +259,36 @@ __global__ __launch_bounds__(kBlock) void k_conv_count_scan_assign(const int *__
         for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < fill_a_words; i += stride) fill_a[i] = -1;
         for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < fill_b_words; i += stride) fill_b[i] = -1;
     }
+    using G = Geo<GEO>;
     const int tile = scan_take_tile(ticket, &s_tile);
     const int j = tile * kBlock + threadIdx.x;
-    const int n_in = g.n_in, ncand = g.ncand;
+    const int n_in = g.n_in, ncand = G::fixed ? G::NCAND : g.ncand;
     int cnt = 0;
     unsigned m = 0;
     if (j < n_in) {
-        for (int c = 0; c < ncand; ++c) {
-            const size_t t = (size_t)j * ncand + c;
-            const int s = cand_slot[t];
-            const bool f = s >= 0 && vals[s] == j * g.kvol + (int)cand_k[t];
-            cnt += f ? 1 : 0;
-            if (f) m |= 1u << c;
+        if constexpr (G::fixed) {   // all candidate slots, then all their tokens: two load rounds instead of 2 x NCAND dependent ones
+            int sl[G::NCAND], tk[G::NCAND], kk[G::NCAND];
+#pragma unroll
+            for (int c = 0; c < G::NCAND; ++c) {
+                sl[c] = cand_slot[(size_t)j * G::NCAND + c];
+                kk[c] = sl[c] >= 0 ? (int)cand_k[(size_t)j * G::NCAND + c] : 0;
+            }
+#pragma unroll
+            for (int c = 0; c < G::NCAND; ++c) tk[c] = sl[c] >= 0 ? vals[sl[c]] : -1;
+#pragma unroll
+            for (int c = 0; c < G::NCAND; ++c) {
+                const bool f = sl[c] >= 0 && tk[c] == j * G::KVOL + kk[c];
+                cnt += f ? 1 : 0;
+                if (f) m |= 1u << c;
+            }
+        } else {
+            for (int c = 0; c < ncand; ++c) {
+                const size_t t = (size_t)j * ncand + c;
+                const int s = cand_slot[t];
+                const bool f = s >= 0 && vals[s] == j * g.kvol + (int)cand_k[t];
+                cnt += f ? 1 : 0;
+                if (f) m |= 1u << c;
+            }
         }
     }
     int r = scan_lookback(cnt, tile, (int)gridDim.x, status, smem, num_out);
@@ -310,11 +371,14 @@ __global__ __launch_bounds__(kBlock) void k_conv_assign(const int *__restrict__ 
 }
 
 // nbr_out[o][k] = j (pre-filled with -1); nbr_in[j][k] = o only when requested (backward / pair lists; pre-filled too)
+template <int GEO>
 __global__ __launch_bounds__(kBlock) void k_conv_tables(const int *__restrict__ cand_slot,
                                                        const unsigned char *__restrict__ cand_k,
                                                        const int *__restrict__ orank, long long n, int kvol, int ncand,
                                                        int *__restrict__ nbr_in, int *__restrict__ nbr_out,
                                                        int nbr_out_rows) {
+    using G = Geo<GEO>;
+    if (G::fixed) { kvol = G::KVOL; ncand = G::NCAND; }
     long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (t >= n) return;
     int s = cand_slot[t];
@@ -491,7 +555,10 @@ SEC_API int sec_rulebook_subm3d(const int *indices, int n_in, const int *n_in_de
     rb_init(w.keys, w.table, kEmptyKey, nbr_out, nk, -1, nullptr, 0, 0, st);
     hipLaunchKernelGGL(k_rb_hash_rows, dim3(div_up(n_in, kBlock)), dim3(kBlock), 0, st, indices, g, n_in_dev, w.keys, w.vals);
     long long nh = (long long)n_in * (g.kvol / 2 + 1);
-    hipLaunchKernelGGL(k_subm_nbr_sym, dim3(div_up(nh, kBlock)), dim3(kBlock), 0, st, indices, g, n_in_dev, w.keys, w.vals, nbr_out);
+    if (g.kvol == 27 && g.ksize[0] == 3 && g.ksize[1] == 3)
+        hipLaunchKernelGGL(k_subm_nbr_sym<true>, dim3(div_up(nh, kBlock)), dim3(kBlock), 0, st, indices, g, n_in_dev, w.keys, w.vals, nbr_out);
+    else
+        hipLaunchKernelGGL(k_subm_nbr_sym<false>, dim3(div_up(nh, kBlock)), dim3(kBlock), 0, st, indices, g, n_in_dev, w.keys, w.vals, nbr_out);
     if ((rc = check_launch())) return rc;
     if (pairs) return emit_pairs(nbr_out, n_in, g.kvol, /*mirror=*/1, w.blk, w.scan2, pairs, pair_num, st);
     return SEC_OK;
@@ -521,7 +588,10 @@ SEC_API int sec_rulebook_subm3d_after_conv(const int *indices, int n_in, const i
     rb_init(nullptr, 0, 0, nbr_out, (long long)n_in * g.kvol, -1, nullptr, 0, 0, st);
     long long nh = (long long)n_in * (g.kvol / 2 + 1);
     // the strided build's table maps output cell -> slot and orank[slot] = output row: exactly this layer's site lookup
-    hipLaunchKernelGGL(k_subm_nbr_sym, dim3(div_up(nh, kBlock)), dim3(kBlock), 0, st, indices, g, n_in_dev, w.keys, w.orank, nbr_out);
+    if (g.kvol == 27 && g.ksize[0] == 3 && g.ksize[1] == 3)
+        hipLaunchKernelGGL(k_subm_nbr_sym<true>, dim3(div_up(nh, kBlock)), dim3(kBlock), 0, st, indices, g, n_in_dev, w.keys, w.orank, nbr_out);
+    else
+        hipLaunchKernelGGL(k_subm_nbr_sym<false>, dim3(div_up(nh, kBlock)), dim3(kBlock), 0, st, indices, g, n_in_dev, w.keys, w.orank, nbr_out);
     return check_launch();
 }
 
@@ -553,14 +623,22 @@ SEC_API int sec_rulebook_conv3d_build(const int *indices, int n_in, const int *n
     }
     rb_init(w.keys, w.table, kEmptyKey, w.vals, w.table, kEmptyI32, w.ticket, w.ctl_words, 0, st);
     int nb = div_up(nc, kBlock);
-    hipLaunchKernelGGL(k_conv_cand, dim3(nb), dim3(kBlock), 0, st, indices, g, n_in_dev, w.keys, w.vals, w.cand_slot,
-                       w.cand_k, w.overflow);
-    if (g.ncand <= 32) {
-        hipLaunchKernelGGL(k_conv_count_scan_assign, dim3(div_up(n_in, kBlock)), dim3(kBlock), 0, st, w.cand_slot, w.cand_k, w.vals,
-                           w.keys, g, w.orank, out_indices, out_cap, w.status, w.ticket, num_out, w.overflow, prefill_nbr_out,
-                           fill_a, prefill_nbr_in, fill_b);
-        return check_launch();
-    }
+    const int geo = geo_of(g);
+#define SEC_RB_BUILD(GEO)                                                                                                         \
+    do {                                                                                                                          \
+        hipLaunchKernelGGL(k_conv_cand<GEO>, dim3(nb), dim3(kBlock), 0, st, indices, g, n_in_dev, w.keys, w.vals, w.cand_slot,    \
+                           w.cand_k, w.overflow);                                                                                \
+        if (g.ncand <= 32) {                                                                                                      \
+            hipLaunchKernelGGL(k_conv_count_scan_assign<GEO>, dim3(div_up(n_in, kBlock)), dim3(kBlock), 0, st, w.cand_slot,       \
+                               w.cand_k, w.vals, w.keys, g, w.orank, out_indices, out_cap, w.status, w.ticket, num_out,           \
+                               w.overflow, prefill_nbr_out, fill_a, prefill_nbr_in, fill_b);                                      \
+            return check_launch();                                                                                                \
+        }                                                                                                                         \
+    } while (0)
+    if (geo == 1) SEC_RB_BUILD(1);
+    else if (geo == 2) SEC_RB_BUILD(2);
+    else SEC_RB_BUILD(0);
+#undef SEC_RB_BUILD
     if (fill_a + fill_b > 0) rb_init(nullptr, 0, 0, prefill_nbr_out, fill_a, -1, prefill_nbr_in, fill_b, -1, st);
     hipLaunchKernelGGL(k_conv_count_scan, dim3(div_up(n_in, kBlock)), dim3(kBlock), 0, st, w.cand_slot, w.cand_k, w.vals, n_in,
                        g.kvol, g.ncand, w.rank, w.first_mask, w.status, w.ticket, num_out);
@@ -589,8 +667,16 @@ SEC_API int sec_rulebook_conv3d_tables(int n_in, const int *h_ksize3, const int 
         rb_init(nullptr, 0, 0, nbr_out, n_out_words, -1, nbr_in, n_in_words, -1, st);
     long long nc = (long long)n_in * g.ncand;
     if (nc > 0) {
-        hipLaunchKernelGGL(k_conv_tables, dim3(div_up(nc, kBlock)), dim3(kBlock), 0, st, w.cand_slot, w.cand_k, w.orank, nc,
-                           kvol, g.ncand, nbr_in, nbr_out, nbr_out_rows);
+        const int geo = geo_of(g);
+        if (geo == 1)
+            hipLaunchKernelGGL(k_conv_tables<1>, dim3(div_up(nc, kBlock)), dim3(kBlock), 0, st, w.cand_slot, w.cand_k, w.orank, nc,
+                               kvol, g.ncand, nbr_in, nbr_out, nbr_out_rows);
+        else if (geo == 2)
+            hipLaunchKernelGGL(k_conv_tables<2>, dim3(div_up(nc, kBlock)), dim3(kBlock), 0, st, w.cand_slot, w.cand_k, w.orank, nc,
+                               kvol, g.ncand, nbr_in, nbr_out, nbr_out_rows);
+        else
+            hipLaunchKernelGGL(k_conv_tables<0>, dim3(div_up(nc, kBlock)), dim3(kBlock), 0, st, w.cand_slot, w.cand_k, w.orank, nc,
+                               kvol, g.ncand, nbr_in, nbr_out, nbr_out_rows);
         if ((rc = check_launch())) return rc;
     }
     if (pairs) return emit_pairs(nbr_in, n_in, kvol, /*mirror=*/0, w.blk, w.scan2, pairs, pair_num, st);

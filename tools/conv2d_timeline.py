@@ -34,7 +34,7 @@ for batch in [int(v) for v in os.environ.get("BATCHES", "1,2,3,4,6,8,16").split(
     flop = 2.0 * batch * 200 * 176 * 128 * 128 * 9
     print(f"batch {batch:2d}: {tiles:5d} tiles = {tiles / 768:5.2f} rounds of 768  {t:7.2f} us  {flop / t / 1e6:6.0f} TFLOP/s  stagger={os.environ.get('SEC_CONV2D_STAGGER', '0')}", flush=True)
     if batch == 8 and hasattr(rt.lib(), "sec__debug_timeline2"):
-        buf = torch.zeros((tiles + 8, 4), dtype=torch.int64, device="cuda")
+        buf = torch.zeros((tiles + 8, 8), dtype=torch.int64, device="cuda")
         rt.lib().sec__debug_timeline2(ctypes.c_void_p(buf.data_ptr()))
         ops.conv2d_nhwc(x, pk, b, 128, 3, 1, 1, relu=True)
         torch.cuda.synchronize()
@@ -49,6 +49,29 @@ for batch in [int(v) for v in os.environ.get("BATCHES", "1,2,3,4,6,8,16").split(
                           ("workgroup life", tt[:, 3] - tt[:, 0])):
             q = np.percentile(col, [5, 50, 95])
             print(f"    {name:22s} p5={q[0]:8.0f} p50={q[1]:8.0f} p95={q[2]:8.0f} clocks")
+        # real time (s_memrealtime, 100 MHz): shader clock during the kernel and how full the 3 resident slots per CU are
+        w0, w1 = tt[:, 4], tt[:, 5]
+        span = (w1.max() - w0.min()) * 10e-9
+        ghz = (tt[:, 3] - tt[:, 0]) / ((w1 - w0) * 10.0)
+        q = np.percentile(ghz, [5, 50, 95])
+        ncu = len(np.unique(raw[:, 6]))
+        print(f"    kernel span {span * 1e6:.1f} us over {ncu} CUs; shader clock per workgroup life p5={q[0]:.2f} p50={q[1]:.2f} p95={q[2]:.2f} GHz")
+        print(f"    resident-slot utilisation = sum(lives) / (3 slots x {ncu} CUs x span) = {((w1 - w0).sum() * 10e-9) / (3 * ncu * span):.3f}")
+        per_cu = {}
+        for k, a, b_ in zip(raw[:, 6], w0, w1):
+            per_cu.setdefault(int(k), []).append((a, b_))
+        gaps = []
+        for k, iv in per_cu.items():
+            iv.sort()
+            ends = sorted(b_ for _, b_ in iv)
+            # the i-th start beyond the first three follows the (i-3)-th end on this CU
+            for i in range(3, len(iv)):
+                gaps.append((iv[i][0] - ends[i - 3]) * 10.0)
+        if gaps:
+            q = np.percentile(gaps, [5, 50, 95])
+            print(f"    slot turnaround (end of a workgroup -> start of its successor on the CU) p5={q[0]:.0f} p50={q[1]:.0f} p95={q[2]:.0f} ns")
+        first = np.array([min(a for a, _ in iv) for iv in per_cu.values()]); last = np.array([max(b_ for _, b_ in iv) for iv in per_cu.values()])
+        print(f"    first start per CU spread {(first.max() - first.min()) * 10:.0f} ns; last end per CU: p5={np.percentile(last - w0.min(), 5) * 10e-3:.1f} p50={np.percentile(last - w0.min(), 50) * 10e-3:.1f} max={(last.max() - w0.min()) * 10e-3:.1f} us")
         # start times per XCD (blockIdx % 8), relative to the XCD's first workgroup: the rounds
         for xcd in (0, 3):
             sel = np.arange(len(buf))[:len(tt)] % 8 == xcd
