@@ -230,6 +230,12 @@ WORKLOADS["car.fhd.train"] = dict(cfg="CAR_FHD", batch=4, metric="samples/sec Vo
                                        "smooth-L1 / direction loss, backward, one flat-bucket gradient all-reduce, clip, AdamW), "
                                        "batch=4 synthetic KITTI clouds/GPU (17000 pts, 16000 voxels, 12 ground-truth boxes each), "
                                        "random-init weights, inputs resident in HBM")
+WORKLOADS["nusc.fhd.train"] = dict(cfg="ALL_FHD_NUSC", batch=3, points=300000, dtype="fp16",
+                                   metric="samples/sec VoxelNet training step (nuscenes/all.fhd, batch 3/GPU)",
+                                   desc="nuscenes/all.fhd.config training step (BASELINE config 5: ten classes, per-class target "
+                                        "assignment, fp16 features over fp32 master weights, DDP), batch=3 synthetic 10-sweep clouds/GPU "
+                                        "(~300k pts each, 24 ground-truth boxes over the ten classes), random-init weights, inputs "
+                                        "resident in HBM")
 WL = WORKLOADS["car.fhd"]
 
 
@@ -241,15 +247,34 @@ def train_bench(args, rank, local_rank, world, device):
     from second_amd import synthetic as syn
     from second_amd.models import SecondDetector, CAR_FHD
     from second_amd.training import DeviceTrainer
+    from second_amd import models as M
     bs = WL["batch"]
-    clouds = [syn.syn_kitti_cloud(rank * bs + s) for s in range(bs)]
-    boxes = [syn.syn_kitti_boxes(rank * bs + s, 12) for s in range(bs)]
+    cfg = getattr(M, WL["cfg"])
+    gcls = None
+    if WL["cfg"] == "CAR_FHD":
+        clouds = [syn.syn_kitti_cloud(rank * bs + s) for s in range(bs)]
+        boxes = [syn.syn_kitti_boxes(rank * bs + s, 12) for s in range(bs)]
+    else:
+        # ten-class ground truth: class-sized boxes (the class's anchor size, scaled a little) at random places and headings
+        r = cfg["point_cloud_range"]
+        clouds = [syn.syn_nusc_cloud(rank * bs + s, num_points=WL["points"], point_cloud_range=tuple(r)) for s in range(bs)]
+        boxes, classes = [], []
+        for s in range(bs):
+            g = np.random.default_rng(1000 + rank * bs + s)
+            k = 24
+            cls = g.integers(1, cfg["num_class"] + 1, k)
+            size = np.array([cfg["anchor_sizes"][cfg["anchor_groups"][c - 1][0]] for c in cls], np.float32) * g.uniform(0.9, 1.1, (k, 3))
+            z = np.array([cfg["anchor_ranges"][cfg["anchor_groups"][c - 1][0]][2] for c in cls], np.float32)
+            xy = g.uniform(r[0] + 5, r[3] - 5, (k, 2))
+            boxes.append(np.concatenate([xy, z[:, None], size, g.uniform(-np.pi, np.pi, (k, 1))], 1).astype(np.float32))
+            classes.append(cls.astype(np.int32))
+        gcls = torch.from_numpy(np.concatenate(classes)).to(device)
     pts, offs = syn.batch_clouds(clouds)
     gt = np.concatenate(boxes).astype(np.float32)
     goffs = np.cumsum([0] + [len(b) for b in boxes]).astype(np.int32)
     pts, offs, gt, goffs = (torch.from_numpy(a).to(device) for a in (pts, offs, gt, goffs))
     torch.manual_seed(0)
-    det = SecondDetector(CAR_FHD).to(device)
+    det = SecondDetector(cfg).to(device)
     amp = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": None}[args.dtype]
     tr = DeviceTrainer(det, amp_dtype=amp)
 
@@ -258,11 +283,11 @@ def train_bench(args, rank, local_rank, world, device):
             dist.barrier()
         torch.cuda.synchronize()
     for _ in range(args.warmup):
-        tr.step(pts, offs, gt, goffs)
+        tr.step(pts, offs, gt, goffs, gcls)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out6 = tr.step(pts, offs, gt, goffs)
+        out6 = tr.step(pts, offs, gt, goffs, gcls)
     barrier()
     elapsed = time.perf_counter() - t0
     # the gradient all-reduce alone (the only collective of the step): 20 back-to-back reductions of the live bucket
@@ -285,7 +310,8 @@ def train_bench(args, rank, local_rank, world, device):
                "dtype": "fp32" if amp is None else f"{args.dtype} features (sparse stack + RPN autocast) over fp32 master weights", "data": "synthetic",
                "config": {"workload": WL["desc"], "samples_per_step_per_gpu": bs, "parallelism": f"ddp{world}",
                           "gradient_bucket_bytes": tr.bucket.numel * 4, "allreduce_us": round(ar_us, 1),
-                          "optimizer": "AdamW (adam + fixed weight decay 0.01, car.fhd.config:180-188)"},
+                          "optimizer": "AdamW (adam + fixed weight decay 0.01, car.fhd.config:180-188)",
+                          "target_assignment": "per anchor range" if tr.class_ranges else "single class"},
                "roofline": None, "cpu_baseline": None, "loss_last_step": {k: round(v, 5) for k, v in losses.items()}}
         print(json.dumps(res), flush=True)
     if world > 1:
@@ -414,9 +440,9 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.dtype]
 
-    if args.workload == "car.fhd.train":
-        if args.dtype == "bf16" and "--dtype" not in " ".join(sys.argv):
-            args.dtype = "fp32"                     # training default: the reference's precision
+    if args.workload.endswith(".train"):
+        if args.workload == "car.fhd.train" and args.dtype == "bf16" and "--dtype" not in " ".join(sys.argv):
+            args.dtype = "fp32"                     # training default: the reference's precision (config 5 names fp16)
         return train_bench(args, rank, local_rank, world, device)
     from second_amd import ops
     clouds, points, offsets = build_inputs(rank, device, args.point_order)

@@ -302,6 +302,18 @@ int sec_assign_targets_f32(const float *anchors, int n_anchor, const float *gt_b
                            const float *gt_importance, const int *gt_offsets, int n_gt, int batch,
                            float matched_threshold, float unmatched_threshold, int *labels, float *bbox_targets,
                            float *importance, void *workspace, size_t workspace_bytes, void *stream);
+/* Anchor ranges with their own thresholds.  Range c = anchors [h_class_anchor_begin[c], h_class_anchor_begin[c+1]) (the
+ * reference concatenates the anchor generators class-major, target_assigner.py:169-207), thresholds h_matched[c] /
+ * h_unmatched[c].  h_class_ids[c] = k > 0: TargetAssigner.assign_per_class (target_assigner.py:90-160; all.fhd.config:295) --
+ * the range is matched against the ground truth of class k only, a frame without such a box labels the range background, and
+ * gt_importance is indexed the way the reference does (position within the class's boxes, applied to the frame's array).
+ * h_class_ids[c] = 0: TargetAssigner.assign_all with per-anchor threshold arrays (target_assigner.py:53-88;
+ * all.pp.largea.config:269) -- every ground truth, best overlap per ground truth taken over all ranges. */
+int sec_assign_targets_per_class_f32(const float *anchors, int n_anchor, const float *gt_boxes, const int *gt_classes,
+                                     const float *gt_importance, const int *gt_offsets, int n_gt, int batch, int n_class,
+                                     const int *h_class_anchor_begin, const int *h_class_ids, const float *h_matched,
+                                     const float *h_unmatched, int *labels, float *bbox_targets, float *importance,
+                                     void *workspace, size_t workspace_bytes, void *stream);
 size_t sec_second_loss_workspace_bytes(int batch, int n_anchor);
 int sec_second_loss_f32(const float *cls_preds, const float *box_preds, const float *dir_preds, const int *labels,
                         const float *reg_targets, const float *anchors, const float *importance, int batch,

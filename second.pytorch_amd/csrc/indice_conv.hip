@@ -617,9 +617,11 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_conv_rows_buf(const T *__r
         const long long tile_row0 = (long long)blockIdx.x * (32 * WAVES) + w * 32;
         const long long tbl_bytes = (long long)n_cap * KVOL * 4;
         const int *tile = nbr + tile_row0 * KVOL;
-        const long long left = tbl_bytes - tile_row0 * KVOL * 4;      // bytes of the table from this tile on (> 0 here)
+        // bytes of the table from this tile on: <= 0 for the waves of the last workgroup that start beyond the table (a table
+        // of exactly n_out rows) -- an empty resource then, never a negative record count (= unbounded reads past the table)
+        const long long left = tbl_bytes - tile_row0 * KVOL * 4;
         const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<int *>(tile), 0, (int)(left < 32 * KVOL * 4 ? left : 32 * KVOL * 4), 0x00020000);
+            const_cast<int *>(left > 0 ? tile : nbr), 0, (int)(left <= 0 ? 0 : (left < 32 * KVOL * 4 ? left : 32 * KVOL * 4)), 0x00020000);
 #pragma unroll
         for (int i = 0; i < (TBL16 + 63) / 64; ++i) {
             const int p16 = i * 64 + lane;

@@ -45,13 +45,23 @@ __device__ __forceinline__ float iou_eps0(const float4 a, const float4 q) {
 
 // pass 1: per (frame, anchor) best ground truth (first index on ties, like np.argmax) and, per ground truth, the best overlap
 // over all anchors (atomicMax on the float bits: overlaps are >= 0, so integer order == float order)
+//
+// assign_per_class (target_assigner.py:90-160): one launch pair per class handles the class's anchor range
+// [a_begin, a_end) against the ground truth of that class only (`filter` = its 1-based id, 0 = every ground truth); boxes of
+// other classes are skipped, and a frame without a box of the class labels the whole range background (len(gt_boxes) == 0).
+struct AssignRange { int a_begin, a_end, filter; };
+
 __global__ __launch_bounds__(kBlock) void k_assign_max(const float *__restrict__ anchors, int n_anchor,
-                                                      const float *__restrict__ gt, const int *__restrict__ gt_offsets,
+                                                      const float *__restrict__ gt, const int *__restrict__ gt_classes,
+                                                      const int *__restrict__ gt_offsets, AssignRange R,
                                                       float *__restrict__ a_max, int *__restrict__ a_arg,
                                                       int *__restrict__ gt_max_bits) {
     __shared__ float4 s_gt[kMaxGtLds];
-    const int b = blockIdx.y, a = blockIdx.x * kBlock + threadIdx.x;
+    __shared__ unsigned char s_on[kMaxGtLds];
+    const int b = blockIdx.y, a = R.a_begin + blockIdx.x * kBlock + threadIdx.x;
     const int g0 = gt_offsets[b], g1 = gt_offsets[b + 1];
+    const int n_total = n_anchor;            // row pitch of the per-(frame, anchor) arrays
+    n_anchor = min(n_anchor, R.a_end);       // below: a < n_anchor == this launch owns the anchor
     float4 abv = make_float4(0, 0, 0, 0);
     if (a < n_anchor) {
         const float *p = anchors + (size_t)a * 7;
@@ -65,10 +75,12 @@ __global__ __launch_bounds__(kBlock) void k_assign_max(const float *__restrict__
         for (int i = threadIdx.x; i < cn; i += kBlock) {
             const float *q = gt + (size_t)(c0 + i) * 7;
             s_gt[i] = near_bbox(q[0], q[1], q[3], q[4], q[6]);
+            s_on[i] = (R.filter == 0 || (gt_classes ? gt_classes[c0 + i] : 1) == R.filter) ? 1 : 0;
         }
         __syncthreads();
         if (a < n_anchor) {
             for (int i = 0; i < cn; ++i) {
+                if (!s_on[i]) continue;
                 const float v = iou_eps0(abv, s_gt[i]);
                 if (v > best) { best = v; arg = c0 + i - g0; }
                 if (v > 0.0f) atomicMax(&gt_max_bits[c0 + i], __float_as_int(v));
@@ -76,8 +88,8 @@ __global__ __launch_bounds__(kBlock) void k_assign_max(const float *__restrict__
         }
     }
     if (a < n_anchor) {
-        a_max[(size_t)b * n_anchor + a] = best;
-        a_arg[(size_t)b * n_anchor + a] = arg;
+        a_max[(size_t)b * n_total + a] = best;
+        a_arg[(size_t)b * n_total + a] = arg;
     }
 }
 
@@ -85,15 +97,19 @@ __global__ __launch_bounds__(kBlock) void k_assign_max(const float *__restrict__
 __global__ __launch_bounds__(kBlock) void k_assign_write(const float *__restrict__ anchors, int n_anchor,
                                                         const float *__restrict__ gt, const int *__restrict__ gt_classes,
                                                         const float *__restrict__ gt_importance,
-                                                        const int *__restrict__ gt_offsets, const float *__restrict__ a_max,
+                                                        const int *__restrict__ gt_offsets, AssignRange R,
+                                                        const float *__restrict__ a_max,
                                                         const int *__restrict__ a_arg, const int *__restrict__ gt_max_bits,
                                                         float matched, float unmatched, int *__restrict__ labels,
                                                         float *__restrict__ targets, float *__restrict__ importance) {
     __shared__ float4 s_gt[kMaxGtLds];
     __shared__ float s_gmax[kMaxGtLds];
-    const int b = blockIdx.y, a = blockIdx.x * kBlock + threadIdx.x;
+    __shared__ int s_any;
+    const int b = blockIdx.y, a = R.a_begin + blockIdx.x * kBlock + threadIdx.x;
     const int g0 = gt_offsets[b], g1 = gt_offsets[b + 1];
     const size_t o = (size_t)b * n_anchor + a;
+    n_anchor = min(n_anchor, R.a_end);
+    if (threadIdx.x == 0) s_any = 0;
     float4 abv = make_float4(0, 0, 0, 0);
     const float *p = anchors + (size_t)(a < n_anchor ? a : 0) * 7;
     if (a < n_anchor) abv = near_bbox(p[0], p[1], p[3], p[4], p[6]);
@@ -105,23 +121,36 @@ __global__ __launch_bounds__(kBlock) void k_assign_write(const float *__restrict
             const float *q = gt + (size_t)(c0 + i) * 7;
             s_gt[i] = near_bbox(q[0], q[1], q[3], q[4], q[6]);
             const float m = __int_as_float(gt_max_bits[c0 + i]);
-            s_gmax[i] = m == 0.0f ? -1.0f : m;       // a ground truth no anchor overlaps matches nothing
+            const bool on = R.filter == 0 || (gt_classes ? gt_classes[c0 + i] : 1) == R.filter;
+            // a ground truth no anchor overlaps matches nothing (-1); one of another class can never be matched (-2: an IoU is >= 0)
+            s_gmax[i] = !on ? -2.0f : (m == 0.0f ? -1.0f : m);
+            if (on) s_any = 1;
         }
         __syncthreads();
         if (a < n_anchor)
             for (int i = 0; i < cn; ++i) force |= iou_eps0(abv, s_gt[i]) == s_gmax[i];
     }
+    __syncthreads();
     if (a >= n_anchor) return;
     int label = -1;
     float imp = 1.0f;
     float t[7] = {0, 0, 0, 0, 0, 0, 0};
-    if (g1 > g0) {
+    if (s_any) {
         const float best = a_max[o];
         const int arg = a_arg[o];
         const bool pos = best >= matched;
         if (best < unmatched) label = 0;
         if (force || pos) label = gt_classes ? gt_classes[g0 + arg] : 1;
-        if (pos && gt_importance) imp = gt_importance[g0 + arg];
+        if (pos && gt_importance) {
+            // create_target_np reads gt_importance[index within the ground truth it was GIVEN]; assign_per_class hands it the
+            // class's boxes but the frame's whole importance array (target_assigner.py:141): reproduce that indexing
+            int local = arg;
+            if (R.filter != 0 && gt_classes) {
+                local = 0;
+                for (int i = 0; i < arg; ++i) local += gt_classes[g0 + i] == R.filter ? 1 : 0;
+            }
+            imp = gt_importance[g0 + local];
+        }
         if (label > 0) {   // second_box_encode(gt[arg], anchor)
             const float *q = gt + (size_t)(g0 + arg) * 7;
             const float diag = sqrtf(__fadd_rn(__fmul_rn(p[4], p[4]), __fmul_rn(p[3], p[3])));
@@ -213,7 +242,9 @@ __global__ __launch_bounds__(kBlock) void k_loss_main(const float *__restrict__ 
             const float at = t * P.alpha + (1.0f - t) * (1.0f - P.alpha);
             const float l = mod * at * ce * wcls;
             s_cls += l;
+            // _get_pos_neg_loss (voxelnet.py:20-34): one class -> by label; several -> columns 1.. vs column 0 of the loss
             if (P.num_class == 1) { s_pos += pos ? l : 0.0f; s_neg += neg ? l : 0.0f; }
+            else { s_pos += c > 0 ? l : 0.0f; s_neg += c == 0 ? l : 0.0f; }
             // d/dx: at * w * [ dmod/dx * ce + mod * (p - t) ],  dmod/dx = -gamma * om^(gamma-1) * dpt/dx,  dpt/dx = (2t-1) p (1-p)
             const float dpt = (2.0f * t - 1.0f) * p * (1.0f - p);
             const float dmod = P.gamma == 2.0f ? -2.0f * om * dpt : (P.gamma == 0.0f ? 0.0f : -P.gamma * powf(om, P.gamma - 1.0f) * dpt);
@@ -331,9 +362,51 @@ SEC_API int sec_assign_targets_f32(const float *anchors, int n_anchor, const flo
     int rc;
     if ((rc = hip_ok(hipMemsetAsync(gt_max, 0, (size_t)(n_gt > 0 ? n_gt : 1) * sizeof(int), st)))) return rc;
     dim3 grid(div_up(n_anchor, kBlock), batch);
-    hipLaunchKernelGGL(k_assign_max, grid, dim3(kBlock), 0, st, anchors, n_anchor, gt_boxes, gt_offsets, a_max, a_arg, gt_max);
+    const AssignRange all{0, n_anchor, 0};
+    hipLaunchKernelGGL(k_assign_max, grid, dim3(kBlock), 0, st, anchors, n_anchor, gt_boxes, gt_classes, gt_offsets, all, a_max,
+                       a_arg, gt_max);
     hipLaunchKernelGGL(k_assign_write, grid, dim3(kBlock), 0, st, anchors, n_anchor, gt_boxes, gt_classes, gt_importance,
-                       gt_offsets, a_max, a_arg, gt_max, matched_threshold, unmatched_threshold, labels, bbox_targets, importance);
+                       gt_offsets, all, a_max, a_arg, gt_max, matched_threshold, unmatched_threshold, labels, bbox_targets,
+                       importance);
+    return check_launch();
+}
+
+SEC_API int sec_assign_targets_per_class_f32(const float *anchors, int n_anchor, const float *gt_boxes, const int *gt_classes,
+                                             const float *gt_importance, const int *gt_offsets, int n_gt, int batch,
+                                             int n_class, const int *h_class_anchor_begin, const int *h_class_ids,
+                                             const float *h_matched, const float *h_unmatched, int *labels,
+                                             float *bbox_targets, float *importance, void *workspace, size_t workspace_bytes,
+                                             void *stream) {
+    if (n_anchor <= 0 || batch <= 0 || n_gt < 0 || n_class <= 0 || !anchors || !gt_offsets || !labels || !bbox_targets ||
+        !importance || !h_class_anchor_begin || !h_class_ids || !h_matched || !h_unmatched || (n_gt > 0 && (!gt_boxes || !gt_classes)))
+        return SEC_E_INVALID;
+    if (h_class_anchor_begin[0] != 0 || h_class_anchor_begin[n_class] != n_anchor) return SEC_E_INVALID;
+    for (int c = 0; c < n_class; ++c)
+        if (h_class_anchor_begin[c + 1] < h_class_anchor_begin[c] || h_class_ids[c] < 0) return SEC_E_INVALID;
+    if (!workspace || workspace_bytes < sec_assign_targets_workspace_bytes(batch, n_anchor, n_gt)) return SEC_E_WORKSPACE;
+    Arena ar(workspace, workspace_bytes);
+    float *a_max = ar.take<float>((size_t)batch * n_anchor);
+    int *a_arg = ar.take<int>((size_t)batch * n_anchor);
+    int *gt_max = ar.take<int>(n_gt > 0 ? n_gt : 1);
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    // one best-overlap word per ground truth.  assign_per_class: a box belongs to one class, so the ranges touch disjoint
+    // words; assign_all (class id 0 = every ground truth): the best overlap is taken over ALL anchors (target_ops.py:108-112),
+    // hence every range's first pass before any second pass.
+    if ((rc = hip_ok(hipMemsetAsync(gt_max, 0, (size_t)(n_gt > 0 ? n_gt : 1) * sizeof(int), st)))) return rc;
+    for (int pass = 0; pass < 2; ++pass)
+        for (int c = 0; c < n_class; ++c) {
+            const AssignRange R{h_class_anchor_begin[c], h_class_anchor_begin[c + 1], h_class_ids[c]};
+            if (R.a_end == R.a_begin) continue;
+            dim3 grid(div_up(R.a_end - R.a_begin, kBlock), batch);
+            if (pass == 0)
+                hipLaunchKernelGGL(k_assign_max, grid, dim3(kBlock), 0, st, anchors, n_anchor, gt_boxes, gt_classes, gt_offsets, R,
+                                   a_max, a_arg, gt_max);
+            else
+                hipLaunchKernelGGL(k_assign_write, grid, dim3(kBlock), 0, st, anchors, n_anchor, gt_boxes, gt_classes,
+                                   gt_importance, gt_offsets, R, a_max, a_arg, gt_max, h_matched[c], h_unmatched[c], labels,
+                                   bbox_targets, importance);
+        }
     return check_launch();
 }
 

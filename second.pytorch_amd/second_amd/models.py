@@ -33,6 +33,7 @@ CAR_FHD = dict(
              num_upsample_filters=[128], num_input_features=128),
     downsample_factor=8,
     anchor_sizes=[[1.6, 3.9, 1.56]], anchor_ranges=[[0, -40.0, -1.00, 70.4, 40.0, -1.00]], rotations=[0, 1.57],
+    matched_thresholds=[0.6], unmatched_thresholds=[0.45], assign_per_class=True,
     num_class=1, num_direction_bins=2, direction_offset=0.0, direction_limit_offset=1.0,
     nms_score_threshold=0.3, nms_pre_max_size=1000, nms_post_max_size=100, nms_iou_threshold=0.01,
     use_rotate_nms=True, post_center_range=[0, -40, -2.2, 70.4, 40, 0.8],
@@ -54,6 +55,9 @@ ALL_PP_LARGEA = dict(
                    [-50, -50, -0.08168083, 50, 50, -0.08168083], [-50, -50, 0.22228277, 50, 50, 0.22228277],
                    [-50, -50, 0.22228277, 50, 50, 0.22228277], [-50, -50, -0.37937912, 50, 50, -0.37937912]],
     anchor_groups=[[0], [1], [2], [3, 4], [5]],   # sizes belonging to one anchor generator (class)
+    # class ids (1-based position in class_settings) of the anchored classes; assign_all with per-anchor thresholds (:269)
+    group_class_ids=[1, 2, 3, 4, 5], matched_thresholds=[0.4, 0.5, 0.5, 0.5, 0.5],
+    unmatched_thresholds=[0.3, 0.35, 0.35, 0.35, 0.35], assign_per_class=False,
     rotations=[0, 1.57],
     num_class=10, num_direction_bins=2, direction_offset=0.78, direction_limit_offset=0.0,
     nms_score_threshold=0.05, nms_pre_max_size=1000, nms_post_max_size=300, nms_iou_threshold=0.5,
@@ -81,6 +85,8 @@ ALL_FHD_NUSC = dict(
                     0.22228277, 0.22228277, -0.37937912, -1.27247965)],
     anchor_groups=[[0], [1], [2], [3], [4], [5], [6], [7, 8], [9], [10]],
     rotations=[0, 1.57], group_rotations={5: [0], 6: [0]},   # pedestrian / traffic_cone: one rotation
+    group_class_ids=[1, 2, 3, 4, 5, 6, 7, 8, 9, 10], matched_thresholds=[0.4, 0.2, 0.5, 0.4, 0.2, 0.5, 0.5, 0.5, 0.5, 0.3],
+    unmatched_thresholds=[0.3, 0.15, 0.35, 0.3, 0.15, 0.35, 0.35, 0.35, 0.35, 0.2], assign_per_class=True,   # :85-295
     num_class=10, num_direction_bins=2, direction_offset=0.78, direction_limit_offset=0.0,
     nms_score_threshold=0.05, nms_pre_max_size=1000, nms_post_max_size=300, nms_iou_threshold=0.5,
     use_rotate_nms=False, post_center_range=[-59.6, -59.6, -10, 59.6, 59.6, 10],
@@ -91,6 +97,16 @@ def anchors_per_location(cfg):
     """target_assigner.num_anchors_per_location (target_assigner.py:249-254): sum over generators of sizes x rotations."""
     groups = cfg.get("anchor_groups") or [[i] for i in range(len(cfg["anchor_sizes"]))]
     return sum(len(g) * len(cfg.get("group_rotations", {}).get(gi, cfg["rotations"])) for gi, g in enumerate(groups))
+
+
+def anchor_class_ranges(cfg, feature_map_size):
+    """Start of every anchor generator's range in the class-major anchor array of generate_anchors (+ the total)."""
+    d, h, w = feature_map_size
+    groups = cfg.get("anchor_groups") or [[i] for i in range(len(cfg["anchor_sizes"]))]
+    begin = [0]
+    for gi, g in enumerate(groups):
+        begin.append(begin[-1] + len(g) * len(cfg.get("group_rotations", {}).get(gi, cfg["rotations"])) * d * h * w)
+    return begin
 
 
 def grid_size_of(cfg):

@@ -6,6 +6,7 @@ the reference interface its kernel replaces (see the header for file:line).
 import numpy as np
 import torch
 
+import ctypes
 import functools
 
 from . import runtime as rt
@@ -562,6 +563,38 @@ def assign_targets(anchors, gt_boxes, gt_offsets, matched_threshold, unmatched_t
                                   rt.ptr(gt_offsets), g, b, float(matched_threshold), float(unmatched_threshold), rt.ptr(labels),
                                   rt.ptr(targets), rt.ptr(importance), rt.ptr(ws), ws.numel(), rt.stream())
     rt.check(rc, "sec_assign_targets_f32")
+    return labels, targets, importance
+
+
+@_traced("assign_targets_per_class")
+def assign_targets_per_class(anchors, gt_boxes, gt_offsets, gt_classes, class_anchor_begin, class_ids, matched_thresholds,
+                             unmatched_thresholds, gt_importance=None):
+    """TargetAssigner.assign for multi-class configs, a whole batch on the device.  Range c of the class-major anchor array =
+    anchors[class_anchor_begin[c]:class_anchor_begin[c+1]] with its own thresholds; class_ids[c] = k > 0: assign_per_class
+    (target_assigner.py:90-160, only ground truth of class k); class_ids[c] = 0: assign_all with per-anchor thresholds
+    (target_assigner.py:53-88).  Same outputs as assign_targets."""
+    rt.require_gpu(anchors, gt_boxes, gt_offsets)
+    assert anchors.dtype == torch.float32 and anchors.is_contiguous() and anchors.shape[1] == 7
+    assert gt_offsets.dtype == torch.int32
+    gt_boxes = gt_boxes.float().contiguous()
+    a, b, g = anchors.shape[0], gt_offsets.numel() - 1, gt_boxes.shape[0]
+    n = len(class_ids)
+    assert len(class_anchor_begin) == n + 1 and len(matched_thresholds) == n and len(unmatched_thresholds) == n
+    assert gt_classes is not None and gt_classes.dtype == torch.int32 and gt_classes.numel() == g
+    dev = anchors.device
+    labels = torch.empty((b, a), dtype=torch.int32, device=dev)
+    targets = torch.empty((b, a, 7), dtype=torch.float32, device=dev)
+    importance = torch.empty((b, a), dtype=torch.float32, device=dev)
+    l = rt.lib()
+    ws = rt.workspace(l.sec_assign_targets_workspace_bytes(b, a, g), dev)
+    begin = (ctypes.c_int * (n + 1))(*[int(v) for v in class_anchor_begin])
+    ids = (ctypes.c_int * n)(*[int(v) for v in class_ids])
+    mt = (ctypes.c_float * n)(*[float(v) for v in matched_thresholds])
+    ut = (ctypes.c_float * n)(*[float(v) for v in unmatched_thresholds])
+    rc = l.sec_assign_targets_per_class_f32(rt.ptr(anchors), a, rt.ptr(gt_boxes) if g else None, rt.ptr(gt_classes),
+                                            rt.ptr(gt_importance), rt.ptr(gt_offsets), g, b, n, begin, ids, mt, ut, rt.ptr(labels),
+                                            rt.ptr(targets), rt.ptr(importance), rt.ptr(ws), ws.numel(), rt.stream())
+    rt.check(rc, "sec_assign_targets_per_class_f32")
     return labels, targets, importance
 
 

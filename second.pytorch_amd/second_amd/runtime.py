@@ -26,7 +26,8 @@ SYMBOLS = [
     "sec_voxel_block_filter_f32", "sec_bias_act_nhwc", "sec_conv2d_packed_weight_bytes",
     "sec_conv2d_pack_weight", "sec_conv2d_nhwc", "sec_conv1x1_chain_nhwc", "sec_rotate_iou_f32", "sec_nms_workspace_bytes", "sec_nms_sorted_f32",
     "sec_predict_select", "sec_predict_decode", "sec_predict_finalize",
-    "sec_assign_targets_workspace_bytes", "sec_assign_targets_f32", "sec_second_loss_workspace_bytes", "sec_second_loss_f32",
+    "sec_assign_targets_workspace_bytes", "sec_assign_targets_f32", "sec_assign_targets_per_class_f32",
+    "sec_second_loss_workspace_bytes", "sec_second_loss_f32",
 ]
 
 _lib = None
@@ -87,6 +88,7 @@ def lib():
         l.sec_predict_finalize.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, cf, ci, vp, vp, vp, vp, vp, vp]
         l.sec_assign_targets_workspace_bytes.argtypes = [ci, ci, ci]
         l.sec_assign_targets_f32.argtypes = [vp, ci, vp, vp, vp, vp, ci, ci, cf, cf, vp, vp, vp, vp, sz, vp]
+        l.sec_assign_targets_per_class_f32.argtypes = [vp, ci, vp, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
         l.sec_second_loss_workspace_bytes.argtypes = [ci, ci]
         l.sec_second_loss_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, sz, vp]
         _lib = l

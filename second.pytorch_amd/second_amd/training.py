@@ -27,15 +27,27 @@ from . import ops
 
 
 class DeviceTrainer:
-    def __init__(self, det, lr=3e-3, weight_decay=0.01, max_grad_norm=10.0, matched_threshold=0.6, unmatched_threshold=0.45,
+    def __init__(self, det, lr=3e-3, weight_decay=0.01, max_grad_norm=10.0, matched_threshold=None, unmatched_threshold=None,
                  loss_cfg=None, amp_dtype=None):
         """det: SecondDetector on this rank's GPU (training mode is set here).  ``amp_dtype`` (torch.bfloat16 / float16):
         mixed precision -- 16-bit features in the sparse stack and the RPN over fp32 master weights; None = fp32 throughout
-        (the reference's default training precision)."""
+        (the reference's default training precision).  Thresholds default to the config's class_settings."""
+        from . import models
         self.det = det.train()
         self.cfg = det.cfg
         self.max_grad_norm = float(max_grad_norm)
-        self.thresholds = (float(matched_threshold), float(unmatched_threshold))
+        mts, uts = list(self.cfg["matched_thresholds"]), list(self.cfg["unmatched_thresholds"])
+        if matched_threshold is not None:
+            mts = [float(matched_threshold)] * len(mts)
+        if unmatched_threshold is not None:
+            uts = [float(unmatched_threshold)] * len(uts)
+        self.thresholds = (mts[0], uts[0])
+        # several anchor generators: per-class matching (all.fhd.config:295) or all boxes with per-anchor thresholds
+        # (all.pp.largea.config:269) over the class-major anchor ranges
+        self.class_ranges = None
+        if len(mts) > 1:
+            ids = self.cfg["group_class_ids"] if self.cfg.get("assign_per_class", True) else [0] * len(mts)
+            self.class_ranges = (models.anchor_class_ranges(self.cfg, det.feature_map_size), ids, mts, uts)
         self.loss_cfg = dict(ops.LOSS_DEFAULTS, direction_offset=self.cfg["direction_offset"], num_class=self.cfg["num_class"],
                              num_direction_bins=self.cfg["num_direction_bins"], **(loss_cfg or {}))
         self.amp_dtype = amp_dtype
@@ -52,8 +64,13 @@ class DeviceTrainer:
         batch = point_offsets.numel() - 1
         with torch.no_grad():
             vox = det.voxel_generator.generate_device(points, point_offsets, mean_features=cfg["num_point_features"])
-            labels, reg_targets, importance = ops.assign_targets(det.anchors, gt_boxes, gt_offsets, *self.thresholds,
-                                                                 gt_classes=gt_classes)
+            if self.class_ranges is None:
+                labels, reg_targets, importance = ops.assign_targets(det.anchors, gt_boxes, gt_offsets, *self.thresholds,
+                                                                     gt_classes=gt_classes)
+            else:
+                begin, ids, mts, uts = self.class_ranges
+                labels, reg_targets, importance = ops.assign_targets_per_class(det.anchors, gt_boxes, gt_offsets, gt_classes,
+                                                                               begin, ids, mts, uts)
         if self.amp_dtype is not None:
             # fp32 master weights; 16-bit features through the sparse stack (MFMA forward / dgrad / wgrad kernels) and,
             # under autocast, through the dense RPN; BatchNorm statistics and the loss in fp32

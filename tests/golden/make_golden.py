@@ -484,9 +484,114 @@ def gen_train_targets_losses():
     print("loss", loss.item(), "loc", loc_red.item(), "cls", cls_red.item(), "dir", dir_loss.item())
 
 
+def gen_train_targets_multiclass():
+    """Multi-class fixtures (BASELINE configs 4 / 5): the reference's TargetAssigner (second/core/target_assigner.py) over three
+    AnchorGeneratorRange generators -- two rotations, one rotation, two sizes -- in both of its modes: assign_per_class
+    (all.fhd.config:295) and assign_all with per-anchor threshold arrays (all.pp.largea.config:269); non-uniform gt importance
+    (pins how assign_per_class indexes it); then VoxelNet.loss pieces for num_class = 3."""
+    import torch
+    if not getattr(np.meshgrid, "_as_list", False):
+        _mg = np.meshgrid
+        np.meshgrid = lambda *a, **k: list(_mg(*a, **k))
+        np.meshgrid._as_list = True
+    from second.core import region_similarity
+    from second.core.anchor_generator import AnchorGeneratorRange
+    from second.core.box_coders import GroundBox3dCoder
+    from second.core.target_assigner import TargetAssigner
+    from second.pytorch.core import losses
+    from second.pytorch.models import voxelnet as V
+    rng = np.random.default_rng(23)
+    fm = [1, 40, 36]
+    classes = ["car", "pedestrian", "trailer"]
+    spec = [dict(sizes=[1.95, 4.6, 1.72], rotations=[0, 1.57], z=-0.94, mt=0.4, ut=0.3),
+            dict(sizes=[0.66, 0.73, 1.76], rotations=[0], z=-0.74, mt=0.5, ut=0.35),
+            dict(sizes=[3.0, 15.0, 3.8, 2.0, 3.0, 3.8], rotations=[0, 1.57], z=0.22, mt=0.5, ut=0.35)]
+    gens = [AnchorGeneratorRange([-20, -20, sp["z"], 20, 20, sp["z"]], sizes=sp["sizes"], rotations=sp["rotations"], class_name=c,
+                                 match_threshold=sp["mt"], unmatch_threshold=sp["ut"]) for c, sp in zip(classes, spec)]
+    sims = [region_similarity.NearestIouSimilarity() for _ in classes]
+    out = {"feature_map_size": np.array(fm), "matched": np.array([sp["mt"] for sp in spec], np.float32),
+           "unmatched": np.array([sp["ut"] for sp in spec], np.float32)}
+    res = {}
+    for per_class in (True, False):
+        ta = TargetAssigner(GroundBox3dCoder(), gens, classes, feature_map_sizes=[fm] * 3, positive_fraction=None,
+                            region_similarity_calculators=sims, sample_size=512, assign_per_class=per_class)
+        ret = ta.generate_anchors(fm)
+        anchors = ret["anchors"].reshape(-1, 7)
+        adict = ta.generate_anchors_dict(fm)
+        begin = np.cumsum([0] + [adict[c]["anchors"].shape[0] for c in classes])
+        if per_class:
+            out["anchors"], out["class_anchor_begin"] = anchors, begin.astype(np.int32)
+            # ground truth: jittered copies of anchors of each class
+            frames = []
+            g, names = [], []
+            for ci, (c, k) in enumerate(zip(classes, (5, 4, 3))):
+                a = adict[c]["anchors"]
+                b = a[rng.choice(len(a), k, replace=False)].copy()
+                b[:, :2] += rng.normal(0, 0.15 if ci != 1 else 0.05, (k, 2)).astype(np.float32)
+                b[:, 3:6] *= rng.uniform(0.9, 1.15, (k, 3)).astype(np.float32)
+                b[:, 6] += rng.normal(0, 0.2, k).astype(np.float32)
+                g.append(b); names += [c] * k
+            order = rng.permutation(len(names))             # classes interleaved: index-within-class != index-in-frame
+            frames.append((np.concatenate(g)[order].astype(np.float32), [names[i] for i in order]))
+            a = adict["car"]["anchors"]
+            b = a[rng.choice(len(a), 4, replace=False)].copy()
+            b[:, :2] += rng.normal(0, 0.3, (4, 2)).astype(np.float32)
+            frames.append((b.astype(np.float32), ["car"] * 4))                     # no pedestrian / trailer boxes
+            frames.append((np.zeros((0, 7), np.float32), []))                      # no ground truth at all
+            imps = [rng.uniform(0.5, 1.5, len(f[0])).astype(np.float32) for f in frames]
+        labels, targets, importance = [], [], []
+        for f, ((gt, names), imp) in enumerate(zip(frames, imps)):
+            gt_classes = np.array([classes.index(n) + 1 for n in names], np.int32)
+            r = ta.assign(anchors, adict, gt, None, gt_classes=gt_classes, gt_names=np.array(names),
+                          matched_thresholds=ret["matched_thresholds"], unmatched_thresholds=ret["unmatched_thresholds"],
+                          importance=imp)
+            labels.append(r["labels"]); targets.append(r["bbox_targets"]); importance.append(r["importance"])
+            out[f"gt_{f}"], out[f"gt_classes_{f}"], out[f"gt_importance_{f}"] = gt, gt_classes, imp
+        tag = "per_class" if per_class else "all"
+        out[f"labels_{tag}"] = np.stack(labels).astype(np.int32)
+        out[f"bbox_targets_{tag}"] = np.stack(targets).astype(np.float32)
+        out[f"importance_{tag}"] = np.stack(importance).astype(np.float32)
+        print(tag, "positives per frame / class", [[int((l == k).sum()) for k in (1, 2, 3)] for l in labels],
+              "dont-care", [int((l == -1).sum()) for l in labels])
+    # ---- loss for three classes (all.fhd settings: focal, smooth-L1 sigma 3, sin difference, direction offset 0.78)
+    b, n = len(frames), len(out["anchors"])
+    tg = torch.Generator().manual_seed(9)
+    cls = (torch.randn(b, n, 3, generator=tg) * 2 - 2).requires_grad_()
+    box = (torch.randn(b, n, 7, generator=tg) * 0.3).requires_grad_()
+    dirp = torch.randn(b, n, 2, generator=tg).requires_grad_()
+    lab = torch.from_numpy(out["labels_per_class"]).int()
+    reg = torch.from_numpy(out["bbox_targets_per_class"])
+    imp = torch.from_numpy(out["importance_per_class"])
+    cls_w, reg_w, cared = V.prepare_loss_weights(lab, pos_cls_weight=1.0, neg_cls_weight=1.0,
+                                                 loss_norm_type=V.LossNormType.NormByNumPositives, dtype=torch.float32)
+    cls_t = (lab * cared.type_as(lab)).unsqueeze(-1)
+    loc_ftor = losses.WeightedSmoothL1LocalizationLoss(sigma=3.0, code_weights=[1.0] * 7, codewise=True)
+    cls_ftor = losses.SigmoidFocalClassificationLoss(gamma=2.0, alpha=0.25)
+    dir_ftor = losses.WeightedSoftmaxClassificationLoss()
+    loc_loss, cls_loss = V.create_loss(loc_ftor, cls_ftor, box_preds=box, cls_preds=cls, cls_targets=cls_t, cls_weights=cls_w * imp,
+                                       reg_targets=reg, reg_weights=reg_w * imp, num_class=3, encode_rad_error_by_sin=True,
+                                       encode_background_as_zeros=True, box_code_size=7, sin_error_factor=1.0, num_direction_bins=2)
+    loc_red = loc_loss.sum() / b * 2.0
+    cls_red = cls_loss.sum() / b * 1.0
+    pos_l, neg_l = V._get_pos_neg_loss(cls_loss, lab)
+    anc_t = torch.from_numpy(out["anchors"]).unsqueeze(0).repeat(b, 1, 1)
+    dir_t = V.get_direction_target(anc_t, reg, dir_offset=0.78, num_bins=2)
+    w = (lab > 0).type_as(dirp) * imp
+    w = w / torch.clamp(w.sum(-1, keepdim=True), min=1.0)
+    dir_loss = dir_ftor(dirp, dir_t, weights=w).sum() / b
+    loss = loc_red + cls_red + dir_loss * 0.2
+    loss.backward()
+    out.update(cls_preds=cls.detach().numpy(), box_preds=box.detach().numpy(), dir_preds=dirp.detach().numpy(),
+               loss=np.float32(loss.item()), loc_loss_reduced=np.float32(loc_red.item()), cls_loss_reduced=np.float32(cls_red.item()),
+               dir_loss_reduced=np.float32(dir_loss.item()), cls_pos_loss=np.float32(pos_l.item()), cls_neg_loss=np.float32(neg_l.item()),
+               d_cls=cls.grad.numpy(), d_box=box.grad.numpy(), d_dir=dirp.grad.numpy())
+    np.savez_compressed(os.path.join(OUT, "train_targets_multiclass.npz"), **out)
+    print("loss", loss.item(), "loc", loc_red.item(), "cls", cls_red.item(), "dir", dir_loss.item(), "pos", pos_l.item(), "neg", neg_l.item())
+
+
 if __name__ == "__main__":
     install_shims()
     which = sys.argv[1:] or ["rotate_iou", "rotate_nms", "nms_axis_aligned", "standup", "voxel_coords",
-                             "torch_modules", "train_targets_losses"]
+                             "torch_modules", "train_targets_losses", "train_targets_multiclass"]
     for w in which:
         globals()["gen_" + w]()

@@ -80,3 +80,87 @@ def test_second_loss_autograd_function(ops, golden):
     np.testing.assert_allclose(cls.grad.reshape(b, n, 1).cpu().numpy(), 3.0 * g["d_cls"], rtol=1e-4, atol=1e-8)
     np.testing.assert_allclose(box.grad.reshape(b, n, 7).cpu().numpy(), 3.0 * g["d_box"], rtol=1e-4, atol=1e-8)
     np.testing.assert_allclose(dirp.grad.reshape(b, n, 2).cpu().numpy(), 3.0 * g["d_dir"], rtol=1e-4, atol=1e-8)
+
+
+# ---------------------------------------------------------------------------------------------- multi-class (configs 4 / 5)
+def _gt_mc(g):
+    frames = [g[f"gt_{i}"] for i in range(3)]
+    offs = np.cumsum([0] + [len(f) for f in frames]).astype(np.int32)
+    cls = np.concatenate([g[f"gt_classes_{i}"] for i in range(3)]).astype(np.int32)
+    imp = np.concatenate([g[f"gt_importance_{i}"] for i in range(3)]).astype(np.float32)
+    return np.concatenate(frames).astype(np.float32), offs, cls, imp
+
+
+@pytest.mark.parametrize("mode", ["per_class", "all"])
+def test_assign_targets_multiclass_matches_reference_target_assigner(ops, golden, mode):
+    """TargetAssigner.assign over three anchor generators, executed by the reference (make_golden.py::gen_train_targets_multiclass):
+    assign_per_class (class-filtered ground truth, class thresholds, the reference's importance indexing) and assign_all with
+    per-anchor thresholds.  Frame 1 holds boxes of one class only, frame 2 none."""
+    g = golden("train_targets_multiclass")
+    gt, offs, cls, imp = _gt_mc(g)
+    ids = [1, 2, 3] if mode == "per_class" else [0, 0, 0]
+    labels, targets, importance = ops.assign_targets_per_class(dev(g["anchors"]), dev(gt), dev(offs), dev(cls),
+                                                               g["class_anchor_begin"].tolist(), ids, g["matched"].tolist(),
+                                                               g["unmatched"].tolist(), gt_importance=dev(imp))
+    want = g[f"labels_{mode}"]
+    np.testing.assert_array_equal(labels.cpu().numpy(), want)
+    assert sorted(set(np.unique(want).tolist())) == [-1, 0, 1, 2, 3]
+    np.testing.assert_allclose(targets.cpu().numpy(), g[f"bbox_targets_{mode}"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_array_equal(importance.cpu().numpy(), g[f"importance_{mode}"])
+    assert (g[f"importance_{mode}"] != 1.0).any()
+
+
+def test_second_loss_three_classes_matches_reference(ops, golden):
+    g = golden("train_targets_multiclass")
+    args = (dev(g["cls_preds"]), dev(g["box_preds"]), dev(g["dir_preds"]), dev(g["labels_per_class"]), dev(g["bbox_targets_per_class"]),
+            dev(g["anchors"]), dev(g["importance_per_class"]))
+    out6, d_cls, d_box, d_dir = ops.second_loss_raw(*args, direction_offset=0.78)
+    want = [g[k] for k in ("loss", "cls_loss_reduced", "loc_loss_reduced", "dir_loss_reduced", "cls_pos_loss", "cls_neg_loss")]
+    np.testing.assert_allclose(out6.cpu().numpy(), np.array(want, np.float32), rtol=1e-4)
+    for name, got_g, ref_g in (("cls", d_cls, g["d_cls"]), ("box", d_box, g["d_box"]), ("dir", d_dir, g["d_dir"])):
+        np.testing.assert_allclose(got_g.cpu().numpy(), ref_g, rtol=1e-4, atol=1e-6 * np.abs(ref_g).max() + 1e-9, err_msg=name)
+
+
+def test_device_trainer_multiclass_step_runs_and_learns():
+    """config 5 (nuscenes all.fhd, ten classes, assign_per_class) on a reduced range: three optimisation steps, finite losses,
+    parameters move, per-class ranges line up with the anchor array."""
+    from second_amd import models, synthetic
+    from second_amd.training import DeviceTrainer
+    cfg = dict(models.ALL_FHD_NUSC, point_cloud_range=[-12.8, -12.8, -5, 12.8, 12.8, 3], max_voxels=20000,
+               anchor_ranges=[[-12.8, -12.8, r[2], 12.8, 12.8, r[5]] for r in models.ALL_FHD_NUSC["anchor_ranges"]],
+               post_center_range=[-15, -15, -10, 15, 15, 10], block_filtering=None)
+    torch.manual_seed(0)
+    det = models.SecondDetector(cfg).cuda()
+    tr = DeviceTrainer(det, lr=1e-3)
+    begin = tr.class_ranges[0]
+    assert begin[-1] == det.anchors.shape[0] and len(begin) == 11
+    rng = np.random.default_rng(0)
+    pts, offs, gts, goffs, gcls = [], [0], [], [0], []
+    for f in range(2):
+        p = rng.uniform([-12.7, -12.7, -4.9, 0], [12.7, 12.7, 2.9, 1], (6000, 4)).astype(np.float32)
+        pts.append(p); offs.append(offs[-1] + len(p))
+        k = 6
+        cls = rng.integers(1, 11, k)
+        anc = det.anchors.cpu().numpy()
+        b = np.stack([anc[rng.integers(begin[c - 1], begin[c])] for c in cls]).astype(np.float32)
+        b[:, :2] += rng.normal(0, 0.05, (k, 2)).astype(np.float32)
+        gts.append(b); goffs.append(goffs[-1] + k); gcls.append(cls.astype(np.int32))
+    args = (dev(np.concatenate(pts)), dev(np.array(offs, np.int32)), dev(np.concatenate(gts)), dev(np.array(goffs, np.int32)),
+            dev(np.concatenate(gcls)))
+    before = torch.cat([p.detach().reshape(-1) for p in det.parameters()]).clone()
+    losses = []
+    for _ in range(3):
+        tr.step(*args)
+        losses.append(tr.loss_dict())
+    assert all(np.isfinite(l["loss"]) for l in losses), losses
+    _, _, labels = tr.forward_loss(*args)
+    lab = labels.cpu().numpy()
+    gc = np.concatenate(gcls)
+    for f in range(2):
+        for c in set(gc[goffs[f]:goffs[f + 1]].tolist()):          # every ground-truth class got positives inside its own range
+            assert (lab[f, begin[c - 1]:begin[c]] == c).any(), (f, c)
+        for c in range(1, 11):                                      # and no range holds another class's label
+            seg = lab[f, begin[c - 1]:begin[c]]
+            assert set(np.unique(seg).tolist()) <= {-1, 0, c}
+    after = torch.cat([p.detach().reshape(-1) for p in det.parameters()])
+    assert not torch.equal(before, after)

@@ -1,6 +1,6 @@
-mkdir -p gpurun_out/r2v
+mkdir -p gpurun_out/r2x
 export PYTHONUNBUFFERED=1
-timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_properties.py tests/test_gpu_round2.py tests/test_gpu_e2e.py -m gpu -q -x > gpurun_out/r2v/pytest.log 2>&1; echo "rc=$?" >> gpurun_out/r2v/pytest.log
-timeout 600 python bench.py > gpurun_out/r2v/bench.json 2> gpurun_out/r2v/bench.err
-timeout 300 python bench.py --inflight 1 --no-kernel-table > gpurun_out/r2v/bench1.json 2>> gpurun_out/r2v/bench.err
-tail -4 gpurun_out/r2v/pytest.log; cat gpurun_out/r2v/bench1.json | cut -c1-300
+AMD_SERIALIZE_KERNEL=3 timeout 600 python tools/_dbg_train.py > gpurun_out/r2x/dbg.txt 2>&1
+tail -12 gpurun_out/r2x/dbg.txt
+timeout 900 python bench.py --workload nusc.fhd.train --steps 10 --warmup 3 > gpurun_out/r2x/bench_nusc_train.json 2> gpurun_out/r2x/bench_nusc_train.err
+cat gpurun_out/r2x/bench_nusc_train.json; tail -5 gpurun_out/r2x/bench_nusc_train.err
