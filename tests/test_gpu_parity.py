@@ -897,3 +897,26 @@ def test_detector_steps_in_flight(syn):
     for o in runner.outputs:
         assert torch.equal(m, o["valid"])
         assert torch.equal(e["scores"][m], o["scores"][m]) and torch.equal(e["boxes"][m], o["boxes"][m])
+
+
+@pytest.mark.parametrize("levels,k", [(3, 1000), (40, 1000), (700, 1000), (5, 64), (1, 1000), (100000, 1000)])
+def test_predict_select_tie_ranking(levels, k):
+    """Heavily tied 16-bit logits (an untrained or saturated head): the selection is the k largest keys, ties by ascending
+    anchor index (the order torch.topk of voxelnet.py:551-570 is replaced by, documented in DESIGN), identical run to run.
+    levels = number of distinct logit values per frame (1 = every anchor ties; 100000 = practically distinct)."""
+    from second_amd import ops
+    b, a, h, w = 3, 2, 200, 176
+    n = a * h * w
+    g = torch.Generator(device="cuda").manual_seed(levels)
+    vals = (torch.randn(levels, device="cuda", generator=g) * 2.0 - 1.0).bfloat16()
+    pick = torch.randint(0, levels, (b, n), device="cuda", generator=g)
+    cls = vals[pick].reshape(b, a, h, w, 1).contiguous()
+    top_idx, top_score, _, counts = ops.predict_select(cls, k, 0.3)
+    again = ops.predict_select(cls, k, 0.3)
+    assert torch.equal(top_idx, again[0]) and torch.equal(top_score, again[1])
+    flat = cls.reshape(b, n).float()
+    # reference: stable sort by descending logit -> ties keep ascending index
+    order = torch.sort(flat, dim=1, descending=True, stable=True).indices[:, :k]
+    assert torch.equal(top_idx.long(), order), (levels, k)
+    np.testing.assert_allclose(top_score.cpu().numpy(), torch.sigmoid(torch.gather(flat, 1, order)).cpu().numpy(), rtol=1e-6)
+    assert torch.equal(counts.long(), (torch.sigmoid(torch.gather(flat, 1, order)) >= 0.3).sum(1))
