@@ -1,6 +1,4 @@
 mkdir -p gpurun_out/r2z
 export PYTHONUNBUFFERED=1
-for n in 2 3 4 5; do timeout 300 python bench.py --inflight $n --no-kernel-table --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('inflight', $n, d['value'], d['ms_per_step'], d['config'].get('single_step_latency_ms'))"; done
-timeout 300 python bench.py --inflight 1 --branches 2 --no-kernel-table --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('inflight 1 branches 2', d['value'], d['ms_per_step'])"
-timeout 300 python bench.py --inflight 3 --branches 2 --no-kernel-table --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('inflight 3 branches 2', d['value'], d['ms_per_step'])"
-timeout 300 python -m pytest tests/test_gpu_parity.py -m gpu -q -k "tie_ranking" 2>&1 | tail -1
+SEC_HIP_LIB=$PWD/second.pytorch_amd/lib/libsecond_hip_exp.so timeout 600 python tools/conv_microbench.py --all-layers --variants 29,19,32,33 > gpurun_out/r2z/layers_deep.txt 2>&1
+grep "layer  [6-9]\|layer 1[0-3]\|sum" gpurun_out/r2z/layers_deep.txt | cut -c1-260

@@ -57,11 +57,19 @@ def all_layers(args, dev):
             for _ in range(5):
                 run()
             torch.cuda.synchronize()
+            # the re-issues are replayed from a hipGraph: a Python -> ctypes launch costs ~10-15 us on the host, more than the
+            # small layers' kernels take, so eager back-to-back launches would measure the host
+            g_ = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_, capture_error_mode="thread_local"):
+                for _ in range(args.iters):
+                    run()
+            g_.replay()
+            torch.cuda.synchronize()
             e0.record()
-            for _ in range(args.iters):
-                run()
+            g_.replay()
             e1.record()
             torch.cuda.synchronize()
+            del g_
             us = e0.elapsed_time(e1) * 1e3 / args.iters
             total[v] += us
             line += f" v{v}(plan {pl}): {us:6.2f} us {b_alg / us / 1e3 / 8000:.3f}"
