@@ -123,6 +123,36 @@ int sec_rulebook_conv3d_tables(int n_in, const int *h_ksize3, const int *h_strid
                                const int *h_dilation3, int out_per_in_hint, int *nbr_out,
                                int nbr_out_rows, int *nbr_in, int prefilled, int *pairs, int *pair_num,
                                void *workspace, size_t workspace_bytes, void *stream);
+/* The same three steps with spconv's GPU output numbering (spconv src/spconv/indice.cu, the path the reference takes on a
+ * GPU: outputs = unique(linear cell index) in ASCENDING order; SURVEY.md Appendix A.4 "numbering = sorted"), pair order inside
+ * an offset = ascending input row (the reference's GPU path has atomic-arrival order there: compare as sets).  The gather
+ * tables describe the same convolution as the first-touch form with the output rows permuted -- features after dense() are
+ * identical.  No hash table: a bitmap over the batch * D * H * W output cells (batch * volume < 2^32, else
+ * SEC_E_UNSUPPORTED), one single-pass scan, rank = prefix[word] + popcount.  num_out as in sec_rulebook_conv3d_build. */
+size_t sec_rulebook_sorted_workspace_bytes(int n_in, int kvol, int batch, const int *h_out_shape3);
+int sec_rulebook_conv3d_build_sorted(const int *indices, int n_in, const int *n_in_dev, int batch,
+                                     const int *h_in_shape3, const int *h_out_shape3, const int *h_ksize3,
+                                     const int *h_stride3, const int *h_padding3, const int *h_dilation3,
+                                     int *out_indices, int out_cap, int *num_out, int *prefill_nbr_out,
+                                     int prefill_nbr_out_rows, int *prefill_nbr_in,
+                                     const void *in_sites_workspace, size_t in_sites_workspace_bytes,
+                                     void *workspace, size_t workspace_bytes, void *stream);
+/* (build_sorted) out_indices may be NULL when the tables call below is given the buffer instead (it writes the same rows:
+ * one launch less).  in_sites_workspace (optional): the workspace of the sorted build that produced `indices` (this layer's
+ * inputs are that layer's outputs, e.g. through SubM layers on the same sites; it must be unmodified) -- the output bitmap
+ * is then derived from that bitmap with plain loads (3x3x3 stride-2 and (3,1,1) stride-(2,1,1) layers, padding <= 1)
+ * instead of one atomic per candidate. */
+int sec_rulebook_conv3d_tables_sorted(const int *indices, int n_in, const int *n_in_dev, int batch,
+                                      const int *h_in_shape3, const int *h_out_shape3, const int *h_ksize3,
+                                      const int *h_stride3, const int *h_padding3, const int *h_dilation3,
+                                      int *nbr_out, int nbr_out_rows, int *nbr_in, int prefilled, int *out_indices,
+                                      int out_cap, int *pairs, int *pair_num, void *workspace,
+                                      size_t workspace_bytes, void *stream);
+/* SubMConv3d on the outputs of sec_rulebook_conv3d_build_sorted (its bitmap + ranks are the site lookup) */
+int sec_rulebook_subm3d_after_conv_sorted(const int *indices, int n_in, const int *n_in_dev, int batch,
+                                          const int *h_shape3, const int *h_ksize3, const int *h_dilation3,
+                                          int *nbr_out, const void *conv_workspace, size_t conv_workspace_bytes,
+                                          void *stream);
 void sec_conv_output_shape(const int *h_in_shape3, const int *h_ksize3, const int *h_stride3,
                            const int *h_padding3, const int *h_dilation3, int *h_out_shape3);
 

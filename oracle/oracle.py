@@ -137,6 +137,24 @@ def rulebook_conv(indices, batch_size, spatial_shape, ksize, stride, padding, di
     return out_idx[:m].copy(), pairs, pair_num, out_shape
 
 
+def rulebook_conv_sorted(indices, batch_size, spatial_shape, ksize, stride, padding, dilation=1):
+    """The strided rulebook in spconv's GPU output numbering (SURVEY.md Appendix A.4 [recall]: the CUDA path of
+    spconv src/spconv/indice.cu numbers the outputs by sort / unique of the linear cell index
+    lin = ((b * D + z) * H + y) * W + x, ascending; its pair order inside an offset is atomic-arrival order, for which the
+    canonical comparison form is ascending input row).  Restated as a relabelling of the first-touch rulebook."""
+    out_idx, pairs, pair_num, out_shape = rulebook_conv(indices, batch_size, spatial_shape, ksize, stride, padding, dilation)
+    d, h, w = (int(v) for v in out_shape)
+    lin = ((out_idx[:, 0].astype(np.int64) * d + out_idx[:, 1]) * h + out_idx[:, 2]) * w + out_idx[:, 3]
+    perm = np.argsort(lin, kind="stable")
+    rank = np.empty(len(perm), np.int32)
+    rank[perm] = np.arange(len(perm), dtype=np.int32)
+    pairs = pairs.copy()
+    for k in range(pairs.shape[0]):
+        c = int(pair_num[k])
+        pairs[k, 1, :c] = rank[pairs[k, 1, :c]]
+    return out_idx[perm].copy(), pairs, pair_num, out_shape
+
+
 def indice_conv(features, weight, pairs, pair_num, num_out, acc64=True):
     """orc_indice_conv_fwd.  weight [kD,kH,kW,Cin,Cout] or [K,Cin,Cout]."""
     features = _f(features)

@@ -448,6 +448,291 @@ static int emit_pairs(const int *table, int n, int kvol, int mirror, int *blk, i
     return check_launch();
 }
 
+
+// ---- "sorted" output numbering: spconv's GPU path -----------------------------------------------------
+// Outputs are numbered by ascending linear cell index lin = ((b * D + z) * H + y) * W + x instead of by first touch.  That
+// order needs no hash table and no winner election: a bitmap over the output grid (one bit per cell: 11.8 MB for the first
+// strided layer of car.fhd at batch 8) is filled, ONE single-pass scan turns the word popcounts into ranks, and a cell's
+// output row is prefix[word] + popc(bits below).  Filling the bitmap:
+//   * from the input rows (k_bm_set*): atomicOr per candidate cell -- device-scope atomics retire at ~20 G/s on this chip, so
+//     the 3x3x3 stride-2 form handles the two x candidates of an input (adjacent cells) with one atomic;
+//   * from the INPUT sites' bitmap when the inputs are themselves the outputs of a sorted build (k_bm_dilate): an output word
+//     is the OR over the <= 9 (z, y) input rows of a 65-bit input window, every second bit kept -- plain loads and stores, no atomics.
+// Pair order inside an offset stays ascending input row (emit_pairs), where the reference's GPU path has atomic-arrival order.
+constexpr int kBmWpt = 64;                       // bitmap words per thread of the scan (256 contiguous bytes): few tiles -> short look-back chain
+constexpr int kBmTile = kBlock * kBmWpt;         // words per scan tile
+
+template <int GEO>
+__device__ __forceinline__ bool bm_candidate(const RbGeom &g, int4 q, int c, int *k_out, unsigned *lin_out, int *out) {
+    using G = Geo<GEO>;
+    int in[3] = {q.y, q.z, q.w}, kk[3];
+    bool ok = true;
+    int k = 0;
+    if constexpr (G::fixed) {
+        const int c0 = c / (G::C1 * G::C2), c1 = (c / G::C2) % G::C1, c2 = c % G::C2;
+        ok &= cand_offset_fixed<3, 2>(in[0], g.pad[0], g.out_shape[0], c0, &kk[0], &out[0]);
+        ok &= cand_offset_fixed<G::K1, G::K1 == 3 ? 2 : 1>(in[1], g.pad[1], g.out_shape[1], c1, &kk[1], &out[1]);
+        ok &= cand_offset_fixed<G::K2, G::K2 == 3 ? 2 : 1>(in[2], g.pad[2], g.out_shape[2], c2, &kk[2], &out[2]);
+        k = (kk[0] * G::K1 + kk[1]) * G::K2 + kk[2];
+    } else {
+        int cc[3] = {c / (g.cand[2] * g.cand[1]), (c / g.cand[2]) % g.cand[1], c % g.cand[2]};
+#pragma unroll
+        for (int d = 0; d < 3; ++d) ok &= cand_offset(g, d, in[d], cc[d], &kk[d], &out[d]);
+        k = (kk[0] * g.ksize[1] + kk[1]) * g.ksize[2] + kk[2];
+    }
+    *k_out = k;
+    *lin_out = ok ? (((unsigned)q.x * g.out_shape[0] + out[0]) * g.out_shape[1] + out[1]) * g.out_shape[2] + out[2] : 0u;
+    return ok;
+}
+
+template <int GEO>
+__global__ __launch_bounds__(kBlock) void k_bm_set(const int *__restrict__ indices, RbGeom g, const int *__restrict__ n_dev,
+                                                  unsigned *__restrict__ bm) {
+    using G = Geo<GEO>;
+    const int ncand = G::fixed ? G::NCAND : g.ncand;
+    long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= (long long)g.n_in * ncand) return;
+    const int j = (int)(t / ncand), c = (int)(t % ncand);
+    if (j >= live_rows(g, n_dev)) return;
+    const int4 q = *reinterpret_cast<const int4 *>(indices + (size_t)j * 4);
+    int k, out[3];
+    unsigned lin;
+    if (bm_candidate<GEO>(g, q, c, &k, &lin, out)) atomicOr(&bm[lin >> 5], 1u << (lin & 31u));
+}
+
+// 3x3x3 stride 2: one thread per (input row, z candidate, y candidate); its two x candidates are adjacent cells
+__global__ __launch_bounds__(kBlock) void k_bm_set_x2(const int *__restrict__ indices, RbGeom g, const int *__restrict__ n_dev,
+                                                     unsigned *__restrict__ bm) {
+    long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= (long long)g.n_in * 4) return;
+    const int j = (int)(t >> 2), c = (int)(t & 3);
+    if (j >= live_rows(g, n_dev)) return;
+    const int4 q = *reinterpret_cast<const int4 *>(indices + (size_t)j * 4);
+    int kz, ky, oz, oy;
+    if (!cand_offset_fixed<3, 2>(q.y, g.pad[0], g.out_shape[0], c >> 1, &kz, &oz)) return;
+    if (!cand_offset_fixed<3, 2>(q.z, g.pad[1], g.out_shape[1], c & 1, &ky, &oy)) return;
+    int kx, ox0, ox1;
+    const bool v0 = cand_offset_fixed<3, 2>(q.w, g.pad[2], g.out_shape[2], 0, &kx, &ox0);
+    const bool v1 = cand_offset_fixed<3, 2>(q.w, g.pad[2], g.out_shape[2], 1, &kx, &ox1);
+    const unsigned rowb = (((unsigned)q.x * g.out_shape[0] + oz) * g.out_shape[1] + oy) * g.out_shape[2];
+    const unsigned l0 = rowb + ox0, l1 = rowb + ox1;
+    if (v0 && v1 && (l0 >> 5) == (l1 >> 5)) {
+        atomicOr(&bm[l0 >> 5], (1u << (l0 & 31u)) | (1u << (l1 & 31u)));
+    } else {
+        if (v0) atomicOr(&bm[l0 >> 5], 1u << (l0 & 31u));
+        if (v1) atomicOr(&bm[l1 >> 5], 1u << (l1 & 31u));
+    }
+}
+
+// 64 bits of a row of the INPUT bitmap starting at x = s (s may be -1: the padding column), zero beyond the row; *b64 = bit s + 64
+__device__ __forceinline__ unsigned long long bm_window(const unsigned *__restrict__ bm, long long n_words, unsigned row_base,
+                                                        int s, int w_in, unsigned *b64) {
+    const int s0 = s < 0 ? 0 : s;                       // first real column fetched
+    const unsigned p = row_base + (unsigned)s0;
+    long long w0 = p >> 5;
+    if (w0 >= n_words) w0 = n_words - 1;               // only when the window starts beyond the last row (masked to zero below)
+    const unsigned sh = p & 31u;
+    const unsigned a0 = bm[w0], a1 = bm[w0 + 1 < n_words ? w0 + 1 : w0], a2 = bm[w0 + 2 < n_words ? w0 + 2 : w0];
+    unsigned long long lo = ((unsigned long long)a1 << 32) | a0;
+    unsigned long long v = sh ? (lo >> sh) | ((unsigned long long)a2 << (64 - sh)) : lo;     // 64 bits from column s0
+    // bit 64 from column s0: bit (sh + 64) of the 96 fetched = bit (sh + 32) of (a2:a1) -- only needed when s0 == s
+    unsigned top = (unsigned)((((unsigned long long)a2 << 32) | a1) >> sh >> 31 >> 1) & 1u;      // (a2:a1) >> (sh + 32), sh + 32 < 64
+    const int left = w_in - s0;                        // columns of the row from s0 on
+    if (left < 64) v &= left <= 0 ? 0ull : ((1ull << left) - 1ull);
+    if (left <= 64) top = 0u;
+    if (s < 0) {                                       // window starts one column before the row: shift in a zero
+        top = (unsigned)(v >> 63);
+        v <<= 1;
+    }
+    *b64 = top;
+    return v;
+}
+
+__device__ __forceinline__ unsigned compress_even(unsigned long long x) {      // bit o of the result = bit 2 o of x
+    x &= 0x5555555555555555ull;
+    x = (x | (x >> 1)) & 0x3333333333333333ull;
+    x = (x | (x >> 2)) & 0x0f0f0f0f0f0f0f0full;
+    x = (x | (x >> 4)) & 0x00ff00ff00ff00ffull;
+    x = (x | (x >> 8)) & 0x0000ffff0000ffffull;
+    x = (x | (x >> 16)) & 0x00000000ffffffffull;
+    return (unsigned)x;
+}
+
+// output bitmap from the input sites' bitmap.  GEO 1: 3x3x3 stride 2 (any padding); GEO 2: (3,1,1) stride (2,1,1).
+// One thread per output word; a word that straddles a row end is assembled from its row segments.
+template <int GEO>
+__global__ __launch_bounds__(kBlock) void k_bm_dilate(const unsigned *__restrict__ bm_in, long long n_words_in, RbGeom g,
+                                                     unsigned *__restrict__ bm_out, long long n_words_out) {
+    const long long wi = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (wi >= n_words_out) return;
+    const unsigned Wo = (unsigned)g.out_shape[2], Ho = (unsigned)g.out_shape[1], Do = (unsigned)g.out_shape[0];
+    const unsigned total = (unsigned)g.batch * Do * Ho * Wo;
+    const unsigned lin0 = (unsigned)wi << 5;
+    if (lin0 >= total) { bm_out[wi] = 0u; return; }
+    unsigned row = lin0 / Wo, x = lin0 - row * Wo;     // row = (b * Do + oz) * Ho + oy
+    unsigned word = 0u;
+    int done = 0;
+    while (done < 32 && row < (unsigned)g.batch * Do * Ho) {
+        const int len = min(32 - done, (int)(Wo - x));
+        const unsigned plane = row / Ho, oy = row - plane * Ho, b = plane / Do, oz = plane - b * Do;
+        unsigned seg = 0u;
+        if constexpr (GEO == 1) {
+            unsigned long long acc = 0ull;
+            unsigned acc64 = 0u;
+            const int s = 2 * (int)x - g.pad[2];
+#pragma unroll
+            for (int kz = 0; kz < 3; ++kz) {
+                const int iz = 2 * (int)oz - g.pad[0] + kz;
+                if (iz < 0 || iz >= g.in_shape[0]) continue;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int iy = 2 * (int)oy - g.pad[1] + ky;
+                    if (iy < 0 || iy >= g.in_shape[1]) continue;
+                    const unsigned rb = ((b * g.in_shape[0] + iz) * g.in_shape[1] + iy) * g.in_shape[2];
+                    unsigned t64;
+                    acc |= bm_window(bm_in, n_words_in, rb, s, g.in_shape[2], &t64);
+                    acc64 |= t64;
+                }
+            }
+            const unsigned e = compress_even(acc), o1 = compress_even(acc >> 1);
+            seg = e | o1 | (e >> 1) | (acc64 << 31);   // out bit o = in[2o] | in[2o+1] | in[2o+2] (window-relative)
+        } else {                                         // (3,1,1) / (2,1,1): same (y, x), three input planes
+            unsigned long long acc = 0ull;
+#pragma unroll
+            for (int kz = 0; kz < 3; ++kz) {
+                const int iz = 2 * (int)oz - g.pad[0] + kz;
+                if (iz < 0 || iz >= g.in_shape[0]) continue;
+                const int iy = (int)oy - g.pad[1], s = (int)x - g.pad[2];
+                if (iy < 0 || iy >= g.in_shape[1]) continue;
+                const unsigned rb = ((b * g.in_shape[0] + iz) * g.in_shape[1] + iy) * g.in_shape[2];
+                unsigned t64;
+                acc |= bm_window(bm_in, n_words_in, rb, s, g.in_shape[2], &t64);
+            }
+            seg = (unsigned)acc;
+        }
+        if (len < 32) seg &= (1u << len) - 1u;
+        word |= seg << done;
+        done += len;
+        x = 0;
+        ++row;
+    }
+    bm_out[wi] = word;
+}
+
+// ranks: exclusive scan of the word popcounts (decoupled look-back over tiles of kBmTile words) -> prefix[] per word,
+// num_out[0] = live outputs (clamped to out_cap), num_out[1] = raw count
+__global__ __launch_bounds__(kBlock) void k_bm_scan(const unsigned *__restrict__ bm, int *__restrict__ prefix, int out_cap,
+                                                   unsigned long long *__restrict__ status, int *__restrict__ ticket,
+                                                   int *__restrict__ num_out) {
+    __shared__ int smem[8];
+    __shared__ int s_tile;
+    const int tile = scan_take_tile(ticket, &s_tile);
+    const size_t base = ((size_t)tile * kBlock + threadIdx.x) * kBmWpt;
+    int cnt = 0;
+#pragma unroll
+    for (int i = 0; i < kBmWpt / 4; ++i) {
+        const uint4 w4 = *reinterpret_cast<const uint4 *>(bm + base + 4 * i);
+        cnt += __popc(w4.x) + __popc(w4.y) + __popc(w4.z) + __popc(w4.w);
+    }
+    int r = scan_lookback(cnt, tile, (int)gridDim.x, status, smem, num_out);
+    if (tile == (int)gridDim.x - 1 && threadIdx.x == 0) {
+        const int tot = num_out[0];
+        num_out[1] = tot;
+        if (tot > out_cap) num_out[0] = out_cap;
+    }
+#pragma unroll
+    for (int i = 0; i < kBmWpt / 4; ++i) {
+        const uint4 w4 = *reinterpret_cast<const uint4 *>(bm + base + 4 * i);      // second read: L1 / L2 hit
+        int4 pf;
+        pf.x = r; r += __popc(w4.x);
+        pf.y = r; r += __popc(w4.y);
+        pf.z = r; r += __popc(w4.z);
+        pf.w = r; r += __popc(w4.w);
+        *reinterpret_cast<int4 *>(prefix + base + 4 * i) = pf;
+    }
+}
+
+// out_indices in rank order, one thread per bitmap word (for callers that want them before the tables exist; the tables
+// kernel writes them too -- every candidate knows its output's coordinates)
+__global__ __launch_bounds__(kBlock) void k_bm_emit(const unsigned *__restrict__ bm, const int *__restrict__ prefix, RbGeom g,
+                                                   long long n_words, int *__restrict__ out_indices, int out_cap) {
+    const long long wi = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (wi >= n_words) return;
+    unsigned word = bm[wi];
+    if (!word) return;
+    int r = prefix[wi];
+    const unsigned W = (unsigned)g.out_shape[2], H = (unsigned)g.out_shape[1], D = (unsigned)g.out_shape[0];
+    const unsigned lin0 = (unsigned)wi << 5;
+    const unsigned row = lin0 / W;                   // (b * D + z) * H + y of the word's first cell
+    const unsigned x0 = lin0 - row * W;
+    while (word && r < out_cap) {
+        const int bit = __ffs((int)word) - 1;
+        word &= word - 1u;
+        unsigned x = x0 + bit, rw = row;
+        while (x >= W) { x -= W; ++rw; }             // a word may straddle row ends when W is not a multiple of 32
+        const unsigned plane = rw / H, y = rw - plane * H;
+        const unsigned b = plane / D, z = plane - b * D;
+        *reinterpret_cast<int4 *>(out_indices + (size_t)r * 4) = make_int4((int)b, (int)z, (int)y, (int)x);
+        ++r;
+    }
+}
+
+__device__ __forceinline__ int bm_rank(const unsigned *__restrict__ bm, const int *__restrict__ prefix, unsigned lin) {
+    const unsigned word = bm[lin >> 5], bit = 1u << (lin & 31u);
+    if (!(word & bit)) return -1;
+    return prefix[lin >> 5] + __popc(word & (bit - 1u));
+}
+
+template <int GEO>
+__global__ __launch_bounds__(kBlock) void k_bm_tables(const int *__restrict__ indices, RbGeom g, const int *__restrict__ n_dev,
+                                                     const unsigned *__restrict__ bm, const int *__restrict__ prefix,
+                                                     int *__restrict__ nbr_in, int *__restrict__ nbr_out, int nbr_out_rows,
+                                                     int *__restrict__ out_indices, int out_cap) {
+    using G = Geo<GEO>;
+    const int ncand = G::fixed ? G::NCAND : g.ncand, kvol = G::fixed ? G::KVOL : g.kvol;
+    long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= (long long)g.n_in * ncand) return;
+    const int j = (int)(t / ncand), c = (int)(t % ncand);
+    if (j >= live_rows(g, n_dev)) return;
+    const int4 q = *reinterpret_cast<const int4 *>(indices + (size_t)j * 4);
+    int k, out[3];
+    unsigned lin;
+    if (!bm_candidate<GEO>(g, q, c, &k, &lin, out)) return;
+    const int o = bm_rank(bm, prefix, lin);
+    if (o < 0) return;
+    if (nbr_in) nbr_in[(size_t)j * kvol + k] = o;
+    if (o < nbr_out_rows) nbr_out[(size_t)o * kvol + k] = j;
+    // every candidate of an output writes the same four ints: no election needed
+    if (out_indices && o < out_cap) *reinterpret_cast<int4 *>(out_indices + (size_t)o * 4) = make_int4(q.x, out[0], out[1], out[2]);
+}
+
+// SubM layer on the outputs of a sorted-numbering strided build: the site lookup is the bitmap rank
+template <bool K3>
+__global__ __launch_bounds__(kBlock) void k_subm_nbr_bm(const int *__restrict__ indices, RbGeom g, const int *__restrict__ n_dev,
+                                                       const unsigned *__restrict__ bm, const int *__restrict__ prefix,
+                                                       int *__restrict__ nbr) {
+    if (K3) { g.kvol = 27; g.ksize[0] = g.ksize[1] = g.ksize[2] = 3; }
+    const int half = K3 ? 13 : g.kvol / 2;
+    long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (t >= (long long)live_rows(g, n_dev) * (half + 1)) return;
+    int o = (int)(t / (half + 1)), k = (int)(t % (half + 1));
+    if (k == half) { nbr[(size_t)o * g.kvol + half] = o; return; }
+    int kx = K3 ? k % 3 : k % g.ksize[2], ky = K3 ? (k / 3) % 3 : (k / g.ksize[2]) % g.ksize[1],
+        kz = K3 ? k / 9 : k / (g.ksize[2] * g.ksize[1]);
+    int4 c = *reinterpret_cast<const int4 *>(indices + (size_t)o * 4);
+    int z = c.y + (kz - g.ksize[0] / 2) * g.dil[0];
+    int y = c.z + (ky - g.ksize[1] / 2) * g.dil[1];
+    int x = c.w + (kx - g.ksize[2] / 2) * g.dil[2];
+    if (z >= 0 && z < g.in_shape[0] && y >= 0 && y < g.in_shape[1] && x >= 0 && x < g.in_shape[2]) {
+        const unsigned lin = (((unsigned)c.x * g.in_shape[0] + z) * g.in_shape[1] + y) * g.in_shape[2] + x;
+        const int j = bm_rank(bm, prefix, lin);
+        if ((unsigned)j < (unsigned)g.n_in) {
+            nbr[(size_t)o * g.kvol + k] = j;
+            nbr[(size_t)j * g.kvol + (g.kvol - 1 - k)] = o;
+        }
+    }
+}
+
 struct RbWorkspace {
     unsigned long long *keys;
     int *vals, *orank, *cand_slot, *rank, *scan, *blk, *scan2, *overflow, *ticket;
@@ -646,6 +931,150 @@ SEC_API int sec_rulebook_conv3d_build(const int *indices, int n_in, const int *n
                        w.orank, out_indices, out_cap, num_out, w.overflow, w.first_mask);
     return check_launch();
 }
+
+// ---- sorted (spconv-GPU) numbering: host side --------------------------------------------------------------------------
+struct BmWorkspace {
+    unsigned *bm;
+    int *prefix, *ticket, *blk, *scan2;
+    unsigned long long *status;
+    long long n_words, ctl_words, zero_words64;   // zero_words64: 64-bit words from bm to the end of the control block
+    size_t bytes;
+};
+
+static BmWorkspace carve_bm(void *ws, size_t cap, int n_in, int kvol, long long cells) {
+    BmWorkspace w;
+    Arena a(ws, cap);
+    w.n_words = (long long)div_up(div_up(cells > 0 ? cells : 1, 32), kBmTile) * kBmTile;
+    w.bm = a.take<unsigned>(w.n_words);
+    // the scan's control block directly behind the bitmap: ONE zero fill covers both
+    w.ctl_words = (long long)scan_ctl_words(w.n_words / kBmWpt);
+    w.ticket = a.take<int>(w.ctl_words);
+    w.status = reinterpret_cast<unsigned long long *>(w.ticket + 4);
+    w.zero_words64 = (long long)((reinterpret_cast<char *>(w.ticket + w.ctl_words) - reinterpret_cast<char *>(w.bm)) / 8);
+    w.prefix = a.take<int>(w.n_words);
+    long long nblk = (long long)kvol * div_up(n_in > 0 ? n_in : 1, kBlock);
+    w.blk = a.take<int>(nblk + 1);
+    w.scan2 = a.take<int>(scan_scratch_ints(nblk));
+    w.bytes = align_up(a.used);
+    return w;
+}
+
+static long long bm_cells(int batch, const int *shape3) { return (long long)batch * shape3[0] * shape3[1] * shape3[2]; }
+
+
+SEC_API size_t sec_rulebook_sorted_workspace_bytes(int n_in, int kvol, int batch, const int *h_out_shape3) {
+    if (n_in < 0 || kvol <= 0 || kvol > kMaxKvol || batch <= 0 || !h_out_shape3) return 0;
+    return carve_bm(nullptr, 0, n_in, kvol, bm_cells(batch, h_out_shape3)).bytes;
+}
+
+SEC_API int sec_rulebook_conv3d_build_sorted(const int *indices, int n_in, const int *n_in_dev, int batch, const int *h_in_shape3,
+                                             const int *h_out_shape3, const int *h_ksize3, const int *h_stride3,
+                                             const int *h_padding3, const int *h_dilation3, int *out_indices, int out_cap,
+                                             int *num_out, int *prefill_nbr_out, int prefill_nbr_out_rows, int *prefill_nbr_in,
+                                             const void *in_sites_workspace, size_t in_sites_workspace_bytes, void *workspace,
+                                             size_t workspace_bytes, void *stream) {
+    if (n_in < 0 || batch <= 0 || !h_in_shape3 || !h_out_shape3 || !h_ksize3 || !h_stride3 || !h_padding3 || !num_out ||
+        out_cap < 0 || prefill_nbr_out_rows < 0)
+        return SEC_E_INVALID;
+    RbGeom g;
+    int rc = fill_geom(g, h_in_shape3, h_out_shape3, h_ksize3, h_stride3, h_padding3, h_dilation3, n_in, batch);
+    if (rc) return rc;
+    for (int d = 0; d < 3; ++d)
+        if (g.stride[d] > 1 && g.dil[d] > 1) return SEC_E_UNSUPPORTED;
+    const long long cells = bm_cells(batch, h_out_shape3);
+    if (cells >= (1ll << 32) - 64) return SEC_E_UNSUPPORTED;            // cell indices are 32-bit here
+    hipStream_t st = (hipStream_t)stream;
+    BmWorkspace w = carve_bm(workspace, workspace_bytes, n_in, g.kvol, cells);
+    if (!workspace || w.bytes > workspace_bytes) return SEC_E_WORKSPACE;
+    const long long fill_a = prefill_nbr_out ? (long long)prefill_nbr_out_rows * g.kvol : 0;
+    const long long fill_b = prefill_nbr_in ? (long long)n_in * g.kvol : 0;
+    const int geo = geo_of(g);
+    // the inputs are the outputs of an earlier sorted build whose bitmap is still around: no atomics at all
+    const long long cells_in = bm_cells(batch, h_in_shape3);
+    bool dilate = in_sites_workspace && (geo == 1 || geo == 2) && cells_in < (1ll << 32) - 64;
+    for (int d = 0; d < 3; ++d) dilate = dilate && g.pad[d] >= 0 && g.pad[d] <= 1;
+    BmWorkspace wi{};
+    if (dilate) {
+        wi = carve_bm(const_cast<void *>(in_sites_workspace), in_sites_workspace_bytes, 0, 1, cells_in);
+        if (wi.bytes > in_sites_workspace_bytes) return SEC_E_WORKSPACE;
+    }
+    // scan control (+ the bitmap unless the dilation writes every word) := 0, both gather tables := -1, one launch
+    if (dilate)
+        rb_init(reinterpret_cast<unsigned long long *>(w.ticket), w.ctl_words / 2, 0ull, prefill_nbr_out, fill_a, -1, prefill_nbr_in,
+                fill_b, -1, st);
+    else
+        rb_init(reinterpret_cast<unsigned long long *>(w.bm), w.zero_words64, 0ull, prefill_nbr_out, fill_a, -1, prefill_nbr_in,
+                fill_b, -1, st);
+    const long long nc = (long long)n_in * g.ncand;
+    if (dilate) {
+        const unsigned nb = (unsigned)div_up(w.n_words, kBlock);
+        if (geo == 1) hipLaunchKernelGGL(k_bm_dilate<1>, dim3(nb), dim3(kBlock), 0, st, wi.bm, wi.n_words, g, w.bm, w.n_words);
+        else hipLaunchKernelGGL(k_bm_dilate<2>, dim3(nb), dim3(kBlock), 0, st, wi.bm, wi.n_words, g, w.bm, w.n_words);
+    } else if (nc > 0) {
+        const int nb = div_up(nc, kBlock);
+        if (geo == 1) hipLaunchKernelGGL(k_bm_set_x2, dim3(div_up((long long)n_in * 4, kBlock)), dim3(kBlock), 0, st, indices, g, n_in_dev, w.bm);
+        else if (geo == 2) hipLaunchKernelGGL(k_bm_set<2>, dim3(nb), dim3(kBlock), 0, st, indices, g, n_in_dev, w.bm);
+        else hipLaunchKernelGGL(k_bm_set<0>, dim3(nb), dim3(kBlock), 0, st, indices, g, n_in_dev, w.bm);
+    }
+    hipLaunchKernelGGL(k_bm_scan, dim3((unsigned)(w.n_words / kBmTile)), dim3(kBlock), 0, st, w.bm, w.prefix, out_cap, w.status,
+                       w.ticket, num_out);
+    if (out_indices)      // NULL: the caller lets sec_rulebook_conv3d_tables_sorted write them (one launch less)
+        hipLaunchKernelGGL(k_bm_emit, dim3((unsigned)div_up(w.n_words, kBlock)), dim3(kBlock), 0, st, w.bm, w.prefix, g, w.n_words,
+                           out_indices, out_cap);
+    return check_launch();
+}
+
+SEC_API int sec_rulebook_conv3d_tables_sorted(const int *indices, int n_in, const int *n_in_dev, int batch,
+                                              const int *h_in_shape3, const int *h_out_shape3, const int *h_ksize3,
+                                              const int *h_stride3, const int *h_padding3, const int *h_dilation3, int *nbr_out,
+                                              int nbr_out_rows, int *nbr_in, int prefilled, int *out_indices, int out_cap,
+                                              int *pairs, int *pair_num, void *workspace, size_t workspace_bytes, void *stream) {
+    if (n_in < 0 || batch <= 0 || !h_in_shape3 || !h_out_shape3 || !h_ksize3 || !h_stride3 || !h_padding3 ||
+        (nbr_out_rows > 0 && !nbr_out) || nbr_out_rows < 0 || (pairs && (!pair_num || !nbr_in)))
+        return SEC_E_INVALID;
+    RbGeom g;
+    int rc = fill_geom(g, h_in_shape3, h_out_shape3, h_ksize3, h_stride3, h_padding3, h_dilation3, n_in, batch);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    BmWorkspace w = carve_bm(workspace, workspace_bytes, n_in, g.kvol, bm_cells(batch, h_out_shape3));
+    if (!workspace || w.bytes > workspace_bytes) return SEC_E_WORKSPACE;
+    const long long n_out_words = (long long)nbr_out_rows * g.kvol, n_in_words = nbr_in ? (long long)n_in * g.kvol : 0;
+    if (!prefilled && n_out_words + n_in_words > 0) rb_init(nullptr, 0, 0, nbr_out, n_out_words, -1, nbr_in, n_in_words, -1, st);
+    const long long nc = (long long)n_in * g.ncand;
+    if (nc > 0) {
+        const int nb = div_up(nc, kBlock), geo = geo_of(g);
+        if (geo == 1) hipLaunchKernelGGL(k_bm_tables<1>, dim3(nb), dim3(kBlock), 0, st, indices, g, n_in_dev, w.bm, w.prefix, nbr_in, nbr_out, nbr_out_rows, out_indices, out_cap);
+        else if (geo == 2) hipLaunchKernelGGL(k_bm_tables<2>, dim3(nb), dim3(kBlock), 0, st, indices, g, n_in_dev, w.bm, w.prefix, nbr_in, nbr_out, nbr_out_rows, out_indices, out_cap);
+        else hipLaunchKernelGGL(k_bm_tables<0>, dim3(nb), dim3(kBlock), 0, st, indices, g, n_in_dev, w.bm, w.prefix, nbr_in, nbr_out, nbr_out_rows, out_indices, out_cap);
+        if ((rc = check_launch())) return rc;
+    }
+    if (pairs) return emit_pairs(nbr_in, n_in, g.kvol, /*mirror=*/0, w.blk, w.scan2, pairs, pair_num, st);
+    return SEC_OK;
+}
+
+SEC_API int sec_rulebook_subm3d_after_conv_sorted(const int *indices, int n_in, const int *n_in_dev, int batch,
+                                                  const int *h_shape3, const int *h_ksize3, const int *h_dilation3, int *nbr_out,
+                                                  const void *conv_workspace, size_t conv_workspace_bytes, void *stream) {
+    if (n_in < 0 || batch <= 0 || !h_shape3 || !h_ksize3 || (n_in > 0 && !nbr_out) || !conv_workspace) return SEC_E_INVALID;
+    RbGeom g;
+    int rc = fill_geom(g, h_shape3, nullptr, h_ksize3, nullptr, nullptr, h_dilation3, n_in, batch);
+    if (rc) return rc;
+    for (int d = 0; d < 3; ++d)
+        if (g.ksize[d] % 2 == 0) return SEC_E_UNSUPPORTED;
+    // only the bitmap and the prefix array are read: their place in the workspace depends on the grid alone
+    BmWorkspace w = carve_bm(const_cast<void *>(conv_workspace), conv_workspace_bytes, 0, 1, bm_cells(batch, h_shape3));
+    if (w.bytes > conv_workspace_bytes) return SEC_E_WORKSPACE;
+    if (n_in == 0) return SEC_OK;
+    hipStream_t st = (hipStream_t)stream;
+    rb_init(nullptr, 0, 0, nbr_out, (long long)n_in * g.kvol, -1, nullptr, 0, 0, st);
+    const long long nh = (long long)n_in * (g.kvol / 2 + 1);
+    if (g.kvol == 27 && g.ksize[0] == 3 && g.ksize[1] == 3)
+        hipLaunchKernelGGL(k_subm_nbr_bm<true>, dim3(div_up(nh, kBlock)), dim3(kBlock), 0, st, indices, g, n_in_dev, w.bm, w.prefix, nbr_out);
+    else
+        hipLaunchKernelGGL(k_subm_nbr_bm<false>, dim3(div_up(nh, kBlock)), dim3(kBlock), 0, st, indices, g, n_in_dev, w.bm, w.prefix, nbr_out);
+    return check_launch();
+}
+
 
 SEC_API int sec_rulebook_conv3d_tables(int n_in, const int *h_ksize3, const int *h_stride3, const int *h_dilation3,
                                        int out_per_in_hint, int *nbr_out, int nbr_out_rows, int *nbr_in, int prefilled,

@@ -13,6 +13,7 @@ produces the same numbers (tests/test_dropin_reference.py checks that in the bui
     predict          voxelnet.py:377-645        (decode -> score filter -> top-k -> rotated NMS -> direction fix)
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -549,6 +550,7 @@ class SecondDetector(nn.Module):
                              persistent=False)
         self._infer_dtype = None
         self.fused_predict = True
+        self.rulebook_numbering = os.environ.get("SEC_RULEBOOK_NUMBERING", "sorted")
         bf = cfg.get("block_filtering")
         self.voxel_generator = spconv.utils.VoxelGeneratorV2(cfg["voxel_size"], cfg["point_cloud_range"],
                                                             cfg["max_points_per_voxel"], cfg["max_voxels"],
@@ -599,7 +601,18 @@ class SecondDetector(nn.Module):
         """points [N,4] cuda float32 (clouds concatenated), point_offsets [B+1] cuda int32.
 
         ``static=True``: static-capacity, sync-free pipeline (every buffer sized for N rows, live counts stay
-        on the device) -- hipGraph-capturable; call :meth:`check_overflow` whenever the host next syncs."""
+        on the device) -- hipGraph-capturable; call :meth:`check_overflow` whenever the host next syncs.
+
+        The strided rulebooks of this path use ``self.rulebook_numbering`` ("sorted" = spconv's GPU output numbering: no
+        hash table; the row order is internal here -- the dense feature map and the detections are identical to the
+        first-touch form; SEC_RULEBOOK_NUMBERING overrides)."""
+        prev = ops.set_rulebook_numbering(self.rulebook_numbering)
+        try:
+            return self._forward_points(points, point_offsets, static)
+        finally:
+            ops.set_rulebook_numbering(prev)
+
+    def _forward_points(self, points, point_offsets, static=False):
         batch_size = point_offsets.numel() - 1
         nf = self.cfg["num_point_features"]
         if self.pillars:

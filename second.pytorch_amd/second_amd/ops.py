@@ -8,6 +8,7 @@ import torch
 
 import ctypes
 import functools
+import os
 
 from . import runtime as rt
 
@@ -101,6 +102,15 @@ def rulebook_subm(indices, batch_size, spatial_shape, ksize=3, dilation=1, want_
     n = indices.shape[0]
     k = _kvol(ksize)
     dev = indices.device
+    if site_table is not None and not want_pairs and n > 0 and isinstance(site_table[0], str) and site_table[0] == "sorted":
+        ws = site_table[1]
+        ws.record_stream(torch.cuda.current_stream())
+        nbr = torch.empty((n, k), dtype=torch.int32, device=dev)
+        rc = rt.lib().sec_rulebook_subm3d_after_conv_sorted(rt.ptr(indices), n, rt.ptr(n_dev), int(batch_size), rt.i3(spatial_shape),
+                                                            rt.i3(ksize), rt.i3(dilation), rt.ptr(nbr), rt.ptr(ws), ws.numel(), rt.stream())
+        rt.check(rc, "sec_rulebook_subm3d_after_conv_sorted")
+        return {"nbr_out": nbr, "nbr_in": None, "pairs": None, "pair_num": None, "out_indices": indices,
+                "num_out": n, "num_out_dev": n_dev, "out_shape": [int(s) for s in spatial_shape]}
     if site_table is not None and not want_pairs and n > 0:
         ws, cn, cks, cst, cdl, chint = site_table
         ws.record_stream(torch.cuda.current_stream())     # the strided build may have run (and allocated) on another stream
@@ -132,16 +142,81 @@ def _out_per_in(ks, st, dl):
     return tot
 
 
+_numbering = os.environ.get("SEC_RULEBOOK_NUMBERING", "first_touch")
+
+
+def set_rulebook_numbering(mode):
+    """Default output numbering of :func:`rulebook_conv`: "first_touch" (spconv's CPU path = the oracle's canonical order) or
+    "sorted" (spconv's GPU path: ascending linear cell index; no hash table, about half the launches' time).  Returns the
+    previous setting."""
+    global _numbering
+    assert mode in ("first_touch", "sorted")
+    prev, _numbering = _numbering, mode
+    return prev
+
+
+def _rulebook_conv_sorted(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, want_pairs, n_dev, out_cap,
+                          want_nbr_in, in_sites=None):
+    n = indices.shape[0]
+    ks, st, pd, dl = rt.i3(ksize), rt.i3(stride), rt.i3(padding), rt.i3(dilation)
+    k = _kvol(ksize)
+    dev = indices.device
+    out_shape = conv_output_shape(spatial_shape, ksize, stride, padding, dilation)
+    per_in = _out_per_in(ks, st, dl)
+    static = out_cap is not None
+    cap = int(out_cap) if static else max(1, min(n * per_in, int(batch_size) * int(np.prod(out_shape))))
+    out_idx = torch.empty((cap, 4), dtype=torch.int32, device=dev)
+    num_out = torch.empty((2,), dtype=torch.int32, device=dev)
+    l = rt.lib()
+    nbytes = l.sec_rulebook_sorted_workspace_bytes(n, k, int(batch_size), rt.i3(out_shape))
+    if nbytes == 0:
+        raise ValueError("sorted rulebook numbering: output grid too large")
+    ws = rt.workspace(nbytes, dev)
+    pre_out = torch.empty((cap, k), dtype=torch.int32, device=dev) if static else None
+    pre_in = torch.empty((n, k), dtype=torch.int32, device=dev) if (static and (want_nbr_in or want_pairs)) else None
+    geo = (rt.i3(spatial_shape), rt.i3(out_shape), ks, st, pd, dl)
+    in_ws = in_sites[1] if (in_sites is not None and isinstance(in_sites[0], str)) else None
+    if in_ws is not None:
+        in_ws.record_stream(torch.cuda.current_stream())
+    # out_indices are written by the tables call (every candidate knows its output's coordinates)
+    rc = l.sec_rulebook_conv3d_build_sorted(rt.ptr(indices), n, rt.ptr(n_dev), int(batch_size), *geo, None, cap,
+                                            rt.ptr(num_out), rt.ptr(pre_out), cap if static else 0, rt.ptr(pre_in),
+                                            rt.ptr(in_ws), in_ws.numel() if in_ws is not None else 0, rt.ptr(ws),
+                                            ws.numel(), rt.stream())
+    rt.check(rc, "sec_rulebook_conv3d_build_sorted")
+    m = cap if static else int(num_out[0].item())
+    nbr_out = pre_out if static else torch.empty((m, k), dtype=torch.int32, device=dev)
+    if static:
+        nbr_in = pre_in
+    else:
+        nbr_in = torch.empty((n, k), dtype=torch.int32, device=dev) if (want_nbr_in or want_pairs) else None
+    pairs = torch.empty((k, 2, n), dtype=torch.int32, device=dev) if want_pairs else None
+    pair_num = torch.zeros((k,), dtype=torch.int32, device=dev) if want_pairs else None
+    rc = l.sec_rulebook_conv3d_tables_sorted(rt.ptr(indices), n, rt.ptr(n_dev), int(batch_size), *geo, rt.ptr(nbr_out), m,
+                                             rt.ptr(nbr_in), 1 if static else 0, rt.ptr(out_idx), cap, rt.ptr(pairs),
+                                             rt.ptr(pair_num), rt.ptr(ws), ws.numel(), rt.stream())
+    rt.check(rc, "sec_rulebook_conv3d_tables_sorted")
+    return {"nbr_out": nbr_out, "nbr_in": nbr_in, "pairs": pairs, "pair_num": pair_num,
+            "out_indices": out_idx[:m], "num_out": m, "num_out_dev": num_out if static else None,
+            "out_shape": out_shape, "site_table": ("sorted", ws) if n > 0 else None}
+
+
 @_traced("rulebook_conv")
 def rulebook_conv(indices, batch_size, spatial_shape, ksize, stride, padding, dilation=1, want_pairs=False,
-                  n_dev=None, out_cap=None, out_per_in_hint=0, want_nbr_in=True):
-    """SparseConv3d rulebook (spconv.ops.get_indice_pairs(subm=False)), first-touch output numbering.
+                  n_dev=None, out_cap=None, out_per_in_hint=0, want_nbr_in=True, numbering=None, in_sites=None):
+    """SparseConv3d rulebook (spconv.ops.get_indice_pairs(subm=False)); output numbering "first_touch" (default: spconv's CPU
+    path, the oracle's canonical order) or "sorted" (spconv's GPU path, ascending linear cell index) -- see
+    :func:`set_rulebook_numbering`.  ``in_sites`` (sorted numbering only): the ``site_table`` entry of the sorted build whose
+    out_indices these ``indices`` are -- the output bitmap is then derived from that build's bitmap without atomics.
 
     Eager mode (default): one D2H sync for the active-output count, like the reference's numActOut.
     Static-capacity mode (``out_cap`` given, optional ``n_dev``): no sync; tables are sized ``out_cap`` rows,
     ``num_out_dev`` int32[2] = (live outputs clamped to out_cap, raw count for the overflow check)."""
     rt.require_gpu(indices)
     assert indices.dtype == torch.int32 and indices.is_contiguous()
+    if (numbering or _numbering) == "sorted":
+        return _rulebook_conv_sorted(indices, batch_size, spatial_shape, ksize, stride, padding, dilation, want_pairs, n_dev,
+                                     out_cap, want_nbr_in, in_sites)
     n = indices.shape[0]
     ks, st = rt.i3(ksize), rt.i3(stride)
     k = _kvol(ksize)

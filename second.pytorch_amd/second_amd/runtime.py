@@ -20,7 +20,8 @@ _ERRORS = {-1: "SEC_E_INVALID (bad argument)", -2: "SEC_E_WORKSPACE (workspace t
 SYMBOLS = [
     "sec_abi_version", "sec_last_error", "sec_voxelize_workspace_bytes", "sec_voxelize_f32",
     "sec_rulebook_workspace_bytes", "sec_rulebook_subm3d", "sec_rulebook_subm3d_after_conv", "sec_rulebook_conv3d_build",
-    "sec_rulebook_conv3d_tables", "sec_conv_output_shape", "sec_packed_weight_bytes",
+    "sec_rulebook_conv3d_tables", "sec_rulebook_sorted_workspace_bytes", "sec_rulebook_conv3d_build_sorted",
+    "sec_rulebook_conv3d_tables_sorted", "sec_rulebook_subm3d_after_conv_sorted", "sec_conv_output_shape", "sec_packed_weight_bytes",
     "sec_pack_conv_weight", "sec_indice_conv_fwd", "sec_indice_conv_fwd_plan", "sec_indice_conv_set_variant", "sec_indice_conv_bwd_workspace_bytes", "sec_indice_conv_bwd", "sec_sparse_to_dense", "sec_dense_to_sparse",
     "sec_pillar_scatter", "sec_pfn_fwd", "sec_block_filter_workspace_bytes",
     "sec_voxel_block_filter_f32", "sec_bias_act_nhwc", "sec_conv2d_packed_weight_bytes",
@@ -46,7 +47,7 @@ def lib():
                 f"{LIB_PATH} is missing: build it with `python second.pytorch_amd/build.py` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
         l = ctypes.CDLL(LIB_PATH)
-        for name in ("sec_voxelize_workspace_bytes", "sec_rulebook_workspace_bytes",
+        for name in ("sec_voxelize_workspace_bytes", "sec_rulebook_workspace_bytes", "sec_rulebook_sorted_workspace_bytes",
                      "sec_packed_weight_bytes", "sec_nms_workspace_bytes", "sec_block_filter_workspace_bytes",
                      "sec_conv2d_packed_weight_bytes", "sec_indice_conv_bwd_workspace_bytes",
                      "sec_assign_targets_workspace_bytes", "sec_second_loss_workspace_bytes"):
@@ -61,6 +62,10 @@ def lib():
         l.sec_rulebook_subm3d_after_conv.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp, vp, sz, ci, vp, vp, vp, ci, vp]
         l.sec_rulebook_conv3d_build.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, vp, ci, vp, ci, vp, vp, sz, vp]
         l.sec_rulebook_conv3d_tables.argtypes = [ci, vp, vp, vp, ci, vp, ci, vp, ci, vp, vp, vp, sz, vp]
+        l.sec_rulebook_sorted_workspace_bytes.argtypes = [ci, ci, ci, vp]
+        l.sec_rulebook_conv3d_build_sorted.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, vp, vp, ci, vp, vp, sz, vp, sz, vp]
+        l.sec_rulebook_conv3d_tables_sorted.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, vp, ci, vp, ci, vp, vp, vp, sz, vp]
+        l.sec_rulebook_subm3d_after_conv_sorted.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp, vp, sz, vp]
         l.sec_conv_output_shape.argtypes = [vp] * 6
         l.sec_packed_weight_bytes.argtypes = [ci, ci, ci, ci]
         l.sec_pack_conv_weight.argtypes = [vp, ci, ci, ci, ci, vp, vp]

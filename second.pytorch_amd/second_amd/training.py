@@ -60,6 +60,13 @@ class DeviceTrainer:
         self.last = {}
 
     def forward_loss(self, points, point_offsets, gt_boxes, gt_offsets, gt_classes=None):
+        prev = ops.set_rulebook_numbering(self.det.rulebook_numbering)    # row order of the strided layers is internal here
+        try:
+            return self._forward_loss(points, point_offsets, gt_boxes, gt_offsets, gt_classes)
+        finally:
+            ops.set_rulebook_numbering(prev)
+
+    def _forward_loss(self, points, point_offsets, gt_boxes, gt_offsets, gt_classes=None):
         det, cfg = self.det, self.cfg
         batch = point_offsets.numel() - 1
         with torch.no_grad():

@@ -82,19 +82,30 @@ class SparseConvolution(SparseModule):
             hint = max(1, -(-cap // max(indices.shape[0], 1)))
             r = _ops.rulebook_conv(indices, x.batch_size, x.spatial_shape, self.kernel_size, self.stride, self.padding,
                                    self.dilation, n_dev=nd, out_cap=cap, out_per_in_hint=hint,
-                                   want_nbr_in=torch.is_grad_enabled())
+                                   want_nbr_in=torch.is_grad_enabled(), in_sites=self._in_sites(x, indices))
         else:
             r = _ops.rulebook_conv(indices, x.batch_size, x.spatial_shape, self.kernel_size, self.stride, self.padding,
-                                   self.dilation, want_nbr_in=torch.is_grad_enabled())
+                                   self.dilation, want_nbr_in=torch.is_grad_enabled(), in_sites=self._in_sites(x, indices))
         rb = Rulebook(r["out_indices"], indices, r["nbr_out"], r["nbr_in"], r["num_out"], x.spatial_shape,
                       r["out_shape"], self.subm, num_out_dev=r["num_out_dev"])
         if r.get("site_table") is not None:
             rb._site_table = ((r["out_indices"].data_ptr(), r["out_indices"].shape[0]), r["site_table"])
+            if isinstance(r["site_table"][0], str):      # its bitmap also serves the NEXT strided build (kept until then)
+                rb._site_bitmap = rb._site_table
         if self.indice_key is not None:
             x.indice_dict[self.indice_key] = rb
         if nd is None:
             self.last_num_out = rb.num_out
         return rb
+
+    @staticmethod
+    def _in_sites(x, indices):
+        """The sorted-numbering site table of the strided layer that produced these sites (carried through the SubM layers
+        of the stage), if it still describes exactly this index tensor."""
+        tbl = getattr(x, "site_bitmap", None)
+        if tbl is not None and tbl[0] == (indices.data_ptr(), indices.shape[0]):
+            return tbl[1]
+        return None
 
     def packed_weight(self):
         w = self.weight
@@ -113,6 +124,9 @@ class SparseConvolution(SparseModule):
         out.indice_dict = x.indice_dict
         if not rb.subm:
             out.site_table = rb.__dict__.pop("_site_table", None)   # handed to the next SubM rulebook build, then dropped
+            out.site_bitmap = rb.__dict__.pop("_site_bitmap", None)
+        else:
+            out.site_bitmap = getattr(x, "site_bitmap", None)       # same sites: still valid for the next strided build
         return out
 
     # -- forward ----------------------------------------------------------------------------------

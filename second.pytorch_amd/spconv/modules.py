@@ -89,6 +89,7 @@ class SparseSequential(SparseModule):
                     nxt.indice_dict = cur.indice_dict
                     nxt.overflow_checks = cur.overflow_checks + [(rb.num_out_dev, rb.out_indices.shape[0])]
                     nxt.site_table = rb.__dict__.pop("_site_table", None)
+                    nxt.site_bitmap = rb.__dict__.pop("_site_bitmap", None)
                     cur = nxt
                     level_ready = ev
         self._planned_overflow = cur.overflow_checks

@@ -155,6 +155,89 @@ def test_rulebook_conv_bit_exact(ops, ksize, stride, padding, dilation):
     np.testing.assert_array_equal(rb["nbr_in"].cpu().numpy(), nbr_in)
 
 
+@pytest.mark.parametrize("ksize,stride,padding,dilation", [
+    (3, 2, 1, 1), (3, 2, (0, 1, 1), 1), ((3, 1, 1), (2, 1, 1), 0, 1), (3, 1, 0, 1), (2, 2, 0, 1), (3, 1, 1, 1), (3, 3, 1, 1),
+    (3, 1, 2, 2), (3, (2, 1, 1), 1, (1, 2, 2)), (5, 2, 2, 1), (4, 2, 1, 1)])
+def test_rulebook_conv_sorted_numbering_bit_exact(ops, ksize, stride, padding, dilation):
+    """numbering="sorted" (spconv's GPU path: outputs by ascending linear cell index) -- bitmap + rank build,
+    no hash table -- against the oracle's restatement, same 11 geometries as the first-touch form."""
+    rng = np.random.default_rng(1)
+    shape = (11, 24, 19)
+    idx = _random_indices(rng, 2, shape, 500)
+    rb = ops.rulebook_conv(dev(idx), 2, shape, ksize, stride, padding, dilation, want_pairs=True, numbering="sorted")
+    out_idx, pairs, pair_num, out_shape = orc.rulebook_conv_sorted(idx, 2, shape, ksize, stride, padding, dilation)
+    assert rb["out_shape"] == out_shape.tolist() and rb["num_out"] == len(out_idx)
+    np.testing.assert_array_equal(rb["out_indices"].cpu().numpy(), out_idx)
+    lin = ((out_idx[:, 0].astype(np.int64) * out_shape[0] + out_idx[:, 1]) * out_shape[1] + out_idx[:, 2]) * out_shape[2] + out_idx[:, 3]
+    assert np.all(np.diff(lin) > 0)
+    np.testing.assert_array_equal(rb["pair_num"].cpu().numpy(), pair_num)
+    np.testing.assert_array_equal(rb["pairs"].cpu().numpy(), pairs)
+    nbr_out, nbr_in = _tables_from_pairs(pairs, pair_num, len(idx), len(out_idx))
+    np.testing.assert_array_equal(rb["nbr_out"].cpu().numpy(), nbr_out)
+    np.testing.assert_array_equal(rb["nbr_in"].cpu().numpy(), nbr_in)
+    # the same convolution as the first-touch rulebook: identical (offset, input coordinate, output coordinate) triples
+    ft = ops.rulebook_conv(dev(idx), 2, shape, ksize, stride, padding, dilation, want_pairs=True)
+    def triples(r):
+        oi, pr, pn = r["out_indices"].cpu().numpy(), r["pairs"].cpu().numpy(), r["pair_num"].cpu().numpy()
+        return {(k, tuple(idx[pr[k, 0, i]]), tuple(oi[pr[k, 1, i]])) for k in range(len(pn)) for i in range(pn[k])}
+    assert triples(rb) == triples(ft)
+    # inference form + SubM layer on the outputs through the bitmap ranks == stand-alone SubM build
+    lean = ops.rulebook_conv(dev(idx), 2, shape, ksize, stride, padding, dilation, want_nbr_in=False, numbering="sorted")
+    assert lean["nbr_in"] is None and torch.equal(lean["nbr_out"], rb["nbr_out"])
+    sub_reuse = ops.rulebook_subm(lean["out_indices"], 2, lean["out_shape"], 3, 1, site_table=lean["site_table"])
+    sub_plain = ops.rulebook_subm(lean["out_indices"].clone(), 2, lean["out_shape"], 3, 1)
+    assert torch.equal(sub_reuse["nbr_out"], sub_plain["nbr_out"])
+
+
+@pytest.mark.parametrize("shape", [(11, 24, 19), (9, 16, 64), (5, 33, 96), (41, 40, 32)])
+def test_rulebook_conv_sorted_chain_from_input_bitmap(ops, shape):
+    """A chain of sorted-numbering strided layers (the SpMiddleFHD pattern: 3x3x3 s2 p1, 3x3x3 s2 p(0,1,1), (3,1,1) s(2,1,1)): from
+    the second layer on the output bitmap is derived from the previous layer's bitmap (no atomics).  Row widths that are and are
+    not multiples of 32 (words straddling row ends), each layer against the oracle."""
+    rng = np.random.default_rng(7)
+    batch = 3
+    idx = _random_indices(rng, batch, shape, 900)
+    layers = [(3, 2, 1), (3, 2, (0, 1, 1)), ((3, 1, 1), (2, 1, 1), 0)]
+    cur, cur_shape, sites = idx, list(shape), None
+    for li, (ks, st, pd) in enumerate(layers):
+        if min(cur_shape) < 3:
+            break
+        want_idx, pairs, pair_num, out_shape = orc.rulebook_conv_sorted(cur, batch, cur_shape, ks, st, pd, 1)
+        rb = ops.rulebook_conv(dev(cur), batch, cur_shape, ks, st, pd, 1, want_pairs=True, numbering="sorted", in_sites=sites)
+        assert rb["num_out"] == len(want_idx), (li, rb["num_out"], len(want_idx))
+        np.testing.assert_array_equal(rb["out_indices"].cpu().numpy(), want_idx, err_msg=f"layer {li}")
+        np.testing.assert_array_equal(rb["pairs"].cpu().numpy(), pairs)
+        # the atomics form of the same layer
+        plain = ops.rulebook_conv(dev(cur), batch, cur_shape, ks, st, pd, 1, numbering="sorted")
+        assert torch.equal(plain["out_indices"], rb["out_indices"]) and torch.equal(plain["nbr_out"], rb["nbr_out"])
+        cur, cur_shape, sites = want_idx, [int(v) for v in out_shape], rb["site_table"]
+
+
+def test_rulebook_conv_sorted_static_capacity_and_overflow(ops):
+    """static-capacity form (device row counts, caller-owned tables) of the sorted numbering, with padding rows and with a
+    capacity smaller than the output count (overflow reported in num_out[1], nothing written past the tables)."""
+    rng = np.random.default_rng(5)
+    shape = (11, 24, 19)
+    idx = _random_indices(rng, 2, shape, 400)
+    want_idx, pairs, pair_num, out_shape = orc.rulebook_conv_sorted(idx, 2, shape, 3, 2, 1, 1)
+    m = len(want_idx)
+    padded = np.concatenate([idx, np.full((100, 4), 7, np.int32)])           # rows beyond n_dev are garbage
+    n_dev = dev(np.array([len(idx)], np.int32))
+    rb = ops.rulebook_conv(dev(padded), 2, shape, 3, 2, 1, 1, n_dev=n_dev, out_cap=m + 50, numbering="sorted")
+    cnt = rb["num_out_dev"].cpu().numpy()
+    assert cnt.tolist() == [m, m]
+    np.testing.assert_array_equal(rb["out_indices"].cpu().numpy()[:m], want_idx)
+    nbr_out, nbr_in = _tables_from_pairs(pairs, pair_num, len(idx), m)
+    np.testing.assert_array_equal(rb["nbr_out"].cpu().numpy()[:m], nbr_out)
+    assert (rb["nbr_out"].cpu().numpy()[m:] == -1).all()
+    np.testing.assert_array_equal(rb["nbr_in"].cpu().numpy()[:len(idx)], nbr_in)
+    small = ops.rulebook_conv(dev(padded), 2, shape, 3, 2, 1, 1, n_dev=n_dev, out_cap=m - 40, numbering="sorted")
+    cnt = small["num_out_dev"].cpu().numpy()
+    assert cnt.tolist() == [m - 40, m]
+    np.testing.assert_array_equal(small["out_indices"].cpu().numpy(), want_idx[:m - 40])
+    np.testing.assert_array_equal(small["nbr_out"].cpu().numpy(), nbr_out[:m - 40])
+
+
 def test_rulebook_conv_stride_with_dilation_is_refused(ops):
     from second_amd.runtime import SecondHipError
     idx = _random_indices(np.random.default_rng(2), 1, (11, 24, 19), 50)
@@ -920,3 +1003,37 @@ def test_predict_select_tie_ranking(levels, k):
     assert torch.equal(top_idx.long(), order), (levels, k)
     np.testing.assert_allclose(top_score.cpu().numpy(), torch.sigmoid(torch.gather(flat, 1, order)).cpu().numpy(), rtol=1e-6)
     assert torch.equal(counts.long(), (torch.sigmoid(torch.gather(flat, 1, order)) >= 0.3).sum(1))
+
+
+def test_detector_sorted_and_first_touch_numbering_give_identical_results(syn):
+    """The device fast path numbers the strided layers' outputs the spconv-GPU way ("sorted", no hash table); the row order is
+    internal: the dense RPN input and the detections are bit-identical to the first-touch (spconv-CPU / oracle) numbering, in
+    eager, static-capacity and bf16 inference form."""
+    from second_amd import ops
+    from second_amd.models import SecondDetector, CAR_FHD
+    torch.manual_seed(0)
+    det = SecondDetector(CAR_FHD).cuda().eval()
+    pts, offs = syn.batch_clouds([syn.syn_kitti_cloud(s, num_points=9000, num_voxels=8000) for s in range(3)])
+    pts, offs = dev(pts), dev(offs)
+    res = {}
+    with torch.no_grad():
+        vox = det.voxel_generator.generate_device(pts, offs, mean_features=4)
+        for mode in ("first_touch", "sorted"):
+            prev = ops.set_rulebook_numbering(mode)
+            try:
+                res["dense", mode] = det.middle_feature_extractor(vox["mean"], vox["coordinates"], 3)
+            finally:
+                ops.set_rulebook_numbering(prev)
+            det.rulebook_numbering = mode
+            res["eager", mode] = det.forward_points(pts, offs)
+            res["static", mode] = det.forward_points(pts, offs, static=True)
+        det.prepare_inference(torch.bfloat16)
+        for mode in ("first_touch", "sorted"):
+            det.rulebook_numbering = mode
+            res["bf16", mode] = det.forward_points(pts, offs, static=True)
+    assert torch.equal(res["dense", "first_touch"], res["dense", "sorted"])
+    for form in ("eager", "static", "bf16"):
+        a, b = res[form, "first_touch"], res[form, "sorted"]
+        assert a["valid"].any() and torch.equal(a["valid"], b["valid"])
+        m = a["valid"]
+        assert torch.equal(a["scores"][m], b["scores"][m]) and torch.equal(a["boxes"][m], b["boxes"][m])

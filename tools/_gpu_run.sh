@@ -1,4 +1,7 @@
 mkdir -p gpurun_out/r2z
 export PYTHONUNBUFFERED=1
-SEC_HIP_LIB=$PWD/second.pytorch_amd/lib/libsecond_hip_exp.so timeout 600 python tools/conv_microbench.py --all-layers --variants 29,19,32,33 > gpurun_out/r2z/layers_deep.txt 2>&1
-grep "layer  [6-9]\|layer 1[0-3]\|sum" gpurun_out/r2z/layers_deep.txt | cut -c1-260
+timeout 600 python bench.py --no-cpu-baseline --no-kernel-table 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('inflight3', d['value'], d['ms_per_step'], d['config'].get('single_step_latency_ms'))"
+timeout 300 python bench.py --inflight 1 --no-kernel-table --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('inflight1', d['value'], d['ms_per_step'])"
+SEC_RULEBOOK_NUMBERING=first_touch timeout 300 python bench.py --inflight 1 --no-kernel-table --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('inflight1 first_touch', d['value'], d['ms_per_step'])"
+timeout 1500 python -m pytest tests -m gpu -q -x > gpurun_out/r2z/pytest_all.log 2>&1; echo "rc=$?" >> gpurun_out/r2z/pytest_all.log
+tail -5 gpurun_out/r2z/pytest_all.log
