@@ -102,6 +102,16 @@ int sec_rulebook_subm3d_after_conv(const int *indices, int n_in, const int *n_in
                                    int conv_n_in, const int *h_conv_ksize3, const int *h_conv_stride3,
                                    const int *h_conv_dilation3, int conv_out_per_in_hint, void *stream);
 
+/* SubMConv3d on the voxels of a sec_voxelize_f32 call whose workspace is still intact (the first layer of SpMiddleFHD,
+ * middle.py:146): the voxeliser's hash table (cell -> voxel row) is this layer's site lookup, no re-hash.  `indices` must be
+ * that call's coors (all rows, unfiltered), vox_* its num_points / max_voxels / max_points arguments, h_vox_grid3_zyx its
+ * grid in (z, y, x) order (<= h_shape3 per dim).  Same nbr_out as sec_rulebook_subm3d. */
+int sec_rulebook_subm3d_after_voxelize(const int *indices, int n_in, const int *n_in_dev, int batch,
+                                       const int *h_shape3, const int *h_ksize3, const int *h_dilation3,
+                                       int *nbr_out, const void *vox_workspace, size_t vox_workspace_bytes,
+                                       int vox_num_points, int vox_max_voxels, int vox_max_points,
+                                       const int *h_vox_grid3_zyx, void *stream);
+
 /* SparseConv3d, step 1: discover the active outputs in first-touch order (oracle numbering).
  *   A dim with both stride > 1 and dilation > 1 returns SEC_E_UNSUPPORTED (no SECOND config has one).
  *   out_indices [out_cap,4]; num_out = device int[2]: [0] live outputs clamped to out_cap (feed it to the

@@ -181,4 +181,8 @@ constexpr int kScanTile = kBlock * kScanItems;     // 2048 per block
 inline size_t scan_scratch_ints(long long n) { return (size_t)div_up(n, kScanTile) + 8; }
 int exclusive_scan_i32(const int *in, int *out, long long n, int *total_out, int *scratch, hipStream_t st);
 
+// voxelize.hip: hash table left in the workspace of sec_voxelize_f32 (see sec_rulebook_subm3d_after_voxelize)
+bool vox_table_of(const void *ws, size_t bytes, int n, int batch, int max_voxels, int max_points, const unsigned long long **keys,
+                  const int **svid, uint32_t *mask);
+
 }  // namespace sec

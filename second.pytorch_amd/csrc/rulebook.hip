@@ -459,8 +459,10 @@ static int emit_pairs(const int *table, int n, int kvol, int mirror, int *blk, i
 //   * from the INPUT sites' bitmap when the inputs are themselves the outputs of a sorted build (k_bm_dilate): an output word
 //     is the OR over the <= 9 (z, y) input rows of a 65-bit input window, every second bit kept -- plain loads and stores, no atomics.
 // Pair order inside an offset stays ascending input row (emit_pairs), where the reference's GPU path has atomic-arrival order.
-constexpr int kBmWpt = 64;                       // bitmap words per thread of the scan (256 contiguous bytes): few tiles -> short look-back chain
-constexpr int kBmTile = kBlock * kBmWpt;         // words per scan tile
+constexpr int kBmWpt = 64;                       // bitmap words per thread of the scan of a LARGE grid (few tiles -> short look-back chain)
+constexpr int kBmWptSmall = 16;                  // ... of a small one (the 64-word form has an ~8 us floor of serial per-thread work)
+constexpr int kBmTile = kBlock * kBmWpt;         // words per scan tile = padding unit of the bitmap
+constexpr long long kBmSmallWords = 1 << 20;     // grids up to this many words take the 16-word form (<= 256 tiles)
 
 template <int GEO>
 __device__ __forceinline__ bool bm_candidate(const RbGeom &g, int4 q, int c, int *k_out, unsigned *lin_out, int *out) {
@@ -621,16 +623,17 @@ __global__ __launch_bounds__(kBlock) void k_bm_dilate(const unsigned *__restrict
 
 // ranks: exclusive scan of the word popcounts (decoupled look-back over tiles of kBmTile words) -> prefix[] per word,
 // num_out[0] = live outputs (clamped to out_cap), num_out[1] = raw count
+template <int WPT>
 __global__ __launch_bounds__(kBlock) void k_bm_scan(const unsigned *__restrict__ bm, int *__restrict__ prefix, int out_cap,
                                                    unsigned long long *__restrict__ status, int *__restrict__ ticket,
                                                    int *__restrict__ num_out) {
     __shared__ int smem[8];
     __shared__ int s_tile;
     const int tile = scan_take_tile(ticket, &s_tile);
-    const size_t base = ((size_t)tile * kBlock + threadIdx.x) * kBmWpt;
+    const size_t base = ((size_t)tile * kBlock + threadIdx.x) * WPT;
     int cnt = 0;
 #pragma unroll
-    for (int i = 0; i < kBmWpt / 4; ++i) {
+    for (int i = 0; i < WPT / 4; ++i) {
         const uint4 w4 = *reinterpret_cast<const uint4 *>(bm + base + 4 * i);
         cnt += __popc(w4.x) + __popc(w4.y) + __popc(w4.z) + __popc(w4.w);
     }
@@ -641,7 +644,7 @@ __global__ __launch_bounds__(kBlock) void k_bm_scan(const unsigned *__restrict__
         if (tot > out_cap) num_out[0] = out_cap;
     }
 #pragma unroll
-    for (int i = 0; i < kBmWpt / 4; ++i) {
+    for (int i = 0; i < WPT / 4; ++i) {
         const uint4 w4 = *reinterpret_cast<const uint4 *>(bm + base + 4 * i);      // second read: L1 / L2 hit
         int4 pf;
         pf.x = r; r += __popc(w4.x);
@@ -880,6 +883,39 @@ SEC_API int sec_rulebook_subm3d_after_conv(const int *indices, int n_in, const i
     return check_launch();
 }
 
+SEC_API int sec_rulebook_subm3d_after_voxelize(const int *indices, int n_in, const int *n_in_dev, int batch, const int *h_shape3,
+                                               const int *h_ksize3, const int *h_dilation3, int *nbr_out,
+                                               const void *vox_workspace, size_t vox_workspace_bytes, int vox_num_points,
+                                               int vox_max_voxels, int vox_max_points, const int *h_vox_grid3_zyx, void *stream) {
+    if (n_in < 0 || batch <= 0 || !h_shape3 || !h_ksize3 || (n_in > 0 && !nbr_out) || !vox_workspace || !h_vox_grid3_zyx)
+        return SEC_E_INVALID;
+    RbGeom g;
+    int rc = fill_geom(g, h_shape3, nullptr, h_ksize3, nullptr, nullptr, h_dilation3, n_in, batch);
+    if (rc) return rc;
+    for (int d = 0; d < 3; ++d) {
+        if (g.ksize[d] % 2 == 0) return SEC_E_UNSUPPORTED;
+        if (h_vox_grid3_zyx[d] <= 0 || h_vox_grid3_zyx[d] > h_shape3[d]) return SEC_E_INVALID;
+        // the voxeliser keys its cells with ITS grid (SpMiddleFHD's sparse shape has one more z plane, middle.py:139); a
+        // neighbour outside that grid holds no voxel, so bounding the lookups by it is exact
+        g.in_shape[d] = h_vox_grid3_zyx[d];
+    }
+    const unsigned long long *keys;
+    const int *svid;
+    uint32_t mask;
+    if (!vox_table_of(vox_workspace, vox_workspace_bytes, vox_num_points, batch, vox_max_voxels, vox_max_points, &keys, &svid, &mask))
+        return SEC_E_WORKSPACE;
+    if (n_in == 0) return SEC_OK;
+    g.mask = mask;
+    hipStream_t st = (hipStream_t)stream;
+    rb_init(nullptr, 0, 0, nbr_out, (long long)n_in * g.kvol, -1, nullptr, 0, 0, st);
+    const long long nh = (long long)n_in * (g.kvol / 2 + 1);
+    if (g.kvol == 27 && g.ksize[0] == 3 && g.ksize[1] == 3)
+        hipLaunchKernelGGL(k_subm_nbr_sym<true>, dim3(div_up(nh, kBlock)), dim3(kBlock), 0, st, indices, g, n_in_dev, keys, svid, nbr_out);
+    else
+        hipLaunchKernelGGL(k_subm_nbr_sym<false>, dim3(div_up(nh, kBlock)), dim3(kBlock), 0, st, indices, g, n_in_dev, keys, svid, nbr_out);
+    return check_launch();
+}
+
 SEC_API int sec_rulebook_conv3d_build(const int *indices, int n_in, const int *n_in_dev, int batch, const int *h_in_shape3,
                                       const int *h_out_shape3, const int *h_ksize3, const int *h_stride3,
                                       const int *h_padding3, const int *h_dilation3, int *out_indices, int out_cap,
@@ -947,7 +983,7 @@ static BmWorkspace carve_bm(void *ws, size_t cap, int n_in, int kvol, long long 
     w.n_words = (long long)div_up(div_up(cells > 0 ? cells : 1, 32), kBmTile) * kBmTile;
     w.bm = a.take<unsigned>(w.n_words);
     // the scan's control block directly behind the bitmap: ONE zero fill covers both
-    w.ctl_words = (long long)scan_ctl_words(w.n_words / kBmWpt);
+    w.ctl_words = (long long)scan_ctl_words(w.n_words / kBmWptSmall);   // status words for the finer of the two tilings
     w.ticket = a.take<int>(w.ctl_words);
     w.status = reinterpret_cast<unsigned long long *>(w.ticket + 4);
     w.zero_words64 = (long long)((reinterpret_cast<char *>(w.ticket + w.ctl_words) - reinterpret_cast<char *>(w.bm)) / 8);
@@ -1016,8 +1052,12 @@ SEC_API int sec_rulebook_conv3d_build_sorted(const int *indices, int n_in, const
         else if (geo == 2) hipLaunchKernelGGL(k_bm_set<2>, dim3(nb), dim3(kBlock), 0, st, indices, g, n_in_dev, w.bm);
         else hipLaunchKernelGGL(k_bm_set<0>, dim3(nb), dim3(kBlock), 0, st, indices, g, n_in_dev, w.bm);
     }
-    hipLaunchKernelGGL(k_bm_scan, dim3((unsigned)(w.n_words / kBmTile)), dim3(kBlock), 0, st, w.bm, w.prefix, out_cap, w.status,
-                       w.ticket, num_out);
+    if (w.n_words <= kBmSmallWords)
+        hipLaunchKernelGGL(k_bm_scan<kBmWptSmall>, dim3((unsigned)(w.n_words / (kBlock * kBmWptSmall))), dim3(kBlock), 0, st, w.bm,
+                           w.prefix, out_cap, w.status, w.ticket, num_out);
+    else
+        hipLaunchKernelGGL(k_bm_scan<kBmWpt>, dim3((unsigned)(w.n_words / kBmTile)), dim3(kBlock), 0, st, w.bm, w.prefix, out_cap,
+                           w.status, w.ticket, num_out);
     if (out_indices)      // NULL: the caller lets sec_rulebook_conv3d_tables_sorted write them (one launch less)
         hipLaunchKernelGGL(k_bm_emit, dim3((unsigned)div_up(w.n_words, kBlock)), dim3(kBlock), 0, st, w.bm, w.prefix, g, w.n_words,
                            out_indices, out_cap);

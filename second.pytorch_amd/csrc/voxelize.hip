@@ -232,6 +232,18 @@ static VoxWorkspace carve_vox(void *ws, size_t cap, int n, int batch, int max_vo
     return w;
 }
 
+// the voxel hash table of a finished sec_voxelize_f32 call (cell key -> slot, svid[slot] = voxel row): the first SubM rulebook
+// looks its sites up here instead of hashing them again (sec_rulebook_subm3d_after_voxelize)
+bool vox_table_of(const void *ws, size_t bytes, int n, int batch, int max_voxels, int max_points, const unsigned long long **keys,
+                  const int **svid, uint32_t *mask) {
+    VoxWorkspace w = carve_vox(const_cast<void *>(ws), bytes, n, batch, max_voxels, max_points);
+    if (!ws || w.bytes > bytes) return false;
+    *keys = w.keys;
+    *svid = w.svid;
+    *mask = w.table - 1;
+    return true;
+}
+
 }  // namespace sec
 
 using namespace sec;

@@ -250,9 +250,13 @@ class SpMiddleFHD(nn.Module):
         self.overlap_rulebooks_split = os.environ.get("SEC_OVERLAP_RULEBOOKS", "0") == "2"
         self._side_stream = None
 
-    def forward(self, voxel_features, coors, batch_size, channels_last=False, num_active_dev=None):
+    def forward(self, voxel_features, coors, batch_size, channels_last=False, num_active_dev=None, site_table=None):
+        """``site_table``: the ``site_table`` entry of the ops.voxelize result these (unfiltered) coors come from -- the first
+        SubM rulebook then looks its sites up in the voxeliser's hash table instead of hashing them again."""
         x = spconv.SparseConvTensor(voxel_features, coors.int(), self.sparse_shape, batch_size,
                                     num_active_dev=num_active_dev)
+        if site_table is not None and x.indices.data_ptr() == coors.data_ptr():
+            x.site_table = ((x.indices.data_ptr(), x.indices.shape[0]), site_table)
         side = None
         if num_active_dev is not None and self.overlap_rulebooks:
             # static pipeline: all 8 rulebooks on a side stream, overlapped with the conv layers (fork / join)
@@ -575,7 +579,7 @@ class SecondDetector(nn.Module):
         return self
 
     # -- stages ------------------------------------------------------------------------------------
-    def network_forward(self, voxel_features, coors, batch_size, num_active_dev=None):
+    def network_forward(self, voxel_features, coors, batch_size, num_active_dev=None, site_table=None):
         dt = self._infer_dtype
         if self.pillars:
             spatial = self.middle_feature_extractor(voxel_features if dt is None else voxel_features.to(dt), coors,
@@ -583,9 +587,10 @@ class SecondDetector(nn.Module):
             return self.rpn(spatial)
         if dt is not None:
             spatial = self.middle_feature_extractor(voxel_features.to(dt), coors, batch_size, channels_last=True,
-                                                    num_active_dev=num_active_dev)
+                                                    num_active_dev=num_active_dev, site_table=site_table)
         else:
-            spatial = self.middle_feature_extractor(voxel_features, coors, batch_size, num_active_dev=num_active_dev)
+            spatial = self.middle_feature_extractor(voxel_features, coors, batch_size, num_active_dev=num_active_dev,
+                                                    site_table=site_table)
         return self.rpn(spatial)
 
     def forward(self, example):
@@ -624,11 +629,11 @@ class SecondDetector(nn.Module):
             return self.predict_device(preds, batch_size)
         if not static:
             vox = self.voxel_generator.generate_device(points, point_offsets, mean_features=nf)
-            preds = self.network_forward(vox["mean"], vox["coordinates"], batch_size)
+            preds = self.network_forward(vox["mean"], vox["coordinates"], batch_size, site_table=vox.get("site_table"))
         else:
             vox = self.voxel_generator.generate_device(points, point_offsets, mean_features=nf, sync=False)
             preds = self.network_forward(vox["mean"], vox["coordinates"], batch_size,
-                                         num_active_dev=vox["voxel_offsets"][batch_size:])
+                                         num_active_dev=vox["voxel_offsets"][batch_size:], site_table=vox.get("site_table"))
         return self.predict_device(preds, batch_size)
 
     def calibrate(self, points, point_offsets, margin=1.25):

@@ -68,6 +68,10 @@ def voxelize(points, point_offsets, point_cloud_range, voxel_size, max_points, m
                             rt.ptr(voff), rt.ptr(mean), int(mean_features), rt.ptr(ws), ws.numel(), rt.stream())
     rt.check(rc, "sec_voxelize_f32")
     out = {"voxels": voxels, "coordinates": coors, "num_points_per_voxel": npv, "voxel_offsets": voff}
+    # the hash table this call leaves in its workspace (cell -> voxel row) is the site lookup of the first SubM rulebook
+    r6, v3 = np.asarray(point_cloud_range, np.float32), np.asarray(voxel_size, np.float32)
+    grid_zyx = [int(v) for v in np.round((r6[3:] - r6[:3]) / v3).astype(np.int64)[::-1]]
+    out["site_table"] = ("vox", ws, int(n), int(max_voxels), int(max_points), grid_zyx)
     if mean is not None:
         out["mean"] = mean
     if sync:
@@ -102,6 +106,16 @@ def rulebook_subm(indices, batch_size, spatial_shape, ksize=3, dilation=1, want_
     n = indices.shape[0]
     k = _kvol(ksize)
     dev = indices.device
+    if site_table is not None and not want_pairs and n > 0 and isinstance(site_table[0], str) and site_table[0] == "vox":
+        _, ws, vn, vmv, vmp, vgrid = site_table
+        ws.record_stream(torch.cuda.current_stream())
+        nbr = torch.empty((n, k), dtype=torch.int32, device=dev)
+        rc = rt.lib().sec_rulebook_subm3d_after_voxelize(rt.ptr(indices), n, rt.ptr(n_dev), int(batch_size), rt.i3(spatial_shape),
+                                                         rt.i3(ksize), rt.i3(dilation), rt.ptr(nbr), rt.ptr(ws), ws.numel(), vn, vmv,
+                                                         vmp, rt.i3(vgrid), rt.stream())
+        rt.check(rc, "sec_rulebook_subm3d_after_voxelize")
+        return {"nbr_out": nbr, "nbr_in": None, "pairs": None, "pair_num": None, "out_indices": indices,
+                "num_out": n, "num_out_dev": n_dev, "out_shape": [int(s) for s in spatial_shape]}
     if site_table is not None and not want_pairs and n > 0 and isinstance(site_table[0], str) and site_table[0] == "sorted":
         ws = site_table[1]
         ws.record_stream(torch.cuda.current_stream())

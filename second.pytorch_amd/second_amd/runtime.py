@@ -19,7 +19,8 @@ _ERRORS = {-1: "SEC_E_INVALID (bad argument)", -2: "SEC_E_WORKSPACE (workspace t
 # every symbol include/second_hip.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
     "sec_abi_version", "sec_last_error", "sec_voxelize_workspace_bytes", "sec_voxelize_f32",
-    "sec_rulebook_workspace_bytes", "sec_rulebook_subm3d", "sec_rulebook_subm3d_after_conv", "sec_rulebook_conv3d_build",
+    "sec_rulebook_workspace_bytes", "sec_rulebook_subm3d", "sec_rulebook_subm3d_after_conv", "sec_rulebook_subm3d_after_voxelize",
+    "sec_rulebook_conv3d_build",
     "sec_rulebook_conv3d_tables", "sec_rulebook_sorted_workspace_bytes", "sec_rulebook_conv3d_build_sorted",
     "sec_rulebook_conv3d_tables_sorted", "sec_rulebook_subm3d_after_conv_sorted", "sec_conv_output_shape", "sec_packed_weight_bytes",
     "sec_pack_conv_weight", "sec_indice_conv_fwd", "sec_indice_conv_fwd_plan", "sec_indice_conv_set_variant", "sec_indice_conv_bwd_workspace_bytes", "sec_indice_conv_bwd", "sec_sparse_to_dense", "sec_dense_to_sparse",
@@ -60,6 +61,7 @@ def lib():
         l.sec_rulebook_workspace_bytes.argtypes = [ci, ci, ci]
         l.sec_rulebook_subm3d.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, sz, vp]
         l.sec_rulebook_subm3d_after_conv.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp, vp, sz, ci, vp, vp, vp, ci, vp]
+        l.sec_rulebook_subm3d_after_voxelize.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp, vp, sz, ci, ci, ci, vp, vp]
         l.sec_rulebook_conv3d_build.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, vp, ci, vp, ci, vp, vp, sz, vp]
         l.sec_rulebook_conv3d_tables.argtypes = [ci, vp, vp, vp, ci, vp, ci, vp, ci, vp, vp, vp, sz, vp]
         l.sec_rulebook_sorted_workspace_bytes.argtypes = [ci, ci, ci, vp]

@@ -81,11 +81,12 @@ class DeviceTrainer:
         if self.amp_dtype is not None:
             # fp32 master weights; 16-bit features through the sparse stack (MFMA forward / dgrad / wgrad kernels) and,
             # under autocast, through the dense RPN; BatchNorm statistics and the loss in fp32
-            spatial = det.middle_feature_extractor(vox["mean"].to(self.amp_dtype), vox["coordinates"], batch)
+            spatial = det.middle_feature_extractor(vox["mean"].to(self.amp_dtype), vox["coordinates"], batch,
+                                                   site_table=vox.get("site_table"))
             with torch.autocast("cuda", dtype=self.amp_dtype):
                 preds = det.rpn(spatial.contiguous(memory_format=torch.channels_last))
         else:
-            preds = det.network_forward(vox["mean"], vox["coordinates"], batch)
+            preds = det.network_forward(vox["mean"], vox["coordinates"], batch, site_table=vox.get("site_table"))
         loss, out6 = ops.SecondLossFunction.apply(preds["cls_preds"], preds["box_preds"], preds.get("dir_cls_preds"), labels,
                                                   reg_targets, det.anchors, importance, self.loss_cfg)
         return loss, out6, labels

@@ -1037,3 +1037,19 @@ def test_detector_sorted_and_first_touch_numbering_give_identical_results(syn):
         assert a["valid"].any() and torch.equal(a["valid"], b["valid"])
         m = a["valid"]
         assert torch.equal(a["scores"][m], b["scores"][m]) and torch.equal(a["boxes"][m], b["boxes"][m])
+
+
+def test_rulebook_subm_after_voxelize_reuses_the_voxel_hash_table(ops, syn):
+    """First SubM layer of SpMiddleFHD: site lookup in the hash table the voxeliser left in its workspace (grid z = 40, sparse
+    shape z = 41) == the stand-alone build; eager (sliced rows) and static-capacity (device row count) forms, two frames."""
+    pts, offs = syn.batch_clouds([syn.syn_kitti_cloud(s, num_points=9000, num_voxels=8000) for s in range(2)])
+    for sync in (True, False):
+        vox = ops.voxelize(dev(pts), dev(offs), syn.CAR_FHD_RANGE, syn.CAR_FHD_VOXEL, 5, 40000, mean_features=4, sync=sync)
+        assert vox["site_table"][0] == "vox" and vox["site_table"][5] == [40, 1600, 1408]
+        idx = vox["coordinates"]
+        nd = None if sync else vox["voxel_offsets"][2:]
+        plain = ops.rulebook_subm(idx.clone(), 2, [41, 1600, 1408], 3, 1, n_dev=nd)
+        reuse = ops.rulebook_subm(idx, 2, [41, 1600, 1408], 3, 1, n_dev=nd, site_table=vox["site_table"])
+        live = int(vox["voxel_offsets"][2].item())
+        assert live == 16000 and torch.equal(reuse["nbr_out"][:live], plain["nbr_out"][:live])
+        assert (reuse["nbr_out"][:live, 13] == torch.arange(live, device="cuda", dtype=torch.int32)).all()
