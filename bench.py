@@ -119,7 +119,16 @@ def kernel_table(det, points, offsets, reps=30):
         det.forward_points(points, offsets, static=True)
     torch.cuda.synchronize()
     ops.set_op_hook(None)
+    prev_numbering = ops.set_rulebook_numbering(det.rulebook_numbering)   # the re-issues below run outside forward_points: same numbering as the pass
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def site_note(kw, key):
+        t = kw.get(key)
+        if t is None:
+            return ""
+        tag = t[0] if isinstance(t[0], str) else "hash"
+        return {"vox": " (site lookup: the voxeliser's hash table)", "sorted": " (site lookup: bitmap ranks of the strided build)" if key == "site_table"
+                else " (output bitmap derived from the input sites' bitmap)", "hash": " (reuses the strided build's hash table)"}[tag]
 
     def live(t, cap):
         return cap if t is None else int(t.reshape(-1)[0].item())
@@ -169,13 +178,13 @@ def kernel_table(det, points, offsets, reps=30):
             n = live(kw.get("n_dev"), a[0].shape[0])
             p_ = int((res["nbr_out"][:n] >= 0).sum().item())
             k = res["nbr_out"].shape[1]
-            ent.update(bytes=16 * n + 8 * p_ + 4 * k, detail=f"subm {n} rows {p_} pairs" + (" (reuses the strided build's hash table)" if kw.get("site_table") is not None else ""))
+            ent.update(bytes=16 * n + 8 * p_ + 4 * k, detail=f"subm {n} rows {p_} pairs" + site_note(kw, "site_table"))
         elif name == "rulebook_conv":
             n = live(kw.get("n_dev"), a[0].shape[0])
             m = live(res["num_out_dev"], res["num_out"])
             p_ = int((res["nbr_out"][:m] >= 0).sum().item())
             k = res["nbr_out"].shape[1]
-            ent.update(bytes=16 * n + 16 * m + 8 * p_ + 4 * k, detail=f"strided {n} -> {m} rows {p_} pairs")
+            ent.update(bytes=16 * n + 16 * m + 8 * p_ + 4 * k, detail=f"strided {n} -> {m} rows {p_} pairs, {det.rulebook_numbering} numbering" + site_note(kw, "in_sites"))
         elif name == "indice_conv":
             feat, w, nbr, cap = a[:4]
             m = live(kw.get("num_out_dev"), cap)
@@ -204,6 +213,7 @@ def kernel_table(det, points, offsets, reps=30):
         elif "bytes" in ent:
             ent["bound"], ent["frac"] = "hbm", round(ent["bytes"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
         rows.append(ent)
+    ops.set_rulebook_numbering(prev_numbering)
     return rows
 
 
@@ -592,7 +602,7 @@ def main():
                        "frames_per_step_per_gpu": WL["batch"], "parallelism": f"frame-dp{world}", "launch_mode": args.mode,
                        "graph_branches": args.branches if args.mode == "graph" else None,
                        "steps_in_flight": max(1, args.inflight) if args.mode == "graph" else 1,
-                       "single_step_latency_ms": latency_ms, "points_per_frame": int(points.shape[0]) // WL["batch"],
+                       "single_step_latency_ms": latency_ms, "rulebook_numbering": det.rulebook_numbering, "points_per_frame": int(points.shape[0]) // WL["batch"],
                        "rows_per_frame": rows_per_frame},
             "roofline": roof,
             "roofline_mfma": roof_mfma,     # second-largest consumer by kind: the dense RPN conv, MFMA bound
