@@ -14,7 +14,11 @@ SRC = [os.path.join(HERE, "csrc", f) for f in
        ("common.hip", "voxelize.hip", "rulebook.hip", "indice_conv.hip", "scatter.hip", "nms.hip", "dense.hip", "pillars.hip", "predict.hip", "train.hip")]
 HDR = [os.path.join(HERE, "csrc", "common.hpp"), os.path.join(HERE, "..", "include", "second_hip.h")]
 OUT = os.path.join(HERE, "lib", "libsecond_hip.so")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+# -fno-slp-vectorize -fno-vectorize: the vectorisers turn adjacent scalar fp32 adds / muls into packed v_pk_mul_f32 / v_pk_add_f32.  On gfx950
+# (ROCm 7.2) those were measured to return WRONG results in lanes 48..63 of a wave -- a product term missing -- while another wave of
+# the CU runs the dense v_mfma_f32_32x32x16_bf16 loop of the RPN conv kernel (tools/nms_stress.py: the rotated-NMS clipper's corner
+# arithmetic differed in ~1 % of its evaluations beside k_conv2d_halo_reg, 0 of 400 runs without packed fp32).  DESIGN.md section 5.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-slp-vectorize", "-fno-vectorize",
          "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 
 

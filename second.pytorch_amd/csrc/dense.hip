@@ -958,6 +958,24 @@ __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(con
 }
 
 #ifdef SEC_CONV_TIMELINE
+// LDS canary (debug builds): a workgroup fills 40 KB of LDS with a pattern, idles for `spin` clocks and counts the words that
+// changed -- run beside another kernel to see whether that kernel writes outside its own LDS allocation.
+__global__ __launch_bounds__(256) void k_lds_canary(int *errors, int spin, int *first_bad) {
+    __shared__ unsigned canary[10240];
+    for (int i = threadIdx.x; i < 10240; i += 256) canary[i] = 0xC0DE0000u + i;
+    __syncthreads();
+    const long long until = clock64() + spin;
+    while (clock64() < until) __builtin_amdgcn_s_sleep(8);
+    __syncthreads();
+    int bad = 0;
+    for (int i = threadIdx.x; i < 10240; i += 256)
+        if (canary[i] != 0xC0DE0000u + i) { ++bad; atomicMin(first_bad, i); }
+    if (bad) atomicAdd(errors, bad);
+}
+extern "C" __attribute__((visibility("default"))) int sec__debug_lds_canary(int *errors, int *first_bad, int blocks, int spin, void *stream) {
+    hipLaunchKernelGGL(k_lds_canary, dim3(blocks), dim3(256), 0, (hipStream_t)stream, errors, spin, first_bad);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
 extern "C" __attribute__((visibility("default"))) int sec__debug_timeline2(long long *buf) {
     return hipMemcpyToSymbol(HIP_SYMBOL(g_timeline2), &buf, sizeof(buf)) == hipSuccess ? 0 : -4;
 }

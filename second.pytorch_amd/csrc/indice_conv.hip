@@ -586,6 +586,10 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_conv_rows_buf(const T *__r
     constexpr int NBW = (C::BPIECES + WAVES - 1) / WAVES;   // 1 KB weight pieces per wave and offset (narrow layers: duplicated)
     constexpr int ROWB = CIN * (int)sizeof(T);           // bytes per feature row
     constexpr bool STAGE = (FL & 1) != 0, PIPE = (FL & 2) != 0;
+    // FL bit 6 (ALLW, narrow layers): W[0..KVOL) of a 16- or 32-channel layer is 14-55 KB -- the whole tensor is copied into LDS
+    // once per workgroup and the offset loop runs WITHOUT the per-offset workgroup barrier of the three-slot ring: the eight
+    // waves drift apart and hide each other's gather latency.  The staged neighbour tables alias the same LDS (prologue only).
+    constexpr bool ALLW = (FL & 64) != 0;
     // FL bit 5 (SKEW, 8-wave workgroups): every step ends in a workgroup barrier, so the two waves of a SIMD leave it together,
     // want the MFMA pipe together, and the loser's later instructions (its next gathers) sit behind its queued MFMAs.  Waves
     // 4..7 therefore issue their gathers BEFORE their MFMAs (one offset later than waves 0..3 would): while one wave of the
@@ -596,9 +600,12 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_conv_rows_buf(const T *__r
     static_assert(NBW >= 1 && NBW <= 2, "one or two weight pieces per wave");
     static_assert(C::KS <= 4, "up to four 16-channel k-steps per row");
     static_assert(!STAGE || (32 * KVOL) % 4 == 0, "tile table in whole 16-byte pieces");
-    __shared__ __attribute__((aligned(16))) uint4 bring[3][C::BSLOT];
+    static_assert(!ALLW || (STAGE && PIPE), "the all-weights form stages its tables and double-buffers its B fragments");
+    constexpr int LBUF = ALLW ? (KVOL * C::BSLOT > WAVES * TBL16 ? KVOL * C::BSLOT : WAVES * TBL16) : 1;
+    __shared__ __attribute__((aligned(16))) uint4 lbuf[LBUF];
+    __shared__ __attribute__((aligned(16))) uint4 bring[ALLW ? 1 : 3][ALLW ? 1 : C::BSLOT];
     __shared__ __attribute__((aligned(16))) float aff[2 * COUT];
-    __shared__ __attribute__((aligned(16))) u32x4_t stage[STAGE ? WAVES : 1][STAGE ? TBL16 : 1];
+    __shared__ __attribute__((aligned(16))) u32x4_t stage[(STAGE && !ALLW) ? WAVES : 1][(STAGE && !ALLW) ? TBL16 : 1];
     rows_stage_affine<COUT>(aff, scale, shift);
     const int n_cap = n_out;                             // rows the table holds (>= the live count of a static-capacity launch)
     if (num_out_dev) n_out = *num_out_dev;
@@ -622,13 +629,14 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_conv_rows_buf(const T *__r
         const long long left = tbl_bytes - tile_row0 * KVOL * 4;
         const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<int *>(left > 0 ? tile : nbr), 0, (int)(left <= 0 ? 0 : (left < 32 * KVOL * 4 ? left : 32 * KVOL * 4)), 0x00020000);
+        u32x4_t *stg = ALLW ? reinterpret_cast<u32x4_t *>(lbuf) + w * TBL16 : &stage[w][0];
 #pragma unroll
         for (int i = 0; i < (TBL16 + 63) / 64; ++i) {
             const int p16 = i * 64 + lane;
-            if (p16 < TBL16) stage[w][p16] = __builtin_amdgcn_raw_buffer_load_b128(trs, p16 * 16, 0, 0);
+            if (p16 < TBL16) stg[p16] = __builtin_amdgcn_raw_buffer_load_b128(trs, p16 * 16, 0, 0);
         }
         __builtin_amdgcn_wave_barrier();
-        const int *mine = reinterpret_cast<const int *>(&stage[w][0]) + r * KVOL;
+        const int *mine = reinterpret_cast<const int *>(stg) + r * KVOL;
 #pragma unroll
         for (int k = 0; k < KVOL; ++k) {
             const int t = valid ? mine[k] : -1;
@@ -663,6 +671,46 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void k_conv_rows_buf(const T *__r
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
     u32x4_t areg[DIST][C::KS];
+    if constexpr (ALLW) {
+#define SEC_FETCH_A(k)                                                                                                \
+    {                                                                                                                 \
+        areg[(k) % DIST][0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[k], 0, 0);                              \
+        if (C::KS > 1) areg[(k) % DIST][1 % C::KS] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[k] + 32, 0, 0);  \
+        if (C::KS > 2) areg[(k) % DIST][2 % C::KS] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[k] + 64, 0, 0);  \
+        if (C::KS > 3) areg[(k) % DIST][3 % C::KS] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off[k] + 96, 0, 0);  \
+    }
+#pragma unroll
+        for (int k = 0; k < DIST && k < KVOL; ++k) SEC_FETCH_A(k)
+        __syncthreads();                                     // every wave has turned its staged table into offsets: the LDS is free
+        {
+            const uint4 *pk = reinterpret_cast<const uint4 *>(packed);
+            for (int i = threadIdx.x; i < KVOL * C::BSLOT; i += WAVES * 64) lbuf[i] = pk[i];
+        }
+        __syncthreads();
+        uint4 bf[2][C::KS * C::NT];
+#pragma unroll
+        for (int i = 0; i < C::KS * C::NT; ++i) bf[0][i] = lbuf[i * 64 + lane];
+#pragma unroll
+        for (int k = 0; k < KVOL; ++k) {
+            if (k + 1 < KVOL) {
+#pragma unroll
+                for (int i = 0; i < C::KS * C::NT; ++i) bf[(k + 1) & 1][i] = lbuf[(k + 1) * C::BSLOT + i * 64 + lane];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < C::KS; ++s) {
+                const uint4 a = __builtin_bit_cast(uint4, areg[k % DIST][s]);
+#pragma unroll
+                for (int t = 0; t < C::NT; ++t) acc[t] = Mfma<T>::run(bf[k & 1][s * C::NT + t], a, acc[t]);   // D^T
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (k + DIST < KVOL) SEC_FETCH_A(k + DIST)
+        }
+#undef SEC_FETCH_A
+        SEC_RTL(if (tl) tl2 = clock64();)
+        rows_store<T, COUT>(acc, out, row, valid, h, aff, scale != nullptr, shift != nullptr, relu);
+        return;
+    }
     u32x4_t wr0[DIST], wr1[DIST];
     u32x4_t *bslot = reinterpret_cast<u32x4_t *>(&bring[0][piece0 * 64 + lane]);
 #define SEC_FETCH(k)                                                                                                  \
@@ -860,6 +908,7 @@ static int rows_plan(int cin, int cout, int kvol, int n_out, bool same_dtype) {
     const int v = conv_variant();
     if (buf_shape(cin, cout, kvol)) {
         if (v == 22 || (v >= 16 && v <= 28 && cin == 64 && cout == 64 && kvol == 27)) return PLAN_ROWS_BUF;
+        if (v >= 36 && v <= 40) return PLAN_ROWS_BUF;
         if (v == 1 && n_out >= rows_min()) return PLAN_ROWS_BUF;
     }
 #ifdef SEC_CONV_EXPERIMENTS
@@ -887,6 +936,16 @@ static void launch_mfma(const void *feat, long long n_feat, const void *packed, 
                 if constexpr (CIN == 64 && COUT == 64) { SEC_BUF(3, 8, 3, 3); return; }
             } else {
 #ifdef SEC_CONV_EXPERIMENTS   // A/B forms of the buffer-load kernel: prefetch distance, 4- or 8-wave workgroups, staging / pipelining off, skew
+                if constexpr (CIN <= 32) {     // narrow layers: a gather is 1-2 registers per offset, deeper prefetch is nearly free
+                    switch (conv_variant()) {
+                    case 36: SEC_BUF(6, 8, 3, 27); return;
+                    case 37: SEC_BUF(8, 8, 3, 27); return;
+                    case 38: SEC_BUF(12, 8, 3, 27); return;
+                    case 39: if constexpr (COUT <= 32) { SEC_BUF(4, 8, 3 + 64, 27); return; } break;
+                    case 40: if constexpr (COUT <= 32) { SEC_BUF(6, 8, 3 + 64, 27); return; } break;
+                    default: break;
+                    }
+                }
                 if constexpr (CIN == 64 && COUT == 64) {
                     switch (conv_variant()) {
                     case 16: SEC_BUF(4, 4, 0, 27); return;
@@ -907,7 +966,9 @@ static void launch_mfma(const void *feat, long long n_feat, const void *packed, 
                     }
                 }
 #endif
-                SEC_BUF(4, 8, 3, 27);
+                // 16- and 32-channel layers: the whole weight tensor lives in LDS, no per-offset barrier (-13 .. -24 % per layer)
+                if constexpr (CIN <= 32 && COUT <= 32) { SEC_BUF(6, 8, 3 + 64, 27); }
+                else { SEC_BUF(4, 8, 3, 27); }
                 return;
             }
 #undef SEC_BUF

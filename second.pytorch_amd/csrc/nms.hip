@@ -193,6 +193,10 @@ __global__ __launch_bounds__(kBlock) void k_rotate_iou(const float *__restrict__
 //      suppression words (LDS atomics).
 // The reference (and a lanes-are-columns mapping) runs the ~1000-instruction clipper for all 64 lanes whenever a
 // single pair of the wave overlaps; with ~1 % of the pairs overlapping that wastes > 95 % of the lanes.
+#ifdef SEC_NMS_DEBUG
+__device__ int g_nms_dbg[4];
+__device__ float g_nms_vals[8 * 32];
+#endif
 __global__ __launch_bounds__(kBlock) void k_nms_mask(const float *__restrict__ dets, const int *__restrict__ counts,
                                                     int max_n, int stride, float thresh, int kind, int semantics,
                                                     float eps, int words, unsigned long long *__restrict__ mask) {
@@ -229,6 +233,31 @@ __global__ __launch_bounds__(kBlock) void k_nms_mask(const float *__restrict__ d
         }
     }
     __syncthreads();
+#ifdef SEC_NMS_DEBUG
+    if (w < 2) {     // right after the tile was written: does LDS hold what a second load + derivation gives?
+        int idx = (w == 0 ? cb : rb) * 64 + lane;
+        if (idx < n && kind == 0) {
+            const float *d = base + (size_t)idx * stride;
+            float c[8], c2[8];
+            box_corners(c, d);
+            box_corners(c2, d);
+            bool bad = false, bad2 = false;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { bad |= tile[w][lane][i] != c[i]; bad2 |= c[i] != c2[i]; }
+            if (bad) atomicAdd(&g_nms_dbg[2], 1);
+            if (bad2) {
+                const int slot = atomicAdd(&g_nms_dbg[3], 1);
+                if (slot < 8) {
+                    float *o = g_nms_vals + slot * 32;
+                    for (int i = 0; i < 8; ++i) { o[i] = c[i]; o[8 + i] = c2[i]; o[16 + i] = tile[w][lane][i]; }
+                    for (int i = 0; i < 6; ++i) o[24 + i] = d[i];
+                    o[30] = (float)idx; o[31] = (float)(w * 1000 + lane);
+                }
+            }
+        }
+    }
+    __syncthreads();
+#endif
     // ---- phase A: screen
 #pragma unroll 1
     for (int it = 0; it < 16; ++it) {
@@ -286,6 +315,21 @@ __global__ __launch_bounds__(kBlock) void k_nms_mask(const float *__restrict__ d
     }
     __syncthreads();
     if (tid < 64 && rb * 64 + tid < n) mask[((size_t)b * max_n + rb * 64 + tid) * words + cb] = sup_words[tid];
+#ifdef SEC_NMS_DEBUG
+    // debug build: is the tile still what the global loads delivered at the start?  (re-load, re-derive, compare)
+    if (w < 2) {
+        int idx = (w == 0 ? cb : rb) * 64 + lane;
+        if (idx < n && kind == 0) {
+            const float *d = base + (size_t)idx * stride;
+            float c[8];
+            box_corners(c, d);
+            bool bad = false;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) bad |= tile[w][lane][i] != c[i];
+            if (bad) atomicAdd(&g_nms_dbg[w], 1);
+        }
+    }
+#endif
 }
 
 __device__ __forceinline__ unsigned long long wave_or64(unsigned long long v) {
@@ -363,6 +407,64 @@ SEC_API int sec_rotate_iou_f32(const float *boxes, int n, const float *qboxes, i
     return check_launch();
 }
 
+#ifdef SEC_NMS_DEBUG
+// which unit misbehaves beside the RPN conv?  counters: [0] repeated global loads differ, [1] sinf / cosf of the same argument
+// differ, [2] plain fp32 arithmetic differs, [3] an LDS word read back differs from what was written
+template <int BIG, int VG>
+__global__ __launch_bounds__(256) void k_unit_check(const float *__restrict__ data, int n, int iters, int *cnt) {
+    __shared__ float lds[256 * 8];
+    __shared__ float big[BIG ? 8192 : 1];               // BIG: the 40 KB LDS footprint of k_nms_mask
+    if (BIG) big[threadIdx.x * 32 % 8192] = 1.0f;
+    if (VG == 80) asm volatile("v_mov_b32 v79, 0" ::: "v79");     // register footprint of k_nms_mask (80 VGPRs)
+    if (VG == 88) asm volatile("v_mov_b32 v87, 0" ::: "v87");
+    const int i = (blockIdx.x * 256 + threadIdx.x) % n;
+    const float *p = data + (size_t)i * 6;
+    float v0[6];
+    for (int k = 0; k < 6; ++k) v0[k] = __builtin_nontemporal_load(p + k);
+    const float s0 = sinf(v0[4]), c0 = cosf(v0[4]);
+    const float a0 = s0 * v0[2] + c0 * v0[3] + v0[0] / (v0[3] + 1.5f);
+    for (int k = 0; k < 8; ++k) lds[threadIdx.x * 8 + k] = v0[k % 6] + (float)k;
+    int bad[4] = {0, 0, 0, 0};
+    for (int it = 0; it < iters; ++it) {
+        float v[6];
+        for (int k = 0; k < 6; ++k) {                    // plain cached loads (default policy, through the vector L1), not foldable
+            const float *q = p + k;
+            asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v[k]) : "v"(q) : "memory");
+        }
+        for (int k = 0; k < 6; ++k) bad[0] += v[k] != v0[k];
+        float arg = v0[4];
+        asm volatile("" : "+v"(arg));                   // keep the compiler from folding the repeats
+        const float s1 = sinf(arg), c1 = cosf(arg);
+        bad[1] += (s1 != s0) + (c1 != c0);
+        float x2 = v0[2], x3 = v0[3], x0 = v0[0];
+        asm volatile("" : "+v"(x2), "+v"(x3), "+v"(x0));
+        const float a1 = s0 * x2 + c0 * x3 + x0 / (x3 + 1.5f);
+        bad[2] += a1 != a0;
+        for (int k = 0; k < 8; ++k) bad[3] += lds[threadIdx.x * 8 + k] != v0[k % 6] + (float)k;
+    }
+    for (int k = 0; k < 4; ++k)
+        if (bad[k]) atomicAdd(&cnt[k], bad[k]);
+}
+extern "C" __attribute__((visibility("default"))) int sec__debug_unit_check(const float *data, int n, int blocks, int iters, int *cnt, void *stream) {
+    const char *e = getenv("SEC_UNIT_CHECK");
+    const int mode = e ? atoi(e) : 0;
+    if (mode == 1) hipLaunchKernelGGL((k_unit_check<1, 0>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, data, n, iters, cnt);
+    else if (mode == 2) hipLaunchKernelGGL((k_unit_check<0, 80>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, data, n, iters, cnt);
+    else if (mode == 3) hipLaunchKernelGGL((k_unit_check<1, 80>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, data, n, iters, cnt);
+    else if (mode == 4) hipLaunchKernelGGL((k_unit_check<1, 88>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, data, n, iters, cnt);
+    else hipLaunchKernelGGL((k_unit_check<0, 0>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, data, n, iters, cnt);
+    return hipGetLastError() == hipSuccess ? 0 : -4;
+}
+extern "C" __attribute__((visibility("default"))) int sec__debug_nms_vals(float *h256) {
+    return hipMemcpyFromSymbol(h256, HIP_SYMBOL(g_nms_vals), 256 * sizeof(float)) == hipSuccess ? 0 : -4;
+}
+extern "C" __attribute__((visibility("default"))) int sec__debug_nms_counters(int *h4, int reset) {
+    int z[4] = {0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(h4, HIP_SYMBOL(g_nms_dbg), sizeof(z)) != hipSuccess) return -4;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_nms_dbg), z, sizeof(z)) != hipSuccess) return -4;
+    return 0;
+}
+#endif
 SEC_API size_t sec_nms_workspace_bytes(int batch, int max_n) {
     if (batch <= 0 || max_n <= 0) return 0;
     return align_up((size_t)batch * max_n * ((max_n + 63) / 64) * sizeof(unsigned long long));

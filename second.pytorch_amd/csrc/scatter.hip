@@ -46,11 +46,33 @@ static int run_gather(const void *dense, const int *idx, int n, int c, void *row
     return check_launch();
 }
 
+// Zero fill of the dense image as a KERNEL, not hipMemsetAsync: inside a captured hipGraph the runtime's memset node was
+// measured (tools/inflight_stress.py, ROCm 7.2) to start writing a small non-zero pattern (bf16 0x0180, 0x01c0, ...) instead of
+// zeros after some tens of replays of the same graph -- numerically invisible (4.7e-38) but it defeats the all-zero-tile test of
+// the first RPN layer and flips rounding in a tie-dominated top-k once in a few hundred steps.
+__global__ __launch_bounds__(kBlock) void k_zero_fill(uint4 *__restrict__ p, long long n16, unsigned char *__restrict__ tail, int ntail) {
+    const long long stride = (long long)gridDim.x * kBlock;
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n16; i += stride) p[i] = z;
+    if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0;
+}
+
+static int zero_fill(void *out, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return SEC_OK;
+    if (((uintptr_t)out & 15) != 0) return hip_ok(hipMemsetAsync(out, 0, bytes, st));     // never for torch tensors (256-byte aligned)
+    const long long n16 = (long long)(bytes / 16);
+    const int ntail = (int)(bytes - (size_t)n16 * 16);
+    long long blocks = div_up(n16 > 0 ? n16 : 1, (long long)kBlock * 4);
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(k_zero_fill, dim3((unsigned)blocks), dim3(kBlock), 0, st, (uint4 *)out, n16, (unsigned char *)out + (size_t)n16 * 16, ntail);
+    return check_launch();
+}
+
 template <typename T>
 static int run_scatter(const void *feat, const int *idx, int n, const int *num_dev, int c, void *out, size_t out_elems,
                        long long sb, long long sc, long long sz, long long sy, long long sx, hipStream_t st) {
     int rc;
-    if ((rc = hip_ok(hipMemsetAsync(out, 0, out_elems * sizeof(T), st)))) return rc;
+    if ((rc = zero_fill(out, out_elems * sizeof(T), st))) return rc;
     if (n == 0) return SEC_OK;
     int blocks = div_up((long long)n * c, kBlock);
     if (blocks > 256 * 32) blocks = 256 * 32;

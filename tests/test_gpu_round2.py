@@ -140,3 +140,44 @@ def test_eval_rotate_iou_replacement_matches_the_numba_kernel(golden):
     # float64 inputs (what eval.py passes) are accepted and come back in the input precision class of the kernel
     got = rotate_iou_gpu_eval(g["boxes"].astype(np.float64), g["qboxes"].astype(np.float64), -1)
     np.testing.assert_allclose(got, g["iou_c-1"], atol=2e-5)
+
+
+def test_nms_is_deterministic_beside_the_rpn_conv():
+    """Regression for two round-2 findings (tools/nms_stress.py, tools/inflight_stress.py): (1) packed fp32 VALU instructions, which
+    the compiler's vectorisers emit for the rotated-NMS clipper, returned wrong results in lanes 48..63 while another wave of the CU
+    ran the RPN conv's dense MFMA loop (the library is built with the vectorisers off since); (2) a hipMemsetAsync node inside a
+    replayed hipGraph started to write non-zero patterns after some tens of replays (the dense zero fill is a kernel now).  Here:
+    the NMS of a fixed input, run on one stream while two others run the RPN conv, must return the same keep list every time."""
+    import ctypes
+    import numpy as np
+    from second_amd import ops, runtime as rt
+    rng = np.random.default_rng(0)
+    b, n = 3, 1000
+    # a lattice of near-identical boxes: many borderline overlaps, like an untrained detector's candidates
+    xs = (np.arange(n) % 40) * 0.4 + rng.normal(0, 0.003, n)
+    ys = (np.arange(n) // 40) * 0.9 + rng.normal(0, 0.003, n)
+    d = np.stack([xs, ys, np.full(n, 1.6), np.full(n, 3.9), np.full(n, 1.52), np.linspace(0.9, 0.3, n)], 1).astype(np.float32)
+    dets = torch.from_numpy(np.stack([d] * b)).cuda().contiguous()
+    counts = torch.full((b,), n, dtype=torch.int32, device="cuda")
+    x = torch.relu(torch.randn(8, 128, 200, 176, device="cuda")).bfloat16().contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(128, 128, 3, 3, device="cuda") / 34).bfloat16()
+    pk = ops.conv2d_pack_weight(w)
+    bias = torch.randn(128, device="cuda")
+    load = [torch.cuda.Stream(), torch.cuda.Stream()]
+    s_nms = torch.cuda.Stream()
+    with torch.cuda.stream(s_nms):
+        keep0, nk0 = ops.nms_sorted(dets, counts, 0.01, "rotate", "cpu", post_max=100)
+    torch.cuda.synchronize()
+    nk = nk0.tolist()
+    assert all(0 < v <= 100 for v in nk)
+    for it in range(150):
+        for s in load:
+            with torch.cuda.stream(s):
+                for _ in range(3):
+                    ops.conv2d_nhwc(x, pk, bias, 128, 3, 1, 1, relu=True)
+        with torch.cuda.stream(s_nms):
+            keep, nk1 = ops.nms_sorted(dets, counts, 0.01, "rotate", "cpu", post_max=100)
+        torch.cuda.synchronize()
+        assert torch.equal(nk1, nk0), it
+        for i in range(b):
+            assert torch.equal(keep[i, :nk[i]], keep0[i, :nk[i]]), (it, i)
