@@ -1,5 +1,3 @@
 export PYTHONUNBUFFERED=1
-for i in 1 2; do
-timeout 600 python bench.py --no-cpu-baseline --no-kernel-table 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('no vectorisers  inflight3', d['value'], d['ms_per_step'], d['config'].get('single_step_latency_ms'))"
-SEC_HIP_LIB=$PWD/second.pytorch_amd/lib/libsecond_hip_slp.so timeout 600 python bench.py --no-cpu-baseline --no-kernel-table 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('with vectorisers inflight3', d['value'], d['ms_per_step'], d['config'].get('single_step_latency_ms'))"
-done
+echo "== regression test on the shipped build"; timeout 600 python -m pytest tests/test_gpu_round2.py -m gpu -q -k "deterministic_beside" 2>&1 | tail -2
+echo "== same test on a build WITH the vectorisers (must fail to have teeth)"; SEC_HIP_LIB=$PWD/second.pytorch_amd/lib/libsecond_hip_slp.so timeout 600 python -m pytest tests/test_gpu_round2.py -m gpu -q -k "deterministic_beside" 2>&1 | tail -3
