@@ -14,11 +14,14 @@ SRC = [os.path.join(HERE, "csrc", f) for f in
        ("common.hip", "voxelize.hip", "rulebook.hip", "indice_conv.hip", "scatter.hip", "nms.hip", "dense.hip", "pillars.hip", "predict.hip", "train.hip")]
 HDR = [os.path.join(HERE, "csrc", "common.hpp"), os.path.join(HERE, "..", "include", "second_hip.h")]
 OUT = os.path.join(HERE, "lib", "libsecond_hip.so")
-# -fno-slp-vectorize -fno-vectorize: the vectorisers turn adjacent scalar fp32 adds / muls into packed v_pk_mul_f32 / v_pk_add_f32.  On gfx950
-# (ROCm 7.2) those were measured to return WRONG results in lanes 48..63 of a wave -- a product term missing -- while another wave of
-# the CU runs the dense v_mfma_f32_32x32x16_bf16 loop of the RPN conv kernel (tools/nms_stress.py: the rotated-NMS clipper's corner
-# arithmetic differed in ~1 % of its evaluations beside k_conv2d_halo_reg, 0 of 400 runs without packed fp32).  DESIGN.md section 5.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-slp-vectorize", "-fno-vectorize",
+# No packed fp32 VALU: `-Xclang -target-feature -Xclang -packed-fp32-ops` makes the backend split every <2 x float> operation, so no
+# v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 is emitted (the vectorisers stay on: they also merge loads / stores, worth 9-15 % on the
+# 64-channel sparse-conv kernels).  On gfx950 (ROCm 7.2) those instructions were measured to return WRONG results in lanes 48..63 of a
+# wave -- a product term missing -- while another wave of the CU runs the dense v_mfma_f32_32x32x16_bf16 loop of the RPN conv kernel
+# (tools/nms_stress.py: the rotated-NMS clipper's corner arithmetic differed in ~1 % of its evaluations beside k_conv2d_halo_reg;
+# 0 of 400 runs without packed fp32).  DESIGN.md section 5.  The host pass of hipcc prints "not a recognized feature" for it (filtered below).
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+         "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops",
          "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 
 
@@ -46,7 +49,12 @@ def build(force=False, verbose=True, tag=None, extra_flags=None):
         cmd = [hipcc, *cflags, *extra, "-c", "-o", obj, src]
         if verbose:
             print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
+        r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+        err = "\n".join(l for l in r.stderr.splitlines() if "is not a recognized feature for this target" not in l)
+        if err.strip():
+            print(err, file=sys.stderr, flush=True)
+        if r.returncode:
+            raise subprocess.CalledProcessError(r.returncode, cmd)
         return obj
 
     with ThreadPoolExecutor(max_workers=min(len(SRC), os.cpu_count() or 1)) as ex:

@@ -1,3 +1,3 @@
 export PYTHONUNBUFFERED=1
-echo "== regression test on the shipped build"; timeout 600 python -m pytest tests/test_gpu_round2.py -m gpu -q -k "deterministic_beside" 2>&1 | tail -2
-echo "== same test on a build WITH the vectorisers (must fail to have teeth)"; SEC_HIP_LIB=$PWD/second.pytorch_amd/lib/libsecond_hip_slp.so timeout 600 python -m pytest tests/test_gpu_round2.py -m gpu -q -k "deterministic_beside" 2>&1 | tail -3
+echo "== vectorisers on, packed-fp32 feature off"; SEC_HIP_LIB=$PWD/second.pytorch_amd/lib/libsecond_hip_pf.so timeout 600 python tools/conv_microbench.py --all-layers --variants 1 2>&1 | grep "layer  [1-8]\|sum" | cut -c60-200
+SEC_HIP_LIB=$PWD/second.pytorch_amd/lib/libsecond_hip_pf.so LOADKIND=conv LOAD=2 timeout 900 python tools/nms_stress.py 400 2>&1 | grep -v amdgpu.ids | tail -1

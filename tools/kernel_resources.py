@@ -23,7 +23,7 @@ def main():
     flt = args[1] if len(args) > 1 else ""
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "k.s")
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fno-vectorize", "-S",
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops", "-S",
                                "--cuda-device-only", "-Wno-unused-command-line-argument", *extra, "-o", out, src])
         txt = open(out).read()
     names = re.findall(r"^(_Z\w+):\s*; @", txt, re.M)
