@@ -576,8 +576,18 @@ typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 //           pipe busy for ~5000 clocks before the first offset);
 //    bit 1: the B fragments of offset k+1 are read from LDS while offset k's MFMAs run (register double buffer), so a wave's
 //           step no longer starts with an exposed LDS round trip.
+// SEC_PACKED_F32_OK: the library is built without packed fp32 VALU instructions (build.py: they were measured to return wrong results
+// beside the RPN conv's MFMA loop in a VALU-heavy kernel).  This kernel keeps them: its only packed operations are the 32 scale / shift
+// instructions of the epilogue, once per wave, it loses ~10 % without them (the scheduling of the whole loop shifts), and in every
+// concurrency stress run before the flag existed (9000+ lane replays, every layer output compared bit for bit) it never produced a
+// different result.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SEC_PACKED_F32_OK __attribute__((target("packed-fp32-ops")))
+#else
+#define SEC_PACKED_F32_OK
+#endif
 template <typename T, int CIN, int COUT, int KVOL, int DIST, int WAVES, int MINW, int FL>
-__global__ __launch_bounds__(WAVES * 64, MINW) void k_conv_rows_buf(const T *__restrict__ feat, long long feat_bytes,
+SEC_PACKED_F32_OK __global__ __launch_bounds__(WAVES * 64, MINW) void k_conv_rows_buf(const T *__restrict__ feat, long long feat_bytes,
                                                                    const T *__restrict__ packed, const int *__restrict__ nbr,
                                                                    int n_out, const int *__restrict__ num_out_dev,
                                                                    const float *__restrict__ scale, const float *__restrict__ shift,
