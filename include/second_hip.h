@@ -145,9 +145,12 @@ int sec_rulebook_conv3d_build_sorted(const int *indices, int n_in, const int *n_
                                      const int *h_stride3, const int *h_padding3, const int *h_dilation3,
                                      int *out_indices, int out_cap, int *num_out, int *prefill_nbr_out,
                                      int prefill_nbr_out_rows, int *prefill_nbr_in,
+                                     int *prefill_extra, long long prefill_extra_words,
                                      const void *in_sites_workspace, size_t in_sites_workspace_bytes,
                                      void *workspace, size_t workspace_bytes, void *stream);
-/* (build_sorted) out_indices may be NULL when the tables call below is given the buffer instead (it writes the same rows:
+/* (build_sorted) prefill_extra: prefill_extra_words more int32 words set to -1 by the same init launch -- the gather table of
+ * the SubM layer that follows on this layer's outputs (pass prefilled = 1 to sec_rulebook_subm3d_after_conv_sorted then).
+ * out_indices may be NULL when the tables call below is given the buffer instead (it writes the same rows:
  * one launch less).  in_sites_workspace (optional): the workspace of the sorted build that produced `indices` (this layer's
  * inputs are that layer's outputs, e.g. through SubM layers on the same sites; it must be unmodified) -- the output bitmap
  * is then derived from that bitmap with plain loads (3x3x3 stride-2 and (3,1,1) stride-(2,1,1) layers, padding <= 1)
@@ -161,8 +164,8 @@ int sec_rulebook_conv3d_tables_sorted(const int *indices, int n_in, const int *n
 /* SubMConv3d on the outputs of sec_rulebook_conv3d_build_sorted (its bitmap + ranks are the site lookup) */
 int sec_rulebook_subm3d_after_conv_sorted(const int *indices, int n_in, const int *n_in_dev, int batch,
                                           const int *h_shape3, const int *h_ksize3, const int *h_dilation3,
-                                          int *nbr_out, const void *conv_workspace, size_t conv_workspace_bytes,
-                                          void *stream);
+                                          int *nbr_out, int prefilled, const void *conv_workspace,
+                                          size_t conv_workspace_bytes, void *stream);
 void sec_conv_output_shape(const int *h_in_shape3, const int *h_ksize3, const int *h_stride3,
                            const int *h_padding3, const int *h_dilation3, int *h_out_shape3);
 

@@ -42,19 +42,21 @@ __device__ __forceinline__ int live_rows(const RbGeom &g, const int *n_dev) {
 // 32-bit words b := vb, c := vc
 __global__ __launch_bounds__(kBlock) void k_rb_init(unsigned long long *__restrict__ a, long long na, unsigned long long va,
                                                    int *__restrict__ b, long long nb, int vb, int *__restrict__ c,
-                                                   long long nc, int vc) {
+                                                   long long nc, int vc, int *__restrict__ d, long long nd) {
     long long stride = (long long)gridDim.x * kBlock;
     for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < na; i += stride) a[i] = va;
     for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < nb; i += stride) b[i] = vb;
     for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < nc; i += stride) c[i] = vc;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < nd; i += stride) d[i] = -1;
 }
 static void rb_init(unsigned long long *a, long long na, unsigned long long va, int *b, long long nb, int vb, int *c,
-                    long long nc, int vc, hipStream_t st) {
+                    long long nc, int vc, hipStream_t st, int *d = nullptr, long long nd = 0) {
     long long m = na > nb ? na : nb;
     if (nc > m) m = nc;
+    if (nd > m) m = nd;
     int blocks = div_up(m > 0 ? m : 1, kBlock);
     if (blocks > 256 * 8) blocks = 256 * 8;
-    hipLaunchKernelGGL(k_rb_init, dim3(blocks), dim3(kBlock), 0, st, a, na, va, b, nb, vb, c, nc, vc);
+    hipLaunchKernelGGL(k_rb_init, dim3(blocks), dim3(kBlock), 0, st, a, na, va, b, nb, vb, c, nc, vc, d, nd);
 }
 
 __global__ __launch_bounds__(kBlock) void k_rb_hash_rows(const int *__restrict__ indices, RbGeom g,
@@ -1007,10 +1009,11 @@ SEC_API int sec_rulebook_conv3d_build_sorted(const int *indices, int n_in, const
                                              const int *h_out_shape3, const int *h_ksize3, const int *h_stride3,
                                              const int *h_padding3, const int *h_dilation3, int *out_indices, int out_cap,
                                              int *num_out, int *prefill_nbr_out, int prefill_nbr_out_rows, int *prefill_nbr_in,
+                                             int *prefill_extra, long long prefill_extra_words,
                                              const void *in_sites_workspace, size_t in_sites_workspace_bytes, void *workspace,
                                              size_t workspace_bytes, void *stream) {
     if (n_in < 0 || batch <= 0 || !h_in_shape3 || !h_out_shape3 || !h_ksize3 || !h_stride3 || !h_padding3 || !num_out ||
-        out_cap < 0 || prefill_nbr_out_rows < 0)
+        out_cap < 0 || prefill_nbr_out_rows < 0 || prefill_extra_words < 0 || (prefill_extra_words > 0 && !prefill_extra))
         return SEC_E_INVALID;
     RbGeom g;
     int rc = fill_geom(g, h_in_shape3, h_out_shape3, h_ksize3, h_stride3, h_padding3, h_dilation3, n_in, batch);
@@ -1037,10 +1040,10 @@ SEC_API int sec_rulebook_conv3d_build_sorted(const int *indices, int n_in, const
     // scan control (+ the bitmap unless the dilation writes every word) := 0, both gather tables := -1, one launch
     if (dilate)
         rb_init(reinterpret_cast<unsigned long long *>(w.ticket), w.ctl_words / 2, 0ull, prefill_nbr_out, fill_a, -1, prefill_nbr_in,
-                fill_b, -1, st);
+                fill_b, -1, st, prefill_extra, prefill_extra_words);
     else
         rb_init(reinterpret_cast<unsigned long long *>(w.bm), w.zero_words64, 0ull, prefill_nbr_out, fill_a, -1, prefill_nbr_in,
-                fill_b, -1, st);
+                fill_b, -1, st, prefill_extra, prefill_extra_words);
     const long long nc = (long long)n_in * g.ncand;
     if (dilate) {
         const unsigned nb = (unsigned)div_up(w.n_words, kBlock);
@@ -1094,7 +1097,8 @@ SEC_API int sec_rulebook_conv3d_tables_sorted(const int *indices, int n_in, cons
 
 SEC_API int sec_rulebook_subm3d_after_conv_sorted(const int *indices, int n_in, const int *n_in_dev, int batch,
                                                   const int *h_shape3, const int *h_ksize3, const int *h_dilation3, int *nbr_out,
-                                                  const void *conv_workspace, size_t conv_workspace_bytes, void *stream) {
+                                                  int prefilled, const void *conv_workspace, size_t conv_workspace_bytes,
+                                                  void *stream) {
     if (n_in < 0 || batch <= 0 || !h_shape3 || !h_ksize3 || (n_in > 0 && !nbr_out) || !conv_workspace) return SEC_E_INVALID;
     RbGeom g;
     int rc = fill_geom(g, h_shape3, nullptr, h_ksize3, nullptr, nullptr, h_dilation3, n_in, batch);
@@ -1106,7 +1110,7 @@ SEC_API int sec_rulebook_subm3d_after_conv_sorted(const int *indices, int n_in, 
     if (w.bytes > conv_workspace_bytes) return SEC_E_WORKSPACE;
     if (n_in == 0) return SEC_OK;
     hipStream_t st = (hipStream_t)stream;
-    rb_init(nullptr, 0, 0, nbr_out, (long long)n_in * g.kvol, -1, nullptr, 0, 0, st);
+    if (!prefilled) rb_init(nullptr, 0, 0, nbr_out, (long long)n_in * g.kvol, -1, nullptr, 0, 0, st);
     const long long nh = (long long)n_in * (g.kvol / 2 + 1);
     if (g.kvol == 27 && g.ksize[0] == 3 && g.ksize[1] == 3)
         hipLaunchKernelGGL(k_subm_nbr_bm<true>, dim3(div_up(nh, kBlock)), dim3(kBlock), 0, st, indices, g, n_in_dev, w.bm, w.prefix, nbr_out);

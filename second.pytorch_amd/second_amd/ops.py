@@ -119,9 +119,15 @@ def rulebook_subm(indices, batch_size, spatial_shape, ksize=3, dilation=1, want_
     if site_table is not None and not want_pairs and n > 0 and isinstance(site_table[0], str) and site_table[0] == "sorted":
         ws = site_table[1]
         ws.record_stream(torch.cuda.current_stream())
-        nbr = torch.empty((n, k), dtype=torch.int32, device=dev)
+        pre = site_table[2] if len(site_table) > 2 else None     # table already filled with -1 by the strided build's init launch
+        if pre is not None and tuple(pre.shape) == (n, k):
+            nbr, prefilled = pre, 1
+            nbr.record_stream(torch.cuda.current_stream())
+        else:
+            nbr, prefilled = torch.empty((n, k), dtype=torch.int32, device=dev), 0
         rc = rt.lib().sec_rulebook_subm3d_after_conv_sorted(rt.ptr(indices), n, rt.ptr(n_dev), int(batch_size), rt.i3(spatial_shape),
-                                                            rt.i3(ksize), rt.i3(dilation), rt.ptr(nbr), rt.ptr(ws), ws.numel(), rt.stream())
+                                                            rt.i3(ksize), rt.i3(dilation), rt.ptr(nbr), prefilled, rt.ptr(ws), ws.numel(),
+                                                            rt.stream())
         rt.check(rc, "sec_rulebook_subm3d_after_conv_sorted")
         return {"nbr_out": nbr, "nbr_in": None, "pairs": None, "pair_num": None, "out_indices": indices,
                 "num_out": n, "num_out_dev": n_dev, "out_shape": [int(s) for s in spatial_shape]}
@@ -193,8 +199,11 @@ def _rulebook_conv_sorted(indices, batch_size, spatial_shape, ksize, stride, pad
     if in_ws is not None:
         in_ws.record_stream(torch.cuda.current_stream())
     # out_indices are written by the tables call (every candidate knows its output's coordinates)
+    # static inference pipelines: the 3x3x3 SubM layer that follows on these outputs gets its gather table filled by the same launch
+    sub_nbr = torch.empty((cap, 27), dtype=torch.int32, device=dev) if (static and not want_pairs and not torch.is_grad_enabled()) else None
     rc = l.sec_rulebook_conv3d_build_sorted(rt.ptr(indices), n, rt.ptr(n_dev), int(batch_size), *geo, None, cap,
                                             rt.ptr(num_out), rt.ptr(pre_out), cap if static else 0, rt.ptr(pre_in),
+                                            rt.ptr(sub_nbr), sub_nbr.numel() if sub_nbr is not None else 0,
                                             rt.ptr(in_ws), in_ws.numel() if in_ws is not None else 0, rt.ptr(ws),
                                             ws.numel(), rt.stream())
     rt.check(rc, "sec_rulebook_conv3d_build_sorted")
@@ -212,7 +221,7 @@ def _rulebook_conv_sorted(indices, batch_size, spatial_shape, ksize, stride, pad
     rt.check(rc, "sec_rulebook_conv3d_tables_sorted")
     return {"nbr_out": nbr_out, "nbr_in": nbr_in, "pairs": pairs, "pair_num": pair_num,
             "out_indices": out_idx[:m], "num_out": m, "num_out_dev": num_out if static else None,
-            "out_shape": out_shape, "site_table": ("sorted", ws) if n > 0 else None}
+            "out_shape": out_shape, "site_table": ("sorted", ws, sub_nbr) if n > 0 else None}
 
 
 @_traced("rulebook_conv")

@@ -65,9 +65,10 @@ def lib():
         l.sec_rulebook_conv3d_build.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, vp, ci, vp, ci, vp, vp, sz, vp]
         l.sec_rulebook_conv3d_tables.argtypes = [ci, vp, vp, vp, ci, vp, ci, vp, ci, vp, vp, vp, sz, vp]
         l.sec_rulebook_sorted_workspace_bytes.argtypes = [ci, ci, ci, vp]
-        l.sec_rulebook_conv3d_build_sorted.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, vp, vp, ci, vp, vp, sz, vp, sz, vp]
+        l.sec_rulebook_conv3d_build_sorted.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, vp, vp, ci, vp, vp, ctypes.c_longlong,
+                                                       vp, sz, vp, sz, vp]
         l.sec_rulebook_conv3d_tables_sorted.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, vp, ci, vp, ci, vp, vp, vp, sz, vp]
-        l.sec_rulebook_subm3d_after_conv_sorted.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp, vp, sz, vp]
+        l.sec_rulebook_subm3d_after_conv_sorted.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp, ci, vp, sz, vp]
         l.sec_conv_output_shape.argtypes = [vp] * 6
         l.sec_packed_weight_bytes.argtypes = [ci, ci, ci, ci]
         l.sec_pack_conv_weight.argtypes = [vp, ci, ci, ci, ci, vp, vp]

@@ -77,6 +77,27 @@ def test_strided_rulebook_laws(case, geom):
     assert order == list(range(m))
 
 
+@settings(**SETTINGS)
+@given(sparse_sites(), st.sampled_from([(3, 2, 1), (3, 2, 0), ((3, 1, 1), (2, 1, 1), 0), (2, 2, 0), (3, 1, 1), (3, 2, (0, 1, 1))]))
+def test_sorted_numbering_is_a_relabelling_of_first_touch(case, geom):
+    """spconv's GPU numbering (ascending linear cell index) vs its CPU numbering (first touch): the same set of output sites,
+    the same (offset, input row, output cell) triples, rows in strictly ascending cell order, pairs in ascending input row."""
+    idx, batch, shape = case
+    ks, stv, pad = geom
+    if min(orc.conv_output_size(shape, ks, stv, pad, 1)) <= 0:
+        return
+    o1, p1, n1, oshape = orc.rulebook_conv(idx, batch, shape, ks, stv, pad)
+    o2, p2, n2, _ = orc.rulebook_conv_sorted(idx, batch, shape, ks, stv, pad)
+    np.testing.assert_array_equal(n1, n2)
+    lin = ((o2[:, 0].astype(np.int64) * oshape[0] + o2[:, 1]) * oshape[1] + o2[:, 2]) * oshape[2] + o2[:, 3]
+    assert np.all(np.diff(lin) > 0)
+    assert {tuple(r) for r in o1} == {tuple(r) for r in o2}
+    for k in range(p1.shape[0]):
+        c = n1[k]
+        np.testing.assert_array_equal(p1[k, 0, :c], p2[k, 0, :c])                      # same inputs, same (ascending) order
+        np.testing.assert_array_equal(o1[p1[k, 1, :c]], o2[p2[k, 1, :c]])              # reaching the same output cells
+
+
 @settings(max_examples=15, deadline=None)
 @given(st.integers(0, 2 ** 31 - 1), st.integers(1, 60))
 def test_voxel_count_is_monotone_in_max_voxels(seed, cap):
@@ -135,6 +156,38 @@ def test_gpu_rulebook_laws_at_bench_size():
         first = tok.min(1).values
         assert torch.all(first[1:] > first[:-1])
         idx, shape = out.contiguous(), oshape
+
+
+@pytest.mark.gpu
+def test_gpu_sorted_rulebook_chain_laws_at_bench_size():
+    """The device fast path's rulebook chain at batch 8 x 16 000 voxels (bitmap builds, layers 2-4 derived from the previous
+    layer's bitmap, SubM lookups by bitmap rank): ascending-cell output order, the same output sites and the same pair counts as
+    the first-touch (hash) build, tables consistent with each other, SubM tables equal to the stand-alone build."""
+    import torch
+    from second_amd import ops, synthetic as syn
+    pts, offs = syn.batch_clouds([syn.syn_kitti_cloud(s) for s in range(8)])
+    vox = ops.voxelize(torch.from_numpy(pts).cuda(), torch.from_numpy(offs).cuda(), syn.CAR_FHD_RANGE, syn.CAR_FHD_VOXEL, 5, 40000)
+    idx, shape, sites = vox["coordinates"].contiguous(), [41, 1600, 1408], None
+    idx_ft = idx
+    for li, (ks, stv, pad) in enumerate([(3, 2, 1), (3, 2, 1), (3, 2, (0, 1, 1)), ((3, 1, 1), (2, 1, 1), 0)]):
+        r = ops.rulebook_conv(idx, 8, shape, ks, stv, pad, want_pairs=True, numbering="sorted", in_sites=sites)
+        ft = ops.rulebook_conv(idx_ft, 8, shape, ks, stv, pad, want_pairs=True)
+        out, m, oshape = r["out_indices"], r["num_out"], r["out_shape"]
+        assert m == ft["num_out"] and torch.equal(r["pair_num"], ft["pair_num"]), li
+        lin = ((out[:, 0].long() * oshape[0] + out[:, 1]) * oshape[1] + out[:, 2]) * oshape[2] + out[:, 3]
+        assert torch.all(lin[1:] > lin[:-1])                                                       # ascending cell order
+        fo = ft["out_indices"]
+        lin_ft = ((fo[:, 0].long() * oshape[0] + fo[:, 1]) * oshape[1] + fo[:, 2]) * oshape[2] + fo[:, 3]
+        assert torch.equal(torch.sort(lin_ft).values, lin)                                         # the same output sites
+        no, ni = r["nbr_out"], r["nbr_in"]
+        assert (no >= 0).any(1).all() and int((no >= 0).sum()) == int((ni >= 0).sum()) == int(r["pair_num"].sum())
+        k = 4 if no.shape[1] == 27 else 1
+        o = torch.nonzero(no[:, k] >= 0).squeeze(1)
+        assert torch.equal(ni[no[o, k].long(), k].long(), o)
+        sub = ops.rulebook_subm(out, 8, oshape, 3, site_table=r["site_table"])                    # bitmap-rank site lookup
+        plain = ops.rulebook_subm(out.clone(), 8, oshape, 3)
+        assert torch.equal(sub["nbr_out"], plain["nbr_out"])
+        idx, idx_ft, shape, sites = out.contiguous(), fo.contiguous(), oshape, r["site_table"]
 
 
 @pytest.mark.gpu
