@@ -237,12 +237,16 @@ __global__ __launch_bounds__(kSelThreads) void k_predict_select(const T *__restr
 // thread loads its KPT keys ONCE (wave-contiguous segments, so "first by index" among equal keys is a prefix over waves),
 // the radix passes, tie ranking and compaction run out of registers, and the sort does its in-wave steps with shuffles
 // (10 LDS exchange steps instead of 55).  Same outputs as k_predict_select.
-template <typename T, int KP>     // 16-bit logits only (bf16); KP = key PAIRS (dwords) per thread
+// INDIRECT (second stage of the chunked select): `keys` are the per-chunk candidate keys written by k_predict_select_chunk
+// (n_keys of them per frame, chunk-major, ascending anchor index among equal keys inside and across chunks -- which is all the
+// tie ranking needs), slot_anchor their anchor ids.
+template <typename T, int KP, bool INDIRECT = false>     // 16-bit logits only (bf16); KP = key PAIRS (dwords) per thread
 __global__ __launch_bounds__(kSelThreads) void k_predict_select_reg(const T *__restrict__ cls, View5 v, PredGeom g, int K,
                                                                     float score_thr, const unsigned short *__restrict__ keys,
                                                                     int ns, int *__restrict__ top_idx,
                                                                     float *__restrict__ top_score, int *__restrict__ top_label,
-                                                                    int *__restrict__ counts) {
+                                                                    int *__restrict__ counts, int n_keys = 0,
+                                                                    const int *__restrict__ slot_anchor = nullptr) {
     __shared__ unsigned ckey[kSelThreads];
     __shared__ int cidx[kSelThreads];
     __shared__ int wsum[kSelThreads / 64];
@@ -251,7 +255,7 @@ __global__ __launch_bounds__(kSelThreads) void k_predict_select_reg(const T *__r
     __shared__ unsigned short cand_key[kCandCap];
     __shared__ int cand_idx[kCandCap];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int N = g.A * g.H * g.W;
+    const int N = INDIRECT ? n_keys : g.A * g.H * g.W;
     const unsigned *fk2 = reinterpret_cast<const unsigned *>(keys + (size_t)b * ns);   // ns is even: dword aligned
     if (K > kSelThreads) K = kSelThreads;
     if (K > N) K = N;
@@ -419,15 +423,20 @@ __global__ __launch_bounds__(kSelThreads) void k_predict_select_reg(const T *__r
     }
     SEC_TS();
     // ---- outputs
+    if (INDIRECT) {                                   // slot -> anchor id (empty candidate slots carry 0x7fffffff)
+        const int a_ = (mi < N) ? slot_anchor[(size_t)b * N + mi] : 0x7fffffff;
+        mi = (a_ < g.A * g.H * g.W) ? a_ : 0x7fffffff;
+    }
+    const int n_valid = INDIRECT ? 0x7fffffff : N;    // below: mi < n_valid == a real anchor
     if (tid < K) {
         float sc = sigmoidf_(key2f(mk));
         int lab = 0;
-        if (g.nc > 1 && mi < N) anchor_key(cls, v, g, b, mi, &lab);
-        top_idx[(size_t)b * K + tid] = mi < N ? mi : 0;
+        if (g.nc > 1 && mi < n_valid) anchor_key(cls, v, g, b, mi, &lab);
+        top_idx[(size_t)b * K + tid] = mi < n_valid ? mi : 0;
         top_score[(size_t)b * K + tid] = sc;
         top_label[(size_t)b * K + tid] = lab;
     }
-    const bool ok = tid < K && mi < N && sigmoidf_(key2f(mk)) >= score_thr;
+    const bool ok = tid < K && mi < n_valid && sigmoidf_(key2f(mk)) >= score_thr;
     const unsigned long long m = __ballot(ok);
     __syncthreads();
     if (lane == 0) wsum[wv] = __popcll(m);
@@ -444,6 +453,101 @@ __global__ __launch_bounds__(kSelThreads) void k_predict_select_reg(const T *__r
                tstamp[2] - tstamp[1], tstamp[3] - tstamp[2], tstamp[4] - tstamp[3], tstamp[5] - tstamp[4]);
 #endif
 #undef SEC_TS
+}
+
+// ---- chunked select, stage 1 (whole chip) -------------------------------------------------------------------------------
+// One workgroup per (frame, chunk of 8192 anchors): its top-min(K, chunk) keys -- everything above the chunk's K-th largest key
+// T plus the first ties at T by anchor index -- written in ASCENDING ANCHOR ORDER (deterministic ballot-prefix slots) to
+// cand_key / cand_idx [frame][chunk][1024], zero / 0x7fffffff padded.  The frame's top K is a subset of the union of its chunks'
+// top K, with the same tie order, so stage 2 (k_predict_select_reg<INDIRECT>) selects and sorts ~9 k candidates instead of
+// bisecting 70 k keys in one workgroup: 65 us -> two launches of ~6 and ~17 us.
+constexpr int kSelChunk = 8192;                  // 16 waves x 4 key pairs x 128
+__global__ __launch_bounds__(kSelThreads) void k_predict_select_chunk(const unsigned short *__restrict__ keys, int ns, int N, int K,
+                                                                      int chunks, unsigned short *__restrict__ cand_key,
+                                                                      int *__restrict__ cand_idx) {
+    constexpr int KP = 4;
+    __shared__ int sweep_tot[20];
+    __shared__ int w_eq[kSelThreads / 64], w_gt[kSelThreads / 64];
+    const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int base = c * kSelChunk;
+    const int nloc = min(kSelChunk, N - base);                         // > 0 by construction of the grid
+    const int Kc = K < nloc ? K : nloc;
+    const unsigned *fk2 = reinterpret_cast<const unsigned *>(keys + (size_t)b * ns + base);
+    const int n_base = wv * (KP * 128) + lane * 2;
+    unsigned k2[KP];
+#pragma unroll
+    for (int i = 0; i < KP; ++i) {
+        const int n = n_base + i * 128;
+        k2[i] = base + n < ns ? fk2[n >> 1] : 0u;                      // slots beyond the frame hold key 0
+    }
+    unsigned short *ok_ = cand_key + ((size_t)b * chunks + c) * kSelThreads;
+    int *oi_ = cand_idx + ((size_t)b * chunks + c) * kSelThreads;
+    ok_[tid] = 0;
+    oi_[tid] = 0x7fffffff;
+    if (tid < 20) sweep_tot[tid] = 0;
+    __syncthreads();
+    auto block_sum = [&](int x, int it) -> int {
+        x += __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, true);     // quad_perm [1,0,3,2]
+        x += __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, true);     // quad_perm [2,3,0,1]
+        x += __builtin_amdgcn_update_dpp(0, x, 0x141, 0xf, 0xf, true);    // row_half_mirror
+        x += __builtin_amdgcn_update_dpp(0, x, 0x140, 0xf, 0xf, true);    // row_mirror
+        const int ws_ = __builtin_amdgcn_readlane(x, 0) + __builtin_amdgcn_readlane(x, 16) + __builtin_amdgcn_readlane(x, 32) +
+                        __builtin_amdgcn_readlane(x, 48);
+        if (lane == 0) atomicAdd(&sweep_tot[it], ws_);
+        __syncthreads();
+        return sweep_tot[it];
+    };
+    auto count_ge = [&](unsigned t, int it) -> int {
+        int cnt = 0;
+#pragma unroll
+        for (int i = 0; i < KP; ++i) cnt += ((k2[i] & 0xffffu) >= t ? 1 : 0) + ((k2[i] >> 16) >= t ? 1 : 0);
+        return block_sum(cnt, it);
+    };
+    unsigned T_key = 0;
+    int it = 0;
+    for (int bit = 15; bit >= 0; --bit, ++it) {
+        const unsigned t = T_key | (1u << bit);
+        if (count_ge(t, it) >= Kc) T_key = t;
+    }
+    const int above = T_key == 0xffffu ? 0 : count_ge(T_key + 1, it);
+    const int need = Kc - above;                                          // ties at T to keep, by ascending anchor index
+    int my_eq = 0, my_gt = 0;
+#pragma unroll
+    for (int i = 0; i < KP; ++i)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const unsigned kj = (k2[i] >> (hf * 16)) & 0xffffu;
+            my_eq += __popcll(__ballot(kj == T_key));
+            my_gt += __popcll(__ballot(kj > T_key));
+        }
+    if (lane == 0) { w_eq[wv] = my_eq; w_gt[wv] = my_gt; }
+    __syncthreads();
+    int erun = 0, slot = 0;
+    for (int w2 = 0; w2 < wv; ++w2) {
+        const int left = need - erun;
+        slot += w_gt[w2] + (left <= 0 ? 0 : (left < w_eq[w2] ? left : w_eq[w2]));
+        erun += w_eq[w2];
+    }
+    const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int i = 0; i < KP; ++i) {
+        const int n = n_base + i * 128;
+        const unsigned ka = k2[i] & 0xffffu, kb = k2[i] >> 16;
+        const bool eqa = ka == T_key, eqb = kb == T_key;
+        const unsigned long long ma = __ballot(eqa), mb = __ballot(eqb);
+        const int before = erun + __popcll(ma & lt) + __popcll(mb & lt);
+        erun += __popcll(ma) + __popcll(mb);
+        const bool ta = ka > T_key || (eqa && before < need);
+        const bool tb = kb > T_key || (eqb && before + (eqa ? 1 : 0) < need);
+        const unsigned long long qa = __ballot(ta), qb = __ballot(tb);
+        const unsigned long long both_lt = lt;
+        // ascending anchor order inside the pair row: lane L's two anchors (2L, 2L + 1) come before lane L + 1's
+        const int pa = slot + __popcll(qa & both_lt) + __popcll(qb & both_lt);
+        const int pb = pa + (ta ? 1 : 0);
+        slot += __popcll(qa) + __popcll(qb);
+        if (ta && pa < kSelThreads) { ok_[pa] = (unsigned short)ka; oi_[pa] = base + n; }
+        if (tb && pb < kSelThreads) { ok_[pb] = (unsigned short)kb; oi_[pb] = base + n + 1; }
+    }
 }
 
 template <typename T>
@@ -559,6 +663,29 @@ SEC_API int sec_predict_select(const void *cls, const int64_t *h_cls_strides5, i
         const int ns = (int)((nfr + 1) & ~1ll);
         hipLaunchKernelGGL(k_predict_keys16<T>, dim3(div_up((long long)batch * ns, kBlock)), dim3(kBlock), 0, st, (const T *)cls, v, g, ns,
                            reinterpret_cast<unsigned short *>(key_scratch));
+        // chunked form: per-chunk top-K on the whole chip, then one workgroup per frame over the ~9 k candidates.  The candidate
+        // arrays live in the unused upper part of key_scratch (sized 4 bytes per anchor, the 16-bit keys take 2).
+        static int chunked = -1;
+        if (chunked < 0) { const char *e = getenv("SEC_SELECT_CHUNKS"); chunked = e ? atoi(e) : 1; }
+        const int chunks = (int)((nfr + kSelChunk - 1) / kSelChunk);
+        const long long n2 = (long long)chunks * kSelThreads;
+        const size_t key_bytes = ((size_t)batch * ns * 2 + 255) & ~(size_t)255;
+        const size_t need_bytes = key_bytes + (size_t)batch * n2 * 6;
+        if (chunked && chunks >= 2 && n2 <= (long long)kSelThreads * 72 && need_bytes <= (size_t)total * 4) {
+            unsigned short *ck = reinterpret_cast<unsigned short *>(reinterpret_cast<char *>(key_scratch) + key_bytes + (size_t)batch * n2 * 4);
+            int *ci = reinterpret_cast<int *>(reinterpret_cast<char *>(key_scratch) + key_bytes);
+            hipLaunchKernelGGL(k_predict_select_chunk, dim3(chunks, batch), dim3(kSelThreads), 0, st,
+                               reinterpret_cast<const unsigned short *>(key_scratch), ns, (int)nfr, k, chunks, ck, ci);
+#define SEC_SEL2(KP2) hipLaunchKernelGGL((k_predict_select_reg<T, KP2, true>), dim3(batch), dim3(kSelThreads), 0, st, (const T *)cls, v, g, k, \
+                                         score_thr, ck, (int)n2, top_idx, top_score, top_label, counts, (int)n2, ci)
+            const int pairs = (int)((n2 / 2 + kSelThreads - 1) / kSelThreads);
+            if (pairs <= 5) SEC_SEL2(5);
+            else if (pairs <= 10) SEC_SEL2(10);
+            else if (pairs <= 20) SEC_SEL2(20);
+            else SEC_SEL2(36);
+#undef SEC_SEL2
+            return check_launch();
+        }
         hipLaunchKernelGGL((k_predict_select_reg<T, 36>), dim3(batch), dim3(kSelThreads), 0, st, (const T *)cls, v, g, k, score_thr,
                            reinterpret_cast<const unsigned short *>(key_scratch), ns, top_idx, top_score, top_label, counts);
         return check_launch();

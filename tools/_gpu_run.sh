@@ -1,4 +1,6 @@
 export PYTHONUNBUFFERED=1
-timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_properties.py tests/test_gpu_e2e.py -m gpu -q -x -k "sorted or detector or rulebook or e2e or laws" 2>&1 | tail -3
-for i in 1 2; do timeout 300 python bench.py --inflight 1 --no-kernel-table --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('inflight1', d['value'], d['ms_per_step'])"; done
-timeout 600 python bench.py --no-kernel-table --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('inflight3', d['value'], d['ms_per_step'])"
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_e2e.py tests/test_gpu_round2.py -m gpu -q -x -k "predict or tie or detector or e2e or in_flight or nms" 2>&1 | tail -4
+for i in 1 2; do timeout 300 python bench.py --inflight 1 --no-kernel-table --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('chunked  inflight1', d['value'], d['ms_per_step'])"
+SEC_SELECT_CHUNKS=0 timeout 300 python bench.py --inflight 1 --no-kernel-table --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('one WG   inflight1', d['value'], d['ms_per_step'])"; done
+timeout 600 python bench.py --no-cpu-baseline 2>/dev/null | python -c "
+import sys,json; d=json.loads(sys.stdin.read()); print('inflight3', d['value'], d['ms_per_step'], [ (k['op'],k['us']) for k in d['kernels'] if k['op'].startswith('predict') or k['op']=='nms_sorted'])"
