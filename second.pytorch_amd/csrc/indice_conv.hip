@@ -906,6 +906,7 @@ static int rows_min() {
     if (v < 0) { const char *e = getenv("SEC_CONV_ROWS_MIN"); v = e ? atoi(e) : 40000; }   // car.fhd batch 8: layers 1-8 (>= 56k rows) gain 25-30 %, the 23k-row layers lose
     return v;
 }
+constexpr int kRowsMinSmall = 8192;
 static bool buf_shape(int cin, int cout, int kvol) {
     if (kvol == 3) return cin == 64 && cout == 64;
     if (kvol != 27) return false;
@@ -920,6 +921,9 @@ static int rows_plan(int cin, int cout, int kvol, int n_out, bool same_dtype) {
         if (v == 22 || (v >= 16 && v <= 28 && cin == 64 && cout == 64 && kvol == 27)) return PLAN_ROWS_BUF;
         if (v >= 36 && v <= 40) return PLAN_ROWS_BUF;
         if (v == 1 && n_out >= rows_min()) return PLAN_ROWS_BUF;
+        // 64 -> 64, 27 offsets, 8 k .. 40 k rows (the 23 k-row stage of car.fhd at batch 8): four-wave workgroups (128 rows) fill the
+        // chip where the eight-wave form leaves CUs idle: 13.2 us vs 14.9 us split-K
+        if (v == 1 && cin == 64 && cout == 64 && kvol == 27 && n_out >= kRowsMinSmall) return PLAN_ROWS_BUF;
     }
 #ifdef SEC_CONV_EXPERIMENTS
     if (kvol != 27 || !(cin == 64 || cin == 32) || !(cout == 64 || cout == 32)) return 0;
@@ -978,7 +982,10 @@ static void launch_mfma(const void *feat, long long n_feat, const void *packed, 
 #endif
                 // 16- and 32-channel layers: the whole weight tensor lives in LDS, no per-offset barrier (-13 .. -24 % per layer)
                 if constexpr (CIN <= 32 && COUT <= 32) { SEC_BUF(6, 8, 3 + 64, 27); }
-                else { SEC_BUF(4, 8, 3, 27); }
+                else if constexpr (CIN == 64 && COUT == 64) {
+                    if (n_out < rows_min() && conv_variant() == 1) { SEC_BUF(4, 4, 3, 27); }      // mid-size layers: 128-row workgroups
+                    else { SEC_BUF(4, 8, 3, 27); }
+                } else { SEC_BUF(4, 8, 3, 27); }
                 return;
             }
 #undef SEC_BUF

@@ -96,8 +96,14 @@ def test_conv_rows_bench_launch_vs_oracle(ops, layer, dtype):
         out = ops.indice_conv(f_t, w_t, nbr, n, packed=packed, scale=dev(scale), shift=dev(shift), relu=True)
         np.testing.assert_allclose(out.float().cpu().numpy(), ref_fused, rtol=tol, atol=tol * np.abs(ref_fused).max(), err_msg=f"variant {variant}")
     ops.indice_conv_set_variant(-1)
-    # below the row threshold the automatic choice is split-K: the two families must agree on a prefix of the layer
-    assert ops.indice_conv_plan(64, 64, 27, 16000, dtype) != PLAN_ROWS_BUF
+    # mid-size layers (8 k .. 40 k rows) take the four-wave form of the same kernel, small ones split-K: a 23 k-row and a 6 k-row prefix
+    # of the layer must agree with the oracle too
+    assert ops.indice_conv_plan(64, 64, 27, 22834, dtype) == PLAN_ROWS_BUF
+    assert ops.indice_conv_plan(64, 64, 27, 6000, dtype) != PLAN_ROWS_BUF
+    for m in (22834, 6000):
+        sub = layer["nbr"][:m]
+        out = ops.indice_conv(f_t, w_t, dev(sub), m, packed=packed, scale=dev(scale), shift=dev(shift), relu=True)
+        np.testing.assert_allclose(out.float().cpu().numpy(), ref_fused[:m], rtol=tol, atol=tol * np.abs(ref_fused).max(), err_msg=f"{m} rows")
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
