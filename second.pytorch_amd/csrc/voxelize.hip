@@ -17,6 +17,8 @@
 
 namespace sec {
 
+constexpr int kFusedFrames = 64;  // batches up to this size compute the per-cloud frames inside k_vox_assign
+
 struct VoxParams {
     float lo[3], vs[3];
     int grid[3];  // x, y, z
@@ -61,8 +63,11 @@ __global__ __launch_bounds__(kBlock) void k_vox_hash(const float *__restrict__ p
 
 __global__ __launch_bounds__(kBlock) void k_vox_init(unsigned long long *__restrict__ keys, int *__restrict__ vals, long long table,
                                                     int *__restrict__ count, long long rows, int *__restrict__ slot_idx,
-                                                    long long slots, int *__restrict__ ctl, long long ctl_words) {
+                                                    long long slots, int *__restrict__ ctl, long long ctl_words,
+                                                    int *__restrict__ break_idx, int batch) {
     long long stride = (long long)gridDim.x * kBlock;
+    if (blockIdx.x == 0)
+        for (int b = threadIdx.x; b < batch; b += kBlock) break_idx[b] = 0x7fffffff;      // "no cloud has hit its voxel cap yet"
     for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < ctl_words; i += stride) ctl[i] = 0;
     for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < table; i += stride) { keys[i] = kEmptyKey; vals[i] = kEmptyI32; }
     for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < rows; i += stride) count[i] = 0;
@@ -87,7 +92,8 @@ __global__ __launch_bounds__(kBlock) void k_vox_flag_scan(const int *__restrict_
     if (i < n) rank[i] = ex;
 }
 
-// one thread: per-cloud voxel counts (capped) -> voxel_offsets; rank base per cloud; reset break markers
+// one thread: per-cloud voxel counts (capped) -> voxel_offsets; rank base per cloud.  Only for empty inputs and batches > 64:
+// otherwise every workgroup of k_vox_assign derives the same few numbers itself (one launch less on the latency chain).
 __global__ void k_vox_frames(const int *__restrict__ offs, const int *__restrict__ rank,
                              const int *__restrict__ total, VoxParams p, int *__restrict__ base,
                              int *__restrict__ break_idx, int *__restrict__ voxel_offsets) {
@@ -105,7 +111,6 @@ __global__ void k_vox_frames(const int *__restrict__ offs, const int *__restrict
         if (cnt > p.max_voxels) cnt = p.max_voxels;
         acc += cnt;
         voxel_offsets[b + 1] = acc;
-        break_idx[b] = 0x7fffffff;
         prev = nxt;
     }
 }
@@ -115,18 +120,41 @@ __global__ __launch_bounds__(kBlock) void k_vox_assign(const int *__restrict__ o
                                                       const int *__restrict__ vals,
                                                       const unsigned long long *__restrict__ keys,
                                                       const int *__restrict__ rank,
-                                                      const int *__restrict__ base,
-                                                      const int *__restrict__ voxel_offsets, VoxParams p,
+                                                      int *__restrict__ base,
+                                                      int *__restrict__ voxel_offsets, VoxParams p,
                                                       int *__restrict__ svid, int *__restrict__ break_idx,
-                                                      int *__restrict__ coors) {
+                                                      int *__restrict__ coors, const int *__restrict__ total) {
+    // total != NULL: base[] / voxel_offsets[] (what k_vox_frames computes) are derived here, per workgroup, in LDS; workgroup 0
+    // also stores them for the kernels that follow
+    __shared__ int s_base[kFusedFrames + 1], s_voff[kFusedFrames + 1];
+    if (total) {
+        const int t = threadIdx.x;
+        if (t <= p.batch) {
+            const int o = offs[t];
+            s_base[t] = o < p.num_points ? rank[o] : *total;
+        }
+        __syncthreads();
+        if (t == 0) {
+            int acc = 0;
+            s_voff[0] = 0;
+            for (int b = 0; b < p.batch; ++b) {
+                int cnt = s_base[b + 1] - s_base[b];
+                if (cnt > p.max_voxels) cnt = p.max_voxels;
+                acc += cnt;
+                s_voff[b + 1] = acc;
+            }
+        }
+        __syncthreads();
+        if (blockIdx.x == 0 && t <= p.batch) { base[t] = s_base[t]; voxel_offsets[t] = s_voff[t]; }
+    }
     int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= p.num_points) return;
     int s = pslot[i];
     if (s < 0 || vals[s] != i) return;  // only the first point of a voxel acts
     int b = frame_of(offs, p.batch, i);
-    int r = rank[i] - base[b];
+    int r = rank[i] - (total ? s_base[b] : base[b]);
     if (r < p.max_voxels) {
-        int vid = voxel_offsets[b] + r;
+        int vid = (total ? s_voff[b] : voxel_offsets[b]) + r;
         svid[s] = vid;
         unsigned long long vol = (unsigned long long)p.grid[0] * p.grid[1] * p.grid[2];
         unsigned long long lin = keys[s] - (unsigned long long)b * vol;
@@ -285,19 +313,22 @@ SEC_API int sec_voxelize_f32(const float *points, const int *point_offsets, int 
         int blocks = div_up((long long)w.table, kBlock);
         if (blocks > 256 * 8) blocks = 256 * 8;
         hipLaunchKernelGGL(k_vox_init, dim3(blocks), dim3(kBlock), 0, st, w.keys, w.vals, (long long)w.table, w.count, cap_rows,
-                           w.slot_idx, cap_rows * max_points, w.ctl, (long long)scan_ctl_words(num_points));
+                           w.slot_idx, cap_rows * max_points, w.ctl, (long long)scan_ctl_words(num_points), w.break_idx, batch);
     }
+    const bool fused_frames = num_points > 0 && batch <= kFusedFrames;
     int nb = div_up(num_points > 0 ? num_points : 1, kBlock);
     if (num_points > 0) {
         hipLaunchKernelGGL(k_vox_hash, dim3(nb), dim3(kBlock), 0, st, points, point_offsets, p, w.keys, w.vals, w.pslot);
         hipLaunchKernelGGL(k_vox_flag_scan, dim3(nb), dim3(kBlock), 0, st, w.pslot, w.vals, num_points, w.rank,
                            reinterpret_cast<unsigned long long *>(w.ctl + 4), w.ctl, w.total);
     } else if ((rc = hip_ok(hipMemsetAsync(w.total, 0, sizeof(int), st)))) return rc;
-    hipLaunchKernelGGL(k_vox_frames, dim3(1), dim3(64), 0, st, point_offsets, w.rank, w.total, p, w.base,
-                       w.break_idx, voxel_offsets);
+    if (!fused_frames)
+        hipLaunchKernelGGL(k_vox_frames, dim3(1), dim3(64), 0, st, point_offsets, w.rank, w.total, p, w.base,
+                           w.break_idx, voxel_offsets);
     if (num_points > 0) {
         hipLaunchKernelGGL(k_vox_assign, dim3(nb), dim3(kBlock), 0, st, point_offsets, w.pslot, w.vals, w.keys,
-                           w.rank, w.base, voxel_offsets, p, w.svid, w.break_idx, coors);
+                           w.rank, w.base, voxel_offsets, p, w.svid, w.break_idx, coors,
+                           fused_frames ? w.total : (const int *)nullptr);
         hipLaunchKernelGGL(k_vox_cascade, dim3(nb), dim3(kBlock), 0, st, point_offsets, w.pslot, w.svid,
                            w.break_idx, p, w.count, w.slot_idx);
     }
