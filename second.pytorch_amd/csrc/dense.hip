@@ -695,7 +695,11 @@ static int launch_conv2d_halo_pipe(const void *x, const void *wpk, const float *
 // B fragment and each streams its own from L2 (1 KB coalesced per k-step, prefetched one iteration ahead in VGPRs).
 // LDS holds only the halo (46 KB -> 3 workgroups per CU, 2200 / 768 = 2.9 rounds), the main loop has no barrier,
 // and LDS traffic drops to one conflict-free ds_read_b128 per MFMA.
-// Cin = 128 runs the ROLL main loop (below): B fragments in an 8-deep ring loaded 7 k-steps ahead, and halo addresses built
+// Cin = 128 runs the ROLL == 2 main loop (below): m-tiles pair output rows (mt, mt + 4) so that SIX halo fragments per (dx, k-step)
+// feed the twelve MFMAs of the three kernel rows -- half the LDS reads of one fragment per MFMA (ROLL == 1, kept for A/B as
+// SEC_CONV2D_VARIANT=15): 79.9 -> 74.0 us on one box, 76.7 -> 71.8 us on another (batch 8, 200 x 176, 128 -> 128).  Setting wave
+// priorities (prologue / epilogue above the loop, and the reverse) and a 12-deep B ring were measured on that loop: +1 ... +5 % slower.
+// Both ROLL loops: B fragments in an 8-deep ring loaded 7 fragments ahead, and halo addresses built
 // from a per-lane base, a dx-only swizzle key and ds_read immediates.  The first version recomputed `hp % HW_` per m-tile and
 // tap -- ~125 VALU instructions per tap, a third of them quarter-rate 32-bit multiplies, against 32 MFMAs: 93 us -> 84 us
 // (1000 TFLOP/s) once they were gone.  Bounding runs on that shape: halos served from L2-resident tiles -2 us, epilogue
@@ -704,7 +708,7 @@ static int launch_conv2d_halo_pipe(const void *x, const void *wpk, const float *
 // With the ROLL loop re-measured: persistent workgroups (96 per XCD striding through the tiles, next halo DMA issued before the
 // epilogue stores, B ring wrapping into the next tile; 159 VGPRs, no spills) 83.7 vs 83.2 us -- no gain; 12 x 16 tiles 89 us,
 // 4 x 16 tiles at 5 workgroups per CU 94 us.
-template <typename T, int CIN, int TH, bool ROLL = false>
+template <typename T, int CIN, int TH, int ROLL = 0>
 __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(const T *__restrict__ x, const T *__restrict__ wpk,
                                                             const float *__restrict__ bias, T *__restrict__ y,
                                                             Conv2dParams p, int tiles_y, int tiles_x, int per_xcd) {
@@ -795,7 +799,19 @@ __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(con
         uint4 bq[2][4];
         constexpr int RD = 8;
         uint4 br[RD];                               // ROLL: ring of B fragments, each loaded RD - 1 k-steps ahead of its use
-        if constexpr (ROLL) {
+        // ROLL == 2: B fragments by buffer loads -- one lane-offset VGPR + a SCALAR chunk offset per fragment (24 global pointers
+        // per dx cost 48 VGPRs and spilled)
+        typedef unsigned int u32x4b __attribute__((ext_vector_type(4)));
+        const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(wpk), 0, (int)((9 * cin8 + 1) * p.cout * 16), 0x00020000);
+        const unsigned wvoff = (unsigned)(hh * p.cout + n0 + r) * 16u;
+        const unsigned wstep = (unsigned)p.cout * 16u;            // bytes per chunk row of the packed weights
+        auto ld_b = [&](unsigned chunk) {
+            return __builtin_bit_cast(uint4, (u32x4b)__builtin_amdgcn_raw_buffer_load_b128(wrs, wvoff, chunk * wstep, 0));
+        };
+        if constexpr (ROLL >= 2) {
+#pragma unroll
+            for (int f = 0; f < RD - 1; ++f) br[f] = ld_b((f % 3) * 48 + (f / 3) * 2);
+        } else if constexpr (ROLL) {
 #pragma unroll
             for (int f = 0; f < RD - 1; ++f) br[f] = wlane[(size_t)f * 2 * p.cout];
         } else {
@@ -825,7 +841,53 @@ __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(con
         uint4 af[2][MT];
         int tap = 0, kc = 0;
         if (live && !ROLL) load_a(0, 0, 0, af[0]);
-        if constexpr (ROLL) {
+        if constexpr (ROLL >= 2) {
+            // Shared-row fragments.  An m-tile pairs output rows (mt, mt + 4), so its A fragment for kernel row dy is the pair of
+            // halo rows (mt + dy, mt + dy + 4) = F[mt + dy]: for one (dx, k-step) SIX fragments F[0..5] feed all 3 x 4 = 12 MFMAs
+            // of the three kernel rows -- half the ds_read_b128 traffic of the ROLL == 1 loop (12 reads per 12 MFMAs), same B
+            // stream (one fragment per four MFMAs), same accumulators.  Rolled over dx, unrolled over 8 k-steps x 3 kernel rows;
+            // B fragment j = (k-step, dy) of this dx sits at chunk dy * 48 + dx * 16 + 2 * k-step of the packed [tap][cin8][cout].
+            static_assert(ROLL < 2 || (KC == 2 && CH == 16 && TH == 8), "8 k-steps per tap, rows (mt, mt + 4)");
+            const char *halb = reinterpret_cast<const char *>(hal);
+            const int colr = r & 15;
+            const unsigned base0 = (unsigned)((r >> 4) * 4 * HW_ + colr) * (CH * 16);
+            uint4 fr[2][6];
+            auto load_f2 = [&](unsigned bdx, unsigned key, int cidx, int j0, uint4 (&dst)[6]) {
+                const unsigned a = bdx + (((unsigned)cidx << 4) ^ key);
+#pragma unroll
+                for (int j = j0; j < j0 + 2; ++j) dst[j] = *reinterpret_cast<const uint4 *>(halb + a + j * HW_ * (CH * 16));
+            };
+            auto frag_off = [](int j) { return (j % 3) * 48 + (j / 3) * 2; };
+            if (live) {
+                {
+                    const unsigned key0 = (unsigned)(hh ^ (colr & 15)) << 4;
+#pragma unroll
+                    for (int h = 0; h < 3; ++h) load_f2(base0, key0, 0, 2 * h, fr[0]);
+                }
+#pragma unroll 1
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int dxn = dx < 2 ? dx + 1 : 2;
+                    const unsigned bdx = base0 + dx * (CH * 16), bdn = base0 + dxn * (CH * 16);
+                    const unsigned key = (unsigned)(hh ^ ((colr + dx) & 15)) << 4, keyn = (unsigned)(hh ^ ((colr + dxn) & 15)) << 4;
+                    const unsigned ct = dx * 16, cn = dxn * 16;
+#pragma unroll
+                    for (int ks = 0; ks < 8; ++ks) {
+#pragma unroll
+                        for (int dy = 0; dy < 3; ++dy) {
+                            const int j = ks * 3 + dy;
+                            br[(j + RD - 1) % RD] = j + RD - 1 < 24 ? ld_b(ct + frag_off(j + RD - 1)) : ld_b(cn + frag_off(j + RD - 1 - 24));
+                            // a third of the next k-step's six fragments per kernel row
+                            if (ks + 1 < 8) load_f2(bdx, key, (ks + 1) * 2, 2 * dy, fr[(ks + 1) & 1]);
+                            else load_f2(bdn, keyn, 0, 2 * dy, fr[0]);
+#pragma unroll
+                            for (int mt = 0; mt < MT; ++mt) acc[mt] = MfmaD<T>::run(br[j % RD], fr[ks & 1][mt + dy], acc[mt]);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                }
+            }
+            live = false;
+        } else if constexpr (ROLL) {
             // Rolled over the kernel ROW dy, unrolled over its 3 taps x 8 k-steps (three turns of the 8-deep B ring; fragment g
             // of the packed weights [tap][cin8][cout] sits at chunk 2 g).  The halo address of (pixel, tap, chunk) splits into
             //   lane base + dy * row pitch            (one VGPR, updated per dy)
@@ -913,7 +975,7 @@ __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(con
                     for (int j = 0; j < 4; ++j) v[j] = p.relu ? (v[j] > 0.0f ? v[j] : 0.0f) : v[j];
                     pk[g] = pack4<T>(v[0], v[1], v[2], v[3]);
                 }
-                const int q = mt * 32 + r;
+                const int q = ROLL >= 2 ? (mt + 4 * (r >> 4)) * 16 + (r & 15) : mt * 32 + r;   // tile pixel of (m-tile, lane)
 #pragma unroll
                 for (int pr = 0; pr < 2; ++pr) {
                     const uint2 keep = hh ? pk[2 * pr + 1] : pk[2 * pr];
@@ -934,6 +996,7 @@ __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(con
 #if defined(SEC_CONV2D_ABL) && SEC_CONV2D_ABL == 4
                 if (v.x != 0x12345678u) continue;                          // ablation build: no output stores
 #endif
+                // (non-temporal stores here: 76.0 vs 76.5 us, within noise)
                 if (oy < p.h && ox < p.w) y4[(((size_t)b * p.h + oy) * p.w + ox) * (p.cout / 8) + blockIdx.y * 16 + ch] = v;
             }
         } else {
@@ -981,7 +1044,7 @@ extern "C" __attribute__((visibility("default"))) int sec__debug_timeline2(long 
 }
 #endif
 
-template <typename T, int CIN, int TH, bool ROLL = false>
+template <typename T, int CIN, int TH, int ROLL = 0>
 static int launch_conv2d_halo_reg(const void *x, const void *wpk, const float *bias, void *y, const Conv2dParams &p, hipStream_t st) {
     constexpr size_t lds = (size_t)(TH + 2) * 18 * (CIN / 8) * 16;
     static bool configured = false;
@@ -1222,7 +1285,9 @@ static int launch_conv2d(const void *x, const void *wpk, const float *bias, void
     if (conv2d_variant() == 14 && p.ksize == 3 && p.stride == 1 && p.pad == 1 && p.cout % 128 == 0 && p.cin == 128)
         return launch_conv2d_halo_reg<T, 128, 8>(x, wpk, bias, y, p, st);   // A/B: the two-stage loop with per-m-tile halo addressing
     if (conv2d_variant() == 13 && p.ksize == 3 && p.stride == 1 && p.pad == 1 && p.cout % 128 == 0 && (p.cin == 128 || p.cin == 64))
-        return p.cin == 128 ? launch_conv2d_halo_reg<T, 128, 8, true>(x, wpk, bias, y, p, st) : launch_conv2d_halo_reg<T, 64, 8>(x, wpk, bias, y, p, st);
+        return p.cin == 128 ? launch_conv2d_halo_reg<T, 128, 8, 2>(x, wpk, bias, y, p, st) : launch_conv2d_halo_reg<T, 64, 8>(x, wpk, bias, y, p, st);
+    if (conv2d_variant() == 15 && p.ksize == 3 && p.stride == 1 && p.pad == 1 && p.cout % 128 == 0 && p.cin == 128)
+        return launch_conv2d_halo_reg<T, 128, 8, 1>(x, wpk, bias, y, p, st);   // A/B: one A fragment per MFMA (12 LDS reads per 12 MFMAs)
 #ifdef SEC_CONV2D_EXPERIMENTS   // earlier 3x3 kernels (LDS weight slabs / rings), kept for A/B builds: DESIGN.md section 4
     if (conv2d_variant() >= 5 && conv2d_variant() <= 12 && p.ksize == 3 && p.stride == 1 && p.pad == 1 && p.cout % 128 == 0 &&
         (p.cin == 128 || p.cin == 64)) {

@@ -1,4 +1,7 @@
 export PYTHONUNBUFFERED=1
-timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_e2e.py tests/test_gpu_round2.py -m gpu -q -x -k "predict or tie or detector or e2e or in_flight or nms or nuscenes or pointpillars" 2>&1 | tail -3
-timeout 600 python bench.py --no-cpu-baseline 2>/dev/null | python -c "
-import sys,json; d=json.loads(sys.stdin.read()); print('inflight3', d['value'], d['ms_per_step'], d['config']['single_step_latency_ms'], [ (k['op'],k['us']) for k in d['kernels'] if k['op'].startswith('predict') or k['op']=='nms_sorted'])"
+mkdir -p gpurun_out
+timeout 1200 python -m pytest tests -m gpu -q -x 2>&1 | tail -3
+timeout 600 python tools/inflight_stress.py 2>&1 | tail -2
+timeout 600 python bench.py > gpurun_out/bench_i3.json 2> gpurun_out/bench_i3.err; tail -c 600 gpurun_out/bench_i3.err
+python -c "
+import json; d=json.load(open('gpurun_out/bench_i3.json')); print('inflight3', d['value'], d['ms_per_step'], d['config']['single_step_latency_ms'], d['roofline'], d['cpu_baseline'])"
