@@ -2,6 +2,7 @@
 // through MIOpen in phase 1; the per-channel bias (folded BatchNorm2d) + ReLU that follows every conv is ONE
 // in-place pass here instead of MIOpen's separate bias tensor-op plus a ReLU kernel (3 passes -> 1).
 #include "common.hpp"
+#include <type_traits>
 #include <stdio.h>
 #include <stdlib.h>
 #include <stdlib.h>
@@ -68,6 +69,21 @@ template <> struct MfmaD<__half> {
     }
 };
 
+
+// Two fp32 -> one dword of two 16-bit values with ONE conversion instruction pair (v_cvt_pk_bf16_f32 on gfx950; the scalar
+// from_f<T> form compiles to one convert + one merge per VALUE).  Same rounding as from_f<T> (round to nearest even).
+typedef float f32x2d __attribute__((ext_vector_type(2)));
+template <typename T> __device__ __forceinline__ unsigned pack2(float a, float b);
+template <> __device__ __forceinline__ unsigned pack2<__hip_bfloat16>(float a, float b) {
+    typedef __bf16 bf16x2d __attribute__((ext_vector_type(2)));
+    const f32x2d v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2d));
+}
+template <> __device__ __forceinline__ unsigned pack2<__half>(float a, float b) {
+    typedef _Float16 f16x2d __attribute__((ext_vector_type(2)));
+    const f32x2d v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2d));
+}
 
 // Transposed-accumulator epilogue.  With the MFMA operands swapped (weights as the first operand) the 32x32 result
 // tile is D^T: a lane owns ONE pixel (lane & 31) and, per group g = i >> 2, four CONSECUTIVE output channels
@@ -748,6 +764,40 @@ __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(con
             __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)&hal[i * 64], 16, 0, 0);
         }
     };
+    // The same halo by buffer LDS-DMA with incrementally built offsets (ROLL == 2).  The loop above costs ~40 instructions per
+    // 1 KB piece (two divisions by 18, 64-bit address multiplies, two divergent branches) and, issued beside two other waves'
+    // MFMA loops at one slot per ~18 clocks, took 8 900 of the prologue's 9 850 clocks (timeline) -- the DMA latency was the small
+    // part.  Here a piece's four halo pixels advance by 16 per step (hx += 16, wrapping at 18 into the next row), the image is a
+    // buffer resource whose bounds check zero-fills the rows above and below it, and only the left / right border columns need
+    // a select: ~14 VALU per piece, no branches.
+    auto issue_halo2 = [&](int tile) {
+        const int b = tile / (tiles_y * tiles_x);
+        const int trem = tile - b * tiles_y * tiles_x;
+        const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
+        const unsigned img_bytes = (unsigned)p.h * (unsigned)p.w * (CIN * 2u);
+        const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(x) + (size_t)b * p.h * p.w * CIN, 0, (int)img_bytes, 0x00020000);
+        const int wvs = __builtin_amdgcn_readfirstlane(wv);
+        const unsigned slot = lane & 15;
+        const unsigned row_pitch = (unsigned)p.w * (CIN * 2u);
+        int hx = wvs * 4 + (lane >> 4);                                                   // halo pixel hp = i * 4 + lane / 16 -> (hy, hx), hy = 0 here
+        unsigned rowoff = (unsigned)((y0 - 1) * p.w + (x0 - 1)) * (CIN * 2u);            // may wrap below zero: out of bounds, zero fill
+#pragma unroll
+        for (int t = 0; t < (HENT / 64 + 3) / 4; ++t) {
+            const int i = wvs + 4 * t;
+            if (i < HENT / 64) {
+                const unsigned key = (slot ^ ((unsigned)hx & 15u)) << 4;
+                unsigned off = rowoff + ((unsigned)hx << 8) + key;
+                const unsigned ix = (unsigned)(x0 - 1 + hx);
+                off = ix < (unsigned)p.w ? off : 0xfffffff0u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)&hal[i * 64], 16, off, 0, 0, 0);
+            }
+            hx += 16;
+            const bool wrap = hx >= HW_;
+            hx = wrap ? hx - HW_ : hx;
+            rowoff = wrap ? rowoff + row_pitch : rowoff;
+        }
+    };
+    static_assert(HENT % 64 == 0 || ROLL < 2, "whole 1 KB pieces");
     // B fragment of k-step s of slab `it` = (tap, kc): packed weights are [tap][cin8][cout] uint4
     const uint4 *wlane = w4 + (size_t)hh * p.cout + n0 + r;
     auto load_b = [&](int it, uint4 (&dst)[4]) {
@@ -791,7 +841,12 @@ __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(con
         resident_at_start = atomicAdd(&g_cu_resident[cu_key], 1);
     }
 #endif
-    issue_halo(tile);
+    if constexpr (ROLL >= 2) issue_halo2(tile);
+    else issue_halo(tile);
+#ifdef SEC_CONV_TIMELINE
+    long long tl_issue = 0, tl_eb1 = 0, tl_eb2 = 0;
+    if (tl) tl_issue = clock64();
+#endif
     {
         const int b = tile / (tiles_y * tiles_x);
         const int trem = tile - b * tiles_y * tiles_x;
@@ -961,32 +1016,48 @@ __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(con
             // and after one barrier every instruction of the workgroup stores ONE 4 KB tile row (16 pixels x 256 B, contiguous).
             constexpr int PITCH = 17;                       // uint4 per pixel row: 16 + 1 pad
             __syncthreads();                                // every wave is done reading the halo
+#ifdef SEC_CONV_TIMELINE
+            if (tl) tl_eb1 = clock64();
+#endif
             uint4 *ot = halo_smem;
             float4 bv[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) bv[g] = bias ? *reinterpret_cast<const float4 *>(bias + n0 + 8 * g + 4 * hh) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            // This phase runs beside two other waves' MFMA loops on the SIMD and gets an issue slot every ~18 clocks (timeline:
+            // 7 300 clocks for the ~900 instructions of the first form -- a branch per value for the ReLU, one convert + merge per
+            // value, ds_bpermute + selects for the half-wave exchange).  Here: add, max, one convert per PAIR, and
+            // v_permlane32_swap, which IS the exchange: after swap(pk[2pr], pk[2pr+1]) the low half-wave holds both halves of
+            // chunk 2pr and the high half-wave both halves of chunk 2pr+1 -- no selects.  ~200 instructions.
+            auto put_tile = [&](auto relu_tag) {
+                constexpr bool RELU = decltype(relu_tag)::value;
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                uint2 pk[4];
+                for (int mt = 0; mt < MT; ++mt) {
+                    unsigned lo[4], hi[4];                  // channels 8g+4hh+(0,1) and +(2,3) of this lane's pixel
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    float v[4] = {acc[mt][4 * g] + bv[g].x, acc[mt][4 * g + 1] + bv[g].y, acc[mt][4 * g + 2] + bv[g].z, acc[mt][4 * g + 3] + bv[g].w};
+                    for (int g = 0; g < 4; ++g) {
+                        float v[4] = {acc[mt][4 * g] + bv[g].x, acc[mt][4 * g + 1] + bv[g].y, acc[mt][4 * g + 2] + bv[g].z, acc[mt][4 * g + 3] + bv[g].w};
+                        if (RELU) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = p.relu ? (v[j] > 0.0f ? v[j] : 0.0f) : v[j];
-                    pk[g] = pack4<T>(v[0], v[1], v[2], v[3]);
+                            for (int j = 0; j < 4; ++j) v[j] = __builtin_fmaxf(v[j], 0.0f);
+                        }
+                        lo[g] = pack2<T>(v[0], v[1]);
+                        hi[g] = pack2<T>(v[2], v[3]);
+                    }
+                    const int q = ROLL >= 2 ? (mt + 4 * (r >> 4)) * 16 + (r & 15) : mt * 32 + r;   // tile pixel of (m-tile, lane)
+#pragma unroll
+                    for (int pr = 0; pr < 2; ++pr) {
+                        const auto sx = __builtin_amdgcn_permlane32_swap(lo[2 * pr], lo[2 * pr + 1], false, false);
+                        const auto sy = __builtin_amdgcn_permlane32_swap(hi[2 * pr], hi[2 * pr + 1], false, false);
+                        ot[q * PITCH + wv * 4 + 2 * pr + hh] = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+                    }
                 }
-                const int q = ROLL >= 2 ? (mt + 4 * (r >> 4)) * 16 + (r & 15) : mt * 32 + r;   // tile pixel of (m-tile, lane)
-#pragma unroll
-                for (int pr = 0; pr < 2; ++pr) {
-                    const uint2 keep = hh ? pk[2 * pr + 1] : pk[2 * pr];
-                    const uint2 send = hh ? pk[2 * pr] : pk[2 * pr + 1];
-                    uint2 recv;
-                    recv.x = (unsigned)__shfl_xor((int)send.x, 32, 64);
-                    recv.y = (unsigned)__shfl_xor((int)send.y, 32, 64);
-                    ot[q * PITCH + wv * 4 + 2 * pr + hh] = hh ? make_uint4(recv.x, recv.y, keep.x, keep.y) : make_uint4(keep.x, keep.y, recv.x, recv.y);
-                }
-            }
+            };
+            if (p.relu) put_tile(std::true_type{});
+            else put_tile(std::false_type{});
             __syncthreads();
+#ifdef SEC_CONV_TIMELINE
+            if (tl) tl_eb2 = clock64();
+#endif
             uint4 *y4 = reinterpret_cast<uint4 *>(y);
 #pragma unroll
             for (int ty_ = 0; ty_ < TH; ++ty_) {            // one tile row (16 pixels x 16 chunks) per instruction
@@ -1013,6 +1084,7 @@ __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(con
         if (tl && tid == 0 && blockIdx.y == 0) {
             long long *rec = tl + (size_t)blockIdx.x * 8;
             rec[0] = tl0; rec[1] = tl1; rec[2] = tl2 + ((long long)resident_at_start << 56); rec[3] = clock64();
+            rec[7] = ((tl_issue - tl0) >> 4 & 0xffff) | ((tl_eb1 - tl2) >> 4 & 0xffff) << 16 | ((tl_eb2 - tl2) >> 4 & 0xffff) << 32;
             rec[4] = wl0; rec[5] = wall_clock64(); rec[6] = cu_key;       // constant 100 MHz counter: real time, comparable across CUs
             atomicSub(&g_cu_resident[cu_key], 1);
         }

@@ -49,6 +49,12 @@ for batch in [int(v) for v in os.environ.get("BATCHES", "1,2,3,4,6,8,16").split(
                           ("workgroup life", tt[:, 3] - tt[:, 0])):
             q = np.percentile(col, [5, 50, 95])
             print(f"    {name:22s} p5={q[0]:8.0f} p50={q[1]:8.0f} p95={q[2]:8.0f} clocks")
+        if raw[:, 7].any():                                 # finer stamps (16-clock units): DMA issue, the two epilogue barriers
+            sub = raw[:, 7]
+            for name, col in (("  prologue: halo DMA issue", (sub & 0xffff) * 16), ("  epilogue: loop end -> barrier 1 (wave skew)", (sub >> 16 & 0xffff) * 16),
+                              ("  epilogue: -> barrier 2 (transposed tile in LDS)", (sub >> 32 & 0xffff) * 16)):
+                q = np.percentile(col.astype(np.float64), [5, 50, 95])
+                print(f"    {name:50s} p5={q[0]:8.0f} p50={q[1]:8.0f} p95={q[2]:8.0f} clocks")
         # real time (s_memrealtime, 100 MHz): shader clock during the kernel and how full the 3 resident slots per CU are
         w0, w1 = tt[:, 4], tt[:, 5]
         span = (w1.max() - w0.min()) * 10e-9
