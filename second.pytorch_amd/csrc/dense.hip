@@ -98,26 +98,32 @@ template <typename T> __device__ __forceinline__ uint2 pack4(float a, float b, f
 template <typename T, bool HAS_BIAS>
 __device__ __forceinline__ void store_tile_tb(const f32x16d &acc, const float *__restrict__ bias, int c0, int relu,
                                               T *__restrict__ ypix, bool ok, int hh) {
-    uint2 pk[4];
+    // (`relu ? (v > 0 ? v : 0) : v` per value compiled into a BRANCH per value, and from_f<T> into one convert + merge per
+    // value: ~230 instructions per tile.  One uniform branch, max, pair converts and v_permlane32_swap for the half-wave
+    // exchange -- see the epilogue of k_conv2d_halo_reg -- are ~60.)
+    unsigned lo[4], hi[4];
+    auto cvt = [&](auto relu_tag) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const int c = c0 + 8 * g + 4 * hh;
-        float4 bv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (HAS_BIAS) bv = *reinterpret_cast<const float4 *>(bias + c);
-        float v[4] = {acc[4 * g] + bv.x, acc[4 * g + 1] + bv.y, acc[4 * g + 2] + bv.z, acc[4 * g + 3] + bv.w};
+        for (int g = 0; g < 4; ++g) {
+            const int c = c0 + 8 * g + 4 * hh;
+            float4 bv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (HAS_BIAS) bv = *reinterpret_cast<const float4 *>(bias + c);
+            float v[4] = {acc[4 * g] + bv.x, acc[4 * g + 1] + bv.y, acc[4 * g + 2] + bv.z, acc[4 * g + 3] + bv.w};
+            if (decltype(relu_tag)::value) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = relu ? (v[j] > 0.0f ? v[j] : 0.0f) : v[j];
-        pk[g] = pack4<T>(v[0], v[1], v[2], v[3]);
-    }
+                for (int j = 0; j < 4; ++j) v[j] = __builtin_fmaxf(v[j], 0.0f);
+            }
+            lo[g] = pack2<T>(v[0], v[1]);
+            hi[g] = pack2<T>(v[2], v[3]);
+        }
+    };
+    if (relu) cvt(std::true_type{});
+    else cvt(std::false_type{});
 #pragma unroll
     for (int pr = 0; pr < 2; ++pr) {
-        const uint2 keep = hh ? pk[2 * pr + 1] : pk[2 * pr];
-        const uint2 send = hh ? pk[2 * pr] : pk[2 * pr + 1];
-        uint2 recv;
-        recv.x = (unsigned)__shfl_xor((int)send.x, 32, 64);
-        recv.y = (unsigned)__shfl_xor((int)send.y, 32, 64);
-        const uint4 out = hh ? make_uint4(recv.x, recv.y, keep.x, keep.y) : make_uint4(keep.x, keep.y, recv.x, recv.y);
-        if (ok) *reinterpret_cast<uint4 *>(ypix + c0 + 8 * (2 * pr + hh)) = out;
+        const auto sx = __builtin_amdgcn_permlane32_swap(lo[2 * pr], lo[2 * pr + 1], false, false);
+        const auto sy = __builtin_amdgcn_permlane32_swap(hi[2 * pr], hi[2 * pr + 1], false, false);
+        if (ok) *reinterpret_cast<uint4 *>(ypix + c0 + 8 * (2 * pr + hh)) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
     }
 }
 template <typename T>
@@ -1274,6 +1280,8 @@ __global__ __launch_bounds__(256, 3) void k_conv1x1_chain(const T *__restrict__ 
             acc[mt] = MfmaD<T>::run(bq[s], tile[px * CH + ((s * 2 + hh) ^ (px & 15))], acc[mt]);   // D^T: see store_tile_t
         }
     // second-GEMM weights: wave = 64 pixels (wm) x N2 / 2 couts (wn); issued now, needed after the two barriers
+    // (launch bound 4 per CU -- 128 VGPRs -- spills 8 ... 14 dwords whether these loads sit here or are staggered through the
+    // first GEMM's steps)
     const int wm = wv & 1, wn = wv >> 1;
     uint4 cq[8][NT2];
     {
@@ -1286,19 +1294,25 @@ __global__ __launch_bounds__(256, 3) void k_conv1x1_chain(const T *__restrict__ 
     lds_barrier();                                  // every wave has read all of x
     {   // intermediate -> LDS (bias, ReLU, 16-bit): lane owns pixel mt*32 + r, channels 32 wv + 8 g + 4 hh + (0..3)
         unsigned char *tb = reinterpret_cast<unsigned char *>(tile);
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const int px = mt * 32 + r;
+        auto put = [&](auto relu_tag) {         // one uniform branch for the ReLU, pair converts (see store_tile_tb)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int c = wv * 32 + 8 * g + 4 * hh;
-                const float4 bv = *reinterpret_cast<const float4 *>(b1 + c);
-                float v[4] = {acc[mt][4 * g] + bv.x, acc[mt][4 * g + 1] + bv.y, acc[mt][4 * g + 2] + bv.z, acc[mt][4 * g + 3] + bv.w};
+                const float4 bv = *reinterpret_cast<const float4 *>(b1 + wv * 32 + 8 * g + 4 * hh);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = relu1 ? (v[j] > 0.0f ? v[j] : 0.0f) : v[j];
-                *reinterpret_cast<uint2 *>(tb + ((size_t)px * CH + ((wv * 4 + g) ^ (px & 15))) * 16 + hh * 8) = pack4<T>(v[0], v[1], v[2], v[3]);
+                for (int mt = 0; mt < 4; ++mt) {
+                    const int px = mt * 32 + r;
+                    float v[4] = {acc[mt][4 * g] + bv.x, acc[mt][4 * g + 1] + bv.y, acc[mt][4 * g + 2] + bv.z, acc[mt][4 * g + 3] + bv.w};
+                    if (decltype(relu_tag)::value) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = __builtin_fmaxf(v[j], 0.0f);
+                    }
+                    *reinterpret_cast<uint2 *>(tb + ((size_t)px * CH + ((wv * 4 + g) ^ (px & 15))) * 16 + hh * 8) =
+                        make_uint2(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]));
+                }
             }
-        }
+        };
+        if (relu1) put(std::true_type{});
+        else put(std::false_type{});
     }
     lds_barrier();
     f32x16d acc2[2][NT2];
