@@ -377,10 +377,14 @@ def cpu_baseline(cpu_state, clouds, gpu_out=None, budget_s=20.0):
     res = []
     while len(res) < len(clouds) and (len(res) < 1 or time.perf_counter() - t0 < budget_s):
         res.append(forward_frame(det, clouds[len(res)]))
-    dt = time.perf_counter() - t0
     n = len(res)
-    out = {"value": round(n / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
-           "sample": f"{n} synthetic KITTI frame(s) (17k pts, 16k voxels), fp32; oracle (1 thread) for voxelise/"
+    timed = n
+    while time.perf_counter() - t0 < min(10.0, budget_s):      # a sample of >= 10 s: the same frames again, timing only
+        forward_frame(det, clouds[timed % len(clouds)])
+        timed += 1
+    dt = time.perf_counter() - t0
+    out = {"value": round(timed / dt, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+           "sample": f"{timed} forward(s) over {n} synthetic KITTI frame(s) (17k pts, 16k voxels), fp32; oracle (1 thread) for voxelise/"
                      f"rulebook/indice_conv/NMS + torch CPU ({cores} threads) for the RPN; {dt:.1f} s",
            "detections": [r["num_detections"] for r in res]}
     if gpu_out is not None:
