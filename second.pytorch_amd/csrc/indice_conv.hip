@@ -490,6 +490,21 @@ struct RowsCfg {
     static constexpr int RING = 3;
 };
 
+// two fp32 -> one dword of two 16-bit values, one conversion per PAIR (v_cvt_pk_bf16_f32; Cvt<T>::from per value compiles
+// into a convert plus a merge each); round to nearest even like Cvt<T>::from
+typedef float f32x2p __attribute__((ext_vector_type(2)));
+template <typename T> __device__ __forceinline__ unsigned pack2_16(float a, float b);
+template <> __device__ __forceinline__ unsigned pack2_16<__hip_bfloat16>(float a, float b) {
+    typedef __bf16 bf16x2p __attribute__((ext_vector_type(2)));
+    const f32x2p v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2p));
+}
+template <> __device__ __forceinline__ unsigned pack2_16<__half>(float a, float b) {
+    typedef _Float16 f16x2p __attribute__((ext_vector_type(2)));
+    const f32x2p v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2p));
+}
+
 // epilogue of the row-per-lane (D^T) accumulator layout: lane owns row `r`, channels t*32 + 8g + 4h + (0..3); half-waves
 // swap a register group so every lane stores 16-byte runs; fused scale / shift / ReLU
 // `aff` = LDS copy of scale[COUT] | shift[COUT] made by rows_stage_affine at kernel start (16-byte reads, all in flight together)
@@ -511,25 +526,24 @@ __device__ __forceinline__ void rows_store_impl(f32x16 (&acc)[(COUT + 31) / 32],
         }
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        uint2 pk[NG];
+        unsigned lo[NG], hi[NG];
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             const float sc[4] = {sc4[t][g].x, sc4[t][g].y, sc4[t][g].z, sc4[t][g].w};
             const float sh[4] = {sh4[t][g].x, sh4[t][g].y, sh4[t][g].z, sh4[t][g].w};
-            T v4[4];
+            float v4[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v4[j] = Cvt<T>::from(epilogue_v(acc[t][4 * g + j], sc[j], sh[j], has_scale, has_shift, relu));
-            __builtin_memcpy(&pk[g], v4, 8);
+            for (int j = 0; j < 4; ++j) v4[j] = epilogue_v(acc[t][4 * g + j], sc[j], sh[j], has_scale, has_shift, relu);
+            lo[g] = pack2_16<T>(v4[0], v4[1]);
+            hi[g] = pack2_16<T>(v4[2], v4[3]);
         }
+        // half-wave exchange = v_permlane32_swap of the two group registers: afterwards the low half-wave holds both halves of
+        // 16-byte run 2pr, the high half-wave of run 2pr + 1 (ds_bpermute + selects before)
 #pragma unroll
         for (int pr = 0; pr < NG / 2; ++pr) {
-            const uint2 keep = h ? pk[2 * pr + 1] : pk[2 * pr];
-            const uint2 send = h ? pk[2 * pr] : pk[2 * pr + 1];
-            uint2 recv;
-            recv.x = (unsigned)__shfl_xor((int)send.x, 32, 64);
-            recv.y = (unsigned)__shfl_xor((int)send.y, 32, 64);
-            const uint4 o = h ? make_uint4(recv.x, recv.y, keep.x, keep.y) : make_uint4(keep.x, keep.y, recv.x, recv.y);
-            if (valid) *reinterpret_cast<uint4 *>(orow + t * 32 + 8 * (2 * pr + h)) = o;
+            const auto sx = __builtin_amdgcn_permlane32_swap(lo[2 * pr], lo[2 * pr + 1], false, false);
+            const auto sy = __builtin_amdgcn_permlane32_swap(hi[2 * pr], hi[2 * pr + 1], false, false);
+            if (valid) *reinterpret_cast<uint4 *>(orow + t * 32 + 8 * (2 * pr + h)) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
         }
     }
 }
