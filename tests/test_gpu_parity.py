@@ -723,7 +723,11 @@ def test_pointpillars_detector_runs_fused_equals_module_path(syn):
 @pytest.mark.parametrize("cin,cout,k,stride,pad,hw", [(128, 128, 3, 1, 1, (200, 176)), (64, 64, 3, 2, 1, (37, 29)),
                                                      (128, 256, 3, 2, 1, (50, 50)), (128, 64, 1, 1, 0, (33, 17)),
                                                      (128, 128, 1, 1, 0, (61, 43)),
-                                                     (64, 128, 3, 1, 1, (9, 7))])
+                                                     (64, 128, 3, 1, 1, (9, 7)),
+                                                     # the halo kernel's border handling: ragged right / bottom edges, a single tile, one pixel
+                                                     # over a tile, two output-channel blocks
+                                                     (128, 128, 3, 1, 1, (37, 29)), (128, 128, 3, 1, 1, (8, 16)), (128, 128, 3, 1, 1, (9, 17)),
+                                                     (128, 256, 3, 1, 1, (23, 40)), (128, 128, 3, 1, 1, (1, 1))])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_conv2d_nhwc_mfma_vs_torch(ops, cin, cout, k, stride, pad, hw, dtype):
     torch.manual_seed(cin + cout + k)
