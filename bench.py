@@ -204,6 +204,16 @@ def kernel_table(det, points, offsets, reps=30):
             b_, cin, _, _ = x.shape
             ent.update(flop=2.0 * b_ * res.shape[2] * res.shape[3] * cin * cout * ks * ks,
                        bytes=elt(x.dtype) * (x.numel() + res.numel()), detail=f"{cin}->{cout} k{ks} {tuple(x.shape[2:])}")
+        elif name == "sparse_site_map":
+            n = live(kw.get("num_dev"), a[0].shape[0])
+            ent.update(bytes=16 * n + 4 * res.numel(), detail=f"{n} sites -> map {tuple(res.shape)}")
+        elif name == "conv2d_nhwc_gather":
+            feat, smap, cout = a[0], a[1], a[4]
+            b_, _, h_, w_ = smap.shape
+            n = int((smap > 0).sum().item())
+            # FLOPs of the dense-equivalent layer (what the fraction is quoted on); bytes actually named: map + live rows + output
+            ent.update(flop=2.0 * b_ * h_ * w_ * 128 * cout * 9, bytes=4 * smap.numel() + elt(feat.dtype) * n * 64 + elt(feat.dtype) * res.numel(),
+                       detail=f"128->{cout} k3 ({h_}, {w_}) gathered from {n} sparse rows (no dense image)")
         elif name == "conv1x1_chain":
             x = a[0]
             ent.update(flop=2.0 * x.shape[0] * x.shape[2] * x.shape[3] * 128 * (128 + res.shape[1]), bytes=elt(x.dtype) * (x.numel() + res.numel()),

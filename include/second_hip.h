@@ -212,6 +212,18 @@ int sec_sparse_to_dense(const void *features, const int *indices, int n, int c, 
                         void *out, size_t out_elems, int64_t stride_b, int64_t stride_c,
                         int64_t stride_z, int64_t stride_y, int64_t stride_x, int dtype, void *stream);
 
+/* SparseConvTensor.dense() WITHOUT the dense image, for the first RPN convolution (middle.py:206-210 -> rpn.py:486-497):
+ * site_map[b][z][y][x] = row + 1 of the active site (0 = none), d = 2 planes.  sec_conv2d_nhwc_gather then runs the 3x3 /
+ * stride 1 / pad 1 convolution of the [B, 2 * 64, H, W] view straight from the feature rows [rows][64] (16-bit): input channel
+ * z * 64 + c, i.e. the weights must be packed from `weight[:, perm]` with perm[z * 64 + c] = c * 2 + z (the reference's
+ * channel order after `.view(N, C * D, H, W)` is c * D + z).  Tiles without any active site write act(bias).
+ * `feature_rows` = rows the feature buffer holds (capacity; only rows named by the map are read). */
+int sec_sparse_site_map(const int *indices, int n, const int *num_dev, int batch, int d, int h, int w,
+                        int *site_map, void *stream);
+int sec_conv2d_nhwc_gather(const void *features, long long feature_rows, const int *site_map, int batch, int h,
+                           int w, const void *packed_weight, const float *bias, int cout, int relu, void *y,
+                           int dtype, void *stream);
+
 /* Adjoint of sec_sparse_to_dense -- rows[i,:] = dense[indices[i]] -- i.e. the backward of
  * SparseConvTensor.dense() (upstream gets it from autograd through scatter_nd, spconv/__init__.py) and of
  * PointPillarsScatter (pointpillars.py:444-476) with stride_z = 0. */

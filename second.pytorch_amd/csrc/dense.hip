@@ -730,10 +730,17 @@ static int launch_conv2d_halo_pipe(const void *x, const void *wpk, const float *
 // With the ROLL loop re-measured: persistent workgroups (96 per XCD striding through the tiles, next halo DMA issued before the
 // epilogue stores, B ring wrapping into the next tile; 159 VGPRs, no spills) 83.7 vs 83.2 us -- no gain; 12 x 16 tiles 89 us,
 // 4 x 16 tiles at 5 workgroups per CU 94 us.
-template <typename T, int CIN, int TH, int ROLL = 0>
+// GATHER: the input is not a dense image but a sparse tensor -- `x` = its feature rows [rows][CIN / 2] (the two z planes of a
+// site column are two rows), `site_map` = [batch][2][h][w] row + 1 (sec_sparse_site_map).  The halo pieces are gathered from
+// the rows (input channel z * 64 + c: the weights are packed in that order), sites without a row read zeros through the buffer
+// bounds check, and a tile whose 2 x 180 map entries are all empty skips the DMA, the LDS sweep and the MFMA loop: what the
+// zero fill + scatter + zero-tile test of the dense form computed, without the 72 MB image.
+template <typename T, int CIN, int TH, int ROLL = 0, bool GATHER = false>
 __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(const T *__restrict__ x, const T *__restrict__ wpk,
                                                             const float *__restrict__ bias, T *__restrict__ y,
-                                                            Conv2dParams p, int tiles_y, int tiles_x, int per_xcd) {
+                                                            Conv2dParams p, int tiles_y, int tiles_x, int per_xcd,
+                                                            const int *__restrict__ site_map, unsigned feat_bytes) {
+    static_assert(!GATHER || (ROLL == 2 && CIN == 128), "gather prologue: the shared-row loop on two 64-channel planes");
     constexpr int TW = 16, HW_ = TW + 2, HPIX = (TH + 2) * (TW + 2);
     constexpr int MT = TH * TW / 32;               // 32-pixel m-tiles per wave (4 for an 8 x 16 tile)
     constexpr int CH = CIN / 8, HENT = HPIX * CH;
@@ -803,6 +810,52 @@ __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(con
             rowoff = wrap ? rowoff + row_pitch : rowoff;
         }
     };
+    // GATHER form of the same pieces: lane (pixel, slot) fetches chunk c = slot ^ key of its halo pixel = 16 bytes at
+    // (c & 7) * 16 of the row of plane z = c >> 3; the row comes from the site map (0 = none -> out-of-range offset -> zeros).
+    // Returns whether any of this lane's map entries names a row.
+    auto issue_halo_gather = [&](int tile) -> unsigned {
+        constexpr int NP = (HENT / 64 + 3) / 4;
+        const int b = tile / (tiles_y * tiles_x);
+        const int trem = tile - b * tiles_y * tiles_x;
+        const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
+        const unsigned plane = (unsigned)p.h * (unsigned)p.w;
+        const __amdgpu_buffer_rsrc_t mrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<int *>(site_map) + (size_t)b * 2 * plane, 0, (int)(plane * 8u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(x), 0, (int)feat_bytes, 0x00020000);
+        const int wvs = __builtin_amdgcn_readfirstlane(wv);
+        const unsigned slot = lane & 15;
+        int hx = wvs * 4 + (lane >> 4), iy = y0 - 1;
+        unsigned rowp1[NP], coff[NP], any = 0;
+#pragma unroll
+        for (int t = 0; t < NP; ++t) {
+            const int i = wvs + 4 * t;
+            rowp1[t] = 0;
+            coff[t] = 0;
+            if (i < HENT / 64) {
+                const unsigned c = slot ^ ((unsigned)hx & 15u);
+                const int ix = x0 - 1 + hx;
+                const bool ok = (unsigned)ix < (unsigned)p.w && (unsigned)iy < (unsigned)p.h;
+                const unsigned moff = ((c >> 3 ? plane : 0u) + (unsigned)(iy * p.w + ix)) * 4u;
+                rowp1[t] = __builtin_amdgcn_raw_buffer_load_b32(mrs, ok ? moff : 0xfffffffcu, 0, 0);
+                coff[t] = (c & 7u) << 4;
+            }
+            hx += 16;
+            const bool wrap = hx >= HW_;
+            hx = wrap ? hx - HW_ : hx;
+            iy = wrap ? iy + 1 : iy;
+        }
+#pragma unroll
+        for (int t = 0; t < NP; ++t) any |= rowp1[t];
+        if (__syncthreads_or((int)(any != 0)) == 0) return 0u;          // empty tile: nothing to fetch
+#pragma unroll
+        for (int t = 0; t < NP; ++t) {
+            const int i = wvs + 4 * t;
+            if (i < HENT / 64) {
+                const unsigned off = rowp1[t] ? (rowp1[t] - 1u) * (CIN * 1u) + coff[t] : 0xfffffff0u;   // a row = CIN / 2 16-bit channels = CIN bytes
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(frs, (lds_ptr_t)&hal[i * 64], 16, off, 0, 0, 0);
+            }
+        }
+        return 1u;
+    };
     static_assert(HENT % 64 == 0 || ROLL < 2, "whole 1 KB pieces");
     // B fragment of k-step s of slab `it` = (tap, kc): packed weights are [tap][cin8][cout] uint4
     const uint4 *wlane = w4 + (size_t)hh * p.cout + n0 + r;
@@ -847,7 +900,9 @@ __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(con
         resident_at_start = atomicAdd(&g_cu_resident[cu_key], 1);
     }
 #endif
-    if constexpr (ROLL >= 2) issue_halo2(tile);
+    unsigned gather_live = 1;
+    if constexpr (GATHER) gather_live = issue_halo_gather(tile);
+    else if constexpr (ROLL >= 2) issue_halo2(tile);
     else issue_halo(tile);
 #ifdef SEC_CONV_TIMELINE
     long long tl_issue = 0, tl_eb1 = 0, tl_eb2 = 0;
@@ -890,7 +945,8 @@ __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(con
         // First RPN layer: its input is the scattered sparse-middle output, most 10 x 18 halos hold nothing but zeros and
         // the result is act(bias) exactly (0 * w accumulates to 0) -- one LDS sweep + a barrier decides, uniformly.
         bool live = true;
-        if (p.zskip) {
+        if constexpr (GATHER) live = gather_live != 0;   // uniform: decided from the site map before any DMA
+        else if (p.zskip) {
             unsigned nz = 0;
             for (int e = tid; e < HENT; e += 256) {
                 const uint4 v = hal[e];
@@ -1122,11 +1178,12 @@ extern "C" __attribute__((visibility("default"))) int sec__debug_timeline2(long 
 }
 #endif
 
-template <typename T, int CIN, int TH, int ROLL = 0>
-static int launch_conv2d_halo_reg(const void *x, const void *wpk, const float *bias, void *y, const Conv2dParams &p, hipStream_t st) {
+template <typename T, int CIN, int TH, int ROLL = 0, bool GATHER = false>
+static int launch_conv2d_halo_reg(const void *x, const void *wpk, const float *bias, void *y, const Conv2dParams &p, hipStream_t st,
+                                  const int *site_map = nullptr, unsigned feat_bytes = 0) {
     constexpr size_t lds = (size_t)(TH + 2) * 18 * (CIN / 8) * 16;
     static bool configured = false;
-    auto fn = k_conv2d_halo_reg<T, CIN, TH, ROLL>;
+    auto fn = k_conv2d_halo_reg<T, CIN, TH, ROLL, GATHER>;
     if (!configured) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         configured = true;
@@ -1142,7 +1199,8 @@ static int launch_conv2d_halo_reg(const void *x, const void *wpk, const float *b
     const int ty = div_up(p.h, TH), tx = div_up(p.w, 16);
     const int per_xcd = div_up(p.batch * ty * tx, 8);
     const int gx = per_xcd * 8;
-    hipLaunchKernelGGL(fn, dim3(gx, p.cout / 128), dim3(256), lds, st, (const T *)x, (const T *)wpk, bias, (T *)y, p, ty, tx, per_xcd);
+    hipLaunchKernelGGL(fn, dim3(gx, p.cout / 128), dim3(256), lds, st, (const T *)x, (const T *)wpk, bias, (T *)y, p, ty, tx, per_xcd,
+                       site_map, feat_bytes);
     return check_launch();
 }
 
@@ -1472,6 +1530,22 @@ SEC_API int sec_conv2d_nhwc(const void *x, int batch, int h, int w, int cin, con
     hipStream_t st = (hipStream_t)stream;
     if (dtype == SEC_BF16) return launch_conv2d<__hip_bfloat16>(x, packed_weight, bias, y, p, st);
     return launch_conv2d<__half>(x, packed_weight, bias, y, p, st);
+}
+
+SEC_API int sec_conv2d_nhwc_gather(const void *features, long long feature_rows, const int *site_map, int batch, int h, int w,
+                                   const void *packed_weight, const float *bias, int cout, int relu, void *y, int dtype, void *stream) {
+    if (!site_map || !packed_weight || !y || batch <= 0 || h <= 0 || w <= 0 || feature_rows < 0 || (!features && feature_rows > 0)) return SEC_E_INVALID;
+    if (cout % 128 || (dtype != SEC_BF16 && dtype != SEC_F16) || feature_rows * 128 >= (1ll << 31) ||
+        (long long)h * w * 8 >= (1ll << 31)) return SEC_E_UNSUPPORTED;
+    Conv2dParams p;
+    p.batch = batch; p.h = h; p.w = w; p.cin = 128; p.cout = cout; p.ksize = 3; p.stride = 1; p.pad = 1;
+    p.relu = relu & 1; p.zskip = 0; p.stagger = 0;
+    p.ho = h; p.wo = w;
+    p.m = (long long)batch * h * w;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned fb = (unsigned)(feature_rows * 128);
+    if (dtype == SEC_BF16) return launch_conv2d_halo_reg<__hip_bfloat16, 128, 8, 2, true>(features, packed_weight, bias, y, p, st, site_map, fb);
+    return launch_conv2d_halo_reg<__half, 128, 8, 2, true>(features, packed_weight, bias, y, p, st, site_map, fb);
 }
 
 SEC_API int sec_conv1x1_chain_nhwc(const void *x, long long pixels, const void *packed_w1, const float *bias1, int relu1,

@@ -81,9 +81,34 @@ static int run_scatter(const void *feat, const int *idx, int n, const int *num_d
     return check_launch();
 }
 
+// Site map of a sparse tensor: map[b][z][y][x] = row + 1 (0 = no active site).  What sec_conv2d_nhwc_gather reads instead
+// of a dense image.
+__global__ __launch_bounds__(kBlock) void k_site_map(const int *__restrict__ idx, int n, const int *__restrict__ num_dev, int d, int h,
+                                                    int w, int *__restrict__ map) {
+    if (num_dev) n = *num_dev;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+        const int4 q = *reinterpret_cast<const int4 *>(idx + (size_t)i * 4);
+        if ((unsigned)q.y < (unsigned)d && (unsigned)q.z < (unsigned)h && (unsigned)q.w < (unsigned)w)
+            map[(((size_t)q.x * d + q.y) * h + q.z) * w + q.w] = i + 1;
+    }
+}
+
 }  // namespace sec
 
 using namespace sec;
+
+SEC_API int sec_sparse_site_map(const int *indices, int n, const int *num_dev, int batch, int d, int h, int w, int *site_map,
+                                void *stream) {
+    if (n < 0 || batch <= 0 || d <= 0 || h <= 0 || w <= 0 || !site_map || (n > 0 && !indices)) return SEC_E_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if ((rc = zero_fill(site_map, (size_t)batch * d * h * w * sizeof(int), st))) return rc;
+    if (n == 0) return SEC_OK;
+    int blocks = div_up(n, kBlock);
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    hipLaunchKernelGGL(k_site_map, dim3(blocks), dim3(kBlock), 0, st, indices, n, num_dev, d, h, w, site_map);
+    return check_launch();
+}
 
 SEC_API int sec_sparse_to_dense(const void *features, const int *indices, int n, int c, const int *num_dev, void *out,
                                 size_t out_elems, int64_t stride_b, int64_t stride_c, int64_t stride_z, int64_t stride_y,

@@ -250,9 +250,10 @@ class SpMiddleFHD(nn.Module):
         self.overlap_rulebooks_split = os.environ.get("SEC_OVERLAP_RULEBOOKS", "0") == "2"
         self._side_stream = None
 
-    def forward(self, voxel_features, coors, batch_size, channels_last=False, num_active_dev=None, site_table=None):
+    def forward(self, voxel_features, coors, batch_size, channels_last=False, num_active_dev=None, site_table=None, bev_sparse=False):
         """``site_table``: the ``site_table`` entry of the ops.voxelize result these (unfiltered) coors come from -- the first
-        SubM rulebook then looks its sites up in the voxeliser's hash table instead of hashing them again."""
+        SubM rulebook then looks its sites up in the voxeliser's hash table instead of hashing them again.
+        ``bev_sparse``: return a :class:`SparseBEV` (rows + indices) instead of the dense image when the output grid allows it."""
         x = spconv.SparseConvTensor(voxel_features, coors.int(), self.sparse_shape, batch_size,
                                     num_active_dev=num_active_dev)
         if site_table is not None and x.indices.data_ptr() == coors.data_ptr():
@@ -275,11 +276,29 @@ class SpMiddleFHD(nn.Module):
             self.last_overflow_checks = self.middle_conv._planned_overflow
         else:
             self.last_overflow_checks = x.overflow_checks
+        if channels_last and bev_sparse and x.features.shape[1] == 64 and int(x.spatial_shape[0]) == 2:
+            return SparseBEV(x)                      # the RPN's first conv gathers from the rows: no dense image
         if channels_last:
             return x.dense_channels_last_2d()
         d = x.dense()
         n, c, dd, h, w = d.shape
         return d.view(n, c * dd, h, w)
+
+
+class SparseBEV:
+    """The sparse middle's output handed to RPNInference WITHOUT ``.dense()``: rows + (b, z, y, x) indices of a [2, H, W] grid.
+    ``dense()`` gives the reference's [B, C * D, H, W] channels_last tensor (middle.py:206-210) for consumers that need it."""
+
+    def __init__(self, sp):
+        self.sp = sp
+        self.features, self.indices, self.num_dev = sp.features, sp.indices, sp.num_active_dev
+        self.batch_size, self.spatial_shape = sp.batch_size, [int(v) for v in sp.spatial_shape]
+
+    def site_map(self):
+        return ops.sparse_site_map(self.indices, self.batch_size, self.spatial_shape, num_dev=self.num_dev)
+
+    def dense(self):
+        return self.sp.dense_channels_last_2d()
 
 
 class RPNV2(nn.Module):
@@ -468,6 +487,14 @@ class RPNInference(nn.Module):
         # deblock (1x1, stride 1, 128 -> 128) + heads (<= 128 padded channels) run as ONE kernel (sec_conv1x1_chain_nhwc)
         wl = self.ws[-1]
         self.sparse_input = os.environ.get("SEC_RPN_ZSKIP", "1") == "1"   # forward()'s input comes from SparseConvTensor.dense()
+        # first conv straight from the sparse rows (sec_conv2d_nhwc_gather): 3x3 / s1 / p1 on 2 planes x 64 channels; its weights
+        # are packed a second time with the input channels in plane-major order (SEC_RPN_GATHER=0: always the dense image)
+        self.gather_packed = None
+        w0 = self.ws[0]
+        if (self.use_hip and self.plan[0][0] == "c" and tuple(w0.shape[1:]) == (128, 3, 3) and w0.shape[0] % 128 == 0
+                and self.cfgs[0] == ([1, 1], [1, 1]) and self.ups[0] == 1 and os.environ.get("SEC_RPN_GATHER", "1") == "1"):
+            perm = ops.gather_channel_perm(64, 2).to(w0.device)
+            self.gather_packed = ops.conv2d_pack_weight(w0.detach()[:, perm].contiguous())
         self.chain_tail = (single and self.use_hip and tuple(wl.shape) == (128, 128, 1, 1) and self.cfgs[-1] == ([1, 1], [0, 0])
                            and self.ups[-1] == 1
                            and self.head_cout in (64, 128) and os.environ.get("SEC_RPN_CHAIN", "1") == "1")
@@ -490,8 +517,17 @@ class RPNInference(nn.Module):
     def forward(self, x):
         ups = []
         first = self.sparse_input     # x is the scattered sparse-middle output: mostly empty tiles
+        gather = None
+        if isinstance(x, SparseBEV):
+            if self.gather_packed is not None:
+                gather = x
+            else:
+                x = x.dense()
         for kind, i in self.plan:
-            if kind == "c":
+            if kind == "c" and gather is not None:
+                x = ops.conv2d_nhwc_gather(gather.features, gather.site_map(), self.gather_packed, self.bs[i], self.ws[i].shape[0], relu=True)
+                gather, first = None, False
+            elif kind == "c":
                 x = self._conv(x, i, sparse_input=first)
                 first = False
             elif self.chain_tail:
@@ -587,7 +623,8 @@ class SecondDetector(nn.Module):
             return self.rpn(spatial)
         if dt is not None:
             spatial = self.middle_feature_extractor(voxel_features.to(dt), coors, batch_size, channels_last=True,
-                                                    num_active_dev=num_active_dev, site_table=site_table)
+                                                    num_active_dev=num_active_dev, site_table=site_table,
+                                                    bev_sparse=getattr(self.rpn, "gather_packed", None) is not None)
         else:
             spatial = self.middle_feature_extractor(voxel_features, coors, batch_size, num_active_dev=num_active_dev,
                                                     site_table=site_table)

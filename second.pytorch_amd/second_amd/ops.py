@@ -525,6 +525,41 @@ def conv2d_nhwc(x, packed, bias, cout, ksize, stride=1, pad=0, relu=False, spars
     return y
 
 
+@_traced("sparse_site_map")
+def sparse_site_map(indices, batch_size, spatial_shape, num_dev=None):
+    """[B, D, H, W] int32 map of a sparse tensor's sites: row + 1, 0 = no active site (input of :func:`conv2d_nhwc_gather`)."""
+    rt.require_gpu(indices)
+    d, h, w = [int(v) for v in spatial_shape]
+    m = torch.empty((int(batch_size), d, h, w), dtype=torch.int32, device=indices.device)
+    rc = rt.lib().sec_sparse_site_map(rt.ptr(indices.contiguous()), indices.shape[0], rt.ptr(num_dev), int(batch_size), d, h, w,
+                                      rt.ptr(m), rt.stream())
+    rt.check(rc, "sec_sparse_site_map")
+    return m
+
+
+def gather_channel_perm(c, d):
+    """perm[z * c + ch] = ch * d + z: the reference's channel ch * D + z of ``dense().view(N, C * D, H, W)`` in the order the
+    gather convolution reads it (plane-major).  ``w[:, perm]`` are the weights to pack for :func:`conv2d_nhwc_gather`."""
+    j = torch.arange(c * d)
+    return (j % c) * d + j // c
+
+
+@_traced("conv2d_nhwc_gather")
+def conv2d_nhwc_gather(features, site_map, packed, bias, cout, relu=True):
+    """3x3 / stride 1 / pad 1 conv + bias + ReLU of ``SparseConvTensor.dense().view(B, 128, H, W)`` read straight from the
+    sparse tensor's rows ``features`` [rows, 64] through ``site_map`` [B, 2, H, W] (:func:`sparse_site_map`): no dense image,
+    tiles without sites cost a map lookup.  ``packed`` = conv2d_pack_weight(w[:, gather_channel_perm(64, 2)])."""
+    rt.require_gpu(features, site_map, packed)
+    assert features.dim() == 2 and features.shape[1] == 64 and features.is_contiguous() and site_map.dtype == torch.int32
+    b, d, h, w = site_map.shape
+    assert d == 2 and site_map.is_contiguous()
+    y = torch.empty((b, int(cout), h, w), dtype=features.dtype, device=features.device, memory_format=torch.channels_last)
+    rc = rt.lib().sec_conv2d_nhwc_gather(rt.ptr(features), features.shape[0], rt.ptr(site_map), b, h, w, rt.ptr(packed), rt.ptr(bias),
+                                         int(cout), int(bool(relu)), rt.ptr(y), rt.dtype_code(features.dtype), rt.stream())
+    rt.check(rc, "sec_conv2d_nhwc_gather")
+    return y
+
+
 # ----------------------------------------------------------------------------- IoU / NMS
 @_traced("conv1x1_chain")
 def conv1x1_chain(x, packed_w1, bias1, packed_w2, bias2, cout2, relu1=True):

@@ -181,3 +181,83 @@ def test_nms_is_deterministic_beside_the_rpn_conv():
         assert torch.equal(nk1, nk0), it
         for i in range(b):
             assert torch.equal(keep[i, :nk[i]], keep0[i, :nk[i]]), (it, i)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("batch,h,w,cout,n,cap", [(2, 50, 70, 128, 900, 0),        # ragged against the 8 x 16 tile
+                                                   (3, 200, 176, 128, 7000, 9000),   # car.fhd map, static capacity with garbage rows
+                                                   (1, 8, 16, 256, 40, 0),           # one tile, two output-channel blocks
+                                                   (2, 33, 17, 128, 0, 64)])         # no active site at all
+def test_first_rpn_conv_gathered_from_sparse_rows(ops, dtype, batch, h, w, cout, n, cap):
+    """sec_sparse_site_map + sec_conv2d_nhwc_gather == dense().view(B, C*D, H, W) -> Conv2d(3x3, pad 1) + bias + ReLU
+    (middle.py:206-210, rpn.py:486-497): vs torch fp32 on the scattered image and vs our dense-image path (same kernel loop,
+    the input channels in another order: equal up to the rounding of the 16-bit result)."""
+    rng = np.random.default_rng(batch * 1000 + h)
+    idx = _scattered_indices(rng, batch, [2, h, w], n) if n else np.zeros((0, 4), np.int32)
+    # clusters: leave whole tiles empty, put sites on tile borders and image corners
+    if n:
+        idx[: n // 2, 2] = idx[: n // 2, 2] % max(h // 3, 1)
+        idx = np.unique(idx, axis=0)
+        idx = idx[rng.permutation(len(idx))].astype(np.int32)
+        n = len(idx)
+    rows = max(cap, n)
+    torch.manual_seed(7)
+    feat = torch.randn(rows, 64, device="cuda").to(dtype)           # rows >= n: garbage the map never names
+    ind = torch.zeros((rows, 4), dtype=torch.int32, device="cuda")
+    ind[:n] = dev(idx)
+    if rows > n:
+        ind[n:] = torch.tensor([0, 1, 0, 0], dtype=torch.int32, device="cuda")      # garbage rows point at a real cell
+    num_dev = torch.tensor([n], dtype=torch.int32, device="cuda") if cap else None
+    wt = (torch.randn(cout, 128, 3, 3, device="cuda") / 34).to(dtype)
+    bias = torch.randn(cout, device="cuda")
+    smap = ops.sparse_site_map(ind if cap else ind[:n], batch, [2, h, w], num_dev=num_dev)
+    m = smap.cpu().numpy()
+    assert (m > 0).sum() == n
+    if n:
+        assert np.array_equal(m[idx[:, 0], idx[:, 1], idx[:, 2], idx[:, 3]], np.arange(n) + 1)
+    perm = ops.gather_channel_perm(64, 2).cuda()
+    out = ops.conv2d_nhwc_gather(feat, smap, ops.conv2d_pack_weight(wt[:, perm].contiguous()), bias, cout, relu=True)
+    dense = ops.sparse_to_dense(feat, ind, batch, [2, h, w], channels_last_2d=True, num_dev=num_dev) if cap else \
+        ops.sparse_to_dense(feat[:n], ind[:n], batch, [2, h, w], channels_last_2d=True)
+    ref = torch.relu(torch.nn.functional.conv2d(dense.float(), wt.float(), bias, 1, 1))
+    tol = 2 ** -7 if dtype == torch.bfloat16 else 2 ** -9
+    assert out.shape == ref.shape and out.is_contiguous(memory_format=torch.channels_last)
+    np.testing.assert_allclose(out.float().cpu().numpy(), ref.cpu().numpy(), rtol=tol, atol=tol * max(ref.abs().max().item(), 1.0))
+    same = ops.conv2d_nhwc(dense, ops.conv2d_pack_weight(wt), bias, cout, 3, 1, 1, relu=True, sparse_input=True)
+    np.testing.assert_allclose(out.float().cpu().numpy(), same.float().cpu().numpy(), rtol=2 * tol, atol=tol * max(ref.abs().max().item(), 1.0))
+    # tiles without any site are act(bias) exactly, in both forms
+    if n == 0:
+        assert torch.equal(out, same)
+
+
+def test_detector_with_and_without_the_dense_image_agree(monkeypatch):
+    """SecondDetector with the first RPN conv gathering from the sparse rows (default) vs SEC_RPN_GATHER=0 (dense image +
+    zero-tile skip): the RPN head outputs agree up to 16-bit rounding through six conv layers; eager and static forwards of
+    the gathered form are identical."""
+    from second_amd.models import SecondDetector, CAR_FHD
+    from second_amd import synthetic as syn
+    clouds = [syn.syn_kitti_cloud(s) for s in range(2)]
+    pts, offs = syn.batch_clouds(clouds)
+    pts, offs = dev(pts), dev(offs)
+    heads, state = {}, None
+    for flag in ("1", "0"):
+        monkeypatch.setenv("SEC_RPN_GATHER", flag)
+        torch.manual_seed(0)
+        det = SecondDetector(CAR_FHD).cuda()
+        if state is None:
+            state = {k: v.clone() for k, v in det.state_dict().items()}
+        det.load_state_dict(state)
+        det.prepare_inference(torch.bfloat16)
+        assert (det.rpn.gather_packed is not None) == (flag == "1")
+        with torch.no_grad():
+            vox = det.voxel_generator.generate_device(pts, offs, mean_features=4)
+            heads[flag] = {k: v.float().clone() for k, v in det.network_forward(vox["mean"], vox["coordinates"], 2).items()}
+            if flag == "1":
+                a, b = det.forward_points(pts, offs), det.forward_points(pts, offs, static=True)
+                assert torch.equal(a["valid"], b["valid"]) and torch.equal(a["scores"][a["valid"]], b["scores"][b["valid"]])
+                assert torch.equal(a["boxes"][a["valid"]], b["boxes"][b["valid"]])
+    for k in heads["1"]:
+        x, y = heads["1"][k], heads["0"][k]
+        scale = y.abs().max().item()
+        assert (x - y).abs().max().item() <= 0.03 * scale, (k, (x - y).abs().max().item(), scale)
+        assert (x - y).abs().mean().item() <= 0.003 * scale
