@@ -845,7 +845,12 @@ __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(con
         }
 #pragma unroll
         for (int t = 0; t < NP; ++t) any |= rowp1[t];
-        if (__syncthreads_or((int)(any != 0)) == 0) return 0u;          // empty tile: nothing to fetch
+        // workgroup-wide "any": one word per wave, ONE barrier (__syncthreads_or compiles to three)
+        __shared__ unsigned wave_any[4];
+        const unsigned long long bal = __ballot(any != 0);
+        if (lane == 0) wave_any[wv] = bal != 0ull;
+        __syncthreads();
+        if ((wave_any[0] | wave_any[1] | wave_any[2] | wave_any[3]) == 0u) return 0u;          // empty tile: nothing to fetch
 #pragma unroll
         for (int t = 0; t < NP; ++t) {
             const int i = wvs + 4 * t;
@@ -901,8 +906,32 @@ __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(con
     }
 #endif
     unsigned gather_live = 1;
-    if constexpr (GATHER) gather_live = issue_halo_gather(tile);
-    else if constexpr (ROLL >= 2) issue_halo2(tile);
+    if constexpr (GATHER) {
+        gather_live = issue_halo_gather(tile);
+        if (!gather_live) {
+            // Empty tile (four of five on the KITTI-like clouds): every pixel is act(0 + bias).  Written straight from the bias -- no
+            // weight prefetch, no LDS, no further barrier; bit-identical to the full epilogue on zero accumulators.
+            const int b = tile / (tiles_y * tiles_x);
+            const int trem = tile - b * tiles_y * tiles_x;
+            const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
+            const int px = tid >> 4, ch = tid & 15;
+            float bv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                bv[j] = 0.0f + (bias ? bias[blockIdx.y * 128 + ch * 8 + j] : 0.0f);
+                if (p.relu) bv[j] = __builtin_fmaxf(bv[j], 0.0f);
+            }
+            const uint4 v = make_uint4(pack2<T>(bv[0], bv[1]), pack2<T>(bv[2], bv[3]), pack2<T>(bv[4], bv[5]), pack2<T>(bv[6], bv[7]));
+            uint4 *y4 = reinterpret_cast<uint4 *>(y);
+            const int ox = x0 + px;
+#pragma unroll
+            for (int ty_ = 0; ty_ < TH; ++ty_) {
+                const int oy = y0 + ty_;
+                if (oy < p.h && ox < p.w) y4[(((size_t)b * p.h + oy) * p.w + ox) * (p.cout / 8) + blockIdx.y * 16 + ch] = v;
+            }
+            return;
+        }
+    } else if constexpr (ROLL >= 2) issue_halo2(tile);
     else issue_halo(tile);
 #ifdef SEC_CONV_TIMELINE
     long long tl_issue = 0, tl_eb1 = 0, tl_eb2 = 0;
