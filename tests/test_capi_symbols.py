@@ -64,3 +64,23 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not bad.search(src), os.path.join(dirpath, f)
+
+
+def test_gather_channel_perm_is_the_plane_major_view_of_dense_view():
+    """ops.gather_channel_perm: the weights sec_conv2d_nhwc_gather is packed from, `w[:, perm]`, applied to the plane-major channel
+    order (z * C + c) give what `w` gives on the reference's `dense().view(N, C * D, H, W)` order (c * D + z; middle.py:206-210)."""
+    import sys, os
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "second.pytorch_amd"))
+    from second_amd import ops
+    torch.manual_seed(0)
+    c, d = 64, 2
+    dense = torch.randn(2, c, d, 6, 5)
+    ref_in = dense.view(2, c * d, 6, 5)                                   # channel c * D + z
+    plane_major = dense.permute(0, 2, 1, 3, 4).reshape(2, d * c, 6, 5)    # channel z * C + c
+    w = torch.randn(8, c * d, 3, 3)
+    perm = ops.gather_channel_perm(c, d)
+    assert sorted(perm.tolist()) == list(range(c * d))
+    a = torch.nn.functional.conv2d(ref_in, w, None, 1, 1)
+    b = torch.nn.functional.conv2d(plane_major, w[:, perm], None, 1, 1)
+    assert torch.allclose(a, b, rtol=1e-5, atol=1e-5)
