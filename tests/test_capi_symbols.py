@@ -83,4 +83,4 @@ def test_gather_channel_perm_is_the_plane_major_view_of_dense_view():
     assert sorted(perm.tolist()) == list(range(c * d))
     a = torch.nn.functional.conv2d(ref_in, w, None, 1, 1)
     b = torch.nn.functional.conv2d(plane_major, w[:, perm], None, 1, 1)
-    assert torch.allclose(a, b, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(a, b, rtol=1e-4, atol=1e-3)      # same products, another summation order
