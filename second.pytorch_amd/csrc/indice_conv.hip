@@ -769,12 +769,15 @@ SEC_PACKED_F32_OK __global__ __launch_bounds__(WAVES * 64, MINW) void k_conv_row
     }
 #pragma unroll
     for (int k = 0; k < DIST && k < KVOL; ++k) SEC_FETCH(k)
+    SEC_RTL(long long ts_wait = 0, ts_comp = 0, ts_issue = 0;)
     if constexpr (!PIPE) {
         SEC_WPUT(0)
 #pragma unroll
         for (int k = 0; k < KVOL; ++k) {
+            SEC_RTL(long long s0 = 0, s1 = 0, s2 = 0; if (tl) s0 = clock64();)
             if (k + 1 < KVOL) SEC_WPUT(k + 1)                // W[k+1] leaves the register ring; its LDS slot was last read two barriers ago
             __syncthreads();                                 // W[k] (stored during step k-1) is visible to every wave
+            SEC_RTL(if (tl) s1 = clock64();)                 // profiling builds: W store + barrier (the slowest wave's gather wait included)
             uint4 bf[C::KS * C::NT];
 #pragma unroll
             for (int i = 0; i < C::KS * C::NT; ++i) bf[i] = bring[k % 3][i * 64 + lane];
@@ -786,7 +789,9 @@ SEC_PACKED_F32_OK __global__ __launch_bounds__(WAVES * 64, MINW) void k_conv_row
                 for (int t = 0; t < C::NT; ++t) acc[t] = Mfma<T>::run(bf[s * C::NT + t], a, acc[t]);   // D^T
             }
             __builtin_amdgcn_sched_barrier(0);
+            SEC_RTL(if (tl) s2 = clock64();)                 // ... B reads, this wave's own gather wait, MFMA issue
             if (k + DIST < KVOL) SEC_FETCH(k + DIST)         // into the registers this step just consumed
+            SEC_RTL(if (tl) { const long long s3 = clock64(); ts_wait += s1 - s0; ts_comp += s2 - s1; ts_issue += s3 - s2; })
         }
     } else {
         static_assert(!PIPE || DIST >= 3, "W[k+2] must have left the ring before its registers are refilled");
@@ -828,7 +833,7 @@ SEC_PACKED_F32_OK __global__ __launch_bounds__(WAVES * 64, MINW) void k_conv_row
 #ifdef SEC_CONV_TIMELINE
     if (tl && lane == 0) {
         long long *rec = tl + ((size_t)blockIdx.x * WAVES + w) * 8;
-        rec[0] = tl0; rec[1] = tl1; rec[2] = tl2; rec[3] = clock64(); rec[4] = rec[5] = rec[6] = 0;
+        rec[0] = tl0; rec[1] = tl1; rec[2] = tl2; rec[3] = clock64(); rec[4] = ts_wait; rec[5] = ts_issue; rec[6] = ts_comp;   // per-step sums: non-pipelined forms only
         rec[7] = __builtin_amdgcn_s_getreg((4 << 11) | 20);
     }
 #endif
