@@ -629,9 +629,15 @@ SEC_PACKED_F32_OK __global__ __launch_bounds__(WAVES * 64, MINW) void k_conv_row
     static_assert(C::KS <= 4, "up to four 16-channel k-steps per row");
     static_assert(!STAGE || (32 * KVOL) % 4 == 0, "tile table in whole 16-byte pieces");
     static_assert(!ALLW || (STAGE && PIPE), "the all-weights form stages its tables and double-buffers its B fragments");
+    // FL bit 9 (WIN3): a six-slot weight ring and ONE workgroup barrier per THREE offsets -- inside a window the waves of a SIMD drift
+    // apart, so one's B reads run under the other's MFMAs instead of both leaving every barrier together (the ablations put 18 of the
+    // launch's 24 us on that lock step).  W of window g + 1 is loaded when window g starts and stored into the other half of the ring
+    // when it ends; every wave has left that half at the barrier that opened window g.
+    constexpr bool WIN3 = (FL & 512) != 0;
+    static_assert(!WIN3 || (STAGE && !PIPE && !ALLW && KVOL % 3 == 0 && DIST <= 3), "window form: non-pipelined, 3 offsets per window");
     constexpr int LBUF = ALLW ? (KVOL * C::BSLOT > WAVES * TBL16 ? KVOL * C::BSLOT : WAVES * TBL16) : 1;
     __shared__ __attribute__((aligned(16))) uint4 lbuf[LBUF];
-    __shared__ __attribute__((aligned(16))) uint4 bring[ALLW ? 1 : 3][ALLW ? 1 : C::BSLOT];
+    __shared__ __attribute__((aligned(16))) uint4 bring[ALLW ? 1 : (WIN3 ? 6 : 3)][ALLW ? 1 : C::BSLOT];
     __shared__ __attribute__((aligned(16))) float aff[2 * COUT];
     __shared__ __attribute__((aligned(16))) u32x4_t stage[(STAGE && !ALLW) ? WAVES : 1][(STAGE && !ALLW) ? TBL16 : 1];
     rows_stage_affine<COUT>(aff, scale, shift);
@@ -770,7 +776,63 @@ SEC_PACKED_F32_OK __global__ __launch_bounds__(WAVES * 64, MINW) void k_conv_row
 #pragma unroll
     for (int k = 0; k < DIST && k < KVOL; ++k) SEC_FETCH(k)
     SEC_RTL(long long ts_wait = 0, ts_comp = 0, ts_issue = 0;)
-    if constexpr (!PIPE) {
+    if constexpr (WIN3) {
+        u32x4_t ww0[3], ww1[3];
+#define SEC_GFETCH(k)                                                                                                 \
+    {                                                                                                                 \
+        const unsigned o_ = off_of(k);                                                                                \
+        areg[(k) % DIST][0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o_, 0, 0);                                  \
+        if (C::KS > 1) areg[(k) % DIST][1 % C::KS] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o_ + 32, 0, 0);      \
+        if (C::KS > 2) areg[(k) % DIST][2 % C::KS] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o_ + 64, 0, 0);      \
+        if (C::KS > 3) areg[(k) % DIST][3 % C::KS] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o_ + 96, 0, 0);      \
+    }
+#define SEC_WLOAD(g)                                                                                                  \
+    {                                                                                                                 \
+        _Pragma("unroll") for (int j_ = 0; j_ < 3; ++j_) {                                                            \
+            ww0[j_] = wpv[(size_t)(3 * (g) + j_) * C::BSLOT];                                                         \
+            if (NBW > 1) ww1[j_] = wpv[(size_t)(3 * (g) + j_) * C::BSLOT + 64];                                       \
+        }                                                                                                             \
+    }
+#define SEC_WSTORE(g)                                                                                                 \
+    {                                                                                                                 \
+        _Pragma("unroll") for (int j_ = 0; j_ < 3; ++j_) {                                                            \
+            bslot[((((g) & 1) * 3) + j_) * C::BSLOT] = ww0[j_];                                                       \
+            if (NBW > 1) bslot[((((g) & 1) * 3) + j_) * C::BSLOT + 64] = ww1[j_];                                     \
+        }                                                                                                             \
+    }
+        SEC_WLOAD(0)
+#pragma unroll
+        for (int k = 0; k < DIST && k < KVOL; ++k) SEC_GFETCH(k)
+        SEC_WSTORE(0)
+        if (KVOL > 3) SEC_WLOAD(1)
+#pragma unroll
+        for (int g = 0; g < KVOL / 3; ++g) {
+            __syncthreads();                                 // W of window g is visible; every wave has left the other half of the ring
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int k = 3 * g + j;
+                uint4 bf[C::KS * C::NT];
+#pragma unroll
+                for (int i = 0; i < C::KS * C::NT; ++i) bf[i] = bring[(g & 1) * 3 + j][i * 64 + lane];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s2 = 0; s2 < C::KS; ++s2) {
+                    const uint4 a = __builtin_bit_cast(uint4, areg[k % DIST][s2]);
+#pragma unroll
+                    for (int t = 0; t < C::NT; ++t) acc[t] = Mfma<T>::run(bf[s2 * C::NT + t], a, acc[t]);   // D^T
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (k + DIST < KVOL) SEC_GFETCH(k + DIST)
+            }
+            if (g + 1 < KVOL / 3) {
+                SEC_WSTORE(g + 1)
+                if (g + 2 < KVOL / 3) SEC_WLOAD(g + 2)
+            }
+        }
+#undef SEC_GFETCH
+#undef SEC_WLOAD
+#undef SEC_WSTORE
+    } else if constexpr (!PIPE) {
         SEC_WPUT(0)
 #pragma unroll
         for (int k = 0; k < KVOL; ++k) {
@@ -942,8 +1004,9 @@ static int rows_min() {
     return v;
 }
 constexpr int kRowsMinSmall = 8192;
-// A/B switch of the 64 -> 64 row-split kernel's register footprint: 0 = default (134 VGPRs), 1 = the 194-VGPR form (prefetch distance 4,
-// double-buffered B fragments)
+// A/B switch of the 64 -> 64 row-split kernel: 0 = default (small footprint + one barrier per three offsets, 142 VGPRs), 1 = the 194-VGPR
+// form (prefetch distance 4, double-buffered B fragments, a barrier per offset), 3 = small footprint with a barrier per offset (134 VGPRs),
+// 4 = the window form also for the 128-row workgroups of the mid-size layers
 static int rows_footprint() {
     static int v = -1;
     if (v < 0) { const char *e = getenv("SEC_CONV_FOOTPRINT"); v = e ? atoi(e) : 0; }
@@ -1030,9 +1093,13 @@ static void launch_mfma(const void *feat, long long n_feat, const void *packed, 
                     // 134 VGPRs instead of 194 at the same stand-alone time (23.3 vs 23.6 us) -- and +3.9 % frames/s with three steps in
                     // flight, where the kernel's footprint decides what else fits on the CU beside it (SEC_CONV_FOOTPRINT=1: the old form)
                     // (the same form for the 128-row workgroups of the mid-size layers: 13.4 vs 13.2 us stand-alone, no gain in flight)
-                    if (n_out < rows_min() && conv_variant() == 1) { SEC_BUF(4, 4, 3, 27); }      // mid-size layers: 128-row workgroups
-                    else if (rows_footprint() == 1) { SEC_BUF(4, 8, 3, 27); }
-                    else { SEC_BUFM(3, 8, 3, 1 + 128); }
+                    // + one barrier per three offsets (FL 512, six-slot weight ring): 23.5 -> 22.1 us stand-alone
+                    if (n_out < rows_min() && conv_variant() == 1) {      // mid-size layers: 128-row workgroups
+                        if (rows_footprint() == 4) { SEC_BUFM(3, 4, 3, 1 + 128 + 512); }
+                        else { SEC_BUF(4, 4, 3, 27); }
+                    } else if (rows_footprint() == 1) { SEC_BUF(4, 8, 3, 27); }
+                    else if (rows_footprint() == 3) { SEC_BUFM(3, 8, 3, 1 + 128); }
+                    else { SEC_BUFM(3, 8, 3, 1 + 128 + 512); }
 #undef SEC_BUFM
                 } else { SEC_BUF(4, 8, 3, 27); }
                 return;
