@@ -1006,7 +1006,7 @@ static int rows_min() {
 constexpr int kRowsMinSmall = 8192;
 // A/B switch of the 64 -> 64 row-split kernel: 0 = default (small footprint + one barrier per three offsets, 142 VGPRs), 1 = the 194-VGPR
 // form (prefetch distance 4, double-buffered B fragments, a barrier per offset), 3 = small footprint with a barrier per offset (134 VGPRs),
-// 4 = the window form also for the 128-row workgroups of the mid-size layers
+// 4 = the 128-row workgroups of the mid-size layers with a barrier per offset (198 VGPRs)
 static int rows_footprint() {
     static int v = -1;
     if (v < 0) { const char *e = getenv("SEC_CONV_FOOTPRINT"); v = e ? atoi(e) : 0; }
@@ -1095,8 +1095,8 @@ static void launch_mfma(const void *feat, long long n_feat, const void *packed, 
                     // (the same form for the 128-row workgroups of the mid-size layers: 13.4 vs 13.2 us stand-alone, no gain in flight)
                     // + one barrier per three offsets (FL 512, six-slot weight ring): 23.5 -> 22.1 us stand-alone
                     if (n_out < rows_min() && conv_variant() == 1) {      // mid-size layers: 128-row workgroups
-                        if (rows_footprint() == 4) { SEC_BUFM(3, 4, 3, 1 + 128 + 512); }
-                        else { SEC_BUF(4, 4, 3, 27); }
+                        if (rows_footprint() == 4) { SEC_BUF(4, 4, 3, 27); }          // the form with a barrier per offset (13.3 vs 12.65 us)
+                        else { SEC_BUFM(3, 4, 3, 1 + 128 + 512); }
                     } else if (rows_footprint() == 1) { SEC_BUF(4, 8, 3, 27); }
                     else if (rows_footprint() == 3) { SEC_BUFM(3, 8, 3, 1 + 128); }
                     else { SEC_BUFM(3, 8, 3, 1 + 128 + 512); }
