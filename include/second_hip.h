@@ -39,6 +39,11 @@ extern "C" {
 int sec_abi_version(void);
 /* last HIP error string seen by this library (thread-unsafe convenience for diagnostics) */
 const char *sec_last_error(void);
+/* measurement aid: the kernel instantiation (template arguments as rocprofv3 prints them, e.g.
+ * "k_conv_rows_buf<__hip_bfloat16, 64, 64, 27, 3, 8, 3, 641>") that the last sec_indice_conv_fwd / sec_conv2d_nhwc call of the
+ * calling thread dispatched to; "" if that call took a kernel that does not report itself.  bench.py keys the committed PMC
+ * passes (profiles/rNN_traffic.json) on this string, so a counter file can never be attributed to a superseded kernel form. */
+const char *sec_last_kernel_name(void);
 
 /* ---------------------------------------------------------------------------------------------
  * points_to_voxel  -- replaces spconv.utils.VoxelGeneratorV2.generate / generate_multi_gpu
@@ -292,7 +297,9 @@ int sec_conv1x1_chain_nhwc(const void *x, long long pixels, const void *packed_w
  * (rotate_iou_kernel_eval :564-602, rotate_nms_kernel :404-437, nms_kernel :70-101, nms_postprocess
  * :109-126) and the CPU path rotate_nms_cc (nms_cpu.py:17-28 -> spconv rotate_non_max_suppression_cpu).
  * --------------------------------------------------------------------------------------------- */
-/* iou[n,k] for boxes [N,5], qboxes [K,5] (x,y,w,l,r); criterion -1 IoU, 0 inter/area(q), 1 inter/area(box), 2 inter */
+/* iou[n,k] for boxes [N,5], qboxes [K,5] (x,y,w,l,r); criterion -1 IoU, 0 inter/area(qbox k), 1 inter/area(box n), 2 inter.
+ * (nms_gpu.py:549-561 writes 0 -> inter/area1, 1 -> inter/area2 with rbox1 = the QUERY box: rotate_iou_kernel_eval passes
+ *  block_qboxes first, nms_gpu.py:600-604; tests/golden/rotate_iou.npz pins all four criteria on asymmetric N != K inputs.) */
 int sec_rotate_iou_f32(const float *boxes, int n, const float *qboxes, int k, int criterion,
                        float *iou, void *stream);
 /* Batched greedy NMS on boxes ALREADY SORTED by descending score.

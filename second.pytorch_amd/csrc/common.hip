@@ -1,6 +1,8 @@
 // Library-wide helpers: error reporting and the device-wide exclusive scan used by the voxeliser and
 // the rulebook builders (wave64 shuffles -> block scan -> three-launch device scan).
 #include "common.hpp"
+#include <stdarg.h>
+#include <stdio.h>
 #include <string.h>
 
 namespace sec {
@@ -8,6 +10,13 @@ namespace sec {
 static char g_last_error[256] = "";
 void set_last_error(hipError_t e) {
     strncpy(g_last_error, hipGetErrorString(e), sizeof(g_last_error) - 1);
+}
+static thread_local char g_last_kernel[192] = "";
+void set_last_kernel(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_last_kernel, sizeof(g_last_kernel), fmt, ap);
+    va_end(ap);
 }
 
 __global__ __launch_bounds__(kBlock) void k_scan_reduce(const int *__restrict__ in, long long n,
@@ -110,3 +119,4 @@ int exclusive_scan_i32(const int *in, int *out, long long n, int *total_out, int
 
 SEC_API int sec_abi_version(void) { return SEC_ABI_VERSION; }
 SEC_API const char *sec_last_error(void) { return sec::g_last_error; }
+SEC_API const char *sec_last_kernel_name(void) { return sec::g_last_kernel; }

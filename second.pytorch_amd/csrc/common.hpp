@@ -17,6 +17,11 @@ constexpr int kEmptyI32 = 0x7f7f7f7f;               // hipMemsetAsync(…, 0x7f)
 constexpr unsigned long long kEmptyKey = ~0ull;     // hipMemsetAsync(…, 0xff) pattern
 
 void set_last_error(hipError_t e);
+// name (as a profiler prints it) of the kernel instantiation the dispatchers of sec_indice_conv_fwd / sec_conv2d_nhwc picked last
+void set_last_kernel(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+template <typename T> inline const char *dtype_name() { return "float"; }
+template <> inline const char *dtype_name<__hip_bfloat16>() { return "__hip_bfloat16"; }
+template <> inline const char *dtype_name<__half>() { return "__half"; }
 inline int check_launch() {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_last_error(e); return SEC_E_LAUNCH; }

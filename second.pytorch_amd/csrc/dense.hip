@@ -1228,6 +1228,7 @@ static int launch_conv2d_halo_reg(const void *x, const void *wpk, const float *b
     const int ty = div_up(p.h, TH), tx = div_up(p.w, 16);
     const int per_xcd = div_up(p.batch * ty * tx, 8);
     const int gx = per_xcd * 8;
+    set_last_kernel("k_conv2d_halo_reg<%s, %d, %d, %d, %s>", dtype_name<T>(), CIN, TH, ROLL, GATHER ? "true" : "false");
     hipLaunchKernelGGL(fn, dim3(gx, p.cout / 128), dim3(256), lds, st, (const T *)x, (const T *)wpk, bias, (T *)y, p, ty, tx, per_xcd,
                        site_map, feat_bytes);
     return check_launch();

@@ -904,6 +904,7 @@ SEC_PACKED_F32_OK __global__ __launch_bounds__(WAVES * 64, MINW) void k_conv_row
 template <typename T, int CIN, int COUT, int DIST, int WAVES, int MINW, int FL, int KVOL = 27>
 static void launch_rows_buf(const void *feat, long long n_feat, const void *packed, const int *nbr, int n_out, const int *num_out_dev,
                             const float *scale, const float *shift, int relu, void *out, hipStream_t st) {
+    set_last_kernel("k_conv_rows_buf<%s, %d, %d, %d, %d, %d, %d, %d>", dtype_name<T>(), CIN, COUT, KVOL, DIST, WAVES, MINW, FL);
     hipLaunchKernelGGL((k_conv_rows_buf<T, CIN, COUT, KVOL, DIST, WAVES, MINW, FL>), dim3(div_up(n_out, 32 * WAVES)), dim3(WAVES * 64), 0, st,
                        (const T *)feat, n_feat * CIN * (long long)sizeof(T), (const T *)packed, nbr, n_out, num_out_dev, scale, shift,
                        relu, (T *)out);

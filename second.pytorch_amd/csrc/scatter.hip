@@ -83,12 +83,12 @@ static int run_scatter(const void *feat, const int *idx, int n, const int *num_d
 
 // Site map of a sparse tensor: map[b][z][y][x] = row + 1 (0 = no active site).  What sec_conv2d_nhwc_gather reads instead
 // of a dense image.
-__global__ __launch_bounds__(kBlock) void k_site_map(const int *__restrict__ idx, int n, const int *__restrict__ num_dev, int d, int h,
-                                                    int w, int *__restrict__ map) {
+__global__ __launch_bounds__(kBlock) void k_site_map(const int *__restrict__ idx, int n, const int *__restrict__ num_dev, int batch, int d,
+                                                    int h, int w, int *__restrict__ map) {
     if (num_dev) n = *num_dev;
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
         const int4 q = *reinterpret_cast<const int4 *>(idx + (size_t)i * 4);
-        if ((unsigned)q.y < (unsigned)d && (unsigned)q.z < (unsigned)h && (unsigned)q.w < (unsigned)w)
+        if ((unsigned)q.x < (unsigned)batch && (unsigned)q.y < (unsigned)d && (unsigned)q.z < (unsigned)h && (unsigned)q.w < (unsigned)w)
             map[(((size_t)q.x * d + q.y) * h + q.z) * w + q.w] = i + 1;
     }
 }
@@ -106,7 +106,7 @@ SEC_API int sec_sparse_site_map(const int *indices, int n, const int *num_dev, i
     if (n == 0) return SEC_OK;
     int blocks = div_up(n, kBlock);
     if (blocks > 256 * 8) blocks = 256 * 8;
-    hipLaunchKernelGGL(k_site_map, dim3(blocks), dim3(kBlock), 0, st, indices, n, num_dev, d, h, w, site_map);
+    hipLaunchKernelGGL(k_site_map, dim3(blocks), dim3(kBlock), 0, st, indices, n, num_dev, batch, d, h, w, site_map);
     return check_launch();
 }
 

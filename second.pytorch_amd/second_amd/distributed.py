@@ -17,8 +17,14 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None):
-    """Initialise the default process group from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun)."""
+def init_from_env(backend=None, timeout_s=None):
+    """Initialise the default process group from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun).
+    ``timeout_s`` (default SEC_DIST_TIMEOUT_S, else 4 h): collective timeout -- ranks != 0 sit in the gradient all-reduce
+    while rank 0 evaluates and checkpoints (launch.py seam 5), which can outlast the 10-minute RCCL default."""
+    import datetime
+    if timeout_s is None:
+        timeout_s = float(os.environ.get("SEC_DIST_TIMEOUT_S", 4 * 3600))
+    timeout = datetime.timedelta(seconds=timeout_s)
     world = int(os.environ.get("WORLD_SIZE", 1))
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
@@ -29,9 +35,10 @@ def init_from_env(backend=None):
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local_rank),
+                                    timeout=timeout)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=timeout)
     return rank, local_rank, world
 
 
@@ -63,15 +70,23 @@ class GradBucket:
 
     The bucket is laid out from ``requires_grad`` (identical on all ranks), never from which ``.grad`` happen to exist: a
     parameter without a gradient on this rank this step (an empty shard, an unused head) contributes zeros, so the ranks
-    always reduce buffers of the same length and layout.  After :meth:`allreduce` every such parameter HAS a gradient (the
-    mean over ranks), and every ``p.grad`` is a view of the bucket -- later steps accumulate straight into it, so the
-    flatten / unflatten copies disappear."""
+    always reduce buffers of the same length and layout.  After :meth:`allreduce` every fp32 ``p.grad`` is a view of the
+    bucket -- later steps accumulate straight into it, so the flatten / unflatten copies disappear.
 
-    def __init__(self, module):
+    Parameters that have no gradient on ANY rank: with ``track_presence=False`` (the sync-free device trainer) they end up
+    with an all-zero gradient, so an optimizer with weight decay / moments still touches them; with ``track_presence=True``
+    (the launcher around the reference's loop, whose optimizer skips ``grad is None`` parameters) one flag per parameter
+    rides at the end of the same all-reduce and those parameters get ``grad = None`` back -- at the price of one small
+    device-to-host read per step."""
+
+    def __init__(self, module, track_presence=False):
         self.params = [p for p in module.parameters() if p.requires_grad]
         self.numel = sum(p.numel() for p in self.params)
+        self.track_presence = bool(track_presence)
         dev = self.params[0].device if self.params else torch.device("cpu")
-        self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        self._buf = torch.zeros(self.numel + (len(self.params) if self.track_presence else 0), dtype=torch.float32, device=dev)
+        self.flat = self._buf[:self.numel]
+        self.flags = self._buf[self.numel:]
         self.views = []
         off = 0
         for p in self.params:
@@ -79,28 +94,45 @@ class GradBucket:
             off += p.numel()
 
     def pack(self):
+        present = []
         for p, v in zip(self.params, self.views):
+            present.append(0.0 if p.grad is None else 1.0)
             if p.grad is None:
                 v.zero_()
             elif p.grad.data_ptr() != v.data_ptr():
                 v.copy_(p.grad)
-        return self.flat
+        if self.track_presence and present:
+            self.flags.copy_(torch.tensor(present, dtype=torch.float32))
+        return self._buf
 
     def unpack(self):
-        for p, v in zip(self.params, self.views):
-            if p.dtype == torch.float32:
+        absent = set()
+        if self.track_presence and len(self.params):
+            absent = {i for i, f in enumerate(self.flags.tolist()) if f == 0.0}
+        for i, (p, v) in enumerate(zip(self.params, self.views)):
+            if i in absent:
+                p.grad = None                 # no rank produced a gradient: the optimizer skips it, as in a single process
+            elif p.dtype == torch.float32:
                 p.grad = v                    # a view of the bucket: the next backward accumulates into it in place
             else:
                 if p.grad is None:
                     p.grad = torch.empty_like(p)
                 p.grad.copy_(v)
 
+    def zero_grad(self):
+        """After the optimizer step: one fill for the bucket (= every fp32 ``p.grad``); gradients of non-fp32 parameters are
+        separate tensors and are dropped, otherwise the next :meth:`pack` would add the stale (already averaged) values."""
+        self._buf.zero_()
+        for p, v in zip(self.params, self.views):
+            if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
+                p.grad = None
+
     def allreduce(self, average=True):
-        flat = self.pack()
+        buf = self.pack()
         if dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
             if average:
-                flat /= dist.get_world_size()
+                self.flat /= dist.get_world_size()
         self.unpack()
         return self.numel * 4
 
@@ -114,7 +146,7 @@ def allreduce_gradients(module, average=True):
     trainable = [p for p in module.parameters() if p.requires_grad]
     if bucket is None or len(bucket.params) != len(trainable) or any(a is not b for a, b in zip(bucket.params, trainable)) or \
             (trainable and bucket.flat.device != trainable[0].device):
-        bucket = GradBucket(module)
+        bucket = GradBucket(module, track_presence=True)   # the caller's optimizer skips ``grad is None`` parameters
         module._sec_grad_bucket = bucket
     if bucket.numel == 0:
         return 0

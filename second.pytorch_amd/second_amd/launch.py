@@ -21,7 +21,9 @@ GPU and this module patches five seams around it -- no file of the reference is 
                         workers call ``spconv.utils.VoxelGeneratorV2.generate`` (second/data/preprocess.py:301-316), which
                         runs on the GPU here, and a HIP context does not survive ``fork()``;
   5. rank-0 side effects  checkpoints (``torchplus.train.save_models``), the model log (``SimpleModelLog``) and the periodic
-                        evaluation (``steps_per_eval``) happen on rank 0 only; the other ranks wait in the next all-reduce.
+                        evaluation (``steps_per_eval``) happen on rank 0 only; the other ranks wait in the next all-reduce --
+                        the process group is therefore created with a long collective timeout (SEC_DIST_TIMEOUT_S, default
+                        4 h: a full nuScenes evaluation outlasts the 10-minute RCCL watchdog default).
 
 BatchNorm statistics stay per rank, as in the reference (DataParallel replicas do not synchronise them either).
 """
@@ -30,14 +32,27 @@ import sys
 import time
 
 
-def _isolate_device():
-    """Must run before torch initialises the GPU runtime."""
-    lr = os.environ.get("LOCAL_RANK")
-    if lr is not None and os.environ.get("SEC_LAUNCH_NO_ISOLATION") != "1":
-        os.environ.setdefault("HIP_VISIBLE_DEVICES", lr)
-        os.environ.setdefault("CUDA_VISIBLE_DEVICES", lr)
-        os.environ["LOCAL_RANK_ORIGINAL"] = lr
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this driver
+def _isolate_device(env=None):
+    """Must run before torch initialises the GPU runtime.  Rank r keeps ONE visible GPU -- entry r of a visible-device list the
+    user already set, else physical GPU r -- and from then on addresses it as device 0: LOCAL_RANK becomes "0" (the
+    reference hard-codes ``cuda:0``, train.py:29, and ``distributed.init_from_env`` binds RCCL to ``cuda:LOCAL_RANK``), the
+    launcher's value stays in LOCAL_RANK_ORIGINAL."""
+    env = os.environ if env is None else env
+    lr = env.get("LOCAL_RANK")
+    if lr is not None and env.get("SEC_LAUNCH_NO_ISOLATION") != "1" and "LOCAL_RANK_ORIGINAL" not in env:
+        preset = env.get("HIP_VISIBLE_DEVICES") or env.get("CUDA_VISIBLE_DEVICES")
+        if preset:
+            ids = [t.strip() for t in preset.split(",") if t.strip()]
+            if int(lr) >= len(ids):
+                raise SystemExit(f"second_amd.launch: LOCAL_RANK={lr} but only {len(ids)} visible device(s): {preset!r}")
+            dev = ids[int(lr)]
+        else:
+            dev = lr
+        env["HIP_VISIBLE_DEVICES"] = dev
+        env["CUDA_VISIBLE_DEVICES"] = dev
+        env["LOCAL_RANK_ORIGINAL"] = lr
+        env["LOCAL_RANK"] = "0"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL needs it on this driver
 
 
 class _NullLog:
@@ -158,8 +173,10 @@ def run_train(reference_root, config_path, model_dir, backend=None, device=None,
     try:
         config = load_config(T, config_path, rank)
         if rank != 0:                                    # rank 0 creates (and checks) the model directory first
-            deadline = time.time() + 600
-            while not Path(model_dir).exists() and time.time() < deadline:
+            deadline = time.time() + float(os.environ.get("SEC_LAUNCH_MODEL_DIR_WAIT_S", 600))
+            while not Path(model_dir).exists():
+                if time.time() > deadline:
+                    raise RuntimeError(f"rank {rank}: model_dir {model_dir!r} was never created by rank 0")
                 time.sleep(0.1)
             train_kwargs["resume"] = True
         T.train(config, model_dir, multi_gpu=False, **train_kwargs)

@@ -861,6 +861,14 @@ class SecondDetector(nn.Module):
         return res
 
 
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
 class InFlightRunner:
     """Serving loop with several steps in flight: ``inflight`` captured forwards (hipGraphs with their own activation
     buffers, all reading the same resident input buffers -- ``points`` / ``point_offsets``, or ``self.parts`` with branches)
@@ -871,31 +879,51 @@ class InFlightRunner:
     ``step()`` enqueues one full forward and returns (outputs, stream): the output tensors of that lane, valid once
     ``stream`` has been synchronised (or after :meth:`synchronize`) and until the lane is stepped again."""
 
-    def __init__(self, det, points, point_offsets, inflight=3, branches=1):
+    def __init__(self, det, points, point_offsets, inflight=3, branches=1, private_inputs=False):
+        """``private_inputs``: every lane gets its OWN copy of the input buffers (``self.inputs[k]``) and pinned host
+        mirrors of its outputs, so that :meth:`step` can take a host-resident batch: the pinned-host -> HBM copy of lane k's
+        next clouds then overlaps the compute of the other lanes (the end-to-end serving form; with shared buffers a copy
+        would race with the lanes still reading them)."""
         self.det = det
         self.replays, self.outputs, self.parts = [], [], None
+        self.inputs, self.host_outputs = [], []
         self._overflow = []                       # overflow counters of EVERY lane (each capture has its own rulebook buffers)
+        assert not (private_inputs and branches > 1), "private input buffers are a single-chain feature"
         for _ in range(max(1, int(inflight))):
             if branches > 1:
                 # the per-branch input buffers are created by the first lane and shared by all others: one place to refill
                 replay, outs, self.parts = det.make_graphed(points, point_offsets, branches=branches, parts=self.parts)
             else:
-                replay, outs = det.make_graphed(points, point_offsets)
+                pk, ok = (points.clone(), point_offsets.clone()) if private_inputs else (points, point_offsets)
+                replay, outs = det.make_graphed(pk, ok)
+                self.inputs.append((pk, ok))
+                if private_inputs:
+                    self.host_outputs.append({k: torch.empty(v.shape, dtype=v.dtype, pin_memory=True) for k, v in outs.items()})
             self.replays.append(replay)
             self.outputs.append(outs)
             self._overflow += [c for lst in getattr(det, "_branch_overflow", []) for c in lst]
         self.lanes = [torch.cuda.Stream() for _ in self.replays] if len(self.replays) > 1 else [None]
         self._k = 0
 
-    def step(self):
+    def step(self, host_points=None, host_offsets=None, fetch=False):
+        """Enqueue one full forward on the next lane.  ``host_points`` [n <= capacity, F] / ``host_offsets`` [B + 1] (pinned
+        host tensors; needs ``private_inputs``): copied into the lane's input buffers on the lane's stream ahead of the
+        replay.  ``fetch``: the lane's detections are copied to its pinned host mirrors (``self.host_outputs[k]``) behind the
+        replay.  Nothing here synchronises the host."""
         k = self._k % len(self.replays)
         self._k += 1
-        if self.lanes[k] is None:
+        lane = self.lanes[k]
+        ctx = torch.cuda.stream(lane) if lane is not None else _NullCtx()
+        with ctx:
+            if host_points is not None:
+                pk, ok = self.inputs[k]
+                pk[:host_points.shape[0]].copy_(host_points, non_blocking=True)
+                ok.copy_(host_offsets, non_blocking=True)
             self.replays[k]()
-            return self.outputs[k], torch.cuda.current_stream()
-        with torch.cuda.stream(self.lanes[k]):
-            self.replays[k]()
-        return self.outputs[k], self.lanes[k]
+            if fetch:
+                for name, t in self.outputs[k].items():
+                    self.host_outputs[k][name].copy_(t, non_blocking=True)
+        return self.outputs[k], (lane if lane is not None else torch.cuda.current_stream())
 
     def synchronize(self):
         torch.cuda.synchronize()

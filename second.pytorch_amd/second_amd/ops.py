@@ -22,6 +22,12 @@ def set_op_hook(hook):
     _op_hook = hook
 
 
+def last_kernel_name():
+    """The kernel instantiation the last indice_conv / conv2d_nhwc call of this thread dispatched to, as a profiler prints it
+    (sec_last_kernel_name); "" for kernels that do not report themselves."""
+    return rt.lib().sec_last_kernel_name().decode()
+
+
 def _traced(name):
     def deco(fn):
         @functools.wraps(fn)
@@ -687,6 +693,15 @@ def assign_targets(anchors, gt_boxes, gt_offsets, matched_threshold, unmatched_t
     gt_boxes = gt_boxes.float().contiguous()
     a, b, g = anchors.shape[0], gt_offsets.numel() - 1, gt_boxes.shape[0]
     dev = anchors.device
+    # the kernel reads raw int32 / float32 arrays: an int64 label tensor (torch.from_numpy's default) would be read as garbage
+    if gt_classes is not None:
+        rt.require_gpu(gt_classes)
+        assert gt_classes.numel() == g and gt_classes.device == dev, "gt_classes: one class id per ground-truth box, on the anchors' device"
+        gt_classes = gt_classes.to(torch.int32).contiguous()
+    if gt_importance is not None:
+        rt.require_gpu(gt_importance)
+        assert gt_importance.numel() == g and gt_importance.device == dev, "gt_importance: one weight per ground-truth box, on the anchors' device"
+        gt_importance = gt_importance.to(torch.float32).contiguous()
     labels = torch.empty((b, a), dtype=torch.int32, device=dev)
     targets = torch.empty((b, a, 7), dtype=torch.float32, device=dev)
     importance = torch.empty((b, a), dtype=torch.float32, device=dev)

@@ -18,7 +18,7 @@ _ERRORS = {-1: "SEC_E_INVALID (bad argument)", -2: "SEC_E_WORKSPACE (workspace t
 
 # every symbol include/second_hip.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
-    "sec_abi_version", "sec_last_error", "sec_voxelize_workspace_bytes", "sec_voxelize_f32",
+    "sec_abi_version", "sec_last_error", "sec_last_kernel_name", "sec_voxelize_workspace_bytes", "sec_voxelize_f32",
     "sec_rulebook_workspace_bytes", "sec_rulebook_subm3d", "sec_rulebook_subm3d_after_conv", "sec_rulebook_subm3d_after_voxelize",
     "sec_rulebook_conv3d_build",
     "sec_rulebook_conv3d_tables", "sec_rulebook_sorted_workspace_bytes", "sec_rulebook_conv3d_build_sorted",
@@ -54,6 +54,7 @@ def lib():
                      "sec_assign_targets_workspace_bytes", "sec_second_loss_workspace_bytes"):
             getattr(l, name).restype = ctypes.c_size_t
         l.sec_last_error.restype = ctypes.c_char_p
+        l.sec_last_kernel_name.restype = ctypes.c_char_p
         l.sec_conv_output_shape.restype = None
         vp, ci, cf, sz, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_int64
         l.sec_voxelize_workspace_bytes.argtypes = [ci, ci, ci, ci]

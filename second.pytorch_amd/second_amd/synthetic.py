@@ -123,3 +123,53 @@ def syn_kitti_boxes(seed, max_boxes=None):
     ground = -1.73
     b = np.stack([cx, cy, ground + sz / 2, sx, sy, sz, np.zeros(n_box)], 1).astype(np.float32)
     return b[:max_boxes] if max_boxes else b
+
+
+# ------------------------------------------------------------------------------------------ synthetic weights
+# No checkpoint exists in the build or GPU containers.  Default-initialised weights make a poor stand-in for a trained
+# detector in anything that looks at SCORES: every empty region of the BEV map produces the same class logit, ~35 000
+# anchors per frame tie at the top and the top-k / NMS result is decided by tie order.  The two helpers below give a
+# seeded random network the two properties of a trained one that the selection stages depend on (bench.py, the end-to-end
+# tests): empty regions carry exactly zero activations and score below the threshold, and candidate scores are distinct.
+def randomise_like_trained(det, seed=1):
+    """In place, on whatever device ``det`` lives: conv gains that keep the activations O(10-100) through the 14 + 6 layers
+    (the default init shrinks them ~3x per sparse layer), BatchNorm statistics with positive means and zero beta (negative
+    folded shifts), so that -- as with trained weights -- empty regions of the map carry exactly zero activations."""
+    import torch
+    import spconv
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for m in det.modules():
+            if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+                m.running_mean.copy_(torch.empty(m.running_mean.shape).uniform_(0.0, 0.1, generator=g))
+                m.running_var.copy_(torch.empty(m.running_var.shape).uniform_(0.5, 1.5, generator=g))
+            if isinstance(m, spconv.SparseConvolution):
+                m.weight.mul_(4.0)
+        for blk in list(det.rpn.blocks) + list(det.rpn.deblocks):
+            for m in blk:
+                if isinstance(m, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)):
+                    m.weight.mul_(2.5)
+    return det
+
+
+def sharpen_heads(det, cls_preds, box_preds):
+    """conv_cls <- a * (conv_cls - empty-region logit) - 2 with a = 14 / max: empty map regions score sigmoid(-2) = 0.12,
+    below the 0.3 threshold; the strongest anchor gets logit 12 (no fp32 sigmoid saturation, so no score ties); a few hundred
+    anchors per frame pass the threshold.  conv_box is scaled to residuals of trained-network size (|delta| <= 0.5).
+    ``cls_preds`` [1, A, H, W, C] / ``box_preds``: the fp32 head outputs of ONE calibration frame through ``det`` as it is
+    now (from the device forward in bench.py, from the CPU oracle forward in the tests -- the same state dict results)."""
+    import torch
+    with torch.no_grad():
+        p = next(det.rpn.parameters())
+        cin = det.rpn.blocks[0][1].in_channels
+        zero = det.rpn(torch.zeros(1, cin, 24, 24, device=p.device, dtype=p.dtype))["cls_preds"]   # the map of an empty scene
+        c_empty = zero[0, :, 12, 12].float()                              # interior value per (anchor, class) channel
+        cls = torch.as_tensor(cls_preds).float().to(p.device)
+        d = cls[0] - c_empty.view(c_empty.shape[0], 1, 1, -1)
+        a = 14.0 / float(d.max())
+        det.rpn.conv_cls.weight.mul_(a)
+        det.rpn.conv_cls.bias.copy_(a * (det.rpn.conv_cls.bias - c_empty.reshape(-1).to(p.dtype)) - 2.0)
+        sb = 0.5 / float(torch.as_tensor(box_preds).float().abs().max())
+        det.rpn.conv_box.weight.mul_(sb)
+        det.rpn.conv_box.bias.mul_(sb)
+    return det

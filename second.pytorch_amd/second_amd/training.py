@@ -28,10 +28,11 @@ from . import ops
 
 class DeviceTrainer:
     def __init__(self, det, lr=3e-3, weight_decay=0.01, max_grad_norm=10.0, matched_threshold=None, unmatched_threshold=None,
-                 loss_cfg=None, amp_dtype=None):
+                 loss_cfg=None, amp_dtype=None, init_loss_scale=2.0 ** 12):
         """det: SecondDetector on this rank's GPU (training mode is set here).  ``amp_dtype`` (torch.bfloat16 / float16):
         mixed precision -- 16-bit features in the sparse stack and the RPN over fp32 master weights; None = fp32 throughout
-        (the reference's default training precision).  Thresholds default to the config's class_settings."""
+        (the reference's default training precision); float16 adds dynamic loss scaling (``init_loss_scale``, see
+        :meth:`_unscale_and_check`).  Thresholds default to the config's class_settings."""
         from . import models
         self.det = det.train()
         self.cfg = det.cfg
@@ -56,6 +57,9 @@ class DeviceTrainer:
         self.opt = torch.optim.AdamW([p for p in det.parameters() if p.requires_grad], lr=lr, weight_decay=weight_decay,
                                      betas=(0.9, 0.99))
         self.bucket = D.GradBucket(det)
+        # fp16 features need loss scaling (5 exponent bits: head gradients are O(1 / num_pos / batch)); bf16 / fp32 do not
+        self.loss_scale = float(init_loss_scale) if amp_dtype == torch.float16 else None
+        self._good_steps, self.skipped_steps = 0, 0
         self.steps = 0
         self.last = {}
 
@@ -92,16 +96,39 @@ class DeviceTrainer:
         return loss, out6, labels
 
     def step(self, points, point_offsets, gt_boxes, gt_offsets, gt_classes=None):
-        """One optimisation step on this rank's shard; returns the device tensor of the six loss scalars (no host sync)."""
+        """One optimisation step on this rank's shard; returns the device tensor of the six loss scalars (no host sync,
+        except with fp16 features: dynamic loss scaling reads one overflow flag per step)."""
         loss, out6, _ = self.forward_loss(points, point_offsets, gt_boxes, gt_offsets, gt_classes)
-        loss.backward()
+        if self.loss_scale is None:
+            loss.backward()
+        else:
+            (loss * self.loss_scale).backward()                   # fp16 gradients: scaled so that small ones do not flush to zero
         self.bucket.allreduce(average=True)                       # one flat bucket, zeros for parameters without a gradient
+        self.last = {"out6": out6}
+        if self.loss_scale is not None and not self._unscale_and_check():
+            self.bucket.zero_grad()                               # overflow on some rank: skip the step everywhere (same bucket)
+            self.skipped_steps += 1
+            return out6
         torch.nn.utils.clip_grad_norm_(self.bucket.params, self.max_grad_norm)
         self.opt.step()
-        self.bucket.flat.zero_()                                  # p.grad are views of the bucket: zero_grad in one launch
+        self.bucket.zero_grad()                                   # fp32 p.grad are views of the bucket: one fill
         self.steps += 1
-        self.last = {"out6": out6}
         return out6
+
+    def _unscale_and_check(self):
+        """Dynamic loss scaling for fp16 features (the reference trains mixed precision through apex amp with
+        ``loss_scale_factor``, train.py:209-216,318-322): unscale the reduced bucket; a non-finite value anywhere (every rank
+        sees the same reduced bucket, so every rank decides alike) halves the scale and skips the step; 200 clean steps in a
+        row double it."""
+        flat = self.bucket.flat
+        flat.mul_(1.0 / self.loss_scale)
+        if bool(torch.isfinite(flat).all().item()):
+            self._good_steps += 1
+            if self._good_steps >= 200:
+                self.loss_scale, self._good_steps = min(self.loss_scale * 2.0, 2.0 ** 24), 0
+            return True
+        self.loss_scale, self._good_steps = max(self.loss_scale * 0.5, 1.0), 0
+        return False
 
     def loss_dict(self):
         names = ("loss", "cls_loss_reduced", "loc_loss_reduced", "dir_loss_reduced", "cls_pos_loss", "cls_neg_loss")

@@ -204,8 +204,10 @@ def rbbox_iou(box_corners, qbox_corners, standup_iou, standup_thresh):
 
 
 def rbbox_intersection(box_corners, qbox_corners, standup_iou, standup_thresh):
-    """[N,K] rotated intersection / area(box) (second/core/box_np_ops.py:23-34 -> spconv rbbox_intersection)."""
+    """[N,K] area of the rotated intersection polygon (second/core/box_np_ops.py:23-34 ``rinter_cc`` -> spconv
+    ``rbbox_intersection``; the reference's own GPU substitute for ``rinter_cc`` is ``rotate_iou_gpu_eval(..., 2)``, the raw
+    intersection: second/utils/eval.py:174-175), zero where ``standup_iou <= standup_thresh``."""
     dev = _dev()
     inter = _ops.rotate_iou(torch.from_numpy(_corners_to_rbox(box_corners)).to(dev),
-                            torch.from_numpy(_corners_to_rbox(qbox_corners)).to(dev), 1).cpu().numpy()
+                            torch.from_numpy(_corners_to_rbox(qbox_corners)).to(dev), 2).cpu().numpy()
     return np.where(np.asarray(standup_iou) > standup_thresh, inter, 0).astype(np.asarray(box_corners).dtype)
