@@ -8,8 +8,9 @@ Two error figures per layer, because they answer different questions:
                how far 16-bit storage of the activations has drifted after this many layers (sparse rows are aligned through their
                coordinates, which must agree exactly -- rulebook / numbering parity at bench size comes for free);
   single       the layer re-computed on the CPU from the DEVICE's own 16-bit input, 16-bit weights and fp32 scale / shift, compared
-               with the device's 16-bit output in units of the only error that output may carry: half an ulp of the storage type
-               plus BASELINE.json's 1e-4 of the layer's range.  <= ~1 means the kernel's arithmetic is exact up to the rounding of
+               with the device's 16-bit output in units of the only error that output may carry: the unit roundoff of the storage
+               type (round to nearest: 2^-8 relative for bf16's 8 significant bits, 2^-11 for fp16) plus BASELINE.json's 1e-4 of
+               the layer's range.  <= ~1 means the kernel's arithmetic is exact up to the rounding of
                its stored result; it isolates a wrong kernel from accumulated rounding."""
 import numpy as np
 import torch
@@ -50,7 +51,7 @@ def _pairs_from_table(nbr):
 
 
 def _unit_err(got, ref, ulp):
-    """max |got - ref| in units of (half an ulp of the 16-bit result + 1e-4 of the layer's range)."""
+    """max |got - ref| in units of (unit roundoff of the 16-bit result, `ulp` * |ref|, + 1e-4 of the layer's range)."""
     tol = ulp * np.abs(ref) + 1e-4 * max(float(np.abs(ref).max()), 1e-30)
     return float((np.abs(got - ref) / tol).max())
 
@@ -251,7 +252,7 @@ def attribute_misses(calls, refs, missed, score_thr):
 
 
 def format_table(rows):
-    out = [f"{'layer':>9s} {'kind':34s} {'shape':>9s} {'rows':>7s} {'cumulative (rel to range)':>26s} {'single (units of 1/2 ulp + 1e-4)':>33s}"]
+    out = [f"{'layer':>9s} {'kind':34s} {'shape':>9s} {'rows':>7s} {'cumulative (rel to range)':>26s} {'single (units of roundoff + 1e-4)':>33s}"]
     for r in rows:
         out.append(f"{str(r['layer']):>9s} {r['kind']:34s} {str(r['cin']) + '->' + str(r['cout']):>9s} {str(r.get('rows', '')):>7s} "
                    f"{r['cumulative']:26.5f} {r.get('single', float('nan')):33.3f}")

@@ -100,14 +100,14 @@ def test_detector_bf16_bench_configuration_per_stage_trace_and_detections():
     with torch.no_grad():
         gpu.calibrate(pts, offs)
     calls, out_eager = T.run_device_trace(gpu, pts, offs)
-    ulp = 2.0 ** -9                                             # half an ulp of bf16 (8 significant bits), relative
+    ulp = 2.0 ** -8                                             # unit roundoff of bf16 (8 significant bits, round to nearest)
     rows = T.sparse_stage_errors(calls, traces, ulp, gpu.middle_feature_extractor.sparse_shape)
     rows += T.dense_stage_errors(calls, gpu, det, traces, ulp, single_frames=2)
     print("\n" + T.format_table(rows))
     assert len(rows) == 14 + 6 + 1
     for r in rows:
-        # single: 1.0 = exactly half an ulp + 1e-4 of range; fp32 summation-order differences and ties add a little
-        assert r["single"] <= 1.6, f"layer {r['layer']}: arithmetic differs beyond the rounding of its bf16 result ({r['single']:.2f} units)"
+        # single: 1.0 = exactly one rounding of the stored result + 1e-4 of range (measured 0.83-0.92 on every layer)
+        assert r["single"] <= 1.1, f"layer {r['layer']}: arithmetic differs beyond the rounding of its bf16 result ({r['single']:.2f} units)"
         assert r["cumulative"] <= 0.06, f"layer {r['layer']}: cumulative bf16 drift {r['cumulative']:.4f} of the layer's range"
     # -- detections of the graph / in-flight path
     with torch.no_grad():

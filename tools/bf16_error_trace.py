@@ -25,7 +25,7 @@ def main():
     from second_amd import synthetic as syn
     from second_amd.models import SecondDetector, CAR_FHD
     dt = {"bf16": torch.bfloat16, "fp16": torch.float16}[args.dtype]
-    ulp = {"bf16": 2.0 ** -9, "fp16": 2.0 ** -12}[args.dtype]
+    ulp = {"bf16": 2.0 ** -8, "fp16": 2.0 ** -11}[args.dtype]     # unit roundoff (round to nearest)
     clouds = [syn.syn_kitti_cloud(s) for s in range(args.frames)]
     det = T.trained_like_detector(CAR_FHD, clouds[0])
     results = [forward_frame(det, c, collect=True) for c in clouds]
@@ -42,7 +42,7 @@ def main():
     rows += T.dense_stage_errors(calls, gpu, det, traces, ulp, single_frames=min(2, args.frames))
     print(f"# car.fhd, {args.frames} synthetic KITTI frames (17 000 points -> 16 000 voxels each), {args.dtype} features, static capacities;")
     print("# reference: oracle/cpu_forward.py in fp32 from the raw points.  cumulative = max |device - cpu| / max |cpu| of the layer output;")
-    print("# single = the layer recomputed on the CPU from the device's own 16-bit input, in units of (1/2 ulp of the stored result + 1e-4 of range)")
+    print("# single = the layer recomputed on the CPU from the device's own 16-bit input, in units of (unit roundoff of the stored result, 2^-8 |x| for bf16, + 1e-4 of range)")
     print(T.format_table(rows))
     found, total, counts, missed = T.match_detections(out, results)
     why = T.attribute_misses(calls, results, missed, CAR_FHD["nms_score_threshold"])

@@ -60,6 +60,14 @@ def main():
         if "GRBM_GUI_ACTIVE" in m and us > 0:
             cyc = m["GRBM_GUI_ACTIVE"] / 8
             ghz = cyc / us / 1e3
+            if ghz > 2.4:
+                # GRBM_GUI_ACTIVE also counts the dispatch / drain around a launch this short: the ratio exceeds the 2.4 GHz
+                # maximum clock.  The busy fractions below then use duration x 2.4 GHz (an upper bound on the kernel's cycles,
+                # so the fractions are lower bounds).
+                lines.append(f"  GRBM_GUI_ACTIVE / 8 / duration = {ghz:.2f} GHz > 2.4 GHz max: counter spans more than the launch; "
+                             f"fractions below use duration x 2.4 GHz")
+                cyc, ghz = us * 2400.0, 2.4
+                ent["clock_note"] = "GRBM_GUI_ACTIVE spans more than the launch; 2.4 GHz assumed"
             lines.append(f"  effective clock              {ghz:.2f} GHz")
             ent["effective_clock_ghz"] = round(ghz, 3)
             if "SQ_VALU_MFMA_BUSY_CYCLES" in m:

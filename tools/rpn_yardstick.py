@@ -40,7 +40,13 @@ class Sampler(threading.Thread):
             a = self.amdsmi
             try:
                 m = a.amdsmi_get_gpu_metrics_info(self.h)
-                return {"power_w": m.get("average_socket_power") or m.get("current_socket_power"),
+                def pick(*keys):
+                    for k in keys:
+                        v = m.get(k)
+                        if v not in (None, "N/A", 0, 65535):
+                            return v
+                    return None
+                return {"power_w": pick("current_socket_power", "average_socket_power"), "raw_keys": sorted(m)[:80] if not self.samples else None,
                         "gfxclk_mhz": m.get("current_gfxclk") or m.get("average_gfxclk_frequency"),
                         "gfxclks_mhz": (m.get("current_gfxclks") or [])[:8], "temp_c": m.get("temperature_hotspot")}
             except Exception:  # noqa: BLE001
@@ -82,9 +88,16 @@ def loop(fn, seconds, flop, sampler, label):
     torch.cuda.synchronize()
     sampler.label = "idle"
     us = e0.elapsed_time(e1) * 1e3 / n
-    ss = [s for s in sampler.samples if s["label"] == label and s.get("power_w")]
-    pw = [float(s["power_w"]) for s in ss]
-    ck = [float(s["gfxclk_mhz"]) for s in ss if s.get("gfxclk_mhz")]
+    def num(v):
+        try:
+            return float(v)
+        except (TypeError, ValueError):
+            return None
+    ss = [s for s in sampler.samples if s["label"] == label]
+    pw = [v for v in (num(s.get("power_w")) for s in ss) if v]
+    ck = [v for v in (num(s.get("gfxclk_mhz")) for s in ss) if v]
+    if not ck:      # per-XCD clocks
+        ck = [sum(c) / len(c) for c in ([v for v in map(num, s.get("gfxclks_mhz") or []) if v] for s in ss) if c]
     res = {"what": label, "us": round(us, 2), "tflops": round(flop / us / 1e6, 1), "frac_of_2.5PF": round(flop / us / 1e6 / 2500, 4), "launches": n,
            "power_w_mean": round(sum(pw) / len(pw), 1) if pw else None, "power_w_max": max(pw) if pw else None,
            "gfxclk_mhz_mean": round(sum(ck) / len(ck)) if ck else None, "gfxclk_mhz_min": min(ck) if ck else None, "samples": len(ss)}
@@ -121,8 +134,8 @@ def main():
     out.append(loop(lambda: ops.bias_act_(torch.nn.functional.conv2d(x, wcl, None, 1, 1), b, True), secs, flop, sm,
                     "MIOpen conv2d (torch, channels_last bf16) + fused bias / ReLU pass"))
     sm.stop_flag = True
-    idle = [s for s in sm.samples if s["label"] == "idle" and s.get("power_w")]
-    print(json.dumps({"idle_power_w": [s["power_w"] for s in idle[:3]], "sampler": "amdsmi" if sm.h is not None else "rocm-smi",
+    idle = [s for s in sm.samples if s["label"] == "idle"]
+    print(json.dumps({"idle_power_w": [s.get("power_w") for s in idle[:3]], "sampler": "amdsmi" if sm.h is not None else "rocm-smi",
                       "sampler_error": getattr(sm, "err", None), "first_sample": sm.samples[0] if sm.samples else None}))
     series = [{k: s.get(k) for k in ("t", "label", "power_w", "gfxclk_mhz")} for s in sm.samples]
     t0 = series[0]["t"] if series else 0
