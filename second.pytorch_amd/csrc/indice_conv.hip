@@ -911,6 +911,152 @@ static void launch_rows_buf(const void *feat, long long n_feat, const void *pack
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Row-split kernel, TWO 32-row tiles per wave (SEC_CONV_VARIANT 41; round 3).  What round 2 left on the table for the 64 -> 64
+// layers: at batch 8 the subm2 stage is 220 workgroups of 256 rows -- ONE workgroup per CU, every workgroup resident at once -- so a
+// launch is one workgroup life of 27 offset steps, and a step cost ~1350 clocks for 256 clocks of MFMA per wave: two waves per SIMD
+// that each read the full 8 KB W[k] from LDS, leave every barrier together and queue for the same matrix pipe.  Here a wave owns 64
+// rows (tiles r and 32 + r): ONE wave per SIMD (four per workgroup, still 256 rows), each B fragment read from LDS feeds two MFMAs,
+// and the step is software-pipelined INSIDE the wave instead of across waves: per 16-channel k-step s the wave issues 4 MFMAs
+// (two tiles x two 32-column halves), the two ds_read_b128 of offset k+1's fragments for that k-step, and the two gathers of offset
+// k + DIST that refill the registers the 4 MFMAs just consumed (sched_group_barrier keeps that interleaving).  The four accumulator
+// chains are independent, so the matrix pipe sees back-to-back issue; one workgroup barrier per three offsets (six-slot weight ring, as
+// in the WIN3 form above).  Gathers, zero rows, epilogue: as in k_conv_rows_buf.
+template <typename T, int DIST>
+SEC_PACKED_F32_OK __global__ __launch_bounds__(256, 1) void k_conv_rows_m2(const T *__restrict__ feat, long long feat_bytes,
+                                                                           const T *__restrict__ packed, const int *__restrict__ nbr,
+                                                                           int n_out, const int *__restrict__ num_out_dev,
+                                                                           const float *__restrict__ scale, const float *__restrict__ shift,
+                                                                           int relu, T *__restrict__ out) {
+    constexpr int CIN = 64, COUT = 64, KVOL = 27, WAVES = 4, RPW = 64;
+    using C = RowsCfg<T, CIN, COUT>;                       // KS = 4 k-steps, NT = 2 column tiles, BPIECES = 8, BSLOT = 512
+    constexpr int NBW = C::BPIECES / WAVES;                // 1 KB weight pieces per wave and offset (2)
+    constexpr int ROWB = CIN * (int)sizeof(T);
+    constexpr int TBL16 = RPW * KVOL / 4;                  // 16-byte pieces of one wave's 64 x 27 neighbour table (432)
+    static_assert(DIST == 3, "the gather registers of offset k are refilled for offset k + 3");
+    __shared__ __attribute__((aligned(16))) uint4 bring[6][C::BSLOT];
+    __shared__ __attribute__((aligned(16))) float aff[2 * COUT];
+    __shared__ __attribute__((aligned(16))) u32x4_t stage[WAVES][TBL16];
+    rows_stage_affine<COUT>(aff, scale, shift);
+    const int n_cap = n_out;
+    if (num_out_dev) n_out = *num_out_dev;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    if ((long long)blockIdx.x * (RPW * WAVES) >= n_out) return;
+    const long long tile_row0 = (long long)blockIdx.x * (RPW * WAVES) + w * RPW;
+    const long long row0 = tile_row0 + r, row1 = tile_row0 + 32 + r;
+    const bool valid0 = row0 < n_out, valid1 = row1 < n_out;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(feat), 0, (int)feat_bytes, 0x00020000);
+    const u32x4_t *wpv = reinterpret_cast<const u32x4_t *>(packed) + (size_t)(w * NBW) * 64 + lane;
+    {   // the wave's 64 x 27 neighbour table: coalesced 16-byte loads (bounded by the table's end), staged in LDS
+        const long long left = (long long)n_cap * KVOL * 4 - tile_row0 * KVOL * 4;
+        const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<int *>(left > 0 ? nbr + tile_row0 * KVOL : nbr), 0,
+            (int)(left <= 0 ? 0 : (left < RPW * KVOL * 4 ? left : RPW * KVOL * 4)), 0x00020000);
+#pragma unroll
+        for (int i = 0; i < (TBL16 + 63) / 64; ++i) {
+            const int p16 = i * 64 + lane;
+            if (p16 < TBL16) stage[w][p16] = __builtin_amdgcn_raw_buffer_load_b128(trs, p16 * 16, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    const int *tbl0 = reinterpret_cast<const int *>(&stage[w][0]) + r * KVOL, *tbl1 = tbl0 + 32 * KVOL;
+    f32x16 acc[2][C::NT];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int t = 0; t < C::NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[m][t][i] = 0.0f;
+    u32x4_t areg[DIST][2][C::KS];
+    u32x4_t ww[3][NBW];
+    u32x4_t *bslot = reinterpret_cast<u32x4_t *>(&bring[0][(w * NBW) * 64 + lane]);
+    // byte offset of this lane's 16-byte chunk of neighbour row t; no neighbour (t < 0) -> beyond the buffer -> the load returns zeros
+    // without touching memory.  Rows past n_out read whatever the table holds there (zeros past its end): their gathers stay inside the
+    // buffer's bounds check and their results are never stored, so no `valid` test (it compiled into an exec-mask branch per read).
+    auto off_of = [&](int t) -> unsigned { return t >= 0 ? (unsigned)t * ROWB + h * 16 : 0x80000000u; };
+#define SEC_M2_WLOAD(g)                                                                                               \
+    {                                                                                                                 \
+        _Pragma("unroll") for (int j_ = 0; j_ < 3; ++j_)                                                              \
+            _Pragma("unroll") for (int p_ = 0; p_ < NBW; ++p_) ww[j_][p_] = wpv[(size_t)(3 * (g) + j_) * C::BSLOT + p_ * 64]; \
+    }
+#define SEC_M2_WSTORE(g)                                                                                              \
+    {                                                                                                                 \
+        _Pragma("unroll") for (int j_ = 0; j_ < 3; ++j_)                                                              \
+            _Pragma("unroll") for (int p_ = 0; p_ < NBW; ++p_) bslot[((((g) & 1) * 3) + j_) * C::BSLOT + p_ * 64] = ww[j_][p_]; \
+    }
+    SEC_M2_WLOAD(0)
+    unsigned o0[DIST], o1[DIST];
+#pragma unroll
+    for (int k = 0; k < DIST; ++k) {
+        o0[k] = off_of(tbl0[k]);
+        o1[k] = off_of(tbl1[k]);
+#pragma unroll
+        for (int s2 = 0; s2 < C::KS; ++s2) {
+            areg[k][0][s2] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o0[k] + 32 * s2, 0, 0);
+            areg[k][1][s2] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o1[k] + 32 * s2, 0, 0);
+        }
+    }
+    SEC_M2_WSTORE(0)
+    SEC_M2_WLOAD(1)
+    uint4 bf[2][C::KS * C::NT];
+    int tq0 = tbl0[DIST], tq1 = tbl1[DIST];                  // table entries of the NEXT fetch, read one step ahead of their use
+#pragma unroll
+    for (int g = 0; g < KVOL / 3; ++g) {
+        __syncthreads();                                     // W of window g is visible; every wave has left the other half of the ring
+#pragma unroll
+        for (int i = 0; i < C::KS * C::NT; ++i) bf[0][i] = bring[(g & 1) * 3][i * 64 + lane];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int k = 3 * g + j;
+            const int cur = j & 1, nxt = cur ^ 1;
+            const unsigned n0 = off_of(tq0), n1 = off_of(tq1);   // rows gathered for offset k + DIST during this step
+            if (k + 1 + DIST < KVOL) {                        // (their LDS reads were issued a step ago; these are next step's)
+                tq0 = tbl0[k + 1 + DIST];
+                tq1 = tbl1[k + 1 + DIST];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s2 = 0; s2 < C::KS; ++s2) {
+                const uint4 a0 = __builtin_bit_cast(uint4, areg[k % DIST][0][s2]), a1 = __builtin_bit_cast(uint4, areg[k % DIST][1][s2]);
+#pragma unroll
+                for (int t = 0; t < C::NT; ++t) {
+                    acc[0][t] = Mfma<T>::run(bf[cur][s2 * C::NT + t], a0, acc[0][t]);   // D^T: weights first
+                    acc[1][t] = Mfma<T>::run(bf[cur][s2 * C::NT + t], a1, acc[1][t]);
+                }
+                if (j < 2) {                                 // the next offset of this window: its fragments for k-step s2
+#pragma unroll
+                    for (int t = 0; t < C::NT; ++t) bf[nxt][s2 * C::NT + t] = bring[(g & 1) * 3 + j + 1][(s2 * C::NT + t) * 64 + lane];
+                }
+                if (k + DIST < KVOL) {                       // refill the gather registers the four MFMAs above just read
+                    areg[k % DIST][0][s2] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, n0 + 32 * s2, 0, 0);
+                    areg[k % DIST][1][s2] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, n1 + 32 * s2, 0, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);      // 4 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // 2 DS reads
+                __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);      // 2 VMEM reads
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (g + 1 < KVOL / 3) {
+            SEC_M2_WSTORE(g + 1)
+            if (g + 2 < KVOL / 3) SEC_M2_WLOAD(g + 2)
+        }
+    }
+#undef SEC_M2_WLOAD
+#undef SEC_M2_WSTORE
+    rows_store<T, COUT>(acc[0], out, row0, valid0, h, aff, scale != nullptr, shift != nullptr, relu);
+    rows_store<T, COUT>(acc[1], out, row1, valid1, h, aff, scale != nullptr, shift != nullptr, relu);
+}
+
+template <typename T>
+static void launch_rows_m2(const void *feat, long long n_feat, const void *packed, const int *nbr, int n_out, const int *num_out_dev,
+                           const float *scale, const float *shift, int relu, void *out, hipStream_t st) {
+    set_last_kernel("k_conv_rows_m2<%s, 3>", dtype_name<T>());
+    hipLaunchKernelGGL((k_conv_rows_m2<T, 3>), dim3(div_up(n_out, 256)), dim3(256), 0, st, (const T *)feat,
+                       n_feat * 64 * (long long)sizeof(T), (const T *)packed, nbr, n_out, num_out_dev, scale, shift, relu, (T *)out);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // First layer of SpMiddleFHD (Cin = 4 -> 16, 3x3x3; middle.py:146) on the matrix cores.  The whole receptive field of a
 // row is ONE K dimension: 27 neighbours x 4 channels = 108, padded to 112 = seven 16-deep MFMA steps.  Lane (r, h) feeds step s
 // with the 8-byte rows of neighbours 4s + 2h and 4s + 2h + 1 of output row r (raw buffer loads: no neighbour -> out-of-range
@@ -995,7 +1141,7 @@ static int conv_variant() {
 
 // kernel ids reported by sec_indice_conv_fwd_plan
 enum { PLAN_GENERIC = 0, PLAN_TILED = 1, PLAN_C4 = 2, PLAN_MFMA_WAVE = 3, PLAN_MFMA_SK = 4, PLAN_MFMA_SKS = 5, PLAN_ROWS = 6,
-       PLAN_ROWS_COMPACT = 7, PLAN_ROWS_TOUCH = 8, PLAN_ROWS_COMPACT_TOUCH = 9, PLAN_ROWS_REG = 10, PLAN_ROWS_BUF = 11, PLAN_C4_MFMA = 12, PLAN_EXPERIMENT = 99 };
+       PLAN_ROWS_COMPACT = 7, PLAN_ROWS_TOUCH = 8, PLAN_ROWS_COMPACT_TOUCH = 9, PLAN_ROWS_REG = 10, PLAN_ROWS_BUF = 11, PLAN_C4_MFMA = 12, PLAN_ROWS_M2 = 13, PLAN_EXPERIMENT = 99 };
 
 // Row count from which the buffer-load row-split kernel replaces split-K in the automatic choice (SEC_CONV_ROWS_MIN; the
 // row-split chain of 27 offsets needs enough workgroups to fill the chip, split-K has a 4x shorter chain per wave)
@@ -1013,6 +1159,12 @@ static int rows_footprint() {
     if (v < 0) { const char *e = getenv("SEC_CONV_FOOTPRINT"); v = e ? atoi(e) : 0; }
     return v;
 }
+// SEC_CONV_M2 = 1: the automatic choice takes the two-tiles-per-wave kernel (k_conv_rows_m2) for the 64 -> 64 layers from rows_min() rows
+static int m2_auto() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("SEC_CONV_M2"); v = e ? atoi(e) : 0; }
+    return v;
+}
 static bool buf_shape(int cin, int cout, int kvol) {
     if (kvol == 3) return cin == 64 && cout == 64;
     if (kvol != 27) return false;
@@ -1024,6 +1176,8 @@ static int rows_plan(int cin, int cout, int kvol, int n_out, bool same_dtype) {
     if (!same_dtype) return 0;
     const int v = conv_variant();
     if (buf_shape(cin, cout, kvol)) {
+        if (cin == 64 && cout == 64 && kvol == 27 && (v == 41 || (v == 1 && m2_auto() && n_out >= rows_min())))
+            return PLAN_ROWS_M2;                                                           // two row tiles per wave (round 3)
         if (v == 22 || (v >= 16 && v <= 28 && cin == 64 && cout == 64 && kvol == 27)) return PLAN_ROWS_BUF;
         if (v >= 36 && v <= 40) return PLAN_ROWS_BUF;
         if (v == 1 && n_out >= rows_min()) return PLAN_ROWS_BUF;
@@ -1050,6 +1204,12 @@ static void launch_mfma(const void *feat, long long n_feat, const void *packed, 
     constexpr int MT = 1;
     if constexpr (std::is_same<T, OT>::value && CIN <= 64 && COUT <= 64 && (COUT >= CIN) ) {
         const int rp = feat ? rows_plan(CIN, COUT, kvol, n_out, true) : 0;
+        if constexpr (CIN == 64 && COUT == 64) {
+            if (rp == PLAN_ROWS_M2 && n_feat * CIN * (long long)sizeof(T) < 0x7fffffffll) {
+                launch_rows_m2<T>(feat, n_feat, packed, nbr, n_out, num_out_dev, scale, shift, relu, out, st);
+                return;
+            }
+        }
         if (rp == PLAN_ROWS_BUF && n_feat * CIN * (long long)sizeof(T) < 0x7fffffffll) {
 #define SEC_BUF(D, W, FLG, KV) launch_rows_buf<T, CIN, COUT, D, W, 2, FLG, KV>(feat, n_feat, packed, nbr, n_out, num_out_dev, scale, shift, relu, out, st)
             if (kvol == 3) {

@@ -17,7 +17,7 @@ PLAN_ROWS_BUF = 11
 # (variant number, expected plan id): None = the automatic choice, 22 = the same kernel forced.  A library built with
 # -DSEC_CONV_EXPERIMENTS also carries the superseded row-split forms (9-15: LDS-DMA / register-direct gathers) and the A/B forms of
 # the buffer-load kernel (16-21, 23, 27, 28); they are run through the same comparisons when present.
-ROW_VARIANTS = [(None, 11), (22, 11)]
+ROW_VARIANTS = [(None, 11), (22, 11), (41, 13)]      # 41 = two row tiles per wave (k_conv_rows_m2, plan 13)
 EXPERIMENT_VARIANTS = [(9, 6), (10, 7), (11, 8), (12, 9), (13, 10), (14, 10), (15, 10), (16, 11), (17, 11), (18, 11), (19, 11),
                        (20, 11), (21, 11), (23, 11), (27, 11), (28, 11)]
 
