@@ -214,6 +214,23 @@ def kernel_table(det, points, offsets, reps=30):
             ent.update(bytes=s_ * (p_ * cin + m * cout) + 8 * p_ + s_ * k * cin * cout, flop=2.0 * p_ * cin * cout,
                        kernel=(ops.last_kernel_name() if plan in (11, 13) else "") or PLAN_NAMES.get(plan, str(plan)),
                        detail=f"{cin}->{cout} k{k} {m} rows {p_} pairs")
+        elif name == "pfn_forward":
+            vox_, npv = a[0], a[1]
+            n = live(kw.get("num_dev"), vox_.shape[0])
+            t_, f_ = vox_.shape[1], vox_.shape[2]
+            # every point slot of a live pillar read once (4F bytes), 64 output channels written once
+            ent.update(bytes=4 * f_ * t_ * n + 4 * n + 16 * n + elt(res.dtype) * res.shape[1] * n, flop=2.0 * n * t_ * (f_ + 5) * res.shape[1],
+                       detail=f"PillarFeatureNet {n} pillars x {t_} point slots x {f_} -> {res.shape[1]} channels")
+        elif name == "pillar_scatter":
+            n = live(kw.get("num_dev"), a[0].shape[0])
+            c = a[0].shape[1]
+            ent.update(bytes=elt(a[0].dtype) * n * c + 16 * n + elt(a[0].dtype) * res.numel(), detail=f"{n} pillars x {c} -> {tuple(res.shape)} (zero fill included)")
+        elif name == "voxel_block_filter":
+            vin = a[0]
+            nv = live(vin["voxel_offsets"][-1:], vin["voxels"].shape[0])
+            t_, f_ = vin["voxels"].shape[1], vin["voxels"].shape[2]
+            kept = live(res["voxel_offsets"][-1:], res["voxels"].shape[0])
+            ent.update(bytes=nv * (4 * f_ * t_ + 20) + kept * (4 * f_ * t_ + 20), detail=f"block filter {nv} -> {kept} voxels")
         elif name == "sparse_to_dense":
             n = live(kw.get("num_dev"), a[0].shape[0])
             c = a[0].shape[1]
@@ -303,7 +320,7 @@ def train_bench(args, rank, local_rank, world, device):
     else:
         # ten-class ground truth: class-sized boxes (the class's anchor size, scaled a little) at random places and headings
         r = cfg["point_cloud_range"]
-        clouds = [syn.syn_nusc_cloud(rank * bs + s, num_points=WL["points"], point_cloud_range=tuple(r)) for s in range(bs)]
+        clouds = [syn.syn_nusc_cloud(rank * bs + s, num_points=WL["points"], point_cloud_range=tuple(r), scene="urban") for s in range(bs)]
         boxes, classes = [], []
         for s in range(bs):
             g = np.random.default_rng(1000 + rank * bs + s)
@@ -355,6 +372,7 @@ def train_bench(args, rank, local_rank, world, device):
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "fp32" if amp is None else f"{args.dtype} features (sparse stack + RPN autocast) over fp32 master weights", "data": "synthetic",
                "config": {"workload": WL["desc"], "samples_per_step_per_gpu": bs, "parallelism": f"ddp{world}",
+                          "points_per_frame": int(pts.shape[0]) // bs,
                           "gradient_bucket_bytes": tr.bucket.numel * 4,
                           "allreduce_us": round(ar_us, 1) if world > 1 else None, "bucket_pack_unpack_us": round(ar_us, 1) if world == 1 else None,
                           "skipped_steps_loss_scale": tr.skipped_steps if tr.loss_scale is not None else None,
@@ -371,7 +389,7 @@ def build_inputs(rank, device, order="shuffle"):
     from second_amd import synthetic as syn
     if WL["cfg"] != "CAR_FHD":
         rng = (-50, -50, -5, 50, 50, 3) if WL["cfg"] == "ALL_PP_LARGEA" else (-49.6, -49.6, -5, 49.6, 49.6, 3)
-        clouds = [syn.syn_nusc_cloud(rank * BATCH + s, num_points=WL["points"], point_cloud_range=rng) for s in range(WL["batch"])]
+        clouds = [syn.syn_nusc_cloud(rank * BATCH + s, num_points=WL["points"], point_cloud_range=rng, scene="urban") for s in range(WL["batch"])]
         pts, offs = syn.batch_clouds(clouds)
         return clouds, torch.from_numpy(pts).to(device), torch.from_numpy(offs).to(device)
     clouds = [syn.syn_kitti_cloud(rank * BATCH + s) for s in range(WL["batch"])]
@@ -501,6 +519,34 @@ def dry_run(args, rank, local_rank, world):
                           "workload": args.workload}), flush=True)
 
 
+def other_configs(budget_s=240.0):
+    """BASELINE.json configs 3 / 4 / 5 at their stated sizes, measured by THIS command (each in a child process: same file, --workload,
+    a short run) so that the driver's record carries them; never part of `value`.  Best effort: a failure is reported, not raised."""
+    import subprocess
+    runs = [("car.fhd.train", ["--dtype", "bf16"], "config 3 (per-GPU step; DDP adds one 7.3 MB gradient all-reduce)"),
+            ("nusc.pp", [], "config 4"), ("nusc.fhd", [], "config 5 network, inference, fp16"),
+            ("nusc.fhd.train", [], "config 5 (per-GPU step, fp16 features + dynamic loss scaling)")]
+    out, t0 = {}, time.time()
+    for wl, extra, what in runs:
+        if time.time() - t0 > budget_s:
+            out[wl] = {"skipped": "time budget"}
+            continue
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", wl, "--steps", "30", "--warmup", "5", "--no-kernel-table",
+               "--no-cpu-baseline", "--no-extra-lines", "--no-other-configs", *extra]
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            d = json.loads(line[-1])
+            cfg = d.get("config", {})
+            out[wl] = {"what": what, "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "dtype": d["dtype"],
+                       "per_step_per_gpu": cfg.get("frames_per_step_per_gpu") or cfg.get("samples_per_step_per_gpu"),
+                       "points_per_frame": cfg.get("points_per_frame"), "rows_per_frame": cfg.get("rows_per_frame"),
+                       "steps_in_flight": cfg.get("steps_in_flight"), "loss_last_step": d.get("loss_last_step"), "steps": d["steps"]}
+        except Exception as e:  # noqa: BLE001
+            out[wl] = {"error": repr(e)[:300]}
+    return out
+
+
 # ------------------------------------------------------------------------------------------ extra lines
 def time_e2e(det, points, offsets, inflight, steps, warmup):
     """SURVEY 8(d) "end-to-end": the same loop as the timed region, but every step's clouds start in PINNED HOST memory
@@ -580,6 +626,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-table", action="store_true", help="skip the per-launch roofline table (`kernels` key)")
     ap.add_argument("--no-extra-lines", action="store_true", help="skip config.e2e_from_pinned_host and config.batch1")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short child runs of BASELINE configs 3 / 4 / 5 (`other_configs`)")
     ap.add_argument("--stages", action="store_true", help="also print per-stage timings to stderr")
     ap.add_argument("--inflight", type=int, default=3,
                     help="graph mode: number of steps (graph replays, each a full pass over the batch with its own activation "
@@ -718,8 +765,11 @@ def main():
         ops.set_conv_profiler(None)
         roof_mfma = time_rpn_conv(det, WL["batch"]) if args.dtype == "bf16" else None
         ktable = None
-        if rank == 0 and args.mode != "eager" and args.workload == "car.fhd" and not args.no_kernel_table:
-            ktable = kernel_table(det, points, offsets)
+        if rank == 0 and args.mode != "eager" and not args.no_kernel_table:
+            try:
+                ktable = kernel_table(det, points, offsets)
+            except Exception as e:  # noqa: BLE001 -- the table is diagnostics: never lose the line over it
+                ktable = [{"error": repr(e)}]
         e2e = batch1 = None
         if rank == 0 and args.mode == "graph" and args.branches == 1 and args.workload == "car.fhd" and not args.no_extra_lines:
             e2e = time_e2e(det, points, offsets, max(1, args.inflight), min(args.steps, 200), args.warmup)
@@ -801,6 +851,9 @@ def main():
             res["detections_match_cpu"] = res["cpu_baseline"].pop("detections_match_cpu", None)
         det_count = int(out["valid"].sum().item())
         res["detections_last_step"] = det_count
+        if world == 1 and args.workload == "car.fhd" and not args.no_other_configs and not args.no_cpu_baseline:
+            torch.cuda.synchronize()
+            res["other_configs"] = other_configs()     # child processes on the same GPU, after every timed region of this one
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()

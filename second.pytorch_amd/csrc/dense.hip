@@ -161,123 +161,12 @@ __global__ __launch_bounds__(kBlock) void k_conv2d_pack(const T *__restrict__ w,
     packed[g] = w[(((size_t)n * cin + ci) * ks + tap / ks) * ks + tap % ks];
 }
 
-template <typename T, int BN>
-__global__ __launch_bounds__(kBlock) void k_conv2d_nhwc(const T *__restrict__ x, const T *__restrict__ wpk,
-                                                       const float *__restrict__ bias, T *__restrict__ y, Conv2dParams p) {
-    constexpr int BM = 128, NTW = BN / 64;          // n-tiles per wave
-    constexpr int PERB = BN * 8 / kBlock;           // B uint4 per thread per slab
-    __shared__ uint4 sA[2][BM * 8];
-    __shared__ uint4 sB[2][8 * BN];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int r = lane & 31, hh = lane >> 5;
-    const int wm = wv & 1, wn = wv >> 1;
-    const long long m0 = (long long)blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
-    const int cin8 = p.cin / 8, CC = p.cin / 64, NIT = p.ksize * p.ksize * CC;
-    const uint4 *x4 = reinterpret_cast<const uint4 *>(x);
-    const uint4 *w4 = reinterpret_cast<const uint4 *>(wpk);
-
-    // A rows owned by this thread: pixels tid/8 + 32 j (j = 0..3), 16-byte chunk tid % 8
-    const int chunk = tid & 7;
-    long long abase[4];
-    int iy0[4], ix0[4];
-    bool pval[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        long long pix = m0 + (tid >> 3) + 32 * j;
-        pval[j] = pix < p.m;
-        long long q = pval[j] ? pix : 0;
-        int ox = (int)(q % p.wo);
-        q /= p.wo;
-        int oy = (int)(q % p.ho);
-        int b = (int)(q / p.ho);
-        iy0[j] = oy * p.stride - p.pad;
-        ix0[j] = ox * p.stride - p.pad;
-        abase[j] = ((long long)b * p.h + iy0[j]) * p.w + ix0[j];
-    }
-    uint4 ra[4], rb[PERB];
-    auto load = [&](int it) {
-        const int tap = it / CC, cc = it - tap * CC;
-        const int dy = tap / p.ksize, dx = tap - dy * p.ksize;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int iy = iy0[j] + dy, ix = ix0[j] + dx;
-            const bool ok = pval[j] && iy >= 0 && iy < p.h && ix >= 0 && ix < p.w;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (ok) v = x4[(abase[j] + (long long)dy * p.w + dx) * cin8 + cc * 8 + chunk];
-            ra[j] = v;
-        }
-#pragma unroll
-        for (int j = 0; j < PERB; ++j) {
-            const int e = tid + j * kBlock, ch = e / BN, n = e - ch * BN;
-            rb[j] = w4[((size_t)tap * cin8 + cc * 8 + ch) * p.cout + n0 + n];
-        }
-    };
-    auto store = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int pl = (tid >> 3) + 32 * j;
-            sA[buf][pl * 8 + (chunk ^ (pl & 7))] = ra[j];
-        }
-#pragma unroll
-        for (int j = 0; j < PERB; ++j) sB[buf][tid + j * kBlock] = rb[j];
-    };
-
-    f32x16d acc[2][NTW];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < NTW; ++b)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
-
-    load(0);
-    store(0);
-    __syncthreads();
-    for (int it = 0; it < NIT; ++it) {
-        const int buf = it & 1;
-        if (it + 1 < NIT) load(it + 1);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            uint4 af[2], bf[NTW];
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) af[mt] = sA[buf][(wm * 64 + mt * 32 + r) * 8 + ((s * 2 + hh) ^ (r & 7))];
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) bf[nt] = sB[buf][(s * 2 + hh) * BN + wn * (BN / 2) + nt * 32 + r];
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = MfmaD<T>::run(af[mt], bf[nt], acc[mt][nt]);
-        }
-        if (it + 1 < NIT) store(buf ^ 1);
-        __syncthreads();
-    }
-    // epilogue: C/D layout col = lane & 31 (cout), row = (i & 3) + 8 (i >> 2) + 4 (lane >> 5) (pixel)
-#pragma unroll
-    for (int nt = 0; nt < NTW; ++nt) {
-        const int co = n0 + wn * (BN / 2) + nt * 32 + r;
-        const float bv = bias ? bias[co] : 0.0f;
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const long long pix = m0 + wm * 64 + mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-                if (pix < p.m) {
-                    float v = acc[mt][nt][i] + bv;
-                    if (p.relu) v = v > 0.0f ? v : 0.0f;
-                    y[(size_t)pix * p.cout + co] = from_f<T>(v);
-                }
-            }
-    }
-}
-
 // Same tiling, but both slabs travel global -> LDS with the asynchronous LDS-DMA (global_load_lds_dwordx4): no
 // staging VGPRs, no ds_write pass.  The DMA writes LDS linearly in lane order, so the XOR swizzle of the A slab is
 // applied to the SOURCE chunk index (guide rule 21); rows that fall into the zero padding read a 16-byte zero
 // block appended to the packed weights (an exec-masked lane would leave stale LDS bytes).
 typedef __attribute__((address_space(3))) void *lds_ptr_t;
 typedef const __attribute__((address_space(1))) void *glb_ptr_t;
-
 template <typename T, int BN>
 __global__ __launch_bounds__(kBlock) void k_conv2d_nhwc_dma(const T *__restrict__ x, const T *__restrict__ wpk,
                                                            const float *__restrict__ bias, T *__restrict__ y, Conv2dParams p) {
@@ -401,128 +290,6 @@ __global__ __launch_bounds__(kBlock) void k_conv2d_nhwc_dma(const T *__restrict_
     }
 }
 
-// Halo-tile variant for the 3x3 / stride 1 / pad 1 layers (all six 128->128 layers of the car.fhd RPN): the
-// implicit-GEMM kernels above re-fetch every input pixel once per tap (9x); here a workgroup owns a 16 x 16 output
-// tile, brings the (16+2)^2 input halo into LDS ONCE (all Cin channels: 18*18*Cin*2 B = 83 KB for Cin = 128 --
-// CDNA4's 160 KB LDS makes this possible) and then only streams the nine 3x3 weight slabs (double-buffered LDS-DMA).
-// 8 waves as 4 (pixel quarters) x 2 (cout halves), each 64 px x 64 cout on MFMA 32x32x16.
-template <typename T, int CIN, int TH, int NQ>
-__global__ __launch_bounds__(TH * 16 * NQ) void k_conv2d_halo(const T *__restrict__ x, const T *__restrict__ wpk,
-                                                    const float *__restrict__ bias, T *__restrict__ y, Conv2dParams p,
-                                                    int tiles_y, int tiles_x) {
-    constexpr int TW = 16, HW_ = TW + 2, HPIX = (TH + 2) * (TW + 2);   // TH = 16: 324 halo pixels, 8 waves; TH = 8: 180, 4 waves
-    constexpr int PQ = TH / 4, NWV = PQ * NQ;      // pixel groups (64 px = 4 tile rows each) x NQ cout groups = waves
-    constexpr int NTW = 128 / (NQ * 32);           // 32-wide cout tiles per wave
-    constexpr int CH = CIN / 8;                    // 16-byte chunks per pixel (16 for Cin = 128)
-    constexpr int HENT = HPIX * CH;                // uint4 entries of the halo
-    constexpr int BN = 128, CC = CIN / 64, NIT = 9 * CC;
-    extern __shared__ __attribute__((aligned(16))) uint4 halo_smem[];
-    uint4 *hal = halo_smem;                        // [HPIX][CH], chunk index XOR-swizzled with (pixel & (CH-1))
-    uint4 *sB = halo_smem + HENT;                  // [2][8 * BN]
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int r = lane & 31, hh = lane >> 5;
-    const int wm = wv % PQ, wn = wv / PQ;
-    // XCD-aware tile order
-    const int per = gridDim.x / 8;
-    const int tile = (blockIdx.x % 8) * per + blockIdx.x / 8;
-    const int ntile = p.batch * tiles_y * tiles_x;
-    if (tile >= ntile) return;
-    const int b = tile / (tiles_y * tiles_x);
-    const int trem = tile - b * tiles_y * tiles_x;
-    const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
-    const int n0 = blockIdx.y * BN;
-    const int cin8 = CIN / 8;
-    const uint4 *x4 = reinterpret_cast<const uint4 *>(x);
-    const uint4 *w4 = reinterpret_cast<const uint4 *>(wpk);
-    const uint4 *zero16 = w4 + (size_t)9 * cin8 * p.cout;
-
-    // halo DMA: instruction i fills entries [i*64, i*64+64); HENT is a multiple of 64 for CIN in {64, 128}
-    for (int i = wv; i < (HENT + 63) / 64; i += NWV) {
-        const int e = i * 64 + lane;
-        if (e >= HENT) break;
-        const int hp = e / CH, slot = e - hp * CH;
-        const int hy = hp / HW_, hx = hp - hy * HW_;
-        const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
-        const bool ok = iy >= 0 && iy < p.h && ix >= 0 && ix < p.w;
-        const uint4 *src = ok ? x4 + (((long long)b * p.h + iy) * p.w + ix) * cin8 + (slot ^ (hp & (CH - 1))) : zero16;
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)&hal[i * 64], 16, 0, 0);
-    }
-    auto issue_b = [&](int it, int buf) {
-        const int tap = it / CC, cc = it - tap * CC;
-#pragma unroll
-        for (int j = 0; j < 16 / NWV; ++j) {
-            const int e = (j * NWV + wv) * 64 + lane, ch = e / BN, n = e - ch * BN;
-            const uint4 *src = w4 + ((size_t)tap * cin8 + cc * 8 + ch) * p.cout + n0 + n;
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)&sB[buf * (8 * BN) + (j * NWV + wv) * 64], 16, 0, 0);
-        }
-    };
-    f32x16d acc[2][NTW];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int c = 0; c < NTW; ++c)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[a][c][i] = 0.0f;
-    // halo pixel (top-left tap) of this lane's two A rows: wave quarter wm = 4 tile rows, m-tile mt = 2 rows
-    int hp0[2];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        const int q = mt * 32 + r;
-        hp0[mt] = (wm * 4 + (q >> 4)) * HW_ + (q & 15);
-    }
-    issue_b(0, 0);
-    __syncthreads();
-    for (int it = 0; it < NIT; ++it) {
-        const int buf = it & 1;
-        if (it + 1 < NIT) issue_b(it + 1, buf ^ 1);
-        const int tap = it / CC, cc = it - tap * CC;
-        const int dy = tap / 3, dx = tap - dy * 3;
-        const uint4 *bb = sB + buf * (8 * BN);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            uint4 af[2], bf[NTW];
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                const int hp = hp0[mt] + dy * HW_ + dx;
-                af[mt] = hal[hp * CH + ((cc * 8 + s * 2 + hh) ^ (hp & (CH - 1)))];
-            }
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) bf[nt] = bb[(s * 2 + hh) * BN + wn * (BN / NQ) + nt * 32 + r];
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = MfmaD<T>::run(bf[nt], af[mt], acc[mt][nt]);   // D^T: see store_tile_t
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        const int q = mt * 32 + r;                                         // this lane's pixel inside the wave's 64
-        const int oy = y0 + wm * 4 + (q >> 4), ox = x0 + (q & 15);
-        const bool ok = oy < p.h && ox < p.w;
-        T *ypix = y + (((size_t)b * p.h + oy) * p.w + ox) * p.cout;
-#pragma unroll
-        for (int nt = 0; nt < NTW; ++nt)
-            store_tile_t<T>(acc[mt][nt], bias, n0 + wn * (BN / NQ) + nt * 32, p.relu, ypix, ok, hh);
-    }
-}
-
-template <typename T, int CIN, int TH, int NQ>
-static int launch_conv2d_halo(const void *x, const void *wpk, const float *bias, void *y, const Conv2dParams &p, hipStream_t st) {
-    constexpr size_t lds = ((size_t)(TH + 2) * 18 * (CIN / 8) + 2 * 8 * 128) * 16;
-    static bool configured = false;
-    auto fn = k_conv2d_halo<T, CIN, TH, NQ>;
-    if (!configured) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        configured = true;
-    }
-    const int ty = div_up(p.h, TH), tx = div_up(p.w, 16);
-    const int gx = (p.batch * ty * tx + 7) / 8 * 8;
-    hipLaunchKernelGGL(fn, dim3(gx, p.cout / 128), dim3(TH * 16 * NQ), lds, st, (const T *)x, (const T *)wpk, bias, (T *)y, p, ty, tx);
-    return check_launch();
-}
-
-
 // ---- software-pipelined halo kernel -------------------------------------------------------------------------
 // k_conv2d_halo above double-buffers the weight slabs, but the compiler cannot tell the LDS-DMA destination from
 // the slab being read (one dynamic LDS array) and puts s_waitcnt vmcnt(0) in front of the first ds_read of every
@@ -541,173 +308,9 @@ template <int CH, int HW_, bool COLKEY> __device__ __forceinline__ int halo_key(
     return (COLKEY && CH == 16) ? ((hp % HW_) & 15) : (hp & (CH - 1));
 }
 
-template <typename T, int CH, int HW_, int BN, int NTW, int NQ, int NWV, int KS, bool COLKEY, bool FPIPE>
-__device__ __forceinline__ void halo_step(const uint4 *__restrict__ hal, const uint4 *__restrict__ bb,
-                                          uint4 *__restrict__ bnext, const uint4 *__restrict__ wnext, int cout,
-                                          const int (&hp0)[2], int dy, int dx, int kc, int wn, int wv, int lane,
-                                          f32x16d (&acc)[2][NTW]) {
-    constexpr int SLAB = (KS / 8) * BN;            // uint4 entries per slab
-    const int r = lane & 31, hh = lane >> 5;
-    if (wnext) {
-#pragma unroll
-        for (int j = 0; j < SLAB / 64 / NWV; ++j) {
-            const int e = (j * NWV + wv) * 64 + lane, ch = e / BN, n = e - ch * BN;
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(wnext + (size_t)ch * cout + n), (lds_ptr_t)&bnext[(j * NWV + wv) * 64], 16, 0, 0);
-        }
-    }
-    // fragment loads run one k-step ahead of the MFMAs that consume them (register double buffer)
-    int hoff[2], key[2];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        const int hp = hp0[mt] + dy * HW_ + dx;
-        hoff[mt] = hp * CH;
-        key[mt] = halo_key<CH, HW_, COLKEY>(hp);
-    }
-    if (!FPIPE) {
-#pragma unroll
-        for (int s = 0; s < KS / 16; ++s) {
-            uint4 a1[2], b1[NTW];
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) a1[mt] = hal[hoff[mt] + ((kc * (KS / 8) + s * 2 + hh) ^ key[mt])];
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) b1[nt] = bb[(s * 2 + hh) * BN + wn * (BN / NQ) + nt * 32 + r];
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = MfmaD<T>::run(b1[nt], a1[mt], acc[mt][nt]);
-        }
-        return;
-    }
-    uint4 af[2][2], bf[2][NTW];
-    auto load_frag = [&](int s, int w) {
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) af[w][mt] = hal[hoff[mt] + ((kc * (KS / 8) + s * 2 + hh) ^ key[mt])];
-#pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) bf[w][nt] = bb[(s * 2 + hh) * BN + wn * (BN / NQ) + nt * 32 + r];
-    };
-    load_frag(0, 0);
-#pragma unroll
-    for (int s = 0; s < KS / 16; ++s) {
-        if (s + 1 < KS / 16) load_frag(s + 1, (s + 1) & 1);
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt)
-                acc[mt][nt] = MfmaD<T>::run(bf[s & 1][nt], af[s & 1][mt], acc[mt][nt]);   // D^T: see store_tile_t
-    }
-}
-
-template <typename T, int CIN, int TH, int NQ, int KS, int NB, bool COLKEY, bool FPIPE>
-__global__ __launch_bounds__(TH * 16 * NQ) void k_conv2d_halo_pipe(const T *__restrict__ x, const T *__restrict__ wpk,
-                                                                   const float *__restrict__ bias, T *__restrict__ y,
-                                                                   Conv2dParams p, int tiles_y, int tiles_x) {
-    constexpr int TW = 16, HW_ = TW + 2, HPIX = (TH + 2) * (TW + 2);
-    constexpr int PQ = TH / 4, NWV = PQ * NQ;
-    constexpr int NTW = 128 / (NQ * 32);
-    constexpr int CH = CIN / 8, HENT = HPIX * CH;
-    constexpr int BN = 128, KC = CIN / KS, NIT = 9 * KC, SLAB = (KS / 8) * BN, DIST = NB - 1;
-    constexpr int L = SLAB / 64 / NWV;             // DMA instructions per wave per slab
-    static_assert(SLAB % (64 * NWV) == 0 && NIT > DIST, "slab must split evenly over the waves");
-    extern __shared__ __attribute__((aligned(16))) uint4 halo_smem[];
-    uint4 *hal = halo_smem;
-    uint4 *ring = halo_smem + HENT;                // [NB][SLAB]
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int r = lane & 31, hh = lane >> 5;
-    const int wm = wv % PQ, wn = wv / PQ;
-    const int per = gridDim.x / 8;
-    const int tile = (blockIdx.x % 8) * per + blockIdx.x / 8;    // XCD-aware tile order
-    const int ntile = p.batch * tiles_y * tiles_x;
-    if (tile >= ntile) return;
-    const int b = tile / (tiles_y * tiles_x);
-    const int trem = tile - b * tiles_y * tiles_x;
-    const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
-    const int n0 = blockIdx.y * BN;
-    constexpr int cin8 = CIN / 8;
-    const uint4 *x4 = reinterpret_cast<const uint4 *>(x);
-    const uint4 *w4 = reinterpret_cast<const uint4 *>(wpk);
-    const uint4 *zero16 = w4 + (size_t)9 * cin8 * p.cout;
-    auto slab_src = [&](int it) {                  // first entry of slab `it` = (tap, kc): [tap][cin8][cout] uint4
-        const int tap = it / KC, kc = it - tap * KC;
-        return w4 + ((size_t)tap * cin8 + kc * (KS / 8)) * p.cout + n0;
-    };
-    for (int i = wv; i < (HENT + 63) / 64; i += NWV) {
-        const int e = i * 64 + lane;
-        if (e >= HENT) break;
-        const int hp = e / CH, slot = e - hp * CH;
-        const int hy = hp / HW_, hx = hp - hy * HW_;
-        const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
-        const bool ok = iy >= 0 && iy < p.h && ix >= 0 && ix < p.w;
-        const uint4 *src = ok ? x4 + (((long long)b * p.h + iy) * p.w + ix) * cin8 + (slot ^ halo_key<CH, HW_, COLKEY>(hp)) : zero16;
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)&hal[i * 64], 16, 0, 0);
-    }
-#pragma unroll
-    for (int d = 0; d < DIST; ++d) {
-        const uint4 *src = slab_src(d);
-#pragma unroll
-        for (int j = 0; j < L; ++j) {
-            const int e = (j * NWV + wv) * 64 + lane, ch = e / BN, n = e - ch * BN;
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(src + (size_t)ch * p.cout + n), (lds_ptr_t)&ring[d * SLAB + (j * NWV + wv) * 64], 16, 0, 0);
-        }
-    }
-    f32x16d acc[2][NTW];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int c = 0; c < NTW; ++c)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[a][c][i] = 0.0f;
-    int hp0[2];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        const int q = mt * 32 + r;
-        hp0[mt] = (wm * 4 + (q >> 4)) * HW_ + (q & 15);
-    }
-    // halo + slab 0 must have landed; slabs 1 .. DIST-1 (the youngest (DIST-1)*L DMAs of this wave) may still fly
-    wait_vmcnt<(DIST - 1) * L>();
-    lds_barrier();
-    int slot = 0, tap = 0, kc = 0;
-    for (int it = 0; it < NIT; ++it) {
-        const int dy = tap / 3, dx = tap - dy * 3;
-        int nslot = slot + DIST;
-        if (nslot >= NB) nslot -= NB;
-        const bool more = it + DIST < NIT;
-        halo_step<T, CH, HW_, BN, NTW, NQ, NWV, KS, COLKEY, FPIPE>(hal, ring + slot * SLAB, ring + nslot * SLAB,
-                                                     more ? slab_src(it + DIST) : nullptr, p.cout, hp0, dy, dx, kc, wn, wv,
-                                                     lane, acc);
-        // slab it+1 must be complete in every wave before anyone reads it; younger slabs stay in flight
-        if (more) wait_vmcnt<(DIST - 1) * L>();
-        else wait_vmcnt<0>();
-        lds_barrier();
-        if (++slot == NB) slot = 0;
-        if (++kc == KC) { kc = 0; ++tap; }
-    }
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        const int q = mt * 32 + r;
-        const int oy = y0 + wm * 4 + (q >> 4), ox = x0 + (q & 15);
-        const bool ok = oy < p.h && ox < p.w;
-        T *ypix = y + (((size_t)b * p.h + oy) * p.w + ox) * p.cout;
-#pragma unroll
-        for (int nt = 0; nt < NTW; ++nt)
-            store_tile_t<T>(acc[mt][nt], bias, n0 + wn * (BN / NQ) + nt * 32, p.relu, ypix, ok, hh);
-    }
-}
-
-template <typename T, int CIN, int TH, int NQ, int KS, int NB, bool COLKEY, bool FPIPE>
-static int launch_conv2d_halo_pipe(const void *x, const void *wpk, const float *bias, void *y, const Conv2dParams &p, hipStream_t st) {
-    constexpr size_t lds = ((size_t)(TH + 2) * 18 * (CIN / 8) + (size_t)NB * (KS / 8) * 128) * 16;
-    static bool configured = false;
-    auto fn = k_conv2d_halo_pipe<T, CIN, TH, NQ, KS, NB, COLKEY, FPIPE>;
-    if (!configured) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        configured = true;
-    }
-    const int ty = div_up(p.h, TH), tx = div_up(p.w, 16);
-    const int gx = (p.batch * ty * tx + 7) / 8 * 8;
-    hipLaunchKernelGGL(fn, dim3(gx, p.cout / 128), dim3(TH * 16 * NQ), lds, st, (const T *)x, (const T *)wpk, bias, (T *)y, p, ty, tx);
-    return check_launch();
-}
-
+#ifdef SEC_CONV2D_EXPERIMENTS   // superseded 3x3 kernels (register-staged implicit GEMM, LDS weight slabs / rings): A/B builds only
+#include "experiments/dense_conv2d_ab.inc"
+#endif
 
 // ---- halo kernel with register-resident weights ----------------------------------------------------------------
 // PMC on the LDS-slab kernels (profiles/r01_g_pmc_conv2d.txt): MFMA pipe 38 % busy, waves parked 48 % of their
