@@ -293,6 +293,34 @@ int sec_conv1x1_chain_nhwc(const void *x, long long pixels, const void *packed_w
                            int dtype, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Training of the dense RPN with 16-bit activations over fp32 master weights -- replaces what autograd runs for
+ * nn.Conv2d(128, 128, 3, padding=1, bias=False) + nn.BatchNorm2d(eps 1e-3, momentum 0.01) + nn.ReLU
+ * (second/pytorch/models/rpn.py:486-497) inside loss.backward() (second/pytorch/train.py:316-322): MIOpen's igemm
+ * backward-weights / backward-data kernels and ~8 torch kernels per BatchNorm + ReLU pair.
+ *   forward conv        sec_conv2d_nhwc (bias NULL, relu 0);
+ *   data gradient       sec_conv2d_nhwc on dY with the weights flipped and transposed: dX = conv(dY, W[ci][co][2-ky][2-kx]);
+ *   weight gradient     sec_conv2d_wgrad_nhwc: dweight [cout][cin][3][3] fp32 (torch's layout) = sum over pixels of
+ *                       x[p + tap] (x) dy[p]; 3x3 / stride 1 / pad 1, cin = cout = 128; deterministic (partials in the
+ *                       workspace, summed in a fixed order -- no float atomics);
+ *   BatchNorm + ReLU    sec_bn_relu_fwd_nhwc: batch statistics over `pixels` rows of a channels-last [pixels][channels] tensor
+ *                       (biased variance for the normalisation, running statistics updated with the unbiased one, as
+ *                       torch.nn.BatchNorm2d does), z = act((y - mean) * invstd * gamma + beta); save_mean / save_invstd
+ *                       [channels] are kept for the backward.  sec_bn_relu_bwd_nhwc: dy, dgamma, dbeta from dz and y (the ReLU
+ *                       mask is recomputed from y).  channels % 8 == 0, <= 256, a divisor of 2048.
+ * --------------------------------------------------------------------------------------------- */
+size_t sec_conv2d_wgrad_workspace_bytes(int batch, int h, int w, int cin, int cout, int ksize);
+int sec_conv2d_wgrad_nhwc(const void *x, const void *dy, int batch, int h, int w, int cin, int cout, int ksize,
+                          int stride, int pad, float *dweight, void *workspace, size_t workspace_bytes, int dtype,
+                          void *stream);
+size_t sec_bn_train_workspace_bytes(int channels);
+int sec_bn_relu_fwd_nhwc(const void *y, long long pixels, int channels, const float *gamma, const float *beta, float eps,
+                         float momentum, float *running_mean, float *running_var, int relu, void *z, float *save_mean,
+                         float *save_invstd, void *workspace, size_t workspace_bytes, int dtype, void *stream);
+int sec_bn_relu_bwd_nhwc(const void *dz, const void *y, long long pixels, int channels, const float *gamma,
+                         const float *beta, const float *save_mean, const float *save_invstd, int relu, void *dy,
+                         float *dgamma, float *dbeta, void *workspace, size_t workspace_bytes, int dtype, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Rotated IoU / NMS -- replace the numba.cuda kernels of second/core/non_max_suppression/nms_gpu.py
  * (rotate_iou_kernel_eval :564-602, rotate_nms_kernel :404-437, nms_kernel :70-101, nms_postprocess
  * :109-126) and the CPU path rotate_nms_cc (nms_cpu.py:17-28 -> spconv rotate_non_max_suppression_cpu).

@@ -359,6 +359,66 @@ class RPNV2(nn.Module):
         return ret
 
 
+def rpn_forward_mixed(rpn, x, dtype):
+    """Training forward of an RPNV2 with 16-bit activations over its fp32 master weights (the DeviceTrainer's amp path).  Every
+    Conv2d(128, 128, 3, stride 1) + BatchNorm2d + ReLU triple of the blocks runs on the hand-written kernels -- forward and data
+    gradient on k_conv2d_halo_reg, weight gradient on k_conv2d_wgrad3x3, BatchNorm (batch statistics) + ReLU fused
+    (ops.Conv3x3Function / ops.BatchNormReluFunction; rpn.py:486-497 trained by train.py:316-322); anything else (strided or
+    other-width convs, the deblocks, the 1x1 heads) stays on torch under autocast.  SEC_RPN_TRAIN_BACKEND=miopen: all of it on torch
+    (the round-2 path, for A/B runs).  Same arithmetic as RPNV2.forward up to 16-bit rounding of the activations."""
+    use_hip = os.environ.get("SEC_RPN_TRAIN_BACKEND", "hip") == "hip" and x.is_cuda
+    x = x.to(dtype).contiguous(memory_format=torch.channels_last)
+
+    def run_block(blk, x):
+        mods = list(blk.children())
+        i, pad = 0, 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, nn.ZeroPad2d):
+                pad = m.padding[0]
+                i += 1
+                continue
+            fused = (use_hip and isinstance(m, nn.Conv2d) and i + 2 < len(mods) and isinstance(mods[i + 1], nn.BatchNorm2d)
+                     and isinstance(mods[i + 2], nn.ReLU) and m.bias is None and m.kernel_size == (3, 3) and m.stride == (1, 1)
+                     and m.padding[0] + pad == 1 and m.padding[1] + pad == 1 and m.dilation == (1, 1) and m.groups == 1
+                     and ops.conv2d_wgrad_supported(m.in_channels, m.out_channels, 3, 1, 1, dtype) and mods[i + 1].training
+                     and mods[i + 1].track_running_stats and mods[i + 1].affine)
+            if fused:
+                bn = mods[i + 1]
+                y = ops.Conv3x3Function.apply(x, m.weight)
+                mom = bn.momentum if bn.momentum is not None else 0.1
+                x = ops.BatchNormReluFunction.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, mom, True)
+                bn.num_batches_tracked += 1
+                i, pad = i + 3, 0
+                continue
+            with torch.autocast("cuda", dtype=dtype, enabled=x.is_cuda):
+                if pad:
+                    x = F.pad(x, (pad, pad, pad, pad))
+                    pad = 0
+                x = m(x)
+            i += 1
+        return x
+    ups = []
+    for i, blk in enumerate(rpn.blocks):
+        x = run_block(blk, x)
+        if i - rpn._upsample_start_idx >= 0:
+            with torch.autocast("cuda", dtype=dtype, enabled=x.is_cuda):
+                ups.append(rpn.deblocks[i - rpn._upsample_start_idx](x))
+    with torch.autocast("cuda", dtype=dtype, enabled=x.is_cuda):
+        if ups:
+            x = torch.cat(ups, dim=1) if len(ups) > 1 else ups[0]
+        a = rpn._num_anchor_per_loc
+
+        def head(conv, code):
+            y = conv(x)
+            h, w = y.shape[2:]
+            return y.view(-1, a, code, h, w).permute(0, 1, 3, 4, 2).contiguous()
+        ret = {"box_preds": head(rpn.conv_box, rpn._box_code_size), "cls_preds": head(rpn.conv_cls, rpn._num_class)}
+        if rpn._use_direction_classifier:
+            ret["dir_cls_preds"] = head(rpn.conv_dir_cls, rpn._num_direction_bins)
+    return ret
+
+
 def fold_conv_bn_(seq):
     """In place: fold every (Conv2d|ConvTranspose2d, BatchNorm2d) pair of an nn.Sequential (eval mode)."""
     mods = list(seq.children())

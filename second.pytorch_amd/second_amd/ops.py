@@ -806,3 +806,117 @@ class SecondLossFunction(torch.autograd.Function):
         gd = None if shapes[2] is None else (d_dir * g_loss).reshape(shapes[2]).to(dts[2])
         return ((d_cls * g_loss).reshape(shapes[0]).to(dts[0]), (d_box * g_loss).reshape(shapes[1]).to(dts[1]), gd,
                 None, None, None, None, None)
+
+
+# ----------------------------------------------------------------------------- dense RPN training (rpn.py:486-497 under train.py:316-322)
+def conv2d_dgrad_weight(weight):
+    """[Cout,Cin,3,3] -> the weights of the convolution that maps dY to dX for stride 1 / pad 1: W'[ci][co][ky][kx] =
+    W[co][ci][2-ky][2-kx] (the data gradient of a correlation is the correlation with the flipped, transposed kernel)."""
+    return weight.flip(2, 3).transpose(0, 1).contiguous()
+
+
+def conv2d_wgrad(x, dy):
+    """dW [Cout,Cin,3,3] fp32 of y = conv2d(x, W, stride 1, padding 1): x [B,Cin,H,W], dy [B,Cout,H,W], both channels_last 16-bit,
+    Cin = Cout = 128 (sec_conv2d_wgrad_nhwc).  Deterministic."""
+    rt.require_gpu(x, dy)
+    assert x.dtype == dy.dtype and x.dim() == 4 and x.shape[0] == dy.shape[0] and x.shape[2:] == dy.shape[2:]
+    assert x.is_contiguous(memory_format=torch.channels_last) and dy.is_contiguous(memory_format=torch.channels_last)
+    b, cin, h, w = x.shape
+    cout = dy.shape[1]
+    l = rt.lib()
+    nb = l.sec_conv2d_wgrad_workspace_bytes(b, h, w, cin, cout, 3)
+    if nb == 0:
+        raise rt.SecondHipError(f"conv2d_wgrad: unsupported shape {cin}->{cout} (3x3 / s1 / p1 with 128 channels only)")
+    ws = rt.workspace(nb, x.device)
+    dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=x.device)
+    rt.check(l.sec_conv2d_wgrad_nhwc(rt.ptr(x), rt.ptr(dy), b, h, w, cin, cout, 3, 1, 1, rt.ptr(dw), rt.ptr(ws), ws.numel(),
+                                     rt.dtype_code(x.dtype), rt.stream()), "sec_conv2d_wgrad_nhwc")
+    return dw
+
+
+def conv2d_wgrad_supported(cin, cout, ksize, stride, pad, dtype):
+    return (cin, cout, ksize, stride, pad) == (128, 128, 3, 1, 1) and dtype in (torch.bfloat16, torch.float16)
+
+
+def bn_relu_forward(y, gamma, beta, eps, momentum, running_mean=None, running_var=None, relu=True):
+    """Training-mode BatchNorm2d + ReLU of a channels_last 16-bit [B,C,H,W] tensor (sec_bn_relu_fwd_nhwc).  gamma / beta fp32 [C];
+    running_mean / running_var (fp32, updated in place) may be None.  -> (z, save_mean, save_invstd)."""
+    rt.require_gpu(y, gamma, beta)
+    assert y.dim() == 4 and y.is_contiguous(memory_format=torch.channels_last)
+    b, c, h, w = y.shape
+    for t in (gamma, beta, running_mean, running_var):
+        assert t is None or (t.dtype == torch.float32 and t.is_contiguous() and t.numel() == c and t.is_cuda)
+    l = rt.lib()
+    nb = l.sec_bn_train_workspace_bytes(c)
+    if nb == 0 or 256 % (c // 8):
+        raise rt.SecondHipError(f"bn_relu_forward: unsupported channel count {c}")
+    ws = rt.workspace(nb, y.device)
+    z = torch.empty_like(y)
+    mean = torch.empty((c,), dtype=torch.float32, device=y.device)
+    invstd = torch.empty((c,), dtype=torch.float32, device=y.device)
+    rt.check(l.sec_bn_relu_fwd_nhwc(rt.ptr(y), b * h * w, c, rt.ptr(gamma), rt.ptr(beta), float(eps), float(momentum),
+                                    rt.ptr(running_mean), rt.ptr(running_var), int(bool(relu)), rt.ptr(z), rt.ptr(mean), rt.ptr(invstd),
+                                    rt.ptr(ws), ws.numel(), rt.dtype_code(y.dtype), rt.stream()), "sec_bn_relu_fwd_nhwc")
+    return z, mean, invstd
+
+
+def bn_relu_backward(dz, y, gamma, beta, save_mean, save_invstd, relu=True):
+    """-> (dy, dgamma, dbeta) of :func:`bn_relu_forward` (sec_bn_relu_bwd_nhwc); dz, y channels_last 16-bit."""
+    rt.require_gpu(dz, y, gamma, beta, save_mean, save_invstd)
+    assert dz.shape == y.shape and dz.dtype == y.dtype
+    assert y.is_contiguous(memory_format=torch.channels_last) and dz.is_contiguous(memory_format=torch.channels_last)
+    b, c, h, w = y.shape
+    l = rt.lib()
+    ws = rt.workspace(l.sec_bn_train_workspace_bytes(c), y.device)
+    dy = torch.empty_like(y)
+    dgamma = torch.empty((c,), dtype=torch.float32, device=y.device)
+    dbeta = torch.empty((c,), dtype=torch.float32, device=y.device)
+    rt.check(l.sec_bn_relu_bwd_nhwc(rt.ptr(dz), rt.ptr(y), b * h * w, c, rt.ptr(gamma), rt.ptr(beta), rt.ptr(save_mean),
+                                    rt.ptr(save_invstd), int(bool(relu)), rt.ptr(dy), rt.ptr(dgamma), rt.ptr(dbeta), rt.ptr(ws),
+                                    ws.numel(), rt.dtype_code(y.dtype), rt.stream()), "sec_bn_relu_bwd_nhwc")
+    return dy, dgamma, dbeta
+
+
+class Conv3x3Function(torch.autograd.Function):
+    """nn.Conv2d(128, 128, 3, padding=1, bias=False) on channels_last 16-bit activations over an fp32 master weight: forward and
+    data gradient on k_conv2d_halo_reg, weight gradient on k_conv2d_wgrad3x3.  ``pad_first``: ZeroPad2d(1) + Conv2d(padding=0) of
+    the first RPN layer is the same operator."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        w16 = weight.detach().to(x.dtype)
+        y = conv2d_nhwc(x, conv2d_pack_weight(w16.contiguous()), None, weight.shape[0], 3, 1, 1, relu=False)
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            wt = conv2d_dgrad_weight(weight.detach().to(x.dtype))
+            dx = conv2d_nhwc(dy, conv2d_pack_weight(wt), None, weight.shape[1], 3, 1, 1, relu=False)
+        if ctx.needs_input_grad[1]:
+            dw = conv2d_wgrad(x, dy).to(weight.dtype)
+        return dx, dw
+
+
+class BatchNormReluFunction(torch.autograd.Function):
+    """nn.BatchNorm2d (training mode: batch statistics, running statistics updated) + nn.ReLU in two launches + a finalize, on
+    channels_last 16-bit activations with fp32 affine parameters."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, running_mean, running_var, eps, momentum, relu):
+        z, mean, invstd = bn_relu_forward(y, gamma.detach().float().contiguous(), beta.detach().float().contiguous(), eps, momentum,
+                                          running_mean, running_var, relu)
+        ctx.save_for_backward(y, gamma, beta, mean, invstd)
+        ctx.relu = relu
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        y, gamma, beta, mean, invstd = ctx.saved_tensors
+        dy, dgamma, dbeta = bn_relu_backward(dz.contiguous(memory_format=torch.channels_last), y, gamma.detach().float().contiguous(),
+                                             beta.detach().float().contiguous(), mean, invstd, ctx.relu)
+        return dy, dgamma.to(gamma.dtype), dbeta.to(beta.dtype), None, None, None, None, None

@@ -30,6 +30,8 @@ SYMBOLS = [
     "sec_predict_select", "sec_predict_decode", "sec_predict_finalize",
     "sec_assign_targets_workspace_bytes", "sec_assign_targets_f32", "sec_assign_targets_per_class_f32",
     "sec_second_loss_workspace_bytes", "sec_second_loss_f32",
+    "sec_conv2d_wgrad_workspace_bytes", "sec_conv2d_wgrad_nhwc", "sec_bn_train_workspace_bytes", "sec_bn_relu_fwd_nhwc",
+    "sec_bn_relu_bwd_nhwc",
 ]
 
 _lib = None
@@ -51,7 +53,8 @@ def lib():
         for name in ("sec_voxelize_workspace_bytes", "sec_rulebook_workspace_bytes", "sec_rulebook_sorted_workspace_bytes",
                      "sec_packed_weight_bytes", "sec_nms_workspace_bytes", "sec_block_filter_workspace_bytes",
                      "sec_conv2d_packed_weight_bytes", "sec_indice_conv_bwd_workspace_bytes",
-                     "sec_assign_targets_workspace_bytes", "sec_second_loss_workspace_bytes"):
+                     "sec_assign_targets_workspace_bytes", "sec_second_loss_workspace_bytes",
+                     "sec_conv2d_wgrad_workspace_bytes", "sec_bn_train_workspace_bytes"):
             getattr(l, name).restype = ctypes.c_size_t
         l.sec_last_error.restype = ctypes.c_char_p
         l.sec_last_kernel_name.restype = ctypes.c_char_p
@@ -102,6 +105,12 @@ def lib():
         l.sec_assign_targets_per_class_f32.argtypes = [vp, ci, vp, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
         l.sec_second_loss_workspace_bytes.argtypes = [ci, ci]
         l.sec_second_loss_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, sz, vp]
+        ll = ctypes.c_longlong
+        l.sec_conv2d_wgrad_workspace_bytes.argtypes = [ci] * 6
+        l.sec_conv2d_wgrad_nhwc.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, vp, sz, ci, vp]
+        l.sec_bn_train_workspace_bytes.argtypes = [ci]
+        l.sec_bn_relu_fwd_nhwc.argtypes = [vp, ll, ci, vp, vp, cf, cf, vp, vp, ci, vp, vp, vp, vp, sz, ci, vp]
+        l.sec_bn_relu_bwd_nhwc.argtypes = [vp, vp, ll, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp, sz, ci, vp]
         _lib = l
     return _lib
 

@@ -10,7 +10,8 @@ Here the whole step stays on the GPU and every rank owns one GPU:
       -> sec_voxelize_f32 (+ SimpleVoxel mean)                         [no worker-side numpy, no padded H2D copies]
       -> SpMiddleFHD in train mode: rulebooks, sec_indice_conv_fwd, BatchNorm1d batch statistics, ReLU (autograd through
          sec_indice_conv_bwd / sec_dense_to_sparse)
-      -> RPNV2 (torch convolutions, channels_last)                     [MIOpen backward; the hand-written conv is inference-only]
+      -> RPNV2: 16-bit features: 3x3 convs (forward, dgrad, wgrad) and BatchNorm + ReLU on the hand-written kernels
+         (models.rpn_forward_mixed); fp32: torch convolutions (MIOpen's Winograd kernels)
       -> sec_assign_targets_f32 (anchor <-> ground truth, box encoding)
       -> sec_second_loss_f32 (focal + smooth-L1 + direction loss, values and head gradients in one pass)
       -> backward -> ONE all-reduce of the flat gradient bucket over RCCL/xGMI (distributed.GradBucket)
@@ -87,8 +88,8 @@ class DeviceTrainer:
             # under autocast, through the dense RPN; BatchNorm statistics and the loss in fp32
             spatial = det.middle_feature_extractor(vox["mean"].to(self.amp_dtype), vox["coordinates"], batch,
                                                    site_table=vox.get("site_table"))
-            with torch.autocast("cuda", dtype=self.amp_dtype):
-                preds = det.rpn(spatial.contiguous(memory_format=torch.channels_last))
+            from .models import rpn_forward_mixed
+            preds = rpn_forward_mixed(det.rpn, spatial, self.amp_dtype)   # 3x3 convs + BatchNorm/ReLU on the hand-written kernels
         else:
             preds = det.network_forward(vox["mean"], vox["coordinates"], batch, site_table=vox.get("site_table"))
         loss, out6 = ops.SecondLossFunction.apply(preds["cls_preds"], preds["box_preds"], preds.get("dir_cls_preds"), labels,
