@@ -265,6 +265,8 @@ def kernel_table(det, points, offsets, reps=30):
             ent["bound"], ent["frac"] = "mfma", round(ent["flop"] / (us * 1e-6) / 2.5e15, 4)
         elif "bytes" in ent:
             ent["bound"], ent["frac"] = "hbm", round(ent["bytes"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+            if ent["frac"] > 1.0:   # possible only through cache reuse -- every pair's row counts in the algorithmic bytes
+                ent["note"] = "above the HBM peak on ALGORITHMIC bytes: the gathered rows of a dense rulebook are re-read from L2 / Infinity Cache"
         rows.append(ent)
     ops.set_rulebook_numbering(prev_numbering)
     return rows

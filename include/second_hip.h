@@ -308,6 +308,12 @@ int sec_conv1x1_chain_nhwc(const void *x, long long pixels, const void *packed_w
  *                       [channels] are kept for the backward.  sec_bn_relu_bwd_nhwc: dy, dgamma, dbeta from dz and y (the ReLU
  *                       mask is recomputed from y).  channels % 8 == 0, <= 256, a divisor of 2048.
  * --------------------------------------------------------------------------------------------- */
+/* fp32 master weight [cout][cin][k][k] -> the 16-bit packed images of BOTH launches of a training step in one pass: `packed_fwd`
+ * (what sec_conv2d_pack_weight makes of the 16-bit rounding of the weight) and `packed_dgrad` (the same of the flipped, transposed
+ * kernel W'[ci][co][ky][kx] = W[co][ci][k-1-ky][k-1-kx], the weights of the data-gradient convolution); each
+ * sec_conv2d_packed_weight_bytes(cout, cin, ksize, dtype) bytes. */
+int sec_conv2d_pack_weight_train(const float *weight, int cout, int cin, int ksize, int dtype, void *packed_fwd,
+                                 void *packed_dgrad, void *stream);
 size_t sec_conv2d_wgrad_workspace_bytes(int batch, int h, int w, int cin, int cout, int ksize);
 int sec_conv2d_wgrad_nhwc(const void *x, const void *dy, int batch, int h, int w, int cin, int cout, int ksize,
                           int stride, int pad, float *dweight, void *workspace, size_t workspace_bytes, int dtype,

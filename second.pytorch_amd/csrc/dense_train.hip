@@ -270,6 +270,37 @@ __global__ __launch_bounds__(256) void k_bn_apply(const T *__restrict__ y, const
     }
 }
 
+// fp32 master weight [cout][cin][k][k] -> BOTH 16-bit MFMA slab images of a training step in one launch: `fwd` in the layout of
+// k_conv2d_pack (packed[((tap * cin/8 + chunk) * cout + n) * 8 + e] = w[n][chunk*8 + e][tap]) and `dgrad` = the same layout of the
+// flipped, transposed kernel W'[ci][co][ky][kx] = W[co][ci][k-1-ky][k-1-kx] (cin and cout swap roles): what the data gradient's
+// forward-kernel launch reads.  Replaces to(dtype) + pack + flip + transpose + contiguous + to(dtype) + pack (7 launches).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_conv2d_pack_train(const float *__restrict__ w, int cout, int cin, int ks, T *__restrict__ fwd,
+                                                             T *__restrict__ dgrad) {
+    const long long total = (long long)ks * ks * cin * cout;
+    const long long g = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (g >= total) return;
+    if (g < 8) {                                            // the 16-byte zero block behind each image
+        fwd[total + g] = f2t<T>(0.0f);
+        dgrad[total + g] = f2t<T>(0.0f);
+    }
+    const int e = (int)(g & 7);
+    long long q = g >> 3;
+    {   // forward image: n = output channel, chunk over input channels
+        const int n = (int)(q % cout);
+        const long long q2 = q / cout;
+        const int chunk = (int)(q2 % (cin / 8)), tap = (int)(q2 / (cin / 8));
+        fwd[g] = f2t<T>(w[(((size_t)n * cin + chunk * 8 + e) * ks + tap / ks) * ks + tap % ks]);
+    }
+    {   // dgrad image: n = INPUT channel (the dgrad conv's output), chunk over OUTPUT channels, taps mirrored
+        const int n = (int)(q % cin);
+        const long long q2 = q / cin;
+        const int chunk = (int)(q2 % (cout / 8)), tap = (int)(q2 / (cout / 8));
+        const int ky = ks - 1 - tap / ks, kx = ks - 1 - tap % ks;
+        dgrad[g] = f2t<T>(w[(((size_t)(chunk * 8 + e) * cin + n) * ks + ky) * ks + kx]);
+    }
+}
+
 constexpr int kBnGroups = 512;
 
 template <typename T>
@@ -308,6 +339,22 @@ SEC_API int sec_conv2d_wgrad_nhwc(const void *x, const void *dy, int batch, int 
     hipStream_t st = (hipStream_t)stream;
     if (dtype == SEC_BF16) return run_wgrad<__hip_bfloat16>(x, dy, batch, h, w, dweight, workspace, workspace_bytes, st);
     return run_wgrad<__half>(x, dy, batch, h, w, dweight, workspace, workspace_bytes, st);
+}
+
+SEC_API int sec_conv2d_pack_weight_train(const float *weight, int cout, int cin, int ksize, int dtype, void *packed_fwd,
+                                         void *packed_dgrad, void *stream) {
+    if (!weight || !packed_fwd || !packed_dgrad || cout <= 0 || cin <= 0 || ksize <= 0) return SEC_E_INVALID;
+    if (cin % 64 || cout % 64 || (dtype != SEC_BF16 && dtype != SEC_F16)) return SEC_E_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const long long total = (long long)ksize * ksize * cin * cout;
+    // (the kernel also writes the 16-byte zero block sec_conv2d_packed_weight_bytes reserves behind each image)
+    if (dtype == SEC_BF16)
+        hipLaunchKernelGGL((k_conv2d_pack_train<__hip_bfloat16>), dim3(div_up(total, kBlock)), dim3(kBlock), 0, st, weight, cout, cin, ksize,
+                           (__hip_bfloat16 *)packed_fwd, (__hip_bfloat16 *)packed_dgrad);
+    else
+        hipLaunchKernelGGL((k_conv2d_pack_train<__half>), dim3(div_up(total, kBlock)), dim3(kBlock), 0, st, weight, cout, cin, ksize,
+                           (__half *)packed_fwd, (__half *)packed_dgrad);
+    return check_launch();
 }
 
 SEC_API size_t sec_bn_train_workspace_bytes(int channels) {

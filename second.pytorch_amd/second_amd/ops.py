@@ -877,28 +877,44 @@ def bn_relu_backward(dz, y, gamma, beta, save_mean, save_invstd, relu=True):
     return dy, dgamma, dbeta
 
 
+def conv2d_pack_weight_train(weight, dtype):
+    """fp32 master weight [Cout,Cin,k,k] -> (packed forward image, packed data-gradient image) in `dtype`, one launch
+    (sec_conv2d_pack_weight_train).  The second is conv2d_pack_weight(conv2d_dgrad_weight(weight.to(dtype)))."""
+    rt.require_gpu(weight)
+    assert weight.dtype == torch.float32 and weight.is_contiguous() and weight.shape[2] == weight.shape[3]
+    cout, cin, k, _ = weight.shape
+    l = rt.lib()
+    nbytes = l.sec_conv2d_packed_weight_bytes(cout, cin, k, rt.dtype_code(dtype))
+    if nbytes == 0:
+        raise rt.SecondHipError(f"conv2d_pack_weight_train: unsupported shape {tuple(weight.shape)}")
+    both = torch.empty((2, nbytes // 2), dtype=dtype, device=weight.device)
+    rt.check(l.sec_conv2d_pack_weight_train(rt.ptr(weight), cout, cin, k, rt.dtype_code(dtype), rt.ptr(both[0]), rt.ptr(both[1]),
+                                            rt.stream()), "sec_conv2d_pack_weight_train")
+    return both[0], both[1]
+
+
 class Conv3x3Function(torch.autograd.Function):
     """nn.Conv2d(128, 128, 3, padding=1, bias=False) on channels_last 16-bit activations over an fp32 master weight: forward and
-    data gradient on k_conv2d_halo_reg, weight gradient on k_conv2d_wgrad3x3.  ``pad_first``: ZeroPad2d(1) + Conv2d(padding=0) of
-    the first RPN layer is the same operator."""
+    data gradient on k_conv2d_halo_reg, weight gradient on k_conv2d_wgrad3x3; both packed weight images come from one launch over
+    the master weight.  (ZeroPad2d(1) + Conv2d(padding=0) of the first RPN layer is the same operator.)"""
 
     @staticmethod
     def forward(ctx, x, weight):
-        w16 = weight.detach().to(x.dtype)
-        y = conv2d_nhwc(x, conv2d_pack_weight(w16.contiguous()), None, weight.shape[0], 3, 1, 1, relu=False)
-        ctx.save_for_backward(x, weight)
+        pk_f, pk_d = conv2d_pack_weight_train(weight.detach().contiguous(), x.dtype)
+        y = conv2d_nhwc(x, pk_f, None, weight.shape[0], 3, 1, 1, relu=False)
+        ctx.save_for_backward(x, pk_d)
+        ctx.wshape, ctx.wdtype = tuple(weight.shape), weight.dtype
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, weight = ctx.saved_tensors
+        x, pk_d = ctx.saved_tensors
         dy = dy.contiguous(memory_format=torch.channels_last)
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            wt = conv2d_dgrad_weight(weight.detach().to(x.dtype))
-            dx = conv2d_nhwc(dy, conv2d_pack_weight(wt), None, weight.shape[1], 3, 1, 1, relu=False)
+            dx = conv2d_nhwc(dy, pk_d, None, ctx.wshape[1], 3, 1, 1, relu=False)
         if ctx.needs_input_grad[1]:
-            dw = conv2d_wgrad(x, dy).to(weight.dtype)
+            dw = conv2d_wgrad(x, dy).to(ctx.wdtype)
         return dx, dw
 
 

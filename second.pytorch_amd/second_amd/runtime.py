@@ -30,7 +30,7 @@ SYMBOLS = [
     "sec_predict_select", "sec_predict_decode", "sec_predict_finalize",
     "sec_assign_targets_workspace_bytes", "sec_assign_targets_f32", "sec_assign_targets_per_class_f32",
     "sec_second_loss_workspace_bytes", "sec_second_loss_f32",
-    "sec_conv2d_wgrad_workspace_bytes", "sec_conv2d_wgrad_nhwc", "sec_bn_train_workspace_bytes", "sec_bn_relu_fwd_nhwc",
+    "sec_conv2d_pack_weight_train", "sec_conv2d_wgrad_workspace_bytes", "sec_conv2d_wgrad_nhwc", "sec_bn_train_workspace_bytes", "sec_bn_relu_fwd_nhwc",
     "sec_bn_relu_bwd_nhwc",
 ]
 
@@ -106,6 +106,7 @@ def lib():
         l.sec_second_loss_workspace_bytes.argtypes = [ci, ci]
         l.sec_second_loss_f32.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, sz, vp]
         ll = ctypes.c_longlong
+        l.sec_conv2d_pack_weight_train.argtypes = [vp, ci, ci, ci, ci, vp, vp, vp]
         l.sec_conv2d_wgrad_workspace_bytes.argtypes = [ci] * 6
         l.sec_conv2d_wgrad_nhwc.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, vp, sz, ci, vp]
         l.sec_bn_train_workspace_bytes.argtypes = [ci]

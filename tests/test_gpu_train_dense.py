@@ -95,34 +95,45 @@ def test_bn_relu_forward_backward_vs_torch(ops, dtype, c, relu):
     assert torch.equal(z, ops.bn_relu_forward(y, gamma, beta, 1e-3, 0.01, None, None, relu)[0])    # deterministic
 
 
-def test_rpn_forward_mixed_hip_matches_torch_autocast(ops, monkeypatch):
-    """models.rpn_forward_mixed: the hand-written path vs the same function with SEC_RPN_TRAIN_BACKEND=miopen (torch convolutions +
-    torch BatchNorm under autocast) on the car.fhd RPN in training mode: head outputs and parameter gradients."""
+def test_rpn_forward_mixed_hip_vs_fp32_and_torch_autocast(ops, monkeypatch):
+    """models.rpn_forward_mixed on the car.fhd RPN in training mode: the hand-written bf16 path and torch's bf16 autocast path
+    (SEC_RPN_TRAIN_BACKEND=miopen) are two different 16-bit chains, so each is measured against the SAME network in fp32 (plain
+    torch): the hand-written path may not be further from fp32 than autocast is (x 1.5 + a small floor), for the head outputs and
+    for every parameter gradient; running statistics agree with fp32's."""
     from second_amd.models import RPNV2, rpn_forward_mixed
     torch.manual_seed(0)
-    rpn = RPNV2().cuda().train()
-    ref = RPNV2().cuda().train()
-    ref.load_state_dict(rpn.state_dict())
+    nets = [RPNV2().cuda().train() for _ in range(3)]
+    for n in nets[1:]:
+        n.load_state_dict(nets[0].state_dict())
     x = (torch.randn(2, 128, 48, 40, device="cuda") * (torch.rand(2, 1, 48, 40, device="cuda") < 0.3)).contiguous(memory_format=torch.channels_last)
 
-    def run(net, backend):
-        monkeypatch.setenv("SEC_RPN_TRAIN_BACKEND", backend)
-        preds = rpn_forward_mixed(net, x, torch.bfloat16)
-        loss = sum((p.float() ** 2).mean() for p in preds.values())
-        loss.backward()
-        return preds
-    a, b = run(rpn, "hip"), run(ref, "miopen")
+    def loss_of(preds):
+        return sum((p.float() ** 2).mean() for p in preds.values())
+    monkeypatch.setenv("SEC_RPN_TRAIN_BACKEND", "hip")
+    a = rpn_forward_mixed(nets[0], x, torch.bfloat16)
+    loss_of(a).backward()
+    monkeypatch.setenv("SEC_RPN_TRAIN_BACKEND", "miopen")
+    b = rpn_forward_mixed(nets[1], x, torch.bfloat16)
+    loss_of(b).backward()
+    r = nets[2](x)                                            # fp32 reference
+    loss_of(r).backward()
+
+    def rel(u, v):
+        return (u.float() - v.float()).abs().max().item() / (v.float().abs().max().item() + 1e-20)
     for k in a:
-        torch.testing.assert_close(a[k].float(), b[k].float(), rtol=0.05, atol=0.05 * b[k].float().abs().max().item(), msg=k)
-    for (n, p), (_, q) in zip(rpn.named_parameters(), ref.named_parameters()):
-        assert p.grad is not None and q.grad is not None, n
-        den = q.grad.abs().max().item() + 1e-12
-        assert (p.grad - q.grad).abs().max().item() / den < 0.08, (n, (p.grad - q.grad).abs().max().item() / den)   # two bf16 chains
-    for (n, p), (_, q) in zip(rpn.named_buffers(), ref.named_buffers()):
+        assert rel(a[k], r[k]) <= 1.5 * rel(b[k], r[k]) + 0.01, (k, rel(a[k], r[k]), rel(b[k], r[k]))
+    worst = 0.0
+    for (n, p), (_, q), (_, f) in zip(*(net.named_parameters() for net in nets)):
+        assert p.grad is not None and q.grad is not None and f.grad is not None, n
+        eh, ea = rel(p.grad, f.grad), rel(q.grad, f.grad)
+        worst = max(worst, eh)
+        assert eh <= 1.5 * ea + 0.02, (n, eh, ea)
+    assert worst < 0.5
+    for (n, p), (_, f) in zip(nets[0].named_buffers(), nets[2].named_buffers()):
         if p.is_floating_point():
-            torch.testing.assert_close(p, q, rtol=2e-2, atol=2e-3, msg=n)     # running statistics
+            torch.testing.assert_close(p, f, rtol=2e-2, atol=2e-3, msg=n)     # running statistics
         else:
-            assert torch.equal(p, q), n                                         # num_batches_tracked
+            assert torch.equal(p, f), n                                         # num_batches_tracked
 
 
 def test_device_trainer_step_matches_cpu_chain():
