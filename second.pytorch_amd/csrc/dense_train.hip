@@ -57,7 +57,12 @@ __global__ __launch_bounds__(256, 2) void k_conv2d_wgrad3x3(const T *__restrict_
     const long long step0 = (long long)blockIdx.x * steps;
     const long long total_steps = (P + 63) / 64;
     const int nst = (int)(step0 + steps <= total_steps ? steps : (total_steps > step0 ? total_steps - step0 : 0));
-    const int chg = tid & 15, pg = tid >> 4;               // this thread stages channels chg*8.. of pixels pg*4..pg*4+3 of a step
+    // this thread stages channels chg*8.. of pixels pg*4..pg*4+3 of a step.  The PIXEL group runs fastest across lanes: the sixteen
+    // lanes of a ds_write_b64 group then store 128 contiguous bytes of one channel row (conflict-free); with the channel group fastest
+    // (fully coalesced 256-byte global reads) all sixteen hit ONE bank -- rows are 8 x 144 bytes apart -- and the kernel ran at 175 us
+    // instead of ~50.  The global reads are 64-byte segments this way (four channel groups per wave and pixel); the other waves read the
+    // rest of the same lines.
+    const int pg = tid & 15, chg = tid >> 4;
     const uint4 *x4 = reinterpret_cast<const uint4 *>(x), *d4 = reinterpret_cast<const uint4 *>(dy);
     const long long HW = (long long)H * W;
     uint4 rx[4], rd[4];
@@ -207,14 +212,27 @@ __global__ __launch_bounds__(256) void k_bn_partial(const T *__restrict__ y, con
     }
 }
 
-// forward finalize: mean, invstd (biased variance, eps), running statistics (momentum; unbiased variance as torch does)
+// fixed-order sum of one channel's `groups` partials by ONE wave: lane l adds partials l, l + 64, ... then a shuffle tree (the same
+// order on every run).  (First cut: one THREAD per channel walking 512 strided partials -- 130 us per finalize.)
+__device__ __forceinline__ void wave_sum2(const float *__restrict__ part, int groups, int C, int c, double &s0, double &s1) {
+    const int lane = threadIdx.x & 63;
+    double a = 0.0, b = 0.0;
+    for (int g = lane; g < groups; g += 64) { a += part[((size_t)g * 2 + 0) * C + c]; b += part[((size_t)g * 2 + 1) * C + c]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+    s0 = a; s1 = b;
+}
+
+// forward finalize: mean, invstd (biased variance, eps), running statistics (momentum; unbiased variance as torch does).
+// One wave per channel (256-thread workgroups: four channels each).
 __global__ __launch_bounds__(256) void k_bn_fwd_finalize(const float *__restrict__ part, int groups, int C, long long P, float eps,
                                                         float momentum, float *__restrict__ mean, float *__restrict__ invstd,
                                                         float *__restrict__ running_mean, float *__restrict__ running_var) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= C) return;
-    double s0 = 0.0, s1 = 0.0;                              // doubles: E[y^2] - E[y]^2 over 1e5 pixels cancels badly in fp32
-    for (int g = 0; g < groups; ++g) { s0 += part[((size_t)g * 2 + 0) * C + c]; s1 += part[((size_t)g * 2 + 1) * C + c]; }
+    double s0, s1;                                          // doubles: E[y^2] - E[y]^2 over 1e5 pixels cancels badly in fp32
+    wave_sum2(part, groups, C, c, s0, s1);
+    if ((threadIdx.x & 63) != 0) return;
     const double m = s0 / (double)P;
     double var = s1 / (double)P - m * m;
     if (var < 0.0) var = 0.0;
@@ -226,12 +244,13 @@ __global__ __launch_bounds__(256) void k_bn_fwd_finalize(const float *__restrict
 
 __global__ __launch_bounds__(256) void k_bn_bwd_finalize(const float *__restrict__ part, int groups, int C, float *__restrict__ dbeta,
                                                         float *__restrict__ dgamma) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= C) return;
-    float s0 = 0.0f, s1 = 0.0f;
-    for (int g = 0; g < groups; ++g) { s0 += part[((size_t)g * 2 + 0) * C + c]; s1 += part[((size_t)g * 2 + 1) * C + c]; }
-    dbeta[c] = s0;
-    dgamma[c] = s1;
+    double s0, s1;
+    wave_sum2(part, groups, C, c, s0, s1);
+    if ((threadIdx.x & 63) != 0) return;
+    dbeta[c] = (float)s0;
+    dgamma[c] = (float)s1;
 }
 
 // MODE 0: z = act((y - mean) * invstd * gamma + beta);  MODE 1: dy = gamma * invstd * (g - dbeta / P - xh * dgamma / P)
@@ -374,7 +393,7 @@ SEC_API int sec_bn_relu_fwd_nhwc(const void *y, long long pixels, int channels, 
 #define SEC_BN_FWD(T)                                                                                                              \
     hipLaunchKernelGGL((k_bn_partial<T, 0>), dim3(kBnGroups), dim3(256), 0, st, (const T *)y, (const T *)nullptr, pixels, channels, \
                        nullptr, nullptr, nullptr, nullptr, 0, part);                                                               \
-    hipLaunchKernelGGL(k_bn_fwd_finalize, dim3(div_up(channels, 256)), dim3(256), 0, st, part, kBnGroups, channels, pixels, eps,    \
+    hipLaunchKernelGGL(k_bn_fwd_finalize, dim3(div_up(channels, 4)), dim3(256), 0, st, part, kBnGroups, channels, pixels, eps,    \
                        momentum, save_mean, save_invstd, running_mean, running_var);                                               \
     hipLaunchKernelGGL((k_bn_apply<T, 0>), dim3(blocks), dim3(256), 0, st, (const T *)y, (const T *)nullptr, pixels, channels,      \
                        save_mean, save_invstd, gamma, beta, nullptr, nullptr, relu, (T *)z);
@@ -395,7 +414,7 @@ SEC_API int sec_bn_relu_bwd_nhwc(const void *dz, const void *y, long long pixels
 #define SEC_BN_BWD(T)                                                                                                              \
     hipLaunchKernelGGL((k_bn_partial<T, 1>), dim3(kBnGroups), dim3(256), 0, st, (const T *)y, (const T *)dz, pixels, channels,      \
                        save_mean, save_invstd, gamma, beta, relu, part);                                                           \
-    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(div_up(channels, 256)), dim3(256), 0, st, part, kBnGroups, channels, dbeta, dgamma); \
+    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(div_up(channels, 4)), dim3(256), 0, st, part, kBnGroups, channels, dbeta, dgamma); \
     hipLaunchKernelGGL((k_bn_apply<T, 1>), dim3(blocks), dim3(256), 0, st, (const T *)y, (const T *)dz, pixels, channels, save_mean, \
                        save_invstd, gamma, beta, dbeta, dgamma, relu, (T *)dy);
     if (dtype == SEC_BF16) { SEC_BN_BWD(__hip_bfloat16) } else { SEC_BN_BWD(__half) }

@@ -838,12 +838,25 @@ def conv2d_wgrad_supported(cin, cout, ksize, stride, pad, dtype):
     return (cin, cout, ksize, stride, pad) == (128, 128, 3, 1, 1) and dtype in (torch.bfloat16, torch.float16)
 
 
-def bn_relu_forward(y, gamma, beta, eps, momentum, running_mean=None, running_var=None, relu=True):
-    """Training-mode BatchNorm2d + ReLU of a channels_last 16-bit [B,C,H,W] tensor (sec_bn_relu_fwd_nhwc).  gamma / beta fp32 [C];
-    running_mean / running_var (fp32, updated in place) may be None.  -> (z, save_mean, save_invstd)."""
-    rt.require_gpu(y, gamma, beta)
+def _bn_dims(y):
+    if y.dim() == 2:
+        assert y.is_contiguous()
+        return y.shape[0], y.shape[1], 1, 1
     assert y.dim() == 4 and y.is_contiguous(memory_format=torch.channels_last)
-    b, c, h, w = y.shape
+    return tuple(y.shape)
+
+
+def bn_train_supported(channels, dtype):
+    return dtype in (torch.bfloat16, torch.float16) and channels % 8 == 0 and channels <= 256 and 256 % (channels // 8) == 0
+
+
+def bn_relu_forward(y, gamma, beta, eps, momentum, running_mean=None, running_var=None, relu=True):
+    """Training-mode BatchNorm + ReLU of a 16-bit activation whose channels are innermost in memory: a channels_last [B,C,H,W]
+    tensor (BatchNorm2d of the RPN) or the [N,C] feature rows of a sparse tensor (BatchNorm1d of the sparse middle:
+    middle.py:146-189) (sec_bn_relu_fwd_nhwc).  gamma / beta fp32 [C]; running_mean / running_var (fp32, updated in place) may be
+    None.  -> (z, save_mean, save_invstd)."""
+    rt.require_gpu(y, gamma, beta)
+    b, c, h, w = _bn_dims(y)
     for t in (gamma, beta, running_mean, running_var):
         assert t is None or (t.dtype == torch.float32 and t.is_contiguous() and t.numel() == c and t.is_cuda)
     l = rt.lib()
@@ -864,8 +877,8 @@ def bn_relu_backward(dz, y, gamma, beta, save_mean, save_invstd, relu=True):
     """-> (dy, dgamma, dbeta) of :func:`bn_relu_forward` (sec_bn_relu_bwd_nhwc); dz, y channels_last 16-bit."""
     rt.require_gpu(dz, y, gamma, beta, save_mean, save_invstd)
     assert dz.shape == y.shape and dz.dtype == y.dtype
-    assert y.is_contiguous(memory_format=torch.channels_last) and dz.is_contiguous(memory_format=torch.channels_last)
-    b, c, h, w = y.shape
+    b, c, h, w = _bn_dims(y)
+    _bn_dims(dz)
     l = rt.lib()
     ws = rt.workspace(l.sec_bn_train_workspace_bytes(c), y.device)
     dy = torch.empty_like(y)
@@ -933,6 +946,7 @@ class BatchNormReluFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dz):
         y, gamma, beta, mean, invstd = ctx.saved_tensors
-        dy, dgamma, dbeta = bn_relu_backward(dz.contiguous(memory_format=torch.channels_last), y, gamma.detach().float().contiguous(),
+        dz = dz.contiguous() if y.dim() == 2 else dz.contiguous(memory_format=torch.channels_last)
+        dy, dgamma, dbeta = bn_relu_backward(dz, y, gamma.detach().float().contiguous(),
                                              beta.detach().float().contiguous(), mean, invstd, ctx.relu)
         return dy, dgamma.to(gamma.dtype), dbeta.to(beta.dtype), None, None, None, None, None

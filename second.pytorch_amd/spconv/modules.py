@@ -13,6 +13,11 @@ def _is_sparse(m):
     return isinstance(m, SparseModule)
 
 
+def _sec_ops():
+    from second_amd import ops
+    return ops
+
+
 class SparseSequential(SparseModule):
     """nn.Sequential that applies SparseModules to the tensor and plain modules to ``.features``.
 
@@ -32,6 +37,8 @@ class SparseSequential(SparseModule):
                 raise ValueError("name exists.")
             self.add_module(name, module)
         self.fuse_inference = True
+        import os
+        self.fuse_train_bn = os.environ.get("SEC_SPARSE_BN_TRAIN", "hip") == "hip"   # training, 16-bit rows: fused BatchNorm1d + ReLU kernels
         self._fold_cache = {}
 
     def __getitem__(self, idx):
@@ -133,6 +140,18 @@ class SparseSequential(SparseModule):
                 scale, shift = self._folded(m, mods[i + 1])
                 input = m.forward_fused(input, scale, shift, relu)
                 i += 3 if relu else 2
+                continue
+            if (self.fuse_train_bn and isinstance(m, nn.BatchNorm1d) and m.training and m.affine and m.track_running_stats
+                    and isinstance(input, SparseConvTensor) and input.indices.shape[0] != 0 and input.features.is_cuda
+                    and _sec_ops().bn_train_supported(m.num_features, input.features.dtype)):
+                # training with 16-bit features: BatchNorm1d (batch statistics) + ReLU in two passes + a finalize on the rows
+                # (sec_bn_relu_fwd_nhwc / _bwd_nhwc) instead of torch's statistics / transform / ReLU kernels and their backward
+                relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+                mom = m.momentum if m.momentum is not None else 0.1
+                input.features = _sec_ops().BatchNormReluFunction.apply(input.features.contiguous(), m.weight, m.bias, m.running_mean,
+                                                                       m.running_var, m.eps, mom, relu)
+                m.num_batches_tracked += 1
+                i += 2 if relu else 1
                 continue
             if _is_sparse(m):
                 input = m(input)

@@ -261,3 +261,42 @@ def test_first_layer_c4_mfma_kernel(ops, dtype):
     b = ops.indice_conv(f_t, w_t, dev(nbr), n, packed=None, scale=dev(scale), shift=dev(shift), relu=True)
     np.testing.assert_allclose(a.float().cpu().numpy(), ref_f, rtol=tol, atol=tol * np.abs(ref_f).max())
     np.testing.assert_allclose(b.float().cpu().numpy(), ref_f, rtol=tol, atol=tol * np.abs(ref_f).max())
+
+
+def test_conv_rows_are_deterministic_beside_the_rpn_conv(ops, layer):
+    """k_conv_rows_buf / k_conv_rows_m2 keep the packed-fp32 target feature (their fused scale / shift epilogue compiles to
+    v_pk_mul_f32 / v_pk_add_f32) although the rest of the library is built without it: round 2 saw packed fp32 VALU results go
+    wrong in a VALU-heavy kernel (the rotated-NMS clipper) while another wave of the CU ran the RPN conv's MFMA loop
+    (tests/test_gpu_round2.py::test_nms_is_deterministic_beside_the_rpn_conv, tools/pkfp32_repro.py).  The exemption is therefore
+    part of the stress-tested set: the bench launch (fused epilogue, every row-split form) on one stream while two other streams
+    run the RPN conv back to back must return the same bits every time."""
+    dtype = torch.bfloat16
+    rng = np.random.default_rng(21)
+    n = layer["n"]
+    f_t, w_t, _, _ = _operands(rng, n, dtype)
+    scale, shift = dev(rng.uniform(0.5, 1.5, 64).astype(np.float32)), dev(rng.uniform(-0.2, 0.2, 64).astype(np.float32))
+    packed, nbr = ops.pack_weight(w_t), dev(layer["nbr"])
+    x = torch.relu(torch.randn(8, 128, 200, 176, device="cuda")).bfloat16().contiguous(memory_format=torch.channels_last)
+    wc = (torch.randn(128, 128, 3, 3, device="cuda") / 34).bfloat16()
+    pk, bias = ops.conv2d_pack_weight(wc), torch.randn(128, device="cuda")
+    load = [torch.cuda.Stream(), torch.cuda.Stream()]
+    s_conv = torch.cuda.Stream()
+    m_small = 22834                                          # the four-wave form of the mid-size layers
+    for variant, plan in ROW_VARIANTS[:3]:
+        ops.indice_conv_set_variant(-1 if variant is None else variant)
+        first, first_small = None, None
+        for it in range(60):
+            for s in load:
+                with torch.cuda.stream(s):
+                    for _ in range(2):
+                        ops.conv2d_nhwc(x, pk, bias, 128, 3, 1, 1, relu=True)
+            with torch.cuda.stream(s_conv):
+                out = ops.indice_conv(f_t, w_t, nbr, n, packed=packed, scale=scale, shift=shift, relu=True)
+                out_small = ops.indice_conv(f_t, w_t, nbr[:m_small], m_small, packed=packed, scale=scale, shift=shift, relu=True)
+            torch.cuda.synchronize()
+            if first is None:
+                first, first_small = out.clone(), out_small.clone()
+            else:
+                assert torch.equal(out, first), (variant, it)
+                assert torch.equal(out_small, first_small), (variant, it)
+    ops.indice_conv_set_variant(-1)

@@ -184,3 +184,63 @@ def test_device_trainer_step_matches_cpu_chain():
         a, b = gp[n].grad.float().cpu(), cp[n].grad.float()
         rel = (a - b).abs().max().item() / (b.abs().max().item() + 1e-20)
         assert rel < 2e-2, (n, rel)                          # fp32 on both sides; MIOpen vs torch-CPU convolutions, 20 layers deep
+
+
+@pytest.mark.parametrize("c", [16, 32, 64])
+def test_bn_relu_on_sparse_rows_vs_torch(ops, c):
+    """The same kernels on the [N, C] feature rows of a sparse tensor (BatchNorm1d + ReLU of SpMiddleFHD in training, middle.py:146-189)."""
+    g = torch.Generator().manual_seed(c)
+    n = 5003
+    y = (torch.randn(n, c, generator=g) * 3 + 0.5).cuda().bfloat16()
+    gamma, beta = (torch.rand(c, generator=g) + 0.5).cuda(), (torch.randn(c, generator=g) / 4).cuda()
+    rm, rv = torch.zeros(c, device="cuda"), torch.ones(c, device="cuda")
+    y_in = y.clone().requires_grad_()
+    gp, bp = gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+    z = ops.BatchNormReluFunction.apply(y_in, gp, bp, rm, rv, 1e-3, 0.01, True)
+    dz = torch.randn(n, c, generator=g).cuda().bfloat16()
+    z.backward(dz)
+    y32, g32, b32 = y.float().requires_grad_(), gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+    rm2, rv2 = torch.zeros(c, device="cuda"), torch.ones(c, device="cuda")
+    z32 = F.relu(F.batch_norm(y32, rm2, rv2, g32, b32, True, 0.01, 1e-3))
+    z32.backward(dz.float())
+    tol = 2 ** -7
+    torch.testing.assert_close(z.float(), z32.detach(), rtol=tol, atol=tol * z32.abs().max().item())
+    torch.testing.assert_close(rm, rm2, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(rv, rv2, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(gp.grad, g32.grad, rtol=1e-3, atol=1e-3 * g32.grad.abs().max().item())
+    torch.testing.assert_close(bp.grad, b32.grad, rtol=1e-3, atol=1e-3 * b32.grad.abs().max().item())
+    d = (y_in.grad.float() - y32.grad).abs()
+    assert (d > tol * y32.grad.abs().max().item() + tol * y32.grad.abs()).float().mean().item() < 1e-3
+
+
+def test_device_trainer_bf16_step_uses_the_hand_written_path_and_tracks_fp32():
+    """One bf16 training step (sparse stack + RPN on the hand-written forward / dgrad / wgrad / BatchNorm kernels) next to the
+    fp32 step of the same network on the same frames: the six loss scalars within a few percent, every parameter receives a finite
+    gradient, the op trace shows the hand-written RPN convolution (not MIOpen) in the step."""
+    from second_amd import ops, synthetic as syn
+    from second_amd.models import SecondDetector, CAR_FHD
+    from second_amd.training import DeviceTrainer
+    clouds = [syn.syn_kitti_cloud(s) for s in range(2)]
+    pts, offs = syn.batch_clouds(clouds)
+    gt = np.concatenate([syn.syn_kitti_boxes(s, 12) for s in range(2)]).astype(np.float32)
+    goffs = np.array([0, 12, 24], np.int32)
+    d = lambda a: torch.from_numpy(a).cuda()
+    torch.manual_seed(0)
+    a = SecondDetector(CAR_FHD).cuda()
+    b = SecondDetector(CAR_FHD).cuda()
+    b.load_state_dict(a.state_dict())
+    t32, t16 = DeviceTrainer(a), DeviceTrainer(b, amp_dtype=torch.bfloat16)
+    l32, o32, _ = t32.forward_loss(d(pts), d(offs), d(gt), d(goffs))
+    l32.backward()
+    seen = []
+    ops.set_op_hook(lambda name, fn, args, kw, res: seen.append(name))
+    try:
+        l16, o16, _ = t16.forward_loss(d(pts), d(offs), d(gt), d(goffs))
+        l16.backward()
+    finally:
+        ops.set_op_hook(None)
+    assert seen.count("conv2d_nhwc") >= 12, seen.count("conv2d_nhwc")      # 6 forward + 6 data-gradient launches of the 3x3 kernel
+    np.testing.assert_allclose(o16.float().cpu().numpy(), o32.cpu().numpy(), rtol=0.05, atol=1e-3)
+    for (n, p), (_, q) in zip(b.named_parameters(), a.named_parameters()):
+        assert p.grad is not None and torch.isfinite(p.grad).all(), n
+        assert q.grad is not None, n
