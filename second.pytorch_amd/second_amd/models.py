@@ -365,7 +365,9 @@ def rpn_forward_mixed(rpn, x, dtype):
     gradient on k_conv2d_halo_reg, weight gradient on k_conv2d_wgrad3x3, BatchNorm (batch statistics) + ReLU fused
     (ops.Conv3x3Function / ops.BatchNormReluFunction; rpn.py:486-497 trained by train.py:316-322); anything else (strided or
     other-width convs, the deblocks, the 1x1 heads) stays on torch under autocast.  SEC_RPN_TRAIN_BACKEND=miopen: all of it on torch
-    (the round-2 path, for A/B runs).  Same arithmetic as RPNV2.forward up to 16-bit rounding of the activations."""
+    (the round-2 path, for A/B runs).  Same arithmetic as RPNV2.forward up to 16-bit rounding of the activations.  (autocast's
+    weight-cast cache is off: the function is captured into hipGraphs by DeviceTrainer, and a cached cast made during capture
+    would be stale on replay.)"""
     use_hip = os.environ.get("SEC_RPN_TRAIN_BACKEND", "hip") == "hip" and x.is_cuda
     x = x.to(dtype).contiguous(memory_format=torch.channels_last)
 
@@ -391,7 +393,7 @@ def rpn_forward_mixed(rpn, x, dtype):
                 bn.num_batches_tracked += 1
                 i, pad = i + 3, 0
                 continue
-            with torch.autocast("cuda", dtype=dtype, enabled=x.is_cuda):
+            with torch.autocast("cuda", dtype=dtype, enabled=x.is_cuda, cache_enabled=False):
                 if pad:
                     x = F.pad(x, (pad, pad, pad, pad))
                     pad = 0
@@ -402,9 +404,9 @@ def rpn_forward_mixed(rpn, x, dtype):
     for i, blk in enumerate(rpn.blocks):
         x = run_block(blk, x)
         if i - rpn._upsample_start_idx >= 0:
-            with torch.autocast("cuda", dtype=dtype, enabled=x.is_cuda):
+            with torch.autocast("cuda", dtype=dtype, enabled=x.is_cuda, cache_enabled=False):
                 ups.append(rpn.deblocks[i - rpn._upsample_start_idx](x))
-    with torch.autocast("cuda", dtype=dtype, enabled=x.is_cuda):
+    with torch.autocast("cuda", dtype=dtype, enabled=x.is_cuda, cache_enabled=False):
         if ups:
             x = torch.cat(ups, dim=1) if len(ups) > 1 else ups[0]
         a = rpn._num_anchor_per_loc

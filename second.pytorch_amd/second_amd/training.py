@@ -61,6 +61,7 @@ class DeviceTrainer:
         # fp16 features need loss scaling (5 exponent bits: head gradients are O(1 / num_pos / batch)); bf16 / fp32 do not
         self.loss_scale = float(init_loss_scale) if amp_dtype == torch.float16 else None
         self._good_steps, self.skipped_steps = 0, 0
+        self._graphed_rpn = None
         self.steps = 0
         self.last = {}
 
@@ -88,13 +89,65 @@ class DeviceTrainer:
             # under autocast, through the dense RPN; BatchNorm statistics and the loss in fp32
             spatial = det.middle_feature_extractor(vox["mean"].to(self.amp_dtype), vox["coordinates"], batch,
                                                    site_table=vox.get("site_table"))
-            from .models import rpn_forward_mixed
-            preds = rpn_forward_mixed(det.rpn, spatial, self.amp_dtype)   # 3x3 convs + BatchNorm/ReLU on the hand-written kernels
+            preds = self._rpn_mixed(spatial)                  # 3x3 convs + BatchNorm/ReLU on the hand-written kernels
         else:
             preds = det.network_forward(vox["mean"], vox["coordinates"], batch, site_table=vox.get("site_table"))
         loss, out6 = ops.SecondLossFunction.apply(preds["cls_preds"], preds["box_preds"], preds.get("dir_cls_preds"), labels,
                                                   reg_targets, det.anchors, importance, self.loss_cfg)
         return loss, out6, labels
+
+    def _rpn_mixed(self, spatial):
+        """The dense part of the step has static shapes ([B, 128, H, W] whatever the clouds hold), ~100 launches forward + backward,
+        and the eager step is HOST bound (541 launches at ~14 us each = 7.6 ms for 4.9 ms of kernels, profiles/r03_e_*): its
+        forward and backward are therefore captured once as two hipGraphs (torch.cuda.make_graphed_callables over the same
+        rpn_forward_mixed) and replayed.  SEC_TRAIN_GRAPH_RPN=0, a changed input shape or a failed capture fall back to eager."""
+        import os
+        from .models import rpn_forward_mixed
+        x = spatial.to(self.amp_dtype).contiguous(memory_format=torch.channels_last)
+        if os.environ.get("SEC_TRAIN_GRAPH_RPN", "1") != "1" or not x.is_cuda:
+            return rpn_forward_mixed(self.det.rpn, x, self.amp_dtype)
+        key = (tuple(x.shape), x.dtype)
+        if self._graphed_rpn is None or self._graphed_rpn[0] != key:
+            self._graphed_rpn = (key, self._capture_rpn(x))
+        fn = self._graphed_rpn[1]
+        if fn is None:
+            return rpn_forward_mixed(self.det.rpn, x, self.amp_dtype)
+        if not x.requires_grad:
+            x = x.detach().requires_grad_()
+        box, cls, dirp = fn(x)
+        out = {"box_preds": box, "cls_preds": cls}
+        if dirp.numel():
+            out["dir_cls_preds"] = dirp
+        return out
+
+    def _capture_rpn(self, x):
+        from .models import rpn_forward_mixed
+        rpn, dt = self.det.rpn, self.amp_dtype
+
+        class _Mixed(torch.nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.rpn = rpn
+
+            def forward(self, inp):
+                p = rpn_forward_mixed(self.rpn, inp, dt)
+                return p["box_preds"], p["cls_preds"], p.get("dir_cls_preds", p["cls_preds"].new_zeros(0))
+        # the warm-up iterations of the capture run BatchNorm in training mode: keep the running statistics out of it
+        saved = {k: v.clone() for k, v in rpn.state_dict().items() if "running_" in k or "num_batches" in k}
+        try:
+            sample = x.detach().clone().requires_grad_()
+            fn = torch.cuda.make_graphed_callables(_Mixed(), (sample,))
+        except Exception as e:  # noqa: BLE001 -- capture is an optimisation: the eager path is always correct
+            import warnings
+            warnings.warn(f"second_amd: hipGraph capture of the RPN training segment failed ({e!r}); running it eagerly")
+            fn = None
+        with torch.no_grad():
+            sd = rpn.state_dict()
+            for k, v in saved.items():
+                sd[k].copy_(v)
+        for p in rpn.parameters():
+            p.grad = None
+        return fn
 
     def step(self, points, point_offsets, gt_boxes, gt_offsets, gt_classes=None):
         """One optimisation step on this rank's shard; returns the device tensor of the six loss scalars (no host sync,

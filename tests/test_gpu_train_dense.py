@@ -244,3 +244,38 @@ def test_device_trainer_bf16_step_uses_the_hand_written_path_and_tracks_fp32():
     for (n, p), (_, q) in zip(b.named_parameters(), a.named_parameters()):
         assert p.grad is not None and torch.isfinite(p.grad).all(), n
         assert q.grad is not None, n
+
+
+def test_device_trainer_graphed_rpn_segment_equals_eager(monkeypatch):
+    """DeviceTrainer captures the static-shape RPN segment of the bf16 step (forward and backward) into hipGraphs: three steps with
+    the capture and three without, from the same initial state on the same frames, must agree -- losses of every step and the
+    parameters afterwards (bf16 path both ways: same kernels, same order; only the launch mechanism differs)."""
+    from second_amd import synthetic as syn
+    from second_amd.models import SecondDetector, CAR_FHD
+    from second_amd.training import DeviceTrainer
+    clouds = [syn.syn_kitti_cloud(s) for s in range(2)]
+    pts, offs = syn.batch_clouds(clouds)
+    gt = np.concatenate([syn.syn_kitti_boxes(s, 12) for s in range(2)]).astype(np.float32)
+    goffs = np.array([0, 12, 24], np.int32)
+    d = lambda a: torch.from_numpy(a).cuda()
+    torch.manual_seed(0)
+    init = SecondDetector(CAR_FHD).state_dict()
+    results = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SEC_TRAIN_GRAPH_RPN", mode)
+        det = SecondDetector(CAR_FHD)
+        det.load_state_dict(init)
+        tr = DeviceTrainer(det.cuda(), amp_dtype=torch.bfloat16)
+        losses = [tr.step(d(pts), d(offs), d(gt), d(goffs)).clone() for _ in range(3)]
+        torch.cuda.synchronize()
+        if mode == "1":
+            assert tr._graphed_rpn is not None and tr._graphed_rpn[1] is not None, "the capture fell back to eager"
+        results[mode] = (torch.stack(losses).cpu(), {k: v.detach().float().cpu() for k, v in det.state_dict().items()})
+    la, lb = results["1"][0], results["0"][0]
+    torch.testing.assert_close(la, lb, rtol=2e-3, atol=1e-5)
+    for k, v in results["1"][1].items():
+        w = results["0"][1][k]
+        if v.is_floating_point() and v.numel():
+            assert (v - w).abs().max().item() <= 2e-3 * (w.abs().max().item() + 1e-6) + 1e-6, k
+        else:
+            assert torch.equal(v, w), k
