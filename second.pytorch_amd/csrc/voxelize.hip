@@ -188,7 +188,15 @@ __global__ __launch_bounds__(kBlock) void k_vox_cascade(const int *__restrict__ 
     atomicAdd(&count[vid], 1);
     int v = i;
     int *row = slot_idx + (size_t)vid * p.max_points;
+    // Slot values only ever DECREASE, so a relaxed peek that already shows a smaller index than the one in hand is final for this
+    // thread: the atomicMin there would change nothing and hand back something smaller (v stays), and a LAST slot that is already
+    // smaller means max_points smaller indices exist -- this point cannot be among the first max_points of its voxel at all.
+    // With 60-point pillars (nuscenes/all.pp.largea: a near pillar collects hundreds of points) the late points used to walk all 60
+    // positions with returning device-scope atomics -- 1.8 ms of the 2.7 ms step; a stale (larger) peek only costs the atomic it
+    // would have saved.
+    if (__hip_atomic_load(&row[p.max_points - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < v) return;
     for (int t = 0; t < p.max_points; ++t) {
+        if (__hip_atomic_load(&row[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < v) continue;
         int old = atomicMin(&row[t], v);
         if (old == kEmptyI32) break;
         v = old > v ? old : v;
