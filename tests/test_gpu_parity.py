@@ -79,6 +79,21 @@ def test_voxelize_batched_ragged_and_edge_cases(ops, golden, syn):
     _check_voxelize(ops, [dense.astype(np.float32)], vs, rng_, 60, 1000, "break")
 
 
+def test_voxelize_pillars_sorted_slot_path(ops, syn):
+    """max_points > 8 takes the stable-sort slot assignment (csrc/voxelize.hip: k_vox_sort_keys -> radix sort -> run starts ->
+    slots) instead of the atomicMin cascade: nuScenes-size pillar clouds (0.25 m pillars, 60 points each, hundreds of points in the
+    pillars near the sensor), a ragged batch with an empty cloud, the voxel cap hit and not hit, both cap modes -- voxel order,
+    slot order, counts and contents bit-exact against the sequential oracle loop (pointpillars: all.pp.largea.config:6-15)."""
+    rng_ = [-50, -50, -10, 50, 50, 10]
+    vs = [0.25, 0.25, 20]
+    clouds = [syn.syn_nusc_cloud(0, 120000, tuple(rng_), scene="urban"), np.zeros((0, 4), np.float32),
+              syn.syn_nusc_cloud(1, 40000, tuple(rng_), scene="urban")]
+    for cap_mode in ("break", "continue"):
+        for max_points, max_voxels in ((60, 30000), (60, 4000), (9, 30000)):
+            res = _check_voxelize(ops, clouds, vs, rng_, max_points, max_voxels, cap_mode)
+    assert int(res["num_points_per_voxel"].max()) == 9 and res["voxel_num"] > 15000
+
+
 def test_voxelize_car_fhd_batch8(ops, syn):
     clouds = [syn.syn_kitti_cloud(s) for s in range(8)]
     res = _check_voxelize(ops, clouds, syn.CAR_FHD_VOXEL, syn.CAR_FHD_RANGE, 5, 40000, "break")
