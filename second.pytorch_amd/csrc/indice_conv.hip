@@ -585,6 +585,7 @@ __device__ __forceinline__ void rows_stage_affine(float *aff, const float *__res
 // gathers because vmcnt retires in order), 8 ds_read_b128 and 8 MFMAs: ~35 instructions.  WAVES = 8 makes the workgroup 256
 // rows, so one copy of W[k] per CU and step instead of two.
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+constexpr int kBalWgs = 256;                                 // one workgroup per CU of an MI355X (FL bit 11, below)
 // FL bit 0: the tile's 32 x KVOL neighbour table arrives as four coalesced 16-byte loads per lane staged through LDS (instead
 //           of KVOL strided dword loads per lane, each a 32-cache-line gather: 27 x 8 waves of them kept the CU's address
 //           pipe busy for ~5000 clocks before the first offset);
@@ -645,9 +646,23 @@ SEC_PACKED_F32_OK __global__ __launch_bounds__(WAVES * 64, MINW) void k_conv_row
     if (num_out_dev) n_out = *num_out_dev;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
-    if ((long long)blockIdx.x * (32 * WAVES) >= n_out) return;
-    const long long row = (long long)blockIdx.x * (32 * WAVES) + w * 32 + r;
-    const bool valid = row < n_out;
+    // FL bit 11 (BAL): rows per wave chosen so that the launch fills every CU once.  The subm2 stage of car.fhd at batch 8 is 56 298 rows
+    // = 220 workgroups of 256 rows for 256 CUs -- 36 CUs idle while the others each push their 590 KB through a ~13 B/clk/CU fill path,
+    // which is what the launch time is made of (round 3: a software-pipelined one-wave-per-SIMD form of the same loop, k_conv_rows_m2,
+    // lands on the same 21-22 us).  With 28 rows per wave instead of 32 the same rows make 252 workgroups: every CU busy, 12 % less per
+    // CU; the 23 k-row stage goes from 179 four-wave workgroups to 238 of 96 rows.  Lanes r >= rw of the 32-row MFMA tile gather
+    // nothing (out-of-range offsets) and store nothing.  rw is a multiple of 4 (16-byte table pieces) computed from the DEVICE-side row
+    // count; the host launches max(ceil(capacity / (32 * WAVES)), kBalWgs) workgroups, the surplus ones exit here.
+    constexpr bool BAL = (FL & 2048) != 0;
+    int rw = 32;
+    if constexpr (BAL) {
+        const int per_wg = (n_out + kBalWgs - 1) / kBalWgs;
+        rw = ((per_wg + WAVES - 1) / WAVES + 3) & ~3;
+        rw = rw < 4 ? 4 : (rw > 32 ? 32 : rw);
+    }
+    if ((long long)blockIdx.x * (rw * WAVES) >= n_out) return;
+    const long long row = (long long)blockIdx.x * (rw * WAVES) + w * rw + r;
+    const bool valid = row < n_out && r < rw;
     SEC_RTL(long long *tl = g_timeline; long long tl0 = 0, tl1 = 0, tl2 = 0; if (tl) tl0 = clock64();)
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(feat), 0, (int)feat_bytes, 0x00020000);
     const int piece0 = (w * NBW) % C::BPIECES;           // waves beyond the last piece re-copy one (identical bytes, same slot)
@@ -655,7 +670,7 @@ SEC_PACKED_F32_OK __global__ __launch_bounds__(WAVES * 64, MINW) void k_conv_row
     // byte offset of this lane's first 16-byte chunk of every neighbour row; no neighbour -> beyond the buffer -> zeros
     unsigned off[KVOL];
     if constexpr (STAGE) {
-        const long long tile_row0 = (long long)blockIdx.x * (32 * WAVES) + w * 32;
+        const long long tile_row0 = (long long)blockIdx.x * (rw * WAVES) + w * rw;   // (32 rows are staged whatever rw is)
         const long long tbl_bytes = (long long)n_cap * KVOL * 4;
         const int *tile = nbr + tile_row0 * KVOL;
         // bytes of the table from this tile on: <= 0 for the waves of the last workgroup that start beyond the table (a table
@@ -905,7 +920,9 @@ template <typename T, int CIN, int COUT, int DIST, int WAVES, int MINW, int FL, 
 static void launch_rows_buf(const void *feat, long long n_feat, const void *packed, const int *nbr, int n_out, const int *num_out_dev,
                             const float *scale, const float *shift, int relu, void *out, hipStream_t st) {
     set_last_kernel("k_conv_rows_buf<%s, %d, %d, %d, %d, %d, %d, %d>", dtype_name<T>(), CIN, COUT, KVOL, DIST, WAVES, MINW, FL);
-    hipLaunchKernelGGL((k_conv_rows_buf<T, CIN, COUT, KVOL, DIST, WAVES, MINW, FL>), dim3(div_up(n_out, 32 * WAVES)), dim3(WAVES * 64), 0, st,
+    int blocks = div_up(n_out, 32 * WAVES);
+    if ((FL & 2048) != 0 && blocks < kBalWgs) blocks = kBalWgs;      // BAL: the kernel spreads the rows over up to kBalWgs workgroups
+    hipLaunchKernelGGL((k_conv_rows_buf<T, CIN, COUT, KVOL, DIST, WAVES, MINW, FL>), dim3(blocks), dim3(WAVES * 64), 0, st,
                        (const T *)feat, n_feat * CIN * (long long)sizeof(T), (const T *)packed, nbr, n_out, num_out_dev, scale, shift,
                        relu, (T *)out);
 }
@@ -1165,6 +1182,11 @@ static int m2_auto() {
     if (v < 0) { const char *e = getenv("SEC_CONV_M2"); v = e ? atoi(e) : 0; }
     return v;
 }
+static bool rows_balance() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("SEC_CONV_BAL"); v = e ? atoi(e) : 1; }
+    return v != 0;
+}
 static bool buf_shape(int cin, int cout, int kvol) {
     if (kvol == 3) return cin == 64 && cout == 64;
     if (kvol != 27) return false;
@@ -1246,8 +1268,10 @@ static void launch_mfma(const void *feat, long long n_feat, const void *packed, 
                     }
                 }
 #endif
+                // FL + 2048 (BAL): rows per wave chosen on the device so that the launch fills every CU once (SEC_CONV_BAL=0: fixed 32)
+                const bool bal = rows_balance();
                 // 16- and 32-channel layers: the whole weight tensor lives in LDS, no per-offset barrier (-13 .. -24 % per layer)
-                if constexpr (CIN <= 32 && COUT <= 32) { SEC_BUF(6, 8, 3 + 64, 27); }
+                if constexpr (CIN <= 32 && COUT <= 32) { if (bal) { SEC_BUF(6, 8, 3 + 64 + 2048, 27); } else { SEC_BUF(6, 8, 3 + 64, 27); } }
                 else if constexpr (CIN == 64 && COUT == 64) {
 #define SEC_BUFM(D, W, M, FLG) launch_rows_buf<T, CIN, COUT, D, W, M, FLG, 27>(feat, n_feat, packed, nbr, n_out, num_out_dev, scale, shift, relu, out, st)
                     // prefetch distance 3, B fragments not double-buffered, neighbour offsets re-read from the staged table (FL 1 + 128):
@@ -1257,12 +1281,15 @@ static void launch_mfma(const void *feat, long long n_feat, const void *packed, 
                     // + one barrier per three offsets (FL 512, six-slot weight ring): 23.5 -> 22.1 us stand-alone
                     if (n_out < rows_min() && conv_variant() == 1) {      // mid-size layers: 128-row workgroups
                         if (rows_footprint() == 4) { SEC_BUF(4, 4, 3, 27); }          // the form with a barrier per offset (13.3 vs 12.65 us)
+                        else if (bal) { SEC_BUFM(3, 4, 3, 1 + 128 + 512 + 2048); }
                         else { SEC_BUFM(3, 4, 3, 1 + 128 + 512); }
                     } else if (rows_footprint() == 1) { SEC_BUF(4, 8, 3, 27); }
                     else if (rows_footprint() == 3) { SEC_BUFM(3, 8, 3, 1 + 128); }
+                    else if (bal) { SEC_BUFM(3, 8, 3, 1 + 128 + 512 + 2048); }
                     else { SEC_BUFM(3, 8, 3, 1 + 128 + 512); }
 #undef SEC_BUFM
-                } else { SEC_BUF(4, 8, 3, 27); }
+                } else if (bal) { SEC_BUF(4, 8, 3 + 2048, 27); }
+                else { SEC_BUF(4, 8, 3, 27); }
                 return;
             }
 #undef SEC_BUF

@@ -213,8 +213,7 @@ constexpr int kCascadeMaxPoints = 8;       // up to here the cascade wins (car.f
 
 __global__ __launch_bounds__(kBlock) void k_vox_sort_keys(const int *__restrict__ offs, const int *__restrict__ pslot,
                                                          const int *__restrict__ svid, const int *__restrict__ break_idx, VoxParams p,
-                                                         unsigned invalid_key, int *__restrict__ count, unsigned *__restrict__ key,
-                                                         int *__restrict__ val) {
+                                                         unsigned invalid_key, unsigned *__restrict__ key, int *__restrict__ val) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= p.num_points) return;
     unsigned k = invalid_key;
@@ -223,10 +222,7 @@ __global__ __launch_bounds__(kBlock) void k_vox_sort_keys(const int *__restrict_
         const int vid = svid[s];
         bool ok = vid >= 0;
         if (ok && p.cap_mode == 0) ok = i < break_idx[frame_of(offs, p.batch, i)];
-        if (ok) {
-            k = (unsigned)vid;
-            atomicAdd(&count[vid], 1);
-        }
+        if (ok) k = (unsigned)vid;
     }
     key[i] = k;
     val[i] = i;
@@ -242,13 +238,14 @@ __global__ __launch_bounds__(kBlock) void k_vox_run_starts(const unsigned *__res
 
 __global__ __launch_bounds__(kBlock) void k_vox_sorted_slots(const unsigned *__restrict__ skey, const int *__restrict__ sval, int n,
                                                             unsigned invalid_key, const int *__restrict__ run_start, int max_points,
-                                                            int *__restrict__ slot_idx) {
+                                                            int *__restrict__ slot_idx, int *__restrict__ count) {
     const int j = blockIdx.x * kBlock + threadIdx.x;
     if (j >= n) return;
     const unsigned k = skey[j];
     if (k == invalid_key) return;
     const int t = j - run_start[k];
     if (t < max_points) slot_idx[(size_t)k * max_points + t] = sval[j];
+    if (j == n - 1 || skey[j + 1] != k) count[k] = t + 1;       // the run's last point knows the voxel's point count: no atomics
 }
 
 __global__ __launch_bounds__(kBlock) void k_vox_fill(const float *__restrict__ points,
@@ -412,13 +409,13 @@ SEC_API int sec_voxelize_f32(const float *points, const int *point_offsets, int 
         if (w.sort_tmp) {
             const unsigned invalid_key = (unsigned)batch * (unsigned)max_voxels;
             hipLaunchKernelGGL(k_vox_sort_keys, dim3(nb), dim3(kBlock), 0, st, point_offsets, w.pslot, w.svid, w.break_idx, p,
-                               invalid_key, w.count, w.skey_in, w.sval_in);
+                               invalid_key, w.skey_in, w.sval_in);
             if ((rc = vox_sort_pairs(w.sort_tmp, w.sort_tmp_bytes, w.skey_in, w.skey_out, w.sval_in, w.sval_out, num_points,
                                      w.sort_bits, st)))
                 return rc;
             hipLaunchKernelGGL(k_vox_run_starts, dim3(nb), dim3(kBlock), 0, st, w.skey_out, num_points, invalid_key, w.run_start);
             hipLaunchKernelGGL(k_vox_sorted_slots, dim3(nb), dim3(kBlock), 0, st, w.skey_out, w.sval_out, num_points, invalid_key,
-                               w.run_start, max_points, w.slot_idx);
+                               w.run_start, max_points, w.slot_idx, w.count);
         } else {
             hipLaunchKernelGGL(k_vox_cascade, dim3(nb), dim3(kBlock), 0, st, point_offsets, w.pslot, w.svid,
                                w.break_idx, p, w.count, w.slot_idx);
