@@ -59,14 +59,15 @@ const char *sec_last_kernel_name(void);
  *   voxels [batch*max_voxels, max_points, num_features] (zero padded), coors [.,4] = (b,z,y,x),
  *   num_points_per_voxel [.], voxel_offsets [batch+1];
  *   mean (optional, may be NULL) [., mean_features] = SimpleVoxel.forward
- *   (second/pytorch/models/voxel_encoder.py:220-225) fused as an epilogue.
+ *   (second/pytorch/models/voxel_encoder.py:220-225) fused as an epilogue, stored as mean_dtype (SEC_F32, or the 16-bit
+ *   dtype of the sparse stack that consumes it: the reference's `.to(dtype)` of example_convert_to_torch, train.py:36-38).
  * --------------------------------------------------------------------------------------------- */
 size_t sec_voxelize_workspace_bytes(int num_points, int batch, int max_voxels, int max_points);
 int sec_voxelize_f32(const float *points, const int *point_offsets, int num_points, int num_features,
                      int batch, const float *h_range6, const float *h_voxel_size3, int max_points,
                      int max_voxels, int cap_mode, float *voxels, int *coors,
-                     int *num_points_per_voxel, int *voxel_offsets, float *mean, int mean_features,
-                     void *workspace, size_t workspace_bytes, void *stream);
+                     int *num_points_per_voxel, int *voxel_offsets, void *mean, int mean_features,
+                     int mean_dtype, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Rulebooks -- replace spconv.ops.get_indice_pairs (torch.ops.spconv.get_indice_pairs; CPU oracle

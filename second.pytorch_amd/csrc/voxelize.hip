@@ -14,6 +14,7 @@
 //       ends up holding the (t+1)-th smallest index regardless of interleaving)
 //   4. voxel-major fill (coalesced stores) + optional SimpleVoxel mean epilogue.
 #include "common.hpp"
+#include <type_traits>
 
 namespace sec {
 
@@ -271,12 +272,14 @@ __global__ __launch_bounds__(kBlock) void k_vox_fill(const float *__restrict__ p
     }
 }
 
-// SimpleVoxel.forward (second/pytorch/models/voxel_encoder.py:220-225): sum over slots / num_points
+// SimpleVoxel.forward (second/pytorch/models/voxel_encoder.py:220-225): sum over slots / num_points; stored as fp32 or, for a
+// 16-bit sparse stack, directly in its dtype (the cast torch ran as two extra kernels inside every captured step)
+template <typename OT>
 __global__ __launch_bounds__(kBlock) void k_vox_mean(const float *__restrict__ voxels,
                                                     const int *__restrict__ voxel_offsets,
                                                     const int *__restrict__ num_points_per_voxel,
                                                     VoxParams p, int mean_features,
-                                                    float *__restrict__ mean) {
+                                                    OT *__restrict__ mean) {
     long long g = (long long)blockIdx.x * kBlock + threadIdx.x;  // (vid, f)
     int vid = (int)(g / mean_features);
     int f = (int)(g % mean_features);
@@ -284,7 +287,10 @@ __global__ __launch_bounds__(kBlock) void k_vox_mean(const float *__restrict__ v
     const float *src = voxels + (size_t)vid * p.max_points * p.num_features + f;
     float s = 0.0f;
     for (int t = 0; t < p.max_points; ++t) s = __fadd_rn(s, src[(size_t)t * p.num_features]);
-    mean[g] = __fdiv_rn(s, (float)num_points_per_voxel[vid]);
+    const float m = __fdiv_rn(s, (float)num_points_per_voxel[vid]);
+    if constexpr (std::is_same<OT, float>::value) mean[g] = m;
+    else if constexpr (std::is_same<OT, __half>::value) mean[g] = __float2half_rn(m);
+    else mean[g] = __float2bfloat16(m);
 }
 
 struct VoxWorkspace {
@@ -362,11 +368,11 @@ SEC_API int sec_voxelize_f32(const float *points, const int *point_offsets, int 
                              int num_features, int batch, const float *h_range6,
                              const float *h_voxel_size3, int max_points, int max_voxels, int cap_mode,
                              float *voxels, int *coors, int *num_points_per_voxel, int *voxel_offsets,
-                             float *mean, int mean_features, void *workspace, size_t workspace_bytes,
+                             void *mean, int mean_features, int mean_dtype, void *workspace, size_t workspace_bytes,
                              void *stream) {
     if (num_points < 0 || num_features < 3 || batch <= 0 || max_points <= 0 || max_voxels <= 0 ||
         !h_range6 || !h_voxel_size3 || !voxels || !coors || !num_points_per_voxel || !voxel_offsets ||
-        (mean && (mean_features <= 0 || mean_features > num_features)))
+        (mean && (mean_features <= 0 || mean_features > num_features || mean_dtype < SEC_F32 || mean_dtype > SEC_BF16)))
         return SEC_E_INVALID;
     hipStream_t st = (hipStream_t)stream;
     VoxWorkspace w = carve_vox(workspace, workspace_bytes, num_points, batch, max_voxels, max_points);
@@ -426,9 +432,16 @@ SEC_API int sec_voxelize_f32(const float *points, const int *point_offsets, int 
     if (bound > 0) {
         hipLaunchKernelGGL(k_vox_fill, dim3(div_up(bound * max_points, kBlock)), dim3(kBlock), 0, st, points,
                            voxel_offsets, w.count, w.slot_idx, p, voxels, num_points_per_voxel);
-        if (mean)
-            hipLaunchKernelGGL(k_vox_mean, dim3(div_up(bound * mean_features, kBlock)), dim3(kBlock), 0, st,
-                               voxels, voxel_offsets, num_points_per_voxel, p, mean_features, mean);
+        if (mean) {
+            const dim3 gm(div_up(bound * mean_features, kBlock));
+            if (mean_dtype == SEC_F32)
+                hipLaunchKernelGGL(k_vox_mean<float>, gm, dim3(kBlock), 0, st, voxels, voxel_offsets, num_points_per_voxel, p, mean_features, (float *)mean);
+            else if (mean_dtype == SEC_F16)
+                hipLaunchKernelGGL(k_vox_mean<__half>, gm, dim3(kBlock), 0, st, voxels, voxel_offsets, num_points_per_voxel, p, mean_features, (__half *)mean);
+            else
+                hipLaunchKernelGGL(k_vox_mean<__hip_bfloat16>, gm, dim3(kBlock), 0, st, voxels, voxel_offsets, num_points_per_voxel, p, mean_features,
+                                   (__hip_bfloat16 *)mean);
+        }
     }
     return check_launch();
 }

@@ -727,10 +727,11 @@ class SecondDetector(nn.Module):
             preds = self.network_forward(feats, vox["coordinates"], batch_size, num_active_dev=nd)
             return self.predict_device(preds, batch_size)
         if not static:
-            vox = self.voxel_generator.generate_device(points, point_offsets, mean_features=nf)
+            vox = self.voxel_generator.generate_device(points, point_offsets, mean_features=nf, mean_dtype=self._infer_dtype)
             preds = self.network_forward(vox["mean"], vox["coordinates"], batch_size, site_table=vox.get("site_table"))
         else:
-            vox = self.voxel_generator.generate_device(points, point_offsets, mean_features=nf, sync=False)
+            # (the voxel means are stored in the sparse stack's dtype by the voxeliser itself: no cast launch inside the captured step)
+            vox = self.voxel_generator.generate_device(points, point_offsets, mean_features=nf, sync=False, mean_dtype=self._infer_dtype)
             preds = self.network_forward(vox["mean"], vox["coordinates"], batch_size,
                                          num_active_dev=vox["voxel_offsets"][batch_size:], site_table=vox.get("site_table"))
         return self.predict_device(preds, batch_size)

@@ -44,7 +44,7 @@ def _traced(name):
 # ----------------------------------------------------------------------------- voxelisation
 @_traced("voxelize")
 def voxelize(points, point_offsets, point_cloud_range, voxel_size, max_points, max_voxels,
-             cap_mode="break", mean_features=0, sync=True):
+             cap_mode="break", mean_features=0, sync=True, mean_dtype=None):
     """Batched points_to_voxel (spconv VoxelGeneratorV2.generate; second/data/preprocess.py:301-316).
 
     points [N,F] float32 cuda (clouds concatenated), point_offsets [B+1] int32 cuda.
@@ -64,14 +64,15 @@ def voxelize(points, point_offsets, point_cloud_range, voxel_size, max_points, m
     coors = torch.empty((rows, 4), dtype=torch.int32, device=dev)
     npv = torch.empty((rows,), dtype=torch.int32, device=dev)
     voff = torch.empty((batch + 1,), dtype=torch.int32, device=dev)
-    mean = torch.empty((rows, mean_features), dtype=torch.float32, device=dev) if mean_features else None
+    mean_dtype = mean_dtype or torch.float32      # SimpleVoxel's output in the dtype of the stack that consumes it (no cast launch)
+    mean = torch.empty((rows, mean_features), dtype=mean_dtype, device=dev) if mean_features else None
     l = rt.lib()
     ws_bytes = l.sec_voxelize_workspace_bytes(n, batch, max_voxels, max_points)
     ws = rt.workspace(ws_bytes, dev)
     rc = l.sec_voxelize_f32(rt.ptr(points), rt.ptr(point_offsets), n, f, batch, rt.f_arr(point_cloud_range),
                             rt.f_arr(voxel_size), int(max_points), int(max_voxels),
                             {"break": 0, "continue": 1}[cap_mode], rt.ptr(voxels), rt.ptr(coors), rt.ptr(npv),
-                            rt.ptr(voff), rt.ptr(mean), int(mean_features), rt.ptr(ws), ws.numel(), rt.stream())
+                            rt.ptr(voff), rt.ptr(mean), int(mean_features), rt.dtype_code(mean_dtype), rt.ptr(ws), ws.numel(), rt.stream())
     rt.check(rc, "sec_voxelize_f32")
     out = {"voxels": voxels, "coordinates": coors, "num_points_per_voxel": npv, "voxel_offsets": voff}
     # the hash table this call leaves in its workspace (cell -> voxel row) is the site lookup of the first SubM rulebook

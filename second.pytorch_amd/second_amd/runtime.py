@@ -61,7 +61,7 @@ def lib():
         l.sec_conv_output_shape.restype = None
         vp, ci, cf, sz, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_int64
         l.sec_voxelize_workspace_bytes.argtypes = [ci, ci, ci, ci]
-        l.sec_voxelize_f32.argtypes = [vp, vp, ci, ci, ci, vp, vp, ci, ci, ci, vp, vp, vp, vp, vp, ci, vp, sz, vp]
+        l.sec_voxelize_f32.argtypes = [vp, vp, ci, ci, ci, vp, vp, ci, ci, ci, vp, vp, vp, vp, vp, ci, ci, vp, sz, vp]
         l.sec_rulebook_workspace_bytes.argtypes = [ci, ci, ci]
         l.sec_rulebook_subm3d.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, sz, vp]
         l.sec_rulebook_subm3d_after_conv.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp, vp, sz, ci, vp, vp, vp, ci, vp]

@@ -76,7 +76,8 @@ class DeviceTrainer:
         det, cfg = self.det, self.cfg
         batch = point_offsets.numel() - 1
         with torch.no_grad():
-            vox = det.voxel_generator.generate_device(points, point_offsets, mean_features=cfg["num_point_features"])
+            vox = det.voxel_generator.generate_device(points, point_offsets, mean_features=cfg["num_point_features"],
+                                                      mean_dtype=self.amp_dtype)
             if self.class_ranges is None:
                 labels, reg_targets, importance = ops.assign_targets(det.anchors, gt_boxes, gt_offsets, *self.thresholds,
                                                                      gt_classes=gt_classes)

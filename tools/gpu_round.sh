@@ -13,7 +13,9 @@ fi
 timeout 600 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
 cut -c1-400 $O/bench.json
 timeout 600 python tools/bf16_error_trace.py > $O/bf16_error_trace.txt 2>&1; echo "trace rc=$?"; tail -32 $O/bf16_error_trace.txt
-SERIES_OUT=$O/power_series.json timeout 300 python tools/rpn_yardstick.py > $O/rpn_yardstick.txt 2>&1; echo "yardstick rc=$?"; cat $O/rpn_yardstick.txt | cut -c1-330
+if [ "$3" == "yardstick" ]; then
+  SERIES_OUT=$O/power_series.json timeout 300 python tools/rpn_yardstick.py > $O/rpn_yardstick.txt 2>&1; echo "yardstick rc=$?"; cat $O/rpn_yardstick.txt | cut -c1-330
+fi
 cd /tmp; export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof1 -- python $R/bench.py --steps 50 --warmup 10 --inflight 1 --no-kernel-table --no-cpu-baseline --no-extra-lines > $O/prof1.log 2>&1
 cd $R
