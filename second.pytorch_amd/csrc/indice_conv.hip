@@ -768,6 +768,10 @@ SEC_PACKED_F32_OK __global__ __launch_bounds__(WAVES * 64, MINW) void k_conv_row
     auto off_of = [&](int k) -> unsigned {
         if constexpr (LAZY) {
             const int t = valid ? lazy_tbl[k] : -1;
+#ifdef SEC_CONV_ABLATIONS
+            if constexpr ((FL & 4) != 0) return 0x80000000u;                                  // no gather touches memory
+            if constexpr ((FL & 16) != 0) return t >= 0 ? (unsigned)(h * 16) : 0x80000000u;   // all gathers hit one row
+#endif
             return t >= 0 ? (unsigned)t * ROWB + h * 16 : 0x80000000u;
         } else {
             return off[k];
@@ -938,7 +942,7 @@ static void launch_rows_buf(const void *feat, long long n_feat, const void *pack
 // k + DIST that refill the registers the 4 MFMAs just consumed (sched_group_barrier keeps that interleaving).  The four accumulator
 // chains are independent, so the matrix pipe sees back-to-back issue; one workgroup barrier per three offsets (six-slot weight ring, as
 // in the WIN3 form above).  Gathers, zero rows, epilogue: as in k_conv_rows_buf.
-template <typename T, int DIST>
+template <typename T, int DIST, int ABL = 0>      // ABL (timing-only, -DSEC_CONV_ABLATIONS): 1 = no gather touches memory, 2 = all gathers hit one row
 SEC_PACKED_F32_OK __global__ __launch_bounds__(256, 1) void k_conv_rows_m2(const T *__restrict__ feat, long long feat_bytes,
                                                                            const T *__restrict__ packed, const int *__restrict__ nbr,
                                                                            int n_out, const int *__restrict__ num_out_dev,
@@ -990,7 +994,11 @@ SEC_PACKED_F32_OK __global__ __launch_bounds__(256, 1) void k_conv_rows_m2(const
     // byte offset of this lane's 16-byte chunk of neighbour row t; no neighbour (t < 0) -> beyond the buffer -> the load returns zeros
     // without touching memory.  Rows past n_out read whatever the table holds there (zeros past its end): their gathers stay inside the
     // buffer's bounds check and their results are never stored, so no `valid` test (it compiled into an exec-mask branch per read).
-    auto off_of = [&](int t) -> unsigned { return t >= 0 ? (unsigned)t * ROWB + h * 16 : 0x80000000u; };
+    auto off_of = [&](int t) -> unsigned {
+        if constexpr (ABL == 1) return 0x80000000u;
+        if constexpr (ABL == 2) return t >= 0 ? (unsigned)(h * 16) : 0x80000000u;
+        return t >= 0 ? (unsigned)t * ROWB + h * 16 : 0x80000000u;
+    };
 #define SEC_M2_WLOAD(g)                                                                                               \
     {                                                                                                                 \
         _Pragma("unroll") for (int j_ = 0; j_ < 3; ++j_)                                                              \
@@ -1065,10 +1073,22 @@ SEC_PACKED_F32_OK __global__ __launch_bounds__(256, 1) void k_conv_rows_m2(const
     rows_store<T, COUT>(acc[1], out, row1, valid1, h, aff, scale != nullptr, shift != nullptr, relu);
 }
 
+static int conv_variant();
 template <typename T>
 static void launch_rows_m2(const void *feat, long long n_feat, const void *packed, const int *nbr, int n_out, const int *num_out_dev,
                            const float *scale, const float *shift, int relu, void *out, hipStream_t st) {
     set_last_kernel("k_conv_rows_m2<%s, 3>", dtype_name<T>());
+#ifdef SEC_CONV_ABLATIONS
+    if (conv_variant() == 42 || conv_variant() == 43) {
+        if (conv_variant() == 42)
+            hipLaunchKernelGGL((k_conv_rows_m2<T, 3, 1>), dim3(div_up(n_out, 256)), dim3(256), 0, st, (const T *)feat,
+                               n_feat * 64 * (long long)sizeof(T), (const T *)packed, nbr, n_out, num_out_dev, scale, shift, relu, (T *)out);
+        else
+            hipLaunchKernelGGL((k_conv_rows_m2<T, 3, 2>), dim3(div_up(n_out, 256)), dim3(256), 0, st, (const T *)feat,
+                               n_feat * 64 * (long long)sizeof(T), (const T *)packed, nbr, n_out, num_out_dev, scale, shift, relu, (T *)out);
+        return;
+    }
+#endif
     hipLaunchKernelGGL((k_conv_rows_m2<T, 3>), dim3(div_up(n_out, 256)), dim3(256), 0, st, (const T *)feat,
                        n_feat * 64 * (long long)sizeof(T), (const T *)packed, nbr, n_out, num_out_dev, scale, shift, relu, (T *)out);
 }
@@ -1198,9 +1218,9 @@ static int rows_plan(int cin, int cout, int kvol, int n_out, bool same_dtype) {
     if (!same_dtype) return 0;
     const int v = conv_variant();
     if (buf_shape(cin, cout, kvol)) {
-        if (cin == 64 && cout == 64 && kvol == 27 && (v == 41 || (v == 1 && m2_auto() && n_out >= rows_min())))
+        if (cin == 64 && cout == 64 && kvol == 27 && (v == 41 || v == 42 || v == 43 || (v == 1 && m2_auto() && n_out >= rows_min())))
             return PLAN_ROWS_M2;                                                           // two row tiles per wave (round 3)
-        if (v == 22 || (v >= 16 && v <= 28 && cin == 64 && cout == 64 && kvol == 27)) return PLAN_ROWS_BUF;
+        if (v == 22 || (((v >= 16 && v <= 28) || v == 44 || v == 45) && cin == 64 && cout == 64 && kvol == 27)) return PLAN_ROWS_BUF;
         if (v >= 36 && v <= 40) return PLAN_ROWS_BUF;
         if (v == 1 && n_out >= rows_min()) return PLAN_ROWS_BUF;
         // 64 -> 64, 27 offsets, 8 k .. 40 k rows (the 23 k-row stage of car.fhd at batch 8): four-wave workgroups (128 rows) fill the
@@ -1263,6 +1283,8 @@ static void launch_mfma(const void *feat, long long n_feat, const void *packed, 
                     case 24: SEC_BUF(4, 8, 3 + 4, 27); return;
                     case 25: SEC_BUF(4, 8, 3 + 8, 27); return;
                     case 26: SEC_BUF(4, 8, 3 + 16, 27); return;
+                    case 44: launch_rows_buf<T, CIN, COUT, 3, 8, 3, 1 + 128 + 512 + 4, 27>(feat, n_feat, packed, nbr, n_out, num_out_dev, scale, shift, relu, out, st); return;
+                    case 45: launch_rows_buf<T, CIN, COUT, 3, 8, 3, 1 + 128 + 512 + 16, 27>(feat, n_feat, packed, nbr, n_out, num_out_dev, scale, shift, relu, out, st); return;
 #endif
                     default: break;
                     }
