@@ -17,7 +17,7 @@ PLAN_ROWS_BUF = 11
 # (variant number, expected plan id): None = the automatic choice, 22 = the same kernel forced.  A library built with
 # -DSEC_CONV_EXPERIMENTS also carries the superseded row-split forms (9-15: LDS-DMA / register-direct gathers) and the A/B forms of
 # the buffer-load kernel (16-21, 23, 27, 28); they are run through the same comparisons when present.
-ROW_VARIANTS = [(None, 11), (22, 11), (41, 13)]      # 41 = two row tiles per wave (k_conv_rows_m2, plan 13)
+ROW_VARIANTS = [(None, 11), (22, 11), (41, 13), (46, 14)]      # 41 = two row tiles per wave (k_conv_rows_m2, plan 13); 46 = input planes staged in LDS (k_conv_rows_lds, plan 14: on these first-touch-ordered rows its windows mostly MISS -- the exact fallback)
 EXPERIMENT_VARIANTS = [(9, 6), (10, 7), (11, 8), (12, 9), (13, 10), (14, 10), (15, 10), (16, 11), (17, 11), (18, 11), (19, 11),
                        (20, 11), (21, 11), (23, 11), (27, 11), (28, 11)]
 
@@ -300,3 +300,52 @@ def test_conv_rows_are_deterministic_beside_the_rpn_conv(ops, layer):
                 assert torch.equal(out, first), (variant, it)
                 assert torch.equal(out_small, first_small), (variant, it)
     ops.indice_conv_set_variant(-1)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_conv_rows_lds_windows_hit_on_sorted_rows(ops, layer, dtype):
+    """k_conv_rows_lds takes its operands from LDS windows of consecutive input rows; they only fill when the rows are in ascending
+    cell order (the device fast path's sorted numbering).  The bench layer relabelled into that order -- same sites, same pairs --
+    must give the oracle's result bit for bit on integer operands (window hits, window overflows and global fallbacks all mix
+    in one launch), within one rounding on Gaussian operands with the fused epilogue, and the same bits with the ragged tail cut."""
+    idx, shape, n = layer["idx"], layer["shape"], layer["n"]
+    lin = ((idx[:, 0].astype(np.int64) * shape[0] + idx[:, 1]) * shape[1] + idx[:, 2]) * shape[2] + idx[:, 3]
+    perm = np.argsort(lin, kind="stable")                    # new row j = old row perm[j]
+    inv = np.empty(n, np.int64)
+    inv[perm] = np.arange(n)
+    old = layer["nbr"][perm]
+    nbr = np.where(old >= 0, inv[np.maximum(old, 0)], -1).astype(np.int32)
+    assert np.all(np.diff(lin[perm]) > 0)
+    pairs = -np.ones((27, 2, n), np.int32)
+    pair_num = np.zeros(27, np.int32)
+    for k in range(27):
+        o = np.nonzero(nbr[:, k] >= 0)[0]
+        pairs[k, 0, :len(o)], pairs[k, 1, :len(o)], pair_num[k] = nbr[o, k], o, len(o)
+    rng = np.random.default_rng(17)
+    feat = rng.integers(-1, 2, (n, 64)).astype(np.float32)
+    dens = 0.04 if dtype == torch.bfloat16 else 0.5
+    w = (rng.integers(-1, 2, (3, 3, 3, 64, 64)) * (rng.random((3, 3, 3, 64, 64)) < dens)).astype(np.float32)
+    ref = orc.indice_conv(feat, w, pairs, pair_num, n, acc64=True)
+    f_t, w_t = dev(feat, dtype), dev(w, dtype)
+    packed = ops.pack_weight(w_t)
+    ops.indice_conv_set_variant(46)
+    try:
+        assert ops.indice_conv_plan(64, 64, 27, n, dtype) == 14
+        out = ops.indice_conv(f_t, w_t, dev(nbr), n, packed=packed)
+        np.testing.assert_array_equal(out.float().cpu().numpy(), ref)
+        m = n - (n % 256) - 255                              # ragged: the last workgroup holds one row
+        out = ops.indice_conv(f_t, w_t, dev(nbr[:m]), m, packed=packed)
+        np.testing.assert_array_equal(out.float().cpu().numpy(), ref[:m])
+        table = dev(np.concatenate([nbr[:m], np.full((512, 27), 0x3fffffff, np.int32)]))
+        out = ops.indice_conv(f_t, w_t, table, m + 512, packed=packed, num_out_dev=dev(np.array([m], np.int32)))
+        np.testing.assert_array_equal(out[:m].float().cpu().numpy(), ref[:m])
+        # Gaussian operands + fused epilogue
+        f_g, w_g, f_np, w_np = _operands(rng, n, dtype)
+        refg = orc.indice_conv(f_np, w_np, pairs, pair_num, n, acc64=True)
+        scale, shift = rng.uniform(0.5, 1.5, 64).astype(np.float32), rng.uniform(-0.2, 0.2, 64).astype(np.float32)
+        ref_f = torch.from_numpy(np.maximum(refg * scale + shift, 0)).to(dtype).float().numpy()
+        out = ops.indice_conv(f_g, w_g, dev(nbr), n, packed=ops.pack_weight(w_g), scale=dev(scale), shift=dev(shift), relu=True)
+        tol = _tol(dtype)
+        np.testing.assert_allclose(out.float().cpu().numpy(), ref_f, rtol=tol, atol=tol * np.abs(ref_f).max())
+    finally:
+        ops.indice_conv_set_variant(-1)

@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--layer", default="subm2")
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--sorted", action="store_true", help="spatially sorted clouds (rows in (z,y,x) order per frame)")
+    ap.add_argument("--sorted-numbering", action="store_true", help="strided rulebooks in spconv's GPU numbering (ascending cell order): what the device fast path runs")
     ap.add_argument("--timeline", action="store_true", help="per-wave clock64 timeline of the row-split kernels (with --variants; needs a build with SEC_EXTRA_HIPCC_FLAGS=-DSEC_CONV_TIMELINE)")
     ap.add_argument("--variants", default="", help="comma list of SEC_CONV_VARIANT numbers timed back to back in this process (each checked against split-K)")
     ap.add_argument("--repeat", type=int, default=1)
@@ -93,6 +94,8 @@ def main():
     ap.add_argument("--all-layers", action="store_true", help="every conv layer of SpMiddleFHD at batch 8, each --variants entry per layer")
     args = ap.parse_args()
     dev = torch.device("cuda")
+    if args.sorted_numbering:
+        ops.set_rulebook_numbering("sorted")
     if args.all_layers:
         return all_layers(args, dev)
     clouds = [syn.syn_kitti_cloud(s) for s in range(args.batch)]
