@@ -931,378 +931,9 @@ static void launch_rows_buf(const void *feat, long long n_feat, const void *pack
                        relu, (T *)out);
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// Row-split kernel, TWO 32-row tiles per wave (SEC_CONV_VARIANT 41; round 3).  What round 2 left on the table for the 64 -> 64
-// layers: at batch 8 the subm2 stage is 220 workgroups of 256 rows -- ONE workgroup per CU, every workgroup resident at once -- so a
-// launch is one workgroup life of 27 offset steps, and a step cost ~1350 clocks for 256 clocks of MFMA per wave: two waves per SIMD
-// that each read the full 8 KB W[k] from LDS, leave every barrier together and queue for the same matrix pipe.  Here a wave owns 64
-// rows (tiles r and 32 + r): ONE wave per SIMD (four per workgroup, still 256 rows), each B fragment read from LDS feeds two MFMAs,
-// and the step is software-pipelined INSIDE the wave instead of across waves: per 16-channel k-step s the wave issues 4 MFMAs
-// (two tiles x two 32-column halves), the two ds_read_b128 of offset k+1's fragments for that k-step, and the two gathers of offset
-// k + DIST that refill the registers the 4 MFMAs just consumed (sched_group_barrier keeps that interleaving).  The four accumulator
-// chains are independent, so the matrix pipe sees back-to-back issue; one workgroup barrier per three offsets (six-slot weight ring, as
-// in the WIN3 form above).  Gathers, zero rows, epilogue: as in k_conv_rows_buf.
-template <typename T, int DIST, int ABL = 0>      // ABL (timing-only, -DSEC_CONV_ABLATIONS): 1 = no gather touches memory, 2 = all gathers hit one row
-SEC_PACKED_F32_OK __global__ __launch_bounds__(256, 1) void k_conv_rows_m2(const T *__restrict__ feat, long long feat_bytes,
-                                                                           const T *__restrict__ packed, const int *__restrict__ nbr,
-                                                                           int n_out, const int *__restrict__ num_out_dev,
-                                                                           const float *__restrict__ scale, const float *__restrict__ shift,
-                                                                           int relu, T *__restrict__ out) {
-    constexpr int CIN = 64, COUT = 64, KVOL = 27, WAVES = 4, RPW = 64;
-    using C = RowsCfg<T, CIN, COUT>;                       // KS = 4 k-steps, NT = 2 column tiles, BPIECES = 8, BSLOT = 512
-    constexpr int NBW = C::BPIECES / WAVES;                // 1 KB weight pieces per wave and offset (2)
-    constexpr int ROWB = CIN * (int)sizeof(T);
-    constexpr int TBL16 = RPW * KVOL / 4;                  // 16-byte pieces of one wave's 64 x 27 neighbour table (432)
-    static_assert(DIST == 3, "the gather registers of offset k are refilled for offset k + 3");
-    __shared__ __attribute__((aligned(16))) uint4 bring[6][C::BSLOT];
-    __shared__ __attribute__((aligned(16))) float aff[2 * COUT];
-    __shared__ __attribute__((aligned(16))) u32x4_t stage[WAVES][TBL16];
-    rows_stage_affine<COUT>(aff, scale, shift);
-    const int n_cap = n_out;
-    if (num_out_dev) n_out = *num_out_dev;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    if ((long long)blockIdx.x * (RPW * WAVES) >= n_out) return;
-    const long long tile_row0 = (long long)blockIdx.x * (RPW * WAVES) + w * RPW;
-    const long long row0 = tile_row0 + r, row1 = tile_row0 + 32 + r;
-    const bool valid0 = row0 < n_out, valid1 = row1 < n_out;
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(feat), 0, (int)feat_bytes, 0x00020000);
-    const u32x4_t *wpv = reinterpret_cast<const u32x4_t *>(packed) + (size_t)(w * NBW) * 64 + lane;
-    {   // the wave's 64 x 27 neighbour table: coalesced 16-byte loads (bounded by the table's end), staged in LDS
-        const long long left = (long long)n_cap * KVOL * 4 - tile_row0 * KVOL * 4;
-        const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<int *>(left > 0 ? nbr + tile_row0 * KVOL : nbr), 0,
-            (int)(left <= 0 ? 0 : (left < RPW * KVOL * 4 ? left : RPW * KVOL * 4)), 0x00020000);
-#pragma unroll
-        for (int i = 0; i < (TBL16 + 63) / 64; ++i) {
-            const int p16 = i * 64 + lane;
-            if (p16 < TBL16) stage[w][p16] = __builtin_amdgcn_raw_buffer_load_b128(trs, p16 * 16, 0, 0);
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-    const int *tbl0 = reinterpret_cast<const int *>(&stage[w][0]) + r * KVOL, *tbl1 = tbl0 + 32 * KVOL;
-    f32x16 acc[2][C::NT];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int t = 0; t < C::NT; ++t)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[m][t][i] = 0.0f;
-    u32x4_t areg[DIST][2][C::KS];
-    u32x4_t ww[3][NBW];
-    u32x4_t *bslot = reinterpret_cast<u32x4_t *>(&bring[0][(w * NBW) * 64 + lane]);
-    // byte offset of this lane's 16-byte chunk of neighbour row t; no neighbour (t < 0) -> beyond the buffer -> the load returns zeros
-    // without touching memory.  Rows past n_out read whatever the table holds there (zeros past its end): their gathers stay inside the
-    // buffer's bounds check and their results are never stored, so no `valid` test (it compiled into an exec-mask branch per read).
-    auto off_of = [&](int t) -> unsigned {
-        if constexpr (ABL == 1) return 0x80000000u;
-        if constexpr (ABL == 2) return t >= 0 ? (unsigned)(h * 16) : 0x80000000u;
-        return t >= 0 ? (unsigned)t * ROWB + h * 16 : 0x80000000u;
-    };
-#define SEC_M2_WLOAD(g)                                                                                               \
-    {                                                                                                                 \
-        _Pragma("unroll") for (int j_ = 0; j_ < 3; ++j_)                                                              \
-            _Pragma("unroll") for (int p_ = 0; p_ < NBW; ++p_) ww[j_][p_] = wpv[(size_t)(3 * (g) + j_) * C::BSLOT + p_ * 64]; \
-    }
-#define SEC_M2_WSTORE(g)                                                                                              \
-    {                                                                                                                 \
-        _Pragma("unroll") for (int j_ = 0; j_ < 3; ++j_)                                                              \
-            _Pragma("unroll") for (int p_ = 0; p_ < NBW; ++p_) bslot[((((g) & 1) * 3) + j_) * C::BSLOT + p_ * 64] = ww[j_][p_]; \
-    }
-    SEC_M2_WLOAD(0)
-    unsigned o0[DIST], o1[DIST];
-#pragma unroll
-    for (int k = 0; k < DIST; ++k) {
-        o0[k] = off_of(tbl0[k]);
-        o1[k] = off_of(tbl1[k]);
-#pragma unroll
-        for (int s2 = 0; s2 < C::KS; ++s2) {
-            areg[k][0][s2] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o0[k] + 32 * s2, 0, 0);
-            areg[k][1][s2] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o1[k] + 32 * s2, 0, 0);
-        }
-    }
-    SEC_M2_WSTORE(0)
-    SEC_M2_WLOAD(1)
-    uint4 bf[2][C::KS * C::NT];
-    int tq0 = tbl0[DIST], tq1 = tbl1[DIST];                  // table entries of the NEXT fetch, read one step ahead of their use
-#pragma unroll
-    for (int g = 0; g < KVOL / 3; ++g) {
-        __syncthreads();                                     // W of window g is visible; every wave has left the other half of the ring
-#pragma unroll
-        for (int i = 0; i < C::KS * C::NT; ++i) bf[0][i] = bring[(g & 1) * 3][i * 64 + lane];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int k = 3 * g + j;
-            const int cur = j & 1, nxt = cur ^ 1;
-            const unsigned n0 = off_of(tq0), n1 = off_of(tq1);   // rows gathered for offset k + DIST during this step
-            if (k + 1 + DIST < KVOL) {                        // (their LDS reads were issued a step ago; these are next step's)
-                tq0 = tbl0[k + 1 + DIST];
-                tq1 = tbl1[k + 1 + DIST];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int s2 = 0; s2 < C::KS; ++s2) {
-                const uint4 a0 = __builtin_bit_cast(uint4, areg[k % DIST][0][s2]), a1 = __builtin_bit_cast(uint4, areg[k % DIST][1][s2]);
-#pragma unroll
-                for (int t = 0; t < C::NT; ++t) {
-                    acc[0][t] = Mfma<T>::run(bf[cur][s2 * C::NT + t], a0, acc[0][t]);   // D^T: weights first
-                    acc[1][t] = Mfma<T>::run(bf[cur][s2 * C::NT + t], a1, acc[1][t]);
-                }
-                if (j < 2) {                                 // the next offset of this window: its fragments for k-step s2
-#pragma unroll
-                    for (int t = 0; t < C::NT; ++t) bf[nxt][s2 * C::NT + t] = bring[(g & 1) * 3 + j + 1][(s2 * C::NT + t) * 64 + lane];
-                }
-                if (k + DIST < KVOL) {                       // refill the gather registers the four MFMAs above just read
-                    areg[k % DIST][0][s2] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, n0 + 32 * s2, 0, 0);
-                    areg[k % DIST][1][s2] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, n1 + 32 * s2, 0, 0);
-                }
-                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);      // 4 MFMA
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // 2 DS reads
-                __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);      // 2 VMEM reads
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (g + 1 < KVOL / 3) {
-            SEC_M2_WSTORE(g + 1)
-            if (g + 2 < KVOL / 3) SEC_M2_WLOAD(g + 2)
-        }
-    }
-#undef SEC_M2_WLOAD
-#undef SEC_M2_WSTORE
-    rows_store<T, COUT>(acc[0], out, row0, valid0, h, aff, scale != nullptr, shift != nullptr, relu);
-    rows_store<T, COUT>(acc[1], out, row1, valid1, h, aff, scale != nullptr, shift != nullptr, relu);
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// Row-split kernel with the INPUT rows of two of the three kernel planes staged in LDS (SEC_CONV_VARIANT 46 / the automatic choice
-// for SubM 64 -> 64 layers whose rows are in ascending cell order; round 3).  The ablations of the forms above
-// (profiles/r03_l_ablations_subm2.txt) put 7-11 us of the 20-22 us launch on the gathers themselves -- every (output row, offset)
-// pair pulls its 128-byte input row through the texture path and the L2, 88 MB per launch for 7.2 MB of distinct rows -- and 11 us on
-// everything else.  With the sorted numbering of the device fast path the rows are in ascending cell order, so the neighbours a
-// workgroup's 256 consecutive output rows have in ONE kernel plane (fixed dz: nine offsets) form a near-contiguous run of input rows
-// that starts at the smallest neighbour index of that plane.  The workgroup copies CAP = 320 rows from that start (coalesced 16-byte
-// loads -> registers -> LDS, chunk index XOR row & 7 against bank conflicts) while the previous plane is being multiplied, and a
-// lane then takes its operand from LDS when its neighbour lies in the window and from memory when it does not: BOTH reads are issued
-// for every fragment -- the gather with an out-of-range offset (zeros, no memory access) for lanes served by LDS, the LDS read of a
-// zero row for the others -- and OR-ed, so there is no branch and no assumption about the data: any row order, any window overflow
-// stays exact, only slower.  Plane 0 (offsets 0..8) is gathered as before while plane 1's window is in flight.  Otherwise the loop
-// is k_conv_rows_m2's (two row tiles per wave, one wave per SIMD, in-wave software pipeline, one barrier per three offsets).
-template <typename T>
-SEC_PACKED_F32_OK __global__ __launch_bounds__(256, 1) void k_conv_rows_lds(const T *__restrict__ feat, long long feat_bytes,
-                                                                            const T *__restrict__ packed, const int *__restrict__ nbr,
-                                                                            int n_out, const int *__restrict__ num_out_dev,
-                                                                            const float *__restrict__ scale, const float *__restrict__ shift,
-                                                                            int relu, T *__restrict__ out) {
-    constexpr int CIN = 64, COUT = 64, KVOL = 27, WAVES = 4, RPW = 64, DIST = 3, CAP = 320, NST = CAP * 8 / 256;
-    using C = RowsCfg<T, CIN, COUT>;                       // KS = 4 k-steps, NT = 2 column tiles, BPIECES = 8, BSLOT = 512
-    constexpr int NBW = C::BPIECES / WAVES;
-    constexpr int ROWB = CIN * (int)sizeof(T);
-    constexpr int TBL16 = RPW * KVOL / 4;
-    constexpr int ZIDX = 2 * CAP * 8;                      // uint4 index of the zero row behind the two plane windows
-    static_assert(ROWB == 128, "a feature row is eight 16-byte chunks");
-    __shared__ __attribute__((aligned(16))) uint4 bring[6][C::BSLOT];
-    __shared__ __attribute__((aligned(16))) float aff[2 * COUT];
-    __shared__ __attribute__((aligned(16))) u32x4_t stage[WAVES][TBL16];
-    __shared__ __attribute__((aligned(16))) uint4 inp[2 * CAP * 8 + 8];
-    __shared__ int plo[3];
-    rows_stage_affine<COUT>(aff, scale, shift);
-    const int n_cap = n_out;
-    if (num_out_dev) n_out = *num_out_dev;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    if ((long long)blockIdx.x * (RPW * WAVES) >= n_out) return;
-    const long long tile_row0 = (long long)blockIdx.x * (RPW * WAVES) + w * RPW;
-    const long long row0 = tile_row0 + r, row1 = tile_row0 + 32 + r;
-    const bool valid0 = row0 < n_out, valid1 = row1 < n_out;
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(feat), 0, (int)feat_bytes, 0x00020000);
-    const u32x4_t *wpv = reinterpret_cast<const u32x4_t *>(packed) + (size_t)(w * NBW) * 64 + lane;
-    if (tid < 3) plo[tid] = 0x7fffffff;
-    if (tid < 8) inp[ZIDX + tid] = make_uint4(0, 0, 0, 0);
-    {
-        const long long left = (long long)n_cap * KVOL * 4 - tile_row0 * KVOL * 4;
-        const __amdgpu_buffer_rsrc_t trs = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<int *>(left > 0 ? nbr + tile_row0 * KVOL : nbr), 0,
-            (int)(left <= 0 ? 0 : (left < RPW * KVOL * 4 ? left : RPW * KVOL * 4)), 0x00020000);
-#pragma unroll
-        for (int i = 0; i < (TBL16 + 63) / 64; ++i) {
-            const int p16 = i * 64 + lane;
-            if (p16 < TBL16) stage[w][p16] = __builtin_amdgcn_raw_buffer_load_b128(trs, p16 * 16, 0, 0);
-        }
-    }
-    __syncthreads();                                         // tables staged, plo initialised
-    const int *tbl0 = reinterpret_cast<const int *>(&stage[w][0]) + r * KVOL, *tbl1 = tbl0 + 32 * KVOL;
-    {   // smallest neighbour index of planes 1 and 2 over the workgroup's rows (rows past n_out hold no promise: excluded)
-#pragma unroll
-        for (int p = 1; p < 3; ++p) {
-            int m = 0x7fffffff;
-#pragma unroll
-            for (int k = 9 * p; k < 9 * p + 9; ++k) {
-                const int t0 = valid0 ? tbl0[k] : -1, t1 = valid1 ? tbl1[k] : -1;
-                m = (t0 >= 0 && t0 < m) ? t0 : m;
-                m = (t1 >= 0 && t1 < m) ? t1 : m;
-            }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const int q = __shfl_xor(m, o, 64);
-                m = q < m ? q : m;
-            }
-            if (lane == 0 && m != 0x7fffffff) atomicMin(&plo[p], m);
-        }
-    }
-    __syncthreads();
-    const int lo1 = plo[1], lo2 = plo[2];
-    // window copies: thread tid moves chunk (tid & 7) of rows (i * 32 + tid / 8), i = 0 .. NST-1, of a plane's window
-    u32x4_t pst[NST];
-    auto plane_load = [&](int lo) {
-        if (lo != 0x7fffffff) {
-#pragma unroll
-            for (int i = 0; i < NST; ++i)
-                pst[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (unsigned)(lo + i * 32 + (tid >> 3)) * ROWB + (tid & 7) * 16, 0, 0);
-        }
-    };
-    auto plane_store = [&](int lo, int buf) {
-        if (lo != 0x7fffffff) {
-#pragma unroll
-            for (int i = 0; i < NST; ++i) {
-                const int u = i * 32 + (tid >> 3);
-                inp[buf * CAP * 8 + u * 8 + ((tid & 7) ^ (u & 7))] = __builtin_bit_cast(uint4, pst[i]);
-            }
-        }
-    };
-    plane_load(lo1);                                         // in flight under plane 0; stored at the end of window 1
-    f32x16 acc[2][C::NT];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int t = 0; t < C::NT; ++t)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[m][t][i] = 0.0f;
-    u32x4_t areg[DIST][2][C::KS];
-    uint4 alds[2][2][C::KS];
-    u32x4_t ww[3][NBW];
-    u32x4_t *bslot = reinterpret_cast<u32x4_t *>(&bring[0][(w * NBW) * 64 + lane]);
-    // (k < 9: plane 0, never staged) gather offset of neighbour row t for offset k: out of range when there is no neighbour or when the
-    // row sits in the plane's LDS window
-    auto goff = [&](int t, int k) -> unsigned {
-        const int lo = k < 9 ? 0x7fffffff : (k < 18 ? lo1 : lo2);
-        const bool in = k >= 9 && (unsigned)(t - lo) < (unsigned)CAP;
-        return (t >= 0 && !in) ? (unsigned)t * ROWB + h * 16 : 0x80000000u;
-    };
-    // LDS reads of the four k-step fragments of neighbour row t for offset k (k >= 9): from the plane's window, or the zero row
-    auto lds_a = [&](uint4 (&dst)[C::KS], int t, int k) {
-        const int lo = k < 18 ? lo1 : lo2;
-        const unsigned u = (unsigned)(t - lo);
-        const bool in = t >= 0 && u < (unsigned)CAP;
-        const int base = (((k / 9) & 1) ? CAP * 8 : 0) + (int)u * 8, key = (int)(u & 7);     // plane 1 -> buffer 1, plane 2 -> buffer 0
-#pragma unroll
-        for (int s2 = 0; s2 < C::KS; ++s2) dst[s2] = inp[in ? base + ((s2 * 2 + h) ^ key) : ZIDX + (lane & 7)];
-    };
-#define SEC_L_WLOAD(g)                                                                                                \
-    {                                                                                                                 \
-        _Pragma("unroll") for (int j_ = 0; j_ < 3; ++j_)                                                              \
-            _Pragma("unroll") for (int p_ = 0; p_ < NBW; ++p_) ww[j_][p_] = wpv[(size_t)(3 * (g) + j_) * C::BSLOT + p_ * 64]; \
-    }
-#define SEC_L_WSTORE(g)                                                                                               \
-    {                                                                                                                 \
-        _Pragma("unroll") for (int j_ = 0; j_ < 3; ++j_)                                                              \
-            _Pragma("unroll") for (int p_ = 0; p_ < NBW; ++p_) bslot[((((g) & 1) * 3) + j_) * C::BSLOT + p_ * 64] = ww[j_][p_]; \
-    }
-    SEC_L_WLOAD(0)
-    int te0[5], te1[5];                                      // table entries of offsets k .. k+4 (ring indexed by offset % 5)
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { te0[k] = tbl0[k]; te1[k] = tbl1[k]; }
-#pragma unroll
-    for (int k = 0; k < DIST; ++k) {
-        const unsigned a = goff(te0[k], k), b = goff(te1[k], k);
-#pragma unroll
-        for (int s2 = 0; s2 < C::KS; ++s2) {
-            areg[k][0][s2] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, a + 32 * s2, 0, 0);
-            areg[k][1][s2] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, b + 32 * s2, 0, 0);
-        }
-    }
-    SEC_L_WSTORE(0)
-    SEC_L_WLOAD(1)
-    uint4 bf[2][C::KS * C::NT];
-#pragma unroll
-    for (int g = 0; g < KVOL / 3; ++g) {
-        __syncthreads();                                     // W of window g visible; plane windows stored two windows ago visible
-        if (g == 3) plane_load(lo2);                         // plane 0's buffer is free from here on (plane 2 lands there at the end of window 4)
-#pragma unroll
-        for (int i = 0; i < C::KS * C::NT; ++i) bf[0][i] = bring[(g & 1) * 3][i * 64 + lane];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int k = 3 * g + j;
-            const int cur = j & 1, nxt = cur ^ 1;
-            const unsigned n0 = k + DIST < KVOL ? goff(te0[(k + 3) % 5], k + 3) : 0x80000000u;
-            const unsigned n1 = k + DIST < KVOL ? goff(te1[(k + 3) % 5], k + 3) : 0x80000000u;
-            if (k + 4 < KVOL) {                               // next step's gather offsets: their table entries, one step ahead
-                te0[(k + 4) % 5] = tbl0[k + 4];
-                te1[(k + 4) % 5] = tbl1[k + 4];
-            }
-            if (k + 1 >= 9 && k + 1 < KVOL) {                 // LDS half of offset k + 1's operands (its window is visible: stored >= 2 barriers ago)
-                lds_a(alds[(k + 1) & 1][0], te0[(k + 1) % 5], k + 1);
-                lds_a(alds[(k + 1) & 1][1], te1[(k + 1) % 5], k + 1);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int s2 = 0; s2 < C::KS; ++s2) {
-                uint4 a0 = __builtin_bit_cast(uint4, areg[k % DIST][0][s2]), a1 = __builtin_bit_cast(uint4, areg[k % DIST][1][s2]);
-                if (k >= 9) {                                  // exactly one of the two sources is non-zero per lane
-                    const uint4 l0 = alds[k & 1][0][s2], l1 = alds[k & 1][1][s2];
-                    a0 = make_uint4(a0.x | l0.x, a0.y | l0.y, a0.z | l0.z, a0.w | l0.w);
-                    a1 = make_uint4(a1.x | l1.x, a1.y | l1.y, a1.z | l1.z, a1.w | l1.w);
-                }
-#pragma unroll
-                for (int t = 0; t < C::NT; ++t) {
-                    acc[0][t] = Mfma<T>::run(bf[cur][s2 * C::NT + t], a0, acc[0][t]);   // D^T: weights first
-                    acc[1][t] = Mfma<T>::run(bf[cur][s2 * C::NT + t], a1, acc[1][t]);
-                }
-                if (j < 2) {
-#pragma unroll
-                    for (int t = 0; t < C::NT; ++t) bf[nxt][s2 * C::NT + t] = bring[(g & 1) * 3 + j + 1][(s2 * C::NT + t) * 64 + lane];
-                }
-                if (k + DIST < KVOL) {
-                    areg[k % DIST][0][s2] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, n0 + 32 * s2, 0, 0);
-                    areg[k % DIST][1][s2] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, n1 + 32 * s2, 0, 0);
-                }
-                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);      // 4 MFMA
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // 2 DS reads
-                __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);      // 2 VMEM reads
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (g == 1) plane_store(lo1, 1);                      // visible after the barriers of windows 2 and 3; first read during step 8
-        if (g == 4) plane_store(lo2, 0);                      // first read during step 17
-        if (g + 1 < KVOL / 3) {
-            SEC_L_WSTORE(g + 1)
-            if (g + 2 < KVOL / 3) SEC_L_WLOAD(g + 2)
-        }
-    }
-#undef SEC_L_WLOAD
-#undef SEC_L_WSTORE
-    rows_store<T, COUT>(acc[0], out, row0, valid0, h, aff, scale != nullptr, shift != nullptr, relu);
-    rows_store<T, COUT>(acc[1], out, row1, valid1, h, aff, scale != nullptr, shift != nullptr, relu);
-}
-
-static int conv_variant();
-template <typename T>
-static void launch_rows_m2(const void *feat, long long n_feat, const void *packed, const int *nbr, int n_out, const int *num_out_dev,
-                           const float *scale, const float *shift, int relu, void *out, hipStream_t st) {
-    set_last_kernel("k_conv_rows_m2<%s, 3>", dtype_name<T>());
-#ifdef SEC_CONV_ABLATIONS
-    if (conv_variant() == 42 || conv_variant() == 43) {
-        if (conv_variant() == 42)
-            hipLaunchKernelGGL((k_conv_rows_m2<T, 3, 1>), dim3(div_up(n_out, 256)), dim3(256), 0, st, (const T *)feat,
-                               n_feat * 64 * (long long)sizeof(T), (const T *)packed, nbr, n_out, num_out_dev, scale, shift, relu, (T *)out);
-        else
-            hipLaunchKernelGGL((k_conv_rows_m2<T, 3, 2>), dim3(div_up(n_out, 256)), dim3(256), 0, st, (const T *)feat,
-                               n_feat * 64 * (long long)sizeof(T), (const T *)packed, nbr, n_out, num_out_dev, scale, shift, relu, (T *)out);
-        return;
-    }
+#ifdef SEC_CONV_EXPERIMENTS   // round-3 A/B forms: two row tiles per wave (k_conv_rows_m2), input planes in LDS windows (k_conv_rows_lds)
+#include "experiments/indice_conv_rows_r03.inc"
 #endif
-    hipLaunchKernelGGL((k_conv_rows_m2<T, 3>), dim3(div_up(n_out, 256)), dim3(256), 0, st, (const T *)feat,
-                       n_feat * 64 * (long long)sizeof(T), (const T *)packed, nbr, n_out, num_out_dev, scale, shift, relu, (T *)out);
-}
 
 // ------------------------------------------------------------------------------------------------------------------
 // First layer of SpMiddleFHD (Cin = 4 -> 16, 3x3x3; middle.py:146) on the matrix cores.  The whole receptive field of a
@@ -1429,9 +1060,11 @@ static int rows_plan(int cin, int cout, int kvol, int n_out, bool same_dtype) {
     if (!same_dtype) return 0;
     const int v = conv_variant();
     if (buf_shape(cin, cout, kvol)) {
+#ifdef SEC_CONV_EXPERIMENTS
         if (cin == 64 && cout == 64 && kvol == 27 && v == 46) return PLAN_ROWS_LDS;          // input planes staged in LDS (round 3)
         if (cin == 64 && cout == 64 && kvol == 27 && (v == 41 || v == 42 || v == 43 || (v == 1 && m2_auto() && n_out >= rows_min())))
             return PLAN_ROWS_M2;                                                           // two row tiles per wave (round 3)
+#endif
         if (v == 22 || (((v >= 16 && v <= 28) || v == 44 || v == 45) && cin == 64 && cout == 64 && kvol == 27)) return PLAN_ROWS_BUF;
         if (v >= 36 && v <= 40) return PLAN_ROWS_BUF;
         if (v == 1 && n_out >= rows_min()) return PLAN_ROWS_BUF;
@@ -1452,6 +1085,7 @@ static int rows_plan(int cin, int cout, int kvol, int n_out, bool same_dtype) {
     return 0;
 }
 
+#ifdef SEC_CONV_EXPERIMENTS
 template <typename T>
 static void launch_rows_lds(const void *feat, long long n_feat, const void *packed, const int *nbr, int n_out, const int *num_out_dev,
                             const float *scale, const float *shift, int relu, void *out, hipStream_t st) {
@@ -1460,12 +1094,14 @@ static void launch_rows_lds(const void *feat, long long n_feat, const void *pack
                        n_feat * 64 * (long long)sizeof(T), (const T *)packed, nbr, n_out, num_out_dev, scale, shift, relu, (T *)out);
 }
 
+#endif
 template <typename T, typename OT, int CIN, int COUT>
 static void launch_mfma(const void *feat, long long n_feat, const void *packed, const int *nbr, int n_out, const int *num_out_dev,
                         int kvol, const float *scale, const float *shift, int relu, void *out, hipStream_t st) {
     constexpr int MT = 1;
     if constexpr (std::is_same<T, OT>::value && CIN <= 64 && COUT <= 64 && (COUT >= CIN) ) {
         const int rp = feat ? rows_plan(CIN, COUT, kvol, n_out, true) : 0;
+#ifdef SEC_CONV_EXPERIMENTS
         if constexpr (CIN == 64 && COUT == 64) {
             if (rp == PLAN_ROWS_M2 && n_feat * CIN * (long long)sizeof(T) < 0x7fffffffll) {
                 launch_rows_m2<T>(feat, n_feat, packed, nbr, n_out, num_out_dev, scale, shift, relu, out, st);
@@ -1476,6 +1112,7 @@ static void launch_mfma(const void *feat, long long n_feat, const void *packed, 
                 return;
             }
         }
+#endif
         if (rp == PLAN_ROWS_BUF && n_feat * CIN * (long long)sizeof(T) < 0x7fffffffll) {
 #define SEC_BUF(D, W, FLG, KV) launch_rows_buf<T, CIN, COUT, D, W, 2, FLG, KV>(feat, n_feat, packed, nbr, n_out, num_out_dev, scale, shift, relu, out, st)
             if (kvol == 3) {

@@ -17,9 +17,11 @@ PLAN_ROWS_BUF = 11
 # (variant number, expected plan id): None = the automatic choice, 22 = the same kernel forced.  A library built with
 # -DSEC_CONV_EXPERIMENTS also carries the superseded row-split forms (9-15: LDS-DMA / register-direct gathers) and the A/B forms of
 # the buffer-load kernel (16-21, 23, 27, 28); they are run through the same comparisons when present.
-ROW_VARIANTS = [(None, 11), (22, 11), (41, 13), (46, 14)]      # 41 = two row tiles per wave (k_conv_rows_m2, plan 13); 46 = input planes staged in LDS (k_conv_rows_lds, plan 14: on these first-touch-ordered rows its windows mostly MISS -- the exact fallback)
+ROW_VARIANTS = [(None, 11), (22, 11)]
+# Round 3 added 41 = two row tiles per wave (k_conv_rows_m2, plan 13) and 46 = input planes staged in LDS windows (k_conv_rows_lds,
+# plan 14: on the first-touch-ordered rows of the `layer` fixture its windows mostly MISS -- the exact gather fallback).
 EXPERIMENT_VARIANTS = [(9, 6), (10, 7), (11, 8), (12, 9), (13, 10), (14, 10), (15, 10), (16, 11), (17, 11), (18, 11), (19, 11),
-                       (20, 11), (21, 11), (23, 11), (27, 11), (28, 11)]
+                       (20, 11), (21, 11), (23, 11), (27, 11), (28, 11), (41, 13), (46, 14)]
 
 
 def dev(a, dtype=None):
@@ -282,7 +284,7 @@ def test_conv_rows_are_deterministic_beside_the_rpn_conv(ops, layer):
     load = [torch.cuda.Stream(), torch.cuda.Stream()]
     s_conv = torch.cuda.Stream()
     m_small = 22834                                          # the four-wave form of the mid-size layers
-    for variant, plan in ROW_VARIANTS[:3]:
+    for variant, plan in ROW_VARIANTS[:2] + [v for v in ROW_VARIANTS if v[0] == 41]:
         ops.indice_conv_set_variant(-1 if variant is None else variant)
         first, first_small = None, None
         for it in range(60):
@@ -329,6 +331,9 @@ def test_conv_rows_lds_windows_hit_on_sorted_rows(ops, layer, dtype):
     f_t, w_t = dev(feat, dtype), dev(w, dtype)
     packed = ops.pack_weight(w_t)
     ops.indice_conv_set_variant(46)
+    if ops.indice_conv_plan(64, 64, 27, n, dtype) != 14:
+        ops.indice_conv_set_variant(-1)
+        pytest.skip("k_conv_rows_lds is an A/B form: built with -DSEC_CONV_EXPERIMENTS only")
     try:
         assert ops.indice_conv_plan(64, 64, 27, n, dtype) == 14
         out = ops.indice_conv(f_t, w_t, dev(nbr), n, packed=packed)
