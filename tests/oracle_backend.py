@@ -44,7 +44,7 @@ def _pairs_from_nbr(nbr_out, n_in):
 
 
 def voxelize(points, point_offsets, point_cloud_range, voxel_size, max_points, max_voxels, cap_mode="break",
-             mean_features=0, sync=True):
+             mean_features=0, sync=True, mean_dtype=None):
     pts, offs = _np(points), _np(point_offsets)
     outs = {"voxels": [], "coordinates": [], "num_points_per_voxel": []}
     voff = [0]
@@ -59,6 +59,8 @@ def voxelize(points, point_offsets, point_cloud_range, voxel_size, max_points, m
     res["voxel_num"] = voff[-1]
     if mean_features:
         res["mean"] = torch.from_numpy(orc.simple_voxel_mean(_np(res["voxels"]), _np(res["num_points_per_voxel"]), mean_features))
+        if mean_dtype is not None:
+            res["mean"] = res["mean"].to(mean_dtype)
     return res
 
 
