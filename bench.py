@@ -301,6 +301,12 @@ WORKLOADS["nusc.fhd.train"] = dict(cfg="ALL_FHD_NUSC", batch=3, points=300000, d
                                         "assignment, fp16 features over fp32 master weights, DDP), batch=3 synthetic 10-sweep clouds/GPU "
                                         "(~300k pts each, 24 ground-truth boxes over the ten classes), random-init weights, inputs "
                                         "resident in HBM")
+WORKLOADS["nusc.pp.train"] = dict(cfg="ALL_PP_LARGEA", batch=3, points=300000, dtype="bf16",
+                                  metric="samples/sec VoxelNet training step (nuscenes/all.pp.largea, batch 3/GPU)",
+                                  desc="nuscenes/all.pp.largea.config training step (PointPillars: PillarFeatureNet in its torch formulation, "
+                                       "differentiable pillar scatter, three-block RPN, assign_all targets with per-anchor thresholds), "
+                                       "batch=3 synthetic 10-sweep clouds/GPU (~300k pts each, 24 ground-truth boxes), random-init weights, "
+                                       "inputs resident in HBM")
 WL = WORKLOADS["car.fhd"]
 
 
@@ -327,7 +333,7 @@ def train_bench(args, rank, local_rank, world, device):
         for s in range(bs):
             g = np.random.default_rng(1000 + rank * bs + s)
             k = 24
-            cls = g.integers(1, cfg["num_class"] + 1, k)
+            cls = g.integers(1, len(cfg["anchor_groups"]) + 1, k)      # classes that own an anchor generator
             size = np.array([cfg["anchor_sizes"][cfg["anchor_groups"][c - 1][0]] for c in cls], np.float32) * g.uniform(0.9, 1.1, (k, 3))
             z = np.array([cfg["anchor_ranges"][cfg["anchor_groups"][c - 1][0]][2] for c in cls], np.float32)
             xy = g.uniform(r[0] + 5, r[3] - 5, (k, 2))

@@ -678,7 +678,8 @@ def predict_finalize(dec, top_score, top_label, dir_label, keep, num_keep, post_
                                        float(dir_limit_offset), int(num_dir_bins), rt.ptr(range6), rt.ptr(boxes),
                                        rt.ptr(scores), rt.ptr(labels), rt.ptr(valid), rt.stream())
     rt.check(rc, "sec_predict_finalize")
-    return {"boxes": boxes, "scores": scores, "labels": labels, "valid": valid.bool()}
+    # (the kernel writes 0 / 1 bytes: reinterpret, do not convert -- `.bool()` was the last torch kernel inside the captured step, 7.8 us)
+    return {"boxes": boxes, "scores": scores, "labels": labels, "valid": valid.view(torch.bool)}
 
 
 # ----------------------------------------------------------------------------- training: targets + loss

@@ -76,8 +76,11 @@ class DeviceTrainer:
         det, cfg = self.det, self.cfg
         batch = point_offsets.numel() - 1
         with torch.no_grad():
-            vox = det.voxel_generator.generate_device(points, point_offsets, mean_features=cfg["num_point_features"],
-                                                      mean_dtype=self.amp_dtype)
+            if det.pillars:
+                vox = det.voxel_generator.generate_device(points, point_offsets)
+            else:
+                vox = det.voxel_generator.generate_device(points, point_offsets, mean_features=cfg["num_point_features"],
+                                                          mean_dtype=self.amp_dtype)
             if self.class_ranges is None:
                 labels, reg_targets, importance = ops.assign_targets(det.anchors, gt_boxes, gt_offsets, *self.thresholds,
                                                                      gt_classes=gt_classes)
@@ -85,7 +88,15 @@ class DeviceTrainer:
                 begin, ids, mts, uts = self.class_ranges
                 labels, reg_targets, importance = ops.assign_targets_per_class(det.anchors, gt_boxes, gt_offsets, gt_classes,
                                                                                begin, ids, mts, uts)
-        if self.amp_dtype is not None:
+        if det.pillars:
+            # PointPillars (nuscenes/all.pp.largea): PillarFeatureNet in its differentiable torch formulation (the fused
+            # sec_pfn_fwd kernel is the inference form), differentiable pillar scatter (sec_pillar_scatter / sec_dense_to_sparse),
+            # the three-block RPN on torch convolutions (autocast with 16-bit features)
+            with torch.autocast("cuda", dtype=self.amp_dtype or torch.float32, enabled=self.amp_dtype is not None):
+                feats = det.voxel_feature_extractor(vox["voxels"], vox["num_points_per_voxel"], vox["coordinates"])
+                spatial = det.middle_feature_extractor(feats.float() if self.amp_dtype is None else feats, vox["coordinates"], batch)
+                preds = det.rpn(spatial)
+        elif self.amp_dtype is not None:
             # fp32 master weights; 16-bit features through the sparse stack (MFMA forward / dgrad / wgrad kernels) and,
             # under autocast, through the dense RPN; BatchNorm statistics and the loss in fp32
             spatial = det.middle_feature_extractor(vox["mean"].to(self.amp_dtype), vox["coordinates"], batch,
