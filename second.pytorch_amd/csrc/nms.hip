@@ -67,64 +67,88 @@ __device__ __forceinline__ bool seg_intersect(const float *p1, const float *p2, 
 }
 
 // intersection area of two quads given by their corners (nms_gpu.py:329-350,172-219,379-393)
-// The vertex list is indexed dynamically (append, insertion sort), which in registers means scratch memory -- a
-// global-memory round trip per access on the serial critical path of the few lanes that clip.  It lives in LDS instead:
-// `lp` points at this thread's column of a [24][blockDim] float array (16 vertex coordinates + 8 sort keys), element i
-// at lp[i * LSTR].  At most 8 vertices are ever used (the reference's int_pts holds 8), so later ones are counted but
-// not stored.
-template <int LSTR>
-__device__ float quad_inter(const float *c1, const float *c2, float *lp) {
-#define SEC_P(i) lp[(i) * LSTR]
-#define SEC_V(i) lp[(16 + (i)) * LSTR]
+// The reference indexes its vertex list dynamically (append, insertion sort).  In registers that means scratch memory, in LDS
+// (rounds 1-2) a ~100-clock round trip per access on a serial chain of a few hundred accesses: ~18 us per clip with one wave per
+// SIMD, and a launch lasts as long as its slowest clip.  Here the list (at most 8 vertices are ever used -- the reference's
+// int_pts holds 8; later ones are counted, not stored) lives in registers and every index is static: an append is eight selects
+// on "n == slot", the insertion sort is unrolled with a `moving` predicate that replays the reference's while loop step by step
+// (same comparisons in the same order, so ties and NaN keys fall exactly where the reference's sort leaves them), the centroid
+// and the triangle fan run to 8 / 6 with "i < n" predicates.  No LDS, no data-dependent branches except the per-edge-pair
+// "these two segments cross" block.
+__device__ __forceinline__ void vl_append(float (&px)[8], float (&py)[8], int &n, bool hit, float vx, float vy) {
+#pragma unroll
+    for (int sl = 0; sl < 8; ++sl) {
+        const bool wr = hit && n == sl;
+        px[sl] = wr ? vx : px[sl];
+        py[sl] = wr ? vy : py[sl];
+    }
+    n += hit ? 1 : 0;
+}
+
+__device__ float quad_inter(const float (&c1)[8], const float (&c2)[8]) {
+    float px[8], py[8], key[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) px[i] = py[i] = key[i] = 0.0f;
     int n = 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        if (pt_in_quad(c1[2 * i], c1[2 * i + 1], c2)) { if (n < 8) { SEC_P(2 * n) = c1[2 * i]; SEC_P(2 * n + 1) = c1[2 * i + 1]; } ++n; }
-        if (pt_in_quad(c2[2 * i], c2[2 * i + 1], c1)) { if (n < 8) { SEC_P(2 * n) = c2[2 * i]; SEC_P(2 * n + 1) = c2[2 * i + 1]; } ++n; }
+        vl_append(px, py, n, pt_in_quad(c1[2 * i], c1[2 * i + 1], c2), c1[2 * i], c1[2 * i + 1]);
+        vl_append(px, py, n, pt_in_quad(c2[2 * i], c2[2 * i + 1], c1), c2[2 * i], c2[2 * i + 1]);
     }
-    float t[2];
+#pragma unroll
     for (int i = 0; i < 4; ++i)
-        for (int j = 0; j < 4; ++j)
-            if (seg_intersect(c1, c2, i, j, t)) { if (n < 8) { SEC_P(2 * n) = t[0]; SEC_P(2 * n + 1) = t[1]; } ++n; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float t[2] = {0.0f, 0.0f};
+            const bool hit = seg_intersect(c1, c2, i, j, t);
+            vl_append(px, py, n, hit, t[0], t[1]);
+        }
     if (n > 8) n = 8;
     if (n < 3) return 0.0f;
     // angular sort about the centroid (insertion sort on the reference's key)
     float cx = 0.0f, cy = 0.0f;
-    for (int i = 0; i < n; ++i) { cx += SEC_P(2 * i); cy += SEC_P(2 * i + 1); }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        cx = i < n ? cx + px[i] : cx;
+        cy = i < n ? cy + py[i] : cy;
+    }
     cx /= (float)n;
     cy /= (float)n;
-    for (int i = 0; i < n; ++i) {
-        float vx = SEC_P(2 * i) - cx, vy = SEC_P(2 * i + 1) - cy;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float vx = px[i] - cx, vy = py[i] - cy;
         float d = sqrtf(vx * vx + vy * vy);
         vx = vx / d;
         vy = vy / d;
         if (vy < 0) vx = -2 - vx;
-        SEC_V(i) = vx;
+        key[i] = vx;                        // slots >= n are never compared (every step below is predicated on i < n)
     }
-    for (int i = 1; i < n; ++i) {
-        if (SEC_V(i - 1) > SEC_V(i)) {
-            float temp = SEC_V(i), tx = SEC_P(2 * i), ty = SEC_P(2 * i + 1);
-            int j = i;
-            while (j > 0 && SEC_V(j - 1) > temp) {
-                SEC_V(j) = SEC_V(j - 1);
-                SEC_P(2 * j) = SEC_P(2 * j - 2);
-                SEC_P(2 * j + 1) = SEC_P(2 * j - 1);
-                --j;
-            }
-            SEC_V(j) = temp;
-            SEC_P(2 * j) = tx;
-            SEC_P(2 * j + 1) = ty;
+#pragma unroll
+    for (int i = 1; i < 8; ++i) {
+        // reference: if (V[i-1] > V[i]) { temp = V[i]; j = i; while (j > 0 && V[j-1] > temp) { V[j] = V[j-1]; --j; } V[j] = temp; }
+        const float temp = key[i], tx = px[i], ty = py[i];
+        bool moving = i < n && key[i - 1] > temp;
+#pragma unroll
+        for (int j = i; j >= 1; --j) {
+            const bool shift = moving && key[j - 1] > temp;
+            key[j] = shift ? key[j - 1] : (moving ? temp : key[j]);
+            px[j] = shift ? px[j - 1] : (moving ? tx : px[j]);
+            py[j] = shift ? py[j - 1] : (moving ? ty : py[j]);
+            moving = shift;
         }
+        key[0] = moving ? temp : key[0];
+        px[0] = moving ? tx : px[0];
+        py[0] = moving ? ty : py[0];
     }
     float s = 0.0f;
-    const float p0[2] = {SEC_P(0), SEC_P(1)};
-    for (int i = 0; i < n - 2; ++i) {
-        const float pa[2] = {SEC_P(2 * i + 2), SEC_P(2 * i + 3)}, pb[2] = {SEC_P(2 * i + 4), SEC_P(2 * i + 5)};
-        s += fabsf(tri_area(p0, pa, pb));
+    const float p0[2] = {px[0], py[0]};
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const float pa[2] = {px[i + 1], py[i + 1]}, pb[2] = {px[i + 2], py[i + 2]};
+        const float a = fabsf(tri_area(p0, pa, pb));
+        s = i < n - 2 ? s + a : s;
     }
     return s;
-#undef SEC_P
-#undef SEC_V
 }
 
 struct Standup { float x0, y0, x1, y1; };
@@ -148,7 +172,6 @@ __global__ __launch_bounds__(kBlock) void k_rotate_iou(const float *__restrict__
                                                       const float *__restrict__ qboxes, int K, int criterion,
                                                       float *__restrict__ iou) {
     __shared__ float qc[64][9];   // corners of the 64 query boxes of this column tile (+1 pad)
-    __shared__ float clip_scratch[24][kBlock];   // per-thread vertex lists of the clipper
     __shared__ float qa[64];
     int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int kq = blockIdx.y * 64 + lane;
@@ -174,7 +197,7 @@ __global__ __launch_bounds__(kBlock) void k_rotate_iou(const float *__restrict__
         float c2[8];
         box_corners(c2, boxes + (size_t)n * 5);
         float a2 = boxes[(size_t)n * 5 + 2] * boxes[(size_t)n * 5 + 3];
-        float in = far_apart(standup_of(c1), standup_of(c2)) ? 0.0f : quad_inter<kBlock>(c1, c2, &clip_scratch[0][threadIdx.x]);
+        float in = far_apart(standup_of(c1), standup_of(c2)) ? 0.0f : quad_inter(c1, c2);
         float v;
         if (criterion == -1) v = in / (a1 + a2 - in);
         else if (criterion == 0) v = in / a1;
@@ -185,39 +208,49 @@ __global__ __launch_bounds__(kBlock) void k_rotate_iou(const float *__restrict__
 }
 
 // ---------------------------------------------------------------- suppression bit matrix
-// grid (col_block, row_block, batch); only col_block >= row_block is computed.  Two phases per 64 x 64 tile:
-//   A. every thread screens 16 (row, col) pairs with the cheap standup test (corners / standup boxes of the 128
-//      boxes of the tile are computed once into LDS); survivors are appended to an LDS queue with one wave-level
-//      atomic per ballot;
+// A tile is ROWS rows x 64 columns of one frame's pair matrix; tiles entirely below the diagonal are skipped.
+// Two phases per tile:
+//   A. every thread screens ROWS / 4 (row, col) pairs with the cheap standup test (corners / standup boxes of the
+//      ROWS + 64 boxes of the tile are computed once into LDS); survivors are appended to an LDS queue with one
+//      wave-level atomic per ballot;
 //   B. the queue is processed densely -- one polygon clip per thread -- and hits are OR-ed into the tile's 64
 //      suppression words (LDS atomics).
 // The reference (and a lanes-are-columns mapping) runs the ~1000-instruction clipper for all 64 lanes whenever a
 // single pair of the wave overlaps; with ~1 % of the pairs overlapping that wastes > 95 % of the lanes.
+// ROWS = 16 (round 3; 64 before): the launch lasts as long as its busiest tile, and the candidates of a detector cluster
+// -- with 64 x 64 tiles the tile of the top-scoring boxes queued > 1000 pairs (five clipper rounds of 256 threads, 49 us
+// for the launch) while most workgroups idled; 16-row tiles spread the same pairs over four times as many workgroups.
 #ifdef SEC_NMS_DEBUG
 __device__ int g_nms_dbg[4];
 __device__ float g_nms_vals[8 * 32];
 #endif
+template <int ROWS>
 __global__ __launch_bounds__(kBlock) void k_nms_mask(const float *__restrict__ dets, const int *__restrict__ counts,
                                                     int max_n, int stride, float thresh, int kind, int semantics,
                                                     float eps, int words, unsigned long long *__restrict__ mask) {
-    int cb = blockIdx.x, rb = blockIdx.y, b = blockIdx.z;
-    if (cb < rb) return;
+    static_assert(ROWS % 4 == 0 && ROWS <= 64 && 64 % ROWS == 0, "a tile is ROWS rows (a multiple of the 4 waves) x 64 columns");
+    // grid (workgroups per frame, batch): a workgroup walks the tiles of ITS frame's live rectangle (ceil(n / ROWS) x ceil(n / 64),
+    // n read from the device) with a stride of gridDim.x.  A grid sized for max_n (1000 candidates: 8 000 workgroups at ROWS = 16)
+    // spends its time launching workgroups that read counts[b] and leave -- ~6 rounds of them per CU before the few live ones.
+    const int b = blockIdx.y;
     int n = counts[b];
     if (n > max_n) n = max_n;
-    if (rb * 64 >= n || cb * 64 >= n) return;
+    const int ncb = (n + 63) >> 6, nrb = (n + ROWS - 1) / ROWS;
     __shared__ float tile[2][64][10];              // [0] column boxes, [1] row boxes: 8 corner floats (or x1,y1,x2,y2), area
     __shared__ Standup su[2][64];
-    __shared__ float ctr[2][64][3];
-    __shared__ unsigned long long sup_words[64];
-    __shared__ unsigned short queue[64 * 64];
+    __shared__ float ctr[2][64][5];                // centre, inscribed radius, offset of the outer inscribed circles (see phase A)
+    __shared__ unsigned long long sup_words[ROWS];
+    __shared__ unsigned short queue[ROWS * 64];
     __shared__ int qcount;
-    __shared__ float clip_scratch[24][kBlock];   // per-thread vertex lists of the clipper
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const float *base = dets + (size_t)b * max_n * stride;
+    for (int ti = blockIdx.x; ti < nrb * ncb; ti += gridDim.x) {
+    const int rb = ti / ncb, cb = ti - rb * ncb;
+    if (cb * 64 + 63 <= rb * ROWS) continue;       // no column of the tile lies right of any of its rows
     if (tid == 0) qcount = 0;
-    if (tid < 64) sup_words[tid] = 0ull;
-    if (w < 2) {
-        int idx = (w == 0 ? cb : rb) * 64 + lane;
+    if (tid < ROWS) sup_words[tid] = 0ull;
+    if (w < 2 && (w == 0 || lane < ROWS)) {
+        int idx = w == 0 ? cb * 64 + lane : rb * ROWS + lane;
         if (idx < n) {
             const float *d = base + (size_t)idx * stride;
             if (kind == 0) {
@@ -230,6 +263,13 @@ __global__ __launch_bounds__(kBlock) void k_nms_mask(const float *__restrict__ d
                 ctr[w][lane][0] = d[0];
                 ctr[w][lane][1] = d[1];
                 ctr[w][lane][2] = 0.5f * fminf(d[2], d[3]);   // radius of the circle inscribed at the centre (any rotation)
+                // the same circle slid along the long axis stays inside until it touches the short sides: +-(long - short) / 2
+                // (taken from the corners, so no angle convention enters; shortened by 0.1 % against rounding)
+                const bool ylong = d[3] >= d[2];
+                const float lng = ylong ? d[3] : d[2], sht = ylong ? d[2] : d[3];
+                const float f = (lng > 0.0f && sht > 0.0f) ? 0.4995f * (lng - sht) / lng : 0.0f;
+                ctr[w][lane][3] = f * (ylong ? c[2] - c[0] : c[4] - c[2]);
+                ctr[w][lane][4] = f * (ylong ? c[3] - c[1] : c[5] - c[3]);
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) tile[w][lane][i] = d[i];
@@ -238,8 +278,8 @@ __global__ __launch_bounds__(kBlock) void k_nms_mask(const float *__restrict__ d
     }
     __syncthreads();
 #ifdef SEC_NMS_DEBUG
-    if (w < 2) {     // right after the tile was written: does LDS hold what a second load + derivation gives?
-        int idx = (w == 0 ? cb : rb) * 64 + lane;
+    if (w < 2 && (w == 0 || lane < ROWS)) {     // right after the tile was written: does LDS hold what a second load + derivation gives?
+        int idx = w == 0 ? cb * 64 + lane : rb * ROWS + lane;
         if (idx < n && kind == 0) {
             const float *d = base + (size_t)idx * stride;
             float c[8], c2[8];
@@ -264,9 +304,9 @@ __global__ __launch_bounds__(kBlock) void k_nms_mask(const float *__restrict__ d
 #endif
     // ---- phase A: screen
 #pragma unroll 1
-    for (int it = 0; it < 16; ++it) {
+    for (int it = 0; it < ROWS / 4; ++it) {
         const int rl = it * 4 + w, cl = lane;      // a wave = one row of the tile x 64 columns
-        const int row = rb * 64 + rl, col = cb * 64 + cl;
+        const int row = rb * ROWS + rl, col = cb * 64 + cl;
         bool cand = false;
         if (row < n && col < n && col > row) {
             if (kind == 0) {
@@ -288,9 +328,21 @@ __global__ __launch_bounds__(kBlock) void k_nms_mask(const float *__restrict__ d
                         // intersection.  If even that bound clears the threshold (with a margin far above fp32 rounding) the pair is
                         // decided; only undecided pairs are queued for the clipper.  The candidates of a trained detector cluster on
                         // the objects -- most overlapping pairs are decided here (car.fhd: iou_threshold 0.01, car.fhd.config:94).
+                        // Three such circles per box (centre and both ends of the long axis; a car is ~2.4 x as long as wide, one
+                        // circle covers a third of it): the closest of the nine pairs gives the bound.  Round 3: 3 600 -> 10 800 of the
+                        // 14 700 standup survivors of a bench frame decided here.
                         const float rr = fminf(ctr[1][rl][2], ctr[0][cl][2]);
                         const float dx = ctr[1][rl][0] - ctr[0][cl][0], dy = ctr[1][rl][1] - ctr[0][cl][1];
-                        const float dd = sqrtf(dx * dx + dy * dy);
+                        const float ax = ctr[1][rl][3], ay = ctr[1][rl][4], bx = ctr[0][cl][3], by = ctr[0][cl][4];
+                        float d2 = 3.0e38f;
+#pragma unroll
+                        for (int ka = -1; ka <= 1; ++ka)
+#pragma unroll
+                            for (int kb = -1; kb <= 1; ++kb) {
+                                const float ex = dx + (float)ka * ax - (float)kb * bx, ey = dy + (float)ka * ay - (float)kb * by;
+                                d2 = fminf(d2, ex * ex + ey * ey);
+                            }
+                        const float dd = sqrtf(d2);
                         if (dd < 1.9f * rr) {
                             const float lens = 2.0f * rr * rr * acosf(fminf(dd / (2.0f * rr), 1.0f)) - 0.5f * dd * sqrtf(fmaxf(4.0f * rr * rr - dd * dd, 0.0f));
                             const float lb = lens / (tile[1][rl][8] + tile[0][cl][8] - lens);
@@ -331,16 +383,16 @@ __global__ __launch_bounds__(kBlock) void k_nms_mask(const float *__restrict__ d
         float c1[8], c2[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) { c1[i] = tile[1][rl][i]; c2[i] = tile[0][cl][i]; }
-        float in = quad_inter<kBlock>(c1, c2, &clip_scratch[0][tid]);
+        float in = quad_inter(c1, c2);
         float v = in / (tile[1][rl][8] + tile[0][cl][8] - in);
         if (semantics == 1 ? v >= thresh : v > thresh) atomicOr(&sup_words[rl], 1ull << cl);
     }
     __syncthreads();
-    if (tid < 64 && rb * 64 + tid < n) mask[((size_t)b * max_n + rb * 64 + tid) * words + cb] = sup_words[tid];
+    if (tid < ROWS && rb * ROWS + tid < n) mask[((size_t)b * max_n + rb * ROWS + tid) * words + cb] = sup_words[tid];
 #ifdef SEC_NMS_DEBUG
     // debug build: is the tile still what the global loads delivered at the start?  (re-load, re-derive, compare)
-    if (w < 2) {
-        int idx = (w == 0 ? cb : rb) * 64 + lane;
+    if (w < 2 && (w == 0 || lane < ROWS)) {
+        int idx = w == 0 ? cb * 64 + lane : rb * ROWS + lane;
         if (idx < n && kind == 0) {
             const float *d = base + (size_t)idx * stride;
             float c[8];
@@ -352,6 +404,8 @@ __global__ __launch_bounds__(kBlock) void k_nms_mask(const float *__restrict__ d
         }
     }
 #endif
+    __syncthreads();                               // the next tile re-initialises the LDS state read above
+    }
 }
 
 __device__ __forceinline__ unsigned long long wave_or64(unsigned long long v) {
@@ -502,8 +556,23 @@ SEC_API int sec_nms_sorted_f32(const float *dets, const int *counts, int batch, 
     hipStream_t st = (hipStream_t)stream;
     int words = (max_n + 63) / 64;
     unsigned long long *mask = (unsigned long long *)workspace;
-    hipLaunchKernelGGL(k_nms_mask, dim3(words, words, batch), dim3(kBlock), 0, st, dets, counts, max_n, stride, thresh,
-                       kind, semantics, eps, words, mask);
+    // SEC_NMS_TILE_ROWS = 64 | 16 | 8 and SEC_NMS_WGS (workgroups per frame) for A/B runs
+    static int tile_rows = -1, wgs = -1;
+    if (tile_rows < 0) { const char *e = getenv("SEC_NMS_TILE_ROWS"); tile_rows = e ? atoi(e) : 16; }
+    if (wgs < 0) { const char *e = getenv("SEC_NMS_WGS"); wgs = e ? atoi(e) : 0; }
+    // a tile costs ~12 us start to finish (box corners, screen, one clipper round), so the launch is as long as the most tiles any
+    // workgroup walks: enough workgroups that a few hundred candidates leave each at most one live tile (car.fhd batch 8, ~400
+    // candidates per frame, nms_sorted: 64 per frame 44 us, 128: 35 us, 256: 28 us), capped so that 1000 candidates x a large batch
+    // do not flood the chip: 2048 / batch, between 32 and 256
+    int per_frame = wgs > 0 ? wgs : 2048 / batch;
+    if (wgs <= 0) per_frame = per_frame < 32 ? 32 : per_frame > 256 ? 256 : per_frame;
+    const dim3 grid(per_frame, batch);
+    if (tile_rows == 64)
+        hipLaunchKernelGGL(k_nms_mask<64>, grid, dim3(kBlock), 0, st, dets, counts, max_n, stride, thresh, kind, semantics, eps, words, mask);
+    else if (tile_rows == 8)
+        hipLaunchKernelGGL(k_nms_mask<8>, grid, dim3(kBlock), 0, st, dets, counts, max_n, stride, thresh, kind, semantics, eps, words, mask);
+    else
+        hipLaunchKernelGGL(k_nms_mask<16>, grid, dim3(kBlock), 0, st, dets, counts, max_n, stride, thresh, kind, semantics, eps, words, mask);
     hipLaunchKernelGGL(k_nms_reduce, dim3(batch), dim3(64), 0, st, mask, counts, max_n, words, post_max, keep, num_keep);
     return check_launch();
 }

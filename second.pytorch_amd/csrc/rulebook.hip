@@ -564,15 +564,21 @@ __device__ __forceinline__ unsigned compress_even(unsigned long long x) {      /
 
 // output bitmap from the input sites' bitmap.  GEO 1: 3x3x3 stride 2 (any padding); GEO 2: (3,1,1) stride (2,1,1).
 // One thread per output word; a word that straddles a row end is assembled from its row segments.
+// The launch also does what k_rb_init did for this build (scan control := 0, gather tables := -1): the dilation writes every
+// bitmap word itself, so nothing has to be cleared BEFORE it, and the tables are only read by the launches after it -- one launch
+// less per strided layer on the latency chain.
+struct RbFill {
+    unsigned long long *a; long long na;      // := 0
+    int *b; long long nb;                     // := -1
+    int *c; long long nc;                     // := -1
+    int *d; long long nd;                     // := -1
+};
 template <int GEO>
-__global__ __launch_bounds__(kBlock) void k_bm_dilate(const unsigned *__restrict__ bm_in, long long n_words_in, RbGeom g,
-                                                     unsigned *__restrict__ bm_out, long long n_words_out) {
-    const long long wi = (long long)blockIdx.x * kBlock + threadIdx.x;
-    if (wi >= n_words_out) return;
+__device__ __forceinline__ unsigned bm_dilate_word(const unsigned *__restrict__ bm_in, long long n_words_in, const RbGeom &g, long long wi) {
     const unsigned Wo = (unsigned)g.out_shape[2], Ho = (unsigned)g.out_shape[1], Do = (unsigned)g.out_shape[0];
     const unsigned total = (unsigned)g.batch * Do * Ho * Wo;
     const unsigned lin0 = (unsigned)wi << 5;
-    if (lin0 >= total) { bm_out[wi] = 0u; return; }
+    if (lin0 >= total) return 0u;
     unsigned row = lin0 / Wo, x = lin0 - row * Wo;     // row = (b * Do + oz) * Ho + oy
     unsigned word = 0u;
     int done = 0;
@@ -620,52 +626,98 @@ __global__ __launch_bounds__(kBlock) void k_bm_dilate(const unsigned *__restrict
         x = 0;
         ++row;
     }
-    bm_out[wi] = word;
+    return word;
+}
+template <int GEO>
+__global__ __launch_bounds__(kBlock) void k_bm_dilate(const unsigned *__restrict__ bm_in, long long n_words_in, RbGeom g,
+                                                     unsigned *__restrict__ bm_out, long long n_words_out, RbFill f) {
+    const long long wi = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (wi < n_words_out) bm_out[wi] = bm_dilate_word<GEO>(bm_in, n_words_in, g, wi);
+    const long long stride = (long long)gridDim.x * kBlock;
+    for (long long i = wi; i < f.na; i += stride) f.a[i] = 0ull;
+    for (long long i = wi; i < f.nb; i += stride) f.b[i] = -1;
+    for (long long i = wi; i < f.nc; i += stride) f.c[i] = -1;
+    for (long long i = wi; i < f.nd; i += stride) f.d[i] = -1;
 }
 
-// ranks: exclusive scan of the word popcounts (decoupled look-back over tiles of kBmTile words) -> prefix[] per word,
+// ranks: exclusive scan of the bitmap popcounts (decoupled look-back over tiles of kBlock * WPT words) -> prefix8[] = set bits
+// before every BLOCK of kBmBlk = 8 words (one 32-byte sector of the bitmap); a cell's rank is prefix8[block] + the popcounts of
+// the block's words before its own + the bits below it (bm_rank) -- the consumer's extra reads stay inside the sector that
+// holds its word.  Round 2 stored one prefix per WORD: the scan wrote (and its consumers cached) an array as large as the
+// bitmap itself, with each thread walking 256 contiguous bytes (every wave load touching 64 lines): 15 us for the 11.8 MB
+// bitmap of car.fhd's first strided layer.  Here a thread counts blocks i * 256 + t (coalesced 32-byte loads), the counts are
+// transposed through LDS so that thread t scans blocks t * BPT .. t * BPT + BPT - 1, and 1/8 of the bytes are written.
 // num_out[0] = live outputs (clamped to out_cap), num_out[1] = raw count
+constexpr int kBmBlk = 8;
+__device__ __forceinline__ int popc4(const uint4 &v) { return __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w); }
 template <int WPT>
-__global__ __launch_bounds__(kBlock) void k_bm_scan(const unsigned *__restrict__ bm, int *__restrict__ prefix, int out_cap,
+__global__ __launch_bounds__(kBlock) void k_bm_scan(const unsigned *__restrict__ bm, int *__restrict__ prefix8, int out_cap,
                                                    unsigned long long *__restrict__ status, int *__restrict__ ticket,
                                                    int *__restrict__ num_out) {
+    constexpr int BPT = WPT / kBmBlk;                 // blocks per thread
+    static_assert(WPT % kBmBlk == 0 && (BPT == 2 || BPT % 4 == 0), "prefix stores are int2 / int4");
     __shared__ int smem[8];
     __shared__ int s_tile;
+    __shared__ int cnt[kBlock * BPT];
     const int tile = scan_take_tile(ticket, &s_tile);
-    const size_t base = ((size_t)tile * kBlock + threadIdx.x) * WPT;
-    int cnt = 0;
+    const int t = threadIdx.x;
+    const size_t blk0 = (size_t)tile * kBlock * BPT;
 #pragma unroll
-    for (int i = 0; i < WPT / 4; ++i) {
-        const uint4 w4 = *reinterpret_cast<const uint4 *>(bm + base + 4 * i);
-        cnt += __popc(w4.x) + __popc(w4.y) + __popc(w4.z) + __popc(w4.w);
+    for (int i = 0; i < BPT; ++i) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(bm + (blk0 + (size_t)i * kBlock + t) * kBmBlk);
+        cnt[i * kBlock + t] = popc4(src[0]) + popc4(src[1]);
     }
-    int r = scan_lookback(cnt, tile, (int)gridDim.x, status, smem, num_out);
-    if (tile == (int)gridDim.x - 1 && threadIdx.x == 0) {
+    __syncthreads();
+    int mine[BPT], v = 0;
+#pragma unroll
+    for (int k = 0; k < BPT; ++k) { mine[k] = cnt[t * BPT + k]; v += mine[k]; }
+    int r = scan_lookback(v, tile, (int)gridDim.x, status, smem, num_out);
+    if (tile == (int)gridDim.x - 1 && t == 0) {
         const int tot = num_out[0];
         num_out[1] = tot;
         if (tot > out_cap) num_out[0] = out_cap;
     }
+    int *dst = prefix8 + blk0 + (size_t)t * BPT;
+    if constexpr (BPT == 2) {
+        *reinterpret_cast<int2 *>(dst) = make_int2(r, r + mine[0]);
+    } else {
 #pragma unroll
-    for (int i = 0; i < WPT / 4; ++i) {
-        const uint4 w4 = *reinterpret_cast<const uint4 *>(bm + base + 4 * i);      // second read: L1 / L2 hit
-        int4 pf;
-        pf.x = r; r += __popc(w4.x);
-        pf.y = r; r += __popc(w4.y);
-        pf.z = r; r += __popc(w4.z);
-        pf.w = r; r += __popc(w4.w);
-        *reinterpret_cast<int4 *>(prefix + base + 4 * i) = pf;
+        for (int k = 0; k < BPT; k += 4) {
+            int4 pf;
+            pf.x = r; r += mine[k];
+            pf.y = r; r += mine[k + 1];
+            pf.z = r; r += mine[k + 2];
+            pf.w = r; r += mine[k + 3];
+            *reinterpret_cast<int4 *>(dst + k) = pf;
+        }
     }
+}
+
+// set bits before word `w` of the bitmap: the block's prefix + the popcounts of the block's words in front of it
+__device__ __forceinline__ int bm_word_prefix(const unsigned *__restrict__ bm, const int *__restrict__ prefix8, size_t w) {
+    const size_t blk = w / kBmBlk;
+    const unsigned wi = (unsigned)(w % kBmBlk);
+    const uint4 a = *reinterpret_cast<const uint4 *>(bm + blk * kBmBlk), b = *reinterpret_cast<const uint4 *>(bm + blk * kBmBlk + 4);
+    int r = prefix8[blk];
+    r += wi > 0 ? __popc(a.x) : 0;
+    r += wi > 1 ? __popc(a.y) : 0;
+    r += wi > 2 ? __popc(a.z) : 0;
+    r += wi > 3 ? __popc(a.w) : 0;
+    r += wi > 4 ? __popc(b.x) : 0;
+    r += wi > 5 ? __popc(b.y) : 0;
+    r += wi > 6 ? __popc(b.z) : 0;
+    return r;
 }
 
 // out_indices in rank order, one thread per bitmap word (for callers that want them before the tables exist; the tables
 // kernel writes them too -- every candidate knows its output's coordinates)
-__global__ __launch_bounds__(kBlock) void k_bm_emit(const unsigned *__restrict__ bm, const int *__restrict__ prefix, RbGeom g,
+__global__ __launch_bounds__(kBlock) void k_bm_emit(const unsigned *__restrict__ bm, const int *__restrict__ prefix8, RbGeom g,
                                                    long long n_words, int *__restrict__ out_indices, int out_cap) {
     const long long wi = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (wi >= n_words) return;
     unsigned word = bm[wi];
     if (!word) return;
-    int r = prefix[wi];
+    int r = bm_word_prefix(bm, prefix8, (size_t)wi);
     const unsigned W = (unsigned)g.out_shape[2], H = (unsigned)g.out_shape[1], D = (unsigned)g.out_shape[0];
     const unsigned lin0 = (unsigned)wi << 5;
     const unsigned row = lin0 / W;                   // (b * D + z) * H + y of the word's first cell
@@ -682,10 +734,10 @@ __global__ __launch_bounds__(kBlock) void k_bm_emit(const unsigned *__restrict__
     }
 }
 
-__device__ __forceinline__ int bm_rank(const unsigned *__restrict__ bm, const int *__restrict__ prefix, unsigned lin) {
+__device__ __forceinline__ int bm_rank(const unsigned *__restrict__ bm, const int *__restrict__ prefix8, unsigned lin) {
     const unsigned word = bm[lin >> 5], bit = 1u << (lin & 31u);
     if (!(word & bit)) return -1;
-    return prefix[lin >> 5] + __popc(word & (bit - 1u));
+    return bm_word_prefix(bm, prefix8, (size_t)(lin >> 5)) + __popc(word & (bit - 1u));
 }
 
 template <int GEO>
@@ -989,7 +1041,7 @@ static BmWorkspace carve_bm(void *ws, size_t cap, int n_in, int kvol, long long 
     w.ticket = a.take<int>(w.ctl_words);
     w.status = reinterpret_cast<unsigned long long *>(w.ticket + 4);
     w.zero_words64 = (long long)((reinterpret_cast<char *>(w.ticket + w.ctl_words) - reinterpret_cast<char *>(w.bm)) / 8);
-    w.prefix = a.take<int>(w.n_words);
+    w.prefix = a.take<int>(w.n_words / kBmBlk);      // one entry per 8-word block (k_bm_scan)
     long long nblk = (long long)kvol * div_up(n_in > 0 ? n_in : 1, kBlock);
     w.blk = a.take<int>(nblk + 1);
     w.scan2 = a.take<int>(scan_scratch_ints(nblk));
@@ -1038,17 +1090,23 @@ SEC_API int sec_rulebook_conv3d_build_sorted(const int *indices, int n_in, const
         if (wi.bytes > in_sites_workspace_bytes) return SEC_E_WORKSPACE;
     }
     // scan control (+ the bitmap unless the dilation writes every word) := 0, both gather tables := -1, one launch
-    if (dilate)
-        rb_init(reinterpret_cast<unsigned long long *>(w.ticket), w.ctl_words / 2, 0ull, prefill_nbr_out, fill_a, -1, prefill_nbr_in,
-                fill_b, -1, st, prefill_extra, prefill_extra_words);
-    else
+    if (!dilate)
         rb_init(reinterpret_cast<unsigned long long *>(w.bm), w.zero_words64, 0ull, prefill_nbr_out, fill_a, -1, prefill_nbr_in,
                 fill_b, -1, st, prefill_extra, prefill_extra_words);
     const long long nc = (long long)n_in * g.ncand;
     if (dilate) {
-        const unsigned nb = (unsigned)div_up(w.n_words, kBlock);
-        if (geo == 1) hipLaunchKernelGGL(k_bm_dilate<1>, dim3(nb), dim3(kBlock), 0, st, wi.bm, wi.n_words, g, w.bm, w.n_words);
-        else hipLaunchKernelGGL(k_bm_dilate<2>, dim3(nb), dim3(kBlock), 0, st, wi.bm, wi.n_words, g, w.bm, w.n_words);
+        // scan control := 0 and both gather tables := -1 ride on the same launch (grid-stride tail)
+        const RbFill fl{reinterpret_cast<unsigned long long *>(w.ticket), w.ctl_words / 2, prefill_nbr_out, fill_a, prefill_nbr_in, fill_b,
+                        prefill_extra, prefill_extra_words};
+        long long most = w.n_words;
+        for (long long v : {fl.na, fl.nb, fl.nc, fl.nd}) most = v > most ? v : most;
+        long long nbl = div_up(most, (long long)kBlock);
+        const long long cover = div_up(w.n_words, (long long)kBlock);       // every bitmap word needs its own thread
+        if (nbl > 256 * 8) nbl = 256 * 8;
+        if (nbl < cover) nbl = cover;
+        const unsigned nb = (unsigned)nbl;
+        if (geo == 1) hipLaunchKernelGGL(k_bm_dilate<1>, dim3(nb), dim3(kBlock), 0, st, wi.bm, wi.n_words, g, w.bm, w.n_words, fl);
+        else hipLaunchKernelGGL(k_bm_dilate<2>, dim3(nb), dim3(kBlock), 0, st, wi.bm, wi.n_words, g, w.bm, w.n_words, fl);
     } else if (nc > 0) {
         const int nb = div_up(nc, kBlock);
         if (geo == 1) hipLaunchKernelGGL(k_bm_set_x2, dim3(div_up((long long)n_in * 4, kBlock)), dim3(kBlock), 0, st, indices, g, n_in_dev, w.bm);

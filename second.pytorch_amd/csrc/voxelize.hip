@@ -76,21 +76,45 @@ __global__ __launch_bounds__(kBlock) void k_vox_init(unsigned long long *__restr
 }
 
 // rank[i] = number of voxel-creating points before point i (exclusive scan of the first-touch flags), in one launch
-// (single-pass scan of common.hpp); *total = number of voxels over all clouds
+// (single-pass scan of common.hpp); *total = number of voxels over all clouds.  Four points per thread: a quarter of the tiles, so a
+// quarter of the same-address ticket atomics and status words on the look-back chain (round 3).
+constexpr int kFlagItems = 4;
 __global__ __launch_bounds__(kBlock) void k_vox_flag_scan(const int *__restrict__ pslot, const int *__restrict__ vals, int n,
                                                          int *__restrict__ rank, unsigned long long *__restrict__ status,
                                                          int *__restrict__ ticket, int *__restrict__ total) {
     __shared__ int smem[5];
     __shared__ int s_tile;
     const int tile = scan_take_tile(ticket, &s_tile);
-    const int i = tile * kBlock + threadIdx.x;
-    int f = 0;
-    if (i < n) {
-        int s = pslot[i];
-        f = (s >= 0 && vals[s] == i) ? 1 : 0;
+    const int i0 = (tile * kBlock + threadIdx.x) * kFlagItems;
+    int f[kFlagItems], v = 0;
+    int s4[kFlagItems];
+    if (i0 + kFlagItems <= n) {
+        const int4 q = *reinterpret_cast<const int4 *>(pslot + i0);
+        s4[0] = q.x; s4[1] = q.y; s4[2] = q.z; s4[3] = q.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < kFlagItems; ++j) s4[j] = i0 + j < n ? pslot[i0 + j] : -1;
     }
-    const int ex = scan_lookback(f, tile, (int)gridDim.x, status, smem, total);
-    if (i < n) rank[i] = ex;
+#pragma unroll
+    for (int j = 0; j < kFlagItems; ++j) {
+        f[j] = (s4[j] >= 0 && vals[s4[j]] == i0 + j) ? 1 : 0;
+        v += f[j];
+    }
+    int ex = scan_lookback(v, tile, (int)gridDim.x, status, smem, total);
+    if (i0 + kFlagItems <= n) {
+        int4 r;
+        r.x = ex; ex += f[0];
+        r.y = ex; ex += f[1];
+        r.z = ex; ex += f[2];
+        r.w = ex;
+        *reinterpret_cast<int4 *>(rank + i0) = r;
+    } else {
+#pragma unroll
+        for (int j = 0; j < kFlagItems; ++j) {
+            if (i0 + j < n) rank[i0 + j] = ex;
+            ex += f[j];
+        }
+    }
 }
 
 // one thread: per-cloud voxel counts (capped) -> voxel_offsets; rank base per cloud.  Only for empty inputs and batches > 64:
@@ -272,6 +296,44 @@ __global__ __launch_bounds__(kBlock) void k_vox_fill(const float *__restrict__ p
     }
 }
 
+// k_vox_fill + k_vox_mean in one launch for the common shape (4 point features, a handful of points per voxel): one thread per
+// voxel copies its points and accumulates the SimpleVoxel sums in the same slot order k_vox_mean uses (padded slots add +0.0f,
+// exactly as there), so the results are bit-identical to the two-kernel path; one launch less on the latency chain.
+template <typename OT>
+__global__ __launch_bounds__(kBlock) void k_vox_fill_mean4(const float *__restrict__ points, const int *__restrict__ voxel_offsets,
+                                                          const int *__restrict__ count, const int *__restrict__ slot_idx,
+                                                          VoxParams p, int mean_features, float *__restrict__ voxels,
+                                                          int *__restrict__ num_points_per_voxel, OT *__restrict__ mean) {
+    const int vid = blockIdx.x * kBlock + threadIdx.x;
+    if (vid >= voxel_offsets[p.batch]) return;
+    int n = count[vid];
+    if (n > p.max_points) n = p.max_points;
+    num_points_per_voxel[vid] = n;
+    const float4 *pts = reinterpret_cast<const float4 *>(points);
+    float4 *dst = reinterpret_cast<float4 *>(voxels) + (size_t)vid * p.max_points;
+    const int *slots = slot_idx + (size_t)vid * p.max_points;
+    float4 s = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    float4 q[kCascadeMaxPoints];
+#pragma unroll
+    for (int t = 0; t < kCascadeMaxPoints; ++t)       // all gathers in flight together (max_points <= kCascadeMaxPoints here)
+        q[t] = t < n ? pts[slots[t]] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+    for (int t = 0; t < kCascadeMaxPoints; ++t) {
+        if (t >= p.max_points) break;
+        dst[t] = q[t];
+        s.x = __fadd_rn(s.x, q[t].x); s.y = __fadd_rn(s.y, q[t].y); s.z = __fadd_rn(s.z, q[t].z); s.w = __fadd_rn(s.w, q[t].w);
+    }
+    const float inv = (float)n;
+    const float m[4] = {__fdiv_rn(s.x, inv), __fdiv_rn(s.y, inv), __fdiv_rn(s.z, inv), __fdiv_rn(s.w, inv)};
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        if (f >= mean_features) break;
+        if constexpr (std::is_same<OT, float>::value) mean[(size_t)vid * mean_features + f] = m[f];
+        else if constexpr (std::is_same<OT, __half>::value) mean[(size_t)vid * mean_features + f] = __float2half_rn(m[f]);
+        else mean[(size_t)vid * mean_features + f] = __float2bfloat16(m[f]);
+    }
+}
+
 // SimpleVoxel.forward (second/pytorch/models/voxel_encoder.py:220-225): sum over slots / num_points; stored as fp32 or, for a
 // 16-bit sparse stack, directly in its dtype (the cast torch ran as two extra kernels inside every captured step)
 template <typename OT>
@@ -402,7 +464,7 @@ SEC_API int sec_voxelize_f32(const float *points, const int *point_offsets, int 
     int nb = div_up(num_points > 0 ? num_points : 1, kBlock);
     if (num_points > 0) {
         hipLaunchKernelGGL(k_vox_hash, dim3(nb), dim3(kBlock), 0, st, points, point_offsets, p, w.keys, w.vals, w.pslot);
-        hipLaunchKernelGGL(k_vox_flag_scan, dim3(nb), dim3(kBlock), 0, st, w.pslot, w.vals, num_points, w.rank,
+        hipLaunchKernelGGL(k_vox_flag_scan, dim3(div_up(num_points, kBlock * kFlagItems)), dim3(kBlock), 0, st, w.pslot, w.vals, num_points, w.rank,
                            reinterpret_cast<unsigned long long *>(w.ctl + 4), w.ctl, w.total);
     } else if ((rc = hip_ok(hipMemsetAsync(w.total, 0, sizeof(int), st)))) return rc;
     if (!fused_frames)
@@ -429,7 +491,17 @@ SEC_API int sec_voxelize_f32(const float *points, const int *point_offsets, int 
     }
     long long cap = (long long)batch * max_voxels;
     long long bound = num_points < cap ? num_points : cap;  // #voxels <= #points
-    if (bound > 0) {
+    if (bound > 0 && mean && num_features == 4 && max_points <= kCascadeMaxPoints &&
+        (reinterpret_cast<uintptr_t>(points) & 15) == 0 && (reinterpret_cast<uintptr_t>(voxels) & 15) == 0) {
+        const dim3 gf(div_up(bound, kBlock));
+        if (mean_dtype == SEC_F32)
+            hipLaunchKernelGGL(k_vox_fill_mean4<float>, gf, dim3(kBlock), 0, st, points, voxel_offsets, w.count, w.slot_idx, p, mean_features, voxels, num_points_per_voxel, (float *)mean);
+        else if (mean_dtype == SEC_F16)
+            hipLaunchKernelGGL(k_vox_fill_mean4<__half>, gf, dim3(kBlock), 0, st, points, voxel_offsets, w.count, w.slot_idx, p, mean_features, voxels, num_points_per_voxel, (__half *)mean);
+        else
+            hipLaunchKernelGGL(k_vox_fill_mean4<__hip_bfloat16>, gf, dim3(kBlock), 0, st, points, voxel_offsets, w.count, w.slot_idx, p, mean_features, voxels, num_points_per_voxel,
+                               (__hip_bfloat16 *)mean);
+    } else if (bound > 0) {
         hipLaunchKernelGGL(k_vox_fill, dim3(div_up(bound * max_points, kBlock)), dim3(kBlock), 0, st, points,
                            voxel_offsets, w.count, w.slot_idx, p, voxels, num_points_per_voxel);
         if (mean) {

@@ -486,6 +486,33 @@ def test_rotate_nms_1000_boxes_vs_oracle(ops):
             np.testing.assert_array_equal(k[1], r1[:post] if post else r1)
 
 
+@pytest.mark.parametrize("thr", [0.01, 0.1, 0.3, 0.5])
+def test_rotate_nms_clustered_candidates_vs_oracle(ops, thr):
+    """The candidates of a detector cluster on the objects (a few dozen jittered boxes per object): the regime where the mask
+    kernel decides most overlapping pairs with the three-inscribed-circles lower bound of the IoU instead of the polygon clipper
+    (csrc/nms.hip phase A) and where one 64 x 64 tile used to queue > 1000 pairs.  Keep lists must still equal the sequential
+    oracle's, for both semantics, elongated and near-square boxes, thresholds from car.fhd's 0.01 to 0.5, and a ragged batch."""
+    rng = np.random.default_rng(int(thr * 1000) + 5)
+    frames = []
+    for n_obj, per, aspect in ((13, 32, (1.5, 1.9, 3.4, 4.6)), (6, 60, (0.6, 2.6, 0.6, 2.6)), (25, 40, (1.4, 2.0, 3.0, 12.0))):
+        cx, cy = rng.uniform(0, 70, n_obj), rng.uniform(-40, 40, n_obj)
+        rot = rng.uniform(-3.2, 3.2, n_obj)
+        k = n_obj * per
+        o = rng.integers(0, n_obj, k)
+        # jitter up to a box length: same-object pairs run from nearly identical to barely touching
+        x = cx[o] + rng.normal(0, 0.9, k)
+        y = cy[o] + rng.normal(0, 0.9, k)
+        w = rng.uniform(aspect[0], aspect[1], k)
+        l = rng.uniform(aspect[2], aspect[3], k)
+        r = rot[o] + rng.normal(0, 0.25, k) + (rng.random(k) < 0.1) * np.pi / 2
+        sc = np.sort(rng.uniform(0.3, 1, k))[::-1]
+        frames.append(np.stack([x, y, w, l, r, sc], 1).astype(np.float32))
+    for sem in ("numba", "cpu"):
+        keeps = _nms_call(ops, frames, thr, "rotate", sem)
+        for d, k in zip(frames, keeps):
+            np.testing.assert_array_equal(k, orc.rotate_nms_sorted(d, thr, sem))
+
+
 @pytest.mark.parametrize("thr", [0.1, 0.5])
 def test_axis_aligned_nms_golden(ops, golden, thr):
     g = golden("nms_axis_aligned")

@@ -2,13 +2,37 @@
 """Summarise a rocprofv3 (rocpd sqlite) kernel trace into the per-kernel stats table we commit under profiles/.
 
     python tools/rocprof_summary.py gpurun_out/prof1/r01_results.db [--steps N] > profiles/r01_....txt
+    python tools/rocprof_summary.py <db> --timeline k_vox_init      # one step (between the last two launches of that kernel):
+                                                                    # every launch with start offset, duration and the idle gap before it
 """
 import sqlite3
 import sys
 
 
+def timeline(db, marker):
+    c = sqlite3.connect(db)
+    rows = list(c.execute("select name, start, end from kernels order by start"))
+    marks = [i for i, r in enumerate(rows) if marker in r[0]]
+    if len(marks) < 3:
+        print(f"# fewer than three launches of {marker}")
+        return
+    a, b = marks[-3], marks[-2]          # the last complete step
+    t0, prev_end = rows[a][1], rows[a][1]
+    busy = gaps = 0.0
+    print(f"# one step = launches {a}..{b - 1} of {db}: start offset, duration, idle gap before the launch (us)")
+    for name, st, en in rows[a:b]:
+        gap = (st - prev_end) / 1e3
+        print(f"{(st - t0) / 1e3:9.2f} {(en - st) / 1e3:8.2f} {gap:7.2f}  {name[:100]}")
+        busy += (en - st) / 1e3
+        gaps += max(gap, 0.0)
+        prev_end = max(prev_end, en)
+    print(f"# {b - a} launches, {busy:.1f} us of kernels, {gaps:.1f} us idle between them, {(prev_end - t0) / 1e3:.1f} us first start to last end")
+
+
 def main():
     db = sys.argv[1]
+    if "--timeline" in sys.argv:
+        return timeline(db, sys.argv[sys.argv.index("--timeline") + 1])
     steps = int(sys.argv[sys.argv.index("--steps") + 1]) if "--steps" in sys.argv else None
     c = sqlite3.connect(db)
     rows = list(c.execute("select name, count(*), sum(end-start)/1e3, avg(end-start)/1e3, min(end-start)/1e3, "
