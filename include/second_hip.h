@@ -355,7 +355,10 @@ int sec_nms_sorted_f32(const float *dets, const int *counts, int batch, int max_
  * RPN outputs are addressed in place through element strides of a [B, A, H, W, C] view (h_*_strides5 =
  * {sb, sa, sy, sx, sc}); anchor n = (a*H + y)*W + x as in target_assigner.generate_anchors.
  *   select  : best class per anchor (num_class > 1), top-k by score (k <= 1024) sorted descending;
- *             counts[b] = entries with sigmoid score >= score_thr (voxelnet.py:545-569, box_torch_ops.py:497-501)
+ *             counts[b] = entries with sigmoid score >= score_thr (voxelnet.py:545-569, box_torch_ops.py:497-501).
+ *             The reference masks by the threshold BEFORE its topk: the result is rows [0, counts[b]) of each frame; what
+ *             the rows behind them hold is unspecified (the next-best anchors, or anchor 0 / score 0 when the bf16 path
+ *             skipped its bisection because no more than k anchors reach the threshold)
  *   decode  : second_box_decode (box_torch_ops.py:56-101) of the selected anchors -> decoded [B,k,7];
  *             dets [B,k,6] = NMS rows (rotate: x,y,w,l,r,score ; else standup x1,y1,x2,y2,score,0); direction argmax
  *   finalize: gather of the NMS survivors (keep / num_keep of sec_nms_sorted_f32), direction fix

@@ -246,7 +246,7 @@ __global__ __launch_bounds__(kSelThreads) void k_predict_select_reg(const T *__r
                                                                     int ns, int *__restrict__ top_idx,
                                                                     float *__restrict__ top_score, int *__restrict__ top_label,
                                                                     int *__restrict__ counts, int n_keys = 0,
-                                                                    const int *__restrict__ slot_anchor = nullptr) {
+                                                                    const int *__restrict__ slot_anchor = nullptr, unsigned thr16 = 0u) {
     __shared__ unsigned ckey[kSelThreads];
     __shared__ int cidx[kSelThreads];
     __shared__ int wsum[kSelThreads / 64];
@@ -300,6 +300,12 @@ __global__ __launch_bounds__(kSelThreads) void k_predict_select_reg(const T *__r
     };
     unsigned cand = 0;
     int it = 0, bit = 15, above = N;                  // above = number of keys >= cand
+    // thr16 (see k_predict_select_chunk): no more than K keys at or above the threshold's key -> they are the selection, no bisection
+    bool quick = false;
+    if (thr16 > 0u) {
+        const int c = count_ge(thr16, it++);
+        if (c <= K) { quick = true; cand = thr16; above = c; bit = -1; }
+    }
     for (; bit >= 0 && above > kCandCap; --bit, ++it) {
         const unsigned t = cand | (1u << bit);
         const int c = count_ge(t, it);
@@ -308,7 +314,28 @@ __global__ __launch_bounds__(kSelThreads) void k_predict_select_reg(const T *__r
     bool sorted_ready = false;                        // the sort buffer already holds every key >= T (ties included)
     ckey[tid] = 0u;
     cidx[tid] = 0x7fffffff;
-    if (bit >= 0) {
+    if (quick) {
+        if (tid == 0) s_cnt = 0;
+        __syncthreads();
+        const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+        for (int i = 0; i < KP; ++i)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const unsigned kj = (k2[i] >> (hf * 16)) & 0xffffu;
+                const int n = n_base + i * 128 + hf;
+                const bool hit = n < N && kj >= cand;
+                const unsigned long long m = __ballot(hit);
+                if (m) {                               // one LDS atomic per wave; the sort orders the slots
+                    int p0 = 0;
+                    if (lane == 0) p0 = atomicAdd(&s_cnt, __popcll(m));
+                    p0 = __shfl(p0, 0, 64);
+                    const int pos = p0 + __popcll(m & lt);
+                    if (hit && pos < kSelThreads) { ckey[pos] = (kj << 16) | ((kj & 0x8000u) ? 0u : 0xffffu); cidx[pos] = n; }
+                }
+            }
+        sorted_ready = true;
+    } else if (bit >= 0) {
         if (tid == 0) s_cnt = 0;
         __syncthreads();
 #pragma unroll
@@ -429,7 +456,7 @@ __global__ __launch_bounds__(kSelThreads) void k_predict_select_reg(const T *__r
     }
     const int n_valid = INDIRECT ? 0x7fffffff : N;    // below: mi < n_valid == a real anchor
     if (tid < K) {
-        float sc = sigmoidf_(key2f(mk));
+        float sc = mi < n_valid ? sigmoidf_(key2f(mk)) : 0.0f;      // empty slots (fewer than K selected): score 0, anchor 0
         int lab = 0;
         if (g.nc > 1 && mi < n_valid) anchor_key(cls, v, g, b, mi, &lab);
         top_idx[(size_t)b * K + tid] = mi < n_valid ? mi : 0;
@@ -462,8 +489,16 @@ __global__ __launch_bounds__(kSelThreads) void k_predict_select_reg(const T *__r
 // top K, with the same tie order, so stage 2 (k_predict_select_reg<INDIRECT>) selects and sorts ~9 k candidates instead of
 // bisecting 70 k keys in one workgroup: 65 us -> two launches of ~6 and ~17 us.
 constexpr int kSelChunk = 8192;                  // 16 waves x 4 key pairs x 128
-__global__ __launch_bounds__(kSelThreads) void k_predict_select_chunk(const unsigned short *__restrict__ keys, int ns, int N, int K,
-                                                                      int chunks, unsigned short *__restrict__ cand_key,
+// Round 3: (a) the keys are computed HERE from the head output (the separate whole-chip k_predict_keys16 launch, 12.5 us, is gone
+// from this path; a chunk's 8192 anchors are 8192 scattered 2-byte reads either way); (b) `thr16` > 0 is a 16-bit key at or below
+// the key of every logit whose score reaches the caller's threshold (computed conservatively on the host): when no more than K
+// keys of the chunk lie at or above it -- the normal case for a trained head: a few hundred candidates per frame -- they ARE the
+// chunk's contribution and the 16-step bisection is skipped.  Entries below the threshold can then be missing from the frame's
+// top K; they lie behind counts[b] and were never part of the reference's result (voxelnet.py:551-570 masks by the threshold
+// before its topk).
+template <typename T>
+__global__ __launch_bounds__(kSelThreads) void k_predict_select_chunk(const T *__restrict__ cls, View5 v, PredGeom g, int N, int K,
+                                                                      int chunks, unsigned thr16, unsigned short *__restrict__ cand_key,
                                                                       int *__restrict__ cand_idx) {
     constexpr int KP = 4;
     __shared__ int sweep_tot[20];
@@ -472,13 +507,14 @@ __global__ __launch_bounds__(kSelThreads) void k_predict_select_chunk(const unsi
     const int base = c * kSelChunk;
     const int nloc = min(kSelChunk, N - base);                         // > 0 by construction of the grid
     const int Kc = K < nloc ? K : nloc;
-    const unsigned *fk2 = reinterpret_cast<const unsigned *>(keys + (size_t)b * ns + base);
     const int n_base = wv * (KP * 128) + lane * 2;
     unsigned k2[KP];
 #pragma unroll
     for (int i = 0; i < KP; ++i) {
-        const int n = n_base + i * 128;
-        k2[i] = base + n < ns ? fk2[n >> 1] : 0u;                      // slots beyond the frame hold key 0
+        const int a0 = base + n_base + i * 128;
+        const unsigned ka = a0 < N ? anchor_key(cls, v, g, b, a0, nullptr) >> 16 : 0u;        // slots beyond the frame hold key 0
+        const unsigned kb = a0 + 1 < N ? anchor_key(cls, v, g, b, a0 + 1, nullptr) >> 16 : 0u;
+        k2[i] = ka | (kb << 16);
     }
     unsigned short *ok_ = cand_key + ((size_t)b * chunks + c) * kSelThreads;
     int *oi_ = cand_idx + ((size_t)b * chunks + c) * kSelThreads;
@@ -505,10 +541,16 @@ __global__ __launch_bounds__(kSelThreads) void k_predict_select_chunk(const unsi
     };
     unsigned T_key = 0;
     int it = 0;
-    for (int bit = 15; bit >= 0; --bit, ++it) {
-        const unsigned t = T_key | (1u << bit);
-        if (count_ge(t, it) >= Kc) T_key = t;
+    bool quick = false;
+    if (thr16 > 0u) {
+        quick = count_ge(thr16, it++) <= Kc;
+        if (quick) T_key = thr16;
     }
+    if (!quick)
+        for (int bit = 15; bit >= 0; --bit, ++it) {
+            const unsigned t = T_key | (1u << bit);
+            if (count_ge(t, it) >= Kc) T_key = t;
+        }
     const int above = T_key == 0xffffu ? 0 : count_ge(T_key + 1, it);
     const int need = Kc - above;                                          // ties at T to keep, by ascending anchor index
     int my_eq = 0, my_gt = 0;
@@ -640,6 +682,20 @@ using namespace sec;
 
 static View5 mkview(const int64_t *s) { return View5{s[0], s[1], s[2], s[3], s[4]}; }
 
+// a 16-bit key no larger than the key of any bf16 logit whose sigmoid reaches `thr` (0 = no such bound): the logit of thr, lowered
+// by more than bf16's and sigmoidf's rounding, mapped like f2key() >> 16, minus one key step (truncation of a negative value's
+// bits rounds it UP)
+static unsigned conservative_thr16(float thr) {
+    if (!(thr > 0.0f) || !(thr < 1.0f)) return 0u;
+    float x = logf(thr / (1.0f - thr));
+    x -= fabsf(x) / 64.0f + 0.01f;
+    unsigned u;
+    __builtin_memcpy(&u, &x, 4);
+    const unsigned key = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    const unsigned k16 = key >> 16;
+    return k16 > 1u ? k16 - 1u : 0u;
+}
+
 SEC_API int sec_predict_select(const void *cls, const int64_t *h_cls_strides5, int batch, int anchors_per_loc, int h, int w,
                                int num_class, int k, float score_thr, unsigned *key_scratch, int *top_idx, float *top_score,
                                int *top_label, int *counts, int dtype, void *stream) {
@@ -661,8 +717,9 @@ SEC_API int sec_predict_select(const void *cls, const int64_t *h_cls_strides5, i
     if (dtype == SEC_BF16 && nfr <= (long long)kSelThreads * 72) {   // register-resident select on 16-bit keys
         using T = __hip_bfloat16;
         const int ns = (int)((nfr + 1) & ~1ll);
-        hipLaunchKernelGGL(k_predict_keys16<T>, dim3(div_up((long long)batch * ns, kBlock)), dim3(kBlock), 0, st, (const T *)cls, v, g, ns,
-                           reinterpret_cast<unsigned short *>(key_scratch));
+        static int use_thr = -1;
+        if (use_thr < 0) { const char *e = getenv("SEC_SELECT_THRESHOLD_SHORTCUT"); use_thr = e ? atoi(e) : 1; }
+        const unsigned thr16 = use_thr ? conservative_thr16(score_thr) : 0u;
         // chunked form: per-chunk top-K on the whole chip, then one workgroup per frame over the ~9 k candidates.  The candidate
         // arrays live in the unused upper part of key_scratch (sized 4 bytes per anchor, the 16-bit keys take 2).
         static int chunked = -1;
@@ -674,10 +731,10 @@ SEC_API int sec_predict_select(const void *cls, const int64_t *h_cls_strides5, i
         if (chunked && chunks >= 2 && n2 <= (long long)kSelThreads * 72 && need_bytes <= (size_t)total * 4) {
             unsigned short *ck = reinterpret_cast<unsigned short *>(reinterpret_cast<char *>(key_scratch) + key_bytes + (size_t)batch * n2 * 4);
             int *ci = reinterpret_cast<int *>(reinterpret_cast<char *>(key_scratch) + key_bytes);
-            hipLaunchKernelGGL(k_predict_select_chunk, dim3(chunks, batch), dim3(kSelThreads), 0, st,
-                               reinterpret_cast<const unsigned short *>(key_scratch), ns, (int)nfr, k, chunks, ck, ci);
+            hipLaunchKernelGGL(k_predict_select_chunk<T>, dim3(chunks, batch), dim3(kSelThreads), 0, st, (const T *)cls, v, g, (int)nfr, k,
+                               chunks, thr16, ck, ci);
 #define SEC_SEL2(KP2) hipLaunchKernelGGL((k_predict_select_reg<T, KP2, true>), dim3(batch), dim3(kSelThreads), 0, st, (const T *)cls, v, g, k, \
-                                         score_thr, ck, (int)n2, top_idx, top_score, top_label, counts, (int)n2, ci)
+                                         score_thr, ck, (int)n2, top_idx, top_score, top_label, counts, (int)n2, ci, thr16)
             const int pairs = (int)((n2 / 2 + kSelThreads - 1) / kSelThreads);
             if (pairs <= 5) SEC_SEL2(5);
             else if (pairs <= 10) SEC_SEL2(10);
@@ -686,8 +743,11 @@ SEC_API int sec_predict_select(const void *cls, const int64_t *h_cls_strides5, i
 #undef SEC_SEL2
             return check_launch();
         }
+        hipLaunchKernelGGL(k_predict_keys16<T>, dim3(div_up((long long)batch * ns, kBlock)), dim3(kBlock), 0, st, (const T *)cls, v, g, ns,
+                           reinterpret_cast<unsigned short *>(key_scratch));
         hipLaunchKernelGGL((k_predict_select_reg<T, 36>), dim3(batch), dim3(kSelThreads), 0, st, (const T *)cls, v, g, k, score_thr,
-                           reinterpret_cast<const unsigned short *>(key_scratch), ns, top_idx, top_score, top_label, counts);
+                           reinterpret_cast<const unsigned short *>(key_scratch), ns, top_idx, top_score, top_label, counts, 0,
+                           (const int *)nullptr, thr16);
         return check_launch();
     }
     if (dtype == SEC_F32) SEC_SEL(float, false);

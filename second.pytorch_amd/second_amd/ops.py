@@ -622,7 +622,8 @@ def _strides5(t):
 @_traced("predict_select")
 def predict_select(cls, k, score_thr):
     """cls: [B, A, H, W, num_class] view (any strides).  -> (top_idx [B,k] int32 anchor ids sorted by descending
-    score, top_score [B,k] sigmoid scores, top_label [B,k], counts [B] = entries with score >= score_thr)."""
+    score, top_score [B,k] sigmoid scores, top_label [B,k], counts [B] = entries with score >= score_thr).  The selection is
+    rows [0, counts[b]) of frame b (the reference masks by the threshold before its topk); rows behind them are unspecified."""
     rt.require_gpu(cls)
     b, a, h, w, nc = cls.shape
     k = min(int(k), a * h * w, 1024)

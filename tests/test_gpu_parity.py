@@ -1042,13 +1042,51 @@ def test_predict_select_tie_ranking(levels, k):
     cls = vals[pick].reshape(b, a, h, w, 1).contiguous()
     top_idx, top_score, _, counts = ops.predict_select(cls, k, 0.3)
     again = ops.predict_select(cls, k, 0.3)
-    assert torch.equal(top_idx, again[0]) and torch.equal(top_score, again[1])
+    assert torch.equal(counts, again[3])
     flat = cls.reshape(b, n).float()
-    # reference: stable sort by descending logit -> ties keep ascending index
+    # reference: stable sort by descending logit -> ties keep ascending index; voxelnet.py:551-570 masks by the score threshold
+    # BEFORE its topk, so the selection is the first counts[b] entries (what lies behind them is unspecified)
     order = torch.sort(flat, dim=1, descending=True, stable=True).indices[:, :k]
-    assert torch.equal(top_idx.long(), order), (levels, k)
-    np.testing.assert_allclose(top_score.cpu().numpy(), torch.sigmoid(torch.gather(flat, 1, order)).cpu().numpy(), rtol=1e-6)
-    assert torch.equal(counts.long(), (torch.sigmoid(torch.gather(flat, 1, order)) >= 0.3).sum(1))
+    ref_scores = torch.sigmoid(torch.gather(flat, 1, order))
+    assert torch.equal(counts.long(), (ref_scores >= 0.3).sum(1))
+    for f in range(b):
+        c = int(counts[f])
+        assert torch.equal(top_idx[f, :c], again[0][f, :c]) and torch.equal(top_score[f, :c], again[1][f, :c])
+        assert torch.equal(top_idx[f, :c].long(), order[f, :c]), (levels, k, f)
+        np.testing.assert_allclose(top_score[f, :c].cpu().numpy(), ref_scores[f, :c].cpu().numpy(), rtol=1e-6)
+
+
+@pytest.mark.parametrize("thr", [0.05, 0.3, 0.5, 0.9])
+def test_predict_select_threshold_shortcut(thr):
+    """A trained-like head: a few hundred anchors per frame above the score threshold, logits spread around it (some within one
+    bf16 step of the threshold's logit, some exactly on it).  The selection with the threshold shortcut (no bisection when at most
+    k keys reach the threshold's conservative 16-bit key; csrc/predict.hip) equals the stable-sort reference entry for entry up
+    to counts[b], for a frame with fewer than k candidates, one with none and one with far more than k."""
+    from second_amd import ops
+    b, a, h, w = 3, 2, 200, 176
+    n = a * h * w
+    g = torch.Generator(device="cuda").manual_seed(int(thr * 100))
+    lt = float(np.log(thr / (1 - thr)))
+    cls = torch.full((b, n), lt - 6.0, device="cuda")
+    cls += torch.rand(b, n, device="cuda", generator=g)                      # background: well below the threshold, distinct-ish
+    hot = torch.randperm(n, device="cuda", generator=g)[:700]
+    cls[0, hot] = lt + torch.randn(700, device="cuda", generator=g) * 0.05    # ~350 above, many within a bf16 step of the threshold
+    cls[0, hot[:40]] = lt                                                    # exactly the threshold's logit (before bf16 rounding)
+    many = torch.randperm(n, device="cuda", generator=g)[:5000]
+    cls[2, many] = lt + 0.5 + torch.rand(5000, device="cuda", generator=g) * 4   # more than k candidates: bisection path
+    cls = cls.bfloat16().reshape(b, a, h, w, 1).contiguous()
+    k = 1000
+    top_idx, top_score, _, counts = ops.predict_select(cls, k, thr)
+    flat = cls.reshape(b, n).float()
+    order = torch.sort(flat, dim=1, descending=True, stable=True).indices[:, :k]
+    ref_scores = torch.sigmoid(torch.gather(flat, 1, order))
+    ref_counts = (ref_scores >= thr).sum(1)
+    assert torch.equal(counts.long(), ref_counts), (counts, ref_counts)
+    assert 100 < int(counts[0]) < 700 and int(counts[1]) == 0 and int(counts[2]) == k
+    for f in range(b):
+        c = int(counts[f])
+        assert torch.equal(top_idx[f, :c].long(), order[f, :c])
+        np.testing.assert_allclose(top_score[f, :c].cpu().numpy(), ref_scores[f, :c].cpu().numpy(), rtol=1e-6)
 
 
 def test_detector_sorted_and_first_touch_numbering_give_identical_results(syn):
