@@ -226,6 +226,11 @@ int sec_sparse_to_dense(const void *features, const int *indices, int n, int c, 
  * `feature_rows` = rows the feature buffer holds (capacity; only rows named by the map are read). */
 int sec_sparse_site_map(const int *indices, int n, const int *num_dev, int batch, int d, int h, int w,
                         int *site_map, void *stream);
+/* The same map for the outputs of a sorted-numbering strided build (sec_rulebook_conv3d_build_sorted), read off that build's
+ * bitmap in ONE launch (no zero fill, no scatter): rows are numbered by ascending cell index, so a cell's row is its rank.
+ * conv_workspace = the build's workspace, (d, h, w) = its output grid; rows beyond min(*num_dev, rows_cap) read as absent. */
+int sec_sparse_site_map_sorted(const void *conv_workspace, size_t conv_workspace_bytes, const int *num_dev, int rows_cap,
+                               int batch, int d, int h, int w, int *site_map, void *stream);
 int sec_conv2d_nhwc_gather(const void *features, long long feature_rows, const int *site_map, int batch, int h,
                            int w, const void *packed_weight, const float *bias, int cout, int relu, void *y,
                            int dtype, void *stream);
@@ -252,6 +257,25 @@ int sec_pfn_fwd(const float *voxels, const int *num_points, const int *coords, i
                 const int *num_dev, int max_points, int num_features, const float *weight_t,
                 const float *scale, const float *shift, int channels, float vx, float vy,
                 float x_offset, float y_offset, void *out, int out_dtype, void *stream);
+
+/* PillarFeatureNet in TRAINING mode (PFNLayer.forward under train(), pointpillars.py:51-65, trained by train.py:316-322):
+ * Linear(9, C, bias=False) on the decorated, masked points, BatchNorm1d with BATCH statistics over all P * T rows (padded slots
+ * included, as the reference's [P, T, C] tensor has them), ReLU, max over the T slots -- and its backward -- without ever
+ * materialising [P, T, C].  C <= 64, 4 point features, T <= 127.
+ *   fwd : out [P, C] f32; argmax [P, C] int8 (slot of the maximum, -1 = a padded slot); stats f32[C * 11 + 9] = mean[C],
+ *         invstd[C], M[C][9] = sum x_c * input_j, S1[9] = sum input_j (kept for the backward); running_mean / running_var (may be
+ *         NULL) updated with `momentum` (unbiased variance), like torch.nn.BatchNorm1d.
+ *   bwd : grad_out [P, C] f32 -> dweight_t [9][C] (the layout of weight_t), dgamma [C], dbeta [C]; no gradient for the points.
+ * workspace: sec_pfn_train_workspace_bytes(num_pillars, channels) for either call. */
+size_t sec_pfn_train_workspace_bytes(int num_pillars, int channels);
+int sec_pfn_train_fwd(const float *voxels, const int *num_points, const int *coords, int num_pillars, int max_points,
+                      int num_features, const float *weight_t, const float *gamma, const float *beta, float eps, float momentum,
+                      float *running_mean, float *running_var, int channels, float vx, float vy, float x_offset, float y_offset,
+                      float *out, signed char *argmax, float *stats, void *workspace, size_t workspace_bytes, void *stream);
+int sec_pfn_train_bwd(const float *voxels, const int *num_points, const int *coords, int num_pillars, int max_points,
+                      int num_features, const float *weight_t, const float *gamma, const float *stats, int channels, float vx,
+                      float vy, float x_offset, float y_offset, const float *grad_out, const float *out, const signed char *argmax,
+                      float *dweight_t, float *dgamma, float *dbeta, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Block filtering of points_to_voxel_3d_with_filtering (spconv point2voxel.h; enabled by
  * second/configs/nuscenes/all.fhd.config:9-12): keep a voxel iff the z-span of the stored points inside the

@@ -65,6 +65,268 @@ __global__ __launch_bounds__(kBlock) void k_pfn_fwd(const float *__restrict__ vo
     }
 }
 
+// ---- PillarFeatureNet in TRAINING mode: batch statistics, forward and backward -------------------------------------------
+// Reference: PFNLayer.forward (pointpillars.py:51-65) under train(): x = Linear(9, C, bias=False)(decorated, masked points);
+// BatchNorm1d over ALL P * T rows (the zero rows of the padded slots included), ReLU, max over the T slots; autograd then runs
+// ~25 kernels over a [P, T, C] tensor (1.1 GB in fp32 at 75 k pillars x 60 points x 64 channels) forward and again backward.
+// Here the [P, T, C] tensor never exists: lane = channel, a wave walks the points of a pillar.
+//   k_pfn_stats     per channel: sum x, sum x^2, M[c][j] = sum x_c * dec_j, and S1[j] = sum dec_j (block partials)
+//   k_pfn_finalize  mean, 1 / sqrt(var + eps) (biased variance over P * T rows, as BatchNorm does), running statistics
+//   k_pfn_fwd<.., TRAIN>  normalise, ReLU, max over the slots, slot of the maximum (-1: a padded slot won)
+//   k_pfn_bwd       the gradient of the max reaches ONE row per (pillar, channel): dz = g * [out > 0]; block partials of
+//                   dbeta = sum dz, dgamma = sum dz * xhat, A[c][j] = sum dz * dec_j over those rows
+//   k_pfn_bwd_finalize  BatchNorm's backward spreads dbeta / dgamma over every row (dx = gamma * invstd * (dz - dbeta / N -
+//                   xhat * dgamma / N)); summed against the inputs that is closed form in S1 and M:
+//                   dW[c][j] = gamma_c invstd_c (A[c][j] - dbeta_c / N * S1[j] - dgamma_c / N * invstd_c (M[c][j] - mean_c S1[j]))
+// No gradient with respect to the points (they are data).
+constexpr int kPfnIn = 9;
+constexpr int kPfnStatVals = 2 + kPfnIn;          // per channel: sum x, sum x^2, M[c][0..8]
+constexpr int kPfnBwdVals = 2 + kPfnIn;           // per channel: dbeta, dgamma, A[c][0..8]
+constexpr int kPfnMaxBlocks = 1024;
+
+struct PfnPillar {
+    float mx, my, mz, cx, cy;
+    int n;
+};
+// the pillar constants exactly as k_pfn_fwd derives them (mean over all T slots / n, pillar centre from its coordinates)
+__device__ __forceinline__ PfnPillar pfn_pillar(const float4 *__restrict__ pv, int T, int n, const int *__restrict__ coords, int p,
+                                                float vx, float vy, float xo, float yo, int lane) {
+    const int4 co = *reinterpret_cast<const int4 *>(coords + (size_t)p * 4);
+    PfnPillar r;
+    r.cx = __fadd_rn(__fmul_rn((float)co.w, vx), xo);
+    r.cy = __fadd_rn(__fmul_rn((float)co.z, vy), yo);
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (int t0 = 0; t0 < T; t0 += 64) {
+        float4 q = (t0 + lane < T) ? pv[t0 + lane] : make_float4(0, 0, 0, 0);
+        sx += q.x; sy += q.y; sz += q.z;
+    }
+    const float inv = (float)n;
+    r.mx = wave_sum(sx) / inv; r.my = wave_sum(sy) / inv; r.mz = wave_sum(sz) / inv;
+    r.n = n < T ? n : T;
+    return r;
+}
+__device__ __forceinline__ void pfn_decorate(const float4 q, const PfnPillar &pl, float (&f)[kPfnIn]) {
+    f[0] = q.x; f[1] = q.y; f[2] = q.z; f[3] = q.w;
+    f[4] = q.x - pl.mx; f[5] = q.y - pl.my; f[6] = q.z - pl.mz;
+    f[7] = q.x - pl.cx; f[8] = q.y - pl.cy;
+}
+
+// partial[block][c][kPfnStatVals], partial_s1[block][kPfnIn]; C <= 64 (one wave = all channels)
+__global__ __launch_bounds__(kBlock) void k_pfn_stats(const float *__restrict__ voxels, const int *__restrict__ num_points,
+                                                     const int *__restrict__ coords, int P, int T, const float *__restrict__ wt, int C,
+                                                     float vx, float vy, float xo, float yo, float *__restrict__ partial,
+                                                     float *__restrict__ partial_s1) {
+    __shared__ float red[kBlock / 64][64][kPfnStatVals + 1];
+    __shared__ float red1[kBlock / 64][kPfnIn];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const bool live = lane < C;
+    float w[kPfnIn];
+#pragma unroll
+    for (int j = 0; j < kPfnIn; ++j) w[j] = live ? wt[(size_t)j * C + lane] : 0.f;
+    float acc[kPfnStatVals], s1[kPfnIn];
+#pragma unroll
+    for (int j = 0; j < kPfnStatVals; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int j = 0; j < kPfnIn; ++j) s1[j] = 0.f;
+    for (int p = blockIdx.x * (kBlock / 64) + wv; p < P; p += gridDim.x * (kBlock / 64)) {
+        const float4 *pv = reinterpret_cast<const float4 *>(voxels) + (size_t)p * T;
+        const PfnPillar pl = pfn_pillar(pv, T, num_points[p], coords, p, vx, vy, xo, yo, lane);
+        for (int t = 0; t < pl.n; ++t) {
+            float f[kPfnIn];
+            pfn_decorate(pv[t], pl, f);
+            float x = 0.f;
+#pragma unroll
+            for (int j = 0; j < kPfnIn; ++j) x = fmaf(f[j], w[j], x);
+            acc[0] += x;
+            acc[1] = fmaf(x, x, acc[1]);
+#pragma unroll
+            for (int j = 0; j < kPfnIn; ++j) { acc[2 + j] = fmaf(x, f[j], acc[2 + j]); s1[j] += f[j]; }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kPfnStatVals; ++j) red[wv][lane][j] = acc[j];
+    if (lane == 0)
+#pragma unroll
+        for (int j = 0; j < kPfnIn; ++j) red1[wv][j] = s1[j];
+    __syncthreads();
+    if (wv == 0) {
+        if (live)
+#pragma unroll
+            for (int j = 0; j < kPfnStatVals; ++j) {
+                float v = 0.f;
+                for (int k = 0; k < kBlock / 64; ++k) v += red[k][lane][j];
+                partial[((size_t)blockIdx.x * C + lane) * kPfnStatVals + j] = v;
+            }
+        if (lane < kPfnIn) {
+            float v = 0.f;
+            for (int k = 0; k < kBlock / 64; ++k) v += red1[k][lane];
+            partial_s1[(size_t)blockIdx.x * kPfnIn + lane] = v;
+        }
+    }
+}
+
+__device__ __forceinline__ double block_sum_f64(double v, double *sh) {   // 256 threads
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double r = 0.0;
+    for (int k = 0; k < kBlock / 64; ++k) r += sh[k];
+    __syncthreads();
+    return r;
+}
+
+// one block per channel (+ one for S1).  stats[c] layout: mean[C], invstd[C], M[C][9], S1[9]
+__global__ __launch_bounds__(kBlock) void k_pfn_finalize(const float *__restrict__ partial, const float *__restrict__ partial_s1,
+                                                        int blocks, int C, double rows, float eps, float momentum,
+                                                        float *__restrict__ running_mean, float *__restrict__ running_var,
+                                                        float *__restrict__ stats) {
+    __shared__ double sh[kBlock / 64];
+    const int c = blockIdx.x;
+    if (c == C) {                                     // S1
+        for (int j = 0; j < kPfnIn; ++j) {
+            double v = 0.0;
+            for (int b = threadIdx.x; b < blocks; b += kBlock) v += (double)partial_s1[(size_t)b * kPfnIn + j];
+            v = block_sum_f64(v, sh);
+            if (threadIdx.x == 0) stats[(size_t)C * (2 + kPfnIn) + j] = (float)v;
+        }
+        return;
+    }
+    double tot[kPfnStatVals];
+    for (int j = 0; j < kPfnStatVals; ++j) {
+        double v = 0.0;
+        for (int b = threadIdx.x; b < blocks; b += kBlock) v += (double)partial[((size_t)b * C + c) * kPfnStatVals + j];
+        tot[j] = block_sum_f64(v, sh);
+    }
+    if (threadIdx.x == 0) {
+        const double mean = tot[0] / rows;
+        double var = tot[1] / rows - mean * mean;
+        if (var < 0.0) var = 0.0;
+        stats[c] = (float)mean;
+        stats[C + c] = (float)(1.0 / sqrt(var + (double)eps));
+        for (int j = 0; j < kPfnIn; ++j) stats[(size_t)2 * C + (size_t)c * kPfnIn + j] = (float)tot[2 + j];
+        if (running_mean) running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+        if (running_var) running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * var * (rows > 1.0 ? rows / (rows - 1.0) : 1.0));
+    }
+}
+
+// normalise with the batch statistics, ReLU, max over the slots; argmax[p][c] = slot of the maximum (first one; -1 = a padded slot)
+__global__ __launch_bounds__(kBlock) void k_pfn_fwd_train(const float *__restrict__ voxels, const int *__restrict__ num_points,
+                                                         const int *__restrict__ coords, int P, int T, const float *__restrict__ wt,
+                                                         const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                         const float *__restrict__ stats, int C, float vx, float vy, float xo,
+                                                         float yo, float *__restrict__ out, signed char *__restrict__ argmax) {
+    const int lane = threadIdx.x & 63;
+    const int p = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (p >= P) return;
+    const bool live = lane < C;
+    float w[kPfnIn];
+#pragma unroll
+    for (int j = 0; j < kPfnIn; ++j) w[j] = live ? wt[(size_t)j * C + lane] : 0.f;
+    const float mean = live ? stats[lane] : 0.f, invstd = live ? stats[C + lane] : 0.f;
+    const float ga = live ? gamma[lane] : 0.f, be = live ? beta[lane] : 0.f;
+    const float4 *pv = reinterpret_cast<const float4 *>(voxels) + (size_t)p * T;
+    const PfnPillar pl = pfn_pillar(pv, T, num_points[p], coords, p, vx, vy, xo, yo, lane);
+    float best = -INFINITY;
+    int arg = -1;
+    for (int t = 0; t < pl.n; ++t) {
+        float f[kPfnIn];
+        pfn_decorate(pv[t], pl, f);
+        float x = 0.f;
+#pragma unroll
+        for (int j = 0; j < kPfnIn; ++j) x = fmaf(f[j], w[j], x);
+        const float y = fmaxf(fmaf((x - mean) * invstd, ga, be), 0.f);
+        if (y > best) { best = y; arg = t; }
+    }
+    if (pl.n < T) {                                   // padded slots: x = 0
+        const float y = fmaxf(fmaf((0.f - mean) * invstd, ga, be), 0.f);
+        if (y > best) { best = y; arg = -1; }
+    }
+    if (live) {
+        out[(size_t)p * C + lane] = best;
+        argmax[(size_t)p * C + lane] = (signed char)arg;
+    }
+}
+
+// partial[block][c][kPfnBwdVals] = (dbeta, dgamma, A[c][0..8])
+__global__ __launch_bounds__(kBlock) void k_pfn_bwd(const float *__restrict__ voxels, const int *__restrict__ num_points,
+                                                   const int *__restrict__ coords, int P, int T, const float *__restrict__ wt,
+                                                   const float *__restrict__ stats, int C, float vx, float vy, float xo, float yo,
+                                                   const float *__restrict__ grad_out, const float *__restrict__ out,
+                                                   const signed char *__restrict__ argmax, float *__restrict__ partial) {
+    __shared__ float red[kBlock / 64][64][kPfnBwdVals + 1];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const bool live = lane < C;
+    float w[kPfnIn];
+#pragma unroll
+    for (int j = 0; j < kPfnIn; ++j) w[j] = live ? wt[(size_t)j * C + lane] : 0.f;
+    const float mean = live ? stats[lane] : 0.f, invstd = live ? stats[C + lane] : 0.f;
+    float acc[kPfnBwdVals];
+#pragma unroll
+    for (int j = 0; j < kPfnBwdVals; ++j) acc[j] = 0.f;
+    for (int p = blockIdx.x * (kBlock / 64) + wv; p < P; p += gridDim.x * (kBlock / 64)) {
+        const float4 *pv = reinterpret_cast<const float4 *>(voxels) + (size_t)p * T;
+        const PfnPillar pl = pfn_pillar(pv, T, num_points[p], coords, p, vx, vy, xo, yo, lane);
+        if (!live) continue;
+        const float g = grad_out[(size_t)p * C + lane];
+        const float dz = out[(size_t)p * C + lane] > 0.f ? g : 0.f;
+        const int t = argmax[(size_t)p * C + lane];
+        float x = 0.f;
+        float f[kPfnIn];
+#pragma unroll
+        for (int j = 0; j < kPfnIn; ++j) f[j] = 0.f;
+        if (t >= 0) {
+            pfn_decorate(pv[t], pl, f);
+#pragma unroll
+            for (int j = 0; j < kPfnIn; ++j) x = fmaf(f[j], w[j], x);
+        }
+        acc[0] += dz;
+        acc[1] = fmaf(dz, (x - mean) * invstd, acc[1]);
+#pragma unroll
+        for (int j = 0; j < kPfnIn; ++j) acc[2 + j] = fmaf(dz, f[j], acc[2 + j]);
+    }
+#pragma unroll
+    for (int j = 0; j < kPfnBwdVals; ++j) red[wv][lane][j] = acc[j];
+    __syncthreads();
+    if (wv == 0 && live)
+#pragma unroll
+        for (int j = 0; j < kPfnBwdVals; ++j) {
+            float v = 0.f;
+            for (int k = 0; k < kBlock / 64; ++k) v += red[k][lane][j];
+            partial[((size_t)blockIdx.x * C + lane) * kPfnBwdVals + j] = v;
+        }
+}
+
+// one block per channel: dweight_t[j][c], dgamma[c], dbeta[c]
+__global__ __launch_bounds__(kBlock) void k_pfn_bwd_finalize(const float *__restrict__ partial, int blocks, int C, double rows,
+                                                            const float *__restrict__ gamma, const float *__restrict__ stats,
+                                                            float *__restrict__ dweight_t, float *__restrict__ dgamma,
+                                                            float *__restrict__ dbeta) {
+    __shared__ double sh[kBlock / 64];
+    const int c = blockIdx.x;
+    double tot[kPfnBwdVals];
+    for (int j = 0; j < kPfnBwdVals; ++j) {
+        double v = 0.0;
+        for (int b = threadIdx.x; b < blocks; b += kBlock) v += (double)partial[((size_t)b * C + c) * kPfnBwdVals + j];
+        tot[j] = block_sum_f64(v, sh);
+    }
+    if (threadIdx.x == 0) {
+        const double mean = stats[c], invstd = stats[C + c], ga = gamma[c];
+        const double db = tot[0], dg = tot[1];
+        dbeta[c] = (float)db;
+        dgamma[c] = (float)dg;
+        for (int j = 0; j < kPfnIn; ++j) {
+            const double s1 = stats[(size_t)C * (2 + kPfnIn) + j], m = stats[(size_t)2 * C + (size_t)c * kPfnIn + j];
+            dweight_t[(size_t)j * C + c] = (float)(ga * invstd * (tot[2 + j] - db / rows * s1 - dg / rows * invstd * (m - mean * s1)));
+        }
+    }
+}
+
+static int pfn_blocks(int P) {
+    int b = div_up(P > 0 ? P : 1, kBlock / 64);
+    return b > kPfnMaxBlocks ? kPfnMaxBlocks : b;
+}
+
 // ---- block filter ---------------------------------------------------------------------------------
 __device__ __forceinline__ int f2ord(float f) {  // monotonic float -> int map for atomicMin/Max
     int i = __float_as_int(f);
@@ -176,6 +438,62 @@ SEC_API int sec_pfn_fwd(const float *voxels, const int *num_points, const int *c
     else if (out_dtype == SEC_F16) SEC_PFN(__half);
     else return SEC_E_UNSUPPORTED;
 #undef SEC_PFN
+    return check_launch();
+}
+
+SEC_API size_t sec_pfn_train_workspace_bytes(int num_pillars, int channels) {
+    if (num_pillars < 0 || channels <= 0 || channels > 64) return 0;
+    const size_t b = (size_t)pfn_blocks(num_pillars);
+    return align_up(b * channels * kPfnStatVals * sizeof(float)) + align_up(b * kPfnIn * sizeof(float));
+}
+
+SEC_API int sec_pfn_train_fwd(const float *voxels, const int *num_points, const int *coords, int num_pillars, int max_points,
+                              int num_features, const float *weight_t, const float *gamma, const float *beta, float eps,
+                              float momentum, float *running_mean, float *running_var, int channels, float vx, float vy,
+                              float x_offset, float y_offset, float *out, signed char *argmax, float *stats, void *workspace,
+                              size_t workspace_bytes, void *stream) {
+    if (num_pillars < 0 || max_points <= 0 || max_points > 127 || channels <= 0 || !weight_t || !gamma || !beta || !out || !argmax || !stats)
+        return SEC_E_INVALID;
+    if (num_features != 4 || channels > 64) return SEC_E_UNSUPPORTED;
+    if (!workspace || workspace_bytes < sec_pfn_train_workspace_bytes(num_pillars, channels)) return SEC_E_WORKSPACE;
+    if (num_pillars == 0) return SEC_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int blocks = pfn_blocks(num_pillars);
+    float *partial = (float *)workspace;
+    float *partial_s1 = (float *)((char *)workspace + align_up((size_t)blocks * channels * kPfnStatVals * sizeof(float)));
+    hipLaunchKernelGGL(k_pfn_stats, dim3(blocks), dim3(kBlock), 0, st, voxels, num_points, coords, num_pillars, max_points, weight_t,
+                       channels, vx, vy, x_offset, y_offset, partial, partial_s1);
+    const double rows = (double)num_pillars * (double)max_points;
+    hipLaunchKernelGGL(k_pfn_finalize, dim3(channels + 1), dim3(kBlock), 0, st, partial, partial_s1, blocks, channels, rows, eps,
+                       momentum, running_mean, running_var, stats);
+    hipLaunchKernelGGL(k_pfn_fwd_train, dim3(div_up(num_pillars, kBlock / 64)), dim3(kBlock), 0, st, voxels, num_points, coords,
+                       num_pillars, max_points, weight_t, gamma, beta, stats, channels, vx, vy, x_offset, y_offset, out, argmax);
+    return check_launch();
+}
+
+SEC_API int sec_pfn_train_bwd(const float *voxels, const int *num_points, const int *coords, int num_pillars, int max_points,
+                              int num_features, const float *weight_t, const float *gamma, const float *stats, int channels, float vx,
+                              float vy, float x_offset, float y_offset, const float *grad_out, const float *out,
+                              const signed char *argmax, float *dweight_t, float *dgamma, float *dbeta, void *workspace,
+                              size_t workspace_bytes, void *stream) {
+    if (num_pillars < 0 || max_points <= 0 || max_points > 127 || channels <= 0 || !weight_t || !gamma || !stats || !grad_out || !out ||
+        !argmax || !dweight_t || !dgamma || !dbeta)
+        return SEC_E_INVALID;
+    if (num_features != 4 || channels > 64) return SEC_E_UNSUPPORTED;
+    if (!workspace || workspace_bytes < sec_pfn_train_workspace_bytes(num_pillars, channels)) return SEC_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    if (num_pillars == 0) {
+        int rc = hip_ok(hipMemsetAsync(dweight_t, 0, sizeof(float) * kPfnIn * channels, st));
+        if (!rc) rc = hip_ok(hipMemsetAsync(dgamma, 0, sizeof(float) * channels, st));
+        if (!rc) rc = hip_ok(hipMemsetAsync(dbeta, 0, sizeof(float) * channels, st));
+        return rc;
+    }
+    const int blocks = pfn_blocks(num_pillars);
+    float *partial = (float *)workspace;
+    hipLaunchKernelGGL(k_pfn_bwd, dim3(blocks), dim3(kBlock), 0, st, voxels, num_points, coords, num_pillars, max_points, weight_t, stats,
+                       channels, vx, vy, x_offset, y_offset, grad_out, out, argmax, partial);
+    hipLaunchKernelGGL(k_pfn_bwd_finalize, dim3(channels), dim3(kBlock), 0, st, partial, blocks, channels,
+                       (double)num_pillars * (double)max_points, gamma, stats, dweight_t, dgamma, dbeta);
     return check_launch();
 }
 

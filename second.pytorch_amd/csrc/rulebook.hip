@@ -740,6 +740,20 @@ __device__ __forceinline__ int bm_rank(const unsigned *__restrict__ bm, const in
     return bm_word_prefix(bm, prefix8, (size_t)(lin >> 5)) + __popc(word & (bit - 1u));
 }
 
+// Site map of the outputs of a sorted build, straight from its bitmap: map[cell] = rank + 1 (the output row, rows are numbered
+// by ascending cell index) or 0.  One launch that writes every cell -- the generic sec_sparse_site_map needs a zero fill and a
+// scatter.
+__global__ __launch_bounds__(kBlock) void k_bm_site_map(const unsigned *__restrict__ bm, const int *__restrict__ prefix8,
+                                                       const int *__restrict__ num_dev, int rows_cap, long long cells,
+                                                       int *__restrict__ map) {
+    const long long i = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= cells) return;
+    int rows = num_dev ? *num_dev : rows_cap;
+    if (rows > rows_cap) rows = rows_cap;
+    const int r = bm_rank(bm, prefix8, (unsigned)i);
+    map[i] = (r >= 0 && r < rows) ? r + 1 : 0;
+}
+
 template <int GEO>
 __global__ __launch_bounds__(kBlock) void k_bm_tables(const int *__restrict__ indices, RbGeom g, const int *__restrict__ n_dev,
                                                      const unsigned *__restrict__ bm, const int *__restrict__ prefix,
@@ -1177,6 +1191,19 @@ SEC_API int sec_rulebook_subm3d_after_conv_sorted(const int *indices, int n_in, 
     return check_launch();
 }
 
+
+SEC_API int sec_sparse_site_map_sorted(const void *conv_workspace, size_t conv_workspace_bytes, const int *num_dev, int rows_cap,
+                                       int batch, int d, int h, int w, int *site_map, void *stream) {
+    if (!conv_workspace || batch <= 0 || d <= 0 || h <= 0 || w <= 0 || rows_cap < 0 || !site_map) return SEC_E_INVALID;
+    const int shape[3] = {d, h, w};
+    const long long cells = bm_cells(batch, shape);
+    if (cells >= (1ll << 32) - 64) return SEC_E_UNSUPPORTED;
+    BmWorkspace wk = carve_bm(const_cast<void *>(conv_workspace), conv_workspace_bytes, 0, 1, cells);
+    if (wk.bytes > conv_workspace_bytes) return SEC_E_WORKSPACE;
+    hipLaunchKernelGGL(k_bm_site_map, dim3(div_up(cells, (long long)kBlock)), dim3(kBlock), 0, (hipStream_t)stream, wk.bm, wk.prefix,
+                       num_dev, rows_cap, cells, site_map);
+    return check_launch();
+}
 
 SEC_API int sec_rulebook_conv3d_tables(int n_in, const int *h_ksize3, const int *h_stride3, const int *h_dilation3,
                                        int out_per_in_hint, int *nbr_out, int nbr_out_rows, int *nbr_in, int prefilled,

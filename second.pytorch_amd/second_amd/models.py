@@ -159,7 +159,9 @@ class PFNLayer(nn.Module):
 
 class PillarFeatureNet(nn.Module):
     """One-layer PillarFeatureNet (pointpillars.py:150-237); keys pfn_layers.0.{linear,norm}.  Inference on the
-    GPU runs the fused sec_pfn_fwd kernel; the torch formulation below serves training (autograd) and CPU tests."""
+    GPU runs the fused sec_pfn_fwd kernel, training on the GPU sec_pfn_train_fwd / _bwd (ops.PFNTrainFunction: batch statistics,
+    backward through the argmax; SEC_PFN_TRAIN_BACKEND=torch selects the formulation below); the torch formulation serves CPU
+    tests and as the autograd reference of the training kernels."""
 
     def __init__(self, num_input_features=4, num_filters=(64,), voxel_size=(0.2, 0.2, 4), pc_range=(0, -40, -3, 70.4, 40, 1)):
         super().__init__()
@@ -180,6 +182,17 @@ class PillarFeatureNet(nn.Module):
             wt, scale, shift = self.folded()
             return ops.pfn_forward(features.float().contiguous(), num_voxels.int(), coors.int(), wt, scale, shift, self.vx,
                                    self.vy, self.x_offset, self.y_offset, out_dtype=out_dtype, num_dev=num_dev)
+        bn = l.norm
+        if (features.is_cuda and self.training and bn.training and bn.track_running_stats and bn.affine and l.linear.bias is None
+                and os.environ.get("SEC_PFN_TRAIN_BACKEND", "hip") == "hip" and ops.pfn_train_supported(features, bn.num_features)
+                and features.shape[0] > 0):
+            # training on the device: sec_pfn_train_fwd / _bwd (batch statistics, argmax backward), no [P, T, C] tensor
+            mom = bn.momentum if bn.momentum is not None else 0.1
+            out = ops.PFNTrainFunction.apply(features.contiguous(), num_voxels, coors.int(), l.linear.weight, bn.weight, bn.bias,
+                                             bn.running_mean, bn.running_var, bn.eps, mom,
+                                             (self.vx, self.vy, self.x_offset, self.y_offset))
+            bn.num_batches_tracked += 1
+            return out
         n = num_voxels.to(features.dtype).view(-1, 1, 1)
         xyz = features[:, :, :3]
         mean = xyz.sum(1, keepdim=True) / n
@@ -295,6 +308,12 @@ class SparseBEV:
         self.batch_size, self.spatial_shape = sp.batch_size, [int(v) for v in sp.spatial_shape]
 
     def site_map(self):
+        # rows numbered by the sorted build of the last strided layer: the map is that build's bitmap ranks (one launch)
+        tbl = getattr(self.sp, "site_bitmap", None)
+        if (tbl is not None and tbl[0] == (self.indices.data_ptr(), self.indices.shape[0]) and isinstance(tbl[1][0], str)
+                and tbl[1][0] == "sorted"):
+            tbl[1][1].record_stream(torch.cuda.current_stream())
+            return ops.sparse_site_map_sorted(tbl[1][1], self.indices.shape[0], self.batch_size, self.spatial_shape, num_dev=self.num_dev)
         return ops.sparse_site_map(self.indices, self.batch_size, self.spatial_shape, num_dev=self.num_dev)
 
     def dense(self):

@@ -452,6 +452,63 @@ def pfn_forward(voxels, num_points, coords, weight_t, scale, shift, vx, vy, x_of
     return out
 
 
+def pfn_train_supported(voxels, channels):
+    return bool(voxels.is_cuda and voxels.dtype == torch.float32 and voxels.dim() == 3 and voxels.shape[2] == 4
+                and voxels.shape[1] <= 127 and channels <= 64)
+
+
+class PFNTrainFunction(torch.autograd.Function):
+    """PFNLayer in training mode (Linear(9, C) -> BatchNorm1d batch statistics -> ReLU -> max over the points; pointpillars.py:51-65)
+    on sec_pfn_train_fwd / sec_pfn_train_bwd: the [P, T, C] activation tensor of the torch formulation never exists.  Gradients for
+    linear.weight [C, 9], the BatchNorm weight and bias; the points get none (they are data).  running_mean / running_var are
+    updated in place like torch.nn.BatchNorm1d does."""
+
+    @staticmethod
+    def forward(ctx, voxels, num_points, coords, weight, gamma, beta, running_mean, running_var, eps, momentum, geom):
+        rt.require_gpu(voxels, num_points, coords, weight, gamma, beta)
+        assert voxels.dtype == torch.float32 and voxels.is_contiguous() and coords.dtype == torch.int32
+        p, t, f = voxels.shape
+        c = weight.shape[0]
+        wt = weight.detach().float().t().contiguous()
+        ga, be = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        dev = voxels.device
+        out = torch.empty((p, c), dtype=torch.float32, device=dev)
+        arg = torch.empty((p, c), dtype=torch.int8, device=dev)
+        stats = torch.empty((c * 11 + 9,), dtype=torch.float32, device=dev)
+        l = rt.lib()
+        ws = rt.workspace(l.sec_pfn_train_workspace_bytes(p, c), dev)
+        num_points, coords = num_points.int().contiguous(), coords.contiguous()
+        vx, vy, xo, yo = [float(v) for v in geom]
+        rc = l.sec_pfn_train_fwd(rt.ptr(voxels), rt.ptr(num_points), rt.ptr(coords), p, t, f, rt.ptr(wt), rt.ptr(ga), rt.ptr(be),
+                                 float(eps), float(momentum), rt.ptr(running_mean), rt.ptr(running_var), c, vx, vy, xo, yo,
+                                 rt.ptr(out), rt.ptr(arg), rt.ptr(stats), rt.ptr(ws), ws.numel(), rt.stream())
+        rt.check(rc, "sec_pfn_train_fwd")
+        ctx.save_for_backward(voxels, num_points, coords, wt, ga, stats, out, arg)
+        ctx.geom = (vx, vy, xo, yo)
+        ctx.dtypes = (weight.dtype, gamma.dtype, beta.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        voxels, num_points, coords, wt, ga, stats, out, arg = ctx.saved_tensors
+        p, t, f = voxels.shape
+        c = wt.shape[1]
+        dev = voxels.device
+        dwt = torch.empty((9, c), dtype=torch.float32, device=dev)
+        dga = torch.empty((c,), dtype=torch.float32, device=dev)
+        dbe = torch.empty((c,), dtype=torch.float32, device=dev)
+        l = rt.lib()
+        ws = rt.workspace(l.sec_pfn_train_workspace_bytes(p, c), dev)
+        g = grad_out.float().contiguous()
+        vx, vy, xo, yo = ctx.geom
+        rc = l.sec_pfn_train_bwd(rt.ptr(voxels), rt.ptr(num_points), rt.ptr(coords), p, t, f, rt.ptr(wt), rt.ptr(ga), rt.ptr(stats), c,
+                                 vx, vy, xo, yo, rt.ptr(g), rt.ptr(out), rt.ptr(arg), rt.ptr(dwt), rt.ptr(dga), rt.ptr(dbe),
+                                 rt.ptr(ws), ws.numel(), rt.stream())
+        rt.check(rc, "sec_pfn_train_bwd")
+        wd, gd, bd = ctx.dtypes
+        return (None, None, None, dwt.t().contiguous().to(wd), dga.to(gd), dbe.to(bd), None, None, None, None, None)
+
+
 @_traced("voxel_block_filter")
 def voxel_block_filter(vox, grid_size_xy, block_factor, block_size, height_threshold, height_high_threshold=3.0,
                        sync=True):
@@ -541,6 +598,19 @@ def sparse_site_map(indices, batch_size, spatial_shape, num_dev=None):
     rc = rt.lib().sec_sparse_site_map(rt.ptr(indices.contiguous()), indices.shape[0], rt.ptr(num_dev), int(batch_size), d, h, w,
                                       rt.ptr(m), rt.stream())
     rt.check(rc, "sec_sparse_site_map")
+    return m
+
+
+@_traced("sparse_site_map")
+def sparse_site_map_sorted(conv_workspace, rows_cap, batch_size, spatial_shape, num_dev=None):
+    """:func:`sparse_site_map` for the outputs of a sorted-numbering strided build, read off that build's bitmap
+    (``conv_workspace`` = the ``site_table`` workspace of its :func:`rulebook_conv` result): one launch instead of fill + scatter."""
+    rt.require_gpu(conv_workspace)
+    d, h, w = [int(v) for v in spatial_shape]
+    m = torch.empty((int(batch_size), d, h, w), dtype=torch.int32, device=conv_workspace.device)
+    rc = rt.lib().sec_sparse_site_map_sorted(rt.ptr(conv_workspace), conv_workspace.numel(), rt.ptr(num_dev), int(rows_cap),
+                                             int(batch_size), d, h, w, rt.ptr(m), rt.stream())
+    rt.check(rc, "sec_sparse_site_map_sorted")
     return m
 
 

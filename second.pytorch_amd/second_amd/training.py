@@ -89,11 +89,13 @@ class DeviceTrainer:
                 labels, reg_targets, importance = ops.assign_targets_per_class(det.anchors, gt_boxes, gt_offsets, gt_classes,
                                                                                begin, ids, mts, uts)
         if det.pillars:
-            # PointPillars (nuscenes/all.pp.largea): PillarFeatureNet in its differentiable torch formulation (the fused
-            # sec_pfn_fwd kernel is the inference form), differentiable pillar scatter (sec_pillar_scatter / sec_dense_to_sparse),
+            # PointPillars (nuscenes/all.pp.largea): PillarFeatureNet on sec_pfn_train_fwd / _bwd (batch statistics; the [P, T, C]
+            # tensor of the reference formulation is never built), differentiable pillar scatter (sec_pillar_scatter / sec_dense_to_sparse),
             # the three-block RPN on torch convolutions (autocast with 16-bit features)
             with torch.autocast("cuda", dtype=self.amp_dtype or torch.float32, enabled=self.amp_dtype is not None):
                 feats = det.voxel_feature_extractor(vox["voxels"], vox["num_points_per_voxel"], vox["coordinates"])
+                if self.amp_dtype is not None:
+                    feats = feats.to(self.amp_dtype)          # the fused PFN returns fp32; the pseudo image is built in 16 bits
                 spatial = det.middle_feature_extractor(feats.float() if self.amp_dtype is None else feats, vox["coordinates"], batch)
                 preds = det.rpn(spatial)
         elif self.amp_dtype is not None:

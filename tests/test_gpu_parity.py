@@ -253,6 +253,25 @@ def test_rulebook_conv_sorted_static_capacity_and_overflow(ops):
     np.testing.assert_array_equal(small["nbr_out"].cpu().numpy(), nbr_out[:m - 40])
 
 
+def test_site_map_from_the_sorted_builds_bitmap(ops):
+    """sec_sparse_site_map_sorted (one launch off the strided build's bitmap) == the generic fill + scatter map of the same
+    outputs, eager and static-capacity, including a capacity smaller than the output count (rows past it read as absent)."""
+    rng = np.random.default_rng(9)
+    shape = (11, 24, 19)
+    idx = _random_indices(rng, 3, shape, 500)
+    rb = ops.rulebook_conv(dev(idx), 3, shape, 3, 2, 1, 1, numbering="sorted")
+    m = rb["num_out"]
+    want = ops.sparse_site_map(rb["out_indices"], 3, rb["out_shape"])
+    got = ops.sparse_site_map_sorted(rb["site_table"][1], m, 3, rb["out_shape"])
+    assert torch.equal(want, got) and int((got > 0).sum()) == m
+    n_dev = dev(np.array([len(idx)], np.int32))
+    for cap in (m + 30, m - 25):
+        st = ops.rulebook_conv(dev(idx), 3, shape, 3, 2, 1, 1, n_dev=n_dev, out_cap=cap, numbering="sorted")
+        want = ops.sparse_site_map(st["out_indices"], 3, st["out_shape"], num_dev=st["num_out_dev"])
+        got = ops.sparse_site_map_sorted(st["site_table"][1], cap, 3, st["out_shape"], num_dev=st["num_out_dev"])
+        assert torch.equal(want, got) and int((got > 0).sum()) == min(cap, m)
+
+
 def test_rulebook_conv_stride_with_dilation_is_refused(ops):
     from second_amd.runtime import SecondHipError
     idx = _random_indices(np.random.default_rng(2), 1, (11, 24, 19), 50)

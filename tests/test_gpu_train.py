@@ -203,3 +203,48 @@ def test_device_trainer_pointpillars_step_runs_and_learns():
         p.grad = None
     losses = [float(tr.step(*args)[0]) for _ in range(6)]
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+
+
+@pytest.mark.parametrize("pillars,points", [(700, 60), (33, 5), (5000, 20)])
+def test_pfn_training_kernels_vs_torch_autograd(pillars, points, monkeypatch):
+    """sec_pfn_train_fwd / sec_pfn_train_bwd (PFNLayer under train(): Linear -> BatchNorm1d batch statistics -> ReLU -> max over the
+    points, pointpillars.py:51-65, and its backward through the argmax) against torch autograd of the reference formulation in
+    fp32: output, gradients of linear.weight / norm.weight / norm.bias, running statistics.  Ragged pillars (1 .. T points, some
+    full), so padded slots enter the statistics and sometimes win the max."""
+    from second_amd.models import PillarFeatureNet
+    torch.manual_seed(pillars)
+    g = torch.Generator().manual_seed(pillars + 1)
+    t = points
+    n = torch.randint(1, t + 1, (pillars,), generator=g)
+    n[:: 7] = t
+    vox = torch.zeros(pillars, t, 4)
+    coors = torch.stack([torch.zeros(pillars, dtype=torch.long), torch.zeros(pillars, dtype=torch.long),
+                         torch.randint(0, 400, (pillars,), generator=g), torch.randint(0, 400, (pillars,), generator=g)], 1).int()
+    for p in range(pillars):
+        k = int(n[p])
+        cx, cy = coors[p, 3].item() * 0.25 - 50 + 0.125, coors[p, 2].item() * 0.25 - 50 + 0.125
+        vox[p, :k, 0] = cx + (torch.rand(k, generator=g) - 0.5) * 0.25
+        vox[p, :k, 1] = cy + (torch.rand(k, generator=g) - 0.5) * 0.25
+        vox[p, :k, 2] = torch.rand(k, generator=g) * 4 - 3
+        vox[p, :k, 3] = torch.rand(k, generator=g)
+    res = {}
+    for backend in ("torch", "hip"):
+        monkeypatch.setenv("SEC_PFN_TRAIN_BACKEND", backend)
+        torch.manual_seed(3)
+        net = PillarFeatureNet(4, (64,), (0.25, 0.25, 8), (-50, -50, -5, 50, 50, 3)).cuda().train()
+        with torch.no_grad():
+            net.pfn_layers[0].norm.weight.uniform_(0.5, 1.5)
+            net.pfn_layers[0].norm.bias.uniform_(-0.3, 0.3)
+        out = net(vox.cuda(), n.int().cuda(), coors.cuda())
+        w = torch.randn(out.shape, generator=torch.Generator().manual_seed(9)).cuda()
+        (out * w).sum().backward()
+        l = net.pfn_layers[0]
+        res[backend] = dict(out=out.detach().float().cpu(), dw=l.linear.weight.grad.cpu(), dg=l.norm.weight.grad.cpu(),
+                            db=l.norm.bias.grad.cpu(), rm=l.norm.running_mean.cpu(), rv=l.norm.running_var.cpu(),
+                            nb=int(l.norm.num_batches_tracked))
+    a, b = res["torch"], res["hip"]
+    assert a["nb"] == b["nb"] == 1
+    for k, tol in (("out", 2e-4), ("dw", 2e-3), ("dg", 2e-3), ("db", 2e-3), ("rm", 1e-5), ("rv", 1e-5)):
+        scale = max(a[k].abs().max().item(), 1e-6)
+        err = (a[k] - b[k]).abs().max().item() / scale
+        assert err <= tol, (k, err)
