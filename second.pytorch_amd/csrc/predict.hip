@@ -509,12 +509,32 @@ __global__ __launch_bounds__(kSelThreads) void k_predict_select_chunk(const T *_
     const int Kc = K < nloc ? K : nloc;
     const int n_base = wv * (KP * 128) + lane * 2;
     unsigned k2[KP];
+    // (a, y, x) of the thread's first anchor by division, of the others by stepping (anchor n = (a * H + y) * W + x): the runtime
+    // divisions of anchor_key() were a third of this kernel's instructions
+    int ax, ay, aa;
+    {
+        const int n0 = base + n_base;
+        ax = n0 % g.W;
+        const int t0 = n0 / g.W;
+        ay = t0 % g.H;
+        aa = t0 / g.H;
+    }
+    auto key_at = [&](int a, int y, int x) -> unsigned {
+        const T *p = cls + b * v.sb + a * v.sa + y * v.sy + x * v.sx;
+        float best = ldf(p);
+        for (int c2 = 1; c2 < g.nc; ++c2) { const float f = ldf(p + c2 * v.sc); if (f > best) best = f; }   // as anchor_key()
+        return f2key(best) >> 16;
+    };
 #pragma unroll
     for (int i = 0; i < KP; ++i) {
         const int a0 = base + n_base + i * 128;
-        const unsigned ka = a0 < N ? anchor_key(cls, v, g, b, a0, nullptr) >> 16 : 0u;        // slots beyond the frame hold key 0
-        const unsigned kb = a0 + 1 < N ? anchor_key(cls, v, g, b, a0 + 1, nullptr) >> 16 : 0u;
+        int bx = ax + 1, by = ay, ba = aa;             // the pair's second anchor
+        if (bx >= g.W) { bx = 0; if (++by >= g.H) { by = 0; ++ba; } }
+        const unsigned ka = a0 < N ? key_at(aa, ay, ax) : 0u;          // slots beyond the frame hold key 0
+        const unsigned kb = a0 + 1 < N ? key_at(ba, by, bx) : 0u;
         k2[i] = ka | (kb << 16);
+        ax += 128;
+        while (ax >= g.W) { ax -= g.W; if (++ay >= g.H) { ay = 0; ++aa; } }
     }
     unsigned short *ok_ = cand_key + ((size_t)b * chunks + c) * kSelThreads;
     int *oi_ = cand_idx + ((size_t)b * chunks + c) * kSelThreads;
