@@ -813,7 +813,12 @@ extern "C" __attribute__((visibility("default"))) int sec__debug_timeline2(long 
 template <typename T, int CIN, int TH, int ROLL = 0, bool GATHER = false>
 static int launch_conv2d_halo_reg(const void *x, const void *wpk, const float *bias, void *y, const Conv2dParams &p, hipStream_t st,
                                   const int *site_map = nullptr, unsigned feat_bytes = 0) {
-    constexpr size_t lds = (size_t)(TH + 2) * 18 * (CIN / 8) * 16;
+    constexpr size_t lds_tile = (size_t)(TH + 2) * 18 * (CIN / 8) * 16;
+    // SEC_CONV2D_LDS_PAD (bytes, A/B runs): unused dynamic LDS that lowers the workgroups per CU (46 KB tile: 3 per CU; + 12 KB: 2),
+    // leaving registers and LDS for the kernels of the other steps in flight
+    static long lds_pad = -1;
+    if (lds_pad < 0) { const char *e = getenv("SEC_CONV2D_LDS_PAD"); lds_pad = e ? atol(e) : 0; }
+    const size_t lds = lds_tile + (size_t)lds_pad;
     static bool configured = false;
     auto fn = k_conv2d_halo_reg<T, CIN, TH, ROLL, GATHER>;
     if (!configured) {

@@ -191,7 +191,7 @@ class PillarFeatureNet(nn.Module):
             out = ops.PFNTrainFunction.apply(features.contiguous(), num_voxels, coors.int(), l.linear.weight, bn.weight, bn.bias,
                                              bn.running_mean, bn.running_var, bn.eps, mom,
                                              (self.vx, self.vy, self.x_offset, self.y_offset))
-            bn.num_batches_tracked += 1
+            ops.bump_bn_counter(bn)
             return out
         n = num_voxels.to(features.dtype).view(-1, 1, 1)
         xyz = features[:, :, :3]
@@ -217,7 +217,7 @@ class PointPillarsScatter(nn.Module):
         if torch.is_grad_enabled() and voxel_features.requires_grad:   # training: differentiable scatter
             from spconv.functional import PillarScatterFunction
             return PillarScatterFunction.apply(voxel_features.contiguous(), coords.int().contiguous(), batch_size,
-                                               self.ny, self.nx)
+                                               self.ny, self.nx, channels_last)
         return ops.pillar_scatter(voxel_features.contiguous(), coords.int().contiguous(), batch_size, self.ny, self.nx,
                                   channels_last=channels_last, num_dev=num_dev)
 
@@ -409,7 +409,7 @@ def rpn_forward_mixed(rpn, x, dtype):
                 y = ops.Conv3x3Function.apply(x, m.weight)
                 mom = bn.momentum if bn.momentum is not None else 0.1
                 x = ops.BatchNormReluFunction.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, mom, True)
-                bn.num_batches_tracked += 1
+                ops.bump_bn_counter(bn)
                 i, pad = i + 3, 0
                 continue
             with torch.autocast("cuda", dtype=dtype, enabled=x.is_cuda, cache_enabled=False):

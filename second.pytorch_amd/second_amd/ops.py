@@ -358,8 +358,10 @@ def indice_conv_set_variant(variant):
     rt.check(rt.lib().sec_indice_conv_set_variant(int(variant)), "sec_indice_conv_set_variant")
 
 
-def indice_conv_backward(features, weight, nbr_out, nbr_in, dout, need_dfeat=True, need_dweight=True):
-    """(dfeat, dweight) of indice_conv (spconv.ops.indice_conv_backward). nbr_in None => SubM mirror."""
+def indice_conv_backward(features, weight, nbr_out, nbr_in, dout, need_dfeat=True, need_dweight=True, dweight_dtype=None):
+    """(dfeat, dweight) of indice_conv (spconv.ops.indice_conv_backward). nbr_in None => SubM mirror.  The kernels accumulate
+    dweight in fp32; it is returned in ``dweight_dtype`` (default: the weight's dtype; torch.float32 hands a mixed-precision
+    caller the unrounded gradient of its fp32 master weight without a cast launch)."""
     rt.require_gpu(features, weight, nbr_out, dout)
     cin, cout = weight.shape[-2], weight.shape[-1]
     k = weight.numel() // (cin * cout)
@@ -372,7 +374,7 @@ def indice_conv_backward(features, weight, nbr_out, nbr_in, dout, need_dfeat=Tru
                                rt.ptr(nbr_in), dout.shape[0], rt.ptr(dout), rt.ptr(dfeat), rt.ptr(dw),
                                rt.dtype_code(features.dtype), rt.ptr(ws), ws.numel(), rt.stream())
     rt.check(rc, "sec_indice_conv_bwd")
-    return dfeat, (dw.to(weight.dtype) if dw is not None else None)
+    return dfeat, (dw.to(dweight_dtype or weight.dtype) if dw is not None else None)
 
 
 # ----------------------------------------------------------------------------- scatters
@@ -450,6 +452,33 @@ def pfn_forward(voxels, num_points, coords, weight_t, scale, shift, vx, vy, x_of
                               float(y_offset), rt.ptr(out), rt.dtype_code(out_dtype), rt.stream())
     rt.check(rc, "sec_pfn_fwd")
     return out
+
+
+# ---- BatchNorm step counters of the fused training paths ----------------------------------------------------------------------
+# `bn.num_batches_tracked += 1` is one tiny launch per BatchNorm layer (21 per step of the SECOND networks).  Inside
+# deferred_bn_counters() the fused paths only note the counter; leaving the context adds 1 to all of them with one multi-tensor launch.
+_bn_counter_stack = []
+
+
+class deferred_bn_counters:
+    def __enter__(self):
+        _bn_counter_stack.append([])
+        return self
+
+    def __exit__(self, *exc):
+        pending = _bn_counter_stack.pop()
+        if pending:
+            torch._foreach_add_(pending, 1)
+        return False
+
+
+def bump_bn_counter(bn):
+    """num_batches_tracked += 1 now, or at the exit of the enclosing :class:`deferred_bn_counters` (never deferred while a
+    stream is being captured: a captured step must replay its own increments)."""
+    if _bn_counter_stack and not (bn.num_batches_tracked.is_cuda and torch.cuda.is_current_stream_capturing()):
+        _bn_counter_stack[-1].append(bn.num_batches_tracked)
+    else:
+        bn.num_batches_tracked += 1
 
 
 def pfn_train_supported(voxels, channels):

@@ -20,6 +20,7 @@ Here the whole step stays on the GPU and every rank owns one GPU:
 BatchNorm statistics stay per rank (the reference's DataParallel replicas never synchronise them either).
 """
 import math
+import os
 
 import torch
 
@@ -91,13 +92,21 @@ class DeviceTrainer:
         if det.pillars:
             # PointPillars (nuscenes/all.pp.largea): PillarFeatureNet on sec_pfn_train_fwd / _bwd (batch statistics; the [P, T, C]
             # tensor of the reference formulation is never built), differentiable pillar scatter (sec_pillar_scatter / sec_dense_to_sparse),
-            # the three-block RPN on torch convolutions (autocast with 16-bit features)
+            # the three-block RPN through _rpn_mixed (16-bit) or torch convolutions (fp32 / SEC_PP_TRAIN_RPN=torch)
             with torch.autocast("cuda", dtype=self.amp_dtype or torch.float32, enabled=self.amp_dtype is not None):
                 feats = det.voxel_feature_extractor(vox["voxels"], vox["num_points_per_voxel"], vox["coordinates"])
                 if self.amp_dtype is not None:
                     feats = feats.to(self.amp_dtype)          # the fused PFN returns fp32; the pseudo image is built in 16 bits
-                spatial = det.middle_feature_extractor(feats.float() if self.amp_dtype is None else feats, vox["coordinates"], batch)
-                preds = det.rpn(spatial)
+                mixed = self.amp_dtype is not None and os.environ.get("SEC_PP_TRAIN_RPN", "mixed") == "mixed"
+                # the mixed-precision RPN segment works on channels-last activations: the scatter writes them that way
+                spatial = det.middle_feature_extractor(feats.float() if self.amp_dtype is None else feats, vox["coordinates"], batch,
+                                                       channels_last=mixed)
+                if not mixed:
+                    preds = det.rpn(spatial)
+            if mixed:
+                # the same captured mixed-precision RPN segment as config 3: the 128 -> 128 3x3 layers of the second block on the
+                # hand-written kernels, the other widths on MIOpen, forward and backward replayed as two hipGraphs
+                preds = self._rpn_mixed(spatial)
         elif self.amp_dtype is not None:
             # fp32 master weights; 16-bit features through the sparse stack (MFMA forward / dgrad / wgrad kernels) and,
             # under autocast, through the dense RPN; BatchNorm statistics and the loss in fp32
@@ -166,7 +175,8 @@ class DeviceTrainer:
     def step(self, points, point_offsets, gt_boxes, gt_offsets, gt_classes=None):
         """One optimisation step on this rank's shard; returns the device tensor of the six loss scalars (no host sync,
         except with fp16 features: dynamic loss scaling reads one overflow flag per step)."""
-        loss, out6, _ = self.forward_loss(points, point_offsets, gt_boxes, gt_offsets, gt_classes)
+        with ops.deferred_bn_counters():
+            loss, out6, _ = self.forward_loss(points, point_offsets, gt_boxes, gt_offsets, gt_classes)
         if self.loss_scale is None:
             loss.backward()
         else:

@@ -143,9 +143,8 @@ class SparseConvolution(SparseModule):
         if self.weight.dtype == x.features.dtype:
             w, packed = self.weight, self.packed_weight()
         else:
-            # mixed precision (fp32 master weights, 16-bit features): cast under autograd, pack the cast copy for the MFMA path
-            w = self.weight.to(x.features.dtype)
-            packed = _ops.pack_weight(w.detach().contiguous()) if w.is_cuda and w.dtype != torch.float32 else None
+            # mixed precision (fp32 master weights, 16-bit features): IndiceConvFunction casts + packs and returns dW in fp32
+            w, packed = self.weight, None
         feats = Fsp.indice_conv(x.features, w, rb, packed)
         if self.bias is not None:
             feats = feats + self.bias.to(feats.dtype)

@@ -8,6 +8,13 @@ class IndiceConvFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, features, weight, rulebook, packed):
         ctx.rulebook = rulebook
+        ctx.master_dtype = weight.dtype
+        if weight.dtype != features.dtype:
+            # mixed precision (fp32 master weight, 16-bit features): the cast copy is made HERE, outside autograd -- the weight
+            # gradient comes out of the kernels in fp32 and goes straight to the master weight (no fp32 -> 16-bit -> fp32 round
+            # trip: two launches per layer and a rounding of dW less)
+            weight = weight.detach().to(features.dtype)
+            packed = _ops.pack_weight(weight.contiguous()) if weight.is_cuda and weight.dtype != torch.float32 else None
         ctx.save_for_backward(features, weight)
         return _ops.indice_conv(features.contiguous(), weight.contiguous(), rulebook.nbr_out, rulebook.num_out,
                                 packed=packed, num_out_dev=rulebook.num_out_dev)
@@ -20,7 +27,8 @@ class IndiceConvFunction(torch.autograd.Function):
             raise RuntimeError("this rulebook was built with autograd disabled (no input-major table); rebuild it "
                                "under torch.enable_grad() to back-propagate through a strided sparse conv")
         dfeat, dw = _ops.indice_conv_backward(features.contiguous(), weight.contiguous(), rb.nbr_out, rb.nbr_in,
-                                              grad_out.contiguous(), ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+                                              grad_out.contiguous(), ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+                                              dweight_dtype=ctx.master_dtype)
         return dfeat, dw, None, None
 
 
@@ -49,11 +57,11 @@ class PillarScatterFunction(torch.autograd.Function):
     """PointPillarsScatter with a gradient (pointpillars.py:444-476 relies on index assignment under autograd)."""
 
     @staticmethod
-    def forward(ctx, features, coords, batch_size, ny, nx):
+    def forward(ctx, features, coords, batch_size, ny, nx, channels_last=False):
         ctx.save_for_backward(coords)
-        return _ops.pillar_scatter(features, coords, batch_size, ny, nx)
+        return _ops.pillar_scatter(features, coords, batch_size, ny, nx, channels_last=channels_last)
 
     @staticmethod
     def backward(ctx, grad):
         (coords,) = ctx.saved_tensors
-        return _ops.dense_to_sparse(grad, coords), None, None, None, None
+        return _ops.dense_to_sparse(grad, coords), None, None, None, None, None

@@ -150,7 +150,7 @@ class SparseSequential(SparseModule):
                 mom = m.momentum if m.momentum is not None else 0.1
                 input.features = _sec_ops().BatchNormReluFunction.apply(input.features.contiguous(), m.weight, m.bias, m.running_mean,
                                                                        m.running_var, m.eps, mom, relu)
-                m.num_batches_tracked += 1
+                _sec_ops().bump_bn_counter(m)
                 i += 2 if relu else 1
                 continue
             if _is_sparse(m):

@@ -80,11 +80,20 @@ def test_grad_bucket_presence_and_stale_half_gradients():
     assert net["unused"].weight.grad is None and net["unused"].bias.grad is None      # no rank had a gradient: stays None
     assert net["a"].weight.grad.data_ptr() == bucket.views[0].data_ptr()              # fp32: a view of the bucket
     g1 = net["h"].weight.grad.clone()
-    bucket.zero_grad()
+    ga = net["a"].weight.grad.clone()
+    bucket.zero_grad(set_to_none=False)                                                # the in-place form: one fill, views stay
     assert net["h"].weight.grad is None and float(bucket.flat.abs().sum()) == 0.0
+    assert net["a"].weight.grad.data_ptr() == bucket.views[0].data_ptr()
     backward()
     bucket.allreduce()
     assert torch.equal(net["h"].weight.grad, g1)                                       # not g1 + g1: nothing stale was re-packed
+    assert torch.equal(net["a"].weight.grad, ga)
+    bucket.zero_grad()                                                                 # default: every grad dropped, nothing filled;
+    assert all(p.grad is None for p in bucket.params)                                  # the next backward hands its tensors over
+    backward()
+    bucket.allreduce()                                                                 # pack gathers them (stale bucket contents overwritten)
+    assert torch.equal(net["a"].weight.grad, ga) and torch.equal(net["h"].weight.grad, g1)
+    assert net["a"].weight.grad.data_ptr() == bucket.views[0].data_ptr() and net["unused"].weight.grad is None
     # the sync-free form keeps the old contract: zeros for absent gradients
     b2 = D.GradBucket(net)
     net.zero_grad(set_to_none=True)

@@ -2,6 +2,8 @@
 """Summarise a rocprofv3 (rocpd sqlite) kernel trace into the per-kernel stats table we commit under profiles/.
 
     python tools/rocprof_summary.py gpurun_out/prof1/r01_results.db [--steps N] > profiles/r01_....txt
+    python tools/rocprof_summary.py <db> --after 0.5 --steps N      # only the dispatches of the last half of the run (steady state)
+    python tools/rocprof_summary.py <db> --last-steps 20 --marker k_vox_init   # the 20 steps before the marker kernel's last launch
     python tools/rocprof_summary.py <db> --timeline k_vox_init      # one step (between the last two launches of that kernel):
                                                                     # every launch with start offset, duration and the idle gap before it
 """
@@ -35,8 +37,20 @@ def main():
         return timeline(db, sys.argv[sys.argv.index("--timeline") + 1])
     steps = int(sys.argv[sys.argv.index("--steps") + 1]) if "--steps" in sys.argv else None
     c = sqlite3.connect(db)
+    where = ""
+    if "--after" in sys.argv:        # only dispatches in the last part of the run, e.g. --after 0.5: skips warm-up (MIOpen's find runs)
+        frac = float(sys.argv[sys.argv.index("--after") + 1])
+        t0, t1 = c.execute("select min(start), max(end) from kernels").fetchone()
+        where = f" where start >= {t0 + (t1 - t0) * frac:.0f}"
+    if "--last-steps" in sys.argv:   # --last-steps N --marker k_vox_init: the N steps before the last launch of the marker kernel
+        nst = int(sys.argv[sys.argv.index("--last-steps") + 1])
+        marker = sys.argv[sys.argv.index("--marker") + 1]
+        marks = [r[0] for r in c.execute(f"select start from kernels where name like '%{marker}%' order by start")]
+        if len(marks) > nst:
+            where = f" where start >= {marks[-nst - 1]} and start < {marks[-1]}"
+            steps = nst
     rows = list(c.execute("select name, count(*), sum(end-start)/1e3, avg(end-start)/1e3, min(end-start)/1e3, "
-                          "max(end-start)/1e3 from kernels group by name order by 3 desc"))
+                          f"max(end-start)/1e3 from kernels{where} group by name order by 3 desc"))
     tot = sum(r[2] for r in rows)
     n = sum(r[1] for r in rows)
     print(f"# rocprofv3 --kernel-trace --stats summary of {db}")
