@@ -486,11 +486,8 @@ __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(con
             dst[mt] = hal[hp * CH + ((kc_ * 8 + s * 2 + hh) ^ halo_key<CH, HW_, true>(hp))];
         }
     };
-    // per_xcd == 0 (gathered first layer): tiles dealt round-robin over the XCDs.  Its input rows are a few MB (no halo locality to
-    // keep in one L2), but its LIVE tiles are what cost time, and a frame per XCD made the frame with the most sites the launch's
-    // duration (> 96 live tiles on an XCD's 96 slots = a second round)
-    const int tile = per_xcd > 0 ? xcd * per_xcd + local : (int)blockIdx.x;
-    if ((per_xcd > 0 && local >= per_xcd) || tile >= ntile) return;
+    const int tile = xcd * per_xcd + local;
+    if (local >= per_xcd || tile >= ntile) return;
 #ifdef SEC_CONV_TIMELINE
     long long *tl = g_timeline2;
     long long tl0 = 0, tl1 = 0, tl2 = 0;
@@ -840,10 +837,8 @@ static int launch_conv2d_halo_reg(const void *x, const void *wpk, const float *b
     const int per_xcd = div_up(p.batch * ty * tx, 8);
     const int gx = per_xcd * 8;
     set_last_kernel("k_conv2d_halo_reg<%s, %d, %d, %d, %s>", dtype_name<T>(), CIN, TH, ROLL, GATHER ? "true" : "false");
-    static int interleave = -1;
-    if (interleave < 0) { const char *e = getenv("SEC_GATHER_INTERLEAVE"); interleave = e ? atoi(e) : 1; }
-    hipLaunchKernelGGL(fn, dim3(gx, p.cout / 128), dim3(256), lds, st, (const T *)x, (const T *)wpk, bias, (T *)y, p, ty, tx,
-                       (GATHER && interleave) ? 0 : per_xcd, site_map, feat_bytes);
+    hipLaunchKernelGGL(fn, dim3(gx, p.cout / 128), dim3(256), lds, st, (const T *)x, (const T *)wpk, bias, (T *)y, p, ty, tx, per_xcd,
+                       site_map, feat_bytes);
     return check_launch();
 }
 
