@@ -36,6 +36,26 @@ __device__ __forceinline__ float key2f(unsigned k) {
 }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// 16-bit order-preserving keys of 16-bit logits.  bf16: the high half of f2key(float(x)) (a bf16 is the high half of its float);
+// fp16: the same sign trick on the half's own bits (all 16 bits are significant, none are lost).  key16_score() is the sigmoid of
+// the logit a key stands for.
+template <typename T> __device__ __forceinline__ unsigned key16_of(float best);
+template <> __device__ __forceinline__ unsigned key16_of<__hip_bfloat16>(float best) { return f2key(best) >> 16; }
+template <> __device__ __forceinline__ unsigned key16_of<__half>(float best) {
+    const unsigned u = __half_as_ushort(__float2half_rn(best));      // exact: `best` came from a half
+    return (u & 0x8000u) ? (~u & 0xffffu) : (u | 0x8000u);
+}
+template <> __device__ __forceinline__ unsigned key16_of<float>(float best) { return f2key(best) >> 16; }   // unused (fp32 heads take the 32-bit path)
+template <typename T> __device__ __forceinline__ float key16_logit(unsigned k);
+template <> __device__ __forceinline__ float key16_logit<__hip_bfloat16>(unsigned k) {
+    return key2f((k << 16) | ((k & 0x8000u) ? 0u : 0xffffu));        // low half of f2key: 0 for a non-negative bf16, 0xffff for a negative one
+}
+template <> __device__ __forceinline__ float key16_logit<__half>(unsigned k) {
+    const unsigned u = (k & 0x8000u) ? (k & 0x7fffu) : (~k & 0xffffu);
+    return __half2float(__ushort_as_half((unsigned short)u));
+}
+template <> __device__ __forceinline__ float key16_logit<float>(unsigned k) { return key16_logit<__hip_bfloat16>(k); }
+
 template <typename T>
 __device__ __forceinline__ unsigned anchor_key(const T *cls, const View5 &v, const PredGeom &g, int b, int n, int *label) {
     int x = n % g.W;
@@ -76,7 +96,7 @@ __global__ __launch_bounds__(kBlock) void k_predict_keys16(const T *__restrict__
     long long t = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (t >= (long long)g.batch * ns) return;
     const int b = (int)(t / ns), n = (int)(t % ns);
-    keys[t] = n < N ? (unsigned short)(anchor_key(cls, v, g, b, n, nullptr) >> 16) : (unsigned short)0;
+    keys[t] = n < N ? (unsigned short)key16_of<T>(key2f(anchor_key(cls, v, g, b, n, nullptr))) : (unsigned short)0;
 }
 
 // one workgroup per frame
@@ -240,7 +260,7 @@ __global__ __launch_bounds__(kSelThreads) void k_predict_select(const T *__restr
 // INDIRECT (second stage of the chunked select): `keys` are the per-chunk candidate keys written by k_predict_select_chunk
 // (n_keys of them per frame, chunk-major, ascending anchor index among equal keys inside and across chunks -- which is all the
 // tie ranking needs), slot_anchor their anchor ids.
-template <typename T, int KP, bool INDIRECT = false>     // 16-bit logits only (bf16); KP = key PAIRS (dwords) per thread
+template <typename T, int KP, bool INDIRECT = false>     // 16-bit logits (bf16 / fp16: key16_of); KP = key PAIRS (dwords) per thread
 __global__ __launch_bounds__(kSelThreads) void k_predict_select_reg(const T *__restrict__ cls, View5 v, PredGeom g, int K,
                                                                     float score_thr, const unsigned short *__restrict__ keys,
                                                                     int ns, int *__restrict__ top_idx,
@@ -456,14 +476,14 @@ __global__ __launch_bounds__(kSelThreads) void k_predict_select_reg(const T *__r
     }
     const int n_valid = INDIRECT ? 0x7fffffff : N;    // below: mi < n_valid == a real anchor
     if (tid < K) {
-        float sc = mi < n_valid ? sigmoidf_(key2f(mk)) : 0.0f;      // empty slots (fewer than K selected): score 0, anchor 0
+        float sc = mi < n_valid ? sigmoidf_(key16_logit<T>(mk >> 16)) : 0.0f;      // empty slots (fewer than K selected): score 0, anchor 0
         int lab = 0;
         if (g.nc > 1 && mi < n_valid) anchor_key(cls, v, g, b, mi, &lab);
         top_idx[(size_t)b * K + tid] = mi < n_valid ? mi : 0;
         top_score[(size_t)b * K + tid] = sc;
         top_label[(size_t)b * K + tid] = lab;
     }
-    const bool ok = tid < K && mi < n_valid && sigmoidf_(key2f(mk)) >= score_thr;
+    const bool ok = tid < K && mi < n_valid && sigmoidf_(key16_logit<T>(mk >> 16)) >= score_thr;
     const unsigned long long m = __ballot(ok);
     __syncthreads();
     if (lane == 0) wsum[wv] = __popcll(m);
@@ -488,7 +508,7 @@ __global__ __launch_bounds__(kSelThreads) void k_predict_select_reg(const T *__r
 // cand_key / cand_idx [frame][chunk][1024], zero / 0x7fffffff padded.  The frame's top K is a subset of the union of its chunks'
 // top K, with the same tie order, so stage 2 (k_predict_select_reg<INDIRECT>) selects and sorts ~9 k candidates instead of
 // bisecting 70 k keys in one workgroup: 65 us -> two launches of ~6 and ~17 us.
-constexpr int kSelChunk = 8192;                  // 16 waves x 4 key pairs x 128
+constexpr int kSelChunk = 8192;                  // 16 waves x 4 key pairs x 128 (KP = 4)
 // Round 3: (a) the keys are computed HERE from the head output (the separate whole-chip k_predict_keys16 launch, 12.5 us, is gone
 // from this path; a chunk's 8192 anchors are 8192 scattered 2-byte reads either way); (b) `thr16` > 0 is a 16-bit key at or below
 // the key of every logit whose score reaches the caller's threshold (computed conservatively on the host): when no more than K
@@ -496,16 +516,18 @@ constexpr int kSelChunk = 8192;                  // 16 waves x 4 key pairs x 128
 // chunk's contribution and the 16-step bisection is skipped.  Entries below the threshold can then be missing from the frame's
 // top K; they lie behind counts[b] and were never part of the reference's result (voxelnet.py:551-570 masks by the threshold
 // before its topk).
-template <typename T>
+// KP = key pairs per thread: 4 (8192-anchor chunks, the usual heads) or 36 (73 728-anchor chunks: heads of > 600 k anchors per
+// frame -- nuScenes all.fhd has 1.23 M -- whose 8192-anchor chunks would hand the second stage more candidate slots than it holds).
+template <typename T, int KP>
 __global__ __launch_bounds__(kSelThreads) void k_predict_select_chunk(const T *__restrict__ cls, View5 v, PredGeom g, int N, int K,
                                                                       int chunks, unsigned thr16, unsigned short *__restrict__ cand_key,
                                                                       int *__restrict__ cand_idx) {
-    constexpr int KP = 4;
+    constexpr int kChunk = kSelThreads * 2 * KP;
     __shared__ int sweep_tot[20];
     __shared__ int w_eq[kSelThreads / 64], w_gt[kSelThreads / 64];
     const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int base = c * kSelChunk;
-    const int nloc = min(kSelChunk, N - base);                         // > 0 by construction of the grid
+    const int base = c * kChunk;
+    const int nloc = min(kChunk, N - base);                            // > 0 by construction of the grid
     const int Kc = K < nloc ? K : nloc;
     const int n_base = wv * (KP * 128) + lane * 2;
     unsigned k2[KP];
@@ -523,7 +545,7 @@ __global__ __launch_bounds__(kSelThreads) void k_predict_select_chunk(const T *_
         const T *p = cls + b * v.sb + a * v.sa + y * v.sy + x * v.sx;
         float best = ldf(p);
         for (int c2 = 1; c2 < g.nc; ++c2) { const float f = ldf(p + c2 * v.sc); if (f > best) best = f; }   // as anchor_key()
-        return f2key(best) >> 16;
+        return key16_of<T>(best);
     };
 #pragma unroll
     for (int i = 0; i < KP; ++i) {
@@ -705,15 +727,22 @@ static View5 mkview(const int64_t *s) { return View5{s[0], s[1], s[2], s[3], s[4
 // a 16-bit key no larger than the key of any bf16 logit whose sigmoid reaches `thr` (0 = no such bound): the logit of thr, lowered
 // by more than bf16's and sigmoidf's rounding, mapped like f2key() >> 16, minus one key step (truncation of a negative value's
 // bits rounds it UP)
-static unsigned conservative_thr16(float thr) {
+static unsigned conservative_thr16(float thr, int dtype) {
     if (!(thr > 0.0f) || !(thr < 1.0f)) return 0u;
     float x = logf(thr / (1.0f - thr));
     x -= fabsf(x) / 64.0f + 0.01f;
-    unsigned u;
-    __builtin_memcpy(&u, &x, 4);
-    const unsigned key = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-    const unsigned k16 = key >> 16;
-    return k16 > 1u ? k16 - 1u : 0u;
+    unsigned k16;
+    if (dtype == SEC_F16) {                          // key16_of<__half>: the sign trick on the half's own bits
+        if (!(fabsf(x) < 60000.0f)) return 0u;
+        const unsigned u = __half_as_ushort(__float2half_rn(x));
+        k16 = (u & 0x8000u) ? (~u & 0xffffu) : (u | 0x8000u);
+    } else {
+        unsigned u;
+        __builtin_memcpy(&u, &x, 4);
+        const unsigned key = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+        k16 = key >> 16;
+    }
+    return k16 > 2u ? k16 - 2u : 0u;                 // two key steps down: covers the rounding of the conversions above
 }
 
 SEC_API int sec_predict_select(const void *cls, const int64_t *h_cls_strides5, int batch, int anchors_per_loc, int h, int w,
@@ -734,40 +763,65 @@ SEC_API int sec_predict_select(const void *cls, const int64_t *h_cls_strides5, i
                                score_thr, key_scratch, top_idx, top_score, top_label, counts);                                   \
     } while (0)
     const long long nfr = (long long)anchors_per_loc * h * w;
-    if (dtype == SEC_BF16 && nfr <= (long long)kSelThreads * 72) {   // register-resident select on 16-bit keys
-        using T = __hip_bfloat16;
-        const int ns = (int)((nfr + 1) & ~1ll);
-        static int use_thr = -1;
-        if (use_thr < 0) { const char *e = getenv("SEC_SELECT_THRESHOLD_SHORTCUT"); use_thr = e ? atoi(e) : 1; }
-        const unsigned thr16 = use_thr ? conservative_thr16(score_thr) : 0u;
-        // chunked form: per-chunk top-K on the whole chip, then one workgroup per frame over the ~9 k candidates.  The candidate
-        // arrays live in the unused upper part of key_scratch (sized 4 bytes per anchor, the 16-bit keys take 2).
-        static int chunked = -1;
-        if (chunked < 0) { const char *e = getenv("SEC_SELECT_CHUNKS"); chunked = e ? atoi(e) : 1; }
-        const int chunks = (int)((nfr + kSelChunk - 1) / kSelChunk);
+    // 16-bit heads (bf16 / fp16): register-resident select on 16-bit keys
+    static int use_thr = -1, chunked = -1;
+    if (use_thr < 0) { const char *e = getenv("SEC_SELECT_THRESHOLD_SHORTCUT"); use_thr = e ? atoi(e) : 1; }
+    if (chunked < 0) { const char *e = getenv("SEC_SELECT_CHUNKS"); chunked = e ? atoi(e) : 1; }
+    const bool h16 = dtype == SEC_BF16 || dtype == SEC_F16;
+    const unsigned thr16 = (use_thr && h16) ? conservative_thr16(score_thr, dtype) : 0u;
+    const long long reg_cap = (long long)kSelThreads * 72;           // keys one workgroup of k_predict_select_reg holds
+    // chunked form: per-chunk top-K on the whole chip, then one workgroup per frame over the candidates.  Chunks of 8192 anchors
+    // (KP 4) while their candidate lists fit the second stage, of 73 728 anchors (KP 36) for larger heads (up to 5.3 M anchors per
+    // frame).  The candidate arrays live in key_scratch (4 bytes per anchor; they need 6 bytes per candidate slot).
+    int kp = 0;
+    if (h16 && chunked) {
+        const long long c4 = (nfr + kSelChunk - 1) / kSelChunk, c36 = (nfr + reg_cap - 1) / reg_cap;
+        if (c4 >= 2 && c4 * kSelThreads <= reg_cap) kp = 4;
+        else if (nfr > reg_cap && c36 * kSelThreads <= reg_cap) kp = 36;
+    }
+    if (kp) {
+        const long long per = (long long)kSelThreads * 2 * kp;
+        const int chunks = (int)((nfr + per - 1) / per);
         const long long n2 = (long long)chunks * kSelThreads;
-        const size_t key_bytes = ((size_t)batch * ns * 2 + 255) & ~(size_t)255;
-        const size_t need_bytes = key_bytes + (size_t)batch * n2 * 6;
-        if (chunked && chunks >= 2 && n2 <= (long long)kSelThreads * 72 && need_bytes <= (size_t)total * 4) {
-            unsigned short *ck = reinterpret_cast<unsigned short *>(reinterpret_cast<char *>(key_scratch) + key_bytes + (size_t)batch * n2 * 4);
-            int *ci = reinterpret_cast<int *>(reinterpret_cast<char *>(key_scratch) + key_bytes);
-            hipLaunchKernelGGL(k_predict_select_chunk<T>, dim3(chunks, batch), dim3(kSelThreads), 0, st, (const T *)cls, v, g, (int)nfr, k,
-                               chunks, thr16, ck, ci);
-#define SEC_SEL2(KP2) hipLaunchKernelGGL((k_predict_select_reg<T, KP2, true>), dim3(batch), dim3(kSelThreads), 0, st, (const T *)cls, v, g, k, \
-                                         score_thr, ck, (int)n2, top_idx, top_score, top_label, counts, (int)n2, ci, thr16)
+        if ((size_t)batch * n2 * 6 <= (size_t)total * 4) {
+            unsigned short *ck = reinterpret_cast<unsigned short *>(reinterpret_cast<char *>(key_scratch) + (size_t)batch * n2 * 4);
+            int *ci = reinterpret_cast<int *>(key_scratch);
             const int pairs = (int)((n2 / 2 + kSelThreads - 1) / kSelThreads);
-            if (pairs <= 5) SEC_SEL2(5);
-            else if (pairs <= 10) SEC_SEL2(10);
-            else if (pairs <= 20) SEC_SEL2(20);
-            else SEC_SEL2(36);
+#define SEC_SEL2(T, KP2) hipLaunchKernelGGL((k_predict_select_reg<T, KP2, true>), dim3(batch), dim3(kSelThreads), 0, st, (const T *)cls, v, g, k, \
+                                            score_thr, ck, (int)n2, top_idx, top_score, top_label, counts, (int)n2, ci, thr16)
+#define SEC_CHUNKED(T)                                                                                                                      \
+    do {                                                                                                                                    \
+        if (kp == 4)                                                                                                                        \
+            hipLaunchKernelGGL((k_predict_select_chunk<T, 4>), dim3(chunks, batch), dim3(kSelThreads), 0, st, (const T *)cls, v, g, (int)nfr, k, \
+                               chunks, thr16, ck, ci);                                                                                      \
+        else                                                                                                                                \
+            hipLaunchKernelGGL((k_predict_select_chunk<T, 36>), dim3(chunks, batch), dim3(kSelThreads), 0, st, (const T *)cls, v, g, (int)nfr, k, \
+                               chunks, thr16, ck, ci);                                                                                      \
+        if (pairs <= 5) SEC_SEL2(T, 5);                                                                                                     \
+        else if (pairs <= 10) SEC_SEL2(T, 10);                                                                                              \
+        else if (pairs <= 20) SEC_SEL2(T, 20);                                                                                              \
+        else SEC_SEL2(T, 36);                                                                                                               \
+    } while (0)
+            if (dtype == SEC_BF16) SEC_CHUNKED(__hip_bfloat16);
+            else SEC_CHUNKED(__half);
+#undef SEC_CHUNKED
 #undef SEC_SEL2
             return check_launch();
         }
-        hipLaunchKernelGGL(k_predict_keys16<T>, dim3(div_up((long long)batch * ns, kBlock)), dim3(kBlock), 0, st, (const T *)cls, v, g, ns,
-                           reinterpret_cast<unsigned short *>(key_scratch));
-        hipLaunchKernelGGL((k_predict_select_reg<T, 36>), dim3(batch), dim3(kSelThreads), 0, st, (const T *)cls, v, g, k, score_thr,
-                           reinterpret_cast<const unsigned short *>(key_scratch), ns, top_idx, top_score, top_label, counts, 0,
-                           (const int *)nullptr, thr16);
+    }
+    if (h16 && nfr <= reg_cap) {                                     // one workgroup per frame over a compact 16-bit key array
+        const int ns = (int)((nfr + 1) & ~1ll);
+#define SEC_REG(T)                                                                                                                          \
+    do {                                                                                                                                    \
+        hipLaunchKernelGGL(k_predict_keys16<T>, dim3(div_up((long long)batch * ns, kBlock)), dim3(kBlock), 0, st, (const T *)cls, v, g, ns, \
+                           reinterpret_cast<unsigned short *>(key_scratch));                                                                \
+        hipLaunchKernelGGL((k_predict_select_reg<T, 36>), dim3(batch), dim3(kSelThreads), 0, st, (const T *)cls, v, g, k, score_thr,       \
+                           reinterpret_cast<const unsigned short *>(key_scratch), ns, top_idx, top_score, top_label, counts, 0,            \
+                           (const int *)nullptr, thr16);                                                                                    \
+    } while (0)
+        if (dtype == SEC_BF16) SEC_REG(__hip_bfloat16);
+        else SEC_REG(__half);
+#undef SEC_REG
         return check_launch();
     }
     if (dtype == SEC_F32) SEC_SEL(float, false);

@@ -1047,8 +1047,9 @@ def test_detector_steps_in_flight(syn):
         assert torch.equal(e["scores"][m], o["scores"][m]) and torch.equal(e["boxes"][m], o["boxes"][m])
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("levels,k", [(3, 1000), (40, 1000), (700, 1000), (5, 64), (1, 1000), (100000, 1000)])
-def test_predict_select_tie_ranking(levels, k):
+def test_predict_select_tie_ranking(levels, k, dtype):
     """Heavily tied 16-bit logits (an untrained or saturated head): the selection is the k largest keys, ties by ascending
     anchor index (the order torch.topk of voxelnet.py:551-570 is replaced by, documented in DESIGN), identical run to run.
     levels = number of distinct logit values per frame (1 = every anchor ties; 100000 = practically distinct)."""
@@ -1056,7 +1057,7 @@ def test_predict_select_tie_ranking(levels, k):
     b, a, h, w = 3, 2, 200, 176
     n = a * h * w
     g = torch.Generator(device="cuda").manual_seed(levels)
-    vals = (torch.randn(levels, device="cuda", generator=g) * 2.0 - 1.0).bfloat16()
+    vals = (torch.randn(levels, device="cuda", generator=g) * 2.0 - 1.0).to(dtype)
     pick = torch.randint(0, levels, (b, n), device="cuda", generator=g)
     cls = vals[pick].reshape(b, a, h, w, 1).contiguous()
     top_idx, top_score, _, counts = ops.predict_select(cls, k, 0.3)
@@ -1075,15 +1076,18 @@ def test_predict_select_tie_ranking(levels, k):
         np.testing.assert_allclose(top_score[f, :c].cpu().numpy(), ref_scores[f, :c].cpu().numpy(), rtol=1e-6)
 
 
+@pytest.mark.parametrize("dtype,a,h,w", [(torch.bfloat16, 2, 200, 176), (torch.float16, 2, 200, 176), (torch.float16, 20, 248, 248),
+                                         (torch.bfloat16, 12, 200, 200)])
 @pytest.mark.parametrize("thr", [0.05, 0.3, 0.5, 0.9])
-def test_predict_select_threshold_shortcut(thr):
+def test_predict_select_threshold_shortcut(thr, dtype, a, h, w):
     """A trained-like head: a few hundred anchors per frame above the score threshold, logits spread around it (some within one
     bf16 step of the threshold's logit, some exactly on it).  The selection with the threshold shortcut (no bisection when at most
     k keys reach the threshold's conservative 16-bit key; csrc/predict.hip) equals the stable-sort reference entry for entry up
-    to counts[b], for a frame with fewer than k candidates, one with none and one with far more than k."""
+    to counts[b], for a frame with fewer than k candidates, one with none and one with far more than k -- for bf16 and fp16 heads
+    (fp16 keys are the half's own bits) and for heads large enough to take the 73 728-anchor chunks."""
     from second_amd import ops
-    b, a, h, w = 3, 2, 200, 176
-    n = a * h * w
+    b = 3                                           # (a, h, w): car.fhd's head, nuScenes all.fhd's (1.23 M anchors: 73 728-anchor
+    n = a * h * w                                   # chunks), a 480 k-anchor head (59 chunks of 8192); bf16 and fp16 keys
     g = torch.Generator(device="cuda").manual_seed(int(thr * 100))
     lt = float(np.log(thr / (1 - thr)))
     cls = torch.full((b, n), lt - 6.0, device="cuda")
@@ -1093,7 +1097,7 @@ def test_predict_select_threshold_shortcut(thr):
     cls[0, hot[:40]] = lt                                                    # exactly the threshold's logit (before bf16 rounding)
     many = torch.randperm(n, device="cuda", generator=g)[:5000]
     cls[2, many] = lt + 0.5 + torch.rand(5000, device="cuda", generator=g) * 4   # more than k candidates: bisection path
-    cls = cls.bfloat16().reshape(b, a, h, w, 1).contiguous()
+    cls = cls.to(dtype).reshape(b, a, h, w, 1).contiguous()
     k = 1000
     top_idx, top_score, _, counts = ops.predict_select(cls, k, thr)
     flat = cls.reshape(b, n).float()
