@@ -807,7 +807,10 @@ def main():
         # (the full template signature is the key) on this (seeded, deterministic) launch; the file says how they were
         # collected; null if no pass matches signature + rows + pairs
         traffic, traffic_source, pmc = None, None, None
-        for fname in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json")), reverse=True):
+        def _recency(fname):         # profiles are tagged rNN_<a..z, aa..>: the newest pass of this kernel wins
+            part = fname.split("_")
+            return (part[0], len(part[1]) if len(part) > 1 else 0, part[1] if len(part) > 1 else "")
+        for fname in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json")), key=_recency, reverse=True):
             try:
                 with open(os.path.join(ROOT, "profiles", fname)) as f:
                     tj = json.load(f)
