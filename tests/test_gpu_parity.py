@@ -465,6 +465,35 @@ def test_rotate_iou_golden(ops, golden):
     np.testing.assert_allclose(sp, g["special_iou"], atol=2e-5)
 
 
+def test_rotate_iou_degenerate_and_tied_polygons_vs_oracle(ops):
+    """The clipper keeps its vertex list in registers and replays the reference's insertion sort with predicates (csrc/nms.hip):
+    the cases where the ORDER of appended vertices, ties between sort keys or a degenerate polygon decide the result must give the
+    oracle's result -- identical boxes (8 coincident vertices), boxes sharing an edge or only a corner, a box inside another,
+    45 / 90 degree rotations of the same box (symmetric keys), sliver and dot-sized boxes, far-apart boxes, a cross, plus a
+    dense jittered cluster; all four criteria (values to 2e-5, zeros and non-finite entries exactly)."""
+    base = np.array([[0, 0, 2, 4, 0.0], [0, 0, 2, 4, 0.0], [2, 0, 2, 4, 0.0], [2, 4, 2, 4, 0.0], [0, 0, 1, 1, 0.3],
+                     [0, 0, 2, 4, np.pi / 2], [0, 0, 2, 4, np.pi / 4], [0, 0, 4, 2, 0.0], [0, 0, 1e-3, 4, 0.0], [7, 7, 1e-3, 1e-3, 0.0],
+                     [50, 50, 2, 4, 1.0], [0, 0, 6, 1, 0.0], [0, 0, 1, 6, 0.0], [0.5, 0.25, 2, 4, 1e-3], [0, 0, 2, 4, np.pi],
+                     [1, 2, 2, 4, 0.0], [0, 0, 2, 2, np.pi / 4], [0, 0, 2.8284271, 2.8284271, 0.0]], np.float32)
+    rng = np.random.default_rng(21)
+    k = 150
+    cluster = np.stack([rng.normal(0, 0.6, k), rng.normal(0, 0.6, k), rng.uniform(1.4, 2.0, k), rng.uniform(3.4, 4.6, k),
+                        rng.normal(0.3, 0.2, k)], 1).astype(np.float32)
+    boxes = np.concatenate([base, cluster])
+    for crit in (-1, 0, 1, 2):
+        want = orc.rotate_iou(boxes, boxes, crit)
+        got = ops.rotate_iou(dev(boxes), dev(boxes), crit).cpu().numpy()
+        # sinf / cosf of the device and of the host libm may differ in the last bit, so rotated corners are compared to 2e-5 like the
+        # golden test; everything is finite (no zero-area box: x / 0 is outside the reference's domain too) and the exact zeros coincide
+        # A ROTATED box against itself is outside the comparison: all its edges are colinear with the other's, the reference
+        # algorithm's crossing tests are then decided by the last bit of sin / cos, and it returns 1 or 1/3 depending on the libm
+        # (device and host disagree on 5 of 150 such pairs; identical AXIS-ALIGNED boxes -- rows 0 and 1 -- are exact and compared).
+        off = ~np.eye(len(boxes), dtype=bool)
+        assert np.isfinite(want[off]).all() and np.isfinite(got[off]).all(), crit
+        np.testing.assert_allclose(got[off], want[off], atol=2e-5, rtol=1e-5)
+        assert np.array_equal(got[off] == 0.0, want[off] == 0.0), crit
+
+
 def _nms_call(ops, dets_sorted_list, thr, kind, semantics, eps=1.0, post_max=0):
     b = len(dets_sorted_list)
     max_n = max(1, max(len(d) for d in dets_sorted_list))
