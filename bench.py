@@ -11,9 +11,11 @@ One *step* = one pass of the whole hot path over one batch of 8 synthetic KITTI 
 resident in HBM: points_to_voxel (+SimpleVoxel mean) -> 14 sparse conv layers (rulebooks + fused
 indice_conv) -> dense -> RPNV2 (bf16, hand-written MFMA convs) -> decode / top-k / rotated NMS, detections left on the device.
 Per-frame data parallel: every rank runs its own batch, no data-path collective ("weak" scaling).
-Default launch mode: ONE hipGraph replay per step (a single chain, --branches 1) with three steps in flight (--inflight 3:
-three graphs with their own activation buffers on three streams; every step is still a full pass over its batch).
-`config.single_step_latency_ms` is one step alone, start to finish; `--inflight 1` runs strictly one step at a time.
+Default launch mode: hipGraph replays with four steps in flight (--inflight 4: four lanes with their own activation buffers on
+four streams; every step is still a full pass over its batch).  A step is three graphs -- sparse front end / RPN / predict -- and the
+lanes pass a token from RPN segment to RPN segment (--serialize-rpn 1), so that one lane at a time is in its MFMA-bound segment while
+the others' latency-bound segments run beside it; --serialize-rpn 0 replays one graph per step on uncoordinated lanes.
+`config.single_step_latency_ms` is one step alone as ONE graph, start to finish; `--inflight 1` runs strictly one step at a time.
 
 Prints ONE JSON line on rank 0 with, besides the contract fields,
   roofline      -- the SubMConv3d 64->64 gather-GEMM kernel (the kernel BASELINE.json's metric names): algorithmic bytes
@@ -558,12 +560,12 @@ def other_configs(budget_s=270.0):
 
 
 # ------------------------------------------------------------------------------------------ extra lines
-def time_e2e(det, points, offsets, inflight, steps, warmup):
+def time_e2e(det, points, offsets, inflight, steps, warmup, serialize_rpn=False):
     """SURVEY 8(d) "end-to-end": the same loop as the timed region, but every step's clouds start in PINNED HOST memory
     (copied into the step's own input buffers on its stream) and its detections end in pinned host memory.  Per-lane input
     buffers, so lane k's copy overlaps the other lanes' compute."""
     from second_amd.models import InFlightRunner
-    runner = InFlightRunner(det, points, offsets, inflight=inflight, private_inputs=True)
+    runner = InFlightRunner(det, points, offsets, inflight=inflight, private_inputs=True, serialize_rpn=serialize_rpn and not det.pillars)
     hp, ho = points.cpu().pin_memory(), offsets.cpu().pin_memory()
     for _ in range(max(3, warmup)):
         runner.step(hp, ho, fetch=True)
@@ -638,10 +640,13 @@ def main():
     ap.add_argument("--no-extra-lines", action="store_true", help="skip config.e2e_from_pinned_host and config.batch1")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short child runs of BASELINE configs 3 / 4 / 5 (`other_configs`)")
     ap.add_argument("--stages", action="store_true", help="also print per-stage timings to stderr")
-    ap.add_argument("--inflight", type=int, default=3,
+    ap.add_argument("--inflight", type=int, default=4,
                     help="graph mode: number of steps (graph replays, each a full pass over the batch with its own activation "
                          "buffers) kept in flight on separate HIP streams; the latency-bound sparse stages of one step then "
                          "overlap the MFMA-bound RPN of another.  1 = strictly one step at a time")
+    ap.add_argument("--serialize-rpn", type=int, default=1,
+                    help="1 (default, car.fhd-type networks): every step is three graphs (sparse front / RPN / predict) and the lanes' RPN "
+                         "segments pass a token: one MFMA-bound segment at a time; 0: one graph per step, lanes uncoordinated")
     ap.add_argument("--branches", type=int, default=1,
                     help="graph mode: capture the batch as this many independent frame-group chains on separate streams of "
                          "ONE hipGraph (the single-step-latency variant of --inflight); 1 = a single chain")
@@ -707,7 +712,9 @@ def main():
             det.calibrate(points, offsets)
         if args.mode == "graph":
             from second_amd.models import InFlightRunner
-            runner = InFlightRunner(det, points, offsets, inflight=args.inflight, branches=args.branches)
+            serialize = (bool(args.serialize_rpn) and not det.pillars and getattr(det, "_infer_dtype", None) is not None
+                         and args.branches <= 1 and args.inflight > 1)
+            runner = InFlightRunner(det, points, offsets, inflight=args.inflight, branches=args.branches, serialize_rpn=serialize)
             graph_parts = runner.parts      # branches > 1: the roofline probe below times one branch's launch
             replays = runner.replays
             outs = runner.outputs[-1]
@@ -726,10 +733,14 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         latency_ms = None
-        if args.mode == "graph":   # one step alone, start to finish (what --inflight 1 would run back to back)
+        if args.mode == "graph":   # one step alone, start to finish, as ONE graph (what --inflight 1 would run back to back)
+            one = det.make_graphed(points, offsets)[0] if isinstance(replays[0], tuple) else replays[0]
+            for _ in range(3):
+                one()
+            torch.cuda.synchronize()
             t1 = time.perf_counter()
             for _ in range(20):
-                replays[0]()
+                one()
                 torch.cuda.synchronize()
             latency_ms = round((time.perf_counter() - t1) / 20 * 1e3, 4)
         if args.mode != "graph":
@@ -782,7 +793,7 @@ def main():
                 ktable = [{"error": repr(e)}]
         e2e = batch1 = None
         if rank == 0 and args.mode == "graph" and args.branches == 1 and args.workload == "car.fhd" and not args.no_extra_lines:
-            e2e = time_e2e(det, points, offsets, max(1, args.inflight), min(args.steps, 200), args.warmup)
+            e2e = time_e2e(det, points, offsets, max(1, args.inflight), min(args.steps, 200), args.warmup, serialize_rpn=serialize)
             batch1 = time_batch1(det, points, offsets)      # last: it re-calibrates the static capacities for one frame
 
     if world > 1:
@@ -849,6 +860,7 @@ def main():
                        "frames_per_step_per_gpu": WL["batch"], "parallelism": f"frame-dp{world}", "launch_mode": args.mode,
                        "graph_branches": args.branches if args.mode == "graph" else None,
                        "steps_in_flight": max(1, args.inflight) if args.mode == "graph" else 1,
+                       "rpn_segments_serialized": bool(serialize) if args.mode == "graph" else None,
                        "single_step_latency_ms": latency_ms, "frames_per_s_one_step_at_a_time": one_at_a_time,
                        "rulebook_numbering": det.rulebook_numbering, "points_per_frame": int(points.shape[0]) // WL["batch"],
                        "rows_per_frame": rows_per_frame,

@@ -841,6 +841,43 @@ class SecondDetector(nn.Module):
                 cur.wait_stream(st)
         return graph.replay, (outs[0] if len(parts) == 1 else outs), graph
 
+    def _capture_stages(self, points, point_offsets, warmup=3):
+        """The static forward as THREE hipGraphs sharing one memory pool -- (A) voxelise + sparse middle, (B) the dense RPN, (C)
+        decode / top-k / NMS -- so that a serving loop with several steps in flight can pass a token between the lanes' (B)
+        segments (InFlightRunner(serialize_rpn=True)): the MFMA-bound RPN segments then run one after another while the
+        latency-bound (A) / (C) segments of the other lanes run beside them.  Returns ((replay_a, replay_b, replay_c), outputs)."""
+        assert not self.pillars and self._infer_dtype is not None, "staged capture: the sparse-middle inference path"
+        batch_size = point_offsets.numel() - 1
+        nf = self.cfg["num_point_features"]
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s), torch.no_grad():
+            for _ in range(warmup):
+                self.forward_points(points, point_offsets, static=True)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        pool = torch.cuda.graph_pool_handle()
+        ga, gb, gc = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        prev = ops.set_rulebook_numbering(self.rulebook_numbering)
+        try:
+            with torch.no_grad():
+                with torch.cuda.graph(ga, pool=pool, capture_error_mode="thread_local"):
+                    vox = self.voxel_generator.generate_device(points, point_offsets, mean_features=nf, sync=False,
+                                                               mean_dtype=self._infer_dtype)
+                    spatial = self.middle_feature_extractor(vox["mean"].to(self._infer_dtype), vox["coordinates"], batch_size,
+                                                            channels_last=True, num_active_dev=vox["voxel_offsets"][batch_size:],
+                                                            site_table=vox.get("site_table"),
+                                                            bev_sparse=getattr(self.rpn, "gather_packed", None) is not None)
+                    self._branch_overflow = [list(getattr(self.middle_feature_extractor, "last_overflow_checks", []))]
+                with torch.cuda.graph(gb, pool=pool, capture_error_mode="thread_local"):
+                    preds = self.rpn(spatial)
+                with torch.cuda.graph(gc, pool=pool, capture_error_mode="thread_local"):
+                    out = self.predict_device(preds, batch_size)
+        finally:
+            ops.set_rulebook_numbering(prev)
+        self._stage_keepalive = getattr(self, "_stage_keepalive", []) + [(vox, spatial, preds)]   # buffers the later graphs read
+        return (ga.replay, gb.replay, gc.replay), out
+
     # -- post-processing -----------------------------------------------------------------------------
     def _select(self, preds, batch_size, anchors):
         """score filter + top-k + decode of the selected boxes, all on device, fixed shapes."""
@@ -957,11 +994,17 @@ class InFlightRunner:
     are replayed round-robin on their own HIP streams.  Replays on
     one lane serialise, different lanes overlap -- the latency-bound sparse stages of one step run beside the MFMA-bound
     RPN of another (car.fhd, batch 8: 5600 -> 7200 frames/s with three lanes; more lanes add nothing).
+    ``serialize_rpn``: a step is three graphs (sparse front / RPN / predict) and the lanes hand a token (an event) from RPN
+    segment to RPN segment, so that at most ONE lane is in its MFMA-bound segment at any time: uncoordinated lanes now and then
+    sit in their RPN segments together (the others' launches wait for conv tiles to retire) or all in their latency-bound
+    segments (matrix pipes idle).  Round 3: 14.0 k -> 14.7 k frames/s with four lanes (three lanes: 14.4 k; five: 13.3 k; the RPN
+    segments on one extra stream with or without a CU mask instead of the token: 11.5 k -- the event ping-pong costs more than it
+    orders; `gpurun_out` r03_as-au).
 
     ``step()`` enqueues one full forward and returns (outputs, stream): the output tensors of that lane, valid once
     ``stream`` has been synchronised (or after :meth:`synchronize`) and until the lane is stepped again."""
 
-    def __init__(self, det, points, point_offsets, inflight=3, branches=1, private_inputs=False):
+    def __init__(self, det, points, point_offsets, inflight=3, branches=1, private_inputs=False, serialize_rpn=False):
         """``private_inputs``: every lane gets its OWN copy of the input buffers (``self.inputs[k]``) and pinned host
         mirrors of its outputs, so that :meth:`step` can take a host-resident batch: the pinned-host -> HBM copy of lane k's
         next clouds then overlaps the compute of the other lanes (the end-to-end serving form; with shared buffers a copy
@@ -970,9 +1013,20 @@ class InFlightRunner:
         self.replays, self.outputs, self.parts = [], [], None
         self.inputs, self.host_outputs = [], []
         self._overflow = []                       # overflow counters of EVERY lane (each capture has its own rulebook buffers)
+        # ``serialize_rpn``: every lane's step is three graphs (SecondDetector._capture_stages) and the RPN segments pass a token
+        # (an event) from lane to lane: at most one lane is in its MFMA-bound segment at a time, the others' latency-bound
+        # segments fill the rest of the chip
+        self.serialize_rpn = bool(serialize_rpn) and branches <= 1 and int(inflight) > 1
+        self._rpn_token = None
         assert not (private_inputs and branches > 1), "private input buffers are a single-chain feature"
         for _ in range(max(1, int(inflight))):
-            if branches > 1:
+            if self.serialize_rpn:
+                pk, ok = (points.clone(), point_offsets.clone()) if private_inputs else (points, point_offsets)
+                replay, outs = det._capture_stages(pk, ok)
+                self.inputs.append((pk, ok))
+                if private_inputs:
+                    self.host_outputs.append({k: torch.empty(v.shape, dtype=v.dtype, pin_memory=True) for k, v in outs.items()})
+            elif branches > 1:
                 # the per-branch input buffers are created by the first lane and shared by all others: one place to refill
                 replay, outs, self.parts = det.make_graphed(points, point_offsets, branches=branches, parts=self.parts)
             else:
@@ -1001,7 +1055,18 @@ class InFlightRunner:
                 pk, ok = self.inputs[k]
                 pk[:host_points.shape[0]].copy_(host_points, non_blocking=True)
                 ok.copy_(host_offsets, non_blocking=True)
-            self.replays[k]()
+            if self.serialize_rpn:
+                ra, rb, rc = self.replays[k]
+                st = lane if lane is not None else torch.cuda.current_stream()
+                ra()
+                if self._rpn_token is not None:
+                    st.wait_event(self._rpn_token)          # the previous step's RPN segment (another lane) has finished
+                rb()
+                self._rpn_token = torch.cuda.Event()
+                self._rpn_token.record(st)
+                rc()
+            else:
+                self.replays[k]()
             if fetch:
                 for name, t in self.outputs[k].items():
                     self.host_outputs[k][name].copy_(t, non_blocking=True)

@@ -1076,6 +1076,34 @@ def test_detector_steps_in_flight(syn):
         assert torch.equal(e["scores"][m], o["scores"][m]) and torch.equal(e["boxes"][m], o["boxes"][m])
 
 
+def test_detector_steps_in_flight_with_serialised_rpn_segments(syn):
+    """InFlightRunner(serialize_rpn=True): a step is three graphs sharing one memory pool (sparse front / RPN / predict) and the
+    lanes pass an event from RPN segment to RPN segment -- the bench's default serving form.  Every lane's detections equal the
+    eager path's bit for bit, with the clouds fed through per-lane input buffers too."""
+    from second_amd.models import SecondDetector, CAR_FHD, InFlightRunner
+    torch.manual_seed(0)
+    det = SecondDetector(CAR_FHD).cuda().prepare_inference(torch.bfloat16)
+    pts, offs = syn.batch_clouds([syn.syn_kitti_cloud(s, num_points=7000, num_voxels=6000) for s in range(3)])
+    pts, offs = dev(pts), dev(offs)
+    with torch.no_grad():
+        e = det.forward_points(pts, offs)
+        det.calibrate(pts, offs)
+        for private in (False, True):
+            runner = InFlightRunner(det, pts, offs, inflight=4, serialize_rpn=True, private_inputs=private)
+            assert runner.serialize_rpn and isinstance(runner.replays[0], tuple) and len(runner.replays[0]) == 3
+            hp, ho = (pts.cpu().pin_memory(), offs.cpu().pin_memory()) if private else (None, None)
+            for _ in range(11):
+                runner.step(hp, ho, fetch=private)
+            runner.synchronize()
+            m = e["valid"]
+            for o in runner.outputs:
+                assert torch.equal(m, o["valid"])
+                assert torch.equal(e["scores"][m], o["scores"][m]) and torch.equal(e["boxes"][m], o["boxes"][m])
+            if private:
+                for h in runner.host_outputs:
+                    assert torch.equal(h["valid"], m.cpu()) and torch.equal(h["boxes"][m.cpu()], e["boxes"][m].cpu())
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("levels,k", [(3, 1000), (40, 1000), (700, 1000), (5, 64), (1, 1000), (100000, 1000)])
 def test_predict_select_tie_ranking(levels, k, dtype):
