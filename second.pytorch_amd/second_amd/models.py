@@ -1059,11 +1059,14 @@ class InFlightRunner:
                 ra, rb, rc = self.replays[k]
                 st = lane if lane is not None else torch.cuda.current_stream()
                 ra()
-                if self._rpn_token is not None:
-                    st.wait_event(self._rpn_token)          # the previous step's RPN segment (another lane) has finished
+                width = int(os.environ.get("SEC_RPN_TOKENS", "1"))          # RPN segments allowed at a time (A/B knob; default 1)
+                toks = self._rpn_token or []
+                if len(toks) >= width:
+                    st.wait_event(toks[-width])             # the RPN segment `width` steps back (another lane) has finished
                 rb()
-                self._rpn_token = torch.cuda.Event()
-                self._rpn_token.record(st)
+                ev = torch.cuda.Event()
+                ev.record(st)
+                self._rpn_token = (toks + [ev])[-4:]
                 rc()
             else:
                 self.replays[k]()
