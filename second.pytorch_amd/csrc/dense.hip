@@ -1109,7 +1109,11 @@ static int launch_conv2d(const void *x, const void *wpk, const float *bias, void
     }
     if (conv2d_variant() >= 1 || !kConv2dExperiments) {
         const int gx = (div_up(p.m, 128) + 7) / 8 * 8;   // multiple of 8 for the XCD-aware tile order
-        if (p.cout % 128 == 0)
+        // small images (the 50 x 50 third block of the PointPillars RPN: 80 pixel tiles x 2 cout tiles = 160 workgroups for 256 CUs):
+        // 64-wide cout tiles double the workgroups; the input tile is re-read from L2.  SEC_CONV2D_SMALL_SPLIT=0: always 128.
+        static int small_split = -1;
+        if (small_split < 0) { const char *e = getenv("SEC_CONV2D_SMALL_SPLIT"); small_split = e ? atoi(e) : 1; }
+        if (p.cout % 128 == 0 && !(small_split && (long long)gx * (p.cout / 128) < 384))
             hipLaunchKernelGGL((k_conv2d_nhwc_dma<T, 128>), dim3(gx, p.cout / 128), block, 0, st, (const T *)x,
                                (const T *)wpk, bias, (T *)y, p);
         else
