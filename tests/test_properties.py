@@ -207,3 +207,103 @@ def test_gpu_voxel_count_monotone_and_prefix_at_bench_size():
                 assert torch.all(prev["num_points_per_voxel"] <= v["num_points_per_voxel"][:prev["voxel_num"]])
             if mode == "break":
                 prev = v
+
+
+@pytest.mark.gpu
+def test_gpu_rulebook_and_conv_laws_at_nuscenes_size():
+    """BASELINE configs 4 / 5 sizes (4 synthetic 10-sweep nuScenes clouds, ~293 k points each; all.fhd grid 40 x 1984 x 1984, one
+    point per voxel, cap 90 000 per frame): where an element-by-element oracle comparison would take minutes, the size-independent
+    laws -- SubM table symmetric with identity centre, the sorted strided chain ascending / unique / consistent in both tables, its
+    site-map equal to the generic one -- and for indice_conv at that size: linearity in the features and in the weights, a
+    permutation of the input rows (with the table relabelled) leaves the output unchanged, fp32 and bf16."""
+    import torch
+    from second_amd import ops, synthetic as syn
+    from second_amd.models import ALL_FHD_NUSC as C
+    clouds = [syn.syn_nusc_cloud(s, 293000, tuple(C["point_cloud_range"]), scene="urban") for s in range(4)]
+    pts, offs = syn.batch_clouds(clouds)
+    vox = ops.voxelize(torch.from_numpy(pts).cuda(), torch.from_numpy(offs).cuda(), C["point_cloud_range"], C["voxel_size"], 1, C["max_voxels"])
+    idx = vox["coordinates"].contiguous()
+    n = idx.shape[0]
+    assert n == 4 * 90000                                                              # every frame hits its cap
+    shape = [41, 1984, 1984]
+    rb = ops.rulebook_subm(idx, 4, shape, 3, want_pairs=True)
+    nbr = rb["nbr_out"]
+    assert torch.equal(nbr[:, 13], torch.arange(n, device="cuda", dtype=torch.int32)) and rb["pair_num"][13].item() == n
+    for k in (1, 9, 12):
+        o = torch.nonzero(nbr[:, k] >= 0).squeeze(1)
+        assert torch.equal(nbr[nbr[o, k].long(), 26 - k].long(), o) and rb["pair_num"][k].item() == o.numel()
+    # sorted strided chain (the device fast path): two levels down
+    cur, cshape, sites = idx, shape, None
+    for ks, stv, pad in [(3, 2, 1), (3, 2, 1)]:
+        r = ops.rulebook_conv(cur, 4, cshape, ks, stv, pad, want_pairs=True, numbering="sorted", in_sites=sites)
+        out, m, oshape = r["out_indices"], r["num_out"], r["out_shape"]
+        lin = ((out[:, 0].long() * oshape[0] + out[:, 1]) * oshape[1] + out[:, 2]) * oshape[2] + out[:, 3]
+        assert torch.all(lin[1:] > lin[:-1])
+        no, ni = r["nbr_out"], r["nbr_in"]
+        assert (no >= 0).any(1).all() and int((no >= 0).sum()) == int((ni >= 0).sum()) == int(r["pair_num"].sum())
+        o = torch.nonzero(no[:, 4] >= 0).squeeze(1)
+        assert torch.equal(ni[no[o, 4].long(), 4].long(), o)
+        cur, cshape, sites = out.contiguous(), oshape, r["site_table"]
+    assert torch.equal(ops.sparse_site_map_sorted(sites[1], cur.shape[0], 4, cshape), ops.sparse_site_map(cur, 4, cshape))
+    # indice_conv laws on the first level's SubM rulebook (360 000 rows, 1.5 M pairs)
+    g = torch.Generator(device="cuda").manual_seed(7)
+    for dtype, tol in ((torch.float32, 2e-5), (torch.bfloat16, 2e-2)):
+        cin, cout = 16, 32
+        x = torch.randn(n, cin, device="cuda", generator=g).to(dtype)
+        y = torch.randn(n, cin, device="cuda", generator=g).to(dtype)
+        w = (torch.randn(3, 3, 3, cin, cout, device="cuda", generator=g) / 20).to(dtype)
+        v = (torch.randn(3, 3, 3, cin, cout, device="cuda", generator=g) / 20).to(dtype)
+
+        def conv(f, wt, table=nbr):
+            return ops.indice_conv(f, wt, table, n, packed=ops.pack_weight(wt)).float()
+        fx, fy = conv(x, w), conv(y, w)
+        scale = fx.abs().max().item()
+        assert (conv((x.float() + y.float()).to(dtype), w) - (fx + fy)).abs().max().item() <= tol * 4 * scale       # linear in the features
+        assert (conv(x, (w.float() + v.float()).to(dtype)) - (fx + conv(x, v))).abs().max().item() <= tol * 4 * scale  # ... and in the weights
+        perm = torch.randperm(n, device="cuda", generator=g)
+        inv = torch.empty_like(perm)
+        inv[perm] = torch.arange(n, device="cuda")
+        relabelled = torch.where(nbr >= 0, inv[nbr.clamp(min=0).long()].int(), nbr)    # row r now lives at position inv[r]
+        xp = torch.empty_like(x)
+        xp[inv] = x
+        assert torch.equal(conv(xp, w, relabelled.contiguous()), fx)                    # same sums in the same order: same bits
+
+
+@pytest.mark.gpu
+def test_gpu_nms_and_iou_laws_at_full_size():
+    """1000 candidates per frame (nms_pre_max_size) x 8 frames: rotated IoU is symmetric and 1 on the diagonal of distinct
+    axis-aligned boxes; NMS is idempotent (the kept boxes survive a second pass untouched), its keep list is ascending (score
+    order), no kept pair overlaps beyond the threshold, and every dropped box overlaps an earlier kept one."""
+    import torch
+    from second_amd import ops
+    rng = np.random.default_rng(17)
+    b, n, thr = 8, 1000, 0.3
+    dets = np.zeros((b, n, 6), np.float32)
+    for f in range(b):
+        c = rng.uniform(-35, 35, (40, 2))
+        o = rng.integers(0, 40, n)
+        dets[f, :, 0:2] = c[o] + rng.normal(0, 0.8, (n, 2))
+        dets[f, :, 2] = rng.uniform(1.4, 2.0, n)
+        dets[f, :, 3] = rng.uniform(3.4, 4.6, n)
+        dets[f, :, 4] = rng.uniform(-3.2, 3.2, n)
+        dets[f, :, 5] = np.sort(rng.uniform(0.3, 1, n))[::-1]
+    d = torch.from_numpy(dets).cuda()
+    counts = torch.full((b,), n, dtype=torch.int32, device="cuda")
+    keep, num = ops.nms_sorted(d, counts, thr, "rotate", "numba", 1.0, 0)
+    for f in range(b):
+        k = keep[f, :int(num[f])].long()
+        assert torch.all(k[1:] > k[:-1])
+        kept = d[f, k][:, :5].contiguous()
+        iou = ops.rotate_iou(kept, kept)
+        assert torch.allclose(iou, iou.t(), atol=2e-5)
+        off = iou - torch.diag(torch.diag(iou))
+        assert off.max().item() <= thr + 2e-5                                           # no kept pair overlaps beyond the threshold
+        dropped = torch.ones(n, dtype=torch.bool, device="cuda")
+        dropped[k] = False
+        di = torch.nonzero(dropped).squeeze(1)
+        cross = ops.rotate_iou(d[f, di][:, :5].contiguous(), kept)                      # [dropped, kept]
+        earlier = k.view(1, -1) < di.view(-1, 1)
+        assert torch.all(((cross > thr - 2e-5) & earlier).any(1))                       # every dropped box has an earlier kept suppressor
+        again, num2 = ops.nms_sorted(d[f:f + 1, k].contiguous(), torch.tensor([k.numel()], dtype=torch.int32, device="cuda"), thr,
+                                     "rotate", "numba", 1.0, 0)
+        assert int(num2[0]) == k.numel() and torch.equal(again[0, :k.numel()].long(), torch.arange(k.numel(), device="cuda"))
