@@ -781,6 +781,32 @@ def test_block_filter_vs_oracle(ops):
     assert kept_any
 
 
+def test_voxelize_and_block_filter_at_nuscenes_fhd_size_vs_oracle(ops, syn):
+    """BASELINE config 5's front end at its stated size -- two synthetic 10-sweep nuScenes clouds of ~293 k points on the
+    all.fhd grid (0.05 x 0.05 x 0.2 m, one point per voxel, cap 90 000 voxels per frame, hit by both frames; nuscenes/all.fhd.config:6-12)
+    -- voxel order, coordinates, contents and the block-filtered subset bit-exact against the sequential oracle, both cap modes."""
+    from second_amd.models import ALL_FHD_NUSC as C
+    rng_, vs = C["point_cloud_range"], C["voxel_size"]
+    clouds = [syn.syn_nusc_cloud(s, 293000, tuple(rng_), scene="urban") for s in (3, 4)]
+    for mode in ("break", "continue"):
+        res = _check_voxelize(ops, clouds, vs, rng_, 1, C["max_voxels"], mode)
+        assert res["voxel_num"] == 2 * C["max_voxels"]
+    pts, offs = syn.batch_clouds(clouds)
+    bf = C["block_filtering"]
+    grid_xy = [int(round((rng_[3] - rng_[0]) / vs[0])), int(round((rng_[4] - rng_[1]) / vs[1]))]
+    vox = ops.voxelize(dev(pts), dev(offs), rng_, vs, 1, C["max_voxels"], sync=False)
+    out = ops.voxel_block_filter(vox, grid_xy, bf["block_factor"], bf["block_size"], bf["height_threshold"], 3.0)
+    ooff = out["voxel_offsets"].cpu().numpy()
+    for b, c in enumerate(clouds):
+        r = orc.points_to_voxel(c, vs, rng_, 1, C["max_voxels"])
+        keep = orc.block_filter(r["voxels"], r["coordinates"], r["num_points_per_voxel"], grid_xy, bf["block_factor"], bf["block_size"],
+                                bf["height_threshold"], 3.0)
+        lo, hi = ooff[b], ooff[b + 1]
+        assert hi - lo == keep.sum() and 0.5 * len(keep) < keep.sum() < len(keep)
+        np.testing.assert_array_equal(out["coordinates"][lo:hi, 1:].cpu().numpy(), r["coordinates"][keep])
+        np.testing.assert_array_equal(out["voxels"][lo:hi].cpu().numpy(), r["voxels"][keep])
+
+
 def test_pointpillars_detector_runs_fused_equals_module_path(syn):
     from second_amd.models import SecondDetector, ALL_PP_LARGEA
     torch.manual_seed(0)
