@@ -313,6 +313,41 @@ def test_rulebook_car_fhd_stack(ops, syn):
     assert shape == [2, 200, 176]
 
 
+def test_rulebook_nuscenes_fhd_stack_vs_oracle(ops, syn):
+    """BASELINE config 5 at its stated size: the rulebooks of SpMiddleFHD on the all.fhd grid (41 x 1984 x 1984) for two
+    block-filtered synthetic nuScenes frames (~85 k voxels each) -- every SubM pair list and both numberings of every strided
+    layer (first touch = spconv's CPU order, sorted = its GPU order, the chain fed from the previous layer's bitmap) element by
+    element against the oracle."""
+    from second_amd.models import ALL_FHD_NUSC as C
+    rng_, vs, bf = C["point_cloud_range"], C["voxel_size"], C["block_filtering"]
+    coors = []
+    for b, seed in enumerate((3, 4)):
+        c = syn.syn_nusc_cloud(seed, 293000, tuple(rng_), scene="urban")
+        r = orc.points_to_voxel(c, vs, rng_, 1, C["max_voxels"])
+        keep = orc.block_filter(r["voxels"], r["coordinates"], r["num_points_per_voxel"], [1984, 1984], bf["block_factor"], bf["block_size"],
+                                bf["height_threshold"], 3.0)
+        coors.append(np.concatenate([np.full((int(keep.sum()), 1), b, np.int32), r["coordinates"][keep]], 1))
+    idx = np.concatenate(coors).astype(np.int32)
+    assert len(idx) > 160000
+    idx_sorted, sites, shape = idx, None, [41, 1984, 1984]
+    for ks, st, pd in ((3, 2, 1), (3, 2, 1), (3, 2, (0, 1, 1)), ((3, 1, 1), (2, 1, 1), 0)):
+        rb = ops.rulebook_subm(dev(idx), 2, shape, 3, 1, want_pairs=True)
+        _, pairs, pair_num = orc.rulebook_subm(idx, 2, shape, 3)
+        np.testing.assert_array_equal(rb["pair_num"].cpu().numpy(), pair_num)
+        np.testing.assert_array_equal(rb["pairs"].cpu().numpy(), pairs)
+        rb = ops.rulebook_conv(dev(idx), 2, shape, ks, st, pd, 1, want_pairs=True)
+        out_idx, pairs, pair_num, out_shape = orc.rulebook_conv(idx, 2, shape, ks, st, pd)
+        np.testing.assert_array_equal(rb["out_indices"].cpu().numpy(), out_idx)
+        np.testing.assert_array_equal(rb["pairs"].cpu().numpy(), pairs)
+        rs = ops.rulebook_conv(dev(idx_sorted), 2, shape, ks, st, pd, 1, want_pairs=True, numbering="sorted", in_sites=sites)
+        s_idx, s_pairs, s_num, _ = orc.rulebook_conv_sorted(idx_sorted, 2, shape, ks, st, pd)
+        np.testing.assert_array_equal(rs["out_indices"].cpu().numpy(), s_idx)
+        np.testing.assert_array_equal(rs["pair_num"].cpu().numpy(), s_num)
+        np.testing.assert_array_equal(rs["pairs"].cpu().numpy(), s_pairs)
+        idx, idx_sorted, sites, shape = out_idx, s_idx, rs["site_table"], out_shape.tolist()
+    assert shape == [2, 248, 248]
+
+
 # ------------------------------------------------------------------ indice_conv
 CONV_SHAPES = [(4, 16), (16, 16), (16, 32), (32, 32), (32, 64), (64, 64), (5, 7), (64, 128)]
 
