@@ -788,6 +788,30 @@ def test_pfn_kernel_matches_reference_module_and_oracle(ops, golden):
     np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-4, atol=1e-4)
 
 
+def test_pointpillars_front_end_at_config4_size_vs_oracle(ops, syn):
+    """BASELINE config 4's front end at its stated size: a synthetic 10-sweep nuScenes cloud (~293 k points) on the all.pp.largea
+    grid (0.25 m pillars, 60 points per pillar, cap 30 000; all.pp.largea.config:6-15): pillars, slot order and contents bit-exact vs
+    the sequential oracle (25-27 k pillars, near ones holding hundreds of points); the PillarFeatureNet kernel on those pillars vs the
+    oracle (1e-4); the pseudo image bit-exact."""
+    from second_amd.models import ALL_PP_LARGEA as C
+    rng_, vs = C["point_cloud_range"], C["voxel_size"]
+    cloud = syn.syn_nusc_cloud(5, 293000, tuple(rng_), scene="urban")
+    res = _check_voxelize(ops, [cloud], vs, rng_, C["max_points_per_voxel"], C["max_voxels"], "break")
+    p = res["voxel_num"]
+    assert 20000 < p <= C["max_voxels"] and int(res["num_points_per_voxel"].max()) == C["max_points_per_voxel"]
+    vox, npts, coords = res["voxels"][:p].contiguous(), res["num_points_per_voxel"][:p].contiguous(), res["coordinates"][:p].contiguous()
+    rng = np.random.default_rng(3)
+    wt = (rng.standard_normal((9, 64)) / 3).astype(np.float32)
+    sc, sh = rng.uniform(0.5, 1.5, 64).astype(np.float32), rng.uniform(-0.3, 0.3, 64).astype(np.float32)
+    xo, yo = vs[0] / 2 + rng_[0], vs[1] / 2 + rng_[1]
+    ref = orc.pfn_forward(vox.cpu().numpy(), npts.cpu().numpy(), coords.cpu().numpy(), wt, sc, sh, vs[0], vs[1], xo, yo)
+    out = ops.pfn_forward(vox, npts, coords, dev(wt), dev(sc), dev(sh), vs[0], vs[1], xo, yo)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-4, atol=1e-4)
+    ny, nx = int(round((rng_[4] - rng_[1]) / vs[1])), int(round((rng_[3] - rng_[0]) / vs[0]))
+    img = ops.pillar_scatter(out, coords, 1, ny, nx)
+    np.testing.assert_array_equal(img.cpu().numpy(), orc.pillar_scatter(out.cpu().numpy(), coords.cpu().numpy(), 1, ny, nx))
+
+
 def test_block_filter_vs_oracle(ops):
     rng = np.random.default_rng(1)
     rng_, vs = [-10, -10, -3, 10, 10, 1], [0.1, 0.1, 0.2]
