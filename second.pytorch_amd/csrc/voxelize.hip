@@ -24,6 +24,7 @@ struct VoxParams {
     float lo[3], vs[3];
     int grid[3];  // x, y, z
     int num_points, num_features, batch, max_points, max_voxels, cap_mode;
+    int peek;        // k_vox_hash: look before the atomics (pays when most points share their cell with an earlier point)
     uint32_t table_mask;
 };
 
@@ -57,8 +58,30 @@ __global__ __launch_bounds__(kBlock) void k_vox_hash(const float *__restrict__ p
     int b = frame_of(offs, p.batch, i);
     unsigned long long vol = (unsigned long long)p.grid[0] * p.grid[1] * p.grid[2];
     unsigned long long lin = ((unsigned long long)c[2] * p.grid[1] + c[1]) * p.grid[0] + c[0];
-    uint32_t s = hash_insert(keys, p.table_mask, (unsigned long long)b * vol + lin);
-    atomicMin(&vals[s], i);
+    // Peek before the atomics (agent-scope loads: L2): a slot only goes empty -> key and vals[] only decreases, so a key already in
+    // place / an index already smaller is final and the returning compare-and-swap (a fabric round trip) and the atomicMin can be
+    // skipped; a stale read only costs the atomic we would have issued anyway.  Pillars collect hundreds of points each
+    // (nuscenes/all.pp.largea): most points find their cell taken by an earlier one.
+    // (p.peek is set by the host when the points outnumber the voxel capacity more than twice -- nuScenes sweeps: 358 -> 335 us
+    // for config 4's voxeliser, 230 -> 211 us for config 5's; on KITTI-like clouds, ~1 point per voxel, the extra loads cost 5 us.)
+    const unsigned long long key = (unsigned long long)b * vol + lin;
+    uint32_t s;
+    if (p.peek) {
+        s = hash64(key) & p.table_mask;
+        while (true) {
+            unsigned long long cur = __hip_atomic_load(&keys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (cur == key) break;
+            if (cur == kEmptyKey) {
+                cur = atomicCAS(&keys[s], kEmptyKey, key);
+                if (cur == kEmptyKey || cur == key) break;
+            }
+            s = (s + 1) & p.table_mask;
+        }
+        if (__hip_atomic_load(&vals[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > i) atomicMin(&vals[s], i);
+    } else {
+        s = hash_insert(keys, p.table_mask, key);
+        atomicMin(&vals[s], i);
+    }
     pslot[i] = (int)s;
 }
 
@@ -450,6 +473,7 @@ SEC_API int sec_voxelize_f32(const float *points, const int *point_offsets, int 
     p.num_points = num_points; p.num_features = num_features; p.batch = batch;
     p.max_points = max_points; p.max_voxels = max_voxels; p.cap_mode = cap_mode;
     p.table_mask = w.table - 1;
+    p.peek = (long long)num_points > 2ll * batch * max_voxels ? 1 : 0;
 
     int rc;
     {   // one init launch instead of four memset nodes; only the rows that can be live (#voxels <= #points) are touched
