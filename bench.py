@@ -192,8 +192,13 @@ def kernel_table(det, points, offsets, reps=30):
         if name == "voxelize":
             pts = a[0]
             nv = int(res["voxel_offsets"][-1].item())
-            f, t = pts.shape[1], res["voxels"].shape[1]
-            ent.update(bytes=4 * f * pts.shape[0] + nv * (4 * f * t + 16), detail=f"{pts.shape[0]} points -> {nv} voxels")
+            f = pts.shape[1]
+            if res.get("voxels") is not None:
+                t = res["voxels"].shape[1]
+                ent.update(bytes=4 * f * pts.shape[0] + nv * (4 * f * t + 16), detail=f"{pts.shape[0]} points -> {nv} voxels")
+            else:            # fill=False: point lists only, the [rows, T, F] tensor is never written (pfn_forward_slots reads the lists)
+                ent.update(bytes=4 * f * pts.shape[0] + nv * 20 + 4 * pts.shape[0],
+                           detail=f"{pts.shape[0]} points -> {nv} voxels (point lists only, no voxel tensor)")
         elif name == "rulebook_subm":
             n = live(kw.get("n_dev"), a[0].shape[0])
             p_ = int((res["nbr_out"][:n] >= 0).sum().item())
@@ -217,9 +222,14 @@ def kernel_table(det, points, offsets, reps=30):
                        kernel=(ops.last_kernel_name() if plan in (11, 13, 14) else "") or PLAN_NAMES.get(plan, str(plan)),
                        detail=f"{cin}->{cout} k{k} {m} rows {p_} pairs")
         elif name == "pfn_forward":
-            vox_, npv = a[0], a[1]
-            n = live(kw.get("num_dev"), vox_.shape[0])
-            t_, f_ = vox_.shape[1], vox_.shape[2]
+            if isinstance(a[1], dict):           # pfn_forward_slots(points, vox, ...): pillars read through the voxeliser's point lists
+                vd = a[1]
+                n = live(kw.get("num_dev"), vd["coordinates"].shape[0])
+                t_, f_ = int(vd["site_table"][4]), a[0].shape[1]
+            else:
+                vox_, npv = a[0], a[1]
+                n = live(kw.get("num_dev"), vox_.shape[0])
+                t_, f_ = vox_.shape[1], vox_.shape[2]
             # every point slot of a live pillar read once (4F bytes), 64 output channels written once
             ent.update(bytes=4 * f_ * t_ * n + 4 * n + 16 * n + elt(res.dtype) * res.shape[1] * n, flop=2.0 * n * t_ * (f_ + 5) * res.shape[1],
                        detail=f"PillarFeatureNet {n} pillars x {t_} point slots x {f_} -> {res.shape[1]} channels")

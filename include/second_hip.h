@@ -58,6 +58,8 @@ const char *sec_last_kernel_name(void);
  * Outputs are compact: cloud b's voxels are rows [voxel_offsets[b], voxel_offsets[b+1]).
  *   voxels [batch*max_voxels, max_points, num_features] (zero padded), coors [.,4] = (b,z,y,x),
  *   num_points_per_voxel [.], voxel_offsets [batch+1];
+ *   voxels may be NULL (then mean must be NULL too): the tensor is not written, the per-voxel point lists stay in the workspace
+ *   for a consumer that walks them itself (sec_pfn_fwd_slots);
  *   mean (optional, may be NULL) [., mean_features] = SimpleVoxel.forward
  *   (second/pytorch/models/voxel_encoder.py:220-225) fused as an epilogue, stored as mean_dtype (SEC_F32, or the 16-bit
  *   dtype of the sparse stack that consumes it: the reference's `.to(dtype)` of example_convert_to_torch, train.py:36-38).
@@ -257,6 +259,15 @@ int sec_pfn_fwd(const float *voxels, const int *num_points, const int *coords, i
                 const int *num_dev, int max_points, int num_features, const float *weight_t,
                 const float *scale, const float *shift, int channels, float vx, float vy,
                 float x_offset, float y_offset, void *out, int out_dtype, void *stream);
+/* The same on the voxeliser's point lists instead of a [P, T, 4] tensor: `points` is the flat point array sec_voxelize_f32 was
+ * called on, (vox_workspace, vox_num_points, vox_batch, vox_max_voxels, max_points) identify that call's workspace, which still
+ * holds every pillar's point indices (sec_voxelize_f32 may then be called with voxels = NULL: it skips writing the tensor and only
+ * fills num_points_per_voxel).  Bit-identical to sec_pfn_fwd on the materialised pillars. */
+int sec_pfn_fwd_slots(const float *points, const void *vox_workspace, size_t vox_workspace_bytes, int vox_num_points,
+                      int vox_batch, int vox_max_voxels, int max_points, int num_features, const int *num_points_per_voxel,
+                      const int *coords, int num_pillars, const int *num_dev, const float *weight_t, const float *scale,
+                      const float *shift, int channels, float vx, float vy, float x_offset, float y_offset, void *out,
+                      int out_dtype, void *stream);
 
 /* PillarFeatureNet in TRAINING mode (PFNLayer.forward under train(), pointpillars.py:51-65, trained by train.py:316-322):
  * Linear(9, C, bias=False) on the decorated, masked points, BatchNorm1d with BATCH statistics over all P * T rows (padded slots

@@ -191,6 +191,8 @@ inline size_t scan_scratch_ints(long long n) { return (size_t)div_up(n, kScanTil
 int exclusive_scan_i32(const int *in, int *out, long long n, int *total_out, int *scratch, hipStream_t st);
 
 // voxelize.hip: hash table left in the workspace of sec_voxelize_f32 (see sec_rulebook_subm3d_after_voxelize)
+bool vox_slots_of(const void *ws, size_t bytes, int n, int batch, int max_voxels, int max_points, const int **count,
+                  const int **slot_idx);
 bool vox_table_of(const void *ws, size_t bytes, int n, int batch, int max_voxels, int max_points, const unsigned long long **keys,
                   const int **svid, uint32_t *mask);
 

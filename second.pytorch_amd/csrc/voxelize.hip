@@ -440,6 +440,27 @@ bool vox_table_of(const void *ws, size_t bytes, int n, int batch, int max_voxels
     return true;
 }
 
+// the per-voxel point lists of a finished sec_voxelize_f32 call: count[row] points (uncapped), slot_idx[row * max_points + t] = index
+// of the t-th of them in the caller's point array (the first max_points, in arrival order) -- what k_vox_fill copies from.  A
+// consumer that walks these lists itself (sec_pfn_fwd_slots) needs no [rows, max_points, F] tensor at all.
+bool vox_slots_of(const void *ws, size_t bytes, int n, int batch, int max_voxels, int max_points, const int **count,
+                  const int **slot_idx) {
+    VoxWorkspace w = carve_vox(const_cast<void *>(ws), bytes, n, batch, max_voxels, max_points);
+    if (!ws || w.bytes > bytes) return false;
+    *count = w.count;
+    *slot_idx = w.slot_idx;
+    return true;
+}
+
+// sec_voxelize_f32 with voxels == NULL: only the per-voxel point counts are written (the point lists stay in the workspace)
+__global__ __launch_bounds__(kBlock) void k_vox_counts(const int *__restrict__ voxel_offsets, const int *__restrict__ count, VoxParams p,
+                                                      int *__restrict__ num_points_per_voxel) {
+    const int vid = blockIdx.x * kBlock + threadIdx.x;
+    if (vid >= voxel_offsets[p.batch]) return;
+    const int n = count[vid];
+    num_points_per_voxel[vid] = n > p.max_points ? p.max_points : n;
+}
+
 }  // namespace sec
 
 using namespace sec;
@@ -456,7 +477,7 @@ SEC_API int sec_voxelize_f32(const float *points, const int *point_offsets, int 
                              void *mean, int mean_features, int mean_dtype, void *workspace, size_t workspace_bytes,
                              void *stream) {
     if (num_points < 0 || num_features < 3 || batch <= 0 || max_points <= 0 || max_voxels <= 0 ||
-        !h_range6 || !h_voxel_size3 || !voxels || !coors || !num_points_per_voxel || !voxel_offsets ||
+        !h_range6 || !h_voxel_size3 || (!voxels && mean) || !coors || !num_points_per_voxel || !voxel_offsets ||
         (mean && (mean_features <= 0 || mean_features > num_features || mean_dtype < SEC_F32 || mean_dtype > SEC_BF16)))
         return SEC_E_INVALID;
     hipStream_t st = (hipStream_t)stream;
@@ -515,7 +536,10 @@ SEC_API int sec_voxelize_f32(const float *points, const int *point_offsets, int 
     }
     long long cap = (long long)batch * max_voxels;
     long long bound = num_points < cap ? num_points : cap;  // #voxels <= #points
-    if (bound > 0 && mean && num_features == 4 && max_points <= kCascadeMaxPoints &&
+    if (bound > 0 && !voxels) {
+        // the caller consumes the point lists in the workspace directly (sec_pfn_fwd_slots): no [rows, max_points, F] tensor
+        hipLaunchKernelGGL(k_vox_counts, dim3(div_up(bound, kBlock)), dim3(kBlock), 0, st, voxel_offsets, w.count, p, num_points_per_voxel);
+    } else if (bound > 0 && mean && num_features == 4 && max_points <= kCascadeMaxPoints &&
         (reinterpret_cast<uintptr_t>(points) & 15) == 0 && (reinterpret_cast<uintptr_t>(voxels) & 15) == 0) {
         const dim3 gf(div_up(bound, kBlock));
         if (mean_dtype == SEC_F32)

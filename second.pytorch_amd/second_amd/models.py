@@ -176,6 +176,13 @@ class PillarFeatureNet(nn.Module):
         shift = (l.norm.bias - l.norm.running_mean * scale).float()
         return l.linear.weight.detach().t().contiguous().float(), scale.detach().contiguous(), shift.detach().contiguous()
 
+    def forward_slots(self, points, vox, out_dtype=None, num_dev=None):
+        """Inference straight from the voxeliser's point lists (``vox`` = generate_device(points, ..., fill=False)): the
+        [P, T, 4] pillar tensor is neither written nor read; bit-identical to :meth:`forward` on the materialised pillars."""
+        wt, scale, shift = self.folded()
+        return ops.pfn_forward_slots(points, vox, wt, scale, shift, self.vx, self.vy, self.x_offset, self.y_offset,
+                                     out_dtype=out_dtype, num_dev=num_dev)
+
     def forward(self, features, num_voxels, coors, out_dtype=None, num_dev=None):
         l = self.pfn_layers[0]
         if features.is_cuda and not self.training and not torch.is_grad_enabled():
@@ -739,10 +746,17 @@ class SecondDetector(nn.Module):
         batch_size = point_offsets.numel() - 1
         nf = self.cfg["num_point_features"]
         if self.pillars:
-            vox = self.voxel_generator.generate_device(points, point_offsets, sync=not static)
+            # inference on 4-feature points: the PillarFeatureNet walks the voxeliser's point lists (no [P, 60, 4] tensor: 98 MB
+            # written and re-read per step at nuScenes size); SEC_PFN_SLOTS=0 materialises the pillars as the reference does
+            slots = (not self.training and not torch.is_grad_enabled() and nf == 4 and points.shape[1] == 4 and points.is_cuda
+                     and os.environ.get("SEC_PFN_SLOTS", "1") == "1")
+            vox = self.voxel_generator.generate_device(points, point_offsets, sync=not static, fill=not slots)
             nd = vox["voxel_offsets"][batch_size:] if static else None    # device count of live pillars
-            feats = self.voxel_feature_extractor(vox["voxels"], vox["num_points_per_voxel"], vox["coordinates"],
-                                                 out_dtype=self._infer_dtype, num_dev=nd)
+            if slots:
+                feats = self.voxel_feature_extractor.forward_slots(points, vox, out_dtype=self._infer_dtype, num_dev=nd)
+            else:
+                feats = self.voxel_feature_extractor(vox["voxels"], vox["num_points_per_voxel"], vox["coordinates"],
+                                                     out_dtype=self._infer_dtype, num_dev=nd)
             preds = self.network_forward(feats, vox["coordinates"], batch_size, num_active_dev=nd)
             return self.predict_device(preds, batch_size)
         if not static:

@@ -44,13 +44,15 @@ def _traced(name):
 # ----------------------------------------------------------------------------- voxelisation
 @_traced("voxelize")
 def voxelize(points, point_offsets, point_cloud_range, voxel_size, max_points, max_voxels,
-             cap_mode="break", mean_features=0, sync=True, mean_dtype=None):
+             cap_mode="break", mean_features=0, sync=True, mean_dtype=None, fill=True):
     """Batched points_to_voxel (spconv VoxelGeneratorV2.generate; second/data/preprocess.py:301-316).
 
     points [N,F] float32 cuda (clouds concatenated), point_offsets [B+1] int32 cuda.
     Returns dict(voxels, coordinates [M,4]=(b,z,y,x), num_points_per_voxel, voxel_offsets [B+1], mean?).
     With ``sync=True`` the outputs are sliced to the total voxel count (one D2H of B+1 ints);
     with ``sync=False`` they keep capacity B*max_voxels and only rows < voxel_offsets[B] are defined.
+    ``fill=False``: no ``voxels`` tensor (None in the result); the per-voxel point lists stay in the workspace behind
+    ``site_table`` for :func:`pfn_forward_slots` (``points`` must stay alive and unchanged until then).
     """
     rt.require_gpu(points, point_offsets)
     assert points.dtype == torch.float32 and points.dim() == 2 and points.is_contiguous()
@@ -60,7 +62,8 @@ def voxelize(points, point_offsets, point_cloud_range, voxel_size, max_points, m
     dev = points.device
     cap = batch * max_voxels
     rows = min(cap, max(n, 1))
-    voxels = torch.empty((rows, max_points, f), dtype=torch.float32, device=dev)
+    assert fill or not mean_features, "the SimpleVoxel mean is an epilogue of the fill"
+    voxels = torch.empty((rows, max_points, f), dtype=torch.float32, device=dev) if fill else None
     coors = torch.empty((rows, 4), dtype=torch.int32, device=dev)
     npv = torch.empty((rows,), dtype=torch.int32, device=dev)
     voff = torch.empty((batch + 1,), dtype=torch.int32, device=dev)
@@ -84,7 +87,7 @@ def voxelize(points, point_offsets, point_cloud_range, voxel_size, max_points, m
     if sync:
         total = int(voff[-1].item())
         for k in ("voxels", "coordinates", "num_points_per_voxel", "mean"):
-            if k in out:
+            if out.get(k) is not None:
                 out[k] = out[k][:total]
         out["voxel_num"] = total
     return out
@@ -536,6 +539,26 @@ class PFNTrainFunction(torch.autograd.Function):
         rt.check(rc, "sec_pfn_train_bwd")
         wd, gd, bd = ctx.dtypes
         return (None, None, None, dwt.t().contiguous().to(wd), dga.to(gd), dbe.to(bd), None, None, None, None, None)
+
+
+@_traced("pfn_forward")
+def pfn_forward_slots(points, vox, weight_t, scale, shift, vx, vy, x_offset, y_offset, out_dtype=None, num_dev=None):
+    """:func:`pfn_forward` straight from the voxeliser's point lists: ``vox`` = the result of ``voxelize(points, ..., fill=False)``
+    (or with fill), ``points`` the array it was called on.  Bit-identical to the tensor form; no [P, T, 4] tensor is read."""
+    rt.require_gpu(points, weight_t, scale, shift)
+    kind, ws, n, max_voxels, max_points, _ = vox["site_table"]
+    assert kind == "vox" and points.shape[0] == n and points.dtype == torch.float32 and points.is_contiguous()
+    npv, coords = vox["num_points_per_voxel"], vox["coordinates"].contiguous()
+    p, c = coords.shape[0], weight_t.shape[1]
+    batch = vox["voxel_offsets"].numel() - 1
+    out_dtype = out_dtype or torch.float32
+    out = torch.empty((p, c), dtype=out_dtype, device=points.device)
+    rc = rt.lib().sec_pfn_fwd_slots(rt.ptr(points), rt.ptr(ws), ws.numel(), n, batch, max_voxels, max_points, points.shape[1],
+                                    rt.ptr(npv), rt.ptr(coords), p, rt.ptr(num_dev), rt.ptr(weight_t), rt.ptr(scale), rt.ptr(shift), c,
+                                    float(vx), float(vy), float(x_offset), float(y_offset), rt.ptr(out), rt.dtype_code(out_dtype),
+                                    rt.stream())
+    rt.check(rc, "sec_pfn_fwd_slots")
+    return out
 
 
 @_traced("voxel_block_filter")

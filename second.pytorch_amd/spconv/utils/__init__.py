@@ -43,11 +43,11 @@ class VoxelGeneratorV2:
             assert block_factor > 0 and block_size > 0, "block_filtering needs block_factor / block_size"
 
     # -- device-resident path (no host round trip): points [N,F] cuda float32, offsets [B+1] cuda int32
-    def generate_device(self, points, point_offsets, max_voxels=None, mean_features=0, sync=True, mean_dtype=None):
+    def generate_device(self, points, point_offsets, max_voxels=None, mean_features=0, sync=True, mean_dtype=None, fill=True):
         if not self._block_filtering:
             return _ops.voxelize(points, point_offsets, self._point_cloud_range.tolist(), self._voxel_size.tolist(),
                                  self._max_num_points, int(max_voxels or self._max_voxels), self._mode,
-                                 mean_features=mean_features, sync=sync, mean_dtype=mean_dtype)
+                                 mean_features=mean_features, sync=sync, mean_dtype=mean_dtype, fill=fill)
         # points_to_voxel_3d_with_filtering: voxelise, then drop flat (ground-only) neighbourhoods
         vox = _ops.voxelize(points, point_offsets, self._point_cloud_range.tolist(), self._voxel_size.tolist(),
                             self._max_num_points, int(max_voxels or self._max_voxels), self._mode, sync=False)

@@ -44,7 +44,7 @@ def _pairs_from_nbr(nbr_out, n_in):
 
 
 def voxelize(points, point_offsets, point_cloud_range, voxel_size, max_points, max_voxels, cap_mode="break",
-             mean_features=0, sync=True, mean_dtype=None):
+             mean_features=0, sync=True, mean_dtype=None, fill=True):
     pts, offs = _np(points), _np(point_offsets)
     outs = {"voxels": [], "coordinates": [], "num_points_per_voxel": []}
     voff = [0]

@@ -807,6 +807,14 @@ def test_pointpillars_front_end_at_config4_size_vs_oracle(ops, syn):
     ref = orc.pfn_forward(vox.cpu().numpy(), npts.cpu().numpy(), coords.cpu().numpy(), wt, sc, sh, vs[0], vs[1], xo, yo)
     out = ops.pfn_forward(vox, npts, coords, dev(wt), dev(sc), dev(sh), vs[0], vs[1], xo, yo)
     np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-4, atol=1e-4)
+    # the same from the voxeliser's point lists (no pillar tensor): bit-identical, with and without the tensor having been written
+    pts, offs = syn.batch_clouds([cloud])
+    pts, offs = dev(pts), dev(offs)
+    for fill in (False, True):
+        v2 = ops.voxelize(pts, offs, rng_, vs, C["max_points_per_voxel"], C["max_voxels"], "break", fill=fill)
+        assert (v2["voxels"] is None) == (not fill) and v2["voxel_num"] == p
+        assert torch.equal(v2["num_points_per_voxel"], npts) and torch.equal(v2["coordinates"], coords)
+        assert torch.equal(ops.pfn_forward_slots(pts, v2, dev(wt), dev(sc), dev(sh), vs[0], vs[1], xo, yo), out)
     ny, nx = int(round((rng_[4] - rng_[1]) / vs[1])), int(round((rng_[3] - rng_[0]) / vs[0]))
     img = ops.pillar_scatter(out, coords, 1, ny, nx)
     np.testing.assert_array_equal(img.cpu().numpy(), orc.pillar_scatter(out.cpu().numpy(), coords.cpu().numpy(), 1, ny, nx))
