@@ -379,7 +379,12 @@ int sec_rotate_iou_f32(const float *boxes, int n, const float *qboxes, int k, in
  *   '+1' convention), 1 = CPU path (rotated: standup-IoU pre-filter then IoU >= thr; axis-aligned:
  *   eps convention, >= thr).
  *   keep [batch, max_n] receives kept positions (ascending), num_keep [batch] their count (capped at post_max, <=0 = no cap).
+ *   semantics | SEC_NMS_EXACT_CLIP: every standup-overlapping pair goes through the reference's polygon clipper.  Without the
+ *   flag a pair whose inscribed-circle LOWER bound of the IoU already clears the threshold is decided without clipping (same
+ *   keep lists wherever the reference's clipper computes the true intersection; it can under-report it for vertex lists of
+ *   more than 8 points / near-degenerate boxes, where the flag reproduces nms_gpu.py's own answer).
  *   workspace: sec_nms_workspace_bytes(batch, max_n). */
+#define SEC_NMS_EXACT_CLIP 256
 size_t sec_nms_workspace_bytes(int batch, int max_n);
 int sec_nms_sorted_f32(const float *dets, const int *counts, int batch, int max_n, int stride,
                        float thresh, int kind, int semantics, float eps, int post_max, int *keep,

@@ -233,6 +233,8 @@ __global__ __launch_bounds__(kBlock) void k_nms_mask(const float *__restrict__ d
     // n read from the device) with a stride of gridDim.x.  A grid sized for max_n (1000 candidates: 8 000 workgroups at ROWS = 16)
     // spends its time launching workgroups that read counts[b] and leave -- ~6 rounds of them per CU before the few live ones.
     const int b = blockIdx.y;
+    const bool screen = !(semantics & SEC_NMS_EXACT_CLIP);      // inscribed-circle lower bound before the clipper (see below)
+    semantics &= 0xff;
     int n = counts[b];
     if (n > max_n) n = max_n;
     const int ncb = (n + 63) >> 6, nrb = (n + ROWS - 1) / ROWS;
@@ -322,7 +324,7 @@ __global__ __launch_bounds__(kBlock) void k_nms_mask(const float *__restrict__ d
                             cand = iw * ih / ua > 0.0f;
                         }
                     }
-                    if (cand && thresh >= 0.0f) {
+                    if (cand && thresh >= 0.0f && screen) {
                         // Certain suppression without clipping: the circles of radius min(w, l) / 2 about the two centres lie inside
                         // their boxes, so the lens they share is a LOWER bound of the polygon intersection, and IoU grows with the
                         // intersection.  If even that bound clears the threshold (with a margin far above fp32 rounding) the pair is
@@ -550,29 +552,21 @@ SEC_API int sec_nms_sorted_f32(const float *dets, const int *counts, int batch, 
                                int kind, int semantics, float eps, int post_max, int *keep, int *num_keep,
                                void *workspace, size_t workspace_bytes, void *stream) {
     if (!dets || !counts || !keep || !num_keep || batch <= 0 || max_n <= 0 || max_n > 4096 ||
-        stride < (kind == 0 ? 5 : 4) || kind < 0 || kind > 1 || semantics < 0 || semantics > 1)
+        stride < (kind == 0 ? 5 : 4) || kind < 0 || kind > 1 || (semantics & ~SEC_NMS_EXACT_CLIP) < 0 ||
+        (semantics & ~SEC_NMS_EXACT_CLIP) > 1)
         return SEC_E_INVALID;
     if (!workspace || workspace_bytes < sec_nms_workspace_bytes(batch, max_n)) return SEC_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     int words = (max_n + 63) / 64;
     unsigned long long *mask = (unsigned long long *)workspace;
-    // SEC_NMS_TILE_ROWS = 64 | 16 | 8 and SEC_NMS_WGS (workgroups per frame) for A/B runs
-    static int tile_rows = -1, wgs = -1;
-    if (tile_rows < 0) { const char *e = getenv("SEC_NMS_TILE_ROWS"); tile_rows = e ? atoi(e) : 16; }
-    if (wgs < 0) { const char *e = getenv("SEC_NMS_WGS"); wgs = e ? atoi(e) : 0; }
     // a tile costs ~12 us start to finish (box corners, screen, one clipper round), so the launch is as long as the most tiles any
     // workgroup walks: enough workgroups that a few hundred candidates leave each at most one live tile (car.fhd batch 8, ~400
     // candidates per frame, nms_sorted: 64 per frame 44 us, 128: 35 us, 256: 28 us), capped so that 1000 candidates x a large batch
     // do not flood the chip: 2048 / batch, between 32 and 256
-    int per_frame = wgs > 0 ? wgs : 2048 / batch;
-    if (wgs <= 0) per_frame = per_frame < 32 ? 32 : per_frame > 256 ? 256 : per_frame;
+    int per_frame = 2048 / batch;
+    per_frame = per_frame < 32 ? 32 : per_frame > 256 ? 256 : per_frame;
     const dim3 grid(per_frame, batch);
-    if (tile_rows == 64)
-        hipLaunchKernelGGL(k_nms_mask<64>, grid, dim3(kBlock), 0, st, dets, counts, max_n, stride, thresh, kind, semantics, eps, words, mask);
-    else if (tile_rows == 8)
-        hipLaunchKernelGGL(k_nms_mask<8>, grid, dim3(kBlock), 0, st, dets, counts, max_n, stride, thresh, kind, semantics, eps, words, mask);
-    else
-        hipLaunchKernelGGL(k_nms_mask<16>, grid, dim3(kBlock), 0, st, dets, counts, max_n, stride, thresh, kind, semantics, eps, words, mask);
+    hipLaunchKernelGGL(k_nms_mask<16>, grid, dim3(kBlock), 0, st, dets, counts, max_n, stride, thresh, kind, semantics, eps, words, mask);
     hipLaunchKernelGGL(k_nms_reduce, dim3(batch), dim3(64), 0, st, mask, counts, max_n, words, post_max, keep, num_keep);
     return check_launch();
 }

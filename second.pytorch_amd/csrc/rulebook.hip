@@ -650,16 +650,13 @@ __global__ __launch_bounds__(kBlock) void k_bm_dilate(const unsigned *__restrict
 // num_out[0] = live outputs (clamped to out_cap), num_out[1] = raw count
 constexpr int kBmBlk = 8;
 __device__ __forceinline__ int popc4(const uint4 &v) { return __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w); }
+// one tile of the scan: `tile` of `ntiles` (of THIS bitmap), status words of this bitmap; cnt = LDS scratch of kBlock * WPT / 8 ints
 template <int WPT>
-__global__ __launch_bounds__(kBlock) void k_bm_scan(const unsigned *__restrict__ bm, int *__restrict__ prefix8, int out_cap,
-                                                   unsigned long long *__restrict__ status, int *__restrict__ ticket,
-                                                   int *__restrict__ num_out) {
+__device__ __forceinline__ void bm_scan_tile(const unsigned *__restrict__ bm, int *__restrict__ prefix8, int out_cap,
+                                             unsigned long long *__restrict__ status, int tile, int ntiles,
+                                             int *__restrict__ num_out, int *smem, int *cnt) {
     constexpr int BPT = WPT / kBmBlk;                 // blocks per thread
     static_assert(WPT % kBmBlk == 0 && (BPT == 2 || BPT % 4 == 0), "prefix stores are int2 / int4");
-    __shared__ int smem[8];
-    __shared__ int s_tile;
-    __shared__ int cnt[kBlock * BPT];
-    const int tile = scan_take_tile(ticket, &s_tile);
     const int t = threadIdx.x;
     const size_t blk0 = (size_t)tile * kBlock * BPT;
 #pragma unroll
@@ -671,8 +668,8 @@ __global__ __launch_bounds__(kBlock) void k_bm_scan(const unsigned *__restrict__
     int mine[BPT], v = 0;
 #pragma unroll
     for (int k = 0; k < BPT; ++k) { mine[k] = cnt[t * BPT + k]; v += mine[k]; }
-    int r = scan_lookback(v, tile, (int)gridDim.x, status, smem, num_out);
-    if (tile == (int)gridDim.x - 1 && t == 0) {
+    int r = scan_lookback(v, tile, ntiles, status, smem, num_out);
+    if (tile == ntiles - 1 && t == 0) {
         const int tot = num_out[0];
         num_out[1] = tot;
         if (tot > out_cap) num_out[0] = out_cap;
@@ -691,6 +688,16 @@ __global__ __launch_bounds__(kBlock) void k_bm_scan(const unsigned *__restrict__
             *reinterpret_cast<int4 *>(dst + k) = pf;
         }
     }
+}
+template <int WPT>
+__global__ __launch_bounds__(kBlock) void k_bm_scan(const unsigned *__restrict__ bm, int *__restrict__ prefix8, int out_cap,
+                                                   unsigned long long *__restrict__ status, int *__restrict__ ticket,
+                                                   int *__restrict__ num_out) {
+    __shared__ int smem[8];
+    __shared__ int s_tile;
+    __shared__ int cnt[kBlock * (WPT / kBmBlk)];
+    const int tile = scan_take_tile(ticket, &s_tile);
+    bm_scan_tile<WPT>(bm, prefix8, out_cap, status, tile, (int)gridDim.x, num_out, smem, cnt);
 }
 
 // set bits before word `w` of the bitmap: the block's prefix + the popcounts of the block's words in front of it
@@ -800,6 +807,238 @@ __global__ __launch_bounds__(kBlock) void k_subm_nbr_bm(const int *__restrict__ 
         if ((unsigned)j < (unsigned)g.n_in) {
             nbr[(size_t)o * g.kvol + k] = j;
             nbr[(size_t)j * g.kvol + (g.kvol - 1 - k)] = o;
+        }
+    }
+}
+
+
+// ---- the whole rulebook stack of a sparse middle in one call (sec_rulebook_chain_sorted) -----------------------------------------
+// Eight rulebooks (four SubM, four strided) built layer by layer are ~25 dependent launches of 4-17 us each (round 3: 160 us of a
+// 610 us step, 1-3 % of the HBM roofline): every launch pays the ~2 us boundary plus a near-empty grid.  But in the sorted
+// numbering a level's OUTPUT SET is a pure function of the level below -- bitmap l+1 = dilate(bitmap l) -- and every gather table is
+// a pure function of two adjacent bitmaps and their rank prefixes.  So the stack is built in phases, not layers:
+//   front : SubM table of level 0 (probes of the voxeliser's hash table) || level-1 bitmap (atomicOr per voxel) || -1 fill of the
+//           level-1 conv table -- three independent jobs in ONE launch (block ranges);
+//   dilate: bitmap l from bitmap l-1 for l >= 2 (plain loads / stores);
+//   scan  : rank prefixes of ALL levels in one launch (one ticket counter; the look-back chain restarts at every level);
+//   tables: ALL conv and SubM tables, output coordinates and the BEV site map in one launch.  Levels >= 2 are built OUTPUT-side:
+//           a workgroup takes 256 bitmap words, compacts their set bits into LDS (ranks are consecutive: first rank of the run +
+//           position) and its threads walk (output, offset) items with the offset fastest -- every table entry is written, -1
+//           included, in fully coalesced runs: no pre-fill, no scattered stores, no mirror trick.  Level 1 (inputs = voxels in
+//           arrival order, findable only through the hash table) keeps the input-side form on a pre-filled table.
+constexpr int kChainMaxLevels = 6;
+struct ChainLevel {
+    int shape[3];                     // D, H, W of this level's grid
+    int ksize[3], pad[3];             // the strided conv that makes this level from the one below (level >= 1); stride = geo
+    int geo, kvol;                    // 1: 3x3x3 stride 2, 2: (3,1,1) stride (2,1,1)
+    int out_cap;                      // rows reserved for this level (level 0: capacity of the caller's rows)
+    long long n_words;                // bitmap words (padded to the scan tile)
+    unsigned *bm;
+    int *prefix8;
+    unsigned long long *status;       // scan status words of this level
+    int tile0, ntiles, wpt64;         // scan tiles [tile0, tile0 + ntiles) of the scan launch; 64 or 16 words per thread
+    int *nbr_out, *out_indices, *num_out, *subm_nbr;
+    int blk0, blks;                   // word-pass workgroups [blk0, blk0 + blks) of the tables launch
+};
+struct ChainParams {
+    ChainLevel lv[kChainMaxLevels + 1];
+    int levels, batch;
+    int n0;                           // capacity of the level-0 rows
+    const int *indices0, *n0_dev;
+    int *ticket;
+    // tables launch: [0, cand_blks) level-1 candidates, then the word passes, then [map_blk0, ...) the site map
+    int cand_blks, map_blk0;
+    int *site_map;
+    long long map_cells;
+};
+
+__device__ __forceinline__ int chain_live0(const ChainParams &P) {
+    if (!P.n0_dev) return P.n0;
+    const int n = *P.n0_dev;
+    return n < P.n0 ? n : P.n0;
+}
+
+// front: [0, nb_subm) SubM level 0 through the voxel hash table (k_subm_nbr_sym<true>), [nb_subm, nb_subm + nb_set) level-1 bitmap
+// (k_bm_set_x2), the rest: -1 fill of the level-1 conv table
+__global__ __launch_bounds__(kBlock) void k_chain_front(const int *__restrict__ indices, RbGeom gs, RbGeom gc, const int *__restrict__ n_dev,
+                                                       const unsigned long long *__restrict__ keys, const int *__restrict__ svid,
+                                                       int *__restrict__ subm0, unsigned *__restrict__ bm1, int nb_subm, int nb_set,
+                                                       int *__restrict__ fill, long long fill_words) {
+    const int blk = blockIdx.x;
+    if (blk < nb_subm) {
+        const long long t = (long long)blk * kBlock + threadIdx.x;
+        if (t >= (long long)live_rows(gs, n_dev) * 14) return;
+        const int o = (int)(t / 14), k = (int)(t % 14);
+        if (k == 13) { subm0[(size_t)o * 27 + 13] = o; return; }
+        const int kx = k % 3, ky = (k / 3) % 3, kz = k / 9;
+        const int4 c = *reinterpret_cast<const int4 *>(indices + (size_t)o * 4);
+        const int z = c.y + kz - 1, y = c.z + ky - 1, x = c.w + kx - 1;
+        if (z >= 0 && z < gs.in_shape[0] && y >= 0 && y < gs.in_shape[1] && x >= 0 && x < gs.in_shape[2]) {
+            const int s = hash_find(keys, gs.mask, cell_key(c.x, z, y, x, gs.in_shape));
+            if (s >= 0) {
+                const int j = svid[s];
+                if ((unsigned)j < (unsigned)gs.n_in) {
+                    subm0[(size_t)o * 27 + k] = j;
+                    subm0[(size_t)j * 27 + (26 - k)] = o;
+                }
+            }
+        }
+        return;
+    }
+    if (blk < nb_subm + nb_set) {
+        const long long t = (long long)(blk - nb_subm) * kBlock + threadIdx.x;
+        if (t >= (long long)gc.n_in * 4) return;
+        const int j = (int)(t >> 2), c = (int)(t & 3);
+        if (j >= live_rows(gc, n_dev)) return;
+        const int4 q = *reinterpret_cast<const int4 *>(indices + (size_t)j * 4);
+        int kz, ky, oz, oy;
+        if (!cand_offset_fixed<3, 2>(q.y, gc.pad[0], gc.out_shape[0], c >> 1, &kz, &oz)) return;
+        if (!cand_offset_fixed<3, 2>(q.z, gc.pad[1], gc.out_shape[1], c & 1, &ky, &oy)) return;
+        int kx, ox0, ox1;
+        const bool v0 = cand_offset_fixed<3, 2>(q.w, gc.pad[2], gc.out_shape[2], 0, &kx, &ox0);
+        const bool v1 = cand_offset_fixed<3, 2>(q.w, gc.pad[2], gc.out_shape[2], 1, &kx, &ox1);
+        const unsigned rowb = (((unsigned)q.x * gc.out_shape[0] + oz) * gc.out_shape[1] + oy) * gc.out_shape[2];
+        const unsigned l0 = rowb + ox0, l1 = rowb + ox1;
+        if (v0 && v1 && (l0 >> 5) == (l1 >> 5)) {
+            atomicOr(&bm1[l0 >> 5], (1u << (l0 & 31u)) | (1u << (l1 & 31u)));
+        } else {
+            if (v0) atomicOr(&bm1[l0 >> 5], 1u << (l0 & 31u));
+            if (v1) atomicOr(&bm1[l1 >> 5], 1u << (l1 & 31u));
+        }
+        return;
+    }
+    const long long nthreads = (long long)(gridDim.x - nb_subm - nb_set) * kBlock;
+    int4 *f4 = reinterpret_cast<int4 *>(fill);
+    const long long n4 = fill_words >> 2;
+    for (long long i = (long long)(blk - nb_subm - nb_set) * kBlock + threadIdx.x; i < n4; i += nthreads) f4[i] = make_int4(-1, -1, -1, -1);
+    if (blk == nb_subm + nb_set && threadIdx.x < (int)(fill_words & 3)) fill[(n4 << 2) + threadIdx.x] = -1;
+}
+
+// prep: 64-bit words a := 0 (level-1 bitmap + scan control), 32-bit words b := -1 (SubM table of level 0: the mirror writes of the
+// symmetric probe need it)
+__global__ __launch_bounds__(kBlock) void k_chain_prep(uint4 *__restrict__ a, long long na16, int4 *__restrict__ b, long long nb16,
+                                                      int *__restrict__ b_tail, int nb_tail) {
+    const long long stride = (long long)gridDim.x * kBlock;
+    const long long i0 = (long long)blockIdx.x * kBlock + threadIdx.x;
+    for (long long i = i0; i < na16; i += stride) a[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (long long i = i0; i < nb16; i += stride) b[i] = make_int4(-1, -1, -1, -1);
+    if (i0 < nb_tail) b_tail[i0] = -1;
+}
+
+__global__ __launch_bounds__(kBlock) void k_chain_scan(ChainParams P) {
+    __shared__ int smem[8];
+    __shared__ int s_tile;
+    __shared__ int cnt[kBlock * (kBmWpt / kBmBlk)];
+    const int g = scan_take_tile(P.ticket, &s_tile);
+    int l = 1;
+    while (l < P.levels && g >= P.lv[l].tile0 + P.lv[l].ntiles) ++l;
+    const ChainLevel &L = P.lv[l];
+    if (L.wpt64) bm_scan_tile<kBmWpt>(L.bm, L.prefix8, L.out_cap, L.status, g - L.tile0, L.ntiles, L.num_out, smem, cnt);
+    else bm_scan_tile<kBmWptSmall>(L.bm, L.prefix8, L.out_cap, L.status, g - L.tile0, L.ntiles, L.num_out, smem, cnt);
+}
+
+__device__ __forceinline__ int chain_rank(const ChainLevel &L, int b, int z, int y, int x) {
+    if ((unsigned)z >= (unsigned)L.shape[0] || (unsigned)y >= (unsigned)L.shape[1] || (unsigned)x >= (unsigned)L.shape[2]) return -1;
+    const unsigned lin = (((unsigned)b * L.shape[0] + z) * L.shape[1] + y) * L.shape[2] + x;
+    const int r = bm_rank(L.bm, L.prefix8, lin);
+    return r < L.out_cap ? r : -1;             // a rank past the capacity is not a row (overflow is reported by num_out[1])
+}
+
+constexpr int kChainChunk = 1024;              // set bits of a 256-word run handled per LDS round
+__global__ __launch_bounds__(kBlock) void k_chain_tables(ChainParams P) {
+    const int blk = blockIdx.x;
+    if (blk < P.cand_blks) {
+        // level 1, input side: voxel row j reaches <= 8 outputs; nbr_out[rank][k] = j (table pre-filled with -1 by the front launch)
+        const ChainLevel &L = P.lv[1];
+        const long long t = (long long)blk * kBlock + threadIdx.x;
+        const int j = (int)(t >> 3), c = (int)(t & 7);
+        if (j >= chain_live0(P)) return;
+        const int4 q = *reinterpret_cast<const int4 *>(P.indices0 + (size_t)j * 4);
+        int kk[3], out[3];
+        bool ok = cand_offset_fixed<3, 2>(q.y, L.pad[0], L.shape[0], c >> 2, &kk[0], &out[0]);
+        ok &= cand_offset_fixed<3, 2>(q.z, L.pad[1], L.shape[1], (c >> 1) & 1, &kk[1], &out[1]);
+        ok &= cand_offset_fixed<3, 2>(q.w, L.pad[2], L.shape[2], c & 1, &kk[2], &out[2]);
+        if (!ok) return;
+        const int o = chain_rank(L, q.x, out[0], out[1], out[2]);
+        if (o >= 0) L.nbr_out[(size_t)o * 27 + (kk[0] * 3 + kk[1]) * 3 + kk[2]] = j;
+        return;
+    }
+    if (blk >= P.map_blk0) {
+        const ChainLevel &L = P.lv[P.levels];
+        const long long i = (long long)(blk - P.map_blk0) * kBlock + threadIdx.x;
+        if (i >= P.map_cells) return;
+        int r = bm_rank(L.bm, L.prefix8, (unsigned)i);
+        P.site_map[i] = (r >= 0 && r < L.out_cap) ? r + 1 : 0;
+        return;
+    }
+    int l = 1;
+    while (l < P.levels && blk >= P.lv[l].blk0 + P.lv[l].blks) ++l;
+    const ChainLevel &L = P.lv[l];
+    __shared__ int smem[5];
+    __shared__ int s_r0;
+    __shared__ unsigned cells[kChainChunk];
+    __shared__ int4 coord[kChainChunk];
+    const long long w0 = (long long)(blk - L.blk0) * kBlock;
+    const unsigned word = L.bm[w0 + threadIdx.x];
+    int tot;
+    const int ex = block_exclusive_scan(__popc(word), smem, &tot);
+    if (tot == 0) return;
+    if (threadIdx.x == 0) s_r0 = bm_word_prefix(L.bm, L.prefix8, (size_t)w0);
+    const unsigned W = (unsigned)L.shape[2], H = (unsigned)L.shape[1], D = (unsigned)L.shape[0];
+    for (int base = 0; base < tot; base += kChainChunk) {
+        __syncthreads();
+        {   // set bits [base, base + chunk) of the run -> LDS (cell index + decoded coordinates)
+            unsigned wd = word;
+            int e = ex;
+            const unsigned lin0 = (unsigned)(w0 + threadIdx.x) << 5;
+            while (wd) {
+                const int bit = __ffs((int)wd) - 1;
+                wd &= wd - 1u;
+                if (e >= base && e < base + kChainChunk) {
+                    const unsigned lin = lin0 + bit;
+                    const unsigned row = lin / W, x = lin - row * W;
+                    const unsigned plane = row / H, y = row - plane * H;
+                    const unsigned b = plane / D, z = plane - b * D;
+                    cells[e - base] = lin;
+                    coord[e - base] = make_int4((int)b, (int)z, (int)y, (int)x);
+                }
+                ++e;
+            }
+        }
+        __syncthreads();
+        const int r0 = s_r0 + base;
+        int n = tot - base;
+        if (n > kChainChunk) n = kChainChunk;
+        if (r0 + n > L.out_cap) n = L.out_cap - r0;         // rows past the capacity do not exist
+        if (n <= 0) break;
+        if (L.out_indices)
+            for (int e = threadIdx.x; e < n; e += kBlock) *reinterpret_cast<int4 *>(L.out_indices + (size_t)(r0 + e) * 4) = coord[e];
+        if (L.subm_nbr) {
+            int *dst = L.subm_nbr + (size_t)r0 * 27;
+            for (int it = threadIdx.x; it < n * 27; it += kBlock) {
+                const int e = it / 27, k = it - e * 27;
+                const int4 c = coord[e];
+                const int kz = k / 9, ky = (k / 3) % 3, kx = k % 3;
+                dst[it] = k == 13 ? r0 + e : chain_rank(L, c.x, c.y + kz - 1, c.z + ky - 1, c.w + kx - 1);
+            }
+        }
+        if (l >= 2) {
+            const ChainLevel &I = P.lv[l - 1];
+            int *dst = L.nbr_out + (size_t)r0 * L.kvol;
+            if (L.geo == 1) {
+                for (int it = threadIdx.x; it < n * 27; it += kBlock) {
+                    const int e = it / 27, k = it - e * 27;
+                    const int4 c = coord[e];
+                    const int kz = k / 9, ky = (k / 3) % 3, kx = k % 3;
+                    dst[it] = chain_rank(I, c.x, 2 * c.y - L.pad[0] + kz, 2 * c.z - L.pad[1] + ky, 2 * c.w - L.pad[2] + kx);
+                }
+            } else {
+                for (int it = threadIdx.x; it < n * 3; it += kBlock) {
+                    const int e = it / 3, k = it - e * 3;
+                    const int4 c = coord[e];
+                    dst[it] = chain_rank(I, c.x, 2 * c.y - L.pad[0] + k, c.z - L.pad[1], c.w - L.pad[2]);
+                }
+            }
         }
     }
 }
@@ -1239,4 +1478,160 @@ SEC_API int sec_rulebook_conv3d_tables(int n_in, const int *h_ksize3, const int 
     }
     if (pairs) return emit_pairs(nbr_in, n_in, kvol, /*mirror=*/0, w.blk, w.scan2, pairs, pair_num, st);
     return SEC_OK;
+}
+
+
+// ---- fused chain: host side ---------------------------------------------------------------------------------------------------------
+namespace sec {
+struct ChainWorkspace {
+    unsigned *bm[kChainMaxLevels + 1];
+    int *prefix[kChainMaxLevels + 1];
+    long long n_words[kChainMaxLevels + 1];
+    int ntiles[kChainMaxLevels + 1], wpt64[kChainMaxLevels + 1];
+    int *ticket;
+    unsigned long long *status;
+    long long zero16;        // 16-byte words from bm[1] to the end of the scan control block
+    size_t bytes;
+};
+static ChainWorkspace carve_chain(void *ws, size_t cap, int batch, int levels, const int *shapes) {
+    ChainWorkspace w{};
+    Arena a(ws, cap);
+    int tiles = 0;
+    for (int l = 1; l <= levels; ++l) {
+        const long long cells = bm_cells(batch, shapes + 3 * l);
+        w.n_words[l] = (long long)div_up(div_up(cells > 0 ? cells : 1, 32), kBmTile) * kBmTile;
+        w.wpt64[l] = w.n_words[l] > kBmSmallWords;
+        w.ntiles[l] = (int)(w.n_words[l] / (kBlock * (w.wpt64[l] ? kBmWpt : kBmWptSmall)));
+        tiles += w.ntiles[l];
+    }
+    w.bm[1] = a.take<unsigned>(w.n_words[1]);
+    const long long ctl_words = 4 + 2 * (long long)tiles;          // [ticket, -, -, -, status (64-bit) ...]
+    w.ticket = a.take<int>(ctl_words + 4);
+    w.status = reinterpret_cast<unsigned long long *>(w.ticket + 4);
+    w.zero16 = (long long)((reinterpret_cast<char *>(w.ticket + ctl_words + 4) - reinterpret_cast<char *>(w.bm[1])) / 16);
+    for (int l = 2; l <= levels; ++l) w.bm[l] = a.take<unsigned>(w.n_words[l]);
+    for (int l = 1; l <= levels; ++l) w.prefix[l] = a.take<int>(w.n_words[l] / kBmBlk);
+    w.bytes = align_up(a.used);
+    return w;
+}
+static bool chain_geometry_ok(int levels, const int *shapes, const int *ksize, const int *stride, const int *pad, int batch, int *geo) {
+    if (levels < 1 || levels > kChainMaxLevels) return false;
+    for (int l = 1; l <= levels; ++l) {
+        const int *ks = ksize + 3 * (l - 1), *st = stride + 3 * (l - 1), *pd = pad + 3 * (l - 1);
+        const bool g1 = ks[0] == 3 && ks[1] == 3 && ks[2] == 3 && st[0] == 2 && st[1] == 2 && st[2] == 2;
+        const bool g2 = ks[0] == 3 && ks[1] == 1 && ks[2] == 1 && st[0] == 2 && st[1] == 1 && st[2] == 1;
+        if (!g1 && !g2) return false;
+        if (l == 1 && !g1) return false;
+        geo[l] = g1 ? 1 : 2;
+        for (int d = 0; d < 3; ++d) {
+            if (pd[d] < 0 || pd[d] > 1) return false;
+            const int in = shapes[3 * (l - 1) + d], out = shapes[3 * l + d];
+            if (in <= 0 || out != (in + 2 * pd[d] - (ks[d] - 1) - 1) / st[d] + 1) return false;
+        }
+        if (bm_cells(batch, shapes + 3 * l) >= (1ll << 32) - 64) return false;
+    }
+    return true;
+}
+}  // namespace sec
+
+SEC_API size_t sec_rulebook_chain_workspace_bytes(int batch, int levels, const int *h_shapes) {
+    if (batch <= 0 || levels < 1 || levels > kChainMaxLevels || !h_shapes) return 0;
+    return carve_chain(nullptr, 0, batch, levels, h_shapes).bytes;
+}
+
+SEC_API int sec_rulebook_chain_sorted(const int *indices0, int n0, const int *n0_dev, int batch, int levels, const int *h_shapes,
+                                      const int *h_ksize, const int *h_stride, const int *h_pad, const int *h_out_cap,
+                                      int *const *h_nbr_out, int *const *h_out_indices, int *const *h_num_out,
+                                      int *const *h_subm_nbr, const void *vox_workspace, size_t vox_workspace_bytes,
+                                      int vox_num_points, int vox_max_voxels, int vox_max_points, const int *h_vox_grid3_zyx,
+                                      int *site_map, void *workspace, size_t workspace_bytes, void *stream) {
+    if (!indices0 || n0 <= 0 || batch <= 0 || !h_shapes || !h_ksize || !h_stride || !h_pad || !h_out_cap || !h_nbr_out ||
+        !h_num_out || !h_subm_nbr || !h_out_indices)
+        return SEC_E_INVALID;
+    int geo[kChainMaxLevels + 1] = {0};
+    if (!chain_geometry_ok(levels, h_shapes, h_ksize, h_stride, h_pad, batch, geo)) return SEC_E_UNSUPPORTED;
+    for (int l = 1; l <= levels; ++l)
+        if (!h_nbr_out[l - 1] || !h_num_out[l - 1] || h_out_cap[l - 1] <= 0) return SEC_E_INVALID;
+    if (h_subm_nbr[0] && (!vox_workspace || !h_vox_grid3_zyx)) return SEC_E_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    ChainWorkspace w = carve_chain(workspace, workspace_bytes, batch, levels, h_shapes);
+    if (!workspace || w.bytes > workspace_bytes) return SEC_E_WORKSPACE;
+
+    ChainParams P{};
+    P.levels = levels; P.batch = batch; P.n0 = n0; P.indices0 = indices0; P.n0_dev = n0_dev; P.ticket = w.ticket;
+    int tile0 = 0, blk0 = div_up((long long)n0 * 8, kBlock);
+    P.cand_blks = blk0;
+    for (int l = 0; l <= levels; ++l) {
+        ChainLevel &L = P.lv[l];
+        for (int d = 0; d < 3; ++d) L.shape[d] = h_shapes[3 * l + d];
+        L.out_cap = l == 0 ? n0 : h_out_cap[l - 1];
+        L.subm_nbr = h_subm_nbr[l];
+        if (l == 0) continue;
+        for (int d = 0; d < 3; ++d) { L.ksize[d] = h_ksize[3 * (l - 1) + d]; L.pad[d] = h_pad[3 * (l - 1) + d]; }
+        L.geo = geo[l]; L.kvol = geo[l] == 1 ? 27 : 3;
+        L.n_words = w.n_words[l]; L.bm = w.bm[l]; L.prefix8 = w.prefix[l];
+        L.status = w.status + tile0; L.tile0 = tile0; L.ntiles = w.ntiles[l]; L.wpt64 = w.wpt64[l];
+        tile0 += w.ntiles[l];
+        L.nbr_out = h_nbr_out[l - 1]; L.out_indices = h_out_indices[l - 1]; L.num_out = h_num_out[l - 1];
+        L.blk0 = blk0; L.blks = (int)(w.n_words[l] / kBlock);
+        blk0 += L.blks;
+    }
+    P.map_blk0 = blk0;
+    P.site_map = site_map;
+    P.map_cells = site_map ? bm_cells(batch, h_shapes + 3 * levels) : 0;
+    const int map_blks = site_map ? div_up(P.map_cells, (long long)kBlock) : 0;
+
+    // geometry of the front launch: SubM level 0 over the voxeliser's table, level-1 bitmap
+    RbGeom gs{}, gc{};
+    const int k3[3] = {3, 3, 3};
+    int rc = fill_geom(gs, h_shapes, nullptr, k3, nullptr, nullptr, nullptr, n0, batch);
+    if (rc) return rc;
+    if ((rc = fill_geom(gc, h_shapes, h_shapes + 3, h_ksize, h_stride, h_pad, nullptr, n0, batch))) return rc;
+    const unsigned long long *keys = nullptr;
+    const int *svid = nullptr;
+    if (h_subm_nbr[0]) {
+        uint32_t mask;
+        for (int d = 0; d < 3; ++d) {
+            if (h_vox_grid3_zyx[d] <= 0 || h_vox_grid3_zyx[d] > h_shapes[d]) return SEC_E_INVALID;
+            gs.in_shape[d] = h_vox_grid3_zyx[d];       // the voxeliser keys its cells with ITS grid (see sec_rulebook_subm3d_after_voxelize)
+        }
+        if (!vox_table_of(vox_workspace, vox_workspace_bytes, vox_num_points, batch, vox_max_voxels, vox_max_points, &keys, &svid, &mask))
+            return SEC_E_WORKSPACE;
+        gs.mask = mask;
+    }
+    // 1. prep: level-1 bitmap + scan control := 0, SubM table of level 0 := -1
+    {
+        const long long nb = h_subm_nbr[0] ? (long long)n0 * 27 : 0;
+        long long most = w.zero16 > nb / 4 ? w.zero16 : nb / 4;
+        int blocks = div_up(most > 0 ? most : 1, kBlock);
+        if (blocks > 256 * 8) blocks = 256 * 8;
+        hipLaunchKernelGGL(k_chain_prep, dim3(blocks), dim3(kBlock), 0, st, reinterpret_cast<uint4 *>(w.bm[1]), w.zero16,
+                           reinterpret_cast<int4 *>(h_subm_nbr[0]), nb / 4, h_subm_nbr[0] ? h_subm_nbr[0] + (nb / 4) * 4 : nullptr,
+                           (int)(nb & 3));
+    }
+    // 2. front: SubM level 0 || level-1 bitmap || -1 fill of the level-1 conv table
+    {
+        const int nb_subm = h_subm_nbr[0] ? div_up((long long)n0 * 14, kBlock) : 0;
+        const int nb_set = div_up((long long)n0 * 4, kBlock);
+        const long long fill_words = (long long)P.lv[1].out_cap * 27;
+        int nb_fill = div_up(fill_words / 4 + 1, (long long)kBlock * 4);
+        if (nb_fill > 512) nb_fill = 512;
+        hipLaunchKernelGGL(k_chain_front, dim3(nb_subm + nb_set + nb_fill), dim3(kBlock), 0, st, indices0, gs, gc, n0_dev, keys, svid,
+                           h_subm_nbr[0], w.bm[1], nb_subm, nb_set, P.lv[1].nbr_out, fill_words);
+    }
+    // 3. bitmaps of the levels above, each from the one below
+    for (int l = 2; l <= levels; ++l) {
+        RbGeom g{};
+        if ((rc = fill_geom(g, h_shapes + 3 * (l - 1), h_shapes + 3 * l, h_ksize + 3 * (l - 1), h_stride + 3 * (l - 1), h_pad + 3 * (l - 1),
+                            nullptr, 0, batch)))
+            return rc;
+        const RbFill none{nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0};
+        const unsigned nb = (unsigned)(w.n_words[l] / kBlock);
+        if (geo[l] == 1) hipLaunchKernelGGL(k_bm_dilate<1>, dim3(nb), dim3(kBlock), 0, st, w.bm[l - 1], w.n_words[l - 1], g, w.bm[l], w.n_words[l], none);
+        else hipLaunchKernelGGL(k_bm_dilate<2>, dim3(nb), dim3(kBlock), 0, st, w.bm[l - 1], w.n_words[l - 1], g, w.bm[l], w.n_words[l], none);
+    }
+    // 4. rank prefixes of every level, 5. every table
+    hipLaunchKernelGGL(k_chain_scan, dim3(tile0), dim3(kBlock), 0, st, P);
+    hipLaunchKernelGGL(k_chain_tables, dim3(P.map_blk0 + map_blks), dim3(kBlock), 0, st, P);
+    return check_launch();
 }

@@ -748,7 +748,9 @@ class SecondDetector(nn.Module):
         if self.pillars:
             # inference on 4-feature points: the PillarFeatureNet walks the voxeliser's point lists (no [P, 60, 4] tensor: 98 MB
             # written and re-read per step at nuScenes size); SEC_PFN_SLOTS=0 materialises the pillars as the reference does
+            # (block filtering returns compacted pillars without the voxeliser's point lists: tensor path)
             slots = (not self.training and not torch.is_grad_enabled() and nf == 4 and points.shape[1] == 4 and points.is_cuda
+                     and not getattr(self.voxel_generator, "_block_filtering", False)
                      and os.environ.get("SEC_PFN_SLOTS", "1") == "1")
             vox = self.voxel_generator.generate_device(points, point_offsets, sync=not static, fill=not slots)
             nd = vox["voxel_offsets"][batch_size:] if static else None    # device count of live pillars
@@ -889,7 +891,9 @@ class SecondDetector(nn.Module):
                     out = self.predict_device(preds, batch_size)
         finally:
             ops.set_rulebook_numbering(prev)
-        self._stage_keepalive = getattr(self, "_stage_keepalive", []) + [(vox, spatial, preds)]   # buffers the later graphs read
+        # buffers the later graphs read: owned by whoever keeps the replays (InFlightRunner stores them per lane); the detector
+        # only remembers the LAST capture, so rebuilding runners does not accumulate graph-pool buffers here
+        self._last_stage_buffers = (vox, spatial, preds)
         return (ga.replay, gb.replay, gc.replay), out
 
     # -- post-processing -----------------------------------------------------------------------------
@@ -1032,11 +1036,13 @@ class InFlightRunner:
         # segments fill the rest of the chip
         self.serialize_rpn = bool(serialize_rpn) and branches <= 1 and int(inflight) > 1
         self._rpn_token = None
+        self._keepalive = []                      # per lane: the buffers its three graphs hand to each other
         assert not (private_inputs and branches > 1), "private input buffers are a single-chain feature"
         for _ in range(max(1, int(inflight))):
             if self.serialize_rpn:
                 pk, ok = (points.clone(), point_offsets.clone()) if private_inputs else (points, point_offsets)
                 replay, outs = det._capture_stages(pk, ok)
+                self._keepalive.append(det._last_stage_buffers)
                 self.inputs.append((pk, ok))
                 if private_inputs:
                     self.host_outputs.append({k: torch.empty(v.shape, dtype=v.dtype, pin_memory=True) for k, v in outs.items()})
@@ -1073,14 +1079,11 @@ class InFlightRunner:
                 ra, rb, rc = self.replays[k]
                 st = lane if lane is not None else torch.cuda.current_stream()
                 ra()
-                width = int(os.environ.get("SEC_RPN_TOKENS", "1"))          # RPN segments allowed at a time (A/B knob; default 1)
-                toks = self._rpn_token or []
-                if len(toks) >= width:
-                    st.wait_event(toks[-width])             # the RPN segment `width` steps back (another lane) has finished
+                if self._rpn_token is not None:
+                    st.wait_event(self._rpn_token)          # the previous step's RPN segment (another lane) has finished
                 rb()
-                ev = torch.cuda.Event()
-                ev.record(st)
-                self._rpn_token = (toks + [ev])[-4:]
+                self._rpn_token = torch.cuda.Event()        # one RPN segment at a time (two at a time measured slower, round 3)
+                self._rpn_token.record(st)
                 rc()
             else:
                 self.replays[k]()

@@ -717,9 +717,10 @@ def rotate_iou(boxes, qboxes, criterion=-1):
 
 
 @_traced("nms_sorted")
-def nms_sorted(dets, counts, thresh, kind="rotate", semantics="numba", eps=1.0, post_max=0):
+def nms_sorted(dets, counts, thresh, kind="rotate", semantics="numba", eps=1.0, post_max=0, exact_clip=False):
     """Greedy NMS of score-sorted boxes. dets [B,max_n,stride] float32, counts [B] int32 (device).
-    Returns (keep [B,max_n] int32 positions, num_keep [B] int32), all on device, no host sync."""
+    Returns (keep [B,max_n] int32 positions, num_keep [B] int32), all on device, no host sync.
+    ``exact_clip``: SEC_NMS_EXACT_CLIP -- no inscribed-circle shortcut, every overlapping pair runs the reference's clipper."""
     rt.require_gpu(dets, counts)
     assert dets.dtype == torch.float32 and dets.dim() == 3 and dets.is_contiguous() and counts.dtype == torch.int32
     b, max_n, stride = dets.shape
@@ -728,7 +729,7 @@ def nms_sorted(dets, counts, thresh, kind="rotate", semantics="numba", eps=1.0, 
     l = rt.lib()
     ws = rt.workspace(l.sec_nms_workspace_bytes(b, max_n), dets.device)
     rc = l.sec_nms_sorted_f32(rt.ptr(dets), rt.ptr(counts), b, max_n, stride, float(thresh),
-                              {"rotate": 0, "axis_aligned": 1}[kind], {"numba": 0, "cpu": 1}[semantics], float(eps),
+                              {"rotate": 0, "axis_aligned": 1}[kind], {"numba": 0, "cpu": 1}[semantics] | (256 if exact_clip else 0), float(eps),
                               int(post_max or 0), rt.ptr(keep), rt.ptr(num_keep), rt.ptr(ws), ws.numel(), rt.stream())
     rt.check(rc, "sec_nms_sorted_f32")
     return keep, num_keep

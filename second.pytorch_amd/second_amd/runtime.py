@@ -41,9 +41,51 @@ class SecondHipError(RuntimeError):
     pass
 
 
+# ---- fork guard ---------------------------------------------------------------------------------------------------------
+# The reference forks its DataLoader workers (second/pytorch/train.py:262-277) and they call VoxelGeneratorV2.generate
+# (second/data/preprocess.py:301-316), which runs on the GPU here.  A HIP context does not survive fork(): a child of a
+# process that already initialised HIP can neither use the parent's context nor create its own (the runtime's state is
+# inherited half-initialised; the first call hangs or fails with "Cannot re-initialize CUDA in forked subprocess").  Such a
+# child is marked at fork time and every entry into the library raises with instructions instead.
+_forked_after_gpu_init = False
+_parent_used_gpu = False
+
+
+def _gpu_in_use():
+    return _lib is not None or torch.cuda.is_initialized()
+
+
+def _before_fork():
+    global _parent_used_gpu
+    _parent_used_gpu = _gpu_in_use()
+
+
+def _after_fork_in_child():
+    global _forked_after_gpu_init
+    if _parent_used_gpu:
+        _forked_after_gpu_init = True
+
+
+os.register_at_fork(before=_before_fork, after_in_child=_after_fork_in_child)
+
+FORK_MESSAGE = (
+    "second.pytorch_amd: this process was fork()ed from a parent that had already initialised the GPU; a HIP context does not "
+    "survive fork(), so spconv ops (VoxelGeneratorV2.generate, rulebooks, NMS) cannot run here. `import spconv` makes "
+    "torch.utils.data.DataLoader(num_workers > 0) default to the 'spawn' start method -- construct the DataLoader through "
+    "torch.utils.data.DataLoader after importing spconv (the unmodified second/pytorch/train.py does), pass "
+    "multiprocessing_context='spawn' yourself, use num_workers=0, or voxelise in the main process with "
+    "VoxelGeneratorV2.generate_device / SecondDetector.forward_points.")
+
+
+def check_not_forked():
+    if _forked_after_gpu_init:
+        raise SecondHipError(FORK_MESSAGE)
+
+
 def lib():
     """The loaded library.  Raises if it has not been built (python second.pytorch_amd/build.py)."""
     global _lib
+    check_not_forked()
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise SecondHipError(
@@ -135,10 +177,12 @@ def dtype_code(dt):
 
 
 def require_gpu(*tensors):
+    check_not_forked()
     for t in tensors:
         if t is not None and not t.is_cuda:
             raise SecondHipError(
-                "second_amd ops run on the GPU only (got a CPU tensor); there is no CPU fallback")
+                "second_amd ops are GPU only (got a CPU tensor): there is no CPU path by decision (INTEGRATION.md section 1, CPU tensors); "
+                "move the tensors to the MI355X -- the reference does with example_convert_to_torch(..., device), train.py:24-55")
 
 
 def ptr(t):

@@ -157,13 +157,16 @@ class DeviceTrainer:
                 return p["box_preds"], p["cls_preds"], p.get("dir_cls_preds", p["cls_preds"].new_zeros(0))
         # the warm-up iterations of the capture run BatchNorm in training mode: keep the running statistics out of it
         saved = {k: v.clone() for k, v in rpn.state_dict().items() if "running_" in k or "num_batches" in k}
-        try:
+        ops._bn_counter_stack.append([])        # throw-away frame: the three non-capturing warm-up iterations of make_graphed_callables
+        try:                                    # must not queue num_batches_tracked increments into the step's deferred list
             sample = x.detach().clone().requires_grad_()
             fn = torch.cuda.make_graphed_callables(_Mixed(), (sample,))
         except Exception as e:  # noqa: BLE001 -- capture is an optimisation: the eager path is always correct
             import warnings
             warnings.warn(f"second_amd: hipGraph capture of the RPN training segment failed ({e!r}); running it eagerly")
             fn = None
+        finally:
+            ops._bn_counter_stack.pop()
         with torch.no_grad():
             sd = rpn.state_dict()
             for k, v in saved.items():

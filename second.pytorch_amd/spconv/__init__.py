@@ -5,6 +5,17 @@ second/pytorch/core/box_torch_ops.py:13, second/core/non_max_suppression/nms_cpu
 second/core/box_np_ops.py:5), so second/pytorch/train.py runs unmodified with this directory first on
 sys.path.  GPU only: ops on CPU tensors raise (no fallback).
 """
+from second_amd.compat import spawn_dataloader_workers as _spawn_dataloader_workers
+from second_amd import runtime as _runtime  # noqa: F401  (registers the fork guard)
+
+# Zero-edit path: the reference forks its DataLoader workers (second/pytorch/train.py:262-277) and the workers call
+# spconv.utils.VoxelGeneratorV2.generate, which needs a HIP context here.  Importing spconv is all the reference does, so the
+# import itself switches DataLoader(num_workers > 0) to spawned workers (idempotent; an explicit multiprocessing_context wins;
+# SEC_KEEP_FORK=1 opts out).
+import os as _os
+if _os.environ.get("SEC_KEEP_FORK", "0") != "1":
+    _spawn_dataloader_workers()
+
 from .tensor import SparseConvTensor, Rulebook
 from .modules import SparseModule, SparseSequential
 from .conv import SparseConvolution, SubMConv3d, SparseConv3d

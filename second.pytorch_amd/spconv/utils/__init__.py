@@ -4,8 +4,9 @@ second/core/non_max_suppression/nms_gpu.py:8,16, nms_cpu.py:5-6,14,27).
 
 The arithmetic runs on the MI355X through libsecond_hip.so: numpy arrays are staged to the GPU and back
 (that is what the upstream `non_max_suppression` did too).  GPU required; no CPU path.
-NOTE: HIP contexts do not survive fork(); use a `spawn` DataLoader context or voxelise in the main process
-(`VoxelGeneratorV2.generate_device`) when driving the reference's training loop.
+NOTE: HIP contexts do not survive fork().  `import spconv` therefore makes torch DataLoader workers default to the `spawn`
+start method (the reference forks them, train.py:262-277), and a child that WAS forked from a GPU-initialised parent gets a
+SecondHipError with instructions from every entry point (second_amd.runtime.check_not_forked) -- never a hang.
 """
 import numpy as np
 import torch
@@ -14,6 +15,8 @@ from second_amd import ops as _ops
 
 
 def _dev():
+    from second_amd.runtime import check_not_forked
+    check_not_forked()      # a forked DataLoader worker of a GPU-initialised parent: clear error instead of a hang
     if not torch.cuda.is_available():
         from second_amd.runtime import SecondHipError
         raise SecondHipError("spconv.utils needs a GPU: the MI355X path has no CPU fallback")
