@@ -204,6 +204,22 @@ def kernel_table(det, points, offsets, reps=30):
             p_ = int((res["nbr_out"][:n] >= 0).sum().item())
             k = res["nbr_out"].shape[1]
             ent.update(bytes=16 * n + 8 * p_ + 4 * k, detail=f"subm {n} rows {p_} pairs" + site_note(kw, "site_table"))
+        elif name == "rulebook_chain":
+            # all rulebooks of the stack from one fused build: the sum of the per-layer formulas above over its levels
+            lv = res["levels"]
+            tot, parts = 0, []
+            for li, L in enumerate(lv):
+                n = live(L["num_dev"], L["cap"])
+                if L["subm_nbr"] is not None:
+                    p_ = int((L["subm_nbr"][:n] >= 0).sum().item())
+                    tot += 16 * n + 8 * p_ + 4 * 27
+                    parts.append(f"subm{li} {n} rows {p_} pairs")
+                if li >= 1:
+                    n_in = live(lv[li - 1]["num_dev"], lv[li - 1]["cap"])
+                    p_ = int((L["nbr_out"][:n] >= 0).sum().item())
+                    tot += 16 * n_in + 16 * n + 8 * p_ + 4 * L["nbr_out"].shape[1]
+                    parts.append(f"conv{li} {n_in} -> {n} rows {p_} pairs")
+            ent.update(bytes=tot, detail="fused chain (sorted numbering): " + "; ".join(parts) + ("; + BEV site map" if res["site_map"] is not None else ""))
         elif name == "rulebook_conv":
             n = live(kw.get("n_dev"), a[0].shape[0])
             m = live(res["num_out_dev"], res["num_out"])
@@ -475,7 +491,7 @@ def measure(step, barrier, steps, warmup, world=1, device=None):
     for _ in range(warmup):
         r = step()
     t_start, prev, warm_windows = time.perf_counter(), None, 0
-    while True:
+    while SELF_WARM_MAX_S > 0:
         t, r = window(50)
         warm_windows += 1
         spent = agree(time.perf_counter() - t_start)
@@ -485,7 +501,7 @@ def measure(step, barrier, steps, warmup, world=1, device=None):
     times = []
     t, r = window(steps)
     times.append(t)
-    n = int(min(200, max(5, -(-TIMED_MIN_S // max(t, 1e-6)))))
+    n = int(min(200, max(5, -(-TIMED_MIN_S // max(t, 1e-6))))) if TIMED_MIN_S > 0 else 1
     for _ in range(n - 1):
         t, r = window(steps)
         times.append(t)
@@ -708,9 +724,14 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="frames (samples) per step per GPU; 0 = the workload's BASELINE batch")
     ap.add_argument("--default-heads", action="store_true",
                     help="car.fhd: keep the default-initialised heads (tie-dominated top-k; the round-1/2 bench network)")
+    ap.add_argument("--profile-run", action="store_true",
+                    help="for runs under rocprofv3: no self-warming beyond --warmup and ONE timed window (keeps the trace small); the "
+                         "printed value is then not a benchmark figure")
     ap.add_argument("--dry-run", action="store_true", help="launcher plumbing only: ranks report themselves (gloo), no GPU work")
     args = ap.parse_args()
-    global WL
+    global WL, SELF_WARM_MIN_S, SELF_WARM_MAX_S, TIMED_MIN_S
+    if args.profile_run:
+        SELF_WARM_MIN_S = SELF_WARM_MAX_S = TIMED_MIN_S = 0.0
     WL = dict(WORKLOADS[args.workload])
     if args.batch > 0:
         WL["desc"] = WL["desc"].replace(f"batch={WL['batch']} ", f"batch={args.batch} ")

@@ -35,7 +35,7 @@ extern "C" {
 #define SEC_F16 1
 #define SEC_BF16 2
 
-#define SEC_ABI_VERSION 1
+#define SEC_ABI_VERSION 2
 int sec_abi_version(void);
 /* last HIP error string seen by this library (thread-unsafe convenience for diagnostics) */
 const char *sec_last_error(void);
@@ -233,6 +233,27 @@ int sec_sparse_site_map(const int *indices, int n, const int *num_dev, int batch
  * conv_workspace = the build's workspace, (d, h, w) = its output grid; rows beyond min(*num_dev, rows_cap) read as absent. */
 int sec_sparse_site_map_sorted(const void *conv_workspace, size_t conv_workspace_bytes, const int *num_dev, int rows_cap,
                                int batch, int d, int h, int w, int *site_map, void *stream);
+/* The WHOLE rulebook stack of a sparse middle in one call (second/pytorch/models/middle.py:146-189: SubM and strided layers
+ * alternate; every spconv.ops.get_indice_pairs call of the stack, spconv GPU numbering = ascending linear cell index).
+ * Level 0 = the caller's rows `indices0` [n0, 4] (any order, e.g. the voxeliser's arrival order; live rows = *n0_dev when given);
+ * level l = 1 .. levels = outputs of the l-th strided conv (3x3x3 stride 2, or (3,1,1) stride (2,1,1); padding 0 / 1 per dim;
+ * level 1 must be 3x3x3 stride 2; anything else: SEC_E_UNSUPPORTED -> build layer by layer).  h_shapes [(levels + 1) * 3] = grids
+ * (D, H, W) of levels 0 .. levels; h_ksize / h_stride / h_pad [levels * 3]; h_out_cap [levels] = rows reserved per level.
+ * HOST arrays of DEVICE pointers, one per level: h_nbr_out[l-1] [cap_l, kvol_l] (input row of level l-1 per (output, offset),
+ * -1 = none), h_out_indices[l-1] [cap_l, 4] (coordinates of the output rows), h_num_out[l-1] int[2] = (live outputs clamped to cap_l, raw count:
+ * raw > cap_l = overflow, reported, never out of bounds); h_subm_nbr[l] for l = 0 .. levels: the 3x3x3 SubM table [cap_l, 27]
+ * on level l's sites or NULL.  h_subm_nbr[0] needs the finished sec_voxelize_f32 call's workspace (its hash table is the site
+ * lookup of level 0; arguments as sec_rulebook_subm3d_after_voxelize).  site_map (or NULL): [batch, D, H, W] of the LAST level,
+ * row + 1 / 0 (sec_sparse_site_map_sorted).  Rows at or past num_out[0] of any table are unspecified.
+ * Same tables, element for element, as the layer-by-layer sorted builds (sec_rulebook_conv3d_build_sorted + _tables_sorted +
+ * sec_rulebook_subm3d_after_conv_sorted / _after_voxelize) -- in 4 + (levels - 1) launches instead of ~25. */
+size_t sec_rulebook_chain_workspace_bytes(int batch, int levels, const int *h_shapes);
+int sec_rulebook_chain_sorted(const int *indices0, int n0, const int *n0_dev, int batch, int levels, const int *h_shapes,
+                              const int *h_ksize, const int *h_stride, const int *h_pad, const int *h_out_cap,
+                              int *const *h_nbr_out, int *const *h_out_indices, int *const *h_num_out,
+                              int *const *h_subm_nbr, const void *vox_workspace, size_t vox_workspace_bytes,
+                              int vox_num_points, int vox_max_voxels, int vox_max_points, const int *h_vox_grid3_zyx,
+                              int *site_map, void *workspace, size_t workspace_bytes, void *stream);
 int sec_conv2d_nhwc_gather(const void *features, long long feature_rows, const int *site_map, int batch, int h,
                            int w, const void *packed_weight, const float *bias, int cout, int relu, void *y,
                            int dtype, void *stream);

@@ -573,6 +573,8 @@ struct RbFill {
     int *c; long long nc;                     // := -1
     int *d; long long nd;                     // := -1
 };
+// (A form with one input row per lane and a shuffle OR across 16-lane groups was measured in round 4: 34 us instead of 9 us on
+// car.fhd's second level -- 16 x the threads, each still paying the address arithmetic -- and 7.8 instead of 8.6 us on the third.)
 template <int GEO>
 __device__ __forceinline__ unsigned bm_dilate_word(const unsigned *__restrict__ bm_in, long long n_words_in, const RbGeom &g, long long wi) {
     const unsigned Wo = (unsigned)g.out_shape[2], Ho = (unsigned)g.out_shape[1], Do = (unsigned)g.out_shape[0];
@@ -652,7 +654,7 @@ constexpr int kBmBlk = 8;
 __device__ __forceinline__ int popc4(const uint4 &v) { return __popc(v.x) + __popc(v.y) + __popc(v.z) + __popc(v.w); }
 // one tile of the scan: `tile` of `ntiles` (of THIS bitmap), status words of this bitmap; cnt = LDS scratch of kBlock * WPT / 8 ints
 template <int WPT>
-__device__ __forceinline__ void bm_scan_tile(const unsigned *__restrict__ bm, int *__restrict__ prefix8, int out_cap,
+__device__ __forceinline__ int bm_scan_tile(const unsigned *__restrict__ bm, int *__restrict__ prefix8, int out_cap,
                                              unsigned long long *__restrict__ status, int tile, int ntiles,
                                              int *__restrict__ num_out, int *smem, int *cnt) {
     constexpr int BPT = WPT / kBmBlk;                 // blocks per thread
@@ -669,6 +671,7 @@ __device__ __forceinline__ void bm_scan_tile(const unsigned *__restrict__ bm, in
 #pragma unroll
     for (int k = 0; k < BPT; ++k) { mine[k] = cnt[t * BPT + k]; v += mine[k]; }
     int r = scan_lookback(v, tile, ntiles, status, smem, num_out);
+    const int r_first = r;                            // set bits before this thread's blocks (blk0 + t * BPT ...)
     if (tile == ntiles - 1 && t == 0) {
         const int tot = num_out[0];
         num_out[1] = tot;
@@ -688,6 +691,7 @@ __device__ __forceinline__ void bm_scan_tile(const unsigned *__restrict__ bm, in
             *reinterpret_cast<int4 *>(dst + k) = pf;
         }
     }
+    return r_first;
 }
 template <int WPT>
 __global__ __launch_bounds__(kBlock) void k_bm_scan(const unsigned *__restrict__ bm, int *__restrict__ prefix8, int out_cap,
@@ -745,6 +749,25 @@ __device__ __forceinline__ int bm_rank(const unsigned *__restrict__ bm, const in
     const unsigned word = bm[lin >> 5], bit = 1u << (lin & 31u);
     if (!(word & bit)) return -1;
     return bm_word_prefix(bm, prefix8, (size_t)(lin >> 5)) + __popc(word & (bit - 1u));
+}
+
+// The same rank in ONE round of loads: the 32-byte block that holds the cell's word (two 16-byte loads of one sector) and the
+// block's prefix are fetched together; bit test, popcounts of the words in front and of the bits below come out of registers.
+// bm_rank needs two dependent rounds (word, then block + prefix): in the output-side table build of the fused chain a thread
+// walks tens of (output, offset) items, each a rank lookup, and the dependent round doubled the latency of every item.
+__device__ __forceinline__ int bm_rank1(const unsigned *__restrict__ bm, const int *__restrict__ prefix8, unsigned lin) {
+    const size_t blk = lin >> 8;                                     // kBmBlk = 8 words = 256 cells
+    const unsigned wi = (lin >> 5) & 7u, bit = 1u << (lin & 31u);
+    const uint4 a = *reinterpret_cast<const uint4 *>(bm + blk * kBmBlk), b = *reinterpret_cast<const uint4 *>(bm + blk * kBmBlk + 4);
+    int r = prefix8[blk];
+    const unsigned w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    unsigned word = 0u;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        word = wi == (unsigned)q ? w[q] : word;
+        r += wi > (unsigned)q ? __popc(w[q]) : 0;
+    }
+    return (word & bit) ? r + __popc(word & (bit - 1u)) : -1;
 }
 
 // Site map of the outputs of a sorted build, straight from its bitmap: map[cell] = rank + 1 (the output row, rows are numbered
@@ -838,7 +861,8 @@ struct ChainLevel {
     unsigned long long *status;       // scan status words of this level
     int tile0, ntiles, wpt64;         // scan tiles [tile0, tile0 + ntiles) of the scan launch; 64 or 16 words per thread
     int *nbr_out, *out_indices, *num_out, *subm_nbr;
-    int blk0, blks;                   // word-pass workgroups [blk0, blk0 + blks) of the tables launch
+    int sblk0, sblks, cblk0, cblks;   // tables launch: workgroups of the SubM table / the conv table of this level
+    int eblk0, eblks;                 // emit launch: workgroups of this level (one thread per bitmap word)
 };
 struct ChainParams {
     ChainLevel lv[kChainMaxLevels + 1];
@@ -864,7 +888,12 @@ __global__ __launch_bounds__(kBlock) void k_chain_front(const int *__restrict__ 
                                                        const unsigned long long *__restrict__ keys, const int *__restrict__ svid,
                                                        int *__restrict__ subm0, unsigned *__restrict__ bm1, int nb_subm, int nb_set,
                                                        int *__restrict__ fill, long long fill_words) {
-    const int blk = blockIdx.x;
+    // roles are interleaved in groups of ten workgroups (7 SubM probes, 2 bitmap atomics, 1 fill): the three jobs lean on
+    // different parts of the memory system (L2 random reads / memory-side atomics / streaming stores) and the dispatcher hands out
+    // workgroups in index order -- back-to-back block ranges would run them one after the other
+    const int grp = blockIdx.x / 10, role = blockIdx.x % 10;
+    const int blk = role < 7 ? grp * 7 + role : role < 9 ? nb_subm + grp * 2 + (role - 7) : nb_subm + nb_set + grp;
+    if (role < 7 ? blk >= nb_subm : role < 9 ? blk >= nb_subm + nb_set : false) return;
     if (blk < nb_subm) {
         const long long t = (long long)blk * kBlock + threadIdx.x;
         if (t >= (long long)live_rows(gs, n_dev) * 14) return;
@@ -874,13 +903,14 @@ __global__ __launch_bounds__(kBlock) void k_chain_front(const int *__restrict__ 
         const int4 c = *reinterpret_cast<const int4 *>(indices + (size_t)o * 4);
         const int z = c.y + kz - 1, y = c.z + ky - 1, x = c.w + kx - 1;
         if (z >= 0 && z < gs.in_shape[0] && y >= 0 && y < gs.in_shape[1] && x >= 0 && x < gs.in_shape[2]) {
+            // (fetching key and row of the home slot together -- one dependent round less on a hit -- was measured: 33 -> 42 us.
+            // The probes are bound by the lines they pull from the Infinity Cache, not by latency: a speculative row load is
+            // another random line for the ~80 % of probes that miss.)
             const int s = hash_find(keys, gs.mask, cell_key(c.x, z, y, x, gs.in_shape));
-            if (s >= 0) {
-                const int j = svid[s];
-                if ((unsigned)j < (unsigned)gs.n_in) {
-                    subm0[(size_t)o * 27 + k] = j;
-                    subm0[(size_t)j * 27 + (26 - k)] = o;
-                }
+            const int j = s >= 0 ? svid[s] : -1;
+            if ((unsigned)j < (unsigned)gs.n_in) {
+                subm0[(size_t)o * 27 + k] = j;
+                subm0[(size_t)j * 27 + (26 - k)] = o;
             }
         }
         return;
@@ -907,7 +937,7 @@ __global__ __launch_bounds__(kBlock) void k_chain_front(const int *__restrict__ 
         }
         return;
     }
-    const long long nthreads = (long long)(gridDim.x - nb_subm - nb_set) * kBlock;
+    const long long nthreads = (long long)(gridDim.x / 10) * kBlock;
     int4 *f4 = reinterpret_cast<int4 *>(fill);
     const long long n4 = fill_words >> 2;
     for (long long i = (long long)(blk - nb_subm - nb_set) * kBlock + threadIdx.x; i < n4; i += nthreads) f4[i] = make_int4(-1, -1, -1, -1);
@@ -925,6 +955,7 @@ __global__ __launch_bounds__(kBlock) void k_chain_prep(uint4 *__restrict__ a, lo
     if (i0 < nb_tail) b_tail[i0] = -1;
 }
 
+// rank prefixes of every level in one launch (one ticket counter; the look-back chain restarts at every level)
 __global__ __launch_bounds__(kBlock) void k_chain_scan(ChainParams P) {
     __shared__ int smem[8];
     __shared__ int s_tile;
@@ -937,14 +968,43 @@ __global__ __launch_bounds__(kBlock) void k_chain_scan(ChainParams P) {
     else bm_scan_tile<kBmWptSmall>(L.bm, L.prefix8, L.out_cap, L.status, g - L.tile0, L.ntiles, L.num_out, smem, cnt);
 }
 
+// output coordinates of every level in rank order, one thread per bitmap word: the tables launch then runs one thread per
+// (output row, offset), perfectly balanced whatever the sites' spatial clustering.  (Measured alternatives: a table pass that
+// walked the set bits of fixed word runs per workgroup left most of the chip waiting for the runs on the ground plane, 117-220 us;
+// emission inside the scan tiles -- ~300 workgroups, a wave alone on its SIMD looping over the densest of its 64 words -- 43 us.)
+__global__ __launch_bounds__(kBlock) void k_chain_emit(ChainParams P) {
+    int l = 1;
+    while (l < P.levels && (int)blockIdx.x >= P.lv[l].eblk0 + P.lv[l].eblks) ++l;
+    const ChainLevel &L = P.lv[l];
+    const long long wi = (long long)((int)blockIdx.x - L.eblk0) * kBlock + threadIdx.x;
+    unsigned word = L.bm[wi];
+    if (!word) return;
+    int r = bm_word_prefix(L.bm, L.prefix8, (size_t)wi);
+    const unsigned W = (unsigned)L.shape[2], H = (unsigned)L.shape[1], D = (unsigned)L.shape[0];
+    const unsigned lin0 = (unsigned)wi << 5;
+    const unsigned rw = lin0 / W, x0 = lin0 - rw * W;
+    const unsigned plane = rw / H, y0 = rw - plane * H, b0 = plane / D, z0 = plane - b0 * D;
+    while (word && r < L.out_cap) {
+        const int bit = __ffs((int)word) - 1;
+        word &= word - 1u;
+        unsigned x = x0 + bit, y = y0, z = z0, bb = b0;
+        while (x >= W) {                              // a word may straddle row ends when W is not a multiple of 32
+            x -= W;
+            if (++y == H) { y = 0; if (++z == D) { z = 0; ++bb; } }
+        }
+        *reinterpret_cast<int4 *>(L.out_indices + (size_t)r * 4) = make_int4((int)bb, (int)z, (int)y, (int)x);
+        ++r;
+    }
+}
+
 __device__ __forceinline__ int chain_rank(const ChainLevel &L, int b, int z, int y, int x) {
     if ((unsigned)z >= (unsigned)L.shape[0] || (unsigned)y >= (unsigned)L.shape[1] || (unsigned)x >= (unsigned)L.shape[2]) return -1;
     const unsigned lin = (((unsigned)b * L.shape[0] + z) * L.shape[1] + y) * L.shape[2] + x;
-    const int r = bm_rank(L.bm, L.prefix8, lin);
+    const int r = bm_rank1(L.bm, L.prefix8, lin);
     return r < L.out_cap ? r : -1;             // a rank past the capacity is not a row (overflow is reported by num_out[1])
 }
 
-constexpr int kChainChunk = 1024;              // set bits of a 256-word run handled per LDS round
+constexpr int kTabU = 4;                       // table items per thread of k_chain_tables
 __global__ __launch_bounds__(kBlock) void k_chain_tables(ChainParams P) {
     const int blk = blockIdx.x;
     if (blk < P.cand_blks) {
@@ -967,80 +1027,49 @@ __global__ __launch_bounds__(kBlock) void k_chain_tables(ChainParams P) {
         const ChainLevel &L = P.lv[P.levels];
         const long long i = (long long)(blk - P.map_blk0) * kBlock + threadIdx.x;
         if (i >= P.map_cells) return;
-        int r = bm_rank(L.bm, L.prefix8, (unsigned)i);
+        const int r = bm_rank1(L.bm, L.prefix8, (unsigned)i);
         P.site_map[i] = (r >= 0 && r < L.out_cap) ? r + 1 : 0;
         return;
     }
+    // (output row, kernel offset) items, offset fastest: every table entry is written (-1 included) in coalesced runs.  A thread
+    // takes kTabU items a workgroup-width apart and issues their loads together -- one item per thread left the launch waiting on
+    // two dependent memory rounds per workgroup times 18 rounds of resident workgroups (41 us for 7.5 M lookups).  The output's
+    // coordinates come from out_indices (rank order, k_chain_emit); items of rows at or past the live count are skipped (the grid is
+    // sized for the capacity).
     int l = 1;
-    while (l < P.levels && blk >= P.lv[l].blk0 + P.lv[l].blks) ++l;
+    while (l < P.levels && blk >= P.lv[l].cblk0 + P.lv[l].cblks) ++l;
     const ChainLevel &L = P.lv[l];
-    __shared__ int smem[5];
-    __shared__ int s_r0;
-    __shared__ unsigned cells[kChainChunk];
-    __shared__ int4 coord[kChainChunk];
-    const long long w0 = (long long)(blk - L.blk0) * kBlock;
-    const unsigned word = L.bm[w0 + threadIdx.x];
-    int tot;
-    const int ex = block_exclusive_scan(__popc(word), smem, &tot);
-    if (tot == 0) return;
-    if (threadIdx.x == 0) s_r0 = bm_word_prefix(L.bm, L.prefix8, (size_t)w0);
-    const unsigned W = (unsigned)L.shape[2], H = (unsigned)L.shape[1], D = (unsigned)L.shape[0];
-    for (int base = 0; base < tot; base += kChainChunk) {
-        __syncthreads();
-        {   // set bits [base, base + chunk) of the run -> LDS (cell index + decoded coordinates)
-            unsigned wd = word;
-            int e = ex;
-            const unsigned lin0 = (unsigned)(w0 + threadIdx.x) << 5;
-            while (wd) {
-                const int bit = __ffs((int)wd) - 1;
-                wd &= wd - 1u;
-                if (e >= base && e < base + kChainChunk) {
-                    const unsigned lin = lin0 + bit;
-                    const unsigned row = lin / W, x = lin - row * W;
-                    const unsigned plane = row / H, y = row - plane * H;
-                    const unsigned b = plane / D, z = plane - b * D;
-                    cells[e - base] = lin;
-                    coord[e - base] = make_int4((int)b, (int)z, (int)y, (int)x);
-                }
-                ++e;
-            }
-        }
-        __syncthreads();
-        const int r0 = s_r0 + base;
-        int n = tot - base;
-        if (n > kChainChunk) n = kChainChunk;
-        if (r0 + n > L.out_cap) n = L.out_cap - r0;         // rows past the capacity do not exist
-        if (n <= 0) break;
-        if (L.out_indices)
-            for (int e = threadIdx.x; e < n; e += kBlock) *reinterpret_cast<int4 *>(L.out_indices + (size_t)(r0 + e) * 4) = coord[e];
-        if (L.subm_nbr) {
-            int *dst = L.subm_nbr + (size_t)r0 * 27;
-            for (int it = threadIdx.x; it < n * 27; it += kBlock) {
-                const int e = it / 27, k = it - e * 27;
-                const int4 c = coord[e];
-                const int kz = k / 9, ky = (k / 3) % 3, kx = k % 3;
-                dst[it] = k == 13 ? r0 + e : chain_rank(L, c.x, c.y + kz - 1, c.z + ky - 1, c.w + kx - 1);
-            }
-        }
-        if (l >= 2) {
-            const ChainLevel &I = P.lv[l - 1];
-            int *dst = L.nbr_out + (size_t)r0 * L.kvol;
-            if (L.geo == 1) {
-                for (int it = threadIdx.x; it < n * 27; it += kBlock) {
-                    const int e = it / 27, k = it - e * 27;
-                    const int4 c = coord[e];
-                    const int kz = k / 9, ky = (k / 3) % 3, kx = k % 3;
-                    dst[it] = chain_rank(I, c.x, 2 * c.y - L.pad[0] + kz, 2 * c.z - L.pad[1] + ky, 2 * c.w - L.pad[2] + kx);
-                }
-            } else {
-                for (int it = threadIdx.x; it < n * 3; it += kBlock) {
-                    const int e = it / 3, k = it - e * 3;
-                    const int4 c = coord[e];
-                    dst[it] = chain_rank(I, c.x, 2 * c.y - L.pad[0] + k, c.z - L.pad[1], c.w - L.pad[2]);
-                }
-            }
-        }
+    const int live = L.num_out[0];
+    const bool subm = blk < L.sblk0 + L.sblks;
+    const ChainLevel &T = subm ? L : P.lv[l - 1];                 // the level whose bitmap answers the lookups
+    const int kv = subm ? 27 : L.kvol;
+    int *dst = subm ? L.subm_nbr : L.nbr_out;
+    const long long t0 = (long long)(blk - (subm ? L.sblk0 : L.cblk0)) * (kBlock * kTabU) + threadIdx.x;
+    if (t0 >= (long long)live * kv) return;                      // (uniform enough: whole workgroups past the live rows leave here)
+    int4 c[kTabU];
+    int rr[kTabU], kk[kTabU];
+    bool on[kTabU];
+#pragma unroll
+    for (int u = 0; u < kTabU; ++u) {
+        const long long t = t0 + (long long)u * kBlock;
+        const int r = kv == 27 ? (int)(t / 27) : (int)(t / 3);
+        rr[u] = r; kk[u] = (int)(t - (long long)r * kv);
+        on[u] = r < live;
+        c[u] = *reinterpret_cast<const int4 *>(L.out_indices + (size_t)(on[u] ? r : 0) * 4);
     }
+    int val[kTabU];
+#pragma unroll
+    for (int u = 0; u < kTabU; ++u) {
+        const int k = kk[u];
+        int z, y, x;
+        if (subm) { z = c[u].y + k / 9 - 1; y = c[u].z + (k / 3) % 3 - 1; x = c[u].w + k % 3 - 1; }
+        else if (kv == 27) { z = 2 * c[u].y - L.pad[0] + k / 9; y = 2 * c[u].z - L.pad[1] + (k / 3) % 3; x = 2 * c[u].w - L.pad[2] + k % 3; }
+        else { z = 2 * c[u].y - L.pad[0] + k; y = c[u].z - L.pad[1]; x = c[u].w - L.pad[2]; }
+        val[u] = (subm && k == 13) ? rr[u] : chain_rank(T, c[u].x, z, y, x);
+    }
+#pragma unroll
+    for (int u = 0; u < kTabU; ++u)
+        if (on[u]) dst[t0 + (long long)u * kBlock] = val[u];
 }
 
 struct RbWorkspace {
@@ -1551,7 +1580,7 @@ SEC_API int sec_rulebook_chain_sorted(const int *indices0, int n0, const int *n0
     int geo[kChainMaxLevels + 1] = {0};
     if (!chain_geometry_ok(levels, h_shapes, h_ksize, h_stride, h_pad, batch, geo)) return SEC_E_UNSUPPORTED;
     for (int l = 1; l <= levels; ++l)
-        if (!h_nbr_out[l - 1] || !h_num_out[l - 1] || h_out_cap[l - 1] <= 0) return SEC_E_INVALID;
+        if (!h_nbr_out[l - 1] || !h_num_out[l - 1] || !h_out_indices[l - 1] || h_out_cap[l - 1] <= 0) return SEC_E_INVALID;
     if (h_subm_nbr[0] && (!vox_workspace || !h_vox_grid3_zyx)) return SEC_E_INVALID;
     hipStream_t st = (hipStream_t)stream;
     ChainWorkspace w = carve_chain(workspace, workspace_bytes, batch, levels, h_shapes);
@@ -1573,10 +1602,15 @@ SEC_API int sec_rulebook_chain_sorted(const int *indices0, int n0, const int *n0
         L.status = w.status + tile0; L.tile0 = tile0; L.ntiles = w.ntiles[l]; L.wpt64 = w.wpt64[l];
         tile0 += w.ntiles[l];
         L.nbr_out = h_nbr_out[l - 1]; L.out_indices = h_out_indices[l - 1]; L.num_out = h_num_out[l - 1];
-        L.blk0 = blk0; L.blks = (int)(w.n_words[l] / kBlock);
-        blk0 += L.blks;
+        // tables launch: SubM table of this level, then its conv table (levels >= 2 are built output side), sized for the capacity
+        L.sblk0 = blk0; L.sblks = L.subm_nbr ? div_up((long long)L.out_cap * 27, kBlock * kTabU) : 0;
+        blk0 += L.sblks;
+        L.cblk0 = blk0; L.cblks = l >= 2 ? div_up((long long)L.out_cap * L.kvol, kBlock * kTabU) : 0;
+        blk0 += L.cblks;
     }
     P.map_blk0 = blk0;
+    int eblk = 0;
+    for (int l = 1; l <= levels; ++l) { P.lv[l].eblk0 = eblk; P.lv[l].eblks = (int)(w.n_words[l] / kBlock); eblk += P.lv[l].eblks; }
     P.site_map = site_map;
     P.map_cells = site_map ? bm_cells(batch, h_shapes + 3 * levels) : 0;
     const int map_blks = site_map ? div_up(P.map_cells, (long long)kBlock) : 0;
@@ -1614,9 +1648,9 @@ SEC_API int sec_rulebook_chain_sorted(const int *indices0, int n0, const int *n0
         const int nb_subm = h_subm_nbr[0] ? div_up((long long)n0 * 14, kBlock) : 0;
         const int nb_set = div_up((long long)n0 * 4, kBlock);
         const long long fill_words = (long long)P.lv[1].out_cap * 27;
-        int nb_fill = div_up(fill_words / 4 + 1, (long long)kBlock * 4);
-        if (nb_fill > 512) nb_fill = 512;
-        hipLaunchKernelGGL(k_chain_front, dim3(nb_subm + nb_set + nb_fill), dim3(kBlock), 0, st, indices0, gs, gc, n0_dev, keys, svid,
+        int groups = div_up(nb_subm, 7);                 // groups of 7 + 2 + 1 workgroups
+        if (div_up(nb_set, 2) > groups) groups = div_up(nb_set, 2);
+        hipLaunchKernelGGL(k_chain_front, dim3(groups * 10), dim3(kBlock), 0, st, indices0, gs, gc, n0_dev, keys, svid,
                            h_subm_nbr[0], w.bm[1], nb_subm, nb_set, P.lv[1].nbr_out, fill_words);
     }
     // 3. bitmaps of the levels above, each from the one below
@@ -1632,6 +1666,7 @@ SEC_API int sec_rulebook_chain_sorted(const int *indices0, int n0, const int *n0
     }
     // 4. rank prefixes of every level, 5. every table
     hipLaunchKernelGGL(k_chain_scan, dim3(tile0), dim3(kBlock), 0, st, P);
+    hipLaunchKernelGGL(k_chain_emit, dim3(eblk), dim3(kBlock), 0, st, P);
     hipLaunchKernelGGL(k_chain_tables, dim3(P.map_blk0 + map_blks), dim3(kBlock), 0, st, P);
     return check_launch();
 }

@@ -18,6 +18,7 @@
 
 namespace sec {
 
+constexpr int kFusedItems = 2;    // points per thread of k_vox_scan_assign_cascade
 constexpr int kFusedFrames = 64;  // batches up to this size compute the per-cloud frames inside k_vox_assign
 
 struct VoxParams {
@@ -88,11 +89,16 @@ __global__ __launch_bounds__(kBlock) void k_vox_hash(const float *__restrict__ p
 __global__ __launch_bounds__(kBlock) void k_vox_init(unsigned long long *__restrict__ keys, int *__restrict__ vals, long long table,
                                                     int *__restrict__ count, long long rows, int *__restrict__ slot_idx,
                                                     long long slots, int *__restrict__ ctl, long long ctl_words,
-                                                    int *__restrict__ break_idx, int batch) {
+                                                    int *__restrict__ break_idx, int batch, int *__restrict__ svid,
+                                                    unsigned long long *__restrict__ frame_words) {
     long long stride = (long long)gridDim.x * kBlock;
     if (blockIdx.x == 0)
         for (int b = threadIdx.x; b < batch; b += kBlock) break_idx[b] = 0x7fffffff;      // "no cloud has hit its voxel cap yet"
+    if (blockIdx.x == 0 && frame_words)
+        for (int b = threadIdx.x; b <= batch; b += kBlock) frame_words[b] = 0ull;         // fused scan: "rank at the cloud's first point" not published yet
     for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < ctl_words; i += stride) ctl[i] = 0;
+    if (svid)      // fused scan: a point of a voxel spins on svid[slot] until the voxel's first point has numbered it
+        for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < table; i += stride) svid[i] = kEmptyI32;
     for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < table; i += stride) { keys[i] = kEmptyKey; vals[i] = kEmptyI32; }
     for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < rows; i += stride) count[i] = 0;
     for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < slots; i += stride) slot_idx[i] = kEmptyI32;
@@ -251,6 +257,142 @@ __global__ __launch_bounds__(kBlock) void k_vox_cascade(const int *__restrict__ 
     }
 }
 
+// k_vox_flag_scan + k_vox_assign + k_vox_cascade in ONE launch (batches <= kFusedFrames, max_points <= kCascadeMaxPoints: car.fhd).
+// The three kernels were each a near-empty grid paying its own launch boundary on the step's latency chain (7.5 + 7.7 + 8.3 us for
+// 136 k points).  What ties them together is ordering information that the ticketed tiles of the single-pass scan already carry:
+//   * a tile knows the global rank of its points after its look-back; the rank at each cloud's first point (`base`) is published by
+//     the tile that owns that point as one 64-bit word (flag << 32 | rank), and a tile waits only for the words of the clouds its own
+//     points belong to -- all of them published by tiles with SMALLER tickets, i.e. tiles that are already running;
+//   * a voxel is numbered by its first point (smallest index => an earlier or the same tile); the other points of the voxel spin on
+//     svid[slot] (initialised to "empty") until that happened -- again only ever waiting for a smaller ticket;
+//   * the `break` position needs no break_idx round trip: point i comes after the break iff more than max_voxels voxel-creating
+//     points of its cloud have an index <= i, which its own inclusive rank says.
+template <int ITEMS>
+__global__ __launch_bounds__(kBlock) void k_vox_scan_assign_cascade(const float *__restrict__ points, const int *__restrict__ offs,
+                                                                   const int *__restrict__ pslot, const int *__restrict__ vals,
+                                                                   int n, VoxParams p, unsigned long long *__restrict__ status,
+                                                                   int *__restrict__ ticket, int *__restrict__ total,
+                                                                   unsigned long long *__restrict__ frame_words, int *__restrict__ base,
+                                                                   int *__restrict__ voxel_offsets, int *__restrict__ svid,
+                                                                   int *__restrict__ break_idx, int *__restrict__ coors,
+                                                                   int *__restrict__ count, int *__restrict__ slot_idx) {
+    __shared__ int smem[5];
+    __shared__ int s_tile, s_end;
+    __shared__ int s_rank[kBlock * ITEMS];
+    __shared__ int s_base[kFusedFrames + 1], s_voff[kFusedFrames + 1];
+    const int tile = scan_take_tile(ticket, &s_tile), ntiles = (int)gridDim.x, tid = threadIdx.x;
+    const int i0 = (tile * kBlock + tid) * ITEMS;
+    int f[ITEMS], s4[ITEMS], r[ITEMS], v = 0;
+    if (i0 + ITEMS <= n) {
+        if constexpr (ITEMS == 4) {
+            const int4 q = *reinterpret_cast<const int4 *>(pslot + i0);
+            s4[0] = q.x; s4[1] = q.y; s4[2] = q.z; s4[3] = q.w;
+        } else if constexpr (ITEMS == 2) {
+            const int2 q = *reinterpret_cast<const int2 *>(pslot + i0);
+            s4[0] = q.x; s4[1] = q.y;
+        } else {
+#pragma unroll
+            for (int j = 0; j < ITEMS; ++j) s4[j] = pslot[i0 + j];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) s4[j] = i0 + j < n ? pslot[i0 + j] : -1;
+    }
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        f[j] = (s4[j] >= 0 && vals[s4[j]] == i0 + j) ? 1 : 0;
+        v += f[j];
+    }
+    int ex = scan_lookback(v, tile, ntiles, status, smem, total);
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) { r[j] = ex; s_rank[tid * ITEMS + j] = ex; ex += f[j]; }
+    if (tid == kBlock - 1) s_end = ex;                 // rank behind this tile's last point
+    __syncthreads();
+    const int t0 = tile * kBlock * ITEMS;
+    const int t1 = min(t0 + kBlock * ITEMS, n);
+    if (tid <= p.batch) {                              // publish the rank at every cloud start that lies in this tile
+        const int o = offs[tid];
+        int val = -1;
+        if (o >= t0 && o < t1) val = s_rank[o - t0];
+        else if (o >= n && tile == ntiles - 1) val = s_end;
+        if (val >= 0) __hip_atomic_store(&frame_words[tid], (1ull << 32) | (unsigned)val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const bool last = tile == ntiles - 1;
+    const int b_hi = last ? p.batch : frame_of(offs, p.batch, t1 - 1);      // clouds 0 .. b_hi are needed here (the last tile: all + the end)
+    if (tid <= b_hi) {
+        unsigned long long wv;
+        while (((wv = __hip_atomic_load(&frame_words[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) == 0)
+            __builtin_amdgcn_s_sleep(1);
+        s_base[tid] = (int)(unsigned)wv;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0;
+        s_voff[0] = 0;
+        for (int b = 0; b < b_hi; ++b) {
+            int cnt = s_base[b + 1] - s_base[b];
+            if (cnt > p.max_voxels) cnt = p.max_voxels;
+            acc += cnt;
+            s_voff[b + 1] = acc;
+        }
+    }
+    __syncthreads();
+    if (last && tid <= p.batch) { base[tid] = s_base[tid]; voxel_offsets[tid] = s_voff[tid]; }
+    // number the voxels whose first point is here
+    int vid4[ITEMS], fb[ITEMS];
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        vid4[j] = -1;
+        fb[j] = 0;
+        const int i = i0 + j, s = s4[j];
+        if (s < 0) continue;
+        const int b = frame_of(offs, p.batch, i);
+        fb[j] = b;
+        if (!f[j]) continue;
+        const int rr = r[j] - s_base[b];
+        if (rr < p.max_voxels) {
+            const int vid = s_voff[b] + rr;
+            vid4[j] = vid;
+            __hip_atomic_store(&svid[s], vid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // the cell of the voxel's first point, recomputed exactly as k_vox_hash computed it (a coalesced load of the point
+            // instead of a random 8-byte read of the hash key and two 64-bit divisions)
+            const float *pt = points + (size_t)i * p.num_features;
+            int c[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) c[d] = (int)floorf(__fdiv_rn(__fsub_rn(pt[d], p.lo[d]), p.vs[d]));
+            *reinterpret_cast<int4 *>(coors + (size_t)vid * 4) = make_int4(b, c[2], c[1], c[0]);
+            slot_idx[(size_t)vid * p.max_points] = i;       // slot 0 IS the first point (the smallest index of the voxel): no atomics
+        } else {
+            __hip_atomic_store(&svid[s], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (rr == p.max_voxels && p.cap_mode == 0) break_idx[b] = i;       // (the sort path of large max_points reads it)
+        }
+    }
+    __syncthreads();     // first points of this tile have stored their svid before any lane of the tile starts to wait
+    // slots: the max_points smallest point indices of every voxel (the atomicMin cascade of k_vox_cascade)
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const int i = i0 + j, s = s4[j];
+        if (s < 0) continue;
+        int vid = vid4[j];
+        if (!f[j]) {
+            while ((vid = __hip_atomic_load(&svid[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == kEmptyI32) __builtin_amdgcn_s_sleep(1);
+        }
+        if (vid < 0) continue;
+        if (p.cap_mode == 0 && r[j] + f[j] - s_base[fb[j]] > p.max_voxels) continue;     // at or behind the sequential loop's `break`
+        atomicAdd(&count[vid], 1);
+        if (f[j] || p.max_points < 2) continue;             // the first point sits in slot 0 already; the others cascade through 1 ..
+        int pv = i;
+        int *row = slot_idx + (size_t)vid * p.max_points;
+        if (__hip_atomic_load(&row[p.max_points - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < pv) continue;
+        for (int t = 1; t < p.max_points; ++t) {
+            if (__hip_atomic_load(&row[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < pv) continue;
+            const int old = atomicMin(&row[t], pv);
+            if (old == kEmptyI32) break;
+            pv = old > pv ? old : pv;
+        }
+    }
+}
+
 // ---- many points per voxel (pillars, max_points 60): slots by a stable sort instead of the cascade ------------------------------
 // The cascade is O(points x occupied slots) returning atomics on the voxel's slot row, and the hundreds of points of a near pillar
 // all walk the same 60 addresses at the same time: 2.0 ms of a 2.7 ms nuscenes/all.pp.largea step (profiles/r03_h_*).  Here every
@@ -388,6 +530,7 @@ struct VoxWorkspace {
     size_t sort_tmp_bytes;
     int sort_bits;
     uint32_t table;
+    unsigned long long *frame_words;
     size_t bytes;
 };
 
@@ -424,6 +567,7 @@ static VoxWorkspace carve_vox(void *ws, size_t cap, int n, int batch, int max_vo
         w.sort_tmp_bytes = vox_sort_temp_bytes(n, bits);
         w.sort_tmp = a.take<char>(w.sort_tmp_bytes);
     }
+    w.frame_words = a.take<unsigned long long>((size_t)batch + 1);     // fused scan (appended: earlier offsets never move)
     w.bytes = align_up(a.used);
     return w;
 }
@@ -497,17 +641,27 @@ SEC_API int sec_voxelize_f32(const float *points, const int *point_offsets, int 
     p.peek = (long long)num_points > 2ll * batch * max_voxels ? 1 : 0;
 
     int rc;
+    // scan + numbering + slots in one launch (k_vox_scan_assign_cascade) for the shapes of the sparse-middle configs
+    const bool fused_scan = num_points > 0 && batch <= kFusedFrames && max_points <= kCascadeMaxPoints;
     {   // one init launch instead of four memset nodes; only the rows that can be live (#voxels <= #points) are touched
         long long cap_rows = (long long)batch * max_voxels;
         if (cap_rows > num_points) cap_rows = num_points > 0 ? num_points : 1;
         int blocks = div_up((long long)w.table, kBlock);
         if (blocks > 256 * 8) blocks = 256 * 8;
         hipLaunchKernelGGL(k_vox_init, dim3(blocks), dim3(kBlock), 0, st, w.keys, w.vals, (long long)w.table, w.count, cap_rows,
-                           w.slot_idx, cap_rows * max_points, w.ctl, (long long)scan_ctl_words(num_points), w.break_idx, batch);
+                           w.slot_idx, cap_rows * max_points, w.ctl, (long long)scan_ctl_words(num_points), w.break_idx, batch,
+                           fused_scan ? w.svid : (int *)nullptr, fused_scan ? w.frame_words : (unsigned long long *)nullptr);
     }
     const bool fused_frames = num_points > 0 && batch <= kFusedFrames;
     int nb = div_up(num_points > 0 ? num_points : 1, kBlock);
-    if (num_points > 0) {
+    if (fused_scan) {
+        hipLaunchKernelGGL(k_vox_hash, dim3(nb), dim3(kBlock), 0, st, points, point_offsets, p, w.keys, w.vals, w.pslot);
+        // two points per thread: ~270 tiles for car.fhd's 136 k points (four: 133 workgroups = one wave per SIMD on half the chip, every
+        // dependent round of the tile paid in full; one: a look-back chain four times as long)
+        hipLaunchKernelGGL(k_vox_scan_assign_cascade<kFusedItems>, dim3(div_up(num_points, kBlock * kFusedItems)), dim3(kBlock), 0, st, points, point_offsets,
+                           w.pslot, w.vals, num_points, p, reinterpret_cast<unsigned long long *>(w.ctl + 4), w.ctl, w.total,
+                           w.frame_words, w.base, voxel_offsets, w.svid, w.break_idx, coors, w.count, w.slot_idx);
+    } else if (num_points > 0) {
         hipLaunchKernelGGL(k_vox_hash, dim3(nb), dim3(kBlock), 0, st, points, point_offsets, p, w.keys, w.vals, w.pslot);
         hipLaunchKernelGGL(k_vox_flag_scan, dim3(div_up(num_points, kBlock * kFlagItems)), dim3(kBlock), 0, st, w.pslot, w.vals, num_points, w.rank,
                            reinterpret_cast<unsigned long long *>(w.ctl + 4), w.ctl, w.total);
@@ -515,7 +669,7 @@ SEC_API int sec_voxelize_f32(const float *points, const int *point_offsets, int 
     if (!fused_frames)
         hipLaunchKernelGGL(k_vox_frames, dim3(1), dim3(64), 0, st, point_offsets, w.rank, w.total, p, w.base,
                            w.break_idx, voxel_offsets);
-    if (num_points > 0) {
+    if (num_points > 0 && !fused_scan) {
         hipLaunchKernelGGL(k_vox_assign, dim3(nb), dim3(kBlock), 0, st, point_offsets, w.pslot, w.vals, w.keys,
                            w.rank, w.base, voxel_offsets, p, w.svid, w.break_idx, coors,
                            fused_frames ? w.total : (const int *)nullptr);

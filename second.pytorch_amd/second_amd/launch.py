@@ -3,6 +3,8 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \\
         -m second_amd.launch --reference-root /path/to/second.pytorch \\
         train --config_path=second/configs/car.fhd.config --model_dir=/data/model
+    python [-m torch.distributed.run ... ] -m second_amd.launch --reference-root /path/to/second.pytorch \\
+        evaluate --config_path=second/configs/car.fhd.config --model_dir=/data/model        (run_evaluate: sharded over the ranks)
 
 The reference's only multi-GPU mechanism is single-process nn.DataParallel over padded batches
 (second/pytorch/train.py:203-206, second/data/preprocess.py:57-88).  ``train()`` offers no hook between
@@ -185,12 +187,105 @@ def run_train(reference_root, config_path, model_dir, backend=None, device=None,
     return saved["state"]
 
 
+class _ShardedEvaluation:
+    """Proxy of the reference's dataset object (``eval_dataset.dataset``, train.py:535) for an evaluation sharded over ranks:
+    every attribute is the dataset's own, except ``evaluation(detections, output_dir)`` -- it first gathers the ranks' detection
+    lists (rank r holds frames r, r + world, ...; ``all_gather_object``), restores the dataset order and runs the reference's
+    evaluation on rank 0 only (the other ranks return None, which evaluate() accepts, train.py:537)."""
+
+    def __init__(self, dataset, rank, world):
+        self.__dict__.update(_ds=dataset, _rank=rank, _world=world)
+
+    def __getattr__(self, name):
+        return getattr(self._ds, name)
+
+    def __len__(self):
+        return len(self._ds)
+
+    def evaluation(self, detections, output_dir):
+        import torch.distributed as dist
+        if self._world > 1:
+            parts = [None] * self._world
+            dist.all_gather_object(parts, _detections_to_host(detections))
+            total = sum(len(p) for p in parts)
+            detections = [parts[i % self._world][i // self._world] for i in range(total)]
+        self.__dict__["last_detections"] = detections
+        if self._rank != 0:
+            return None
+        return self._ds.evaluation(detections, output_dir)
+
+
+def _detections_to_host(dets):
+    import torch
+    return [{k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in d.items()} for d in dets]
+
+
+def run_evaluate(reference_root, config_path, model_dir, backend=None, device=None, accelerate=True, **eval_kwargs):
+    """The reference's UNMODIFIED ``second.pytorch.train.evaluate`` (train.py:433-545) over this package: one process per GPU,
+    every rank evaluates frames rank, rank + world, ... of the evaluation set (a sequential sharded sampler on the loader
+    evaluate() builds, train.py:485-491), the detections are gathered inside ``eval_dataset.dataset.evaluation`` and the KITTI /
+    nuScenes metrics run once on rank 0.  ``accelerate``: ``compat.accelerate_nms`` (device-resident rotate_nms / nms behind
+    VoxelNet.predict, voxelnet.py:452-455,578-584) and ``compat.accelerate_eval`` (rotate_iou_gpu_eval of second/utils/eval.py on
+    sec_rotate_iou_f32).  No collective on the data path.  Returns the proxy dataset (tests read ``last_detections``)."""
+    import torch
+    import torch.utils.data as tud
+    from . import compat, distributed as D
+    world_env = int(os.environ.get("WORLD_SIZE", 1))
+    rank, local_rank, world = D.init_from_env(backend) if world_env > 1 else (0, 0, 1)
+    compat.install(reference_root)
+    import second.pytorch.train as T
+    if accelerate:
+        compat.accelerate_nms()
+        compat.accelerate_eval()
+    saved = {"DataLoader": tud.DataLoader, "build": T.input_reader_builder.build, "convert": T.example_convert_to_torch}
+    holder = {}
+
+    class ShardSampler(tud.Sampler):
+        def __init__(self, n):
+            self.n = n
+
+        def __iter__(self):
+            return iter(range(rank, self.n, world))
+
+        def __len__(self):
+            return len(range(rank, self.n, world))
+
+    def DataLoader(dataset, *a, **k):
+        if world > 1 and not k.get("shuffle") and k.get("sampler") is None:
+            k["sampler"] = ShardSampler(len(dataset))
+        if k.get("num_workers", 0) > 0 and k.get("multiprocessing_context") is None:
+            k["multiprocessing_context"] = "spawn"
+        return saved["DataLoader"](dataset, *a, **k)
+
+    def build(*a, **k):
+        ds = saved["build"](*a, **k)
+        holder["proxy"] = ds.dataset = _ShardedEvaluation(ds.dataset, rank, world)
+        return ds
+
+    def convert(example, dtype=torch.float32, dev=None):
+        return saved["convert"](example, dtype, dev if dev is not None else device)
+
+    tud.DataLoader = DataLoader
+    T.input_reader_builder.build = build
+    if device is not None:
+        T.example_convert_to_torch = convert
+    try:
+        if rank != 0 and eval_kwargs.get("result_path") is None:      # result.pkl of the shards must not collide with rank 0's
+            eval_kwargs["result_path"] = os.path.join(str(model_dir), f"eval_results_rank{rank}")
+        T.evaluate(load_config(T, config_path, 0) if isinstance(config_path, str) else config_path, model_dir, **eval_kwargs)
+    finally:
+        tud.DataLoader = saved["DataLoader"]
+        T.input_reader_builder.build = saved["build"]
+        T.example_convert_to_torch = saved["convert"]
+    return holder.get("proxy")
+
+
 def main(argv=None):
     _isolate_device()
     argv = list(sys.argv[1:] if argv is None else argv)
-    if len(argv) < 3 or argv[0] != "--reference-root" or argv[2] != "train":
+    if len(argv) < 3 or argv[0] != "--reference-root" or argv[2] not in ("train", "evaluate"):
         print(__doc__)
-        raise SystemExit("usage: -m second_amd.launch --reference-root DIR train --config_path=... --model_dir=... [--key=value ...]")
+        raise SystemExit("usage: -m second_amd.launch --reference-root DIR {train|evaluate} --config_path=... --model_dir=... [--key=value ...]")
     reference_root = argv[1]
     kwargs = {}
     for tok in argv[3:]:
@@ -205,6 +300,9 @@ def main(argv=None):
         kwargs[key] = val
     config_path, model_dir = kwargs.pop("config_path"), kwargs.pop("model_dir")
     kwargs.pop("multi_gpu", None)
+    if argv[2] == "evaluate":
+        run_evaluate(reference_root, config_path, model_dir, **kwargs)
+        return
     state = run_train(reference_root, config_path, model_dir, **kwargs)
     if int(os.environ.get("RANK", 0)) == 0:
         print(f"[second_amd.launch] {state['allreduce_calls']} gradient all-reduces of {state['allreduce_bytes']} bytes each")

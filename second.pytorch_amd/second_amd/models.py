@@ -269,6 +269,7 @@ class SpMiddleFHD(nn.Module):
         self.overlap_rulebooks = os.environ.get("SEC_OVERLAP_RULEBOOKS", "0") in ("1", "2")
         self.overlap_rulebooks_split = os.environ.get("SEC_OVERLAP_RULEBOOKS", "0") == "2"
         self._side_stream = None
+        self.fused_chain = True       # static inference: all eight rulebooks from one fused build (SparseSequential.plan_chain)
 
     def forward(self, voxel_features, coors, batch_size, channels_last=False, num_active_dev=None, site_table=None, bev_sparse=False):
         """``site_table``: the ``site_table`` entry of the ops.voxelize result these (unfiltered) coors come from -- the first
@@ -279,6 +280,8 @@ class SpMiddleFHD(nn.Module):
         if site_table is not None and x.indices.data_ptr() == coors.data_ptr():
             x.site_table = ((x.indices.data_ptr(), x.indices.shape[0]), site_table)
         side = None
+        if num_active_dev is not None and self.fused_chain and not self.overlap_rulebooks:
+            x.planned = self.middle_conv.plan_chain(x)       # None: layer-by-layer builds
         if num_active_dev is not None and self.overlap_rulebooks:
             # static pipeline: all 8 rulebooks on a side stream, overlapped with the conv layers (fork / join)
             # one side stream per launching stream: branches of a branched graph must not share it
@@ -315,6 +318,9 @@ class SparseBEV:
         self.batch_size, self.spatial_shape = sp.batch_size, [int(v) for v in sp.spatial_shape]
 
     def site_map(self):
+        m = getattr(self.sp, "site_map_tensor", None)
+        if m is not None:                            # written by the fused rulebook chain's tables launch
+            return m
         # rows numbered by the sorted build of the last strided layer: the map is that build's bitmap ranks (one launch)
         tbl = getattr(self.sp, "site_bitmap", None)
         if (tbl is not None and tbl[0] == (self.indices.data_ptr(), self.indices.shape[0]) and isinstance(tbl[1][0], str)

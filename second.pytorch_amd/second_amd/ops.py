@@ -288,6 +288,67 @@ def rulebook_conv(indices, batch_size, spatial_shape, ksize, stride, padding, di
             "out_shape": out_shape, "site_table": (ws, n, ks, st, dl, hint) if n > 0 else None}
 
 
+@_traced("rulebook_chain")
+def rulebook_chain(indices0, batch_size, shape0, convs, n_dev=None, site_table=None, want_subm=None, want_site_map=False):
+    """Every rulebook of a SubM / strided-conv stack in ONE call (sec_rulebook_chain_sorted; spconv GPU numbering), static
+    capacity only.  ``indices0`` [n0, 4] = level-0 rows; ``convs`` = [(ksize, stride, padding, out_cap), ...] the strided layers in
+    order; ``want_subm`` [levels + 1] bools: a 3x3x3 SubM table on that level's sites (level 0 needs ``site_table`` = the
+    ``site_table`` entry of the :func:`voxelize` result the rows come from).  Returns None when the geometry is outside what the
+    fused build covers (build layer by layer then), else a dict: ``levels`` = list (index 0 .. L) of dicts with ``shape``,
+    ``indices``, ``num_dev`` (int32[2]: live clamped, raw), ``cap``, ``nbr_out`` (conv table, level >= 1), ``subm_nbr``; ``site_map``."""
+    rt.require_gpu(indices0)
+    assert indices0.dtype == torch.int32 and indices0.is_contiguous()
+    levels = len(convs)
+    want_subm = list(want_subm) if want_subm is not None else [False] * (levels + 1)
+    assert len(want_subm) == levels + 1
+    dev = indices0.device
+    n0 = indices0.shape[0]
+    if n0 == 0 or levels == 0:
+        return None
+    shapes = [[int(v) for v in shape0]]
+    ks_all, st_all, pd_all, caps = [], [], [], []
+    for ks, st, pd, cap in convs:
+        ks3, st3, pd3 = list(rt.i3(ks)), list(rt.i3(st)), list(rt.i3(pd))
+        shapes.append(conv_output_shape(shapes[-1], ks3, st3, pd3, 1))
+        ks_all += ks3; st_all += st3; pd_all += pd3
+        caps.append(int(cap))
+    vox = site_table if (site_table is not None and isinstance(site_table[0], str) and site_table[0] == "vox") else None
+    if want_subm[0] and vox is None:
+        return None
+    ia = lambda v: (ctypes.c_int * len(v))(*[int(x) for x in v])
+    flat_shapes = ia([v for sh in shapes for v in sh])
+    l = rt.lib()
+    nbytes = l.sec_rulebook_chain_workspace_bytes(int(batch_size), levels, flat_shapes)
+    if nbytes == 0:
+        return None
+    ws = rt.workspace(nbytes, dev)
+    kvols = [int(np.prod(ks_all[3 * i:3 * i + 3])) for i in range(levels)]
+    nbr = [torch.empty((caps[i], kvols[i]), dtype=torch.int32, device=dev) for i in range(levels)]
+    oidx = [torch.empty((caps[i], 4), dtype=torch.int32, device=dev) for i in range(levels)]
+    nout = [torch.empty((2,), dtype=torch.int32, device=dev) for _ in range(levels)]
+    rows = [n0] + caps
+    subm = [torch.empty((rows[i], 27), dtype=torch.int32, device=dev) if want_subm[i] else None for i in range(levels + 1)]
+    smap = torch.empty((int(batch_size), *shapes[-1]), dtype=torch.int32, device=dev) if want_site_map else None
+    pa = lambda ts: (ctypes.c_void_p * len(ts))(*[(t.data_ptr() if t is not None else None) for t in ts])
+    if vox is not None:
+        _, vws, vn, vmv, vmp, vgrid = vox
+        vws.record_stream(torch.cuda.current_stream())
+    else:
+        vws, vn, vmv, vmp, vgrid = None, 0, 0, 0, shapes[0]
+    rc = l.sec_rulebook_chain_sorted(rt.ptr(indices0), n0, rt.ptr(n_dev), int(batch_size), levels, flat_shapes, ia(ks_all), ia(st_all),
+                                     ia(pd_all), ia(caps), pa(nbr), pa(oidx), pa(nout), pa(subm), rt.ptr(vws),
+                                     vws.numel() if vws is not None else 0, int(vn), int(vmv), int(vmp), rt.i3(vgrid), rt.ptr(smap),
+                                     rt.ptr(ws), ws.numel(), rt.stream())
+    if rc == -3:
+        return None
+    rt.check(rc, "sec_rulebook_chain_sorted")
+    out = [{"shape": shapes[0], "indices": indices0, "num_dev": n_dev, "cap": n0, "nbr_out": None, "subm_nbr": subm[0]}]
+    for i in range(levels):
+        out.append({"shape": shapes[i + 1], "indices": oidx[i], "num_dev": nout[i], "cap": caps[i], "nbr_out": nbr[i],
+                    "subm_nbr": subm[i + 1]})
+    return {"levels": out, "site_map": smap, "workspace": ws}
+
+
 # ----------------------------------------------------------------------------- indice_conv
 _conv_profiler = None
 

@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libsecond_hip.so")
 LIB_PATH = os.environ.get("SEC_HIP_LIB", LIB_PATH)   # A/B builds: point at another libsecond_hip.so
 
 SEC_F32, SEC_F16, SEC_BF16 = 0, 1, 2
+ABI_VERSION = 2          # include/second_hip.h SEC_ABI_VERSION the argtypes in lib() were written for
 _DTYPES = {torch.float32: SEC_F32, torch.float16: SEC_F16, torch.bfloat16: SEC_BF16}
 _ERRORS = {-1: "SEC_E_INVALID (bad argument)", -2: "SEC_E_WORKSPACE (workspace too small)",
            -3: "SEC_E_UNSUPPORTED", -4: "SEC_E_LAUNCH (HIP error)"}
@@ -22,7 +23,8 @@ SYMBOLS = [
     "sec_rulebook_workspace_bytes", "sec_rulebook_subm3d", "sec_rulebook_subm3d_after_conv", "sec_rulebook_subm3d_after_voxelize",
     "sec_rulebook_conv3d_build",
     "sec_rulebook_conv3d_tables", "sec_rulebook_sorted_workspace_bytes", "sec_rulebook_conv3d_build_sorted",
-    "sec_rulebook_conv3d_tables_sorted", "sec_rulebook_subm3d_after_conv_sorted", "sec_conv_output_shape", "sec_packed_weight_bytes",
+    "sec_rulebook_conv3d_tables_sorted", "sec_rulebook_subm3d_after_conv_sorted", "sec_rulebook_chain_workspace_bytes",
+    "sec_rulebook_chain_sorted", "sec_conv_output_shape", "sec_packed_weight_bytes",
     "sec_pack_conv_weight", "sec_indice_conv_fwd", "sec_indice_conv_fwd_plan", "sec_indice_conv_set_variant", "sec_indice_conv_bwd_workspace_bytes", "sec_indice_conv_bwd", "sec_sparse_to_dense", "sec_dense_to_sparse", "sec_sparse_site_map", "sec_sparse_site_map_sorted", "sec_conv2d_nhwc_gather",
     "sec_pillar_scatter", "sec_pfn_fwd", "sec_pfn_fwd_slots", "sec_pfn_train_workspace_bytes", "sec_pfn_train_fwd", "sec_pfn_train_bwd", "sec_block_filter_workspace_bytes",
     "sec_voxel_block_filter_f32", "sec_bias_act_nhwc", "sec_conv2d_packed_weight_bytes",
@@ -92,7 +94,11 @@ def lib():
                 f"{LIB_PATH} is missing: build it with `python second.pytorch_amd/build.py` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
         l = ctypes.CDLL(LIB_PATH)
+        if l.sec_abi_version() != ABI_VERSION:       # the argtypes below are written for exactly this header revision
+            raise SecondHipError(f"{LIB_PATH} has ABI version {l.sec_abi_version()}, these bindings expect {ABI_VERSION}: "
+                                 "rebuild it (python second.pytorch_amd/build.py --force)")
         for name in ("sec_voxelize_workspace_bytes", "sec_rulebook_workspace_bytes", "sec_rulebook_sorted_workspace_bytes",
+                     "sec_rulebook_chain_workspace_bytes",
                      "sec_packed_weight_bytes", "sec_nms_workspace_bytes", "sec_block_filter_workspace_bytes",
                      "sec_conv2d_packed_weight_bytes", "sec_indice_conv_bwd_workspace_bytes",
                      "sec_assign_targets_workspace_bytes", "sec_second_loss_workspace_bytes",
@@ -115,6 +121,8 @@ def lib():
                                                        vp, sz, vp, sz, vp]
         l.sec_rulebook_conv3d_tables_sorted.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, vp, ci, vp, ci, vp, vp, vp, sz, vp]
         l.sec_rulebook_subm3d_after_conv_sorted.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp, ci, vp, sz, vp]
+        l.sec_rulebook_chain_workspace_bytes.argtypes = [ci, ci, vp]
+        l.sec_rulebook_chain_sorted.argtypes = [vp, ci, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, ci, ci, ci, vp, vp, vp, sz, vp]
         l.sec_conv_output_shape.argtypes = [vp] * 6
         l.sec_packed_weight_bytes.argtypes = [ci, ci, ci, ci]
         l.sec_pack_conv_weight.argtypes = [vp, ci, ci, ci, ci, vp, vp]

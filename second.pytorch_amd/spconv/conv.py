@@ -125,6 +125,7 @@ class SparseConvolution(SparseModule):
         if not rb.subm:
             out.site_table = rb.__dict__.pop("_site_table", None)   # handed to the next SubM rulebook build, then dropped
             out.site_bitmap = rb.__dict__.pop("_site_bitmap", None)
+            out.site_map_tensor = rb.__dict__.get("_site_map")      # fused chain build: the BEV site map of the last level
         else:
             out.site_bitmap = getattr(x, "site_bitmap", None)       # same sites: still valid for the next strided build
         return out

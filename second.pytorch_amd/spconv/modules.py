@@ -103,6 +103,62 @@ class SparseSequential(SparseModule):
         self._plan_streams = (stream, stream2)
         return plans
 
+    def plan_chain(self, x):
+        """Static-capacity inference: ALL rulebooks of this sequence from ONE fused build (ops.rulebook_chain: 4 + (levels - 1)
+        launches instead of ~25 dependent ones) when the stack is what SECOND builds -- 3x3x3 SubM layers between 3x3x3 stride-2 /
+        (3,1,1) stride-(2,1,1) convs (middle.py:146-189) -- and the rulebook numbering in force is "sorted".  Returns the
+        ``planned`` dict ({id(conv): (Rulebook, None)}) or None (then every layer builds its own rulebook as before)."""
+        from .conv import SparseConvolution
+        from .tensor import Rulebook
+        ops = _sec_ops()
+        if x.num_active_dev is None or torch.is_grad_enabled() or ops._numbering != "sorted" or not x.features.is_cuda:
+            return None
+        convs, want_subm, plan, cap = [], [False], [], x.indices.shape[0]
+        for m in self._modules.values():
+            if not isinstance(m, SparseConvolution) or m.conv1x1:
+                continue
+            if m.subm:
+                if m.kernel_size != [3, 3, 3] or m.dilation != [1, 1, 1]:
+                    return None
+                want_subm[-1] = True
+                plan.append((m, len(convs), True))
+            else:
+                if m.dilation != [1, 1, 1]:
+                    return None
+                cap = m.static_out_rows or int(cap * m.static_growth)
+                convs.append((m.kernel_size, m.stride, m.padding, cap))
+                want_subm.append(False)
+                plan.append((m, len(convs), False))
+        if not convs:
+            return None
+        tbl = getattr(x, "site_table", None)
+        tbl = tbl[1] if (tbl is not None and tbl[0] == (x.indices.data_ptr(), x.indices.shape[0])) else None
+        if not (tbl is not None and isinstance(tbl[0], str) and tbl[0] == "vox"):
+            # level-0 rows that do not come straight from the voxeliser (block-filtered voxels of nuscenes/all.fhd): their SubM
+            # layers hash the sites themselves, the levels above still come from the fused build
+            tbl, want_subm[0] = None, False
+            plan = [p for p in plan if not (p[2] and p[1] == 0)]
+        r = ops.rulebook_chain(x.indices.contiguous(), x.batch_size, x.spatial_shape, convs, n_dev=x.num_active_dev, site_table=tbl,
+                               want_subm=want_subm, want_site_map=int(x.spatial_shape[0]) > 0)
+        if r is None:
+            return None
+        lv = r["levels"]
+        planned = {}
+        for m, level, subm in plan:
+            L = lv[level]
+            if subm:
+                rb = Rulebook(L["indices"], L["indices"], L["subm_nbr"], None, L["cap"], L["shape"], L["shape"], True,
+                              num_out_dev=L["num_dev"])
+            else:
+                I = lv[level - 1]
+                rb = Rulebook(L["indices"], I["indices"], L["nbr_out"], None, L["cap"], I["shape"], L["shape"], False,
+                              num_out_dev=L["num_dev"])
+                if level == len(convs):
+                    rb._site_map = r["site_map"]
+            rb._chain_workspace = r["workspace"]
+            planned[id(m)] = (rb, None)
+        return planned
+
     def _folded(self, conv, bn):
         key = (id(conv), id(bn), bn.weight._version if bn.weight is not None else 0,
                bn.bias._version if bn.bias is not None else 0, bn.running_mean._version, bn.running_var._version,

@@ -86,13 +86,23 @@ def sparse_stage_errors(calls, refs, ulp, sparse_shape, single=True):
     for f, r in enumerate(refs):
         got = idx[voffs[f]:voffs[f + 1]]
         assert np.array_equal(got[:, 1:], r["voxel_coordinates"][:, 1:]) and np.all(got[:, 0] == f), f"voxel coordinates of frame {f}"
+    by_table = {}          # fused rulebook chain: gather table (data_ptr) -> (output sites, grid) of the level it belongs to
     for name, a, kw, res in calls:
         if name == "rulebook_conv":
             m = int(res["num_out_dev"][0].item()) if res.get("num_out_dev") is not None else int(res["num_out"])
             idx, shape = res["out_indices"][:m].cpu().numpy(), [int(s) for s in res["out_shape"]]
+        if name == "rulebook_chain" and res is not None:
+            for L in res["levels"]:
+                m = int(L["num_dev"].reshape(-1)[0].item()) if L["num_dev"] is not None else int(L["cap"])
+                ent = (L["indices"][:m].cpu().numpy(), [int(v) for v in L["shape"]])
+                for t in (L["nbr_out"], L["subm_nbr"]):
+                    if t is not None:
+                        by_table[t.data_ptr()] = ent
         if name != "indice_conv":
             continue
         feat, w, nbr, cap = a[:4]
+        if nbr.data_ptr() in by_table:
+            idx, shape = by_table[nbr.data_ptr()]
         m = int(kw["num_out_dev"][0].item()) if kw.get("num_out_dev") is not None else int(cap)
         got = res[:m].float().cpu().numpy()
         assert idx.shape[0] == m, (li, idx.shape, m)
