@@ -693,6 +693,46 @@ def time_batch1(det, points, offsets, steps=100):
     return res
 
 
+def time_dropin_modules(cpu_state, points, offsets, iters=15):
+    """The drop-in path's own speed (never `value`): ``SecondDetector.forward(example)`` -- the reference's VoxelNet.forward contract
+    (voxelnet.py:339-375: example dict of voxels / num_points / coordinates / anchors in, list of per-frame dicts out) through the
+    MODULE graph the unmodified reference builds over this package's `spconv`: SimpleVoxel module, spconv.SparseSequential of 14 x
+    (conv, BatchNorm1d, ReLU) with the drop-in default first-touch rulebooks (hash builds, one host sync per strided layer, like
+    spconv's numActOut), `.dense()`, the torch RPN (MIOpen convolutions), per-frame result dicts -- in fp32, the reference's default
+    precision, on the same 8 frames.  `peephole`: the inference fusion conv + BN + ReLU inside SparseSequential (what the reference
+    gets in eval mode); `unfused`: three separate modules per layer."""
+    from second_amd.models import SecondDetector, CAR_FHD
+    from second_amd import ops
+    det = SecondDetector(CAR_FHD)
+    det.load_state_dict(cpu_state)
+    det = det.eval().cuda()
+    batch = offsets.numel() - 1
+    prev = ops.set_rulebook_numbering("first_touch")
+    try:
+        with torch.no_grad():
+            vox = det.voxel_generator.generate_device(points, offsets)
+            example = {"voxels": vox["voxels"], "num_points": vox["num_points_per_voxel"], "coordinates": vox["coordinates"],
+                       "anchors": det.anchors.unsqueeze(0).expand(batch, -1, -1).contiguous()}
+            out = {}
+            for tag, fuse in (("peephole", True), ("unfused", False)):
+                det.middle_feature_extractor.middle_conv.fuse_inference = fuse
+                for _ in range(3):
+                    res = det(example)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(iters):
+                    res = det(example)
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / iters
+                out[tag] = {"frames_per_s": round(batch / dt, 1), "ms_per_batch": round(dt * 1e3, 3)}
+            out["detections_last_batch"] = int(sum(r["box3d_lidar"].shape[0] for r in res))
+    finally:
+        ops.set_rulebook_numbering(prev)
+    out["what"] = ("SecondDetector.forward(example), fp32, eager dynamic shapes, first-touch rulebooks, .dense(), torch RPN; voxelisation "
+                   "not included (the example dict is the reference's input to VoxelNet.forward)")
+    return out
+
+
 # ------------------------------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
@@ -858,7 +898,12 @@ def main():
                 ktable = kernel_table(det, points, offsets)
             except Exception as e:  # noqa: BLE001 -- the table is diagnostics: never lose the line over it
                 ktable = [{"error": repr(e)}]
-        e2e = batch1 = None
+        e2e = batch1 = dropin = None
+        if rank == 0 and args.workload == "car.fhd" and not args.no_extra_lines and not args.default_heads:
+            try:
+                dropin = time_dropin_modules(cpu_state, points, offsets)
+            except Exception as e:  # noqa: BLE001 -- a side measurement: never lose the line over it
+                dropin = {"error": repr(e)[:300]}
         if rank == 0 and args.mode == "graph" and args.branches == 1 and args.workload == "car.fhd" and not args.no_extra_lines:
             e2e = time_e2e(det, points, offsets, max(1, args.inflight), min(args.steps, 200), args.warmup, serialize_rpn=serialize)
             batch1 = time_batch1(det, points, offsets)      # last: it re-calibrates the static capacities for one frame
@@ -928,7 +973,7 @@ def main():
                        "rows_per_frame": rows_per_frame,
                        "weights": "seeded random, default heads (tie-dominated top-k)" if args.default_heads or WL["cfg"] != "CAR_FHD"
                                   else "seeded random with trained-like heads (synthetic.randomise_like_trained / sharpen_heads)",
-                       "e2e_from_pinned_host": e2e, "batch1": batch1},
+                       "e2e_from_pinned_host": e2e, "batch1": batch1, "dropin_module_path": dropin},
             "roofline": roof,
             "roofline_mfma": roof_mfma,     # second-largest consumer by kind: the dense RPN conv, MFMA bound
             "kernels": ktable,              # per-launch table of one step (SURVEY 8d formulas)
