@@ -381,7 +381,17 @@ def train_bench(args, rank, local_rank, world, device):
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-    elapsed, timing, out6 = measure(lambda: tr.step(pts, offs, gt, goffs, gcls), barrier, args.steps, args.warmup, world, device)
+    step_fn, launch = (lambda: tr.step(pts, offs, gt, goffs, gcls)), "eager"
+    if args.mode == "graph" and amp is not None and tr.loss_scale is None and not det.pillars:
+        try:        # the whole step as one hipGraph (DeviceTrainer.capture_step); anything that cannot be captured keeps the eager step
+            replay = tr.capture_step(pts, offs, gt, goffs, gcls)
+            step_fn, launch = (lambda: replay()), "one hipGraph per step (static-capacity rows)"
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench] whole-step capture failed ({e!r}); eager steps", file=sys.stderr)
+            tr.static = False
+    elapsed, timing, out6 = measure(step_fn, barrier, args.steps, args.warmup, world, device)
+    if tr.static:
+        tr.check_overflow()
     # the gradient all-reduce alone (the only collective of the step): 20 back-to-back reductions of the live bucket
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -397,7 +407,7 @@ def train_bench(args, rank, local_rank, world, device):
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "timing": timing,
                "dtype": "fp32" if amp is None else f"{args.dtype} features (sparse stack + RPN autocast) over fp32 master weights", "data": "synthetic",
                "config": {"workload": WL["desc"], "samples_per_step_per_gpu": bs, "parallelism": f"ddp{world}",
-                          "points_per_frame": int(pts.shape[0]) // bs,
+                          "points_per_frame": int(pts.shape[0]) // bs, "launch_mode": launch,
                           "gradient_bucket_bytes": tr.bucket.numel * 4,
                           "allreduce_us": round(ar_us, 1) if world > 1 else None, "bucket_pack_unpack_us": round(ar_us, 1) if world == 1 else None,
                           "skipped_steps_loss_scale": tr.skipped_steps if tr.loss_scale is not None else None,

@@ -261,9 +261,9 @@ int sec_conv2d_nhwc_gather(const void *features, long long feature_rows, const i
 /* Adjoint of sec_sparse_to_dense -- rows[i,:] = dense[indices[i]] -- i.e. the backward of
  * SparseConvTensor.dense() (upstream gets it from autograd through scatter_nd, spconv/__init__.py) and of
  * PointPillarsScatter (pointpillars.py:444-476) with stride_z = 0. */
-int sec_dense_to_sparse(const void *dense, const int *indices, int n, int c, void *rows,
+int sec_dense_to_sparse(const void *dense, const int *indices, int n, int c, const int *num_dev, void *rows,
                         int64_t stride_b, int64_t stride_c, int64_t stride_z, int64_t stride_y,
-                        int64_t stride_x, int dtype, void *stream);
+                        int64_t stride_x, int dtype, void *stream);     /* num_dev: as in sec_sparse_to_dense (rows past it untouched) */
 
 /* PointPillarsScatter.forward (second/pytorch/models/pointpillars.py:444-476): coords (b,z,y,x),
  * canvas [B, C, ny, nx] (strides given in elements), cleared first.  num_dev (optional device int): only the
@@ -376,12 +376,16 @@ int sec_conv2d_wgrad_nhwc(const void *x, const void *dy, int batch, int h, int w
                           int stride, int pad, float *dweight, void *workspace, size_t workspace_bytes, int dtype,
                           void *stream);
 size_t sec_bn_train_workspace_bytes(int channels);
+/* pixels_dev (device int, or NULL): static-capacity rows -- `pixels` is the capacity, the first *pixels_dev rows are live;
+ * statistics and both passes run over the live rows only, rows past them are neither read nor written. */
 int sec_bn_relu_fwd_nhwc(const void *y, long long pixels, int channels, const float *gamma, const float *beta, float eps,
                          float momentum, float *running_mean, float *running_var, int relu, void *z, float *save_mean,
-                         float *save_invstd, void *workspace, size_t workspace_bytes, int dtype, void *stream);
+                         float *save_invstd, void *workspace, size_t workspace_bytes, int dtype, const int *pixels_dev,
+                         void *stream);
 int sec_bn_relu_bwd_nhwc(const void *dz, const void *y, long long pixels, int channels, const float *gamma,
                          const float *beta, const float *save_mean, const float *save_invstd, int relu, void *dy,
-                         float *dgamma, float *dbeta, void *workspace, size_t workspace_bytes, int dtype, void *stream);
+                         float *dgamma, float *dbeta, void *workspace, size_t workspace_bytes, int dtype,
+                         const int *pixels_dev, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Rotated IoU / NMS -- replace the numba.cuda kernels of second/core/non_max_suppression/nms_gpu.py

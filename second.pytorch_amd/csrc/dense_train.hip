@@ -155,12 +155,20 @@ __global__ __launch_bounds__(256) void k_conv2d_wgrad_reduce(const float *__rest
 // pass.  Backward: with g = dz * [z > 0], xh = (y - mean) * invstd:  dbeta = sum g, dgamma = sum g * xh,
 // dy = gamma * invstd * (g - dbeta / P - xh * dgamma / P): one partial-sum pass, one finalize, one apply pass.
 // Thread layout: a thread owns 8 channels (one 16-byte chunk) of every (256 / (C/8))-th pixel.
+// static-capacity training (DeviceTrainer with a captured step): the activation holds `P` rows of CAPACITY, the first *p_dev are
+// live; statistics, normalisation and the backward sums run over the live rows only (NULL: all P rows)
+__device__ __forceinline__ long long bn_live_rows(long long P, const int *p_dev) {
+    if (!p_dev) return P;
+    const long long live = *p_dev;
+    return live < P ? (live > 0 ? live : 0) : P;
+}
 template <typename T, int MODE>     // MODE 0: (sum y, sum y^2);  MODE 1: (sum g, sum g * xh) with mean / invstd / gamma / beta given
 __global__ __launch_bounds__(256) void k_bn_partial(const T *__restrict__ y, const T *__restrict__ dz, long long P, int C,
                                                    const float *__restrict__ mean, const float *__restrict__ invstd,
                                                    const float *__restrict__ gamma, const float *__restrict__ beta, int relu,
-                                                   float *__restrict__ part) {
+                                                   float *__restrict__ part, const int *__restrict__ p_dev) {
     __shared__ float red[2][256][8 + 1];
+    P = bn_live_rows(P, p_dev);
     const int cg = C / 8, tid = threadIdx.x;
     const int chg = tid % cg, pl = tid / cg, ppi = 256 / cg;      // pixels per iteration of this workgroup
     float a[8], b2[8];
@@ -227,7 +235,10 @@ __device__ __forceinline__ void wave_sum2(const float *__restrict__ part, int gr
 // One wave per channel (256-thread workgroups: four channels each).
 __global__ __launch_bounds__(256) void k_bn_fwd_finalize(const float *__restrict__ part, int groups, int C, long long P, float eps,
                                                         float momentum, float *__restrict__ mean, float *__restrict__ invstd,
-                                                        float *__restrict__ running_mean, float *__restrict__ running_var) {
+                                                        float *__restrict__ running_mean, float *__restrict__ running_var,
+                                                        const int *__restrict__ p_dev) {
+    P = bn_live_rows(P, p_dev);
+    if (P < 1) P = 1;
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (c >= C) return;
     double s0, s1;                                          // doubles: E[y^2] - E[y]^2 over 1e5 pixels cancels badly in fp32
@@ -259,10 +270,11 @@ __global__ __launch_bounds__(256) void k_bn_apply(const T *__restrict__ y, const
                                                  const float *__restrict__ mean, const float *__restrict__ invstd,
                                                  const float *__restrict__ gamma, const float *__restrict__ beta,
                                                  const float *__restrict__ dbeta, const float *__restrict__ dgamma, int relu,
-                                                 T *__restrict__ out) {
+                                                 T *__restrict__ out, const int *__restrict__ p_dev) {
+    P = bn_live_rows(P, p_dev);                        // rows past the live count are neither read nor written
     const int cg = C / 8;
     const long long n = P * cg;
-    const float inv_p = 1.0f / (float)P;
+    const float inv_p = 1.0f / (float)(P > 0 ? P : 1);
     for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < n; q += (long long)gridDim.x * 256) {
         const int chg = (int)(q % cg);
         const uint4 v = reinterpret_cast<const uint4 *>(y)[q];
@@ -383,7 +395,8 @@ SEC_API size_t sec_bn_train_workspace_bytes(int channels) {
 
 SEC_API int sec_bn_relu_fwd_nhwc(const void *y, long long pixels, int channels, const float *gamma, const float *beta, float eps,
                                  float momentum, float *running_mean, float *running_var, int relu, void *z, float *save_mean,
-                                 float *save_invstd, void *workspace, size_t workspace_bytes, int dtype, void *stream) {
+                                 float *save_invstd, void *workspace, size_t workspace_bytes, int dtype, const int *pixels_dev,
+                                 void *stream) {
     if (!y || !z || !gamma || !beta || !save_mean || !save_invstd || !workspace || pixels <= 0) return SEC_E_INVALID;
     if (channels <= 0 || channels % 8 || channels > 256 || 256 % (channels / 8) || (dtype != SEC_BF16 && dtype != SEC_F16)) return SEC_E_UNSUPPORTED;
     if (workspace_bytes < sec_bn_train_workspace_bytes(channels)) return SEC_E_WORKSPACE;
@@ -392,11 +405,11 @@ SEC_API int sec_bn_relu_fwd_nhwc(const void *y, long long pixels, int channels, 
     const int blocks = (int)((pixels * (channels / 8) + 255) / 256 < 2048 ? (pixels * (channels / 8) + 255) / 256 : 2048);
 #define SEC_BN_FWD(T)                                                                                                              \
     hipLaunchKernelGGL((k_bn_partial<T, 0>), dim3(kBnGroups), dim3(256), 0, st, (const T *)y, (const T *)nullptr, pixels, channels, \
-                       nullptr, nullptr, nullptr, nullptr, 0, part);                                                               \
+                       nullptr, nullptr, nullptr, nullptr, 0, part, pixels_dev);                                                   \
     hipLaunchKernelGGL(k_bn_fwd_finalize, dim3(div_up(channels, 4)), dim3(256), 0, st, part, kBnGroups, channels, pixels, eps,    \
-                       momentum, save_mean, save_invstd, running_mean, running_var);                                               \
+                       momentum, save_mean, save_invstd, running_mean, running_var, pixels_dev);                                   \
     hipLaunchKernelGGL((k_bn_apply<T, 0>), dim3(blocks), dim3(256), 0, st, (const T *)y, (const T *)nullptr, pixels, channels,      \
-                       save_mean, save_invstd, gamma, beta, nullptr, nullptr, relu, (T *)z);
+                       save_mean, save_invstd, gamma, beta, nullptr, nullptr, relu, (T *)z, pixels_dev);
     if (dtype == SEC_BF16) { SEC_BN_FWD(__hip_bfloat16) } else { SEC_BN_FWD(__half) }
 #undef SEC_BN_FWD
     return check_launch();
@@ -404,7 +417,7 @@ SEC_API int sec_bn_relu_fwd_nhwc(const void *y, long long pixels, int channels, 
 
 SEC_API int sec_bn_relu_bwd_nhwc(const void *dz, const void *y, long long pixels, int channels, const float *gamma, const float *beta,
                                  const float *save_mean, const float *save_invstd, int relu, void *dy, float *dgamma, float *dbeta,
-                                 void *workspace, size_t workspace_bytes, int dtype, void *stream) {
+                                 void *workspace, size_t workspace_bytes, int dtype, const int *pixels_dev, void *stream) {
     if (!dz || !y || !dy || !gamma || !beta || !save_mean || !save_invstd || !dgamma || !dbeta || !workspace || pixels <= 0) return SEC_E_INVALID;
     if (channels <= 0 || channels % 8 || channels > 256 || 256 % (channels / 8) || (dtype != SEC_BF16 && dtype != SEC_F16)) return SEC_E_UNSUPPORTED;
     if (workspace_bytes < sec_bn_train_workspace_bytes(channels)) return SEC_E_WORKSPACE;
@@ -413,10 +426,10 @@ SEC_API int sec_bn_relu_bwd_nhwc(const void *dz, const void *y, long long pixels
     const int blocks = (int)((pixels * (channels / 8) + 255) / 256 < 2048 ? (pixels * (channels / 8) + 255) / 256 : 2048);
 #define SEC_BN_BWD(T)                                                                                                              \
     hipLaunchKernelGGL((k_bn_partial<T, 1>), dim3(kBnGroups), dim3(256), 0, st, (const T *)y, (const T *)dz, pixels, channels,      \
-                       save_mean, save_invstd, gamma, beta, relu, part);                                                           \
+                       save_mean, save_invstd, gamma, beta, relu, part, pixels_dev);                                               \
     hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(div_up(channels, 4)), dim3(256), 0, st, part, kBnGroups, channels, dbeta, dgamma); \
     hipLaunchKernelGGL((k_bn_apply<T, 1>), dim3(blocks), dim3(256), 0, st, (const T *)y, (const T *)dz, pixels, channels, save_mean, \
-                       save_invstd, gamma, beta, dbeta, dgamma, relu, (T *)dy);
+                       save_invstd, gamma, beta, dbeta, dgamma, relu, (T *)dy, pixels_dev);
     if (dtype == SEC_BF16) { SEC_BN_BWD(__hip_bfloat16) } else { SEC_BN_BWD(__half) }
 #undef SEC_BN_BWD
     return check_launch();

@@ -26,7 +26,8 @@ __global__ __launch_bounds__(kBlock) void k_scatter_rows(const T *__restrict__ f
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_gather_rows(const T *__restrict__ dense, const int *__restrict__ idx, int n,
                                                        int c, T *__restrict__ rows, long long sb, long long sc,
-                                                       long long sz, long long sy, long long sx) {
+                                                       long long sz, long long sy, long long sx, const int *__restrict__ num_dev) {
+    if (num_dev) { const int live = *num_dev; n = live < n ? (live > 0 ? live : 0) : n; }   // static capacity: indices past the live rows are unspecified
     long long total = (long long)n * c;
     for (long long g = (long long)blockIdx.x * kBlock + threadIdx.x; g < total; g += (long long)gridDim.x * kBlock) {
         int i = (int)(g / c), ch = (int)(g % c);
@@ -37,12 +38,12 @@ __global__ __launch_bounds__(kBlock) void k_gather_rows(const T *__restrict__ de
 
 template <typename T>
 static int run_gather(const void *dense, const int *idx, int n, int c, void *rows, long long sb, long long sc,
-                      long long sz, long long sy, long long sx, hipStream_t st) {
+                      long long sz, long long sy, long long sx, const int *num_dev, hipStream_t st) {
     if (n == 0) return SEC_OK;
     int blocks = div_up((long long)n * c, kBlock);
     if (blocks > 256 * 32) blocks = 256 * 32;
     hipLaunchKernelGGL(k_gather_rows<T>, dim3(blocks), dim3(kBlock), 0, st, (const T *)dense, idx, n, c, (T *)rows, sb, sc,
-                       sz, sy, sx);
+                       sz, sy, sx, num_dev);
     return check_launch();
 }
 
@@ -122,15 +123,15 @@ SEC_API int sec_sparse_to_dense(const void *features, const int *indices, int n,
     return SEC_E_UNSUPPORTED;
 }
 
-SEC_API int sec_dense_to_sparse(const void *dense, const int *indices, int n, int c, void *rows, int64_t stride_b,
+SEC_API int sec_dense_to_sparse(const void *dense, const int *indices, int n, int c, const int *num_dev, void *rows, int64_t stride_b,
                                 int64_t stride_c, int64_t stride_z, int64_t stride_y, int64_t stride_x, int dtype,
                                 void *stream) {
     if (n < 0 || c <= 0 || (n > 0 && (!dense || !indices || !rows))) return SEC_E_INVALID;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == SEC_F32)
-        return run_gather<float>(dense, indices, n, c, rows, stride_b, stride_c, stride_z, stride_y, stride_x, st);
+        return run_gather<float>(dense, indices, n, c, rows, stride_b, stride_c, stride_z, stride_y, stride_x, num_dev, st);
     if (dtype == SEC_F16 || dtype == SEC_BF16)
-        return run_gather<unsigned short>(dense, indices, n, c, rows, stride_b, stride_c, stride_z, stride_y, stride_x, st);
+        return run_gather<unsigned short>(dense, indices, n, c, rows, stride_b, stride_c, stride_z, stride_y, stride_x, num_dev, st);
     return SEC_E_UNSUPPORTED;
 }
 

@@ -465,9 +465,10 @@ def sparse_to_dense(features, indices, batch_size, spatial_shape, channels_last_
     return out
 
 
-def dense_to_sparse(dense, indices):
+def dense_to_sparse(dense, indices, num_dev=None):
     """rows[i,:] = dense[b_i, :, (z_i,) y_i, x_i]: the adjoint of :func:`sparse_to_dense` ([B,C,D,H,W]) and of
-    :func:`pillar_scatter` ([B,C,H,W], z ignored) -- what autograd needs for their backward."""
+    :func:`pillar_scatter` ([B,C,H,W], z ignored) -- what autograd needs for their backward.  ``num_dev``: static capacity --
+    only the first num_dev[0] rows are gathered (the others stay unwritten)."""
     rt.require_gpu(dense, indices)
     n = indices.shape[0]
     c = dense.shape[1]
@@ -477,7 +478,7 @@ def dense_to_sparse(dense, indices):
         sb, sc, sz, sy, sx = st
     else:
         (sb, sc, sy, sx), sz = st, 0
-    rc = rt.lib().sec_dense_to_sparse(rt.ptr(dense), rt.ptr(indices.contiguous()), n, c, rt.ptr(rows), sb, sc, sz, sy, sx,
+    rc = rt.lib().sec_dense_to_sparse(rt.ptr(dense), rt.ptr(indices.contiguous()), n, c, rt.ptr(num_dev), rt.ptr(rows), sb, sc, sz, sy, sx,
                                       rt.dtype_code(dense.dtype), rt.stream())
     rt.check(rc, "sec_dense_to_sparse")
     return rows
@@ -1037,7 +1038,7 @@ def bn_train_supported(channels, dtype):
     return dtype in (torch.bfloat16, torch.float16) and channels % 8 == 0 and channels <= 256 and 256 % (channels // 8) == 0
 
 
-def bn_relu_forward(y, gamma, beta, eps, momentum, running_mean=None, running_var=None, relu=True):
+def bn_relu_forward(y, gamma, beta, eps, momentum, running_mean=None, running_var=None, relu=True, rows_dev=None):
     """Training-mode BatchNorm + ReLU of a 16-bit activation whose channels are innermost in memory: a channels_last [B,C,H,W]
     tensor (BatchNorm2d of the RPN) or the [N,C] feature rows of a sparse tensor (BatchNorm1d of the sparse middle:
     middle.py:146-189) (sec_bn_relu_fwd_nhwc).  gamma / beta fp32 [C]; running_mean / running_var (fp32, updated in place) may be
@@ -1056,11 +1057,11 @@ def bn_relu_forward(y, gamma, beta, eps, momentum, running_mean=None, running_va
     invstd = torch.empty((c,), dtype=torch.float32, device=y.device)
     rt.check(l.sec_bn_relu_fwd_nhwc(rt.ptr(y), b * h * w, c, rt.ptr(gamma), rt.ptr(beta), float(eps), float(momentum),
                                     rt.ptr(running_mean), rt.ptr(running_var), int(bool(relu)), rt.ptr(z), rt.ptr(mean), rt.ptr(invstd),
-                                    rt.ptr(ws), ws.numel(), rt.dtype_code(y.dtype), rt.stream()), "sec_bn_relu_fwd_nhwc")
+                                    rt.ptr(ws), ws.numel(), rt.dtype_code(y.dtype), rt.ptr(rows_dev), rt.stream()), "sec_bn_relu_fwd_nhwc")
     return z, mean, invstd
 
 
-def bn_relu_backward(dz, y, gamma, beta, save_mean, save_invstd, relu=True):
+def bn_relu_backward(dz, y, gamma, beta, save_mean, save_invstd, relu=True, rows_dev=None):
     """-> (dy, dgamma, dbeta) of :func:`bn_relu_forward` (sec_bn_relu_bwd_nhwc); dz, y channels_last 16-bit."""
     rt.require_gpu(dz, y, gamma, beta, save_mean, save_invstd)
     assert dz.shape == y.shape and dz.dtype == y.dtype
@@ -1073,7 +1074,7 @@ def bn_relu_backward(dz, y, gamma, beta, save_mean, save_invstd, relu=True):
     dbeta = torch.empty((c,), dtype=torch.float32, device=y.device)
     rt.check(l.sec_bn_relu_bwd_nhwc(rt.ptr(dz), rt.ptr(y), b * h * w, c, rt.ptr(gamma), rt.ptr(beta), rt.ptr(save_mean),
                                     rt.ptr(save_invstd), int(bool(relu)), rt.ptr(dy), rt.ptr(dgamma), rt.ptr(dbeta), rt.ptr(ws),
-                                    ws.numel(), rt.dtype_code(y.dtype), rt.stream()), "sec_bn_relu_bwd_nhwc")
+                                    ws.numel(), rt.dtype_code(y.dtype), rt.ptr(rows_dev), rt.stream()), "sec_bn_relu_bwd_nhwc")
     return dy, dgamma, dbeta
 
 
@@ -1123,11 +1124,12 @@ class BatchNormReluFunction(torch.autograd.Function):
     channels_last 16-bit activations with fp32 affine parameters."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, running_mean, running_var, eps, momentum, relu):
+    def forward(ctx, y, gamma, beta, running_mean, running_var, eps, momentum, relu, rows_dev=None):
+        """``rows_dev`` (device int32[>=1]): static-capacity rows -- statistics and both passes over the first rows_dev[0] rows only."""
         z, mean, invstd = bn_relu_forward(y, gamma.detach().float().contiguous(), beta.detach().float().contiguous(), eps, momentum,
-                                          running_mean, running_var, relu)
+                                          running_mean, running_var, relu, rows_dev=rows_dev)
         ctx.save_for_backward(y, gamma, beta, mean, invstd)
-        ctx.relu = relu
+        ctx.relu, ctx.rows_dev = relu, rows_dev
         return z
 
     @staticmethod
@@ -1135,5 +1137,5 @@ class BatchNormReluFunction(torch.autograd.Function):
         y, gamma, beta, mean, invstd = ctx.saved_tensors
         dz = dz.contiguous() if y.dim() == 2 else dz.contiguous(memory_format=torch.channels_last)
         dy, dgamma, dbeta = bn_relu_backward(dz, y, gamma.detach().float().contiguous(),
-                                             beta.detach().float().contiguous(), mean, invstd, ctx.relu)
-        return dy, dgamma.to(gamma.dtype), dbeta.to(beta.dtype), None, None, None, None, None
+                                             beta.detach().float().contiguous(), mean, invstd, ctx.relu, rows_dev=ctx.rows_dev)
+        return dy, dgamma.to(gamma.dtype), dbeta.to(beta.dtype), None, None, None, None, None, None

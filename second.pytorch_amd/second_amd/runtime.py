@@ -132,7 +132,7 @@ def lib():
         l.sec_indice_conv_bwd.argtypes = [vp, ci, ci, vp, ci, ci, vp, vp, ci, vp, vp, vp, ci, vp, sz, vp]
         l.sec_indice_conv_bwd_workspace_bytes.argtypes = [ci, ci, ci, ci]
         l.sec_sparse_to_dense.argtypes = [vp, vp, ci, ci, vp, vp, sz, i64, i64, i64, i64, i64, ci, vp]
-        l.sec_dense_to_sparse.argtypes = [vp, vp, ci, ci, vp, i64, i64, i64, i64, i64, ci, vp]
+        l.sec_dense_to_sparse.argtypes = [vp, vp, ci, ci, vp, vp, i64, i64, i64, i64, i64, ci, vp]
         l.sec_pillar_scatter.argtypes = [vp, vp, ci, ci, vp, vp, sz, i64, i64, i64, i64, ci, vp]
         l.sec_pfn_fwd.argtypes = [vp, vp, vp, ci, vp, ci, ci, vp, vp, vp, ci, cf, cf, cf, cf, vp, ci, vp]
         l.sec_pfn_fwd_slots.argtypes = [vp, vp, sz, ci, ci, ci, ci, ci, vp, vp, ci, vp, vp, vp, vp, ci, cf, cf, cf, cf, vp, ci, vp]
@@ -165,8 +165,8 @@ def lib():
         l.sec_conv2d_wgrad_workspace_bytes.argtypes = [ci] * 6
         l.sec_conv2d_wgrad_nhwc.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, vp, sz, ci, vp]
         l.sec_bn_train_workspace_bytes.argtypes = [ci]
-        l.sec_bn_relu_fwd_nhwc.argtypes = [vp, ll, ci, vp, vp, cf, cf, vp, vp, ci, vp, vp, vp, vp, sz, ci, vp]
-        l.sec_bn_relu_bwd_nhwc.argtypes = [vp, vp, ll, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp, sz, ci, vp]
+        l.sec_bn_relu_fwd_nhwc.argtypes = [vp, ll, ci, vp, vp, cf, cf, vp, vp, ci, vp, vp, vp, vp, sz, ci, vp, vp]
+        l.sec_bn_relu_bwd_nhwc.argtypes = [vp, vp, ll, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp, sz, ci, vp, vp]
         _lib = l
     return _lib
 

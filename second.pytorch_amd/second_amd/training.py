@@ -56,8 +56,13 @@ class DeviceTrainer:
         self.amp_dtype = amp_dtype
         D.broadcast_parameters(det, 0)
         # the reference's adam_optimizer + fixed weight decay (car.fhd.config:180-188) -> AdamW
-        self.opt = torch.optim.AdamW([p for p in det.parameters() if p.requires_grad], lr=lr, weight_decay=weight_decay,
-                                     betas=(0.9, 0.99))
+        params = [p for p in det.parameters() if p.requires_grad]
+        # capturable: the step counters live on the device, so that a whole optimisation step can be captured in a hipGraph
+        # (capture_step); identical arithmetic to the default implementation
+        self.opt = torch.optim.AdamW(params, lr=lr, weight_decay=weight_decay, betas=(0.9, 0.99),
+                                     **({"capturable": True, "foreach": True} if params and params[0].is_cuda else {}))
+        self.static = False          # static-capacity rows (device-side live counts, no host sync): set by capture_step
+        self._captured = None
         self.bucket = D.GradBucket(det)
         # fp16 features need loss scaling (5 exponent bits: head gradients are O(1 / num_pos / batch)); bf16 / fp32 do not
         self.loss_scale = float(init_loss_scale) if amp_dtype == torch.float16 else None
@@ -76,12 +81,16 @@ class DeviceTrainer:
     def _forward_loss(self, points, point_offsets, gt_boxes, gt_offsets, gt_classes=None):
         det, cfg = self.det, self.cfg
         batch = point_offsets.numel() - 1
+        static = self.static and not det.pillars and self.amp_dtype is not None
+        nd = None
         with torch.no_grad():
             if det.pillars:
                 vox = det.voxel_generator.generate_device(points, point_offsets)
             else:
                 vox = det.voxel_generator.generate_device(points, point_offsets, mean_features=cfg["num_point_features"],
-                                                          mean_dtype=self.amp_dtype)
+                                                          mean_dtype=self.amp_dtype, sync=not static)
+                if static:
+                    nd = vox["voxel_offsets"][batch:]         # live voxel rows stay on the device
             if self.class_ranges is None:
                 labels, reg_targets, importance = ops.assign_targets(det.anchors, gt_boxes, gt_offsets, *self.thresholds,
                                                                      gt_classes=gt_classes)
@@ -111,7 +120,7 @@ class DeviceTrainer:
             # fp32 master weights; 16-bit features through the sparse stack (MFMA forward / dgrad / wgrad kernels) and,
             # under autocast, through the dense RPN; BatchNorm statistics and the loss in fp32
             spatial = det.middle_feature_extractor(vox["mean"].to(self.amp_dtype), vox["coordinates"], batch,
-                                                   site_table=vox.get("site_table"))
+                                                   site_table=vox.get("site_table"), num_active_dev=nd)
             preds = self._rpn_mixed(spatial)                  # 3x3 convs + BatchNorm/ReLU on the hand-written kernels
         else:
             preds = det.network_forward(vox["mean"], vox["coordinates"], batch, site_table=vox.get("site_table"))
@@ -127,8 +136,8 @@ class DeviceTrainer:
         import os
         from .models import rpn_forward_mixed
         x = spatial.to(self.amp_dtype).contiguous(memory_format=torch.channels_last)
-        if os.environ.get("SEC_TRAIN_GRAPH_RPN", "1") != "1" or not x.is_cuda:
-            return rpn_forward_mixed(self.det.rpn, x, self.amp_dtype)
+        if self.static or os.environ.get("SEC_TRAIN_GRAPH_RPN", "1") != "1" or not x.is_cuda:
+            return rpn_forward_mixed(self.det.rpn, x, self.amp_dtype)      # static: the WHOLE step is one graph (capture_step)
         key = (tuple(x.shape), x.dtype)
         if self._graphed_rpn is None or self._graphed_rpn[0] != key:
             self._graphed_rpn = (key, self._capture_rpn(x))
@@ -195,6 +204,56 @@ class DeviceTrainer:
         self.bucket.zero_grad()                                   # fp32 p.grad are views of the bucket: one fill
         self.steps += 1
         return out6
+
+    def capture_step(self, points, point_offsets, gt_boxes, gt_offsets, gt_classes=None, margin=1.25, warmup=2):
+        """The WHOLE optimisation step -- voxelise, targets, forward, loss, backward, gradient all-reduce, clip, AdamW -- as ONE
+        hipGraph (second/pytorch/train.py:306-330 is ~520 dispatches here, host bound when launched one by one).  What makes it
+        capturable: static-capacity rows through the sparse stack (row counts stay on the device; every strided layer gets
+        ``margin`` x the rows this batch produced, rounded up to 256), BatchNorm statistics / dense scatter over the LIVE rows
+        only (``rows_dev`` / ``num_dev`` arguments of the kernels), an optimizer whose step counters live on the device.  16-bit
+        features without dynamic loss scaling only (bf16; fp16 reads an overflow flag on the host every step).
+        Returns ``replay(points=None, point_offsets=None, gt_boxes=None, gt_offsets=None, gt_classes=None) -> out6``: new inputs
+        (same shapes or fewer rows) are copied into the graph's buffers first.  Raises what the capture raises: callers fall back
+        to :meth:`step`.  Call :meth:`check_overflow` now and then (one host sync)."""
+        import spconv
+        assert self.amp_dtype is not None and self.loss_scale is None and not self.det.pillars, "capture_step: bf16 sparse-middle configs"
+        ins = [points, point_offsets, gt_boxes, gt_offsets, gt_classes]
+        self.static = False
+        self.step(*ins)                                   # one dynamic step: records every strided layer's output rows
+        for m in self.det.middle_feature_extractor.modules():
+            if isinstance(m, spconv.SparseConvolution) and not m.subm and m.last_num_out is not None:
+                m.static_out_rows = int(-(-int(m.last_num_out * margin) // 256) * 256)
+        self.static = True
+        bufs = [None if t is None else t.clone() for t in ins]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):                       # static eager steps: allocator warm-up, optimizer state, autotuned plans
+                self.step(*bufs)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.check_overflow()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            out6 = self.step(*bufs)
+        self._captured = (graph, bufs, out6)
+
+        def replay(*new):
+            for dst, src in zip(bufs, new):
+                if src is not None and dst is not None and src.data_ptr() != dst.data_ptr():
+                    dst[:src.shape[0]].copy_(src, non_blocking=True)
+            graph.replay()
+            self.steps += 1
+            self.last = {"out6": out6}
+            return out6
+        return replay
+
+    def check_overflow(self):
+        """Static-capacity steps: raise if a strided layer produced more rows than its capacity (one host sync)."""
+        for num, cap in getattr(self.det.middle_feature_extractor, "last_overflow_checks", []):
+            raw = int(num[1].item())
+            if raw > cap:
+                raise RuntimeError(f"static-capacity overflow in training: a strided sparse conv produced {raw} rows, capacity {cap}")
 
     def _unscale_and_check(self):
         """Dynamic loss scaling for fp16 features (the reference trains mixed precision through apex amp with

@@ -43,14 +43,15 @@ class SparseToDenseFunction(torch.autograd.Function):
     """dense() with a gradient (upstream: scatter_nd under autograd, spconv/__init__.py SparseConvTensor.dense)."""
 
     @staticmethod
-    def forward(ctx, features, indices, batch_size, spatial_shape):
+    def forward(ctx, features, indices, batch_size, spatial_shape, num_dev=None):
         ctx.save_for_backward(indices)
-        return _ops.sparse_to_dense(features, indices, batch_size, spatial_shape)
+        ctx.num_dev = num_dev              # static capacity: rows past num_dev[0] are neither scattered nor gathered back
+        return _ops.sparse_to_dense(features, indices, batch_size, spatial_shape, num_dev=num_dev)
 
     @staticmethod
     def backward(ctx, grad):
         (indices,) = ctx.saved_tensors
-        return _ops.dense_to_sparse(grad, indices), None, None, None
+        return _ops.dense_to_sparse(grad, indices, num_dev=ctx.num_dev), None, None, None, None
 
 
 class PillarScatterFunction(torch.autograd.Function):

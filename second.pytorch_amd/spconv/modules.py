@@ -205,7 +205,7 @@ class SparseSequential(SparseModule):
                 relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
                 mom = m.momentum if m.momentum is not None else 0.1
                 input.features = _sec_ops().BatchNormReluFunction.apply(input.features.contiguous(), m.weight, m.bias, m.running_mean,
-                                                                       m.running_var, m.eps, mom, relu)
+                                                                       m.running_var, m.eps, mom, relu, input.num_active_dev)
                 _sec_ops().bump_bn_counter(m)
                 i += 2 if relu else 1
                 continue
@@ -213,6 +213,10 @@ class SparseSequential(SparseModule):
                 input = m(input)
             elif isinstance(input, SparseConvTensor):
                 if input.indices.shape[0] != 0:
+                    if input.num_active_dev is not None and isinstance(m, nn.modules.batchnorm._BatchNorm) and m.training:
+                        raise RuntimeError("static-capacity sparse tensor through a torch BatchNorm in training mode: its statistics "
+                                           "would include the rows past the live count (the fused BatchNorm1d path needs 16-bit "
+                                           "features and a supported channel count)")
                     input.features = m(input.features)
             else:
                 input = m(input)

@@ -54,7 +54,8 @@ class SparseConvTensor:
     def dense(self, channels_first=True):
         if torch.is_grad_enabled() and self.features.requires_grad:   # training: differentiable scatter
             from .functional import SparseToDenseFunction
-            out = SparseToDenseFunction.apply(self.features, self.indices.contiguous(), self.batch_size, self.spatial_shape)
+            out = SparseToDenseFunction.apply(self.features, self.indices.contiguous(), self.batch_size, self.spatial_shape,
+                                              self.num_active_dev)
         else:
             out = _ops.sparse_to_dense(self.features, self.indices.contiguous(), self.batch_size, self.spatial_shape,
                                        num_dev=self.num_active_dev)

@@ -134,7 +134,7 @@ def pillar_scatter(features, coords, batch_size, ny, nx, channels_last=False, nu
     return torch.from_numpy(orc.pillar_scatter(_np(features.float()), _np(coords), batch_size, ny, nx)).to(features.dtype)
 
 
-def dense_to_sparse(dense, indices):
+def dense_to_sparse(dense, indices, num_dev=None):
     idx = indices.long()
     if dense.dim() == 5:
         return dense[idx[:, 0], :, idx[:, 1], idx[:, 2], idx[:, 3]].contiguous()

@@ -291,3 +291,101 @@ def test_device_trainer_graphed_rpn_segment_equals_eager(monkeypatch):
     la, lb = results["1"][2], results["0"][2]
     assert torch.isfinite(la).all() and torch.isfinite(lb).all()
     torch.testing.assert_close(la[0], lb[0], rtol=2e-3, atol=1e-5)
+
+
+@pytest.mark.parametrize("c", [16, 64])
+def test_bn_relu_static_capacity_rows_equal_the_live_slice(ops, c):
+    """rows_dev (static-capacity training): statistics, normalisation and the backward sums over the first rows_dev[0] rows only --
+    bit-identical to the same call on the live slice, whatever the rows behind it hold (NaN / Inf garbage here); those rows are
+    neither read nor written."""
+    g = torch.Generator().manual_seed(c + 1)
+    n, cap = 3001, 4096
+    y = torch.full((cap, c), float("nan")).bfloat16()
+    y[:n] = (torch.randn(n, c, generator=g) * 2 + 0.3).bfloat16()
+    y[n + 5:] = float("inf")
+    y = y.cuda()
+    dz = torch.full((cap, c), float("nan")).bfloat16()
+    dz[:n] = torch.randn(n, c, generator=g).bfloat16()
+    dz = dz.cuda()
+    gamma, beta = (torch.rand(c, generator=g) + 0.5).cuda(), (torch.randn(c, generator=g) / 4).cuda()
+    rows = torch.tensor([n], dtype=torch.int32, device="cuda")
+    res = []
+    for yy, dd, rd in ((y, dz, rows), (y[:n].contiguous(), dz[:n].contiguous(), None)):
+        rm, rv = torch.zeros(c, device="cuda"), torch.ones(c, device="cuda")
+        yi, gp, bp = yy.clone().requires_grad_(), gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+        z = ops.BatchNormReluFunction.apply(yi, gp, bp, rm, rv, 1e-3, 0.01, True, rd)
+        z.backward(dd)
+        res.append((z[:n].clone(), yi.grad[:n].clone(), gp.grad.clone(), bp.grad.clone(), rm, rv))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+
+def _train_inputs(frames=2):
+    from second_amd import synthetic as syn
+    clouds = [syn.syn_kitti_cloud(s) for s in range(frames)]
+    pts, offs = syn.batch_clouds(clouds)
+    gt = np.concatenate([syn.syn_kitti_boxes(s, 12) for s in range(frames)]).astype(np.float32)
+    goffs = np.arange(frames + 1, dtype=np.int32) * 12
+    return [torch.from_numpy(a).cuda() for a in (pts, offs, gt, goffs)]
+
+
+def test_static_capacity_training_forward_backward_matches_the_dynamic_one():
+    """The static-capacity form of the training forward / backward (row counts on the device, capacity rows of garbage behind the
+    live ones: what DeviceTrainer.capture_step captures) against the dynamic one from the same state on the same frames: loss
+    scalars and every gradient agree up to the fp32-atomic summation order of the sparse weight gradients."""
+    import spconv
+    from second_amd.models import SecondDetector, CAR_FHD
+    from second_amd.training import DeviceTrainer
+    ins = _train_inputs()
+    torch.manual_seed(0)
+    init = SecondDetector(CAR_FHD).state_dict()
+    out = {}
+    for static in (False, True):
+        det = SecondDetector(CAR_FHD)
+        det.load_state_dict(init)
+        tr = DeviceTrainer(det.cuda(), amp_dtype=torch.bfloat16)
+        if static:
+            with torch.no_grad():
+                tr.forward_loss(*ins)                       # dynamic pass: rows per strided layer
+            for m in det.middle_feature_extractor.modules():
+                if isinstance(m, spconv.SparseConvolution) and not m.subm:
+                    m.static_out_rows = int(-(-int(m.last_num_out * 1.25) // 256) * 256)
+            for mod in det.modules():                       # the extra pass must not leave traces in the BatchNorm statistics
+                if isinstance(mod, torch.nn.modules.batchnorm._BatchNorm):
+                    mod.reset_running_stats()
+            det.load_state_dict(init)
+            tr.static = True
+        loss, out6, _ = tr.forward_loss(*ins)
+        loss.backward()
+        torch.cuda.synchronize()
+        if static:
+            tr.check_overflow()
+        out[static] = (out6.float().cpu(), {n: p.grad.detach().float().cpu() for n, p in det.named_parameters()},
+                       {n: b.detach().float().cpu() for n, b in det.named_buffers() if "running" in n})
+    torch.testing.assert_close(out[True][0], out[False][0], rtol=1e-3, atol=1e-5)
+    for n, g in out[True][1].items():
+        w = out[False][1][n]
+        assert (g - w).abs().max().item() <= 2e-2 * w.abs().max().item() + 1e-7, n
+    for n, b in out[True][2].items():
+        torch.testing.assert_close(b, out[False][2][n], rtol=1e-4, atol=1e-6, msg=n)
+
+
+def test_whole_training_step_captured_in_one_graph_replays_and_learns():
+    """DeviceTrainer.capture_step: the whole optimisation step as ONE hipGraph.  Replays run without host synchronisation, the
+    loss on the fixed batch goes down, capacities are not exceeded, new inputs are taken through the graph's buffers."""
+    from second_amd.models import SecondDetector, CAR_FHD
+    from second_amd.training import DeviceTrainer
+    ins = _train_inputs()
+    torch.manual_seed(0)
+    tr = DeviceTrainer(SecondDetector(CAR_FHD).cuda(), amp_dtype=torch.bfloat16)
+    replay = tr.capture_step(*ins)
+    first = replay().clone()
+    for _ in range(14):
+        last = replay(*ins)                                 # same tensors: copied into the graph's buffers first
+    torch.cuda.synchronize()
+    tr.check_overflow()
+    first, last = first.float().cpu(), last.float().cpu()
+    assert torch.isfinite(first).all() and torch.isfinite(last).all()
+    assert last[0] < first[0], (first.tolist(), last.tolist())
+    for p in tr.det.parameters():
+        assert torch.isfinite(p).all()
