@@ -485,6 +485,16 @@ int sec_second_loss_f32(const float *cls_preds, const float *box_preds, const fl
                         int n_anchor, int num_class, int num_dir_bins, const float *h_params17, float *d_cls, float *d_box,
                         float *d_dir, float *out6, void *workspace, size_t workspace_bytes, void *stream);
 
+/* torch.nn.utils.clip_grad_norm_(parameters, max_grad_norm) + the AdamW step (second/pytorch/train.py:323-325; adam + fixed weight
+ * decay, car.fhd.config:180-188) on ONE flat fp32 buffer of master weights whose flat gradient is the all-reduce bucket: two launches
+ * (fixed-order sum of squares + element-wise update).  state2 (device float[2]) = (gradient norm of this step, step count): the call
+ * advances the count itself; zero it before the first step.  workspace: sec_flat_adamw_workspace_bytes(), zeroed before the first
+ * call.  max_grad_norm <= 0: no clipping.  Same formulas and operation order as torch.optim.AdamW / clip_grad_norm_. */
+size_t sec_flat_adamw_workspace_bytes(void);
+int sec_flat_adamw_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long long n, float lr, float beta1,
+                       float beta2, float eps, float weight_decay, float max_grad_norm, float *state2, void *workspace,
+                       size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

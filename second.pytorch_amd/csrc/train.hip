@@ -336,6 +336,71 @@ __global__ __launch_bounds__(kBlock) void k_loss_final(const float *__restrict__
     }
 }
 
+
+// ---- clip_grad_norm_ + AdamW on ONE flat fp32 parameter buffer -----------------------------------------------------------------------
+// second/pytorch/train.py:323-325: torch.nn.utils.clip_grad_norm_(net.parameters(), 10.0); mixed_optimizer.step() (adam + fixed
+// weight decay, car.fhd.config:180-188).  With torch.optim.AdamW over 69 parameter tensors a captured step spends ~0.6 ms here: the
+// capturable implementation computes beta^step per PARAMETER (2 x 69 one-element pow launches) besides ~15 multi-tensor kernels.
+// The device trainer keeps all master weights as views of one flat buffer whose gradient is the all-reduce bucket, so the update is
+// two launches: (1) sum of squares of the flat gradient in fixed-order partials; the last workgroup to finish (ticket) adds them in
+// index order, stores the norm and advances the step counter; (2) the element-wise update with the clip factor
+// min(1, max_norm / (norm + 1e-6)) folded in.  Same formulas as torch: p *= 1 - lr * wd; m = b1 m + (1 - b1) g; v = b2 v + (1 - b2) g^2;
+// p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps).
+constexpr int kAdamBlocks = 512;
+__global__ __launch_bounds__(kBlock) void k_flat_sumsq(const float *__restrict__ g, long long n, float *__restrict__ part,
+                                                      unsigned *__restrict__ ticket, float *__restrict__ state /* [norm, step] */) {
+    __shared__ float red[kBlock];
+    __shared__ bool last;
+    float a = 0.0f;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) { const float v = g[i]; a += v * v; }
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = kBlock / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        part[blockIdx.x] = red[0];
+        __threadfence();
+        last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    double t = 0.0;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += kBlock) t += (double)__hip_atomic_load(&part[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __shared__ double redd[kBlock];
+    redd[threadIdx.x] = t;
+    __syncthreads();
+    for (int o = kBlock / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) redd[threadIdx.x] += redd[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        state[0] = (float)sqrt(redd[0]);
+        state[1] += 1.0f;
+        *ticket = 0u;                                   // ready for the next step (graph replays)
+    }
+}
+__global__ __launch_bounds__(kBlock) void k_flat_adamw(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
+                                                      float *__restrict__ v, long long n, float lr, float b1, float b2, float eps,
+                                                      float wd, float max_norm, const float *__restrict__ state) {
+    const float norm = state[0], step = state[1];
+    float clip = max_norm > 0.0f ? max_norm / (norm + 1e-6f) : 1.0f;
+    if (clip > 1.0f) clip = 1.0f;
+    const float bc1 = 1.0f - powf(b1, step), bc2 = 1.0f - powf(b2, step);
+    const float step_size = lr / bc1, rs2 = sqrtf(bc2);
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) {
+        const float gi = g[i] * clip;
+        float pi = p[i] * (1.0f - lr * wd);
+        const float mi = m[i] + (gi - m[i]) * (1.0f - b1);                 // lerp, as torch
+        const float vi = v[i] * b2 + gi * gi * (1.0f - b2);
+        m[i] = mi; v[i] = vi;
+        const float denom = sqrtf(vi) / rs2 + eps;
+        p[i] = pi - step_size * (mi / denom);
+    }
+}
+
 }  // namespace sec
 
 using namespace sec;
@@ -440,5 +505,25 @@ SEC_API int sec_second_loss_f32(const float *cls_preds, const float *box_preds, 
     hipLaunchKernelGGL(k_loss_main, dim3(nb, batch), dim3(kBlock), 0, st, cls_preds, box_preds, dir_preds, labels, reg_targets,
                        anchors, importance, cnt, P, d_cls, d_box, d_dir, partial);
     hipLaunchKernelGGL(k_loss_final, dim3(1), dim3(kBlock), 0, st, partial, batch * nb, P, out6);
+    return check_launch();
+}
+
+SEC_API size_t sec_flat_adamw_workspace_bytes(void) { return align_up((size_t)kAdamBlocks * sizeof(float) + 256); }
+
+SEC_API int sec_flat_adamw_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long long n, float lr, float beta1,
+                               float beta2, float eps, float weight_decay, float max_grad_norm, float *state2, void *workspace,
+                               size_t workspace_bytes, void *stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !state2 || n <= 0 || !workspace) return SEC_E_INVALID;
+    if (workspace_bytes < sec_flat_adamw_workspace_bytes()) return SEC_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float *part = (float *)workspace;
+    unsigned *ticket = (unsigned *)((char *)workspace + (size_t)kAdamBlocks * sizeof(float));      // zero before the first call
+    int blocks = div_up(n, (long long)kBlock * 4);
+    if (blocks > kAdamBlocks) blocks = kAdamBlocks;
+    hipLaunchKernelGGL(k_flat_sumsq, dim3(blocks), dim3(kBlock), 0, st, grad, n, part, ticket, state2);
+    int ub = div_up(n, (long long)kBlock * 4);
+    if (ub > 2048) ub = 2048;
+    hipLaunchKernelGGL(k_flat_adamw, dim3(ub), dim3(kBlock), 0, st, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps,
+                       weight_decay, max_grad_norm, (const float *)state2);
     return check_launch();
 }

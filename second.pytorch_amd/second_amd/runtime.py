@@ -33,7 +33,7 @@ SYMBOLS = [
     "sec_assign_targets_workspace_bytes", "sec_assign_targets_f32", "sec_assign_targets_per_class_f32",
     "sec_second_loss_workspace_bytes", "sec_second_loss_f32",
     "sec_conv2d_pack_weight_train", "sec_conv2d_wgrad_workspace_bytes", "sec_conv2d_wgrad_nhwc", "sec_bn_train_workspace_bytes", "sec_bn_relu_fwd_nhwc",
-    "sec_bn_relu_bwd_nhwc",
+    "sec_bn_relu_bwd_nhwc", "sec_flat_adamw_workspace_bytes", "sec_flat_adamw_f32",
 ]
 
 _lib = None
@@ -102,7 +102,8 @@ def lib():
                      "sec_packed_weight_bytes", "sec_nms_workspace_bytes", "sec_block_filter_workspace_bytes",
                      "sec_conv2d_packed_weight_bytes", "sec_indice_conv_bwd_workspace_bytes",
                      "sec_assign_targets_workspace_bytes", "sec_second_loss_workspace_bytes",
-                     "sec_conv2d_wgrad_workspace_bytes", "sec_bn_train_workspace_bytes", "sec_pfn_train_workspace_bytes"):
+                     "sec_conv2d_wgrad_workspace_bytes", "sec_bn_train_workspace_bytes", "sec_pfn_train_workspace_bytes",
+                     "sec_flat_adamw_workspace_bytes"):
             getattr(l, name).restype = ctypes.c_size_t
         l.sec_last_error.restype = ctypes.c_char_p
         l.sec_last_kernel_name.restype = ctypes.c_char_p
@@ -167,6 +168,8 @@ def lib():
         l.sec_bn_train_workspace_bytes.argtypes = [ci]
         l.sec_bn_relu_fwd_nhwc.argtypes = [vp, ll, ci, vp, vp, cf, cf, vp, vp, ci, vp, vp, vp, vp, sz, ci, vp, vp]
         l.sec_bn_relu_bwd_nhwc.argtypes = [vp, vp, ll, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp, sz, ci, vp, vp]
+        l.sec_flat_adamw_workspace_bytes.argtypes = []
+        l.sec_flat_adamw_f32.argtypes = [vp, vp, vp, vp, ll, cf, cf, cf, cf, cf, cf, vp, vp, sz, vp]
         _lib = l
     return _lib
 

@@ -28,6 +28,50 @@ from . import distributed as D
 from . import ops
 
 
+class FlatAdamW:
+    """clip_grad_norm_ + AdamW (train.py:323-325) on ONE flat fp32 buffer in two launches (sec_flat_adamw_f32).
+
+    The parameters become views of ``self.flat`` (same layout as the gradient bucket, whose flat buffer is the gradient), so the
+    update needs no per-parameter work: torch.optim.AdamW over the 69 tensors of a SECOND network is ~15 multi-tensor launches plus
+    -- in its capturable form -- two one-element ``pow`` launches PER PARAMETER (0.4-0.6 ms of a 4.5 ms captured step).  Same
+    formulas as torch (tests/test_gpu_train_dense.py::test_flat_adamw_matches_torch_adamw_with_clipping)."""
+
+    def __init__(self, params, grad_flat, lr, weight_decay, betas=(0.9, 0.99), eps=1e-8, max_grad_norm=10.0):
+        from . import runtime as rt
+        self.params = list(params)
+        assert all(p.dtype == torch.float32 and p.is_cuda for p in self.params), "FlatAdamW: fp32 master weights on the GPU"
+        n = sum(p.numel() for p in self.params)
+        assert grad_flat.numel() == n and grad_flat.dtype == torch.float32
+        dev = grad_flat.device
+        self.flat = torch.empty(n, dtype=torch.float32, device=dev)
+        off = 0
+        with torch.no_grad():
+            for p in self.params:
+                v = self.flat[off:off + p.numel()].view_as(p)
+                v.copy_(p)
+                p.data = v                                   # the module's parameter IS this slice from now on
+                off += p.numel()
+        self.grad = grad_flat
+        self.exp_avg, self.exp_avg_sq = torch.zeros_like(self.flat), torch.zeros_like(self.flat)
+        self.state = torch.zeros(2, dtype=torch.float32, device=dev)         # (gradient norm of the last step, step count)
+        self.ws = torch.zeros(rt.lib().sec_flat_adamw_workspace_bytes(), dtype=torch.uint8, device=dev)
+        self.lr, self.weight_decay, self.betas, self.eps, self.max_grad_norm = float(lr), float(weight_decay), betas, float(eps), float(max_grad_norm)
+
+    def step(self):
+        from . import runtime as rt
+        rt.check(rt.lib().sec_flat_adamw_f32(rt.ptr(self.flat), rt.ptr(self.grad), rt.ptr(self.exp_avg), rt.ptr(self.exp_avg_sq),
+                                             self.flat.numel(), self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
+                                             self.max_grad_norm, rt.ptr(self.state), rt.ptr(self.ws), self.ws.numel(), rt.stream()),
+                 "sec_flat_adamw_f32")
+
+    def state_dict(self):
+        return {"exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "state": self.state,
+                "hyper": {"lr": self.lr, "weight_decay": self.weight_decay, "betas": self.betas, "eps": self.eps}}
+
+    def load_state_dict(self, sd):
+        self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"]); self.state.copy_(sd["state"])
+
+
 class DeviceTrainer:
     def __init__(self, det, lr=3e-3, weight_decay=0.01, max_grad_norm=10.0, matched_threshold=None, unmatched_threshold=None,
                  loss_cfg=None, amp_dtype=None, init_loss_scale=2.0 ** 12):
@@ -57,13 +101,16 @@ class DeviceTrainer:
         D.broadcast_parameters(det, 0)
         # the reference's adam_optimizer + fixed weight decay (car.fhd.config:180-188) -> AdamW
         params = [p for p in det.parameters() if p.requires_grad]
-        # capturable: the step counters live on the device, so that a whole optimisation step can be captured in a hipGraph
-        # (capture_step); identical arithmetic to the default implementation
-        self.opt = torch.optim.AdamW(params, lr=lr, weight_decay=weight_decay, betas=(0.9, 0.99),
-                                     **({"capturable": True, "foreach": True} if params and params[0].is_cuda else {}))
+        self.bucket = D.GradBucket(det)
+        self.flat_opt = bool(params) and all(p.is_cuda and p.dtype == torch.float32 for p in params)
+        if self.flat_opt:
+            # clip + AdamW as two launches on a flat master-weight buffer (the parameters become views of it); step counter on the
+            # device, so a whole optimisation step can be captured in a hipGraph (capture_step)
+            self.opt = FlatAdamW(params, self.bucket.flat, lr, weight_decay, betas=(0.9, 0.99), max_grad_norm=self.max_grad_norm)
+        else:
+            self.opt = torch.optim.AdamW(params, lr=lr, weight_decay=weight_decay, betas=(0.9, 0.99))
         self.static = False          # static-capacity rows (device-side live counts, no host sync): set by capture_step
         self._captured = None
-        self.bucket = D.GradBucket(det)
         # fp16 features need loss scaling (5 exponent bits: head gradients are O(1 / num_pos / batch)); bf16 / fp32 do not
         self.loss_scale = float(init_loss_scale) if amp_dtype == torch.float16 else None
         self._good_steps, self.skipped_steps = 0, 0
@@ -199,8 +246,9 @@ class DeviceTrainer:
             self.bucket.zero_grad()                               # overflow on some rank: skip the step everywhere (same bucket)
             self.skipped_steps += 1
             return out6
-        torch.nn.utils.clip_grad_norm_(self.bucket.params, self.max_grad_norm)
-        self.opt.step()
+        if not self.flat_opt:
+            torch.nn.utils.clip_grad_norm_(self.bucket.params, self.max_grad_norm)
+        self.opt.step()                                           # FlatAdamW: clip + update, two launches
         self.bucket.zero_grad()                                   # fp32 p.grad are views of the bucket: one fill
         self.steps += 1
         return out6

@@ -389,3 +389,30 @@ def test_whole_training_step_captured_in_one_graph_replays_and_learns():
     assert last[0] < first[0], (first.tolist(), last.tolist())
     for p in tr.det.parameters():
         assert torch.isfinite(p).all()
+
+
+def test_flat_adamw_matches_torch_adamw_with_clipping():
+    """sec_flat_adamw_f32 (clip_grad_norm_ + AdamW on one flat buffer, two launches) against torch.nn.utils.clip_grad_norm_ +
+    torch.optim.AdamW on the same tensors for four steps: gradients large enough to be clipped in some steps and not in others."""
+    from second_amd.training import FlatAdamW
+    g = torch.Generator().manual_seed(3)
+    shapes = [(3, 3, 3, 4, 16), (16,), (64, 32, 3, 3), (7,), (128, 128)]
+    ref = [torch.nn.Parameter(torch.randn(*s, generator=g).cuda()) for s in shapes]
+    mine = [torch.nn.Parameter(p.detach().clone()) for p in ref]
+    n = sum(p.numel() for p in ref)
+    flat_grad = torch.zeros(n, device="cuda")
+    opt_ref = torch.optim.AdamW(ref, lr=3e-3, weight_decay=0.01, betas=(0.9, 0.99))
+    opt = FlatAdamW(mine, flat_grad, 3e-3, 0.01, betas=(0.9, 0.99), max_grad_norm=10.0)
+    assert all(p.data_ptr() >= opt.flat.data_ptr() and p.data_ptr() < opt.flat.data_ptr() + 4 * n for p in mine)
+    for step, scale in enumerate((0.001, 0.5, 0.01, 2.0)):
+        grads = [torch.randn(*s, generator=g).cuda() * scale for s in shapes]
+        for p, gr in zip(ref, grads):
+            p.grad = gr.clone()
+        norm_ref = torch.nn.utils.clip_grad_norm_(ref, 10.0)
+        opt_ref.step()
+        flat_grad.copy_(torch.cat([gr.reshape(-1) for gr in grads]))
+        opt.step()
+        torch.cuda.synchronize()
+        assert abs(float(opt.state[0]) - float(norm_ref)) <= 1e-5 * float(norm_ref) and float(opt.state[1]) == step + 1
+        for a, b in zip(mine, ref):
+            torch.testing.assert_close(a.detach(), b.detach(), rtol=2e-6, atol=2e-7)
