@@ -410,7 +410,7 @@ def train_bench(args, rank, local_rank, world, device):
                           "points_per_frame": int(pts.shape[0]) // bs, "launch_mode": launch,
                           "gradient_bucket_bytes": tr.bucket.numel * 4,
                           "allreduce_us": round(ar_us, 1) if world > 1 else None, "bucket_pack_unpack_us": round(ar_us, 1) if world == 1 else None,
-                          "skipped_steps_loss_scale": tr.skipped_steps if tr.loss_scale is not None else None,
+                          "skipped_steps_loss_scale": tr.skipped_steps if (tr.loss_scale is not None or tr.loss_scale_dev is not None) else None,
                           "optimizer": "AdamW (adam + fixed weight decay 0.01, car.fhd.config:180-188)",
                           "target_assignment": "per anchor range" if tr.class_ranges else "single class"},
                "roofline": None, "cpu_baseline": None, "loss_last_step": {k: round(v, 5) for k, v in losses.items()}}

@@ -487,13 +487,17 @@ int sec_second_loss_f32(const float *cls_preds, const float *box_preds, const fl
 
 /* torch.nn.utils.clip_grad_norm_(parameters, max_grad_norm) + the AdamW step (second/pytorch/train.py:323-325; adam + fixed weight
  * decay, car.fhd.config:180-188) on ONE flat fp32 buffer of master weights whose flat gradient is the all-reduce bucket: two launches
- * (fixed-order sum of squares + element-wise update).  state2 (device float[2]) = (gradient norm of this step, step count): the call
- * advances the count itself; zero it before the first step.  workspace: sec_flat_adamw_workspace_bytes(), zeroed before the first
- * call.  max_grad_norm <= 0: no clipping.  Same formulas and operation order as torch.optim.AdamW / clip_grad_norm_. */
+ * (fixed-order sum of squares + element-wise update).  state4 (device float[4]) = (gradient norm of this step, step count, 1 if
+ * this step was skipped, the loss scale its gradients carried): the call advances the count itself; zero it before the first step.  loss_scale4 (device float[4] or
+ * NULL) = (loss scale, clean steps in a row, growth interval, skipped steps): dynamic loss scaling ON THE DEVICE for fp16 features
+ * (train.py:209-216,318-322 does it through apex amp on the host) -- the gradients carry the scale, a non-finite norm halves the
+ * scale and skips the update, `growth interval` clean steps double it; nothing is read back.  workspace:
+ * sec_flat_adamw_workspace_bytes(), zeroed before the first call.  max_grad_norm <= 0: no clipping.  Same formulas and operation
+ * order as torch.optim.AdamW / clip_grad_norm_. */
 size_t sec_flat_adamw_workspace_bytes(void);
 int sec_flat_adamw_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long long n, float lr, float beta1,
-                       float beta2, float eps, float weight_decay, float max_grad_norm, float *state2, void *workspace,
-                       size_t workspace_bytes, void *stream);
+                       float beta2, float eps, float weight_decay, float max_grad_norm, float *state4, float *loss_scale4,
+                       void *workspace, size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

@@ -347,8 +347,13 @@ __global__ __launch_bounds__(kBlock) void k_loss_final(const float *__restrict__
 // min(1, max_norm / (norm + 1e-6)) folded in.  Same formulas as torch: p *= 1 - lr * wd; m = b1 m + (1 - b1) g; v = b2 v + (1 - b2) g^2;
 // p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps).
 constexpr int kAdamBlocks = 512;
+// Dynamic loss scaling on the device (fp16 features; the reference trains mixed precision through apex amp, train.py:209-216,
+// 318-322): scale4 (or NULL) = (loss scale, clean steps in a row, growth interval, skipped steps).  The gradients in `g` carry the
+// scale; the norm is taken of g / scale.  A non-finite norm (every rank sees the same reduced bucket, so every rank decides alike)
+// halves the scale and makes the update launch a no-op; `growth interval` clean steps in a row double it.  No host read.
 __global__ __launch_bounds__(kBlock) void k_flat_sumsq(const float *__restrict__ g, long long n, float *__restrict__ part,
-                                                      unsigned *__restrict__ ticket, float *__restrict__ state /* [norm, step] */) {
+                                                      unsigned *__restrict__ ticket, float *__restrict__ state /* [norm, step, skip, scale used] */,
+                                                      float *__restrict__ scale4) {
     __shared__ float red[kBlock];
     __shared__ bool last;
     float a = 0.0f;
@@ -377,21 +382,33 @@ __global__ __launch_bounds__(kBlock) void k_flat_sumsq(const float *__restrict__
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        state[0] = (float)sqrt(redd[0]);
-        state[1] += 1.0f;
+        float norm = (float)sqrt(redd[0]);
+        bool skip = false;
+        state[3] = scale4 ? scale4[0] : 1.0f;          // the scale these gradients were produced with (the update divides by it)
+        if (scale4) {
+            norm /= scale4[0];
+            skip = !(norm == norm) || norm > 3.0e38f;     // NaN or Inf somewhere in the reduced bucket
+            if (skip) { scale4[0] = fmaxf(scale4[0] * 0.5f, 1.0f); scale4[1] = 0.0f; scale4[3] += 1.0f; }
+            else if ((scale4[1] += 1.0f) >= scale4[2]) { scale4[0] = fminf(scale4[0] * 2.0f, 16777216.0f); scale4[1] = 0.0f; }
+        }
+        state[0] = norm;
+        if (!skip) state[1] += 1.0f;
+        state[2] = skip ? 1.0f : 0.0f;
         *ticket = 0u;                                   // ready for the next step (graph replays)
     }
 }
 __global__ __launch_bounds__(kBlock) void k_flat_adamw(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
                                                       float *__restrict__ v, long long n, float lr, float b1, float b2, float eps,
                                                       float wd, float max_norm, const float *__restrict__ state) {
+    if (state[2] != 0.0f) return;                        // overflow: the step is skipped on every rank
+    const float unscale = 1.0f / state[3];
     const float norm = state[0], step = state[1];
     float clip = max_norm > 0.0f ? max_norm / (norm + 1e-6f) : 1.0f;
     if (clip > 1.0f) clip = 1.0f;
     const float bc1 = 1.0f - powf(b1, step), bc2 = 1.0f - powf(b2, step);
     const float step_size = lr / bc1, rs2 = sqrtf(bc2);
     for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long long)gridDim.x * kBlock) {
-        const float gi = g[i] * clip;
+        const float gi = g[i] * unscale * clip;
         float pi = p[i] * (1.0f - lr * wd);
         const float mi = m[i] + (gi - m[i]) * (1.0f - b1);                 // lerp, as torch
         const float vi = v[i] * b2 + gi * gi * (1.0f - b2);
@@ -511,19 +528,19 @@ SEC_API int sec_second_loss_f32(const float *cls_preds, const float *box_preds, 
 SEC_API size_t sec_flat_adamw_workspace_bytes(void) { return align_up((size_t)kAdamBlocks * sizeof(float) + 256); }
 
 SEC_API int sec_flat_adamw_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long long n, float lr, float beta1,
-                               float beta2, float eps, float weight_decay, float max_grad_norm, float *state2, void *workspace,
-                               size_t workspace_bytes, void *stream) {
-    if (!param || !grad || !exp_avg || !exp_avg_sq || !state2 || n <= 0 || !workspace) return SEC_E_INVALID;
+                               float beta2, float eps, float weight_decay, float max_grad_norm, float *state4, float *loss_scale4,
+                               void *workspace, size_t workspace_bytes, void *stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !state4 || n <= 0 || !workspace) return SEC_E_INVALID;
     if (workspace_bytes < sec_flat_adamw_workspace_bytes()) return SEC_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     float *part = (float *)workspace;
     unsigned *ticket = (unsigned *)((char *)workspace + (size_t)kAdamBlocks * sizeof(float));      // zero before the first call
     int blocks = div_up(n, (long long)kBlock * 4);
     if (blocks > kAdamBlocks) blocks = kAdamBlocks;
-    hipLaunchKernelGGL(k_flat_sumsq, dim3(blocks), dim3(kBlock), 0, st, grad, n, part, ticket, state2);
+    hipLaunchKernelGGL(k_flat_sumsq, dim3(blocks), dim3(kBlock), 0, st, grad, n, part, ticket, state4, loss_scale4);
     int ub = div_up(n, (long long)kBlock * 4);
     if (ub > 2048) ub = 2048;
     hipLaunchKernelGGL(k_flat_adamw, dim3(ub), dim3(kBlock), 0, st, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps,
-                       weight_decay, max_grad_norm, (const float *)state2);
+                       weight_decay, max_grad_norm, (const float *)state4);
     return check_launch();
 }

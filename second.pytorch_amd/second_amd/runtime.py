@@ -169,7 +169,7 @@ def lib():
         l.sec_bn_relu_fwd_nhwc.argtypes = [vp, ll, ci, vp, vp, cf, cf, vp, vp, ci, vp, vp, vp, vp, sz, ci, vp, vp]
         l.sec_bn_relu_bwd_nhwc.argtypes = [vp, vp, ll, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp, sz, ci, vp, vp]
         l.sec_flat_adamw_workspace_bytes.argtypes = []
-        l.sec_flat_adamw_f32.argtypes = [vp, vp, vp, vp, ll, cf, cf, cf, cf, cf, cf, vp, vp, sz, vp]
+        l.sec_flat_adamw_f32.argtypes = [vp, vp, vp, vp, ll, cf, cf, cf, cf, cf, cf, vp, vp, vp, sz, vp]
         _lib = l
     return _lib
 

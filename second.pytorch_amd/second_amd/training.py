@@ -53,15 +53,24 @@ class FlatAdamW:
                 off += p.numel()
         self.grad = grad_flat
         self.exp_avg, self.exp_avg_sq = torch.zeros_like(self.flat), torch.zeros_like(self.flat)
-        self.state = torch.zeros(2, dtype=torch.float32, device=dev)         # (gradient norm of the last step, step count)
+        self.state = torch.zeros(4, dtype=torch.float32, device=dev)         # (gradient norm, step count, skipped flag, loss scale used)
+        self.loss_scale = None                                               # device float[4] for fp16: see enable_loss_scaling
         self.ws = torch.zeros(rt.lib().sec_flat_adamw_workspace_bytes(), dtype=torch.uint8, device=dev)
         self.lr, self.weight_decay, self.betas, self.eps, self.max_grad_norm = float(lr), float(weight_decay), betas, float(eps), float(max_grad_norm)
+
+    def enable_loss_scaling(self, init_scale=2.0 ** 12, growth_interval=200):
+        """Dynamic loss scaling kept on the device (fp16 features): ``self.loss_scale`` = (scale, clean steps in a row, growth
+        interval, skipped steps).  Multiply the loss by ``self.loss_scale[0]`` before backward(); step() unscales, skips the update
+        and halves the scale on a non-finite gradient norm, doubles it after ``growth_interval`` clean steps -- no host read."""
+        self.loss_scale = torch.tensor([float(init_scale), 0.0, float(growth_interval), 0.0], dtype=torch.float32, device=self.flat.device)
+        return self.loss_scale
 
     def step(self):
         from . import runtime as rt
         rt.check(rt.lib().sec_flat_adamw_f32(rt.ptr(self.flat), rt.ptr(self.grad), rt.ptr(self.exp_avg), rt.ptr(self.exp_avg_sq),
                                              self.flat.numel(), self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
-                                             self.max_grad_norm, rt.ptr(self.state), rt.ptr(self.ws), self.ws.numel(), rt.stream()),
+                                             self.max_grad_norm, rt.ptr(self.state), rt.ptr(self.loss_scale), rt.ptr(self.ws),
+                                             self.ws.numel(), rt.stream()),
                  "sec_flat_adamw_f32")
 
     def state_dict(self):
@@ -112,8 +121,11 @@ class DeviceTrainer:
         self.static = False          # static-capacity rows (device-side live counts, no host sync): set by capture_step
         self._captured = None
         # fp16 features need loss scaling (5 exponent bits: head gradients are O(1 / num_pos / batch)); bf16 / fp32 do not
-        self.loss_scale = float(init_loss_scale) if amp_dtype == torch.float16 else None
-        self._good_steps, self.skipped_steps = 0, 0
+        # flat optimizer: the scale lives on the device (FlatAdamW.enable_loss_scaling: no host read, the step stays capturable);
+        # otherwise a host float and one overflow-flag read per step (_unscale_and_check)
+        self.loss_scale_dev = self.opt.enable_loss_scaling(init_loss_scale) if (amp_dtype == torch.float16 and self.flat_opt) else None
+        self.loss_scale = float(init_loss_scale) if (amp_dtype == torch.float16 and not self.flat_opt) else None
+        self._good_steps, self._skipped_host = 0, 0
         self._graphed_rpn = None
         self.steps = 0
         self.last = {}
@@ -233,18 +245,20 @@ class DeviceTrainer:
 
     def step(self, points, point_offsets, gt_boxes, gt_offsets, gt_classes=None):
         """One optimisation step on this rank's shard; returns the device tensor of the six loss scalars (no host sync,
-        except with fp16 features: dynamic loss scaling reads one overflow flag per step)."""
+        except with fp16 features on a non-flat optimizer: dynamic loss scaling then reads one overflow flag per step)."""
         with ops.deferred_bn_counters():
             loss, out6, _ = self.forward_loss(points, point_offsets, gt_boxes, gt_offsets, gt_classes)
-        if self.loss_scale is None:
+        if self.loss_scale_dev is not None:
+            (loss * self.loss_scale_dev[0]).backward()            # fp16 gradients: scaled (device scalar) so that small ones do not flush to zero
+        elif self.loss_scale is None:
             loss.backward()
         else:
-            (loss * self.loss_scale).backward()                   # fp16 gradients: scaled so that small ones do not flush to zero
+            (loss * self.loss_scale).backward()
         self.bucket.allreduce(average=True)                       # one flat bucket, zeros for parameters without a gradient
         self.last = {"out6": out6}
         if self.loss_scale is not None and not self._unscale_and_check():
             self.bucket.zero_grad()                               # overflow on some rank: skip the step everywhere (same bucket)
-            self.skipped_steps += 1
+            self._skipped_host += 1
             return out6
         if not self.flat_opt:
             torch.nn.utils.clip_grad_norm_(self.bucket.params, self.max_grad_norm)
@@ -258,13 +272,13 @@ class DeviceTrainer:
         hipGraph (second/pytorch/train.py:306-330 is ~520 dispatches here, host bound when launched one by one).  What makes it
         capturable: static-capacity rows through the sparse stack (row counts stay on the device; every strided layer gets
         ``margin`` x the rows this batch produced, rounded up to 256), BatchNorm statistics / dense scatter over the LIVE rows
-        only (``rows_dev`` / ``num_dev`` arguments of the kernels), an optimizer whose step counters live on the device.  16-bit
-        features without dynamic loss scaling only (bf16; fp16 reads an overflow flag on the host every step).
+        only (``rows_dev`` / ``num_dev`` arguments of the kernels), an optimizer whose step counter -- and, for fp16 features, whose
+        dynamic loss scale -- live on the device (FlatAdamW).
         Returns ``replay(points=None, point_offsets=None, gt_boxes=None, gt_offsets=None, gt_classes=None) -> out6``: new inputs
         (same shapes or fewer rows) are copied into the graph's buffers first.  Raises what the capture raises: callers fall back
         to :meth:`step`.  Call :meth:`check_overflow` now and then (one host sync)."""
         import spconv
-        assert self.amp_dtype is not None and self.loss_scale is None and not self.det.pillars, "capture_step: bf16 sparse-middle configs"
+        assert self.amp_dtype is not None and self.loss_scale is None and not self.det.pillars, "capture_step: 16-bit sparse-middle configs on the flat optimizer"
         ins = [points, point_offsets, gt_boxes, gt_offsets, gt_classes]
         self.static = False
         self.step(*ins)                                   # one dynamic step: records every strided layer's output rows
@@ -302,6 +316,13 @@ class DeviceTrainer:
             raw = int(num[1].item())
             if raw > cap:
                 raise RuntimeError(f"static-capacity overflow in training: a strided sparse conv produced {raw} rows, capacity {cap}")
+
+    @property
+    def skipped_steps(self):
+        """Steps skipped by the dynamic loss scaling (fp16).  Device-side scaling: one host read, here, not in the step."""
+        if self.loss_scale_dev is not None:
+            return int(self.loss_scale_dev[3].item())
+        return self._skipped_host
 
     def _unscale_and_check(self):
         """Dynamic loss scaling for fp16 features (the reference trains mixed precision through apex amp with

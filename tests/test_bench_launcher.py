@@ -107,7 +107,7 @@ def test_loss_scale_state_machine():
     from second_amd.training import DeviceTrainer
     net = torch.nn.Linear(2, 2)
     tr = DeviceTrainer.__new__(DeviceTrainer)
-    tr.bucket, tr.loss_scale, tr._good_steps, tr.skipped_steps = D.GradBucket(net), 1024.0, 0, 0
+    tr.bucket, tr.loss_scale, tr.loss_scale_dev, tr._good_steps, tr._skipped_host = D.GradBucket(net), 1024.0, None, 0, 0
     tr.bucket.flat.fill_(2048.0)
     assert tr._unscale_and_check() and float(tr.bucket.flat[0]) == 2.0 and tr.loss_scale == 1024.0
     tr.bucket.flat[1] = float("inf")

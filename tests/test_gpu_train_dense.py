@@ -416,3 +416,41 @@ def test_flat_adamw_matches_torch_adamw_with_clipping():
         assert abs(float(opt.state[0]) - float(norm_ref)) <= 1e-5 * float(norm_ref) and float(opt.state[1]) == step + 1
         for a, b in zip(mine, ref):
             torch.testing.assert_close(a.detach(), b.detach(), rtol=2e-6, atol=2e-7)
+
+
+def test_flat_adamw_device_side_loss_scaling_state_machine():
+    """Dynamic loss scaling without a host read (sec_flat_adamw_f32's loss_scale4): scaled gradients are unscaled inside the update
+    (same parameters as the unscaled torch step), an Inf in the bucket skips the update and halves the scale, `growth interval`
+    clean steps double it; the step counter only counts applied steps."""
+    from second_amd.training import FlatAdamW
+    g = torch.Generator().manual_seed(5)
+    ref = [torch.nn.Parameter(torch.randn(300, generator=g).cuda())]
+    mine = [torch.nn.Parameter(ref[0].detach().clone())]
+    flat_grad = torch.zeros(300, device="cuda")
+    opt_ref = torch.optim.AdamW(ref, lr=3e-3, weight_decay=0.01, betas=(0.9, 0.99))
+    opt = FlatAdamW(mine, flat_grad, 3e-3, 0.01, betas=(0.9, 0.99), max_grad_norm=10.0)
+    ls = opt.enable_loss_scaling(1024.0, growth_interval=3)
+    grad = torch.randn(300, generator=g).cuda() * 0.1
+    # 1. a clean step: gradients arrive multiplied by the scale
+    ref[0].grad = grad.clone()
+    torch.nn.utils.clip_grad_norm_(ref, 10.0)
+    opt_ref.step()
+    flat_grad.copy_(grad * 1024.0)
+    opt.step()
+    torch.testing.assert_close(mine[0].detach(), ref[0].detach(), rtol=2e-6, atol=2e-7)
+    assert ls.tolist() == [1024.0, 1.0, 3.0, 0.0] and opt.state[1].item() == 1.0
+    # 2. overflow: nothing moves, the scale halves, the step is not counted
+    before = mine[0].detach().clone()
+    flat_grad[7] = float("inf")
+    opt.step()
+    assert torch.equal(mine[0].detach(), before) and ls.tolist() == [512.0, 0.0, 3.0, 1.0]
+    assert opt.state[1].item() == 1.0 and opt.state[2].item() == 1.0
+    # 3. three clean steps double the scale
+    for k in range(3):
+        ref[0].grad = grad.clone()
+        torch.nn.utils.clip_grad_norm_(ref, 10.0)
+        opt_ref.step()
+        flat_grad.copy_(grad * float(ls[0].item()))
+        opt.step()
+    torch.testing.assert_close(mine[0].detach(), ref[0].detach(), rtol=5e-6, atol=5e-7)
+    assert ls.tolist() == [1024.0, 0.0, 3.0, 1.0] and opt.state[1].item() == 4.0
