@@ -31,7 +31,8 @@ def build(force=False, verbose=True, tag=None, extra_flags=None):
     tag = tag or os.environ.get("SEC_BUILD_TAG", "")
     out_path = OUT.replace(".so", f"_{tag}.so") if tag else OUT
     os.makedirs(os.path.dirname(out_path), exist_ok=True)
-    hdrs = HDR + [os.path.join(HERE, "csrc", "experiments", f) for f in os.listdir(os.path.join(HERE, "csrc", "experiments"))]
+    exp_dir = os.path.join(HERE, "..", "tools", "kernel_experiments")      # A/B kernels of -DSEC_CONV_EXPERIMENTS builds: outside the product tree
+    hdrs = HDR + ([os.path.join(exp_dir, f) for f in os.listdir(exp_dir)] if os.path.isdir(exp_dir) else [])
     if not force and os.path.exists(out_path):
         newest = max(os.path.getmtime(p) for p in SRC + hdrs)
         if os.path.getmtime(out_path) >= newest:

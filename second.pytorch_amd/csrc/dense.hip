@@ -309,7 +309,7 @@ template <int CH, int HW_, bool COLKEY> __device__ __forceinline__ int halo_key(
 }
 
 #ifdef SEC_CONV2D_EXPERIMENTS   // superseded 3x3 kernels (register-staged implicit GEMM, LDS weight slabs / rings): A/B builds only
-#include "experiments/dense_conv2d_ab.inc"
+#include "../../tools/kernel_experiments/dense_conv2d_ab.inc"
 #endif
 
 // ---- halo kernel with register-resident weights ----------------------------------------------------------------
@@ -814,24 +814,14 @@ template <typename T, int CIN, int TH, int ROLL = 0, bool GATHER = false>
 static int launch_conv2d_halo_reg(const void *x, const void *wpk, const float *bias, void *y, const Conv2dParams &p, hipStream_t st,
                                   const int *site_map = nullptr, unsigned feat_bytes = 0) {
     constexpr size_t lds_tile = (size_t)(TH + 2) * 18 * (CIN / 8) * 16;
-    // SEC_CONV2D_LDS_PAD (bytes, A/B runs): unused dynamic LDS that lowers the workgroups per CU (46 KB tile: 3 per CU; + 12 KB: 2),
-    // leaving registers and LDS for the kernels of the other steps in flight
-    static long lds_pad = -1;
-    if (lds_pad < 0) { const char *e = getenv("SEC_CONV2D_LDS_PAD"); lds_pad = e ? atol(e) : 0; }
+    // (padding the dynamic LDS to hold 2 instead of 3 workgroups per CU was measured in round 3: slower in every combination)
+    const long lds_pad = 0;
     const size_t lds = lds_tile + (size_t)lds_pad;
     static bool configured = false;
     auto fn = k_conv2d_halo_reg<T, CIN, TH, ROLL, GATHER>;
     if (!configured) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         configured = true;
-        if (getenv("SEC_DEBUG_OCCUPANCY")) {
-            int nb = -1;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(fn), 256, lds);
-            hipFuncAttributes fa;
-            (void)hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(fn));
-            fprintf(stderr, "[sec] k_conv2d_halo_reg: occupancy API %d blocks/CU, lds %zu, regs %d, static lds %zu, scratch %zu\n", nb, lds,
-                    fa.numRegs, fa.sharedSizeBytes, fa.localSizeBytes);
-        }
     }
     const int ty = div_up(p.h, TH), tx = div_up(p.w, 16);
     const int per_xcd = div_up(p.batch * ty * tx, 8);
@@ -1057,7 +1047,7 @@ constexpr bool kConv2dExperiments = false;   // default build: halo_reg (3x3 s1)
 #endif
 static int conv2d_variant() {
     static int v = -1;
-    if (v < 0) { const char *e = getenv("SEC_CONV2D_VARIANT"); v = e ? atoi(e) : 13; }  // 0 register staged, 1 LDS-DMA implicit GEMM, 2/3/4 halo tile 16x16 / 8x16 / 8x16 with 8 waves
+    if (v < 0) v = 13;  // 0 register staged, 1 LDS-DMA implicit GEMM, 2/3/4 halo tile 16x16 / 8x16 / 8x16 with 8 waves
     return v;
 }
 
@@ -1110,9 +1100,9 @@ static int launch_conv2d(const void *x, const void *wpk, const float *bias, void
     if (conv2d_variant() >= 1 || !kConv2dExperiments) {
         const int gx = (div_up(p.m, 128) + 7) / 8 * 8;   // multiple of 8 for the XCD-aware tile order
         // small images (the 50 x 50 third block of the PointPillars RPN: 80 pixel tiles x 2 cout tiles = 160 workgroups for 256 CUs):
-        // 64-wide cout tiles double the workgroups; the input tile is re-read from L2.  SEC_CONV2D_SMALL_SPLIT=0: always 128.
+        // 64-wide cout tiles double the workgroups; the input tile is re-read from L2.  (small_split = 0: always 128.
         static int small_split = -1;
-        if (small_split < 0) { const char *e = getenv("SEC_CONV2D_SMALL_SPLIT"); small_split = e ? atoi(e) : 1; }
+        if (small_split < 0) small_split = 1;
         if (p.cout % 128 == 0 && !(small_split && (long long)gx * (p.cout / 128) < 384))
             hipLaunchKernelGGL((k_conv2d_nhwc_dma<T, 128>), dim3(gx, p.cout / 128), block, 0, st, (const T *)x,
                                (const T *)wpk, bias, (T *)y, p);
@@ -1164,7 +1154,7 @@ SEC_API int sec_conv2d_nhwc(const void *x, int batch, int h, int w, int cin, con
     p.batch = batch; p.h = h; p.w = w; p.cin = cin; p.cout = cout; p.ksize = ksize; p.stride = stride; p.pad = pad;
     p.relu = relu & 1;
     p.zskip = (relu >> 1) & 1;
-    { static int stg = -1; if (stg < 0) { const char *e = getenv("SEC_CONV2D_STAGGER"); stg = e ? atoi(e) : 0; } p.stagger = stg; }
+    p.stagger = 0;
     p.ho = (h + 2 * pad - ksize) / stride + 1;
     p.wo = (w + 2 * pad - ksize) / stride + 1;
     if (p.ho <= 0 || p.wo <= 0) return SEC_E_INVALID;

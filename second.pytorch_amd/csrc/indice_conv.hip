@@ -241,11 +241,7 @@ __device__ long long *g_timeline = nullptr;
 #define SEC_TL_STAMP(x) do {} while (0)
 #endif
 
-static int conv_swizzle() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("SEC_CONV_XCD"); v = e ? atoi(e) : 1; }
-    return v;
-}
+static int conv_swizzle() { return 1; }      // XCD-aware tile order (round-1 A/B settled: on)
   // profiling aid (tools/conv_microbench.py --timeline); null in production
 
 #ifndef SEC_SK_MIN_WAVES
@@ -456,14 +452,14 @@ __global__ __launch_bounds__(kBlock) void k_conv_c4(const T *__restrict__ feat, 
 }
 
 #ifdef SEC_CONV_EXPERIMENTS
-#include "experiments/indice_conv_experiments.inc"
+#include "../../tools/kernel_experiments/indice_conv_experiments.inc"
 #endif
 
 
 
 // ------------------------------------------------------------------------------------------------------------------
 // Row-split kernels: shared configuration and epilogue.  (The first form, with LDS-staged operands -- SEC_CONV_VARIANT=9 -- now lives in
-// experiments/indice_conv_rows_ab.inc; its design notes follow because k_conv_rows_buf keeps the work split.)
+// tools/kernel_experiments/indice_conv_rows_ab.inc; its design notes follow because k_conv_rows_buf keeps the work split.)
 // The split-K kernel above moves 5x more weight bytes than feature bytes through the vector L1 (every 32-row tile
 // re-fetches all kvol weight blocks: 380 MB of B against 76 MB of gathered A for the 64->64 SubM layer) and gathers
 // rows as 32-byte fragments of 32 different cache lines per instruction.  Here a workgroup owns 128 output rows
@@ -571,7 +567,7 @@ __device__ __forceinline__ void rows_stage_affine(float *aff, const float *__res
 #endif
 
 #ifdef SEC_CONV_EXPERIMENTS   // the LDS-DMA and register-direct row-split forms (SEC_CONV_VARIANT 9-15): measured, superseded
-#include "experiments/indice_conv_rows_ab.inc"
+#include "../../tools/kernel_experiments/indice_conv_rows_ab.inc"
 #endif
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -932,7 +928,7 @@ static void launch_rows_buf(const void *feat, long long n_feat, const void *pack
 }
 
 #ifdef SEC_CONV_EXPERIMENTS   // round-3 A/B forms: two row tiles per wave (k_conv_rows_m2), input planes in LDS windows (k_conv_rows_lds)
-#include "experiments/indice_conv_rows_r03.inc"
+#include "../../tools/kernel_experiments/indice_conv_rows_r03.inc"
 #endif
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1010,45 +1006,28 @@ __global__ __launch_bounds__(kBlock) void k_conv_c4_mfma(const T *__restrict__ f
 static int g_variant_override = -1;     // sec_indice_conv_set_variant (A/B runs and the parity tests of every shipped kernel)
 static int conv_variant() {
     if (g_variant_override >= 0) return g_variant_override;
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("SEC_CONV_VARIANT");
-        v = e ? atoi(e) : 1;  // 1 = automatic choice; 0 = one wave per 32-row tile; 8 / 9 / 10.. force one kernel family
-    }
-    return v;
+    return 1;  // 1 = automatic choice; 0 = one wave per 32-row tile; 8 / 9 / 10.. force one kernel family (sec_indice_conv_set_variant)
 }
 
 // kernel ids reported by sec_indice_conv_fwd_plan
 enum { PLAN_GENERIC = 0, PLAN_TILED = 1, PLAN_C4 = 2, PLAN_MFMA_WAVE = 3, PLAN_MFMA_SK = 4, PLAN_MFMA_SKS = 5, PLAN_ROWS = 6,
        PLAN_ROWS_COMPACT = 7, PLAN_ROWS_TOUCH = 8, PLAN_ROWS_COMPACT_TOUCH = 9, PLAN_ROWS_REG = 10, PLAN_ROWS_BUF = 11, PLAN_C4_MFMA = 12, PLAN_ROWS_M2 = 13, PLAN_ROWS_LDS = 14, PLAN_EXPERIMENT = 99 };
 
-// Row count from which the buffer-load row-split kernel replaces split-K in the automatic choice (SEC_CONV_ROWS_MIN; the
+// Row count from which the buffer-load row-split kernel replaces split-K in the automatic choice (the
 // row-split chain of 27 offsets needs enough workgroups to fill the chip, split-K has a 4x shorter chain per wave)
 static int rows_min() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("SEC_CONV_ROWS_MIN"); v = e ? atoi(e) : 40000; }   // car.fhd batch 8: layers 1-8 (>= 56k rows) gain 25-30 %, the 23k-row layers lose
-    return v;
+    return 40000;   // car.fhd batch 8: layers 1-8 (>= 56k rows) gain 25-30 %, the 23k-row layers lose
 }
 constexpr int kRowsMinSmall = 8192;
 // A/B switch of the 64 -> 64 row-split kernel: 0 = default (small footprint + one barrier per three offsets, 142 VGPRs), 1 = the 194-VGPR
 // form (prefetch distance 4, double-buffered B fragments, a barrier per offset), 3 = small footprint with a barrier per offset (134 VGPRs),
 // 4 = the 128-row workgroups of the mid-size layers with a barrier per offset (198 VGPRs)
 static int rows_footprint() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("SEC_CONV_FOOTPRINT"); v = e ? atoi(e) : 0; }
-    return v;
+    return 0;       // rounds 2-3 A/B settled: form 0 (numbers in DESIGN_APPENDIX.md)
 }
-// SEC_CONV_M2 = 1: the automatic choice takes the two-tiles-per-wave kernel (k_conv_rows_m2) for the 64 -> 64 layers from rows_min() rows
-static int m2_auto() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("SEC_CONV_M2"); v = e ? atoi(e) : 0; }
-    return v;
-}
-static bool rows_balance() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("SEC_CONV_BAL"); v = e ? atoi(e) : 1; }
-    return v != 0;
-}
+// 1: the automatic choice would take the two-tiles-per-wave kernel (k_conv_rows_m2, experiment builds) for the 64 -> 64 layers: measured slower
+static int m2_auto() { return 0; }
+static bool rows_balance() { return true; }   // rows per wave chosen on the device so that a launch fills every CU once (round 3: kept)
 static bool buf_shape(int cin, int cout, int kvol) {
     if (kvol == 3) return cin == 64 && cout == 64;
     if (kvol != 27) return false;

@@ -603,9 +603,9 @@ SEC_API int sec_voxel_block_filter_f32(const float *voxels, const int *coors, co
     if (rows > 0) {
         hipLaunchKernelGGL(k_bf_minmax, dim3(div_up((long long)rows * max_points, kBlock)), dim3(kBlock), 0, st, voxels,
                            coors, num_points, voxel_offsets, p, w.mins, w.maxs);
-        // one wave per voxel (SEC_BLOCK_FILTER_WAVE=0: one thread per voxel, the round-2 form)
+        // one wave per voxel (wave_form 0: one thread per voxel, the round-2 form)
         static int wave_form = -1;
-        if (wave_form < 0) { const char *e = getenv("SEC_BLOCK_FILTER_WAVE"); wave_form = e ? atoi(e) : 1; }
+        if (wave_form < 0) wave_form = 1;
         if (wave_form)
             hipLaunchKernelGGL(k_bf_mask_wave, dim3(div_up(rows, kBlock / 64)), dim3(kBlock), 0, st, coors, voxel_offsets, p, w.mins,
                                w.maxs, rows, w.keep);

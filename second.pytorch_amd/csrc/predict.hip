@@ -765,8 +765,8 @@ SEC_API int sec_predict_select(const void *cls, const int64_t *h_cls_strides5, i
     const long long nfr = (long long)anchors_per_loc * h * w;
     // 16-bit heads (bf16 / fp16): register-resident select on 16-bit keys
     static int use_thr = -1, chunked = -1;
-    if (use_thr < 0) { const char *e = getenv("SEC_SELECT_THRESHOLD_SHORTCUT"); use_thr = e ? atoi(e) : 1; }
-    if (chunked < 0) { const char *e = getenv("SEC_SELECT_CHUNKS"); chunked = e ? atoi(e) : 1; }
+    if (use_thr < 0) use_thr = 1;
+    if (chunked < 0) chunked = 1;
     const bool h16 = dtype == SEC_BF16 || dtype == SEC_F16;
     const unsigned thr16 = (use_thr && h16) ? conservative_thr16(score_thr, dtype) : 0u;
     const long long reg_cap = (long long)kSelThreads * 72;           // keys one workgroup of k_predict_select_reg holds

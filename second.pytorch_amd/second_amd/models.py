@@ -160,7 +160,7 @@ class PFNLayer(nn.Module):
 class PillarFeatureNet(nn.Module):
     """One-layer PillarFeatureNet (pointpillars.py:150-237); keys pfn_layers.0.{linear,norm}.  Inference on the
     GPU runs the fused sec_pfn_fwd kernel, training on the GPU sec_pfn_train_fwd / _bwd (ops.PFNTrainFunction: batch statistics,
-    backward through the argmax; SEC_PFN_TRAIN_BACKEND=torch selects the formulation below); the torch formulation serves CPU
+    backward through the argmax; train_backend = "torch" selects the formulation below); the torch formulation serves CPU
     tests and as the autograd reference of the training kernels."""
 
     def __init__(self, num_input_features=4, num_filters=(64,), voxel_size=(0.2, 0.2, 4), pc_range=(0, -40, -3, 70.4, 40, 1)):
@@ -169,6 +169,8 @@ class PillarFeatureNet(nn.Module):
         self.pfn_layers = nn.ModuleList([PFNLayer(num_input_features + 5, num_filters[0])])
         self.vx, self.vy = voxel_size[0], voxel_size[1]
         self.x_offset, self.y_offset = self.vx / 2 + pc_range[0], self.vy / 2 + pc_range[1]
+
+    train_backend = "hip"       # "torch": the reference's materialised [P, T, C] formulation in training (A/B, tests)
 
     def folded(self):
         l = self.pfn_layers[0]
@@ -191,7 +193,7 @@ class PillarFeatureNet(nn.Module):
                                    self.vy, self.x_offset, self.y_offset, out_dtype=out_dtype, num_dev=num_dev)
         bn = l.norm
         if (features.is_cuda and self.training and bn.training and bn.track_running_stats and bn.affine and l.linear.bias is None
-                and os.environ.get("SEC_PFN_TRAIN_BACKEND", "hip") == "hip" and ops.pfn_train_supported(features, bn.num_features)
+                and self.train_backend == "hip" and ops.pfn_train_supported(features, bn.num_features)
                 and features.shape[0] > 0):
             # training on the device: sec_pfn_train_fwd / _bwd (batch statistics, argmax backward), no [P, T, C] tensor
             mom = bn.momentum if bn.momentum is not None else 0.1
@@ -263,12 +265,6 @@ class SpMiddleFHD(nn.Module):
             add(sub(64, 64, "subm3"), 64)
         add(down(64, 64, (3, 1, 1), (2, 1, 1), 0), 64)
         self.middle_conv = spconv.SparseSequential(*layers)
-        import os
-        # rulebooks of all layers built ahead on side streams (graph branches): 1 = one side stream, 2 = strided chain and SubM
-        # builds on two streams.  Shortens one step's latency, costs throughput with several steps in flight
-        self.overlap_rulebooks = os.environ.get("SEC_OVERLAP_RULEBOOKS", "0") in ("1", "2")
-        self.overlap_rulebooks_split = os.environ.get("SEC_OVERLAP_RULEBOOKS", "0") == "2"
-        self._side_stream = None
         self.fused_chain = True       # static inference: all eight rulebooks from one fused build (SparseSequential.plan_chain)
 
     def forward(self, voxel_features, coors, batch_size, channels_last=False, num_active_dev=None, site_table=None, bev_sparse=False):
@@ -279,26 +275,10 @@ class SpMiddleFHD(nn.Module):
                                     num_active_dev=num_active_dev)
         if site_table is not None and x.indices.data_ptr() == coors.data_ptr():
             x.site_table = ((x.indices.data_ptr(), x.indices.shape[0]), site_table)
-        side = None
-        if num_active_dev is not None and self.fused_chain and not self.overlap_rulebooks:
+        if num_active_dev is not None and self.fused_chain:
             x.planned = self.middle_conv.plan_chain(x)       # None: layer-by-layer builds
-        if num_active_dev is not None and self.overlap_rulebooks:
-            # static pipeline: all 8 rulebooks on a side stream, overlapped with the conv layers (fork / join)
-            # one side stream per launching stream: branches of a branched graph must not share it
-            if self._side_stream is None:
-                self._side_stream = {}
-            key = torch.cuda.current_stream().cuda_stream
-            if key not in self._side_stream:
-                self._side_stream[key] = (torch.cuda.Stream(), torch.cuda.Stream())
-            side, side2 = self._side_stream[key]
-            x.planned = self.middle_conv.plan_rulebooks(x, side, side2 if self.overlap_rulebooks_split else None)
         x = self.middle_conv(x)
-        if side is not None:
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.current_stream().wait_stream(side2)
-            self.last_overflow_checks = self.middle_conv._planned_overflow
-        else:
-            self.last_overflow_checks = x.overflow_checks
+        self.last_overflow_checks = x.overflow_checks
         if channels_last and bev_sparse and x.features.shape[1] == 64 and int(x.spatial_shape[0]) == 2:
             return SparseBEV(x)                      # the RPN's first conv gathers from the rows: no dense image
         if channels_last:
@@ -391,16 +371,19 @@ class RPNV2(nn.Module):
         return ret
 
 
+RPN_TRAIN_BACKEND = "hip"
+
+
 def rpn_forward_mixed(rpn, x, dtype):
     """Training forward of an RPNV2 with 16-bit activations over its fp32 master weights (the DeviceTrainer's amp path).  Every
     Conv2d(128, 128, 3, stride 1) + BatchNorm2d + ReLU triple of the blocks runs on the hand-written kernels -- forward and data
     gradient on k_conv2d_halo_reg, weight gradient on k_conv2d_wgrad3x3, BatchNorm (batch statistics) + ReLU fused
     (ops.Conv3x3Function / ops.BatchNormReluFunction; rpn.py:486-497 trained by train.py:316-322); anything else (strided or
-    other-width convs, the deblocks, the 1x1 heads) stays on torch under autocast.  SEC_RPN_TRAIN_BACKEND=miopen: all of it on torch
-    (the round-2 path, for A/B runs).  Same arithmetic as RPNV2.forward up to 16-bit rounding of the activations.  (autocast's
+    other-width convs, the deblocks, the 1x1 heads) stays on torch under autocast.  ``models.RPN_TRAIN_BACKEND = "miopen"``: all of it
+    on torch (the round-2 path; tests compare the two).  Same arithmetic as RPNV2.forward up to 16-bit rounding of the activations.  (autocast's
     weight-cast cache is off: the function is captured into hipGraphs by DeviceTrainer, and a cached cast made during capture
     would be stale on replay.)"""
-    use_hip = os.environ.get("SEC_RPN_TRAIN_BACKEND", "hip") == "hip" and x.is_cuda
+    use_hip = RPN_TRAIN_BACKEND == "hip" and x.is_cuda
     x = x.to(dtype).contiguous(memory_format=torch.channels_last)
 
     def run_block(blk, x):
@@ -485,7 +468,7 @@ class RPNInference(nn.Module):
     bias, ZeroPad2d merged into the conv padding, the stride-1 1x1 ConvTranspose2d rewritten as a 1x1 conv, the three
     1x1 heads merged into one conv (output channels padded to a multiple of 64).  Every 3x3 conv runs on the
     hand-written MFMA kernel with bias + ReLU fused (sec_conv2d_nhwc), the deblock + heads as one fused kernel
-    (sec_conv1x1_chain_nhwc); SEC_RPN_BACKEND=miopen keeps torch convs + one fused bias/ReLU pass for A/B runs.
+    (sec_conv1x1_chain_nhwc); backend="miopen" keeps torch convs + one fused bias/ReLU pass for A/B runs.
     Same arithmetic as RPNV2.forward (rpn.py:314-331,393-420) up to bf16 rounding of the folded weights."""
 
     @staticmethod
@@ -500,7 +483,10 @@ class RPNInference(nn.Module):
                 return False
         return len(rpn.blocks) >= 1 and len(rpn.deblocks) >= 1
 
-    def __init__(self, rpn, dtype):
+    def __init__(self, rpn, dtype, backend="hip", gather_first=True):
+        """``backend``: "hip" = the hand-written MFMA convs (default), "miopen" = torch convolutions + one fused bias / ReLU pass (the
+        phase-1 path: A/B yardstick).  ``gather_first``: the first conv reads the sparse rows through a site map instead of a dense
+        image when the shapes allow (False: always the dense image)."""
         super().__init__()
         assert self.supports(rpn)
         self.a, self.codes = rpn._num_anchor_per_loc, (rpn._box_code_size, rpn._num_class, rpn._num_direction_bins)
@@ -558,11 +544,9 @@ class RPNInference(nn.Module):
         hb = torch.cat([h.bias.detach().float() for h in heads] + [torch.zeros(padc, device=heads[0].weight.device)], 0)
         self.head_w = nn.Parameter(hw.to(dtype).contiguous(memory_format=torch.channels_last), requires_grad=False)
         self.head_b = nn.Parameter(hb.contiguous(), requires_grad=False)
-        # hand-written MFMA conv (sec_conv2d_nhwc, bias + ReLU fused) when shapes allow; SEC_RPN_BACKEND=miopen
-        # keeps the phase-1 path (MIOpen conv + one fused bias/ReLU pass) for A/B measurements
-        import os
+        # hand-written MFMA conv (sec_conv2d_nhwc, bias + ReLU fused) when shapes allow
         self.return_views = True   # the fused predict kernels read the head output in place through strides
-        self.use_hip = os.environ.get("SEC_RPN_BACKEND", "hip") == "hip" and dtype in (torch.bfloat16, torch.float16)
+        self.use_hip = backend == "hip" and dtype in (torch.bfloat16, torch.float16)
         self.packed, self.head_packed = [], None
         if self.use_hip:
             for w in self.ws:
@@ -580,18 +564,18 @@ class RPNInference(nn.Module):
             self.use_hip = self.head_packed is not None
         # deblock (1x1, stride 1, 128 -> 128) + heads (<= 128 padded channels) run as ONE kernel (sec_conv1x1_chain_nhwc)
         wl = self.ws[-1]
-        self.sparse_input = os.environ.get("SEC_RPN_ZSKIP", "1") == "1"   # forward()'s input comes from SparseConvTensor.dense()
+        self.sparse_input = True   # forward()'s input comes from SparseConvTensor.dense(): all-zero halo tiles skip their MFMA loop (bit-identical)
         # first conv straight from the sparse rows (sec_conv2d_nhwc_gather): 3x3 / s1 / p1 on 2 planes x 64 channels; its weights
-        # are packed a second time with the input channels in plane-major order (SEC_RPN_GATHER=0: always the dense image)
+        # are packed a second time with the input channels in plane-major order (gather_first=False: always the dense image)
         self.gather_packed = None
         w0 = self.ws[0]
         if (self.use_hip and self.plan[0][0] == "c" and tuple(w0.shape[1:]) == (128, 3, 3) and w0.shape[0] % 128 == 0
-                and self.cfgs[0] == ([1, 1], [1, 1]) and self.ups[0] == 1 and os.environ.get("SEC_RPN_GATHER", "1") == "1"):
+                and self.cfgs[0] == ([1, 1], [1, 1]) and self.ups[0] == 1 and gather_first):
             perm = ops.gather_channel_perm(64, 2).to(w0.device)
             self.gather_packed = ops.conv2d_pack_weight(w0.detach()[:, perm].contiguous())
         self.chain_tail = (single and self.use_hip and tuple(wl.shape) == (128, 128, 1, 1) and self.cfgs[-1] == ([1, 1], [0, 0])
                            and self.ups[-1] == 1
-                           and self.head_cout in (64, 128) and os.environ.get("SEC_RPN_CHAIN", "1") == "1")
+                           and self.head_cout in (64, 128))
 
     def _conv(self, x, i, sparse_input=False):
         w, b, (s, p) = self.ws[i], self.bs[i], self.cfgs[i]
@@ -683,6 +667,7 @@ class SecondDetector(nn.Module):
         self.register_buffer("post_center_range", torch.tensor(cfg["post_center_range"], dtype=torch.float32),
                              persistent=False)
         self._infer_dtype = None
+        self.pfn_slots = True        # PointPillars inference: the PillarFeatureNet walks the voxeliser's point lists (False: pillar tensor)
         self.fused_predict = True
         self.rulebook_numbering = os.environ.get("SEC_RULEBOOK_NUMBERING", "sorted")
         bf = cfg.get("block_filtering")
@@ -691,13 +676,13 @@ class SecondDetector(nn.Module):
                                                             **(dict(bf, block_filtering=True) if bf else {}))
 
     # -- inference preparation: bf16 channels-last RPN with folded BN; sparse stack in bf16 (BN folded at run time)
-    def prepare_inference(self, dtype=torch.bfloat16):
+    def prepare_inference(self, dtype=torch.bfloat16, rpn_backend="hip", gather_first=True):
         # NOTE: MIOpen's fused conv+bias+ReLU plan (torch.miopen_convolution_relu) was measured at ~160 ms per
         # 3x3 conv for bf16 NHWC on gfx950 (naive fallback kernel) vs 0.14 ms unfused -- not an option; the
         # fused dense path is the hand-written MFMA conv.
         self.eval()
         if isinstance(self.rpn, RPNV2) and RPNInference.supports(self.rpn) and next(self.parameters()).is_cuda:
-            self.rpn = RPNInference(self.rpn, dtype)
+            self.rpn = RPNInference(self.rpn, dtype, backend=rpn_backend, gather_first=gather_first)
         else:
             self.rpn.blocks = nn.ModuleList([fold_conv_bn_(b) for b in self.rpn.blocks])
             self.rpn.deblocks = nn.ModuleList([fold_conv_bn_(b) for b in self.rpn.deblocks])
@@ -753,11 +738,11 @@ class SecondDetector(nn.Module):
         nf = self.cfg["num_point_features"]
         if self.pillars:
             # inference on 4-feature points: the PillarFeatureNet walks the voxeliser's point lists (no [P, 60, 4] tensor: 98 MB
-            # written and re-read per step at nuScenes size); SEC_PFN_SLOTS=0 materialises the pillars as the reference does
+            # written and re-read per step at nuScenes size); pfn_slots = False materialises the pillars as the reference does
             # (block filtering returns compacted pillars without the voxeliser's point lists: tensor path)
             slots = (not self.training and not torch.is_grad_enabled() and nf == 4 and points.shape[1] == 4 and points.is_cuda
                      and not getattr(self.voxel_generator, "_block_filtering", False)
-                     and os.environ.get("SEC_PFN_SLOTS", "1") == "1")
+                     and self.pfn_slots)
             vox = self.voxel_generator.generate_device(points, point_offsets, sync=not static, fill=not slots)
             nd = vox["voxel_offsets"][batch_size:] if static else None    # device count of live pillars
             if slots:
@@ -837,8 +822,6 @@ class SecondDetector(nn.Module):
 
     def _capture(self, parts, warmup):
         mfe = self.middle_feature_extractor
-        if len(parts) > 1 and getattr(mfe, "overlap_rulebooks", False):
-            mfe.overlap_rulebooks = False     # the (experimental) side-stream rulebook planner is a single-chain feature
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s), torch.no_grad():

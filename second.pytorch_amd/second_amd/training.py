@@ -118,6 +118,7 @@ class DeviceTrainer:
             self.opt = FlatAdamW(params, self.bucket.flat, lr, weight_decay, betas=(0.9, 0.99), max_grad_norm=self.max_grad_norm)
         else:
             self.opt = torch.optim.AdamW(params, lr=lr, weight_decay=weight_decay, betas=(0.9, 0.99))
+        self.graph_rpn = True        # eager steps: the static-shape RPN segment replays as two hipGraphs (_rpn_mixed)
         self.static = False          # static-capacity rows (device-side live counts, no host sync): set by capture_step
         self._captured = None
         # fp16 features need loss scaling (5 exponent bits: head gradients are O(1 / num_pos / batch)); bf16 / fp32 do not
@@ -160,12 +161,12 @@ class DeviceTrainer:
         if det.pillars:
             # PointPillars (nuscenes/all.pp.largea): PillarFeatureNet on sec_pfn_train_fwd / _bwd (batch statistics; the [P, T, C]
             # tensor of the reference formulation is never built), differentiable pillar scatter (sec_pillar_scatter / sec_dense_to_sparse),
-            # the three-block RPN through _rpn_mixed (16-bit) or torch convolutions (fp32 / SEC_PP_TRAIN_RPN=torch)
+            # the three-block RPN through _rpn_mixed (16-bit) or torch convolutions (fp32)
             with torch.autocast("cuda", dtype=self.amp_dtype or torch.float32, enabled=self.amp_dtype is not None):
                 feats = det.voxel_feature_extractor(vox["voxels"], vox["num_points_per_voxel"], vox["coordinates"])
                 if self.amp_dtype is not None:
                     feats = feats.to(self.amp_dtype)          # the fused PFN returns fp32; the pseudo image is built in 16 bits
-                mixed = self.amp_dtype is not None and os.environ.get("SEC_PP_TRAIN_RPN", "mixed") == "mixed"
+                mixed = self.amp_dtype is not None
                 # the mixed-precision RPN segment works on channels-last activations: the scatter writes them that way
                 spatial = det.middle_feature_extractor(feats.float() if self.amp_dtype is None else feats, vox["coordinates"], batch,
                                                        channels_last=mixed)
@@ -191,11 +192,11 @@ class DeviceTrainer:
         """The dense part of the step has static shapes ([B, 128, H, W] whatever the clouds hold), ~100 launches forward + backward,
         and the eager step is HOST bound (541 launches at ~14 us each = 7.6 ms for 4.9 ms of kernels, profiles/r03_e_*): its
         forward and backward are therefore captured once as two hipGraphs (torch.cuda.make_graphed_callables over the same
-        rpn_forward_mixed) and replayed.  SEC_TRAIN_GRAPH_RPN=0, a changed input shape or a failed capture fall back to eager."""
+        rpn_forward_mixed) and replayed.  ``self.graph_rpn = False``, a changed input shape or a failed capture fall back to eager."""
         import os
         from .models import rpn_forward_mixed
         x = spatial.to(self.amp_dtype).contiguous(memory_format=torch.channels_last)
-        if self.static or os.environ.get("SEC_TRAIN_GRAPH_RPN", "1") != "1" or not x.is_cuda:
+        if self.static or not self.graph_rpn or not x.is_cuda:
             return rpn_forward_mixed(self.det.rpn, x, self.amp_dtype)      # static: the WHOLE step is one graph (capture_step)
         key = (tuple(x.shape), x.dtype)
         if self._graphed_rpn is None or self._graphed_rpn[0] != key:

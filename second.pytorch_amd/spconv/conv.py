@@ -60,7 +60,7 @@ class SparseConvolution(SparseModule):
     # -- rulebook ---------------------------------------------------------------------------------
     def _rulebook(self, x):
         planned = getattr(x, "planned", None)
-        if planned is not None and id(self) in planned:      # built ahead of time on a side stream (plan_rulebooks)
+        if planned is not None and id(self) in planned:      # built ahead of time by the fused chain (SparseSequential.plan_chain)
             rb, event = planned[id(self)]
             if event is not None:
                 torch.cuda.current_stream().wait_event(event)

@@ -37,8 +37,7 @@ class SparseSequential(SparseModule):
                 raise ValueError("name exists.")
             self.add_module(name, module)
         self.fuse_inference = True
-        import os
-        self.fuse_train_bn = os.environ.get("SEC_SPARSE_BN_TRAIN", "hip") == "hip"   # training, 16-bit rows: fused BatchNorm1d + ReLU kernels
+        self.fuse_train_bn = True   # training, 16-bit rows: fused BatchNorm1d + ReLU kernels (False: torch's BatchNorm1d on the rows)
         self._fold_cache = {}
 
     def __getitem__(self, idx):
@@ -57,51 +56,6 @@ class SparseSequential(SparseModule):
             if name in self._modules:
                 raise KeyError("name exists")
         self.add_module(name, module)
-
-    def plan_rulebooks(self, x, stream, stream2=None):
-        """Build the rulebooks of EVERY sparse conv of this sequence ahead of the feature computation: rulebooks depend on
-        coordinates only, so the (latency-bound) hash / scan kernels of all layers overlap with the conv kernels of the layers
-        before them.  The strided builds form a serial chain (each numbers the sites of the next level) and run on ``stream``;
-        the SubM builds hang off that chain -- each only needs the level's sites -- and run on ``stream2`` (default: the same
-        stream) as soon as the strided build that produced their sites is done.  Returns {id(conv): (Rulebook, event)};
-        assign it to ``x.planned`` before calling forward.  Static-capacity tensors only (no host syncs)."""
-        from .conv import SparseConvolution
-        from .tensor import SparseConvTensor
-        assert x.num_active_dev is not None, "plan_rulebooks needs a static-capacity SparseConvTensor"
-        main = torch.cuda.current_stream()
-        stream.wait_stream(main)
-        stream2 = stream2 or stream
-        if stream2 is not stream:
-            stream2.wait_stream(main)
-        plans = {}
-        cur = SparseConvTensor(None, x.indices, x.spatial_shape, x.batch_size, None, x.num_active_dev)
-        cur.indice_dict = x.indice_dict
-        level_ready = None                           # event: the current level's sites (and its hash table) exist
-        for m in self._modules.values():
-            if not isinstance(m, SparseConvolution) or m.conv1x1:
-                continue
-            st = stream2 if m.subm else stream
-            with torch.cuda.stream(st):
-                if m.subm and level_ready is not None and st is not stream:
-                    st.wait_event(level_ready)
-                rb = m._rulebook(cur)
-                ev = torch.cuda.Event()
-                ev.record(st)
-                for t in (rb.nbr_out, rb.nbr_in, rb.out_indices, rb.num_out_dev):
-                    if t is not None:
-                        t.record_stream(main)
-                plans[id(m)] = (rb, ev)
-                if not m.subm:
-                    nxt = SparseConvTensor(None, rb.out_indices, rb.out_shape, x.batch_size, None, rb.num_out_dev)
-                    nxt.indice_dict = cur.indice_dict
-                    nxt.overflow_checks = cur.overflow_checks + [(rb.num_out_dev, rb.out_indices.shape[0])]
-                    nxt.site_table = rb.__dict__.pop("_site_table", None)
-                    nxt.site_bitmap = rb.__dict__.pop("_site_bitmap", None)
-                    cur = nxt
-                    level_ready = ev
-        self._planned_overflow = cur.overflow_checks
-        self._plan_streams = (stream, stream2)
-        return plans
 
     def plan_chain(self, x):
         """Static-capacity inference: ALL rulebooks of this sequence from ONE fused build (ops.rulebook_chain: 4 + (levels - 1)

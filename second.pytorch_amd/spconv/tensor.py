@@ -32,7 +32,7 @@ class SparseConvTensor:
         synchronisation (hipGraph-capturable).  None = the reference's dynamic-shape behaviour."""
         self.num_active_dev = num_active_dev
         self.overflow_checks = []  # [(device int32[2] = (clamped, raw), capacity)] of strided layers upstream
-        self.planned = None   # {id(conv): (Rulebook, event)} from SparseSequential.plan_rulebooks
+        self.planned = None   # {id(conv): (Rulebook, event or None)} from SparseSequential.plan_chain
         self.features = features
         self.indices = indices
         if self.indices.dtype != torch.int32:

@@ -231,7 +231,7 @@ def test_first_rpn_conv_gathered_from_sparse_rows(ops, dtype, batch, h, w, cout,
 
 
 def test_detector_with_and_without_the_dense_image_agree(monkeypatch):
-    """SecondDetector with the first RPN conv gathering from the sparse rows (default) vs SEC_RPN_GATHER=0 (dense image +
+    """SecondDetector with the first RPN conv gathering from the sparse rows (default) vs gather_first=False (dense image +
     zero-tile skip): the RPN head outputs agree up to 16-bit rounding through six conv layers; eager and static forwards of
     the gathered form are identical."""
     from second_amd.models import SecondDetector, CAR_FHD
@@ -241,13 +241,12 @@ def test_detector_with_and_without_the_dense_image_agree(monkeypatch):
     pts, offs = dev(pts), dev(offs)
     heads, state = {}, None
     for flag in ("1", "0"):
-        monkeypatch.setenv("SEC_RPN_GATHER", flag)
         torch.manual_seed(0)
         det = SecondDetector(CAR_FHD).cuda()
         if state is None:
             state = {k: v.clone() for k, v in det.state_dict().items()}
         det.load_state_dict(state)
-        det.prepare_inference(torch.bfloat16)
+        det.prepare_inference(torch.bfloat16, gather_first=flag == "1")
         assert (det.rpn.gather_packed is not None) == (flag == "1")
         with torch.no_grad():
             vox = det.voxel_generator.generate_device(pts, offs, mean_features=4)

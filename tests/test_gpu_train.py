@@ -229,9 +229,9 @@ def test_pfn_training_kernels_vs_torch_autograd(pillars, points, monkeypatch):
         vox[p, :k, 3] = torch.rand(k, generator=g)
     res = {}
     for backend in ("torch", "hip"):
-        monkeypatch.setenv("SEC_PFN_TRAIN_BACKEND", backend)
         torch.manual_seed(3)
         net = PillarFeatureNet(4, (64,), (0.25, 0.25, 8), (-50, -50, -5, 50, 50, 3)).cuda().train()
+        net.train_backend = backend
         with torch.no_grad():
             net.pfn_layers[0].norm.weight.uniform_(0.5, 1.5)
             net.pfn_layers[0].norm.bias.uniform_(-0.3, 0.3)

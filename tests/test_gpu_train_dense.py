@@ -97,7 +97,7 @@ def test_bn_relu_forward_backward_vs_torch(ops, dtype, c, relu):
 
 def test_rpn_forward_mixed_hip_vs_fp32_and_torch_autocast(ops, monkeypatch):
     """models.rpn_forward_mixed on the car.fhd RPN in training mode: the hand-written bf16 path and torch's bf16 autocast path
-    (SEC_RPN_TRAIN_BACKEND=miopen) are two different 16-bit chains, so each is measured against the SAME network in fp32 (plain
+    (models.RPN_TRAIN_BACKEND = "miopen") are two different 16-bit chains, so each is measured against the SAME network in fp32 (plain
     torch): the hand-written path may not be further from fp32 than autocast is (x 1.5 + a small floor), for the head outputs and
     for every parameter gradient; running statistics agree with fp32's."""
     from second_amd.models import RPNV2, rpn_forward_mixed
@@ -109,10 +109,11 @@ def test_rpn_forward_mixed_hip_vs_fp32_and_torch_autocast(ops, monkeypatch):
 
     def loss_of(preds):
         return sum((p.float() ** 2).mean() for p in preds.values())
-    monkeypatch.setenv("SEC_RPN_TRAIN_BACKEND", "hip")
+    from second_amd import models
+    monkeypatch.setattr(models, "RPN_TRAIN_BACKEND", "hip")
     a = rpn_forward_mixed(nets[0], x, torch.bfloat16)
     loss_of(a).backward()
-    monkeypatch.setenv("SEC_RPN_TRAIN_BACKEND", "miopen")
+    monkeypatch.setattr(models, "RPN_TRAIN_BACKEND", "miopen")
     b = rpn_forward_mixed(nets[1], x, torch.bfloat16)
     loss_of(b).backward()
     r = nets[2](x)                                            # fp32 reference
@@ -267,10 +268,10 @@ def test_device_trainer_graphed_rpn_segment_equals_eager(monkeypatch):
     init = SecondDetector(CAR_FHD).state_dict()
     results = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("SEC_TRAIN_GRAPH_RPN", mode)
         det = SecondDetector(CAR_FHD)
         det.load_state_dict(init)
         tr = DeviceTrainer(det.cuda(), amp_dtype=torch.bfloat16)
+        tr.graph_rpn = mode == "1"
         loss, out6, _ = tr.forward_loss(d(pts), d(offs), d(gt), d(goffs))
         loss.backward()
         torch.cuda.synchronize()

@@ -26,7 +26,7 @@ def bench(fn, n=N):
 ZSKIP = bool(int(os.environ.get("ZSKIP", "0")))   # flag the input as a scattered sparse tensor (all-zero tiles skipped)
 t = bench(lambda: ops.conv2d_nhwc(x, pk, b, 128, 3, 1, 1, relu=True, sparse_input=ZSKIP))
 flop = 2 * 8 * 200 * 176 * 128 * 128 * 9
-print(f"density={density} zskip={int(ZSKIP)} hip variant={os.environ.get('SEC_CONV2D_VARIANT','1')}: {t:.1f} us  {flop / t / 1e6:.0f} TFLOP/s")
+print(f"density={density} zskip={int(ZSKIP)} hip: {t:.1f} us  {flop / t / 1e6:.0f} TFLOP/s")
 if os.environ.get("WITH_MIOPEN"):
     wcl = w.contiguous(memory_format=torch.channels_last)
     t = bench(lambda: ops.bias_act_(torch.nn.functional.conv2d(x, wcl, None, 1, 1), b, True))

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-workgroup timeline of k_conv2d_halo_reg (needs a build with SEC_EXTRA_HIPCC_FLAGS=-DSEC_CONV_TIMELINE, loaded through
 SEC_HIP_LIB) + launch time over the batch size (how the time quantises into rounds of resident workgroups).
-SEC_CONV2D_STAGGER=<clocks> delays the three resident slots of a CU by 0 / 1 / 2 x that many clocks (experiment)."""
+(The SEC_CONV2D_STAGGER experiment of round 2 -- delaying the resident slots of a CU -- is gone: no effect.)"""
 import ctypes, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "second.pytorch_amd"))
@@ -32,7 +32,7 @@ for batch in [int(v) for v in os.environ.get("BATCHES", "1,2,3,4,6,8,16").split(
     t = bench(x)
     tiles = batch * 25 * 11
     flop = 2.0 * batch * 200 * 176 * 128 * 128 * 9
-    print(f"batch {batch:2d}: {tiles:5d} tiles = {tiles / 768:5.2f} rounds of 768  {t:7.2f} us  {flop / t / 1e6:6.0f} TFLOP/s  stagger={os.environ.get('SEC_CONV2D_STAGGER', '0')}", flush=True)
+    print(f"batch {batch:2d}: {tiles:5d} tiles = {tiles / 768:5.2f} rounds of 768  {t:7.2f} us  {flop / t / 1e6:6.0f} TFLOP/s", flush=True)
     if batch == 8 and hasattr(rt.lib(), "sec__debug_timeline2"):
         buf = torch.zeros((tiles + 8, 8), dtype=torch.int64, device="cuda")
         rt.lib().sec__debug_timeline2(ctypes.c_void_p(buf.data_ptr()))

@@ -183,7 +183,7 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
                 print(f"backward {'dgrad' if need[0] else 'wgrad'} {dt}: {e0.elapsed_time(e1) * 100:.1f} us")
-    print(f"variant={os.environ.get('SEC_CONV_VARIANT', 'default')} layer={args.layer} rows={n} pairs={pairs} C={c} "
+    print(f"layer={args.layer} rows={n} pairs={pairs} C={c} "
           f"us/launch={us:.2f} alg_GBs={b_alg / us / 1e3:.1f} frac_of_8TBs={b_alg / us / 1e3 / 8000:.3f}")
 
 
