@@ -616,15 +616,17 @@ def other_configs(budget_s=270.0):
     """BASELINE.json configs 3 / 4 / 5 at their stated sizes, measured by THIS command (each in a child process: same file, --workload,
     a short run) so that the driver's record carries them; never part of `value`.  Best effort: a failure is reported, not raised."""
     import subprocess
-    runs = [("car.fhd.train", ["--dtype", "bf16"], "config 3 (per-GPU step; DDP adds one 7.3 MB gradient all-reduce)"),
-            ("nusc.pp", [], "config 4"), ("nusc.fhd", [], "config 5 network, inference, fp16"),
-            ("nusc.fhd.train", [], "config 5 (per-GPU step, fp16 features + dynamic loss scaling)"),
-            ("nusc.pp.train", [], "config 4's network trained on the device step (PFN batch statistics + argmax backward on "
-                                  "sec_pfn_train_fwd / _bwd)")]
+    runs = [("car.fhd.train", "car.fhd.train", ["--dtype", "bf16"], "config 3 (per-GPU step, whole step one hipGraph; DDP adds one 7.3 MB gradient all-reduce)"),
+            ("nusc.pp", "nusc.pp", [], "config 4"), ("nusc.fhd", "nusc.fhd", [], "config 5 network, inference, fp16"),
+            ("nusc.fhd.train", "nusc.fhd.train", [], "config 5 (per-GPU step, fp16 features + dynamic loss scaling on the device, whole step one hipGraph)"),
+            ("nusc.pp.train", "nusc.pp.train", [], "config 4's network trained on the device step (PFN batch statistics + argmax backward on "
+                                                   "sec_pfn_train_fwd / _bwd)"),
+            ("car.fhd.fp32", "car.fhd", ["--dtype", "fp32"], "config 2's network in fp32, the reference's default precision: sparse convs on "
+                                                              "v_mfma_f32_32x32x2_f32, torch / MIOpen RPN")]
     out, t0 = {}, time.time()
-    for wl, extra, what in runs:
+    for key, wl, extra, what in runs:
         if time.time() - t0 > budget_s:
-            out[wl] = {"skipped": "time budget"}
+            out[key] = {"skipped": "time budget"}
             continue
         cmd = [sys.executable, os.path.abspath(__file__), "--workload", wl, "--steps", "30", "--warmup", "5", "--no-kernel-table",
                "--no-cpu-baseline", "--no-extra-lines", "--no-other-configs", *extra]
@@ -633,12 +635,12 @@ def other_configs(budget_s=270.0):
             line = [l for l in r.stdout.splitlines() if l.startswith("{")]
             d = json.loads(line[-1])
             cfg = d.get("config", {})
-            out[wl] = {"what": what, "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "dtype": d["dtype"],
+            out[key] = {"what": what, "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "dtype": d["dtype"],
                        "per_step_per_gpu": cfg.get("frames_per_step_per_gpu") or cfg.get("samples_per_step_per_gpu"),
                        "points_per_frame": cfg.get("points_per_frame"), "rows_per_frame": cfg.get("rows_per_frame"),
                        "steps_in_flight": cfg.get("steps_in_flight"), "loss_last_step": d.get("loss_last_step"), "steps": d["steps"]}
         except Exception as e:  # noqa: BLE001
-            out[wl] = {"error": repr(e)[:300]}
+            out[key] = {"error": repr(e)[:300]}
     return out
 
 

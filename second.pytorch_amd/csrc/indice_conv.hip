@@ -1359,10 +1359,135 @@ __global__ __launch_bounds__(kBlock) void k_conv_tiled(const T *__restrict__ fea
     }
 }
 
+
+// ------------------------------------------------------------------ fp32 on the matrix cores (v_mfma_f32_32x32x2_f32)
+// The reference's default precision is fp32; k_conv_tiled (VALU, 223 us on the 64 -> 64 layer at 56 k rows) left it ten times
+// slower than the 16-bit path.  Output stationary like every kernel here: a workgroup owns 128 output rows (four waves, a 32-row
+// tile each) x all COUT channels; per kernel offset W[k] sits in LDS as fp32 (double buffered: W[k+1] travels global -> registers
+// -> LDS while offset k computes, one barrier per offset) and a lane gathers 16 bytes of its row per 8 input channels.
+// Operand layout of v_mfma_f32_32x32x2_f32: A[m = lane % 32][k = lane / 32], B[k = lane / 32][n = lane % 32], so with h = lane / 32
+// a lane's float4 of channels 8j + 4h .. + 3 feeds four MFMAs (s = 0..3) whose B operand is W[8j + 4h + s][n]: the contraction
+// index runs in the order (j, s, h) instead of ascending -- any order is a valid dot product -- and no lane shuffles are needed.
+// Rows without a neighbour contribute exact zeros; an offset no row of the wave uses is skipped (wave-uniform ballot).
+// Dense per offset: the MFMAs run for all 32 rows of a tile whatever share of them has a neighbour (39 % on car.fhd's subm2), so
+// the matrix-pipe floor of that layer is 12.4 GFLOP / 157 TFLOP/s = 79 us; pair compaction (LDS accumulators) would be needed to
+// go below it.  Accumulation order differs from the oracle's (offsets outer, channels ascending): results agree to fp32 rounding
+// (tests: 1e-4 of the range, as for the 16-bit kernels), not bit for bit.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <int CIN, int COUT>
+__global__ __launch_bounds__(kBlock) void k_conv_mfma_f32(const float *__restrict__ feat, const float *__restrict__ w,
+                                                         const int *__restrict__ nbr, int n_out, const int *__restrict__ num_out_dev,
+                                                         int kvol, int w_t, int mirror, const float *__restrict__ scale,
+                                                         const float *__restrict__ shift, int relu, float *__restrict__ out) {
+    static_assert(CIN % 8 == 0 && COUT % 32 == 0, "8-channel gathers, 32-column MFMA tiles");
+    constexpr int LDW = COUT + 8, CT = COUT / 32, NJ = CIN / 8, ROWS = 128;
+    constexpr int WPT = CIN * COUT / kBlock;     // weights per thread and offset
+    static_assert(CIN * COUT % kBlock == 0, "whole weights per thread");
+    __shared__ float sW[2][CIN * LDW];
+    __shared__ int s_nbr[ROWS * 27];
+    if (num_out_dev) n_out = *num_out_dev;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, m = lane & 31, h = lane >> 5;
+    const long long base = (long long)blockIdx.x * ROWS;
+    if (base >= n_out) return;
+    {   // the workgroup's slice of the gather table (contiguous), -1 behind the last row
+        const long long lim = ((long long)n_out - base) * kvol;
+        const int *src = nbr + base * kvol;
+        for (int e = tid; e < ROWS * kvol; e += kBlock) s_nbr[e] = e < lim ? src[e] : -1;
+    }
+    // W[k] (or its transpose / mirror: the data gradient) -> registers -> LDS, element e = ci * COUT + co.  (A 16-byte form of this
+    // staging, unconditional gathers with a select, and an explicit double buffer of the B operands were each measured on the
+    // 64 -> 64 layer: 151-155 us against 138 us for this form -- the register count, 206 against 172, costs more than they save.)
+    float wreg[WPT];
+    auto load_w = [&](int k) {
+        const float *wk = w + (size_t)(mirror ? kvol - 1 - k : k) * CIN * COUT;
+#pragma unroll
+        for (int q = 0; q < WPT; ++q) {
+            const int e = q * kBlock + tid, ci = e / COUT, co = e - ci * COUT;
+            wreg[q] = w_t ? wk[(size_t)co * CIN + ci] : wk[e];
+        }
+    };
+    auto store_w = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < WPT; ++q) {
+            const int e = q * kBlock + tid, ci = e / COUT, co = e - ci * COUT;
+            sW[buf][ci * LDW + co] = wreg[q];
+        }
+    };
+    load_w(0);
+    store_w(0);
+    f32x16 acc[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[c][i] = 0.0f;
+    __syncthreads();
+    // the gathers of offset k + 1 are issued before the MFMAs of offset k (a wave is often alone on its SIMD here: 137 VGPRs, and a
+    // 23 k-row layer is fewer workgroups than CUs -- without the prefetch every offset paid a full gather latency: 3.4 us per offset)
+    float4 a[NJ], an[NJ];
+    auto gather = [&](int k, float4 (&dst)[NJ]) -> bool {
+        const int idx = s_nbr[(wave * 32 + m) * kvol + k];
+        const bool any = __ballot(idx >= 0) != 0ull;
+        if (any) {
+            const float4 *row = reinterpret_cast<const float4 *>(feat + (size_t)(idx >= 0 ? idx : 0) * CIN) + h;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) dst[j] = idx >= 0 ? row[2 * j] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+        return any;
+    };
+    bool any = gather(0, a);
+    for (int k = 0; k < kvol; ++k) {
+        bool any_next = false;
+        if (k + 1 < kvol) { load_w(k + 1); any_next = gather(k + 1, an); }
+        if (any) {
+            const float *wb = &sW[k & 1][(4 * h) * LDW + m];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const float as[4] = {a[j].x, a[j].y, a[j].z, a[j].w};
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int c = 0; c < CT; ++c)
+                        acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(as[t], wb[(8 * j + t) * LDW + c * 32], acc[c], 0, 0, 0);
+            }
+        }
+        if (k + 1 < kvol) store_w((k + 1) & 1);      // the other buffer: every wave left it at the barrier that opened offset k
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) a[j] = an[j];
+        any = any_next;
+        __syncthreads();
+    }
+    // D[mm][n]: lane holds column n = lane % 32 and rows mm = 8 * (i / 4) + 4 * h + i % 4
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        const int col = c * 32 + m;
+        const float sc = scale ? scale[col] : 1.0f, sh = shift ? shift[col] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const long long r = base + wave * 32 + 8 * (i / 4) + 4 * h + (i % 4);
+            if (r < n_out) out[(size_t)r * COUT + col] = epilogue_v(acc[c][i], sc, sh, scale != nullptr, shift != nullptr, relu);
+        }
+    }
+}
+
 template <typename T, typename OT>
 static bool launch_tiled(const void *feat, const void *w, const int *nbr, int n_out, const int *num_out_dev, int cin, int cout,
                          int kvol, int w_t, int mirror, const float *scale, const float *shift, int relu, void *out,
                          hipStream_t st) {
+    if constexpr (std::is_same<T, float>::value && std::is_same<OT, float>::value) {
+        // fp32 on the matrix cores for the channel plans of SECOND's layers (and their data gradients); g_variant_override 30 keeps
+        // the VALU form (parity tests compare the two)
+        if (kvol <= 27 && conv_variant() != 30) {
+#define SEC_MF(CI, CO)                                                                                                       \
+            if (cin == CI && cout == CO) {                                                                                   \
+                set_last_kernel("void sec::k_conv_mfma_f32<%d, %d>", CI, CO);                                                \
+                hipLaunchKernelGGL((k_conv_mfma_f32<CI, CO>), dim3(div_up(n_out, 128)), dim3(kBlock), 0, st, (const float *)feat, \
+                                   (const float *)w, nbr, n_out, num_out_dev, kvol, w_t, mirror, scale, shift, relu, (float *)out); \
+                return true;                                                                                                 \
+            }
+            SEC_MF(16, 32) SEC_MF(32, 32) SEC_MF(32, 64) SEC_MF(64, 32) SEC_MF(64, 64)
+#undef SEC_MF
+        }
+    }
 #define SEC_TL(CI, CO)                                                                                                   \
     if (cin == CI && cout == CO) {                                                                                       \
         constexpr int ROWS = (kBlock / (CO / 4)) * 4;                                                                    \

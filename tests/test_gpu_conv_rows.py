@@ -354,3 +354,43 @@ def test_conv_rows_lds_windows_hit_on_sorted_rows(ops, layer, dtype):
         np.testing.assert_allclose(out.float().cpu().numpy(), ref_f, rtol=tol, atol=tol * np.abs(ref_f).max())
     finally:
         ops.indice_conv_set_variant(-1)
+
+
+@pytest.mark.parametrize("cin,cout", [(16, 32), (32, 32), (32, 64), (64, 32), (64, 64)])
+@pytest.mark.parametrize("subm", [True, False])
+def test_indice_conv_fp32_on_the_matrix_cores(ops, cin, cout, subm):
+    """fp32 features (the reference's default precision) on v_mfma_f32_32x32x2_f32 (k_conv_mfma_f32): against the fp64-accumulating
+    oracle within 1e-4 of the range (BASELINE.json's tolerance), against the VALU form (variant 30) to fp32 rounding, ragged row
+    counts, device-side row count below the capacity with garbage table rows behind it, fused scale / shift / ReLU."""
+    from test_gpu_parity import _random_indices, _tables_from_pairs
+    rng = np.random.default_rng(cin * 7 + cout + int(subm))
+    shape = (9, 34, 30)
+    idx = _random_indices(rng, 3, shape, 2500)
+    if subm:
+        _, pairs, pair_num = orc.rulebook_subm(idx, 3, shape, 3)
+        n_out = len(idx)
+    else:
+        out_idx, pairs, pair_num, _ = orc.rulebook_conv(idx, 3, shape, 3, 2, 1)
+        n_out = len(out_idx)
+    nbr, _ = _tables_from_pairs(pairs, pair_num, len(idx), n_out)
+    feat = rng.standard_normal((len(idx), cin)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, 3, cin, cout)) / np.sqrt(27 * cin)).astype(np.float32)
+    ref = orc.indice_conv(feat, w, pairs, pair_num, n_out, acc64=True)
+    f_t, w_t = dev(feat), dev(w)
+    out = ops.indice_conv(f_t, w_t, dev(nbr), n_out)
+    assert "k_conv_mfma_f32" in ops.last_kernel_name(), ops.last_kernel_name()
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-4, atol=1e-5 * np.abs(ref).max())
+    ops.indice_conv_set_variant(30)
+    try:
+        valu = ops.indice_conv(f_t, w_t, dev(nbr), n_out)
+    finally:
+        ops.indice_conv_set_variant(-1)
+    torch.testing.assert_close(out, valu, rtol=1e-5, atol=1e-5 * float(np.abs(ref).max()))
+    # static capacity: garbage rows behind the live count, fused epilogue
+    cap = n_out + 77
+    nbr_pad = np.concatenate([nbr, rng.integers(0, len(idx), (77, 27)).astype(np.int32)])
+    scale, shift = rng.uniform(0.5, 1.5, cout).astype(np.float32), rng.uniform(-0.2, 0.2, cout).astype(np.float32)
+    n_dev = dev(np.array([n_out], np.int32))
+    got = ops.indice_conv(f_t, w_t, dev(nbr_pad), cap, scale=dev(scale), shift=dev(shift), relu=True, num_out_dev=n_dev)
+    want = np.maximum(ref * scale + shift, 0)
+    np.testing.assert_allclose(got[:n_out].cpu().numpy(), want, rtol=1e-4, atol=1e-5 * np.abs(ref).max())

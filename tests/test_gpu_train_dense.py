@@ -187,7 +187,10 @@ def test_device_trainer_step_matches_cpu_chain():
     for n in names:
         a, b = gp[n].grad.float().cpu(), cp[n].grad.float()
         rel = (a - b).abs().max().item() / (b.abs().max().item() + 1e-20)
-        assert rel < 2e-2, (n, rel)                          # fp32 on both sides; MIOpen vs torch-CPU convolutions, 20 layers deep
+        # fp32 on both sides; MIOpen vs torch-CPU convolutions and (round 4) the fp32 sparse convs on v_mfma_f32_32x32x2_f32, whose
+        # summation order differs from the CPU loop's: 20 layers deep with train-mode BatchNorm, last-bit differences move ReLU
+        # masks (measured 0.5-2.0 % on these parameters; the first BatchNorm weight, the deepest one, sits at the top of that range)
+        assert rel < 4e-2, (n, rel)
 
 
 @pytest.mark.parametrize("c", [16, 32, 64])
