@@ -10,16 +10,17 @@ if [ "$2" != "skip-tests" ]; then
   timeout 900 python -m pytest tests -m gpu -q -x -s > $O/pytest.log 2>&1; echo "pytest rc=$?" | tee $O/pytest.rc
   tail -3 $O/pytest.log
 fi
-timeout 600 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
+timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"     # the driver's own command line
 cut -c1-400 $O/bench.json
 timeout 600 python tools/bf16_error_trace.py > $O/bf16_error_trace.txt 2>&1; echo "trace rc=$?"; tail -32 $O/bf16_error_trace.txt
 if [ "$3" == "yardstick" ]; then
   SERIES_OUT=$O/power_series.json timeout 300 python tools/rpn_yardstick.py > $O/rpn_yardstick.txt 2>&1; echo "yardstick rc=$?"; cat $O/rpn_yardstick.txt | cut -c1-330
 fi
 cd /tmp; export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof1 -- python $R/bench.py --steps 50 --warmup 10 --inflight 1 --no-kernel-table --no-cpu-baseline --no-extra-lines > $O/prof1.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof1 -- python $R/bench.py --profile-run --steps 50 --warmup 10 --inflight 1 --no-kernel-table --no-cpu-baseline --no-extra-lines --no-other-configs > $O/prof1.log 2>&1
 cd $R
 db=$(find $O/prof1 -name "*.db" | head -1); python tools/rocprof_summary.py $db --steps 60 > $O/kernel_stats_bench_bs8_inflight1.txt 2>&1
+python tools/rocprof_summary.py $db --timeline k_vox_init > $O/step_timeline_inflight1.txt 2>&1
 rm -rf $O/prof1; head -12 $O/kernel_stats_bench_bs8_inflight1.txt | cut -c1-70,110-175
 # PMC passes (counters only with --kernel-trace; FETCH_SIZE and WRITE_SIZE cannot share a pass)
 cd /tmp

@@ -20,12 +20,18 @@ def load(d):
     kt = glob.glob(d + "/**/*kernel_trace.csv", recursive=True)
     if not cc:
         return {}, {}
-    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    # values in DISPATCH order (the same instantiation serves several layers: pmc_workload.py's meta says how many launches each
+    # layer issued, main() cuts the sequence accordingly)
+    tmp = collections.defaultdict(lambda: collections.defaultdict(dict))
     for r in csv.DictReader(open(cc[0])):
-        acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        d_ = tmp[r["Kernel_Name"]][r["Counter_Name"]]
+        did = int(r["Dispatch_Id"])
+        d_[did] = d_.get(did, 0.0) + float(r["Counter_Value"])
+    acc = {k: {c: [v[i] for i in sorted(v)] for c, v in cs.items()} for k, cs in tmp.items()}
     dur = collections.defaultdict(list)
     if kt:
-        for r in csv.DictReader(open(kt[0])):
+        rows = sorted(csv.DictReader(open(kt[0])), key=lambda r: int(r["Start_Timestamp"]))
+        for r in rows:
             dur[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     return acc, dur
 
@@ -33,24 +39,33 @@ def load(d):
 def main():
     meta = json.load(open(sys.argv[1]))
     prefix, dirs = sys.argv[2], sys.argv[3:]
-    per = collections.defaultdict(dict)          # signature -> counter -> mean
-    durs = collections.defaultdict(list)
-    for d in dirs:
-        acc, dur = load(d)
-        for k, cs in acc.items():
-            for c, v in cs.items():
-                per[k][c] = sum(v) / len(v)
-        for k, v in dur.items():
-            durs[k].append(sum(v) / len(v))
+    passes = [load(d) for d in dirs]
+    names = sorted({k for acc, _ in passes for k in acc})
+    cursor = collections.defaultdict(int)        # kernel name -> launches already attributed to earlier meta entries
     lines, entries = [], []
     for l in meta["launches"]:
         sig = l["kernel_signature"]
-        full = [k for k in per if sig in k]
+        full = [k for k in names if sig in k]
         if not full:
             lines.append(f"== {sig}: not found in the counter files")
             continue
         k = full[0]
-        m = per[k]
+        lo = cursor[k]
+        hi = lo + int(l.get("count", 10 ** 9))
+        cursor[k] = hi
+        m, dd = {}, []
+        for acc, dur in passes:
+            for c, v in acc.get(k, {}).items():
+                seg = v[lo:hi]
+                if seg:
+                    m[c] = sum(seg) / len(seg)
+            seg = dur.get(k, [])[lo:hi]
+            if seg:
+                dd.append(sum(seg) / len(seg))
+        if not m:
+            lines.append(f"== {sig}: launches {lo}..{hi} not found in the counter files")
+            continue
+        durs = {k: dd}
         us = sum(durs[k]) / max(len(durs[k]), 1)
         lines.append(f"== {sig}   ({l['workload']})")
         lines.append(f"  launch under the profiler    {us:.2f} us (mean over {len(durs[k])} passes)")
