@@ -525,7 +525,29 @@ def measure(step, barrier, steps, warmup, world=1, device=None):
 
 
 # ------------------------------------------------------------------------------------------ CPU baseline
-def cpu_baseline(cpu_state, clouds, gpu_out=None, budget_s=20.0):
+def _match_detections(res, gpu_out):
+    """device vs host (fp32 CPU forward): a CPU detection counts as found when the device has a box of the same frame within
+    0.25 m (BEV centre) and 0.05 in score"""
+    gb, gs, gv = gpu_out["boxes"].float().cpu().numpy(), gpu_out["scores"].float().cpu().numpy(), gpu_out["valid"].cpu().numpy()
+    found = total = 0
+    gpu_counts, cpu_counts = [], [r["num_detections"] for r in res]
+    for f, r in enumerate(res):
+        m = gv[f]
+        gpu_counts.append(int(m.sum()))
+        for bx, sc in zip(r["boxes"], r["scores"]):
+            total += 1
+            if m.any():
+                d = np.hypot(gb[f][m][:, 0] - bx[0], gb[f][m][:, 1] - bx[1])
+                found += bool(((d < 0.25) & (np.abs(gs[f][m] - sc) < 0.05)).any())
+    check = {"frames": len(res), "detections_cpu": cpu_counts, "detections_gpu": gpu_counts,
+             "cpu_detections_found_on_gpu": found, "of": total,
+             "rule": f"found / of >= {MATCH_MIN_FOUND} and |count_gpu - count_cpu| <= {MATCH_COUNT_SLACK} in every frame "
+                     f"(found = same frame, BEV centre within 0.25 m, score within 0.05)"}
+    counts_ok = all(abs(a - b) <= MATCH_COUNT_SLACK for a, b in zip(gpu_counts, cpu_counts))
+    return check, bool(total > 0 and found >= MATCH_MIN_FOUND * total and counts_ok)
+
+
+def cpu_baseline(cpu_state, clouds, gpu_out=None, budget_s=20.0, gpu_out_fp32=None):
     """The same forward on the host through the oracle ("port"): single-threaded oracle for voxelise /
     rulebook / indice_conv / NMS (like the reference's worker-side C++), torch CPU (all cores) for the RPN
     (oracle/cpu_forward.py).  ``gpu_out``: the device results of the same frames -- every CPU detection is looked up in them."""
@@ -551,25 +573,11 @@ def cpu_baseline(cpu_state, clouds, gpu_out=None, budget_s=20.0):
                      f"rulebook/indice_conv/NMS + torch CPU ({cores} threads) for the RPN; {dt:.1f} s",
            "detections": [r["num_detections"] for r in res]}
     if gpu_out is not None:
-        # device (16-bit features) vs host (fp32): a CPU detection counts as found when the device has a box of the same frame
-        # within 0.25 m (BEV centre) and 0.05 in score
-        gb, gs, gv = gpu_out["boxes"].float().cpu().numpy(), gpu_out["scores"].float().cpu().numpy(), gpu_out["valid"].cpu().numpy()
-        found = total = 0
-        gpu_counts = []
-        for f, r in enumerate(res):
-            m = gv[f]
-            gpu_counts.append(int(m.sum()))
-            for bx, sc in zip(r["boxes"], r["scores"]):
-                total += 1
-                if m.any():
-                    d = np.hypot(gb[f][m][:, 0] - bx[0], gb[f][m][:, 1] - bx[1])
-                    found += bool(((d < 0.25) & (np.abs(gs[f][m] - sc) < 0.05)).any())
-        out["check"] = {"frames": n, "detections_cpu": out["detections"], "detections_gpu": gpu_counts,
-                        "cpu_detections_found_on_gpu": found, "of": total,
-                        "rule": f"found / of >= {MATCH_MIN_FOUND} and |count_gpu - count_cpu| <= {MATCH_COUNT_SLACK} in every frame "
-                                f"(found = same frame, BEV centre within 0.25 m, score within 0.05)"}
-        counts_ok = all(abs(a - b) <= MATCH_COUNT_SLACK for a, b in zip(gpu_counts, out["detections"]))
-        out["detections_match_cpu"] = bool(total > 0 and found >= MATCH_MIN_FOUND * total and counts_ok)
+        out["check"], out["detections_match_cpu"] = _match_detections(res, gpu_out)
+    if gpu_out_fp32 is not None:    # the SAME network in fp32 on the device (the reference's default precision)
+        chk, ok = _match_detections(res, gpu_out_fp32)
+        chk.pop("rule")
+        out["check_fp32_device"] = dict(chk, match=ok)
     return out
 
 
@@ -991,7 +999,17 @@ def main():
             "kernels": ktable,              # per-launch table of one step (SURVEY 8d formulas)
         }
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(cpu_state, clouds, out if "boxes" in out else None)
+            out32 = None
+            if args.workload == "car.fhd" and args.dtype != "fp32" and "boxes" in out:
+                from second_amd.models import SecondDetector, CAR_FHD
+                det32 = SecondDetector(CAR_FHD)
+                det32.load_state_dict(cpu_state)
+                det32 = det32.eval().to(device)
+                with torch.no_grad():
+                    out32 = det32.forward_points(points, offsets)
+                torch.cuda.synchronize()
+                del det32
+            res["cpu_baseline"] = cpu_baseline(cpu_state, clouds, out if "boxes" in out else None, gpu_out_fp32=out32)
             res["detections_match_cpu"] = res["cpu_baseline"].pop("detections_match_cpu", None)
         det_count = int(out["valid"].sum().item())
         res["detections_last_step"] = det_count

@@ -142,3 +142,99 @@ def test_reference_train_loop_two_ranks_three_steps(tmp_path):
     assert any(f.startswith("voxelnet-") and f.endswith(".tckpt") for f in files), files
     assert "log.txt" in files or any("log" in f for f in files), files
     assert len([f for f in files if f.startswith("voxelnet-")]) == 1
+
+
+# ------------------------------------------------------------------------------------------ launch.py evaluate
+def _eval_worker(rank, world, port, model_dir, q):
+    try:
+        _eval_body(rank, world, port, model_dir, q)
+    except BaseException:   # noqa: BLE001
+        import traceback
+        q.put((rank, "error", traceback.format_exc()))
+        raise
+
+
+def _eval_body(rank, world, port, model_dir, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      SEC_LAUNCH_NO_ISOLATION="1")
+    for p in (ROOT, os.path.join(ROOT, "second.pytorch_amd"), os.path.join(ROOT, "tests")):
+        sys.path.insert(0, p)
+    torch.set_num_threads(4)
+    import oracle_backend
+    from second_amd import compat, launch
+    compat.install(REF)
+    from google.protobuf import text_format
+    from second.protos import pipeline_pb2
+    from second.pytorch.builder import input_reader_builder
+    cfg = pipeline_pb2.TrainEvalPipelineConfig()
+    text_format.Merge(open(os.path.join(REF, "second/configs/car.fhd.config")).read(), cfg)
+    m = cfg.model.second
+    m.voxel_generator.point_cloud_range[:] = [0, -8.0, -3, 17.6, 8.0, 1]
+    cs = m.target_assigner.class_settings[0]
+    cs.anchor_generator_range.anchor_ranges[:] = [0, -8.0, -1.0, 17.6, 8.0, -1.0]
+    cs.nms_score_threshold = 0.005                          # random-init heads score ~0.01: keep some boxes to compare
+    m.post_center_limit_range[:] = [0, -8.0, -2.2, 17.6, 8.0, 0.8]
+    cfg.eval_input_reader.batch_size = 2
+    cfg.eval_input_reader.preprocess.num_workers = 0
+    cfg_path = os.path.join(os.path.dirname(model_dir), f"eval_w{world}_rank{rank}.config")
+    with open(cfg_path, "w") as f:
+        f.write(text_format.MessageToString(cfg, indent=2))
+    evaluated = []
+
+    def build(input_cfg, model_cfg, training, voxel_generator, target_assigner, multi_gpu=False):
+        ds = SynDataset(voxel_generator, target_assigner, model_cfg.rpn.layer_strides[0] * 8, n=7)   # 7: ragged over 2 ranks
+
+        def evaluation(detections, output_dir):               # the reference's dataset.evaluation contract (train.py:535-545)
+            evaluated.append(len(detections))
+            return {"results": {"official": f"{len(detections)} frames"}, "detail": {}}
+        ds.evaluation = evaluation
+        return ds
+    input_reader_builder.build = build
+    torch.manual_seed(7)                                      # no checkpoint in model_dir: every rank builds the same network
+    os.makedirs(model_dir, exist_ok=True)
+    with oracle_backend.installed():
+        proxy = launch.run_evaluate(REF, cfg_path, model_dir, backend="gloo", device=torch.device("cpu"), accelerate=False)
+    dets = proxy.last_detections
+    summary = [(int(d["metadata"]["image_idx"]), d["box3d_lidar"].float().numpy().round(4).tolist(),
+                d["scores"].float().numpy().round(5).tolist()) for d in dets]
+    q.put((rank, summary, evaluated))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+def _run_eval(world, tmp_path):
+    port = _free_port()
+    model_dir = str(tmp_path / f"eval_model_w{world}")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_eval_worker, args=(r, world, port, model_dir, q)) for r in range(world)]
+    [p.start() for p in procs]
+    res = []
+    for _ in range(world):
+        r = q.get(timeout=900)
+        assert r[1] != "error", r[2]
+        res.append(r)
+    [p.join(60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    return sorted(res), model_dir
+
+
+def test_reference_evaluate_two_ranks_equals_one_rank(tmp_path):
+    """``launch.py evaluate``: the reference's unmodified evaluate() (train.py:433-545), every rank running net(example) on frames
+    rank, rank + world, ...; the detections gathered in dataset order and handed to the dataset's evaluation ONCE, on rank 0."""
+    one, _ = _run_eval(1, tmp_path)
+    two, model_dir = _run_eval(2, tmp_path)
+    ref = one[0][1]
+    assert [s[0] for s in ref] == list(range(7)) and one[0][2] == [7]
+    assert sum(len(s[1]) for s in ref) > 0, "no detections at all: the comparison would be empty"
+    for rank, summary, evaluated in two:
+        assert [s[0] for s in summary] == list(range(7)), "gathered detections are not in dataset order"
+        assert evaluated == ([7] if rank == 0 else []), "dataset.evaluation must run on rank 0 only"
+        for a, b in zip(summary, ref):
+            assert a[0] == b[0]
+            np.testing.assert_allclose(np.array(a[1]).reshape(-1, 7), np.array(b[1]).reshape(-1, 7), atol=1e-4)
+            np.testing.assert_allclose(a[2], b[2], atol=1e-5)
+    # rank 0 wrote result.pkl where evaluate() puts it; the other rank wrote its shard elsewhere
+    assert os.path.isfile(os.path.join(model_dir, "eval_results", "step_0", "result.pkl"))
+    assert os.path.isdir(os.path.join(model_dir, "eval_results_rank1"))
