@@ -285,6 +285,18 @@ def kernel_table(det, points, offsets, reps=30):
                        live_tiles=live, tiles=b_ * th * tw, dense_equivalent_flop=2.0 * b_ * h_ * w_ * 128 * cout * 9,
                        detail=f"128->{cout} k3 ({h_}, {w_}) gathered from {n} sparse rows (no dense image); {live} of {b_ * th * tw} "
                               f"tiles hold sites, the others are written from the bias vector")
+        elif name == "conv2d_nhwc_tiles":
+            x, cout, tl = a[0], a[3], a[4]
+            b_, cin, h_, w_ = x.shape
+            lv, tot = int(a[5].sum().item()), tl.numel()
+            # MFMA fraction on the LIVE tiles' FLOPs (128 pixels x 128 x cout x 9 MACs each); background tiles are one 4 KB store each
+            ent.update(flop=2.0 * lv * 128 * cin * cout * 9, bytes=elt(x.dtype) * (x.numel() * lv // tot + res.numel()), live_tiles=lv, tiles=tot,
+                       dense_equivalent_flop=2.0 * b_ * h_ * w_ * cin * cout * 9,
+                       detail=f"{cin}->{cout} k3 ({h_}, {w_}); {lv} of {tot} tiles can differ from the background vector and are convolved, "
+                              f"the others are filled with it")
+        elif name == "rpn_tile_live":
+            smap = a[0]
+            ent.update(bytes=4 * smap.numel() + 2 * res[0].numel(), detail=f"site map {tuple(smap.shape)} -> live-tile maps of {a[1]} conv layers")
         elif name == "conv1x1_chain":
             x = a[0]
             ent.update(flop=2.0 * x.shape[0] * x.shape[2] * x.shape[3] * 128 * (128 + res.shape[1]), bytes=elt(x.dtype) * (x.numel() + res.numel()),
@@ -787,6 +799,9 @@ def main():
     ap.add_argument("--profile-run", action="store_true",
                     help="for runs under rocprofv3: no self-warming beyond --warmup and ONE timed window (keeps the trace small); the "
                          "printed value is then not a benchmark figure")
+    ap.add_argument("--background-skip", type=int, default=1,
+                    help="RPN convs after the first compute only the tiles a site (or the zero padding) can reach and fill the others "
+                         "with the layer's background vector (bit-identical outputs; 0 = convolve every tile)")
     ap.add_argument("--dry-run", action="store_true", help="launcher plumbing only: ranks report themselves (gloo), no GPU work")
     args = ap.parse_args()
     global WL, SELF_WARM_MIN_S, SELF_WARM_MAX_S, TIMED_MIN_S
@@ -830,6 +845,8 @@ def main():
     # the heads are calibrated on seed-0's cloud on EVERY rank (same network everywhere), not on the rank's own first frame
     from second_amd import synthetic as syn
     det, cpu_state = build_detector(device, dtype, None if args.default_heads else syn.syn_kitti_cloud(0))
+    if hasattr(det.rpn, "skip_background"):
+        det.rpn.skip_background = bool(args.background_skip)
 
     # first subm2 layer (64->64 SubM on the 11x400x352 grid): the largest 64->64 3x3x3 launch of the forward
     timer = ConvCapture(lambda m: m["cin"] == 64 and m["cout"] == 64 and m["kvol"] == 27 and m["n_in"] == m["n_out"]
@@ -970,6 +987,16 @@ def main():
     if args.stages and rank == 0:
         stage_times(det, points, offsets)
 
+    bg_tiles = None
+    if rank == 0 and getattr(det.rpn, "background", None) is not None:
+        if det.rpn.skip_background:
+            lt = [k for k in (ktable or []) if k["op"] in ("conv2d_nhwc_tiles", "conv2d_nhwc_gather")]
+            bg_tiles = {"enabled": True, "live_tiles_per_conv": [k.get("live_tiles") for k in lt] or None, "tiles": lt[0].get("tiles") if lt else None,
+                        "what": "the RPN's 3x3 convs convolve only the 8 x 16 tiles a site of the sparse middle (dilated once per layer) or, "
+                                "from the second conv on, the image border can reach; the other tiles hold the layer's background vector "
+                                "exactly (any weights) and are filled with it.  Data dependent: --background-skip 0 convolves every tile"}
+        else:
+            bg_tiles = {"enabled": False}
     rows_per_frame = None
     if rank == 0:
         with torch.no_grad():   # live voxel / pillar count of this input (what BASELINE quotes the configs on)
@@ -993,6 +1020,7 @@ def main():
                        "rows_per_frame": rows_per_frame,
                        "weights": "seeded random, default heads (tie-dominated top-k)" if args.default_heads or WL["cfg"] != "CAR_FHD"
                                   else "seeded random with trained-like heads (synthetic.randomise_like_trained / sharpen_heads)",
+                       "rpn_background_tiles": bg_tiles,
                        "e2e_from_pinned_host": e2e, "batch1": batch1, "dropin_module_path": dropin},
             "roofline": roof,
             "roofline_mfma": roof_mfma,     # second-largest consumer by kind: the dense RPN conv, MFMA bound

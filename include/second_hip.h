@@ -35,7 +35,7 @@ extern "C" {
 #define SEC_F16 1
 #define SEC_BF16 2
 
-#define SEC_ABI_VERSION 2
+#define SEC_ABI_VERSION 3
 int sec_abi_version(void);
 /* last HIP error string seen by this library (thread-unsafe convenience for diagnostics) */
 const char *sec_last_error(void);
@@ -255,8 +255,30 @@ int sec_rulebook_chain_sorted(const int *indices0, int n0, const int *n0_dev, in
                               int vox_num_points, int vox_max_voxels, int vox_max_points, const int *h_vox_grid3_zyx,
                               int *site_map, void *workspace, size_t workspace_bytes, void *stream);
 int sec_conv2d_nhwc_gather(const void *features, long long feature_rows, const int *site_map, int batch, int h,
-                           int w, const void *packed_weight, const float *bias, int cout, int relu, void *y,
-                           int dtype, void *stream);
+                           int w, const void *packed_weight, const float *bias, int cout, int relu,
+                           const unsigned short *tile_order, const int *live_counts, const void *background, void *y,
+                           int dtype, void *stream);   /* tile_order .. background: see sec_rpn_tile_live; NULL = every tile tests its own map entries */
+
+/* The dense RPN (rpn.py:486-497: Conv2d 3x3 + BatchNorm2d + ReLU, repeated) on a BEV image that is empty except at the sparse
+ * middle's sites (middle.py:206-210): far from every site each layer's feature map is ONE channel vector, exactly and for any
+ * weights, so only the tiles a site can reach need the convolution.
+ * sec_rpn_tile_live: from the site map of sec_sparse_site_map* ([batch][2][h][w]), for the j-th 3x3 / stride 1 / pad 1 conv
+ * of the RPN (j = 0: the first one, sec_conv2d_nhwc_gather; j = 0 .. layers - 1) and frame b: tile_order[j][b][.] = the frame's
+ * 8 x 16 output tiles (row-major indices, ceil(h / 8) x ceil(w / 16) per frame), tiles that can differ from the background
+ * first (ascending), the others from the end backwards; live_counts[j][b] = how many can differ.  A tile can differ when it
+ * holds a pixel within j + 1 steps (Chebyshev) of a site, or -- from the second conv on, where zero padding is no longer the
+ * background -- within j - 1 steps of the image border.  workspace: sec_rpn_tile_live_workspace_bytes (the BEV bitmap).
+ * sec_conv2d_nhwc_tiles: the 128-channel 3x3 / s1 / p1 conv + bias + ReLU of sec_conv2d_nhwc; the live tiles of
+ * tile_order / live_counts (one layer's [batch][tiles] / [batch] slices) are convolved, spread evenly over the XCDs, the others
+ * are filled with `background` (cout values of the feature dtype: the conv's own output on a constant image, which the caller
+ * computes once per network with sec_conv2d_nhwc).  tile_order == NULL: every tile is convolved.
+ * Outputs are bit-identical to sec_conv2d_nhwc when the lists are the ones sec_rpn_tile_live derives. */
+size_t sec_rpn_tile_live_workspace_bytes(int batch, int h, int w);
+int sec_rpn_tile_live(const int *site_map, int batch, int h, int w, int layers, unsigned short *tile_order, int *live_counts,
+                      void *workspace, size_t workspace_bytes, void *stream);
+int sec_conv2d_nhwc_tiles(const void *x, int batch, int h, int w, const void *packed_weight, const float *bias, int cout,
+                          int relu, const unsigned short *tile_order, const int *live_counts, const void *background, void *y,
+                          int dtype, void *stream);
 
 /* Adjoint of sec_sparse_to_dense -- rows[i,:] = dense[indices[i]] -- i.e. the backward of
  * SparseConvTensor.dense() (upstream gets it from autograd through scatter_nd, spconv/__init__.py) and of

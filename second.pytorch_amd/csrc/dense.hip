@@ -342,7 +342,10 @@ template <typename T, int CIN, int TH, int ROLL = 0, bool GATHER = false>
 __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(const T *__restrict__ x, const T *__restrict__ wpk,
                                                             const float *__restrict__ bias, T *__restrict__ y,
                                                             Conv2dParams p, int tiles_y, int tiles_x, int per_xcd,
-                                                            const int *__restrict__ site_map, unsigned feat_bytes) {
+                                                            const int *__restrict__ site_map, unsigned feat_bytes,
+                                                            const unsigned short *__restrict__ tile_order = nullptr,
+                                                            const int *__restrict__ live_counts = nullptr,
+                                                            const T *__restrict__ background = nullptr) {
     static_assert(!GATHER || (ROLL == 2 && CIN == 128), "gather prologue: the shared-row loop on two 64-channel planes");
     constexpr int TW = 16, HW_ = TW + 2, HPIX = (TH + 2) * (TW + 2);
     constexpr int MT = TH * TW / 32;               // 32-pixel m-tiles per wave (4 for an 8 x 16 tile)
@@ -486,8 +489,52 @@ __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(con
             dst[mt] = hal[hp * CH + ((kc_ * 8 + s * 2 + hh) ^ halo_key<CH, HW_, true>(hp))];
         }
     };
-    const int tile = xcd * per_xcd + local;
-    if (local >= per_xcd || tile >= ntile) return;
+    int tile = xcd * per_xcd + local;
+    if (local >= per_xcd) return;
+    // BACKGROUND tiles (sec_conv2d_nhwc_tiles): the caller knows (sec_rpn_tile_live: from the BEV site map, dilated once per conv
+    // layer) that every input pixel such a tile's outputs see holds the SAME channel vector, so every output pixel is the one vector
+    // `background` = this very kernel's result on a constant image (computed once per network) -- stored without DMA, LDS or MFMA.
+    // The LIVE tiles of all frames form one list (frame-major) that is cut into eight equal contiguous runs, one per XCD, so that a
+    // dense frame does not leave its XCD working while the others idle; the remaining workgroups each fill one background tile.
+    {
+        if (tile_order) {
+            const int tpf = tiles_y * tiles_x;
+            int n_live = 0;
+            for (int f = 0; f < p.batch; ++f) n_live += live_counts[f];
+            const int per_live = (n_live + 7) >> 3;
+            int item;
+            bool is_live = false;
+            if (local < per_live) {
+                item = xcd * per_live + local;
+                is_live = item < n_live;
+                if (!is_live) item -= n_live;
+            } else {
+                item = 8 * per_live - n_live + (local - per_live) * 8 + xcd;
+            }
+            int f = 0;
+            if (is_live) {
+                while (item >= live_counts[f]) item -= live_counts[f++];
+                tile = f * tpf + tile_order[f * tpf + item];
+            } else {
+                if (item >= ntile - n_live) return;
+                while (item >= tpf - live_counts[f]) item -= tpf - live_counts[f++];
+                tile = f * tpf + tile_order[f * tpf + tpf - 1 - item];
+                const int trem = tile - f * tpf;
+                const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
+                const int px = tid >> 4, ch = tid & 15;
+                const uint4 v = reinterpret_cast<const uint4 *>(background)[blockIdx.y * 16 + ch];
+                uint4 *y4 = reinterpret_cast<uint4 *>(y);
+                const int ox = x0 + px;
+#pragma unroll
+                for (int ty_ = 0; ty_ < TH; ++ty_) {
+                    const int oy = y0 + ty_;
+                    if (oy < p.h && ox < p.w) y4[(((size_t)f * p.h + oy) * p.w + ox) * (p.cout / 8) + blockIdx.y * 16 + ch] = v;
+                }
+                return;
+            }
+        }
+    }
+    if (tile >= ntile) return;
 #ifdef SEC_CONV_TIMELINE
     long long *tl = g_timeline2;
     long long tl0 = 0, tl1 = 0, tl2 = 0;
@@ -812,7 +859,8 @@ extern "C" __attribute__((visibility("default"))) int sec__debug_timeline2(long 
 
 template <typename T, int CIN, int TH, int ROLL = 0, bool GATHER = false>
 static int launch_conv2d_halo_reg(const void *x, const void *wpk, const float *bias, void *y, const Conv2dParams &p, hipStream_t st,
-                                  const int *site_map = nullptr, unsigned feat_bytes = 0) {
+                                  const int *site_map = nullptr, unsigned feat_bytes = 0, const unsigned short *tile_order = nullptr,
+                                  const int *live_counts = nullptr, const void *background = nullptr) {
     constexpr size_t lds_tile = (size_t)(TH + 2) * 18 * (CIN / 8) * 16;
     // (padding the dynamic LDS to hold 2 instead of 3 workgroups per CU was measured in round 3: slower in every combination)
     const long lds_pad = 0;
@@ -828,7 +876,7 @@ static int launch_conv2d_halo_reg(const void *x, const void *wpk, const float *b
     const int gx = per_xcd * 8;
     set_last_kernel("k_conv2d_halo_reg<%s, %d, %d, %d, %s>", dtype_name<T>(), CIN, TH, ROLL, GATHER ? "true" : "false");
     hipLaunchKernelGGL(fn, dim3(gx, p.cout / 128), dim3(256), lds, st, (const T *)x, (const T *)wpk, bias, (T *)y, p, ty, tx, per_xcd,
-                       site_map, feat_bytes);
+                       site_map, feat_bytes, tile_order, live_counts, (const T *)background);
     return check_launch();
 }
 
@@ -1123,9 +1171,161 @@ static int launch_conv2d(const void *x, const void *wpk, const float *bias, void
     return check_launch();
 }
 
+// ---- which 8 x 16 tiles of the RPN's feature maps can differ from the background ---------------------------------------------
+// The BEV image the RPN starts from is zero except at the sparse middle's sites, so far from any site every layer's feature map is
+// ONE channel vector (act(bias) after the first conv, the conv of that constant after the second, ...): exactly, for any weights.
+// A pixel of layer j's output can differ from that vector only if one of its nine taps could: O_0 = dilate(sites) for the first
+// (gathered) conv -- its padding is the zero the empty image holds -- and O_j = dilate(O_{j-1}) | image border for every later one
+// (zero padding is not the background any more).  One workgroup per frame keeps the frame's bitmap in LDS (h rows of
+// ceil(w / 32) words), dilates it `layers` times and reduces every stage to the conv kernel's tiles.  Per conv j (0 .. layers - 1)
+// and frame b it writes order[j][b][.] = the frame's tile indices, LIVE tiles (holding a pixel of O_j) first in ascending order,
+// background tiles from the END backwards, and counts[j][b] = live tiles: the conv kernel spreads the live list evenly over the
+// XCDs whatever the frames' occupancies are.
+constexpr int kTileLiveThreads = 1024;
+// occupancy bitmap of the BEV image: bits[b][y][k] bit j = site_map[b][0 or 1][y][32 k + j] != 0.  A thread per word, spread over the
+// chip (one workgroup per frame reading its 280 KB of map took 8 us: one CU's L2 -> L1 path)
+__global__ __launch_bounds__(kBlock) void k_bev_bitmap(const int *__restrict__ site_map, int h, int w, int batch, unsigned *__restrict__ bits) {
+    const int wr = (w + 31) >> 5, words = h * wr;
+    const int g = blockIdx.x * kBlock + threadIdx.x;
+    if (g >= batch * words) return;
+    const int b = g / words, i = g - b * words;
+    const int yy = i / wr, k = i - yy * wr;
+    const long long plane = (long long)h * w;
+    const int *m0 = site_map + (long long)b * 2 * plane + (long long)yy * w, *m1 = m0 + plane;
+    unsigned out = 0u;
+    if ((w & 3) == 0) {           // rows are 16-byte aligned: eight independent 16-byte loads per plane
+        const int4 *r0 = reinterpret_cast<const int4 *>(m0), *r1 = reinterpret_cast<const int4 *>(m1);
+        int4 va[8], vb[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int px = 32 * k + 4 * j;
+            va[j] = px < w ? r0[px >> 2] : make_int4(0, 0, 0, 0);
+            vb[j] = px < w ? r1[px >> 2] : make_int4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            out |= ((unsigned)((va[j].x | vb[j].x) != 0) | (unsigned)((va[j].y | vb[j].y) != 0) << 1 |
+                    (unsigned)((va[j].z | vb[j].z) != 0) << 2 | (unsigned)((va[j].w | vb[j].w) != 0) << 3) << (4 * j);
+    } else {
+        for (int j = 0; j < 32; ++j) {
+            const int px = 32 * k + j;
+            if (px < w && (m0[px] | m1[px])) out |= 1u << j;
+        }
+    }
+    bits[g] = out;
+}
+
+__global__ __launch_bounds__(kTileLiveThreads) void k_rpn_tile_live(const unsigned *__restrict__ bits, int h, int w, int layers, int batch,
+                                                                     unsigned short *__restrict__ order, int *__restrict__ counts) {
+    extern __shared__ unsigned tl_bits[];
+    constexpr int NT = kTileLiveThreads;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wr = (w + 31) >> 5, words = h * wr;
+    const int ty = (h + 7) / 8, tx = (w + 15) / 16, tiles = ty * tx;
+    unsigned *cur = tl_bits, *nxt = tl_bits + words;
+    __shared__ int s_wave[NT / 64], s_run;
+    for (int i = tid; i < words; i += NT) cur[i] = bits[(long long)b * words + i];
+    __syncthreads();
+    const unsigned last_valid = (w & 31) ? (1u << (w & 31)) - 1u : ~0u;
+    for (int l = 0; l < layers; ++l) {
+        for (int i = tid; i < words; i += NT) {
+            const int yy = i / wr, k = i - yy * wr;
+            unsigned acc = 0u;
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy) {
+                const int y2 = yy + dy;
+                if (y2 < 0 || y2 >= h) continue;
+                const unsigned c = cur[y2 * wr + k];
+                const unsigned lf = k > 0 ? cur[y2 * wr + k - 1] : 0u, rt = k + 1 < wr ? cur[y2 * wr + k + 1] : 0u;
+                acc |= c | (c << 1) | (lf >> 31) | (c >> 1) | (rt << 31);
+            }
+            if (l >= 1) {
+                if (yy == 0 || yy == h - 1) acc = ~0u;
+                if (k == 0) acc |= 1u;
+                if (k == ((w - 1) >> 5)) acc |= 1u << ((w - 1) & 31);
+            }
+            nxt[i] = k == wr - 1 ? acc & last_valid : acc;
+        }
+        if (tid == 0) s_run = 0;
+        __syncthreads();
+        {
+            unsigned short *ord = order + ((long long)l * batch + b) * tiles;
+            for (int base = 0; base < tiles; base += NT) {
+                const int t = base + tid;
+                bool any = false;
+                if (t < tiles) {
+                    const int tyi = t / tx, txi = t - tyi * tx;
+                    unsigned acc = 0u;
+                    for (int r = 0; r < 8; ++r) {
+                        const int yy = tyi * 8 + r;
+                        if (yy < h) acc |= (nxt[yy * wr + ((txi * 16) >> 5)] >> ((txi * 16) & 31)) & 0xffffu;
+                    }
+                    any = acc != 0u;
+                }
+                const unsigned long long bal = __ballot(any);
+                if (lane == 0) s_wave[wv] = __popcll(bal);
+                __syncthreads();
+                int before = s_run, total = 0;
+#pragma unroll
+                for (int i2 = 0; i2 < NT / 64; ++i2) {
+                    const int c = s_wave[i2];
+                    if (i2 < wv) before += c;
+                    total += c;
+                }
+                const int rank = before + __popcll(bal & ((1ull << lane) - 1ull));     // live tiles before this one in the frame
+                if (t < tiles) {
+                    if (any) ord[rank] = (unsigned short)t;
+                    else ord[tiles - 1 - (t - rank)] = (unsigned short)t;                   // background: from the end backwards
+                }
+                __syncthreads();
+                if (tid == 0) s_run += total;
+                __syncthreads();
+            }
+            if (tid == 0) counts[l * batch + b] = s_run;
+        }
+        unsigned *t_ = cur; cur = nxt; nxt = t_;
+        __syncthreads();
+    }
+}
+
 }  // namespace sec
 
 using namespace sec;
+
+SEC_API size_t sec_rpn_tile_live_workspace_bytes(int batch, int h, int w) {
+    if (batch <= 0 || h <= 0 || w <= 0) return 0;
+    return align_up((size_t)batch * h * ((w + 31) / 32) * 4);
+}
+
+SEC_API int sec_rpn_tile_live(const int *site_map, int batch, int h, int w, int layers, unsigned short *tile_order, int *live_counts,
+                              void *workspace, size_t workspace_bytes, void *stream) {
+    if (!site_map || !tile_order || !live_counts || !workspace || batch <= 0 || h <= 0 || w <= 0 || layers <= 0) return SEC_E_INVALID;
+    if (workspace_bytes < sec_rpn_tile_live_workspace_bytes(batch, h, w)) return SEC_E_WORKSPACE;
+    const int words = h * ((w + 31) / 32);
+    const size_t lds = (size_t)2 * words * 4;
+    if (lds > 60 * 1024 || (long long)((h + 7) / 8) * ((w + 15) / 16) > 65535) return SEC_E_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_bev_bitmap, dim3(div_up((long long)batch * words, kBlock)), dim3(kBlock), 0, st, site_map, h, w, batch, (unsigned *)workspace);
+    hipLaunchKernelGGL(k_rpn_tile_live, dim3(batch), dim3(kTileLiveThreads), lds, st, (const unsigned *)workspace, h, w, layers, batch, tile_order,
+                       live_counts);
+    return check_launch();
+}
+
+SEC_API int sec_conv2d_nhwc_tiles(const void *x, int batch, int h, int w, const void *packed_weight, const float *bias, int cout,
+                                  int relu, const unsigned short *tile_order, const int *live_counts, const void *background,
+                                  void *y, int dtype, void *stream) {
+    if (!x || !packed_weight || !y || batch <= 0 || h <= 0 || w <= 0 || (tile_order && (!background || !live_counts))) return SEC_E_INVALID;
+    if (cout % 128 || (dtype != SEC_BF16 && dtype != SEC_F16)) return SEC_E_UNSUPPORTED;
+    Conv2dParams p;
+    p.batch = batch; p.h = h; p.w = w; p.cin = 128; p.cout = cout; p.ksize = 3; p.stride = 1; p.pad = 1;
+    p.relu = relu & 1; p.zskip = 0; p.stagger = 0;
+    p.ho = h; p.wo = w;
+    p.m = (long long)batch * h * w;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SEC_BF16)
+        return launch_conv2d_halo_reg<__hip_bfloat16, 128, 8, 2>(x, packed_weight, bias, y, p, st, nullptr, 0, tile_order, live_counts, background);
+    return launch_conv2d_halo_reg<__half, 128, 8, 2>(x, packed_weight, bias, y, p, st, nullptr, 0, tile_order, live_counts, background);
+}
 
 SEC_API size_t sec_conv2d_packed_weight_bytes(int cout, int cin, int ksize, int dtype) {
     if (dtype == SEC_F32 || cout <= 0 || cin <= 0 || cin % 64 || cout % 64 || ksize <= 0) return 0;
@@ -1165,8 +1365,10 @@ SEC_API int sec_conv2d_nhwc(const void *x, int batch, int h, int w, int cin, con
 }
 
 SEC_API int sec_conv2d_nhwc_gather(const void *features, long long feature_rows, const int *site_map, int batch, int h, int w,
-                                   const void *packed_weight, const float *bias, int cout, int relu, void *y, int dtype, void *stream) {
+                                   const void *packed_weight, const float *bias, int cout, int relu, const unsigned short *tile_order,
+                                   const int *live_counts, const void *background, void *y, int dtype, void *stream) {
     if (!site_map || !packed_weight || !y || batch <= 0 || h <= 0 || w <= 0 || feature_rows < 0 || (!features && feature_rows > 0)) return SEC_E_INVALID;
+    if (tile_order && (!live_counts || !background)) return SEC_E_INVALID;
     if (cout % 128 || (dtype != SEC_BF16 && dtype != SEC_F16) || feature_rows * 128 >= (1ll << 31) ||
         (long long)h * w * 8 >= (1ll << 31)) return SEC_E_UNSUPPORTED;
     Conv2dParams p;
@@ -1176,8 +1378,9 @@ SEC_API int sec_conv2d_nhwc_gather(const void *features, long long feature_rows,
     p.m = (long long)batch * h * w;
     hipStream_t st = (hipStream_t)stream;
     const unsigned fb = (unsigned)(feature_rows * 128);
-    if (dtype == SEC_BF16) return launch_conv2d_halo_reg<__hip_bfloat16, 128, 8, 2, true>(features, packed_weight, bias, y, p, st, site_map, fb);
-    return launch_conv2d_halo_reg<__half, 128, 8, 2, true>(features, packed_weight, bias, y, p, st, site_map, fb);
+    if (dtype == SEC_BF16)
+        return launch_conv2d_halo_reg<__hip_bfloat16, 128, 8, 2, true>(features, packed_weight, bias, y, p, st, site_map, fb, tile_order, live_counts, background);
+    return launch_conv2d_halo_reg<__half, 128, 8, 2, true>(features, packed_weight, bias, y, p, st, site_map, fb, tile_order, live_counts, background);
 }
 
 SEC_API int sec_conv1x1_chain_nhwc(const void *x, long long pixels, const void *packed_w1, const float *bias1, int relu1,

@@ -576,6 +576,24 @@ class RPNInference(nn.Module):
         self.chain_tail = (single and self.use_hip and tuple(wl.shape) == (128, 128, 1, 1) and self.cfgs[-1] == ([1, 1], [0, 0])
                            and self.ups[-1] == 1
                            and self.head_cout in (64, 128))
+        # Background tiles (sec_conv2d_nhwc_tiles): with the first conv gathered from the sparse rows the site map is at hand, and
+        # far from every site each layer's map is ONE channel vector (exact for any weights: DESIGN.md section 4).  background[i] =
+        # that vector at the OUTPUT of conv i, from the conv kernels themselves on a constant image; convs 1.. then compute only
+        # the tiles a site (or, from the second conv on, the zero padding) can reach.  skip_background = False computes every tile.
+        self.skip_background = True
+        self.background = None
+        self.last_live_counts = None       # [convs, B] int32 on the device: live tiles per conv and frame of the last forward (bench / tests)
+        convs = [i for kind, i in self.plan if kind == "c"]
+        if (self.gather_packed is not None and len(convs) >= 2 and convs == list(range(len(convs)))
+                and all(tuple(self.ws[i].shape) == (128, 128, 3, 3) and self.cfgs[i] == ([1, 1], [1, 1]) and self.ups[i] == 1 for i in convs)):
+            with torch.no_grad():
+                bg, img = [], torch.zeros((1, 128, 16, 32), dtype=dtype, device=w0.device).contiguous(memory_format=torch.channels_last)
+                for i in convs:
+                    out = ops.conv2d_nhwc(img, self.packed[i], self.bs[i], 128, 3, 1, 1, relu=True)
+                    c = out[0, :, 8, 16].clone().contiguous()                    # an interior pixel: all nine taps inside
+                    bg.append(c)
+                    img = c.view(1, 128, 1, 1).expand(1, 128, 16, 32).contiguous(memory_format=torch.channels_last)
+            self.background = bg
 
     def _conv(self, x, i, sparse_input=False):
         w, b, (s, p) = self.ws[i], self.bs[i], self.cfgs[i]
@@ -601,10 +619,19 @@ class RPNInference(nn.Module):
                 gather = x
             else:
                 x = x.dense()
+        live = None
         for kind, i in self.plan:
             if kind == "c" and gather is not None:
-                x = ops.conv2d_nhwc_gather(gather.features, gather.site_map(), self.gather_packed, self.bs[i], self.ws[i].shape[0], relu=True)
+                sm = gather.site_map()
+                if self.background is not None and self.skip_background:
+                    live, self.last_live_counts = ops.rpn_tile_live(sm, len(self.background))
+                    x = ops.conv2d_nhwc_gather(gather.features, sm, self.gather_packed, self.bs[i], self.ws[i].shape[0], relu=True,
+                                               tile_order=live[0], live_counts=self.last_live_counts[0], background=self.background[0])
+                else:
+                    x = ops.conv2d_nhwc_gather(gather.features, sm, self.gather_packed, self.bs[i], self.ws[i].shape[0], relu=True)
                 gather, first = None, False
+            elif kind == "c" and live is not None:
+                x = ops.conv2d_nhwc_tiles(x, self.packed[i], self.bs[i], 128, live[i], self.last_live_counts[i], self.background[i], relu=True)
             elif kind == "c":
                 x = self._conv(x, i, sparse_input=first)
                 first = False

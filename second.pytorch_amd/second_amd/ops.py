@@ -736,7 +736,7 @@ def gather_channel_perm(c, d):
 
 
 @_traced("conv2d_nhwc_gather")
-def conv2d_nhwc_gather(features, site_map, packed, bias, cout, relu=True):
+def conv2d_nhwc_gather(features, site_map, packed, bias, cout, relu=True, tile_order=None, live_counts=None, background=None):
     """3x3 / stride 1 / pad 1 conv + bias + ReLU of ``SparseConvTensor.dense().view(B, 128, H, W)`` read straight from the
     sparse tensor's rows ``features`` [rows, 64] through ``site_map`` [B, 2, H, W] (:func:`sparse_site_map`): no dense image,
     tiles without sites cost a map lookup.  ``packed`` = conv2d_pack_weight(w[:, gather_channel_perm(64, 2)])."""
@@ -745,9 +745,55 @@ def conv2d_nhwc_gather(features, site_map, packed, bias, cout, relu=True):
     b, d, h, w = site_map.shape
     assert d == 2 and site_map.is_contiguous()
     y = torch.empty((b, int(cout), h, w), dtype=features.dtype, device=features.device, memory_format=torch.channels_last)
+    if tile_order is not None:      # live tiles from rpn_tile_live (layer 0): spread evenly over the XCDs, the others filled with `background`
+        rt.require_gpu(tile_order, live_counts, background)
+        assert tile_order.dtype == torch.int16 and tile_order.is_contiguous() and tile_order.shape[0] == b
+        assert live_counts.dtype == torch.int32 and live_counts.numel() == b and background.dtype == features.dtype and background.numel() == int(cout)
     rc = rt.lib().sec_conv2d_nhwc_gather(rt.ptr(features), features.shape[0], rt.ptr(site_map), b, h, w, rt.ptr(packed), rt.ptr(bias),
-                                         int(cout), int(bool(relu)), rt.ptr(y), rt.dtype_code(features.dtype), rt.stream())
+                                         int(cout), int(bool(relu)), rt.ptr(tile_order) if tile_order is not None else None,
+                                         rt.ptr(live_counts) if tile_order is not None else None,
+                                         rt.ptr(background) if tile_order is not None else None, rt.ptr(y),
+                                         rt.dtype_code(features.dtype), rt.stream())
     rt.check(rc, "sec_conv2d_nhwc_gather")
+    return y
+
+
+@_traced("rpn_tile_live")
+def rpn_tile_live(site_map, layers):
+    """order [layers, B, tiles] int16 + counts [layers, B] int32 for the first ``layers`` 3x3 convs of the RPN (layer 0 = the gathered
+    one): per frame the 8 x 16 tiles (row-major indices) that can differ from the layer's background first, the others from the
+    end backwards; counts = how many can differ (sec_rpn_tile_live)."""
+    rt.require_gpu(site_map)
+    assert site_map.dtype == torch.int32 and site_map.dim() == 4 and site_map.shape[1] == 2 and site_map.is_contiguous()
+    b, _, h, w = site_map.shape
+    tiles = ((h + 7) // 8) * ((w + 15) // 16)
+    assert tiles < 32768
+    order = torch.empty((int(layers), b, tiles), dtype=torch.int16, device=site_map.device)
+    counts = torch.empty((int(layers), b), dtype=torch.int32, device=site_map.device)
+    ws_bytes = rt.lib().sec_rpn_tile_live_workspace_bytes(b, h, w)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=site_map.device)
+    rt.check(rt.lib().sec_rpn_tile_live(rt.ptr(site_map), b, h, w, int(layers), rt.ptr(order), rt.ptr(counts), rt.ptr(ws), ws_bytes,
+                                        rt.stream()), "sec_rpn_tile_live")
+    return order, counts
+
+
+@_traced("conv2d_nhwc_tiles")
+def conv2d_nhwc_tiles(x, packed, bias, cout, tile_order, live_counts, background, relu=True):
+    """3x3 / stride 1 / pad 1 conv + bias + ReLU on a channels_last [B,128,H,W] tensor; only the live tiles of ``tile_order`` [B, tiles] /
+    ``live_counts`` [B] (one layer of :func:`rpn_tile_live`) are convolved, the others are filled with ``background`` [cout]
+    (sec_conv2d_nhwc_tiles)."""
+    rt.require_gpu(x, packed, tile_order, live_counts, background)
+    assert x.dim() == 4 and x.shape[1] == 128 and x.is_contiguous(memory_format=torch.channels_last)
+    b, _, h, w = x.shape
+    tiles = ((h + 7) // 8) * ((w + 15) // 16)
+    assert tile_order.dtype == torch.int16 and tile_order.is_contiguous() and tuple(tile_order.shape) == (b, tiles)
+    assert live_counts.dtype == torch.int32 and live_counts.is_contiguous() and live_counts.numel() == b
+    assert background.dtype == x.dtype and background.numel() == int(cout) and background.is_contiguous()
+    y = torch.empty((b, int(cout), h, w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    rc = rt.lib().sec_conv2d_nhwc_tiles(rt.ptr(x), b, h, w, rt.ptr(packed), rt.ptr(bias), int(cout), int(bool(relu)),
+                                        rt.ptr(tile_order), rt.ptr(live_counts), rt.ptr(background), rt.ptr(y),
+                                        rt.dtype_code(x.dtype), rt.stream())
+    rt.check(rc, "sec_conv2d_nhwc_tiles")
     return y
 
 

@@ -144,7 +144,7 @@ def dense_stage_errors(calls, gpu, det_cpu, refs, ulp, single_frames=2):
     rows = []
     blk = list(det_cpu.rpn.blocks[0].children())
     rpn = gpu.rpn
-    convs = [c for c in calls if c[0] in ("conv2d_nhwc_gather", "conv2d_nhwc")]
+    convs = [c for c in calls if c[0] in ("conv2d_nhwc_gather", "conv2d_nhwc", "conv2d_nhwc_tiles")]
     cum, rng = [0.0] * len(convs), [0.0] * len(convs)
     with torch.no_grad():
         for f, r in enumerate(refs):            # fp32 CPU activation after every Conv + BN + ReLU of the block, frame by frame
@@ -161,7 +161,7 @@ def dense_stage_errors(calls, gpu, det_cpu, refs, ulp, single_frames=2):
             assert i == len(convs), (i, len(convs))
     prev = None
     for i, (name, a, kw, res) in enumerate(convs):
-        ent = {"layer": f"rpn{i}", "kind": "3x3 gathered from sparse rows" if name == "conv2d_nhwc_gather" else "3x3", "cin": 128,
+        ent = {"layer": f"rpn{i}", "kind": "3x3 gathered from sparse rows" if name == "conv2d_nhwc_gather" else "3x3 (live tiles)" if name == "conv2d_nhwc_tiles" else "3x3", "cin": 128,
                "cout": int(res.shape[1]), "cumulative": cum[i], "range": rng[i]}
         if single_frames:
             got = res[:single_frames].float().cpu().numpy()

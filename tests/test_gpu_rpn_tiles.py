@@ -1,0 +1,154 @@
+"""Background tiles of the dense RPN (sec_rpn_tile_live + sec_conv2d_nhwc_tiles): far from every site of the sparse middle each
+RPN layer's feature map is one channel vector, so only tiles a site (or the zero padding) can reach are convolved.  The map is
+checked against a numpy dilation, the RPN with and without the skipping must agree BIT FOR BIT on networks whose background is
+not zero (rpn.py:486-497 semantics: Conv2d 3x3 + BatchNorm2d + ReLU with arbitrary statistics)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from second_amd import ops as o
+    return o
+
+
+def _dilate(m):
+    p = np.zeros((m.shape[0] + 2, m.shape[1] + 2), bool)
+    p[1:-1, 1:-1] = m
+    out = np.zeros_like(m)
+    for dy in range(3):
+        for dx in range(3):
+            out |= p[dy:dy + m.shape[0], dx:dx + m.shape[1]]
+    return out
+
+
+def _live_reference(sites, layers):
+    """sites [B, H, W] bool -> live [layers, B, tiles]; layer 0 = the first (gathered) conv"""
+    b, h, w = sites.shape
+    ty, tx = (h + 7) // 8, (w + 15) // 16
+    out = np.zeros((layers, b, ty * tx), np.uint8)
+    for f in range(b):
+        cur = sites[f]
+        for l in range(layers):
+            cur = _dilate(cur)
+            if l >= 1:                               # zero padding is the background only for the first conv (empty image == 0)
+                cur[0, :] = cur[-1, :] = True
+                cur[:, 0] = cur[:, -1] = True
+            pad = np.zeros((ty * 8, tx * 16), bool)
+            pad[:h, :w] = cur
+            out[l, f] = pad.reshape(ty, 8, tx, 16).any(axis=(1, 3)).reshape(-1)
+    return out
+
+
+@pytest.mark.parametrize("batch,h,w,n", [(3, 200, 176, 900), (2, 37, 50, 12), (1, 8, 16, 1), (2, 64, 33, 0), (2, 120, 97, 3000),
+                                          (1, 200, 176, 1), (8, 200, 176, 6000), (1, 400, 400, 5000)])
+def test_rpn_tile_live_matches_a_numpy_dilation(ops, batch, h, w, n):
+    rng = np.random.default_rng(h * 7 + n)
+    m = np.zeros((batch, 2, h, w), np.int32)
+    if n:
+        b, z = rng.integers(0, batch, n), rng.integers(0, 2, n)
+        y, x = rng.integers(0, h, n), rng.integers(0, w, n)
+        if n > 100:                                  # clusters: whole regions stay empty; plus the four corners
+            y = y % max(h // 3, 1)
+            y[:4], x[:4] = [0, 0, h - 1, h - 1], [0, w - 1, 0, w - 1]
+        m[b, z, y, x] = rng.integers(1, 1000, n)
+        if batch > 1:
+            m[batch - 1] = 0                          # an empty frame
+    order, counts = ops.rpn_tile_live(torch.from_numpy(m).cuda(), 6)
+    ref = _live_reference((m != 0).any(1), 6)
+    order, counts = order.cpu().numpy().astype(np.int64), counts.cpu().numpy()
+    tiles = ref.shape[2]
+    np.testing.assert_array_equal(counts, ref.sum(2))
+    for l in range(6):
+        for f in range(batch):
+            c = counts[l, f]
+            np.testing.assert_array_equal(order[l, f, :c], np.flatnonzero(ref[l, f]))                 # live: ascending
+            np.testing.assert_array_equal(order[l, f, c:][::-1], np.flatnonzero(ref[l, f] == 0))     # background: from the end
+    if h >= 24 and w >= 48 and n <= 1:
+        assert counts[1].sum() < batch * tiles            # an empty / one-site frame keeps background tiles
+
+
+def _rpn_pair(dtype, seed):
+    from second_amd.models import RPNV2, RPNInference
+    torch.manual_seed(seed)
+    rpn = RPNV2().cuda().eval()
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    for mod in rpn.modules():                         # statistics that leave a NON-ZERO background after every layer
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.copy_(torch.empty(mod.num_features).uniform_(-0.3, 0.3, generator=g))
+            mod.running_var.copy_(torch.empty(mod.num_features).uniform_(0.5, 1.5, generator=g))
+            mod.bias.data.copy_(torch.empty(mod.num_features).uniform_(-0.2, 0.4, generator=g))
+            mod.weight.data.copy_(torch.empty(mod.num_features).uniform_(0.5, 1.5, generator=g))
+    return RPNInference(rpn, dtype)
+
+
+def _bev(features, smap):
+    """what RPNInference needs of models.SparseBEV: the rows and their site map"""
+    from second_amd import models
+
+    class BEV(models.SparseBEV):
+        def __init__(self):
+            self.features = features
+
+        def site_map(self):
+            return smap
+    return BEV()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("batch,h,w,n", [(2, 200, 176, 1500), (3, 50, 70, 200), (1, 40, 48, 1), (2, 33, 17, 0)])
+def test_rpn_with_background_tiles_is_bit_identical_to_the_full_convs(ops, dtype, batch, h, w, n):
+    rng = np.random.default_rng(n + h)
+    idx = np.zeros((0, 4), np.int32)
+    if n:
+        idx = np.stack([rng.integers(0, batch, n), rng.integers(0, 2, n), rng.integers(0, h, n) % max(h // 2, 1), rng.integers(0, w, n)], 1)
+        idx[0, 2:] = [0, 0]                                                # on the image border
+        if n > 1:
+            idx[1, 2:] = [h // 2 - 1, w - 1]
+        idx = np.unique(idx, axis=0).astype(np.int32)
+    feat = torch.randn(max(len(idx), 1), 64, device="cuda").to(dtype)
+    smap = ops.sparse_site_map(torch.from_numpy(idx).cuda(), batch, [2, h, w])
+    rpn = _rpn_pair(dtype, 3)
+    assert rpn.background is not None and len(rpn.background) == 6
+    assert all(float(c.float().abs().max()) > 0 for c in rpn.background), "the test needs a non-zero background"
+    bev = _bev(feat, smap)
+    with torch.no_grad():
+        rpn.skip_background = True
+        a = {k: v.clone() for k, v in rpn(bev).items()}
+        counts = rpn.last_live_counts.sum(dim=1).cpu().numpy()
+        rpn.skip_background = False
+        b = rpn(bev)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    tiles = batch * ((h + 7) // 8) * ((w + 15) // 16)
+    assert (counts <= tiles).all() and (np.diff(counts) >= 0).all()
+    if h >= 40 and n <= 1:
+        assert counts[1] < tiles, "nothing was skipped: the comparison would be vacuous"
+
+
+def test_detector_with_and_without_background_tiles_gives_identical_detections():
+    from second_amd.models import SecondDetector, CAR_FHD
+    from second_amd import synthetic as syn
+    clouds = [syn.syn_kitti_cloud(s) for s in range(2)]
+    pts, offs = syn.batch_clouds(clouds)
+    pts, offs = torch.from_numpy(pts).cuda(), torch.from_numpy(offs).cuda()
+    torch.manual_seed(0)
+    det = SecondDetector(CAR_FHD).cuda().eval()
+    g = torch.Generator().manual_seed(1)
+    for m in det.modules():
+        if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+            m.running_mean.copy_(torch.empty(m.num_features).uniform_(-0.1, 0.1, generator=g))
+            m.running_var.copy_(torch.empty(m.num_features).uniform_(0.5, 1.5, generator=g))
+            m.bias.data.copy_(torch.empty(m.num_features).uniform_(-0.2, 0.3, generator=g))
+    det.prepare_inference(torch.bfloat16)
+    outs = []
+    with torch.no_grad():
+        for skip in (True, False):
+            det.rpn.skip_background = skip
+            o = det.forward_points(pts, offs, static=True)
+            outs.append({k: v.clone() for k, v in o.items() if isinstance(v, torch.Tensor)})
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), k
