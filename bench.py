@@ -292,8 +292,8 @@ def kernel_table(det, points, offsets, reps=30):
             # MFMA fraction on the LIVE tiles' FLOPs (128 pixels x 128 x cout x 9 MACs each); background tiles are one 4 KB store each
             ent.update(flop=2.0 * lv * 128 * cin * cout * 9, bytes=elt(x.dtype) * (x.numel() * lv // tot + res.numel()), live_tiles=lv, tiles=tot,
                        dense_equivalent_flop=2.0 * b_ * h_ * w_ * cin * cout * 9,
-                       detail=f"{cin}->{cout} k3 ({h_}, {w_}); {lv} of {tot} tiles can differ from the background vector and are convolved, "
-                              f"the others are filled with it")
+                       detail=f"{cin}->{cout} k3 ({h_}, {w_}); {lv} of {tot} tiles are within reach of a site and are convolved, "
+                              f"the others are copied from the empty frame's output")
         elif name == "rpn_tile_live":
             smap = a[0]
             ent.update(bytes=4 * smap.numel() + 2 * res[0].numel(), detail=f"site map {tuple(smap.shape)} -> live-tile maps of {a[1]} conv layers")
@@ -988,13 +988,13 @@ def main():
         stage_times(det, points, offsets)
 
     bg_tiles = None
-    if rank == 0 and getattr(det.rpn, "background", None) is not None:
+    if rank == 0 and getattr(det.rpn, "background_convs", 0):
         if det.rpn.skip_background:
             lt = [k for k in (ktable or []) if k["op"] in ("conv2d_nhwc_tiles", "conv2d_nhwc_gather")]
             bg_tiles = {"enabled": True, "live_tiles_per_conv": [k.get("live_tiles") for k in lt] or None, "tiles": lt[0].get("tiles") if lt else None,
-                        "what": "the RPN's 3x3 convs convolve only the 8 x 16 tiles a site of the sparse middle (dilated once per layer) or, "
-                                "from the second conv on, the image border can reach; the other tiles hold the layer's background vector "
-                                "exactly (any weights) and are filled with it.  Data dependent: --background-skip 0 convolves every tile"}
+                        "what": "conv j of the RPN (j = 0..5) convolves only the 8 x 16 tiles a site of the sparse middle can reach within j + 1 "
+                                "steps; the other tiles equal the network's output for an EMPTY frame at that position exactly (any weights) "
+                                "and are copied from it.  Data dependent: --background-skip 0 convolves every tile"}
         else:
             bg_tiles = {"enabled": False}
     rows_per_frame = None

@@ -260,18 +260,18 @@ int sec_conv2d_nhwc_gather(const void *features, long long feature_rows, const i
                            int dtype, void *stream);   /* tile_order .. background: see sec_rpn_tile_live; NULL = every tile tests its own map entries */
 
 /* The dense RPN (rpn.py:486-497: Conv2d 3x3 + BatchNorm2d + ReLU, repeated) on a BEV image that is empty except at the sparse
- * middle's sites (middle.py:206-210): far from every site each layer's feature map is ONE channel vector, exactly and for any
- * weights, so only the tiles a site can reach need the convolution.
+ * middle's sites (middle.py:206-210): a pixel of the j-th conv's output sees the image only within j + 1 steps, so a tile
+ * farther than that from every site holds exactly what the same network computes for an EMPTY frame at that position -- for
+ * any weights -- and need not be convolved.
  * sec_rpn_tile_live: from the site map of sec_sparse_site_map* ([batch][2][h][w]), for the j-th 3x3 / stride 1 / pad 1 conv
- * of the RPN (j = 0: the first one, sec_conv2d_nhwc_gather; j = 0 .. layers - 1) and frame b: tile_order[j][b][.] = the frame's
- * 8 x 16 output tiles (row-major indices, ceil(h / 8) x ceil(w / 16) per frame), tiles that can differ from the background
- * first (ascending), the others from the end backwards; live_counts[j][b] = how many can differ.  A tile can differ when it
- * holds a pixel within j + 1 steps (Chebyshev) of a site, or -- from the second conv on, where zero padding is no longer the
- * background -- within j - 1 steps of the image border.  workspace: sec_rpn_tile_live_workspace_bytes (the BEV bitmap).
+ * of the RPN (j = 0: the first one, sec_conv2d_nhwc_gather; j = 0 .. layers - 1 <= 7) and frame b: tile_order[j][b][.] = the
+ * frame's 8 x 16 output tiles (row-major indices, ceil(h / 8) x ceil(w / 16) per frame), the LIVE tiles -- those holding a
+ * pixel within j + 1 steps (Chebyshev) of a site -- first (ascending), the others from the end backwards;
+ * live_counts[j][b] = the number of live tiles.  workspace: sec_rpn_tile_live_workspace_bytes (the BEV bitmap).
  * sec_conv2d_nhwc_tiles: the 128-channel 3x3 / s1 / p1 conv + bias + ReLU of sec_conv2d_nhwc; the live tiles of
  * tile_order / live_counts (one layer's [batch][tiles] / [batch] slices) are convolved, spread evenly over the XCDs, the others
- * are filled with `background` (cout values of the feature dtype: the conv's own output on a constant image, which the caller
- * computes once per network with sec_conv2d_nhwc).  tile_order == NULL: every tile is convolved.
+ * are copied from `background` = this layer's output for an empty frame, [h][w][cout] in the feature dtype, which the caller
+ * computes once per network and map size with the same entry points.  tile_order == NULL: every tile is convolved.
  * Outputs are bit-identical to sec_conv2d_nhwc when the lists are the ones sec_rpn_tile_live derives. */
 size_t sec_rpn_tile_live_workspace_bytes(int batch, int h, int w);
 int sec_rpn_tile_live(const int *site_map, int batch, int h, int w, int layers, unsigned short *tile_order, int *live_counts,

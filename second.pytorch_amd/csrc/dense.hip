@@ -491,11 +491,13 @@ __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(con
     };
     int tile = xcd * per_xcd + local;
     if (local >= per_xcd) return;
-    // BACKGROUND tiles (sec_conv2d_nhwc_tiles): the caller knows (sec_rpn_tile_live: from the BEV site map, dilated once per conv
-    // layer) that every input pixel such a tile's outputs see holds the SAME channel vector, so every output pixel is the one vector
-    // `background` = this very kernel's result on a constant image (computed once per network) -- stored without DMA, LDS or MFMA.
+    // BACKGROUND tiles (sec_conv2d_nhwc_tiles / _gather with tile lists): the caller knows (sec_rpn_tile_live: the BEV site map,
+    // dilated once per conv layer) that no site lies within the receptive field of such a tile's outputs, so they equal what this
+    // very kernel computes for an EMPTY frame at the same position -- `background` = that image [h][w][cout], computed once per
+    // network and map size -- and are copied from it: no halo, no LDS, no MFMA.  (Interior tiles of it hold one channel vector, the
+    // tiles along the image border the zero padding's imprint.)
     // The LIVE tiles of all frames form one list (frame-major) that is cut into eight equal contiguous runs, one per XCD, so that a
-    // dense frame does not leave its XCD working while the others idle; the remaining workgroups each fill one background tile.
+    // dense frame does not leave its XCD working while the others idle; the workgroups behind them copy the background tiles.
     {
         if (tile_order) {
             const int tpf = tiles_y * tiles_x;
@@ -511,24 +513,54 @@ __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(con
             } else {
                 item = 8 * per_live - n_live + (local - per_live) * 8 + xcd;
             }
-            int f = 0;
             if (is_live) {
+                int f = 0;
                 while (item >= live_counts[f]) item -= live_counts[f++];
                 tile = f * tpf + tile_order[f * tpf + item];
             } else {
-                if (item >= ntile - n_live) return;
-                while (item >= tpf - live_counts[f]) item -= tpf - live_counts[f++];
-                tile = f * tpf + tile_order[f * tpf + tpf - 1 - item];
-                const int trem = tile - f * tpf;
-                const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
+                // A copying workgroup takes kCopyTiles background tiles, two at a time with all their loads in flight: one tile per
+                // workgroup left ~1 500 short-lived workgroups queueing for the ~100 slots the live tiles' first round leaves free
+                // (a slot costs this kernel's 46 KB of LDS whatever the workgroup does) and the launch ended with them, not with
+                // the convolution: 31.8 instead of 26 us at 650 live tiles.
+                constexpr int kCopyTiles = 4;
+                const int n_bg = ntile - n_live;
                 const int px = tid >> 4, ch = tid & 15;
-                const uint4 v = reinterpret_cast<const uint4 *>(background)[blockIdx.y * 16 + ch];
+                const uint4 *e4 = reinterpret_cast<const uint4 *>(background);
                 uint4 *y4 = reinterpret_cast<uint4 *>(y);
-                const int ox = x0 + px;
+                auto bg_tile = [&](int it) -> int {              // background item -> tile index over the batch, -1 past the end
+                    if (it >= n_bg) return -1;
+                    int f = 0;
+                    while (it >= tpf - live_counts[f]) it -= tpf - live_counts[f++];
+                    return f * tpf + tile_order[f * tpf + tpf - 1 - it];
+                };
+#pragma unroll 1
+                for (int q = 0; q < kCopyTiles; q += 2) {
+                    const int t0 = bg_tile(item * kCopyTiles + q), t1 = bg_tile(item * kCopyTiles + q + 1);
+                    if (t0 < 0) return;
+                    uint4 v[2][TH];
+                    size_t dst[2];
 #pragma unroll
-                for (int ty_ = 0; ty_ < TH; ++ty_) {
-                    const int oy = y0 + ty_;
-                    if (oy < p.h && ox < p.w) y4[(((size_t)f * p.h + oy) * p.w + ox) * (p.cout / 8) + blockIdx.y * 16 + ch] = v;
+                    for (int u = 0; u < 2; ++u) {
+                        const int tt = u ? t1 : t0;
+                        const int f = tt / tpf, trem = tt - f * tpf;
+                        const int y0 = (trem / tiles_x) * TH, ox = (trem % tiles_x) * TW + px;
+                        const bool okx = tt >= 0 && ox < p.w;
+                        dst[u] = (((size_t)f * p.h + y0) * p.w + ox) * (p.cout / 8) + blockIdx.y * 16 + ch;
+#pragma unroll
+                        for (int ty_ = 0; ty_ < TH; ++ty_)
+                            v[u][ty_] = (okx && y0 + ty_ < p.h) ? e4[((size_t)(y0 + ty_) * p.w + ox) * (p.cout / 8) + blockIdx.y * 16 + ch]
+                                                                 : make_uint4(0, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int tt = u ? t1 : t0;
+                        const int f = tt / tpf, trem = tt - f * tpf;
+                        const int y0 = (trem / tiles_x) * TH, ox = (trem % tiles_x) * TW + px;
+                        if (tt < 0 || ox >= p.w) continue;
+#pragma unroll
+                        for (int ty_ = 0; ty_ < TH; ++ty_)
+                            if (y0 + ty_ < p.h) y4[dst[u] + (size_t)ty_ * p.w * (p.cout / 8)] = v[u][ty_];
+                    }
                 }
                 return;
             }
@@ -1171,16 +1203,13 @@ static int launch_conv2d(const void *x, const void *wpk, const float *bias, void
     return check_launch();
 }
 
-// ---- which 8 x 16 tiles of the RPN's feature maps can differ from the background ---------------------------------------------
-// The BEV image the RPN starts from is zero except at the sparse middle's sites, so far from any site every layer's feature map is
-// ONE channel vector (act(bias) after the first conv, the conv of that constant after the second, ...): exactly, for any weights.
-// A pixel of layer j's output can differ from that vector only if one of its nine taps could: O_0 = dilate(sites) for the first
-// (gathered) conv -- its padding is the zero the empty image holds -- and O_j = dilate(O_{j-1}) | image border for every later one
-// (zero padding is not the background any more).  One workgroup per frame keeps the frame's bitmap in LDS (h rows of
-// ceil(w / 32) words), dilates it `layers` times and reduces every stage to the conv kernel's tiles.  Per conv j (0 .. layers - 1)
-// and frame b it writes order[j][b][.] = the frame's tile indices, LIVE tiles (holding a pixel of O_j) first in ascending order,
-// background tiles from the END backwards, and counts[j][b] = live tiles: the conv kernel spreads the live list evenly over the
-// XCDs whatever the frames' occupancies are.
+// ---- which 8 x 16 tiles of the RPN's feature maps can differ from the empty frame's -------------------------------------------
+// The BEV image the RPN starts from is zero except at the sparse middle's sites, and a pixel of conv j's output (j = 0, 1, ...)
+// sees the image only within j + 1 steps (Chebyshev): a tile farther than that from every site holds exactly what the same
+// network computes for an EMPTY frame at that position -- for any weights.  Per tile: d = distance from the tile's rectangle to
+// the nearest site (from a bitmap of the frame in LDS); the tile is live for conv j when d <= j + 1.  Per conv and frame the tile
+// indices are written LIVE first (ascending), the others from the END backwards, with the live count: the conv kernel spreads the
+// live list evenly over the XCDs whatever the frames' occupancies are.
 constexpr int kTileLiveThreads = 1024;
 // occupancy bitmap of the BEV image: bits[b][y][k] bit j = site_map[b][0 or 1][y][32 k + j] != 0.  A thread per word, spread over the
 // chip (one workgroup per frame reading its 280 KB of map took 8 us: one CU's L2 -> L1 path)
@@ -1215,77 +1244,80 @@ __global__ __launch_bounds__(kBlock) void k_bev_bitmap(const int *__restrict__ s
     bits[g] = out;
 }
 
+constexpr int kTileLiveMaxLayers = 8;
 __global__ __launch_bounds__(kTileLiveThreads) void k_rpn_tile_live(const unsigned *__restrict__ bits, int h, int w, int layers, int batch,
                                                                      unsigned short *__restrict__ order, int *__restrict__ counts) {
     extern __shared__ unsigned tl_bits[];
-    constexpr int NT = kTileLiveThreads;
+    constexpr int NT = kTileLiveThreads, NW = NT / 64;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wr = (w + 31) >> 5, words = h * wr;
     const int ty = (h + 7) / 8, tx = (w + 15) / 16, tiles = ty * tx;
-    unsigned *cur = tl_bits, *nxt = tl_bits + words;
-    __shared__ int s_wave[NT / 64], s_run;
-    for (int i = tid; i < words; i += NT) cur[i] = bits[(long long)b * words + i];
+    __shared__ int s_wave[kTileLiveMaxLayers][NW], s_run[kTileLiveMaxLayers];
+    for (int i = tid; i < words; i += NT) tl_bits[i] = bits[(long long)b * words + i];
+    if (tid < kTileLiveMaxLayers) s_run[tid] = 0;
     __syncthreads();
-    const unsigned last_valid = (w & 31) ? (1u << (w & 31)) - 1u : ~0u;
-    for (int l = 0; l < layers; ++l) {
-        for (int i = tid; i < words; i += NT) {
-            const int yy = i / wr, k = i - yy * wr;
-            unsigned acc = 0u;
-#pragma unroll
-            for (int dy = -1; dy <= 1; ++dy) {
-                const int y2 = yy + dy;
-                if (y2 < 0 || y2 >= h) continue;
-                const unsigned c = cur[y2 * wr + k];
-                const unsigned lf = k > 0 ? cur[y2 * wr + k - 1] : 0u, rt = k + 1 < wr ? cur[y2 * wr + k + 1] : 0u;
-                acc |= c | (c << 1) | (lf >> 31) | (c >> 1) | (rt << 31);
-            }
-            if (l >= 1) {
-                if (yy == 0 || yy == h - 1) acc = ~0u;
-                if (k == 0) acc |= 1u;
-                if (k == ((w - 1) >> 5)) acc |= 1u << ((w - 1) & 31);
-            }
-            nxt[i] = k == wr - 1 ? acc & last_valid : acc;
-        }
-        if (tid == 0) s_run = 0;
-        __syncthreads();
-        {
-            unsigned short *ord = order + ((long long)l * batch + b) * tiles;
-            for (int base = 0; base < tiles; base += NT) {
-                const int t = base + tid;
-                bool any = false;
-                if (t < tiles) {
-                    const int tyi = t / tx, txi = t - tyi * tx;
-                    unsigned acc = 0u;
-                    for (int r = 0; r < 8; ++r) {
-                        const int yy = tyi * 8 + r;
-                        if (yy < h) acc |= (nxt[yy * wr + ((txi * 16) >> 5)] >> ((txi * 16) & 31)) & 0xffffu;
+    const int K = layers;                         // farthest distance that matters
+    for (int base = 0; base < tiles; base += NT) {
+        const int t = base + tid;
+        int d = K + 1;
+        if (t < tiles) {
+            const int tyi = t / tx, txi = t - tyi * tx;
+            const int y0 = tyi * 8, x0 = txi * 16;
+            const int ylo = y0 - K > 0 ? y0 - K : 0, yhi = y0 + 7 + K < h - 1 ? y0 + 7 + K : h - 1;
+            // window of columns [x0 - 32, x0 + 47] as 80 bits around the tile's word: lo = bits of [x0 - 32, x0 + 31], hi = [x0 + 32, x0 + 47]
+            const int k0 = x0 >> 5, sh = x0 & 31;  // x0 is a multiple of 16: sh is 0 or 16
+            for (int yy = ylo; yy <= yhi; ++yy) {
+                const unsigned *row = tl_bits + yy * wr;
+                const unsigned wm = k0 > 0 ? row[k0 - 1] : 0u, wc = row[k0], wp = k0 + 1 < wr ? row[k0 + 1] : 0u;
+                // 96 bits [32 (k0 - 1), 32 (k0 + 2)); the tile's columns are bits [32 + sh, 32 + sh + 15] of it
+                const unsigned long long lo = (unsigned long long)wm | (unsigned long long)wc << 32;      // bits 0..63
+                const unsigned long long win = sh ? (lo >> 16) | (unsigned long long)wp << 48 : lo;      // tile columns at bits [32, 47] either way
+                const unsigned long long hi16 = sh ? (unsigned long long)(wp >> 16) : (unsigned long long)(wp & 0xffffu); // columns x0 + 32 .. x0 + 47 (sh = 16: bits 16.. of wp)
+                int dx = K + 1;
+                if ((win >> 32) & 0xffffull) dx = 0;
+                else {
+                    const unsigned long long left = win & 0xffffffffull;              // columns x0 - 32 .. x0 - 1 at bits 0 .. 31
+                    if (left) dx = 32 - (63 - __clzll((long long)left));            // nearest set bit below the tile: distance x0 - column
+                    const unsigned long long right = (win >> 48) | hi16 << 16;         // columns x0 + 16 .. at bits 0 ..
+                    if (right) {
+                        const int dr = __ffsll((long long)right);                   // 1-based: distance from column x0 + 15
+                        dx = dr < dx ? dr : dx;
                     }
-                    any = acc != 0u;
                 }
-                const unsigned long long bal = __ballot(any);
-                if (lane == 0) s_wave[wv] = __popcll(bal);
-                __syncthreads();
-                int before = s_run, total = 0;
-#pragma unroll
-                for (int i2 = 0; i2 < NT / 64; ++i2) {
-                    const int c = s_wave[i2];
-                    if (i2 < wv) before += c;
-                    total += c;
-                }
-                const int rank = before + __popcll(bal & ((1ull << lane) - 1ull));     // live tiles before this one in the frame
-                if (t < tiles) {
-                    if (any) ord[rank] = (unsigned short)t;
-                    else ord[tiles - 1 - (t - rank)] = (unsigned short)t;                   // background: from the end backwards
-                }
-                __syncthreads();
-                if (tid == 0) s_run += total;
-                __syncthreads();
+                const int dy = yy < y0 ? y0 - yy : (yy > y0 + 7 ? yy - (y0 + 7) : 0);
+                const int dd = dx > dy ? dx : dy;
+                d = dd < d ? dd : d;
             }
-            if (tid == 0) counts[l * batch + b] = s_run;
         }
-        unsigned *t_ = cur; cur = nxt; nxt = t_;
+        // compaction of all layers with one barrier pair: ballots, per-wave totals, prefix
+        unsigned long long bal[kTileLiveMaxLayers];
+#pragma unroll
+        for (int l = 0; l < kTileLiveMaxLayers; ++l) {
+            bal[l] = l < layers ? __ballot(t < tiles && d <= l + 1) : 0ull;
+            if (lane == 0) s_wave[l][wv] = __popcll(bal[l]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int l = 0; l < kTileLiveMaxLayers; ++l) {
+            if (l >= layers) break;
+            int before = s_run[l];
+            for (int i2 = 0; i2 < wv; ++i2) before += s_wave[l][i2];
+            const int rank = before + __popcll(bal[l] & ((1ull << lane) - 1ull));        // live tiles of this layer before this one
+            if (t < tiles) {
+                unsigned short *ord = order + ((long long)l * batch + b) * tiles;
+                if (d <= l + 1) ord[rank] = (unsigned short)t;
+                else ord[tiles - 1 - (t - rank)] = (unsigned short)t;                       // the others: from the end backwards
+            }
+        }
+        __syncthreads();
+        if (tid < layers) {
+            int tot = 0;
+            for (int i2 = 0; i2 < NW; ++i2) tot += s_wave[tid][i2];
+            s_run[tid] += tot;
+        }
         __syncthreads();
     }
+    if (tid < layers) counts[tid * batch + b] = s_run[tid];
 }
 
 }  // namespace sec
@@ -1302,9 +1334,14 @@ SEC_API int sec_rpn_tile_live(const int *site_map, int batch, int h, int w, int 
     if (!site_map || !tile_order || !live_counts || !workspace || batch <= 0 || h <= 0 || w <= 0 || layers <= 0) return SEC_E_INVALID;
     if (workspace_bytes < sec_rpn_tile_live_workspace_bytes(batch, h, w)) return SEC_E_WORKSPACE;
     const int words = h * ((w + 31) / 32);
-    const size_t lds = (size_t)2 * words * 4;
-    if (lds > 60 * 1024 || (long long)((h + 7) / 8) * ((w + 15) / 16) > 65535) return SEC_E_UNSUPPORTED;
+    const size_t lds = (size_t)words * 4;
+    if (lds > 120 * 1024 || (long long)((h + 7) / 8) * ((w + 15) / 16) > 65535 || layers > kTileLiveMaxLayers) return SEC_E_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
+    static bool configured = false;
+    if (!configured) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_rpn_tile_live), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+        configured = true;
+    }
     hipLaunchKernelGGL(k_bev_bitmap, dim3(div_up((long long)batch * words, kBlock)), dim3(kBlock), 0, st, site_map, h, w, batch, (unsigned *)workspace);
     hipLaunchKernelGGL(k_rpn_tile_live, dim3(batch), dim3(kTileLiveThreads), lds, st, (const unsigned *)workspace, h, w, layers, batch, tile_order,
                        live_counts);

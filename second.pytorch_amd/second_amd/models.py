@@ -309,6 +309,14 @@ class SparseBEV:
             return ops.sparse_site_map_sorted(tbl[1][1], self.indices.shape[0], self.batch_size, self.spatial_shape, num_dev=self.num_dev)
         return ops.sparse_site_map(self.indices, self.batch_size, self.spatial_shape, num_dev=self.num_dev)
 
+    def tile_lists(self, layers):
+        """(order, counts) of ops.rpn_tile_live for the first ``layers`` RPN convs, computed once per tensor: whoever asks first
+        decides where the launch sits (the sparse segment of a staged capture, so that it stays out of the serialised RPN segment)."""
+        t = getattr(self, "_tile_lists", None)
+        if t is None or t[0] != layers:
+            t = self._tile_lists = (layers, ops.rpn_tile_live(self.site_map(), layers))
+        return t[1]
+
     def dense(self):
         return self.sp.dense_channels_last_2d()
 
@@ -576,24 +584,37 @@ class RPNInference(nn.Module):
         self.chain_tail = (single and self.use_hip and tuple(wl.shape) == (128, 128, 1, 1) and self.cfgs[-1] == ([1, 1], [0, 0])
                            and self.ups[-1] == 1
                            and self.head_cout in (64, 128))
-        # Background tiles (sec_conv2d_nhwc_tiles): with the first conv gathered from the sparse rows the site map is at hand, and
-        # far from every site each layer's map is ONE channel vector (exact for any weights: DESIGN.md section 4).  background[i] =
-        # that vector at the OUTPUT of conv i, from the conv kernels themselves on a constant image; convs 1.. then compute only
-        # the tiles a site (or, from the second conv on, the zero padding) can reach.  skip_background = False computes every tile.
+        # Background tiles (sec_conv2d_nhwc_tiles): with the first conv gathered from the sparse rows the site map is at hand, and a
+        # tile of conv j's output that no site can reach (j + 1 steps) holds exactly what the network computes for an EMPTY frame at
+        # that position -- any weights.  The empty frame's activations are computed once per map size by the
+        # same kernels (:meth:`empty_frame_maps`); the convs then compute only the reachable tiles and copy the others.
+        # skip_background = False convolves every tile.
         self.skip_background = True
-        self.background = None
         self.last_live_counts = None       # [convs, B] int32 on the device: live tiles per conv and frame of the last forward (bench / tests)
+        self._empty_maps = {}
         convs = [i for kind, i in self.plan if kind == "c"]
-        if (self.gather_packed is not None and len(convs) >= 2 and convs == list(range(len(convs)))
-                and all(tuple(self.ws[i].shape) == (128, 128, 3, 3) and self.cfgs[i] == ([1, 1], [1, 1]) and self.ups[i] == 1 for i in convs)):
+        self.background_convs = len(convs) if (
+            self.gather_packed is not None and 2 <= len(convs) <= 8 and convs == list(range(len(convs)))
+            and all(tuple(self.ws[i].shape) == (128, 128, 3, 3) and self.cfgs[i] == ([1, 1], [1, 1]) and self.ups[i] == 1 for i in convs)) else 0
+
+    def empty_frame_maps(self, h, w):
+        """Output of every 3x3 conv of the block for a frame WITHOUT sites, channels_last [1, 128, h, w] each, from the kernels the
+        forward itself uses (so that a copied tile is bit-identical to a computed one).  Cached per map size; the first call for a
+        size must not happen inside a graph capture."""
+        key = (int(h), int(w))
+        if key not in self._empty_maps:
+            assert not torch.cuda.is_current_stream_capturing(), "RPNInference.empty_frame_maps: run one eager forward before capturing"
+            dev, dt = self.ws[0].device, self.ws[0].dtype
             with torch.no_grad():
-                bg, img = [], torch.zeros((1, 128, 16, 32), dtype=dtype, device=w0.device).contiguous(memory_format=torch.channels_last)
-                for i in convs:
-                    out = ops.conv2d_nhwc(img, self.packed[i], self.bs[i], 128, 3, 1, 1, relu=True)
-                    c = out[0, :, 8, 16].clone().contiguous()                    # an interior pixel: all nine taps inside
-                    bg.append(c)
-                    img = c.view(1, 128, 1, 1).expand(1, 128, 16, 32).contiguous(memory_format=torch.channels_last)
-            self.background = bg
+                feat = torch.zeros((1, 64), dtype=dt, device=dev)
+                sm = torch.zeros((1, 2, h, w), dtype=torch.int32, device=dev)
+                x = ops.conv2d_nhwc_gather(feat, sm, self.gather_packed, self.bs[0], 128, relu=True)
+                maps = [x]
+                for i in range(1, self.background_convs):
+                    x = ops.conv2d_nhwc(x, self.packed[i], self.bs[i], 128, 3, 1, 1, relu=True)
+                    maps.append(x)
+            self._empty_maps[key] = maps
+        return self._empty_maps[key]
 
     def _conv(self, x, i, sparse_input=False):
         w, b, (s, p) = self.ws[i], self.bs[i], self.cfgs[i]
@@ -623,15 +644,16 @@ class RPNInference(nn.Module):
         for kind, i in self.plan:
             if kind == "c" and gather is not None:
                 sm = gather.site_map()
-                if self.background is not None and self.skip_background:
-                    live, self.last_live_counts = ops.rpn_tile_live(sm, len(self.background))
+                if self.background_convs and self.skip_background:
+                    empty = self.empty_frame_maps(sm.shape[2], sm.shape[3])
+                    live, self.last_live_counts = gather.tile_lists(self.background_convs)
                     x = ops.conv2d_nhwc_gather(gather.features, sm, self.gather_packed, self.bs[i], self.ws[i].shape[0], relu=True,
-                                               tile_order=live[0], live_counts=self.last_live_counts[0], background=self.background[0])
+                                               tile_order=live[0], live_counts=self.last_live_counts[0], background=empty[0])
                 else:
                     x = ops.conv2d_nhwc_gather(gather.features, sm, self.gather_packed, self.bs[i], self.ws[i].shape[0], relu=True)
                 gather, first = None, False
             elif kind == "c" and live is not None:
-                x = ops.conv2d_nhwc_tiles(x, self.packed[i], self.bs[i], 128, live[i], self.last_live_counts[i], self.background[i], relu=True)
+                x = ops.conv2d_nhwc_tiles(x, self.packed[i], self.bs[i], 128, live[i], self.last_live_counts[i], empty[i], relu=True)
             elif kind == "c":
                 x = self._conv(x, i, sparse_input=first)
                 first = False
@@ -901,6 +923,8 @@ class SecondDetector(nn.Module):
                                                             site_table=vox.get("site_table"),
                                                             bev_sparse=getattr(self.rpn, "gather_packed", None) is not None)
                     self._branch_overflow = [list(getattr(self.middle_feature_extractor, "last_overflow_checks", []))]
+                    if isinstance(spatial, SparseBEV) and getattr(self.rpn, "background_convs", 0) and self.rpn.skip_background:
+                        spatial.tile_lists(self.rpn.background_convs)     # the live-tile lists belong to the latency-bound segment
                 with torch.cuda.graph(gb, pool=pool, capture_error_mode="thread_local"):
                     preds = self.rpn(spatial)
                 with torch.cuda.graph(gc, pool=pool, capture_error_mode="thread_local"):

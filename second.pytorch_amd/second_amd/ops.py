@@ -745,10 +745,11 @@ def conv2d_nhwc_gather(features, site_map, packed, bias, cout, relu=True, tile_o
     b, d, h, w = site_map.shape
     assert d == 2 and site_map.is_contiguous()
     y = torch.empty((b, int(cout), h, w), dtype=features.dtype, device=features.device, memory_format=torch.channels_last)
-    if tile_order is not None:      # live tiles from rpn_tile_live (layer 0): spread evenly over the XCDs, the others filled with `background`
+    if tile_order is not None:      # live tiles from rpn_tile_live (layer 0): spread evenly over the XCDs, the others copied from `background` (the empty frame's output)
         rt.require_gpu(tile_order, live_counts, background)
         assert tile_order.dtype == torch.int16 and tile_order.is_contiguous() and tile_order.shape[0] == b
-        assert live_counts.dtype == torch.int32 and live_counts.numel() == b and background.dtype == features.dtype and background.numel() == int(cout)
+        assert live_counts.dtype == torch.int32 and live_counts.numel() == b and background.dtype == features.dtype
+        assert background.numel() == h * w * int(cout) and background.is_contiguous(memory_format=torch.channels_last)
     rc = rt.lib().sec_conv2d_nhwc_gather(rt.ptr(features), features.shape[0], rt.ptr(site_map), b, h, w, rt.ptr(packed), rt.ptr(bias),
                                          int(cout), int(bool(relu)), rt.ptr(tile_order) if tile_order is not None else None,
                                          rt.ptr(live_counts) if tile_order is not None else None,
@@ -780,15 +781,15 @@ def rpn_tile_live(site_map, layers):
 @_traced("conv2d_nhwc_tiles")
 def conv2d_nhwc_tiles(x, packed, bias, cout, tile_order, live_counts, background, relu=True):
     """3x3 / stride 1 / pad 1 conv + bias + ReLU on a channels_last [B,128,H,W] tensor; only the live tiles of ``tile_order`` [B, tiles] /
-    ``live_counts`` [B] (one layer of :func:`rpn_tile_live`) are convolved, the others are filled with ``background`` [cout]
-    (sec_conv2d_nhwc_tiles)."""
+    ``live_counts`` [B] (one layer of :func:`rpn_tile_live`) are convolved, the others are copied from ``background`` = this layer's
+    output for an EMPTY frame, channels_last [1, cout, H, W] (sec_conv2d_nhwc_tiles)."""
     rt.require_gpu(x, packed, tile_order, live_counts, background)
     assert x.dim() == 4 and x.shape[1] == 128 and x.is_contiguous(memory_format=torch.channels_last)
     b, _, h, w = x.shape
     tiles = ((h + 7) // 8) * ((w + 15) // 16)
     assert tile_order.dtype == torch.int16 and tile_order.is_contiguous() and tuple(tile_order.shape) == (b, tiles)
     assert live_counts.dtype == torch.int32 and live_counts.is_contiguous() and live_counts.numel() == b
-    assert background.dtype == x.dtype and background.numel() == int(cout) and background.is_contiguous()
+    assert background.dtype == x.dtype and background.numel() == h * w * int(cout) and background.is_contiguous(memory_format=torch.channels_last)
     y = torch.empty((b, int(cout), h, w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
     rc = rt.lib().sec_conv2d_nhwc_tiles(rt.ptr(x), b, h, w, rt.ptr(packed), rt.ptr(bias), int(cout), int(bool(relu)),
                                         rt.ptr(tile_order), rt.ptr(live_counts), rt.ptr(background), rt.ptr(y),

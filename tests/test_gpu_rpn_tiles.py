@@ -1,7 +1,8 @@
-"""Background tiles of the dense RPN (sec_rpn_tile_live + sec_conv2d_nhwc_tiles): far from every site of the sparse middle each
-RPN layer's feature map is one channel vector, so only tiles a site (or the zero padding) can reach are convolved.  The map is
-checked against a numpy dilation, the RPN with and without the skipping must agree BIT FOR BIT on networks whose background is
-not zero (rpn.py:486-497 semantics: Conv2d 3x3 + BatchNorm2d + ReLU with arbitrary statistics)."""
+"""Background tiles of the dense RPN (sec_rpn_tile_live + sec_conv2d_nhwc_tiles / _gather): a tile of conv j's output that no site of
+the sparse middle can reach within j + 1 steps holds exactly what the network computes for an EMPTY frame at that position, so only
+the reachable tiles are convolved and the others are copied from the empty frame's activations.  The tile lists are checked
+against a numpy dilation; the RPN with and without the skipping must agree BIT FOR BIT on networks whose background is not zero
+(rpn.py:486-497 semantics: Conv2d 3x3 + BatchNorm2d + ReLU with arbitrary statistics)."""
 import numpy as np
 import pytest
 import torch
@@ -33,10 +34,7 @@ def _live_reference(sites, layers):
     for f in range(b):
         cur = sites[f]
         for l in range(layers):
-            cur = _dilate(cur)
-            if l >= 1:                               # zero padding is the background only for the first conv (empty image == 0)
-                cur[0, :] = cur[-1, :] = True
-                cur[:, 0] = cur[:, -1] = True
+            cur = _dilate(cur)                       # conv l sees the image within l + 1 steps
             pad = np.zeros((ty * 8, tx * 16), bool)
             pad[:h, :w] = cur
             out[l, f] = pad.reshape(ty, 8, tx, 16).any(axis=(1, 3)).reshape(-1)
@@ -95,7 +93,7 @@ def _bev(features, smap):
 
         def site_map(self):
             return smap
-    return BEV()
+    return BEV()                                      # tile_lists() is the base class's
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
@@ -112,8 +110,11 @@ def test_rpn_with_background_tiles_is_bit_identical_to_the_full_convs(ops, dtype
     feat = torch.randn(max(len(idx), 1), 64, device="cuda").to(dtype)
     smap = ops.sparse_site_map(torch.from_numpy(idx).cuda(), batch, [2, h, w])
     rpn = _rpn_pair(dtype, 3)
-    assert rpn.background is not None and len(rpn.background) == 6
-    assert all(float(c.float().abs().max()) > 0 for c in rpn.background), "the test needs a non-zero background"
+    assert rpn.background_convs == 6
+    empty = rpn.empty_frame_maps(h, w)
+    assert all(float(e.float().abs().max()) > 0 for e in empty), "the test needs a non-zero background"
+    if h >= 24:
+        assert not torch.equal(empty[3][0, :, 0, 0], empty[3][0, :, h // 2, w // 2]), "zero padding must leave its imprint along the border"
     bev = _bev(feat, smap)
     with torch.no_grad():
         rpn.skip_background = True
