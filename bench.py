@@ -299,8 +299,13 @@ def kernel_table(det, points, offsets, reps=30):
             ent.update(bytes=4 * smap.numel() + 2 * res[0].numel(), detail=f"site map {tuple(smap.shape)} -> live-tile maps of {a[1]} conv layers")
         elif name == "conv1x1_chain":
             x = a[0]
-            ent.update(flop=2.0 * x.shape[0] * x.shape[2] * x.shape[3] * 128 * (128 + res.shape[1]), bytes=elt(x.dtype) * (x.numel() + res.numel()),
-                       detail=f"128->128->{res.shape[1]} 1x1")
+            if kw.get("live_counts") is not None:      # only the live tiles (128 pixels each) are computed, the others copied
+                lv, tot = int(kw["live_counts"].sum().item()), kw["tile_order"].numel()
+                ent.update(flop=2.0 * lv * 128 * 128 * (128 + res.shape[1]), bytes=elt(x.dtype) * (x.numel() * lv // tot + res.numel()),
+                           live_tiles=lv, tiles=tot, detail=f"128->128->{res.shape[1]} 1x1 on {lv} of {tot} tiles, the others copied from the empty frame's output")
+            else:
+                ent.update(flop=2.0 * x.shape[0] * x.shape[2] * x.shape[3] * 128 * (128 + res.shape[1]), bytes=elt(x.dtype) * (x.numel() + res.numel()),
+                           detail=f"128->128->{res.shape[1]} 1x1")
         if "flop" in ent and name.startswith("conv"):
             ent["bound"], ent["frac"] = "mfma", round(ent["flop"] / (us * 1e-6) / 2.5e15, 4)
         elif "bytes" in ent:

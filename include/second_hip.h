@@ -273,12 +273,18 @@ int sec_conv2d_nhwc_gather(const void *features, long long feature_rows, const i
  * are copied from `background` = this layer's output for an empty frame, [h][w][cout] in the feature dtype, which the caller
  * computes once per network and map size with the same entry points.  tile_order == NULL: every tile is convolved.
  * Outputs are bit-identical to sec_conv2d_nhwc when the lists are the ones sec_rpn_tile_live derives. */
+/* sec_conv1x1_chain_nhwc_tiles: sec_conv1x1_chain_nhwc (the RPN's deblock + merged heads, rpn.py:275-285,386-391) on the live
+ * tiles of the LAST 3x3 conv's lists (a 1x1 conv reaches no farther); the other tiles are copied from `background` = its own
+ * output for an empty frame, [h][w][cout2]. */
 size_t sec_rpn_tile_live_workspace_bytes(int batch, int h, int w);
 int sec_rpn_tile_live(const int *site_map, int batch, int h, int w, int layers, unsigned short *tile_order, int *live_counts,
                       void *workspace, size_t workspace_bytes, void *stream);
 int sec_conv2d_nhwc_tiles(const void *x, int batch, int h, int w, const void *packed_weight, const float *bias, int cout,
                           int relu, const unsigned short *tile_order, const int *live_counts, const void *background, void *y,
                           int dtype, void *stream);
+int sec_conv1x1_chain_nhwc_tiles(const void *x, int batch, int h, int w, const void *packed_w1, const float *bias1, int relu1,
+                                 const void *packed_w2, const float *bias2, int cout2, const unsigned short *tile_order,
+                                 const int *live_counts, const void *background, void *y, int dtype, void *stream);
 
 /* Adjoint of sec_sparse_to_dense -- rows[i,:] = dense[indices[i]] -- i.e. the backward of
  * SparseConvTensor.dense() (upstream gets it from autograd through scatter_nd, spconv/__init__.py) and of

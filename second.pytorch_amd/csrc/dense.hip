@@ -1005,16 +1005,82 @@ __global__ __launch_bounds__(kBlock) void k_conv1x1_nhwc(const T *__restrict__ x
 // 128-channel intermediate lives only in LDS: 72 MB in, 36 MB out.  One workgroup = one 128-pixel tile; weights are
 // never staged (each wave streams its own B fragments from L2, as in k_conv2d_halo_reg); the x tile and then the
 // intermediate share one 32 KB LDS buffer, so five workgroups fit a CU's LDS and three its registers.
-template <typename T, int NT2>    // NT2 = 32-wide cout tiles per wave in the second GEMM: cout2 = 64 * NT2
+// TILES: the workgroup's 128 pixels are an 8 x 16 tile of the [batch][h][w] map taken from the live-tile lists of sec_rpn_tile_live
+// (the last 3x3 conv's: a 1x1 conv reaches no farther), spread evenly over the XCDs; the workgroups behind them copy the other
+// tiles from `background` = this kernel's output for an empty frame ([h][w][N2]) -- the scheme of k_conv2d_halo_reg.
+template <typename T, int NT2, bool TILES = false>    // NT2 = 32-wide cout tiles per wave in the second GEMM: cout2 = 64 * NT2
 __global__ __launch_bounds__(256, 3) void k_conv1x1_chain(const T *__restrict__ x, const T *__restrict__ w1pk,
                                                           const float *__restrict__ b1, const T *__restrict__ w2pk,
                                                           const float *__restrict__ b2, T *__restrict__ y, long long m,
-                                                          int relu1) {
+                                                          int relu1, int batch = 0, int h = 0, int w = 0, int per_xcd = 0,
+                                                          const unsigned short *__restrict__ tile_order = nullptr,
+                                                          const int *__restrict__ live_counts = nullptr,
+                                                          const T *__restrict__ background = nullptr) {
     constexpr int BM = 128, C = 128, CH = C / 8, N2 = 64 * NT2;
     __shared__ uint4 tile[BM * CH];                 // [pixel][16-byte chunk ^ (pixel & 15)]: x, then relu(W1 x + b1)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
-    const long long m0 = (long long)blockIdx.x * BM;
+    long long m0 = (long long)blockIdx.x * BM;
+    int tf = 0, ty0 = 0, tx0 = 0;                   // TILES: frame and origin of this workgroup's tile
+    if constexpr (TILES) {
+        const int tiles_x = (w + 15) / 16, tpf = ((h + 7) / 8) * tiles_x, ntile = batch * tpf;
+        const int xcd = blockIdx.x % 8, local = blockIdx.x / 8;
+        if (local >= per_xcd) return;
+        int n_live = 0;
+        for (int f = 0; f < batch; ++f) n_live += live_counts[f];
+        const int per_live = (n_live + 7) >> 3;
+        int item;
+        bool is_live = false;
+        if (local < per_live) {
+            item = xcd * per_live + local;
+            is_live = item < n_live;
+            if (!is_live) item -= n_live;
+        } else {
+            item = 8 * per_live - n_live + (local - per_live) * 8 + xcd;
+        }
+        if (!is_live) {
+            constexpr int kCopyTiles = 4, NC = N2 / 8, PER = BM * NC / 256;      // 16-byte chunks per pixel / per thread and tile
+            const int n_bg = ntile - n_live;
+            const uint4 *e4 = reinterpret_cast<const uint4 *>(background);
+            uint4 *y4 = reinterpret_cast<uint4 *>(y);
+#pragma unroll 1
+            for (int q = 0; q < kCopyTiles; ++q) {
+                int it = item * kCopyTiles + q;
+                if (it >= n_bg) return;
+                int f = 0;
+                while (it >= tpf - live_counts[f]) it -= tpf - live_counts[f++];
+                const int t = tile_order[f * tpf + tpf - 1 - it];
+                const int y0 = (t / tiles_x) * 8, x0 = (t % tiles_x) * 16;
+                uint4 v[PER];
+#pragma unroll
+                for (int c = 0; c < PER; ++c) {
+                    const int e = c * 256 + tid, px = e / NC, ch = e - px * NC;
+                    const int oy = y0 + (px >> 4), ox = x0 + (px & 15);
+                    v[c] = (oy < h && ox < w) ? e4[((size_t)oy * w + ox) * NC + ch] : make_uint4(0, 0, 0, 0);
+                }
+#pragma unroll
+                for (int c = 0; c < PER; ++c) {
+                    const int e = c * 256 + tid, px = e / NC, ch = e - px * NC;
+                    const int oy = y0 + (px >> 4), ox = x0 + (px & 15);
+                    if (oy < h && ox < w) y4[(((size_t)f * h + oy) * w + ox) * NC + ch] = v[c];
+                }
+            }
+            return;
+        }
+        while (item >= live_counts[tf]) item -= live_counts[tf++];
+        const int t = tile_order[tf * tpf + item];
+        ty0 = (t / tiles_x) * 8;
+        tx0 = (t % tiles_x) * 16;
+    }
+    // pixel px (0 .. 127) of this workgroup -> index in the [pixels] view, -1 when it lies outside the map
+    auto gpix = [&](int px) -> long long {
+        if constexpr (TILES) {
+            const int oy = ty0 + (px >> 4), ox = tx0 + (px & 15);
+            return (oy < h && ox < w) ? ((long long)tf * h + oy) * w + ox : -1ll;
+        } else {
+            return m0 + px < m ? m0 + px : -1ll;
+        }
+    };
     const uint4 *x4 = reinterpret_cast<const uint4 *>(x);
     const uint4 *w1 = reinterpret_cast<const uint4 *>(w1pk);
     const uint4 *w2 = reinterpret_cast<const uint4 *>(w2pk);
@@ -1022,7 +1088,8 @@ __global__ __launch_bounds__(256, 3) void k_conv1x1_chain(const T *__restrict__ 
 #pragma unroll
     for (int j = 0; j < BM * CH / 64 / 4; ++j) {
         const int e = (j * 4 + wv) * 64 + lane, px = e / CH, slot = e - px * CH;
-        const uint4 *src = m0 + px < m ? x4 + (m0 + px) * CH + (slot ^ (px & 15)) : zero16;
+        const long long gp = gpix(px);
+        const uint4 *src = gp >= 0 ? x4 + gp * CH + (slot ^ (px & 15)) : zero16;
         __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)&tile[(j * 4 + wv) * 64], 16, 0, 0);
     }
     // GEMM 1: this wave = all 128 pixels x mid channels [32 wv, 32 wv + 32)
@@ -1099,12 +1166,27 @@ __global__ __launch_bounds__(256, 3) void k_conv1x1_chain(const T *__restrict__ 
         }
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-        const long long pix = m0 + wm * 64 + mt * 32 + r;
-        T *ypix = y + (size_t)pix * N2;
+        const long long pix = gpix(wm * 64 + mt * 32 + r);
+        T *ypix = y + (size_t)(pix >= 0 ? pix : 0) * N2;
 #pragma unroll
         for (int nt = 0; nt < NT2; ++nt)
-            store_tile_t<T>(acc2[mt][nt], b2, wn * (N2 / 2) + nt * 32, 0, ypix, pix < m, hh);
+            store_tile_t<T>(acc2[mt][nt], b2, wn * (N2 / 2) + nt * 32, 0, ypix, pix >= 0, hh);
     }
+}
+
+template <typename T>
+static int launch_conv1x1_chain_tiles(const void *x, int batch, int h, int w, const void *w1, const float *b1, const void *w2, const float *b2,
+                                      int cout2, int relu1, const unsigned short *tile_order, const int *live_counts, const void *background,
+                                      void *y, hipStream_t st) {
+    const int ntile = batch * div_up(h, 8) * div_up(w, 16), per_xcd = div_up(ntile, 8);
+    const long long m = (long long)batch * h * w;
+    if (cout2 == 64)
+        hipLaunchKernelGGL((k_conv1x1_chain<T, 1, true>), dim3(per_xcd * 8), dim3(256), 0, st, (const T *)x, (const T *)w1, b1, (const T *)w2, b2,
+                           (T *)y, m, relu1, batch, h, w, per_xcd, tile_order, live_counts, (const T *)background);
+    else
+        hipLaunchKernelGGL((k_conv1x1_chain<T, 2, true>), dim3(per_xcd * 8), dim3(256), 0, st, (const T *)x, (const T *)w1, b1, (const T *)w2, b2,
+                           (T *)y, m, relu1, batch, h, w, per_xcd, tile_order, live_counts, (const T *)background);
+    return check_launch();
 }
 
 template <typename T>
@@ -1429,6 +1511,19 @@ SEC_API int sec_conv1x1_chain_nhwc(const void *x, long long pixels, const void *
     if (dtype == SEC_BF16)
         return launch_conv1x1_chain<__hip_bfloat16>(x, pixels, packed_w1, bias1, packed_w2, bias2, cout2, relu1, y, st);
     return launch_conv1x1_chain<__half>(x, pixels, packed_w1, bias1, packed_w2, bias2, cout2, relu1, y, st);
+}
+
+SEC_API int sec_conv1x1_chain_nhwc_tiles(const void *x, int batch, int h, int w, const void *packed_w1, const float *bias1, int relu1,
+                                         const void *packed_w2, const float *bias2, int cout2, const unsigned short *tile_order,
+                                         const int *live_counts, const void *background, void *y, int dtype, void *stream) {
+    if (!x || !packed_w1 || !packed_w2 || !bias1 || !y || !tile_order || !live_counts || !background || batch <= 0 || h <= 0 || w <= 0)
+        return SEC_E_INVALID;
+    if ((cout2 != 64 && cout2 != 128) || (dtype != SEC_BF16 && dtype != SEC_F16)) return SEC_E_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SEC_BF16)
+        return launch_conv1x1_chain_tiles<__hip_bfloat16>(x, batch, h, w, packed_w1, bias1, packed_w2, bias2, cout2, relu1, tile_order, live_counts,
+                                                          background, y, st);
+    return launch_conv1x1_chain_tiles<__half>(x, batch, h, w, packed_w1, bias1, packed_w2, bias2, cout2, relu1, tile_order, live_counts, background, y, st);
 }
 
 SEC_API int sec_bias_act_nhwc(void *x, const float *bias, size_t pixels, int channels, int relu, int dtype, void *stream) {

@@ -613,6 +613,8 @@ class RPNInference(nn.Module):
                 for i in range(1, self.background_convs):
                     x = ops.conv2d_nhwc(x, self.packed[i], self.bs[i], 128, 3, 1, 1, relu=True)
                     maps.append(x)
+                if self.chain_tail:      # the fused deblock + heads on the empty frame: background of the tail
+                    maps.append(ops.conv1x1_chain(x, self.packed[-1], self.bs[-1], self.head_packed, self.head_b64, self.head_cout))
             self._empty_maps[key] = maps
         return self._empty_maps[key]
 
@@ -661,7 +663,11 @@ class RPNInference(nn.Module):
                 ups.append(None)                     # single block: the deblock runs fused with the heads below
             else:
                 ups.append(self._conv(x, i))
-        if self.chain_tail:
+        if self.chain_tail and live is not None:
+            last = self.background_convs - 1
+            y = ops.conv1x1_chain(x, self.packed[-1], self.bs[-1], self.head_packed, self.head_b64, self.head_cout,
+                                  tile_order=live[last], live_counts=self.last_live_counts[last], background=empty[last + 1])
+        elif self.chain_tail:
             y = ops.conv1x1_chain(x, self.packed[-1], self.bs[-1], self.head_packed, self.head_b64, self.head_cout)
         else:
             f = ups[0] if len(ups) == 1 else torch.cat(ups, dim=1)    # channels_last in, channels_last out

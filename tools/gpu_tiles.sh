@@ -9,6 +9,6 @@ for S in 1 0; do
 import json
 d=json.load(open("$O/bench_skip$S.json"))
 print("skip=$S value",d["value"],"ms",d["ms_per_step"],"single",d["config"]["single_step_latency_ms"],"live",d["config"].get("rpn_background_tiles"))
-print([ (k["op"],k.get("us")) for k in d["kernels"] if "conv2d" in k["op"]])
+print([ (k["op"],k.get("us")) for k in d["kernels"] if "conv" in k["op"] or "tile" in k["op"]])
 PY
 done
