@@ -804,6 +804,7 @@ def main():
     ap.add_argument("--profile-run", action="store_true",
                     help="for runs under rocprofv3: no self-warming beyond --warmup and ONE timed window (keeps the trace small); the "
                          "printed value is then not a benchmark figure")
+    ap.add_argument("--rpn-tokens", type=int, default=1, help="--serialize-rpn 1: RPN segments allowed to run at a time")
     ap.add_argument("--background-skip", type=int, default=1,
                     help="RPN convs after the first compute only the tiles a site (or the zero padding) can reach and fill the others "
                          "with the layer's background vector (bit-identical outputs; 0 = convolve every tile)")
@@ -870,7 +871,8 @@ def main():
             from second_amd.models import InFlightRunner
             serialize = (bool(args.serialize_rpn) and not det.pillars and getattr(det, "_infer_dtype", None) is not None
                          and args.branches <= 1 and args.inflight > 1)
-            runner = InFlightRunner(det, points, offsets, inflight=args.inflight, branches=args.branches, serialize_rpn=serialize)
+            runner = InFlightRunner(det, points, offsets, inflight=args.inflight, branches=args.branches, serialize_rpn=serialize,
+                                    rpn_tokens=args.rpn_tokens)
             graph_parts = runner.parts      # branches > 1: the roofline probe below times one branch's launch
             replays = runner.replays
             outs = runner.outputs[-1]

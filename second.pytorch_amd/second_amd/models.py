@@ -1068,7 +1068,7 @@ class InFlightRunner:
     ``step()`` enqueues one full forward and returns (outputs, stream): the output tensors of that lane, valid once
     ``stream`` has been synchronised (or after :meth:`synchronize`) and until the lane is stepped again."""
 
-    def __init__(self, det, points, point_offsets, inflight=3, branches=1, private_inputs=False, serialize_rpn=False):
+    def __init__(self, det, points, point_offsets, inflight=3, branches=1, private_inputs=False, serialize_rpn=False, rpn_tokens=1):
         """``private_inputs``: every lane gets its OWN copy of the input buffers (``self.inputs[k]``) and pinned host
         mirrors of its outputs, so that :meth:`step` can take a host-resident batch: the pinned-host -> HBM copy of lane k's
         next clouds then overlaps the compute of the other lanes (the end-to-end serving form; with shared buffers a copy
@@ -1082,6 +1082,8 @@ class InFlightRunner:
         # segments fill the rest of the chip
         self.serialize_rpn = bool(serialize_rpn) and branches <= 1 and int(inflight) > 1
         self._rpn_token = None
+        self.rpn_tokens = max(1, int(rpn_tokens))   # RPN segments allowed at a time (a ring of that many events)
+        self._rpn_events = []
         self._keepalive = []                      # per lane: the buffers its three graphs hand to each other
         assert not (private_inputs and branches > 1), "private input buffers are a single-chain feature"
         for _ in range(max(1, int(inflight))):
@@ -1125,11 +1127,12 @@ class InFlightRunner:
                 ra, rb, rc = self.replays[k]
                 st = lane if lane is not None else torch.cuda.current_stream()
                 ra()
-                if self._rpn_token is not None:
-                    st.wait_event(self._rpn_token)          # the previous step's RPN segment (another lane) has finished
+                if len(self._rpn_events) >= self.rpn_tokens:
+                    st.wait_event(self._rpn_events[-self.rpn_tokens])   # the RPN segment `rpn_tokens` steps back (another lane) has finished
                 rb()
-                self._rpn_token = torch.cuda.Event()        # one RPN segment at a time (two at a time measured slower, round 3)
-                self._rpn_token.record(st)
+                ev = torch.cuda.Event()
+                ev.record(st)
+                self._rpn_events = (self._rpn_events + [ev])[-self.rpn_tokens:]
                 rc()
             else:
                 self.replays[k]()

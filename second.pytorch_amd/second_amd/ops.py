@@ -522,26 +522,32 @@ def pfn_forward(voxels, num_points, coords, weight_t, scale, shift, vx, vy, x_of
 # ---- BatchNorm step counters of the fused training paths ----------------------------------------------------------------------
 # `bn.num_batches_tracked += 1` is one tiny launch per BatchNorm layer (21 per step of the SECOND networks).  Inside
 # deferred_bn_counters() the fused paths only note the counter; leaving the context adds 1 to all of them with one multi-tensor launch.
-_bn_counter_stack = []
+_bn_counter_stack = []      # frames: [pending counters, frame opened while the stream was being captured]
+
+
+def _capturing():
+    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
 
 
 class deferred_bn_counters:
     def __enter__(self):
-        _bn_counter_stack.append([])
+        _bn_counter_stack.append([[], _capturing()])
         return self
 
     def __exit__(self, *exc):
-        pending = _bn_counter_stack.pop()
+        pending, _ = _bn_counter_stack.pop()
         if pending:
             torch._foreach_add_(pending, 1)
         return False
 
 
 def bump_bn_counter(bn):
-    """num_batches_tracked += 1 now, or at the exit of the enclosing :class:`deferred_bn_counters` (never deferred while a
-    stream is being captured: a captured step must replay its own increments)."""
-    if _bn_counter_stack and not (bn.num_batches_tracked.is_cuda and torch.cuda.is_current_stream_capturing()):
-        _bn_counter_stack[-1].append(bn.num_batches_tracked)
+    """num_batches_tracked += 1 now, or at the exit of the enclosing :class:`deferred_bn_counters`.  While a stream is being
+    captured the increment is deferred only when the frame itself was opened inside the capture (DeviceTrainer.capture_step: the
+    one multi-tensor add at its exit is then part of the same graph); a frame opened outside must not swallow increments a
+    captured segment has to replay."""
+    if _bn_counter_stack and (_bn_counter_stack[-1][1] or not (bn.num_batches_tracked.is_cuda and _capturing())):
+        _bn_counter_stack[-1][0].append(bn.num_batches_tracked)
     else:
         bn.num_batches_tracked += 1
 

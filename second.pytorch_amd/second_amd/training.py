@@ -226,7 +226,7 @@ class DeviceTrainer:
                 return p["box_preds"], p["cls_preds"], p.get("dir_cls_preds", p["cls_preds"].new_zeros(0))
         # the warm-up iterations of the capture run BatchNorm in training mode: keep the running statistics out of it
         saved = {k: v.clone() for k, v in rpn.state_dict().items() if "running_" in k or "num_batches" in k}
-        ops._bn_counter_stack.append([])        # throw-away frame: the three non-capturing warm-up iterations of make_graphed_callables
+        ops._bn_counter_stack.append([[], False])   # throw-away frame: the three non-capturing warm-up iterations of make_graphed_callables
         try:                                    # must not queue num_batches_tracked increments into the step's deferred list
             sample = x.detach().clone().requires_grad_()
             fn = torch.cuda.make_graphed_callables(_Mixed(), (sample,))
