@@ -97,7 +97,8 @@ def _bev(features, smap):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("batch,h,w,n", [(2, 200, 176, 1500), (3, 50, 70, 200), (1, 40, 48, 1), (2, 33, 17, 0)])
+@pytest.mark.parametrize("batch,h,w,n", [(2, 200, 176, 1500), (3, 50, 70, 200), (1, 40, 48, 1), (2, 33, 17, 0),
+                                          (2, 96, 64, 4000)])      # sites reach every tile: the kernels take the plain tile order
 def test_rpn_with_background_tiles_is_bit_identical_to_the_full_convs(ops, dtype, batch, h, w, n):
     rng = np.random.default_rng(n + h)
     idx = np.zeros((0, 4), np.int32)
