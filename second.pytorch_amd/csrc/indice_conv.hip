@@ -1762,7 +1762,7 @@ static bool launch_wgrad_tiled(const void *feat, const void *dout, const int *nb
                                n_out, kvol, chunk, dw);                                                                   \
             return true;                                                                                                  \
         }
-        SEC_WM(16, 16) SEC_WM(16, 32) SEC_WM(32, 32) SEC_WM(32, 64) SEC_WM(64, 64)
+        SEC_WM(4, 16) SEC_WM(16, 16) SEC_WM(16, 32) SEC_WM(32, 32) SEC_WM(32, 64) SEC_WM(64, 64)
 #undef SEC_WM
     }
 #define SEC_WG(CI, CO)                                                                                                    \
