@@ -210,7 +210,14 @@ size_t sec_indice_conv_bwd_workspace_bytes(int kvol, int cin, int cout, int dtyp
 int sec_indice_conv_bwd(const void *features, int n_in, int cin, const void *weight, int kvol, int cout,
                         const int *nbr_out, const int *nbr_in, int n_out, const void *dout,
                         void *dfeat, float *dweight, int dtype, void *workspace, size_t workspace_bytes,
-                        void *stream);
+                        const void *packed_dgrad, void *stream);
+/* Mixed-precision training (fp32 master weights, 16-bit features; train.py:196-203 keeps fp32 copies the same way): the three
+ * 16-bit images of one layer's weight [kvol][cin][cout] in ONE launch -- `weight16` (the plain rounding), `packed_fwd`
+ * (sec_pack_conv_weight's image; NULL when sec_packed_weight_bytes(kvol, cin, cout) is 0) and `packed_dgrad` (the transposed image
+ * sec_indice_conv_bwd otherwise builds per call, sec_packed_weight_bytes(kvol, cout, cin) bytes; `subm` != 0: offsets mirrored,
+ * as for a rulebook without an input-major table; NULL to skip).  Pass `packed_dgrad` to sec_indice_conv_bwd. */
+int sec_pack_conv_weight_train(const float *weight, int kvol, int cin, int cout, int subm, int dtype, void *weight16,
+                               void *packed_fwd, void *packed_dgrad, void *stream);
 
 /* SparseConvTensor.dense() (spconv/__init__.py; consumed at second/pytorch/models/middle.py:206-210).
  * Scatter rows into a zero-initialised dense tensor with arbitrary element strides so the same kernel

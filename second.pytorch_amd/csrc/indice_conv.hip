@@ -1886,10 +1886,49 @@ SEC_API int sec_indice_conv_fwd(const void *features, int n_in, int cin, const v
     return check_launch();
 }
 
+// fp32 master weight -> the three 16-bit images a mixed-precision training step reads, in ONE launch: the plain [k][ci][co]
+// rounding (the weight gradient kernels' shape reference and the VALU fall-backs), the forward MFMA image (k_pack_weight, or
+// k_pack_weight_c4 for the 4-channel first layer) and the data-gradient image (k_pack_weight_t).  Replaces to(dtype) + pack in the
+// forward and the transposed pack in the backward: three launches per layer and step.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_pack_weight_train(const float *__restrict__ w, int kvol, int cin, int cout, int mirror,
+                                                             T *__restrict__ w16, T *__restrict__ packed, long long total_fwd,
+                                                             T *__restrict__ packed_t, long long total_t) {
+    const long long g = (long long)blockIdx.x * kBlock + threadIdx.x;
+    const long long total0 = (long long)kvol * cin * cout;
+    if (g < total0) w16[g] = Cvt<T>::from(w[g]);
+    const int e = (int)(g & 7), lane = (int)((g >> 3) & 63);
+    if (packed && g < total_fwd) {
+        if (cin == 4) {                                         // k_pack_weight_c4
+            const int s_ = (int)(g >> 9);
+            const int K = s_ * 16 + (lane >> 5) * 8 + e, kk = K >> 2, ci = K & 3, c = lane & 31;
+            packed[g] = (kk < 27 && c < cout) ? Cvt<T>::from(w[((size_t)kk * 4 + ci) * cout + c]) : Cvt<T>::from(0.0f);
+        } else {                                                // k_pack_weight
+            const int ks = cin / 16, nt = (cout + 31) / 32;
+            long long q = g >> 9;
+            const int t = (int)(q % nt);
+            q /= nt;
+            const int sidx = (int)(q % ks), k = (int)(q / ks);
+            const int ci = sidx * 16 + (lane >> 5) * 8 + e, co = t * 32 + (lane & 31);
+            packed[g] = co < cout ? Cvt<T>::from(w[((size_t)k * cin + ci) * cout + co]) : Cvt<T>::from(0.0f);
+        }
+    }
+    if (packed_t && g < total_t) {                              // k_pack_weight_t
+        const int ks = cout / 16, nt = (cin + 31) / 32;
+        long long q = g >> 9;
+        const int t = (int)(q % nt);
+        q /= nt;
+        const int sidx = (int)(q % ks), k = (int)(q / ks);
+        const int co = sidx * 16 + (lane >> 5) * 8 + e, ci = t * 32 + (lane & 31);
+        const int km = mirror ? kvol - 1 - k : k;
+        packed_t[g] = ci < cin ? Cvt<T>::from(w[((size_t)km * cin + ci) * cout + co]) : Cvt<T>::from(0.0f);
+    }
+}
+
 template <typename T>
 static int run_bwd(const void *features, int n_in, int cin, const void *weight, int kvol, int cout, const int *nbr_out,
                    const int *nbr_in, int n_out, const void *dout, void *dfeat, float *dweight, void *workspace,
-                   size_t workspace_bytes, int dtype, hipStream_t st) {
+                   size_t workspace_bytes, int dtype, hipStream_t st, const void *packed_dgrad = nullptr) {
     int rc;
     if (dfeat && n_in > 0) {
         const int *tbl = nbr_in ? nbr_in : nbr_out;  // SubM: nbr_in is the mirror image of nbr_out
@@ -1897,7 +1936,9 @@ static int run_bwd(const void *features, int n_in, int cin, const void *weight, 
         if constexpr (!std::is_same<T, float>::value) {
             // MFMA path: forward kernels on (dout, Wt) with Cin <-> Cout swapped
             const size_t need = sec_packed_weight_bytes(kvol, cout, cin, dtype);
-            if (need > 0 && workspace && workspace_bytes >= need && n_out > 0) {
+            if (need > 0 && packed_dgrad && n_out > 0) {   // the caller packed it already (sec_pack_conv_weight_train)
+                done = dispatch_mfma<T, T>(cout, cin, dout, n_out, packed_dgrad, tbl, n_in, nullptr, kvol, nullptr, nullptr, 0, dfeat, st);
+            } else if (need > 0 && workspace && workspace_bytes >= need && n_out > 0) {
                 long long total = (long long)kvol * cout * ((cin + 31) / 32) * 32;
                 hipLaunchKernelGGL(k_pack_weight_t<T>, dim3(div_up(total, kBlock)), dim3(kBlock), 0, st, (const T *)weight, kvol, cin,
                                    cout, nbr_in ? 0 : 1, (T *)workspace);
@@ -1932,12 +1973,32 @@ SEC_API size_t sec_indice_conv_bwd_workspace_bytes(int kvol, int cin, int cout, 
 
 SEC_API int sec_indice_conv_bwd(const void *features, int n_in, int cin, const void *weight, int kvol, int cout,
                                 const int *nbr_out, const int *nbr_in, int n_out, const void *dout, void *dfeat,
-                                float *dweight, int dtype, void *workspace, size_t workspace_bytes, void *stream) {
+                                float *dweight, int dtype, void *workspace, size_t workspace_bytes, const void *packed_dgrad,
+                                void *stream) {
     if (n_in < 0 || n_out < 0 || cin <= 0 || cout <= 0 || kvol <= 0 || !weight || !nbr_out || !dout) return SEC_E_INVALID;
     if (!nbr_in && n_in != n_out) return SEC_E_INVALID;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == SEC_F32) return run_bwd<float>(features, n_in, cin, weight, kvol, cout, nbr_out, nbr_in, n_out, dout, dfeat, dweight, workspace, workspace_bytes, dtype, st);
-    if (dtype == SEC_F16) return run_bwd<__half>(features, n_in, cin, weight, kvol, cout, nbr_out, nbr_in, n_out, dout, dfeat, dweight, workspace, workspace_bytes, dtype, st);
-    if (dtype == SEC_BF16) return run_bwd<__hip_bfloat16>(features, n_in, cin, weight, kvol, cout, nbr_out, nbr_in, n_out, dout, dfeat, dweight, workspace, workspace_bytes, dtype, st);
+    if (dtype == SEC_F16) return run_bwd<__half>(features, n_in, cin, weight, kvol, cout, nbr_out, nbr_in, n_out, dout, dfeat, dweight, workspace, workspace_bytes, dtype, st, packed_dgrad);
+    if (dtype == SEC_BF16) return run_bwd<__hip_bfloat16>(features, n_in, cin, weight, kvol, cout, nbr_out, nbr_in, n_out, dout, dfeat, dweight, workspace, workspace_bytes, dtype, st, packed_dgrad);
     return SEC_E_UNSUPPORTED;
+}
+
+SEC_API int sec_pack_conv_weight_train(const float *weight, int kvol, int cin, int cout, int subm, int dtype, void *weight16,
+                                       void *packed_fwd, void *packed_dgrad, void *stream) {
+    if (!weight || !weight16 || kvol <= 0 || cin <= 0 || cout <= 0 || (dtype != SEC_BF16 && dtype != SEC_F16)) return SEC_E_INVALID;
+    const long long total0 = (long long)kvol * cin * cout;
+    const long long total_fwd = packed_fwd ? (long long)(sec_packed_weight_bytes(kvol, cin, cout, dtype) / 2) : 0;
+    const long long total_t = packed_dgrad ? (long long)(sec_packed_weight_bytes(kvol, cout, cin, dtype) / 2) : 0;
+    if ((packed_fwd && total_fwd == 0) || (packed_dgrad && (total_t == 0 || cout % 16))) return SEC_E_UNSUPPORTED;
+    long long total = total0 > total_fwd ? total0 : total_fwd;
+    if (total_t > total) total = total_t;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == SEC_BF16)
+        hipLaunchKernelGGL(k_pack_weight_train<__hip_bfloat16>, dim3(div_up(total, kBlock)), dim3(kBlock), 0, st, weight, kvol, cin, cout, subm ? 1 : 0,
+                           (__hip_bfloat16 *)weight16, (__hip_bfloat16 *)packed_fwd, total_fwd, (__hip_bfloat16 *)packed_dgrad, total_t);
+    else
+        hipLaunchKernelGGL(k_pack_weight_train<__half>, dim3(div_up(total, kBlock)), dim3(kBlock), 0, st, weight, kvol, cin, cout, subm ? 1 : 0,
+                           (__half *)weight16, (__half *)packed_fwd, total_fwd, (__half *)packed_dgrad, total_t);
+    return check_launch();
 }

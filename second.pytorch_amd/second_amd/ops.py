@@ -422,10 +422,31 @@ def indice_conv_set_variant(variant):
     rt.check(rt.lib().sec_indice_conv_set_variant(int(variant)), "sec_indice_conv_set_variant")
 
 
-def indice_conv_backward(features, weight, nbr_out, nbr_in, dout, need_dfeat=True, need_dweight=True, dweight_dtype=None):
+def pack_weight_train(weight, dtype, subm):
+    """fp32 master weight [kD,kH,kW,Cin,Cout] -> (16-bit copy, forward MFMA image or None, data-gradient MFMA image or None) in
+    ONE launch (sec_pack_conv_weight_train): what a mixed-precision step otherwise spends to(dtype) + pack_weight + the transposed
+    pack inside indice_conv_backward on.  ``subm``: the data-gradient image is offset-mirrored (SubM rulebooks have no input-major
+    table)."""
+    rt.require_gpu(weight)
+    assert weight.dtype == torch.float32 and weight.is_contiguous() and dtype in (torch.bfloat16, torch.float16)
+    cin, cout = weight.shape[-2], weight.shape[-1]
+    k = weight.numel() // (cin * cout)
+    l, code = rt.lib(), rt.dtype_code(dtype)
+    nf, nt = l.sec_packed_weight_bytes(k, cin, cout, code), (l.sec_packed_weight_bytes(k, cout, cin, code) if cout % 16 == 0 else 0)
+    w16 = torch.empty(weight.shape, dtype=dtype, device=weight.device)
+    pk = torch.empty((nf // 2,), dtype=dtype, device=weight.device) if nf else None
+    pkt = torch.empty((nt // 2,), dtype=dtype, device=weight.device) if nt else None
+    rt.check(l.sec_pack_conv_weight_train(rt.ptr(weight), k, cin, cout, int(bool(subm)), code, rt.ptr(w16), rt.ptr(pk), rt.ptr(pkt),
+                                          rt.stream()), "sec_pack_conv_weight_train")
+    return w16, pk, pkt
+
+
+def indice_conv_backward(features, weight, nbr_out, nbr_in, dout, need_dfeat=True, need_dweight=True, dweight_dtype=None,
+                         packed_dgrad=None):
     """(dfeat, dweight) of indice_conv (spconv.ops.indice_conv_backward). nbr_in None => SubM mirror.  The kernels accumulate
     dweight in fp32; it is returned in ``dweight_dtype`` (default: the weight's dtype; torch.float32 hands a mixed-precision
-    caller the unrounded gradient of its fp32 master weight without a cast launch)."""
+    caller the unrounded gradient of its fp32 master weight without a cast launch).  ``packed_dgrad``: the data-gradient image of
+    :func:`pack_weight_train` (mirrored iff nbr_in is None) -- the call then skips its own transposed pack."""
     rt.require_gpu(features, weight, nbr_out, dout)
     cin, cout = weight.shape[-2], weight.shape[-1]
     k = weight.numel() // (cin * cout)
@@ -436,7 +457,7 @@ def indice_conv_backward(features, weight, nbr_out, nbr_in, dout, need_dfeat=Tru
     ws = rt.workspace(l.sec_indice_conv_bwd_workspace_bytes(k, cin, cout, rt.dtype_code(features.dtype)), features.device)
     rc = l.sec_indice_conv_bwd(rt.ptr(features), features.shape[0], cin, rt.ptr(weight), k, cout, rt.ptr(nbr_out),
                                rt.ptr(nbr_in), dout.shape[0], rt.ptr(dout), rt.ptr(dfeat), rt.ptr(dw),
-                               rt.dtype_code(features.dtype), rt.ptr(ws), ws.numel(), rt.stream())
+                               rt.dtype_code(features.dtype), rt.ptr(ws), ws.numel(), rt.ptr(packed_dgrad), rt.stream())
     rt.check(rc, "sec_indice_conv_bwd")
     return dfeat, (dw.to(dweight_dtype or weight.dtype) if dw is not None else None)
 

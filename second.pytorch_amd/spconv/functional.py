@@ -9,12 +9,19 @@ class IndiceConvFunction(torch.autograd.Function):
     def forward(ctx, features, weight, rulebook, packed):
         ctx.rulebook = rulebook
         ctx.master_dtype = weight.dtype
+        ctx.packed_dgrad = None
         if weight.dtype != features.dtype:
             # mixed precision (fp32 master weight, 16-bit features): the cast copy is made HERE, outside autograd -- the weight
             # gradient comes out of the kernels in fp32 and goes straight to the master weight (no fp32 -> 16-bit -> fp32 round
             # trip: two launches per layer and a rounding of dW less)
-            weight = weight.detach().to(features.dtype)
-            packed = _ops.pack_weight(weight.contiguous()) if weight.is_cuda and weight.dtype != torch.float32 else None
+            if (weight.is_cuda and weight.dtype == torch.float32 and features.dtype in (torch.bfloat16, torch.float16)
+                    and getattr(rulebook, "subm", None) is not None):
+                # ... together with BOTH MFMA images of the step, one launch (the backward would pack the transposed one again)
+                weight, packed, ctx.packed_dgrad = _ops.pack_weight_train(weight.detach().contiguous(), features.dtype,
+                                                                          subm=rulebook.nbr_in is None)
+            else:
+                weight = weight.detach().to(features.dtype)
+                packed = _ops.pack_weight(weight.contiguous()) if weight.is_cuda and weight.dtype != torch.float32 else None
         ctx.save_for_backward(features, weight)
         return _ops.indice_conv(features.contiguous(), weight.contiguous(), rulebook.nbr_out, rulebook.num_out,
                                 packed=packed, num_out_dev=rulebook.num_out_dev)
@@ -28,7 +35,7 @@ class IndiceConvFunction(torch.autograd.Function):
                                "under torch.enable_grad() to back-propagate through a strided sparse conv")
         dfeat, dw = _ops.indice_conv_backward(features.contiguous(), weight.contiguous(), rb.nbr_out, rb.nbr_in,
                                               grad_out.contiguous(), ctx.needs_input_grad[0], ctx.needs_input_grad[1],
-                                              dweight_dtype=ctx.master_dtype)
+                                              dweight_dtype=ctx.master_dtype, packed_dgrad=ctx.packed_dgrad)
         return dfeat, dw, None, None
 
 

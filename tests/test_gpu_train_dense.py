@@ -458,3 +458,34 @@ def test_flat_adamw_device_side_loss_scaling_state_machine():
         opt.step()
     torch.testing.assert_close(mine[0].detach(), ref[0].detach(), rtol=5e-6, atol=5e-7)
     assert ls.tolist() == [1024.0, 0.0, 3.0, 1.0] and opt.state[1].item() == 4.0
+
+
+def test_pack_weight_train_equals_the_three_separate_packs():
+    """sec_pack_conv_weight_train: the 16-bit rounding, the forward MFMA image and the (mirrored / plain) data-gradient image of a
+    layer in one launch == to(dtype) + sec_pack_conv_weight + the transposed pack sec_indice_conv_bwd builds itself; and a backward
+    that is handed the image returns the same bits as one that packs its own."""
+    from second_amd import ops
+    torch.manual_seed(5)
+    for (k, cin, cout), dt in [((27, 4, 16), torch.bfloat16), ((27, 16, 32), torch.float16), ((27, 64, 64), torch.bfloat16), ((3, 64, 64), torch.bfloat16)]:
+        shape = (3, 3, 3) if k == 27 else (3, 1, 1)
+        w = torch.randn(*shape, cin, cout, device="cuda")
+        for subm in (True, False):
+            w16, pk, pkt = ops.pack_weight_train(w, dt, subm)
+            assert torch.equal(w16, w.to(dt))
+            ref = ops.pack_weight(w.to(dt).contiguous())
+            assert (pk is None) == (ref is None) and (pk is None or torch.equal(pk, ref))
+            assert pkt is not None
+            rng = np.random.default_rng(cin + cout)
+            n = 300
+            idx = np.unique(np.stack([np.zeros(n, np.int64), rng.integers(0, 6, n), rng.integers(0, 12, n), rng.integers(0, 12, n)], 1), axis=0).astype(np.int32)
+            if subm:
+                rb = ops.rulebook_subm(torch.from_numpy(idx).cuda(), 1, [6, 12, 12], shape, [1, 1, 1])
+                nbr_out, nbr_in, n_out = rb["nbr_out"], None, len(idx)
+            else:
+                rb = ops.rulebook_conv(torch.from_numpy(idx).cuda(), 1, [6, 12, 12], shape, [2, 2, 2] if k == 27 else [2, 1, 1], [1, 1, 1] if k == 27 else [0, 0, 0], [1, 1, 1])
+                nbr_out, nbr_in, n_out = rb["nbr_out"], rb["nbr_in"], int(rb["num_out"])
+            feat = torch.randn(len(idx), cin, device="cuda").to(dt)
+            dout = torch.randn(n_out, cout, device="cuda").to(dt)
+            a = ops.indice_conv_backward(feat, w16, nbr_out[:n_out], nbr_in, dout, packed_dgrad=pkt)
+            b = ops.indice_conv_backward(feat, w16, nbr_out[:n_out], nbr_in, dout)
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
