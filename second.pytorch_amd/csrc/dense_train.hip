@@ -47,14 +47,19 @@ template <> __device__ __forceinline__ __half f2t(float v) { return __float2half
 // tap in a fixed order (deterministic -- no float atomics) into torch's [Cout][Cin][3][3] layout.
 template <typename T>
 __global__ __launch_bounds__(256, 2) void k_conv2d_wgrad3x3(const T *__restrict__ x, const T *__restrict__ dy, float *__restrict__ part,
-                                                            int B, int H, int W, int steps, long long P) {
+                                                            int B, int H, int W, int steps, long long P, int slices) {
     constexpr int C = 128, LD = 72;                        // LD: 64 pixels + 8 pad (144-byte rows)
     __shared__ __attribute__((aligned(16))) T sX[2][C][LD];
     __shared__ __attribute__((aligned(16))) T sD[2][C][LD];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int tap = blockIdx.y, ty = tap / 3 - 1, tx = tap % 3 - 1;
-    const long long step0 = (long long)blockIdx.x * steps;
+    // The nine taps of a pixel slice read the same 2 x 650 KB of x and dy: workgroup id = (group of 8 slices) * 72 + tap * 8 + xcd puts
+    // them on ONE XCD (workgroups go to XCD id % 8) and next to each other in dispatch order, so eight of the nine reads are hits
+    // in that XCD's L2 instead of nine trips to the fabric.
+    const int within = blockIdx.x % 72, slice = (blockIdx.x / 72) * 8 + within % 8;
+    const int tap = within / 8, ty = tap / 3 - 1, tx = tap % 3 - 1;
+    if (slice >= slices) return;
+    const long long step0 = (long long)slice * steps;
     const long long total_steps = (P + 63) / 64;
     const int nst = (int)(step0 + steps <= total_steps ? steps : (total_steps > step0 ? total_steps - step0 : 0));
     // this thread stages channels chg*8.. of pixels pg*4..pg*4+3 of a step.  The PIXEL group runs fastest across lanes: the sixteen
@@ -127,7 +132,7 @@ __global__ __launch_bounds__(256, 2) void k_conv2d_wgrad3x3(const T *__restrict_
         }
     }
     // D layout: column (co) = lane & 31, rows (ci) = (i & 3) + 8 (i >> 2) + 4 h
-    float *dst = part + ((size_t)blockIdx.x * 9 + tap) * C * C;
+    float *dst = part + ((size_t)slice * 9 + tap) * C * C;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -344,8 +349,8 @@ static int run_wgrad(const void *x, const void *dy, int B, int H, int W, float *
     if (gx < 1) gx = 1;
     const size_t need = (size_t)gx * 9 * 128 * 128 * sizeof(float);
     if (ws_bytes < need) return SEC_E_WORKSPACE;
-    hipLaunchKernelGGL((k_conv2d_wgrad3x3<T>), dim3((unsigned)gx, 9), dim3(256), 0, st, (const T *)x, (const T *)dy, (float *)ws, B, H, W,
-                       steps, P);
+    hipLaunchKernelGGL((k_conv2d_wgrad3x3<T>), dim3((unsigned)((gx + 7) / 8 * 72)), dim3(256), 0, st, (const T *)x, (const T *)dy, (float *)ws, B, H, W,
+                       steps, P, (int)gx);
     hipLaunchKernelGGL(k_conv2d_wgrad_reduce, dim3(div_up(9 * 128 * 128, 256)), dim3(256), 0, st, (const float *)ws, (int)gx, dw);
     return check_launch();
 }
