@@ -47,7 +47,7 @@ template <> __device__ __forceinline__ __half f2t(float v) { return __float2half
 // tap in a fixed order (deterministic -- no float atomics) into torch's [Cout][Cin][3][3] layout.
 template <typename T>
 __global__ __launch_bounds__(256, 2) void k_conv2d_wgrad3x3(const T *__restrict__ x, const T *__restrict__ dy, float *__restrict__ part,
-                                                            int B, int H, int W, int steps, long long P, int slices) {
+                                                            int B, int H, int W, int steps, long long P, int slices, int ntaps) {
     constexpr int C = 128, LD = 72;                        // LD: 64 pixels + 8 pad (144-byte rows)
     __shared__ __attribute__((aligned(16))) T sX[2][C][LD];
     __shared__ __attribute__((aligned(16))) T sD[2][C][LD];
@@ -56,8 +56,10 @@ __global__ __launch_bounds__(256, 2) void k_conv2d_wgrad3x3(const T *__restrict_
     // The nine taps of a pixel slice read the same 2 x 650 KB of x and dy: workgroup id = (group of 8 slices) * 72 + tap * 8 + xcd puts
     // them on ONE XCD (workgroups go to XCD id % 8) and next to each other in dispatch order, so eight of the nine reads are hits
     // in that XCD's L2 instead of nine trips to the fabric.
-    const int within = blockIdx.x % 72, slice = (blockIdx.x / 72) * 8 + within % 8;
-    const int tap = within / 8, ty = tap / 3 - 1, tx = tap % 3 - 1;
+    // (ntaps == 1: a 1x1 convolution -- the centre tap alone.)
+    const int per = ntaps * 8;
+    const int within = blockIdx.x % per, slice = (blockIdx.x / per) * 8 + within % 8;
+    const int tslot = within / 8, tap = ntaps == 1 ? 4 : tslot, ty = tap / 3 - 1, tx = tap % 3 - 1;
     if (slice >= slices) return;
     const long long step0 = (long long)slice * steps;
     const long long total_steps = (P + 63) / 64;
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(256, 2) void k_conv2d_wgrad3x3(const T *__restrict_
         }
     }
     // D layout: column (co) = lane & 31, rows (ci) = (i & 3) + 8 (i >> 2) + 4 h
-    float *dst = part + ((size_t)slice * 9 + tap) * C * C;
+    float *dst = part + ((size_t)slice * ntaps + tslot) * C * C;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -143,14 +145,14 @@ __global__ __launch_bounds__(256, 2) void k_conv2d_wgrad3x3(const T *__restrict_
 }
 
 // dw[co][ci][tap] (torch's [Cout][Cin][3][3]) = sum_g part[g][tap][ci][co], g ascending (fixed order: run-to-run identical)
-__global__ __launch_bounds__(256) void k_conv2d_wgrad_reduce(const float *__restrict__ part, int groups, float *__restrict__ dw) {
+__global__ __launch_bounds__(256) void k_conv2d_wgrad_reduce(const float *__restrict__ part, int groups, float *__restrict__ dw, int ntaps) {
     constexpr int C = 128;
     const int e = blockIdx.x * 256 + threadIdx.x;           // e = (tap * C + ci) * C + co
-    if (e >= 9 * C * C) return;
+    if (e >= ntaps * C * C) return;
     float s = 0.0f;
-    for (int g = 0; g < groups; ++g) s += part[(size_t)g * 9 * C * C + e];
+    for (int g = 0; g < groups; ++g) s += part[(size_t)g * ntaps * C * C + e];
     const int co = e % C, ci = (e / C) % C, tap = e / (C * C);
-    dw[((size_t)co * C + ci) * 9 + tap] = s;
+    dw[((size_t)co * C + ci) * ntaps + tap] = s;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -340,18 +342,18 @@ __global__ __launch_bounds__(kBlock) void k_conv2d_pack_train(const float *__res
 constexpr int kBnGroups = 512;
 
 template <typename T>
-static int run_wgrad(const void *x, const void *dy, int B, int H, int W, float *dw, void *ws, size_t ws_bytes, hipStream_t st) {
+static int run_wgrad(const void *x, const void *dy, int B, int H, int W, float *dw, void *ws, size_t ws_bytes, hipStream_t st, int ntaps) {
     const long long P = (long long)B * H * W;
     const long long total_steps = (P + 63) / 64;
-    int steps = 40;                                          // ~2 workgroups per CU at batch 4 (2200 steps -> 55 runs x 9 taps)
+    int steps = ntaps == 1 ? 4 : 40;                         // ~2 workgroups per CU at batch 4 (2200 steps -> 55 runs x 9 taps; one tap: 256 runs)
     long long gx = (total_steps + steps - 1) / steps;
     if (gx > 256) { steps = (int)((total_steps + 255) / 256); gx = (total_steps + steps - 1) / steps; }
     if (gx < 1) gx = 1;
-    const size_t need = (size_t)gx * 9 * 128 * 128 * sizeof(float);
+    const size_t need = (size_t)gx * ntaps * 128 * 128 * sizeof(float);
     if (ws_bytes < need) return SEC_E_WORKSPACE;
-    hipLaunchKernelGGL((k_conv2d_wgrad3x3<T>), dim3((unsigned)((gx + 7) / 8 * 72)), dim3(256), 0, st, (const T *)x, (const T *)dy, (float *)ws, B, H, W,
-                       steps, P, (int)gx);
-    hipLaunchKernelGGL(k_conv2d_wgrad_reduce, dim3(div_up(9 * 128 * 128, 256)), dim3(256), 0, st, (const float *)ws, (int)gx, dw);
+    hipLaunchKernelGGL((k_conv2d_wgrad3x3<T>), dim3((unsigned)((gx + 7) / 8 * 8 * ntaps)), dim3(256), 0, st, (const T *)x, (const T *)dy, (float *)ws, B, H, W,
+                       steps, P, (int)gx, ntaps);
+    hipLaunchKernelGGL(k_conv2d_wgrad_reduce, dim3(div_up(ntaps * 128 * 128, 256)), dim3(256), 0, st, (const float *)ws, (int)gx, dw, ntaps);
     return check_launch();
 }
 
@@ -360,21 +362,23 @@ static int run_wgrad(const void *x, const void *dy, int B, int H, int W, float *
 using namespace sec;
 
 SEC_API size_t sec_conv2d_wgrad_workspace_bytes(int batch, int h, int w, int cin, int cout, int ksize) {
-    if (cin != 128 || cout != 128 || ksize != 3 || batch <= 0 || h <= 0 || w <= 0) return 0;
+    if (cin != 128 || cout != 128 || (ksize != 3 && ksize != 1) || batch <= 0 || h <= 0 || w <= 0) return 0;
     const long long total_steps = ((long long)batch * h * w + 63) / 64;
-    long long gx = (total_steps + 39) / 40;
+    const int steps0 = ksize == 1 ? 4 : 40;
+    long long gx = (total_steps + steps0 - 1) / steps0;
     if (gx > 256) gx = 256;
     if (gx < 1) gx = 1;
-    return (size_t)gx * 9 * 128 * 128 * sizeof(float);
+    return (size_t)gx * ksize * ksize * 128 * 128 * sizeof(float);
 }
 
 SEC_API int sec_conv2d_wgrad_nhwc(const void *x, const void *dy, int batch, int h, int w, int cin, int cout, int ksize, int stride,
                                   int pad, float *dweight, void *workspace, size_t workspace_bytes, int dtype, void *stream) {
     if (!x || !dy || !dweight || !workspace || batch <= 0 || h <= 0 || w <= 0) return SEC_E_INVALID;
-    if (cin != 128 || cout != 128 || ksize != 3 || stride != 1 || pad != 1 || (dtype != SEC_BF16 && dtype != SEC_F16)) return SEC_E_UNSUPPORTED;
+    if (cin != 128 || cout != 128 || stride != 1 || !((ksize == 3 && pad == 1) || (ksize == 1 && pad == 0)) ||
+        (dtype != SEC_BF16 && dtype != SEC_F16)) return SEC_E_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == SEC_BF16) return run_wgrad<__hip_bfloat16>(x, dy, batch, h, w, dweight, workspace, workspace_bytes, st);
-    return run_wgrad<__half>(x, dy, batch, h, w, dweight, workspace, workspace_bytes, st);
+    if (dtype == SEC_BF16) return run_wgrad<__hip_bfloat16>(x, dy, batch, h, w, dweight, workspace, workspace_bytes, st, ksize * ksize);
+    return run_wgrad<__half>(x, dy, batch, h, w, dweight, workspace, workspace_bytes, st, ksize * ksize);
 }
 
 SEC_API int sec_conv2d_pack_weight_train(const float *weight, int cout, int cin, int ksize, int dtype, void *packed_fwd,

@@ -423,12 +423,27 @@ def rpn_forward_mixed(rpn, x, dtype):
                 x = m(x)
             i += 1
         return x
+    def run_deblock(deb, x):
+        mods = list(deb.children())
+        m = mods[0]
+        if (use_hip and len(mods) == 3 and isinstance(m, nn.ConvTranspose2d) and isinstance(mods[1], nn.BatchNorm2d)
+                and isinstance(mods[2], nn.ReLU) and m.bias is None and m.kernel_size == (1, 1) and m.stride == (1, 1)
+                and m.padding == (0, 0) and m.output_padding == (0, 0) and m.groups == 1 and m.in_channels == 128
+                and m.out_channels == 128 and dtype in (torch.bfloat16, torch.float16) and mods[1].training
+                and mods[1].track_running_stats and mods[1].affine):
+            bn = mods[1]
+            y = ops.ConvTranspose1x1Function.apply(x, m.weight)
+            mom = bn.momentum if bn.momentum is not None else 0.1
+            z = ops.BatchNormReluFunction.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, mom, True)
+            ops.bump_bn_counter(bn)
+            return z
+        with torch.autocast("cuda", dtype=dtype, enabled=x.is_cuda, cache_enabled=False):
+            return deb(x)
     ups = []
     for i, blk in enumerate(rpn.blocks):
         x = run_block(blk, x)
         if i - rpn._upsample_start_idx >= 0:
-            with torch.autocast("cuda", dtype=dtype, enabled=x.is_cuda, cache_enabled=False):
-                ups.append(rpn.deblocks[i - rpn._upsample_start_idx](x))
+            ups.append(run_deblock(rpn.deblocks[i - rpn._upsample_start_idx], x))
     with torch.autocast("cuda", dtype=dtype, enabled=x.is_cuda, cache_enabled=False):
         if ups:
             x = torch.cat(ups, dim=1) if len(ups) > 1 else ups[0]

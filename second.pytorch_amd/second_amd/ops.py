@@ -1089,21 +1089,22 @@ def conv2d_dgrad_weight(weight):
     return weight.flip(2, 3).transpose(0, 1).contiguous()
 
 
-def conv2d_wgrad(x, dy):
-    """dW [Cout,Cin,3,3] fp32 of y = conv2d(x, W, stride 1, padding 1): x [B,Cin,H,W], dy [B,Cout,H,W], both channels_last 16-bit,
-    Cin = Cout = 128 (sec_conv2d_wgrad_nhwc).  Deterministic."""
+def conv2d_wgrad(x, dy, ksize=3):
+    """dW [Cout,Cin,k,k] fp32 of y = conv2d(x, W, stride 1, padding k // 2), k = 3 or 1: x [B,Cin,H,W], dy [B,Cout,H,W], both
+    channels_last 16-bit, Cin = Cout = 128 (sec_conv2d_wgrad_nhwc).  Deterministic."""
     rt.require_gpu(x, dy)
     assert x.dtype == dy.dtype and x.dim() == 4 and x.shape[0] == dy.shape[0] and x.shape[2:] == dy.shape[2:]
     assert x.is_contiguous(memory_format=torch.channels_last) and dy.is_contiguous(memory_format=torch.channels_last)
     b, cin, h, w = x.shape
     cout = dy.shape[1]
     l = rt.lib()
-    nb = l.sec_conv2d_wgrad_workspace_bytes(b, h, w, cin, cout, 3)
+    k = int(ksize)
+    nb = l.sec_conv2d_wgrad_workspace_bytes(b, h, w, cin, cout, k)
     if nb == 0:
-        raise rt.SecondHipError(f"conv2d_wgrad: unsupported shape {cin}->{cout} (3x3 / s1 / p1 with 128 channels only)")
+        raise rt.SecondHipError(f"conv2d_wgrad: unsupported shape {cin}->{cout} k{k} (3x3 / s1 / p1 or 1x1 with 128 channels only)")
     ws = rt.workspace(nb, x.device)
-    dw = torch.empty((cout, cin, 3, 3), dtype=torch.float32, device=x.device)
-    rt.check(l.sec_conv2d_wgrad_nhwc(rt.ptr(x), rt.ptr(dy), b, h, w, cin, cout, 3, 1, 1, rt.ptr(dw), rt.ptr(ws), ws.numel(),
+    dw = torch.empty((cout, cin, k, k), dtype=torch.float32, device=x.device)
+    rt.check(l.sec_conv2d_wgrad_nhwc(rt.ptr(x), rt.ptr(dy), b, h, w, cin, cout, k, 1, k // 2, rt.ptr(dw), rt.ptr(ws), ws.numel(),
                                      rt.dtype_code(x.dtype), rt.stream()), "sec_conv2d_wgrad_nhwc")
     return dw
 
@@ -1202,6 +1203,34 @@ class Conv3x3Function(torch.autograd.Function):
             dx = conv2d_nhwc(dy, pk_d, None, ctx.wshape[1], 3, 1, 1, relu=False)
         if ctx.needs_input_grad[1]:
             dw = conv2d_wgrad(x, dy).to(ctx.wdtype)
+        return dx, dw
+
+
+class ConvTranspose1x1Function(torch.autograd.Function):
+    """nn.ConvTranspose2d(128, 128, 1, stride=1, bias=False) -- the deblock of a single-block RPNV2 (rpn.py:275-285) -- on
+    channels_last 16-bit activations over its fp32 master weight [Cin, Cout, 1, 1]: y[co] = sum_ci x[ci] W[ci][co] is a 1x1
+    convolution with the transposed matrix, its data gradient the 1x1 convolution with W itself, its weight gradient the
+    pixel-contraction of k_conv2d_wgrad3x3 with one tap.  Read as a CONV weight [Cin as cout, Cout as cin], the "dgrad image" of
+    sec_conv2d_pack_weight_train is the forward's matrix and its "forward image" the backward's: one pack launch."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        pk_b, pk_f = conv2d_pack_weight_train(weight.detach().contiguous(), x.dtype)
+        y = conv2d_nhwc(x, pk_f, None, weight.shape[1], 1, 1, 0, relu=False)
+        ctx.save_for_backward(x, pk_b)
+        ctx.wshape, ctx.wdtype = tuple(weight.shape), weight.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, pk_b = ctx.saved_tensors
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = conv2d_nhwc(dy, pk_b, None, ctx.wshape[0], 1, 1, 0, relu=False)
+        if ctx.needs_input_grad[1]:
+            # conv2d_wgrad gives [co][ci] = sum_px x[ci] dy[co]; the transposed conv's weight is [ci][co]
+            dw = conv2d_wgrad(x, dy, 1).reshape(ctx.wshape[1], ctx.wshape[0]).t().reshape(ctx.wshape).to(ctx.wdtype)
         return dx, dw
 
 

@@ -489,3 +489,32 @@ def test_pack_weight_train_equals_the_three_separate_packs():
             a = ops.indice_conv_backward(feat, w16, nbr_out[:n_out], nbr_in, dout, packed_dgrad=pkt)
             b = ops.indice_conv_backward(feat, w16, nbr_out[:n_out], nbr_in, dout)
             assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_conv_transpose_1x1_function_vs_torch(dtype):
+    """ops.ConvTranspose1x1Function (the RPN deblock, rpn.py:275-285: ConvTranspose2d(128, 128, 1, stride 1, bias=False)) forward,
+    data gradient and weight gradient vs torch autograd in fp32 on the same 16-bit-rounded operands."""
+    from second_amd import ops
+    torch.manual_seed(3)
+    b, h, w = 2, 37, 50                                      # ragged against every tile size
+    x = torch.randn(b, 128, h, w, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last).requires_grad_()
+    wt = (torch.randn(128, 128, 1, 1, device="cuda") / 11).requires_grad_()
+    go = torch.randn(b, 128, h, w, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)
+    y = ops.ConvTranspose1x1Function.apply(x, wt)
+    y.backward(go)
+    xr = x.detach().float().requires_grad_()
+    wr = wt.detach().to(dtype).float().requires_grad_()
+    yr = F.conv_transpose2d(xr, wr)
+    yr.backward(go.float())
+    tol = 2 ** -7 if dtype == torch.bfloat16 else 2 ** -9
+    for got, ref, what in ((y, yr, "forward"), (x.grad, xr.grad, "data gradient")):
+        np.testing.assert_allclose(got.detach().float().cpu().numpy(), ref.detach().cpu().numpy(), rtol=tol, atol=tol * float(ref.abs().max()), err_msg=what)
+    assert wt.grad.dtype == torch.float32 and wt.grad.shape == wt.shape
+    np.testing.assert_allclose(wt.grad.cpu().numpy(), wr.grad.cpu().numpy(), rtol=2e-3, atol=2e-3 * float(wr.grad.abs().max()))
+    # run-to-run identical (fixed-order reduction)
+    x.grad = None; wt.grad = None
+    ops.ConvTranspose1x1Function.apply(x, wt).backward(go)
+    g1 = wt.grad.clone(); wt.grad = None
+    ops.ConvTranspose1x1Function.apply(x, wt).backward(go)
+    assert torch.equal(g1, wt.grad)
