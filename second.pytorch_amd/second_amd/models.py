@@ -444,10 +444,30 @@ def rpn_forward_mixed(rpn, x, dtype):
         x = run_block(blk, x)
         if i - rpn._upsample_start_idx >= 0:
             ups.append(run_deblock(rpn.deblocks[i - rpn._upsample_start_idx], x))
+    heads = [(rpn.conv_box, rpn._box_code_size, "box_preds"), (rpn.conv_cls, rpn._num_class, "cls_preds")]
+    if rpn._use_direction_classifier:
+        heads.append((rpn.conv_dir_cls, rpn._num_direction_bins, "dir_cls_preds"))
+    a = rpn._num_anchor_per_loc
+    if (use_hip and len(ups) == 1 and ups[0].shape[1] == 128 and dtype in (torch.bfloat16, torch.float16)
+            and sum(c.out_channels for c, _, _ in heads) <= 64
+            and all(isinstance(c, nn.Conv2d) and c.kernel_size == (1, 1) and c.stride == (1, 1) and c.padding == (0, 0) and c.bias is not None
+                    and c.in_channels == 128 for c, _, _ in heads)):
+        # the three heads as one 128 -> 64 1x1 convolution (output channels stacked, zero padded) on the hand-written kernels
+        tot = sum(c.out_channels for c, _, _ in heads)
+        wz = ups[0].new_zeros((64 - tot, 128, 1, 1), dtype=heads[0][0].weight.dtype)
+        wcat = torch.cat([c.weight for c, _, _ in heads] + [wz], 0)
+        bcat = torch.cat([c.bias for c, _, _ in heads] + [wz.new_zeros(64 - tot)], 0)
+        y = ops.Heads1x1Function.apply(ups[0].contiguous(memory_format=torch.channels_last), wcat, bcat)
+        ret, c0 = {}, 0
+        h, w = y.shape[2:]
+        for conv, code, name in heads:
+            o = y[:, c0:c0 + conv.out_channels]
+            c0 += conv.out_channels
+            ret[name] = o.reshape(-1, a, code, h, w).permute(0, 1, 3, 4, 2).contiguous()
+        return ret
     with torch.autocast("cuda", dtype=dtype, enabled=x.is_cuda, cache_enabled=False):
         if ups:
             x = torch.cat(ups, dim=1) if len(ups) > 1 else ups[0]
-        a = rpn._num_anchor_per_loc
 
         def head(conv, code):
             y = conv(x)

@@ -1234,6 +1234,37 @@ class ConvTranspose1x1Function(torch.autograd.Function):
         return dx, dw
 
 
+class Heads1x1Function(torch.autograd.Function):
+    """The RPN's 1x1 heads (conv_box / conv_cls / conv_dir_cls with bias, rpn.py:386-391) as ONE 1x1 convolution 128 -> 64 (the
+    heads' output channels stacked and zero padded) on channels_last 16-bit activations over an fp32 weight [64, 128, 1, 1] and
+    bias [64]: forward and data gradient on sec_conv2d_nhwc, weight gradient on the one-tap form of k_conv2d_wgrad3x3 (the
+    incoming gradient padded to 128 channels), bias gradient a pixel sum."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        pk_f, pk_d = conv2d_pack_weight_train(weight.detach().contiguous(), x.dtype)
+        y = conv2d_nhwc(x, pk_f, bias.detach().float().contiguous(), weight.shape[0], 1, 1, 0, relu=False)
+        ctx.save_for_backward(x, pk_d)
+        ctx.wshape, ctx.wdtype, ctx.bdtype = tuple(weight.shape), weight.dtype, bias.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, pk_d = ctx.saved_tensors
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = conv2d_nhwc(dy, pk_d, None, ctx.wshape[1], 1, 1, 0, relu=False)
+        if ctx.needs_input_grad[1]:
+            b, c, h, w = dy.shape
+            wide = torch.zeros((b, 128, h, w), dtype=dy.dtype, device=dy.device).contiguous(memory_format=torch.channels_last)
+            wide[:, :c] = dy
+            dw = conv2d_wgrad(x, wide, 1)[:c].contiguous().to(ctx.wdtype)
+        if ctx.needs_input_grad[2]:
+            db = dy.float().sum(dim=(0, 2, 3)).to(ctx.bdtype)
+        return dx, dw, db
+
+
 class BatchNormReluFunction(torch.autograd.Function):
     """nn.BatchNorm2d (training mode: batch statistics, running statistics updated) + nn.ReLU in two launches + a finalize, on
     channels_last 16-bit activations with fp32 affine parameters."""

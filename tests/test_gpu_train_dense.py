@@ -518,3 +518,27 @@ def test_conv_transpose_1x1_function_vs_torch(dtype):
     g1 = wt.grad.clone(); wt.grad = None
     ops.ConvTranspose1x1Function.apply(x, wt).backward(go)
     assert torch.equal(g1, wt.grad)
+
+
+def test_heads_1x1_function_vs_torch():
+    """ops.Heads1x1Function (the three 1x1 heads of the RPN stacked into one 128 -> 64 conv with bias, rpn.py:386-391): output, data
+    gradient, weight and bias gradients vs torch autograd in fp32 on the same bf16-rounded operands."""
+    from second_amd import ops
+    torch.manual_seed(4)
+    b, h, w = 2, 33, 48
+    x = torch.randn(b, 128, h, w, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_()
+    wt = (torch.randn(64, 128, 1, 1, device="cuda") / 11).requires_grad_()
+    bs = torch.randn(64, device="cuda").requires_grad_()
+    go = torch.randn(b, 64, h, w, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    y = ops.Heads1x1Function.apply(x, wt, bs)
+    y.backward(go)
+    xr = x.detach().float().requires_grad_()
+    wr = wt.detach().to(torch.bfloat16).float().requires_grad_()
+    br = bs.detach().clone().requires_grad_()
+    yr = F.conv2d(xr, wr, br)
+    yr.backward(go.float())
+    tol = 2 ** -7
+    for got, ref, what in ((y, yr, "forward"), (x.grad, xr.grad, "data gradient")):
+        np.testing.assert_allclose(got.detach().float().cpu().numpy(), ref.detach().cpu().numpy(), rtol=tol, atol=tol * float(ref.abs().max()), err_msg=what)
+    np.testing.assert_allclose(wt.grad.cpu().numpy(), wr.grad.cpu().numpy(), rtol=2e-3, atol=2e-3 * float(wr.grad.abs().max()))
+    np.testing.assert_allclose(bs.grad.cpu().numpy(), br.grad.cpu().numpy(), rtol=2e-3, atol=2e-3 * float(br.grad.abs().max()))
