@@ -1752,6 +1752,10 @@ static bool launch_wgrad_tiled(const void *feat, const void *dout, const int *nb
                                float *dw, hipStream_t st) {
     // large chunks keep the fp32 atomics few, but every workgroup walks its chunk as a serial chain of gather steps:
     // ~5 workgroups per CU measured best on subm2 (chunk 512/1024/2048/4096: 81/67/78/128 us bf16, 222/169/228/417 us fp32)
+    // (A workgroup that owns a chunk of rows AND a group of nine offsets -- dout staged once per 64-row block for all of them, no
+    // pair compaction, accumulators of the nine offsets in registers -- was measured 3-5 x SLOWER, 77 vs 26 us on subm2: its serial
+    // chain is 9 x longer and the kernel is bound by that chain, not by the staging.  Capping the chunk at 1024 rows on the large
+    // nuScenes layers -- 6 600 workgroups instead of 1 700 -- was slower too: 378 vs 207 us for 32 -> 32 at 250 k rows.)
     int chunk = 8192;
     while (chunk > 512 && (long long)div_up(n_out, chunk) * kvol < 1400) chunk >>= 1;
     dim3 grid(div_up(n_out, chunk), kvol);
