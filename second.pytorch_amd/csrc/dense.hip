@@ -338,7 +338,7 @@ template <int CH, int HW_, bool COLKEY> __device__ __forceinline__ int halo_key(
 // the rows (input channel z * 64 + c: the weights are packed in that order), sites without a row read zeros through the buffer
 // bounds check, and a tile whose 2 x 180 map entries are all empty skips the DMA, the LDS sweep and the MFMA loop: what the
 // zero fill + scatter + zero-tile test of the dense form computed, without the 72 MB image.
-template <typename T, int CIN, int TH, int ROLL = 0, bool GATHER = false>
+template <typename T, int CIN, int TH, int ROLL = 0, bool GATHER = false, int NSPLIT = 1>
 __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(const T *__restrict__ x, const T *__restrict__ wpk,
                                                             const float *__restrict__ bias, T *__restrict__ y,
                                                             Conv2dParams p, int tiles_y, int tiles_x, int per_xcd,
@@ -348,7 +348,10 @@ __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(con
                                                             const T *__restrict__ background = nullptr) {
     static_assert(!GATHER || (ROLL == 2 && CIN == 128), "gather prologue: the shared-row loop on two 64-channel planes");
     constexpr int TW = 16, HW_ = TW + 2, HPIX = (TH + 2) * (TW + 2);
-    constexpr int MT = TH * TW / 32;               // 32-pixel m-tiles per wave (4 for an 8 x 16 tile)
+    // NSPLIT == 2: 64 output channels per workgroup -- the waves split the tile's pixels two ways and the channels two ways (the
+    // 64 -> 64 layers of the PointPillars RPN); NSPLIT == 1: a wave owns all pixels for 32 of 128 channels
+    static_assert(NSPLIT == 1 || (NSPLIT == 2 && ROLL == 0 && !GATHER), "pixel split: the two-stage loop only");
+    constexpr int MT = TH * TW / 32 / NSPLIT;      // 32-pixel m-tiles per wave (4 for an 8 x 16 tile)
     constexpr int CH = CIN / 8, HENT = HPIX * CH;
     constexpr int KC = CIN / 64, NIT = 9 * KC;
     extern __shared__ __attribute__((aligned(16))) uint4 halo_smem[];
@@ -363,7 +366,8 @@ __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(con
     // a 6 x 16 tile -- 3 m-tiles, 128 VGPRs, 4 workgroups per CU -- 6 % slower, 97 vs 92 us: 8 x 16 at 3 per CU is the optimum
     // between weight-stream reuse and resident waves.)
     const int xcd = blockIdx.x % 8, local = blockIdx.x / 8;
-    const int n0 = blockIdx.y * 128 + wv * 32;     // this wave's 32 output channels
+    const int n0 = blockIdx.y * (128 / NSPLIT) + (wv % (4 / NSPLIT)) * 32;     // this wave's 32 output channels
+    const int mtb = (wv / (4 / NSPLIT)) * MT;      // ... and its first m-tile of the tile's pixels
     constexpr int cin8 = CIN / 8;
     const uint4 *x4 = reinterpret_cast<const uint4 *>(x);
     const uint4 *w4 = reinterpret_cast<const uint4 *>(wpk);
@@ -478,7 +482,7 @@ __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(con
     int hp0[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        const int q = mt * 32 + r;
+        const int q = (mtb + mt) * 32 + r;
         hp0[mt] = (q >> 4) * HW_ + (q & 15);
     }
     auto load_a = [&](int tap_, int kc_, int s, uint4 (&dst)[MT]) {
@@ -850,7 +854,7 @@ __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(con
         } else {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const int q = mt * 32 + r;
+            const int q = (mtb + mt) * 32 + r;
             const int oy = y0 + (q >> 4), ox = x0 + (q & 15);
             const bool ok = oy < p.h && ox < p.w;
             T *ypix = y + (((size_t)b * p.h + oy) * p.w + ox) * p.cout;
@@ -893,7 +897,7 @@ extern "C" __attribute__((visibility("default"))) int sec__debug_timeline2(long 
 }
 #endif
 
-template <typename T, int CIN, int TH, int ROLL = 0, bool GATHER = false>
+template <typename T, int CIN, int TH, int ROLL = 0, bool GATHER = false, int NSPLIT = 1>
 static int launch_conv2d_halo_reg(const void *x, const void *wpk, const float *bias, void *y, const Conv2dParams &p, hipStream_t st,
                                   const int *site_map = nullptr, unsigned feat_bytes = 0, const unsigned short *tile_order = nullptr,
                                   const int *live_counts = nullptr, const void *background = nullptr) {
@@ -902,7 +906,7 @@ static int launch_conv2d_halo_reg(const void *x, const void *wpk, const float *b
     const long lds_pad = 0;
     const size_t lds = lds_tile + (size_t)lds_pad;
     static bool configured = false;
-    auto fn = k_conv2d_halo_reg<T, CIN, TH, ROLL, GATHER>;
+    auto fn = k_conv2d_halo_reg<T, CIN, TH, ROLL, GATHER, NSPLIT>;
     if (!configured) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         configured = true;
@@ -910,8 +914,9 @@ static int launch_conv2d_halo_reg(const void *x, const void *wpk, const float *b
     const int ty = div_up(p.h, TH), tx = div_up(p.w, 16);
     const int per_xcd = div_up(p.batch * ty * tx, 8);
     const int gx = per_xcd * 8;
-    set_last_kernel("k_conv2d_halo_reg<%s, %d, %d, %d, %s>", dtype_name<T>(), CIN, TH, ROLL, GATHER ? "true" : "false");
-    hipLaunchKernelGGL(fn, dim3(gx, p.cout / 128), dim3(256), lds, st, (const T *)x, (const T *)wpk, bias, (T *)y, p, ty, tx, per_xcd,
+    if (NSPLIT == 1) set_last_kernel("k_conv2d_halo_reg<%s, %d, %d, %d, %s>", dtype_name<T>(), CIN, TH, ROLL, GATHER ? "true" : "false");
+    else set_last_kernel("k_conv2d_halo_reg<%s, %d, %d, %d, %s, %d>", dtype_name<T>(), CIN, TH, ROLL, GATHER ? "true" : "false", NSPLIT);
+    hipLaunchKernelGGL(fn, dim3(gx, p.cout / (128 / NSPLIT)), dim3(256), lds, st, (const T *)x, (const T *)wpk, bias, (T *)y, p, ty, tx, per_xcd,
                        site_map, feat_bytes, tile_order, live_counts, (const T *)background);
     return check_launch();
 }
@@ -1234,6 +1239,13 @@ static int launch_conv2d(const void *x, const void *wpk, const float *bias, void
         return launch_conv2d_halo_reg<T, 128, 8>(x, wpk, bias, y, p, st);   // A/B: the two-stage loop with per-m-tile halo addressing
     if (conv2d_variant() == 13 && p.ksize == 3 && p.stride == 1 && p.pad == 1 && p.cout % 128 == 0 && (p.cin == 128 || p.cin == 64))
         return p.cin == 128 ? launch_conv2d_halo_reg<T, 128, 8, 2>(x, wpk, bias, y, p, st) : launch_conv2d_halo_reg<T, 64, 8>(x, wpk, bias, y, p, st);
+    // 256 input channels (third block of the PointPillars RPN, 50 x 50 maps): 4 x 16 tiles -- 55 KB of halo, two workgroups per CU,
+    // 416 workgroups at batch 4 -- on the two-stage loop (the generic implicit GEMM ran these layers at 0.11 of the MFMA peak)
+    if (conv2d_variant() == 13 && p.ksize == 3 && p.stride == 1 && p.pad == 1 && p.cout % 128 == 0 && p.cin == 256)
+        return launch_conv2d_halo_reg<T, 256, 4>(x, wpk, bias, y, p, st);
+    // 64 -> 64 (first block of the PointPillars RPN, 200 x 200 maps): 64 output channels per workgroup, the waves split the pixels
+    if (conv2d_variant() == 13 && p.ksize == 3 && p.stride == 1 && p.pad == 1 && p.cout == 64 && p.cin == 64)
+        return launch_conv2d_halo_reg<T, 64, 8, 0, false, 2>(x, wpk, bias, y, p, st);
     if (conv2d_variant() == 15 && p.ksize == 3 && p.stride == 1 && p.pad == 1 && p.cout % 128 == 0 && p.cin == 128)
         return launch_conv2d_halo_reg<T, 128, 8, 1>(x, wpk, bias, y, p, st);   // A/B: one A fragment per MFMA (12 LDS reads per 12 MFMAs)
 #ifdef SEC_CONV2D_EXPERIMENTS   // earlier 3x3 kernels (LDS weight slabs / rings), kept for A/B builds: DESIGN.md section 4

@@ -173,10 +173,19 @@ class PillarFeatureNet(nn.Module):
     train_backend = "hip"       # "torch": the reference's materialised [P, T, C] formulation in training (A/B, tests)
 
     def folded(self):
+        """(W^T, scale, shift) of Linear + BatchNorm1d in eval mode; cached until one of the five tensors changes (in-place updates
+        and load_state_dict bump their version counters): six element-wise launches per forward otherwise."""
         l = self.pfn_layers[0]
-        scale = (l.norm.weight * torch.rsqrt(l.norm.running_var + l.norm.eps)).float()
-        shift = (l.norm.bias - l.norm.running_mean * scale).float()
-        return l.linear.weight.detach().t().contiguous().float(), scale.detach().contiguous(), shift.detach().contiguous()
+        src = (l.linear.weight, l.norm.weight, l.norm.bias, l.norm.running_mean, l.norm.running_var)
+        key = tuple((t.data_ptr(), t._version) for t in src)
+        cached = getattr(self, "_folded", None)
+        if cached is None or cached[0] != key:
+            with torch.no_grad():
+                scale = (l.norm.weight * torch.rsqrt(l.norm.running_var + l.norm.eps)).float()
+                shift = (l.norm.bias - l.norm.running_mean * scale).float()
+                cached = self._folded = (key, (l.linear.weight.detach().t().contiguous().float(), scale.detach().contiguous(),
+                                               shift.detach().contiguous()))
+        return cached[1]
 
     def forward_slots(self, points, vox, out_dtype=None, num_dev=None):
         """Inference straight from the voxeliser's point lists (``vox`` = generate_device(points, ..., fill=False)): the

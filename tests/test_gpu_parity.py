@@ -910,7 +910,9 @@ def test_pointpillars_detector_runs_fused_equals_module_path(syn):
                                                      # the halo kernel's border handling: ragged right / bottom edges, a single tile, one pixel
                                                      # over a tile, two output-channel blocks
                                                      (128, 128, 3, 1, 1, (37, 29)), (128, 128, 3, 1, 1, (8, 16)), (128, 128, 3, 1, 1, (9, 17)),
-                                                     (128, 256, 3, 1, 1, (23, 40)), (128, 128, 3, 1, 1, (1, 1))])
+                                                     (128, 256, 3, 1, 1, (23, 40)), (128, 128, 3, 1, 1, (1, 1)),
+                                                     (256, 256, 3, 1, 1, (50, 50)), (256, 128, 3, 1, 1, (7, 19)),    # 4 x 16 tiles, 256 input channels
+                                                     (64, 64, 3, 1, 1, (200, 200)), (64, 64, 3, 1, 1, (13, 21))])     # 64 output channels per workgroup
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_conv2d_nhwc_mfma_vs_torch(ops, cin, cout, k, stride, pad, hw, dtype):
     torch.manual_seed(cin + cout + k)
