@@ -289,11 +289,14 @@ def kernel_table(det, points, offsets, reps=30):
             x, cout, tl = a[0], a[3], a[4]
             b_, cin, h_, w_ = x.shape
             lv, tot = int(a[5].sum().item()), tl.numel()
+            copied = a[6] is not None        # lazy consumers: no background tile is written
             # MFMA fraction on the LIVE tiles' FLOPs (128 pixels x 128 x cout x 9 MACs each); background tiles are one 4 KB store each
-            ent.update(flop=2.0 * lv * 128 * cin * cout * 9, bytes=elt(x.dtype) * (x.numel() * lv // tot + res.numel()), live_tiles=lv, tiles=tot,
+            ent.update(flop=2.0 * lv * 128 * cin * cout * 9,
+                       bytes=elt(x.dtype) * (x.numel() * lv // tot + (res.numel() if copied else res.numel() * lv // tot)), live_tiles=lv, tiles=tot,
                        dense_equivalent_flop=2.0 * b_ * h_ * w_ * cin * cout * 9,
                        detail=f"{cin}->{cout} k3 ({h_}, {w_}); {lv} of {tot} tiles are within reach of a site and are convolved, "
-                              f"the others are copied from the empty frame's output")
+                              + ("the others are copied from the empty frame's output" if copied else
+                                 "the others are not written (the next conv reads them from the empty frame's map)"))
         elif name == "rpn_tile_live":
             smap = a[0]
             ent.update(bytes=4 * smap.numel() + 2 * res[0].numel(), detail=f"site map {tuple(smap.shape)} -> live-tile maps of {a[1]} conv layers")
@@ -811,6 +814,9 @@ def main():
     ap.add_argument("--background-skip", type=int, default=1,
                     help="RPN convs after the first compute only the tiles a site (or the zero padding) can reach and fill the others "
                          "with the layer's background vector (bit-identical outputs; 0 = convolve every tile)")
+    ap.add_argument("--lazy-background", type=int, default=1,
+                    help="with --background-skip 1: the RPN convs write their live tiles only and read background tiles of their input from the "
+                         "empty frame's maps (sec_conv2d_nhwc_tiles_lazy; bit-identical); 0 = every layer copies its background tiles")
     ap.add_argument("--dry-run", action="store_true", help="launcher plumbing only: ranks report themselves (gloo), no GPU work")
     args = ap.parse_args()
     global WL, SELF_WARM_MIN_S, SELF_WARM_MAX_S, TIMED_MIN_S
@@ -856,6 +862,7 @@ def main():
     det, cpu_state = build_detector(device, dtype, None if args.default_heads else syn.syn_kitti_cloud(0))
     if hasattr(det.rpn, "skip_background"):
         det.rpn.skip_background = bool(args.background_skip)
+        det.rpn.lazy_background = bool(args.lazy_background)
 
     # first subm2 layer (64->64 SubM on the 11x400x352 grid): the largest 64->64 3x3x3 launch of the forward
     timer = ConvCapture(lambda m: m["cin"] == 64 and m["cout"] == 64 and m["kvol"] == 27 and m["n_in"] == m["n_out"]
@@ -1001,7 +1008,7 @@ def main():
     if rank == 0 and getattr(det.rpn, "background_convs", 0):
         if det.rpn.skip_background:
             lt = [k for k in (ktable or []) if k["op"] in ("conv2d_nhwc_tiles", "conv2d_nhwc_gather")]
-            bg_tiles = {"enabled": True, "live_tiles_per_conv": [k.get("live_tiles") for k in lt] or None, "tiles": lt[0].get("tiles") if lt else None,
+            bg_tiles = {"enabled": True, "lazy": bool(getattr(det.rpn, "lazy_background", False)), "live_tiles_per_conv": [k.get("live_tiles") for k in lt] or None, "tiles": lt[0].get("tiles") if lt else None,
                         "what": "conv j of the RPN (j = 0..5) convolves only the 8 x 16 tiles a site of the sparse middle can reach within j + 1 "
                                 "steps; the other tiles equal the network's output for an EMPTY frame at that position exactly (any weights) "
                                 "and are copied from it.  Data dependent: --background-skip 0 convolves every tile"}

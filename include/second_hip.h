@@ -35,7 +35,7 @@ extern "C" {
 #define SEC_F16 1
 #define SEC_BF16 2
 
-#define SEC_ABI_VERSION 3
+#define SEC_ABI_VERSION 4
 int sec_abi_version(void);
 /* last HIP error string seen by this library (thread-unsafe convenience for diagnostics) */
 const char *sec_last_error(void);
@@ -264,7 +264,7 @@ int sec_rulebook_chain_sorted(const int *indices0, int n0, const int *n0_dev, in
 int sec_conv2d_nhwc_gather(const void *features, long long feature_rows, const int *site_map, int batch, int h,
                            int w, const void *packed_weight, const float *bias, int cout, int relu,
                            const unsigned short *tile_order, const int *live_counts, const void *background, void *y,
-                           int dtype, void *stream);   /* tile_order .. background: see sec_rpn_tile_live; NULL = every tile tests its own map entries */
+                           int dtype, void *stream);   /* tile_order .. background: see sec_rpn_tile_live; tile_order NULL = every tile tests its own map entries; background NULL with lists = lazy consumers (below) */
 
 /* The dense RPN (rpn.py:486-497: Conv2d 3x3 + BatchNorm2d + ReLU, repeated) on a BEV image that is empty except at the sparse
  * middle's sites (middle.py:206-210): a pixel of the j-th conv's output sees the image only within j + 1 steps, so a tile
@@ -292,6 +292,23 @@ int sec_conv2d_nhwc_tiles(const void *x, int batch, int h, int w, const void *pa
 int sec_conv1x1_chain_nhwc_tiles(const void *x, int batch, int h, int w, const void *packed_w1, const float *bias1, int relu1,
                                  const void *packed_w2, const float *bias2, int cout2, const unsigned short *tile_order,
                                  const int *live_counts, const void *background, void *y, int dtype, void *stream);
+/* LAZY background (round 4): the copies above move a background tile of EVERY layer through memory although its only readers are
+ * the halos of the next conv's live tiles.  With the lazy forms a conv writes its live tiles only (background == NULL in
+ * sec_conv2d_nhwc_gather / sec_conv2d_nhwc_tiles_lazy: the other tiles of y are left unwritten) and its consumer fetches every halo
+ * pixel either from x or -- when the tile holding it was not live in the producing layer -- from `background_in` = the producing
+ * layer's output for an empty frame ([h][w][128]), the very values a copy would have put there: bit-identical results.
+ * sec_rpn_tile_live_masks: sec_rpn_tile_live + nbr_masks [layers][2][batch][tiles] uint16: for conv l >= 1 (slot 0 is unused) and a
+ * tile, bit (dy + 1) * 3 + (dx + 1) = the neighbour tile (dy, dx) was live for conv l - 1 (or lies outside the image: zero padding
+ * either way); [l][0][b][r] follows tile_order[l][b][r] for the live tiles, [l][1][b][t] is indexed by tile (read when a conv falls
+ * back to the plain tile order above three quarters live tiles).
+ * sec_conv2d_nhwc_tiles_lazy: sec_conv2d_nhwc_tiles reading x through nbr_masks (the [2][batch][tiles] slice of ITS layer) and
+ * background_in; background (its own empty-frame output) may be NULL when every consumer of y is lazy too.  The last conv before
+ * sec_conv1x1_chain_nhwc_tiles keeps its background: that kernel reads whole tiles of y when it falls back to the plain order. */
+int sec_rpn_tile_live_masks(const int *site_map, int batch, int h, int w, int layers, unsigned short *tile_order, int *live_counts,
+                            unsigned short *nbr_masks, void *workspace, size_t workspace_bytes, void *stream);
+int sec_conv2d_nhwc_tiles_lazy(const void *x, int batch, int h, int w, const void *packed_weight, const float *bias, int cout,
+                               int relu, const unsigned short *tile_order, const int *live_counts, const void *background,
+                               const unsigned short *nbr_masks, const void *background_in, void *y, int dtype, void *stream);
 
 /* Adjoint of sec_sparse_to_dense -- rows[i,:] = dense[indices[i]] -- i.e. the backward of
  * SparseConvTensor.dense() (upstream gets it from autograd through scatter_nd, spconv/__init__.py) and of

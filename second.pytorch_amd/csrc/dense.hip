@@ -345,7 +345,9 @@ __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(con
                                                             const int *__restrict__ site_map, unsigned feat_bytes,
                                                             const unsigned short *__restrict__ tile_order = nullptr,
                                                             const int *__restrict__ live_counts = nullptr,
-                                                            const T *__restrict__ background = nullptr) {
+                                                            const T *__restrict__ background = nullptr,
+                                                            const unsigned short *__restrict__ nbr_masks = nullptr,
+                                                            const T *__restrict__ bg_in = nullptr) {
     static_assert(!GATHER || (ROLL == 2 && CIN == 128), "gather prologue: the shared-row loop on two 64-channel planes");
     constexpr int TW = 16, HW_ = TW + 2, HPIX = (TH + 2) * (TW + 2);
     // NSPLIT == 2: 64 output channels per workgroup -- the waves split the tile's pixels two ways and the channels two ways (the
@@ -417,6 +419,43 @@ __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(con
             hx += 16;
             const bool wrap = hx >= HW_;
             hx = wrap ? hx - HW_ : hx;
+            rowoff = wrap ? rowoff + row_pitch : rowoff;
+        }
+    };
+    // LAZY-BACKGROUND form of issue_halo2 (sec_conv2d_nhwc_tiles_lazy): the layer that produced `x` wrote only ITS live tiles; the
+    // others were never materialised.  `nmask` bit (ry * 3 + rx) says whether the tile holding the halo pixels of row class ry
+    // (0: the row above the tile, 1: its own rows, 2: the row below) and column class rx (left column / own columns / right column)
+    // was live there; pixels of a tile that was not come from `bg_in` = that layer's output for an EMPTY frame ([h][w][CIN]) at the
+    // same position -- exactly what the producer's copy would have put into `x`.  Both sources share the byte
+    // offsets; a lane issues ONE of the two DMAs (the lanes are the LDS slots, an inactive lane writes nothing).
+    auto issue_halo2_lazy = [&](int tile, unsigned nmask) {
+        const int b = tile / (tiles_y * tiles_x);
+        const int trem = tile - b * tiles_y * tiles_x;
+        const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
+        const unsigned img_bytes = (unsigned)p.h * (unsigned)p.w * (CIN * 2u);
+        const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(x) + (size_t)b * p.h * p.w * CIN, 0, (int)img_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t ers = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(bg_in), 0, (int)img_bytes, 0x00020000);
+        const int wvs = __builtin_amdgcn_readfirstlane(wv);
+        const unsigned slot = lane & 15;
+        const unsigned row_pitch = (unsigned)p.w * (CIN * 2u);
+        int hx = wvs * 4 + (lane >> 4), hy = 0;
+        unsigned rowoff = (unsigned)((y0 - 1) * p.w + (x0 - 1)) * (CIN * 2u);
+#pragma unroll
+        for (int t = 0; t < (HENT / 64 + 3) / 4; ++t) {
+            const int i = wvs + 4 * t;
+            if (i < HENT / 64) {
+                const unsigned key = (slot ^ ((unsigned)hx & 15u)) << 4;
+                unsigned off = rowoff + ((unsigned)hx << 8) + key;
+                const unsigned ix = (unsigned)(x0 - 1 + hx);
+                off = ix < (unsigned)p.w ? off : 0xfffffff0u;
+                const int ry = hy == 0 ? 0 : (hy == TH + 1 ? 2 : 1), rx = hx == 0 ? 0 : (hx == HW_ - 1 ? 2 : 1);
+                if ((nmask >> (ry * 3 + rx)) & 1u) __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)&hal[i * 64], 16, off, 0, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(ers, (lds_ptr_t)&hal[i * 64], 16, off, 0, 0, 0);
+            }
+            hx += 16;
+            const bool wrap = hx >= HW_;
+            hx = wrap ? hx - HW_ : hx;
+            hy = wrap ? hy + 1 : hy;
             rowoff = wrap ? rowoff + row_pitch : rowoff;
         }
     };
@@ -502,6 +541,8 @@ __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(con
     // tiles along the image border the zero padding's imprint.)
     // The LIVE tiles of all frames form one list (frame-major) that is cut into eight equal contiguous runs, one per XCD, so that a
     // dense frame does not leave its XCD working while the others idle; the workgroups behind them copy the background tiles.
+    unsigned nmask = 0x1ffu;
+    bool listed = false;
     {
         int n_live = 0;
         if (tile_order)
@@ -510,6 +551,7 @@ __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(con
         // workgroup's prologue (all tiles live: 480 instead of 427 us for the six convs + tail): above three quarters live, every
         // tile is convolved in the plain order -- computing a background tile is always correct.
         if (tile_order && n_live * 4 <= ntile * 3) {
+            listed = true;
             const int tpf = tiles_y * tiles_x;
             const int per_live = (n_live + 7) >> 3;
             int item;
@@ -525,7 +567,9 @@ __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(con
                 int f = 0;
                 while (item >= live_counts[f]) item -= live_counts[f++];
                 tile = f * tpf + tile_order[f * tpf + item];
+                if (nbr_masks) nmask = nbr_masks[f * tpf + item];        // rank-indexed half: loaded beside the tile index
             } else {
+                if (!background) return;                                  // lazy consumers: background tiles are never materialised
                 // A copying workgroup takes kCopyTiles background tiles, two at a time with all their loads in flight: one tile per
                 // workgroup left ~1 500 short-lived workgroups queueing for the ~100 slots the live tiles' first round leaves free
                 // (a slot costs this kernel's 46 KB of LDS whatever the workgroup does) and the launch ended with them, not with
@@ -575,6 +619,7 @@ __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(con
         }
     }
     if (tile >= ntile) return;
+    if (nbr_masks && !listed) nmask = nbr_masks[ntile + tile];            // plain order: the tile-indexed half of the masks
 #ifdef SEC_CONV_TIMELINE
     long long *tl = g_timeline2;
     long long tl0 = 0, tl1 = 0, tl2 = 0;
@@ -621,8 +666,10 @@ __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(con
             }
             return;
         }
-    } else if constexpr (ROLL >= 2) issue_halo2(tile);
-    else issue_halo(tile);
+    } else if constexpr (ROLL >= 2) {
+        if (nbr_masks) issue_halo2_lazy(tile, nmask);
+        else issue_halo2(tile);
+    } else issue_halo(tile);
 #ifdef SEC_CONV_TIMELINE
     long long tl_issue = 0, tl_eb1 = 0, tl_eb2 = 0;
     if (tl) tl_issue = clock64();
@@ -900,7 +947,8 @@ extern "C" __attribute__((visibility("default"))) int sec__debug_timeline2(long 
 template <typename T, int CIN, int TH, int ROLL = 0, bool GATHER = false, int NSPLIT = 1>
 static int launch_conv2d_halo_reg(const void *x, const void *wpk, const float *bias, void *y, const Conv2dParams &p, hipStream_t st,
                                   const int *site_map = nullptr, unsigned feat_bytes = 0, const unsigned short *tile_order = nullptr,
-                                  const int *live_counts = nullptr, const void *background = nullptr) {
+                                  const int *live_counts = nullptr, const void *background = nullptr,
+                                  const unsigned short *nbr_masks = nullptr, const void *bg_in = nullptr) {
     constexpr size_t lds_tile = (size_t)(TH + 2) * 18 * (CIN / 8) * 16;
     // (padding the dynamic LDS to hold 2 instead of 3 workgroups per CU was measured in round 3: slower in every combination)
     const long lds_pad = 0;
@@ -917,7 +965,7 @@ static int launch_conv2d_halo_reg(const void *x, const void *wpk, const float *b
     if (NSPLIT == 1) set_last_kernel("k_conv2d_halo_reg<%s, %d, %d, %d, %s>", dtype_name<T>(), CIN, TH, ROLL, GATHER ? "true" : "false");
     else set_last_kernel("k_conv2d_halo_reg<%s, %d, %d, %d, %s, %d>", dtype_name<T>(), CIN, TH, ROLL, GATHER ? "true" : "false", NSPLIT);
     hipLaunchKernelGGL(fn, dim3(gx, p.cout / (128 / NSPLIT)), dim3(256), lds, st, (const T *)x, (const T *)wpk, bias, (T *)y, p, ty, tx, per_xcd,
-                       site_map, feat_bytes, tile_order, live_counts, (const T *)background);
+                       site_map, feat_bytes, tile_order, live_counts, (const T *)background, nbr_masks, (const T *)bg_in);
     return check_launch();
 }
 
@@ -1353,50 +1401,62 @@ __global__ __launch_bounds__(kBlock) void k_bev_bitmap(const int *__restrict__ s
 }
 
 constexpr int kTileLiveMaxLayers = 8;
+// `masks` (optional; sec_rpn_tile_live_masks): for the LAZY consumers of a layer's output (sec_conv2d_nhwc_tiles_lazy) -- per conv
+// l >= 1 and tile, nine bits over the tile's 3 x 3 neighbourhood (bit (dy + 1) * 3 + dx + 1): the neighbour was LIVE for conv l - 1
+// (d <= l), i.e. conv l - 1 really wrote it; a neighbour outside the image counts as written (its pixels are zero padding either
+// way).  Two copies per layer, [l][0][b][rank] in the order of the live list and [l][1][b][tile] by tile index (what a conv that
+// falls back to the plain tile order reads).
 __global__ __launch_bounds__(kTileLiveThreads) void k_rpn_tile_live(const unsigned *__restrict__ bits, int h, int w, int layers, int batch,
-                                                                     unsigned short *__restrict__ order, int *__restrict__ counts) {
+                                                                     unsigned short *__restrict__ order, int *__restrict__ counts,
+                                                                     unsigned short *__restrict__ masks) {
     extern __shared__ unsigned tl_bits[];
     constexpr int NT = kTileLiveThreads, NW = NT / 64;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wr = (w + 31) >> 5, words = h * wr;
     const int ty = (h + 7) / 8, tx = (w + 15) / 16, tiles = ty * tx;
+    unsigned char *s_d = reinterpret_cast<unsigned char *>(tl_bits + words);     // distance of every tile of the frame (phase 1)
     __shared__ int s_wave[kTileLiveMaxLayers][NW], s_run[kTileLiveMaxLayers];
     for (int i = tid; i < words; i += NT) tl_bits[i] = bits[(long long)b * words + i];
     if (tid < kTileLiveMaxLayers) s_run[tid] = 0;
     __syncthreads();
     const int K = layers;                         // farthest distance that matters
+    // ---- phase 1: d of every tile
+    for (int t = tid; t < tiles; t += NT) {
+        int d = K + 1;
+        const int tyi = t / tx, txi = t - tyi * tx;
+        const int y0 = tyi * 8, x0 = txi * 16;
+        const int ylo = y0 - K > 0 ? y0 - K : 0, yhi = y0 + 7 + K < h - 1 ? y0 + 7 + K : h - 1;
+        // window of columns [x0 - 32, x0 + 47] as 80 bits around the tile's word: lo = bits of [x0 - 32, x0 + 31], hi = [x0 + 32, x0 + 47]
+        const int k0 = x0 >> 5, sh = x0 & 31;  // x0 is a multiple of 16: sh is 0 or 16
+        for (int yy = ylo; yy <= yhi; ++yy) {
+            const unsigned *row = tl_bits + yy * wr;
+            const unsigned wm = k0 > 0 ? row[k0 - 1] : 0u, wc = row[k0], wp = k0 + 1 < wr ? row[k0 + 1] : 0u;
+            // 96 bits [32 (k0 - 1), 32 (k0 + 2)); the tile's columns are bits [32 + sh, 32 + sh + 15] of it
+            const unsigned long long lo = (unsigned long long)wm | (unsigned long long)wc << 32;      // bits 0..63
+            const unsigned long long win = sh ? (lo >> 16) | (unsigned long long)wp << 48 : lo;      // tile columns at bits [32, 47] either way
+            const unsigned long long hi16 = sh ? (unsigned long long)(wp >> 16) : (unsigned long long)(wp & 0xffffu); // columns x0 + 32 .. x0 + 47 (sh = 16: bits 16.. of wp)
+            int dx = K + 1;
+            if ((win >> 32) & 0xffffull) dx = 0;
+            else {
+                const unsigned long long left = win & 0xffffffffull;              // columns x0 - 32 .. x0 - 1 at bits 0 .. 31
+                if (left) dx = 32 - (63 - __clzll((long long)left));            // nearest set bit below the tile: distance x0 - column
+                const unsigned long long right = (win >> 48) | hi16 << 16;         // columns x0 + 16 .. at bits 0 ..
+                if (right) {
+                    const int dr = __ffsll((long long)right);                   // 1-based: distance from column x0 + 15
+                    dx = dr < dx ? dr : dx;
+                }
+            }
+            const int dy = yy < y0 ? y0 - yy : (yy > y0 + 7 ? yy - (y0 + 7) : 0);
+            const int dd = dx > dy ? dx : dy;
+            d = dd < d ? dd : d;
+        }
+        s_d[t] = (unsigned char)d;
+    }
+    __syncthreads();
+    // ---- phase 2: lists (and masks) of all layers
     for (int base = 0; base < tiles; base += NT) {
         const int t = base + tid;
-        int d = K + 1;
-        if (t < tiles) {
-            const int tyi = t / tx, txi = t - tyi * tx;
-            const int y0 = tyi * 8, x0 = txi * 16;
-            const int ylo = y0 - K > 0 ? y0 - K : 0, yhi = y0 + 7 + K < h - 1 ? y0 + 7 + K : h - 1;
-            // window of columns [x0 - 32, x0 + 47] as 80 bits around the tile's word: lo = bits of [x0 - 32, x0 + 31], hi = [x0 + 32, x0 + 47]
-            const int k0 = x0 >> 5, sh = x0 & 31;  // x0 is a multiple of 16: sh is 0 or 16
-            for (int yy = ylo; yy <= yhi; ++yy) {
-                const unsigned *row = tl_bits + yy * wr;
-                const unsigned wm = k0 > 0 ? row[k0 - 1] : 0u, wc = row[k0], wp = k0 + 1 < wr ? row[k0 + 1] : 0u;
-                // 96 bits [32 (k0 - 1), 32 (k0 + 2)); the tile's columns are bits [32 + sh, 32 + sh + 15] of it
-                const unsigned long long lo = (unsigned long long)wm | (unsigned long long)wc << 32;      // bits 0..63
-                const unsigned long long win = sh ? (lo >> 16) | (unsigned long long)wp << 48 : lo;      // tile columns at bits [32, 47] either way
-                const unsigned long long hi16 = sh ? (unsigned long long)(wp >> 16) : (unsigned long long)(wp & 0xffffu); // columns x0 + 32 .. x0 + 47 (sh = 16: bits 16.. of wp)
-                int dx = K + 1;
-                if ((win >> 32) & 0xffffull) dx = 0;
-                else {
-                    const unsigned long long left = win & 0xffffffffull;              // columns x0 - 32 .. x0 - 1 at bits 0 .. 31
-                    if (left) dx = 32 - (63 - __clzll((long long)left));            // nearest set bit below the tile: distance x0 - column
-                    const unsigned long long right = (win >> 48) | hi16 << 16;         // columns x0 + 16 .. at bits 0 ..
-                    if (right) {
-                        const int dr = __ffsll((long long)right);                   // 1-based: distance from column x0 + 15
-                        dx = dr < dx ? dr : dx;
-                    }
-                }
-                const int dy = yy < y0 ? y0 - yy : (yy > y0 + 7 ? yy - (y0 + 7) : 0);
-                const int dd = dx > dy ? dx : dy;
-                d = dd < d ? dd : d;
-            }
-        }
+        const int d = t < tiles ? (int)s_d[t] : K + 1;
         // compaction of all layers with one barrier pair: ballots, per-wave totals, prefix
         unsigned long long bal[kTileLiveMaxLayers];
 #pragma unroll
@@ -1405,6 +1465,15 @@ __global__ __launch_bounds__(kTileLiveThreads) void k_rpn_tile_live(const unsign
             if (lane == 0) s_wave[l][wv] = __popcll(bal[l]);
         }
         __syncthreads();
+        int nd[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (masks && t < tiles) {
+            const int tyi = t / tx, txi = t - tyi * tx;
+#pragma unroll
+            for (int q = 0; q < 9; ++q) {
+                const int yy = tyi + q / 3 - 1, xx = txi + q % 3 - 1;
+                nd[q] = (yy >= 0 && yy < ty && xx >= 0 && xx < tx) ? (int)s_d[yy * tx + xx] : 0;
+            }
+        }
 #pragma unroll
         for (int l = 0; l < kTileLiveMaxLayers; ++l) {
             if (l >= layers) break;
@@ -1415,6 +1484,14 @@ __global__ __launch_bounds__(kTileLiveThreads) void k_rpn_tile_live(const unsign
                 unsigned short *ord = order + ((long long)l * batch + b) * tiles;
                 if (d <= l + 1) ord[rank] = (unsigned short)t;
                 else ord[tiles - 1 - (t - rank)] = (unsigned short)t;                       // the others: from the end backwards
+                if (masks && l >= 1) {
+                    unsigned m = 0u;
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) m |= (unsigned)(nd[q] <= l) << q;
+                    unsigned short *mk = masks + (((long long)l * 2) * batch + b) * tiles;
+                    if (d <= l + 1) mk[rank] = (unsigned short)m;
+                    mk[(long long)batch * tiles + t] = (unsigned short)m;
+                }
             }
         }
         __syncthreads();
@@ -1437,13 +1514,15 @@ SEC_API size_t sec_rpn_tile_live_workspace_bytes(int batch, int h, int w) {
     return align_up((size_t)batch * h * ((w + 31) / 32) * 4);
 }
 
-SEC_API int sec_rpn_tile_live(const int *site_map, int batch, int h, int w, int layers, unsigned short *tile_order, int *live_counts,
-                              void *workspace, size_t workspace_bytes, void *stream) {
+static int rpn_tile_live_impl(const int *site_map, int batch, int h, int w, int layers, unsigned short *tile_order, int *live_counts,
+                              unsigned short *nbr_masks, void *workspace, size_t workspace_bytes, void *stream) {
     if (!site_map || !tile_order || !live_counts || !workspace || batch <= 0 || h <= 0 || w <= 0 || layers <= 0) return SEC_E_INVALID;
     if (workspace_bytes < sec_rpn_tile_live_workspace_bytes(batch, h, w)) return SEC_E_WORKSPACE;
     const int words = h * ((w + 31) / 32);
-    const size_t lds = (size_t)words * 4;
-    if (lds > 120 * 1024 || (long long)((h + 7) / 8) * ((w + 15) / 16) > 65535 || layers > kTileLiveMaxLayers) return SEC_E_UNSUPPORTED;
+    const long long tiles = (long long)((h + 7) / 8) * ((w + 15) / 16);
+    if (tiles > 65535 || layers > kTileLiveMaxLayers) return SEC_E_UNSUPPORTED;
+    const size_t lds = (size_t)words * 4 + (((size_t)tiles + 15) & ~(size_t)15);     // the frame's bitmap + one distance byte per tile
+    if (lds > 120 * 1024) return SEC_E_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     static bool configured = false;
     if (!configured) {
@@ -1452,14 +1531,25 @@ SEC_API int sec_rpn_tile_live(const int *site_map, int batch, int h, int w, int 
     }
     hipLaunchKernelGGL(k_bev_bitmap, dim3(div_up((long long)batch * words, kBlock)), dim3(kBlock), 0, st, site_map, h, w, batch, (unsigned *)workspace);
     hipLaunchKernelGGL(k_rpn_tile_live, dim3(batch), dim3(kTileLiveThreads), lds, st, (const unsigned *)workspace, h, w, layers, batch, tile_order,
-                       live_counts);
+                       live_counts, nbr_masks);
     return check_launch();
 }
 
-SEC_API int sec_conv2d_nhwc_tiles(const void *x, int batch, int h, int w, const void *packed_weight, const float *bias, int cout,
-                                  int relu, const unsigned short *tile_order, const int *live_counts, const void *background,
-                                  void *y, int dtype, void *stream) {
-    if (!x || !packed_weight || !y || batch <= 0 || h <= 0 || w <= 0 || (tile_order && (!background || !live_counts))) return SEC_E_INVALID;
+SEC_API int sec_rpn_tile_live(const int *site_map, int batch, int h, int w, int layers, unsigned short *tile_order, int *live_counts,
+                              void *workspace, size_t workspace_bytes, void *stream) {
+    return rpn_tile_live_impl(site_map, batch, h, w, layers, tile_order, live_counts, nullptr, workspace, workspace_bytes, stream);
+}
+
+SEC_API int sec_rpn_tile_live_masks(const int *site_map, int batch, int h, int w, int layers, unsigned short *tile_order, int *live_counts,
+                                    unsigned short *nbr_masks, void *workspace, size_t workspace_bytes, void *stream) {
+    if (!nbr_masks) return SEC_E_INVALID;
+    return rpn_tile_live_impl(site_map, batch, h, w, layers, tile_order, live_counts, nbr_masks, workspace, workspace_bytes, stream);
+}
+
+static int conv2d_tiles_impl(const void *x, int batch, int h, int w, const void *packed_weight, const float *bias, int cout, int relu,
+                             const unsigned short *tile_order, const int *live_counts, const void *background,
+                             const unsigned short *nbr_masks, const void *background_in, void *y, int dtype, void *stream) {
+    if (!x || !packed_weight || !y || batch <= 0 || h <= 0 || w <= 0 || (tile_order && !live_counts)) return SEC_E_INVALID;
     if (cout % 128 || (dtype != SEC_BF16 && dtype != SEC_F16)) return SEC_E_UNSUPPORTED;
     Conv2dParams p;
     p.batch = batch; p.h = h; p.w = w; p.cin = 128; p.cout = cout; p.ksize = 3; p.stride = 1; p.pad = 1;
@@ -1468,8 +1558,26 @@ SEC_API int sec_conv2d_nhwc_tiles(const void *x, int batch, int h, int w, const 
     p.m = (long long)batch * h * w;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == SEC_BF16)
-        return launch_conv2d_halo_reg<__hip_bfloat16, 128, 8, 2>(x, packed_weight, bias, y, p, st, nullptr, 0, tile_order, live_counts, background);
-    return launch_conv2d_halo_reg<__half, 128, 8, 2>(x, packed_weight, bias, y, p, st, nullptr, 0, tile_order, live_counts, background);
+        return launch_conv2d_halo_reg<__hip_bfloat16, 128, 8, 2>(x, packed_weight, bias, y, p, st, nullptr, 0, tile_order, live_counts, background,
+                                                                 nbr_masks, background_in);
+    return launch_conv2d_halo_reg<__half, 128, 8, 2>(x, packed_weight, bias, y, p, st, nullptr, 0, tile_order, live_counts, background, nbr_masks,
+                                                     background_in);
+}
+
+SEC_API int sec_conv2d_nhwc_tiles(const void *x, int batch, int h, int w, const void *packed_weight, const float *bias, int cout,
+                                  int relu, const unsigned short *tile_order, const int *live_counts, const void *background,
+                                  void *y, int dtype, void *stream) {
+    if (tile_order && !background) return SEC_E_INVALID;
+    return conv2d_tiles_impl(x, batch, h, w, packed_weight, bias, cout, relu, tile_order, live_counts, background, nullptr, nullptr, y, dtype,
+                             stream);
+}
+
+SEC_API int sec_conv2d_nhwc_tiles_lazy(const void *x, int batch, int h, int w, const void *packed_weight, const float *bias, int cout,
+                                       int relu, const unsigned short *tile_order, const int *live_counts, const void *background,
+                                       const unsigned short *nbr_masks, const void *background_in, void *y, int dtype, void *stream) {
+    if (!tile_order || !nbr_masks || !background_in) return SEC_E_INVALID;
+    return conv2d_tiles_impl(x, batch, h, w, packed_weight, bias, cout, relu, tile_order, live_counts, background, nbr_masks, background_in, y,
+                             dtype, stream);
 }
 
 SEC_API size_t sec_conv2d_packed_weight_bytes(int cout, int cin, int ksize, int dtype) {
@@ -1513,7 +1621,7 @@ SEC_API int sec_conv2d_nhwc_gather(const void *features, long long feature_rows,
                                    const void *packed_weight, const float *bias, int cout, int relu, const unsigned short *tile_order,
                                    const int *live_counts, const void *background, void *y, int dtype, void *stream) {
     if (!site_map || !packed_weight || !y || batch <= 0 || h <= 0 || w <= 0 || feature_rows < 0 || (!features && feature_rows > 0)) return SEC_E_INVALID;
-    if (tile_order && (!live_counts || !background)) return SEC_E_INVALID;
+    if (tile_order && !live_counts) return SEC_E_INVALID;       // background == NULL with lists: the other tiles are left unwritten (lazy consumers)
     if (cout % 128 || (dtype != SEC_BF16 && dtype != SEC_F16) || feature_rows * 128 >= (1ll << 31) ||
         (long long)h * w * 8 >= (1ll << 31)) return SEC_E_UNSUPPORTED;
     Conv2dParams p;

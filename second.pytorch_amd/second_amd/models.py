@@ -318,12 +318,12 @@ class SparseBEV:
             return ops.sparse_site_map_sorted(tbl[1][1], self.indices.shape[0], self.batch_size, self.spatial_shape, num_dev=self.num_dev)
         return ops.sparse_site_map(self.indices, self.batch_size, self.spatial_shape, num_dev=self.num_dev)
 
-    def tile_lists(self, layers):
-        """(order, counts) of ops.rpn_tile_live for the first ``layers`` RPN convs, computed once per tensor: whoever asks first
-        decides where the launch sits (the sparse segment of a staged capture, so that it stays out of the serialised RPN segment)."""
+    def tile_lists(self, layers, masks=False):
+        """(order, counts[, nbr_masks]) of ops.rpn_tile_live for the first ``layers`` RPN convs, computed once per tensor: whoever asks
+        first decides where the launch sits (the sparse segment of a staged capture, so that it stays out of the serialised RPN segment)."""
         t = getattr(self, "_tile_lists", None)
-        if t is None or t[0] != layers:
-            t = self._tile_lists = (layers, ops.rpn_tile_live(self.site_map(), layers))
+        if t is None or t[0] != (layers, bool(masks)):
+            t = self._tile_lists = ((layers, bool(masks)), ops.rpn_tile_live(self.site_map(), layers, masks=bool(masks)))
         return t[1]
 
     def dense(self):
@@ -634,6 +634,10 @@ class RPNInference(nn.Module):
         # same kernels (:meth:`empty_frame_maps`); the convs then compute only the reachable tiles and copy the others.
         # skip_background = False convolves every tile.
         self.skip_background = True
+        # lazy_background: the convs write their live tiles only and read their input's background tiles from the previous layer's
+        # empty-frame map (sec_conv2d_nhwc_tiles_lazy) -- no copy of the ~1 450 background tiles (47 MB read + 47 MB written) per layer;
+        # the last conv keeps its copy (the fused 1x1 tail reads whole tiles when it falls back to the plain order)
+        self.lazy_background = True
         self.last_live_counts = None       # [convs, B] int32 on the device: live tiles per conv and frame of the last forward (bench / tests)
         self._empty_maps = {}
         convs = [i for kind, i in self.plan if kind == "c"]
@@ -686,18 +690,26 @@ class RPNInference(nn.Module):
                 gather = x
             else:
                 x = x.dense()
-        live = None
+        live = nbr = None
         for kind, i in self.plan:
             if kind == "c" and gather is not None:
                 sm = gather.site_map()
                 if self.background_convs and self.skip_background:
                     empty = self.empty_frame_maps(sm.shape[2], sm.shape[3])
-                    live, self.last_live_counts = gather.tile_lists(self.background_convs)
+                    lazy = self.lazy_background and self.background_convs >= 2
+                    if lazy:
+                        live, self.last_live_counts, nbr = gather.tile_lists(self.background_convs, masks=True)
+                    else:
+                        (live, self.last_live_counts), nbr = gather.tile_lists(self.background_convs), None
                     x = ops.conv2d_nhwc_gather(gather.features, sm, self.gather_packed, self.bs[i], self.ws[i].shape[0], relu=True,
-                                               tile_order=live[0], live_counts=self.last_live_counts[0], background=empty[0])
+                                               tile_order=live[0], live_counts=self.last_live_counts[0], background=None if lazy else empty[0])
                 else:
                     x = ops.conv2d_nhwc_gather(gather.features, sm, self.gather_packed, self.bs[i], self.ws[i].shape[0], relu=True)
                 gather, first = None, False
+            elif kind == "c" and live is not None and nbr is not None:
+                keep = i == self.background_convs - 1          # the last conv materialises its background for the 1x1 tail
+                x = ops.conv2d_nhwc_tiles(x, self.packed[i], self.bs[i], 128, live[i], self.last_live_counts[i], empty[i] if keep else None,
+                                          relu=True, nbr_masks=nbr[i], background_in=empty[i - 1])
             elif kind == "c" and live is not None:
                 x = ops.conv2d_nhwc_tiles(x, self.packed[i], self.bs[i], 128, live[i], self.last_live_counts[i], empty[i], relu=True)
             elif kind == "c":
@@ -974,7 +986,8 @@ class SecondDetector(nn.Module):
                                                             bev_sparse=getattr(self.rpn, "gather_packed", None) is not None)
                     self._branch_overflow = [list(getattr(self.middle_feature_extractor, "last_overflow_checks", []))]
                     if isinstance(spatial, SparseBEV) and getattr(self.rpn, "background_convs", 0) and self.rpn.skip_background:
-                        spatial.tile_lists(self.rpn.background_convs)     # the live-tile lists belong to the latency-bound segment
+                        spatial.tile_lists(self.rpn.background_convs,      # the live-tile lists belong to the latency-bound segment
+                                           masks=self.rpn.lazy_background and self.rpn.background_convs >= 2)
                 with torch.cuda.graph(gb, pool=pool, capture_error_mode="thread_local"):
                     preds = self.rpn(spatial)
                 with torch.cuda.graph(gc, pool=pool, capture_error_mode="thread_local"):

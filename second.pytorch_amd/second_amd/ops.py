@@ -762,6 +762,9 @@ def gather_channel_perm(c, d):
     return (j % c) * d + j // c
 
 
+POISON_LAZY_OUTPUTS = False    # tests: the tiles a lazy conv leaves unwritten are filled with NaN first (a wrongful read reaches the output)
+
+
 @_traced("conv2d_nhwc_gather")
 def conv2d_nhwc_gather(features, site_map, packed, bias, cout, relu=True, tile_order=None, live_counts=None, background=None):
     """3x3 / stride 1 / pad 1 conv + bias + ReLU of ``SparseConvTensor.dense().view(B, 128, H, W)`` read straight from the
@@ -772,25 +775,31 @@ def conv2d_nhwc_gather(features, site_map, packed, bias, cout, relu=True, tile_o
     b, d, h, w = site_map.shape
     assert d == 2 and site_map.is_contiguous()
     y = torch.empty((b, int(cout), h, w), dtype=features.dtype, device=features.device, memory_format=torch.channels_last)
+    if POISON_LAZY_OUTPUTS and tile_order is not None and background is None:
+        y.fill_(float("nan"))
     if tile_order is not None:      # live tiles from rpn_tile_live (layer 0): spread evenly over the XCDs, the others copied from `background` (the empty frame's output)
-        rt.require_gpu(tile_order, live_counts, background)
+        rt.require_gpu(tile_order, live_counts)
         assert tile_order.dtype == torch.int16 and tile_order.is_contiguous() and tile_order.shape[0] == b
-        assert live_counts.dtype == torch.int32 and live_counts.numel() == b and background.dtype == features.dtype
-        assert background.numel() == h * w * int(cout) and background.is_contiguous(memory_format=torch.channels_last)
+        assert live_counts.dtype == torch.int32 and live_counts.numel() == b
+        if background is not None:   # None: the other tiles stay unwritten -- every consumer must be lazy (conv2d_nhwc_tiles(nbr_masks=...))
+            rt.require_gpu(background)
+            assert background.dtype == features.dtype
+            assert background.numel() == h * w * int(cout) and background.is_contiguous(memory_format=torch.channels_last)
     rc = rt.lib().sec_conv2d_nhwc_gather(rt.ptr(features), features.shape[0], rt.ptr(site_map), b, h, w, rt.ptr(packed), rt.ptr(bias),
                                          int(cout), int(bool(relu)), rt.ptr(tile_order) if tile_order is not None else None,
                                          rt.ptr(live_counts) if tile_order is not None else None,
-                                         rt.ptr(background) if tile_order is not None else None, rt.ptr(y),
+                                         rt.ptr(background) if (tile_order is not None and background is not None) else None, rt.ptr(y),
                                          rt.dtype_code(features.dtype), rt.stream())
     rt.check(rc, "sec_conv2d_nhwc_gather")
     return y
 
 
 @_traced("rpn_tile_live")
-def rpn_tile_live(site_map, layers):
+def rpn_tile_live(site_map, layers, masks=False):
     """order [layers, B, tiles] int16 + counts [layers, B] int32 for the first ``layers`` 3x3 convs of the RPN (layer 0 = the gathered
     one): per frame the 8 x 16 tiles (row-major indices) that can differ from the layer's background first, the others from the
-    end backwards; counts = how many can differ (sec_rpn_tile_live)."""
+    end backwards; counts = how many can differ (sec_rpn_tile_live).  ``masks``: also nbr_masks [layers, 2, B, tiles] int16 for the
+    lazy consumers (sec_rpn_tile_live_masks: which of a tile's 3 x 3 neighbours the previous conv really wrote)."""
     rt.require_gpu(site_map)
     assert site_map.dtype == torch.int32 and site_map.dim() == 4 and site_map.shape[1] == 2 and site_map.is_contiguous()
     b, _, h, w = site_map.shape
@@ -800,24 +809,46 @@ def rpn_tile_live(site_map, layers):
     counts = torch.empty((int(layers), b), dtype=torch.int32, device=site_map.device)
     ws_bytes = rt.lib().sec_rpn_tile_live_workspace_bytes(b, h, w)
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=site_map.device)
+    if masks:
+        nbr = torch.empty((int(layers), 2, b, tiles), dtype=torch.int16, device=site_map.device)
+        rt.check(rt.lib().sec_rpn_tile_live_masks(rt.ptr(site_map), b, h, w, int(layers), rt.ptr(order), rt.ptr(counts), rt.ptr(nbr), rt.ptr(ws),
+                                                  ws_bytes, rt.stream()), "sec_rpn_tile_live_masks")
+        return order, counts, nbr
     rt.check(rt.lib().sec_rpn_tile_live(rt.ptr(site_map), b, h, w, int(layers), rt.ptr(order), rt.ptr(counts), rt.ptr(ws), ws_bytes,
                                         rt.stream()), "sec_rpn_tile_live")
     return order, counts
 
 
 @_traced("conv2d_nhwc_tiles")
-def conv2d_nhwc_tiles(x, packed, bias, cout, tile_order, live_counts, background, relu=True):
+def conv2d_nhwc_tiles(x, packed, bias, cout, tile_order, live_counts, background, relu=True, nbr_masks=None, background_in=None):
     """3x3 / stride 1 / pad 1 conv + bias + ReLU on a channels_last [B,128,H,W] tensor; only the live tiles of ``tile_order`` [B, tiles] /
     ``live_counts`` [B] (one layer of :func:`rpn_tile_live`) are convolved, the others are copied from ``background`` = this layer's
-    output for an EMPTY frame, channels_last [1, cout, H, W] (sec_conv2d_nhwc_tiles)."""
-    rt.require_gpu(x, packed, tile_order, live_counts, background)
+    output for an EMPTY frame, channels_last [1, cout, H, W] (sec_conv2d_nhwc_tiles).
+    LAZY form (``nbr_masks`` [2, B, tiles] = this layer's slice of rpn_tile_live(masks=True), ``background_in`` = the PRODUCING layer's
+    empty-frame output): ``x`` holds only the tiles its producer found live, the halo pixels of the others are read from
+    ``background_in``; ``background`` may then be None -- this layer writes its live tiles only (sec_conv2d_nhwc_tiles_lazy)."""
+    rt.require_gpu(x, packed, tile_order, live_counts)
     assert x.dim() == 4 and x.shape[1] == 128 and x.is_contiguous(memory_format=torch.channels_last)
     b, _, h, w = x.shape
     tiles = ((h + 7) // 8) * ((w + 15) // 16)
     assert tile_order.dtype == torch.int16 and tile_order.is_contiguous() and tuple(tile_order.shape) == (b, tiles)
     assert live_counts.dtype == torch.int32 and live_counts.is_contiguous() and live_counts.numel() == b
-    assert background.dtype == x.dtype and background.numel() == h * w * int(cout) and background.is_contiguous(memory_format=torch.channels_last)
+    if background is not None:
+        rt.require_gpu(background)
+        assert background.dtype == x.dtype and background.numel() == h * w * int(cout) and background.is_contiguous(memory_format=torch.channels_last)
     y = torch.empty((b, int(cout), h, w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    if POISON_LAZY_OUTPUTS and background is None:
+        y.fill_(float("nan"))
+    if nbr_masks is not None:
+        rt.require_gpu(nbr_masks, background_in)
+        assert nbr_masks.dtype == torch.int16 and nbr_masks.is_contiguous() and tuple(nbr_masks.shape) == (2, b, tiles)
+        assert background_in.dtype == x.dtype and background_in.numel() == h * w * 128 and background_in.is_contiguous(memory_format=torch.channels_last)
+        rc = rt.lib().sec_conv2d_nhwc_tiles_lazy(rt.ptr(x), b, h, w, rt.ptr(packed), rt.ptr(bias), int(cout), int(bool(relu)),
+                                                 rt.ptr(tile_order), rt.ptr(live_counts), rt.ptr(background) if background is not None else None,
+                                                 rt.ptr(nbr_masks), rt.ptr(background_in), rt.ptr(y), rt.dtype_code(x.dtype), rt.stream())
+        rt.check(rc, "sec_conv2d_nhwc_tiles_lazy")
+        return y
+    assert background is not None, "conv2d_nhwc_tiles: without nbr_masks the background tiles must be copied"
     rc = rt.lib().sec_conv2d_nhwc_tiles(rt.ptr(x), b, h, w, rt.ptr(packed), rt.ptr(bias), int(cout), int(bool(relu)),
                                         rt.ptr(tile_order), rt.ptr(live_counts), rt.ptr(background), rt.ptr(y),
                                         rt.dtype_code(x.dtype), rt.stream())

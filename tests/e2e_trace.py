@@ -62,12 +62,19 @@ def run_device_trace(gpu, points, offsets):
     from second_amd import ops
     calls = []
     ops.set_op_hook(lambda name, fn, a, kw, res: calls.append((name, a, kw, res)))
+    # the trace compares WHOLE layer outputs: the RPN convs materialise their background tiles here (lazy_background off; the live
+    # tiles -- all the arithmetic there is -- are bit-identical either way, tests/test_gpu_rpn_tiles.py)
+    lazy = getattr(gpu.rpn, "lazy_background", None)
+    if lazy:
+        gpu.rpn.lazy_background = False
     try:
         with torch.no_grad():
             out = gpu.forward_points(points, offsets, static=True)
         torch.cuda.synchronize()
     finally:
         ops.set_op_hook(None)
+        if lazy:
+            gpu.rpn.lazy_background = lazy
     return calls, out
 
 

@@ -67,6 +67,24 @@ def test_rpn_tile_live_matches_a_numpy_dilation(ops, batch, h, w, n):
             np.testing.assert_array_equal(order[l, f, c:][::-1], np.flatnonzero(ref[l, f] == 0))     # background: from the end
     if h >= 24 and w >= 48 and n <= 1:
         assert counts[1].sum() < batch * tiles            # an empty / one-site frame keeps background tiles
+    # the masks of the lazy consumers (sec_rpn_tile_live_masks): same lists, plus per conv l >= 1 and tile which of its 3 x 3
+    # neighbours conv l - 1 wrote (outside the image counts as written); by list rank for the live tiles and by tile index for all
+    order2, counts2, nbr = ops.rpn_tile_live(torch.from_numpy(m).cuda(), 6, masks=True)
+    np.testing.assert_array_equal(order2.cpu().numpy().astype(np.int64), order)
+    np.testing.assert_array_equal(counts2.cpu().numpy(), counts)
+    nbr = nbr.cpu().numpy().astype(np.int64) & 0xffff
+    ty, tx = (h + 7) // 8, (w + 15) // 16
+    for l in range(1, 6):
+        prev = np.ones((batch, ty + 2, tx + 2), np.int64)
+        prev[:, 1:-1, 1:-1] = ref[l - 1].reshape(batch, ty, tx)
+        want = np.zeros((batch, ty, tx), np.int64)
+        for q in range(9):
+            want |= prev[:, q // 3:q // 3 + ty, q % 3:q % 3 + tx] << q
+        want = want.reshape(batch, tiles)
+        np.testing.assert_array_equal(nbr[l, 1], want)
+        for f in range(batch):
+            c = counts[l, f]
+            np.testing.assert_array_equal(nbr[l, 0, f, :c], want[f, order[l, f, :c]])
 
 
 def _rpn_pair(dtype, seed):
@@ -96,10 +114,12 @@ def _bev(features, smap):
     return BEV()                                      # tile_lists() is the base class's
 
 
+@pytest.mark.parametrize("lazy", [False, True])           # lazy: live tiles written only, background read from the empty frame's maps
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("batch,h,w,n", [(2, 200, 176, 1500), (3, 50, 70, 200), (1, 40, 48, 1), (2, 33, 17, 0),
-                                          (2, 96, 64, 4000)])      # sites reach every tile: the kernels take the plain tile order
-def test_rpn_with_background_tiles_is_bit_identical_to_the_full_convs(ops, dtype, batch, h, w, n):
+                                          (2, 96, 64, 4000),       # sites reach every tile: the kernels take the plain tile order
+                                          (2, 120, 112, 700)])     # ... only in the later layers (lists first, plain order after)
+def test_rpn_with_background_tiles_is_bit_identical_to_the_full_convs(ops, dtype, batch, h, w, n, lazy):
     rng = np.random.default_rng(n + h)
     idx = np.zeros((0, 4), np.int32)
     if n:
@@ -118,8 +138,12 @@ def test_rpn_with_background_tiles_is_bit_identical_to_the_full_convs(ops, dtype
         assert not torch.equal(empty[3][0, :, 0, 0], empty[3][0, :, h // 2, w // 2]), "zero padding must leave its imprint along the border"
     bev = _bev(feat, smap)
     with torch.no_grad():
-        rpn.skip_background = True
-        a = {k: v.clone() for k, v in rpn(bev).items()}
+        rpn.skip_background, rpn.lazy_background = True, lazy
+        ops.POISON_LAZY_OUTPUTS = lazy           # tiles a lazy conv does not write hold NaN: reading one would reach the output
+        try:
+            a = {k: v.clone() for k, v in rpn(bev).items()}
+        finally:
+            ops.POISON_LAZY_OUTPUTS = False
         counts = rpn.last_live_counts.sum(dim=1).cpu().numpy()
         rpn.skip_background = False
         b = rpn(bev)
@@ -146,11 +170,17 @@ def test_detector_with_and_without_background_tiles_gives_identical_detections()
             m.running_var.copy_(torch.empty(m.num_features).uniform_(0.5, 1.5, generator=g))
             m.bias.data.copy_(torch.empty(m.num_features).uniform_(-0.2, 0.3, generator=g))
     det.prepare_inference(torch.bfloat16)
+    from second_amd import ops
     outs = []
     with torch.no_grad():
-        for skip in (True, False):
-            det.rpn.skip_background = skip
-            o = det.forward_points(pts, offs, static=True)
+        for skip, lazy in ((True, False), (True, True), (False, False)):
+            det.rpn.skip_background, det.rpn.lazy_background = skip, lazy
+            ops.POISON_LAZY_OUTPUTS = lazy
+            try:
+                o = det.forward_points(pts, offs, static=True)
+            finally:
+                ops.POISON_LAZY_OUTPUTS = False
             outs.append({k: v.clone() for k, v in o.items() if isinstance(v, torch.Tensor)})
     for k in outs[0]:
-        assert torch.equal(outs[0][k], outs[1][k]), k
+        assert torch.equal(outs[0][k], outs[2][k]), k
+        assert torch.equal(outs[1][k], outs[2][k]), k
