@@ -1011,7 +1011,9 @@ def main():
             bg_tiles = {"enabled": True, "lazy": bool(getattr(det.rpn, "lazy_background", False)), "live_tiles_per_conv": [k.get("live_tiles") for k in lt] or None, "tiles": lt[0].get("tiles") if lt else None,
                         "what": "conv j of the RPN (j = 0..5) convolves only the 8 x 16 tiles a site of the sparse middle can reach within j + 1 "
                                 "steps; the other tiles equal the network's output for an EMPTY frame at that position exactly (any weights) "
-                                "and are copied from it.  Data dependent: --background-skip 0 convolves every tile"}
+                                "and are copied from it -- or, with lazy = true (--lazy-background 1, default), never written: the next conv reads the halo "
+                                "pixels that fall into such a tile from the empty frame's map, the fused 1x1 tail runs on the last conv's live "
+                                "list (bit-identical either way).  Data dependent: --background-skip 0 convolves every tile"}
         else:
             bg_tiles = {"enabled": False}
     rows_per_frame = None

@@ -302,8 +302,10 @@ int sec_conv1x1_chain_nhwc_tiles(const void *x, int batch, int h, int w, const v
  * either way); [l][0][b][r] follows tile_order[l][b][r] for the live tiles, [l][1][b][t] is indexed by tile (read when a conv falls
  * back to the plain tile order above three quarters live tiles).
  * sec_conv2d_nhwc_tiles_lazy: sec_conv2d_nhwc_tiles reading x through nbr_masks (the [2][batch][tiles] slice of ITS layer) and
- * background_in; background (its own empty-frame output) may be NULL when every consumer of y is lazy too.  The last conv before
- * sec_conv1x1_chain_nhwc_tiles keeps its background: that kernel reads whole tiles of y when it falls back to the plain order. */
+ * background_in; background (its own empty-frame output) may be NULL when every consumer of y is lazy too.
+ * sec_conv1x1_chain_nhwc_tiles with relu1 | SEC_CHAIN_X_LIVE_ONLY is the lazy consumer of the LAST conv: it then uses the lists
+ * whatever the live share is (a 1x1 conv reads no halo: the live tiles of the last conv's list are all it needs of x). */
+#define SEC_CHAIN_X_LIVE_ONLY 2
 int sec_rpn_tile_live_masks(const int *site_map, int batch, int h, int w, int layers, unsigned short *tile_order, int *live_counts,
                             unsigned short *nbr_masks, void *workspace, size_t workspace_bytes, void *stream);
 int sec_conv2d_nhwc_tiles_lazy(const void *x, int batch, int h, int w, const void *packed_weight, const float *bias, int cout,

@@ -1085,7 +1085,9 @@ __global__ __launch_bounds__(256, 3) void k_conv1x1_chain(const T *__restrict__ 
         if (local >= per_xcd) return;
         int n_live = 0;
         for (int f = 0; f < batch; ++f) n_live += live_counts[f];
-        const bool lists = n_live * 4 <= ntile * 3;       // above three quarters live: every tile in the plain order (k_conv2d_halo_reg)
+        // above three quarters live: every tile in the plain order (k_conv2d_halo_reg) -- unless x holds its live tiles ONLY (relu1 bit 1,
+        // SEC_CHAIN_X_LIVE_ONLY: a lazy producer left the others unwritten; the lists name exactly the tiles that exist)
+        const bool lists = (relu1 & 2) != 0 || n_live * 4 <= ntile * 3;
         const int per_live = (n_live + 7) >> 3;
         int item;
         bool is_live = false;
@@ -1211,7 +1213,7 @@ __global__ __launch_bounds__(256, 3) void k_conv1x1_chain(const T *__restrict__ 
                 }
             }
         };
-        if (relu1) put(std::true_type{});
+        if (relu1 & 1) put(std::true_type{});
         else put(std::false_type{});
     }
     lds_barrier();

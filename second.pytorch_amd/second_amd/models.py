@@ -636,7 +636,7 @@ class RPNInference(nn.Module):
         self.skip_background = True
         # lazy_background: the convs write their live tiles only and read their input's background tiles from the previous layer's
         # empty-frame map (sec_conv2d_nhwc_tiles_lazy) -- no copy of the ~1 450 background tiles (47 MB read + 47 MB written) per layer;
-        # the last conv keeps its copy (the fused 1x1 tail reads whole tiles when it falls back to the plain order)
+        # the fused 1x1 tail then runs on the last conv's lists whatever the live share (x_live_only)
         self.lazy_background = True
         self.last_live_counts = None       # [convs, B] int32 on the device: live tiles per conv and frame of the last forward (bench / tests)
         self._empty_maps = {}
@@ -707,7 +707,8 @@ class RPNInference(nn.Module):
                     x = ops.conv2d_nhwc_gather(gather.features, sm, self.gather_packed, self.bs[i], self.ws[i].shape[0], relu=True)
                 gather, first = None, False
             elif kind == "c" and live is not None and nbr is not None:
-                keep = i == self.background_convs - 1          # the last conv materialises its background for the 1x1 tail
+                # the last conv keeps its copies unless its consumer is the fused 1x1 tail on the same lists (x_live_only below)
+                keep = i == self.background_convs - 1 and not self.chain_tail
                 x = ops.conv2d_nhwc_tiles(x, self.packed[i], self.bs[i], 128, live[i], self.last_live_counts[i], empty[i] if keep else None,
                                           relu=True, nbr_masks=nbr[i], background_in=empty[i - 1])
             elif kind == "c" and live is not None:
@@ -722,7 +723,8 @@ class RPNInference(nn.Module):
         if self.chain_tail and live is not None:
             last = self.background_convs - 1
             y = ops.conv1x1_chain(x, self.packed[-1], self.bs[-1], self.head_packed, self.head_b64, self.head_cout,
-                                  tile_order=live[last], live_counts=self.last_live_counts[last], background=empty[last + 1])
+                                  tile_order=live[last], live_counts=self.last_live_counts[last], background=empty[last + 1],
+                                  x_live_only=nbr is not None)
         elif self.chain_tail:
             y = ops.conv1x1_chain(x, self.packed[-1], self.bs[-1], self.head_packed, self.head_b64, self.head_cout)
         else:

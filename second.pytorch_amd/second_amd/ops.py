@@ -858,7 +858,7 @@ def conv2d_nhwc_tiles(x, packed, bias, cout, tile_order, live_counts, background
 
 # ----------------------------------------------------------------------------- IoU / NMS
 @_traced("conv1x1_chain")
-def conv1x1_chain(x, packed_w1, bias1, packed_w2, bias2, cout2, relu1=True, tile_order=None, live_counts=None, background=None):
+def conv1x1_chain(x, packed_w1, bias1, packed_w2, bias2, cout2, relu1=True, tile_order=None, live_counts=None, background=None, x_live_only=False):
     """y = W2 * act(W1 * x + bias1) + bias2 for two back-to-back 1x1 convs on a channels_last [B,128,H,W] tensor
     (the RPN deblock + merged heads, rpn.py:275-285,386-391); the 128-channel intermediate stays in LDS.
     ``tile_order`` / ``live_counts`` (the last 3x3 conv's lists of :func:`rpn_tile_live`) + ``background`` (this op's output for an
@@ -872,7 +872,8 @@ def conv1x1_chain(x, packed_w1, bias1, packed_w2, bias2, cout2, relu1=True, tile
         assert tile_order.dtype == torch.int16 and tile_order.is_contiguous() and tuple(tile_order.shape) == (b, ((h + 7) // 8) * ((w + 15) // 16))
         assert live_counts.dtype == torch.int32 and live_counts.numel() == b and background.dtype == x.dtype
         assert background.numel() == h * w * int(cout2) and background.is_contiguous(memory_format=torch.channels_last)
-        rc = rt.lib().sec_conv1x1_chain_nhwc_tiles(rt.ptr(x), b, h, w, rt.ptr(packed_w1), rt.ptr(bias1), int(bool(relu1)), rt.ptr(packed_w2),
+        # x_live_only (SEC_CHAIN_X_LIVE_ONLY): the producer of x wrote the live tiles of these lists only -- the lists are used whatever the live share
+        rc = rt.lib().sec_conv1x1_chain_nhwc_tiles(rt.ptr(x), b, h, w, rt.ptr(packed_w1), rt.ptr(bias1), int(bool(relu1)) | (2 if x_live_only else 0), rt.ptr(packed_w2),
                                                    rt.ptr(bias2), int(cout2), rt.ptr(tile_order), rt.ptr(live_counts), rt.ptr(background),
                                                    rt.ptr(y), rt.dtype_code(x.dtype), rt.stream())
         rt.check(rc, "sec_conv1x1_chain_nhwc_tiles")
