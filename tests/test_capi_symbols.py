@@ -46,6 +46,25 @@ def test_workspace_queries_are_host_only():
     assert list(out) == [21, 800, 704]
 
 
+def test_lazy_background_entry_points_validate_before_any_launch():
+    """The lazy forms refuse what cannot be right before touching the device (status codes of include/second_hip.h; no GPU needed):
+    lists, masks and the producer's empty-frame map are mandatory for sec_conv2d_nhwc_tiles_lazy, the masks for
+    sec_rpn_tile_live_masks, and sec_conv2d_nhwc_tiles still requires the background it copies from."""
+    from second_amd import runtime as rt
+    l = rt.lib()
+    one = ctypes.c_void_p(16)            # never dereferenced: validation fails first
+    inval = -1
+    assert l.sec_conv2d_nhwc_tiles_lazy(one, 1, 8, 16, one, None, 128, 1, None, one, None, one, one, one, rt.SEC_BF16, None) == inval     # no lists
+    assert l.sec_conv2d_nhwc_tiles_lazy(one, 1, 8, 16, one, None, 128, 1, one, one, None, None, one, one, rt.SEC_BF16, None) == inval      # no masks
+    assert l.sec_conv2d_nhwc_tiles_lazy(one, 1, 8, 16, one, None, 128, 1, one, one, None, one, None, one, rt.SEC_BF16, None) == inval      # no empty-frame map
+    assert l.sec_conv2d_nhwc_tiles_lazy(one, 1, 8, 16, one, None, 128, 1, one, None, None, one, one, one, rt.SEC_BF16, None) == inval      # lists without counts
+    assert l.sec_conv2d_nhwc_tiles_lazy(one, 1, 8, 16, one, None, 96, 1, one, one, None, one, one, one, rt.SEC_BF16, None) == -3           # cout: unsupported
+    assert l.sec_conv2d_nhwc_tiles(one, 1, 8, 16, one, None, 128, 1, one, one, None, one, rt.SEC_BF16, None) == inval                       # copying form without background
+    assert l.sec_rpn_tile_live_masks(one, 1, 8, 16, 2, one, one, None, one, 1 << 20, None) == inval
+    assert l.sec_rpn_tile_live_masks(one, 1, 8, 16, 9, one, one, one, one, 1 << 20, None) == -3                                             # more than 8 layers
+    assert l.sec_rpn_tile_live_masks(one, 1, 8, 16, 2, one, one, one, one, 0, None) == -2                                                   # workspace too small
+
+
 def test_no_cpu_fallback():
     from second_amd import ops
     from second_amd.runtime import SecondHipError
