@@ -265,6 +265,15 @@ def accelerate_nms():
     return bto
 
 
+def accelerate_model(net, dtype=None, graph=True, static=None, strict=True):
+    """Serve a reference-built ``VoxelNet``'s ``net(example)`` in eval mode (voxelnet.py:339-375, called by train.py:524) from the
+    fused static-capacity, graph-captured pipeline: parameters adopted by state-dict key, same return value
+    (voxelnet.py:616-643), fp32 by default and 16-bit after ``net.half()``.  See :mod:`second_amd.dropin`.  Call after the
+    network is built (any time before the first eval batch; later ``load_state_dict`` / ``.half()`` / ``.to()`` are followed)."""
+    from ..dropin import accelerate_model as _acc
+    return _acc(net, dtype=dtype, graph=graph, static=static, strict=strict)
+
+
 def rotate_iou_gpu_eval(boxes, query_boxes, criterion=-1, device_id=0):
     """Same signature and numpy-in / numpy-out contract as second/core/non_max_suppression/nms_gpu.py:604-640
     (rotate_iou_gpu_eval, a numba.cuda kernel), on ``sec_rotate_iou_f32``: [N,5] x [K,5] (x, y, w, l, r) -> [N,K];

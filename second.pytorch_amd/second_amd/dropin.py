@@ -1,0 +1,410 @@
+"""The fused MI355X pipeline BEHIND the reference's own ``VoxelNet.forward(example)``.
+
+The reference evaluates with ``net(example)`` (second/pytorch/train.py:524) where ``net`` is the ``VoxelNet`` that
+``build_network`` assembled from ``spconv.SubMConv3d / SparseConv3d / SparseSequential`` modules
+(second/pytorch/models/voxelnet.py:142-171, middle.py:145-210, rpn.py:202-420) and ``example`` is the collated batch of
+``merge_second_batch`` after ``example_convert_to_torch`` (voxels [N, T, F], num_points [N], coordinates [N, 4] with the batch
+index prepended, anchors [B, A, 7]; voxelnet.py:339-375).  Eager execution of that module graph pays a host round trip per
+strided layer, three modules per layer, the dense [B, 128, 200, 176] image and per-frame torch glue in ``predict``.
+
+:class:`FusedVoxelNet` adopts such a network instead of re-running it:
+
+  * :func:`model_config` reads everything the fused pipeline needs from the network object itself (voxel grid, layer plan of
+    the RPN, anchor count, the NMS / score / direction settings of ``predict``) -- no config file, no edit of the reference;
+  * the parameters move by state-dict key into :class:`second_amd.models.SecondDetector` (same keys as the reference), the
+    BatchNorms are folded, the RPN is repacked for the hand-written MFMA convs; adoption is redone whenever a parameter of the
+    network changes (``load_state_dict`` after acceleration, ``net.half()``, ``.to(device)``);
+  * one call = copy the example into static-capacity buffers, ONE hipGraph replay (SimpleVoxel mean | PillarFeatureNet ->
+    fused rulebook chain -> 14 sparse convs -> RPN on live tiles -> select / decode / NMS / finalize), ONE device -> host copy of
+    the padded detections, and the reference's return value (voxelnet.py:616-643: a list of
+    ``{box3d_lidar [k, 7] float32, scores [k] float32, label_preds [k] int64, metadata}`` on the input's device);
+  * precision follows the caller: fp32 networks run the fp32 pipeline, ``net.half()`` (train.py:470) the fp16 one;
+    ``dtype=torch.bfloat16`` may be forced;
+  * training mode, DataParallel-padded examples (``num_points`` 2-D, voxelnet.py:346), ``anchors_mask`` and per-frame anchor
+    sets keep the original forward.
+
+There is no CPU fallback inside the fused path: static capacities and graphs need the HIP library; a CPU network is served
+in the dynamic-shape eager mode only when a test installs the oracle backend.
+"""
+import numpy as np
+import torch
+
+from . import ops
+from .models import SecondDetector
+
+
+class NotAccelerable(NotImplementedError):
+    """The network is outside what the fused pipeline reproduces exactly; the message says which property."""
+
+
+def _seq(v):
+    return [float(x) for x in np.asarray(v).reshape(-1)]
+
+
+def model_config(net):
+    """The ``SecondDetector`` configuration of a reference-built VoxelNet (attribute names of voxelnet.py:100-171, rpn.py:202-300,
+    spconv.utils.VoxelGeneratorV2).  Raises :class:`NotAccelerable` for networks outside the fused path."""
+    why = []
+    vfe, mid, rpn = net.voxel_feature_extractor, net.middle_feature_extractor, net.rpn
+    vfe_t, mid_t, rpn_t = type(vfe).__name__, type(mid).__name__, type(rpn).__name__
+    if vfe_t not in ("SimpleVoxel", "PillarFeatureNet"):
+        why.append(f"voxel feature extractor {vfe_t}")
+    if mid_t not in ("SpMiddleFHD", "PointPillarsScatter"):
+        why.append(f"middle feature extractor {mid_t}")
+    if (vfe_t == "PillarFeatureNet") != (mid_t == "PointPillarsScatter"):
+        why.append(f"{vfe_t} with {mid_t}")
+    if rpn_t != "RPNV2" or getattr(rpn, "_use_groupnorm", False) or not getattr(rpn, "_use_norm", True):
+        why.append(f"rpn {rpn_t} (BatchNorm RPNV2 only)")
+    if getattr(net, "_multiclass_nms", False):
+        why.append("multiclass_nms")
+    if not getattr(net, "_use_sigmoid_score", True) or not getattr(net, "_encode_background_as_zeros", True):
+        why.append("softmax scores / background class")
+    coder = getattr(net, "_box_coder", None) or net.target_assigner.box_coder
+    if int(coder.code_size) != 7 or getattr(coder, "vec_encode", False) or getattr(coder, "linear_dim", False):
+        why.append("box coder other than the 7-value ground coder")
+    if why:
+        raise NotAccelerable("accelerate_model: not reproducible by the fused pipeline: " + "; ".join(why))
+    vg = net.voxel_generator
+    pillars = vfe_t == "PillarFeatureNet"
+    ups = [float(u) for u in rpn._upsample_strides]
+    factor = (1 if pillars else 8) * float(np.prod([float(s) for s in rpn._layer_strides[:rpn._upsample_start_idx + 1]])) / ups[0]
+    if abs(factor - round(factor)) > 1e-6:
+        raise NotAccelerable(f"accelerate_model: non-integer feature map factor {factor}")
+    cfg = dict(
+        name="adopted:" + (getattr(net, "name", None) or type(net).__name__),
+        point_cloud_range=_seq(vg.point_cloud_range), voxel_size=_seq(vg.voxel_size),
+        max_points_per_voxel=int(vg.max_num_points_per_voxel), max_voxels=int(getattr(vg, "_max_voxels", 20000)),
+        num_point_features=int(net._num_input_features),
+        middle=mid_t, middle_in=64 if pillars else int(net._num_input_features),
+        rpn=dict(layer_nums=[int(v) for v in rpn._layer_nums], layer_strides=[int(v) for v in rpn._layer_strides],
+                 num_filters=[int(v) for v in rpn._num_filters], upsample_strides=ups,
+                 num_upsample_filters=[int(v) for v in rpn._num_upsample_filters], num_input_features=int(rpn._num_input_features),
+                 use_direction_classifier=bool(rpn._use_direction_classifier)),
+        downsample_factor=int(round(factor)),
+        num_anchor_per_loc=int(rpn._num_anchor_per_loc),
+        num_class=int(net._num_class), num_direction_bins=int(net._num_direction_bins),
+        direction_offset=float(net._dir_offset), direction_limit_offset=float(net._dir_limit_offset),
+        nms_score_threshold=float(net._nms_score_thresholds[0]), nms_pre_max_size=int(net._nms_pre_max_sizes[0]),
+        nms_post_max_size=int(net._nms_post_max_sizes[0]), nms_iou_threshold=float(net._nms_iou_thresholds[0]),
+        use_rotate_nms=bool(net._use_rotate_nms),
+        post_center_range=_seq(net._post_center_range) if len(net._post_center_range) else [-1e30] * 3 + [1e30] * 3,
+    )
+    if pillars:
+        lin = vfe.pfn_layers[0].linear
+        if len(vfe.pfn_layers) != 1 or lin.in_features != int(net._num_input_features) + 5:
+            raise NotAccelerable("accelerate_model: PillarFeatureNet other than one layer on (x, y, z, r) + 5 decorations")
+        cfg.update(vfe="PillarFeatureNet", vfe_filters=[int(lin.out_features)])
+    if not bool(rpn._use_direction_classifier):
+        raise NotAccelerable("accelerate_model: networks without the direction classifier")   # (every shipped config has it)
+    return cfg
+
+
+class _Session:
+    """Static buffers + captured graph for one (batch size, row capacity, voxel tensor layout)."""
+
+    def __init__(self, eng, batch, cap, vox_shape, vox_dtype, anchors0):
+        self.eng, self.batch, self.cap = eng, batch, cap
+        dev = anchors0.device
+        self.voxels = torch.zeros((cap,) + tuple(vox_shape), dtype=vox_dtype, device=dev)
+        self.num_points = torch.ones((cap,), dtype=torch.int32, device=dev)      # rows past the live count: 0 / 1, never 0 / 0
+        self.coors = torch.zeros((cap, 4), dtype=torch.int32, device=dev)
+        self.n_dev = torch.zeros((1,), dtype=torch.int32, device=dev)
+        self.anchors = anchors0.detach().float().contiguous().clone()
+        self.caps = None            # static_out_rows of the strided layers, in module order
+        self.graph = self.outs = None
+        self.event = torch.cuda.Event()
+
+    def _strided(self):
+        import spconv
+        return [m for m in self.eng._det.middle_feature_extractor.modules()
+                if isinstance(m, spconv.SparseConvolution) and not m.subm]
+
+    def body(self):
+        det, b = self.eng._det, self.batch
+        for m, c in zip(self._strided(), self.caps or []):
+            m.static_out_rows = c
+        dt = det._infer_dtype
+        if det.pillars:
+            feats = det.voxel_feature_extractor(self.voxels, self.num_points, self.coors, out_dtype=dt, num_dev=self.n_dev)
+        else:
+            nf = det.cfg["num_point_features"]      # SimpleVoxel (voxel_encoder.py:207-225), summed in fp32 whatever the storage type
+            feats = self.voxels[:, :, :nf].float().sum(1) / self.num_points.float().unsqueeze(1)
+            if dt is not None:
+                feats = feats.to(dt)
+        preds = det.network_forward(feats, self.coors, b, num_active_dev=self.n_dev)
+        out = det.predict_device(preds, b, self.anchors)
+        checks = list(getattr(det.middle_feature_extractor, "last_overflow_checks", [])) if not det.pillars else []
+        packed = torch.cat([out["boxes"].reshape(b, -1).float(), out["scores"].float(), out["labels"].float(),
+                            out["valid"].float()], 1)
+        counters = torch.stack([num[1] for num, _ in checks]).int() if checks else torch.zeros((1,), dtype=torch.int32, device=packed.device)
+        return {"packed": packed, "labels": out["labels"].long(), "counters": counters, "limits": [int(c) for _, c in checks],
+                "post": int(out["scores"].shape[1])}
+
+    def build(self, graph):
+        prev = ops.set_rulebook_numbering("sorted")
+        try:
+            with torch.no_grad():
+                if not graph:
+                    self.graph, self.outs = None, self.body()
+                else:
+                    s = torch.cuda.Stream()
+                    s.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(s):
+                        for _ in range(2):
+                            self.body()
+                    torch.cuda.current_stream().wait_stream(s)
+                    torch.cuda.synchronize()
+                    self.graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                        self.outs = self.body()
+                    self.eng.stats["captures"] += 1
+        finally:
+            ops.set_rulebook_numbering(prev)
+        self.host_packed = torch.empty(self.outs["packed"].shape, dtype=torch.float32, pin_memory=True)
+        self.host_counters = torch.empty((self.outs["counters"].numel() + 1,), dtype=torch.int32, pin_memory=True)
+        self.dev_counters = torch.zeros((self.outs["counters"].numel() + 1,), dtype=torch.int32, device=self.anchors.device)
+
+    def launch(self):
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            prev = ops.set_rulebook_numbering("sorted")
+            try:
+                with torch.no_grad():
+                    self.outs = self.body()
+            finally:
+                ops.set_rulebook_numbering(prev)
+
+
+class FusedVoxelNet:
+    """See the module docstring.  ``graph=False``: the same static-capacity launches issued one by one (debugging, profiling);
+    ``static=False``: dynamic shapes, eager (what a CPU network under the tests' oracle backend gets)."""
+
+    def __init__(self, net, dtype=None, graph=True, static=None, margin=1.25, row_bucket=16384):
+        self.net, self.cfg = net, model_config(net)
+        self.forced_dtype, self.graph, self.static = dtype, bool(graph), static
+        self.margin, self.row_bucket = float(margin), int(row_bucket)
+        self._det = self._wkey = self._watch = None
+        self._sessions = {}
+        self._akey = None
+        self.stats = {"fused_calls": 0, "original_calls": 0, "adoptions": 0, "captures": 0, "overflow_recaptures": 0,
+                      "anchor_refreshes": 0}
+
+    # ------------------------------------------------------------------ adoption
+    def _tensors(self):
+        net = self.net
+        out = []
+        for m in (net.voxel_feature_extractor, net.middle_feature_extractor, net.rpn):
+            out += list(m.parameters()) + list(m.buffers())
+        return out
+
+    def _weights_key(self):
+        w = self._watch
+        return (sum(t._version for t in w), sum(t.data_ptr() for t in w), w[0].dtype if w else None, self.net.rpn.conv_cls.weight.dtype)
+
+    def run_dtype(self):
+        """None = fp32 pipeline; torch.float16 / torch.bfloat16 = 16-bit features (BatchNorm statistics, biases, box decode and
+        NMS stay fp32 either way, as after the reference's ``convert_norm_to_float``)."""
+        if self.forced_dtype is not None:
+            return None if self.forced_dtype == torch.float32 else self.forced_dtype
+        wd = self.net.rpn.conv_cls.weight.dtype
+        return None if wd == torch.float32 else wd
+
+    def refresh(self):
+        """(Re-)adopt the network's parameters when any of them changed since the last call."""
+        if self._watch is None:
+            self._watch = self._tensors()
+        key = self._weights_key()
+        if self._det is not None and key == self._wkey:
+            return self._det
+        self._watch = self._tensors()
+        key = self._weights_key()
+        net = self.net
+        dev = net.rpn.conv_cls.weight.device
+        det = SecondDetector(self.cfg).eval()
+        mine = det.state_dict()
+        theirs = net.state_dict()
+        absent = [k for k in mine if k not in theirs and k != "global_step"]
+        extra = [k for k in theirs if k.split(".")[0] in ("voxel_feature_extractor", "middle_feature_extractor", "rpn") and k not in mine
+                 and not k.endswith("num_batches_tracked")]
+        if absent or extra:
+            raise NotAccelerable(f"accelerate_model: state dict differs from the fused pipeline's (missing {absent[:4]}, unknown {extra[:4]})")
+        state = {}
+        for k, v in mine.items():
+            if k in theirs:
+                t = theirs[k].detach()
+                if tuple(t.shape) != tuple(v.shape):
+                    raise NotAccelerable(f"accelerate_model: {k} has shape {tuple(t.shape)}, the fused pipeline expects {tuple(v.shape)}")
+                state[k] = t.float() if t.is_floating_point() else t
+        det.load_state_dict(state, strict=False)
+        det = det.to(dev)
+        dt = self.run_dtype()
+        if dev.type == "cuda" and dt is not None:
+            det.prepare_inference(dt)
+        det.eval()
+        self._det, self._wkey = det, key
+        self._sessions.clear()
+        self.stats["adoptions"] += 1
+        return det
+
+    # ------------------------------------------------------------------ dispatch
+    def accepts(self, example):
+        if self.net.training:
+            return False
+        for k in ("voxels", "num_points", "coordinates", "anchors"):
+            if not isinstance(example.get(k), torch.Tensor):
+                return False
+        return example["num_points"].dim() == 1 and "anchors_mask" not in example and example["voxels"].shape[0] > 0
+
+    def __call__(self, example):
+        det = self.refresh()
+        voxels = example["voxels"]
+        static = voxels.is_cuda if self.static is None else self.static
+        if not static:
+            return self._dynamic(det, example)
+        return self._static(det, example)
+
+    def _meta(self, example, batch):
+        meta = example.get("metadata")
+        return list(meta) if meta is not None and len(meta) else [None] * batch
+
+    def _dynamic(self, det, example):
+        batch = example["anchors"].shape[0]
+        anchors = example["anchors"].reshape(batch, -1, 7).float()
+        with torch.no_grad():
+            voxels = example["voxels"]
+            feats = det.voxel_feature_extractor(voxels.float(), example["num_points"], example["coordinates"])
+            preds = det.network_forward(feats, example["coordinates"], batch)
+            out = det.predict_device(preds, batch, anchors)
+        self.stats["fused_calls"] += 1
+        res = []
+        for b, meta in zip(range(batch), self._meta(example, batch)):
+            m = out["valid"][b]
+            res.append({"box3d_lidar": out["boxes"][b][m].float(), "scores": out["scores"][b][m].float(),
+                        "label_preds": out["labels"][b][m].long(), "metadata": meta})
+        return res
+
+    def _session(self, det, example, batch):
+        voxels = example["voxels"]
+        n = voxels.shape[0]
+        key = (batch, tuple(voxels.shape[1:]), voxels.dtype, voxels.device)
+        sess = self._sessions.get(key)
+        if sess is not None and sess.cap >= n:
+            return sess
+        cap = -(-int(n * (1.0 if sess is None else self.margin)) // self.row_bucket) * self.row_bucket
+        anchors0 = example["anchors"].reshape(batch, -1, 7)[0]
+        new = _Session(self, batch, cap, voxels.shape[1:], voxels.dtype, anchors0)
+        new.caps = self._calibrate(det, example, batch)
+        self._fill(new, example)
+        new.build(self.graph)
+        self._sessions[key] = new
+        return new
+
+    def _calibrate(self, det, example, batch):
+        """Capacities of the strided layers from one dynamic-shape forward of this example (live outputs x margin, 256-row
+        granules), like SecondDetector.calibrate."""
+        import spconv
+        if det.pillars:
+            return []
+        prev = ops.set_rulebook_numbering("sorted")
+        try:
+            with torch.no_grad():
+                nf = det.cfg["num_point_features"]
+                feats = example["voxels"][:, :, :nf].float().sum(1) / example["num_points"].float().unsqueeze(1)
+                det.network_forward(feats, example["coordinates"].int(), batch)
+        finally:
+            ops.set_rulebook_numbering(prev)
+        caps = []
+        for m in det.middle_feature_extractor.modules():
+            if isinstance(m, spconv.SparseConvolution) and not m.subm:
+                caps.append(int(-(-int(m.last_num_out * self.margin) // 256) * 256))
+        return caps
+
+    @staticmethod
+    def _fill(sess, example):
+        n = example["voxels"].shape[0]
+        sess.voxels[:n].copy_(example["voxels"], non_blocking=True)
+        sess.num_points[:n].copy_(example["num_points"], non_blocking=True)
+        sess.coors[:n].copy_(example["coordinates"], non_blocking=True)
+        sess.n_dev.fill_(n)
+
+    def _static(self, det, example):
+        batch = example["anchors"].shape[0]
+        anchors = example["anchors"].reshape(batch, -1, 7)
+        for attempt in range(4):
+            sess = self._session(det, example, batch)
+            self._fill(sess, example)
+            akey = (anchors.data_ptr(), anchors._version, tuple(anchors.shape), id(sess))
+            check_anchors = akey != self._akey
+            nc = sess.outs["counters"].numel()
+            if check_anchors:      # anchors of a new tensor: compared on the device, the flag travels with the results
+                sess.dev_counters[nc:].copy_((anchors != sess.anchors.unsqueeze(0)).any().int().reshape(1))
+            sess.launch()
+            sess.dev_counters[:nc].copy_(sess.outs["counters"].reshape(-1))
+            sess.host_packed.copy_(sess.outs["packed"], non_blocking=True)
+            sess.host_counters.copy_(sess.dev_counters, non_blocking=True)
+            packed = sess.outs["packed"].clone()          # the session's buffers are overwritten by the next call
+            labels = sess.outs["labels"].clone()
+            sess.event.record()
+            sess.event.synchronize()
+            cnt = sess.host_counters.numpy()
+            if check_anchors and cnt[nc]:
+                same = bool((anchors == anchors[:1]).all().item())
+                if not same:                              # per-frame anchor sets: the reference's own path handles them
+                    return None
+                sess.anchors.copy_(anchors[0])
+                self.stats["anchor_refreshes"] += 1
+                continue
+            over = [int(r) for r, c in zip(cnt[:nc], sess.outs["limits"]) if int(r) > c]
+            if over:                                      # a strided layer outgrew its capacity: size it from the raw counts, recapture
+                caps = [max(c, int(-(-int(int(r) * self.margin) // 256) * 256)) for r, c in zip(cnt[:nc], sess.caps)]
+                sess.caps = caps
+                sess.build(self.graph)
+                self.stats["overflow_recaptures"] += 1
+                continue
+            self._akey = akey
+            break
+        else:
+            raise RuntimeError("accelerate_model: static capacities did not settle after four attempts")
+        self.stats["fused_calls"] += 1
+        p = sess.outs["post"]
+        hp = sess.host_packed.numpy()
+        valid = hp[:, 9 * p:10 * p] > 0.5
+        boxes = packed[:, :7 * p].view(batch, p, 7)
+        scores = packed[:, 7 * p:8 * p]
+        res = []
+        for b, meta in zip(range(batch), self._meta(example, batch)):
+            idx = np.flatnonzero(valid[b])
+            k = len(idx)
+            if k == 0 or idx[-1] == k - 1:                # the usual case: the kept detections are a prefix
+                res.append({"box3d_lidar": boxes[b, :k], "scores": scores[b, :k], "label_preds": labels[b, :k], "metadata": meta})
+            else:
+                sel = torch.from_numpy(idx).to(packed.device)
+                res.append({"box3d_lidar": boxes[b][sel], "scores": scores[b][sel], "label_preds": labels[b][sel], "metadata": meta})
+        return res
+
+
+def accelerate_model(net, dtype=None, graph=True, static=None, strict=True):
+    """Serve ``net(example)`` (eval mode) from the fused pipeline; see the module docstring.  Returns ``net`` (its ``forward`` is
+    shadowed on the instance; ``net._second_amd_engine`` is the :class:`FusedVoxelNet`, ``net._second_amd_original_forward`` the
+    reference's method).  ``strict=False``: a network outside the fused path is returned unchanged instead of raising."""
+    if getattr(net, "_second_amd_engine", None) is not None:
+        return net
+    try:
+        eng = FusedVoxelNet(net, dtype=dtype, graph=graph, static=static)
+    except NotAccelerable:
+        if strict:
+            raise
+        return net
+    original = net.forward
+
+    def forward(example):
+        if eng.accepts(example):
+            res = eng(example)
+            if res is not None:
+                return res
+        eng.stats["original_calls"] += 1
+        return original(example)
+    net.forward = forward
+    net._second_amd_engine, net._second_amd_original_forward = eng, original
+    return net

@@ -215,6 +215,25 @@ class _ShardedEvaluation:
         return self._ds.evaluation(detections, output_dir)
 
 
+class _EvalDatasetView:
+    """What ``input_reader_builder.build`` returns to evaluate(), with ``.dataset`` answering the sharded proxy.  The
+    reference's ``DatasetWrapper`` exposes ``dataset`` as a read-only property (input_reader_builder.py:44-46), so the proxy cannot
+    be assigned into it; this view forwards ``len`` / indexing (the DataLoader's contract) and every other attribute to the
+    wrapper it stands for."""
+
+    def __init__(self, wrapped, proxy):
+        self.__dict__.update(_wrapped=wrapped, dataset=proxy)
+
+    def __len__(self):
+        return len(self._wrapped)
+
+    def __getitem__(self, idx):
+        return self._wrapped[idx]
+
+    def __getattr__(self, name):
+        return getattr(self._wrapped, name)
+
+
 def _detections_to_host(dets):
     import torch
     return [{k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in d.items()} for d in dets]
@@ -224,9 +243,10 @@ def run_evaluate(reference_root, config_path, model_dir, backend=None, device=No
     """The reference's UNMODIFIED ``second.pytorch.train.evaluate`` (train.py:433-545) over this package: one process per GPU,
     every rank evaluates frames rank, rank + world, ... of the evaluation set (a sequential sharded sampler on the loader
     evaluate() builds, train.py:485-491), the detections are gathered inside ``eval_dataset.dataset.evaluation`` and the KITTI /
-    nuScenes metrics run once on rank 0.  ``accelerate``: ``compat.accelerate_nms`` (device-resident rotate_nms / nms behind
-    VoxelNet.predict, voxelnet.py:452-455,578-584) and ``compat.accelerate_eval`` (rotate_iou_gpu_eval of second/utils/eval.py on
-    sec_rotate_iou_f32).  No collective on the data path.  Returns the proxy dataset (tests read ``last_detections``)."""
+    nuScenes metrics run once on rank 0.  ``accelerate``: ``compat.accelerate_model`` on the network ``build_network`` returns (the fused static-capacity
+    pipeline behind ``net(example)``; SEC_ACCELERATE_MODEL=0 keeps the module graph), ``compat.accelerate_nms`` (device-resident
+    rotate_nms / nms behind VoxelNet.predict, voxelnet.py:452-455,578-584, for whatever still takes the original forward) and
+    ``compat.accelerate_eval`` (rotate_iou_gpu_eval of second/utils/eval.py on sec_rotate_iou_f32).  No collective on the data path.  Returns the proxy dataset (tests read ``last_detections``)."""
     import torch
     import torch.utils.data as tud
     from . import compat, distributed as D
@@ -237,8 +257,16 @@ def run_evaluate(reference_root, config_path, model_dir, backend=None, device=No
     if accelerate:
         compat.accelerate_nms()
         compat.accelerate_eval()
-    saved = {"DataLoader": tud.DataLoader, "build": T.input_reader_builder.build, "convert": T.example_convert_to_torch}
+    saved = {"DataLoader": tud.DataLoader, "build": T.input_reader_builder.build, "convert": T.example_convert_to_torch,
+             "build_network": T.build_network}
     holder = {}
+    fuse = accelerate and os.environ.get("SEC_ACCELERATE_MODEL", "1") != "0"
+
+    def build_network(*a, **k):
+        # the fused static-capacity pipeline behind net(example) (second_amd.dropin); networks outside it stay as built
+        net = saved["build_network"](*a, **k)
+        holder["net"] = compat.accelerate_model(net, strict=False) if fuse else net
+        return holder["net"]
 
     class ShardSampler(tud.Sampler):
         def __init__(self, n):
@@ -259,14 +287,15 @@ def run_evaluate(reference_root, config_path, model_dir, backend=None, device=No
 
     def build(*a, **k):
         ds = saved["build"](*a, **k)
-        holder["proxy"] = ds.dataset = _ShardedEvaluation(ds.dataset, rank, world)
-        return ds
+        holder["proxy"] = _ShardedEvaluation(ds.dataset, rank, world)
+        return _EvalDatasetView(ds, holder["proxy"])
 
     def convert(example, dtype=torch.float32, dev=None):
         return saved["convert"](example, dtype, dev if dev is not None else device)
 
     tud.DataLoader = DataLoader
     T.input_reader_builder.build = build
+    T.build_network = build_network
     if device is not None:
         T.example_convert_to_torch = convert
     try:
@@ -277,7 +306,11 @@ def run_evaluate(reference_root, config_path, model_dir, backend=None, device=No
         tud.DataLoader = saved["DataLoader"]
         T.input_reader_builder.build = saved["build"]
         T.example_convert_to_torch = saved["convert"]
-    return holder.get("proxy")
+        T.build_network = saved["build_network"]
+    proxy = holder.get("proxy")
+    if proxy is not None:
+        proxy.__dict__["net"] = holder.get("net")
+    return proxy
 
 
 def main(argv=None):

@@ -769,13 +769,19 @@ class SecondDetector(nn.Module):
         else:
             self.voxel_feature_extractor = SimpleVoxel(cfg["num_point_features"])
             self.middle_feature_extractor = SpMiddleFHD(dense_shape, cfg["middle_in"])
-        a_per_loc = anchors_per_location(cfg)
+        # a config adopted from a reference-built VoxelNet (second_amd.dropin) names the anchor count only: its anchors arrive
+        # with every example (voxelnet.py:358), so no anchor table is generated here
+        a_per_loc = int(cfg.get("num_anchor_per_loc") or anchors_per_location(cfg))
+        self.num_anchor_per_loc = a_per_loc
         self.rpn = RPNV2(num_class=cfg["num_class"], num_anchor_per_loc=a_per_loc, num_direction_bins=cfg["num_direction_bins"],
                          **cfg["rpn"])
         self.register_buffer("global_step", torch.LongTensor(1).zero_())
         fm = [1, int(gs[1]) // cfg["downsample_factor"], int(gs[0]) // cfg["downsample_factor"]]
         self.feature_map_size = fm
-        self.register_buffer("anchors", torch.from_numpy(generate_anchors(cfg, fm)), persistent=False)
+        if cfg.get("anchor_sizes"):
+            self.register_buffer("anchors", torch.from_numpy(generate_anchors(cfg, fm)), persistent=False)
+        else:
+            self.anchors = None
         self.register_buffer("_arange_p", torch.arange(cfg["nms_post_max_size"], dtype=torch.int32), persistent=False)
         self.register_buffer("post_center_range", torch.tensor(cfg["post_center_range"], dtype=torch.float32),
                              persistent=False)
@@ -1069,7 +1075,7 @@ class SecondDetector(nn.Module):
     def _predict_fused(self, preds, batch_size, anchors):
         """select -> decode -> NMS -> finalize: five launches, no host sync, no torch glue."""
         cfg = self.cfg
-        a_per_loc = anchors_per_location(cfg)
+        a_per_loc = self.num_anchor_per_loc
         _, h, w = self.feature_map_size
 
         def view5(t, code):

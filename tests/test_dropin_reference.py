@@ -253,3 +253,110 @@ def test_accelerated_nms_patch_equals_reference_path(ref):
                 assert torch.equal(got, want) and len(got) > 3
         finally:
             bto._second_amd_force = False
+
+
+def _example_of(train, net, clouds, max_voxels=40000, fm=(1, 200, 176)):
+    vox = [net.voxel_generator.generate(c, max_voxels) for c in clouds]
+    anchors = net.target_assigner.generate_anchors(list(fm))["anchors"].reshape(1, -1, 7)
+    example = {
+        "voxels": np.concatenate([v["voxels"] for v in vox]),
+        "num_points": np.concatenate([v["num_points_per_voxel"] for v in vox]),
+        "coordinates": np.concatenate([np.pad(v["coordinates"], ((0, 0), (1, 0)), mode="constant", constant_values=b)
+                                       for b, v in enumerate(vox)]),
+        "anchors": np.repeat(anchors, len(clouds), 0),
+        "metadata": [{"image_idx": 10 + b} for b in range(len(clouds))],
+    }
+    return train.example_convert_to_torch(example, torch.float32, torch.device("cpu"))
+
+
+def test_accelerate_model_serves_the_reference_voxelnet(ref):
+    """compat.accelerate_model on the network the reference's own build_network returns: the configuration is read off the
+    object, the parameters move by state-dict key, and net(example) (voxelnet.py:339-375) returns what the original forward
+    returns -- same list of dicts, same dtypes, metadata passed through.  Dynamic-shape mode here (CPU, oracle backend); the
+    static-capacity / graph mode of the same engine is tests/test_gpu_dropin_fused.py."""
+    import oracle_backend
+    from e2e_trace import trained_like_detector
+    from second_amd import compat, dropin, synthetic as syn
+    from second_amd.models import CAR_FHD
+    train, cfg = ref
+    model_cfg = cfg.model.second
+    model_cfg.target_assigner.class_settings[0].nms_pre_max_size = 150
+    clouds = [syn.syn_kitti_cloud(s, num_points=6000, num_voxels=5000) for s in range(2)]
+    with oracle_backend.installed():
+        net = train.build_network(model_cfg).eval()
+        like = trained_like_detector(dict(CAR_FHD, nms_pre_max_size=150), clouds[0])      # distinct scores: no tie-order dependence
+        net.load_state_dict(like.state_dict(), strict=False)
+        ex = _example_of(train, net, clouds)
+        with torch.no_grad():
+            want = net(ex)
+        assert sum(w["box3d_lidar"].shape[0] for w in want) >= 4
+        assert compat.accelerate_model(net) is net and compat.accelerate_model(net) is net          # idempotent
+        eng = net._second_amd_engine
+        c = eng.cfg
+        assert c["middle"] == "SpMiddleFHD" and c["downsample_factor"] == 8 and c["num_anchor_per_loc"] == 2
+        assert c["nms_pre_max_size"] == 150 and c["use_rotate_nms"] and abs(c["nms_iou_threshold"] - 0.01) < 1e-6
+        assert c["rpn"]["layer_nums"] == [5] and c["max_points_per_voxel"] == 5 and c["direction_limit_offset"] == 1.0
+        np.testing.assert_allclose(c["post_center_range"], [0, -40, -2.2, 70.4, 40, 0.8], rtol=1e-6)
+        with torch.no_grad():
+            got = net(ex)
+        assert eng.stats["fused_calls"] == 1 and eng.stats["original_calls"] == 0 and eng.stats["adoptions"] == 1
+        assert isinstance(got, list) and len(got) == 2
+
+        def same(a, b):
+            for g, w in zip(a, b):
+                assert set(g) == set(w) and g["metadata"] == w["metadata"]
+                assert g["box3d_lidar"].dtype == w["box3d_lidar"].dtype == torch.float32 and g["label_preds"].dtype == w["label_preds"].dtype
+                assert g["scores"].shape == w["scores"].shape
+                np.testing.assert_allclose(g["scores"].numpy(), w["scores"].numpy(), rtol=1e-4, atol=1e-5)
+                np.testing.assert_allclose(g["box3d_lidar"].numpy(), w["box3d_lidar"].numpy(), rtol=1e-4, atol=1e-4)
+                np.testing.assert_array_equal(g["label_preds"].numpy(), w["label_preds"].numpy())
+        same(got, want)
+        # a checkpoint loaded AFTER acceleration is followed (evaluate() restores after build_network, train.py:476-480)
+        sd = {k: v.clone() for k, v in net.state_dict().items()}
+        sd["rpn.conv_cls.bias"] = sd["rpn.conv_cls.bias"] + 0.4
+        net.load_state_dict(sd)
+        with torch.no_grad():
+            want2 = net._second_amd_original_forward(ex)
+            got2 = net(ex)
+        assert eng.stats["adoptions"] == 2 and sum(w["scores"].shape[0] for w in want2) != sum(w["scores"].shape[0] for w in want)
+        same(got2, want2)
+        # training mode and DataParallel-padded examples keep the reference's own forward
+        assert not eng.accepts(dict(ex, num_points=ex["num_points"].view(1, -1)))
+        assert not eng.accepts(dict(ex, anchors_mask=torch.ones(2, ex["anchors"].shape[1], dtype=torch.bool)))
+        net.train()
+        assert not eng.accepts(ex)
+        net.eval()
+
+
+@pytest.mark.parametrize("rel, want", [
+    ("nuscenes/all.pp.largea.config", dict(middle="PointPillarsScatter", vfe="PillarFeatureNet", vfe_filters=[64], downsample_factor=8,
+                                           num_anchor_per_loc=12, num_class=10, use_rotate_nms=False, max_points_per_voxel=60)),
+    ("nuscenes/all.fhd.config", dict(middle="SpMiddleFHD", downsample_factor=16, num_anchor_per_loc=20, num_class=10,
+                                     use_rotate_nms=False, max_points_per_voxel=1)),
+])
+def test_model_config_of_the_other_benchmark_networks(ref, rel, want):
+    """dropin.model_config on BASELINE configs 4 / 5 as the reference builds them, and the adopted detector takes their state dict."""
+    import oracle_backend
+    from google.protobuf import text_format
+    from second.protos import pipeline_pb2
+    from second_amd import dropin
+    train, _ = ref
+    cfg = pipeline_pb2.TrainEvalPipelineConfig()
+    text_format.Merge(open(os.path.join(REF, "second/configs", rel)).read(), cfg)
+    with oracle_backend.installed():
+        net = train.build_network(cfg.model.second).eval()
+        c = dropin.model_config(net)
+        for k, v in want.items():
+            assert c[k] == v, (k, c[k], v)
+        eng = dropin.FusedVoxelNet(net)
+        det = eng.refresh()
+        assert det.feature_map_size == ([1, 50, 50] if "pp" in rel else [1, 124, 124])
+        for k, v in det.state_dict().items():
+            if k in net.state_dict() and v.is_floating_point():
+                assert torch.equal(v, net.state_dict()[k].float()), k
+    # a network outside the fused path says why
+    net._multiclass_nms = True
+    with pytest.raises(dropin.NotAccelerable, match="multiclass_nms"):
+        dropin.model_config(net)
+    from second_amd import compat
+    assert compat.accelerate_model(net, strict=False) is net and getattr(net, "_second_amd_engine", None) is None

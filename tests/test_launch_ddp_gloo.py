@@ -188,13 +188,17 @@ def _eval_body(rank, world, port, model_dir, q):
             evaluated.append(len(detections))
             return {"results": {"official": f"{len(detections)} frames"}, "detail": {}}
         ds.evaluation = evaluation
-        return ds
+        # the reference's own wrapper: ``dataset`` is a read-only property there (input_reader_builder.py:44-46)
+        return input_reader_builder.DatasetWrapper(ds)
     input_reader_builder.build = build
     torch.manual_seed(7)                                      # no checkpoint in model_dir: every rank builds the same network
     os.makedirs(model_dir, exist_ok=True)
     with oracle_backend.installed():
-        proxy = launch.run_evaluate(REF, cfg_path, model_dir, backend="gloo", device=torch.device("cpu"), accelerate=False)
+        proxy = launch.run_evaluate(REF, cfg_path, model_dir, backend="gloo", device=torch.device("cpu"), accelerate=True)
     dets = proxy.last_detections
+    eng = proxy.net._second_amd_engine              # net(example) was served by the fused engine (dynamic-shape mode on the CPU)
+    assert eng.stats["fused_calls"] > 0
+    assert eng.stats["original_calls"] == 0
     summary = [(int(d["metadata"]["image_idx"]), d["box3d_lidar"].float().numpy().round(4).tolist(),
                 d["scores"].float().numpy().round(5).tolist()) for d in dets]
     q.put((rank, summary, evaluated))
