@@ -140,6 +140,22 @@ struct Conv2dParams {
     int stagger;  // profiling builds (-DSEC_CONV_TIMELINE): start delay in clocks per resident-slot index
 };
 
+// Live share (of 256) up to which a conv / the fused tail follows its live-tile list; above it every tile is taken in the plain order
+// (computing a background tile is always correct).  SEC_RPN_LIST_MAX_LIVE=<percent> overrides (read once, before the first launch).
+__device__ int g_list_max_live_q8 = 192;
+
+static void apply_list_threshold_env() {
+    static bool done = false;
+    if (done) return;
+    done = true;
+    const char *e = getenv("SEC_RPN_LIST_MAX_LIVE");
+    if (!e || !*e) return;
+    int q8 = atoi(e) * 256 / 100;
+    if (q8 < 0) q8 = 0;
+    if (q8 > 256) q8 = 256;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_list_max_live_q8), &q8, sizeof(int));
+}
+
 #ifdef SEC_CONV_TIMELINE
 __device__ long long *g_timeline2 = nullptr;
 __device__ int g_cu_resident[8 * 4096];     // profiling: workgroups currently resident per (XCC, HW_ID cu/sh/se)
@@ -550,7 +566,7 @@ __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(con
         // A scene whose sites reach (almost) every tile gains nothing from the lists and would pay their dependent lookups in every
         // workgroup's prologue (all tiles live: 480 instead of 427 us for the six convs + tail): above three quarters live, every
         // tile is convolved in the plain order -- computing a background tile is always correct.
-        if (tile_order && n_live * 4 <= ntile * 3) {
+        if (tile_order && n_live * 256 <= ntile * g_list_max_live_q8) {
             listed = true;
             const int tpf = tiles_y * tiles_x;
             const int per_live = (n_live + 7) >> 3;
@@ -1087,7 +1103,7 @@ __global__ __launch_bounds__(256, 3) void k_conv1x1_chain(const T *__restrict__ 
         for (int f = 0; f < batch; ++f) n_live += live_counts[f];
         // above three quarters live: every tile in the plain order (k_conv2d_halo_reg) -- unless x holds its live tiles ONLY (relu1 bit 1,
         // SEC_CHAIN_X_LIVE_ONLY: a lazy producer left the others unwritten; the lists name exactly the tiles that exist)
-        const bool lists = (relu1 & 2) != 0 || n_live * 4 <= ntile * 3;
+        const bool lists = (relu1 & 2) != 0 || n_live * 256 <= ntile * g_list_max_live_q8;
         const int per_live = (n_live + 7) >> 3;
         int item;
         bool is_live = false;
@@ -1553,6 +1569,7 @@ static int conv2d_tiles_impl(const void *x, int batch, int h, int w, const void 
                              const unsigned short *nbr_masks, const void *background_in, void *y, int dtype, void *stream) {
     if (!x || !packed_weight || !y || batch <= 0 || h <= 0 || w <= 0 || (tile_order && !live_counts)) return SEC_E_INVALID;
     if (cout % 128 || (dtype != SEC_BF16 && dtype != SEC_F16)) return SEC_E_UNSUPPORTED;
+    apply_list_threshold_env();
     Conv2dParams p;
     p.batch = batch; p.h = h; p.w = w; p.cin = 128; p.cout = cout; p.ksize = 3; p.stride = 1; p.pad = 1;
     p.relu = relu & 1; p.zskip = 0; p.stagger = 0;
@@ -1626,6 +1643,7 @@ SEC_API int sec_conv2d_nhwc_gather(const void *features, long long feature_rows,
     if (tile_order && !live_counts) return SEC_E_INVALID;       // background == NULL with lists: the other tiles are left unwritten (lazy consumers)
     if (cout % 128 || (dtype != SEC_BF16 && dtype != SEC_F16) || feature_rows * 128 >= (1ll << 31) ||
         (long long)h * w * 8 >= (1ll << 31)) return SEC_E_UNSUPPORTED;
+    apply_list_threshold_env();
     Conv2dParams p;
     p.batch = batch; p.h = h; p.w = w; p.cin = 128; p.cout = cout; p.ksize = 3; p.stride = 1; p.pad = 1;
     p.relu = relu & 1; p.zskip = 0; p.stagger = 0;

@@ -37,8 +37,15 @@ def _raycast(rng, elev_deg, azim_deg, sensor_z, ground_z, boxes, origin_xy=(0.0,
 
 
 def syn_kitti_cloud(seed, num_points=17000, num_voxels=16000, point_cloud_range=CAR_FHD_RANGE,
-                    voxel_size=CAR_FHD_VOXEL):
-    """[num_points, 4] float32 (x, y, z, intensity) with exactly num_voxels occupied car.fhd voxels."""
+                    voxel_size=CAR_FHD_VOXEL, scene="open"):
+    """[num_points, 4] float32 (x, y, z, intensity) with exactly num_voxels occupied car.fhd voxels.
+
+    ``scene="open"`` (the bench's workload): flat ground and 40 boxes -- the returns sit on the near ground rings and
+    on the boxes, 4-7 % of the 200 x 176 BEV cells of the RPN input end up occupied.
+    ``scene="dense"``: the returns of :func:`syn_nusc_cloud`'s "urban" scene (ten sweeps from a moving, pitching carrier over
+    rough ground: returns all over the range instead of on a few near rings) cropped to the car.fhd range and thinned at random to the same
+    16 000 voxels / 17 000 points: 14-20 % of the BEV cells occupied (the robustness scene of bench.py's
+    ``rpn_background_tiles``)."""
     rng = np.random.default_rng(seed)
     n_box = 40
     cx, cy = rng.uniform(5, 60, n_box), rng.uniform(-30, 30, n_box)
@@ -46,8 +53,12 @@ def syn_kitti_cloud(seed, num_points=17000, num_voxels=16000, point_cloud_range=
     ground = -1.73
     boxes = [(np.array([cx[i] - sx[i] / 2, cy[i] - sy[i] / 2, ground]),
               np.array([cx[i] + sx[i] / 2, cy[i] + sy[i] / 2, ground + sz[i]])) for i in range(n_box)]
-    pts = _raycast(rng, np.linspace(-24.8, 2.0, 64), np.arange(-40.5, 40.5, 0.16), 0.0, ground, boxes)
-    pts = pts + rng.normal(0, 0.01, pts.shape)
+    dense = scene == "dense"
+    if dense:
+        pts = syn_nusc_cloud(seed, num_points=10 ** 7, point_cloud_range=point_cloud_range, scene="urban")[:, :3].astype(np.float64)
+    else:
+        pts = _raycast(rng, np.linspace(-24.8, 2.0, 64), np.arange(-40.5, 40.5, 0.16), 0.0, ground, boxes)
+        pts = pts + rng.normal(0, 0.01, pts.shape)
     lo, hi = np.array(point_cloud_range[:3]), np.array(point_cloud_range[3:])
     pts = pts[((pts >= lo + 1e-3) & (pts < hi - 1e-3)).all(1)].astype(np.float32)
     vs = np.array(voxel_size, np.float32)
@@ -202,7 +213,9 @@ def sharpen_heads(det, cls_preds, box_preds):
         p = next(det.rpn.parameters())
         cin = det.rpn.blocks[0][1].in_channels
         zero = det.rpn(torch.zeros(1, cin, 24, 24, device=p.device, dtype=p.dtype))["cls_preds"]   # the map of an empty scene
-        c_empty = zero[0, :, 12, 12].float()                              # interior value per (anchor, class) channel
+        if zero.shape[2] < 24:            # a multi-block RPN downsamples: a larger empty map, value at its centre
+            zero = det.rpn(torch.zeros(1, cin, 192, 192, device=p.device, dtype=p.dtype))["cls_preds"]
+        c_empty = zero[0, :, zero.shape[2] // 2, zero.shape[3] // 2].float()   # interior value per (anchor, class) channel
         cls = torch.as_tensor(cls_preds).float().to(p.device)
         d = cls[0] - c_empty.view(c_empty.shape[0], 1, 1, -1)
         a = 14.0 / float(d.max())

@@ -1,0 +1,159 @@
+"""A network OBJECT shaped like the one the reference's ``build_network`` returns, for machines without /root/reference.
+
+The GPU box has no reference checkout, so the `-m gpu` tests and ``bench.py``'s ``dropin_fused`` leg cannot call
+``second.pytorch.train.build_network``.  This file assembles the same object through the public ``spconv`` / torch API the way
+the reference's constructors do -- it restates the *construction recipe*, no arithmetic:
+
+  * layer classes made by a ``change_default_args``-style wrapper that subclasses ``spconv.SubMConv3d`` / ``SparseConv3d`` /
+    ``BatchNorm1d`` and injects defaults after inspecting the base ``__init__`` (torchplus/tools.py:32-45);
+  * ``SpMiddleFHD``: one ``spconv.SparseSequential`` of 14 x (conv, BatchNorm1d(eps 1e-3, momentum 0.01), ReLU) with ``indice_key``
+    reuse, positional kernel / stride arguments, ``padding=[0, 1, 1]``, the (3,1,1)/(2,1,1) last layer, and the forward
+    ``coors.int() -> SparseConvTensor -> sequential -> .dense() -> view(N, C * D, H, W)`` (middle.py:111-210);
+  * ``VoxelNet``: the attribute names ``predict`` reads (voxelnet.py:100-171: ``_num_class``, ``_use_rotate_nms``,
+    ``_nms_score_thresholds`` ..., ``_box_coder``, ``target_assigner``, ``voxel_generator``), ``network_forward(voxels, num_points,
+    coors, batch_size)`` and ``forward(example)`` with the reference's signatures (voxelnet.py:314-375).
+
+tests/test_dropin_reference.py (build container, where the reference IS present) checks that ``dropin.model_config`` reads the
+same configuration from this object and from the real one, and that their state-dict keys agree -- so what the GPU tests
+accelerate is what a user of the reference would hand to ``compat.accelerate_model``.
+"""
+import inspect
+import types
+
+import numpy as np
+import torch
+from torch import nn
+
+
+def with_defaults(**defaults):
+    """Subclass factory with the semantics the reference relies on: keyword defaults are injected unless the caller passed the
+    argument by keyword or by position -- which requires every default to be a NAMED positional-or-keyword parameter of the base
+    class's __init__ (KeyError otherwise, as upstream)."""
+    def wrap(base):
+        params = [n for n, p in inspect.signature(base.__init__).parameters.items() if p.kind is p.POSITIONAL_OR_KEYWORD]
+        position = {n: i for i, n in enumerate(params)}
+
+        class WithDefaults(base):
+            def __init__(self, *args, **kw):
+                for key, val in defaults.items():
+                    if key not in kw and position[key] > len(args):
+                        kw[key] = val
+                super().__init__(*args, **kw)
+        return WithDefaults
+    return wrap
+
+
+def build_middle(output_shape, num_input_features=4):
+    import spconv
+    BatchNorm1d = with_defaults(eps=1e-3, momentum=0.01)(nn.BatchNorm1d)
+    SpConv3d = with_defaults(bias=False)(spconv.SparseConv3d)
+    SubMConv3d = with_defaults(bias=False)(spconv.SubMConv3d)
+
+    class SpMiddleFHD(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.name = "SpMiddleFHD"
+            self.sparse_shape = np.array(output_shape[1:4]) + [1, 0, 0]
+            layers = []
+
+            def add(conv, c):
+                layers.extend([conv, BatchNorm1d(c), nn.ReLU()])
+            add(SubMConv3d(num_input_features, 16, 3, indice_key="subm0"), 16)
+            add(SubMConv3d(16, 16, 3, indice_key="subm0"), 16)
+            add(SpConv3d(16, 32, 3, 2, padding=1), 32)
+            add(SubMConv3d(32, 32, 3, indice_key="subm1"), 32)
+            add(SubMConv3d(32, 32, 3, indice_key="subm1"), 32)
+            add(SpConv3d(32, 64, 3, 2, padding=1), 64)
+            for _ in range(3):
+                add(SubMConv3d(64, 64, 3, indice_key="subm2"), 64)
+            add(SpConv3d(64, 64, 3, 2, padding=[0, 1, 1]), 64)
+            for _ in range(3):
+                add(SubMConv3d(64, 64, 3, indice_key="subm3"), 64)
+            add(SpConv3d(64, 64, (3, 1, 1), (2, 1, 1)), 64)
+            self.middle_conv = spconv.SparseSequential(*layers)
+
+        def forward(self, voxel_features, coors, batch_size):
+            coors = coors.int()
+            ret = spconv.SparseConvTensor(voxel_features, coors, self.sparse_shape, batch_size)
+            ret = self.middle_conv(ret)
+            ret = ret.dense()
+            n, c, d, h, w = ret.shape
+            return ret.view(n, c * d, h, w)
+    return SpMiddleFHD()
+
+
+def build_voxelnet(cfg):
+    """``cfg``: one of second_amd.models' configuration dicts (CAR_FHD, ALL_PP_LARGEA, ALL_FHD_NUSC)."""
+    from second_amd import models as M
+
+    class SimpleVoxel(M.SimpleVoxel):
+        pass
+
+    class VoxelNet(M.SecondDetector):
+        def __init__(self):
+            super().__init__(cfg)
+            self.name = "voxelnet"
+            gs = self.grid_size
+            if not self.pillars:
+                self.voxel_feature_extractor = SimpleVoxel(cfg["num_point_features"])
+                self.voxel_feature_extractor.name = "SimpleVoxel"
+                self.middle_feature_extractor = build_middle([1] + gs[::-1].tolist() + [64], cfg["middle_in"])
+            r, rpn = cfg["rpn"], self.rpn
+            rpn._layer_strides, rpn._num_filters, rpn._layer_nums = list(r["layer_strides"]), list(r["num_filters"]), list(r["layer_nums"])
+            rpn._upsample_strides, rpn._num_upsample_filters = [float(u) for u in r["upsample_strides"]], list(r["num_upsample_filters"])
+            rpn._num_input_features, rpn._use_norm, rpn._use_groupnorm = r["num_input_features"], True, False
+            a = M.anchors_per_location(cfg)
+            coder = types.SimpleNamespace(code_size=7, vec_encode=False, linear_dim=False)
+            self.target_assigner = types.SimpleNamespace(box_coder=coder, num_anchors_per_location=a)
+            self._box_coder = coder
+            nc = cfg["num_class"]
+            self._num_class, self._use_rotate_nms, self._multiclass_nms = nc, cfg["use_rotate_nms"], False
+            self._nms_score_thresholds = [float(np.float32(cfg["nms_score_threshold"]))] * nc
+            self._nms_pre_max_sizes, self._nms_post_max_sizes = [cfg["nms_pre_max_size"]] * nc, [cfg["nms_post_max_size"]] * nc
+            self._nms_iou_thresholds = [float(np.float32(cfg["nms_iou_threshold"]))] * nc
+            self._use_sigmoid_score, self._encode_background_as_zeros, self._use_direction_classifier = True, True, True
+            self._num_input_features = cfg["num_point_features"]
+            self._post_center_range = [float(np.float32(v)) for v in cfg["post_center_range"]]
+            self._dir_offset = float(np.float32(cfg["direction_offset"]))
+            self._dir_limit_offset = float(np.float32(cfg["direction_limit_offset"]))
+            self._num_direction_bins, self._nms_class_agnostic = cfg["num_direction_bins"], False
+            self.fused_predict = False          # the un-accelerated path of this object: torch formulation of predict
+
+        def network_forward(self, voxels, num_points, coors, batch_size):
+            voxel_features = self.voxel_feature_extractor(voxels, num_points, coors)
+            spatial_features = self.middle_feature_extractor(voxel_features, coors, batch_size)
+            return self.rpn(spatial_features)
+
+        def forward(self, example):
+            voxels, num_points, coors = example["voxels"], example["num_points"], example["coordinates"]
+            batch_anchors = example["anchors"]
+            batch_size_dev = batch_anchors.shape[0]
+            preds_dict = self.network_forward(voxels, num_points, coors, batch_size_dev)
+            box_preds = preds_dict["box_preds"].view(batch_size_dev, -1, 7)
+            assert batch_anchors.shape[1] == box_preds.shape[1]
+            with torch.no_grad():
+                res = self.predict({k: v.float() for k, v in preds_dict.items()}, batch_anchors.view(batch_size_dev, -1, 7).float())
+            meta = example.get("metadata") or [None] * batch_size_dev
+            for r, m in zip(res, meta):
+                r["metadata"] = m
+                r["label_preds"] = r["label_preds"].long()
+            return res
+    return VoxelNet()
+
+
+def example_of(net, clouds, device, dtype=torch.float32, max_voxels=None, metadata=True):
+    """The collated, device-resident example dict of ``merge_second_batch`` + ``example_convert_to_torch`` (preprocess.py:22-55,
+    train.py:38-62) for ``clouds``: voxels in ``dtype``, int32 coordinates with the batch index prepended, int32 point counts,
+    float anchors repeated per frame."""
+    gen = net.voxel_generator
+    vox = [gen.generate(c, max_voxels or gen._max_voxels) for c in clouds]
+    ex = {
+        "voxels": torch.from_numpy(np.concatenate([v["voxels"] for v in vox])).to(device=device, dtype=dtype),
+        "num_points": torch.from_numpy(np.concatenate([v["num_points_per_voxel"] for v in vox]).astype(np.int32)).to(device),
+        "coordinates": torch.from_numpy(np.concatenate([np.concatenate([np.full((len(v["coordinates"]), 1), b, np.int32), v["coordinates"]], 1)
+                                                        for b, v in enumerate(vox)])).to(device),
+        "anchors": net.anchors.unsqueeze(0).expand(len(clouds), -1, -1).contiguous().to(device=device, dtype=dtype),
+    }
+    if metadata:
+        ex["metadata"] = [{"image_idx": 100 + b} for b in range(len(clouds))]
+    return ex

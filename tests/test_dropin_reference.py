@@ -360,3 +360,42 @@ def test_model_config_of_the_other_benchmark_networks(ref, rel, want):
         dropin.model_config(net)
     from second_amd import compat
     assert compat.accelerate_model(net, strict=False) is net and getattr(net, "_second_amd_engine", None) is None
+
+
+@pytest.mark.parametrize("rel, name", [("car.fhd.config", "CAR_FHD"), ("nuscenes/all.pp.largea.config", "ALL_PP_LARGEA"),
+                                       ("nuscenes/all.fhd.config", "ALL_FHD_NUSC")])
+def test_gpu_box_standin_is_shaped_like_the_reference_network(ref, rel, name):
+    """tests/reference_standin.py (what the -m gpu tests and bench.py's dropin_fused leg accelerate, because the GPU box has no
+    reference checkout) against the real build_network result: same sub-module type names, same state-dict keys and shapes,
+    and dropin.model_config reads the SAME configuration from both objects."""
+    import oracle_backend
+    import reference_standin
+    from google.protobuf import text_format
+    from second.protos import pipeline_pb2
+    from second_amd import dropin, models
+    train, _ = ref
+    cfg = pipeline_pb2.TrainEvalPipelineConfig()
+    text_format.Merge(open(os.path.join(REF, "second/configs", rel)).read(), cfg)
+    with oracle_backend.installed():
+        real = train.build_network(cfg.model.second).eval()
+        mcfg = dict(getattr(models, name), max_voxels=int(real.voxel_generator._max_voxels))
+        fake = reference_standin.build_voxelnet(mcfg).eval()
+    for part in ("voxel_feature_extractor", "middle_feature_extractor", "rpn"):
+        assert type(getattr(real, part)).__name__ == type(getattr(fake, part)).__name__
+    rs, fs = real.state_dict(), fake.state_dict()
+    keys = lambda sd: {k: tuple(v.shape) for k, v in sd.items() if k.split(".")[0] in ("voxel_feature_extractor", "middle_feature_extractor", "rpn")}
+    assert keys(rs) == keys(fs)
+    c_real, c_fake = dropin.model_config(real), dropin.model_config(fake)
+    c_real.pop("name"), c_fake.pop("name")
+    for k in c_real:
+        if isinstance(c_real[k], list) and c_real[k] and isinstance(c_real[k][0], float):
+            np.testing.assert_allclose(c_fake[k], c_real[k], rtol=1e-6, err_msg=k)
+        else:
+            assert c_fake[k] == c_real[k], (k, c_fake[k], c_real[k])
+    assert set(c_real) == set(c_fake)
+    # the attributes VoxelNet.predict reads exist on the stand-in under the same names
+    for attr in ("_num_class", "_use_rotate_nms", "_multiclass_nms", "_nms_score_thresholds", "_nms_pre_max_sizes", "_nms_post_max_sizes",
+                 "_nms_iou_thresholds", "_use_sigmoid_score", "_encode_background_as_zeros", "_use_direction_classifier",
+                 "_post_center_range", "_dir_offset", "_num_direction_bins", "_dir_limit_offset", "_box_coder", "target_assigner",
+                 "voxel_generator"):
+        assert hasattr(real, attr) and hasattr(fake, attr), attr

@@ -12,8 +12,6 @@ constructors do (second/pytorch/models/middle.py:119-192, rpn.py:248-286,468-497
 on CUDA tensors in eager (dynamic-shape) mode with the drop-in default rulebook numbering (spconv's CPU first-touch order).
 Checked against oracle/cpu_forward.py (fp32, <= 1e-4) layer by layer and at the dense RPN input, with the inference peephole
 (conv + BN + ReLU fused) ON (what the unmodified reference gets in eval mode) and OFF (three separate modules per layer)."""
-import inspect
-
 import numpy as np
 import pytest
 import torch
@@ -22,60 +20,7 @@ from torch import nn
 pytestmark = pytest.mark.gpu
 
 
-def with_defaults(**defaults):
-    """A subclass factory with the semantics the reference relies on: keyword defaults are injected unless the caller passed the
-    argument by keyword or by position -- which requires every default to be a NAMED positional-or-keyword parameter of the base
-    class's __init__ (KeyError otherwise, as upstream)."""
-    def wrap(base):
-        params = [n for n, p in inspect.signature(base.__init__).parameters.items() if p.kind is p.POSITIONAL_OR_KEYWORD]
-        position = {n: i for i, n in enumerate(params)}
-
-        class WithDefaults(base):
-            def __init__(self, *args, **kw):
-                for key, val in defaults.items():
-                    if key not in kw and position[key] > len(args):
-                        kw[key] = val
-                super().__init__(*args, **kw)
-        return WithDefaults
-    return wrap
-
-
-def build_middle(output_shape, num_input_features=4):
-    import spconv
-    BatchNorm1d = with_defaults(eps=1e-3, momentum=0.01)(nn.BatchNorm1d)
-    SpConv3d = with_defaults(bias=False)(spconv.SparseConv3d)
-    SubMConv3d = with_defaults(bias=False)(spconv.SubMConv3d)
-
-    class Middle(nn.Module):
-        def __init__(self):
-            super().__init__()
-            self.sparse_shape = np.array(output_shape[1:4]) + [1, 0, 0]
-            layers = []
-
-            def add(conv, c):
-                layers.extend([conv, BatchNorm1d(c), nn.ReLU()])
-            add(SubMConv3d(num_input_features, 16, 3, indice_key="subm0"), 16)
-            add(SubMConv3d(16, 16, 3, indice_key="subm0"), 16)
-            add(SpConv3d(16, 32, 3, 2, padding=1), 32)
-            add(SubMConv3d(32, 32, 3, indice_key="subm1"), 32)
-            add(SubMConv3d(32, 32, 3, indice_key="subm1"), 32)
-            add(SpConv3d(32, 64, 3, 2, padding=1), 64)
-            for _ in range(3):
-                add(SubMConv3d(64, 64, 3, indice_key="subm2"), 64)
-            add(SpConv3d(64, 64, 3, 2, padding=[0, 1, 1]), 64)
-            for _ in range(3):
-                add(SubMConv3d(64, 64, 3, indice_key="subm3"), 64)
-            add(SpConv3d(64, 64, (3, 1, 1), (2, 1, 1)), 64)
-            self.middle_conv = spconv.SparseSequential(*layers)
-
-        def forward(self, voxel_features, coors, batch_size):
-            coors = coors.int()
-            ret = spconv.SparseConvTensor(voxel_features, coors, self.sparse_shape, batch_size)
-            ret = self.middle_conv(ret)
-            ret = ret.dense()
-            n, c, d, h, w = ret.shape
-            return ret.view(n, c * d, h, w)
-    return Middle()
+from reference_standin import build_middle, with_defaults  # noqa: E402,F401  (the construction recipe, shared with bench.py)
 
 
 @pytest.fixture(scope="module")
