@@ -501,8 +501,7 @@ def build_detector(device, dtype, calib_cloud=None):
                 m.running_var.copy_(torch.empty_like(m.running_var).uniform_(0.5, 1.5, generator=g))
         det = det.eval().to(device)
     cpu_state = {k: v.detach().cpu().clone() for k, v in det.state_dict().items()}
-    if dtype != torch.float32:
-        det.prepare_inference(dtype)
+    det.prepare_inference(dtype)      # (fp32 too: BatchNorms folded, the RPN's 3x3 convs on sec_conv2d_nhwc_x3)
     return det, cpu_state
 
 
@@ -1143,7 +1142,7 @@ def main():
                 sp_ = det.middle_feature_extractor(v_["mean"], v_["coordinates"], WL["batch"], channels_last=True, bev_sparse=True)
                 if hasattr(sp_, "site_map"):
                     bg_tiles["bev_cells_occupied"] = [round(float(x), 4) for x in (sp_.site_map() > 0).any(dim=1).float().mean(dim=(1, 2)).cpu()]
-            if det.rpn.skip_background and det.rpn.last_live_counts is not None:
+            if det.rpn.skip_background and det.rpn.last_live_counts is not None and not bg_tiles.get("live_tiles_per_conv"):
                 bg_tiles["live_tiles_per_conv_last_step"] = [int(x) for x in det.rpn.last_live_counts.sum(1).cpu()]
         except Exception as e:  # noqa: BLE001
             bg_tiles["bev_cells_occupied"] = repr(e)[:200]

@@ -394,6 +394,22 @@ int sec_conv2d_nhwc(const void *x, int batch, int h, int w, int cin, const void 
                     const float *bias, int cout, int ksize, int stride, int pad, int relu, void *y,
                     int dtype, void *stream);
 
+/* The same 3x3 / stride 1 / pad 1, 128-input-channel convolution for fp32 networks -- the reference's default precision
+ * (second/pytorch/train.py:232-235, 497-500: float_dtype = torch.float32 unless mixed precision is enabled; rpn.py:468-497) -- on
+ * the bf16 matrix pipe: every fp32 operand travels as TWO bf16 planes, v = hi + lo with hi = bf16(v), lo = bf16(v - hi), and
+ * the product is x_hi w_hi + x_hi w_lo + x_lo w_hi accumulated in fp32 (relative error <= 3 * 2^-18 per product: within the
+ * 1e-4 feature tolerance; MIOpen's fp32 convolution of this layer runs at the fp32 MFMA rate, 4x slower).
+ *   x_hi, x_lo, y_hi, y_lo : [B,H,W,128] / [B,H,W,Cout] bf16 planes (sec_split_f32_bf16x2 makes them, sec_merge_bf16x2_f32 adds
+ *                            them back to fp32); bias + ReLU are applied in fp32 before the result is split;
+ *   packed_weight_hi_lo    : sec_conv2d_pack_weight(bf16(W)) immediately followed by sec_conv2d_pack_weight(bf16(W - bf16(W)))
+ *                            (each 9 * 128 * Cout * 2 bytes) + 16 zero bytes;
+ *   relu                   : flag word as in sec_conv2d_nhwc (bit 1: all-zero input tiles write act(bias)).
+ * n of the split / merge helpers = number of fp32 elements, a multiple of 4. */
+int sec_split_f32_bf16x2(const float *x, long long n, void *hi, void *lo, void *stream);
+int sec_merge_bf16x2_f32(const void *hi, const void *lo, long long n, float *y, void *stream);
+int sec_conv2d_nhwc_x3(const void *x_hi, const void *x_lo, int batch, int h, int w, const void *packed_weight_hi_lo,
+                       const float *bias, int cout, int relu, void *y_hi, void *y_lo, void *stream);
+
 /* Fused tail of the RPN at inference: y = W2 * act(W1 * x + bias1) + bias2 over `pixels` channels-last pixels with
  * 128 input and 128 intermediate channels -- the 1x1/stride-1 ConvTranspose2d deblock with folded BatchNorm + ReLU
  * (second/pytorch/models/rpn.py:275-285) followed by the merged conv_box / conv_cls / conv_dir_cls 1x1 heads

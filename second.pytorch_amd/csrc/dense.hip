@@ -354,7 +354,15 @@ template <int CH, int HW_, bool COLKEY> __device__ __forceinline__ int halo_key(
 // the rows (input channel z * 64 + c: the weights are packed in that order), sites without a row read zeros through the buffer
 // bounds check, and a tile whose 2 x 180 map entries are all empty skips the DMA, the LDS sweep and the MFMA loop: what the
 // zero fill + scatter + zero-tile test of the dense form computed, without the 72 MB image.
-template <typename T, int CIN, int TH, int ROLL = 0, bool GATHER = false, int NSPLIT = 1>
+// X3 (sec_conv2d_nhwc_x3; fp32 networks, the reference's default precision, rpn.py:468-497 under train.py:232-235): the operands
+// are fp32 values carried as TWO bf16 planes each, v = hi + lo with hi = bf16(v), lo = bf16(v - hi) (16 significant bits), and the
+// product is x_hi w_hi + x_hi w_lo + x_lo w_hi accumulated in fp32 -- the dropped x_lo w_lo term and the two representation errors
+// are each <= 2^-17 relative.  Three passes of the SAME loop over the same accumulators: (x_hi, w_hi), (x_hi, w_lo), then the
+// halo is replaced by x_lo's and (x_lo, w_hi) runs; the LDS footprint and the three workgroups per CU stay.  The epilogue splits
+// the fp32 result (bias + ReLU applied in fp32) into the two planes of the next layer's input.  18.4x the fp32 MFMA rate per
+// product / 3 passes: the matrix pipe's fp32 instruction (v_mfma_f32_32x32x2_f32, 256 FLOP/clk/CU) is what MIOpen's fp32
+// convolution runs at ~80 % of (0.65 ms per layer at batch 8).
+template <typename T, int CIN, int TH, int ROLL = 0, bool GATHER = false, int NSPLIT = 1, bool X3 = false>
 __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(const T *__restrict__ x, const T *__restrict__ wpk,
                                                             const float *__restrict__ bias, T *__restrict__ y,
                                                             Conv2dParams p, int tiles_y, int tiles_x, int per_xcd,
@@ -363,8 +371,11 @@ __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(con
                                                             const int *__restrict__ live_counts = nullptr,
                                                             const T *__restrict__ background = nullptr,
                                                             const unsigned short *__restrict__ nbr_masks = nullptr,
-                                                            const T *__restrict__ bg_in = nullptr) {
+                                                            const T *__restrict__ bg_in = nullptr,
+                                                            const T *__restrict__ x_lo = nullptr, T *__restrict__ y_lo = nullptr) {
     static_assert(!GATHER || (ROLL == 2 && CIN == 128), "gather prologue: the shared-row loop on two 64-channel planes");
+    static_assert(!X3 || (ROLL == 2 && CIN == 128 && TH == 8 && !GATHER && NSPLIT == 1 && std::is_same<T, __hip_bfloat16>::value),
+                  "three-pass split-fp32 form: the shared-row bf16 loop");
     constexpr int TW = 16, HW_ = TW + 2, HPIX = (TH + 2) * (TW + 2);
     // NSPLIT == 2: 64 output channels per workgroup -- the waves split the tile's pixels two ways and the channels two ways (the
     // 64 -> 64 layers of the PointPillars RPN); NSPLIT == 1: a wave owns all pixels for 32 of 128 channels
@@ -411,12 +422,12 @@ __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(con
     // part.  Here a piece's four halo pixels advance by 16 per step (hx += 16, wrapping at 18 into the next row), the image is a
     // buffer resource whose bounds check zero-fills the rows above and below it, and only the left / right border columns need
     // a select: ~14 VALU per piece, no branches.
-    auto issue_halo2 = [&](int tile) {
+    auto issue_halo2 = [&](int tile, const T *xsrc) {
         const int b = tile / (tiles_y * tiles_x);
         const int trem = tile - b * tiles_y * tiles_x;
         const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
         const unsigned img_bytes = (unsigned)p.h * (unsigned)p.w * (CIN * 2u);
-        const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(x) + (size_t)b * p.h * p.w * CIN, 0, (int)img_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(xsrc) + (size_t)b * p.h * p.w * CIN, 0, (int)img_bytes, 0x00020000);
         const int wvs = __builtin_amdgcn_readfirstlane(wv);
         const unsigned slot = lane & 15;
         const unsigned row_pitch = (unsigned)p.w * (CIN * 2u);
@@ -684,7 +695,7 @@ __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(con
         }
     } else if constexpr (ROLL >= 2) {
         if (nbr_masks) issue_halo2_lazy(tile, nmask);
-        else issue_halo2(tile);
+        else issue_halo2(tile, x);
     } else issue_halo(tile);
 #ifdef SEC_CONV_TIMELINE
     long long tl_issue = 0, tl_eb1 = 0, tl_eb2 = 0;
@@ -700,7 +711,7 @@ __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(con
         // ROLL == 2: B fragments by buffer loads -- one lane-offset VGPR + a SCALAR chunk offset per fragment (24 global pointers
         // per dx cost 48 VGPRs and spilled)
         typedef unsigned int u32x4b __attribute__((ext_vector_type(4)));
-        const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(wpk), 0, (int)((9 * cin8 + 1) * p.cout * 16), 0x00020000);
+        const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(wpk), 0, (int)(((X3 ? 18 : 9) * cin8 + 1) * p.cout * 16), 0x00020000);
         const unsigned wvoff = (unsigned)(hh * p.cout + n0 + r) * 16u;
         const unsigned wstep = (unsigned)p.cout * 16u;            // bytes per chunk row of the packed weights
         auto ld_b = [&](unsigned chunk) {
@@ -758,29 +769,45 @@ __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(con
             };
             auto frag_off = [](int j) { return (j % 3) * 48 + (j / 3) * 2; };
             if (live) {
-                {
-                    const unsigned key0 = (unsigned)(hh ^ (colr & 15)) << 4;
-#pragma unroll
-                    for (int h = 0; h < 3; ++h) load_f2(base0, key0, 0, 2 * h, fr[0]);
-                }
+                constexpr int NPASS = X3 ? 3 : 1;
 #pragma unroll 1
-                for (int dx = 0; dx < 3; ++dx) {
-                    const int dxn = dx < 2 ? dx + 1 : 2;
-                    const unsigned bdx = base0 + dx * (CH * 16), bdn = base0 + dxn * (CH * 16);
-                    const unsigned key = (unsigned)(hh ^ ((colr + dx) & 15)) << 4, keyn = (unsigned)(hh ^ ((colr + dxn) & 15)) << 4;
-                    const unsigned ct = dx * 16, cn = dxn * 16;
+                for (int pass = 0; pass < NPASS; ++pass) {
+                    // X3: pass 1 = the same halo (x_hi) against w_lo (the second half of the packed weights); pass 2 = x_lo's halo
+                    // against w_hi.  The B ring is re-primed per pass (its tail prefetched fragments of the pass that just ended).
+                    const unsigned wp = (X3 && pass == 1) ? 9u * cin8 : 0u;
+                    if (X3 && pass > 0) {
+                        if (pass == 2) {
+                            __syncthreads();                    // every wave is done reading x_hi's halo
+                            issue_halo2(tile, x_lo);
+                        }
 #pragma unroll
-                    for (int ks = 0; ks < 8; ++ks) {
+                        for (int f = 0; f < RD - 1; ++f) br[f] = ld_b(wp + (f % 3) * 48 + (f / 3) * 2);
+                        if (pass == 2) __syncthreads();         // x_lo's halo landed
+                    }
+                    {
+                        const unsigned key0 = (unsigned)(hh ^ (colr & 15)) << 4;
 #pragma unroll
-                        for (int dy = 0; dy < 3; ++dy) {
-                            const int j = ks * 3 + dy;
-                            br[(j + RD - 1) % RD] = j + RD - 1 < 24 ? ld_b(ct + frag_off(j + RD - 1)) : ld_b(cn + frag_off(j + RD - 1 - 24));
-                            // a third of the next k-step's six fragments per kernel row
-                            if (ks + 1 < 8) load_f2(bdx, key, (ks + 1) * 2, 2 * dy, fr[(ks + 1) & 1]);
-                            else load_f2(bdn, keyn, 0, 2 * dy, fr[0]);
+                        for (int h = 0; h < 3; ++h) load_f2(base0, key0, 0, 2 * h, fr[0]);
+                    }
+#pragma unroll 1
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const int dxn = dx < 2 ? dx + 1 : 2;
+                        const unsigned bdx = base0 + dx * (CH * 16), bdn = base0 + dxn * (CH * 16);
+                        const unsigned key = (unsigned)(hh ^ ((colr + dx) & 15)) << 4, keyn = (unsigned)(hh ^ ((colr + dxn) & 15)) << 4;
+                        const unsigned ct = wp + dx * 16, cn = wp + dxn * 16;
 #pragma unroll
-                            for (int mt = 0; mt < MT; ++mt) acc[mt] = MfmaD<T>::run(br[j % RD], fr[ks & 1][mt + dy], acc[mt]);
-                            __builtin_amdgcn_sched_barrier(0);
+                        for (int ks = 0; ks < 8; ++ks) {
+#pragma unroll
+                            for (int dy = 0; dy < 3; ++dy) {
+                                const int j = ks * 3 + dy;
+                                br[(j + RD - 1) % RD] = j + RD - 1 < 24 ? ld_b(ct + frag_off(j + RD - 1)) : ld_b(cn + frag_off(j + RD - 1 - 24));
+                                // a third of the next k-step's six fragments per kernel row
+                                if (ks + 1 < 8) load_f2(bdx, key, (ks + 1) * 2, 2 * dy, fr[(ks + 1) & 1]);
+                                else load_f2(bdn, keyn, 0, 2 * dy, fr[0]);
+#pragma unroll
+                                for (int mt = 0; mt < MT; ++mt) acc[mt] = MfmaD<T>::run(br[j % RD], fr[ks & 1][mt + dy], acc[mt]);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
                         }
                     }
                 }
@@ -872,8 +899,9 @@ __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(con
             // value, ds_bpermute + selects for the half-wave exchange).  Here: add, max, one convert per PAIR, and
             // v_permlane32_swap, which IS the exchange: after swap(pk[2pr], pk[2pr+1]) the low half-wave holds both halves of
             // chunk 2pr and the high half-wave both halves of chunk 2pr+1 -- no selects.  ~200 instructions.
-            auto put_tile = [&](auto relu_tag) {
+            auto put_tile = [&](auto relu_tag, auto lo_tag) {
                 constexpr bool RELU = decltype(relu_tag)::value;
+                constexpr bool LOW = decltype(lo_tag)::value;     // X3: the residual plane v - bf16(v) instead of bf16(v)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     unsigned lo[4], hi[4];                  // channels 8g+4hh+(0,1) and +(2,3) of this lane's pixel
@@ -886,6 +914,10 @@ __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(con
                         }
                         lo[g] = pack2<T>(v[0], v[1]);
                         hi[g] = pack2<T>(v[2], v[3]);
+                        if constexpr (LOW) {
+                            lo[g] = pack2<T>(v[0] - __uint_as_float(lo[g] << 16), v[1] - __uint_as_float(lo[g] & 0xffff0000u));
+                            hi[g] = pack2<T>(v[2] - __uint_as_float(hi[g] << 16), v[3] - __uint_as_float(hi[g] & 0xffff0000u));
+                        }
                     }
                     const int q = ROLL >= 2 ? (mt + 4 * (r >> 4)) * 16 + (r & 15) : mt * 32 + r;   // tile pixel of (m-tile, lane)
 #pragma unroll
@@ -896,8 +928,8 @@ __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(con
                     }
                 }
             };
-            if (p.relu) put_tile(std::true_type{});
-            else put_tile(std::false_type{});
+            if (p.relu) put_tile(std::true_type{}, std::false_type{});
+            else put_tile(std::false_type{}, std::false_type{});
             __syncthreads();
 #ifdef SEC_CONV_TIMELINE
             if (tl) tl_eb2 = clock64();
@@ -913,6 +945,20 @@ __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(con
 #endif
                 // (non-temporal stores here: 76.0 vs 76.5 us, within noise)
                 if (oy < p.h && ox < p.w) y4[(((size_t)b * p.h + oy) * p.w + ox) * (p.cout / 8) + blockIdx.y * 16 + ch] = v;
+            }
+            if constexpr (X3) {                             // the residual plane, through the same LDS tile
+                __syncthreads();
+                if (p.relu) put_tile(std::true_type{}, std::true_type{});
+                else put_tile(std::false_type{}, std::true_type{});
+                __syncthreads();
+                uint4 *yl4 = reinterpret_cast<uint4 *>(y_lo);
+#pragma unroll
+                for (int ty_ = 0; ty_ < TH; ++ty_) {
+                    const int px = tid >> 4, ch = tid & 15;
+                    const int oy = y0 + ty_, ox = x0 + px;
+                    const uint4 v = ot[(ty_ * 16 + px) * PITCH + ch];
+                    if (oy < p.h && ox < p.w) yl4[(((size_t)b * p.h + oy) * p.w + ox) * (p.cout / 8) + blockIdx.y * 16 + ch] = v;
+                }
             }
         } else {
 #pragma unroll
@@ -960,17 +1006,18 @@ extern "C" __attribute__((visibility("default"))) int sec__debug_timeline2(long 
 }
 #endif
 
-template <typename T, int CIN, int TH, int ROLL = 0, bool GATHER = false, int NSPLIT = 1>
+template <typename T, int CIN, int TH, int ROLL = 0, bool GATHER = false, int NSPLIT = 1, bool X3 = false>
 static int launch_conv2d_halo_reg(const void *x, const void *wpk, const float *bias, void *y, const Conv2dParams &p, hipStream_t st,
                                   const int *site_map = nullptr, unsigned feat_bytes = 0, const unsigned short *tile_order = nullptr,
                                   const int *live_counts = nullptr, const void *background = nullptr,
-                                  const unsigned short *nbr_masks = nullptr, const void *bg_in = nullptr) {
+                                  const unsigned short *nbr_masks = nullptr, const void *bg_in = nullptr,
+                                  const void *x_lo = nullptr, void *y_lo = nullptr) {
     constexpr size_t lds_tile = (size_t)(TH + 2) * 18 * (CIN / 8) * 16;
     // (padding the dynamic LDS to hold 2 instead of 3 workgroups per CU was measured in round 3: slower in every combination)
     const long lds_pad = 0;
     const size_t lds = lds_tile + (size_t)lds_pad;
     static bool configured = false;
-    auto fn = k_conv2d_halo_reg<T, CIN, TH, ROLL, GATHER, NSPLIT>;
+    auto fn = k_conv2d_halo_reg<T, CIN, TH, ROLL, GATHER, NSPLIT, X3>;
     if (!configured) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         configured = true;
@@ -978,10 +1025,11 @@ static int launch_conv2d_halo_reg(const void *x, const void *wpk, const float *b
     const int ty = div_up(p.h, TH), tx = div_up(p.w, 16);
     const int per_xcd = div_up(p.batch * ty * tx, 8);
     const int gx = per_xcd * 8;
-    if (NSPLIT == 1) set_last_kernel("k_conv2d_halo_reg<%s, %d, %d, %d, %s>", dtype_name<T>(), CIN, TH, ROLL, GATHER ? "true" : "false");
+    if (X3) set_last_kernel("k_conv2d_halo_reg<%s, %d, %d, %d, false, 1, true>", dtype_name<T>(), CIN, TH, ROLL);
+    else if (NSPLIT == 1) set_last_kernel("k_conv2d_halo_reg<%s, %d, %d, %d, %s>", dtype_name<T>(), CIN, TH, ROLL, GATHER ? "true" : "false");
     else set_last_kernel("k_conv2d_halo_reg<%s, %d, %d, %d, %s, %d>", dtype_name<T>(), CIN, TH, ROLL, GATHER ? "true" : "false", NSPLIT);
     hipLaunchKernelGGL(fn, dim3(gx, p.cout / (128 / NSPLIT)), dim3(256), lds, st, (const T *)x, (const T *)wpk, bias, (T *)y, p, ty, tx, per_xcd,
-                       site_map, feat_bytes, tile_order, live_counts, (const T *)background, nbr_masks, (const T *)bg_in);
+                       site_map, feat_bytes, tile_order, live_counts, (const T *)background, nbr_masks, (const T *)bg_in, (const T *)x_lo, (T *)y_lo);
     return check_launch();
 }
 
@@ -1634,6 +1682,56 @@ SEC_API int sec_conv2d_nhwc(const void *x, int batch, int h, int w, int cin, con
     hipStream_t st = (hipStream_t)stream;
     if (dtype == SEC_BF16) return launch_conv2d<__hip_bfloat16>(x, packed_weight, bias, y, p, st);
     return launch_conv2d<__half>(x, packed_weight, bias, y, p, st);
+}
+
+// fp32 <-> two bf16 planes (hi = bf16(v), lo = bf16(v - hi)): the operand form of sec_conv2d_nhwc_x3.  Element-wise, HBM bound.
+__global__ __launch_bounds__(kBlock) void k_split_bf16x2(const float4 *__restrict__ x, long long n4, uint2 *__restrict__ hi, uint2 *__restrict__ lo) {
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (long long)gridDim.x * kBlock) {
+        const float4 v = x[i];
+        const unsigned h0 = pack2<__hip_bfloat16>(v.x, v.y), h1 = pack2<__hip_bfloat16>(v.z, v.w);
+        hi[i] = make_uint2(h0, h1);
+        lo[i] = make_uint2(pack2<__hip_bfloat16>(v.x - __uint_as_float(h0 << 16), v.y - __uint_as_float(h0 & 0xffff0000u)),
+                           pack2<__hip_bfloat16>(v.z - __uint_as_float(h1 << 16), v.w - __uint_as_float(h1 & 0xffff0000u)));
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_merge_bf16x2(const uint2 *__restrict__ hi, const uint2 *__restrict__ lo, long long n4, float4 *__restrict__ y) {
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (long long)gridDim.x * kBlock) {
+        const uint2 h = hi[i], l = lo[i];
+        y[i] = make_float4(__uint_as_float(h.x << 16) + __uint_as_float(l.x << 16), __uint_as_float(h.x & 0xffff0000u) + __uint_as_float(l.x & 0xffff0000u),
+                           __uint_as_float(h.y << 16) + __uint_as_float(l.y << 16), __uint_as_float(h.y & 0xffff0000u) + __uint_as_float(l.y & 0xffff0000u));
+    }
+}
+
+SEC_API int sec_split_f32_bf16x2(const float *x, long long n, void *hi, void *lo, void *stream) {
+    if (n < 0 || n % 4 || (n > 0 && (!x || !hi || !lo))) return SEC_E_INVALID;
+    if (n == 0) return SEC_OK;
+    long long blocks = div_up(n / 4, kBlock);
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(k_split_bf16x2, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, (const float4 *)x, n / 4, (uint2 *)hi, (uint2 *)lo);
+    return check_launch();
+}
+
+SEC_API int sec_merge_bf16x2_f32(const void *hi, const void *lo, long long n, float *y, void *stream) {
+    if (n < 0 || n % 4 || (n > 0 && (!y || !hi || !lo))) return SEC_E_INVALID;
+    if (n == 0) return SEC_OK;
+    long long blocks = div_up(n / 4, kBlock);
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(k_merge_bf16x2, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, (const uint2 *)hi, (const uint2 *)lo, n / 4, (float4 *)y);
+    return check_launch();
+}
+
+SEC_API int sec_conv2d_nhwc_x3(const void *x_hi, const void *x_lo, int batch, int h, int w, const void *packed_weight_hi_lo, const float *bias,
+                               int cout, int relu, void *y_hi, void *y_lo, void *stream) {
+    if (!x_hi || !x_lo || !packed_weight_hi_lo || !y_hi || !y_lo || batch <= 0 || h <= 0 || w <= 0) return SEC_E_INVALID;
+    if (cout % 128 || (long long)h * w * 256 >= (1ll << 31)) return SEC_E_UNSUPPORTED;
+    Conv2dParams p;
+    p.batch = batch; p.h = h; p.w = w; p.cin = 128; p.cout = cout; p.ksize = 3; p.stride = 1; p.pad = 1;
+    p.relu = relu & 1; p.zskip = (relu >> 1) & 1; p.stagger = 0;
+    p.ho = h; p.wo = w;
+    p.m = (long long)batch * h * w;
+    return launch_conv2d_halo_reg<__hip_bfloat16, 128, 8, 2, false, 1, true>(x_hi, packed_weight_hi_lo, bias, y_hi, p, (hipStream_t)stream, nullptr, 0,
+                                                                              nullptr, nullptr, nullptr, nullptr, nullptr, x_lo, y_lo);
 }
 
 SEC_API int sec_conv2d_nhwc_gather(const void *features, long long feature_rows, const int *site_map, int batch, int h, int w,

@@ -239,8 +239,8 @@ class FusedVoxelNet:
         det.load_state_dict(state, strict=False)
         det = det.to(dev)
         dt = self.run_dtype()
-        if dev.type == "cuda" and dt is not None:
-            det.prepare_inference(dt)
+        if dev.type == "cuda":       # fp32: BatchNorms folded, the RPN's 3x3 convs on sec_conv2d_nhwc_x3 (split-bf16 operands, fp32 accumulation)
+            det.prepare_inference(dt if dt is not None else torch.float32)
         det.eval()
         self._det, self._wkey = det, key
         self._sessions.clear()

@@ -614,6 +614,17 @@ class RPNInference(nn.Module):
             self.head_packed = ops.conv2d_pack_weight(hw64)
             self.head_b64 = torch.cat([hb, torch.zeros(cpad, device=hb.device)]).contiguous()
             self.use_hip = self.head_packed is not None
+        # fp32 networks (the reference's default precision): every 3x3 / s1 / p1 128 -> Cout conv of a single-block RPN on the bf16
+        # matrix pipe with split operands (sec_conv2d_nhwc_x3: v = hi + lo, three passes, fp32 accumulation); the 1x1 deblock and
+        # heads stay torch fp32 convolutions (9 GFLOP against the blocks' 500)
+        self.packed_x3 = None
+        if backend == "hip" and dtype == torch.float32 and single and next(rpn.parameters()).is_cuda:
+            convs = [i for kind, i in self.plan if kind == "c"]
+            if all(tuple(self.ws[i].shape[1:]) == (128, 3, 3) and self.ws[i].shape[0] % 128 == 0 and self.cfgs[i] == ([1, 1], [1, 1])
+                   and self.ups[i] == 1 for i in convs):
+                pk = {i: ops.conv2d_pack_weight_x3(self.ws[i]) for i in convs}
+                if all(v is not None for v in pk.values()):
+                    self.packed_x3 = pk
         # deblock (1x1, stride 1, 128 -> 128) + heads (<= 128 padded channels) run as ONE kernel (sec_conv1x1_chain_nhwc)
         wl = self.ws[-1]
         self.sparse_input = True   # forward()'s input comes from SparseConvTensor.dense(): all-zero halo tiles skip their MFMA loop (bit-identical)
@@ -681,7 +692,35 @@ class RPNInference(nn.Module):
             y = y.permute(0, 3, 1, 2)        # a channels_last [B,co,H*u,W*u] tensor
         return y
 
+    def _forward_x3(self, x):
+        """fp32 activations as bf16 (hi, lo) plane pairs through the 3x3 convs; merged back to fp32 for the 1x1 tail."""
+        if isinstance(x, SparseBEV):
+            x = x.dense()
+        hi, lo = ops.split_bf16x2(x.float().contiguous(memory_format=torch.channels_last))
+        first, ups = self.sparse_input, []
+        for kind, i in self.plan:
+            if kind == "c":
+                hi, lo = ops.conv2d_nhwc_x3(hi, lo, self.packed_x3[i], self.bs[i], self.ws[i].shape[0], relu=True, sparse_input=first)
+                first = False
+            else:
+                ups.append(self._conv(ops.merge_bf16x2(hi, lo), i))
+        f = ups[0] if len(ups) == 1 else torch.cat(ups, dim=1)
+        y = ops.bias_act_(F.conv2d(f, self.head_w, None), self.head_b, relu=False)
+        return self._split_heads(y)
+
+    def _split_heads(self, y):
+        n, _, h, wd = y.shape
+        ret, c0 = {}, 0
+        for name, sz, code in zip(["box_preds", "cls_preds", "dir_cls_preds"], self.splits, self.codes):
+            o = y[:, c0:c0 + sz]
+            c0 += sz
+            o = o.reshape(n, self.a, code, h, wd).permute(0, 1, 3, 4, 2)   # [B,A,H,W,code] view of the head output
+            ret[name] = o if self.return_views else o.contiguous()
+        return ret
+
     def forward(self, x):
+        if self.packed_x3 is not None:
+            return self._forward_x3(x)
         ups = []
         first = self.sparse_input     # x is the scattered sparse-middle output: mostly empty tiles
         gather = None
@@ -734,14 +773,7 @@ class RPNInference(nn.Module):
                                     self.head_cout, 1, 1, 0, relu=False)
             else:
                 y = ops.bias_act_(F.conv2d(f, self.head_w, None), self.head_b, relu=False)
-        n, _, h, wd = y.shape
-        ret, c0 = {}, 0
-        for name, sz, code in zip(["box_preds", "cls_preds", "dir_cls_preds"], self.splits, self.codes):
-            o = y[:, c0:c0 + sz]
-            c0 += sz
-            o = o.reshape(n, self.a, code, h, wd).permute(0, 1, 3, 4, 2)   # [B,A,H,W,code] view of the head output
-            ret[name] = o if self.return_views else o.contiguous()
-        return ret
+        return self._split_heads(y)
 
 
 # ------------------------------------------------------------------------------------------ detector

@@ -730,6 +730,58 @@ def conv2d_nhwc(x, packed, bias, cout, ksize, stride=1, pad=0, relu=False, spars
     return y
 
 
+def conv2d_pack_weight_x3(weight):
+    """fp32 [Cout, 128, 3, 3] -> the packed (hi | lo) bf16 weight pair of :func:`conv2d_nhwc_x3`: W = bf16(W) + bf16(W - bf16(W))."""
+    rt.require_gpu(weight)
+    w = weight.detach().float().contiguous()
+    hi = w.to(torch.bfloat16)
+    lo = (w - hi.float()).to(torch.bfloat16)
+    n = w.numel()
+    ph, pl = conv2d_pack_weight(hi), conv2d_pack_weight(lo)
+    if ph is None or pl is None:
+        return None
+    return torch.cat([ph[:n], pl[:n], torch.zeros(8, dtype=torch.bfloat16, device=w.device)])
+
+
+@_traced("split_bf16x2")
+def split_bf16x2(x):
+    """fp32 tensor (any layout, element count a multiple of 4) -> (hi, lo) bf16 tensors of the same shape / strides with
+    hi = bf16(x), lo = bf16(x - hi): the operand form of :func:`conv2d_nhwc_x3` (16 significant bits)."""
+    rt.require_gpu(x)
+    assert x.dtype == torch.float32
+    hi, lo = torch.empty_like(x, dtype=torch.bfloat16), torch.empty_like(x, dtype=torch.bfloat16)
+    assert hi.stride() == x.stride()
+    rt.check(rt.lib().sec_split_f32_bf16x2(rt.ptr(x), x.numel(), rt.ptr(hi), rt.ptr(lo), rt.stream()), "sec_split_f32_bf16x2")
+    return hi, lo
+
+
+@_traced("merge_bf16x2")
+def merge_bf16x2(hi, lo):
+    """(hi, lo) bf16 -> fp32 hi + lo (same shape / strides)."""
+    rt.require_gpu(hi, lo)
+    assert hi.dtype == lo.dtype == torch.bfloat16 and hi.stride() == lo.stride() and hi.shape == lo.shape
+    y = torch.empty_like(hi, dtype=torch.float32)
+    assert y.stride() == hi.stride()
+    rt.check(rt.lib().sec_merge_bf16x2_f32(rt.ptr(hi), rt.ptr(lo), hi.numel(), rt.ptr(y), rt.stream()), "sec_merge_bf16x2_f32")
+    return y
+
+
+@_traced("conv2d_nhwc_x3")
+def conv2d_nhwc_x3(x_hi, x_lo, packed_hi_lo, bias, cout, relu=True, sparse_input=False):
+    """3x3 / stride 1 / pad 1 conv on 128 input channels for fp32 networks, operands as bf16 (hi, lo) plane pairs, three bf16
+    MFMA passes accumulated in fp32 (sec_conv2d_nhwc_x3).  x_hi / x_lo [B,128,H,W] channels_last bf16 -> (y_hi, y_lo)."""
+    rt.require_gpu(x_hi, x_lo, packed_hi_lo)
+    assert x_hi.dim() == 4 and x_hi.shape[1] == 128 and x_hi.dtype == x_lo.dtype == torch.bfloat16 and x_hi.shape == x_lo.shape
+    assert x_hi.is_contiguous(memory_format=torch.channels_last) and x_lo.is_contiguous(memory_format=torch.channels_last)
+    b, _, h, w = x_hi.shape
+    y_hi = torch.empty((b, cout, h, w), dtype=torch.bfloat16, device=x_hi.device, memory_format=torch.channels_last)
+    y_lo = torch.empty_like(y_hi)
+    rc = rt.lib().sec_conv2d_nhwc_x3(rt.ptr(x_hi), rt.ptr(x_lo), b, h, w, rt.ptr(packed_hi_lo), rt.ptr(bias), cout,
+                                     int(bool(relu)) | (2 if sparse_input else 0), rt.ptr(y_hi), rt.ptr(y_lo), rt.stream())
+    rt.check(rc, "sec_conv2d_nhwc_x3")
+    return y_hi, y_lo
+
+
 @_traced("sparse_site_map")
 def sparse_site_map(indices, batch_size, spatial_shape, num_dev=None):
     """[B, D, H, W] int32 map of a sparse tensor's sites: row + 1, 0 = no active site (input of :func:`conv2d_nhwc_gather`)."""
