@@ -642,11 +642,26 @@ def self_launch(n):
     return subprocess.call(cmd, env=env)
 
 
-def dry_run(args, rank, local_rank, world):
+def pin_cpu_affinity(local_rank, local_world):
+    """One process per GPU: give rank r the r-th contiguous share of the cores this process may run on, so that the ranks' launch
+    threads (a hipGraph replay per step each) do not migrate across each other.  Returns the core list (None: not pinned)."""
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+        if local_world <= 1 or len(cores) < 2 * local_world:
+            return None
+        per = len(cores) // local_world
+        mine = cores[local_rank * per:(local_rank + 1) * per]
+        os.sched_setaffinity(0, mine)
+        return mine
+    except (AttributeError, OSError):
+        return None
+
+
+def dry_run(args, rank, local_rank, world, affinity=None):
     """Launcher plumbing without a GPU (tests/test_bench_launcher.py): every rank reports who it is over a gloo group, the
     timing reduction (MAX over ranks) is exercised, rank 0 prints one JSON line."""
     import torch.distributed as dist
-    info = {"rank": rank, "local_rank": local_rank, "world": world, "pid": os.getpid()}
+    info = {"rank": rank, "local_rank": local_rank, "world": world, "pid": os.getpid(), "cpu_affinity": affinity}
     ranks, tmax = [info], float(rank + 1)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -947,8 +962,9 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    affinity = pin_cpu_affinity(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world))) if world > 1 else None
     if args.dry_run:
-        return dry_run(args, rank, local_rank, world)
+        return dry_run(args, rank, local_rank, world, affinity)
     assert torch.cuda.is_available(), "bench.py needs an MI355X (use gpurun)"
     if args.gpus != world and rank == 0:
         print(f"[bench] --gpus {args.gpus} but the launcher started WORLD_SIZE={world} rank(s); running {world}", file=sys.stderr)

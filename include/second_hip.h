@@ -35,7 +35,7 @@ extern "C" {
 #define SEC_F16 1
 #define SEC_BF16 2
 
-#define SEC_ABI_VERSION 4
+#define SEC_ABI_VERSION 5
 int sec_abi_version(void);
 /* last HIP error string seen by this library (thread-unsafe convenience for diagnostics) */
 const char *sec_last_error(void);
@@ -568,6 +568,11 @@ size_t sec_flat_adamw_workspace_bytes(void);
 int sec_flat_adamw_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long long n, float lr, float beta1,
                        float beta2, float eps, float weight_decay, float max_grad_norm, float *state4, float *loss_scale4,
                        void *workspace, size_t workspace_bytes, void *stream);
+/* The same step with its hyper-parameters in DEVICE memory: hyper6 = (lr, beta1, beta2, eps, weight_decay, max_grad_norm), read by
+ * the kernels at run time -- a step captured in a hipGraph follows a learning-rate schedule (the reference's one-cycle schedule
+ * changes lr every step: torchplus/train/learning_schedules_fastai.py via train.py:186-200) by updating six floats between replays. */
+int sec_flat_adamw_dev_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long long n, const float *hyper6,
+                           float *state4, float *loss_scale4, void *workspace, size_t workspace_bytes, void *stream);
 
 #ifdef __cplusplus
 }

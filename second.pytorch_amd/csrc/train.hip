@@ -397,9 +397,13 @@ __global__ __launch_bounds__(kBlock) void k_flat_sumsq(const float *__restrict__
         *ticket = 0u;                                   // ready for the next step (graph replays)
     }
 }
+// `hyper` != NULL: (lr, beta1, beta2, eps, weight decay, max gradient norm) are read from device memory -- a captured step follows a
+// learning-rate schedule (the reference's one-cycle schedule changes lr every step, car.fhd.config:171-188) without re-capture.
 __global__ __launch_bounds__(kBlock) void k_flat_adamw(float *__restrict__ p, const float *__restrict__ g, float *__restrict__ m,
                                                       float *__restrict__ v, long long n, float lr, float b1, float b2, float eps,
-                                                      float wd, float max_norm, const float *__restrict__ state) {
+                                                      float wd, float max_norm, const float *__restrict__ state,
+                                                      const float *__restrict__ hyper) {
+    if (hyper) { lr = hyper[0]; b1 = hyper[1]; b2 = hyper[2]; eps = hyper[3]; wd = hyper[4]; max_norm = hyper[5]; }
     if (state[2] != 0.0f) return;                        // overflow: the step is skipped on every rank
     const float unscale = 1.0f / state[3];
     const float norm = state[0], step = state[1];
@@ -527,9 +531,9 @@ SEC_API int sec_second_loss_f32(const float *cls_preds, const float *box_preds, 
 
 SEC_API size_t sec_flat_adamw_workspace_bytes(void) { return align_up((size_t)kAdamBlocks * sizeof(float) + 256); }
 
-SEC_API int sec_flat_adamw_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long long n, float lr, float beta1,
-                               float beta2, float eps, float weight_decay, float max_grad_norm, float *state4, float *loss_scale4,
-                               void *workspace, size_t workspace_bytes, void *stream) {
+static int flat_adamw_impl(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long long n, float lr, float beta1,
+                           float beta2, float eps, float weight_decay, float max_grad_norm, const float *hyper6, float *state4,
+                           float *loss_scale4, void *workspace, size_t workspace_bytes, void *stream) {
     if (!param || !grad || !exp_avg || !exp_avg_sq || !state4 || n <= 0 || !workspace) return SEC_E_INVALID;
     if (workspace_bytes < sec_flat_adamw_workspace_bytes()) return SEC_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
@@ -541,6 +545,20 @@ SEC_API int sec_flat_adamw_f32(float *param, const float *grad, float *exp_avg, 
     int ub = div_up(n, (long long)kBlock * 4);
     if (ub > 2048) ub = 2048;
     hipLaunchKernelGGL(k_flat_adamw, dim3(ub), dim3(kBlock), 0, st, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps,
-                       weight_decay, max_grad_norm, (const float *)state4);
+                       weight_decay, max_grad_norm, (const float *)state4, hyper6);
     return check_launch();
+}
+
+SEC_API int sec_flat_adamw_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long long n, float lr, float beta1,
+                               float beta2, float eps, float weight_decay, float max_grad_norm, float *state4, float *loss_scale4,
+                               void *workspace, size_t workspace_bytes, void *stream) {
+    return flat_adamw_impl(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, max_grad_norm, nullptr, state4,
+                           loss_scale4, workspace, workspace_bytes, stream);
+}
+
+SEC_API int sec_flat_adamw_dev_f32(float *param, const float *grad, float *exp_avg, float *exp_avg_sq, long long n, const float *hyper6,
+                                   float *state4, float *loss_scale4, void *workspace, size_t workspace_bytes, void *stream) {
+    if (!hyper6) return SEC_E_INVALID;
+    return flat_adamw_impl(param, grad, exp_avg, exp_avg_sq, n, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, hyper6, state4, loss_scale4, workspace,
+                           workspace_bytes, stream);
 }

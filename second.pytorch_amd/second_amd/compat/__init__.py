@@ -155,25 +155,50 @@ def load_protos(reference_root):
     return sorted(m for _, m in files.values())
 
 
-def spawn_dataloader_workers():
+_SPAWN_SCOPE = None          # None: DataLoader untouched; "reference": the reference's own loaders only; "all": every loader with workers
+
+
+def _from_reference(obj):
+    mod = getattr(obj, "__module__", None) or getattr(type(obj), "__module__", "") or ""
+    return mod == "second" or mod.startswith("second.") or mod.startswith("torchplus")
+
+
+def spawn_dataloader_workers(scope="all"):
     """``torch.utils.data.DataLoader(num_workers > 0)`` defaults to the ``spawn`` start method.
 
     The reference forks its loader workers (second/pytorch/train.py:262-277, ``num_workers = 3``) and the workers call
     ``spconv.utils.VoxelGeneratorV2.generate`` (second/data/preprocess.py:301-316).  Upstream that is a CPU loop; here it
     runs on the MI355X, and a HIP context does not survive ``fork()`` ("Cannot re-initialize CUDA in forked subprocess").
     Spawned workers import this package afresh and create their own context.  An explicit ``multiprocessing_context``
-    argument is left alone.  Idempotent."""
+    argument is left alone.  Idempotent.
+
+    ``scope``: "reference" (what a bare ``import spconv`` installs, the zero-edit path) touches only loaders whose dataset or
+    collate function comes from the reference's packages (``second.*``: DatasetWrapper, merge_second_batch) -- any other
+    DataLoader of the host program keeps its start method; "all" (``compat.install()``, an explicit call) switches every loader
+    with workers.  The first loader that is switched is reported once on stderr."""
+    global _SPAWN_SCOPE
     import torch.utils.data as tud
+    if _SPAWN_SCOPE == "all" or (_SPAWN_SCOPE == "reference" and scope == "reference"):
+        return
+    _SPAWN_SCOPE = scope
     if getattr(tud.DataLoader, "_second_amd_spawn", False):
         return
     base = tud.DataLoader
+    told = []
 
     class DataLoader(base):
         _second_amd_spawn = True
 
         def __init__(self, *a, **k):
             if k.get("num_workers", 0) > 0 and k.get("multiprocessing_context") is None:
-                k["multiprocessing_context"] = "spawn"
+                dataset = a[0] if a else k.get("dataset")
+                if _SPAWN_SCOPE == "all" or _from_reference(dataset) or _from_reference(k.get("collate_fn")):
+                    k["multiprocessing_context"] = "spawn"
+                    if not told:
+                        told.append(True)
+                        import sys as _sys
+                        print("[second_amd] DataLoader workers use the 'spawn' start method (they voxelise on the GPU; a HIP context "
+                              "does not survive fork()).  multiprocessing_context=... or SEC_KEEP_FORK=1 overrides.", file=_sys.stderr)
             super().__init__(*a, **k)
     DataLoader.__name__, DataLoader.__qualname__ = base.__name__, base.__qualname__
     tud.DataLoader = DataLoader
@@ -211,7 +236,7 @@ def install(reference_root=None, spconv_path=None, spawn_workers=True):
         if _missing(name):
             _stub(name)
     if spawn_workers:
-        spawn_dataloader_workers()
+        spawn_dataloader_workers("all")
     if reference_root:
         if reference_root not in sys.path:
             sys.path.append(reference_root)

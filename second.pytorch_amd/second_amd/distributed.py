@@ -17,6 +17,12 @@ import torch
 import torch.distributed as dist
 
 
+def world_size():
+    """Ranks of the default process group (1 when torch.distributed is not initialised)."""
+    import torch.distributed as dist
+    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+
 def init_from_env(backend=None, timeout_s=None):
     """Initialise the default process group from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun).
     ``timeout_s`` (default SEC_DIST_TIMEOUT_S, else 4 h): collective timeout -- ranks != 0 sit in the gradient all-reduce
@@ -141,12 +147,17 @@ class GradBucket:
             if p.grad is not None and p.grad.data_ptr() != v.data_ptr():
                 p.grad = None
 
-    def allreduce(self, average=True):
-        buf = self.pack()
+    def reduce(self, average=True):
+        """The collective alone, on the packed bucket (between :meth:`pack` and :meth:`unpack`; a step captured as two graphs
+        issues exactly this between their replays)."""
         if dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+            dist.all_reduce(self._buf, op=dist.ReduceOp.SUM)
             if average:
                 self.flat /= dist.get_world_size()
+
+    def allreduce(self, average=True):
+        self.pack()
+        self.reduce(average)
         self.unpack()
         return self.numel * 4
 

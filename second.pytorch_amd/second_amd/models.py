@@ -651,17 +651,53 @@ class RPNInference(nn.Module):
         self.lazy_background = True
         self.last_live_counts = None       # [convs, B] int32 on the device: live tiles per conv and frame of the last forward (bench / tests)
         self._empty_maps = {}
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module._repack())
         convs = [i for kind, i in self.plan if kind == "c"]
         self.background_convs = len(convs) if (
             self.gather_packed is not None and 2 <= len(convs) <= 8 and convs == list(range(len(convs)))
             and all(tuple(self.ws[i].shape) == (128, 128, 3, 3) and self.cfgs[i] == ([1, 1], [1, 1]) and self.ups[i] == 1 for i in convs)) else 0
 
+    # The packed weight images (MFMA slab order, the gather permutation, the hi | lo pairs of the fp32 form) are derived from the
+    # folded parameters at construction: keep them in step with the parameters.  In place, so that captured graphs stay valid.
+    def _repack(self):
+        with torch.no_grad():
+            if self.use_hip:
+                for i, w in enumerate(self.ws):
+                    self.packed[i].copy_(ops.conv2d_pack_weight(w.detach().contiguous()))
+                pad = self.head_cout - self.head_w.shape[0]
+                hw64 = torch.cat([self.head_w.detach().float(), torch.zeros(pad, *self.head_w.shape[1:], device=self.head_w.device)], 0)
+                self.head_packed.copy_(ops.conv2d_pack_weight(hw64.to(self.head_w.dtype).contiguous()))
+                self.head_b64[:self.head_b.numel()].copy_(self.head_b)
+                if self.gather_packed is not None:
+                    perm = ops.gather_channel_perm(64, 2).to(self.ws[0].device)
+                    self.gather_packed.copy_(ops.conv2d_pack_weight(self.ws[0].detach()[:, perm].contiguous()))
+            if self.packed_x3 is not None:
+                for i, pk in self.packed_x3.items():
+                    pk.copy_(ops.conv2d_pack_weight_x3(self.ws[i]))
+        self._empty_maps.clear()
+
+    def _apply(self, fn, *a, **k):
+        super()._apply(fn, *a, **k)
+        move = lambda t: fn(t) if isinstance(t, torch.Tensor) else t
+        self.packed = [move(t) for t in self.packed]
+        for name in ("head_packed", "head_b64", "gather_packed"):
+            if getattr(self, name, None) is not None:
+                setattr(self, name, move(getattr(self, name)))
+        if self.packed_x3 is not None:
+            self.packed_x3 = {i: move(t) for i, t in self.packed_x3.items()}
+        self._empty_maps.clear()
+        return self
+
     def empty_frame_maps(self, h, w):
         """Output of every 3x3 conv of the block for a frame WITHOUT sites, channels_last [1, 128, h, w] each, from the kernels the
         forward itself uses (so that a copied tile is bit-identical to a computed one).  Cached per map size; the first call for a
         size must not happen inside a graph capture."""
-        key = (int(h), int(w))
+        # keyed on the folded weights too (version counters, storage, device, dtype): load_state_dict into a prepared detector,
+        # .to(device) or a dtype change must not leave maps of the old network behind (they fill every background tile)
+        src = [self.ws[i] for i in range(self.background_convs)] + [self.bs[i] for i in range(self.background_convs)] + [self.ws[-1], self.bs[-1], self.head_w, self.head_b]
+        key = (int(h), int(w), str(self.ws[0].device), self.ws[0].dtype, tuple((t.data_ptr(), t._version) for t in src))
         if key not in self._empty_maps:
+            self._empty_maps.clear()
             assert not torch.cuda.is_current_stream_capturing(), "RPNInference.empty_frame_maps: run one eager forward before capturing"
             dev, dt = self.ws[0].device, self.ws[0].dtype
             with torch.no_grad():

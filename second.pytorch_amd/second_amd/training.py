@@ -56,7 +56,35 @@ class FlatAdamW:
         self.state = torch.zeros(4, dtype=torch.float32, device=dev)         # (gradient norm, step count, skipped flag, loss scale used)
         self.loss_scale = None                                               # device float[4] for fp16: see enable_loss_scaling
         self.ws = torch.zeros(rt.lib().sec_flat_adamw_workspace_bytes(), dtype=torch.uint8, device=dev)
-        self.lr, self.weight_decay, self.betas, self.eps, self.max_grad_norm = float(lr), float(weight_decay), betas, float(eps), float(max_grad_norm)
+        self.max_grad_norm = float(max_grad_norm)
+        # The hyper-parameters live in ONE param group (what torch LR schedulers and checkpoint code attach to) and, for the kernels,
+        # in six device floats that :meth:`sync_hyper` refreshes when the group changed: a step captured in a hipGraph follows a
+        # schedule (the reference's one-cycle lr changes every step) by replaying with new values, not by re-capturing.
+        self.param_groups = [{"params": self.params, "lr": float(lr), "betas": tuple(float(b) for b in betas), "eps": float(eps),
+                              "weight_decay": float(weight_decay)}]
+        self.hyper = torch.zeros(6, dtype=torch.float32, device=dev)
+        self._hyper_host = torch.zeros(6, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(6)
+        self._hyper_last = None
+        self.sync_hyper()
+
+    lr = property(lambda self: self.param_groups[0]["lr"], lambda self, v: self.param_groups[0].__setitem__("lr", float(v)))
+    weight_decay = property(lambda self: self.param_groups[0]["weight_decay"],
+                            lambda self, v: self.param_groups[0].__setitem__("weight_decay", float(v)))
+    betas = property(lambda self: self.param_groups[0]["betas"], lambda self, v: self.param_groups[0].__setitem__("betas", tuple(v)))
+    eps = property(lambda self: self.param_groups[0]["eps"], lambda self, v: self.param_groups[0].__setitem__("eps", float(v)))
+
+    def set_lr(self, lr):
+        self.lr = lr
+
+    def sync_hyper(self):
+        """Upload (lr, beta1, beta2, eps, weight_decay, max_grad_norm) if they changed since the last upload.  Called by
+        :meth:`step` and by the replay function of a captured step (outside the graph, on the replaying stream)."""
+        g = self.param_groups[0]
+        cur = (float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), float(self.max_grad_norm))
+        if cur != self._hyper_last:
+            self._hyper_host.copy_(torch.tensor(cur, dtype=torch.float32))
+            self.hyper.copy_(self._hyper_host, non_blocking=True)
+            self._hyper_last = cur
 
     def enable_loss_scaling(self, init_scale=2.0 ** 12, growth_interval=200):
         """Dynamic loss scaling kept on the device (fp16 features): ``self.loss_scale`` = (scale, clean steps in a row, growth
@@ -67,11 +95,15 @@ class FlatAdamW:
 
     def step(self):
         from . import runtime as rt
-        rt.check(rt.lib().sec_flat_adamw_f32(rt.ptr(self.flat), rt.ptr(self.grad), rt.ptr(self.exp_avg), rt.ptr(self.exp_avg_sq),
-                                             self.flat.numel(), self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
-                                             self.max_grad_norm, rt.ptr(self.state), rt.ptr(self.loss_scale), rt.ptr(self.ws),
-                                             self.ws.numel(), rt.stream()),
-                 "sec_flat_adamw_f32")
+        if not torch.cuda.is_current_stream_capturing():
+            self.sync_hyper()
+        rt.check(rt.lib().sec_flat_adamw_dev_f32(rt.ptr(self.flat), rt.ptr(self.grad), rt.ptr(self.exp_avg), rt.ptr(self.exp_avg_sq),
+                                                 self.flat.numel(), rt.ptr(self.hyper), rt.ptr(self.state), rt.ptr(self.loss_scale),
+                                                 rt.ptr(self.ws), self.ws.numel(), rt.stream()),
+                 "sec_flat_adamw_dev_f32")
+
+    def zero_grad(self, set_to_none=False):
+        self.grad.zero_()
 
     def state_dict(self):
         return {"exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "state": self.state,
@@ -79,6 +111,9 @@ class FlatAdamW:
 
     def load_state_dict(self, sd):
         self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"]); self.state.copy_(sd["state"])
+        for k, v in sd.get("hyper", {}).items():
+            setattr(self, k, v)
+        self.sync_hyper()
 
 
 class DeviceTrainer:
@@ -247,6 +282,17 @@ class DeviceTrainer:
     def step(self, points, point_offsets, gt_boxes, gt_offsets, gt_classes=None):
         """One optimisation step on this rank's shard; returns the device tensor of the six loss scalars (no host sync,
         except with fp16 features on a non-flat optimizer: dynamic loss scaling then reads one overflow flag per step)."""
+        out6 = self._step_backward(points, point_offsets, gt_boxes, gt_offsets, gt_classes)
+        self.bucket.allreduce(average=True)                       # one flat bucket, zeros for parameters without a gradient
+        if self.loss_scale is not None and not self._unscale_and_check():
+            self.bucket.zero_grad()                               # overflow on some rank: skip the step everywhere (same bucket)
+            self._skipped_host += 1
+            return out6
+        self._step_update()
+        self.steps += 1
+        return out6
+
+    def _step_backward(self, points, point_offsets, gt_boxes, gt_offsets, gt_classes=None):
         with ops.deferred_bn_counters():
             loss, out6, _ = self.forward_loss(points, point_offsets, gt_boxes, gt_offsets, gt_classes)
         if self.loss_scale_dev is not None:
@@ -255,20 +301,16 @@ class DeviceTrainer:
             loss.backward()
         else:
             (loss * self.loss_scale).backward()
-        self.bucket.allreduce(average=True)                       # one flat bucket, zeros for parameters without a gradient
         self.last = {"out6": out6}
-        if self.loss_scale is not None and not self._unscale_and_check():
-            self.bucket.zero_grad()                               # overflow on some rank: skip the step everywhere (same bucket)
-            self._skipped_host += 1
-            return out6
+        return out6
+
+    def _step_update(self):
         if not self.flat_opt:
             torch.nn.utils.clip_grad_norm_(self.bucket.params, self.max_grad_norm)
         self.opt.step()                                           # FlatAdamW: clip + update, two launches
         self.bucket.zero_grad()                                   # fp32 p.grad are views of the bucket: one fill
-        self.steps += 1
-        return out6
 
-    def capture_step(self, points, point_offsets, gt_boxes, gt_offsets, gt_classes=None, margin=1.25, warmup=2):
+    def capture_step(self, points, point_offsets, gt_boxes, gt_offsets, gt_classes=None, margin=1.25, warmup=2, restore_state=True):
         """The WHOLE optimisation step -- voxelise, targets, forward, loss, backward, gradient all-reduce, clip, AdamW -- as ONE
         hipGraph (second/pytorch/train.py:306-330 is ~520 dispatches here, host bound when launched one by one).  What makes it
         capturable: static-capacity rows through the sparse stack (row counts stay on the device; every strided layer gets
@@ -277,10 +319,21 @@ class DeviceTrainer:
         dynamic loss scale -- live on the device (FlatAdamW).
         Returns ``replay(points=None, point_offsets=None, gt_boxes=None, gt_offsets=None, gt_classes=None) -> out6``: new inputs
         (same shapes or fewer rows) are copied into the graph's buffers first.  Raises what the capture raises: callers fall back
-        to :meth:`step`.  Call :meth:`check_overflow` now and then (one host sync)."""
+        to :meth:`step`.  Call :meth:`check_overflow` now and then (one host sync).  The hyper-parameters of the flat optimizer are read
+        from device memory by the captured kernels: change ``trainer.opt.lr`` (or its ``param_groups``) between replays freely.
+        ``restore_state`` (default): model, optimizer and BatchNorm state are snapshotted before and restored after the capture, whose
+        1 + ``warmup`` + 1 real steps on the capture batch would otherwise count as training."""
         import spconv
         assert self.amp_dtype is not None and self.loss_scale is None and not self.det.pillars, "capture_step: 16-bit sparse-middle configs on the flat optimizer"
         ins = [points, point_offsets, gt_boxes, gt_offsets, gt_classes]
+        names = ("points", "point_offsets", "gt_boxes", "gt_offsets", "gt_classes")
+        # the dynamic step, the static warm-up steps and the capture itself are real optimizer steps on the capture batch: the
+        # model / optimizer / BatchNorm state is put back afterwards, so that capturing does not train (restore_state=False keeps them)
+        snap = None
+        if restore_state:
+            snap = ({k: v.clone() for k, v in self.det.state_dict().items()},
+                    {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in self.opt.state_dict().items()} if self.flat_opt else None,
+                    None if self.loss_scale_dev is None else self.loss_scale_dev.clone(), self.steps)
         self.static = False
         self.step(*ins)                                   # one dynamic step: records every strided layer's output rows
         for m in self.det.middle_feature_extractor.modules():
@@ -296,16 +349,71 @@ class DeviceTrainer:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.check_overflow()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-            out6 = self.step(*bufs)
-        self._captured = (graph, bufs, out6)
+        # Multi-rank: the gradient all-reduce sits INSIDE the graph when RCCL captures (one replay per step, nothing on the host);
+        # if that capture fails -- or SEC_TRAIN_ALLREDUCE_IN_GRAPH=0 -- the step becomes two graphs (forward / backward, then clip +
+        # AdamW) with the all-reduce issued between them on the same stream.
+        in_graph = os.environ.get("SEC_TRAIN_ALLREDUCE_IN_GRAPH", "1") != "0"
+        graphs, out6 = None, None
+        if in_graph:
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    out6 = self.step(*bufs)
+                graphs = (g,)
+            except Exception as e:  # noqa: BLE001
+                if D.world_size() <= 1:
+                    raise
+                import warnings
+                warnings.warn(f"second_amd: capturing the RCCL all-reduce inside the training graph failed ({e!r}); two graphs per step")
+                torch.cuda.synchronize()
+        if graphs is None:
+            pool = torch.cuda.graph_pool_handle()
+            g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            # graph 1 ends with the gradients PACKED into the flat bucket (the copies are captured: which tensors backward handed over
+            # is host state of the capture, not of a replay); the collective runs on the bucket between the graphs
+            with torch.cuda.graph(g1, pool=pool, capture_error_mode="thread_local"):
+                out6 = self._step_backward(*bufs)
+                self.bucket.pack()
+            self.bucket.reduce(average=True)
+            with torch.cuda.graph(g2, pool=pool, capture_error_mode="thread_local"):
+                self.bucket.unpack()
+                self._step_update()
+            graphs = (g1, g2)
+        self.allreduce_in_graph = len(graphs) == 1
+        self._captured = (graphs, bufs, out6)
+        if snap is not None:
+            with torch.no_grad():
+                sd = self.det.state_dict()
+                for k, v in snap[0].items():
+                    sd[k].copy_(v)
+                if snap[1] is not None:
+                    self.opt.load_state_dict(snap[1])
+                if snap[2] is not None:
+                    self.loss_scale_dev.copy_(snap[2])
+            self.steps = snap[3]
+            self.bucket.zero_grad()
 
         def replay(*new):
-            for dst, src in zip(bufs, new):
-                if src is not None and dst is not None and src.data_ptr() != dst.data_ptr():
-                    dst[:src.shape[0]].copy_(src, non_blocking=True)
-            graph.replay()
+            assert len(new) <= len(bufs), f"replay takes at most {len(bufs)} tensors ({', '.join(names)})"
+            for name, dst, src in zip(names, bufs, new):
+                if src is None:
+                    continue
+                if dst is None:
+                    raise ValueError(f"capture_step.replay: `{name}` was None when the step was captured; capture with a {name} tensor to feed one")
+                if src.data_ptr() == dst.data_ptr():
+                    continue
+                if src.dim() != dst.dim() or tuple(src.shape[1:]) != tuple(dst.shape[1:]) or src.shape[0] > dst.shape[0]:
+                    raise ValueError(f"capture_step.replay: `{name}` has shape {tuple(src.shape)}, the captured buffer holds {tuple(dst.shape)} "
+                                     "(same trailing dimensions, at most as many rows)")
+                if name in ("point_offsets", "gt_offsets") and src.shape[0] != dst.shape[0]:
+                    raise ValueError(f"capture_step.replay: `{name}` must have the captured batch size ({dst.shape[0] - 1} frames)")
+                dst[:src.shape[0]].copy_(src, non_blocking=True)
+            if self.flat_opt:
+                self.opt.sync_hyper()                     # lr / betas / weight decay changed since the last replay: six floats, no re-capture
+            graphs[0].replay()
+            if len(graphs) == 2:
+                self.bucket.reduce(average=True)
+                graphs[1].replay()
             self.steps += 1
             self.last = {"out6": out6}
             return out6

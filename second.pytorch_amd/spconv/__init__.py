@@ -10,11 +10,12 @@ from second_amd import runtime as _runtime  # noqa: F401  (registers the fork gu
 
 # Zero-edit path: the reference forks its DataLoader workers (second/pytorch/train.py:262-277) and the workers call
 # spconv.utils.VoxelGeneratorV2.generate, which needs a HIP context here.  Importing spconv is all the reference does, so the
-# import itself switches DataLoader(num_workers > 0) to spawned workers (idempotent; an explicit multiprocessing_context wins;
-# SEC_KEEP_FORK=1 opts out).
+# import itself switches THE REFERENCE'S loaders (dataset or collate function from its `second` package) to spawned workers;
+# every other DataLoader of the host program keeps its start method (idempotent; an explicit multiprocessing_context wins;
+# SEC_KEEP_FORK=1 opts out; second_amd.compat.install() switches all loaders).
 import os as _os
 if _os.environ.get("SEC_KEEP_FORK", "0") != "1":
-    _spawn_dataloader_workers()
+    _spawn_dataloader_workers("reference")
 
 from .tensor import SparseConvTensor, Rulebook
 from .modules import SparseModule, SparseSequential

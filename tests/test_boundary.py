@@ -33,11 +33,23 @@ def test_import_spconv_alone_switches_loader_workers_to_spawn():
         class D(tud.Dataset):
             def __len__(self): return 4
             def __getitem__(self, i): return i
-        dl = tud.DataLoader(D(), num_workers=2)                 # what train.py:262 does
+        class Theirs(D):
+            pass
+        Theirs.__module__ = "second.pytorch.builder.input_reader_builder"            # where the reference's DatasetWrapper lives
+        def merge_second_batch(b): return b
+        merge_second_batch.__module__ = "second.data.preprocess"
+        dl = tud.DataLoader(Theirs(), num_workers=2)            # what train.py:262 does
         assert dl.multiprocessing_context.get_start_method() == "spawn", dl.multiprocessing_context
-        dl = tud.DataLoader(D(), num_workers=2, multiprocessing_context="fork")      # an explicit choice is left alone
+        dl = tud.DataLoader(D(), num_workers=2, collate_fn=merge_second_batch)
+        assert dl.multiprocessing_context.get_start_method() == "spawn"
+        dl = tud.DataLoader(Theirs(), num_workers=2, multiprocessing_context="fork")      # an explicit choice is left alone
         assert dl.multiprocessing_context.get_start_method() == "fork"
-        assert tud.DataLoader(D(), num_workers=0).multiprocessing_context is None
+        assert tud.DataLoader(Theirs(), num_workers=0).multiprocessing_context is None
+        # a loader of the host program that has nothing to do with the reference keeps its start method
+        assert tud.DataLoader(D(), num_workers=2).multiprocessing_context is None
+        from second_amd import compat
+        compat.install()                                        # the explicit call switches every loader with workers
+        assert tud.DataLoader(D(), num_workers=2).multiprocessing_context.get_start_method() == "spawn"
         print("ok")
     """)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]

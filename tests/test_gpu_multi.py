@@ -80,3 +80,63 @@ dist.destroy_process_group()
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
                         "--master-port", "29617", str(path), ROOT], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "RCCL_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+@needs2
+@pytest.mark.parametrize("in_graph", ["1", "0"])
+def test_captured_training_step_two_ranks_keep_identical_parameters(tmp_path, in_graph):
+    """DeviceTrainer.capture_step on two ranks (one GPU each, different frames): the gradient all-reduce is captured INSIDE the
+    step's hipGraph (in_graph = 1; training.py falls back to two graphs with the all-reduce between them if RCCL refuses to be
+    captured, and says so) or issued between two graphs (in_graph = 0, forced).  After three replays both ranks hold identical
+    parameters, different from the initial ones, and the two modes agree with each other on rank 0."""
+    code = r'''
+import os, sys, torch, torch.distributed as dist
+root = sys.argv[1]
+sys.path.insert(0, os.path.join(root, "second.pytorch_amd")); sys.path.insert(0, root)
+from second_amd import distributed as D, synthetic as syn
+from second_amd.models import SecondDetector, CAR_FHD
+from second_amd.training import DeviceTrainer
+import numpy as np
+rank, local, world = D.init_from_env("nccl")
+torch.cuda.set_device(local)
+torch.manual_seed(0)
+det = SecondDetector(CAR_FHD).cuda()
+tr = DeviceTrainer(det, amp_dtype=torch.bfloat16)
+clouds = [syn.syn_kitti_cloud(rank * 2 + s, num_points=6000, num_voxels=5000) for s in range(2)]
+boxes = [syn.syn_kitti_boxes(rank * 2 + s, 8) for s in range(2)]
+pts, offs = syn.batch_clouds(clouds)
+gt = np.concatenate(boxes).astype(np.float32)
+goffs = np.cumsum([0] + [len(b) for b in boxes]).astype(np.int32)
+ins = [torch.from_numpy(a).cuda() for a in (pts, offs, gt, goffs)]
+start = tr.opt.flat.clone()
+replay = tr.capture_step(*ins)
+for _ in range(3):
+    replay()
+torch.cuda.synchronize()
+flat = tr.opt.flat.clone()
+both = [torch.zeros_like(flat) for _ in range(world)]
+dist.all_gather(both, flat)
+assert torch.equal(both[0], both[1]), "ranks diverged"
+assert not torch.equal(flat, start) and torch.isfinite(flat).all()
+if rank == 0:
+    torch.save(flat.cpu(), sys.argv[2])
+    print("CAPTURED_OK in_graph=%d graphs_per_step=%d" % (int(tr.allreduce_in_graph), 1 if tr.allreduce_in_graph else 2))
+dist.destroy_process_group()
+'''
+    path = tmp_path / "captured_ddp.py"
+    path.write_text(code)
+    out = tmp_path / f"flat_{in_graph}.pt"
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SEC_TRAIN_ALLREDUCE_IN_GRAPH=in_graph)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29631" if in_graph == "1" else "29633", str(path), ROOT, str(out)],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "CAPTURED_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+    if in_graph == "0":
+        assert "graphs_per_step=2" in r.stdout
+    other = tmp_path.parent / "captured_ddp_ref.pt"
+    flat = torch.load(out)
+    if other.exists():                                         # second parametrisation: both modes end at the same weights
+        diff = (flat - torch.load(other)).abs()               # (atomics in the sparse weight gradient: agreement to rounding, see test_gpu_train_dense)
+        assert float((diff > 1e-4).float().mean()) < 2e-3, float(diff.max())
+    else:
+        torch.save(flat, other)

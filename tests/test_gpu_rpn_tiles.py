@@ -211,3 +211,42 @@ def test_detector_with_and_without_background_tiles_gives_identical_detections()
     for k in outs[0]:
         assert torch.equal(outs[0][k], outs[2][k]), k
         assert torch.equal(outs[1][k], outs[2][k]), k
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_prepared_rpn_follows_a_state_dict_loaded_later(dtype):
+    """RPNInference keeps packed copies of its folded weights (MFMA slab order, gather permutation, hi | lo pairs of the fp32
+    form) and the empty frame's activations of the background tiles: load_state_dict into a PREPARED network re-packs them in
+    place -- the next forward is the other network's, bit for bit, including its background tiles."""
+    from second_amd.models import RPNV2, RPNInference, SparseBEV
+    import spconv
+
+    def make(seed):
+        torch.manual_seed(seed)
+        rpn = RPNV2().eval()
+        g = torch.Generator().manual_seed(seed)
+        for m in rpn.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.copy_(torch.empty_like(m.running_mean).uniform_(-0.3, 0.1, generator=g))
+                m.running_var.copy_(torch.empty_like(m.running_var).uniform_(0.5, 1.5, generator=g))
+                m.bias.data.uniform_(-0.1, 0.3, generator=g)               # a non-zero background
+        return RPNInference(rpn.cuda(), dtype)
+    a, b = make(1), make(2)
+    g = torch.Generator().manual_seed(5)
+    n = 600
+    idx = torch.stack([torch.randint(0, 2, (n,), generator=g), torch.randint(0, 2, (n,), generator=g),
+                       torch.randint(20, 90, (n,), generator=g), torch.randint(30, 120, (n,), generator=g)], 1).int()
+    idx = torch.unique(idx, dim=0).cuda()
+    feats = torch.randn(idx.shape[0], 64, generator=g).abs().cuda().to(torch.bfloat16 if dtype != torch.float32 else torch.float32)
+    sp = spconv.SparseConvTensor(feats, idx, [2, 200, 176], 2)
+
+    def run(net):
+        with torch.no_grad():
+            x = SparseBEV(sp) if net.gather_packed is not None else sp.dense_channels_last_2d()
+            return {k: v.float().clone() for k, v in net(x).items()}
+    out_a, out_b = run(a), run(b)
+    assert not torch.equal(out_a["cls_preds"], out_b["cls_preds"])
+    a.load_state_dict(b.state_dict())
+    got = run(a)
+    for k in out_b:
+        assert torch.equal(got[k], out_b[k]), k

@@ -395,6 +395,79 @@ def test_whole_training_step_captured_in_one_graph_replays_and_learns():
         assert torch.isfinite(p).all()
 
 
+def test_captured_step_follows_the_learning_rate_and_leaves_the_state_as_it_found_it():
+    """The captured kernels read the optimizer's hyper-parameters from device memory: a one-cycle schedule (the reference changes
+    lr every step, car.fhd.config:171-188) is followed by replays, no re-capture; lr = 0 leaves the weights alone.  capture_step
+    itself is not training: parameters, Adam moments, step counter and BatchNorm statistics are as before.  replay() validates what
+    it is fed."""
+    from second_amd.models import SecondDetector, CAR_FHD
+    from second_amd.training import DeviceTrainer
+    ins = _train_inputs()
+    torch.manual_seed(0)
+    tr = DeviceTrainer(SecondDetector(CAR_FHD).cuda(), amp_dtype=torch.bfloat16)
+    before = {k: v.clone() for k, v in tr.det.state_dict().items()}
+    replay = tr.capture_step(*ins)
+    torch.cuda.synchronize()
+    for k, v in tr.det.state_dict().items():
+        assert torch.equal(v, before[k]), k
+    assert tr.steps == 0 and float(tr.opt.state[1]) == 0 and float(tr.opt.exp_avg.abs().max()) == 0
+    assert tr.opt.param_groups[0]["lr"] == tr.opt.lr and len(tr.opt.param_groups) == 1
+    flat0 = tr.opt.flat.clone()
+    tr.opt.param_groups[0]["lr"] = 0.0                       # what a torch LR scheduler does
+    tr.opt.weight_decay = 0.0
+    replay()
+    torch.cuda.synchronize()
+    assert torch.equal(tr.opt.flat, flat0), "lr = 0 must leave the weights alone: the captured step still carries the old lr"
+    tr.opt.set_lr(1e-3)
+    replay()
+    torch.cuda.synchronize()
+    d1 = float((tr.opt.flat - flat0).abs().max())
+    assert 0 < d1 <= 1.01e-3, d1                             # the first Adam step moves every weight by at most lr
+    flat1 = tr.opt.flat.clone()
+    tr.opt.lr = 4e-3
+    replay()
+    torch.cuda.synchronize()
+    assert float((tr.opt.flat - flat1).abs().max()) > 1.5 * d1
+    with pytest.raises(ValueError, match="gt_classes"):
+        replay(None, None, None, None, torch.ones(3, dtype=torch.int32, device="cuda"))
+    with pytest.raises(ValueError, match="points"):
+        replay(torch.zeros(ins[0].shape[0] + 5, 4, device="cuda"))
+    with pytest.raises(ValueError, match="point_offsets"):
+        replay(None, ins[1][:-1])
+
+
+def test_two_graph_form_of_the_captured_step_equals_the_one_graph_form(monkeypatch):
+    """The fallback for a RCCL that refuses capture (forward / backward graph, all-reduce on the stream, clip + AdamW graph;
+    SEC_TRAIN_ALLREDUCE_IN_GRAPH=0) ends at the same weights as the single graph (one rank here: the all-reduce is the identity;
+    the two-rank versions are tests/test_gpu_multi.py)."""
+    from second_amd.models import SecondDetector, CAR_FHD
+    from second_amd.training import DeviceTrainer
+    ins = _train_inputs()
+    flats, losses = [], []
+    for mode in ("1", "1", "0"):
+        monkeypatch.setenv("SEC_TRAIN_ALLREDUCE_IN_GRAPH", mode)
+        torch.manual_seed(0)
+        tr = DeviceTrainer(SecondDetector(CAR_FHD).cuda(), amp_dtype=torch.bfloat16)
+        replay = tr.capture_step(*ins)
+        assert tr.allreduce_in_graph == (mode == "1")
+        for _ in range(3):
+            out = replay()
+        torch.cuda.synchronize()
+        assert torch.isfinite(out.float()).all()
+        flats.append(tr.opt.flat.clone())
+        losses.append(out.float().cpu())
+    # Two runs of the SAME form are the yardstick: the sparse weight gradient combines its chunks with fp32 atomics and the features
+    # are bf16, so after three Adam steps two runs agree statistically, not bit for bit.  The two-graph form must sit within that.
+    def spread(a, b):
+        d = (a - b).abs()
+        return float((d > 1e-4).float().mean()), float(d.median())
+    same_frac, same_med = spread(flats[0], flats[1])
+    other_frac, other_med = spread(flats[0], flats[2])
+    assert other_frac <= 2.0 * same_frac + 0.02 and other_med <= 2.0 * same_med + 1e-6, ((same_frac, same_med), (other_frac, other_med))
+    assert float((flats[2] - flats[0]).abs().max()) <= 3 * 3e-3 * 2.2        # nobody moved further than three Adam steps can
+    torch.testing.assert_close(losses[2][0], losses[0][0], rtol=0.05, atol=1e-3)
+
+
 def test_flat_adamw_matches_torch_adamw_with_clipping():
     """sec_flat_adamw_f32 (clip_grad_norm_ + AdamW on one flat buffer, two launches) against torch.nn.utils.clip_grad_norm_ +
     torch.optim.AdamW on the same tensors for four steps: gradients large enough to be clipped in some steps and not in others."""
