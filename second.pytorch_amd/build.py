@@ -19,7 +19,11 @@ OUT = os.path.join(HERE, "lib", "libsecond_hip.so")
 # 64-channel sparse-conv kernels).  On gfx950 (ROCm 7.2) those instructions were measured to return WRONG results in lanes 48..63 of a
 # wave -- a product term missing -- while another wave of the CU runs the dense v_mfma_f32_32x32x16_bf16 loop of the RPN conv kernel
 # (tools/nms_stress.py: the rotated-NMS clipper's corner arithmetic differed in ~1 % of its evaluations beside k_conv2d_halo_reg;
-# 0 of 400 runs without packed fp32).  DESIGN.md section 5.  The host pass of hipcc prints "not a recognized feature" for it (filtered below).
+# 0 of 400 runs without packed fp32).  The cause was never isolated (every instruction-level probe came back clean), so the rule is
+# a blanket one: NO kernel of this library uses packed fp32 -- the one exemption (k_conv_rows_buf, rounds 2-4) was dropped in round 5
+# when an A/B showed it bought nothing any more (profiles/r05_b_packed_fp32_exemption_ab.txt); tests/test_gpu_stress.py replays the
+# bench configuration 600 steps and the NMS 500 times beside the RPN conv.  The host pass of hipcc prints "not a recognized feature"
+# for the flag (filtered below).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
          "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops",
          "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]

@@ -587,12 +587,13 @@ constexpr int kBalWgs = 256;                                 // one workgroup pe
 //           pipe busy for ~5000 clocks before the first offset);
 //    bit 1: the B fragments of offset k+1 are read from LDS while offset k's MFMAs run (register double buffer), so a wave's
 //           step no longer starts with an exposed LDS round trip.
-// SEC_PACKED_F32_OK: the library is built without packed fp32 VALU instructions (build.py: they were measured to return wrong results
-// beside the RPN conv's MFMA loop in a VALU-heavy kernel).  This kernel keeps them: its only packed operations are the 32 scale / shift
-// instructions of the epilogue, once per wave, it loses ~10 % without them (the scheduling of the whole loop shifts), and in every
-// concurrency stress run before the flag existed (9000+ lane replays, every layer output compared bit for bit) it never produced a
-// different result.
-#if defined(__HIP_DEVICE_COMPILE__)
+// Packed fp32 VALU instructions: the whole library is built without them (build.py: they returned wrong results in the rotated-NMS
+// clipper while another wave of the CU ran the RPN conv's MFMA loop; the cause was never isolated).  Until round 5 this kernel alone
+// was exempted (its only packed operations are the 32 scale / shift instructions of the epilogue, it lost ~10 % without them in
+// round 2, and 9000+ stressed replays never differed); with the round-3/4 loop forms the exemption is worth nothing any more
+// (profiles/r05_b_packed_fp32_exemption_ab.txt: 191-194 us for the fourteen layers either way), so it is gone.
+// -DSEC_PACKED_F32_EXEMPTION restores it for A/B builds.
+#if defined(__HIP_DEVICE_COMPILE__) && defined(SEC_PACKED_F32_EXEMPTION)
 #define SEC_PACKED_F32_OK __attribute__((target("packed-fp32-ops")))
 #else
 #define SEC_PACKED_F32_OK
