@@ -408,3 +408,69 @@ def accelerate_model(net, dtype=None, graph=True, static=None, strict=True):
     net.forward = forward
     net._second_amd_engine, net._second_amd_original_forward = eng, original
     return net
+
+
+def accelerate_class(cls):
+    """Class-level form of :func:`accelerate_model`: every instance of ``cls`` (the reference's ``VoxelNet``) builds its engine
+    lazily at its first eval-mode call; instances outside the fused path keep the original forward.  Idempotent."""
+    if getattr(cls, "_second_amd_class_accelerated", False):
+        return cls
+    original = cls.forward
+
+    def forward(self, example):
+        eng = self.__dict__.get("_second_amd_engine")
+        if eng is None and not self.training:
+            try:
+                eng = FusedVoxelNet(self)
+            except NotAccelerable:
+                eng = False
+            self.__dict__["_second_amd_engine"] = eng
+            self.__dict__["_second_amd_original_forward"] = lambda ex: original(self, ex)
+        if eng and eng.accepts(example):
+            res = eng(example)
+            if res is not None:
+                return res
+        if eng:
+            eng.stats["original_calls"] += 1
+        return original(self, example)
+    forward.__doc__ = original.__doc__
+    cls.forward = forward
+    cls._second_amd_class_accelerated = True
+    return cls
+
+
+def install_import_hook(module_name="second.pytorch.models.voxelnet", class_name="VoxelNet"):
+    """The zero-edit, zero-call route (SEC_ACCELERATE_MODEL=1 with a bare ``import spconv``): when the reference's
+    ``second.pytorch.models.voxelnet`` is imported, its ``VoxelNet`` is passed through :func:`accelerate_class`.  If the module
+    is already imported it is patched at once."""
+    import importlib.abc
+    import importlib.util
+    import sys
+    if module_name in sys.modules:
+        accelerate_class(getattr(sys.modules[module_name], class_name))
+        return
+    if any(getattr(f, "_second_amd_hook", None) == module_name for f in sys.meta_path):
+        return
+
+    class Finder(importlib.abc.MetaPathFinder):
+        _second_amd_hook = module_name
+
+        def find_spec(self, name, path, target=None):
+            if name != module_name:
+                return None
+            sys.meta_path.remove(self)
+            spec = importlib.util.find_spec(name)
+            if spec is None or spec.loader is None:
+                return spec
+            inner = spec.loader
+
+            class Loader(importlib.abc.Loader):
+                def create_module(self, spec_):
+                    return inner.create_module(spec_)
+
+                def exec_module(self, module):
+                    inner.exec_module(module)
+                    accelerate_class(getattr(module, class_name))
+            spec.loader = Loader()
+            return spec
+    sys.meta_path.insert(0, Finder())

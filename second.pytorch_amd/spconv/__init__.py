@@ -17,6 +17,13 @@ import os as _os
 if _os.environ.get("SEC_KEEP_FORK", "0") != "1":
     _spawn_dataloader_workers("reference")
 
+# SEC_ACCELERATE_MODEL=1: the fused static-capacity pipeline behind the reference's own VoxelNet.forward(example), without a call
+# (second_amd.dropin: the class is wrapped when second.pytorch.models.voxelnet is imported; eval mode only, networks outside the
+# fused path keep their forward).  Off by default: `compat.accelerate_model(net)` / `second_amd.launch evaluate` are the explicit routes.
+if _os.environ.get("SEC_ACCELERATE_MODEL", "0") == "1":
+    from second_amd.dropin import install_import_hook as _install_import_hook
+    _install_import_hook()
+
 from .tensor import SparseConvTensor, Rulebook
 from .modules import SparseModule, SparseSequential
 from .conv import SparseConvolution, SubMConv3d, SparseConv3d

@@ -399,3 +399,47 @@ def test_gpu_box_standin_is_shaped_like_the_reference_network(ref, rel, name):
                  "_post_center_range", "_dir_offset", "_num_direction_bins", "_dir_limit_offset", "_box_coder", "target_assigner",
                  "voxel_generator"):
         assert hasattr(real, attr) and hasattr(fake, attr), attr
+
+
+def test_zero_call_acceleration_through_the_import_hook(tmp_path):
+    """SEC_ACCELERATE_MODEL=1 + `import spconv`: the reference's VoxelNet class is wrapped when its module is imported; a network
+    built by the unmodified build_network serves net(example) from the fused engine without any call into this package."""
+    import subprocess
+    import sys
+    import textwrap
+    code = textwrap.dedent(f"""
+        import os, sys
+        sys.path[:0] = [{os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "second.pytorch_amd")!r},
+                        {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r}, {os.path.dirname(os.path.abspath(__file__))!r}]
+        import numpy as np, torch
+        from second_amd import compat
+        compat.install({REF!r})
+        import spconv                                   # installs the hook (SEC_ACCELERATE_MODEL=1)
+        from google.protobuf import text_format
+        from second.protos import pipeline_pb2
+        import second.pytorch.train as train             # imports second.pytorch.models.voxelnet -> VoxelNet.forward is wrapped
+        import oracle_backend
+        from second_amd import synthetic as syn
+        cfg = pipeline_pb2.TrainEvalPipelineConfig()
+        text_format.Merge(open(os.path.join({REF!r}, "second/configs/car.fhd.config")).read(), cfg)
+        cfg.model.second.target_assigner.class_settings[0].nms_pre_max_size = 100
+        with oracle_backend.installed():
+            net = train.build_network(cfg.model.second)
+            cloud = syn.syn_kitti_cloud(0, num_points=3000, num_voxels=2500)
+            vox = net.voxel_generator.generate(cloud, 40000)
+            anchors = net.target_assigner.generate_anchors([1, 200, 176])["anchors"].reshape(1, -1, 7)
+            ex = train.example_convert_to_torch({{"voxels": vox["voxels"], "num_points": vox["num_points_per_voxel"],
+                    "coordinates": np.pad(vox["coordinates"], ((0, 0), (1, 0))), "anchors": anchors}}, torch.float32, torch.device("cpu"))
+            net.train()
+            assert "_second_amd_engine" not in net.__dict__
+            net.eval()
+            with torch.no_grad():
+                out = net(ex)
+            eng = net.__dict__["_second_amd_engine"]
+            assert eng and eng.stats["fused_calls"] == 1 and eng.stats["original_calls"] == 0, eng.stats
+            assert isinstance(out, list) and set(out[0]) == {{"box3d_lidar", "scores", "label_preds", "metadata"}}
+        print("HOOK_OK")
+    """)
+    env = dict(os.environ, SEC_ACCELERATE_MODEL="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "HOOK_OK" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
