@@ -218,3 +218,38 @@ def test_pointpillars_network_is_accelerated_too():
         got = net(ex)
     assert eng.stats["captures"] == 1 and eng.stats["fused_calls"] == 1
     _same(got, want, score_tol=2e-4, box_tol=5e-3, canonical=True)
+
+
+def test_anchor_sets_are_checked_on_the_device_and_followed(car):
+    """The example carries its anchors (voxelnet.py:358).  A new tensor with the same content costs nothing on the host (the
+    comparison runs on the device and its flag travels with the results); a different anchor set shared by the frames is adopted and
+    the call re-run; per-frame anchor sets take the reference's own forward."""
+    from reference_standin import example_of
+    from second_amd import compat
+    make, clouds, small = car
+    net = compat.accelerate_model(make())
+    eng = net._second_amd_engine
+    ex = example_of(net, clouds[:2], "cuda")
+    with torch.no_grad():
+        first = net(ex)
+        ex_b = dict(ex, anchors=ex["anchors"].clone())                    # what a data loader hands over: a fresh tensor per batch
+        again = net(ex_b)
+    assert eng.stats["anchor_refreshes"] == 0 and eng.stats["fused_calls"] == 2
+    _same(again, first)
+    shifted = ex["anchors"].clone()
+    shifted[..., 0] += 0.5                                                # every anchor half a metre further along x
+    ex_c = dict(ex, anchors=shifted)
+    with torch.no_grad():
+        got = net(ex_c)
+        want = net._second_amd_original_forward(ex_c)
+    assert eng.stats["anchor_refreshes"] == 1 and eng.stats["original_calls"] == 0
+    _same(got, want)
+    assert abs(float(got[0]["box3d_lidar"][0, 0] - first[0]["box3d_lidar"][0, 0]) - 0.5) < 1e-3
+    per_frame = ex["anchors"].clone()
+    per_frame[1, :, 1] += 0.25                                            # frame 1 has its own anchor set
+    ex_d = dict(ex, anchors=per_frame)
+    with torch.no_grad():
+        got = net(ex_d)
+        want = net._second_amd_original_forward(ex_d)
+    assert eng.stats["original_calls"] == 1
+    _same(got, want)
