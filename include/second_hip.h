@@ -184,9 +184,16 @@ void sec_conv_output_shape(const int *h_in_shape3, const int *h_ksize3, const in
  * ReLU of second/pytorch/models/middle.py:146-191; bias is a shift with scale = 1).
  *   weight: spconv layout [kD,kH,kW,Cin,Cout] == [K,Cin,Cout], dtype = feature dtype.
  *   packed_weight: result of sec_pack_conv_weight for the MFMA path, or NULL (generic path).
+ *     fp32 features (the reference's default precision, train.py:232-235): the products run on the BF16 matrix pipe with split
+ *     operands -- v = bf16(v) + bf16(v - bf16(v)), x_hi w_hi + x_hi w_lo + x_lo w_hi accumulated in fp32, error <= 3 * 2^-18 per
+ *     product -- for the channel plans of SpMiddleFHD (16->32, 32->32, 32->64, 64->32, 64->64).  With packed_weight = the
+ *     PRE-SPLIT image (sec_packed_weight_x3_bytes(kvol, cin, cout) bytes: per offset k the sec_pack_conv_weight image of bf16(W[k])
+ *     followed by that of bf16(W[k] - bf16(W[k])); 27- and 3-offset kernels) the launch is the software-pipelined inference kernel;
+ *     with NULL the weights are split on the fly (training, data gradients).
  *   num_out_dev: optional device int overriding n_out (static-capacity, sync-free pipelines).
  * --------------------------------------------------------------------------------------------- */
 size_t sec_packed_weight_bytes(int kvol, int cin, int cout, int dtype);
+size_t sec_packed_weight_x3_bytes(int kvol, int cin, int cout);
 int sec_pack_conv_weight(const void *weight, int kvol, int cin, int cout, int dtype, void *packed,
                          void *stream);
 int sec_indice_conv_fwd(const void *features, int n_in, int cin, const void *weight,

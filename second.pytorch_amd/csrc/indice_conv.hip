@@ -1258,6 +1258,294 @@ static bool dispatch_mfma(int cin, int cout, const void *feat, long long n_feat,
     return false;
 }
 
+// fp32 features on the BF16 matrix pipe (round 5): every fp32 operand is split in registers into two bf16 values, v = hi + lo with
+// hi = bf16(v), lo = bf16(v - hi) (16 significant bits), and the product is x_hi w_hi + x_hi w_lo + x_lo w_hi accumulated in fp32 --
+// the form sec_conv2d_nhwc_x3 uses for the RPN; error <= 3 * 2^-18 per product, within the 1e-4 feature tolerance of fp32 networks.
+// The fp32 MFMA (v_mfma_f32_32x32x2_f32: 256 FLOP / clk / CU) makes k_conv_mfma_f32 matrix bound -- 79 us of dense-per-offset work on
+// the 64 -> 64 layer at 56 k rows, 105 us measured; three bf16 MFMAs per product term cost a fifth of that, and the launch becomes what
+// the 16-bit kernels are: bound by the bytes a CU gathers.  Same interface as k_conv_mfma_f32 (fp32 rows in, fp32 rows out, fp32
+// weights [k][ci][co] or their transpose / mirror for the data gradient): the split happens on the way into the MFMA operands --
+// W[k] -> registers -> (hi | lo) B fragments in LDS (double buffered, one barrier per offset; a thread owns 8 input channels of one
+// output channel = one 16-byte fragment piece of each plane), gathered rows -> registers -> (hi, lo) A fragments.  WAVES x 32 rows
+// per workgroup (8 waves: one copy of W[k] per 256 rows; 4 waves for launches that would leave CUs idle).
+template <int CIN, int COUT, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_conv_rows_x3_f32(const float *__restrict__ feat, const float *__restrict__ w,
+                                                                const int *__restrict__ nbr, int n_out, const int *__restrict__ num_out_dev,
+                                                                int kvol, int w_t, int mirror, const float *__restrict__ scale,
+                                                                const float *__restrict__ shift, int relu, float *__restrict__ out) {
+    static_assert(CIN % 16 == 0 && COUT % 32 == 0, "16-channel k-steps, 32-column MFMA tiles");
+    constexpr int KS = CIN / 16, NT = COUT / 32, ROWS = WAVES * 32, NTH = WAVES * 64;
+    constexpr int PIECES = KS * NT * 64;                 // 16-byte fragment pieces of one plane of W[k]: piece = (s, t, lane)
+    constexpr int PPT = (PIECES + NTH - 1) / NTH;        // pieces staged per thread and offset
+    __shared__ __attribute__((aligned(16))) uint4 sB[2][2][PIECES];     // [buffer][hi | lo][piece]
+    __shared__ int s_nbr[ROWS * 27];
+    if (num_out_dev) n_out = *num_out_dev;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const long long base = (long long)blockIdx.x * ROWS;
+    if (base >= n_out) return;
+    {   // the workgroup's slice of the gather table (contiguous), -1 behind the last row
+        const long long lim = ((long long)n_out - base) * kvol;
+        const int *src = nbr + base * kvol;
+        for (int e = tid; e < ROWS * kvol; e += NTH) s_nbr[e] = e < lim ? src[e] : -1;
+    }
+    // piece p = (s * NT + t) * 64 + l holds W[ci = s * 16 + (l >> 5) * 8 + e][co = t * 32 + (l & 31)], e = 0..7
+    float wreg[PPT][8];
+    auto load_w = [&](int k) {
+        const float *wk = w + (size_t)(mirror ? kvol - 1 - k : k) * CIN * COUT;
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            const int p = q * NTH + tid;
+            if (PIECES % NTH != 0 && p >= PIECES) break;
+            const int l = p & 63, st = p >> 6, t = st % NT, sidx = st / NT;
+            const int ci = sidx * 16 + (l >> 5) * 8, co = t * 32 + (l & 31);
+            if (w_t) {
+                const float4 a = *reinterpret_cast<const float4 *>(wk + (size_t)co * CIN + ci);
+                const float4 b = *reinterpret_cast<const float4 *>(wk + (size_t)co * CIN + ci + 4);
+                wreg[q][0] = a.x; wreg[q][1] = a.y; wreg[q][2] = a.z; wreg[q][3] = a.w;
+                wreg[q][4] = b.x; wreg[q][5] = b.y; wreg[q][6] = b.z; wreg[q][7] = b.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) wreg[q][e] = wk[(size_t)(ci + e) * COUT + co];
+            }
+        }
+    };
+    auto split8 = [](const float (&v)[8], uint4 &hi, uint4 &lo) {
+        const unsigned h0 = pack2_16<__hip_bfloat16>(v[0], v[1]), h1 = pack2_16<__hip_bfloat16>(v[2], v[3]);
+        const unsigned h2 = pack2_16<__hip_bfloat16>(v[4], v[5]), h3 = pack2_16<__hip_bfloat16>(v[6], v[7]);
+        hi = make_uint4(h0, h1, h2, h3);
+        lo = make_uint4(pack2_16<__hip_bfloat16>(v[0] - __uint_as_float(h0 << 16), v[1] - __uint_as_float(h0 & 0xffff0000u)),
+                        pack2_16<__hip_bfloat16>(v[2] - __uint_as_float(h1 << 16), v[3] - __uint_as_float(h1 & 0xffff0000u)),
+                        pack2_16<__hip_bfloat16>(v[4] - __uint_as_float(h2 << 16), v[5] - __uint_as_float(h2 & 0xffff0000u)),
+                        pack2_16<__hip_bfloat16>(v[6] - __uint_as_float(h3 << 16), v[7] - __uint_as_float(h3 & 0xffff0000u)));
+    };
+    auto store_w = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) {
+            const int p = q * NTH + tid;
+            if (PIECES % NTH != 0 && p >= PIECES) break;
+            uint4 hi, lo;
+            split8(wreg[q], hi, lo);
+            sB[buf][0][p] = hi;
+            sB[buf][1][p] = lo;
+        }
+    };
+    load_w(0);
+    store_w(0);
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+    // gathers of offset k + 1 are issued before the MFMAs of offset k
+    float4 a[2 * KS], an[2 * KS];
+    auto gather = [&](int k, float4 (&dst)[2 * KS]) -> bool {
+        const int idx = s_nbr[(wave * 32 + r) * kvol + k];
+        const bool any = __ballot(idx >= 0) != 0ull;
+        if (any) {
+            const float4 *row = reinterpret_cast<const float4 *>(feat + (size_t)(idx >= 0 ? idx : 0) * CIN) + 2 * h;
+#pragma unroll
+            for (int sidx = 0; sidx < KS; ++sidx) {
+                dst[2 * sidx] = idx >= 0 ? row[4 * sidx] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                dst[2 * sidx + 1] = idx >= 0 ? row[4 * sidx + 1] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+        }
+        return any;
+    };
+    __syncthreads();                                 // s_nbr and W[0] are visible
+    bool any = gather(0, a);
+    for (int k = 0; k < kvol; ++k) {
+        bool any_next = false;
+        if (k + 1 < kvol) { load_w(k + 1); any_next = gather(k + 1, an); }
+        if (any) {
+            const uint4 *bh = &sB[k & 1][0][lane], *bl = &sB[k & 1][1][lane];
+#pragma unroll
+            for (int sidx = 0; sidx < KS; ++sidx) {
+                const float v[8] = {a[2 * sidx].x, a[2 * sidx].y, a[2 * sidx].z, a[2 * sidx].w,
+                                    a[2 * sidx + 1].x, a[2 * sidx + 1].y, a[2 * sidx + 1].z, a[2 * sidx + 1].w};
+                uint4 ahi, alo;
+                split8(v, ahi, alo);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const uint4 whi = bh[(sidx * NT + t) * 64], wlo = bl[(sidx * NT + t) * 64];
+                    acc[t] = Mfma<__hip_bfloat16>::run(whi, ahi, acc[t]);       // D^T: lane owns row r
+                    acc[t] = Mfma<__hip_bfloat16>::run(wlo, ahi, acc[t]);
+                    acc[t] = Mfma<__hip_bfloat16>::run(whi, alo, acc[t]);
+                }
+            }
+        }
+        if (k + 1 < kvol) store_w((k + 1) & 1);      // the other buffer: every wave left it at the barrier that opened offset k
+#pragma unroll
+        for (int j = 0; j < 2 * KS; ++j) a[j] = an[j];
+        any = any_next;
+        __syncthreads();
+    }
+    // D^T layout: lane owns row r, acc[t][4 g + j] = channel t * 32 + 8 g + 4 h + j
+    const long long row = base + wave * 32 + r;
+    if (row < n_out) {
+        float *orow = out + (size_t)row * COUT;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = t * 32 + 8 * g + 4 * h;
+                float v4[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    v4[j] = epilogue_v(acc[t][4 * g + j], scale ? scale[c + j] : 1.0f, shift ? shift[c + j] : 0.0f, scale != nullptr, shift != nullptr, relu);
+                *reinterpret_cast<float4 *>(orow + c) = make_float4(v4[0], v4[1], v4[2], v4[3]);
+            }
+    }
+}
+
+// The same arithmetic for INFERENCE (weights constant): W is pre-split and pre-packed once per layer -- `wpk` = [k][hi | lo][piece]
+// 16-byte B-fragment pieces (ops.pack_weight on an fp32 weight) -- and the loop is software pipelined DIST offsets deep, because with
+// three cheap MFMA sets per term an offset's arithmetic (~0.3 us) no longer hides a load: the form above, which fetches offset k + 1
+// while offset k multiplies, spent ~1.5 us per offset waiting (55 us for the 23 k-row layers).  Here the gathers and the weight
+// pieces of offset k + DIST are issued while offset k runs (register rings), W[k + 1] goes to the LDS buffer the barrier just freed.
+template <int CIN, int COUT, int WAVES, int KVOL>
+__global__ __launch_bounds__(WAVES * 64) void k_conv_rows_x3p_f32(const float *__restrict__ feat, const uint4 *__restrict__ wpk,
+                                                                 const int *__restrict__ nbr, int n_out, const int *__restrict__ num_out_dev,
+                                                                 const float *__restrict__ scale, const float *__restrict__ shift, int relu,
+                                                                 float *__restrict__ out) {
+    constexpr int KS = CIN / 16, NT = (COUT + 31) / 32, ROWS = WAVES * 32, NTH = WAVES * 64, DIST = 3;   // COUT = 16: one half-used tile (the packed image is zero padded)
+    constexpr int PIECES = KS * NT * 64, PPT = (PIECES + NTH - 1) / NTH;
+    constexpr bool PART = PIECES % NTH != 0;             // fewer pieces than threads: the first PIECES threads stage
+    __shared__ __attribute__((aligned(16))) uint4 sB[2][2][PIECES];
+    __shared__ int s_nbr[ROWS * KVOL];
+    if (num_out_dev) n_out = *num_out_dev;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const long long base = (long long)blockIdx.x * ROWS;
+    if (base >= n_out) return;
+    {
+        const long long lim = ((long long)n_out - base) * KVOL;
+        const int *src = nbr + base * KVOL;
+        for (int e = tid; e < ROWS * KVOL; e += NTH) s_nbr[e] = e < lim ? src[e] : -1;
+    }
+    // threads beyond the last piece (narrow layers) re-stage piece p % PIECES: identical bytes into the same slot, no branch
+    typedef unsigned int u32x4w __attribute__((ext_vector_type(4)));      // (an ext-vector ring stays in registers; a ring of HIP's uint4 structs went to scratch)
+    u32x4w wq[DIST][PPT][2];
+    const u32x4w *wpv = reinterpret_cast<const u32x4w *>(wpk);
+    u32x4w *sBv = reinterpret_cast<u32x4w *>(&sB[0][0][0]);
+#define SEC_LOADW(k_, slot_)                                                                                          \
+    {                                                                                                                 \
+        _Pragma("unroll") for (int q_ = 0; q_ < PPT; ++q_) {                                                          \
+            const int p_ = PART ? (q_ * NTH + tid) % PIECES : q_ * NTH + tid;                                         \
+            wq[slot_][q_][0] = wpv[((size_t)(k_) * 2 + 0) * PIECES + p_];                                             \
+            wq[slot_][q_][1] = wpv[((size_t)(k_) * 2 + 1) * PIECES + p_];                                             \
+        }                                                                                                             \
+    }
+#define SEC_STOREW(buf_, slot_)                                                                                       \
+    {                                                                                                                 \
+        _Pragma("unroll") for (int q_ = 0; q_ < PPT; ++q_) {                                                          \
+            const int p_ = PART ? (q_ * NTH + tid) % PIECES : q_ * NTH + tid;                                         \
+            sBv[((buf_) * 2 + 0) * PIECES + p_] = wq[slot_][q_][0];                                                   \
+            sBv[((buf_) * 2 + 1) * PIECES + p_] = wq[slot_][q_][1];                                                   \
+        }                                                                                                             \
+    }
+    auto split8 = [](const float4 &x, const float4 &y, uint4 &hi, uint4 &lo) {
+        const unsigned h0 = pack2_16<__hip_bfloat16>(x.x, x.y), h1 = pack2_16<__hip_bfloat16>(x.z, x.w);
+        const unsigned h2 = pack2_16<__hip_bfloat16>(y.x, y.y), h3 = pack2_16<__hip_bfloat16>(y.z, y.w);
+        hi = make_uint4(h0, h1, h2, h3);
+        lo = make_uint4(pack2_16<__hip_bfloat16>(x.x - __uint_as_float(h0 << 16), x.y - __uint_as_float(h0 & 0xffff0000u)),
+                        pack2_16<__hip_bfloat16>(x.z - __uint_as_float(h1 << 16), x.w - __uint_as_float(h1 & 0xffff0000u)),
+                        pack2_16<__hip_bfloat16>(y.x - __uint_as_float(h2 << 16), y.y - __uint_as_float(h2 & 0xffff0000u)),
+                        pack2_16<__hip_bfloat16>(y.z - __uint_as_float(h3 << 16), y.w - __uint_as_float(h3 & 0xffff0000u)));
+    };
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
+    // rows without a neighbour read zeros through the buffer's bounds check (no select, no memory access)
+    const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(feat), 0, 0x7ffffffc, 0x00020000);
+    typedef unsigned int u32x4g __attribute__((ext_vector_type(4)));
+    u32x4g areg[DIST][2 * KS];
+    __syncthreads();                                 // s_nbr is visible
+    const int *mine = &s_nbr[(wave * 32 + r) * KVOL];
+#define SEC_GATHER(k_, slot_)                                                                                         \
+    {                                                                                                                 \
+        const int idx_ = mine[k_];                                                                                    \
+        const unsigned off_ = idx_ >= 0 ? (unsigned)idx_ * (CIN * 4u) + h * 32u : 0x80000000u;                        \
+        _Pragma("unroll") for (int s_ = 0; s_ < KS; ++s_) {                                                           \
+            areg[slot_][2 * s_] = __builtin_amdgcn_raw_buffer_load_b128(frs, off_ + s_ * 64, 0, 0);                   \
+            areg[slot_][2 * s_ + 1] = __builtin_amdgcn_raw_buffer_load_b128(frs, off_ + s_ * 64 + 16, 0, 0);          \
+        }                                                                                                             \
+    }
+#pragma unroll
+    for (int k = 0; k < DIST && k < KVOL; ++k) { SEC_LOADW(k, k % DIST) SEC_GATHER(k, k % DIST) }
+    SEC_STOREW(0, 0)
+    if (DIST < KVOL) SEC_LOADW(DIST, 0)              // (ring slot 0 is free again: W[0] sits in LDS)
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < KVOL; ++k) {
+        // W[k + 1] -> the LDS buffer every wave left at the last barrier; its loads were issued DIST - 1 offsets ago
+        if (k + 1 < KVOL) SEC_STOREW((k + 1) & 1, (k + 1) % DIST)
+        if (k + 1 + DIST < KVOL) SEC_LOADW(k + 1 + DIST, (k + 1) % DIST)
+        const uint4 *bh = &sB[k & 1][0][lane], *bl = &sB[k & 1][1][lane];
+#pragma unroll
+        for (int sidx = 0; sidx < KS; ++sidx) {
+            uint4 ahi, alo;
+            split8(__builtin_bit_cast(float4, areg[k % DIST][2 * sidx]), __builtin_bit_cast(float4, areg[k % DIST][2 * sidx + 1]), ahi, alo);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const uint4 whi = bh[(sidx * NT + t) * 64], wlo = bl[(sidx * NT + t) * 64];
+                acc[t] = Mfma<__hip_bfloat16>::run(whi, ahi, acc[t]);           // D^T: lane owns row r
+                acc[t] = Mfma<__hip_bfloat16>::run(wlo, ahi, acc[t]);
+                acc[t] = Mfma<__hip_bfloat16>::run(whi, alo, acc[t]);
+            }
+        }
+        if (k + DIST < KVOL) SEC_GATHER(k + DIST, k % DIST)
+        __syncthreads();
+    }
+#undef SEC_LOADW
+#undef SEC_STOREW
+#undef SEC_GATHER
+    const long long row = base + wave * 32 + r;
+    if (row < n_out) {
+        float *orow = out + (size_t)row * COUT;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = t * 32 + 8 * g + 4 * h;
+                if (c >= COUT) continue;
+                float v4[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    v4[j] = epilogue_v(acc[t][4 * g + j], scale ? scale[c + j] : 1.0f, shift ? shift[c + j] : 0.0f, scale != nullptr, shift != nullptr, relu);
+                *reinterpret_cast<float4 *>(orow + c) = make_float4(v4[0], v4[1], v4[2], v4[3]);
+            }
+    }
+}
+
+// packed (hi | lo) weights of k_conv_rows_x3p_f32: bytes, and whether a shape has an instantiation
+static bool x3p_shape(int cin, int cout, int kvol) {
+    const bool sh = (cin == 16 && cout == 16) || (cin == 16 && cout == 32) || (cin == 32 && cout == 32) || (cin == 32 && cout == 64) ||
+                    (cin == 64 && cout == 32) || (cin == 64 && cout == 64);
+    return sh && (kvol == 27 || (kvol == 3 && cin == 64 && cout == 64));
+}
+
+static bool launch_x3p(const void *feat, long long n_in, const void *wpk, const int *nbr, int n_out, const int *num_out_dev, int cin, int cout,
+                       int kvol, const float *scale, const float *shift, int relu, void *out, hipStream_t st) {
+    if (!x3p_shape(cin, cout, kvol) || n_in * cin * 4 >= 0x7fffffffll) return false;
+#define SEC_X3P(CI, CO, KV)                                                                                                   \
+    if (cin == CI && cout == CO && kvol == KV) {                                                                              \
+        if (n_out >= 40000) {                                                                                                 \
+            set_last_kernel("void sec::k_conv_rows_x3p_f32<%d, %d, 8, %d>", CI, CO, KV);                                      \
+            hipLaunchKernelGGL((k_conv_rows_x3p_f32<CI, CO, 8, KV>), dim3(div_up(n_out, 256)), dim3(512), 0, st, (const float *)feat, \
+                               (const uint4 *)wpk, nbr, n_out, num_out_dev, scale, shift, relu, (float *)out);                \
+        } else {                                                                                                              \
+            set_last_kernel("void sec::k_conv_rows_x3p_f32<%d, %d, 4, %d>", CI, CO, KV);                                      \
+            hipLaunchKernelGGL((k_conv_rows_x3p_f32<CI, CO, 4, KV>), dim3(div_up(n_out, 128)), dim3(256), 0, st, (const float *)feat, \
+                               (const uint4 *)wpk, nbr, n_out, num_out_dev, scale, shift, relu, (float *)out);                \
+        }                                                                                                                     \
+        return true;                                                                                                          \
+    }
+    SEC_X3P(16, 16, 27) SEC_X3P(16, 32, 27) SEC_X3P(32, 32, 27) SEC_X3P(32, 64, 27) SEC_X3P(64, 32, 27) SEC_X3P(64, 64, 27) SEC_X3P(64, 64, 3)
+#undef SEC_X3P
+    return false;
+}
+
 template <typename T, typename OT>
 static bool launch_tiled(const void *feat, const void *w, const int *nbr, int n_out, const int *num_out_dev, int cin, int cout,
                          int kvol, int w_t, int mirror, const float *scale, const float *shift, int relu, void *out,
@@ -1477,6 +1765,24 @@ static bool launch_tiled(const void *feat, const void *w, const int *nbr, int n_
     if constexpr (std::is_same<T, float>::value && std::is_same<OT, float>::value) {
         // fp32 on the matrix cores for the channel plans of SECOND's layers (and their data gradients); g_variant_override 30 keeps
         // the VALU form (parity tests compare the two)
+        // round 5: the split-operand form on the bf16 pipe (k_conv_rows_x3_f32); variant 31 keeps the fp32-MFMA form, 30 the VALU form
+        if (kvol <= 27 && conv_variant() != 30 && conv_variant() != 31) {
+#define SEC_X3(CI, CO)                                                                                                       \
+            if (cin == CI && cout == CO) {                                                                                   \
+                if (n_out >= 40000) {                                                                                        \
+                    set_last_kernel("void sec::k_conv_rows_x3_f32<%d, %d, 8>", CI, CO);                                      \
+                    hipLaunchKernelGGL((k_conv_rows_x3_f32<CI, CO, 8>), dim3(div_up(n_out, 256)), dim3(512), 0, st, (const float *)feat, \
+                                       (const float *)w, nbr, n_out, num_out_dev, kvol, w_t, mirror, scale, shift, relu, (float *)out); \
+                } else {                                                                                                     \
+                    set_last_kernel("void sec::k_conv_rows_x3_f32<%d, %d, 4>", CI, CO);                                      \
+                    hipLaunchKernelGGL((k_conv_rows_x3_f32<CI, CO, 4>), dim3(div_up(n_out, 128)), dim3(256), 0, st, (const float *)feat, \
+                                       (const float *)w, nbr, n_out, num_out_dev, kvol, w_t, mirror, scale, shift, relu, (float *)out); \
+                }                                                                                                            \
+                return true;                                                                                                 \
+            }
+            SEC_X3(16, 32) SEC_X3(32, 32) SEC_X3(32, 64) SEC_X3(64, 32) SEC_X3(64, 64)
+#undef SEC_X3
+        }
         if (kvol <= 27 && conv_variant() != 30) {
 #define SEC_MF(CI, CO)                                                                                                       \
             if (cin == CI && cout == CO) {                                                                                   \
@@ -1849,6 +2155,10 @@ SEC_API int sec_indice_conv_fwd_plan(int cin, int cout, int kvol, int n_out, int
     return PLAN_GENERIC;
 }
 
+SEC_API size_t sec_packed_weight_x3_bytes(int kvol, int cin, int cout) {
+    return x3p_shape(cin, cout, kvol) ? (size_t)kvol * 2 * cin * ((cout + 31) / 32 * 32) * 2 : 0;
+}
+
 SEC_API int sec_indice_conv_fwd(const void *features, int n_in, int cin, const void *weight, const void *packed_weight,
                                 int kvol, int cout, const int *nbr_out, int n_out, const int *num_out_dev,
                                 const float *scale, const float *shift, int relu, void *out, int dtype, int out_dtype,
@@ -1881,6 +2191,10 @@ SEC_API int sec_indice_conv_fwd(const void *features, int n_in, int cin, const v
                        : dispatch_mfma<__half, __half>(cin, cout, features, n_in, packed_weight, nbr_out, n_out, num_out_dev, kvol, scale, shift, relu, out, st);
         }
     }
+    // fp32 features with an x3-packed weight (ops.pack_weight of an fp32 weight: [k][hi | lo] bf16 B-fragment pieces): the pipelined
+    // split-operand kernel; variants 30 / 31 (VALU / fp32-MFMA forms) and 32 (the unpacked split form) ignore the packed image
+    if (!done && packed_weight && dtype == SEC_F32 && out_dtype == SEC_F32 && conv_variant() != 30 && conv_variant() != 31 && conv_variant() != 32)
+        done = launch_x3p(features, n_in, packed_weight, nbr_out, n_out, num_out_dev, cin, cout, kvol, scale, shift, relu, out, st);
     if (!done) {
 #define SEC_GEN(T, OT) launch_generic<T, OT>(features, weight, nbr_out, n_out, num_out_dev, cin, cout, kvol, scale, shift, relu, out, st)
         if (dtype == SEC_F32) SEC_GEN(float, float);

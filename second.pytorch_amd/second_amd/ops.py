@@ -365,10 +365,23 @@ def pack_weight(weight):
     rt.require_gpu(weight)
     cin, cout = weight.shape[-2], weight.shape[-1]
     k = weight.numel() // (cin * cout)
-    if weight.dtype == torch.float32:
-        return None
-    code = rt.dtype_code(weight.dtype)
     l = rt.lib()
+    if weight.dtype == torch.float32:
+        # fp32 layers run on the bf16 matrix pipe with split operands (sec_indice_conv_fwd): per offset the fragment image of
+        # bf16(W) followed by that of bf16(W - bf16(W)); None for shapes without an instantiation (VALU / on-the-fly paths then)
+        if l.sec_packed_weight_x3_bytes(k, cin, cout) == 0:
+            return None
+        w = weight.detach().reshape(k, cin, cout).float().contiguous()
+        hi = w.to(torch.bfloat16)
+        lo = (w - hi.float()).to(torch.bfloat16)
+        planes = []
+        for plane in (hi, lo):
+            img = torch.empty((l.sec_packed_weight_bytes(k, cin, cout, rt.dtype_code(torch.bfloat16)) // 2,), dtype=torch.bfloat16, device=w.device)
+            rt.check(l.sec_pack_conv_weight(rt.ptr(plane.contiguous()), k, cin, cout, rt.dtype_code(torch.bfloat16), rt.ptr(img), rt.stream()),
+                     "sec_pack_conv_weight")
+            planes.append(img.view(k, -1))
+        return torch.stack(planes, 1).contiguous()          # [k][hi | lo][fragment image of one offset]
+    code = rt.dtype_code(weight.dtype)
     nbytes = l.sec_packed_weight_bytes(k, cin, cout, code)
     if nbytes == 0:
         return None

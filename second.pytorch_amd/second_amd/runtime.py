@@ -24,7 +24,7 @@ SYMBOLS = [
     "sec_rulebook_conv3d_build",
     "sec_rulebook_conv3d_tables", "sec_rulebook_sorted_workspace_bytes", "sec_rulebook_conv3d_build_sorted",
     "sec_rulebook_conv3d_tables_sorted", "sec_rulebook_subm3d_after_conv_sorted", "sec_rulebook_chain_workspace_bytes",
-    "sec_rulebook_chain_sorted", "sec_conv_output_shape", "sec_packed_weight_bytes",
+    "sec_rulebook_chain_sorted", "sec_conv_output_shape", "sec_packed_weight_bytes", "sec_packed_weight_x3_bytes",
     "sec_pack_conv_weight", "sec_indice_conv_fwd", "sec_indice_conv_fwd_plan", "sec_indice_conv_set_variant", "sec_indice_conv_bwd_workspace_bytes", "sec_indice_conv_bwd", "sec_pack_conv_weight_train", "sec_sparse_to_dense", "sec_dense_to_sparse", "sec_sparse_site_map", "sec_sparse_site_map_sorted", "sec_conv2d_nhwc_gather", "sec_rpn_tile_live_workspace_bytes", "sec_rpn_tile_live", "sec_rpn_tile_live_masks", "sec_conv2d_nhwc_tiles", "sec_conv2d_nhwc_tiles_lazy", "sec_conv1x1_chain_nhwc_tiles",
     "sec_pillar_scatter", "sec_pfn_fwd", "sec_pfn_fwd_slots", "sec_pfn_train_workspace_bytes", "sec_pfn_train_fwd", "sec_pfn_train_bwd", "sec_block_filter_workspace_bytes",
     "sec_voxel_block_filter_f32", "sec_bias_act_nhwc", "sec_conv2d_packed_weight_bytes",
@@ -128,6 +128,8 @@ def lib():
         l.sec_packed_weight_bytes.argtypes = [ci, ci, ci, ci]
         l.sec_pack_conv_weight.argtypes = [vp, ci, ci, ci, ci, vp, vp]
         l.sec_indice_conv_fwd.argtypes = [vp, ci, ci, vp, vp, ci, ci, vp, ci, vp, vp, vp, ci, vp, ci, ci, vp]
+        l.sec_packed_weight_x3_bytes.argtypes = [ci, ci, ci]
+        l.sec_packed_weight_x3_bytes.restype = sz
         l.sec_indice_conv_fwd_plan.argtypes = [ci] * 7
         l.sec_indice_conv_set_variant.argtypes = [ci]
         l.sec_indice_conv_bwd.argtypes = [vp, ci, ci, vp, ci, ci, vp, vp, ci, vp, vp, vp, ci, vp, sz, vp, vp]

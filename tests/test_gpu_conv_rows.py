@@ -356,12 +356,35 @@ def test_conv_rows_lds_windows_hit_on_sorted_rows(ops, layer, dtype):
         ops.indice_conv_set_variant(-1)
 
 
+def test_indice_conv_fp32_16_to_16_packed_split_form(ops):
+    """The 16 -> 16 layer (subm0 of SpMiddleFHD) has no on-the-fly split kernel; with a pre-split weight it runs the pipelined
+    split-operand kernel on a half-used 32-column tile."""
+    from test_gpu_parity import _random_indices, _tables_from_pairs
+    rng = np.random.default_rng(5)
+    shape = (9, 34, 30)
+    idx = _random_indices(rng, 3, shape, 2500)
+    _, pairs, pair_num = orc.rulebook_subm(idx, 3, shape, 3)
+    nbr, _ = _tables_from_pairs(pairs, pair_num, len(idx), len(idx))
+    feat = rng.standard_normal((len(idx), 16)).astype(np.float32)
+    w = (rng.standard_normal((3, 3, 3, 16, 16)) / np.sqrt(27 * 16)).astype(np.float32)
+    ref = orc.indice_conv(feat, w, pairs, pair_num, len(idx), acc64=True)
+    pk = ops.pack_weight(dev(w))
+    assert pk is not None and tuple(pk.shape[:2]) == (27, 2)
+    scale, shift = rng.uniform(0.5, 1.5, 16).astype(np.float32), rng.uniform(-0.2, 0.2, 16).astype(np.float32)
+    out = ops.indice_conv(dev(feat), dev(w), dev(nbr), len(idx), packed=pk, scale=dev(scale), shift=dev(shift), relu=True)
+    assert "k_conv_rows_x3p_f32<16, 16" in ops.last_kernel_name(), ops.last_kernel_name()
+    want = np.maximum(ref * scale + shift, 0)
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-4, atol=1e-5 * np.abs(ref).max())
+
+
 @pytest.mark.parametrize("cin,cout", [(16, 32), (32, 32), (32, 64), (64, 32), (64, 64)])
 @pytest.mark.parametrize("subm", [True, False])
 def test_indice_conv_fp32_on_the_matrix_cores(ops, cin, cout, subm):
-    """fp32 features (the reference's default precision) on v_mfma_f32_32x32x2_f32 (k_conv_mfma_f32): against the fp64-accumulating
-    oracle within 1e-4 of the range (BASELINE.json's tolerance), against the VALU form (variant 30) to fp32 rounding, ragged row
-    counts, device-side row count below the capacity with garbage table rows behind it, fused scale / shift / ReLU."""
+    """fp32 features (the reference's default precision) on the matrix cores: the split-operand form on the bf16 pipe
+    (k_conv_rows_x3_f32, default since round 5: v = bf16(v) + bf16(v - bf16(v)), three MFMAs per product term, fp32 accumulation) and
+    the fp32-MFMA form (k_conv_mfma_f32, variant 31), each against the fp64-accumulating oracle within 1e-4 of the range
+    (BASELINE.json's tolerance) and against the VALU form (variant 30); ragged row counts, device-side row count below the capacity
+    with garbage table rows behind it, fused scale / shift / ReLU."""
     from test_gpu_parity import _random_indices, _tables_from_pairs
     rng = np.random.default_rng(cin * 7 + cout + int(subm))
     shape = (9, 34, 30)
@@ -378,14 +401,30 @@ def test_indice_conv_fp32_on_the_matrix_cores(ops, cin, cout, subm):
     ref = orc.indice_conv(feat, w, pairs, pair_num, n_out, acc64=True)
     f_t, w_t = dev(feat), dev(w)
     out = ops.indice_conv(f_t, w_t, dev(nbr), n_out)
-    assert "k_conv_mfma_f32" in ops.last_kernel_name(), ops.last_kernel_name()
+    assert "k_conv_rows_x3_f32" in ops.last_kernel_name(), ops.last_kernel_name()
     np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-4, atol=1e-5 * np.abs(ref).max())
+    assert float(np.abs(out.cpu().numpy() - ref).max()) <= 2e-5 * float(np.abs(ref).max())      # an order of magnitude inside the bound
+    # the inference form: weights pre-split and pre-packed once (ops.pack_weight of an fp32 weight), loop pipelined three offsets deep:
+    # the same products in the same order -> bit-identical to the on-the-fly form
+    pk = ops.pack_weight(w_t)
+    assert pk is not None and pk.dtype == torch.bfloat16 and pk.shape[:2] == (27, 2)
+    out_p = ops.indice_conv(f_t, w_t, dev(nbr), n_out, packed=pk)
+    assert "k_conv_rows_x3p_f32" in ops.last_kernel_name(), ops.last_kernel_name()
+    assert torch.equal(out_p, out)
+    ops.indice_conv_set_variant(31)
+    try:
+        mf = ops.indice_conv(f_t, w_t, dev(nbr), n_out)
+        assert "k_conv_mfma_f32" in ops.last_kernel_name(), ops.last_kernel_name()
+    finally:
+        ops.indice_conv_set_variant(-1)
+    np.testing.assert_allclose(mf.cpu().numpy(), ref, rtol=1e-4, atol=1e-5 * np.abs(ref).max())
     ops.indice_conv_set_variant(30)
     try:
         valu = ops.indice_conv(f_t, w_t, dev(nbr), n_out)
     finally:
         ops.indice_conv_set_variant(-1)
-    torch.testing.assert_close(out, valu, rtol=1e-5, atol=1e-5 * float(np.abs(ref).max()))
+    torch.testing.assert_close(out, valu, rtol=1e-4, atol=2e-5 * float(np.abs(ref).max()))
+    torch.testing.assert_close(mf, valu, rtol=1e-5, atol=1e-5 * float(np.abs(ref).max()))
     # static capacity: garbage rows behind the live count, fused epilogue
     cap = n_out + 77
     nbr_pad = np.concatenate([nbr, rng.integers(0, len(idx), (77, 27)).astype(np.int32)])
@@ -394,3 +433,5 @@ def test_indice_conv_fp32_on_the_matrix_cores(ops, cin, cout, subm):
     got = ops.indice_conv(f_t, w_t, dev(nbr_pad), cap, scale=dev(scale), shift=dev(shift), relu=True, num_out_dev=n_dev)
     want = np.maximum(ref * scale + shift, 0)
     np.testing.assert_allclose(got[:n_out].cpu().numpy(), want, rtol=1e-4, atol=1e-5 * np.abs(ref).max())
+    got_p = ops.indice_conv(f_t, w_t, dev(nbr_pad), cap, packed=pk, scale=dev(scale), shift=dev(shift), relu=True, num_out_dev=n_dev)
+    assert torch.equal(got_p[:n_out], got[:n_out])
