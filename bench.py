@@ -881,7 +881,7 @@ def time_scene_density(args, main_value, budget_s=150.0):
             res[key] = {"skipped": "time budget"}
             continue
         cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup), "--inflight", str(args.inflight),
-               "--serialize-rpn", str(args.serialize_rpn), "--rpn-tokens", str(args.rpn_tokens), "--no-kernel-table", "--no-cpu-baseline",
+               "--serialize-rpn", str(args.serialize_rpn), "--rpn-tokens", str(args.rpn_tokens), "--dtype", args.dtype, "--no-kernel-table", "--no-cpu-baseline",
                "--no-extra-lines", "--no-other-configs", *extra]
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)

@@ -416,6 +416,16 @@ int sec_split_f32_bf16x2(const float *x, long long n, void *hi, void *lo, void *
 int sec_merge_bf16x2_f32(const void *hi, const void *lo, long long n, float *y, void *stream);
 int sec_conv2d_nhwc_x3(const void *x_hi, const void *x_lo, int batch, int h, int w, const void *packed_weight_hi_lo,
                        const float *bias, int cout, int relu, void *y_hi, void *y_lo, void *stream);
+/* ... on the tiles a site of the sparse middle can reach only (the fp32 counterpart of sec_conv2d_nhwc_tiles / _tiles_lazy; same
+ * lists, masks and semantics, every image as a (hi, lo) plane pair): tile_order / live_counts = one layer of sec_rpn_tile_live;
+ * background_hi / _lo (both or neither) = this layer's output for an EMPTY frame, copied into the tiles that are not live (NULL: they
+ * are left unwritten, for a lazy consumer); nbr_masks (may be NULL: x holds every tile) + background_in_hi / _lo = the PRODUCING
+ * layer's empty-frame output, read for halo pixels of tiles the producer did not write.  Bit-identical to sec_conv2d_nhwc_x3 on
+ * the full image. */
+int sec_conv2d_nhwc_x3_tiles(const void *x_hi, const void *x_lo, int batch, int h, int w, const void *packed_weight_hi_lo,
+                             const float *bias, int cout, int relu, const unsigned short *tile_order, const int *live_counts,
+                             const void *background_hi, const void *background_lo, const unsigned short *nbr_masks,
+                             const void *background_in_hi, const void *background_in_lo, void *y_hi, void *y_lo, void *stream);
 
 /* Fused tail of the RPN at inference: y = W2 * act(W1 * x + bias1) + bias2 over `pixels` channels-last pixels with
  * 128 input and 128 intermediate channels -- the 1x1/stride-1 ConvTranspose2d deblock with folded BatchNorm + ReLU

@@ -372,7 +372,9 @@ __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(con
                                                             const T *__restrict__ background = nullptr,
                                                             const unsigned short *__restrict__ nbr_masks = nullptr,
                                                             const T *__restrict__ bg_in = nullptr,
-                                                            const T *__restrict__ x_lo = nullptr, T *__restrict__ y_lo = nullptr) {
+                                                            const T *__restrict__ x_lo = nullptr, T *__restrict__ y_lo = nullptr,
+                                                            const T *__restrict__ background_lo = nullptr,
+                                                            const T *__restrict__ bg_in_lo = nullptr) {
     static_assert(!GATHER || (ROLL == 2 && CIN == 128), "gather prologue: the shared-row loop on two 64-channel planes");
     static_assert(!X3 || (ROLL == 2 && CIN == 128 && TH == 8 && !GATHER && NSPLIT == 1 && std::is_same<T, __hip_bfloat16>::value),
                   "three-pass split-fp32 form: the shared-row bf16 loop");
@@ -455,13 +457,13 @@ __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(con
     // was live there; pixels of a tile that was not come from `bg_in` = that layer's output for an EMPTY frame ([h][w][CIN]) at the
     // same position -- exactly what the producer's copy would have put into `x`.  Both sources share the byte
     // offsets; a lane issues ONE of the two DMAs (the lanes are the LDS slots, an inactive lane writes nothing).
-    auto issue_halo2_lazy = [&](int tile, unsigned nmask) {
+    auto issue_halo2_lazy = [&](int tile, unsigned nmask, const T *xsrc, const T *bgsrc) {
         const int b = tile / (tiles_y * tiles_x);
         const int trem = tile - b * tiles_y * tiles_x;
         const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
         const unsigned img_bytes = (unsigned)p.h * (unsigned)p.w * (CIN * 2u);
-        const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(x) + (size_t)b * p.h * p.w * CIN, 0, (int)img_bytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t ers = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(bg_in), 0, (int)img_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(xsrc) + (size_t)b * p.h * p.w * CIN, 0, (int)img_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t ers = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(bgsrc), 0, (int)img_bytes, 0x00020000);
         const int wvs = __builtin_amdgcn_readfirstlane(wv);
         const unsigned slot = lane & 15;
         const unsigned row_pitch = (unsigned)p.w * (CIN * 2u);
@@ -604,8 +606,10 @@ __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(con
                 constexpr int kCopyTiles = 4;
                 const int n_bg = ntile - n_live;
                 const int px = tid >> 4, ch = tid & 15;
-                const uint4 *e4 = reinterpret_cast<const uint4 *>(background);
-                uint4 *y4 = reinterpret_cast<uint4 *>(y);
+#pragma unroll 1
+              for (int plane = 0; plane < (X3 ? 2 : 1); ++plane) {       // X3: the residual plane of the empty frame's map too
+                const uint4 *e4 = reinterpret_cast<const uint4 *>(plane ? background_lo : background);
+                uint4 *y4 = reinterpret_cast<uint4 *>(plane ? y_lo : y);
                 auto bg_tile = [&](int it) -> int {              // background item -> tile index over the batch, -1 past the end
                     if (it >= n_bg) return -1;
                     int f = 0;
@@ -615,7 +619,7 @@ __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(con
 #pragma unroll 1
                 for (int q = 0; q < kCopyTiles; q += 2) {
                     const int t0 = bg_tile(item * kCopyTiles + q), t1 = bg_tile(item * kCopyTiles + q + 1);
-                    if (t0 < 0) return;
+                    if (t0 < 0) break;
                     uint4 v[2][TH];
                     size_t dst[2];
 #pragma unroll
@@ -641,6 +645,7 @@ __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(con
                             if (y0 + ty_ < p.h) y4[dst[u] + (size_t)ty_ * p.w * (p.cout / 8)] = v[u][ty_];
                     }
                 }
+              }
                 return;
             }
         }
@@ -694,7 +699,7 @@ __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(con
             return;
         }
     } else if constexpr (ROLL >= 2) {
-        if (nbr_masks) issue_halo2_lazy(tile, nmask);
+        if (nbr_masks) issue_halo2_lazy(tile, nmask, x, bg_in);
         else issue_halo2(tile, x);
     } else issue_halo(tile);
 #ifdef SEC_CONV_TIMELINE
@@ -778,7 +783,8 @@ __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(con
                     if (X3 && pass > 0) {
                         if (pass == 2) {
                             __syncthreads();                    // every wave is done reading x_hi's halo
-                            issue_halo2(tile, x_lo);
+                            if (nbr_masks) issue_halo2_lazy(tile, nmask, x_lo, bg_in_lo);
+                            else issue_halo2(tile, x_lo);
                         }
 #pragma unroll
                         for (int f = 0; f < RD - 1; ++f) br[f] = ld_b(wp + (f % 3) * 48 + (f / 3) * 2);
@@ -1011,7 +1017,8 @@ static int launch_conv2d_halo_reg(const void *x, const void *wpk, const float *b
                                   const int *site_map = nullptr, unsigned feat_bytes = 0, const unsigned short *tile_order = nullptr,
                                   const int *live_counts = nullptr, const void *background = nullptr,
                                   const unsigned short *nbr_masks = nullptr, const void *bg_in = nullptr,
-                                  const void *x_lo = nullptr, void *y_lo = nullptr) {
+                                  const void *x_lo = nullptr, void *y_lo = nullptr, const void *background_lo = nullptr,
+                                  const void *bg_in_lo = nullptr) {
     constexpr size_t lds_tile = (size_t)(TH + 2) * 18 * (CIN / 8) * 16;
     // (padding the dynamic LDS to hold 2 instead of 3 workgroups per CU was measured in round 3: slower in every combination)
     const long lds_pad = 0;
@@ -1029,7 +1036,8 @@ static int launch_conv2d_halo_reg(const void *x, const void *wpk, const float *b
     else if (NSPLIT == 1) set_last_kernel("k_conv2d_halo_reg<%s, %d, %d, %d, %s>", dtype_name<T>(), CIN, TH, ROLL, GATHER ? "true" : "false");
     else set_last_kernel("k_conv2d_halo_reg<%s, %d, %d, %d, %s, %d>", dtype_name<T>(), CIN, TH, ROLL, GATHER ? "true" : "false", NSPLIT);
     hipLaunchKernelGGL(fn, dim3(gx, p.cout / (128 / NSPLIT)), dim3(256), lds, st, (const T *)x, (const T *)wpk, bias, (T *)y, p, ty, tx, per_xcd,
-                       site_map, feat_bytes, tile_order, live_counts, (const T *)background, nbr_masks, (const T *)bg_in, (const T *)x_lo, (T *)y_lo);
+                       site_map, feat_bytes, tile_order, live_counts, (const T *)background, nbr_masks, (const T *)bg_in, (const T *)x_lo, (T *)y_lo,
+                       (const T *)background_lo, (const T *)bg_in_lo);
     return check_launch();
 }
 
@@ -1732,6 +1740,25 @@ SEC_API int sec_conv2d_nhwc_x3(const void *x_hi, const void *x_lo, int batch, in
     p.m = (long long)batch * h * w;
     return launch_conv2d_halo_reg<__hip_bfloat16, 128, 8, 2, false, 1, true>(x_hi, packed_weight_hi_lo, bias, y_hi, p, (hipStream_t)stream, nullptr, 0,
                                                                               nullptr, nullptr, nullptr, nullptr, nullptr, x_lo, y_lo);
+}
+
+SEC_API int sec_conv2d_nhwc_x3_tiles(const void *x_hi, const void *x_lo, int batch, int h, int w, const void *packed_weight_hi_lo,
+                                     const float *bias, int cout, int relu, const unsigned short *tile_order, const int *live_counts,
+                                     const void *background_hi, const void *background_lo, const unsigned short *nbr_masks,
+                                     const void *background_in_hi, const void *background_in_lo, void *y_hi, void *y_lo, void *stream) {
+    if (!x_hi || !x_lo || !packed_weight_hi_lo || !y_hi || !y_lo || !tile_order || !live_counts || batch <= 0 || h <= 0 || w <= 0) return SEC_E_INVALID;
+    if ((background_hi == nullptr) != (background_lo == nullptr)) return SEC_E_INVALID;
+    if (nbr_masks && (!background_in_hi || !background_in_lo)) return SEC_E_INVALID;
+    if (cout % 128 || (long long)h * w * 256 >= (1ll << 31)) return SEC_E_UNSUPPORTED;
+    apply_list_threshold_env();
+    Conv2dParams p;
+    p.batch = batch; p.h = h; p.w = w; p.cin = 128; p.cout = cout; p.ksize = 3; p.stride = 1; p.pad = 1;
+    p.relu = relu & 1; p.zskip = 0; p.stagger = 0;
+    p.ho = h; p.wo = w;
+    p.m = (long long)batch * h * w;
+    return launch_conv2d_halo_reg<__hip_bfloat16, 128, 8, 2, false, 1, true>(x_hi, packed_weight_hi_lo, bias, y_hi, p, (hipStream_t)stream, nullptr, 0,
+                                                                              tile_order, live_counts, background_hi, nbr_masks, background_in_hi,
+                                                                              x_lo, y_lo, background_lo, background_in_lo);
 }
 
 SEC_API int sec_conv2d_nhwc_gather(const void *features, long long feature_rows, const int *site_map, int batch, int h, int w,

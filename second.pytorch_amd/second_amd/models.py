@@ -625,6 +625,8 @@ class RPNInference(nn.Module):
                 pk = {i: ops.conv2d_pack_weight_x3(self.ws[i]) for i in convs}
                 if all(v is not None for v in pk.values()):
                     self.packed_x3 = pk
+                    self._x3_convs = len(convs) if (convs == list(range(len(convs))) and 2 <= len(convs) <= 8
+                                                    and all(self.ws[i].shape[0] == 128 for i in convs)) else 0
         # deblock (1x1, stride 1, 128 -> 128) + heads (<= 128 padded channels) run as ONE kernel (sec_conv1x1_chain_nhwc)
         wl = self.ws[-1]
         self.sparse_input = True   # forward()'s input comes from SparseConvTensor.dense(): all-zero halo tiles skip their MFMA loop (bit-identical)
@@ -656,6 +658,8 @@ class RPNInference(nn.Module):
         self.background_convs = len(convs) if (
             self.gather_packed is not None and 2 <= len(convs) <= 8 and convs == list(range(len(convs)))
             and all(tuple(self.ws[i].shape) == (128, 128, 3, 3) and self.cfgs[i] == ([1, 1], [1, 1]) and self.ups[i] == 1 for i in convs)) else 0
+        if self.packed_x3 is not None:          # fp32: the same live-tile machinery on the split-operand convs (always the lazy form)
+            self.background_convs = getattr(self, "_x3_convs", 0)
 
     # The packed weight images (MFMA slab order, the gather permutation, the hi | lo pairs of the fp32 form) are derived from the
     # folded parameters at construction: keep them in step with the parameters.  In place, so that captured graphs stay valid.
@@ -728,14 +732,50 @@ class RPNInference(nn.Module):
             y = y.permute(0, 3, 1, 2)        # a channels_last [B,co,H*u,W*u] tensor
         return y
 
+    def empty_frame_maps_x3(self, h, w):
+        """(hi, lo) plane pairs of every 3x3 conv's output for a frame WITHOUT sites, from the split-operand kernel itself (a copied or
+        lazily read tile is then bit-identical to a computed one).  Cached per map size and weight version; not inside a capture."""
+        src = [self.ws[i] for i in self.packed_x3] + [self.bs[i] for i in self.packed_x3]
+        key = ("x3", int(h), int(w), str(self.ws[0].device), tuple((t.data_ptr(), t._version) for t in src))
+        if key not in self._empty_maps:
+            assert not torch.cuda.is_current_stream_capturing(), "RPNInference.empty_frame_maps_x3: run one eager forward before capturing"
+            self._empty_maps = {k: v for k, v in self._empty_maps.items() if k[0] != "x3"}
+            dev = self.ws[0].device
+            with torch.no_grad():
+                z = torch.zeros((1, 128, h, w), dtype=torch.bfloat16, device=dev).contiguous(memory_format=torch.channels_last)
+                hi, lo, maps = z, z.clone(), []
+                for kind, i in self.plan:
+                    if kind == "c":
+                        hi, lo = ops.conv2d_nhwc_x3(hi, lo, self.packed_x3[i], self.bs[i], self.ws[i].shape[0], relu=True)
+                        maps.append((hi, lo))
+            self._empty_maps[key] = maps
+        return self._empty_maps[key]
+
     def _forward_x3(self, x):
-        """fp32 activations as bf16 (hi, lo) plane pairs through the 3x3 convs; merged back to fp32 for the 1x1 tail."""
+        """fp32 activations as bf16 (hi, lo) plane pairs through the 3x3 convs; merged back to fp32 for the 1x1 tail.  Given the sparse
+        middle's rows (a SparseBEV) the convs run on the tiles a site can reach only, exactly like the 16-bit path: conv j computes
+        the tiles within j + 1 steps of a site, reads halo pixels of unwritten tiles from the empty frame's planes, and only the last
+        conv materialises its background (the torch 1x1 tail reads the whole map)."""
+        lists = None
         if isinstance(x, SparseBEV):
+            convs = [i for kind, i in self.plan if kind == "c"]
+            if self.background_convs and self.skip_background and convs == list(range(len(convs))):
+                sm = x.site_map()
+                empty = self.empty_frame_maps_x3(sm.shape[2], sm.shape[3])
+                live, self.last_live_counts, nbr = x.tile_lists(self.background_convs, masks=True)
+                lists = (live, nbr, empty)
             x = x.dense()
         hi, lo = ops.split_bf16x2(x.float().contiguous(memory_format=torch.channels_last))
         first, ups = self.sparse_input, []
         for kind, i in self.plan:
-            if kind == "c":
+            if kind == "c" and lists is not None:
+                live, nbr, empty = lists
+                last = i == self.background_convs - 1
+                hi, lo = ops.conv2d_nhwc_x3_tiles(hi, lo, self.packed_x3[i], self.bs[i], self.ws[i].shape[0], live[i], self.last_live_counts[i],
+                                                  background=empty[i] if last else None, relu=True,
+                                                  nbr_masks=nbr[i] if (i > 0 and nbr is not None) else None,
+                                                  background_in=empty[i - 1] if (i > 0 and nbr is not None) else None)
+            elif kind == "c":
                 hi, lo = ops.conv2d_nhwc_x3(hi, lo, self.packed_x3[i], self.bs[i], self.ws[i].shape[0], relu=True, sparse_input=first)
                 first = False
             else:
@@ -890,11 +930,17 @@ class SecondDetector(nn.Module):
         if dt is not None:
             spatial = self.middle_feature_extractor(voxel_features.to(dt), coors, batch_size, channels_last=True,
                                                     num_active_dev=num_active_dev, site_table=site_table,
-                                                    bev_sparse=getattr(self.rpn, "gather_packed", None) is not None)
+                                                    bev_sparse=self._rpn_takes_rows())
         else:
             spatial = self.middle_feature_extractor(voxel_features, coors, batch_size, num_active_dev=num_active_dev,
                                                     site_table=site_table)
         return self.rpn(spatial)
+
+    def _rpn_takes_rows(self):
+        """The RPN consumes the sparse middle's rows + site map (SparseBEV) instead of the dense image: the 16-bit gathered first conv, or
+        the fp32 split-operand convs on live tiles."""
+        return getattr(self.rpn, "gather_packed", None) is not None or (
+            getattr(self.rpn, "packed_x3", None) is not None and getattr(self.rpn, "background_convs", 0) > 0)
 
     def forward(self, example):
         voxels, num_points, coors = example["voxels"], example["num_points"], example["coordinates"]
@@ -1059,7 +1105,7 @@ class SecondDetector(nn.Module):
                     spatial = self.middle_feature_extractor(vox["mean"].to(self._infer_dtype), vox["coordinates"], batch_size,
                                                             channels_last=True, num_active_dev=vox["voxel_offsets"][batch_size:],
                                                             site_table=vox.get("site_table"),
-                                                            bev_sparse=getattr(self.rpn, "gather_packed", None) is not None)
+                                                            bev_sparse=self._rpn_takes_rows())
                     self._branch_overflow = [list(getattr(self.middle_feature_extractor, "last_overflow_checks", []))]
                     if isinstance(spatial, SparseBEV) and getattr(self.rpn, "background_convs", 0) and self.rpn.skip_background:
                         spatial.tile_lists(self.rpn.background_convs,      # the live-tile lists belong to the latency-bound segment

@@ -795,6 +795,41 @@ def conv2d_nhwc_x3(x_hi, x_lo, packed_hi_lo, bias, cout, relu=True, sparse_input
     return y_hi, y_lo
 
 
+@_traced("conv2d_nhwc_x3_tiles")
+def conv2d_nhwc_x3_tiles(x_hi, x_lo, packed_hi_lo, bias, cout, tile_order, live_counts, background=None, relu=True, nbr_masks=None,
+                         background_in=None):
+    """:func:`conv2d_nhwc_x3` on the live tiles of one layer of :func:`rpn_tile_live` only (sec_conv2d_nhwc_x3_tiles; the fp32
+    counterpart of :func:`conv2d_nhwc_tiles`).  ``background`` = (hi, lo) planes of this layer's output for an EMPTY frame, copied into
+    the other tiles (None: they stay unwritten, for a lazy consumer); ``nbr_masks`` + ``background_in`` = (hi, lo) of the producing
+    layer's empty-frame output: halo pixels of tiles the producer did not write are read from it."""
+    rt.require_gpu(x_hi, x_lo, packed_hi_lo, tile_order, live_counts)
+    assert x_hi.dim() == 4 and x_hi.shape[1] == 128 and x_hi.dtype == x_lo.dtype == torch.bfloat16 and x_hi.shape == x_lo.shape
+    assert x_hi.is_contiguous(memory_format=torch.channels_last) and x_lo.is_contiguous(memory_format=torch.channels_last)
+    b, _, h, w = x_hi.shape
+    tiles = ((h + 7) // 8) * ((w + 15) // 16)
+    assert tile_order.dtype == torch.int16 and tile_order.is_contiguous() and tuple(tile_order.shape) == (b, tiles)
+    assert live_counts.dtype == torch.int32 and live_counts.is_contiguous() and live_counts.numel() == b
+    for pair, ch in ((background, int(cout)), (background_in, 128)):
+        if pair is not None:
+            for t in pair:
+                rt.require_gpu(t)
+                assert t.dtype == torch.bfloat16 and t.numel() == h * w * ch and t.is_contiguous(memory_format=torch.channels_last)
+    if nbr_masks is not None:
+        assert background_in is not None and nbr_masks.dtype == torch.int16 and nbr_masks.is_contiguous() and tuple(nbr_masks.shape) == (2, b, tiles)
+    y_hi = torch.empty((b, int(cout), h, w), dtype=torch.bfloat16, device=x_hi.device, memory_format=torch.channels_last)
+    y_lo = torch.empty_like(y_hi)
+    if POISON_LAZY_OUTPUTS and background is None:
+        y_hi.fill_(float("nan"))
+        y_lo.fill_(float("nan"))
+    bg, bgi = background or (None, None), background_in or (None, None)
+    rc = rt.lib().sec_conv2d_nhwc_x3_tiles(rt.ptr(x_hi), rt.ptr(x_lo), b, h, w, rt.ptr(packed_hi_lo), rt.ptr(bias), int(cout), int(bool(relu)),
+                                           rt.ptr(tile_order), rt.ptr(live_counts), rt.ptr(bg[0]), rt.ptr(bg[1]),
+                                           rt.ptr(nbr_masks) if nbr_masks is not None else None, rt.ptr(bgi[0]), rt.ptr(bgi[1]),
+                                           rt.ptr(y_hi), rt.ptr(y_lo), rt.stream())
+    rt.check(rc, "sec_conv2d_nhwc_x3_tiles")
+    return y_hi, y_lo
+
+
 @_traced("sparse_site_map")
 def sparse_site_map(indices, batch_size, spatial_shape, num_dev=None):
     """[B, D, H, W] int32 map of a sparse tensor's sites: row + 1, 0 = no active site (input of :func:`conv2d_nhwc_gather`)."""

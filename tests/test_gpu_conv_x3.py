@@ -98,3 +98,67 @@ def test_fp32_rpn_inference_on_split_convs_matches_the_torch_block():
         a, b = got[k].float().cpu().numpy(), want[k].float().cpu().numpy()
         assert a.shape == b.shape
         np.testing.assert_allclose(a, b, rtol=1e-4, atol=1e-4 * float(np.abs(b).max()), err_msg=k)
+
+
+def _sites(batch, h, w, n, seed):
+    g = torch.Generator().manual_seed(seed)
+    idx = torch.stack([torch.randint(0, batch, (n,), generator=g), torch.randint(0, 2, (n,), generator=g),
+                       torch.randint(0, max(h // 3, 1), (n,), generator=g), torch.randint(0, w, (n,), generator=g)], 1).int()
+    idx[:4, 2] = torch.tensor([0, 0, h - 1, h - 1])                      # the four corners too
+    idx[:4, 3] = torch.tensor([0, w - 1, 0, w - 1])
+    if batch > 1:
+        idx = idx[idx[:, 0] != batch - 1]                                # the last frame stays empty
+    return torch.unique(idx, dim=0)
+
+
+@pytest.mark.parametrize("batch,h,w,n", [(3, 200, 176, 700), (2, 37, 50, 12), (2, 120, 97, 4000)])
+def test_fp32_rpn_on_live_tiles_is_bit_identical_to_the_full_convolutions(batch, h, w, n):
+    """RPNInference(float32) fed the sparse middle's rows (SparseBEV): conv j convolves the tiles within j + 1 steps of a site only
+    (sec_conv2d_nhwc_x3_tiles), reads halo pixels of unwritten tiles from the empty frame's planes, the last conv fills in its
+    background -- the head outputs must equal the full split-operand convolutions BIT FOR BIT on a network whose background is not
+    zero, with the unwritten tiles poisoned with NaN."""
+    import spconv
+    from second_amd import ops
+    from second_amd.models import RPNV2, RPNInference, SparseBEV
+    torch.manual_seed(0)
+    rpn = RPNV2().eval()
+    g = torch.Generator().manual_seed(4)
+    for m in rpn.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.copy_(torch.empty_like(m.running_mean).uniform_(-0.3, 0.1, generator=g))
+            m.running_var.copy_(torch.empty_like(m.running_var).uniform_(0.5, 1.5, generator=g))
+            m.bias.data.uniform_(-0.1, 0.3, generator=g)                   # a non-zero background and border imprint
+    inf = RPNInference(rpn.cuda(), torch.float32)
+    assert inf.packed_x3 is not None and inf.background_convs == 6
+    idx = _sites(batch, h, w, n, seed=h + n).cuda()
+    feats = torch.randn(idx.shape[0], 64, generator=g).abs().cuda()
+    sp = spconv.SparseConvTensor(feats, idx, [2, h, w], batch)
+    merged = []          # the fp32 map behind the last 3x3 conv (what the torch 1x1 tail reads): compared bit for bit; the heads behind
+    #                      the tail within 1e-5 (torch may pick another fp32 1x1 algorithm from one call to the next)
+
+    def run(x):
+        ops.set_op_hook(lambda name, fn, a, kw, res: merged.append(res.clone()) if name == "merge_bf16x2" else None)
+        try:
+            with torch.no_grad():
+                return {k: v.float().clone() for k, v in inf(x).items()}
+        finally:
+            ops.set_op_hook(None)
+    inf.skip_background = False
+    want = run(SparseBEV(sp))
+    dense = run(sp.dense_channels_last_2d())
+    inf.skip_background = True
+    ops.POISON_LAZY_OUTPUTS = True
+    try:
+        got = run(SparseBEV(sp))
+    finally:
+        ops.POISON_LAZY_OUTPUTS = False
+    live = inf.last_live_counts.cpu().numpy()
+    tiles = ((h + 7) // 8) * ((w + 15) // 16)
+    assert live.shape == (6, batch) and (batch == 1 or (live[:, -1] == 0).all())
+    assert live[0].sum() < batch * tiles or n > 3000
+    assert len(merged) == 3 and torch.equal(merged[0], merged[1])
+    assert torch.isfinite(merged[2]).all(), "an unwritten (NaN-poisoned) tile reached the last conv's output"
+    assert torch.equal(merged[2], merged[0])
+    for k in want:
+        torch.testing.assert_close(dense[k], want[k], rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(got[k], want[k], rtol=1e-5, atol=1e-6)
