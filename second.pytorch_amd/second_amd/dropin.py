@@ -199,8 +199,13 @@ class FusedVoxelNet:
         return out
 
     def _weights_key(self):
+        """Cheap per-call fingerprint of the three sub-modules' parameters and buffers: every tensor's version counter (in-place
+        updates: load_state_dict, optimizer steps) plus storage / dtype / device of a few sentinels (`.half()`, `.to()` replace
+        them all at once)."""
         w = self._watch
-        return (sum(t._version for t in w), sum(t.data_ptr() for t in w), w[0].dtype if w else None, self.net.rpn.conv_cls.weight.dtype)
+        heads = self.net.rpn.conv_cls.weight
+        sent = (w[0], w[len(w) // 2], w[-1], heads)
+        return (sum(t._version for t in w), len(w), tuple((t.data_ptr(), t.dtype, t.device) for t in sent))
 
     def run_dtype(self):
         """None = fp32 pipeline; torch.float16 / torch.bfloat16 = 16-bit features (BatchNorm statistics, biases, box decode and
@@ -217,7 +222,7 @@ class FusedVoxelNet:
         key = self._weights_key()
         if self._det is not None and key == self._wkey:
             return self._det
-        self._watch = self._tensors()
+        self._watch = self._tensors()          # (parameters may have been replaced as objects: re-enumerate, then fingerprint again)
         key = self._weights_key()
         net = self.net
         dev = net.rpn.conv_cls.weight.device
