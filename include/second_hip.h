@@ -422,6 +422,11 @@ int sec_conv2d_nhwc_x3(const void *x_hi, const void *x_lo, int batch, int h, int
  * are left unwritten, for a lazy consumer); nbr_masks (may be NULL: x holds every tile) + background_in_hi / _lo = the PRODUCING
  * layer's empty-frame output, read for halo pixels of tiles the producer did not write.  Bit-identical to sec_conv2d_nhwc_x3 on
  * the full image. */
+/* The fused 1x1 tail (sec_conv1x1_chain_nhwc: deblock + merged heads, rpn.py:275-285,386-391) for fp32 networks: x as (hi, lo) bf16
+ * planes [pixels][128] (the output of the last sec_conv2d_nhwc_x3), both weight sets as sec_conv2d_pack_weight(bf16(W)) followed by
+ * sec_conv2d_pack_weight(bf16(W - bf16(W))) (ksize 1) + 16 zero bytes, the heads as fp32 [pixels][cout2], cout2 in {64, 128}. */
+int sec_conv1x1_chain_x3(const void *x_hi, const void *x_lo, long long pixels, const void *packed_w1_hi_lo, const float *bias1,
+                         int relu1, const void *packed_w2_hi_lo, const float *bias2, int cout2, float *y, void *stream);
 int sec_conv2d_nhwc_x3_tiles(const void *x_hi, const void *x_lo, int batch, int h, int w, const void *packed_weight_hi_lo,
                              const float *bias, int cout, int relu, const unsigned short *tile_order, const int *live_counts,
                              const void *background_hi, const void *background_lo, const unsigned short *nbr_masks,

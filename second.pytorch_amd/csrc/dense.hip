@@ -1315,6 +1315,134 @@ __global__ __launch_bounds__(256, 3) void k_conv1x1_chain(const T *__restrict__ 
     }
 }
 
+// The fused 1x1 tail for fp32 networks (sec_conv1x1_chain_x3): the same two GEMMs with every operand as a (hi, lo) bf16 pair and
+// three MFMAs per product term (x_hi w_hi + x_hi w_lo + x_lo w_hi, fp32 accumulation; see k_conv2d_halo_reg<..., X3>).  The last
+// split-operand 3x3 conv hands over its two planes; the bias + ReLU'd intermediate is split again into two LDS tiles; the heads leave
+// as fp32 [pixels][64 * NT2].  What it replaces: merging the planes to fp32 (41 us) and two fp32 GEMMs / MIOpen 1x1 convolutions with
+// their bias / ReLU passes (~280 us for 14 GFLOP at batch 8).
+template <int NT2>
+__global__ __launch_bounds__(256, 2) void k_conv1x1_chain_x3(const __hip_bfloat16 *__restrict__ x_hi, const __hip_bfloat16 *__restrict__ x_lo,
+                                                             const __hip_bfloat16 *__restrict__ w1pk, const float *__restrict__ b1,
+                                                             const __hip_bfloat16 *__restrict__ w2pk, const float *__restrict__ b2,
+                                                             float *__restrict__ y, long long m, int relu1) {
+    using T = __hip_bfloat16;
+    constexpr int BM = 128, C = 128, CH = C / 8, N2 = 64 * NT2;
+    __shared__ uint4 tile[2][BM * CH];              // [plane][pixel][16-byte chunk ^ (pixel & 15)]: x, then relu(W1 x + b1)
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const long long m0 = (long long)blockIdx.x * BM;
+    const uint4 *w1 = reinterpret_cast<const uint4 *>(w1pk);          // [hi | lo][cin8][128]
+    const uint4 *w2 = reinterpret_cast<const uint4 *>(w2pk);          // [hi | lo][cin8][N2]
+    const uint4 *zero16 = w1 + (size_t)2 * CH * C;
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+        const uint4 *x4 = reinterpret_cast<const uint4 *>(pl ? x_lo : x_hi);
+#pragma unroll
+        for (int j = 0; j < BM * CH / 64 / 4; ++j) {
+            const int e = (j * 4 + wv) * 64 + lane, px = e / CH, slot = e - px * CH;
+            const uint4 *src = m0 + px < m ? x4 + (m0 + px) * CH + (slot ^ (px & 15)) : zero16;
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)&tile[pl][(j * 4 + wv) * 64], 16, 0, 0);
+        }
+    }
+    // GEMM 1: this wave = all 128 pixels x mid channels [32 wv, 32 wv + 32)
+    uint4 bh[8], bl[8];
+    {
+        const uint4 *wl = w1 + (size_t)hh * C + wv * 32 + r;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) { bh[s] = wl[(size_t)s * 2 * C]; bl[s] = wl[(size_t)CH * C + (size_t)s * 2 * C]; }
+    }
+    f32x16d acc[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[a][i] = 0.0f;
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int px = mt * 32 + r, at = px * CH + ((s * 2 + hh) ^ (px & 15));
+            const uint4 ahi = tile[0][at], alo = tile[1][at];
+            acc[mt] = MfmaD<T>::run(bh[s], ahi, acc[mt]);
+            acc[mt] = MfmaD<T>::run(bl[s], ahi, acc[mt]);
+            acc[mt] = MfmaD<T>::run(bh[s], alo, acc[mt]);
+        }
+    const int wm = wv & 1, wn = wv >> 1;
+    lds_barrier();                                  // every wave has read all of x
+    {   // intermediate -> the two LDS tiles (bias, ReLU in fp32, then hi / residual): lane owns pixel mt*32 + r, channels 32 wv + 8 g + 4 hh + (0..3)
+        unsigned char *tbh = reinterpret_cast<unsigned char *>(tile[0]), *tbl = reinterpret_cast<unsigned char *>(tile[1]);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 bv = *reinterpret_cast<const float4 *>(b1 + wv * 32 + 8 * g + 4 * hh);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int px = mt * 32 + r;
+                float v[4] = {acc[mt][4 * g] + bv.x, acc[mt][4 * g + 1] + bv.y, acc[mt][4 * g + 2] + bv.z, acc[mt][4 * g + 3] + bv.w};
+                if (relu1 & 1) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = __builtin_fmaxf(v[j], 0.0f);
+                }
+                const unsigned h0 = pack2<T>(v[0], v[1]), h1 = pack2<T>(v[2], v[3]);
+                const size_t at = ((size_t)px * CH + ((wv * 4 + g) ^ (px & 15))) * 16 + hh * 8;
+                *reinterpret_cast<uint2 *>(tbh + at) = make_uint2(h0, h1);
+                *reinterpret_cast<uint2 *>(tbl + at) =
+                    make_uint2(pack2<T>(v[0] - __uint_as_float(h0 << 16), v[1] - __uint_as_float(h0 & 0xffff0000u)),
+                               pack2<T>(v[2] - __uint_as_float(h1 << 16), v[3] - __uint_as_float(h1 & 0xffff0000u)));
+            }
+        }
+    }
+    // second-GEMM weights: wave = 64 pixels (wm) x N2 / 2 couts (wn)
+    uint4 ch_[8][NT2], cl_[8][NT2];
+    {
+        const uint4 *wl = w2 + (size_t)hh * N2 + wn * (N2 / 2) + r;
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int nt = 0; nt < NT2; ++nt) {
+                ch_[s][nt] = wl[(size_t)s * 2 * N2 + nt * 32];
+                cl_[s][nt] = wl[(size_t)CH * N2 + (size_t)s * 2 * N2 + nt * 32];
+            }
+    }
+    lds_barrier();
+    f32x16d acc2[2][NT2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < NT2; ++c)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc2[a][c][i] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int px = wm * 64 + mt * 32 + r, at = px * CH + ((s * 2 + hh) ^ (px & 15));
+            const uint4 ahi = tile[0][at], alo = tile[1][at];
+#pragma unroll
+            for (int nt = 0; nt < NT2; ++nt) {
+                acc2[mt][nt] = MfmaD<T>::run(ch_[s][nt], ahi, acc2[mt][nt]);
+                acc2[mt][nt] = MfmaD<T>::run(cl_[s][nt], ahi, acc2[mt][nt]);
+                acc2[mt][nt] = MfmaD<T>::run(ch_[s][nt], alo, acc2[mt][nt]);
+            }
+        }
+    // D^T: lane owns pixel wm*64 + mt*32 + r, per group g four consecutive channels c0 + 8 g + 4 hh + (0..3): fp32, 16-byte stores
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const long long pix = m0 + wm * 64 + mt * 32 + r;
+        if (pix >= m) continue;
+        float *ypix = y + (size_t)pix * N2;
+#pragma unroll
+        for (int nt = 0; nt < NT2; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = wn * (N2 / 2) + nt * 32 + 8 * g + 4 * hh;
+                float4 bv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (b2) bv = *reinterpret_cast<const float4 *>(b2 + c);
+                *reinterpret_cast<float4 *>(ypix + c) = make_float4(acc2[mt][nt][4 * g] + bv.x, acc2[mt][nt][4 * g + 1] + bv.y,
+                                                                    acc2[mt][nt][4 * g + 2] + bv.z, acc2[mt][nt][4 * g + 3] + bv.w);
+            }
+    }
+}
+
 template <typename T>
 static int launch_conv1x1_chain_tiles(const void *x, int batch, int h, int w, const void *w1, const float *b1, const void *w2, const float *b2,
                                       int cout2, int relu1, const unsigned short *tile_order, const int *live_counts, const void *background,
@@ -1790,6 +1918,22 @@ SEC_API int sec_conv1x1_chain_nhwc(const void *x, long long pixels, const void *
     if (dtype == SEC_BF16)
         return launch_conv1x1_chain<__hip_bfloat16>(x, pixels, packed_w1, bias1, packed_w2, bias2, cout2, relu1, y, st);
     return launch_conv1x1_chain<__half>(x, pixels, packed_w1, bias1, packed_w2, bias2, cout2, relu1, y, st);
+}
+
+SEC_API int sec_conv1x1_chain_x3(const void *x_hi, const void *x_lo, long long pixels, const void *packed_w1_hi_lo, const float *bias1, int relu1,
+                                 const void *packed_w2_hi_lo, const float *bias2, int cout2, float *y, void *stream) {
+    if (!x_hi || !x_lo || !packed_w1_hi_lo || !packed_w2_hi_lo || !bias1 || !y || pixels < 0) return SEC_E_INVALID;
+    if (cout2 != 64 && cout2 != 128) return SEC_E_UNSUPPORTED;
+    if (pixels == 0) return SEC_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int blocks = (int)div_up(pixels, 128);
+    if (cout2 == 64)
+        hipLaunchKernelGGL((k_conv1x1_chain_x3<1>), dim3(blocks), dim3(256), 0, st, (const __hip_bfloat16 *)x_hi, (const __hip_bfloat16 *)x_lo,
+                           (const __hip_bfloat16 *)packed_w1_hi_lo, bias1, (const __hip_bfloat16 *)packed_w2_hi_lo, bias2, y, pixels, relu1);
+    else
+        hipLaunchKernelGGL((k_conv1x1_chain_x3<2>), dim3(blocks), dim3(256), 0, st, (const __hip_bfloat16 *)x_hi, (const __hip_bfloat16 *)x_lo,
+                           (const __hip_bfloat16 *)packed_w1_hi_lo, bias1, (const __hip_bfloat16 *)packed_w2_hi_lo, bias2, y, pixels, relu1);
+    return check_launch();
 }
 
 SEC_API int sec_conv1x1_chain_nhwc_tiles(const void *x, int batch, int h, int w, const void *packed_w1, const float *bias1, int relu1,

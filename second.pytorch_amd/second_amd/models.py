@@ -627,6 +627,15 @@ class RPNInference(nn.Module):
                     self.packed_x3 = pk
                     self._x3_convs = len(convs) if (convs == list(range(len(convs))) and 2 <= len(convs) <= 8
                                                     and all(self.ws[i].shape[0] == 128 for i in convs)) else 0
+                    # the 1x1 deblock + merged heads as ONE split-operand launch (sec_conv1x1_chain_x3) when the shapes allow
+                    wl_ = self.ws[-1]
+                    self.chain_x3 = None
+                    if (self.plan[-1][0] == "u" and tuple(wl_.shape) == (128, 128, 1, 1) and self.cfgs[-1] == ([1, 1], [0, 0])
+                            and self.ups[-1] == 1 and hw.shape[0] <= 64):
+                        pad = 64 - hw.shape[0]
+                        hw64 = torch.cat([hw, torch.zeros(pad, *hw.shape[1:], device=hw.device)], 0).contiguous()
+                        hb64 = torch.cat([hb, torch.zeros(pad, device=hb.device)]).contiguous()
+                        self.chain_x3 = [ops.conv2d_pack_weight_x3(wl_), ops.conv2d_pack_weight_x3(hw64), hb64]
         # deblock (1x1, stride 1, 128 -> 128) + heads (<= 128 padded channels) run as ONE kernel (sec_conv1x1_chain_nhwc)
         wl = self.ws[-1]
         self.sparse_input = True   # forward()'s input comes from SparseConvTensor.dense(): all-zero halo tiles skip their MFMA loop (bit-identical)
@@ -678,6 +687,12 @@ class RPNInference(nn.Module):
             if self.packed_x3 is not None:
                 for i, pk in self.packed_x3.items():
                     pk.copy_(ops.conv2d_pack_weight_x3(self.ws[i]))
+                if getattr(self, "chain_x3", None) is not None:
+                    pad = 64 - self.head_w.shape[0]
+                    hw64 = torch.cat([self.head_w.detach().float(), torch.zeros(pad, *self.head_w.shape[1:], device=self.head_w.device)], 0)
+                    self.chain_x3[0].copy_(ops.conv2d_pack_weight_x3(self.ws[-1]))
+                    self.chain_x3[1].copy_(ops.conv2d_pack_weight_x3(hw64.contiguous()))
+                    self.chain_x3[2][:self.head_b.numel()].copy_(self.head_b)
         self._empty_maps.clear()
 
     def _apply(self, fn, *a, **k):
@@ -689,6 +704,8 @@ class RPNInference(nn.Module):
                 setattr(self, name, move(getattr(self, name)))
         if self.packed_x3 is not None:
             self.packed_x3 = {i: move(t) for i, t in self.packed_x3.items()}
+            if getattr(self, "chain_x3", None) is not None:
+                self.chain_x3 = [move(t) for t in self.chain_x3]
         self._empty_maps.clear()
         return self
 
@@ -793,6 +810,9 @@ class RPNInference(nn.Module):
             elif kind == "c":
                 hi, lo = ops.conv2d_nhwc_x3(hi, lo, self.packed_x3[i], self.bs[i], self.ws[i].shape[0], relu=True, sparse_input=first)
                 first = False
+            elif getattr(self, "chain_x3", None) is not None:
+                w1, w2, b2 = self.chain_x3            # deblock + heads in one launch, straight from the two planes
+                return self._split_heads(ops.conv1x1_chain_x3(hi, lo, w1, self.bs[i], w2, b2, 64, relu1=True))
             else:
                 ups.append(self._conv(ops.merge_bf16x2(hi, lo), i))
         f = ups[0] if len(ups) == 1 else torch.cat(ups, dim=1)

@@ -795,6 +795,22 @@ def conv2d_nhwc_x3(x_hi, x_lo, packed_hi_lo, bias, cout, relu=True, sparse_input
     return y_hi, y_lo
 
 
+@_traced("conv1x1_chain_x3")
+def conv1x1_chain_x3(x_hi, x_lo, packed_w1, bias1, packed_w2, bias2, cout2, relu1=True):
+    """y = W2 * act(W1 * x + bias1) + bias2 on fp32 values carried as (hi, lo) bf16 planes (sec_conv1x1_chain_x3): x_hi / x_lo
+    [B,128,H,W] channels_last bf16 -> fp32 [B, cout2, H, W] channels_last.  Weights: :func:`conv2d_pack_weight_x3` of the [C,128,1,1]
+    tensors (cout2 padded to 64 / 128)."""
+    rt.require_gpu(x_hi, x_lo, packed_w1, packed_w2)
+    assert x_hi.dim() == 4 and x_hi.shape[1] == 128 and x_hi.dtype == x_lo.dtype == torch.bfloat16 and x_hi.shape == x_lo.shape
+    assert x_hi.is_contiguous(memory_format=torch.channels_last) and x_lo.is_contiguous(memory_format=torch.channels_last)
+    b, _, h, w = x_hi.shape
+    y = torch.empty((b, int(cout2), h, w), dtype=torch.float32, device=x_hi.device, memory_format=torch.channels_last)
+    rc = rt.lib().sec_conv1x1_chain_x3(rt.ptr(x_hi), rt.ptr(x_lo), b * h * w, rt.ptr(packed_w1), rt.ptr(bias1), int(bool(relu1)),
+                                       rt.ptr(packed_w2), rt.ptr(bias2), int(cout2), rt.ptr(y), rt.stream())
+    rt.check(rc, "sec_conv1x1_chain_x3")
+    return y
+
+
 @_traced("conv2d_nhwc_x3_tiles")
 def conv2d_nhwc_x3_tiles(x_hi, x_lo, packed_hi_lo, bias, cout, tile_order, live_counts, background=None, relu=True, nbr_masks=None,
                          background_in=None):

@@ -28,7 +28,7 @@ SYMBOLS = [
     "sec_pack_conv_weight", "sec_indice_conv_fwd", "sec_indice_conv_fwd_plan", "sec_indice_conv_set_variant", "sec_indice_conv_bwd_workspace_bytes", "sec_indice_conv_bwd", "sec_pack_conv_weight_train", "sec_sparse_to_dense", "sec_dense_to_sparse", "sec_sparse_site_map", "sec_sparse_site_map_sorted", "sec_conv2d_nhwc_gather", "sec_rpn_tile_live_workspace_bytes", "sec_rpn_tile_live", "sec_rpn_tile_live_masks", "sec_conv2d_nhwc_tiles", "sec_conv2d_nhwc_tiles_lazy", "sec_conv1x1_chain_nhwc_tiles",
     "sec_pillar_scatter", "sec_pfn_fwd", "sec_pfn_fwd_slots", "sec_pfn_train_workspace_bytes", "sec_pfn_train_fwd", "sec_pfn_train_bwd", "sec_block_filter_workspace_bytes",
     "sec_voxel_block_filter_f32", "sec_bias_act_nhwc", "sec_conv2d_packed_weight_bytes",
-    "sec_conv2d_pack_weight", "sec_conv2d_nhwc", "sec_split_f32_bf16x2", "sec_merge_bf16x2_f32", "sec_conv2d_nhwc_x3", "sec_conv2d_nhwc_x3_tiles", "sec_conv1x1_chain_nhwc", "sec_rotate_iou_f32", "sec_nms_workspace_bytes", "sec_nms_sorted_f32",
+    "sec_conv2d_pack_weight", "sec_conv2d_nhwc", "sec_split_f32_bf16x2", "sec_merge_bf16x2_f32", "sec_conv2d_nhwc_x3", "sec_conv2d_nhwc_x3_tiles", "sec_conv1x1_chain_x3", "sec_conv1x1_chain_nhwc", "sec_rotate_iou_f32", "sec_nms_workspace_bytes", "sec_nms_sorted_f32",
     "sec_predict_select", "sec_predict_decode", "sec_predict_finalize",
     "sec_assign_targets_workspace_bytes", "sec_assign_targets_f32", "sec_assign_targets_per_class_f32",
     "sec_second_loss_workspace_bytes", "sec_second_loss_f32",
@@ -152,6 +152,7 @@ def lib():
         l.sec_split_f32_bf16x2.argtypes = [vp, ctypes.c_longlong, vp, vp, vp]
         l.sec_merge_bf16x2_f32.argtypes = [vp, vp, ctypes.c_longlong, vp, vp]
         l.sec_conv2d_nhwc_x3.argtypes = [vp, vp, ci, ci, ci, vp, vp, ci, ci, vp, vp, vp]
+        l.sec_conv1x1_chain_x3.argtypes = [vp, vp, ctypes.c_longlong, vp, vp, ci, vp, vp, ci, vp, vp]
         l.sec_conv2d_nhwc_x3_tiles.argtypes = [vp, vp, ci, ci, ci, vp, vp, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         l.sec_sparse_site_map.argtypes = [vp, ci, vp, ci, ci, ci, ci, vp, vp]
         l.sec_sparse_site_map_sorted.argtypes = [vp, ctypes.c_size_t, vp, ci, ci, ci, ci, ci, vp, vp]

@@ -133,11 +133,10 @@ def test_fp32_rpn_on_live_tiles_is_bit_identical_to_the_full_convolutions(batch,
     idx = _sites(batch, h, w, n, seed=h + n).cuda()
     feats = torch.randn(idx.shape[0], 64, generator=g).abs().cuda()
     sp = spconv.SparseConvTensor(feats, idx, [2, h, w], batch)
-    merged = []          # the fp32 map behind the last 3x3 conv (what the torch 1x1 tail reads): compared bit for bit; the heads behind
-    #                      the tail within 1e-5 (torch may pick another fp32 1x1 algorithm from one call to the next)
+    merged = []          # the (hi, lo) planes behind the last 3x3 conv (what the fused 1x1 tail reads), as fp32: compared bit for bit
 
     def run(x):
-        ops.set_op_hook(lambda name, fn, a, kw, res: merged.append(res.clone()) if name == "merge_bf16x2" else None)
+        ops.set_op_hook(lambda name, fn, a, kw, res: merged.append(a[0].float() + a[1].float()) if name == "conv1x1_chain_x3" else None)
         try:
             with torch.no_grad():
                 return {k: v.float().clone() for k, v in inf(x).items()}
@@ -159,6 +158,26 @@ def test_fp32_rpn_on_live_tiles_is_bit_identical_to_the_full_convolutions(batch,
     assert len(merged) == 3 and torch.equal(merged[0], merged[1])
     assert torch.isfinite(merged[2]).all(), "an unwritten (NaN-poisoned) tile reached the last conv's output"
     assert torch.equal(merged[2], merged[0])
-    for k in want:
-        torch.testing.assert_close(dense[k], want[k], rtol=1e-5, atol=1e-6)
-        torch.testing.assert_close(got[k], want[k], rtol=1e-5, atol=1e-6)
+    for k in want:                                   # the tail is one deterministic launch on identical planes
+        assert torch.equal(dense[k], want[k]), k
+        assert torch.equal(got[k], want[k]), k
+
+
+def test_conv1x1_chain_x3_matches_fp64():
+    """sec_conv1x1_chain_x3: y = W2 relu(W1 x + b1) + b2 on (hi, lo) planes vs float64 on the same fp32 inputs (pixel count not a
+    multiple of the 128-pixel workgroup tile)."""
+    from second_amd import ops
+    g = torch.Generator().manual_seed(7)
+    b, h, w = 2, 37, 45
+    x = torch.randn(b, 128, h, w, generator=g).clamp_min(0) * 2.0
+    w1 = torch.randn(128, 128, 1, 1, generator=g) * 0.1
+    b1 = torch.randn(128, generator=g) * 0.3
+    w2 = torch.randn(64, 128, 1, 1, generator=g) * 0.1
+    w2[20:] = 0                                                   # padded head channels
+    b2 = torch.randn(64, generator=g)
+    ref = F.conv2d(F.conv2d(x.double(), w1.double(), b1.double()).clamp_min(0), w2.double(), b2.double())
+    hi, lo = ops.split_bf16x2(x.cuda().contiguous(memory_format=torch.channels_last))
+    y = ops.conv1x1_chain_x3(hi, lo, ops.conv2d_pack_weight_x3(w1.cuda()), b1.cuda(), ops.conv2d_pack_weight_x3(w2.cuda()), b2.cuda(), 64)
+    assert y.dtype == torch.float32 and y.shape == (b, 64, h, w) and y.is_contiguous(memory_format=torch.channels_last)
+    err = float((y.cpu().double() - ref).abs().max()) / float(ref.abs().max())
+    assert err <= 2e-5, err
