@@ -105,7 +105,7 @@ __global__ __launch_bounds__(kSelThreads) void k_predict_select(const T *__restr
                                                                 float score_thr, const unsigned *__restrict__ keys,
                                                                 int *__restrict__ top_idx,
                                                                 float *__restrict__ top_score, int *__restrict__ top_label,
-                                                                int *__restrict__ counts) {
+                                                                int *__restrict__ counts, unsigned thr_key = 0u) {
     __shared__ unsigned hist[256];
     __shared__ unsigned ckey[kSelThreads];
     __shared__ int cidx[kSelThreads];
@@ -122,7 +122,33 @@ __global__ __launch_bounds__(kSelThreads) void k_predict_select(const T *__restr
     constexpr int UNR = 8;                       // independent key loads in flight per thread
     const int first_shift = 24, last_shift = sizeof(T) == 2 && KEY16 ? 16 : 0;
     unsigned prefix = 0, mask = 0, need = K;
-    for (int shift = first_shift; shift >= last_shift; shift -= 8) {
+    // Threshold shortcut (round 5; the 16-bit paths have had it since round 3): `thr_key` is a key no larger than that of any logit
+    // whose sigmoid reaches the score threshold.  A trained head leaves a few hundred such anchors per frame: when they are at most
+    // K, they ARE the selection (rows behind counts[b] are unspecified by contract), and the four radix sweeps are skipped.
+    bool shortcut = false;
+    if (thr_key > 1u) {
+        if (tid == 0) hist[0] = 0u;
+        __syncthreads();
+        unsigned c = 0;
+        for (int n0 = 0; n0 < N; n0 += kSelThreads * UNR) {
+            unsigned kk[UNR];
+#pragma unroll
+            for (int j = 0; j < UNR; ++j) {
+                const int n = n0 + j * kSelThreads + tid;
+                kk[j] = n < N ? fk[n] : 0u;
+            }
+#pragma unroll
+            for (int j = 0; j < UNR; ++j) c += kk[j] >= thr_key ? 1u : 0u;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+        if (lane == 0 && c) atomicAdd(&hist[0], c);
+        __syncthreads();
+        shortcut = hist[0] <= (unsigned)K;
+        __syncthreads();
+        if (shortcut) { prefix = thr_key - 1u; need = 0u; }
+    }
+    for (int shift = first_shift; !shortcut && shift >= last_shift; shift -= 8) {
         for (int i = tid; i < 256; i += kSelThreads) hist[i] = 0;
         __syncthreads();
         for (int n0 = 0; n0 < N; n0 += kSelThreads * UNR) {
@@ -760,9 +786,18 @@ SEC_API int sec_predict_select(const void *cls, const int64_t *h_cls_strides5, i
     do {                                                                                                                        \
         hipLaunchKernelGGL(k_predict_keys<T>, dim3(div_up(total, kBlock)), dim3(kBlock), 0, st, (const T *)cls, v, g, key_scratch); \
             hipLaunchKernelGGL((k_predict_select<T, K16>), dim3(batch), dim3(kSelThreads), 0, st, (const T *)cls, v, g, k,        \
-                               score_thr, key_scratch, top_idx, top_score, top_label, counts);                                   \
+                               score_thr, key_scratch, top_idx, top_score, top_label, counts, thr_key32);                        \
     } while (0)
     const long long nfr = (long long)anchors_per_loc * h * w;
+    // 32-bit key of a logit safely below the score threshold's (k_predict_select's shortcut; 0: none)
+    unsigned thr_key32 = 0u;
+    if (score_thr > 0.0f && score_thr < 1.0f) {
+        float x = logf(score_thr / (1.0f - score_thr));
+        x -= fabsf(x) * 1e-4f + 1e-5f;
+        unsigned u;
+        __builtin_memcpy(&u, &x, 4);
+        thr_key32 = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    }
     // 16-bit heads (bf16 / fp16): register-resident select on 16-bit keys
     static int use_thr = -1, chunked = -1;
     if (use_thr < 0) use_thr = 1;

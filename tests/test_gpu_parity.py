@@ -1229,14 +1229,15 @@ def test_predict_select_tie_ranking(levels, k, dtype):
 
 
 @pytest.mark.parametrize("dtype,a,h,w", [(torch.bfloat16, 2, 200, 176), (torch.float16, 2, 200, 176), (torch.float16, 20, 248, 248),
-                                         (torch.bfloat16, 12, 200, 200)])
+                                         (torch.bfloat16, 12, 200, 200), (torch.float32, 2, 200, 176)])
 @pytest.mark.parametrize("thr", [0.05, 0.3, 0.5, 0.9])
 def test_predict_select_threshold_shortcut(thr, dtype, a, h, w):
     """A trained-like head: a few hundred anchors per frame above the score threshold, logits spread around it (some within one
     bf16 step of the threshold's logit, some exactly on it).  The selection with the threshold shortcut (no bisection when at most
     k keys reach the threshold's conservative 16-bit key; csrc/predict.hip) equals the stable-sort reference entry for entry up
     to counts[b], for a frame with fewer than k candidates, one with none and one with far more than k -- for bf16 and fp16 heads
-    (fp16 keys are the half's own bits) and for heads large enough to take the 73 728-anchor chunks."""
+    (fp16 keys are the half's own bits), for heads large enough to take the 73 728-anchor chunks, and for fp32 heads (the 32-bit
+    radix select's shortcut on a conservative 32-bit threshold key, round 5)."""
     from second_amd import ops
     b = 3                                           # (a, h, w): car.fhd's head, nuScenes all.fhd's (1.23 M anchors: 73 728-anchor
     n = a * h * w                                   # chunks), a 480 k-anchor head (59 chunks of 8192); bf16 and fp16 keys
