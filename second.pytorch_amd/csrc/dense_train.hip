@@ -38,19 +38,31 @@ template <> __device__ __forceinline__ __half f2t(float v) { return __float2half
 // Weight gradient of the 3x3 / stride 1 / pad 1 convolution, Cin = Cout = 128 (every 3x3 layer of the car.fhd / nuScenes-fhd RPN):
 //     dW[tap][ci][co] = sum over pixels p of  X[p + offset(tap)][ci] * dY[p][co]
 // a GEMM whose contraction runs over the PIXELS (K = B*H*W = 140 800 at batch 4) and whose result is tiny (9 x 128 x 128), so the
-// work is split over (pixel range, tap): blockIdx.y = tap, blockIdx.x = a run of `steps` 64-pixel steps.  Both MFMA operands need 8
-// consecutive pixels per lane for one channel -- the transpose of channels-last memory -- so every step stages X^T and dY^T in LDS
-// ([channel][pixel], 144-byte pitch: conflict-free ds_read_b128): a thread loads the same 8 channels of 4 consecutive pixels (four
-// 16-byte loads), transposes the 4 x 8 block in registers (v_perm_b32) and stores eight 8-byte runs.  Double-buffered: the loads of
-// step s + 1 are in flight while the 64 MFMAs of step s run; one barrier per step.  A wave owns a 32-row ci tile x all 128 co
-// (4 accumulators).  Every workgroup writes its 128 x 128 fp32 partial to the workspace; k_conv2d_wgrad_reduce sums the partials of a
-// tap in a fixed order (deterministic -- no float atomics) into torch's [Cout][Cin][3][3] layout.
-template <typename T>
+// work is split over (pixel range, tap): a workgroup = one tap of a run of `steps` 64-pixel steps.  Both MFMA operands need 8
+// consecutive PIXELS per lane for one channel -- the transpose of channels-last memory.  The first form of this kernel transposed in
+// registers: a thread loaded 8 channels of 4 consecutive pixels, so one wave instruction gathered sixteen 64-byte half lines; the
+// texture path spent ~50 cycles on each (TA busy 63 % of the launch, MFMA busy 0.19, 88 us -- profiles/r05_h_wgrad_pmc.txt), and
+// neither a deeper prefetch nor fewer LDS reads moved it.  This form loads FULL lines (sixteen lanes = the 256 bytes of one pixel),
+// stores them untransposed ([pixel][channel], ds_write_b128, the 16-byte chunk index XOR-ed with 4 * (pixel & 3)) and lets the LDS
+// transpose on the way out: ds_read_b64_tr_b16 hands lane i of a 16-lane group column i of a 4-pixel x 16-channel block, i.e. four
+// pixels of ONE channel -- two of them are an MFMA operand.  (The order of the eight pixels inside an operand does not matter: A and B
+// are read the same way.)  With the XOR the four pixel rows of a 32-lane read group fall into four different 64-byte bank windows.
+// Three register stages of loads in flight (buffer loads, out-of-range offset = zero fill for the padding and the tail: a
+// conditional global load compiles to a branch with s_waitcnt vmcnt(0) behind it), LDS double-buffered, one barrier per step.  A wave
+// owns a 64 (ci) x 64 (co) quadrant.  Every workgroup writes its 128 x 128 fp32 partial to the workspace; k_conv2d_wgrad_reduce sums
+// the partials of a tap in a fixed order (deterministic -- no float atomics) into torch's [Cout][Cin][3][3] layout.
+typedef short ts16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned tu32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint2 lds_tr16_b64(const char *p) {
+    const ts16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ts16x4 __attribute__((address_space(3))) *)p);
+    return __builtin_bit_cast(uint2, v);
+}
+template <typename T, bool NARROW>   // NARROW: maps less than 16 pixels wide (the coordinate advance of 16 pixels may wrap more than one row)
 __global__ __launch_bounds__(256, 2) void k_conv2d_wgrad3x3(const T *__restrict__ x, const T *__restrict__ dy, float *__restrict__ part,
                                                             int B, int H, int W, int steps, long long P, int slices, int ntaps) {
-    constexpr int C = 128, LD = 72;                        // LD: 64 pixels + 8 pad (144-byte rows)
-    __shared__ __attribute__((aligned(16))) T sX[2][C][LD];
-    __shared__ __attribute__((aligned(16))) T sD[2][C][LD];
+    constexpr int C = 128, PIXB = C * 2;                   // 256 bytes per pixel
+    __shared__ __attribute__((aligned(16))) char sX[2][64 * PIXB];
+    __shared__ __attribute__((aligned(16))) char sD[2][64 * PIXB];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     // The nine taps of a pixel slice read the same 2 x 650 KB of x and dy: workgroup id = (group of 8 slices) * 72 + tap * 8 + xcd puts
@@ -64,74 +76,114 @@ __global__ __launch_bounds__(256, 2) void k_conv2d_wgrad3x3(const T *__restrict_
     const long long step0 = (long long)slice * steps;
     const long long total_steps = (P + 63) / 64;
     const int nst = (int)(step0 + steps <= total_steps ? steps : (total_steps > step0 ? total_steps - step0 : 0));
-    // this thread stages channels chg*8.. of pixels pg*4..pg*4+3 of a step.  The PIXEL group runs fastest across lanes: the sixteen
-    // lanes of a ds_write_b64 group then store 128 contiguous bytes of one channel row (conflict-free); with the channel group fastest
-    // (fully coalesced 256-byte global reads) all sixteen hit ONE bank -- rows are 8 x 144 bytes apart -- and the kernel ran at 175 us
-    // instead of ~50.  The global reads are 64-byte segments this way (four channel groups per wave and pixel); the other waves read the
-    // rest of the same lines.
-    const int pg = tid & 15, chg = tid >> 4;
-    const uint4 *x4 = reinterpret_cast<const uint4 *>(x), *d4 = reinterpret_cast<const uint4 *>(dy);
-    const long long HW = (long long)H * W;
-    uint4 rx[4], rd[4];
-    auto fetch = [&](int s) {
-        const long long q0 = (step0 + s) * 64 + pg * 4;
-        const int b = (int)(q0 / HW);
-        const int rem = (int)(q0 - (long long)b * HW);
-        int yy = rem / W, xx = rem - yy * W, bb = b;
+    const unsigned tensor_bytes = (unsigned)(P * PIXB);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(x), 0, (int)tensor_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(dy), 0, (int)tensor_bytes, 0x00020000);
+    // staging: this thread moves chunk `cq` (16 bytes = 8 channels) of the pixels pl, pl + 16, pl + 32, pl + 48 of a step
+    const int cq = tid & 15, pl = tid >> 4;
+    // running coordinates of the NEXT step to fetch (pixel pl of it); they only ever advance by 16 pixels -- no divisions in the loop
+    unsigned fq;
+    int fx, fy, fb;
+    {
+        fq = (unsigned)(step0 * 64 + pl);
+        const unsigned HW = (unsigned)H * (unsigned)W;
+        fb = (int)(fq / HW);
+        const unsigned rem = fq - (unsigned)fb * HW;
+        fy = (int)(rem / (unsigned)W);
+        fx = (int)(rem - (unsigned)fy * (unsigned)W);
+    }
+    int fs = 0;                                             // index of the next step to fetch
+    tu32x4 ra_x[4], ra_d[4], rb_x[4], rb_d[4], rc_x[4], rc_d[4];
+    auto fetch = [&](tu32x4 (&rx)[4], tu32x4 (&rd)[4]) {
+        const bool oks = fs < nst;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const long long q = q0 + i;
-            const bool okp = q < P;
-            rd[i] = okp ? d4[q * (C / 8) + chg] : make_uint4(0, 0, 0, 0);
-            const int sy = yy + ty, sx = xx + tx;
+            const bool okp = oks && (long long)fq < P;
+            rd[i] = __builtin_amdgcn_raw_buffer_load_b128(drs, okp ? fq * (unsigned)PIXB + cq * 16u : 0xfffffff0u, 0, 0);
+            const int sy = fy + ty, sx = fx + tx;
             const bool okx = okp && (unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W;
-            rx[i] = okx ? x4[(((long long)bb * H + sy) * W + sx) * (C / 8) + chg] : make_uint4(0, 0, 0, 0);
-            if (++xx == W) { xx = 0; if (++yy == H) { yy = 0; ++bb; } }
+            const unsigned xo = (unsigned)((fb * H + sy) * W + sx) * (unsigned)PIXB + cq * 16u;
+            rx[i] = __builtin_amdgcn_raw_buffer_load_b128(xrs, okx ? xo : 0xfffffff0u, 0, 0);
+            fq += 16;
+            fx += 16;
+            if (NARROW) {
+                while (fx >= W) { fx -= W; if (++fy == H) { fy = 0; ++fb; } }
+            } else {                                        // selects, no branch: the scheduler may then slide this arithmetic under the MFMAs
+                const bool wrap = fx >= W;
+                fx = wrap ? fx - W : fx;
+                fy = wrap ? fy + 1 : fy;
+                const bool wrapy = fy == H;
+                fy = wrapy ? 0 : fy;
+                fb = wrapy ? fb + 1 : fb;
+            }
         }
+        ++fs;
     };
-    auto put = [&](int buf) {
-        // 4 pixels x 8 channels -> 8 channels x 4 pixels: dword j of pixel i holds channels 2j, 2j+1
-        const unsigned *px[4] = {reinterpret_cast<const unsigned *>(&rx[0]), reinterpret_cast<const unsigned *>(&rx[1]),
-                                 reinterpret_cast<const unsigned *>(&rx[2]), reinterpret_cast<const unsigned *>(&rx[3])};
-        const unsigned *pd[4] = {reinterpret_cast<const unsigned *>(&rd[0]), reinterpret_cast<const unsigned *>(&rd[1]),
-                                 reinterpret_cast<const unsigned *>(&rd[2]), reinterpret_cast<const unsigned *>(&rd[3])};
+    // LDS image of a step: [pixel][16 chunks], chunk index ^ 4 * (pixel & 3); pixel = pl + 16 i keeps pixel & 3 = pl & 3
+    const int st_off = pl * PIXB + ((cq ^ ((pl & 3) << 2)) << 4);
+    auto put = [&](int buf, const tu32x4 (&rx)[4], const tu32x4 (&rd)[4]) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            // __builtin_amdgcn_perm(hi, lo, sel): bytes 0-3 of lo, 4-7 of hi
-            const uint2 xe = make_uint2(__builtin_amdgcn_perm(px[1][j], px[0][j], 0x05040100u), __builtin_amdgcn_perm(px[3][j], px[2][j], 0x05040100u));
-            const uint2 xo = make_uint2(__builtin_amdgcn_perm(px[1][j], px[0][j], 0x07060302u), __builtin_amdgcn_perm(px[3][j], px[2][j], 0x07060302u));
-            *reinterpret_cast<uint2 *>(&sX[buf][chg * 8 + 2 * j][pg * 4]) = xe;
-            *reinterpret_cast<uint2 *>(&sX[buf][chg * 8 + 2 * j + 1][pg * 4]) = xo;
-            const uint2 de = make_uint2(__builtin_amdgcn_perm(pd[1][j], pd[0][j], 0x05040100u), __builtin_amdgcn_perm(pd[3][j], pd[2][j], 0x05040100u));
-            const uint2 dO = make_uint2(__builtin_amdgcn_perm(pd[1][j], pd[0][j], 0x07060302u), __builtin_amdgcn_perm(pd[3][j], pd[2][j], 0x07060302u));
-            *reinterpret_cast<uint2 *>(&sD[buf][chg * 8 + 2 * j][pg * 4]) = de;
-            *reinterpret_cast<uint2 *>(&sD[buf][chg * 8 + 2 * j + 1][pg * 4]) = dO;
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<tu32x4 *>(&sX[buf][st_off + i * 16 * PIXB]) = rx[i];
+            *reinterpret_cast<tu32x4 *>(&sD[buf][st_off + i * 16 * PIXB]) = rd[i];
         }
     };
-    tf32x16 acc[4];
+    // operand reads: 16-lane group g = lane / 16, i = lane % 16: pixels ks * 16 + (g / 2) * 8 + t * 4 + i / 4 (t = 0, 1: two reads),
+    // channels tile * 32 + (g & 1) * 16 + (i & 3) * 4 .. + 3 (8 bytes); the lane receives channel tile * 32 + (g & 1) * 16 + i = tile * 32 + r
+    const int g = lane >> 4, li = lane & 15;
+    const int cih = (wv >> 1) * 64, coh = (wv & 1) * 64;
+    int ra_off[2], rb_off[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int prow = (g >> 1) * 8 + (li >> 2);
+        const int sw = (li >> 2) << 2;                      // = 4 * (pixel & 3)
+        const int ca = (cih / 8 + t * 4 + (g & 1) * 2 + ((li & 3) >> 1)) ^ sw;
+        const int cb = (coh / 8 + t * 4 + (g & 1) * 2 + ((li & 3) >> 1)) ^ sw;
+        ra_off[t] = prow * PIXB + (ca << 4) + (li & 1) * 8;
+        rb_off[t] = prow * PIXB + (cb << 4) + (li & 1) * 8;
+    }
+    tf32x16 acc[2][2];
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[t][i] = 0.0f;
-    if (nst > 0) {
-        fetch(0);
-        put(0);
-        __syncthreads();
-        for (int s = 0; s < nst; ++s) {
-            const int buf = s & 1;
-            if (s + 1 < nst) fetch(s + 1);                  // in flight during this step's MFMAs
+        for (int i = 0; i < 16; ++i) acc[t >> 1][t & 1][i] = 0.0f;
+    auto frag = [&](const char *base, int off) {
+        const uint2 lo = lds_tr16_b64(base + off), hi = lds_tr16_b64(base + off + 4 * PIXB);
+        return make_uint4(lo.x, lo.y, hi.x, hi.y);
+    };
+    auto mfmas = [&](int buf) {
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const uint4 a = *reinterpret_cast<const uint4 *>(&sX[buf][wv * 32 + r][ks * 16 + h * 8]);     // A[ci][8 pixels]
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const uint4 bq = *reinterpret_cast<const uint4 *>(&sD[buf][t * 32 + r][ks * 16 + h * 8]);   // B[8 pixels][co]
-                    acc[t] = MfmaT<T>::run(a, bq, acc[t]);
-                }
-            }
-            if (s + 1 < nst) put(buf ^ 1);                  // the other buffer was last read before the previous barrier
-            __syncthreads();
+        for (int ks = 0; ks < 4; ++ks) {
+            const char *bx = &sX[buf][ks * 16 * PIXB], *bd = &sD[buf][ks * 16 * PIXB];
+            const uint4 a0 = frag(bx, ra_off[0]), a1 = frag(bx, ra_off[1]);
+            const uint4 b0 = frag(bd, rb_off[0]), b1 = frag(bd, rb_off[1]);
+            acc[0][0] = MfmaT<T>::run(a0, b0, acc[0][0]);
+            acc[0][1] = MfmaT<T>::run(a0, b1, acc[0][1]);
+            acc[1][0] = MfmaT<T>::run(a1, b0, acc[1][0]);
+            acc[1][1] = MfmaT<T>::run(a1, b1, acc[1][1]);
         }
+    };
+    if (nst > 0) {
+        // Straight-line steps: every step issues its eight loads (a step past the end loads zeros through the out-of-range offset and
+        // adds zeros), so the compiler can count the loads in flight -- `s_waitcnt vmcnt(16)` before the LDS stores of a stage; with
+        // `if (s + 3 < nst) fetch(...)` in the loop it fell back to vmcnt(0) and the prefetch bought nothing.
+        fetch(ra_x, ra_d);
+        fetch(rb_x, rb_d);
+        fetch(rc_x, rc_d);
+        put(0, ra_x, ra_d);
+        __syncthreads();
+        // step s: LDS buffer s & 1 holds it, the registers hold s + 1 and s + 2; the stage that held s is free for s + 3
+#define SEC_WGRAD_STEP(S, FX, FD, PX, PD)                                                              \
+        mfmas((S) & 1);                                        /* the MFMAs first: the address arithmetic of the fetch runs under them */ \
+        fetch(FX, FD);                                                                                 \
+        put(((S) + 1) & 1, PX, PD);                           /* that buffer was last read before the previous barrier */ \
+        __syncthreads();
+        for (int s = 0; s < nst; s += 3) {
+            SEC_WGRAD_STEP(s, ra_x, ra_d, rb_x, rb_d)
+            SEC_WGRAD_STEP(s + 1, rb_x, rb_d, rc_x, rc_d)
+            SEC_WGRAD_STEP(s + 2, rc_x, rc_d, ra_x, ra_d)
+        }
+#undef SEC_WGRAD_STEP
     }
     // D layout: column (co) = lane & 31, rows (ci) = (i & 3) + 8 (i >> 2) + 4 h
     float *dst = part + ((size_t)slice * ntaps + tslot) * C * C;
@@ -139,8 +191,8 @@ __global__ __launch_bounds__(256, 2) void k_conv2d_wgrad3x3(const T *__restrict_
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const int ci = wv * 32 + (i & 3) + 8 * (i >> 2) + 4 * h, co = t * 32 + r;
-            dst[(size_t)ci * C + co] = acc[t][i];
+            const int ci = cih + (t >> 1) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h, co = coh + (t & 1) * 32 + r;
+            dst[(size_t)ci * C + co] = acc[t >> 1][t & 1][i];
         }
 }
 
@@ -149,8 +201,18 @@ __global__ __launch_bounds__(256) void k_conv2d_wgrad_reduce(const float *__rest
     constexpr int C = 128;
     const int e = blockIdx.x * 256 + threadIdx.x;           // e = (tap * C + ci) * C + co
     if (e >= ntaps * C * C) return;
-    float s = 0.0f;
-    for (int g = 0; g < groups; ++g) s += part[(size_t)g * ntaps * C * C + e];
+    const size_t stride = (size_t)ntaps * C * C;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;       // four chains (eight loads in flight), combined in a fixed order
+    int g = 0;
+    for (; g + 8 <= groups; g += 8) {
+        const float *p = part + (size_t)g * stride + e;
+        const float v0 = p[0], v1 = p[stride], v2 = p[2 * stride], v3 = p[3 * stride];
+        const float v4 = p[4 * stride], v5 = p[5 * stride], v6 = p[6 * stride], v7 = p[7 * stride];
+        s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+        s0 += v4; s1 += v5; s2 += v6; s3 += v7;
+    }
+    for (; g < groups; ++g) s0 += part[(size_t)g * stride + e];
+    const float s = (s0 + s1) + (s2 + s3);
     const int co = e % C, ci = (e / C) % C, tap = e / (C * C);
     dw[((size_t)co * C + ci) * ntaps + tap] = s;
 }
@@ -344,15 +406,20 @@ constexpr int kBnGroups = 512;
 template <typename T>
 static int run_wgrad(const void *x, const void *dy, int B, int H, int W, float *dw, void *ws, size_t ws_bytes, hipStream_t st, int ntaps) {
     const long long P = (long long)B * H * W;
+    if (P * 128 * 2 >= (1ll << 31)) return SEC_E_UNSUPPORTED;   // 32-bit buffer offsets (8.4 M pixels; the nuScenes maps hold 0.5 M)
     const long long total_steps = (P + 63) / 64;
-    int steps = ntaps == 1 ? 4 : 40;                         // ~2 workgroups per CU at batch 4 (2200 steps -> 55 runs x 9 taps; one tap: 256 runs)
+    int steps = ntaps == 1 ? 6 : 42;                         // multiples of 3 (the kernel's unrolled stage ring); ~2 workgroups per CU at batch 4 (2200 steps -> 53 runs x 9 taps)
     long long gx = (total_steps + steps - 1) / steps;
-    if (gx > 256) { steps = (int)((total_steps + 255) / 256); gx = (total_steps + steps - 1) / steps; }
+    if (gx > 256) { steps = (int)((total_steps + 255) / 256); steps = (steps + 2) / 3 * 3; gx = (total_steps + steps - 1) / steps; }
     if (gx < 1) gx = 1;
     const size_t need = (size_t)gx * ntaps * 128 * 128 * sizeof(float);
     if (ws_bytes < need) return SEC_E_WORKSPACE;
-    hipLaunchKernelGGL((k_conv2d_wgrad3x3<T>), dim3((unsigned)((gx + 7) / 8 * 8 * ntaps)), dim3(256), 0, st, (const T *)x, (const T *)dy, (float *)ws, B, H, W,
-                       steps, P, (int)gx, ntaps);
+    if (W >= 16)
+        hipLaunchKernelGGL((k_conv2d_wgrad3x3<T, false>), dim3((unsigned)((gx + 7) / 8 * 8 * ntaps)), dim3(256), 0, st, (const T *)x, (const T *)dy,
+                           (float *)ws, B, H, W, steps, P, (int)gx, ntaps);
+    else
+        hipLaunchKernelGGL((k_conv2d_wgrad3x3<T, true>), dim3((unsigned)((gx + 7) / 8 * 8 * ntaps)), dim3(256), 0, st, (const T *)x, (const T *)dy,
+                           (float *)ws, B, H, W, steps, P, (int)gx, ntaps);
     hipLaunchKernelGGL(k_conv2d_wgrad_reduce, dim3(div_up(ntaps * 128 * 128, 256)), dim3(256), 0, st, (const float *)ws, (int)gx, dw, ntaps);
     return check_launch();
 }
@@ -364,7 +431,7 @@ using namespace sec;
 SEC_API size_t sec_conv2d_wgrad_workspace_bytes(int batch, int h, int w, int cin, int cout, int ksize) {
     if (cin != 128 || cout != 128 || (ksize != 3 && ksize != 1) || batch <= 0 || h <= 0 || w <= 0) return 0;
     const long long total_steps = ((long long)batch * h * w + 63) / 64;
-    const int steps0 = ksize == 1 ? 4 : 40;
+    const int steps0 = ksize == 1 ? 6 : 42;
     long long gx = (total_steps + steps0 - 1) / steps0;
     if (gx > 256) gx = 256;
     if (gx < 1) gx = 1;
