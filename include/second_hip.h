@@ -35,7 +35,7 @@ extern "C" {
 #define SEC_F16 1
 #define SEC_BF16 2
 
-#define SEC_ABI_VERSION 5
+#define SEC_ABI_VERSION 6
 int sec_abi_version(void);
 /* last HIP error string seen by this library (thread-unsafe convenience for diagnostics) */
 const char *sec_last_error(void);
@@ -576,6 +576,24 @@ int sec_second_loss_f32(const float *cls_preds, const float *box_preds, const fl
                         const float *reg_targets, const float *anchors, const float *importance, int batch,
                         int n_anchor, int num_class, int num_dir_bins, const float *h_params17, float *d_cls, float *d_box,
                         float *d_dir, float *out6, void *workspace, size_t workspace_bytes, void *stream);
+/* The same loss read straight from the STACKED heads of the training step: heads [batch, h, w, head_channels] channels last, 16 bit
+ * = box [A*7] | cls [A*num_class] | dir [A*bins] | zero padding, the output of the three 1x1 head convolutions run as one
+ * (second/pytorch/models/rpn.py:386-391; the reference views each as [B, A, H, W, code], anchor n = (a*H + y)*W + x, and hands three
+ * fp32 copies to VoxelNet.loss, voxelnet.py:239-312, whose gradients autograd stitches back).  _fwd: out6 as sec_second_loss_f32.
+ * _bwd: d_heads (the layout and dtype of `heads`, padding channels zero) = grad_loss[0] * d loss / d heads, rounded once after the
+ * multiplication (grad_loss: device float, the gradient arriving at the loss -- the loss scale of fp16 training; NULL = 1), and
+ * d_bias [head_channels] fp32 = its sum over pixels (fixed order).  Same arithmetic as sec_second_loss_f32, expression by expression.
+ * sec_heads_loss_supported: 1 for the instantiated shapes (head_channels 64, A = 2, one class, 0 or 2 direction bins, bf16 / fp16) --
+ * anything else returns SEC_E_UNSUPPORTED and the caller keeps the three-tensor path. */
+int sec_heads_loss_supported(int head_channels, int anchors_per_loc, int num_class, int num_dir_bins, int dtype);
+size_t sec_heads_loss_workspace_bytes(int batch, int h, int w, int anchors_per_loc);
+int sec_heads_loss_fwd(const void *heads, int dtype, int batch, int h, int w, int head_channels, int anchors_per_loc, int num_class,
+                       int num_dir_bins, const int *labels, const float *reg_targets, const float *anchors, const float *importance,
+                       const float *h_params17, float *out6, void *workspace, size_t workspace_bytes, void *stream);
+int sec_heads_loss_bwd(const void *heads, int dtype, int batch, int h, int w, int head_channels, int anchors_per_loc, int num_class,
+                       int num_dir_bins, const int *labels, const float *reg_targets, const float *anchors, const float *importance,
+                       const float *h_params17, const float *grad_loss, void *d_heads, float *d_bias, void *workspace,
+                       size_t workspace_bytes, void *stream);
 
 /* torch.nn.utils.clip_grad_norm_(parameters, max_grad_norm) + the AdamW step (second/pytorch/train.py:323-325; adam + fixed weight
  * decay, car.fhd.config:180-188) on ONE flat fp32 buffer of master weights whose flat gradient is the all-reduce bucket: two launches

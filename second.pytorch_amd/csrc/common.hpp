@@ -106,6 +106,14 @@ __device__ __forceinline__ int hash_find(const unsigned long long *keys, uint32_
 }
 
 // ---------------------------------------------------------------- wave / block scans (wave64)
+// `ok ? p[i] : d` as an UNCONDITIONAL load from a clamped index plus a select.  hipcc compiles the conditional form to a branch with
+// `s_waitcnt vmcnt(0)` behind the load, so "N independent loads in flight" in an unrolled loop become N dependent round trips (found
+// with the dense weight gradient, profiles/r05_h_wgrad_pmc.txt).  p[0] must be readable (the array is not empty).
+template <typename T, typename I>
+__device__ __forceinline__ T ld_sel(const T *__restrict__ p, I i, bool ok, T d) {
+    const T v = p[ok ? i : (I)0];
+    return ok ? v : d;
+}
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 __device__ __forceinline__ int wave_inclusive_scan(int v) {
 #pragma unroll

@@ -1586,8 +1586,8 @@ __global__ __launch_bounds__(kBlock) void k_bev_bitmap(const int *__restrict__ s
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int px = 32 * k + 4 * j;
-            va[j] = px < w ? r0[px >> 2] : make_int4(0, 0, 0, 0);
-            vb[j] = px < w ? r1[px >> 2] : make_int4(0, 0, 0, 0);
+            va[j] = ld_sel(r0, px >> 2, px < w, make_int4(0, 0, 0, 0));
+            vb[j] = ld_sel(r1, px >> 2, px < w, make_int4(0, 0, 0, 0));
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j)

@@ -59,7 +59,7 @@ __device__ __forceinline__ uint2 lds_tr16_b64(const char *p) {
 }
 template <typename T, bool NARROW>   // NARROW: maps less than 16 pixels wide (the coordinate advance of 16 pixels may wrap more than one row)
 __global__ __launch_bounds__(256, 2) void k_conv2d_wgrad3x3(const T *__restrict__ x, const T *__restrict__ dy, float *__restrict__ part,
-                                                            int B, int H, int W, int steps, long long P, int slices, int ntaps) {
+                                                            int B, int H, int W, int steps, long long P, int slices, int ntaps, int dyc) {
     constexpr int C = 128, PIXB = C * 2;                   // 256 bytes per pixel
     __shared__ __attribute__((aligned(16))) char sX[2][64 * PIXB];
     __shared__ __attribute__((aligned(16))) char sD[2][64 * PIXB];
@@ -77,10 +77,14 @@ __global__ __launch_bounds__(256, 2) void k_conv2d_wgrad3x3(const T *__restrict_
     const long long total_steps = (P + 63) / 64;
     const int nst = (int)(step0 + steps <= total_steps ? steps : (total_steps > step0 ? total_steps - step0 : 0));
     const unsigned tensor_bytes = (unsigned)(P * PIXB);
+    // dy may hold fewer channels than the 128 x 128 tile (`dyc` = 64: the stacked 1x1 heads): its pixels are dyc * 2 bytes apart and
+    // the chunks behind them read as zeros (out-of-range offset), so rows co >= dyc of the partial are zero and never leave the reduce
+    const unsigned dpix = (unsigned)dyc * 2u;
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(x), 0, (int)tensor_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(dy), 0, (int)tensor_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(dy), 0, (int)(P * dpix), 0x00020000);
     // staging: this thread moves chunk `cq` (16 bytes = 8 channels) of the pixels pl, pl + 16, pl + 32, pl + 48 of a step
     const int cq = tid & 15, pl = tid >> 4;
+    const bool dchunk = cq * 8 < dyc;
     // running coordinates of the NEXT step to fetch (pixel pl of it); they only ever advance by 16 pixels -- no divisions in the loop
     unsigned fq;
     int fx, fy, fb;
@@ -99,7 +103,7 @@ __global__ __launch_bounds__(256, 2) void k_conv2d_wgrad3x3(const T *__restrict_
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const bool okp = oks && (long long)fq < P;
-            rd[i] = __builtin_amdgcn_raw_buffer_load_b128(drs, okp ? fq * (unsigned)PIXB + cq * 16u : 0xfffffff0u, 0, 0);
+            rd[i] = __builtin_amdgcn_raw_buffer_load_b128(drs, okp && dchunk ? fq * dpix + cq * 16u : 0xfffffff0u, 0, 0);
             const int sy = fy + ty, sx = fx + tx;
             const bool okx = okp && (unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W;
             const unsigned xo = (unsigned)((fb * H + sy) * W + sx) * (unsigned)PIXB + cq * 16u;
@@ -197,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void k_conv2d_wgrad3x3(const T *__restrict_
 }
 
 // dw[co][ci][tap] (torch's [Cout][Cin][3][3]) = sum_g part[g][tap][ci][co], g ascending (fixed order: run-to-run identical)
-__global__ __launch_bounds__(256) void k_conv2d_wgrad_reduce(const float *__restrict__ part, int groups, float *__restrict__ dw, int ntaps) {
+__global__ __launch_bounds__(256) void k_conv2d_wgrad_reduce(const float *__restrict__ part, int groups, float *__restrict__ dw, int ntaps, int cout) {
     constexpr int C = 128;
     const int e = blockIdx.x * 256 + threadIdx.x;           // e = (tap * C + ci) * C + co
     if (e >= ntaps * C * C) return;
@@ -214,7 +218,7 @@ __global__ __launch_bounds__(256) void k_conv2d_wgrad_reduce(const float *__rest
     for (; g < groups; ++g) s0 += part[(size_t)g * stride + e];
     const float s = (s0 + s1) + (s2 + s3);
     const int co = e % C, ci = (e / C) % C, tap = e / (C * C);
-    dw[((size_t)co * C + ci) * ntaps + tap] = s;
+    if (co < cout) dw[((size_t)co * C + ci) * ntaps + tap] = s;      // dw is [cout][128][taps]: cout = 64 for the stacked heads
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -404,7 +408,7 @@ __global__ __launch_bounds__(kBlock) void k_conv2d_pack_train(const float *__res
 constexpr int kBnGroups = 512;
 
 template <typename T>
-static int run_wgrad(const void *x, const void *dy, int B, int H, int W, float *dw, void *ws, size_t ws_bytes, hipStream_t st, int ntaps) {
+static int run_wgrad(const void *x, const void *dy, int B, int H, int W, float *dw, void *ws, size_t ws_bytes, hipStream_t st, int ntaps, int cout) {
     const long long P = (long long)B * H * W;
     if (P * 128 * 2 >= (1ll << 31)) return SEC_E_UNSUPPORTED;   // 32-bit buffer offsets (8.4 M pixels; the nuScenes maps hold 0.5 M)
     const long long total_steps = (P + 63) / 64;
@@ -416,11 +420,11 @@ static int run_wgrad(const void *x, const void *dy, int B, int H, int W, float *
     if (ws_bytes < need) return SEC_E_WORKSPACE;
     if (W >= 16)
         hipLaunchKernelGGL((k_conv2d_wgrad3x3<T, false>), dim3((unsigned)((gx + 7) / 8 * 8 * ntaps)), dim3(256), 0, st, (const T *)x, (const T *)dy,
-                           (float *)ws, B, H, W, steps, P, (int)gx, ntaps);
+                           (float *)ws, B, H, W, steps, P, (int)gx, ntaps, cout);
     else
         hipLaunchKernelGGL((k_conv2d_wgrad3x3<T, true>), dim3((unsigned)((gx + 7) / 8 * 8 * ntaps)), dim3(256), 0, st, (const T *)x, (const T *)dy,
-                           (float *)ws, B, H, W, steps, P, (int)gx, ntaps);
-    hipLaunchKernelGGL(k_conv2d_wgrad_reduce, dim3(div_up(ntaps * 128 * 128, 256)), dim3(256), 0, st, (const float *)ws, (int)gx, dw, ntaps);
+                           (float *)ws, B, H, W, steps, P, (int)gx, ntaps, cout);
+    hipLaunchKernelGGL(k_conv2d_wgrad_reduce, dim3(div_up(ntaps * 128 * 128, 256)), dim3(256), 0, st, (const float *)ws, (int)gx, dw, ntaps, cout);
     return check_launch();
 }
 
@@ -429,7 +433,7 @@ static int run_wgrad(const void *x, const void *dy, int B, int H, int W, float *
 using namespace sec;
 
 SEC_API size_t sec_conv2d_wgrad_workspace_bytes(int batch, int h, int w, int cin, int cout, int ksize) {
-    if (cin != 128 || cout != 128 || (ksize != 3 && ksize != 1) || batch <= 0 || h <= 0 || w <= 0) return 0;
+    if (cin != 128 || !(cout == 128 || (cout == 64 && ksize == 1)) || (ksize != 3 && ksize != 1) || batch <= 0 || h <= 0 || w <= 0) return 0;
     const long long total_steps = ((long long)batch * h * w + 63) / 64;
     const int steps0 = ksize == 1 ? 6 : 42;
     long long gx = (total_steps + steps0 - 1) / steps0;
@@ -441,11 +445,11 @@ SEC_API size_t sec_conv2d_wgrad_workspace_bytes(int batch, int h, int w, int cin
 SEC_API int sec_conv2d_wgrad_nhwc(const void *x, const void *dy, int batch, int h, int w, int cin, int cout, int ksize, int stride,
                                   int pad, float *dweight, void *workspace, size_t workspace_bytes, int dtype, void *stream) {
     if (!x || !dy || !dweight || !workspace || batch <= 0 || h <= 0 || w <= 0) return SEC_E_INVALID;
-    if (cin != 128 || cout != 128 || stride != 1 || !((ksize == 3 && pad == 1) || (ksize == 1 && pad == 0)) ||
+    if (cin != 128 || !(cout == 128 || (cout == 64 && ksize == 1)) || stride != 1 || !((ksize == 3 && pad == 1) || (ksize == 1 && pad == 0)) ||
         (dtype != SEC_BF16 && dtype != SEC_F16)) return SEC_E_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == SEC_BF16) return run_wgrad<__hip_bfloat16>(x, dy, batch, h, w, dweight, workspace, workspace_bytes, st, ksize * ksize);
-    return run_wgrad<__half>(x, dy, batch, h, w, dweight, workspace, workspace_bytes, st, ksize * ksize);
+    if (dtype == SEC_BF16) return run_wgrad<__hip_bfloat16>(x, dy, batch, h, w, dweight, workspace, workspace_bytes, st, ksize * ksize, cout);
+    return run_wgrad<__half>(x, dy, batch, h, w, dweight, workspace, workspace_bytes, st, ksize * ksize, cout);
 }
 
 SEC_API int sec_conv2d_pack_weight_train(const float *weight, int cout, int cin, int ksize, int dtype, void *packed_fwd,

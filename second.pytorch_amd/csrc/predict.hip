@@ -135,7 +135,7 @@ __global__ __launch_bounds__(kSelThreads) void k_predict_select(const T *__restr
 #pragma unroll
             for (int j = 0; j < UNR; ++j) {
                 const int n = n0 + j * kSelThreads + tid;
-                kk[j] = n < N ? fk[n] : 0u;
+                kk[j] = ld_sel(fk, n, n < N, 0u);
             }
 #pragma unroll
             for (int j = 0; j < UNR; ++j) c += kk[j] >= thr_key ? 1u : 0u;
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(kSelThreads) void k_predict_select(const T *__restr
 #pragma unroll
             for (int j = 0; j < UNR; ++j) {
                 int n = n0 + j * kSelThreads + tid;
-                kk[j] = n < N ? fk[n] : 0u;
+                kk[j] = ld_sel(fk, n, n < N, 0u);
             }
 #pragma unroll
             for (int j = 0; j < UNR; ++j) {
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(kSelThreads) void k_predict_select(const T *__restr
 #pragma unroll
         for (int j = 0; j < UNR; ++j) {
             int n = n0 + j * kSelThreads + tid;
-            kk[j] = n < N ? fk[n] : 0u;
+            kk[j] = ld_sel(fk, n, n < N, 0u);
         }
 #pragma unroll
         for (int j = 0; j < UNR; ++j) {
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(kSelThreads) void k_predict_select_reg(const T *__r
 #pragma unroll
     for (int i = 0; i < KP; ++i) {
         const int n = n_base + i * 128;
-        k2[i] = n < ns ? fk2[n >> 1] : 0u;
+        k2[i] = ld_sel(fk2, n >> 1, n < ns, 0u);
     }
     SEC_TS();
     // K-th largest 16-bit key by bisection on its bits, MSB first (no histogram, no atomics).  Counting sweeps run over
@@ -567,22 +567,43 @@ __global__ __launch_bounds__(kSelThreads) void k_predict_select_chunk(const T *_
         ay = t0 % g.H;
         aa = t0 / g.H;
     }
-    auto key_at = [&](int a, int y, int x) -> unsigned {
-        const T *p = cls + b * v.sb + a * v.sa + y * v.sy + x * v.sx;
-        float best = ldf(p);
-        for (int c2 = 1; c2 < g.nc; ++c2) { const float f = ldf(p + c2 * v.sc); if (f > best) best = f; }   // as anchor_key()
-        return key16_of<T>(best);
-    };
+    // Offsets first, then the loads of a batch of four pairs back to back (an anchor past the frame reads element 0 and its key is
+    // forced to 0 afterwards): `a0 < N ? load : 0` compiles to a branch with s_waitcnt vmcnt(0) behind every load -- eight dependent
+    // round trips per thread at KP = 4, most of this kernel's 18 us.
+    constexpr int PB = KP < 4 ? KP : 4;
+    static_assert(KP % PB == 0, "pairs per thread must be a multiple of the load batch");
 #pragma unroll
-    for (int i = 0; i < KP; ++i) {
-        const int a0 = base + n_base + i * 128;
-        int bx = ax + 1, by = ay, ba = aa;             // the pair's second anchor
-        if (bx >= g.W) { bx = 0; if (++by >= g.H) { by = 0; ++ba; } }
-        const unsigned ka = a0 < N ? key_at(aa, ay, ax) : 0u;          // slots beyond the frame hold key 0
-        const unsigned kb = a0 + 1 < N ? key_at(ba, by, bx) : 0u;
-        k2[i] = ka | (kb << 16);
-        ax += 128;
-        while (ax >= g.W) { ax -= g.W; if (++ay >= g.H) { ay = 0; ++aa; } }
+    for (int i0 = 0; i0 < KP; i0 += PB) {
+        long long off[2 * PB];
+        bool ok[2 * PB];
+#pragma unroll
+        for (int j = 0; j < PB; ++j) {
+            const int a0 = base + n_base + (i0 + j) * 128;
+            int bx = ax + 1, by = ay, ba = aa;             // the pair's second anchor
+            if (bx >= g.W) { bx = 0; if (++by >= g.H) { by = 0; ++ba; } }
+            ok[2 * j] = a0 < N;
+            ok[2 * j + 1] = a0 + 1 < N;                                 // slots beyond the frame hold key 0
+            off[2 * j] = ok[2 * j] ? (long long)b * v.sb + (long long)aa * v.sa + (long long)ay * v.sy + (long long)ax * v.sx : 0;
+            off[2 * j + 1] = ok[2 * j + 1] ? (long long)b * v.sb + (long long)ba * v.sa + (long long)by * v.sy + (long long)bx * v.sx : 0;
+            ax += 128;
+            while (ax >= g.W) { ax -= g.W; if (++ay >= g.H) { ay = 0; ++aa; } }
+        }
+        float best[2 * PB];
+#pragma unroll
+        for (int j = 0; j < 2 * PB; ++j) best[j] = ldf(cls + off[j]);
+        for (int c2 = 1; c2 < g.nc; ++c2) {                              // as anchor_key()
+            float f[2 * PB];
+#pragma unroll
+            for (int j = 0; j < 2 * PB; ++j) f[j] = ldf(cls + off[j] + (ok[j] ? (long long)c2 * v.sc : 0));
+#pragma unroll
+            for (int j = 0; j < 2 * PB; ++j) if (f[j] > best[j]) best[j] = f[j];
+        }
+#pragma unroll
+        for (int j = 0; j < PB; ++j) {
+            const unsigned ka = ok[2 * j] ? key16_of<T>(best[2 * j]) : 0u;
+            const unsigned kb = ok[2 * j + 1] ? key16_of<T>(best[2 * j + 1]) : 0u;
+            k2[i0 + j] = ka | (kb << 16);
+        }
     }
     unsigned short *ok_ = cand_key + ((size_t)b * chunks + c) * kSelThreads;
     int *oi_ = cand_idx + ((size_t)b * chunks + c) * kSelThreads;

@@ -337,6 +337,212 @@ __global__ __launch_bounds__(kBlock) void k_loss_final(const float *__restrict__
 }
 
 
+// ------------------------------------------------------------------------------------------------ loss on the stacked heads
+// The training step's 1x1 heads are ONE 128 -> 64 convolution whose output y [B, H, W, 64] (channels last, 16 bit) stacks
+// box [A * 7] | cls [A * NC] | dir [A * BINS] | zero padding (ops.Heads1x1Function; rpn.py:386-391).  The reference views each head
+// as [B, A, H, W, code] (anchor n = (a * H + y) * W + x) and hands three fp32 copies to the loss; autograd then stitches the three
+// gradients back into dY: ~35 small torch launches, 0.25 ms of a 3.5 ms step.  Here the loss reads y and writes dY:
+//   k_heads_loss<.., false>  the six loss scalars (forward)
+//   k_heads_loss<.., true>   dY = g * d loss / d y in y's own layout and dtype (rounded once, after the multiplication by the incoming
+//                            gradient g -- the loss scale of fp16 training) + per-workgroup column sums for the bias gradient
+// A thread owns a pixel: it loads the first 16-byte chunks of its row, runs the A anchors through the arithmetic of k_loss_main
+// (same expressions, same order), and writes the row back -- all indices static, everything in registers.
+template <typename HT> __device__ __forceinline__ float ht2f(HT v);
+template <> __device__ __forceinline__ float ht2f(__hip_bfloat16 v) { return __bfloat162float(v); }
+template <> __device__ __forceinline__ float ht2f(__half v) { return __half2float(v); }
+template <typename HT> __device__ __forceinline__ HT f2ht(float v);
+template <> __device__ __forceinline__ __hip_bfloat16 f2ht(float v) { return __float2bfloat16(v); }
+template <> __device__ __forceinline__ __half f2ht(float v) { return __float2half_rn(v); }
+
+template <typename HT, int A, int NC, int BINS, bool GRAD>
+__global__ __launch_bounds__(kBlock) void k_heads_loss(const HT *__restrict__ heads, int HW, int HC, const int *__restrict__ labels,
+                                                      const float *__restrict__ reg, const float *__restrict__ anchors,
+                                                      const float *__restrict__ importance, const float *__restrict__ cnt, LossParams P,
+                                                      const float *__restrict__ g_loss, HT *__restrict__ d_heads,
+                                                      float *__restrict__ partial) {
+    constexpr int TOT = A * (7 + NC + BINS), NCH = (TOT + 7) / 8;       // 16-byte chunks of a row that hold head outputs
+    constexpr int BOX0 = 0, CLS0 = A * 7, DIR0 = A * 7 + A * NC;
+    const int b = blockIdx.y, pix = blockIdx.x * kBlock + threadIdx.x;
+    __shared__ float s_norm[2];
+    if (threadIdx.x < 2) {                // the frame's normalisers: fixed-order sum of the chunk counts, clamped to >= 1
+        float acc = 0.0f;
+        for (int c = 0; c < kCountChunks; ++c) acc += cnt[((size_t)b * kCountChunks + c) * 2 + threadIdx.x];
+        s_norm[threadIdx.x] = fmaxf(acc, 1.0f);
+    }
+    __syncthreads();
+    float s_cls = 0, s_loc = 0, s_dir = 0, s_pos = 0, s_neg = 0;
+    float v[NCH * 8], d[NCH * 8];
+#pragma unroll
+    for (int i = 0; i < NCH * 8; ++i) { v[i] = 0.0f; d[i] = 0.0f; }
+    const bool live = pix < HW;
+    const float gs = GRAD ? (g_loss ? g_loss[0] : 1.0f) : 0.0f;
+    if (live) {
+        const uint4 *row = reinterpret_cast<const uint4 *>(heads + ((size_t)b * HW + pix) * HC);
+        uint4 q[NCH];
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) q[i] = row[i];
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const HT *e = reinterpret_cast<const HT *>(&q[i]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[i * 8 + j] = ht2f<HT>(e[j]);
+        }
+        const float inv_b = 1.0f / (float)P.batch;
+        const float norm = s_norm[0];
+#pragma unroll
+        for (int a = 0; a < A; ++a) {
+            const int n = a * HW + pix;                                  // the reference's anchor index
+            const size_t o = (size_t)b * P.n_anchor + n;
+            const int label = labels[o];
+            const float imp = importance[o];
+            const bool pos = label > 0, neg = label == 0;
+            // ---- classification (focal, background encoded as zeros)
+            const float wcls = ((neg ? P.neg_w : 0.0f) + (pos ? P.pos_w : 0.0f)) / norm * imp;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const float x = v[CLS0 + a * NC + c];
+                const float t = (label == c + 1) ? 1.0f : 0.0f;
+                const float ce = fmaxf(x, 0.0f) - x * t + log1pf(expf(-fabsf(x)));
+                const float p = 1.0f / (1.0f + expf(-x));
+                const float pt = t * p + (1.0f - t) * (1.0f - p);
+                const float om = 1.0f - pt;
+                const float mod = P.gamma == 2.0f ? om * om : (P.gamma == 0.0f ? 1.0f : powf(om, P.gamma));
+                const float at = t * P.alpha + (1.0f - t) * (1.0f - P.alpha);
+                const float l = mod * at * ce * wcls;
+                s_cls += l;
+                if (NC == 1) { s_pos += pos ? l : 0.0f; s_neg += neg ? l : 0.0f; }
+                else { s_pos += c > 0 ? l : 0.0f; s_neg += c == 0 ? l : 0.0f; }
+                if (GRAD) {
+                    const float dpt = (2.0f * t - 1.0f) * p * (1.0f - p);
+                    const float dmod = P.gamma == 2.0f ? -2.0f * om * dpt : (P.gamma == 0.0f ? 0.0f : -P.gamma * powf(om, P.gamma - 1.0f) * dpt);
+                    d[CLS0 + a * NC + c] = at * wcls * (dmod * ce + mod * (p - t)) * P.cls_w * inv_b;
+                }
+            }
+            // ---- localisation (smooth L1 on the sin-difference encoding), positives only
+            const float wreg = (pos ? 1.0f : 0.0f) / norm * imp;
+            const float s2 = P.sigma * P.sigma;
+            float tg[7];
+#pragma unroll
+            for (int j = 0; j < 7; ++j) tg[j] = reg[o * 7 + j];
+            const float pr = v[BOX0 + a * 7 + 6] * P.sin_factor, tr = tg[6] * P.sin_factor;
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                float pv = v[BOX0 + a * 7 + j], tv = tg[j], dscale = 1.0f;
+                if (j == 6) {
+                    pv = sinf(pr) * cosf(tr);
+                    tv = cosf(pr) * sinf(tr);
+                    dscale = (cosf(pr) * cosf(tr) + sinf(pr) * sinf(tr)) * P.sin_factor;
+                }
+                const float diff = P.code_w[j] * (pv - tv);
+                const float ad = fabsf(diff);
+                const bool small = ad <= 1.0f / s2;
+                const float l = small ? 0.5f * (ad * P.sigma) * (ad * P.sigma) : ad - 0.5f / s2;
+                s_loc += l * wreg;
+                if (GRAD) {
+                    const float dl = small ? s2 * diff : (diff > 0.0f ? 1.0f : (diff < 0.0f ? -1.0f : 0.0f));
+                    d[BOX0 + a * 7 + j] = dl * P.code_w[j] * dscale * wreg * P.loc_w * inv_b;
+                }
+            }
+            // ---- direction classifier (softmax cross-entropy on the heading bin of the ground truth)
+            if (BINS > 0) {
+                const float kTwoPi = 6.28318548202514648f;
+                const float rot_gt = tg[6] + anchors[(size_t)n * 7 + 6];
+                const float off = limit_period_f(rot_gt - P.dir_offset, 0.0f, kTwoPi);
+                int bin = (int)floorf(off / (kTwoPi / (float)BINS));
+                bin = bin < 0 ? 0 : (bin > BINS - 1 ? BINS - 1 : bin);
+                const float wdir = (pos ? imp : 0.0f) / s_norm[1];
+                float mx = -3.0e38f;
+#pragma unroll
+                for (int c = 0; c < BINS; ++c) mx = fmaxf(mx, v[DIR0 + a * BINS + c]);
+                float se = 0.0f;
+#pragma unroll
+                for (int c = 0; c < BINS; ++c) se += expf(v[DIR0 + a * BINS + c] - mx);
+                const float lse = mx + logf(se);
+                float at_bin = 0.0f;
+#pragma unroll
+                for (int c = 0; c < BINS; ++c) at_bin = c == bin ? v[DIR0 + a * BINS + c] : at_bin;
+                s_dir += (lse - at_bin) * wdir;
+                if (GRAD) {
+#pragma unroll
+                    for (int c = 0; c < BINS; ++c) {
+                        const float sm = expf(v[DIR0 + a * BINS + c] - lse);
+                        d[DIR0 + a * BINS + c] = (sm - (c == bin ? 1.0f : 0.0f)) * wdir * P.dir_w * inv_b;
+                    }
+                }
+            }
+        }
+    }
+    if (!GRAD) {
+        // block reduction -> partial[(b * gridDim.x + blockIdx.x)][6]
+        __shared__ float red[5][kBlock / 64];
+        float r5[5] = {s_cls, s_loc, s_dir, s_pos, s_neg};
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+#pragma unroll
+            for (int sft = 32; sft > 0; sft >>= 1) r5[i] += __shfl_xor(r5[i], sft, 64);
+            if ((threadIdx.x & 63) == 0) red[i][threadIdx.x >> 6] = r5[i];
+        }
+        __syncthreads();
+        if (threadIdx.x < 5) {
+            float acc = 0.0f;
+            for (int w = 0; w < kBlock / 64; ++w) acc += red[threadIdx.x][w];
+            partial[((size_t)b * gridDim.x + blockIdx.x) * 6 + threadIdx.x] = acc;
+        }
+    } else {
+        // dY row: the gradient times the incoming scalar, rounded ONCE to the heads' dtype; the padding channels are zeros
+        float dq[NCH * 8];
+#pragma unroll
+        for (int i = 0; i < NCH * 8; ++i) {
+            const HT r = f2ht<HT>(d[i] * gs);
+            dq[i] = ht2f<HT>(r);                          // the bias gradient sums what dY holds (autograd summed the rounded tensor)
+            d[i] = dq[i];
+        }
+        if (live) {
+            uint4 *orow = reinterpret_cast<uint4 *>(d_heads + ((size_t)b * HW + pix) * HC);
+#pragma unroll
+            for (int i = 0; i < NCH; ++i) {
+                uint4 q;
+                HT *e = reinterpret_cast<HT *>(&q);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) e[j] = f2ht<HT>(d[i * 8 + j]);
+                orow[i] = q;
+            }
+            for (int i = NCH; i < HC / 8; ++i) orow[i] = make_uint4(0, 0, 0, 0);
+        }
+        // column sums of this workgroup's rows -> partial[(b * gridDim.x + blockIdx.x)][NCH * 8] (fixed order)
+        __shared__ float red[kBlock / 64][NCH * 8];
+#pragma unroll
+        for (int i = 0; i < NCH * 8; ++i) {
+            float t = dq[i];
+#pragma unroll
+            for (int sft = 32; sft > 0; sft >>= 1) t += __shfl_xor(t, sft, 64);
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][i] = t;
+        }
+        __syncthreads();
+        if (threadIdx.x < NCH * 8) {
+            float acc = 0.0f;
+            for (int w = 0; w < kBlock / 64; ++w) acc += red[w][threadIdx.x];
+            partial[((size_t)b * gridDim.x + blockIdx.x) * (NCH * 8) + threadIdx.x] = acc;
+        }
+    }
+}
+
+// d_bias[c] = sum of the workgroups' column sums (ascending: run-to-run identical); channels behind the heads get 0
+__global__ __launch_bounds__(kBlock) void k_heads_bias_final(const float *__restrict__ partial, int nparts, int cols, int HC, float *__restrict__ d_bias) {
+    __shared__ float red[kBlock / 64][64];
+    const int c = threadIdx.x & 63, part = threadIdx.x >> 6;          // 4 slices of the partial list per channel
+    float acc = 0.0f;
+    if (c < cols)
+        for (int i = part; i < nparts; i += kBlock / 64) acc += partial[(size_t)i * cols + c];
+    red[part][c] = acc;
+    __syncthreads();
+    if (threadIdx.x < HC && threadIdx.x < 64) {
+        float t = 0.0f;
+        for (int w = 0; w < kBlock / 64; ++w) t += red[w][threadIdx.x];
+        d_bias[threadIdx.x] = threadIdx.x < cols ? t : 0.0f;
+    }
+}
+
 // ---- clip_grad_norm_ + AdamW on ONE flat fp32 parameter buffer -----------------------------------------------------------------------
 // second/pytorch/train.py:323-325: torch.nn.utils.clip_grad_norm_(net.parameters(), 10.0); mixed_optimizer.step() (adam + fixed
 // weight decay, car.fhd.config:180-188).  With torch.optim.AdamW over 69 parameter tensors a captured step spends ~0.6 ms here: the
@@ -527,6 +733,81 @@ SEC_API int sec_second_loss_f32(const float *cls_preds, const float *box_preds, 
                        anchors, importance, cnt, P, d_cls, d_box, d_dir, partial);
     hipLaunchKernelGGL(k_loss_final, dim3(1), dim3(kBlock), 0, st, partial, batch * nb, P, out6);
     return check_launch();
+}
+
+// ---- the loss on the stacked heads (k_heads_loss): forward values, backward dY + bias gradient
+static bool heads_loss_shape_ok(int head_channels, int a, int nc, int bins) {
+    return head_channels == 64 && a == 2 && nc == 1 && (bins == 2 || bins == 0);
+}
+SEC_API int sec_heads_loss_supported(int head_channels, int anchors_per_loc, int num_class, int num_dir_bins, int dtype) {
+    return (dtype == SEC_BF16 || dtype == SEC_F16) && heads_loss_shape_ok(head_channels, anchors_per_loc, num_class, num_dir_bins) ? 1 : 0;
+}
+SEC_API size_t sec_heads_loss_workspace_bytes(int batch, int h, int w, int anchors_per_loc) {
+    if (batch <= 0 || h <= 0 || w <= 0 || anchors_per_loc <= 0) return 0;
+    const long long nb = div_up((long long)h * w, kBlock);
+    return align_up((size_t)2 * batch * kCountChunks * sizeof(float)) + align_up((size_t)batch * nb * 64 * sizeof(float)) + 256;
+}
+static void fill_loss_params(LossParams &P, int batch, int n_anchor, int nc, int bins, const float *h) {
+    P.batch = batch; P.n_anchor = n_anchor; P.num_class = nc; P.num_bins = bins;
+    P.alpha = h[0]; P.gamma = h[1]; P.sigma = h[2]; P.pos_w = h[3]; P.neg_w = h[4];
+    P.cls_w = h[5]; P.loc_w = h[6]; P.dir_w = h[7]; P.dir_offset = h[8];
+    P.sin_factor = h[9];
+    for (int j = 0; j < 7; ++j) P.code_w[j] = h[10 + j];
+}
+template <typename HT, bool GRAD>
+static void launch_heads_loss(int bins, dim3 grid, hipStream_t st, const void *heads, int HW, int HC, const int *labels, const float *reg,
+                              const float *anchors, const float *importance, const float *cnt, const LossParams &P, const float *g,
+                              void *d_heads, float *partial) {
+    if (bins == 2)
+        hipLaunchKernelGGL((k_heads_loss<HT, 2, 1, 2, GRAD>), grid, dim3(kBlock), 0, st, (const HT *)heads, HW, HC, labels, reg, anchors, importance,
+                           cnt, P, g, (HT *)d_heads, partial);
+    else
+        hipLaunchKernelGGL((k_heads_loss<HT, 2, 1, 0, GRAD>), grid, dim3(kBlock), 0, st, (const HT *)heads, HW, HC, labels, reg, anchors, importance,
+                           cnt, P, g, (HT *)d_heads, partial);
+}
+static int heads_loss_impl(bool grad, const void *heads, int dtype, int batch, int h, int w, int head_channels, int a, int nc, int bins,
+                           const int *labels, const float *reg_targets, const float *anchors, const float *importance,
+                           const float *h_params17, const float *grad_loss, void *d_heads, float *d_bias, float *out6, void *workspace,
+                           size_t workspace_bytes, void *stream) {
+    if (!heads || batch <= 0 || h <= 0 || w <= 0 || !labels || !reg_targets || !anchors || !importance || !h_params17 ||
+        (grad ? (!d_heads || !d_bias) : !out6))
+        return SEC_E_INVALID;
+    if (!sec_heads_loss_supported(head_channels, a, nc, bins, dtype)) return SEC_E_UNSUPPORTED;
+    if (!workspace || workspace_bytes < sec_heads_loss_workspace_bytes(batch, h, w, a)) return SEC_E_WORKSPACE;
+    const int HW = h * w, n_anchor = a * HW;
+    LossParams P;
+    fill_loss_params(P, batch, n_anchor, nc, bins, h_params17);
+    Arena ar(workspace, workspace_bytes);
+    float *cnt = ar.take<float>((size_t)2 * batch * kCountChunks);
+    const int nb = div_up(HW, kBlock);
+    float *partial = ar.take<float>((size_t)batch * nb * 64);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_loss_count, dim3(kCountChunks, batch), dim3(kBlock), 0, st, labels, n_anchor, cnt, importance);
+    const dim3 grid(nb, batch);
+    if (!grad) {
+        if (dtype == SEC_BF16) launch_heads_loss<__hip_bfloat16, false>(bins, grid, st, heads, HW, head_channels, labels, reg_targets, anchors, importance, cnt, P, nullptr, nullptr, partial);
+        else launch_heads_loss<__half, false>(bins, grid, st, heads, HW, head_channels, labels, reg_targets, anchors, importance, cnt, P, nullptr, nullptr, partial);
+        hipLaunchKernelGGL(k_loss_final, dim3(1), dim3(kBlock), 0, st, partial, batch * nb, P, out6);
+    } else {
+        if (dtype == SEC_BF16) launch_heads_loss<__hip_bfloat16, true>(bins, grid, st, heads, HW, head_channels, labels, reg_targets, anchors, importance, cnt, P, grad_loss, d_heads, partial);
+        else launch_heads_loss<__half, true>(bins, grid, st, heads, HW, head_channels, labels, reg_targets, anchors, importance, cnt, P, grad_loss, d_heads, partial);
+        const int cols = (a * (7 + nc + bins) + 7) / 8 * 8;
+        hipLaunchKernelGGL(k_heads_bias_final, dim3(1), dim3(kBlock), 0, st, partial, batch * nb, cols, head_channels, d_bias);
+    }
+    return check_launch();
+}
+SEC_API int sec_heads_loss_fwd(const void *heads, int dtype, int batch, int h, int w, int head_channels, int anchors_per_loc, int num_class,
+                               int num_dir_bins, const int *labels, const float *reg_targets, const float *anchors, const float *importance,
+                               const float *h_params17, float *out6, void *workspace, size_t workspace_bytes, void *stream) {
+    return heads_loss_impl(false, heads, dtype, batch, h, w, head_channels, anchors_per_loc, num_class, num_dir_bins, labels, reg_targets, anchors,
+                           importance, h_params17, nullptr, nullptr, nullptr, out6, workspace, workspace_bytes, stream);
+}
+SEC_API int sec_heads_loss_bwd(const void *heads, int dtype, int batch, int h, int w, int head_channels, int anchors_per_loc, int num_class,
+                               int num_dir_bins, const int *labels, const float *reg_targets, const float *anchors, const float *importance,
+                               const float *h_params17, const float *grad_loss, void *d_heads, float *d_bias, void *workspace,
+                               size_t workspace_bytes, void *stream) {
+    return heads_loss_impl(true, heads, dtype, batch, h, w, head_channels, anchors_per_loc, num_class, num_dir_bins, labels, reg_targets, anchors,
+                           importance, h_params17, grad_loss, d_heads, d_bias, nullptr, workspace, workspace_bytes, stream);
 }
 
 SEC_API size_t sec_flat_adamw_workspace_bytes(void) { return align_up((size_t)kAdamBlocks * sizeof(float) + 256); }

@@ -122,11 +122,11 @@ __global__ __launch_bounds__(kBlock) void k_vox_flag_scan(const int *__restrict_
         s4[0] = q.x; s4[1] = q.y; s4[2] = q.z; s4[3] = q.w;
     } else {
 #pragma unroll
-        for (int j = 0; j < kFlagItems; ++j) s4[j] = i0 + j < n ? pslot[i0 + j] : -1;
+        for (int j = 0; j < kFlagItems; ++j) s4[j] = ld_sel(pslot, i0 + j, i0 + j < n, -1);
     }
 #pragma unroll
     for (int j = 0; j < kFlagItems; ++j) {
-        f[j] = (s4[j] >= 0 && vals[s4[j]] == i0 + j) ? 1 : 0;
+        f[j] = (ld_sel(vals, s4[j], s4[j] >= 0, -1) == i0 + j) ? 1 : 0;      // unconditional loads: all ITEMS in flight at once
         v += f[j];
     }
     int ex = scan_lookback(v, tile, (int)gridDim.x, status, smem, total);
@@ -296,11 +296,11 @@ __global__ __launch_bounds__(kBlock) void k_vox_scan_assign_cascade(const float 
         }
     } else {
 #pragma unroll
-        for (int j = 0; j < ITEMS; ++j) s4[j] = i0 + j < n ? pslot[i0 + j] : -1;
+        for (int j = 0; j < ITEMS; ++j) s4[j] = ld_sel(pslot, i0 + j, i0 + j < n, -1);
     }
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
-        f[j] = (s4[j] >= 0 && vals[s4[j]] == i0 + j) ? 1 : 0;
+        f[j] = (ld_sel(vals, s4[j], s4[j] >= 0, -1) == i0 + j) ? 1 : 0;      // unconditional loads: all ITEMS in flight at once
         v += f[j];
     }
     int ex = scan_lookback(v, tile, ntiles, status, smem, total);
@@ -479,13 +479,15 @@ __global__ __launch_bounds__(kBlock) void k_vox_fill_mean4(const float *__restri
     const int *slots = slot_idx + (size_t)vid * p.max_points;
     float4 s = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     float4 q[kCascadeMaxPoints];
+    int sl[kCascadeMaxPoints];
 #pragma unroll
-    for (int t = 0; t < kCascadeMaxPoints; ++t)       // all gathers in flight together (max_points <= kCascadeMaxPoints here)
-        q[t] = t < n ? pts[slots[t]] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (int t = 0; t < kCascadeMaxPoints; ++t) sl[t] = ld_sel(slots, t, t < n, 0);
 #pragma unroll
-    for (int t = 0; t < kCascadeMaxPoints; ++t) {
-        if (t >= p.max_points) break;
-        dst[t] = q[t];
+    for (int t = 0; t < kCascadeMaxPoints; ++t)       // all gathers in flight together (max_points <= kCascadeMaxPoints here): ld_sel, not `?:`
+        q[t] = ld_sel(pts, sl[t], t < n, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+#pragma unroll
+    for (int t = 0; t < kCascadeMaxPoints; ++t) {          // (no `break`: an early exit between the gathers made hipcc wait for each one in turn)
+        if (t < p.max_points) dst[t] = q[t];
         s.x = __fadd_rn(s.x, q[t].x); s.y = __fadd_rn(s.y, q[t].y); s.z = __fadd_rn(s.z, q[t].z); s.w = __fadd_rn(s.w, q[t].w);
     }
     const float inv = (float)n;

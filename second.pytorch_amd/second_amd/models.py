@@ -391,7 +391,7 @@ class RPNV2(nn.Module):
 RPN_TRAIN_BACKEND = "hip"
 
 
-def rpn_forward_mixed(rpn, x, dtype):
+def rpn_forward_mixed(rpn, x, dtype, loss_args=None):
     """Training forward of an RPNV2 with 16-bit activations over its fp32 master weights (the DeviceTrainer's amp path).  Every
     Conv2d(128, 128, 3, stride 1) + BatchNorm2d + ReLU triple of the blocks runs on the hand-written kernels -- forward and data
     gradient on k_conv2d_halo_reg, weight gradient on k_conv2d_wgrad3x3, BatchNorm (batch statistics) + ReLU fused
@@ -399,7 +399,10 @@ def rpn_forward_mixed(rpn, x, dtype):
     other-width convs, the deblocks, the 1x1 heads) stays on torch under autocast.  ``models.RPN_TRAIN_BACKEND = "miopen"``: all of it
     on torch (the round-2 path; tests compare the two).  Same arithmetic as RPNV2.forward up to 16-bit rounding of the activations.  (autocast's
     weight-cast cache is off: the function is captured into hipGraphs by DeviceTrainer, and a cached cast made during capture
-    would be stale on replay.)"""
+    would be stale on replay.)
+    ``loss_args`` = (labels, reg_targets, anchors, importance, loss_cfg): when the heads run as one stacked convolution and the loss
+    kernel has that head shape, the loss is taken from the stacked tensor (ops.HeadsLossFunction) and {"loss", "out6"} comes back
+    instead of the three prediction tensors."""
     use_hip = RPN_TRAIN_BACKEND == "hip" and x.is_cuda
     x = x.to(dtype).contiguous(memory_format=torch.channels_last)
 
@@ -466,6 +469,14 @@ def rpn_forward_mixed(rpn, x, dtype):
         wz = ups[0].new_zeros((64 - tot, 128, 1, 1), dtype=heads[0][0].weight.dtype)
         wcat = torch.cat([c.weight for c, _, _ in heads] + [wz], 0)
         bcat = torch.cat([c.bias for c, _, _ in heads] + [wz.new_zeros(64 - tot)], 0)
+        bins = rpn._num_direction_bins if rpn._use_direction_classifier else 0
+        if (loss_args is not None and rpn._box_code_size == 7
+                and ops.heads_loss_supported(64, a, rpn._num_class, bins, dtype)):
+            # the loss straight from the stacked head tensor, its gradient straight back into it (ops.HeadsLossFunction)
+            labels, reg_targets, anchors, importance, loss_cfg = loss_args
+            loss, out6 = ops.HeadsLossFunction.apply(ups[0].contiguous(memory_format=torch.channels_last), wcat, bcat, labels, reg_targets,
+                                                     anchors, importance, a, rpn._num_class, bins, loss_cfg)
+            return {"loss": loss, "out6": out6}
         y = ops.Heads1x1Function.apply(ups[0].contiguous(memory_format=torch.channels_last), wcat, bcat)
         ret, c0 = {}, 0
         h, w = y.shape[2:]

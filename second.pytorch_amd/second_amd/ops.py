@@ -499,19 +499,24 @@ def sparse_to_dense(features, indices, batch_size, spatial_shape, channels_last_
     return out
 
 
-def dense_to_sparse(dense, indices, num_dev=None):
-    """rows[i,:] = dense[b_i, :, (z_i,) y_i, x_i]: the adjoint of :func:`sparse_to_dense` ([B,C,D,H,W]) and of
-    :func:`pillar_scatter` ([B,C,H,W], z ignored) -- what autograd needs for their backward.  ``num_dev``: static capacity --
-    only the first num_dev[0] rows are gathered (the others stay unwritten)."""
+def dense_to_sparse(dense, indices, num_dev=None, depth=0):
+    """rows[i,:] = dense[b_i, :, (z_i,) y_i, x_i]: the adjoint of :func:`sparse_to_dense` ([B,C,D,H,W]; with ``depth`` = D > 0 of its
+    ``channels_last_2d`` form [B, C*D, H, W], channel = c * D + z, in any strides) and of :func:`pillar_scatter` ([B,C,H,W], z
+    ignored) -- what autograd needs for their backward.  ``num_dev``: static capacity -- only the first num_dev[0] rows are gathered
+    (the others stay unwritten)."""
     rt.require_gpu(dense, indices)
     n = indices.shape[0]
     c = dense.shape[1]
-    rows = torch.empty((n, c), dtype=dense.dtype, device=dense.device)
     st = [int(v) for v in dense.stride()]
     if dense.dim() == 5:
         sb, sc, sz, sy, sx = st
+    elif depth:
+        assert c % depth == 0
+        c //= depth
+        sb, sc, sz, sy, sx = st[0], st[1] * depth, st[1], st[2], st[3]
     else:
         (sb, sc, sy, sx), sz = st, 0
+    rows = torch.empty((n, c), dtype=dense.dtype, device=dense.device)
     rc = rt.lib().sec_dense_to_sparse(rt.ptr(dense), rt.ptr(indices.contiguous()), n, c, rt.ptr(num_dev), rt.ptr(rows), sb, sc, sz, sy, sx,
                                       rt.dtype_code(dense.dtype), rt.stream())
     rt.check(rc, "sec_dense_to_sparse")
@@ -1385,8 +1390,8 @@ class ConvTranspose1x1Function(torch.autograd.Function):
 class Heads1x1Function(torch.autograd.Function):
     """The RPN's 1x1 heads (conv_box / conv_cls / conv_dir_cls with bias, rpn.py:386-391) as ONE 1x1 convolution 128 -> 64 (the
     heads' output channels stacked and zero padded) on channels_last 16-bit activations over an fp32 weight [64, 128, 1, 1] and
-    bias [64]: forward and data gradient on sec_conv2d_nhwc, weight gradient on the one-tap form of k_conv2d_wgrad3x3 (the
-    incoming gradient padded to 128 channels), bias gradient a pixel sum."""
+    bias [64]: forward and data gradient on sec_conv2d_nhwc, weight gradient on the one-tap form of k_conv2d_wgrad3x3, bias gradient
+    a pixel sum."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -1404,13 +1409,75 @@ class Heads1x1Function(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = conv2d_nhwc(dy, pk_d, None, ctx.wshape[1], 1, 1, 0, relu=False)
         if ctx.needs_input_grad[1]:
-            b, c, h, w = dy.shape
-            wide = torch.zeros((b, 128, h, w), dtype=dy.dtype, device=dy.device).contiguous(memory_format=torch.channels_last)
-            wide[:, :c] = dy
-            dw = conv2d_wgrad(x, wide, 1)[:c].contiguous().to(ctx.wdtype)
+            dw = conv2d_wgrad(x, dy, 1).to(ctx.wdtype)         # the one-tap kernel reads the 64-channel gradient as it is
         if ctx.needs_input_grad[2]:
             db = dy.float().sum(dim=(0, 2, 3)).to(ctx.bdtype)
         return dx, dw, db
+
+
+def heads_loss_supported(head_channels, anchors_per_loc, num_class, num_dir_bins, dtype):
+    return dtype in (torch.bfloat16, torch.float16) and bool(rt.lib().sec_heads_loss_supported(
+        int(head_channels), int(anchors_per_loc), int(num_class), int(num_dir_bins), rt.dtype_code(dtype)))
+
+
+def _loss_params(cfg):
+    p = dict(LOSS_DEFAULTS, **{k: v for k, v in cfg.items() if k in LOSS_DEFAULTS})
+    return rt.f_arr([p["alpha"], p["gamma"], p["sigma"], p["pos_cls_weight"], p["neg_cls_weight"], p["classification_weight"],
+                     p["localization_weight"], p["direction_loss_weight"], p["direction_offset"], p["sin_error_factor"],
+                     *p["code_weights"]])
+
+
+class HeadsLossFunction(torch.autograd.Function):
+    """loss, out6 = HeadsLossFunction.apply(x, weight, bias, labels, reg_targets, anchors, importance, anchors_per_loc, num_class,
+    num_dir_bins, cfg): the stacked 1x1 heads (Heads1x1Function: one 128 -> 64 convolution, box | cls | dir | padding) AND
+    VoxelNet.loss (voxelnet.py:239-312) on their output without ever splitting it: sec_heads_loss_fwd reads the channels-last 16-bit
+    head tensor, backward's sec_heads_loss_bwd writes the gradient of the loss -- times the gradient arriving at `loss`, a device
+    scalar (the loss scale of fp16 training) -- in the same layout, together with the bias gradient; the data and weight gradients of
+    the convolution follow on sec_conv2d_nhwc / the one-tap weight-gradient kernel.  Replaces the three permute + float copies the
+    reference's formulation needs forward and the ~30 small kernels autograd runs to stitch three gradients back (0.25 ms of a
+    3.5 ms car.fhd step).  Same values as Heads1x1Function + SecondLossFunction up to the order of the loss sums."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, labels, reg_targets, anchors, importance, anchors_per_loc, num_class, num_dir_bins, cfg):
+        rt.require_gpu(x, labels, reg_targets, anchors, importance)
+        pk_f, pk_d = conv2d_pack_weight_train(weight.detach().contiguous(), x.dtype)
+        y = conv2d_nhwc(x, pk_f, bias.detach().float().contiguous(), weight.shape[0], 1, 1, 0, relu=False)
+        b, hc, h, w = y.shape
+        a, nc, bins = int(anchors_per_loc), int(num_class), int(num_dir_bins)
+        assert labels.dtype == torch.int32 and labels.is_contiguous() and tuple(labels.shape) == (b, a * h * w)
+        for t in (reg_targets, anchors, importance):
+            assert t.dtype == torch.float32 and t.is_contiguous()
+        params = _loss_params(cfg)
+        out6 = torch.empty((6,), dtype=torch.float32, device=x.device)
+        l = rt.lib()
+        ws = rt.workspace(l.sec_heads_loss_workspace_bytes(b, h, w, a), x.device)
+        rt.check(l.sec_heads_loss_fwd(rt.ptr(y), rt.dtype_code(y.dtype), b, h, w, hc, a, nc, bins, rt.ptr(labels), rt.ptr(reg_targets),
+                                      rt.ptr(anchors), rt.ptr(importance), params, rt.ptr(out6), rt.ptr(ws), ws.numel(), rt.stream()),
+                 "sec_heads_loss_fwd")
+        ctx.save_for_backward(x, pk_d, y, labels, reg_targets, anchors, importance)
+        ctx.meta = (a, nc, bins, params, tuple(weight.shape), weight.dtype, bias.dtype)
+        ctx.mark_non_differentiable(out6)
+        return out6[0], out6
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_all):
+        x, pk_d, y, labels, reg_targets, anchors, importance = ctx.saved_tensors
+        a, nc, bins, params, wshape, wdtype, bdtype = ctx.meta
+        b, hc, h, w = y.shape
+        g = g_loss.detach().reshape(1).float().contiguous()
+        dy = torch.empty_like(y)                                  # channels_last like y
+        db = torch.empty((hc,), dtype=torch.float32, device=y.device)
+        l = rt.lib()
+        ws = rt.workspace(l.sec_heads_loss_workspace_bytes(b, h, w, a), y.device)
+        rt.check(l.sec_heads_loss_bwd(rt.ptr(y), rt.dtype_code(y.dtype), b, h, w, hc, a, nc, bins, rt.ptr(labels), rt.ptr(reg_targets),
+                                      rt.ptr(anchors), rt.ptr(importance), params, rt.ptr(g), rt.ptr(dy), rt.ptr(db), rt.ptr(ws),
+                                      ws.numel(), rt.stream()), "sec_heads_loss_bwd")
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = conv2d_nhwc(dy, pk_d, None, wshape[1], 1, 1, 0, relu=False)
+        if ctx.needs_input_grad[1]:
+            dw = conv2d_wgrad(x, dy, 1).to(wdtype)
+        return dx, dw, (db.to(bdtype) if ctx.needs_input_grad[2] else None), None, None, None, None, None, None, None, None
 
 
 class BatchNormReluFunction(torch.autograd.Function):

@@ -163,6 +163,7 @@ class DeviceTrainer:
         self.loss_scale = float(init_loss_scale) if (amp_dtype == torch.float16 and not self.flat_opt) else None
         self._good_steps, self._skipped_host = 0, 0
         self._graphed_rpn = None
+        self.fused_head_loss = os.environ.get("SEC_TRAIN_FUSED_HEAD_LOSS", "1") != "0"   # A/B switch (tests compare the two forms)
         self.steps = 0
         self.last = {}
 
@@ -214,16 +215,21 @@ class DeviceTrainer:
         elif self.amp_dtype is not None:
             # fp32 master weights; 16-bit features through the sparse stack (MFMA forward / dgrad / wgrad kernels) and,
             # under autocast, through the dense RPN; BatchNorm statistics and the loss in fp32
-            spatial = det.middle_feature_extractor(vox["mean"].to(self.amp_dtype), vox["coordinates"], batch,
+            # (channels_last: the dense scatter writes the RPN's layout and the gradient is gathered from it -- the [B, C, D, H, W]
+            # form cost a 36 MB permute copy forward and another one backward, 48 us each)
+            spatial = det.middle_feature_extractor(vox["mean"].to(self.amp_dtype), vox["coordinates"], batch, channels_last=True,
                                                    site_table=vox.get("site_table"), num_active_dev=nd)
-            preds = self._rpn_mixed(spatial)                  # 3x3 convs + BatchNorm/ReLU on the hand-written kernels
+            # 3x3 convs + BatchNorm/ReLU on the hand-written kernels; the loss from the stacked head tensor where its shape allows
+            preds = self._rpn_mixed(spatial, loss_args=(labels, reg_targets, det.anchors, importance, self.loss_cfg) if self.fused_head_loss else None)
+            if "loss" in preds:
+                return preds["loss"], preds["out6"], labels
         else:
             preds = det.network_forward(vox["mean"], vox["coordinates"], batch, site_table=vox.get("site_table"))
         loss, out6 = ops.SecondLossFunction.apply(preds["cls_preds"], preds["box_preds"], preds.get("dir_cls_preds"), labels,
                                                   reg_targets, det.anchors, importance, self.loss_cfg)
         return loss, out6, labels
 
-    def _rpn_mixed(self, spatial):
+    def _rpn_mixed(self, spatial, loss_args=None):
         """The dense part of the step has static shapes ([B, 128, H, W] whatever the clouds hold), ~100 launches forward + backward,
         and the eager step is HOST bound (541 launches at ~14 us each = 7.6 ms for 4.9 ms of kernels, profiles/r03_e_*): its
         forward and backward are therefore captured once as two hipGraphs (torch.cuda.make_graphed_callables over the same
@@ -232,7 +238,7 @@ class DeviceTrainer:
         from .models import rpn_forward_mixed
         x = spatial.to(self.amp_dtype).contiguous(memory_format=torch.channels_last)
         if self.static or not self.graph_rpn or not x.is_cuda:
-            return rpn_forward_mixed(self.det.rpn, x, self.amp_dtype)      # static: the WHOLE step is one graph (capture_step)
+            return rpn_forward_mixed(self.det.rpn, x, self.amp_dtype, loss_args=loss_args)      # static: the WHOLE step is one graph (capture_step)
         key = (tuple(x.shape), x.dtype)
         if self._graphed_rpn is None or self._graphed_rpn[0] != key:
             self._graphed_rpn = (key, self._capture_rpn(x))

@@ -50,15 +50,17 @@ class SparseToDenseFunction(torch.autograd.Function):
     """dense() with a gradient (upstream: scatter_nd under autograd, spconv/__init__.py SparseConvTensor.dense)."""
 
     @staticmethod
-    def forward(ctx, features, indices, batch_size, spatial_shape, num_dev=None):
+    def forward(ctx, features, indices, batch_size, spatial_shape, num_dev=None, channels_last_2d=False):
         ctx.save_for_backward(indices)
         ctx.num_dev = num_dev              # static capacity: rows past num_dev[0] are neither scattered nor gathered back
-        return _ops.sparse_to_dense(features, indices, batch_size, spatial_shape, num_dev=num_dev)
+        ctx.depth = int(spatial_shape[0]) if channels_last_2d else 0
+        return _ops.sparse_to_dense(features, indices, batch_size, spatial_shape, channels_last_2d=channels_last_2d, num_dev=num_dev)
 
     @staticmethod
     def backward(ctx, grad):
         (indices,) = ctx.saved_tensors
-        return _ops.dense_to_sparse(grad, indices, num_dev=ctx.num_dev), None, None, None, None
+        # channels_last_2d: grad is the [B, C * D, H, W] gradient of the RPN input, gathered in whatever strides it arrives in
+        return _ops.dense_to_sparse(grad, indices, num_dev=ctx.num_dev, depth=ctx.depth), None, None, None, None, None
 
 
 class PillarScatterFunction(torch.autograd.Function):

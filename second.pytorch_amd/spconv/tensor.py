@@ -66,6 +66,10 @@ class SparseConvTensor:
     def dense_channels_last_2d(self):
         """[B, C*D, H, W] in channels_last memory format == dense().view(B, C*D, H, W) values
         (the RPN input of second/pytorch/models/middle.py:206-210) without the permute copy."""
+        if torch.is_grad_enabled() and self.features.requires_grad:   # training: differentiable, gradient gathered from its own strides
+            from .functional import SparseToDenseFunction
+            return SparseToDenseFunction.apply(self.features, self.indices.contiguous(), self.batch_size, self.spatial_shape,
+                                               self.num_active_dev, True)
         return _ops.sparse_to_dense(self.features, self.indices.contiguous(), self.batch_size, self.spatial_shape,
                                     channels_last_2d=True, num_dev=self.num_active_dev)
 

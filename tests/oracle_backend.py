@@ -134,10 +134,13 @@ def pillar_scatter(features, coords, batch_size, ny, nx, channels_last=False, nu
     return torch.from_numpy(orc.pillar_scatter(_np(features.float()), _np(coords), batch_size, ny, nx)).to(features.dtype)
 
 
-def dense_to_sparse(dense, indices, num_dev=None):
+def dense_to_sparse(dense, indices, num_dev=None, depth=0):
     idx = indices.long()
     if dense.dim() == 5:
         return dense[idx[:, 0], :, idx[:, 1], idx[:, 2], idx[:, 3]].contiguous()
+    if depth:                                     # [B, C * D, H, W], channel = c * D + z
+        b, cd, h, w = dense.shape
+        return dense.reshape(b, cd // depth, depth, h, w)[idx[:, 0], :, idx[:, 1], idx[:, 2], idx[:, 3]].contiguous()
     return dense[idx[:, 0], :, idx[:, 2], idx[:, 3]].contiguous()
 
 
