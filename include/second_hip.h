@@ -212,19 +212,22 @@ int sec_indice_conv_set_variant(int variant);
 /* backward (spconv_ops.h indiceConvBackward): dfeat[j,:] = sum_k dout[nbr_in[j][k],:] @ W[k]^T ;
  * dW[k] = sum_o feat[nbr_out[o][k],:]^T dout[o,:].  fp32 gradients for weights, feature dtype for dfeat.
  * For 16-bit dtypes dfeat runs on the MFMA forward kernels over re-packed transposed weights, which live in
- * `workspace` (sec_indice_conv_bwd_workspace_bytes; NULL / too small selects the slower generic kernel). */
+ * `workspace` (sec_indice_conv_bwd_workspace_bytes; NULL / too small selects the slower generic kernel).
+ * dweight is accumulated with atomics into a zeroed buffer: `dweight_zeroed` != 0 says the caller zeroed it already (the
+ * forward's sec_pack_conv_weight_train does, in the launch it runs anyway); 0: the call zeroes it (one memset node). */
 size_t sec_indice_conv_bwd_workspace_bytes(int kvol, int cin, int cout, int dtype);
 int sec_indice_conv_bwd(const void *features, int n_in, int cin, const void *weight, int kvol, int cout,
                         const int *nbr_out, const int *nbr_in, int n_out, const void *dout,
                         void *dfeat, float *dweight, int dtype, void *workspace, size_t workspace_bytes,
-                        const void *packed_dgrad, void *stream);
+                        const void *packed_dgrad, int dweight_zeroed, void *stream);
 /* Mixed-precision training (fp32 master weights, 16-bit features; train.py:196-203 keeps fp32 copies the same way): the three
  * 16-bit images of one layer's weight [kvol][cin][cout] in ONE launch -- `weight16` (the plain rounding), `packed_fwd`
  * (sec_pack_conv_weight's image; NULL when sec_packed_weight_bytes(kvol, cin, cout) is 0) and `packed_dgrad` (the transposed image
  * sec_indice_conv_bwd otherwise builds per call, sec_packed_weight_bytes(kvol, cout, cin) bytes; `subm` != 0: offsets mirrored,
- * as for a rulebook without an input-major table; NULL to skip).  Pass `packed_dgrad` to sec_indice_conv_bwd. */
+ * as for a rulebook without an input-major table; NULL to skip).  Pass `packed_dgrad` to sec_indice_conv_bwd.
+ * `zero_dweight` (optional, [kvol][cin][cout] fp32): zeroed by the same launch -- the accumulator the layer's backward will use. */
 int sec_pack_conv_weight_train(const float *weight, int kvol, int cin, int cout, int subm, int dtype, void *weight16,
-                               void *packed_fwd, void *packed_dgrad, void *stream);
+                               void *packed_fwd, void *packed_dgrad, float *zero_dweight, void *stream);
 
 /* SparseConvTensor.dense() (spconv/__init__.py; consumed at second/pytorch/models/middle.py:206-210).
  * Scatter rows into a zero-initialised dense tensor with arbitrary element strides so the same kernel

@@ -2212,10 +2212,11 @@ SEC_API int sec_indice_conv_fwd(const void *features, int n_in, int cin, const v
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_pack_weight_train(const float *__restrict__ w, int kvol, int cin, int cout, int mirror,
                                                              T *__restrict__ w16, T *__restrict__ packed, long long total_fwd,
-                                                             T *__restrict__ packed_t, long long total_t) {
+                                                             T *__restrict__ packed_t, long long total_t, float *__restrict__ zero_dw) {
     const long long g = (long long)blockIdx.x * kBlock + threadIdx.x;
     const long long total0 = (long long)kvol * cin * cout;
     if (g < total0) w16[g] = Cvt<T>::from(w[g]);
+    if (zero_dw && g < total0) zero_dw[g] = 0.0f;              // the accumulator of this step's weight gradient (sec_indice_conv_bwd, dweight_zeroed)
     const int e = (int)(g & 7), lane = (int)((g >> 3) & 63);
     if (packed && g < total_fwd) {
         if (cin == 4) {                                         // k_pack_weight_c4
@@ -2247,7 +2248,7 @@ __global__ __launch_bounds__(kBlock) void k_pack_weight_train(const float *__res
 template <typename T>
 static int run_bwd(const void *features, int n_in, int cin, const void *weight, int kvol, int cout, const int *nbr_out,
                    const int *nbr_in, int n_out, const void *dout, void *dfeat, float *dweight, void *workspace,
-                   size_t workspace_bytes, int dtype, hipStream_t st, const void *packed_dgrad = nullptr) {
+                   size_t workspace_bytes, int dtype, hipStream_t st, const void *packed_dgrad = nullptr, bool dweight_zeroed = false) {
     int rc;
     if (dfeat && n_in > 0) {
         const int *tbl = nbr_in ? nbr_in : nbr_out;  // SubM: nbr_in is the mirror image of nbr_out
@@ -2276,7 +2277,8 @@ static int run_bwd(const void *features, int n_in, int cin, const void *weight, 
         }
     }
     if (dweight) {
-        if ((rc = hip_ok(hipMemsetAsync(dweight, 0, (size_t)kvol * cin * cout * sizeof(float), st)))) return rc;
+        // (dweight_zeroed: the forward's sec_pack_conv_weight_train zeroed it -- one memset node per layer and step less)
+        if (!dweight_zeroed && (rc = hip_ok(hipMemsetAsync(dweight, 0, (size_t)kvol * cin * cout * sizeof(float), st)))) return rc;
         if (n_out > 0 && !launch_wgrad_tiled<T>(features, dout, nbr_out, n_out, cin, cout, kvol, dweight, st)) {
             int rows_per_chunk = 512;
             hipLaunchKernelGGL(k_conv_wgrad<T>, dim3(div_up(n_out, rows_per_chunk), kvol), dim3(kBlock), 0, st,
@@ -2293,18 +2295,18 @@ SEC_API size_t sec_indice_conv_bwd_workspace_bytes(int kvol, int cin, int cout, 
 SEC_API int sec_indice_conv_bwd(const void *features, int n_in, int cin, const void *weight, int kvol, int cout,
                                 const int *nbr_out, const int *nbr_in, int n_out, const void *dout, void *dfeat,
                                 float *dweight, int dtype, void *workspace, size_t workspace_bytes, const void *packed_dgrad,
-                                void *stream) {
+                                int dweight_zeroed, void *stream) {
     if (n_in < 0 || n_out < 0 || cin <= 0 || cout <= 0 || kvol <= 0 || !weight || !nbr_out || !dout) return SEC_E_INVALID;
     if (!nbr_in && n_in != n_out) return SEC_E_INVALID;
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == SEC_F32) return run_bwd<float>(features, n_in, cin, weight, kvol, cout, nbr_out, nbr_in, n_out, dout, dfeat, dweight, workspace, workspace_bytes, dtype, st);
-    if (dtype == SEC_F16) return run_bwd<__half>(features, n_in, cin, weight, kvol, cout, nbr_out, nbr_in, n_out, dout, dfeat, dweight, workspace, workspace_bytes, dtype, st, packed_dgrad);
-    if (dtype == SEC_BF16) return run_bwd<__hip_bfloat16>(features, n_in, cin, weight, kvol, cout, nbr_out, nbr_in, n_out, dout, dfeat, dweight, workspace, workspace_bytes, dtype, st, packed_dgrad);
+    if (dtype == SEC_F32) return run_bwd<float>(features, n_in, cin, weight, kvol, cout, nbr_out, nbr_in, n_out, dout, dfeat, dweight, workspace, workspace_bytes, dtype, st, nullptr, dweight_zeroed != 0);
+    if (dtype == SEC_F16) return run_bwd<__half>(features, n_in, cin, weight, kvol, cout, nbr_out, nbr_in, n_out, dout, dfeat, dweight, workspace, workspace_bytes, dtype, st, packed_dgrad, dweight_zeroed != 0);
+    if (dtype == SEC_BF16) return run_bwd<__hip_bfloat16>(features, n_in, cin, weight, kvol, cout, nbr_out, nbr_in, n_out, dout, dfeat, dweight, workspace, workspace_bytes, dtype, st, packed_dgrad, dweight_zeroed != 0);
     return SEC_E_UNSUPPORTED;
 }
 
 SEC_API int sec_pack_conv_weight_train(const float *weight, int kvol, int cin, int cout, int subm, int dtype, void *weight16,
-                                       void *packed_fwd, void *packed_dgrad, void *stream) {
+                                       void *packed_fwd, void *packed_dgrad, float *zero_dweight, void *stream) {
     if (!weight || !weight16 || kvol <= 0 || cin <= 0 || cout <= 0 || (dtype != SEC_BF16 && dtype != SEC_F16)) return SEC_E_INVALID;
     const long long total0 = (long long)kvol * cin * cout;
     const long long total_fwd = packed_fwd ? (long long)(sec_packed_weight_bytes(kvol, cin, cout, dtype) / 2) : 0;
@@ -2315,9 +2317,9 @@ SEC_API int sec_pack_conv_weight_train(const float *weight, int kvol, int cin, i
     hipStream_t st = (hipStream_t)stream;
     if (dtype == SEC_BF16)
         hipLaunchKernelGGL(k_pack_weight_train<__hip_bfloat16>, dim3(div_up(total, kBlock)), dim3(kBlock), 0, st, weight, kvol, cin, cout, subm ? 1 : 0,
-                           (__hip_bfloat16 *)weight16, (__hip_bfloat16 *)packed_fwd, total_fwd, (__hip_bfloat16 *)packed_dgrad, total_t);
+                           (__hip_bfloat16 *)weight16, (__hip_bfloat16 *)packed_fwd, total_fwd, (__hip_bfloat16 *)packed_dgrad, total_t, zero_dweight);
     else
         hipLaunchKernelGGL(k_pack_weight_train<__half>, dim3(div_up(total, kBlock)), dim3(kBlock), 0, st, weight, kvol, cin, cout, subm ? 1 : 0,
-                           (__half *)weight16, (__half *)packed_fwd, total_fwd, (__half *)packed_dgrad, total_t);
+                           (__half *)weight16, (__half *)packed_fwd, total_fwd, (__half *)packed_dgrad, total_t, zero_dweight);
     return check_launch();
 }

@@ -435,11 +435,12 @@ def indice_conv_set_variant(variant):
     rt.check(rt.lib().sec_indice_conv_set_variant(int(variant)), "sec_indice_conv_set_variant")
 
 
-def pack_weight_train(weight, dtype, subm):
+def pack_weight_train(weight, dtype, subm, zero_grad=False):
     """fp32 master weight [kD,kH,kW,Cin,Cout] -> (16-bit copy, forward MFMA image or None, data-gradient MFMA image or None) in
     ONE launch (sec_pack_conv_weight_train): what a mixed-precision step otherwise spends to(dtype) + pack_weight + the transposed
     pack inside indice_conv_backward on.  ``subm``: the data-gradient image is offset-mirrored (SubM rulebooks have no input-major
-    table)."""
+    table).  ``zero_grad``: a fourth result, a zeroed fp32 tensor of the weight's shape written by the same launch -- hand it to
+    :func:`indice_conv_backward` as ``dweight_out`` (its own zeroing is a memset node per layer and step)."""
     rt.require_gpu(weight)
     assert weight.dtype == torch.float32 and weight.is_contiguous() and dtype in (torch.bfloat16, torch.float16)
     cin, cout = weight.shape[-2], weight.shape[-1]
@@ -449,28 +450,33 @@ def pack_weight_train(weight, dtype, subm):
     w16 = torch.empty(weight.shape, dtype=dtype, device=weight.device)
     pk = torch.empty((nf // 2,), dtype=dtype, device=weight.device) if nf else None
     pkt = torch.empty((nt // 2,), dtype=dtype, device=weight.device) if nt else None
+    dw0 = torch.empty(weight.shape, dtype=torch.float32, device=weight.device) if zero_grad else None
     rt.check(l.sec_pack_conv_weight_train(rt.ptr(weight), k, cin, cout, int(bool(subm)), code, rt.ptr(w16), rt.ptr(pk), rt.ptr(pkt),
-                                          rt.stream()), "sec_pack_conv_weight_train")
-    return w16, pk, pkt
+                                          rt.ptr(dw0), rt.stream()), "sec_pack_conv_weight_train")
+    return (w16, pk, pkt, dw0) if zero_grad else (w16, pk, pkt)
 
 
 def indice_conv_backward(features, weight, nbr_out, nbr_in, dout, need_dfeat=True, need_dweight=True, dweight_dtype=None,
-                         packed_dgrad=None):
+                         packed_dgrad=None, dweight_out=None):
     """(dfeat, dweight) of indice_conv (spconv.ops.indice_conv_backward). nbr_in None => SubM mirror.  The kernels accumulate
     dweight in fp32; it is returned in ``dweight_dtype`` (default: the weight's dtype; torch.float32 hands a mixed-precision
     caller the unrounded gradient of its fp32 master weight without a cast launch).  ``packed_dgrad``: the data-gradient image of
-    :func:`pack_weight_train` (mirrored iff nbr_in is None) -- the call then skips its own transposed pack."""
+    :func:`pack_weight_train` (mirrored iff nbr_in is None) -- the call then skips its own transposed pack.  ``dweight_out``: the
+    ZEROED fp32 accumulator of pack_weight_train(zero_grad=True); the gradient is accumulated into it and it is what comes back."""
     rt.require_gpu(features, weight, nbr_out, dout)
     cin, cout = weight.shape[-2], weight.shape[-1]
     k = weight.numel() // (cin * cout)
     dout = dout.contiguous()
     dfeat = torch.empty_like(features) if need_dfeat else None
-    dw = torch.empty(weight.shape, dtype=torch.float32, device=weight.device) if need_dweight else None
+    prezeroed = need_dweight and dweight_out is not None
+    if prezeroed:
+        assert dweight_out.dtype == torch.float32 and dweight_out.is_contiguous() and dweight_out.numel() == weight.numel()
+    dw = (dweight_out if prezeroed else torch.empty(weight.shape, dtype=torch.float32, device=weight.device)) if need_dweight else None
     l = rt.lib()
     ws = rt.workspace(l.sec_indice_conv_bwd_workspace_bytes(k, cin, cout, rt.dtype_code(features.dtype)), features.device)
     rc = l.sec_indice_conv_bwd(rt.ptr(features), features.shape[0], cin, rt.ptr(weight), k, cout, rt.ptr(nbr_out),
                                rt.ptr(nbr_in), dout.shape[0], rt.ptr(dout), rt.ptr(dfeat), rt.ptr(dw),
-                               rt.dtype_code(features.dtype), rt.ptr(ws), ws.numel(), rt.ptr(packed_dgrad), rt.stream())
+                               rt.dtype_code(features.dtype), rt.ptr(ws), ws.numel(), rt.ptr(packed_dgrad), int(prezeroed), rt.stream())
     rt.check(rc, "sec_indice_conv_bwd")
     return dfeat, (dw.to(dweight_dtype or weight.dtype) if dw is not None else None)
 

@@ -133,8 +133,8 @@ def lib():
         l.sec_packed_weight_x3_bytes.restype = sz
         l.sec_indice_conv_fwd_plan.argtypes = [ci] * 7
         l.sec_indice_conv_set_variant.argtypes = [ci]
-        l.sec_indice_conv_bwd.argtypes = [vp, ci, ci, vp, ci, ci, vp, vp, ci, vp, vp, vp, ci, vp, sz, vp, vp]
-        l.sec_pack_conv_weight_train.argtypes = [vp, ci, ci, ci, ci, ci, vp, vp, vp, vp]
+        l.sec_indice_conv_bwd.argtypes = [vp, ci, ci, vp, ci, ci, vp, vp, ci, vp, vp, vp, ci, vp, sz, vp, ci, vp]
+        l.sec_pack_conv_weight_train.argtypes = [vp, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp]
         l.sec_indice_conv_bwd_workspace_bytes.argtypes = [ci, ci, ci, ci]
         l.sec_sparse_to_dense.argtypes = [vp, vp, ci, ci, vp, vp, sz, i64, i64, i64, i64, i64, ci, vp]
         l.sec_dense_to_sparse.argtypes = [vp, vp, ci, ci, vp, vp, i64, i64, i64, i64, i64, ci, vp]

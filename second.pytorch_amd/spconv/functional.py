@@ -10,6 +10,7 @@ class IndiceConvFunction(torch.autograd.Function):
         ctx.rulebook = rulebook
         ctx.master_dtype = weight.dtype
         ctx.packed_dgrad = None
+        ctx.dw0 = None
         if weight.dtype != features.dtype:
             # mixed precision (fp32 master weight, 16-bit features): the cast copy is made HERE, outside autograd -- the weight
             # gradient comes out of the kernels in fp32 and goes straight to the master weight (no fp32 -> 16-bit -> fp32 round
@@ -17,8 +18,11 @@ class IndiceConvFunction(torch.autograd.Function):
             if (weight.is_cuda and weight.dtype == torch.float32 and features.dtype in (torch.bfloat16, torch.float16)
                     and getattr(rulebook, "subm", None) is not None):
                 # ... together with BOTH MFMA images of the step, one launch (the backward would pack the transposed one again)
-                weight, packed, ctx.packed_dgrad = _ops.pack_weight_train(weight.detach().contiguous(), features.dtype,
-                                                                          subm=rulebook.nbr_in is None)
+                # ... and the zeroed accumulator of the backward's weight gradient (otherwise a memset node per layer and step)
+                want_dw = weight.requires_grad and torch.is_grad_enabled()
+                res = _ops.pack_weight_train(weight.detach().contiguous(), features.dtype, subm=rulebook.nbr_in is None, zero_grad=want_dw)
+                weight, packed, ctx.packed_dgrad = res[:3]
+                ctx.dw0 = res[3] if want_dw else None
             else:
                 weight = weight.detach().to(features.dtype)
                 packed = _ops.pack_weight(weight.contiguous()) if weight.is_cuda and weight.dtype != torch.float32 else None
@@ -35,7 +39,8 @@ class IndiceConvFunction(torch.autograd.Function):
                                "under torch.enable_grad() to back-propagate through a strided sparse conv")
         dfeat, dw = _ops.indice_conv_backward(features.contiguous(), weight.contiguous(), rb.nbr_out, rb.nbr_in,
                                               grad_out.contiguous(), ctx.needs_input_grad[0], ctx.needs_input_grad[1],
-                                              dweight_dtype=ctx.master_dtype, packed_dgrad=ctx.packed_dgrad)
+                                              dweight_dtype=ctx.master_dtype, packed_dgrad=ctx.packed_dgrad, dweight_out=ctx.dw0)
+        ctx.dw0 = None                  # consumed: a second backward through this node (retain_graph) zeroes its own
         return dfeat, dw, None, None
 
 

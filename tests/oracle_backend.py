@@ -116,7 +116,8 @@ def indice_conv(features, weight, nbr_out, num_out, packed=None, scale=None, shi
     return torch.from_numpy(y.astype(np.float32)).to(out_dtype or features.dtype)
 
 
-def indice_conv_backward(features, weight, nbr_out, nbr_in, dout, need_dfeat=True, need_dweight=True, dweight_dtype=None, packed_dgrad=None):
+def indice_conv_backward(features, weight, nbr_out, nbr_in, dout, need_dfeat=True, need_dweight=True, dweight_dtype=None, packed_dgrad=None,
+                         dweight_out=None):
     pairs, num = _pairs_from_nbr(nbr_out, features.shape[0])
     dfeat, dw = orc.indice_conv_backward(_np(features.float()), _np(weight.float()), pairs, num, _np(dout.float()))
     return torch.from_numpy(dfeat).to(features.dtype), torch.from_numpy(dw).to(dweight_dtype or weight.dtype)

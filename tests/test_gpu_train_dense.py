@@ -537,7 +537,7 @@ def test_flat_adamw_device_side_loss_scaling_state_machine():
 def test_pack_weight_train_equals_the_three_separate_packs():
     """sec_pack_conv_weight_train: the 16-bit rounding, the forward MFMA image and the (mirrored / plain) data-gradient image of a
     layer in one launch == to(dtype) + sec_pack_conv_weight + the transposed pack sec_indice_conv_bwd builds itself; and a backward
-    that is handed the image returns the same bits as one that packs its own."""
+    that is handed the image returns the same bits as one that packs its own; the optional zeroed weight-gradient accumulator."""
     from second_amd import ops
     torch.manual_seed(5)
     for (k, cin, cout), dt in [((27, 4, 16), torch.bfloat16), ((27, 16, 32), torch.float16), ((27, 64, 64), torch.bfloat16), ((3, 64, 64), torch.bfloat16)]:
@@ -563,6 +563,14 @@ def test_pack_weight_train_equals_the_three_separate_packs():
             a = ops.indice_conv_backward(feat, w16, nbr_out[:n_out], nbr_in, dout, packed_dgrad=pkt)
             b = ops.indice_conv_backward(feat, w16, nbr_out[:n_out], nbr_in, dout)
             assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+            # the zeroed weight-gradient accumulator of the same launch (no memset node in the backward): same gradient to the
+            # order of the float atomics, and the returned tensor IS the accumulator
+            dw0 = ops.pack_weight_train(w, dt, subm, zero_grad=True)[3]
+            assert dw0.dtype == torch.float32 and dw0.shape == w.shape and float(dw0.abs().max()) == 0.0
+            c = ops.indice_conv_backward(feat, w16, nbr_out[:n_out], nbr_in, dout, packed_dgrad=pkt, dweight_dtype=torch.float32, dweight_out=dw0)
+            assert c[1].data_ptr() == dw0.data_ptr() and torch.equal(c[0], a[0])
+            ref32 = ops.indice_conv_backward(feat, w16, nbr_out[:n_out], nbr_in, dout, dweight_dtype=torch.float32)[1]
+            assert float((c[1] - ref32).abs().max()) <= 1e-4 * float(ref32.abs().max()) + 1e-6
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
