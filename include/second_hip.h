@@ -586,6 +586,7 @@ int sec_second_loss_f32(const float *cls_preds, const float *box_preds, const fl
  * _bwd: d_heads (the layout and dtype of `heads`, padding channels zero) = grad_loss[0] * d loss / d heads, rounded once after the
  * multiplication (grad_loss: device float, the gradient arriving at the loss -- the loss scale of fp16 training; NULL = 1), and
  * d_bias [head_channels] fp32 = its sum over pixels (fixed order).  Same arithmetic as sec_second_loss_f32, expression by expression.
+ * counts_ready != 0: `workspace` is the one the matching _fwd call used, untouched since -- the frames' positive counts in it are reused.
  * sec_heads_loss_supported: 1 for the instantiated shapes (head_channels 64, A = 2, one class, 0 or 2 direction bins, bf16 / fp16) --
  * anything else returns SEC_E_UNSUPPORTED and the caller keeps the three-tensor path. */
 int sec_heads_loss_supported(int head_channels, int anchors_per_loc, int num_class, int num_dir_bins, int dtype);
@@ -596,7 +597,7 @@ int sec_heads_loss_fwd(const void *heads, int dtype, int batch, int h, int w, in
 int sec_heads_loss_bwd(const void *heads, int dtype, int batch, int h, int w, int head_channels, int anchors_per_loc, int num_class,
                        int num_dir_bins, const int *labels, const float *reg_targets, const float *anchors, const float *importance,
                        const float *h_params17, const float *grad_loss, void *d_heads, float *d_bias, void *workspace,
-                       size_t workspace_bytes, void *stream);
+                       size_t workspace_bytes, int counts_ready, void *stream);
 
 /* torch.nn.utils.clip_grad_norm_(parameters, max_grad_norm) + the AdamW step (second/pytorch/train.py:323-325; adam + fixed weight
  * decay, car.fhd.config:180-188) on ONE flat fp32 buffer of master weights whose flat gradient is the all-reduce bucket: two launches

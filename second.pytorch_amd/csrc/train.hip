@@ -527,19 +527,31 @@ __global__ __launch_bounds__(kBlock) void k_heads_loss(const HT *__restrict__ he
     }
 }
 
-// d_bias[c] = sum of the workgroups' column sums (ascending: run-to-run identical); channels behind the heads get 0
+// d_bias[c] = sum of the workgroups' column sums (a fixed order: run-to-run identical); channels behind the heads get 0.
+// 32 columns x 8 slices of the partial list per workgroup, eight loads in flight per thread (one thread per channel walking 552
+// partials one dependent load at a time took 34 us).
 __global__ __launch_bounds__(kBlock) void k_heads_bias_final(const float *__restrict__ partial, int nparts, int cols, int HC, float *__restrict__ d_bias) {
-    __shared__ float red[kBlock / 64][64];
-    const int c = threadIdx.x & 63, part = threadIdx.x >> 6;          // 4 slices of the partial list per channel
-    float acc = 0.0f;
-    if (c < cols)
-        for (int i = part; i < nparts; i += kBlock / 64) acc += partial[(size_t)i * cols + c];
-    red[part][c] = acc;
+    __shared__ float red[8][32];
+    const int c = threadIdx.x & 31, part = threadIdx.x >> 5;          // cols <= 32 (the instantiated head shapes hold 20 or 24)
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    if (c < cols) {
+        int i = part;
+        for (; i + 56 < nparts; i += 64) {
+            const float *p = partial + (size_t)i * cols + c;
+            const float v0 = p[0], v1 = p[(size_t)8 * cols], v2 = p[(size_t)16 * cols], v3 = p[(size_t)24 * cols];
+            const float v4 = p[(size_t)32 * cols], v5 = p[(size_t)40 * cols], v6 = p[(size_t)48 * cols], v7 = p[(size_t)56 * cols];
+            a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+            a0 += v4; a1 += v5; a2 += v6; a3 += v7;
+        }
+        for (; i < nparts; i += 8) a0 += partial[(size_t)i * cols + c];
+    }
+    red[part][c] = (a0 + a1) + (a2 + a3);
     __syncthreads();
     if (threadIdx.x < HC && threadIdx.x < 64) {
         float t = 0.0f;
-        for (int w = 0; w < kBlock / 64; ++w) t += red[w][threadIdx.x];
-        d_bias[threadIdx.x] = threadIdx.x < cols ? t : 0.0f;
+        if (threadIdx.x < cols && threadIdx.x < 32)
+            for (int w = 0; w < 8; ++w) t += red[w][threadIdx.x];
+        d_bias[threadIdx.x] = t;
     }
 }
 
@@ -768,7 +780,7 @@ static void launch_heads_loss(int bins, dim3 grid, hipStream_t st, const void *h
 static int heads_loss_impl(bool grad, const void *heads, int dtype, int batch, int h, int w, int head_channels, int a, int nc, int bins,
                            const int *labels, const float *reg_targets, const float *anchors, const float *importance,
                            const float *h_params17, const float *grad_loss, void *d_heads, float *d_bias, float *out6, void *workspace,
-                           size_t workspace_bytes, void *stream) {
+                           size_t workspace_bytes, bool counts_ready, void *stream) {
     if (!heads || batch <= 0 || h <= 0 || w <= 0 || !labels || !reg_targets || !anchors || !importance || !h_params17 ||
         (grad ? (!d_heads || !d_bias) : !out6))
         return SEC_E_INVALID;
@@ -782,7 +794,7 @@ static int heads_loss_impl(bool grad, const void *heads, int dtype, int batch, i
     const int nb = div_up(HW, kBlock);
     float *partial = ar.take<float>((size_t)batch * nb * 64);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_loss_count, dim3(kCountChunks, batch), dim3(kBlock), 0, st, labels, n_anchor, cnt, importance);
+    if (!counts_ready) hipLaunchKernelGGL(k_loss_count, dim3(kCountChunks, batch), dim3(kBlock), 0, st, labels, n_anchor, cnt, importance);
     const dim3 grid(nb, batch);
     if (!grad) {
         if (dtype == SEC_BF16) launch_heads_loss<__hip_bfloat16, false>(bins, grid, st, heads, HW, head_channels, labels, reg_targets, anchors, importance, cnt, P, nullptr, nullptr, partial);
@@ -800,14 +812,14 @@ SEC_API int sec_heads_loss_fwd(const void *heads, int dtype, int batch, int h, i
                                int num_dir_bins, const int *labels, const float *reg_targets, const float *anchors, const float *importance,
                                const float *h_params17, float *out6, void *workspace, size_t workspace_bytes, void *stream) {
     return heads_loss_impl(false, heads, dtype, batch, h, w, head_channels, anchors_per_loc, num_class, num_dir_bins, labels, reg_targets, anchors,
-                           importance, h_params17, nullptr, nullptr, nullptr, out6, workspace, workspace_bytes, stream);
+                           importance, h_params17, nullptr, nullptr, nullptr, out6, workspace, workspace_bytes, false, stream);
 }
 SEC_API int sec_heads_loss_bwd(const void *heads, int dtype, int batch, int h, int w, int head_channels, int anchors_per_loc, int num_class,
                                int num_dir_bins, const int *labels, const float *reg_targets, const float *anchors, const float *importance,
                                const float *h_params17, const float *grad_loss, void *d_heads, float *d_bias, void *workspace,
-                               size_t workspace_bytes, void *stream) {
+                               size_t workspace_bytes, int counts_ready, void *stream) {
     return heads_loss_impl(true, heads, dtype, batch, h, w, head_channels, anchors_per_loc, num_class, num_dir_bins, labels, reg_targets, anchors,
-                           importance, h_params17, grad_loss, d_heads, d_bias, nullptr, workspace, workspace_bytes, stream);
+                           importance, h_params17, grad_loss, d_heads, d_bias, nullptr, workspace, workspace_bytes, counts_ready != 0, stream);
 }
 
 SEC_API size_t sec_flat_adamw_workspace_bytes(void) { return align_up((size_t)kAdamBlocks * sizeof(float) + 256); }

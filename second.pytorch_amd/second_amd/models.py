@@ -466,9 +466,13 @@ def rpn_forward_mixed(rpn, x, dtype, loss_args=None):
                     and c.in_channels == 128 for c, _, _ in heads)):
         # the three heads as one 128 -> 64 1x1 convolution (output channels stacked, zero padded) on the hand-written kernels
         tot = sum(c.out_channels for c, _, _ in heads)
-        wz = ups[0].new_zeros((64 - tot, 128, 1, 1), dtype=heads[0][0].weight.dtype)
-        wcat = torch.cat([c.weight for c, _, _ in heads] + [wz], 0)
-        bcat = torch.cat([c.bias for c, _, _ in heads] + [wz.new_zeros(64 - tot)], 0)
+        wd = heads[0][0].weight
+        pads = getattr(rpn, "_sec_head_pads", None)          # the zero rows of the stacked weight / bias: made once, not filled every step
+        if pads is None or pads[0].shape[0] != 64 - tot or pads[0].device != wd.device or pads[0].dtype != wd.dtype:
+            pads = (torch.zeros((64 - tot, 128, 1, 1), dtype=wd.dtype, device=wd.device), torch.zeros((64 - tot,), dtype=wd.dtype, device=wd.device))
+            rpn._sec_head_pads = pads
+        wcat = torch.cat([c.weight for c, _, _ in heads] + [pads[0]], 0)
+        bcat = torch.cat([c.bias for c, _, _ in heads] + [pads[1]], 0)
         bins = rpn._num_direction_bins if rpn._use_direction_classifier else 0
         if (loss_args is not None and rpn._box_code_size == 7
                 and ops.heads_loss_supported(64, a, rpn._num_class, bins, dtype)):

@@ -1460,24 +1460,23 @@ class HeadsLossFunction(torch.autograd.Function):
         rt.check(l.sec_heads_loss_fwd(rt.ptr(y), rt.dtype_code(y.dtype), b, h, w, hc, a, nc, bins, rt.ptr(labels), rt.ptr(reg_targets),
                                       rt.ptr(anchors), rt.ptr(importance), params, rt.ptr(out6), rt.ptr(ws), ws.numel(), rt.stream()),
                  "sec_heads_loss_fwd")
-        ctx.save_for_backward(x, pk_d, y, labels, reg_targets, anchors, importance)
+        ctx.save_for_backward(x, pk_d, y, labels, reg_targets, anchors, importance, ws)     # ws: the frames' positive counts stay in it
         ctx.meta = (a, nc, bins, params, tuple(weight.shape), weight.dtype, bias.dtype)
         ctx.mark_non_differentiable(out6)
         return out6[0], out6
 
     @staticmethod
     def backward(ctx, g_loss, _g_all):
-        x, pk_d, y, labels, reg_targets, anchors, importance = ctx.saved_tensors
+        x, pk_d, y, labels, reg_targets, anchors, importance, ws = ctx.saved_tensors
         a, nc, bins, params, wshape, wdtype, bdtype = ctx.meta
         b, hc, h, w = y.shape
         g = g_loss.detach().reshape(1).float().contiguous()
         dy = torch.empty_like(y)                                  # channels_last like y
         db = torch.empty((hc,), dtype=torch.float32, device=y.device)
         l = rt.lib()
-        ws = rt.workspace(l.sec_heads_loss_workspace_bytes(b, h, w, a), y.device)
         rt.check(l.sec_heads_loss_bwd(rt.ptr(y), rt.dtype_code(y.dtype), b, h, w, hc, a, nc, bins, rt.ptr(labels), rt.ptr(reg_targets),
                                       rt.ptr(anchors), rt.ptr(importance), params, rt.ptr(g), rt.ptr(dy), rt.ptr(db), rt.ptr(ws),
-                                      ws.numel(), rt.stream()), "sec_heads_loss_bwd")
+                                      ws.numel(), 1, rt.stream()), "sec_heads_loss_bwd")
         dx = dw = None
         if ctx.needs_input_grad[0]:
             dx = conv2d_nhwc(dy, pk_d, None, wshape[1], 1, 1, 0, relu=False)

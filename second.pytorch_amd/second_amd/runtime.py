@@ -180,7 +180,7 @@ def lib():
         l.sec_heads_loss_supported.argtypes = [ci] * 5
         l.sec_heads_loss_workspace_bytes.argtypes = [ci] * 4
         l.sec_heads_loss_fwd.argtypes = [vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, sz, vp]
-        l.sec_heads_loss_bwd.argtypes = [vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
+        l.sec_heads_loss_bwd.argtypes = [vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, ci, vp]
         ll = ctypes.c_longlong
         l.sec_conv2d_pack_weight_train.argtypes = [vp, ci, ci, ci, ci, vp, vp, vp]
         l.sec_conv2d_wgrad_workspace_bytes.argtypes = [ci] * 6

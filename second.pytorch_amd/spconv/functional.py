@@ -19,7 +19,7 @@ class IndiceConvFunction(torch.autograd.Function):
                     and getattr(rulebook, "subm", None) is not None):
                 # ... together with BOTH MFMA images of the step, one launch (the backward would pack the transposed one again)
                 # ... and the zeroed accumulator of the backward's weight gradient (otherwise a memset node per layer and step)
-                want_dw = weight.requires_grad and torch.is_grad_enabled()
+                want_dw = bool(ctx.needs_input_grad[1])          # (grad mode is off inside forward(): ask the context)
                 res = _ops.pack_weight_train(weight.detach().contiguous(), features.dtype, subm=rulebook.nbr_in is None, zero_grad=want_dw)
                 weight, packed, ctx.packed_dgrad = res[:3]
                 ctx.dw0 = res[3] if want_dw else None
