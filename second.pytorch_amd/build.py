@@ -11,7 +11,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = [os.path.join(HERE, "csrc", f) for f in
-       ("common.hip", "voxelize.hip", "rulebook.hip", "indice_conv.hip", "scatter.hip", "nms.hip", "dense.hip", "pillars.hip", "predict.hip", "train.hip", "dense_train.hip", "voxel_sort.hip")]
+       ("common.hip", "voxelize.hip", "rulebook.hip", "indice_conv.hip", "scatter.hip", "nms.hip", "dense.hip", "pillars.hip", "predict.hip", "train.hip", "dense_train.hip")]
 HDR = [os.path.join(HERE, "csrc", "common.hpp"), os.path.join(HERE, "..", "include", "second_hip.h")]
 OUT = os.path.join(HERE, "lib", "libsecond_hip.so")
 # No packed fp32 VALU: `-Xclang -target-feature -Xclang -packed-fp32-ops` makes the backend split every <2 x float> operation, so no

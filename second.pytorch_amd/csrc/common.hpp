@@ -33,10 +33,6 @@ inline int hip_ok(hipError_t e) {
 }
 
 inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
-// voxel_sort.hip: stable radix sort of (voxel row, point index) pairs (rocPRIM), used by the voxeliser when max_points is large
-size_t vox_sort_temp_bytes(int n, int bits);
-int vox_sort_pairs(void *tmp, size_t tmp_bytes, const unsigned *kin, unsigned *kout, const int *vin, int *vout, int n, int bits,
-                   hipStream_t st);
 inline int div_up(long long a, long long b) { return (int)((a + b - 1) / b); }
 inline uint32_t next_pow2(uint32_t v) {
     uint32_t p = 1;

@@ -401,41 +401,161 @@ __global__ __launch_bounds__(kBlock) void k_vox_scan_assign_cascade(const float 
 // distance from the start of its voxel's run: the first max_points of every run are exactly the reference loop's slots.
 constexpr int kCascadeMaxPoints = 8;       // up to here the cascade wins (car.fhd: 5 points per voxel, 7 us)
 
-__global__ __launch_bounds__(kBlock) void k_vox_sort_keys(const int *__restrict__ offs, const int *__restrict__ pslot,
-                                                         const int *__restrict__ svid, const int *__restrict__ break_idx, VoxParams p,
-                                                         unsigned invalid_key, unsigned *__restrict__ key, int *__restrict__ val) {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= p.num_points) return;
-    unsigned k = invalid_key;
-    const int s = pslot[i];
-    if (s >= 0) {
-        const int vid = svid[s];
-        bool ok = vid >= 0;
-        if (ok && p.cap_mode == 0) ok = i < break_idx[frame_of(offs, p.batch, i)];
-        if (ok) k = (unsigned)vid;
+// (1) k_vox_group_rank: every kept point takes a place in its voxel's run: counted per workgroup in an LDS table, ONE returning
+//     atomicAdd(count[row], points of the row in this workgroup) per (workgroup, voxel) hands the group a block of places.  The order
+//     inside a run is whatever the atomics make it.  count[row] ends as the voxel's uncapped point count.
+// (2) k_vox_count_scan: run_start = exclusive scan of the counts (single pass, decoupled look-back).
+// (3) k_vox_run_scatter: run[run_start[row] + place] = point index.
+// (4) k_vox_run_select: one wave per voxel puts the run's max_points SMALLEST indices into slot order.  Up to 64 * R points: ranked
+//     by counting (n readlane rounds) and permuted through LDS; longer runs: the first 64 * R sorted the same way, every later element
+//     below the current largest kept one is inserted (ballot -> position, shift by one lane) -- few qualify once the kept set has
+//     settled.  (Measured alternatives, profiles/r05_n_pillar_voxeliser.txt: a dense cell grid with a returning atomic per point or per
+//     (workgroup, cell) instead of the hash -- 215 / 303 us for that launch against 96 + 83; sixteen lanes per short run plus a list
+//     of long ones -- the list's one counter cost 99 us; a thread per point ranking by counting -- 77 + 31 us.)
+constexpr int kRankBlock = 1024, kRankTable = 2048;
+__global__ __launch_bounds__(kRankBlock) void k_vox_group_rank(const int *__restrict__ offs, const int *__restrict__ pslot,
+                                                              const int *__restrict__ svid, const int *__restrict__ break_idx, VoxParams p,
+                                                              int *__restrict__ count, int *__restrict__ pvid, int *__restrict__ prank,
+                                                              int *__restrict__ ctl, long long ctl_words) {
+    // The points of ONE voxel inside a workgroup are counted in LDS first (a small hash table keyed by the voxel row), so a voxel costs
+    // one returning global atomic per WORKGROUP that touches it: the near pillars of a nuScenes sweep hold thousands of points, and a
+    // returning atomic per point (or per wave) on their counters serialised the launch -- 116 us for 293 k points, 8 us this way.
+    __shared__ int t_key[kRankTable], t_cnt[kRankTable], t_base[kRankTable];
+    const int tid = threadIdx.x, i = blockIdx.x * kRankBlock + tid;
+    for (int j = tid; j < kRankTable; j += kRankBlock) { t_key[j] = -1; t_cnt[j] = 0; }
+    for (long long j = i; j < ctl_words; j += (long long)gridDim.x * kRankBlock) ctl[j] = 0;      // ticket + status words of the scan behind this launch
+    int vid = -1;
+    if (i < p.num_points) {
+        const int s = pslot[i];
+        if (s >= 0) {
+            const int v = svid[s];
+            bool ok = v >= 0;
+            if (ok && p.cap_mode == 0) ok = i < break_idx[frame_of(offs, p.batch, i)];
+            if (ok) vid = v;
+        }
     }
-    key[i] = k;
-    val[i] = i;
+    __syncthreads();
+    int slot = 0, local = 0;
+    if (vid >= 0) {
+        unsigned h = ((unsigned)vid * 2654435761u) >> 21;     // 11 bits
+        while (true) {
+            const int prev = atomicCAS(&t_key[h], -1, vid);
+            if (prev == -1 || prev == vid) break;
+            h = (h + 1) & (kRankTable - 1);                   // at most 1024 distinct rows in 2048 places: the probe ends
+        }
+        slot = (int)h;
+        local = atomicAdd(&t_cnt[h], 1);
+    }
+    __syncthreads();
+    for (int j = tid; j < kRankTable; j += kRankBlock)
+        if (t_key[j] >= 0) t_base[j] = atomicAdd(&count[t_key[j]], t_cnt[j]);
+    __syncthreads();
+    if (i < p.num_points) { pvid[i] = vid; prank[i] = vid >= 0 ? t_base[slot] + local : 0; }
 }
 
-__global__ __launch_bounds__(kBlock) void k_vox_run_starts(const unsigned *__restrict__ skey, int n, unsigned invalid_key,
-                                                          int *__restrict__ run_start) {
-    const int j = blockIdx.x * kBlock + threadIdx.x;
-    if (j >= n) return;
-    const unsigned k = skey[j];
-    if (k != invalid_key && (j == 0 || skey[j - 1] != k)) run_start[k] = j;
+constexpr int kCountItems = 4;
+__global__ __launch_bounds__(kBlock) void k_vox_count_scan(const int *__restrict__ count, int rows, int *__restrict__ run_start,
+                                                          unsigned long long *__restrict__ status, int *__restrict__ ticket) {
+    __shared__ int smem[5];
+    __shared__ int s_tile;
+    const int tile = scan_take_tile(ticket, &s_tile);
+    const int i0 = (tile * kBlock + threadIdx.x) * kCountItems;
+    int c[kCountItems], v = 0;
+#pragma unroll
+    for (int j = 0; j < kCountItems; ++j) { c[j] = ld_sel(count, i0 + j, i0 + j < rows, 0); v += c[j]; }
+    int ex = scan_lookback(v, tile, (int)gridDim.x, status, smem, (int *)nullptr);
+#pragma unroll
+    for (int j = 0; j < kCountItems; ++j) {
+        if (i0 + j < rows) run_start[i0 + j] = ex;
+        ex += c[j];
+    }
 }
 
-__global__ __launch_bounds__(kBlock) void k_vox_sorted_slots(const unsigned *__restrict__ skey, const int *__restrict__ sval, int n,
-                                                            unsigned invalid_key, const int *__restrict__ run_start, int max_points,
-                                                            int *__restrict__ slot_idx, int *__restrict__ count) {
-    const int j = blockIdx.x * kBlock + threadIdx.x;
-    if (j >= n) return;
-    const unsigned k = skey[j];
-    if (k == invalid_key) return;
-    const int t = j - run_start[k];
-    if (t < max_points) slot_idx[(size_t)k * max_points + t] = sval[j];
-    if (j == n - 1 || skey[j + 1] != k) count[k] = t + 1;       // the run's last point knows the voxel's point count: no atomics
+__global__ __launch_bounds__(kBlock) void k_vox_run_scatter(const int *__restrict__ pvid, const int *__restrict__ prank, int n,
+                                                           const int *__restrict__ run_start, int *__restrict__ run) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int v = pvid[i];
+    if (v >= 0) run[run_start[v] + prank[i]] = i;
+}
+
+template <int R>     // max_points <= 64 * R; one WAVE per run: n entries at run[s0 ..], of which `nvalid` are point indices (the others holes)
+__device__ __forceinline__ void vox_select_wave(int v, int n, int s0, int nvalid, int (*s_sorted)[64 * R], const int *__restrict__ run,
+                                                int max_points, int *__restrict__ slot_idx) {
+    constexpr int CAP = 64 * R, BIG = 0x7fffffff;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int m = n < CAP ? n : CAP;                          // the first chunk: ranked by counting
+    int x[R], rk[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { x[r] = ld_sel(run, s0 + r * 64 + lane, r * 64 + lane < m, BIG); rk[r] = 0; }
+#pragma unroll
+    for (int rr = 0; rr < R; ++rr) {                           // every element of the chunk, broadcast: smaller ones (or equal and earlier) count
+        const int lim = m - rr * 64 < 64 ? m - rr * 64 : 64;   // elements of register rr
+        for (int k = 0; k < lim; ++k) {
+            const int o = __shfl(x[rr], k, 64);
+            const int pos = rr * 64 + k;
+#pragma unroll
+            for (int r = 0; r < R; ++r) rk[r] += (o < x[r] || (o == x[r] && pos < r * 64 + lane)) ? 1 : 0;
+        }
+    }
+    // padding lanes (BIG) rank behind every element and among themselves by position: a permutation of 0 .. CAP - 1
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        int rank = rk[r];
+        if (r * 64 + lane >= m) rank = r * 64 + lane;          // m real elements took ranks 0 .. m - 1; padding keeps its own place
+        s_sorted[wv][rank] = x[r];
+    }
+    __builtin_amdgcn_wave_barrier();
+    int S[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) S[r] = s_sorted[wv][r * 64 + lane];
+    if (n > CAP) {
+        int T = __shfl(S[R - 1], 63, 64);                      // the largest kept index
+        for (int base = CAP; base < n; base += 64) {
+            const int y = ld_sel(run, s0 + base + lane, base + lane < n, BIG);
+            unsigned long long pend = __ballot(y < T);
+            while (pend) {
+                const int l = __ffsll((long long)pend) - 1;
+                const int val = __shfl(y, l, 64);
+                pend &= pend - 1;
+                if (val >= T) continue;                        // T fell since the ballot
+                int pos = 0;
+#pragma unroll
+                for (int r = 0; r < R; ++r) pos += (int)__popcll(__ballot(S[r] < val));
+                int carry = val;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int pr = pos - r * 64;               // insertion lane in this register: < 0 everything shifts, >= 64 nothing does
+                    if (pr < 64) {
+                        const int last = __shfl(S[r], 63, 64);
+                        const int up = __shfl_up(S[r], 1, 64);
+                        const int at = pr < 0 ? 0 : pr;
+                        S[r] = lane > at ? up : (lane == at ? carry : S[r]);
+                        carry = last;
+                    }
+                }
+                T = __shfl(S[R - 1], 63, 64);
+            }
+        }
+    }
+    int *row = slot_idx + (size_t)v * max_points;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int t = r * 64 + lane;
+        if (t < max_points && t < nvalid) row[t] = S[r];
+    }
+}
+
+
+template <int R>
+__global__ __launch_bounds__(kBlock) void k_vox_run_select(const int *__restrict__ voxel_offsets, int batch, const int *__restrict__ count,
+                                                          const int *__restrict__ run_start, const int *__restrict__ run, int max_points,
+                                                          int *__restrict__ slot_idx) {
+    __shared__ int s_sorted[kBlock / 64][64 * R];
+    const int v = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+    if (v >= voxel_offsets[batch]) return;                    // (whole waves leave: no barrier below)
+    const int n = count[v];
+    vox_select_wave<R>(v, n, run_start[v], n, s_sorted, run, max_points, slot_idx);
 }
 
 __global__ __launch_bounds__(kBlock) void k_vox_fill(const float *__restrict__ points,
@@ -526,10 +646,8 @@ struct VoxWorkspace {
     unsigned long long *keys;
     int *vals, *svid, *pslot, *rank, *ctl, *base, *break_idx, *total, *count, *slot_idx;
     // sort path (max_points > kCascadeMaxPoints): appended BEHIND everything else, so the offsets vox_table_of relies on never move
-    unsigned *skey_in, *skey_out;
-    int *sval_in, *sval_out, *run_start;
-    void *sort_tmp;
-    size_t sort_tmp_bytes;
+    int *sval_in, *sval_out, *run_start, *run, *ctl2;
+    long long ctl2_words;
     int sort_bits;
     uint32_t table;
     unsigned long long *frame_words;
@@ -551,23 +669,20 @@ static VoxWorkspace carve_vox(void *ws, size_t cap, int n, int batch, int max_vo
     w.total = a.take<int>(1);
     w.count = a.take<int>((size_t)batch * max_voxels);
     w.slot_idx = a.take<int>((size_t)batch * max_voxels * max_points);
-    w.skey_in = w.skey_out = nullptr;
-    w.sval_in = w.sval_out = w.run_start = nullptr;
-    w.sort_tmp = nullptr;
-    w.sort_tmp_bytes = 0;
+    w.sval_in = w.sval_out = w.run_start = w.run = w.ctl2 = nullptr;
+    w.ctl2_words = 0;
     w.sort_bits = 0;
     if (max_points > kCascadeMaxPoints && n > 0) {
-        const unsigned cap = (unsigned)batch * (unsigned)max_voxels;            // keys 0 .. cap (cap = invalid)
-        int bits = 1;
-        while (bits < 32 && (1u << bits) <= cap) ++bits;
-        w.sort_bits = bits;
-        w.skey_in = a.take<unsigned>(n);
-        w.skey_out = a.take<unsigned>(n);
-        w.sval_in = a.take<int>(n);
-        w.sval_out = a.take<int>(n);
-        w.run_start = a.take<int>((size_t)cap + 1);
-        w.sort_tmp_bytes = vox_sort_temp_bytes(n, bits);
-        w.sort_tmp = a.take<char>(w.sort_tmp_bytes);
+        // many points per voxel: group rank -> count scan -> run scatter -> per-voxel select (k_vox_group_rank ...)
+        long long rows = (long long)batch * max_voxels;
+        if (rows > n) rows = n;
+        w.sort_bits = 1;                                      // "the run path is carved"
+        w.sval_in = a.take<int>(n);                           // pvid
+        w.sval_out = a.take<int>(n);                          // prank
+        w.run = a.take<int>(n);
+        w.run_start = a.take<int>((size_t)rows + 1);
+        w.ctl2_words = (long long)scan_ctl_words((rows + kCountItems - 1) / kCountItems);
+        w.ctl2 = a.take<int>((size_t)w.ctl2_words);
     }
     w.frame_words = a.take<unsigned long long>((size_t)batch + 1);     // fused scan (appended: earlier offsets never move)
     w.bytes = align_up(a.used);
@@ -675,16 +790,22 @@ SEC_API int sec_voxelize_f32(const float *points, const int *point_offsets, int 
         hipLaunchKernelGGL(k_vox_assign, dim3(nb), dim3(kBlock), 0, st, point_offsets, w.pslot, w.vals, w.keys,
                            w.rank, w.base, voxel_offsets, p, w.svid, w.break_idx, coors,
                            fused_frames ? w.total : (const int *)nullptr);
-        if (w.sort_tmp) {
-            const unsigned invalid_key = (unsigned)batch * (unsigned)max_voxels;
-            hipLaunchKernelGGL(k_vox_sort_keys, dim3(nb), dim3(kBlock), 0, st, point_offsets, w.pslot, w.svid, w.break_idx, p,
-                               invalid_key, w.skey_in, w.sval_in);
-            if ((rc = vox_sort_pairs(w.sort_tmp, w.sort_tmp_bytes, w.skey_in, w.skey_out, w.sval_in, w.sval_out, num_points,
-                                     w.sort_bits, st)))
-                return rc;
-            hipLaunchKernelGGL(k_vox_run_starts, dim3(nb), dim3(kBlock), 0, st, w.skey_out, num_points, invalid_key, w.run_start);
-            hipLaunchKernelGGL(k_vox_sorted_slots, dim3(nb), dim3(kBlock), 0, st, w.skey_out, w.sval_out, num_points, invalid_key,
-                               w.run_start, max_points, w.slot_idx, w.count);
+        if (w.sort_bits) {
+            if (max_points > 256) return SEC_E_UNSUPPORTED;    // k_vox_run_select keeps 64 * R candidates in registers (reference configs: <= 100)
+            long long rows = (long long)batch * max_voxels;
+            if (rows > num_points) rows = num_points;
+            hipLaunchKernelGGL(k_vox_group_rank, dim3(div_up(num_points, kRankBlock)), dim3(kRankBlock), 0, st, point_offsets, w.pslot, w.svid, w.break_idx, p, w.count,
+                               w.sval_in, w.sval_out, w.ctl2, w.ctl2_words);
+            hipLaunchKernelGGL(k_vox_count_scan, dim3(div_up(rows, kBlock * kCountItems)), dim3(kBlock), 0, st, w.count, (int)rows, w.run_start,
+                               reinterpret_cast<unsigned long long *>(w.ctl2 + 4), w.ctl2);
+            hipLaunchKernelGGL(k_vox_run_scatter, dim3(nb), dim3(kBlock), 0, st, w.sval_in, w.sval_out, num_points, w.run_start, w.run);
+            const dim3 gs(div_up(rows, kBlock / 64));
+            if (max_points <= 64)
+                hipLaunchKernelGGL(k_vox_run_select<1>, gs, dim3(kBlock), 0, st, voxel_offsets, batch, w.count, w.run_start, w.run, max_points, w.slot_idx);
+            else if (max_points <= 128)
+                hipLaunchKernelGGL(k_vox_run_select<2>, gs, dim3(kBlock), 0, st, voxel_offsets, batch, w.count, w.run_start, w.run, max_points, w.slot_idx);
+            else
+                hipLaunchKernelGGL(k_vox_run_select<4>, gs, dim3(kBlock), 0, st, voxel_offsets, batch, w.count, w.run_start, w.run, max_points, w.slot_idx);
         } else {
             hipLaunchKernelGGL(k_vox_cascade, dim3(nb), dim3(kBlock), 0, st, point_offsets, w.pslot, w.svid,
                                w.break_idx, p, w.count, w.slot_idx);

@@ -80,16 +80,18 @@ def test_voxelize_batched_ragged_and_edge_cases(ops, golden, syn):
 
 
 def test_voxelize_pillars_sorted_slot_path(ops, syn):
-    """max_points > 8 takes the stable-sort slot assignment (csrc/voxelize.hip: k_vox_sort_keys -> radix sort -> run starts ->
-    slots) instead of the atomicMin cascade: nuScenes-size pillar clouds (0.25 m pillars, 60 points each, hundreds of points in the
-    pillars near the sensor), a ragged batch with an empty cloud, the voxel cap hit and not hit, both cap modes -- voxel order,
-    slot order, counts and contents bit-exact against the sequential oracle loop (pointpillars: all.pp.largea.config:6-15)."""
+    """max_points > 8 takes the run path (csrc/voxelize.hip: k_vox_group_rank -> k_vox_count_scan -> k_vox_run_scatter ->
+    k_vox_run_select: every voxel's points gathered into a run, its max_points smallest indices put in order by one wave) instead of
+    the atomicMin cascade: nuScenes-size pillar clouds (0.25 m pillars, 60 points each, hundreds of points in the pillars near the
+    sensor), a ragged batch with an empty cloud, the voxel cap hit and not hit, both cap modes, and the 100 / 200-point forms of the
+    select kernel (KITTI pointpillars configs keep 100 points per pillar) -- voxel order, slot order, counts and contents bit-exact
+    against the sequential oracle loop (pointpillars: all.pp.largea.config:6-15)."""
     rng_ = [-50, -50, -10, 50, 50, 10]
     vs = [0.25, 0.25, 20]
     clouds = [syn.syn_nusc_cloud(0, 120000, tuple(rng_), scene="urban"), np.zeros((0, 4), np.float32),
               syn.syn_nusc_cloud(1, 40000, tuple(rng_), scene="urban")]
     for cap_mode in ("break", "continue"):
-        for max_points, max_voxels in ((60, 30000), (60, 4000), (9, 30000)):
+        for max_points, max_voxels in ((100, 30000), (200, 8000), (60, 30000), (60, 4000), (9, 30000)):
             res = _check_voxelize(ops, clouds, vs, rng_, max_points, max_voxels, cap_mode)
     assert int(res["num_points_per_voxel"].max()) == 9 and res["voxel_num"] > 15000
 
