@@ -686,8 +686,8 @@ def other_configs(budget_s=270.0):
             ("nusc.fhd.train", "nusc.fhd.train", [], "config 5 (per-GPU step, fp16 features + dynamic loss scaling on the device, whole step one hipGraph)"),
             ("nusc.pp.train", "nusc.pp.train", [], "config 4's network trained on the device step (PFN batch statistics + argmax backward on "
                                                    "sec_pfn_train_fwd / _bwd)"),
-            ("car.fhd.fp32", "car.fhd", ["--dtype", "fp32"], "config 2's network in fp32, the reference's default precision: sparse convs on "
-                                                              "v_mfma_f32_32x32x2_f32, torch / MIOpen RPN")]
+            ("car.fhd.fp32", "car.fhd", ["--dtype", "fp32"], "config 2's network in fp32, the reference's default precision: sparse convs, RPN and heads on the "
+                                                              "bf16 MFMA pipe with split operands (x = hi + lo, three products, fp32 accumulation)")]
     out, t0 = {}, time.time()
     for key, wl, extra, what in runs:
         if time.time() - t0 > budget_s:
