@@ -65,6 +65,32 @@ def test_lazy_background_entry_points_validate_before_any_launch():
     assert l.sec_rpn_tile_live_masks(one, 1, 8, 16, 2, one, one, one, one, 0, None) == -2                                                   # workspace too small
 
 
+def test_round5_training_entry_points_validate_before_any_launch():
+    """sec_heads_loss_fwd / _bwd, the 64-channel form of sec_conv2d_wgrad_nhwc and the pre-zeroed accumulator arguments: shape
+    support and argument errors are decided on the host, before any launch (no GPU needed)."""
+    import ctypes
+    from second_amd import runtime as rt
+    l = rt.lib()
+    one = ctypes.c_void_p(4096)                       # a non-NULL pointer that is never dereferenced on these paths
+    f17 = rt.f_arr([0.25, 2.0, 3.0, 1, 1, 1, 2, 0.2, 0, 1] + [1.0] * 7)
+    assert l.sec_heads_loss_supported(64, 2, 1, 2, rt.SEC_BF16) == 1 and l.sec_heads_loss_supported(64, 2, 1, 0, rt.SEC_F16) == 1
+    assert l.sec_heads_loss_supported(64, 2, 1, 2, rt.SEC_F32) == 0                       # 16-bit head tensors only
+    assert l.sec_heads_loss_supported(64, 20, 10, 2, rt.SEC_BF16) == 0                    # the nuScenes multi-class head does not fit 64 channels
+    assert l.sec_heads_loss_supported(128, 2, 1, 2, rt.SEC_BF16) == 0
+    assert l.sec_heads_loss_workspace_bytes(4, 200, 176, 2) > 4 * 138 * 64 * 4 and l.sec_heads_loss_workspace_bytes(0, 200, 176, 2) == 0
+    args = (rt.SEC_BF16, 1, 8, 16, 64, 2, 1, 2, one, one, one, one, f17)
+    assert l.sec_heads_loss_fwd(None, *args, one, one, 1 << 20, None) == -1
+    assert l.sec_heads_loss_fwd(one, *args, None, one, 1 << 20, None) == -1               # no out6
+    assert l.sec_heads_loss_fwd(one, *args, one, one, 16, None) == -2                                   # workspace too small
+    assert l.sec_heads_loss_fwd(one, rt.SEC_BF16, 1, 8, 16, 64, 4, 2, 2, one, one, one, one, f17, one, one, 1 << 20, None) == -3      # head shape not instantiated
+    assert l.sec_heads_loss_bwd(one, *args, None, None, one, one, 1 << 20, 0, None) == -1  # no d_heads
+    assert l.sec_heads_loss_bwd(one, *args, None, one, None, one, 1 << 20, 0, None) == -1  # no d_bias
+    # one-tap weight gradient with the 64-channel gradient of the stacked heads: supported; a 3x3 with 64 output channels is not
+    assert l.sec_conv2d_wgrad_workspace_bytes(4, 200, 176, 128, 64, 1) > 0 and l.sec_conv2d_wgrad_workspace_bytes(4, 200, 176, 128, 64, 3) == 0
+    assert l.sec_conv2d_wgrad_nhwc(one, one, 4, 200, 176, 128, 64, 3, 1, 1, one, one, 1 << 30, rt.SEC_BF16, None) == -3
+    assert l.sec_conv2d_wgrad_nhwc(one, one, 4, 200, 176, 128, 64, 1, 1, 0, one, one, 16, rt.SEC_BF16, None) == -2     # workspace too small
+
+
 def test_no_cpu_fallback():
     from second_amd import ops
     from second_amd.runtime import SecondHipError
