@@ -451,9 +451,10 @@ int sec_conv1x1_chain_nhwc(const void *x, long long pixels, const void *packed_w
  * backward-weights / backward-data kernels and ~8 torch kernels per BatchNorm + ReLU pair.
  *   forward conv        sec_conv2d_nhwc (bias NULL, relu 0);
  *   data gradient       sec_conv2d_nhwc on dY with the weights flipped and transposed: dX = conv(dY, W[ci][co][2-ky][2-kx]);
- *   weight gradient     sec_conv2d_wgrad_nhwc: dweight [cout][cin][3][3] fp32 (torch's layout) = sum over pixels of
- *                       x[p + tap] (x) dy[p]; 3x3 / stride 1 / pad 1, cin = cout = 128; deterministic (partials in the
- *                       workspace, summed in a fixed order -- no float atomics);
+ *   weight gradient     sec_conv2d_wgrad_nhwc: dweight [cout][cin][k][k] fp32 (torch's layout) = sum over pixels of
+ *                       x[p + tap] (x) dy[p]; 3x3 / stride 1 / pad 1 with cin = cout = 128, or 1x1 with cin = 128 and cout = 128
+ *                       or 64 (dy then holds 64 channels: the stacked heads); at most 2^23 pixels; deterministic (partials in
+ *                       the workspace, summed in a fixed order -- no float atomics);
  *   BatchNorm + ReLU    sec_bn_relu_fwd_nhwc: batch statistics over `pixels` rows of a channels-last [pixels][channels] tensor
  *                       (biased variance for the normalisation, running statistics updated with the unbiased one, as
  *                       torch.nn.BatchNorm2d does), z = act((y - mean) * invstd * gamma + beta); save_mean / save_invstd
