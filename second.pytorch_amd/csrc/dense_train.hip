@@ -374,6 +374,86 @@ __global__ __launch_bounds__(256) void k_bn_apply(const T *__restrict__ y, const
     }
 }
 
+// Small activations (the sparse stack's BatchNorm1d rows: at most kBnSmallRows): the partial sums come from kBnSmallGroups workgroups
+// only (32 were too few to pull the rows at speed: the partial pass doubled), and every workgroup of the apply pass adds them up
+// itself in its prologue (256 / C threads per channel, fixed order, doubles as in k_bn_fwd_finalize) -- the finalize launch between the two passes, ~6 us of pure latency 28 times per car.fhd step, is gone.
+// Workgroup 0 also stores what the finalize stored (save_mean / save_invstd + running statistics; dgamma / dbeta).
+constexpr int kBnSmallGroups = 128;
+constexpr long long kBnSmallRows = 1 << 17;
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void k_bn_apply_small(const T *__restrict__ y, const T *__restrict__ dz, long long P, int C,
+                                                       const float *__restrict__ part, float eps, float momentum,
+                                                       float *__restrict__ mean_io, float *__restrict__ invstd_io,
+                                                       float *__restrict__ running_mean, float *__restrict__ running_var,
+                                                       const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                       float *__restrict__ dbeta_out, float *__restrict__ dgamma_out, int relu,
+                                                       T *__restrict__ out, const int *__restrict__ p_dev) {
+    __shared__ float s_a[256], s_b[256], s_g[256], s_be[256];     // MODE 0: mean, invstd;  MODE 1: + dbeta, dgamma in s_g2 / s_b2
+    __shared__ float s_g2[256], s_b2[256];
+    P = bn_live_rows(P, p_dev);                        // rows past the live count are neither read nor written
+    // 256 / C threads per channel, each adds its share of the groups (ascending), thread c then adds the shares (ascending): fixed order
+    __shared__ double s_ra[256], s_rb[256];
+    {
+        const int c1 = threadIdx.x % C, slice = threadIdx.x / C, nsl = 256 / C;
+        double a = 0.0, b = 0.0;
+#pragma unroll 8
+        for (int g = slice; g < kBnSmallGroups; g += nsl) { a += part[((size_t)g * 2 + 0) * C + c1]; b += part[((size_t)g * 2 + 1) * C + c1]; }
+        s_ra[threadIdx.x] = a; s_rb[threadIdx.x] = b;
+    }
+    __syncthreads();
+    const int c0 = threadIdx.x;
+    if (c0 < C) {
+        double a = 0.0, b = 0.0;
+        for (int sl = 0; sl < 256 / C; ++sl) { a += s_ra[sl * C + c0]; b += s_rb[sl * C + c0]; }
+        if (MODE == 0) {
+            const long long Pn = P < 1 ? 1 : P;
+            const double m = a / (double)Pn;
+            double var = b / (double)Pn - m * m;
+            if (var < 0.0) var = 0.0;
+            const float mf = (float)m, is = (float)(1.0 / sqrt(var + (double)eps));
+            s_a[c0] = mf; s_b[c0] = is;
+            if (blockIdx.x == 0) {
+                mean_io[c0] = mf; invstd_io[c0] = is;
+                if (running_mean) running_mean[c0] = (1.0f - momentum) * running_mean[c0] + momentum * mf;
+                if (running_var) running_var[c0] = (1.0f - momentum) * running_var[c0] + momentum * (float)(Pn > 1 ? var * (double)Pn / (double)(Pn - 1) : var);
+            }
+        } else {
+            s_a[c0] = mean_io[c0]; s_b[c0] = invstd_io[c0];
+            s_b2[c0] = (float)a; s_g2[c0] = (float)b;             // dbeta, dgamma
+            if (blockIdx.x == 0) { dbeta_out[c0] = (float)a; dgamma_out[c0] = (float)b; }
+        }
+        s_g[c0] = gamma[c0]; s_be[c0] = beta[c0];
+    }
+    __syncthreads();
+    const int cg = C / 8;
+    const long long n = P * cg;
+    const float inv_p = 1.0f / (float)(P > 0 ? P : 1);
+    for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < n; q += (long long)gridDim.x * 256) {
+        const int chg = (int)(q % cg);
+        const uint4 v = reinterpret_cast<const uint4 *>(y)[q];
+        const T *e = reinterpret_cast<const T *>(&v);
+        uint4 gq = make_uint4(0, 0, 0, 0);
+        if (MODE == 1) gq = reinterpret_cast<const uint4 *>(dz)[q];
+        const T *ge = reinterpret_cast<const T *>(&gq);
+        uint4 o;
+        T *oe = reinterpret_cast<T *>(&o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = chg * 8 + j;
+            const float xh = (t2f<T>(e[j]) - s_a[c]) * s_b[c];
+            const float zp = xh * s_g[c] + s_be[c];
+            if (MODE == 0) {
+                oe[j] = f2t<T>(relu ? (zp > 0.0f ? zp : 0.0f) : zp);
+            } else {
+                float g = t2f<T>(ge[j]);
+                if (relu && !(zp > 0.0f)) g = 0.0f;
+                oe[j] = f2t<T>(s_g[c] * s_b[c] * (g - s_b2[c] * inv_p - xh * s_g2[c] * inv_p));
+            }
+        }
+        reinterpret_cast<uint4 *>(out)[q] = o;
+    }
+}
+
 // fp32 master weight [cout][cin][k][k] -> BOTH 16-bit MFMA slab images of a training step in one launch: `fwd` in the layout of
 // k_conv2d_pack (packed[((tap * cin/8 + chunk) * cout + n) * 8 + e] = w[n][chunk*8 + e][tap]) and `dgrad` = the same layout of the
 // flipped, transposed kernel W'[ci][co][ky][kx] = W[co][ci][k-1-ky][k-1-kx] (cin and cout swap roles): what the data gradient's
@@ -483,6 +563,17 @@ SEC_API int sec_bn_relu_fwd_nhwc(const void *y, long long pixels, int channels, 
     hipStream_t st = (hipStream_t)stream;
     float *part = (float *)workspace;
     const int blocks = (int)((pixels * (channels / 8) + 255) / 256 < 2048 ? (pixels * (channels / 8) + 255) / 256 : 2048);
+#define SEC_BN_FWD_SMALL(T)                                                                                                        \
+    hipLaunchKernelGGL((k_bn_partial<T, 0>), dim3(kBnSmallGroups), dim3(256), 0, st, (const T *)y, (const T *)nullptr, pixels, channels, \
+                       nullptr, nullptr, nullptr, nullptr, 0, part, pixels_dev);                                                   \
+    hipLaunchKernelGGL((k_bn_apply_small<T, 0>), dim3(blocks < 512 ? blocks : 512), dim3(256), 0, st, (const T *)y, (const T *)nullptr, pixels, channels, \
+                       part, eps, momentum, save_mean, save_invstd, running_mean, running_var, gamma, beta, nullptr, nullptr, relu, \
+                       (T *)z, pixels_dev);
+    if (pixels <= kBnSmallRows) {
+        if (dtype == SEC_BF16) { SEC_BN_FWD_SMALL(__hip_bfloat16) } else { SEC_BN_FWD_SMALL(__half) }
+        return check_launch();
+    }
+#undef SEC_BN_FWD_SMALL
 #define SEC_BN_FWD(T)                                                                                                              \
     hipLaunchKernelGGL((k_bn_partial<T, 0>), dim3(kBnGroups), dim3(256), 0, st, (const T *)y, (const T *)nullptr, pixels, channels, \
                        nullptr, nullptr, nullptr, nullptr, 0, part, pixels_dev);                                                   \
@@ -504,6 +595,17 @@ SEC_API int sec_bn_relu_bwd_nhwc(const void *dz, const void *y, long long pixels
     hipStream_t st = (hipStream_t)stream;
     float *part = (float *)workspace;
     const int blocks = (int)((pixels * (channels / 8) + 255) / 256 < 2048 ? (pixels * (channels / 8) + 255) / 256 : 2048);
+#define SEC_BN_BWD_SMALL(T)                                                                                                        \
+    hipLaunchKernelGGL((k_bn_partial<T, 1>), dim3(kBnSmallGroups), dim3(256), 0, st, (const T *)y, (const T *)dz, pixels, channels, \
+                       save_mean, save_invstd, gamma, beta, relu, part, pixels_dev);                                               \
+    hipLaunchKernelGGL((k_bn_apply_small<T, 1>), dim3(blocks < 512 ? blocks : 512), dim3(256), 0, st, (const T *)y, (const T *)dz, pixels, channels, part, \
+                       0.0f, 0.0f, const_cast<float *>(save_mean), const_cast<float *>(save_invstd), nullptr, nullptr, gamma, beta, \
+                       dbeta, dgamma, relu, (T *)dy, pixels_dev);
+    if (pixels <= kBnSmallRows) {
+        if (dtype == SEC_BF16) { SEC_BN_BWD_SMALL(__hip_bfloat16) } else { SEC_BN_BWD_SMALL(__half) }
+        return check_launch();
+    }
+#undef SEC_BN_BWD_SMALL
 #define SEC_BN_BWD(T)                                                                                                              \
     hipLaunchKernelGGL((k_bn_partial<T, 1>), dim3(kBnGroups), dim3(256), 0, st, (const T *)y, (const T *)dz, pixels, channels,      \
                        save_mean, save_invstd, gamma, beta, relu, part, pixels_dev);                                               \
