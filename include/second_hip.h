@@ -228,6 +228,11 @@ int sec_indice_conv_bwd(const void *features, int n_in, int cin, const void *wei
  * `zero_dweight` (optional, [kvol][cin][cout] fp32): zeroed by the same launch -- the accumulator the layer's backward will use. */
 int sec_pack_conv_weight_train(const float *weight, int kvol, int cin, int cout, int subm, int dtype, void *weight16,
                                void *packed_fwd, void *packed_dgrad, float *zero_dweight, void *stream);
+/* The same for n layers in ONE launch (host arrays of per-layer arguments; entries of packed_fwd / packed_dgrad / zero_dweight may be
+ * NULL as above): a training step packs every sparse layer's weights before its forward pass instead of launching once per layer. */
+int sec_pack_conv_weight_train_multi(int n, const float *const *weights, const int *kvol, const int *cin, const int *cout,
+                                     const int *subm, int dtype, void *const *weight16, void *const *packed_fwd,
+                                     void *const *packed_dgrad, float *const *zero_dweight, void *stream);
 
 /* SparseConvTensor.dense() (spconv/__init__.py; consumed at second/pytorch/models/middle.py:206-210).
  * Scatter rows into a zero-initialised dense tensor with arbitrary element strides so the same kernel
@@ -467,6 +472,9 @@ int sec_conv1x1_chain_nhwc(const void *x, long long pixels, const void *packed_w
  * sec_conv2d_packed_weight_bytes(cout, cin, ksize, dtype) bytes. */
 int sec_conv2d_pack_weight_train(const float *weight, int cout, int cin, int ksize, int dtype, void *packed_fwd,
                                  void *packed_dgrad, void *stream);
+/* n layers in ONE launch (host arrays of per-layer arguments). */
+int sec_conv2d_pack_weight_train_multi(int n, const float *const *weights, const int *cout, const int *cin, const int *ksize,
+                                       int dtype, void *const *packed_fwd, void *const *packed_dgrad, void *stream);
 size_t sec_conv2d_wgrad_workspace_bytes(int batch, int h, int w, int cin, int cout, int ksize);
 int sec_conv2d_wgrad_nhwc(const void *x, const void *dy, int batch, int h, int w, int cin, int cout, int ksize,
                           int stride, int pad, float *dweight, void *workspace, size_t workspace_bytes, int dtype,

@@ -459,10 +459,9 @@ __global__ __launch_bounds__(256) void k_bn_apply_small(const T *__restrict__ y,
 // flipped, transposed kernel W'[ci][co][ky][kx] = W[co][ci][k-1-ky][k-1-kx] (cin and cout swap roles): what the data gradient's
 // forward-kernel launch reads.  Replaces to(dtype) + pack + flip + transpose + contiguous + to(dtype) + pack (7 launches).
 template <typename T>
-__global__ __launch_bounds__(kBlock) void k_conv2d_pack_train(const float *__restrict__ w, int cout, int cin, int ks, T *__restrict__ fwd,
-                                                             T *__restrict__ dgrad) {
+__device__ __forceinline__ void conv2d_pack_train_at(long long g, const float *__restrict__ w, int cout, int cin, int ks, T *__restrict__ fwd,
+                                                     T *__restrict__ dgrad) {
     const long long total = (long long)ks * ks * cin * cout;
-    const long long g = (long long)blockIdx.x * kBlock + threadIdx.x;
     if (g >= total) return;
     if (g < 8) {                                            // the 16-byte zero block behind each image
         fwd[total + g] = f2t<T>(0.0f);
@@ -483,6 +482,30 @@ __global__ __launch_bounds__(kBlock) void k_conv2d_pack_train(const float *__res
         const int ky = ks - 1 - tap / ks, kx = ks - 1 - tap % ks;
         dgrad[g] = f2t<T>(w[(((size_t)(chunk * 8 + e) * cin + n) * ks + ky) * ks + kx]);
     }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_conv2d_pack_train(const float *__restrict__ w, int cout, int cin, int ks, T *__restrict__ fwd,
+                                                             T *__restrict__ dgrad) {
+    conv2d_pack_train_at<T>((long long)blockIdx.x * kBlock + threadIdx.x, w, cout, cin, ks, fwd, dgrad);
+}
+// several layers in ONE launch (descriptors as kernel arguments: capturable as is)
+constexpr int kPack2dMulti = 16;
+struct Pack2dDesc {
+    const float *w;
+    void *fwd, *dgrad;
+    int cout, cin, ks, blk0;
+};
+struct Pack2dArgs {
+    Pack2dDesc d[kPack2dMulti];
+    int n;
+};
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_conv2d_pack_train_multi(Pack2dArgs a) {
+    int i = 0;
+    while (i + 1 < a.n && (int)blockIdx.x >= a.d[i + 1].blk0) ++i;
+    const Pack2dDesc &d = a.d[i];
+    conv2d_pack_train_at<T>((long long)(blockIdx.x - d.blk0) * kBlock + threadIdx.x, d.w, d.cout, d.cin, d.ks, (T *)d.fwd, (T *)d.dgrad);
 }
 
 constexpr int kBnGroups = 512;
@@ -545,6 +568,28 @@ SEC_API int sec_conv2d_pack_weight_train(const float *weight, int cout, int cin,
     else
         hipLaunchKernelGGL((k_conv2d_pack_train<__half>), dim3(div_up(total, kBlock)), dim3(kBlock), 0, st, weight, cout, cin, ksize,
                            (__half *)packed_fwd, (__half *)packed_dgrad);
+    return check_launch();
+}
+
+SEC_API int sec_conv2d_pack_weight_train_multi(int n, const float *const *weights, const int *cout, const int *cin, const int *ksize, int dtype,
+                                               void *const *packed_fwd, void *const *packed_dgrad, void *stream) {
+    if (n <= 0 || !weights || !cout || !cin || !ksize || !packed_fwd || !packed_dgrad || (dtype != SEC_BF16 && dtype != SEC_F16)) return SEC_E_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    for (int i0 = 0; i0 < n; i0 += kPack2dMulti) {
+        Pack2dArgs a;
+        a.n = n - i0 < kPack2dMulti ? n - i0 : kPack2dMulti;
+        long long blocks = 0;
+        for (int j = 0; j < a.n; ++j) {
+            const int i = i0 + j;
+            if (!weights[i] || !packed_fwd[i] || !packed_dgrad[i] || cout[i] <= 0 || cin[i] <= 0 || ksize[i] <= 0) return SEC_E_INVALID;
+            if (cin[i] % 64 || cout[i] % 64) return SEC_E_UNSUPPORTED;
+            Pack2dDesc &d = a.d[j];
+            d.w = weights[i]; d.fwd = packed_fwd[i]; d.dgrad = packed_dgrad[i]; d.cout = cout[i]; d.cin = cin[i]; d.ks = ksize[i]; d.blk0 = (int)blocks;
+            blocks += div_up((long long)ksize[i] * ksize[i] * cin[i] * cout[i], kBlock);
+        }
+        if (dtype == SEC_BF16) hipLaunchKernelGGL((k_conv2d_pack_train_multi<__hip_bfloat16>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
+        else hipLaunchKernelGGL((k_conv2d_pack_train_multi<__half>), dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
+    }
     return check_launch();
 }
 

@@ -2210,10 +2210,9 @@ SEC_API int sec_indice_conv_fwd(const void *features, int n_in, int cin, const v
 // k_pack_weight_c4 for the 4-channel first layer) and the data-gradient image (k_pack_weight_t).  Replaces to(dtype) + pack in the
 // forward and the transposed pack in the backward: three launches per layer and step.
 template <typename T>
-__global__ __launch_bounds__(kBlock) void k_pack_weight_train(const float *__restrict__ w, int kvol, int cin, int cout, int mirror,
-                                                             T *__restrict__ w16, T *__restrict__ packed, long long total_fwd,
-                                                             T *__restrict__ packed_t, long long total_t, float *__restrict__ zero_dw) {
-    const long long g = (long long)blockIdx.x * kBlock + threadIdx.x;
+__device__ __forceinline__ void pack_weight_train_at(long long g, const float *__restrict__ w, int kvol, int cin, int cout, int mirror,
+                                                     T *__restrict__ w16, T *__restrict__ packed, long long total_fwd,
+                                                     T *__restrict__ packed_t, long long total_t, float *__restrict__ zero_dw) {
     const long long total0 = (long long)kvol * cin * cout;
     if (g < total0) w16[g] = Cvt<T>::from(w[g]);
     if (zero_dw && g < total0) zero_dw[g] = 0.0f;              // the accumulator of this step's weight gradient (sec_indice_conv_bwd, dweight_zeroed)
@@ -2243,6 +2242,35 @@ __global__ __launch_bounds__(kBlock) void k_pack_weight_train(const float *__res
         const int km = mirror ? kvol - 1 - k : k;
         packed_t[g] = ci < cin ? Cvt<T>::from(w[((size_t)km * cin + ci) * cout + co]) : Cvt<T>::from(0.0f);
     }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_pack_weight_train(const float *__restrict__ w, int kvol, int cin, int cout, int mirror,
+                                                             T *__restrict__ w16, T *__restrict__ packed, long long total_fwd,
+                                                             T *__restrict__ packed_t, long long total_t, float *__restrict__ zero_dw) {
+    pack_weight_train_at<T>((long long)blockIdx.x * kBlock + threadIdx.x, w, kvol, cin, cout, mirror, w16, packed, total_fwd, packed_t, total_t, zero_dw);
+}
+
+// every layer of a network in ONE launch: the descriptors travel as kernel arguments (no device table to fill -- capturable as is)
+constexpr int kPackMulti = 16;
+struct PackSparseDesc {
+    const float *w;
+    void *w16, *packed, *packed_t;
+    float *zero_dw;
+    long long total_fwd, total_t;
+    int kvol, cin, cout, mirror, blk0;
+};
+struct PackSparseArgs {
+    PackSparseDesc d[kPackMulti];
+    int n;
+};
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_pack_weight_train_multi(PackSparseArgs a) {
+    int i = 0;
+    while (i + 1 < a.n && (int)blockIdx.x >= a.d[i + 1].blk0) ++i;      // wave-uniform: blockIdx only
+    const PackSparseDesc &d = a.d[i];
+    pack_weight_train_at<T>((long long)(blockIdx.x - d.blk0) * kBlock + threadIdx.x, d.w, d.kvol, d.cin, d.cout, d.mirror, (T *)d.w16, (T *)d.packed,
+                            d.total_fwd, (T *)d.packed_t, d.total_t, d.zero_dw);
 }
 
 template <typename T>
@@ -2321,5 +2349,37 @@ SEC_API int sec_pack_conv_weight_train(const float *weight, int kvol, int cin, i
     else
         hipLaunchKernelGGL(k_pack_weight_train<__half>, dim3(div_up(total, kBlock)), dim3(kBlock), 0, st, weight, kvol, cin, cout, subm ? 1 : 0,
                            (__half *)weight16, (__half *)packed_fwd, total_fwd, (__half *)packed_dgrad, total_t, zero_dweight);
+    return check_launch();
+}
+
+SEC_API int sec_pack_conv_weight_train_multi(int n, const float *const *weights, const int *kvol, const int *cin, const int *cout, const int *subm,
+                                             int dtype, void *const *weight16, void *const *packed_fwd, void *const *packed_dgrad,
+                                             float *const *zero_dweight, void *stream) {
+    if (n <= 0 || !weights || !kvol || !cin || !cout || !subm || !weight16 || !packed_fwd || !packed_dgrad || !zero_dweight ||
+        (dtype != SEC_BF16 && dtype != SEC_F16))
+        return SEC_E_INVALID;
+    hipStream_t st = (hipStream_t)stream;
+    for (int i0 = 0; i0 < n; i0 += kPackMulti) {
+        PackSparseArgs a;
+        a.n = n - i0 < kPackMulti ? n - i0 : kPackMulti;
+        long long blocks = 0;
+        for (int j = 0; j < a.n; ++j) {
+            const int i = i0 + j;
+            if (!weights[i] || !weight16[i] || kvol[i] <= 0 || cin[i] <= 0 || cout[i] <= 0) return SEC_E_INVALID;
+            const long long total0 = (long long)kvol[i] * cin[i] * cout[i];
+            const long long total_fwd = packed_fwd[i] ? (long long)(sec_packed_weight_bytes(kvol[i], cin[i], cout[i], dtype) / 2) : 0;
+            const long long total_t = packed_dgrad[i] ? (long long)(sec_packed_weight_bytes(kvol[i], cout[i], cin[i], dtype) / 2) : 0;
+            if ((packed_fwd[i] && total_fwd == 0) || (packed_dgrad[i] && (total_t == 0 || cout[i] % 16))) return SEC_E_UNSUPPORTED;
+            long long total = total0 > total_fwd ? total0 : total_fwd;
+            if (total_t > total) total = total_t;
+            PackSparseDesc &d = a.d[j];
+            d.w = weights[i]; d.w16 = weight16[i]; d.packed = packed_fwd[i]; d.packed_t = packed_dgrad[i]; d.zero_dw = zero_dweight[i];
+            d.total_fwd = total_fwd; d.total_t = total_t;
+            d.kvol = kvol[i]; d.cin = cin[i]; d.cout = cout[i]; d.mirror = subm[i] ? 1 : 0; d.blk0 = (int)blocks;
+            blocks += div_up(total, kBlock);
+        }
+        if (dtype == SEC_BF16) hipLaunchKernelGGL(k_pack_weight_train_multi<__hip_bfloat16>, dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
+        else hipLaunchKernelGGL(k_pack_weight_train_multi<__half>, dim3((unsigned)blocks), dim3(kBlock), 0, st, a);
+    }
     return check_launch();
 }

@@ -435,6 +435,55 @@ def indice_conv_set_variant(variant):
     rt.check(rt.lib().sec_indice_conv_set_variant(int(variant)), "sec_indice_conv_set_variant")
 
 
+_PREPACK = {}
+
+
+def prepack_training_weights(sparse_items, dense_items, dtype):
+    """Every weight image a mixed-precision training step needs, in TWO launches instead of one per layer
+    (sec_pack_conv_weight_train_multi / sec_conv2d_pack_weight_train_multi): ``sparse_items`` = [(weight [kD,kH,kW,Cin,Cout] fp32,
+    subm, want_dweight)] of the sparse convolutions, ``dense_items`` = [weight [Cout,Cin,k,k] fp32] of the RPN convolutions that run
+    on the hand-written kernels.  The results wait in a table keyed by the weight's storage; :func:`pack_weight_train` /
+    :func:`conv2d_pack_weight_train` hand them out (once) when the layer runs.  Call at the start of every step: the table is
+    cleared first, so an image can never outlive the weights it was made from."""
+    import ctypes
+    _PREPACK.clear()
+    l, code = rt.lib(), rt.dtype_code(dtype)
+    vp, ci = ctypes.c_void_p, ctypes.c_int
+    arr_p = lambda ts: (vp * len(ts))(*[None if t is None else t.data_ptr() for t in ts])
+    arr_i = lambda vs: (ci * len(vs))(*[int(v) for v in vs])
+    sp = [(w, bool(subm), bool(want)) for (w, subm, want) in sparse_items
+          if w.is_cuda and w.dtype == torch.float32 and w.is_contiguous()]
+    if sp:
+        ws, ks, cins, couts, subs, w16s, pks, pkts, dws = [], [], [], [], [], [], [], [], []
+        for w, subm, want in sp:
+            cin, cout = w.shape[-2], w.shape[-1]
+            k = w.numel() // (cin * cout)
+            nf = l.sec_packed_weight_bytes(k, cin, cout, code)
+            nt = l.sec_packed_weight_bytes(k, cout, cin, code) if cout % 16 == 0 else 0
+            ws.append(w); ks.append(k); cins.append(cin); couts.append(cout); subs.append(int(subm))
+            w16s.append(torch.empty(w.shape, dtype=dtype, device=w.device))
+            pks.append(torch.empty((nf // 2,), dtype=dtype, device=w.device) if nf else None)
+            pkts.append(torch.empty((nt // 2,), dtype=dtype, device=w.device) if nt else None)
+            dws.append(torch.empty(w.shape, dtype=torch.float32, device=w.device) if want else None)
+        rt.check(l.sec_pack_conv_weight_train_multi(len(sp), arr_p(ws), arr_i(ks), arr_i(cins), arr_i(couts), arr_i(subs), code, arr_p(w16s),
+                                                    arr_p(pks), arr_p(pkts), arr_p(dws), rt.stream()), "sec_pack_conv_weight_train_multi")
+        for (w, subm, _), w16, pk, pkt, dw in zip(sp, w16s, pks, pkts, dws):
+            _PREPACK[("sp", w.data_ptr(), dtype, subm)] = (w16, pk, pkt, dw)
+    de = [w for w in dense_items if w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() and w.dim() == 4 and w.shape[2] == w.shape[3]
+          and w.shape[0] % 64 == 0 and w.shape[1] % 64 == 0]
+    if de:
+        both = []
+        for w in de:
+            cout, cin, k, _ = w.shape
+            nb = l.sec_conv2d_packed_weight_bytes(cout, cin, k, code)
+            both.append(torch.empty((2, nb // 2), dtype=dtype, device=w.device))
+        rt.check(l.sec_conv2d_pack_weight_train_multi(len(de), arr_p(de), arr_i([w.shape[0] for w in de]), arr_i([w.shape[1] for w in de]),
+                                                      arr_i([w.shape[2] for w in de]), code, arr_p([b[0] for b in both]),
+                                                      arr_p([b[1] for b in both]), rt.stream()), "sec_conv2d_pack_weight_train_multi")
+        for w, b in zip(de, both):
+            _PREPACK[("2d", w.data_ptr(), dtype)] = (b[0], b[1])
+
+
 def pack_weight_train(weight, dtype, subm, zero_grad=False):
     """fp32 master weight [kD,kH,kW,Cin,Cout] -> (16-bit copy, forward MFMA image or None, data-gradient MFMA image or None) in
     ONE launch (sec_pack_conv_weight_train): what a mixed-precision step otherwise spends to(dtype) + pack_weight + the transposed
@@ -443,6 +492,12 @@ def pack_weight_train(weight, dtype, subm, zero_grad=False):
     :func:`indice_conv_backward` as ``dweight_out`` (its own zeroing is a memset node per layer and step)."""
     rt.require_gpu(weight)
     assert weight.dtype == torch.float32 and weight.is_contiguous() and dtype in (torch.bfloat16, torch.float16)
+    hit = _PREPACK.pop(("sp", weight.data_ptr(), dtype, bool(subm)), None)     # packed by prepack_training_weights in this step's one launch
+    if hit is not None:
+        w16, pk, pkt, dw0 = hit
+        if zero_grad and dw0 is None:
+            dw0 = torch.zeros(weight.shape, dtype=torch.float32, device=weight.device)
+        return (w16, pk, pkt, dw0) if zero_grad else (w16, pk, pkt)
     cin, cout = weight.shape[-2], weight.shape[-1]
     k = weight.numel() // (cin * cout)
     l, code = rt.lib(), rt.dtype_code(dtype)
@@ -1329,6 +1384,9 @@ def conv2d_pack_weight_train(weight, dtype):
     (sec_conv2d_pack_weight_train).  The second is conv2d_pack_weight(conv2d_dgrad_weight(weight.to(dtype)))."""
     rt.require_gpu(weight)
     assert weight.dtype == torch.float32 and weight.is_contiguous() and weight.shape[2] == weight.shape[3]
+    hit = _PREPACK.pop(("2d", weight.data_ptr(), dtype), None)     # packed by prepack_training_weights in this step's one launch
+    if hit is not None:
+        return hit
     cout, cin, k, _ = weight.shape
     l = rt.lib()
     nbytes = l.sec_conv2d_packed_weight_bytes(cout, cin, k, rt.dtype_code(dtype))

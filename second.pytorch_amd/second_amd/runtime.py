@@ -33,7 +33,7 @@ SYMBOLS = [
     "sec_assign_targets_workspace_bytes", "sec_assign_targets_f32", "sec_assign_targets_per_class_f32",
     "sec_second_loss_workspace_bytes", "sec_second_loss_f32", "sec_heads_loss_supported", "sec_heads_loss_workspace_bytes",
     "sec_heads_loss_fwd", "sec_heads_loss_bwd",
-    "sec_conv2d_pack_weight_train", "sec_conv2d_wgrad_workspace_bytes", "sec_conv2d_wgrad_nhwc", "sec_bn_train_workspace_bytes", "sec_bn_relu_fwd_nhwc",
+    "sec_conv2d_pack_weight_train", "sec_conv2d_pack_weight_train_multi", "sec_pack_conv_weight_train_multi", "sec_conv2d_wgrad_workspace_bytes", "sec_conv2d_wgrad_nhwc", "sec_bn_train_workspace_bytes", "sec_bn_relu_fwd_nhwc",
     "sec_bn_relu_bwd_nhwc", "sec_flat_adamw_workspace_bytes", "sec_flat_adamw_f32", "sec_flat_adamw_dev_f32",
 ]
 
@@ -183,6 +183,8 @@ def lib():
         l.sec_heads_loss_bwd.argtypes = [vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, ci, vp]
         ll = ctypes.c_longlong
         l.sec_conv2d_pack_weight_train.argtypes = [vp, ci, ci, ci, ci, vp, vp, vp]
+        l.sec_conv2d_pack_weight_train_multi.argtypes = [ci, vp, vp, vp, vp, ci, vp, vp, vp]
+        l.sec_pack_conv_weight_train_multi.argtypes = [ci, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp]
         l.sec_conv2d_wgrad_workspace_bytes.argtypes = [ci] * 6
         l.sec_conv2d_wgrad_nhwc.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, vp, sz, ci, vp]
         l.sec_bn_train_workspace_bytes.argtypes = [ci]

@@ -164,6 +164,7 @@ class DeviceTrainer:
         self._good_steps, self._skipped_host = 0, 0
         self._graphed_rpn = None
         self.fused_head_loss = os.environ.get("SEC_TRAIN_FUSED_HEAD_LOSS", "1") != "0"   # A/B switch (tests compare the two forms)
+        self.prepack = os.environ.get("SEC_TRAIN_PREPACK", "1") != "0"                   # weight images of all layers in two launches per step
         self.steps = 0
         self.last = {}
 
@@ -213,6 +214,8 @@ class DeviceTrainer:
                 # hand-written kernels, the other widths on MIOpen, forward and backward replayed as two hipGraphs
                 preds = self._rpn_mixed(spatial)
         elif self.amp_dtype is not None:
+            if self.prepack:
+                ops.prepack_training_weights(*self._prepack_items(), self.amp_dtype)      # every layer's weight images: two launches
             # fp32 master weights; 16-bit features through the sparse stack (MFMA forward / dgrad / wgrad kernels) and,
             # under autocast, through the dense RPN; BatchNorm statistics and the loss in fp32
             # (channels_last: the dense scatter writes the RPN's layout and the gradient is gathered from it -- the [B, C, D, H, W]
@@ -228,6 +231,24 @@ class DeviceTrainer:
         loss, out6 = ops.SecondLossFunction.apply(preds["cls_preds"], preds["box_preds"], preds.get("dir_cls_preds"), labels,
                                                   reg_targets, det.anchors, importance, self.loss_cfg)
         return loss, out6, labels
+
+    def _prepack_items(self):
+        """(sparse_items, dense_items) for ops.prepack_training_weights: the sparse convolutions of the middle extractor and the RPN
+        convolutions rpn_forward_mixed runs on the hand-written kernels (3x3 / stride 1 128 -> 128 convs, 1x1 128 -> 128 deblocks)."""
+        import spconv
+        from .models import RPN_TRAIN_BACKEND
+        sparse = [(m.weight, bool(m.subm), m.weight.requires_grad) for m in self.det.middle_feature_extractor.modules()
+                  if isinstance(m, spconv.SparseConvolution)]
+        dense = []
+        if RPN_TRAIN_BACKEND == "hip":
+            for m in self.det.rpn.modules():
+                if isinstance(m, torch.nn.Conv2d) and m.kernel_size == (3, 3) and m.stride == (1, 1) and m.bias is None \
+                        and (m.in_channels, m.out_channels) == (128, 128):
+                    dense.append(m.weight)
+                elif isinstance(m, torch.nn.ConvTranspose2d) and m.kernel_size == (1, 1) and m.stride == (1, 1) and m.bias is None \
+                        and (m.in_channels, m.out_channels) == (128, 128):
+                    dense.append(m.weight)
+        return sparse, dense
 
     def _rpn_mixed(self, spatial, loss_args=None):
         """The dense part of the step has static shapes ([B, 128, H, W] whatever the clouds hold), ~100 launches forward + backward,

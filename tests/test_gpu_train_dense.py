@@ -695,3 +695,32 @@ def test_dense_channels_last_scatter_has_the_gradient_of_the_permuted_dense():
         d.backward(go.contiguous(memory_format=torch.channels_last) if cl else go)
         outs.append((d.detach(), f.grad))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_prepack_training_weights_equals_the_per_layer_packs():
+    """ops.prepack_training_weights (every layer's weight images in two launches: sec_pack_conv_weight_train_multi /
+    sec_conv2d_pack_weight_train_multi) leaves in its table exactly what the per-layer launches produce, hands each image out once,
+    and is cleared by the next call."""
+    from second_amd import ops
+    torch.manual_seed(9)
+    dt = torch.bfloat16
+    sp = [(torch.randn(3, 3, 3, 4, 16, device="cuda"), True, True), (torch.randn(3, 3, 3, 16, 32, device="cuda"), False, True),
+          (torch.randn(3, 3, 3, 64, 64, device="cuda"), True, False), (torch.randn(3, 1, 1, 64, 64, device="cuda"), False, True)]
+    de = [torch.randn(128, 128, 3, 3, device="cuda"), torch.randn(128, 128, 1, 1, device="cuda"), torch.randn(64, 128, 1, 1, device="cuda")]
+    ref_sp = [ops.pack_weight_train(w, dt, subm) for w, subm, _ in sp]
+    ref_de = [ops.conv2d_pack_weight_train(w, dt) for w in de]
+    ops.prepack_training_weights(sp, de, dt)
+    assert len(ops._PREPACK) == len(sp) + len(de)
+    for (w, subm, want), ref in zip(sp, ref_sp):
+        got = ops.pack_weight_train(w, dt, subm, zero_grad=True)
+        for a, b in zip(got[:3], ref):
+            assert (a is None) == (b is None) and (a is None or torch.equal(a, b))
+        assert got[3].dtype == torch.float32 and got[3].shape == w.shape and float(got[3].abs().max()) == 0.0
+    for w, ref in zip(de, ref_de):
+        got = ops.conv2d_pack_weight_train(w, dt)
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+    assert len(ops._PREPACK) == 0                             # every image handed out once
+    ops.prepack_training_weights(sp[:1], [], dt)
+    ops.prepack_training_weights([], de[:1], dt)              # the table of the previous call is dropped
+    assert list(ops._PREPACK) == [("2d", de[0].data_ptr(), dt)]
+    ops._PREPACK.clear()
