@@ -377,6 +377,12 @@ def test_indice_conv_fp32(ops, cin, cout, subm):
     ref = orc.indice_conv(feat, w, pairs, pair_num, n_out, acc64=True)
     out = ops.indice_conv(dev(feat), dev(w), dev(nbr_out), n_out).cpu().numpy()
     np.testing.assert_allclose(out, ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max())
+    # PER ELEMENT (the line above is relative to the tensor's maximum): the forward error bound of the arithmetic the kernel runs --
+    # every product within 3 * 2^-18 of exact (fp32 operands carried as two bf16 halves, the lo * lo term dropped: DESIGN 4) plus an
+    # fp32 accumulation over K = 27 * cin terms -- against the sum of the products' magnitudes of THAT output element
+    mag = orc.indice_conv(np.abs(feat), np.abs(w), pairs, pair_num, n_out, acc64=True)
+    bound = (4 * 2.0 ** -18 + (27 * cin + 2) * 2.0 ** -24) * mag + 1e-30
+    assert np.all(np.abs(out - ref) <= bound), float((np.abs(out - ref) / bound).max())
 
 
 @pytest.mark.parametrize("cin,cout", CONV_SHAPES)
@@ -393,6 +399,11 @@ def test_indice_conv_half_mfma(ops, cin, cout, dtype):
     shift = rng.uniform(-0.2, 0.2, cout).astype(np.float32)
     out32 = ops.indice_conv(f_t, w_t, dev(nbr_out), n_out, packed=packed, out_dtype=torch.float32).cpu().numpy()
     np.testing.assert_allclose(out32, ref, rtol=1e-4, atol=1e-4 * np.abs(ref).max())
+    # per element: 16-bit x 16-bit products are exact in fp32, so only the fp32 accumulation of K = 27 * cin terms is left --
+    # gamma_K * sum |x| |w| of that element
+    mag = orc.indice_conv(np.abs(f_t.float().cpu().numpy()), np.abs(w_t.float().cpu().numpy()), pairs, pair_num, n_out, acc64=True)
+    bound = (27 * cin + 2) * 2.0 ** -24 * mag + 1e-30
+    assert np.all(np.abs(out32 - ref) <= bound), float((np.abs(out32 - ref) / bound).max())
     # generic path on the same inputs must agree too (cross-check of the MFMA fragment layouts)
     gen = ops.indice_conv(f_t, w_t, dev(nbr_out), n_out, packed=None, out_dtype=torch.float32).cpu().numpy()
     np.testing.assert_allclose(out32, gen, rtol=1e-4, atol=1e-4 * np.abs(ref).max())
