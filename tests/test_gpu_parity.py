@@ -941,6 +941,12 @@ def test_conv2d_nhwc_mfma_vs_torch(ops, cin, cout, k, stride, pad, hw, dtype):
     nob = ops.conv2d_nhwc(x, ops.conv2d_pack_weight(w), None, cout, k, stride, pad, relu=False)
     ref2 = torch.nn.functional.conv2d(x.float(), w.float(), None, stride, pad)
     np.testing.assert_allclose(nob.float().cpu().numpy(), ref2.cpu().numpy(), rtol=tol, atol=tol * ref2.abs().max().item())
+    # PER ELEMENT (the lines above are relative to the tensor's maximum): exact 16-bit products, fp32 accumulation of K = cin k^2 terms
+    # on both sides (gamma_K * sum |x| |w| of that output element each), one rounding to the output dtype
+    mag = torch.nn.functional.conv2d(x.float().abs(), w.float().abs(), None, stride, pad)
+    u_out = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    bound = u_out * ref2.abs() + 2 * (cin * k * k + 2) * 2.0 ** -24 * mag + 1e-30
+    assert bool(((nob.float() - ref2).abs() <= bound).all()), float(((nob.float() - ref2).abs() / bound).max())
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
