@@ -55,7 +55,7 @@ BATCH = 8
 # present on the device (same frame, BEV centre within 0.25 m, score within 0.05) and the allowed per-frame count difference.
 # bf16 features move a logit by ~1 % through 21 layers; with nms_iou_threshold 0.01 (car.fhd.config:94: any overlap suppresses)
 # two overlapping candidates of near-equal score can swap -- tests/test_gpu_e2e.py attributes every miss to its cause.
-MATCH_MIN_FOUND = 0.85
+MATCH_MIN_FOUND = 0.9      # (0.85 until round 5: observed 90 of 96 on every box; the fp32 device path of the same line must match 96 of 96)
 MATCH_COUNT_SLACK = 2
 
 
