@@ -626,22 +626,25 @@ def test_heads_1x1_function_vs_torch():
     np.testing.assert_allclose(bs.grad.cpu().numpy(), br.grad.cpu().numpy(), rtol=2e-3, atol=2e-3 * float(br.grad.abs().max()))
 
 
+@pytest.mark.parametrize("bins", [2, 0])
 @pytest.mark.parametrize("dtype,scale", [(torch.bfloat16, 1.0), (torch.float16, 512.0)])
-def test_heads_loss_function_equals_the_three_tensor_formulation(dtype, scale):
+def test_heads_loss_function_equals_the_three_tensor_formulation(dtype, scale, bins):
     """ops.HeadsLossFunction (the loss read from the stacked head tensor, its gradient written back into it: sec_heads_loss_fwd / _bwd)
     against the formulation it replaces -- Heads1x1Function, the reference's [B, A, H, W, code] views of the three heads
     (rpn.py:386-391), SecondLossFunction (voxelnet.py:239-312; pinned by tests/golden through sec_second_loss_f32): the six loss
     scalars to summation order, the data / weight / bias gradients of the head convolution exactly as autograd stitches them
-    (the gradient is rounded once after the multiplication by the incoming scalar: `scale` plays the fp16 loss scale)."""
+    (the gradient is rounded once after the multiplication by the incoming scalar: `scale` plays the fp16 loss scale).  bins = 0: a
+    network without the direction classifier (use_direction_classifier false: two heads)."""
     from second_amd import ops
     torch.manual_seed(11)
     b, h, w, a = 2, 24, 20, 2
     n = a * h * w
     x = torch.randn(b, 128, h, w, device="cuda").to(dtype).contiguous(memory_format=torch.channels_last)
+    tot = a * (7 + 1 + bins)
     wt = torch.randn(64, 128, 1, 1, device="cuda") / 11
-    wt[20:] = 0
+    wt[tot:] = 0
     bs = torch.randn(64, device="cuda") / 4
-    bs[20:] = 0
+    bs[tot:] = 0
     g = torch.Generator().manual_seed(5)
     labels = (torch.rand(b, n, generator=g) < 0.03).int()                      # a few positives,
     labels[torch.rand(b, n, generator=g) < 0.05] = -1                            # some don't-cares
@@ -649,19 +652,19 @@ def test_heads_loss_function_equals_the_three_tensor_formulation(dtype, scale):
     reg = (torch.randn(b, n, 7, generator=g) * 0.3).cuda() * (labels > 0).unsqueeze(-1)
     anchors = torch.randn(n, 7, generator=g).cuda()
     imp = (0.5 + torch.rand(b, n, generator=g)).cuda()
-    cfg = dict(num_class=1, num_direction_bins=2, direction_offset=0.0)
+    cfg = dict(num_class=1, num_direction_bins=max(bins, 1), direction_offset=0.0)
     sc = torch.tensor(scale, device="cuda")
 
     def run(fused):
         xi = x.clone().requires_grad_()
         wi, bi = wt.clone().requires_grad_(), bs.clone().requires_grad_()
         if fused:
-            loss, out6 = ops.HeadsLossFunction.apply(xi, wi, bi, labels, reg, anchors, imp, a, 1, 2, cfg)
+            loss, out6 = ops.HeadsLossFunction.apply(xi, wi, bi, labels, reg, anchors, imp, a, 1, bins, cfg)
         else:
             y = ops.Heads1x1Function.apply(xi, wi, bi)
             box = y[:, :14].reshape(-1, a, 7, h, w).permute(0, 1, 3, 4, 2).contiguous()
             cls = y[:, 14:16].reshape(-1, a, 1, h, w).permute(0, 1, 3, 4, 2).contiguous()
-            dr = y[:, 16:20].reshape(-1, a, 2, h, w).permute(0, 1, 3, 4, 2).contiguous()
+            dr = y[:, 16:20].reshape(-1, a, 2, h, w).permute(0, 1, 3, 4, 2).contiguous() if bins else None
             loss, out6 = ops.SecondLossFunction.apply(cls, box, dr, labels, reg, anchors, imp, cfg)
         (loss * sc).backward()
         return out6.detach(), xi.grad, wi.grad, bi.grad
@@ -670,9 +673,9 @@ def test_heads_loss_function_equals_the_three_tensor_formulation(dtype, scale):
     o_r, dx_r, dw_r, db_r = run(False)
     np.testing.assert_allclose(o_f.cpu().numpy(), o_r.cpu().numpy(), rtol=2e-5, atol=1e-7)
     assert torch.equal(dx_f, dx_r)                                               # same dY bit for bit -> same kernel, same result
-    assert torch.equal(dw_f[:20], dw_r[:20]) and float(dw_f[20:].abs().max()) == 0.0
-    np.testing.assert_allclose(db_f[:20].cpu().numpy(), db_r[:20].cpu().numpy(), rtol=1e-4, atol=1e-6 * scale)
-    assert float(db_f[20:].abs().max()) == 0.0 and float(dx_f.float().abs().max()) > 0
+    assert torch.equal(dw_f[:tot], dw_r[:tot]) and float(dw_f[tot:].abs().max()) == 0.0
+    np.testing.assert_allclose(db_f[:tot].cpu().numpy(), db_r[:tot].cpu().numpy(), rtol=1e-4, atol=1e-6 * scale)
+    assert float(db_f[tot:].abs().max()) == 0.0 and float(dx_f.float().abs().max()) > 0
 
 
 def test_dense_channels_last_scatter_has_the_gradient_of_the_permuted_dense():
