@@ -174,6 +174,7 @@ class DeviceTrainer:
             return self._forward_loss(points, point_offsets, gt_boxes, gt_offsets, gt_classes)
         finally:
             ops.set_rulebook_numbering(prev)
+            ops._PREPACK.clear()      # images the forward did not consume must not outlive this step's weights (prepack_training_weights)
 
     def _forward_loss(self, points, point_offsets, gt_boxes, gt_offsets, gt_classes=None):
         det, cfg = self.det, self.cfg
