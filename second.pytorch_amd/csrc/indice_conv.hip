@@ -2054,6 +2054,129 @@ __global__ __launch_bounds__(kBlock) void k_conv_wgrad_mfma(const T *__restrict_
     }
 }
 
+// The same contraction (dW[k] += X[nbr[o][k]]^T dOut[o] over a chunk of output rows o, one offset k per workgroup) with the staging of
+// the dense weight gradient (dense_train.hip, round 5): every 64-row step loads FULL feature / gradient rows with unconditional buffer
+// loads (a row without a neighbour at this offset reads zeros through the out-of-range offset -- no pair compaction, no branch around a
+// load), stores them untransposed ([row][channel], ds_write_b128; 64-channel rows swap their 64-byte halves on rows 2, 3 mod 4 so that
+// the four rows of a read group fall into four bank windows) and lets ds_read_b64_tr_b16 hand each lane eight ROWS of one channel: the
+// MFMA operands of a contraction over rows.  The loads of step s + 1 are in flight under the MFMAs of step s (the neighbour indices one
+// step further), LDS is double-buffered, one barrier per step.  k_conv_wgrad_mfma compacted the pairs through wave 0 and LDS, loaded
+// under `if (p < np)` (a branch and s_waitcnt vmcnt(0) per load) and transposed with eight 2-byte LDS stores per load: three barriers
+// and ~2 us per step -- 26.6 -> 17.9 us for 64 -> 64 at 28 k rows (32 -> 64: 31 -> 26; 32 -> 32 unchanged at 36: one MFMA per wave and step).
+typedef short ws16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned wu32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint2 wg_tr16_b64(const char *p) {
+    const ws16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ws16x4 __attribute__((address_space(3))) *)p);
+    return __builtin_bit_cast(uint2, v);
+}
+template <typename T, int CIN, int COUT>
+__global__ __launch_bounds__(kBlock) void k_conv_wgrad_tr(const T *__restrict__ feat, const T *__restrict__ dout, const int *__restrict__ nbr,
+                                                         int n_out, int kvol, int rows_per_chunk, float *__restrict__ dw) {
+    static_assert((CIN == 32 || CIN == 64) && (COUT == 32 || COUT == 64), "full 32-channel tiles");
+    constexpr int SUB = 64, FP = CIN * 2, DP = COUT * 2;                     // rows per step; row pitches in bytes
+    constexpr int CPR = CIN / 8, DPR = COUT / 8;                             // 16-byte chunks per row
+    constexpr int FL = SUB * CPR / kBlock, DL = SUB * DPR / kBlock;          // loads per thread and step (1 or 2)
+    constexpr int CI_T = CIN / 32, CO_T = COUT / 32, TILES = CI_T * CO_T, WPT = 4 / TILES;
+    __shared__ __attribute__((aligned(16))) char sF[2][SUB * FP];
+    __shared__ __attribute__((aligned(16))) char sD[2][SUB * DP];
+    const int k = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int tile = wv / WPT, ksel = wv % WPT;
+    const int ti = tile / CO_T, tj = tile % CO_T;
+    const int o0 = blockIdx.x * rows_per_chunk;
+    const int o1 = o0 + rows_per_chunk < n_out ? o0 + rows_per_chunk : n_out;
+    const int nsteps = (o1 - o0 + SUB - 1) / SUB;
+    const __amdgpu_buffer_rsrc_t frs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(feat), 0, 0x7ffffff0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(dout), 0, 0x7ffffff0, 0x00020000);
+    // this thread's staging slots: chunk fc[i] of step-row fr[i] (features), dc / dr (gradient rows)
+    int fr[FL], fc[FL], dr[DL], dc[DL], fst[FL], dst_[DL];
+#pragma unroll
+    for (int i = 0; i < FL; ++i) {
+        const int e = tid + kBlock * i;
+        fr[i] = e / CPR; fc[i] = e % CPR;
+        fst[i] = fr[i] * FP + ((fc[i] ^ (CIN == 64 ? ((fr[i] >> 1) & 1) << 2 : 0)) << 4);
+    }
+#pragma unroll
+    for (int i = 0; i < DL; ++i) {
+        const int e = tid + kBlock * i;
+        dr[i] = e / DPR; dc[i] = e % DPR;
+        dst_[i] = dr[i] * DP + ((dc[i] ^ (COUT == 64 ? ((dr[i] >> 1) & 1) << 2 : 0)) << 4);
+    }
+    int idx[FL], didx[DL];                                  // neighbour rows of the NEXT step to load (and, for the gradient rows, whether one exists)
+    auto load_idx = [&](int step) {
+#pragma unroll
+        for (int i = 0; i < FL; ++i) {
+            const int o = o0 + step * SUB + fr[i];
+            const bool ok = o < o1;
+            const int v = nbr[(size_t)(ok ? o : o0) * kvol + k];       // unconditional load, clamped row
+            idx[i] = ok ? v : -1;
+        }
+#pragma unroll
+        for (int i = 0; i < DL; ++i) {                       // a gradient row without a neighbour is NOT read: with static capacities the rows
+            const int o = o0 + step * SUB + dr[i];           // behind the live count hold whatever was there (0 x NaN would poison the sum)
+            const bool ok = o < o1;
+            const int v = nbr[(size_t)(ok ? o : o0) * kvol + k];
+            didx[i] = ok ? v : -1;
+        }
+    };
+    wu32x4 rf[FL], rd[DL];
+    auto fetch = [&](int step) {
+#pragma unroll
+        for (int i = 0; i < FL; ++i)
+            rf[i] = __builtin_amdgcn_raw_buffer_load_b128(frs, idx[i] >= 0 ? (unsigned)idx[i] * (unsigned)FP + fc[i] * 16u : 0xfffffff0u, 0, 0);
+#pragma unroll
+        for (int i = 0; i < DL; ++i) {
+            const int o = o0 + step * SUB + dr[i];
+            rd[i] = __builtin_amdgcn_raw_buffer_load_b128(drs, didx[i] >= 0 ? (unsigned)o * (unsigned)DP + dc[i] * 16u : 0xfffffff0u, 0, 0);
+        }
+    };
+    auto put = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < FL; ++i) *reinterpret_cast<wu32x4 *>(&sF[buf][fst[i]]) = rf[i];
+#pragma unroll
+        for (int i = 0; i < DL; ++i) *reinterpret_cast<wu32x4 *>(&sD[buf][dst_[i]]) = rd[i];
+    };
+    // operand reads: 16-lane group g, lane li: rows ks * 16 + (g / 2) * 8 + t * 4 + li / 4 (t = 0, 1), channels tile * 32 + (g & 1) * 16
+    // + (li & 3) * 4 .. + 3; the lane receives channel tile * 32 + r
+    const int g = lane >> 4, li = lane & 15;
+    const int prow = (g >> 1) * 8 + (li >> 2), swz = ((li >> 3) & 1) << 2;     // (row >> 1) & 1 of every row this lane addresses
+    const int qa = ti * 4 + (g & 1) * 2 + ((li & 3) >> 1), qb = tj * 4 + (g & 1) * 2 + ((li & 3) >> 1);
+    const int a_off = prow * FP + ((qa ^ (CIN == 64 ? swz : 0)) << 4) + (li & 1) * 8;
+    const int b_off = prow * DP + ((qb ^ (COUT == 64 ? swz : 0)) << 4) + (li & 1) * 8;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    if (nsteps > 0) {
+        load_idx(0);
+        fetch(0);
+        load_idx(1);
+        put(0);
+        __syncthreads();
+        for (int s = 0; s < nsteps; ++s) {
+            const int buf = s & 1;
+            fetch(s + 1);                                   // past the chunk: indices -1 / rows >= o1 -> zeros, no memory traffic
+            load_idx(s + 2);
+#pragma unroll
+            for (int ks = 0; ks < SUB / 16; ++ks) {
+                if (ks % WPT == ksel) {
+                    const char *fa = &sF[buf][ks * 16 * FP + a_off], *fb = &sD[buf][ks * 16 * DP + b_off];
+                    const uint2 a0 = wg_tr16_b64(fa), a1 = wg_tr16_b64(fa + 4 * FP);
+                    const uint2 b0 = wg_tr16_b64(fb), b1 = wg_tr16_b64(fb + 4 * DP);
+                    acc = Mfma<T>::run(make_uint4(a0.x, a0.y, a1.x, a1.y), make_uint4(b0.x, b0.y, b1.x, b1.y), acc);
+                }
+            }
+            put(buf ^ 1);                                   // that buffer was last read before the previous barrier
+            __syncthreads();
+        }
+    }
+    // D layout: column (co) = lane & 31, rows (ci) = (i & 3) + 8 (i >> 2) + 4 h
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int ci = ti * 32 + (i & 3) + 8 * (i >> 2) + 4 * h, co = tj * 32 + r;
+        if (acc[i] != 0.0f) atomicAdd(&dw[((size_t)k * CIN + ci) * COUT + co], acc[i]);
+    }
+}
+
 template <typename T>
 static bool launch_wgrad_tiled(const void *feat, const void *dout, const int *nbr, int n_out, int cin, int cout, int kvol,
                                float *dw, hipStream_t st) {
@@ -2064,7 +2187,7 @@ static bool launch_wgrad_tiled(const void *feat, const void *dout, const int *nb
     // chain is 9 x longer and the kernel is bound by that chain, not by the staging.  Capping the chunk at 1024 rows on the large
     // nuScenes layers -- 6 600 workgroups instead of 1 700 -- was slower too: 378 vs 207 us for 32 -> 32 at 250 k rows.)
     int chunk = 8192;
-    while (chunk > 512 && (long long)div_up(n_out, chunk) * kvol < 1400) chunk >>= 1;
+    while (chunk > 512 && (long long)div_up(n_out, chunk) * kvol < 1400) chunk >>= 1;      // (700 / 2800 with k_conv_wgrad_tr: no difference)
     dim3 grid(div_up(n_out, chunk), kvol);
     if constexpr (!std::is_same<T, float>::value) {            // 16-bit dtypes: matrix cores
 #define SEC_WM(CI, CO)                                                                                                    \
@@ -2073,6 +2196,14 @@ static bool launch_wgrad_tiled(const void *feat, const void *dout, const int *nb
                                n_out, kvol, chunk, dw);                                                                   \
             return true;                                                                                                  \
         }
+#define SEC_WT(CI, CO)                                                                                                    \
+        if (cin == CI && cout == CO && conv_variant() != 41) {                                                            \
+            hipLaunchKernelGGL((k_conv_wgrad_tr<T, CI, CO>), grid, dim3(kBlock), 0, st, (const T *)feat, (const T *)dout, nbr,   \
+                               n_out, kvol, chunk, dw);                                                                   \
+            return true;                                                                                                  \
+        }
+        SEC_WT(32, 32) SEC_WT(32, 64) SEC_WT(64, 32) SEC_WT(64, 64)        // (SEC_CONV_VARIANT=41: the compacting kernel below, for A/B)
+#undef SEC_WT
         SEC_WM(4, 16) SEC_WM(16, 16) SEC_WM(16, 32) SEC_WM(32, 32) SEC_WM(32, 64) SEC_WM(64, 64)
 #undef SEC_WM
     }
