@@ -22,6 +22,9 @@ WARM, ITERS = int(os.environ.get("WARM", "10")), int(os.environ.get("ITERS", "25
 dev = torch.device("cuda")
 ops.set_rulebook_numbering("sorted")                      # the numbering of the device fast path (SecondDetector.forward_points)
 clouds = [syn.syn_kitti_cloud(s) for s in range(8)]
+if os.environ.get("POINT_ORDER", "shuffle") == "sorted":   # cell-ordered rows (bench.py --point-order sorted): the gather-locality experiment
+    import numpy as np
+    clouds = [c[np.lexsort((c[:, 0], c[:, 1], c[:, 2]))] for c in clouds]
 pts, offs = syn.batch_clouds(clouds)
 vox = ops.voxelize(torch.from_numpy(pts).to(dev), torch.from_numpy(offs).to(dev), syn.CAR_FHD_RANGE, syn.CAR_FHD_VOXEL, 5, 40000)
 idx, shape = vox["coordinates"].contiguous(), [41, 1600, 1408]
