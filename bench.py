@@ -865,6 +865,68 @@ def time_dropin_fused(cpu_state, points, offsets, iters=60):
     return out
 
 
+def time_dropin_train(iters_eager=6, iters_fused=40, batch=4):
+    """The reference's TRAINING loop on the drop-in surface (never `value`; BASELINE config 3's per-GPU batch of 4): a network OBJECT
+    shaped like ``build_network``'s result (tests/reference_standin.py; default init, train mode) driven exactly as
+    second/pytorch/train.py:306-325 drives it --
+
+        ret = net(example); loss = ret["loss"].mean(); loss.backward()
+        torch.nn.utils.clip_grad_norm_(net.parameters(), 10.0); optimizer.step(); optimizer.zero_grad()
+
+    -- with torch.optim.AdamW on the network's own parameters (adam + fixed weight decay 0.01, car.fhd.config:180-188), samples/s.
+    `eager`: the un-accelerated module graph, fp32 (three modules per sparse layer, first-touch rulebooks with a host round trip per
+    strided layer, .dense(), torch / MIOpen RPN, ~60 torch launches of loss glue, autograd through all of it).  `fused`:
+    ``compat.accelerate_model(net, train_dtype=torch.bfloat16)`` -- the same loop, the same optimizer object type and parameters, forward
+    and backward each ONE hipGraph replay (second_amd/dropin_train.py; bf16 features over the fp32 parameters).  The example dict
+    (voxels, coordinates, labels, reg_targets ...) is resident in HBM: voxelisation and target assignment are the data loader's job
+    in the reference."""
+    tests_dir = os.path.join(ROOT, "tests")
+    if tests_dir not in sys.path:
+        sys.path.insert(0, tests_dir)
+    from reference_standin import build_voxelnet, train_example_of
+    from second_amd import compat, synthetic as syn
+    from second_amd.models import CAR_FHD
+    clouds = [syn.syn_kitti_cloud(s) for s in range(batch)]
+    boxes = [syn.syn_kitti_boxes(s, 12) for s in range(batch)]
+    out = {}
+    for tag, iters in (("eager", iters_eager), ("fused", iters_fused)):
+        torch.manual_seed(0)
+        net = build_voxelnet(CAR_FHD).cuda().train()
+        ex = train_example_of(net, clouds, boxes, torch.device("cuda"))
+        if tag == "fused":
+            compat.accelerate_model(net, train_dtype=torch.bfloat16)
+        opt = torch.optim.AdamW(net.parameters(), lr=1e-3, weight_decay=0.01, betas=(0.9, 0.99))
+
+        def step():
+            ret = net(ex)
+            loss = ret["loss"].mean()
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(net.parameters(), 10.0)
+            opt.step()
+            opt.zero_grad()
+            return loss
+        for _ in range(3):
+            first = step()
+        first = float(first.detach())
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            last = step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / iters
+        out[tag] = {"samples_per_s": round(batch / dt, 1), "ms_per_step": round(dt * 1e3, 3), "steps": iters,
+                    "loss_after_3_steps": round(first, 4), "loss_last_step": round(float(last.detach()), 4)}
+        eng = getattr(net, "_second_amd_engine", None)
+        if eng is not None:
+            out[tag].update(graph_captures=eng.stats.get("train_captures"), calls_served_by_the_original_forward=eng.stats["original_calls"],
+                            fallback_reason=eng.stats.get("train_fallback_reason"))
+        del net, opt, ex
+        torch.cuda.empty_cache()
+    out["what"] = (f"train.py:306-325 loop, batch {batch}, 17 000 points -> 16 000 voxels per frame, torch.optim.AdamW + clip_grad_norm_(10) on the "
+                   "network's own parameters; eager = the fp32 module graph, fused = accelerate_model(train_dtype=bfloat16): two hipGraph replays per step")
+    return out
+
+
 def time_scene_density(args, main_value, budget_s=150.0):
     """How much of the headline depends on the BEV sparsity of the scene: the default path on a DENSE seeded scene
     (synthetic.syn_kitti_cloud(scene="dense"): 14-20 % of the 200 x 176 BEV cells occupied instead of 4-7 %, same 16 000 voxels /
@@ -1078,7 +1140,7 @@ def main():
                 ktable = kernel_table(det, points, offsets)
             except Exception as e:  # noqa: BLE001 -- the table is diagnostics: never lose the line over it
                 ktable = [{"error": repr(e)}]
-        e2e = batch1 = dropin = fused = scenes = None
+        e2e = batch1 = dropin = fused = scenes = dtrain = None
         if rank == 0 and args.workload == "car.fhd" and not args.no_extra_lines and not args.default_heads:
             try:
                 dropin = time_dropin_modules(cpu_state, points, offsets)
@@ -1088,6 +1150,10 @@ def main():
                 fused = time_dropin_fused(cpu_state, points, offsets)
             except Exception as e:  # noqa: BLE001
                 fused = {"error": repr(e)[:300]}
+            try:
+                dtrain = time_dropin_train()
+            except Exception as e:  # noqa: BLE001
+                dtrain = {"error": repr(e)[:300]}
         if rank == 0 and args.mode == "graph" and args.branches == 1 and args.workload == "car.fhd" and not args.no_extra_lines:
             e2e = time_e2e(det, points, offsets, max(1, args.inflight), min(args.steps, 200), args.warmup, serialize_rpn=serialize)
             batch1 = time_batch1(det, points, offsets)      # last: it re-calibrates the static capacities for one frame
@@ -1188,7 +1254,7 @@ def main():
                        "weights": "seeded random, default heads (tie-dominated top-k)" if args.default_heads or WL["cfg"] != "CAR_FHD"
                                   else "seeded random with trained-like heads (synthetic.randomise_like_trained / sharpen_heads)",
                        "rpn_background_tiles": bg_tiles,
-                       "e2e_from_pinned_host": e2e, "batch1": batch1, "dropin_module_path": dropin, "dropin_fused": fused},
+                       "e2e_from_pinned_host": e2e, "batch1": batch1, "dropin_module_path": dropin, "dropin_fused": fused, "dropin_train": dtrain},
             "roofline": roof,
             "roofline_mfma": roof_mfma,     # second-largest consumer by kind: the dense RPN conv, MFMA bound
             "kernels": ktable,              # per-launch table of one step (SURVEY 8d formulas)

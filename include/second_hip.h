@@ -35,7 +35,7 @@ extern "C" {
 #define SEC_F16 1
 #define SEC_BF16 2
 
-#define SEC_ABI_VERSION 6
+#define SEC_ABI_VERSION 7
 int sec_abi_version(void);
 /* last HIP error string seen by this library (thread-unsafe convenience for diagnostics) */
 const char *sec_last_error(void);
@@ -603,6 +603,14 @@ size_t sec_heads_loss_workspace_bytes(int batch, int h, int w, int anchors_per_l
 int sec_heads_loss_fwd(const void *heads, int dtype, int batch, int h, int w, int head_channels, int anchors_per_loc, int num_class,
                        int num_dir_bins, const int *labels, const float *reg_targets, const float *anchors, const float *importance,
                        const float *h_params17, float *out6, void *workspace, size_t workspace_bytes, void *stream);
+/* _fwd_terms: _fwd plus the per-anchor tensors VoxelNet.loss returns beside the scalars (voxelnet.py:299-309; read by train.py:312-313,
+ * 326-329 for update_metrics and the per-code loss display): cls_preds_out [batch, A*h*w, num_class] = the cls logits as fp32 in the
+ * reference's anchor order, cls_loss_out [batch, A*h*w, num_class], loc_loss_out [batch, A*h*w, 7] (weighted focal / smooth-L1 terms
+ * before the batch mean); any of the three may be NULL. */
+int sec_heads_loss_fwd_terms(const void *heads, int dtype, int batch, int h, int w, int head_channels, int anchors_per_loc, int num_class,
+                             int num_dir_bins, const int *labels, const float *reg_targets, const float *anchors, const float *importance,
+                             const float *h_params17, float *out6, float *cls_preds_out, float *cls_loss_out, float *loc_loss_out,
+                             void *workspace, size_t workspace_bytes, void *stream);
 int sec_heads_loss_bwd(const void *heads, int dtype, int batch, int h, int w, int head_channels, int anchors_per_loc, int num_class,
                        int num_dir_bins, const int *labels, const float *reg_targets, const float *anchors, const float *importance,
                        const float *h_params17, const float *grad_loss, void *d_heads, float *d_bias, void *workspace,

@@ -359,7 +359,10 @@ __global__ __launch_bounds__(kBlock) void k_heads_loss(const HT *__restrict__ he
                                                       const float *__restrict__ reg, const float *__restrict__ anchors,
                                                       const float *__restrict__ importance, const float *__restrict__ cnt, LossParams P,
                                                       const float *__restrict__ g_loss, HT *__restrict__ d_heads,
-                                                      float *__restrict__ partial) {
+                                                      float *__restrict__ partial, float *__restrict__ o_cls_pred,
+                                                      float *__restrict__ o_cls_loss, float *__restrict__ o_loc_loss) {
+    // o_*: forward only, optional -- the per-anchor tensors VoxelNet.loss also returns (voxelnet.py:299-309: cls_preds as fp32
+    // [B, n_anchor, NC], cls_loss [B, n_anchor, NC], loc_loss [B, n_anchor, 7]) for the drop-in training forward
     constexpr int TOT = A * (7 + NC + BINS), NCH = (TOT + 7) / 8;       // 16-byte chunks of a row that hold head outputs
     constexpr int BOX0 = 0, CLS0 = A * 7, DIR0 = A * 7 + A * NC;
     const int b = blockIdx.y, pix = blockIdx.x * kBlock + threadIdx.x;
@@ -412,6 +415,8 @@ __global__ __launch_bounds__(kBlock) void k_heads_loss(const HT *__restrict__ he
                 s_cls += l;
                 if (NC == 1) { s_pos += pos ? l : 0.0f; s_neg += neg ? l : 0.0f; }
                 else { s_pos += c > 0 ? l : 0.0f; s_neg += c == 0 ? l : 0.0f; }
+                if (!GRAD && o_cls_pred) o_cls_pred[o * NC + c] = x;
+                if (!GRAD && o_cls_loss) o_cls_loss[o * NC + c] = l;
                 if (GRAD) {
                     const float dpt = (2.0f * t - 1.0f) * p * (1.0f - p);
                     const float dmod = P.gamma == 2.0f ? -2.0f * om * dpt : (P.gamma == 0.0f ? 0.0f : -P.gamma * powf(om, P.gamma - 1.0f) * dpt);
@@ -438,6 +443,7 @@ __global__ __launch_bounds__(kBlock) void k_heads_loss(const HT *__restrict__ he
                 const bool small = ad <= 1.0f / s2;
                 const float l = small ? 0.5f * (ad * P.sigma) * (ad * P.sigma) : ad - 0.5f / s2;
                 s_loc += l * wreg;
+                if (!GRAD && o_loc_loss) o_loc_loss[o * 7 + j] = l * wreg;
                 if (GRAD) {
                     const float dl = small ? s2 * diff : (diff > 0.0f ? 1.0f : (diff < 0.0f ? -1.0f : 0.0f));
                     d[BOX0 + a * 7 + j] = dl * P.code_w[j] * dscale * wreg * P.loc_w * inv_b;
@@ -769,18 +775,19 @@ static void fill_loss_params(LossParams &P, int batch, int n_anchor, int nc, int
 template <typename HT, bool GRAD>
 static void launch_heads_loss(int bins, dim3 grid, hipStream_t st, const void *heads, int HW, int HC, const int *labels, const float *reg,
                               const float *anchors, const float *importance, const float *cnt, const LossParams &P, const float *g,
-                              void *d_heads, float *partial) {
+                              void *d_heads, float *partial, float *const *terms = nullptr) {
+    float *t0 = terms ? terms[0] : nullptr, *t1 = terms ? terms[1] : nullptr, *t2 = terms ? terms[2] : nullptr;
     if (bins == 2)
         hipLaunchKernelGGL((k_heads_loss<HT, 2, 1, 2, GRAD>), grid, dim3(kBlock), 0, st, (const HT *)heads, HW, HC, labels, reg, anchors, importance,
-                           cnt, P, g, (HT *)d_heads, partial);
+                           cnt, P, g, (HT *)d_heads, partial, t0, t1, t2);
     else
         hipLaunchKernelGGL((k_heads_loss<HT, 2, 1, 0, GRAD>), grid, dim3(kBlock), 0, st, (const HT *)heads, HW, HC, labels, reg, anchors, importance,
-                           cnt, P, g, (HT *)d_heads, partial);
+                           cnt, P, g, (HT *)d_heads, partial, t0, t1, t2);
 }
 static int heads_loss_impl(bool grad, const void *heads, int dtype, int batch, int h, int w, int head_channels, int a, int nc, int bins,
                            const int *labels, const float *reg_targets, const float *anchors, const float *importance,
                            const float *h_params17, const float *grad_loss, void *d_heads, float *d_bias, float *out6, void *workspace,
-                           size_t workspace_bytes, bool counts_ready, void *stream) {
+                           size_t workspace_bytes, bool counts_ready, void *stream, float *const *terms = nullptr) {
     if (!heads || batch <= 0 || h <= 0 || w <= 0 || !labels || !reg_targets || !anchors || !importance || !h_params17 ||
         (grad ? (!d_heads || !d_bias) : !out6))
         return SEC_E_INVALID;
@@ -797,8 +804,8 @@ static int heads_loss_impl(bool grad, const void *heads, int dtype, int batch, i
     if (!counts_ready) hipLaunchKernelGGL(k_loss_count, dim3(kCountChunks, batch), dim3(kBlock), 0, st, labels, n_anchor, cnt, importance);
     const dim3 grid(nb, batch);
     if (!grad) {
-        if (dtype == SEC_BF16) launch_heads_loss<__hip_bfloat16, false>(bins, grid, st, heads, HW, head_channels, labels, reg_targets, anchors, importance, cnt, P, nullptr, nullptr, partial);
-        else launch_heads_loss<__half, false>(bins, grid, st, heads, HW, head_channels, labels, reg_targets, anchors, importance, cnt, P, nullptr, nullptr, partial);
+        if (dtype == SEC_BF16) launch_heads_loss<__hip_bfloat16, false>(bins, grid, st, heads, HW, head_channels, labels, reg_targets, anchors, importance, cnt, P, nullptr, nullptr, partial, terms);
+        else launch_heads_loss<__half, false>(bins, grid, st, heads, HW, head_channels, labels, reg_targets, anchors, importance, cnt, P, nullptr, nullptr, partial, terms);
         hipLaunchKernelGGL(k_loss_final, dim3(1), dim3(kBlock), 0, st, partial, batch * nb, P, out6);
     } else {
         if (dtype == SEC_BF16) launch_heads_loss<__hip_bfloat16, true>(bins, grid, st, heads, HW, head_channels, labels, reg_targets, anchors, importance, cnt, P, grad_loss, d_heads, partial);
@@ -813,6 +820,14 @@ SEC_API int sec_heads_loss_fwd(const void *heads, int dtype, int batch, int h, i
                                const float *h_params17, float *out6, void *workspace, size_t workspace_bytes, void *stream) {
     return heads_loss_impl(false, heads, dtype, batch, h, w, head_channels, anchors_per_loc, num_class, num_dir_bins, labels, reg_targets, anchors,
                            importance, h_params17, nullptr, nullptr, nullptr, out6, workspace, workspace_bytes, false, stream);
+}
+SEC_API int sec_heads_loss_fwd_terms(const void *heads, int dtype, int batch, int h, int w, int head_channels, int anchors_per_loc, int num_class,
+                                     int num_dir_bins, const int *labels, const float *reg_targets, const float *anchors, const float *importance,
+                                     const float *h_params17, float *out6, float *cls_preds_out, float *cls_loss_out, float *loc_loss_out,
+                                     void *workspace, size_t workspace_bytes, void *stream) {
+    float *const terms[3] = {cls_preds_out, cls_loss_out, loc_loss_out};
+    return heads_loss_impl(false, heads, dtype, batch, h, w, head_channels, anchors_per_loc, num_class, num_dir_bins, labels, reg_targets, anchors,
+                           importance, h_params17, nullptr, nullptr, nullptr, out6, workspace, workspace_bytes, false, stream, terms);
 }
 SEC_API int sec_heads_loss_bwd(const void *heads, int dtype, int batch, int h, int w, int head_channels, int anchors_per_loc, int num_class,
                                int num_dir_bins, const int *labels, const float *reg_targets, const float *anchors, const float *importance,

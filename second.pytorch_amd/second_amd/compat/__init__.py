@@ -290,13 +290,17 @@ def accelerate_nms():
     return bto
 
 
-def accelerate_model(net, dtype=None, graph=True, static=None, strict=True):
+def accelerate_model(net, dtype=None, graph=True, static=None, strict=True, train_dtype=None):
     """Serve a reference-built ``VoxelNet``'s ``net(example)`` in eval mode (voxelnet.py:339-375, called by train.py:524) from the
     fused static-capacity, graph-captured pipeline: parameters adopted by state-dict key, same return value
     (voxelnet.py:616-643), fp32 by default and 16-bit after ``net.half()``.  See :mod:`second_amd.dropin`.  Call after the
-    network is built (any time before the first eval batch; later ``load_state_dict`` / ``.half()`` / ``.to()`` are followed)."""
+    network is built (any time before the first eval batch; later ``load_state_dict`` / ``.half()`` / ``.to()`` are followed).
+    ``train_dtype=torch.bfloat16`` (or float16; SEC_ACCELERATE_TRAIN=bf16 in the environment): TRAINING-mode calls
+    (train.py:306-325) are served too -- the loss dict of voxelnet.py:299-312 from one hipGraph replay, ``loss.backward()`` from a
+    second one that leaves the gradients on the network's own parameters, 16-bit features over the fp32 weights
+    (:mod:`second_amd.dropin_train`)."""
     from ..dropin import accelerate_model as _acc
-    return _acc(net, dtype=dtype, graph=graph, static=static, strict=strict)
+    return _acc(net, dtype=dtype, graph=graph, static=static, strict=strict, train_dtype=train_dtype)
 
 
 def rotate_iou_gpu_eval(boxes, query_boxes, criterion=-1, device_id=0):

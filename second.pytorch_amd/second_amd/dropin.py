@@ -180,15 +180,18 @@ class FusedVoxelNet:
     """See the module docstring.  ``graph=False``: the same static-capacity launches issued one by one (debugging, profiling);
     ``static=False``: dynamic shapes, eager (what a CPU network under the tests' oracle backend gets)."""
 
-    def __init__(self, net, dtype=None, graph=True, static=None, margin=1.25, row_bucket=16384):
+    def __init__(self, net, dtype=None, graph=True, static=None, margin=1.25, row_bucket=16384, train_dtype=None):
         self.net, self.cfg = net, model_config(net)
         self.forced_dtype, self.graph, self.static = dtype, bool(graph), static
+        # training-mode calls (second_amd.dropin_train): opt-in, because the captured step computes with 16-bit features where the
+        # reference's default training arithmetic is fp32 (its own enable_mixed_precision mode makes the same trade)
+        self.train_dtype, self.trainer = train_dtype, None
         self.margin, self.row_bucket = float(margin), int(row_bucket)
         self._det = self._wkey = self._watch = None
         self._sessions = {}
         self._akey = None
         self.stats = {"fused_calls": 0, "original_calls": 0, "adoptions": 0, "captures": 0, "overflow_recaptures": 0,
-                      "anchor_refreshes": 0}
+                      "anchor_refreshes": 0, "train_fallback_reason": None}
 
     # ------------------------------------------------------------------ adoption
     def _tensors(self):
@@ -255,13 +258,36 @@ class FusedVoxelNet:
     # ------------------------------------------------------------------ dispatch
     def accepts(self, example):
         if self.net.training:
-            return False
+            return self._accepts_training(example)
         for k in ("voxels", "num_points", "coordinates", "anchors"):
             if not isinstance(example.get(k), torch.Tensor):
                 return False
         return example["num_points"].dim() == 1 and "anchors_mask" not in example and example["voxels"].shape[0] > 0
 
+    def _accepts_training(self, example):
+        if self.train_dtype is None or self.trainer is False:
+            return False
+        if self.trainer is None:
+            from . import dropin_train as T
+            try:
+                self.trainer = T.FusedTrainStep(self.net, self.cfg, self.train_dtype)
+                self.stats.update(self.trainer.stats)
+                self.trainer.stats = self.stats
+            except T.NotTrainable as e:
+                self.trainer = False
+                self.stats["train_fallback_reason"] = str(e)
+                return False
+        return self.trainer.accepts(example)
+
     def __call__(self, example):
+        if self.net.training:
+            from . import dropin_train as T
+            try:
+                return self.trainer(example)
+            except T.NotTrainable as e:            # found out at adoption / capture time: keep the original forward from now on
+                self.trainer = False
+                self.stats["train_fallback_reason"] = str(e)
+                return None
         det = self.refresh()
         voxels = example["voxels"]
         static = voxels.is_cuda if self.static is None else self.static
@@ -389,14 +415,17 @@ class FusedVoxelNet:
         return res
 
 
-def accelerate_model(net, dtype=None, graph=True, static=None, strict=True):
-    """Serve ``net(example)`` (eval mode) from the fused pipeline; see the module docstring.  Returns ``net`` (its ``forward`` is
+def accelerate_model(net, dtype=None, graph=True, static=None, strict=True, train_dtype=None):
+    """Serve ``net(example)`` (eval mode) from the fused pipeline; see the module docstring.  ``train_dtype`` (torch.bfloat16 /
+    torch.float16, or SEC_ACCELERATE_TRAIN=bf16|fp16 in the environment): training-mode calls are served too -- loss dict out of one
+    graph replay, ``loss.backward()`` a second one that leaves the gradients on the network's own parameters (dropin_train).  Returns ``net`` (its ``forward`` is
     shadowed on the instance; ``net._second_amd_engine`` is the :class:`FusedVoxelNet`, ``net._second_amd_original_forward`` the
     reference's method).  ``strict=False``: a network outside the fused path is returned unchanged instead of raising."""
     if getattr(net, "_second_amd_engine", None) is not None:
         return net
+    train_dtype = train_dtype if train_dtype is not None else _env_train_dtype()
     try:
-        eng = FusedVoxelNet(net, dtype=dtype, graph=graph, static=static)
+        eng = FusedVoxelNet(net, dtype=dtype, graph=graph, static=static, train_dtype=train_dtype)
     except NotAccelerable:
         if strict:
             raise
@@ -415,6 +444,12 @@ def accelerate_model(net, dtype=None, graph=True, static=None, strict=True):
     return net
 
 
+def _env_train_dtype():
+    import os
+    v = os.environ.get("SEC_ACCELERATE_TRAIN", "").lower()
+    return {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp16": torch.float16, "float16": torch.float16, "half": torch.float16}.get(v)
+
+
 def accelerate_class(cls):
     """Class-level form of :func:`accelerate_model`: every instance of ``cls`` (the reference's ``VoxelNet``) builds its engine
     lazily at its first eval-mode call; instances outside the fused path keep the original forward.  Idempotent."""
@@ -424,9 +459,9 @@ def accelerate_class(cls):
 
     def forward(self, example):
         eng = self.__dict__.get("_second_amd_engine")
-        if eng is None and not self.training:
+        if eng is None and (not self.training or _env_train_dtype() is not None):
             try:
-                eng = FusedVoxelNet(self)
+                eng = FusedVoxelNet(self, train_dtype=_env_train_dtype())
             except NotAccelerable:
                 eng = False
             self.__dict__["_second_amd_engine"] = eng

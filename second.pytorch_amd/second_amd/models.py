@@ -391,7 +391,7 @@ class RPNV2(nn.Module):
 RPN_TRAIN_BACKEND = "hip"
 
 
-def rpn_forward_mixed(rpn, x, dtype, loss_args=None):
+def rpn_forward_mixed(rpn, x, dtype, loss_args=None, loss_terms=False):
     """Training forward of an RPNV2 with 16-bit activations over its fp32 master weights (the DeviceTrainer's amp path).  Every
     Conv2d(128, 128, 3, stride 1) + BatchNorm2d + ReLU triple of the blocks runs on the hand-written kernels -- forward and data
     gradient on k_conv2d_halo_reg, weight gradient on k_conv2d_wgrad3x3, BatchNorm (batch statistics) + ReLU fused
@@ -402,7 +402,8 @@ def rpn_forward_mixed(rpn, x, dtype, loss_args=None):
     would be stale on replay.)
     ``loss_args`` = (labels, reg_targets, anchors, importance, loss_cfg): when the heads run as one stacked convolution and the loss
     kernel has that head shape, the loss is taken from the stacked tensor (ops.HeadsLossFunction) and {"loss", "out6"} comes back
-    instead of the three prediction tensors."""
+    instead of the three prediction tensors; ``loss_terms``: plus "cls_preds" / "cls_loss" / "loc_loss", the per-anchor fp32 tensors of the
+    reference's loss dict (voxelnet.py:299-309), from the same launch."""
     use_hip = RPN_TRAIN_BACKEND == "hip" and x.is_cuda
     x = x.to(dtype).contiguous(memory_format=torch.channels_last)
 
@@ -478,9 +479,12 @@ def rpn_forward_mixed(rpn, x, dtype, loss_args=None):
                 and ops.heads_loss_supported(64, a, rpn._num_class, bins, dtype)):
             # the loss straight from the stacked head tensor, its gradient straight back into it (ops.HeadsLossFunction)
             labels, reg_targets, anchors, importance, loss_cfg = loss_args
-            loss, out6 = ops.HeadsLossFunction.apply(ups[0].contiguous(memory_format=torch.channels_last), wcat, bcat, labels, reg_targets,
-                                                     anchors, importance, a, rpn._num_class, bins, loss_cfg)
-            return {"loss": loss, "out6": out6}
+            res = ops.HeadsLossFunction.apply(ups[0].contiguous(memory_format=torch.channels_last), wcat, bcat, labels, reg_targets,
+                                              anchors, importance, a, rpn._num_class, bins, loss_cfg, bool(loss_terms))
+            out = {"loss": res[0], "out6": res[1]}
+            if loss_terms:
+                out.update(cls_preds=res[2], cls_loss=res[3], loc_loss=res[4])
+            return out
         y = ops.Heads1x1Function.apply(ups[0].contiguous(memory_format=torch.channels_last), wcat, bcat)
         ret, c0 = {}, 0
         h, w = y.shape[2:]

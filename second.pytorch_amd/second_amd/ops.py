@@ -1502,7 +1502,9 @@ class HeadsLossFunction(torch.autograd.Function):
     3.5 ms car.fhd step).  Same values as Heads1x1Function + SecondLossFunction up to the order of the loss sums."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, labels, reg_targets, anchors, importance, anchors_per_loc, num_class, num_dir_bins, cfg):
+    def forward(ctx, x, weight, bias, labels, reg_targets, anchors, importance, anchors_per_loc, num_class, num_dir_bins, cfg, want_terms=False):
+        """``want_terms``: also return (cls_preds [B, N, C] fp32, cls_loss [B, N, C], loc_loss [B, N, 7]) -- the per-anchor tensors of the
+        reference's loss dict (voxelnet.py:299-309), written by the same launch (sec_heads_loss_fwd_terms); not differentiable."""
         rt.require_gpu(x, labels, reg_targets, anchors, importance)
         pk_f, pk_d = conv2d_pack_weight_train(weight.detach().contiguous(), x.dtype)
         y = conv2d_nhwc(x, pk_f, bias.detach().float().contiguous(), weight.shape[0], 1, 1, 0, relu=False)
@@ -1515,16 +1517,25 @@ class HeadsLossFunction(torch.autograd.Function):
         out6 = torch.empty((6,), dtype=torch.float32, device=x.device)
         l = rt.lib()
         ws = rt.workspace(l.sec_heads_loss_workspace_bytes(b, h, w, a), x.device)
-        rt.check(l.sec_heads_loss_fwd(rt.ptr(y), rt.dtype_code(y.dtype), b, h, w, hc, a, nc, bins, rt.ptr(labels), rt.ptr(reg_targets),
-                                      rt.ptr(anchors), rt.ptr(importance), params, rt.ptr(out6), rt.ptr(ws), ws.numel(), rt.stream()),
-                 "sec_heads_loss_fwd")
+        terms = ()
+        if want_terms:
+            n = a * h * w
+            terms = (torch.empty((b, n, nc), dtype=torch.float32, device=x.device), torch.empty((b, n, nc), dtype=torch.float32, device=x.device),
+                     torch.empty((b, n, 7), dtype=torch.float32, device=x.device))
+            rt.check(l.sec_heads_loss_fwd_terms(rt.ptr(y), rt.dtype_code(y.dtype), b, h, w, hc, a, nc, bins, rt.ptr(labels), rt.ptr(reg_targets),
+                                                rt.ptr(anchors), rt.ptr(importance), params, rt.ptr(out6), rt.ptr(terms[0]), rt.ptr(terms[1]),
+                                                rt.ptr(terms[2]), rt.ptr(ws), ws.numel(), rt.stream()), "sec_heads_loss_fwd_terms")
+        else:
+            rt.check(l.sec_heads_loss_fwd(rt.ptr(y), rt.dtype_code(y.dtype), b, h, w, hc, a, nc, bins, rt.ptr(labels), rt.ptr(reg_targets),
+                                          rt.ptr(anchors), rt.ptr(importance), params, rt.ptr(out6), rt.ptr(ws), ws.numel(), rt.stream()),
+                     "sec_heads_loss_fwd")
         ctx.save_for_backward(x, pk_d, y, labels, reg_targets, anchors, importance, ws)     # ws: the frames' positive counts stay in it
         ctx.meta = (a, nc, bins, params, tuple(weight.shape), weight.dtype, bias.dtype)
-        ctx.mark_non_differentiable(out6)
-        return out6[0], out6
+        ctx.mark_non_differentiable(out6, *terms)
+        return (out6[0], out6) + terms
 
     @staticmethod
-    def backward(ctx, g_loss, _g_all):
+    def backward(ctx, g_loss, _g_all, *_g_terms):
         x, pk_d, y, labels, reg_targets, anchors, importance, ws = ctx.saved_tensors
         a, nc, bins, params, wshape, wdtype, bdtype = ctx.meta
         b, hc, h, w = y.shape
@@ -1540,7 +1551,7 @@ class HeadsLossFunction(torch.autograd.Function):
             dx = conv2d_nhwc(dy, pk_d, None, wshape[1], 1, 1, 0, relu=False)
         if ctx.needs_input_grad[1]:
             dw = conv2d_wgrad(x, dy, 1).to(wdtype)
-        return dx, dw, (db.to(bdtype) if ctx.needs_input_grad[2] else None), None, None, None, None, None, None, None, None
+        return dx, dw, (db.to(bdtype) if ctx.needs_input_grad[2] else None), None, None, None, None, None, None, None, None, None
 
 
 class BatchNormReluFunction(torch.autograd.Function):

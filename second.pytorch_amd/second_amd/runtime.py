@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libsecond_hip.so")
 LIB_PATH = os.environ.get("SEC_HIP_LIB", LIB_PATH)   # A/B builds: point at another libsecond_hip.so
 
 SEC_F32, SEC_F16, SEC_BF16 = 0, 1, 2
-ABI_VERSION = 6          # include/second_hip.h SEC_ABI_VERSION the argtypes in lib() were written for
+ABI_VERSION = 7          # include/second_hip.h SEC_ABI_VERSION the argtypes in lib() were written for
 _DTYPES = {torch.float32: SEC_F32, torch.float16: SEC_F16, torch.bfloat16: SEC_BF16}
 _ERRORS = {-1: "SEC_E_INVALID (bad argument)", -2: "SEC_E_WORKSPACE (workspace too small)",
            -3: "SEC_E_UNSUPPORTED", -4: "SEC_E_LAUNCH (HIP error)"}
@@ -32,7 +32,7 @@ SYMBOLS = [
     "sec_predict_select", "sec_predict_decode", "sec_predict_finalize",
     "sec_assign_targets_workspace_bytes", "sec_assign_targets_f32", "sec_assign_targets_per_class_f32",
     "sec_second_loss_workspace_bytes", "sec_second_loss_f32", "sec_heads_loss_supported", "sec_heads_loss_workspace_bytes",
-    "sec_heads_loss_fwd", "sec_heads_loss_bwd",
+    "sec_heads_loss_fwd", "sec_heads_loss_fwd_terms", "sec_heads_loss_bwd",
     "sec_conv2d_pack_weight_train", "sec_conv2d_pack_weight_train_multi", "sec_pack_conv_weight_train_multi", "sec_conv2d_wgrad_workspace_bytes", "sec_conv2d_wgrad_nhwc", "sec_bn_train_workspace_bytes", "sec_bn_relu_fwd_nhwc",
     "sec_bn_relu_bwd_nhwc", "sec_flat_adamw_workspace_bytes", "sec_flat_adamw_f32", "sec_flat_adamw_dev_f32",
 ]
@@ -180,6 +180,7 @@ def lib():
         l.sec_heads_loss_supported.argtypes = [ci] * 5
         l.sec_heads_loss_workspace_bytes.argtypes = [ci] * 4
         l.sec_heads_loss_fwd.argtypes = [vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, sz, vp]
+        l.sec_heads_loss_fwd_terms.argtypes = [vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
         l.sec_heads_loss_bwd.argtypes = [vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, ci, vp]
         ll = ctypes.c_longlong
         l.sec_conv2d_pack_weight_train.argtypes = [vp, ci, ci, ci, ci, vp, vp, vp]

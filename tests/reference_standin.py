@@ -238,3 +238,16 @@ def example_of(net, clouds, device, dtype=torch.float32, max_voxels=None, metada
     if metadata:
         ex["metadata"] = [{"image_idx": 100 + b} for b in range(len(clouds))]
     return ex
+
+
+def train_example_of(net, clouds, boxes, device, dtype=torch.float32, matched=0.6, unmatched=0.45):
+    """``example_of`` plus the training entries of the collated batch (preprocess.py:22-55 after target assignment in
+    prep_pointcloud, :327-356): ``labels`` int32 [B, A], ``reg_targets`` [B, A, 7], ``importance`` [B, A] -- assigned by the device
+    kernel that tests/test_gpu_train.py pins to the reference's create_target_np."""
+    from second_amd import ops
+    ex = example_of(net, clouds, device, dtype=dtype)
+    gt = torch.from_numpy(np.concatenate(boxes).astype(np.float32)).to(device)
+    goffs = torch.from_numpy(np.cumsum([0] + [len(b) for b in boxes]).astype(np.int32)).to(device)
+    labels, reg, imp = ops.assign_targets(net.anchors.to(device), gt, goffs, matched, unmatched)
+    ex.update(labels=labels, reg_targets=reg.to(dtype), importance=imp.to(dtype))
+    return ex

@@ -401,6 +401,41 @@ def test_gpu_box_standin_is_shaped_like_the_reference_network(ref, rel, name):
         assert hasattr(real, attr) and hasattr(fake, attr), attr
 
 
+def test_standin_training_forward_is_the_reference_loss(ref):
+    """What the -m gpu training tests and bench.py's dropin_train leg compare against: reference_standin.standin_loss must be
+    VoxelNet.loss (voxelnet.py:239-312) of the REAL network, and dropin_train.train_config must read the same loss settings from
+    both objects."""
+    import oracle_backend
+    import reference_standin
+    from second_amd import dropin_train, models
+    train, cfg = ref
+    with oracle_backend.installed():
+        real = train.build_network(cfg.model.second).train()
+        fake = reference_standin.build_voxelnet(dict(models.CAR_FHD)).train()
+    c_real, c_fake = dropin_train.train_config(real), dropin_train.train_config(fake)
+    assert set(c_real) == set(c_fake)
+    for k in c_real:
+        np.testing.assert_allclose(np.asarray(c_fake[k], np.float64), np.asarray(c_real[k], np.float64), rtol=1e-6, err_msg=k)
+    g = torch.Generator().manual_seed(7)
+    b, a, h, w = 2, 2, 20, 16
+    n = a * h * w
+    preds = {"box_preds": (torch.randn(b, a, h, w, 7, generator=g) * 0.3), "cls_preds": torch.randn(b, a, h, w, 1, generator=g) * 2 - 2,
+             "dir_cls_preds": torch.randn(b, a, h, w, 2, generator=g)}
+    labels = (torch.rand(b, n, generator=g) < 0.02).int() - (torch.rand(b, n, generator=g) < 0.1).int()      # 1 / 0 / -1, a few overlaps -> 0
+    ex = {"labels": labels, "reg_targets": torch.randn(b, n, 7, generator=g) * 0.4, "importance": torch.rand(b, n, generator=g) + 0.5,
+          "anchors": torch.randn(b, n, 7, generator=g)}
+    pr = {k: v.clone().requires_grad_() for k, v in preds.items()}
+    pf = {k: v.clone().requires_grad_() for k, v in preds.items()}
+    r = real.loss(ex, pr)
+    f = reference_standin.standin_loss(fake, ex, pf)
+    assert set(r) == set(f)
+    for k in r:
+        np.testing.assert_allclose(f[k].detach().float().numpy(), r[k].detach().float().numpy(), rtol=1e-5, atol=1e-7, err_msg=k)
+    r["loss"].backward(), f["loss"].backward()
+    for k in pr:
+        np.testing.assert_allclose(pf[k].grad.numpy(), pr[k].grad.numpy(), rtol=1e-4, atol=1e-8, err_msg=k)
+
+
 def test_zero_call_acceleration_through_the_import_hook(tmp_path):
     """SEC_ACCELERATE_MODEL=1 + `import spconv`: the reference's VoxelNet class is wrapped when its module is imported; a network
     built by the unmodified build_network serves net(example) from the fused engine without any call into this package."""
