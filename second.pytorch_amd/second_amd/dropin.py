@@ -20,7 +20,8 @@ strided layer, three modules per layer, the dense [B, 128, 200, 176] image and p
     ``{box3d_lidar [k, 7] float32, scores [k] float32, label_preds [k] int64, metadata}`` on the input's device);
   * precision follows the caller: fp32 networks run the fp32 pipeline, ``net.half()`` (train.py:470) the fp16 one;
     ``dtype=torch.bfloat16`` may be forced;
-  * training mode, DataParallel-padded examples (``num_points`` 2-D, voxelnet.py:346), ``anchors_mask`` and per-frame anchor
+  * training mode: opt-in (``train_dtype``), served by :mod:`second_amd.dropin_train`; otherwise the original forward;
+  * DataParallel-padded examples (``num_points`` 2-D, voxelnet.py:346), ``anchors_mask`` and per-frame anchor
     sets keep the original forward.
 
 There is no CPU fallback inside the fused path: static capacities and graphs need the HIP library; a CPU network is served
@@ -137,8 +138,11 @@ class _Session:
         packed = torch.cat([out["boxes"].reshape(b, -1).float(), out["scores"].float(), out["labels"].float(),
                             out["valid"].float()], 1)
         counters = torch.stack([num[1] for num, _ in checks]).int() if checks else torch.zeros((1,), dtype=torch.int32, device=packed.device)
+        # content check of the network's tensors (FusedVoxelNet._checksum): their norms now against the norms at adoption, inside the
+        # graph -- in-place updates that bump no version counter (`p.data.copy_()`, `p.data.mul_()`) show up here
+        stale = self.eng.weights_changed_flag()
         return {"packed": packed, "labels": out["labels"].long(), "counters": counters, "limits": [int(c) for _, c in checks],
-                "post": int(out["scores"].shape[1])}
+                "post": int(out["scores"].shape[1]), "stale": stale}
 
     def build(self, graph):
         prev = ops.set_rulebook_numbering("sorted")
@@ -161,8 +165,9 @@ class _Session:
         finally:
             ops.set_rulebook_numbering(prev)
         self.host_packed = torch.empty(self.outs["packed"].shape, dtype=torch.float32, pin_memory=True)
-        self.host_counters = torch.empty((self.outs["counters"].numel() + 1,), dtype=torch.int32, pin_memory=True)
-        self.dev_counters = torch.zeros((self.outs["counters"].numel() + 1,), dtype=torch.int32, device=self.anchors.device)
+        # [overflow counters..., anchors differ, weights changed]
+        self.host_counters = torch.empty((self.outs["counters"].numel() + 2,), dtype=torch.int32, pin_memory=True)
+        self.dev_counters = torch.zeros((self.outs["counters"].numel() + 2,), dtype=torch.int32, device=self.anchors.device)
 
     def launch(self):
         if self.graph is not None:
@@ -189,8 +194,7 @@ class FusedVoxelNet:
         self.margin, self.row_bucket = float(margin), int(row_bucket)
         self._det = self._wkey = self._watch = None
         self._sessions = {}
-        self._akey = None
-        self.stats = {"fused_calls": 0, "original_calls": 0, "adoptions": 0, "captures": 0, "overflow_recaptures": 0,
+        self.stats = {"content_readoptions": 0, "fused_calls": 0, "original_calls": 0, "adoptions": 0, "captures": 0, "overflow_recaptures": 0,
                       "anchor_refreshes": 0, "train_fallback_reason": None}
 
     # ------------------------------------------------------------------ adoption
@@ -202,13 +206,27 @@ class FusedVoxelNet:
         return out
 
     def _weights_key(self):
-        """Cheap per-call fingerprint of the three sub-modules' parameters and buffers: every tensor's version counter (in-place
-        updates: load_state_dict, optimizer steps) plus storage / dtype / device of a few sentinels (`.half()`, `.to()` replace
-        them all at once)."""
+        """Host-side fingerprint of the three sub-modules' parameters and buffers, per call: every tensor's version counter
+        (in-place updates through the tensor: load_state_dict, torch optimizers) and storage address / dtype (`.half()`, `.to()`,
+        `p.data = other`).  Updates through ``.data``
+        (`p.data.copy_()`, `p.data.mul_()`: the reference's torchplus optimizers, EMA swap-ins) bump no counter -- those are caught
+        by the CONTENT check that rides with every call (:meth:`weights_changed_flag`)."""
         w = self._watch
-        heads = self.net.rpn.conv_cls.weight
-        sent = (w[0], w[len(w) // 2], w[-1], heads)
-        return (sum(t._version for t in w), len(w), tuple((t.data_ptr(), t.dtype, t.device) for t in sent))
+        return (sum(t._version for t in w), len(w), tuple(t.data_ptr() for t in w), w[0].dtype, self.net.rpn.conv_cls.weight.dtype,
+                w[0].device)
+
+    def _checksum(self):
+        """L2 norm of every floating-point tensor of the three sub-modules as one fp32 device vector (a multi-tensor launch per dtype)."""
+        groups = {}
+        for t in self._watch:
+            if t.is_floating_point() and t.numel():
+                groups.setdefault(t.dtype, []).append(t.detach())
+        parts = [torch.stack(torch._foreach_norm(ts)).float() for ts in groups.values()]
+        return torch.cat(parts) if len(parts) != 1 else parts[0]
+
+    def weights_changed_flag(self):
+        """int32[1] on the device: 1 when any tensor's norm differs (bit pattern: NaN-safe) from its norm at adoption."""
+        return (self._checksum().view(torch.int32) != self._ref_sum.view(torch.int32)).any().int().reshape(1)
 
     def run_dtype(self):
         """None = fp32 pipeline; torch.float16 / torch.bfloat16 = 16-bit features (BatchNorm statistics, biases, box decode and
@@ -218,12 +236,12 @@ class FusedVoxelNet:
         wd = self.net.rpn.conv_cls.weight.dtype
         return None if wd == torch.float32 else wd
 
-    def refresh(self):
-        """(Re-)adopt the network's parameters when any of them changed since the last call."""
+    def refresh(self, force=False):
+        """(Re-)adopt the network's parameters when any of them changed since the last call (``force``: unconditionally)."""
         if self._watch is None:
             self._watch = self._tensors()
         key = self._weights_key()
-        if self._det is not None and key == self._wkey:
+        if self._det is not None and key == self._wkey and not force:
             return self._det
         self._watch = self._tensors()          # (parameters may have been replaced as objects: re-enumerate, then fingerprint again)
         key = self._weights_key()
@@ -251,6 +269,7 @@ class FusedVoxelNet:
             det.prepare_inference(dt if dt is not None else torch.float32)
         det.eval()
         self._det, self._wkey = det, key
+        self._ref_sum = self._checksum().clone()
         self._sessions.clear()
         self.stats["adoptions"] += 1
         return det
@@ -300,6 +319,8 @@ class FusedVoxelNet:
         return list(meta) if meta is not None and len(meta) else [None] * batch
 
     def _dynamic(self, det, example):
+        if bool(self.weights_changed_flag().item()):     # (this mode syncs per layer anyway)
+            det = self.refresh(force=True)
         batch = example["anchors"].shape[0]
         anchors = example["anchors"].reshape(batch, -1, 7).float()
         with torch.no_grad():
@@ -318,12 +339,12 @@ class FusedVoxelNet:
     def _session(self, det, example, batch):
         voxels = example["voxels"]
         n = voxels.shape[0]
-        key = (batch, tuple(voxels.shape[1:]), voxels.dtype, voxels.device)
+        anchors0 = example["anchors"].reshape(batch, -1, 7)[0]
+        key = (batch, tuple(voxels.shape[1:]), voxels.dtype, voxels.device, int(anchors0.shape[0]))
         sess = self._sessions.get(key)
         if sess is not None and sess.cap >= n:
             return sess
         cap = -(-int(n * (1.0 if sess is None else self.margin)) // self.row_bucket) * self.row_bucket
-        anchors0 = example["anchors"].reshape(batch, -1, 7)[0]
         new = _Session(self, batch, cap, voxels.shape[1:], voxels.dtype, anchors0)
         new.caps = self._calibrate(det, example, batch)
         self._fill(new, example)
@@ -365,13 +386,13 @@ class FusedVoxelNet:
         for attempt in range(4):
             sess = self._session(det, example, batch)
             self._fill(sess, example)
-            akey = (anchors.data_ptr(), anchors._version, tuple(anchors.shape), id(sess))
-            check_anchors = akey != self._akey
             nc = sess.outs["counters"].numel()
-            if check_anchors:      # anchors of a new tensor: compared on the device, the flag travels with the results
-                sess.dev_counters[nc:].copy_((anchors != sess.anchors.unsqueeze(0)).any().int().reshape(1))
+            # the example's anchors against the session's, on the device, EVERY call (a freed-and-reallocated tensor can reuse an
+            # address and a version counter: identity proves nothing); the flag travels with the results
+            sess.dev_counters[nc:nc + 1].copy_((anchors != sess.anchors.unsqueeze(0)).any().int().reshape(1))
             sess.launch()
             sess.dev_counters[:nc].copy_(sess.outs["counters"].reshape(-1))
+            sess.dev_counters[nc + 1:].copy_(sess.outs["stale"])
             sess.host_packed.copy_(sess.outs["packed"], non_blocking=True)
             sess.host_counters.copy_(sess.dev_counters, non_blocking=True)
             packed = sess.outs["packed"].clone()          # the session's buffers are overwritten by the next call
@@ -379,7 +400,11 @@ class FusedVoxelNet:
             sess.event.record()
             sess.event.synchronize()
             cnt = sess.host_counters.numpy()
-            if check_anchors and cnt[nc]:
+            if cnt[nc + 1]:                               # the network's tensors changed under the adopted copy: adopt again, redo
+                det = self.refresh(force=True)
+                self.stats["content_readoptions"] += 1
+                continue
+            if cnt[nc]:
                 same = bool((anchors == anchors[:1]).all().item())
                 if not same:                              # per-frame anchor sets: the reference's own path handles them
                     return None
@@ -393,7 +418,6 @@ class FusedVoxelNet:
                 sess.build(self.graph)
                 self.stats["overflow_recaptures"] += 1
                 continue
-            self._akey = akey
             break
         else:
             raise RuntimeError("accelerate_model: static capacities did not settle after four attempts")

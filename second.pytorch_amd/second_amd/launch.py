@@ -17,7 +17,10 @@ GPU and this module patches five seams around it -- no file of the reference is 
   2. same start         ``torchplus.train.try_restore_latest_checkpoints`` is followed by a broadcast of rank 0's
                         parameters and buffers (so a resumed run and a fresh one both start identical on all ranks);
   3. gradient exchange  ``torch.nn.utils.clip_grad_norm_`` (train.py:323: the first thing after ``backward()``) first averages
-                        the gradients of all ranks with ONE RCCL all-reduce of a flat bucket (distributed.GradBucket);
+                        the gradients of all ranks with ONE RCCL all-reduce of a flat bucket (distributed.GradBucket); with
+                        SEC_ACCELERATE_TRAIN=bf16 the network ``build_network`` returns is also passed through
+                        ``compat.accelerate_model`` -- forward and backward of every step are two hipGraph replays
+                        (second_amd/dropin_train.py) whose gradients are born in that bucket;
   4. data sharding      ``torch.utils.data.DataLoader`` with ``shuffle=True`` (the training loader, train.py:262-270) gets an
                         epoch-advancing DistributedSampler; loaders with workers use the ``spawn`` start method, because the
                         workers call ``spconv.utils.VoxelGeneratorV2.generate`` (second/data/preprocess.py:301-316), which
@@ -83,6 +86,14 @@ def patch_reference(train_module, rank, world, device=None, backend=None):
     def build_network(*a, **k):
         net = saved["build_network"](*a, **k)
         state["net"] = net
+        # SEC_ACCELERATE_TRAIN=bf16|fp16: training-mode net(example) (train.py:306) from the captured device step -- and the
+        # periodic evaluation inside train() from the inference graph.  The gradient seam below finds the gradients already packed
+        # in the engine's bucket (dropin_train registers it as net._sec_grad_bucket).
+        from .dropin import _env_train_dtype
+        if _env_train_dtype() is not None:
+            from . import compat
+            compat.accelerate_model(net, strict=False)
+            state["train_accelerated"] = getattr(net, "_second_amd_engine", None) is not None
         return net
 
     def restore(model_dir, objs, *a, **k):

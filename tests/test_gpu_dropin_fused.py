@@ -253,3 +253,53 @@ def test_anchor_sets_are_checked_on_the_device_and_followed(car):
         want = net._second_amd_original_forward(ex_d)
     assert eng.stats["original_calls"] == 1
     _same(got, want)
+
+
+def test_weight_updates_through_dot_data_are_seen(car):
+    """The reference's own optimizers write weights through ``.data`` (torchplus/train/fastai_optim.py: ``p.data.mul_(1 - wd * lr)``,
+    ``model.data.copy_(master)``; optim.py: ``p.data.copy_``) -- no version counter moves, BatchNorm running statistics of a frozen
+    network do not move either.  Every call carries a content check of the adopted tensors (norms compared inside the graph): a
+    changed head bias must change the detections of the NEXT call, not keep serving the packed copy."""
+    from reference_standin import example_of
+    from second_amd import compat
+    make, clouds, small = car
+    net = compat.accelerate_model(make())
+    eng = net._second_amd_engine
+    ex = example_of(net, clouds[:2], "cuda")
+    with torch.no_grad():
+        first = net(ex)
+        v0 = [t._version for t in eng._watch]
+        net.rpn.conv_cls.bias.data.add_(0.6)                              # what `p.data.copy_(master)` amounts to
+        net.middle_feature_extractor.middle_conv[0].weight.data.mul_(1.0 - 1e-3)
+        assert [t._version for t in eng._watch] == v0                     # nothing for a version-based key to see
+        got = net(ex)
+        want = net._second_amd_original_forward(ex)
+    assert eng.stats["content_readoptions"] == 1 and eng.stats["adoptions"] == 2
+    assert sum(g["scores"].shape[0] for g in got) > sum(g["scores"].shape[0] for g in first)
+    _same(got, want)
+    with torch.no_grad():
+        net(ex)
+    assert eng.stats["adoptions"] == 2                                    # unchanged weights: no further adoption
+    eng.refresh(force=True)
+    assert eng.stats["adoptions"] == 3
+
+
+def test_anchors_edited_in_place_or_resized_are_followed(car):
+    """Same tensor object, same address, new content (and then another anchor COUNT): the comparison runs on the device every call."""
+    from reference_standin import example_of
+    from second_amd import compat
+    make, clouds, small = car
+    net = compat.accelerate_model(make())
+    eng = net._second_amd_engine
+    ex = example_of(net, clouds[:2], "cuda")
+    with torch.no_grad():
+        first = net(ex)
+        ex["anchors"].data[..., 0] += 0.5                                 # in place, through .data: same data_ptr, same _version
+        got = net(ex)
+        want = net._second_amd_original_forward(ex)
+    assert eng.stats["anchor_refreshes"] == 1 and eng.stats["original_calls"] == 0
+    _same(got, want)
+    assert abs(float(got[0]["box3d_lidar"][0, 0] - first[0]["box3d_lidar"][0, 0]) - 0.5) < 1e-3
+    fewer = dict(ex, anchors=ex["anchors"][:, :-2].contiguous())          # an anchor table of another length never reaches the fused graph
+    with torch.no_grad(), pytest.raises(Exception):
+        net._second_amd_original_forward(fewer)                           # (the reference asserts num_anchors == num_output, voxelnet.py:367)
