@@ -394,7 +394,7 @@ def train_bench(args, rank, local_rank, world, device):
     pts, offs, gt, goffs = (torch.from_numpy(a).to(device) for a in (pts, offs, gt, goffs))
     torch.manual_seed(0)
     det = SecondDetector(cfg).to(device)
-    amp = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": None}[args.dtype]
+    amp = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": None, "fp32_exact": None}[args.dtype]
     tr = DeviceTrainer(det, amp_dtype=amp)
 
     def barrier():
@@ -425,7 +425,7 @@ def train_bench(args, rank, local_rank, world, device):
         res = {"metric": WL["metric"], "value": round(bs * args.steps * world / elapsed, 2), "unit": "samples/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "timing": timing,
-               "dtype": "fp32" if amp is None else f"{args.dtype} features (sparse stack + RPN autocast) over fp32 master weights", "data": "synthetic",
+               "dtype": "fp32 (IEEE fp32 products forward and backward: spconv.functional.TRAIN_FP32_MODE = exact)" if amp is None else f"{args.dtype} features (sparse stack + RPN autocast) over fp32 master weights", "data": "synthetic",
                "config": {"workload": WL["desc"], "samples_per_step_per_gpu": bs, "parallelism": f"ddp{world}",
                           "points_per_frame": int(pts.shape[0]) // bs, "launch_mode": launch,
                           "gradient_bucket_bytes": tr.bucket.numel * 4,
@@ -474,7 +474,7 @@ def build_inputs(rank, device, order="shuffle", scene="open"):
     return clouds, torch.from_numpy(pts).to(device), torch.from_numpy(offs).to(device)
 
 
-def build_detector(device, dtype, calib_cloud=None):
+def build_detector(device, dtype, calib_cloud=None, exact=False):
     """Seeded random weights of the configured architecture.  car.fhd: made to BEHAVE like a trained detector where the
     selection stages can tell the difference (second_amd.synthetic.randomise_like_trained / sharpen_heads: empty regions of the
     map carry zero activations and score below nms_score_threshold, candidate scores are distinct) -- with default-initialised
@@ -501,7 +501,8 @@ def build_detector(device, dtype, calib_cloud=None):
                 m.running_var.copy_(torch.empty_like(m.running_var).uniform_(0.5, 1.5, generator=g))
         det = det.eval().to(device)
     cpu_state = {k: v.detach().cpu().clone() for k, v in det.state_dict().items()}
-    det.prepare_inference(dtype)      # (fp32 too: BatchNorms folded, the RPN's 3x3 convs on sec_conv2d_nhwc_x3)
+    # fp32: BatchNorms folded; products as three bf16 MFMA passes on split operands ("bf16x3") unless exact (IEEE fp32 products)
+    det.prepare_inference(dtype, exact=exact)
     return det, cpu_state
 
 
@@ -616,7 +617,13 @@ def cpu_baseline(cpu_state, clouds, gpu_out=None, budget_s=20.0, gpu_out_fp32=No
            "detections": [r["num_detections"] for r in res]}
     if gpu_out is not None:
         out["check"], out["detections_match_cpu"] = _match_detections(res, gpu_out)
-    if gpu_out_fp32 is not None:    # the SAME network in fp32 on the device (the reference's default precision)
+    if gpu_out_fp32 is not None:    # the SAME network on the device in fp32 storage: {"fp32_exact": ..., "bf16x3": ...} (or one output)
+        if isinstance(gpu_out_fp32, dict) and "boxes" not in gpu_out_fp32:
+            for label, o in gpu_out_fp32.items():
+                chk, ok = _match_detections(res, o)
+                out["check_" + label + "_device"] = dict(chk, match=ok)
+            gpu_out_fp32 = None
+    if gpu_out_fp32 is not None:
         chk, ok = _match_detections(res, gpu_out_fp32)
         chk.pop("rule")
         out["check_fp32_device"] = dict(chk, match=ok)
@@ -686,8 +693,11 @@ def other_configs(budget_s=270.0):
             ("nusc.fhd.train", "nusc.fhd.train", [], "config 5 (per-GPU step, fp16 features + dynamic loss scaling on the device, whole step one hipGraph)"),
             ("nusc.pp.train", "nusc.pp.train", [], "config 4's network trained on the device step (PFN batch statistics + argmax backward on "
                                                    "sec_pfn_train_fwd / _bwd)"),
-            ("car.fhd.fp32", "car.fhd", ["--dtype", "fp32"], "config 2's network in fp32, the reference's default precision: sparse convs, RPN and heads on the "
-                                                              "bf16 MFMA pipe with split operands (x = hi + lo, three products, fp32 accumulation)")]
+            ("car.fhd.bf16x3", "car.fhd", ["--dtype", "fp32"], "config 2's network with fp32 storage: sparse convs, RPN and heads on the bf16 MFMA pipe with "
+                                                                "split operands (x = hi + lo, three products, fp32 accumulation; 16 significant bits per operand)"),
+            ("car.fhd.fp32_exact", "car.fhd", ["--dtype", "fp32_exact", "--inflight", "2"],
+             "config 2's network in true fp32, the reference's default precision (train.py:232-235): sparse convs on "
+             "v_mfma_f32_32x32x2_f32 / VALU, RPN on torch's fp32 convolutions (MIOpen)")]
     out, t0 = {}, time.time()
     for key, wl, extra, what in runs:
         if time.time() - t0 > budget_s:
@@ -817,8 +827,9 @@ def time_dropin_fused(cpu_state, points, offsets, iters=60):
     (voxelnet.py:339-375, train.py:524) with the example dict of voxels / num_points / coordinates / anchors in, the list of
     per-frame dicts out.  Every call = copies into the static buffers, ONE hipGraph replay, one device -> host copy, one host
     synchronisation (the reference's return value has data-dependent shapes), result views: wall time per call, synchronous, one
-    call at a time.  fp32 = the reference's default precision; fp16 = after ``net.half()`` (train.py:468-472) with float16
-    examples; bf16 = ``accelerate_model(net, dtype=torch.bfloat16)``.  Voxelisation is not included (it is the data loader's job in
+    call at a time.  An fp32 network (the reference's default) is served either with split-operand products (`fp32_net_bf16x3`: the
+    default, 16 significant bits per operand) or with IEEE fp32 products (`fp32_net_exact`: ``accelerate_model(net, fp32_exact=True)``);
+    fp16 = after ``net.half()`` (train.py:468-472) with float16 examples; bf16 = ``accelerate_model(net, dtype=torch.bfloat16)``.  Voxelisation is not included (it is the data loader's job in
     the reference: the example dict is VoxelNet.forward's input)."""
     tests_dir = os.path.join(ROOT, "tests")
     if tests_dir not in sys.path:
@@ -829,7 +840,8 @@ def time_dropin_fused(cpu_state, points, offsets, iters=60):
     batch = offsets.numel() - 1
     out = {}
     base = None
-    for tag, half, forced in (("fp32", False, None), ("fp16_net_half", True, None), ("bf16_forced", False, torch.bfloat16)):
+    for tag, half, forced, exact in (("fp32_net_bf16x3", False, None, False), ("fp32_net_exact", False, None, True),
+                                     ("fp16_net_half", True, None, False), ("bf16_forced", False, torch.bfloat16, False)):
         net = build_voxelnet(CAR_FHD)
         net.load_state_dict(cpu_state)
         net = net.eval().cuda()
@@ -843,21 +855,22 @@ def time_dropin_fused(cpu_state, points, offsets, iters=60):
             for m in net.modules():
                 if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
                     m.float()
-        compat.accelerate_model(net, dtype=forced)
+        compat.accelerate_model(net, dtype=forced, fp32_exact=exact)
+        n_it = iters if not exact else max(10, iters // 4)
         with torch.no_grad():
             for _ in range(5):
                 res = net(example)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for _ in range(iters):
+            for _ in range(n_it):
                 res = net(example)
             torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / iters
+        dt = (time.perf_counter() - t0) / n_it
         eng = net._second_amd_engine
         dets = int(sum(r["box3d_lidar"].shape[0] for r in res))
         base = dets if base is None else base
-        out[tag] = {"frames_per_s": round(batch / dt, 1), "ms_per_call": round(dt * 1e3, 3), "detections_last_call": dets,
-                    "graph_captures": eng.stats["captures"], "calls_served_by_the_original_forward": eng.stats["original_calls"]}
+        out[tag] = {"frames_per_s": round(batch / dt, 1), "ms_per_call": round(dt * 1e3, 3), "arithmetic": eng._det.arithmetic(),
+                    "detections_last_call": dets, "graph_captures": eng.stats["captures"], "calls_served_by_the_original_forward": eng.stats["original_calls"]}
         del net, eng
         torch.cuda.empty_cache()
     out["what"] = ("compat.accelerate_model(net); net(example) -- VoxelNet.forward's contract, synchronous, one call at a time, batch "
@@ -966,7 +979,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)     # >= 200 timed iterations after 20 warm-ups
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32", "fp32_exact"],
+                    help="fp32 = fp32 storage with split-operand bf16 MFMA products (reported as dtype \"bf16x3\"); fp32_exact = IEEE fp32 "
+                         "products (sparse convs on the fp32 MFMA, RPN on torch's fp32 convolutions): the reference's arithmetic")
     ap.add_argument("--mode", default="graph", choices=["graph", "static", "eager"],
                     help="graph: static-capacity forward captured in a hipGraph (default); static: same, eager "
                          "launches; eager: the dynamic-shape drop-in path (host syncs per strided layer)")
@@ -1037,7 +1052,8 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-    dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.dtype]
+    dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32, "fp32_exact": torch.float32}[args.dtype]
+    exact = args.dtype == "fp32_exact"
 
     if args.workload.endswith(".train"):
         if args.workload == "car.fhd.train" and args.dtype == "bf16" and "--dtype" not in " ".join(sys.argv):
@@ -1047,7 +1063,7 @@ def main():
     clouds, points, offsets = build_inputs(rank, device, args.point_order, args.scene)
     # the heads are calibrated on seed-0's cloud on EVERY rank (same network everywhere), not on the rank's own first frame
     from second_amd import synthetic as syn
-    det, cpu_state = build_detector(device, dtype, None if args.default_heads else syn.syn_kitti_cloud(0))
+    det, cpu_state = build_detector(device, dtype, None if args.default_heads else syn.syn_kitti_cloud(0), exact=exact)
     if hasattr(det.rpn, "skip_background"):
         det.rpn.skip_background = bool(args.background_skip)
         det.rpn.lazy_background = bool(args.lazy_background)
@@ -1134,6 +1150,9 @@ def main():
                        "frac": round(b8 / t8 / 1e9 / HBM_PEAK_GBS, 4)}
         ops.set_conv_profiler(None)
         roof_mfma = time_rpn_conv(det, WL["batch"]) if args.dtype == "bf16" else None
+        dtype_note = {"bf16x3": "fp32 storage; every product = three bf16 MFMA passes on (hi, lo) operand pairs: 16 significant bits per operand "
+                                "and per stored activation plane pair, fp32 accumulation -- narrower than fp32 (see --dtype fp32_exact)",
+                      "fp32": "IEEE fp32 products and accumulation (v_mfma_f32_32x32x2_f32 / VALU sparse convs, torch fp32 RPN)"}.get(det.arithmetic())
         ktable = None
         if rank == 0 and args.mode != "eager" and not args.no_kernel_table:
             try:
@@ -1242,8 +1261,8 @@ def main():
             "metric": WL["metric"], "value": round(frames / elapsed, 2),
             "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic", "timing": timing,
-            "config": {"workload": WL["desc"],
+            "vs_baseline": None, "dtype": det.arithmetic(), "data": "synthetic", "timing": timing,
+            "config": {"workload": WL["desc"], "dtype_note": dtype_note,
                        "frames_per_step_per_gpu": WL["batch"], "parallelism": f"frame-dp{world}", "launch_mode": args.mode,
                        "graph_branches": args.branches if args.mode == "graph" else None,
                        "steps_in_flight": max(1, args.inflight) if args.mode == "graph" else 1,
@@ -1261,13 +1280,19 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out32 = None
-            if args.workload == "car.fhd" and args.dtype != "fp32" and "boxes" in out:
+            if args.workload == "car.fhd" and args.dtype in ("bf16", "fp16") and "boxes" in out:
+                # the SAME network on the device in both fp32 arithmetics: exact (IEEE fp32 products; module graph, torch RPN) and
+                # the split-operand pipeline ("bf16x3": what --dtype fp32 times)
                 from second_amd.models import SecondDetector, CAR_FHD
+                out32 = {}
                 det32 = SecondDetector(CAR_FHD)
                 det32.load_state_dict(cpu_state)
                 det32 = det32.eval().to(device)
+                with torch.no_grad(), ops.fp32_mode("exact"):
+                    out32["fp32_exact"] = det32.forward_points(points, offsets)
+                det32.prepare_inference(torch.float32)
                 with torch.no_grad():
-                    out32 = det32.forward_points(points, offsets)
+                    out32[ops.FP32_SPLIT_LABEL] = det32.forward_points(points, offsets)
                 torch.cuda.synchronize()
                 del det32
             res["cpu_baseline"] = cpu_baseline(cpu_state, clouds, out if "boxes" in out else None, gpu_out_fp32=out32)

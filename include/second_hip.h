@@ -209,6 +209,17 @@ int sec_indice_conv_fwd(const void *features, int n_in, int cin, const void *wei
  * not thread-safe, meant for A/B measurements and tests. */
 int sec_indice_conv_fwd_plan(int cin, int cout, int kvol, int n_out, int dtype, int out_dtype, int has_packed);
 int sec_indice_conv_set_variant(int variant);
+/* Arithmetic of the fp32 sparse convolutions, forward and data gradient (the reference computes fp32 products and sums:
+ * train.py:232-235 builds the network in torch.float32 unless enable_mixed_precision).  Process-wide, not thread-safe, consulted
+ * when a launch is issued (a captured graph keeps what it was captured with).
+ *   SEC_FP32_SPLIT16 (default): the split-operand form described above -- 16 significant bits per operand, fp32 accumulation.
+ *     Results carry the label "bf16x3" wherever this library's callers report a dtype.
+ *   SEC_FP32_EXACT: v_mfma_f32_32x32x2_f32 (16->32 ... 64->64) / VALU fma (4->16, 16->16): IEEE fp32 products, fp32 accumulation;
+ *     packed_weight images of fp32 weights are ignored. */
+#define SEC_FP32_SPLIT16 0
+#define SEC_FP32_EXACT 1
+int sec_set_fp32_mode(int mode);
+int sec_get_fp32_mode(void);
 /* backward (spconv_ops.h indiceConvBackward): dfeat[j,:] = sum_k dout[nbr_in[j][k],:] @ W[k]^T ;
  * dW[k] = sum_o feat[nbr_out[o][k],:]^T dout[o,:].  fp32 gradients for weights, feature dtype for dfeat.
  * For 16-bit dtypes dfeat runs on the MFMA forward kernels over re-packed transposed weights, which live in

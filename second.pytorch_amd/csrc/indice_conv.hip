@@ -1005,6 +1005,10 @@ __global__ __launch_bounds__(kBlock) void k_conv_c4_mfma(const T *__restrict__ f
 }
 
 static int g_variant_override = -1;     // sec_indice_conv_set_variant (A/B runs and the parity tests of every shipped kernel)
+// sec_set_fp32_mode: arithmetic of the fp32 sparse convolutions (forward and data gradient).  0 = SEC_FP32_SPLIT16: operands split
+// into bf16 (hi, lo) pairs on the bf16 matrix pipe, 16 significant bits per operand, fp32 accumulation (fast).  1 = SEC_FP32_EXACT:
+// v_mfma_f32_32x32x2_f32 / VALU fma -- IEEE fp32 products and accumulation, the arithmetic of the reference's default precision.
+static int g_fp32_mode = 0;
 static int conv_variant() {
     if (g_variant_override >= 0) return g_variant_override;
     return 1;  // 1 = automatic choice; 0 = one wave per 32-row tile; 8 / 9 / 10.. force one kernel family (sec_indice_conv_set_variant)
@@ -1766,7 +1770,7 @@ static bool launch_tiled(const void *feat, const void *w, const int *nbr, int n_
         // fp32 on the matrix cores for the channel plans of SECOND's layers (and their data gradients); g_variant_override 30 keeps
         // the VALU form (parity tests compare the two)
         // round 5: the split-operand form on the bf16 pipe (k_conv_rows_x3_f32); variant 31 keeps the fp32-MFMA form, 30 the VALU form
-        if (kvol <= 27 && conv_variant() != 30 && conv_variant() != 31) {
+        if (kvol <= 27 && conv_variant() != 30 && conv_variant() != 31 && g_fp32_mode == 0) {
 #define SEC_X3(CI, CO)                                                                                                       \
             if (cin == CI && cout == CO) {                                                                                   \
                 if (n_out >= 40000) {                                                                                        \
@@ -2258,6 +2262,13 @@ SEC_API int sec_pack_conv_weight(const void *weight, int kvol, int cin, int cout
     return check_launch();
 }
 
+SEC_API int sec_set_fp32_mode(int mode) {
+    if (mode != 0 && mode != 1) return SEC_E_INVALID;
+    g_fp32_mode = mode;
+    return SEC_OK;
+}
+SEC_API int sec_get_fp32_mode(void) { return g_fp32_mode; }
+
 SEC_API int sec_indice_conv_set_variant(int variant) {
     g_variant_override = variant;      // < 0: back to SEC_CONV_VARIANT / the automatic choice
     return SEC_OK;
@@ -2324,7 +2335,8 @@ SEC_API int sec_indice_conv_fwd(const void *features, int n_in, int cin, const v
     }
     // fp32 features with an x3-packed weight (ops.pack_weight of an fp32 weight: [k][hi | lo] bf16 B-fragment pieces): the pipelined
     // split-operand kernel; variants 30 / 31 (VALU / fp32-MFMA forms) and 32 (the unpacked split form) ignore the packed image
-    if (!done && packed_weight && dtype == SEC_F32 && out_dtype == SEC_F32 && conv_variant() != 30 && conv_variant() != 31 && conv_variant() != 32)
+    if (!done && packed_weight && dtype == SEC_F32 && out_dtype == SEC_F32 && conv_variant() != 30 && conv_variant() != 31 && conv_variant() != 32 &&
+        g_fp32_mode == 0)
         done = launch_x3p(features, n_in, packed_weight, nbr_out, n_out, num_out_dev, cin, cout, kvol, scale, shift, relu, out, st);
     if (!done) {
 #define SEC_GEN(T, OT) launch_generic<T, OT>(features, weight, nbr_out, n_out, num_out_dev, cin, cout, kvol, scale, shift, relu, out, st)

@@ -290,7 +290,7 @@ def accelerate_nms():
     return bto
 
 
-def accelerate_model(net, dtype=None, graph=True, static=None, strict=True, train_dtype=None):
+def accelerate_model(net, dtype=None, graph=True, static=None, strict=True, train_dtype=None, fp32_exact=False):
     """Serve a reference-built ``VoxelNet``'s ``net(example)`` in eval mode (voxelnet.py:339-375, called by train.py:524) from the
     fused static-capacity, graph-captured pipeline: parameters adopted by state-dict key, same return value
     (voxelnet.py:616-643), fp32 by default and 16-bit after ``net.half()``.  See :mod:`second_amd.dropin`.  Call after the
@@ -298,9 +298,10 @@ def accelerate_model(net, dtype=None, graph=True, static=None, strict=True, trai
     ``train_dtype=torch.bfloat16`` (or float16; SEC_ACCELERATE_TRAIN=bf16 in the environment): TRAINING-mode calls
     (train.py:306-325) are served too -- the loss dict of voxelnet.py:299-312 from one hipGraph replay, ``loss.backward()`` from a
     second one that leaves the gradients on the network's own parameters, 16-bit features over the fp32 weights
-    (:mod:`second_amd.dropin_train`)."""
+    (:mod:`second_amd.dropin_train`).  ``fp32_exact=True``: an fp32 network is served with IEEE fp32 products (the reference's
+    arithmetic) instead of the default split-operand bf16 passes ("bf16x3", 16 significant bits per operand)."""
     from ..dropin import accelerate_model as _acc
-    return _acc(net, dtype=dtype, graph=graph, static=static, strict=strict, train_dtype=train_dtype)
+    return _acc(net, dtype=dtype, graph=graph, static=static, strict=strict, train_dtype=train_dtype, fp32_exact=fp32_exact)
 
 
 def rotate_iou_gpu_eval(boxes, query_boxes, criterion=-1, device_id=0):

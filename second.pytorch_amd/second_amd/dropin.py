@@ -18,8 +18,10 @@ strided layer, three modules per layer, the dense [B, 128, 200, 176] image and p
     fused rulebook chain -> 14 sparse convs -> RPN on live tiles -> select / decode / NMS / finalize), ONE device -> host copy of
     the padded detections, and the reference's return value (voxelnet.py:616-643: a list of
     ``{box3d_lidar [k, 7] float32, scores [k] float32, label_preds [k] int64, metadata}`` on the input's device);
-  * precision follows the caller: fp32 networks run the fp32 pipeline, ``net.half()`` (train.py:470) the fp16 one;
-    ``dtype=torch.bfloat16`` may be forced;
+  * precision follows the caller: ``net.half()`` (train.py:470) runs the fp16 pipeline, ``dtype=torch.bfloat16`` may be forced; fp32
+    networks run the fp32-storage pipeline whose products are, by default, three bf16 MFMA passes on split operands ("bf16x3": 16
+    significant bits per operand, fp32 accumulation -- inside the 1e-4 of the parity rule, NOT the reference's fp32 arithmetic);
+    ``fp32_exact=True`` computes IEEE fp32 products (sparse convs on the fp32 MFMA, RPN on torch's fp32 convolutions);
   * training mode: opt-in (``train_dtype``), served by :mod:`second_amd.dropin_train`; otherwise the original forward;
   * DataParallel-padded examples (``num_points`` 2-D, voxelnet.py:346), ``anchors_mask`` and per-frame anchor
     sets keep the original forward.
@@ -185,8 +187,9 @@ class FusedVoxelNet:
     """See the module docstring.  ``graph=False``: the same static-capacity launches issued one by one (debugging, profiling);
     ``static=False``: dynamic shapes, eager (what a CPU network under the tests' oracle backend gets)."""
 
-    def __init__(self, net, dtype=None, graph=True, static=None, margin=1.25, row_bucket=16384, train_dtype=None):
+    def __init__(self, net, dtype=None, graph=True, static=None, margin=1.25, row_bucket=16384, train_dtype=None, fp32_exact=False):
         self.net, self.cfg = net, model_config(net)
+        self.fp32_exact = bool(fp32_exact)      # fp32 networks: IEEE fp32 products instead of the split-operand bf16 passes (prepare_inference)
         self.forced_dtype, self.graph, self.static = dtype, bool(graph), static
         # training-mode calls (second_amd.dropin_train): opt-in, because the captured step computes with 16-bit features where the
         # reference's default training arithmetic is fp32 (its own enable_mixed_precision mode makes the same trade)
@@ -266,7 +269,7 @@ class FusedVoxelNet:
         det = det.to(dev)
         dt = self.run_dtype()
         if dev.type == "cuda":       # fp32: BatchNorms folded, the RPN's 3x3 convs on sec_conv2d_nhwc_x3 (split-bf16 operands, fp32 accumulation)
-            det.prepare_inference(dt if dt is not None else torch.float32)
+            det.prepare_inference(dt if dt is not None else torch.float32, exact=self.fp32_exact and dt is None)
         det.eval()
         self._det, self._wkey = det, key
         self._ref_sum = self._checksum().clone()
@@ -439,7 +442,7 @@ class FusedVoxelNet:
         return res
 
 
-def accelerate_model(net, dtype=None, graph=True, static=None, strict=True, train_dtype=None):
+def accelerate_model(net, dtype=None, graph=True, static=None, strict=True, train_dtype=None, fp32_exact=False):
     """Serve ``net(example)`` (eval mode) from the fused pipeline; see the module docstring.  ``train_dtype`` (torch.bfloat16 /
     torch.float16, or SEC_ACCELERATE_TRAIN=bf16|fp16 in the environment): training-mode calls are served too -- loss dict out of one
     graph replay, ``loss.backward()`` a second one that leaves the gradients on the network's own parameters (dropin_train).  Returns ``net`` (its ``forward`` is
@@ -449,7 +452,7 @@ def accelerate_model(net, dtype=None, graph=True, static=None, strict=True, trai
         return net
     train_dtype = train_dtype if train_dtype is not None else _env_train_dtype()
     try:
-        eng = FusedVoxelNet(net, dtype=dtype, graph=graph, static=static, train_dtype=train_dtype)
+        eng = FusedVoxelNet(net, dtype=dtype, graph=graph, static=static, train_dtype=train_dtype, fp32_exact=fp32_exact)
     except NotAccelerable:
         if strict:
             raise

@@ -960,11 +960,18 @@ class SecondDetector(nn.Module):
                                                             **(dict(bf, block_filtering=True) if bf else {}))
 
     # -- inference preparation: bf16 channels-last RPN with folded BN; sparse stack in bf16 (BN folded at run time)
-    def prepare_inference(self, dtype=torch.bfloat16, rpn_backend="hip", gather_first=True):
+    def prepare_inference(self, dtype=torch.bfloat16, rpn_backend="hip", gather_first=True, exact=False):
+        """``dtype=torch.float32`` selects the fp32-STORAGE pipeline, whose products by default run as three bf16 MFMA passes on split
+        operands (16 significant bits per operand, fp32 accumulation; reported as ``ops.FP32_SPLIT_LABEL`` = "bf16x3").  ``exact=True``:
+        true fp32 arithmetic, the reference's default precision (train.py:232-235) -- sparse convs on v_mfma_f32_32x32x2_f32 / VALU
+        (``ops.fp32_mode("exact")`` around every forward), the RPN on torch's fp32 convolutions: several times slower, for parity work."""
         # NOTE: MIOpen's fused conv+bias+ReLU plan (torch.miopen_convolution_relu) was measured at ~160 ms per
         # 3x3 conv for bf16 NHWC on gfx950 (naive fallback kernel) vs 0.14 ms unfused -- not an option; the
         # fused dense path is the hand-written MFMA conv (SURVEY 8f item 1).
         self.eval()
+        self.fp32_exact = bool(exact) and dtype == torch.float32
+        if self.fp32_exact:
+            rpn_backend = "miopen"
         if isinstance(self.rpn, RPNV2) and RPNInference.supports(self.rpn) and next(self.parameters()).is_cuda:
             self.rpn = RPNInference(self.rpn, dtype, backend=rpn_backend, gather_first=gather_first)
         else:
@@ -979,6 +986,20 @@ class SecondDetector(nn.Module):
 
     # -- stages ------------------------------------------------------------------------------------
     def network_forward(self, voxel_features, coors, batch_size, num_active_dev=None, site_table=None):
+        with ops.fp32_mode("exact" if getattr(self, "fp32_exact", False) else None):
+            return self._network_forward(voxel_features, coors, batch_size, num_active_dev, site_table)
+
+    def arithmetic(self):
+        """What the prepared pipeline computes with, for records: "bf16" / "fp16" (16-bit features, fp32 accumulation), "fp32" (exact
+        mode: IEEE fp32 products) or "bf16x3" (fp32 storage, split-operand products)."""
+        dt = self._infer_dtype
+        if dt in (torch.bfloat16, torch.float16):
+            return "bf16" if dt == torch.bfloat16 else "fp16"
+        if getattr(self, "fp32_exact", False) or (next(self.parameters()).is_cuda and ops.get_fp32_mode() == "exact"):
+            return "fp32"
+        return ops.FP32_SPLIT_LABEL if next(self.parameters()).is_cuda else "fp32"
+
+    def _network_forward(self, voxel_features, coors, batch_size, num_active_dev=None, site_table=None):
         dt = self._infer_dtype
         if self.pillars:
             spatial = self.middle_feature_extractor(voxel_features if dt is None else voxel_features.to(dt), coors,

@@ -360,12 +360,51 @@ def set_conv_profiler(profiler):
     _conv_profiler = profiler
 
 
+FP32_MODES = {"split16": 0, "exact": 1}
+# How this package names the split-operand arithmetic wherever a dtype is reported (bench records, docs): fp32 STORAGE, products from
+# three bf16 MFMA passes on (hi, lo) operand pairs -- 16 significant bits per operand, fp32 accumulation.  Not the same thing as fp32.
+FP32_SPLIT_LABEL = "bf16x3"
+
+
+def set_fp32_mode(mode):
+    """Arithmetic of the fp32 sparse convolutions (include/second_hip.h sec_set_fp32_mode): "split16" (default; SEC_FP32_MODE in the
+    environment overrides the default at import) or "exact" (IEEE fp32 products on v_mfma_f32_32x32x2_f32 / VALU -- the reference's
+    arithmetic).  Returns the previous mode's name.  Process-wide; a captured graph keeps the mode it was captured under."""
+    l = rt.lib()
+    prev = "exact" if l.sec_get_fp32_mode() == 1 else "split16"
+    rt.check(l.sec_set_fp32_mode(FP32_MODES[mode]), "sec_set_fp32_mode")
+    return prev
+
+
+def get_fp32_mode():
+    return "exact" if rt.lib().sec_get_fp32_mode() == 1 else "split16"
+
+
+class fp32_mode:
+    """``with ops.fp32_mode("exact"): ...`` -- the launches issued inside use that arithmetic; None = leave the mode alone."""
+
+    def __init__(self, mode):
+        self.mode, self.prev = mode, None
+
+    def __enter__(self):
+        if self.mode is not None:
+            self.prev = set_fp32_mode(self.mode)
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev is not None:
+            set_fp32_mode(self.prev)
+        return False
+
+
 def pack_weight(weight):
     """Fragment-order copy of a [kD,kH,kW,Cin,Cout] weight for the MFMA path; None when not applicable."""
     rt.require_gpu(weight)
     cin, cout = weight.shape[-2], weight.shape[-1]
     k = weight.numel() // (cin * cout)
     l = rt.lib()
+    if weight.dtype == torch.float32 and l.sec_get_fp32_mode() == 1:
+        return None                                     # exact fp32: the kernels read the weight itself
     if weight.dtype == torch.float32:
         # fp32 layers run on the bf16 matrix pipe with split operands (sec_indice_conv_fwd): per offset the fragment image of
         # bf16(W) followed by that of bf16(W - bf16(W)); None for shapes without an instantiation (VALU / on-the-fly paths then)

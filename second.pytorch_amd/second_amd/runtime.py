@@ -32,7 +32,7 @@ SYMBOLS = [
     "sec_predict_select", "sec_predict_decode", "sec_predict_finalize",
     "sec_assign_targets_workspace_bytes", "sec_assign_targets_f32", "sec_assign_targets_per_class_f32",
     "sec_second_loss_workspace_bytes", "sec_second_loss_f32", "sec_heads_loss_supported", "sec_heads_loss_workspace_bytes",
-    "sec_heads_loss_fwd", "sec_heads_loss_fwd_terms", "sec_heads_loss_bwd",
+    "sec_heads_loss_fwd", "sec_heads_loss_fwd_terms", "sec_heads_loss_bwd", "sec_set_fp32_mode", "sec_get_fp32_mode",
     "sec_conv2d_pack_weight_train", "sec_conv2d_pack_weight_train_multi", "sec_pack_conv_weight_train_multi", "sec_conv2d_wgrad_workspace_bytes", "sec_conv2d_wgrad_nhwc", "sec_bn_train_workspace_bytes", "sec_bn_relu_fwd_nhwc",
     "sec_bn_relu_bwd_nhwc", "sec_flat_adamw_workspace_bytes", "sec_flat_adamw_f32", "sec_flat_adamw_dev_f32",
 ]
@@ -106,6 +106,8 @@ def lib():
                      "sec_conv2d_wgrad_workspace_bytes", "sec_bn_train_workspace_bytes", "sec_pfn_train_workspace_bytes",
                      "sec_flat_adamw_workspace_bytes"):
             getattr(l, name).restype = ctypes.c_size_t
+        if os.environ.get("SEC_FP32_MODE", "").lower() == "exact":      # process default of ops.set_fp32_mode
+            l.sec_set_fp32_mode(1)
         l.sec_last_error.restype = ctypes.c_char_p
         l.sec_last_kernel_name.restype = ctypes.c_char_p
         l.sec_conv_output_shape.restype = None
@@ -180,6 +182,8 @@ def lib():
         l.sec_heads_loss_supported.argtypes = [ci] * 5
         l.sec_heads_loss_workspace_bytes.argtypes = [ci] * 4
         l.sec_heads_loss_fwd.argtypes = [vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, sz, vp]
+        l.sec_set_fp32_mode.argtypes = [ci]
+        l.sec_get_fp32_mode.argtypes = []
         l.sec_heads_loss_fwd_terms.argtypes = [vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]
         l.sec_heads_loss_bwd.argtypes = [vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, ci, vp]
         ll = ctypes.c_longlong

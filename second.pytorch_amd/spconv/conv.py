@@ -109,7 +109,7 @@ class SparseConvolution(SparseModule):
 
     def packed_weight(self):
         w = self.weight
-        key = (w._version, w.dtype, w.device, w.data_ptr())
+        key = (w._version, w.dtype, w.device, w.data_ptr(), _ops.get_fp32_mode() if (w.is_cuda and w.dtype == torch.float32) else None)
         if self._packed_key != key:
             self._packed = _ops.pack_weight(w.detach().contiguous()) if w.is_cuda else None
             self._packed_key = key

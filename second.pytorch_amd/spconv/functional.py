@@ -1,7 +1,15 @@
 """Autograd wrappers (spconv/functional.py upstream: SparseConvFunction / SubMConvFunction)."""
+import os
+
 import torch
 
 from second_amd import ops as _ops
+
+# fp32 features AND fp32 weights with a gradient wanted (the reference's default training precision, train.py:232-235): forward and
+# backward run in exact fp32 arithmetic whatever the process-wide inference mode is (ops.set_fp32_mode) -- a training step whose
+# forward silently computed with 16-bit operand halves while its backward used fp32 would be neither.  SEC_FP32_TRAIN_MODE=split16
+# opts in to the faster split-operand forward / data gradient (products good to ~2^-16).
+TRAIN_FP32_MODE = os.environ.get("SEC_FP32_TRAIN_MODE", "exact")
 
 
 class IndiceConvFunction(torch.autograd.Function):
@@ -11,6 +19,11 @@ class IndiceConvFunction(torch.autograd.Function):
         ctx.master_dtype = weight.dtype
         ctx.packed_dgrad = None
         ctx.dw0 = None
+        ctx.fp32_mode = None
+        if features.dtype == torch.float32 and weight.dtype == torch.float32 and features.is_cuda and any(ctx.needs_input_grad[:2]):
+            ctx.fp32_mode = TRAIN_FP32_MODE
+            if ctx.fp32_mode == "exact":
+                packed = None
         if weight.dtype != features.dtype:
             # mixed precision (fp32 master weight, 16-bit features): the cast copy is made HERE, outside autograd -- the weight
             # gradient comes out of the kernels in fp32 and goes straight to the master weight (no fp32 -> 16-bit -> fp32 round
@@ -27,8 +40,9 @@ class IndiceConvFunction(torch.autograd.Function):
                 weight = weight.detach().to(features.dtype)
                 packed = _ops.pack_weight(weight.contiguous()) if weight.is_cuda and weight.dtype != torch.float32 else None
         ctx.save_for_backward(features, weight)
-        return _ops.indice_conv(features.contiguous(), weight.contiguous(), rulebook.nbr_out, rulebook.num_out,
-                                packed=packed, num_out_dev=rulebook.num_out_dev)
+        with _ops.fp32_mode(ctx.fp32_mode):
+            return _ops.indice_conv(features.contiguous(), weight.contiguous(), rulebook.nbr_out, rulebook.num_out,
+                                    packed=packed, num_out_dev=rulebook.num_out_dev)
 
     @staticmethod
     def backward(ctx, grad_out):
@@ -37,9 +51,10 @@ class IndiceConvFunction(torch.autograd.Function):
         if not rb.subm and rb.nbr_in is None:
             raise RuntimeError("this rulebook was built with autograd disabled (no input-major table); rebuild it "
                                "under torch.enable_grad() to back-propagate through a strided sparse conv")
-        dfeat, dw = _ops.indice_conv_backward(features.contiguous(), weight.contiguous(), rb.nbr_out, rb.nbr_in,
-                                              grad_out.contiguous(), ctx.needs_input_grad[0], ctx.needs_input_grad[1],
-                                              dweight_dtype=ctx.master_dtype, packed_dgrad=ctx.packed_dgrad, dweight_out=ctx.dw0)
+        with _ops.fp32_mode(ctx.fp32_mode):
+            dfeat, dw = _ops.indice_conv_backward(features.contiguous(), weight.contiguous(), rb.nbr_out, rb.nbr_in,
+                                                  grad_out.contiguous(), ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+                                                  dweight_dtype=ctx.master_dtype, packed_dgrad=ctx.packed_dgrad, dweight_out=ctx.dw0)
         ctx.dw0 = None                  # consumed: a second backward through this node (retain_graph) zeroes its own
         return dfeat, dw, None, None
 
