@@ -829,7 +829,9 @@ def time_dropin_fused(cpu_state, points, offsets, iters=60):
     synchronisation (the reference's return value has data-dependent shapes), result views: wall time per call, synchronous, one
     call at a time.  An fp32 network (the reference's default) is served either with split-operand products (`fp32_net_bf16x3`: the
     default, 16 significant bits per operand) or with IEEE fp32 products (`fp32_net_exact`: ``accelerate_model(net, fp32_exact=True)``);
-    fp16 = after ``net.half()`` (train.py:468-472) with float16 examples; bf16 = ``accelerate_model(net, dtype=torch.bfloat16)``.  Voxelisation is not included (it is the data loader's job in
+    fp16 = after ``net.half()`` (train.py:468-472) with float16 examples; bf16 = ``accelerate_model(net, dtype=torch.bfloat16)``;
+    `bf16_forced_deferred` = ``accelerate_model(net, dtype=torch.bfloat16, deferred=True)`` driven like evaluate() (results collected in a
+    list, read after the loop; the time includes reading every one of them): calls return at once and alternate between two lanes.  Voxelisation is not included (it is the data loader's job in
     the reference: the example dict is VoxelNet.forward's input)."""
     tests_dir = os.path.join(ROOT, "tests")
     if tests_dir not in sys.path:
@@ -840,8 +842,9 @@ def time_dropin_fused(cpu_state, points, offsets, iters=60):
     batch = offsets.numel() - 1
     out = {}
     base = None
-    for tag, half, forced, exact in (("fp32_net_bf16x3", False, None, False), ("fp32_net_exact", False, None, True),
-                                     ("fp16_net_half", True, None, False), ("bf16_forced", False, torch.bfloat16, False)):
+    for tag, half, forced, exact, deferred in (("fp32_net_bf16x3", False, None, False, False), ("fp32_net_exact", False, None, True, False),
+                                               ("fp16_net_half", True, None, False, False), ("bf16_forced", False, torch.bfloat16, False, False),
+                                               ("bf16_forced_deferred", False, torch.bfloat16, False, True)):
         net = build_voxelnet(CAR_FHD)
         net.load_state_dict(cpu_state)
         net = net.eval().cuda()
@@ -855,20 +858,33 @@ def time_dropin_fused(cpu_state, points, offsets, iters=60):
             for m in net.modules():
                 if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
                     m.float()
-        compat.accelerate_model(net, dtype=forced, fp32_exact=exact)
+        compat.accelerate_model(net, dtype=forced, fp32_exact=exact, deferred=deferred)
         n_it = iters if not exact else max(10, iters // 4)
         with torch.no_grad():
             for _ in range(5):
                 res = net(example)
+                len(res[0])                               # (deferred results resolve when read)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for _ in range(n_it):
-                res = net(example)
+            if deferred:        # the reference's evaluate() loop: `detections += net(example)`, first read after the loop (train.py:519-539)
+                n_it *= 2
+                collected = []
+                for _ in range(n_it):
+                    collected += net(example)
+                t_issue = (time.perf_counter() - t0) / n_it
+                for d in collected:
+                    d["scores"]
+                res = collected[-batch:]
+            else:
+                for _ in range(n_it):
+                    res = net(example)
             torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n_it
         eng = net._second_amd_engine
         dets = int(sum(r["box3d_lidar"].shape[0] for r in res))
         base = dets if base is None else base
+        if deferred:
+            out.setdefault("_issue_ms", {})[tag] = round(t_issue * 1e3, 3)
         out[tag] = {"frames_per_s": round(batch / dt, 1), "ms_per_call": round(dt * 1e3, 3), "arithmetic": eng._det.arithmetic(),
                     "detections_last_call": dets, "graph_captures": eng.stats["captures"], "calls_served_by_the_original_forward": eng.stats["original_calls"]}
         del net, eng

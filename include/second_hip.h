@@ -54,7 +54,8 @@ const char *sec_last_kernel_name(void);
  * [point_offsets[b], point_offsets[b+1]).  Semantics per cloud = the sequential reference loop
  * (second/utils/simplevis.py:31-50): voxel numbering in first-occurrence order, the first
  * `max_points` points of a voxel kept in arrival order, at most `max_voxels` voxels
- * (cap_mode 0 = `break` at the cap, 1 = `continue`).
+ * (cap_mode 0 = `break` at the cap, 1 = `continue`).  max_points <= 256 (the reference's configs keep 1 ... 100 points per voxel);
+ * larger values: SEC_E_UNSUPPORTED before anything is enqueued, and sec_voxelize_workspace_bytes returns 0.
  * Outputs are compact: cloud b's voxels are rows [voxel_offsets[b], voxel_offsets[b+1]).
  *   voxels [batch*max_voxels, max_points, num_features] (zero padded), coors [.,4] = (b,z,y,x),
  *   num_points_per_voxel [.], voxel_offsets [batch+1];

@@ -726,8 +726,11 @@ __global__ __launch_bounds__(kBlock) void k_vox_counts(const int *__restrict__ v
 
 using namespace sec;
 
+static constexpr int kVoxMaxPoints = 256;      // largest max_points (points kept per voxel) sec_voxelize_f32 serves
+
 SEC_API size_t sec_voxelize_workspace_bytes(int num_points, int batch, int max_voxels, int max_points) {
     if (num_points < 0 || batch <= 0 || max_voxels <= 0 || max_points <= 0) return 0;
+    if (max_points > kVoxMaxPoints) return 0;          // no kernel for it (sec_voxelize_f32 returns SEC_E_UNSUPPORTED): no size to report
     return carve_vox(nullptr, 0, num_points, batch, max_voxels, max_points).bytes;
 }
 
@@ -741,6 +744,9 @@ SEC_API int sec_voxelize_f32(const float *points, const int *point_offsets, int 
         !h_range6 || !h_voxel_size3 || (!voxels && mean) || !coors || !num_points_per_voxel || !voxel_offsets ||
         (mean && (mean_features <= 0 || mean_features > num_features || mean_dtype < SEC_F32 || mean_dtype > SEC_BF16)))
         return SEC_E_INVALID;
+    // the per-voxel point selection keeps 64 x 4 candidates in registers (k_vox_run_select<4>); the reference's configs use <= 100
+    // points per pillar.  Refused HERE, before anything is enqueued.
+    if (max_points > kVoxMaxPoints) return SEC_E_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     VoxWorkspace w = carve_vox(workspace, workspace_bytes, num_points, batch, max_voxels, max_points);
     if (!workspace || w.bytes > workspace_bytes) return SEC_E_WORKSPACE;
@@ -791,7 +797,6 @@ SEC_API int sec_voxelize_f32(const float *points, const int *point_offsets, int 
                            w.rank, w.base, voxel_offsets, p, w.svid, w.break_idx, coors,
                            fused_frames ? w.total : (const int *)nullptr);
         if (w.sort_bits) {
-            if (max_points > 256) return SEC_E_UNSUPPORTED;    // k_vox_run_select keeps 64 * R candidates in registers (reference configs: <= 100)
             long long rows = (long long)batch * max_voxels;
             if (rows > num_points) rows = num_points;
             hipLaunchKernelGGL(k_vox_group_rank, dim3(div_up(num_points, kRankBlock)), dim3(kRankBlock), 0, st, point_offsets, w.pslot, w.svid, w.break_idx, p, w.count,

@@ -290,7 +290,7 @@ def accelerate_nms():
     return bto
 
 
-def accelerate_model(net, dtype=None, graph=True, static=None, strict=True, train_dtype=None, fp32_exact=False):
+def accelerate_model(net, dtype=None, graph=True, static=None, strict=True, train_dtype=None, fp32_exact=False, deferred=None):
     """Serve a reference-built ``VoxelNet``'s ``net(example)`` in eval mode (voxelnet.py:339-375, called by train.py:524) from the
     fused static-capacity, graph-captured pipeline: parameters adopted by state-dict key, same return value
     (voxelnet.py:616-643), fp32 by default and 16-bit after ``net.half()``.  See :mod:`second_amd.dropin`.  Call after the
@@ -299,9 +299,13 @@ def accelerate_model(net, dtype=None, graph=True, static=None, strict=True, trai
     (train.py:306-325) are served too -- the loss dict of voxelnet.py:299-312 from one hipGraph replay, ``loss.backward()`` from a
     second one that leaves the gradients on the network's own parameters, 16-bit features over the fp32 weights
     (:mod:`second_amd.dropin_train`).  ``fp32_exact=True``: an fp32 network is served with IEEE fp32 products (the reference's
-    arithmetic) instead of the default split-operand bf16 passes ("bf16x3", 16 significant bits per operand)."""
+    arithmetic) instead of the default split-operand bf16 passes ("bf16x3", 16 significant bits per operand).  ``deferred=True``
+    (SEC_ACCELERATE_DEFERRED=1; what ``second_amd.launch evaluate`` uses): eval-mode calls return at once with dicts that fill
+    themselves when read -- evaluate() only collects them while it loops (train.py:519-524) -- and consecutive calls overlap on two
+    lanes; anything that reads a result gets exactly what the synchronous call returns."""
     from ..dropin import accelerate_model as _acc
-    return _acc(net, dtype=dtype, graph=graph, static=static, strict=strict, train_dtype=train_dtype, fp32_exact=fp32_exact)
+    return _acc(net, dtype=dtype, graph=graph, static=static, strict=strict, train_dtype=train_dtype, fp32_exact=fp32_exact,
+                deferred=deferred)
 
 
 def rotate_iou_gpu_eval(boxes, query_boxes, criterion=-1, device_id=0):

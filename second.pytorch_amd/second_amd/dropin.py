@@ -102,6 +102,119 @@ def model_config(net):
     return cfg
 
 
+class _Pending:
+    """One asynchronous ``net(example)`` call in flight: the clones of its outputs, the pinned host copies of its validity mask and
+    counters, the event that says they have arrived, and the example itself (kept until the call is resolved: the inputs are read on
+    a side stream, and a call whose counters report an overflow / other anchors / changed weights is redone synchronously)."""
+
+    def __init__(self, eng, sess, slot, example, packed, batch, meta):
+        self.eng, self.sess, self.slot, self.example = eng, sess, slot, example
+        self.packed, self.batch, self.meta = packed, batch, meta
+        self.results = None
+
+    def resolve(self):
+        if self.results is not None:
+            return self.results
+        eng, sess, slot = self.eng, self.sess, self.slot
+        slot["event"].synchronize()
+        nc = sess.outs["counters"].numel()
+        cnt = slot["host_counters"].numpy()
+        over = any(int(r) > c for r, c in zip(cnt[:nc], sess.outs["limits"]))
+        if cnt[nc] or cnt[nc + 1] or over:               # rare: settle it through the synchronous path (it adopts / recaptures / falls back)
+            eng.stats["deferred_redone"] += 1
+            res = eng._static(eng.refresh(), self.example)
+            if over:                                     # the lanes' own sessions take the capacities the synchronous session settled on
+                sync = eng._session(eng._det, self.example, self.batch, -1)
+                for other in eng._sessions.values():
+                    if other is not sync and other.batch == sync.batch and other.caps and len(other.caps) == len(sync.caps):
+                        other.grow_to = [max(a, b) for a, b in zip(other.caps, sync.caps)]
+            if res is None:
+                eng.stats["original_calls"] += 1
+                with torch.no_grad():
+                    res = eng.net._second_amd_original_forward(self.example)
+        else:
+            cur = torch.cuda.current_stream()
+            self.packed.record_stream(cur)                # produced on the lane's stream, consumed wherever the caller is
+            p = sess.outs["post"]
+            valid = slot["host_packed"].numpy()[:, 9 * p:10 * p] > 0.5
+            res = eng._results(self.packed, valid, p, self.batch, self.meta)
+            eng.stats["fused_calls"] += 1
+        self.results = res
+        slot["busy"] = None
+        self.example = self.packed = None
+        if self in eng._pending:
+            eng._pending.remove(self)
+        return res
+
+
+class DeferredDetection(dict):
+    """What an asynchronous ``net(example)`` returns per frame: a dict that fills itself with the reference's entries
+    (voxelnet.py:616-643: box3d_lidar, scores, label_preds, metadata) the first time anything reads it -- the reference's evaluate()
+    only collects the dicts in a list while it loops (train.py:519-524) and first looks inside after the loop (train.py:537-539).
+    Pickles as a plain dict."""
+
+    def __init__(self, pending, frame):
+        super().__init__()
+        self._pending, self._frame = pending, frame
+
+    def _fill(self):
+        pend = self.__dict__.get("_pending")
+        if pend is not None:
+            self.__dict__["_pending"] = None
+            super().update(pend.resolve()[self._frame])
+        return self
+
+    def __getitem__(self, k):
+        self._fill()
+        return super().__getitem__(k)
+
+    def get(self, k, default=None):
+        self._fill()
+        return super().get(k, default)
+
+    def __contains__(self, k):
+        self._fill()
+        return super().__contains__(k)
+
+    def __iter__(self):
+        self._fill()
+        return super().__iter__()
+
+    def __len__(self):
+        self._fill()
+        return super().__len__()
+
+    def keys(self):
+        self._fill()
+        return super().keys()
+
+    def items(self):
+        self._fill()
+        return super().items()
+
+    def values(self):
+        self._fill()
+        return super().values()
+
+    def __eq__(self, other):
+        self._fill()
+        return super().__eq__(other)
+
+    __hash__ = None
+
+    def __repr__(self):
+        self._fill()
+        return super().__repr__()
+
+    def copy(self):
+        self._fill()
+        return dict(super().items())
+
+    def __reduce__(self):
+        self._fill()
+        return (dict, (dict(super().items()),))
+
+
 class _Session:
     """Static buffers + captured graph for one (batch size, row capacity, voxel tensor layout)."""
 
@@ -113,9 +226,28 @@ class _Session:
         self.coors = torch.zeros((cap, 4), dtype=torch.int32, device=dev)
         self.n_dev = torch.zeros((1,), dtype=torch.int32, device=dev)
         self.anchors = anchors0.detach().float().contiguous().clone()
+        # the example's anchors [B, A, 7] land here every call (one copy) and are compared with the session's table INSIDE the graph
+        self.anchors_in = self.anchors.unsqueeze(0).repeat(batch, 1, 1)
         self.caps = None            # static_out_rows of the strided layers, in module order
         self.graph = self.outs = None
         self.event = torch.cuda.Event()
+        self.stream = torch.cuda.Stream(device=dev) if eng.deferred else None     # asynchronous calls: this lane's own stream
+        self.slots, self.grow_to = [], None
+
+    def take_slot(self):
+        """Pinned host landing buffers + event for one asynchronous call; a slot is free again once its call has been resolved."""
+        for sl in self.slots:
+            if sl["busy"] is None:
+                return sl
+        if len(self.slots) >= 2:                        # both in flight: the older call is (long) done on the device -- settle it
+            oldest = min(self.slots, key=lambda sl: sl["serial"])
+            oldest["busy"].resolve()
+            return oldest
+        sl = {"host_packed": torch.empty(self.outs["packed"].shape, dtype=torch.float32, pin_memory=True),
+              "host_counters": torch.empty((self.outs["flags"].numel(),), dtype=torch.int32, pin_memory=True),
+              "event": torch.cuda.Event(), "busy": None, "serial": 0}
+        self.slots.append(sl)
+        return sl
 
     def _strided(self):
         import spconv
@@ -143,8 +275,10 @@ class _Session:
         # content check of the network's tensors (FusedVoxelNet._checksum): their norms now against the norms at adoption, inside the
         # graph -- in-place updates that bump no version counter (`p.data.copy_()`, `p.data.mul_()`) show up here
         stale = self.eng.weights_changed_flag()
-        return {"packed": packed, "labels": out["labels"].long(), "counters": counters, "limits": [int(c) for _, c in checks],
-                "post": int(out["scores"].shape[1]), "stale": stale}
+        # a freed-and-reallocated anchor tensor can reuse an address and a version counter (identity proves nothing): content, every call
+        other_anchors = (self.anchors_in != self.anchors.unsqueeze(0)).any().int().reshape(1)
+        flags = torch.cat([counters.reshape(-1), other_anchors, stale])         # [overflow counters..., anchors differ, weights changed]
+        return {"packed": packed, "counters": counters, "limits": [int(c) for _, c in checks], "post": int(out["scores"].shape[1]), "flags": flags}
 
     def build(self, graph):
         prev = ops.set_rulebook_numbering("sorted")
@@ -167,9 +301,7 @@ class _Session:
         finally:
             ops.set_rulebook_numbering(prev)
         self.host_packed = torch.empty(self.outs["packed"].shape, dtype=torch.float32, pin_memory=True)
-        # [overflow counters..., anchors differ, weights changed]
-        self.host_counters = torch.empty((self.outs["counters"].numel() + 2,), dtype=torch.int32, pin_memory=True)
-        self.dev_counters = torch.zeros((self.outs["counters"].numel() + 2,), dtype=torch.int32, device=self.anchors.device)
+        self.host_counters = torch.empty((self.outs["flags"].numel(),), dtype=torch.int32, pin_memory=True)
 
     def launch(self):
         if self.graph is not None:
@@ -187,8 +319,14 @@ class FusedVoxelNet:
     """See the module docstring.  ``graph=False``: the same static-capacity launches issued one by one (debugging, profiling);
     ``static=False``: dynamic shapes, eager (what a CPU network under the tests' oracle backend gets)."""
 
-    def __init__(self, net, dtype=None, graph=True, static=None, margin=1.25, row_bucket=16384, train_dtype=None, fp32_exact=False):
+    def __init__(self, net, dtype=None, graph=True, static=None, margin=1.25, row_bucket=16384, train_dtype=None, fp32_exact=False,
+                 deferred=False, lanes=3):
         self.net, self.cfg = net, model_config(net)
+        # deferred: eval-mode calls return at once with self-filling dicts (DeferredDetection); consecutive calls alternate between
+        # `lanes` sessions on their own streams, so call k + 1's copies and graph overlap call k's tail (see _static_deferred)
+        import os
+        self.deferred, self.lanes = bool(deferred) and bool(graph), max(1, int(os.environ.get("SEC_ACCELERATE_LANES", lanes)))
+        self._pending, self._lane, self._serial = [], 0, 0
         self.fp32_exact = bool(fp32_exact)      # fp32 networks: IEEE fp32 products instead of the split-operand bf16 passes (prepare_inference)
         self.forced_dtype, self.graph, self.static = dtype, bool(graph), static
         # training-mode calls (second_amd.dropin_train): opt-in, because the captured step computes with 16-bit features where the
@@ -197,7 +335,7 @@ class FusedVoxelNet:
         self.margin, self.row_bucket = float(margin), int(row_bucket)
         self._det = self._wkey = self._watch = None
         self._sessions = {}
-        self.stats = {"content_readoptions": 0, "fused_calls": 0, "original_calls": 0, "adoptions": 0, "captures": 0, "overflow_recaptures": 0,
+        self.stats = {"content_readoptions": 0, "deferred_calls": 0, "deferred_redone": 0, "fused_calls": 0, "original_calls": 0, "adoptions": 0, "captures": 0, "overflow_recaptures": 0,
                       "anchor_refreshes": 0, "train_fallback_reason": None}
 
     # ------------------------------------------------------------------ adoption
@@ -315,7 +453,14 @@ class FusedVoxelNet:
         static = voxels.is_cuda if self.static is None else self.static
         if not static:
             return self._dynamic(det, example)
+        if self.deferred:
+            return self._static_deferred(det, example)
         return self._static(det, example)
+
+    def flush(self):
+        """Resolve every asynchronous call still in flight (their dicts fill themselves when read; this only forces it now)."""
+        for pend in list(self._pending):
+            pend.resolve()
 
     def _meta(self, example, batch):
         meta = example.get("metadata")
@@ -339,11 +484,11 @@ class FusedVoxelNet:
                         "label_preds": out["labels"][b][m].long(), "metadata": meta})
         return res
 
-    def _session(self, det, example, batch):
+    def _session(self, det, example, batch, lane=0):
         voxels = example["voxels"]
         n = voxels.shape[0]
         anchors0 = example["anchors"].reshape(batch, -1, 7)[0]
-        key = (batch, tuple(voxels.shape[1:]), voxels.dtype, voxels.device, int(anchors0.shape[0]))
+        key = (batch, tuple(voxels.shape[1:]), voxels.dtype, voxels.device, int(anchors0.shape[0]), lane)
         sess = self._sessions.get(key)
         if sess is not None and sess.cap >= n:
             return sess
@@ -382,24 +527,20 @@ class FusedVoxelNet:
         sess.num_points[:n].copy_(example["num_points"], non_blocking=True)
         sess.coors[:n].copy_(example["coordinates"], non_blocking=True)
         sess.n_dev.fill_(n)
+        sess.anchors_in.copy_(example["anchors"].reshape(sess.anchors_in.shape), non_blocking=True)
 
     def _static(self, det, example):
         batch = example["anchors"].shape[0]
         anchors = example["anchors"].reshape(batch, -1, 7)
+        lane = -1 if self.deferred else 0           # beside asynchronous lanes the synchronous path owns a session of its own
         for attempt in range(4):
-            sess = self._session(det, example, batch)
+            sess = self._session(det, example, batch, lane)
             self._fill(sess, example)
             nc = sess.outs["counters"].numel()
-            # the example's anchors against the session's, on the device, EVERY call (a freed-and-reallocated tensor can reuse an
-            # address and a version counter: identity proves nothing); the flag travels with the results
-            sess.dev_counters[nc:nc + 1].copy_((anchors != sess.anchors.unsqueeze(0)).any().int().reshape(1))
             sess.launch()
-            sess.dev_counters[:nc].copy_(sess.outs["counters"].reshape(-1))
-            sess.dev_counters[nc + 1:].copy_(sess.outs["stale"])
             sess.host_packed.copy_(sess.outs["packed"], non_blocking=True)
-            sess.host_counters.copy_(sess.dev_counters, non_blocking=True)
+            sess.host_counters.copy_(sess.outs["flags"], non_blocking=True)
             packed = sess.outs["packed"].clone()          # the session's buffers are overwritten by the next call
-            labels = sess.outs["labels"].clone()
             sess.event.record()
             sess.event.synchronize()
             cnt = sess.host_counters.numpy()
@@ -428,10 +569,52 @@ class FusedVoxelNet:
         p = sess.outs["post"]
         hp = sess.host_packed.numpy()
         valid = hp[:, 9 * p:10 * p] > 0.5
+        return self._results(packed, valid, p, batch, self._meta(example, batch))
+
+    def _static_deferred(self, det, example):
+        """The asynchronous form of :meth:`_static`: nothing waits.  Lane ``k % lanes`` (its own session: buffers, graph, stream) takes
+        call k -- copies, replay, clones of the outputs, the two small device -> host copies and an event, all on the lane's stream
+        after the caller's stream -- and the call returns dicts that resolve themselves when read (:class:`DeferredDetection`).  What
+        the synchronous path checks after its sync (overflow counters, anchor equality, weight content) is checked when the call is
+        resolved; a call that fails a check is redone synchronously from the example it still holds."""
+        batch = example["anchors"].shape[0]
+        anchors = example["anchors"].reshape(batch, -1, 7)
+        lane = self._lane
+        self._lane = (lane + 1) % self.lanes
+        sess = self._session(det, example, batch, lane)          # (first call of a lane: calibrates and captures, synchronously)
+        if sess.grow_to is not None:                             # an earlier call overflowed a strided layer: larger capacities, recapture
+            for sl in sess.slots:
+                if sl["busy"] is not None:
+                    sl["busy"].resolve()
+            torch.cuda.current_stream().wait_stream(sess.stream)
+            sess.caps, sess.grow_to = sess.grow_to, None
+            sess.build(self.graph)
+            self.stats["overflow_recaptures"] += 1
+        slot = sess.take_slot()
+        nc = sess.outs["counters"].numel()
+        cur = torch.cuda.current_stream()
+        sess.stream.wait_stream(cur)
+        with torch.cuda.stream(sess.stream):
+            self._fill(sess, example)
+            sess.launch()
+            slot["host_packed"].copy_(sess.outs["packed"], non_blocking=True)
+            slot["host_counters"].copy_(sess.outs["flags"], non_blocking=True)
+            packed = sess.outs["packed"].clone()
+            slot["event"].record()
+        self._serial += 1
+        pend = _Pending(self, sess, slot, example, packed, batch, self._meta(example, batch))
+        slot["busy"], slot["serial"] = pend, self._serial
+        self._pending.append(pend)
+        self.stats["deferred_calls"] += 1
+        return [DeferredDetection(pend, b) for b in range(batch)]
+
+    @staticmethod
+    def _results(packed, valid, p, batch, metas):
         boxes = packed[:, :7 * p].view(batch, p, 7)
         scores = packed[:, 7 * p:8 * p]
+        labels = packed[:, 8 * p:9 * p].long()          # (the packed copy carries them as floats: exact for class indices)
         res = []
-        for b, meta in zip(range(batch), self._meta(example, batch)):
+        for b, meta in zip(range(batch), metas):
             idx = np.flatnonzero(valid[b])
             k = len(idx)
             if k == 0 or idx[-1] == k - 1:                # the usual case: the kept detections are a prefix
@@ -442,7 +625,7 @@ class FusedVoxelNet:
         return res
 
 
-def accelerate_model(net, dtype=None, graph=True, static=None, strict=True, train_dtype=None, fp32_exact=False):
+def accelerate_model(net, dtype=None, graph=True, static=None, strict=True, train_dtype=None, fp32_exact=False, deferred=None):
     """Serve ``net(example)`` (eval mode) from the fused pipeline; see the module docstring.  ``train_dtype`` (torch.bfloat16 /
     torch.float16, or SEC_ACCELERATE_TRAIN=bf16|fp16 in the environment): training-mode calls are served too -- loss dict out of one
     graph replay, ``loss.backward()`` a second one that leaves the gradients on the network's own parameters (dropin_train).  Returns ``net`` (its ``forward`` is
@@ -452,7 +635,9 @@ def accelerate_model(net, dtype=None, graph=True, static=None, strict=True, trai
         return net
     train_dtype = train_dtype if train_dtype is not None else _env_train_dtype()
     try:
-        eng = FusedVoxelNet(net, dtype=dtype, graph=graph, static=static, train_dtype=train_dtype, fp32_exact=fp32_exact)
+        import os
+        deferred = (os.environ.get("SEC_ACCELERATE_DEFERRED", "0") == "1") if deferred is None else bool(deferred)
+        eng = FusedVoxelNet(net, dtype=dtype, graph=graph, static=static, train_dtype=train_dtype, fp32_exact=fp32_exact, deferred=deferred)
     except NotAccelerable:
         if strict:
             raise

@@ -276,7 +276,10 @@ def run_evaluate(reference_root, config_path, model_dir, backend=None, device=No
     def build_network(*a, **k):
         # the fused static-capacity pipeline behind net(example) (second_amd.dropin); networks outside it stay as built
         net = saved["build_network"](*a, **k)
-        holder["net"] = compat.accelerate_model(net, strict=False) if fuse else net
+        # deferred: evaluate() only collects the per-frame dicts while it loops (train.py:519-524) and first reads them when it hands
+        # the list to the dataset's evaluation / pickles it (train.py:537-539) -- the calls return at once and overlap on three lanes
+        # (SEC_ACCELERATE_DEFERRED=0: every call synchronous)
+        holder["net"] = compat.accelerate_model(net, strict=False, deferred=os.environ.get("SEC_ACCELERATE_DEFERRED", "1") != "0") if fuse else net
         return holder["net"]
 
     class ShardSampler(tud.Sampler):

@@ -60,6 +60,8 @@ def voxelize(points, point_offsets, point_cloud_range, voxel_size, max_points, m
     n, f = points.shape
     batch = point_offsets.numel() - 1
     dev = points.device
+    if int(max_points) > 256:
+        raise rt.SecondHipError(f"voxelize: max_points = {max_points} > 256 points per voxel is not supported (include/second_hip.h)")
     cap = batch * max_voxels
     rows = min(cap, max(n, 1))
     assert fill or not mean_features, "the SimpleVoxel mean is an epilogue of the fill"

@@ -63,7 +63,6 @@ class FlatAdamW:
         self.param_groups = [{"params": self.params, "lr": float(lr), "betas": tuple(float(b) for b in betas), "eps": float(eps),
                               "weight_decay": float(weight_decay)}]
         self.hyper = torch.zeros(6, dtype=torch.float32, device=dev)
-        self._hyper_host = torch.zeros(6, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(6)
         self._hyper_last = None
         self.sync_hyper()
 
@@ -82,8 +81,10 @@ class FlatAdamW:
         g = self.param_groups[0]
         cur = (float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), float(self.max_grad_norm))
         if cur != self._hyper_last:
-            self._hyper_host.copy_(torch.tensor(cur, dtype=torch.float32))
-            self.hyper.copy_(self._hyper_host, non_blocking=True)
+            # a FRESH pageable source per upload, copied synchronously with respect to the host (24 bytes): the host runs ahead of
+            # captured steps, and a reused pinned staging buffer could be rewritten with step k+1's values before step k's
+            # asynchronous copy had executed (one-cycle schedules change lr every step)
+            self.hyper.copy_(torch.tensor(cur, dtype=torch.float32))
             self._hyper_last = cur
 
     def enable_loss_scaling(self, init_scale=2.0 ** 12, growth_interval=200):

@@ -91,6 +91,26 @@ def test_round5_training_entry_points_validate_before_any_launch():
     assert l.sec_conv2d_wgrad_nhwc(one, one, 4, 200, 176, 128, 64, 1, 1, 0, one, one, 16, rt.SEC_BF16, None) == -2     # workspace too small
 
 
+def test_round6_entry_points_validate_before_any_launch():
+    """sec_voxelize_f32 refuses max_points > 256 up front (and reports no workspace size for it); sec_set_fp32_mode takes the two
+    documented modes only; sec_heads_loss_fwd_terms validates like sec_heads_loss_fwd.  Host-side decisions: no GPU needed."""
+    import ctypes
+    from second_amd import runtime as rt
+    l = rt.lib()
+    one = ctypes.c_void_p(4096)
+    assert l.sec_voxelize_workspace_bytes(1000, 1, 100, 256) > 0 and l.sec_voxelize_workspace_bytes(1000, 1, 100, 257) == 0
+    rng, vs = rt.f_arr([0, -40, -3, 70.4, 40, 1]), rt.f_arr([0.05, 0.05, 0.1])
+    assert l.sec_voxelize_f32(one, one, 1000, 4, 1, rng, vs, 300, 100, 0, one, one, one, one, None, 0, 0, one, 1 << 30, None) == -3
+    prev = l.sec_get_fp32_mode()
+    assert prev in (0, 1) and l.sec_set_fp32_mode(2) == -1 and l.sec_get_fp32_mode() == prev
+    assert l.sec_set_fp32_mode(1) == 0 and l.sec_get_fp32_mode() == 1 and l.sec_set_fp32_mode(prev) == 0
+    f17 = rt.f_arr([0.25, 2.0, 3.0, 1, 1, 1, 2, 0.2, 0, 1] + [1.0] * 7)
+    args = (rt.SEC_BF16, 1, 8, 16, 64, 2, 1, 2, one, one, one, one, f17)
+    assert l.sec_heads_loss_fwd_terms(None, *args, one, one, one, one, one, 1 << 20, None) == -1
+    assert l.sec_heads_loss_fwd_terms(one, *args, one, None, None, None, one, 16, None) == -2            # workspace too small
+    assert l.sec_heads_loss_fwd_terms(one, rt.SEC_F32, *args[1:], one, one, one, one, one, 1 << 20, None) == -3
+
+
 def test_no_cpu_fallback():
     from second_amd import ops
     from second_amd.runtime import SecondHipError

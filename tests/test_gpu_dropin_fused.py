@@ -303,3 +303,66 @@ def test_anchors_edited_in_place_or_resized_are_followed(car):
     fewer = dict(ex, anchors=ex["anchors"][:, :-2].contiguous())          # an anchor table of another length never reaches the fused graph
     with torch.no_grad(), pytest.raises(Exception):
         net._second_amd_original_forward(fewer)                           # (the reference asserts num_anchors == num_output, voxelnet.py:367)
+
+
+def test_deferred_calls_return_at_once_and_fill_themselves_when_read(car):
+    """``accelerate_model(net, deferred=True)``: what evaluate() does (train.py:519-539) -- collect ``net(example)`` in a list for a
+    whole loop, look inside afterwards.  Every deferred result must equal the synchronous engine's for the same example, whatever
+    ran in between (the calls alternate between two sessions on their own streams; results are clones, not views of a session)."""
+    import pickle
+    from reference_standin import example_of
+    from second_amd import compat, dropin
+    make, clouds, small = car
+    sync = compat.accelerate_model(make())
+    net = compat.accelerate_model(make(), deferred=True)
+    eng = net._second_amd_engine
+    examples = [example_of(net, clouds[:2], "cuda"), example_of(net, clouds[1:3], "cuda"), example_of(net, [clouds[2], clouds[0]], "cuda")]
+    with torch.no_grad():
+        want = [sync(ex) for ex in examples]
+        collected = []
+        for rep in range(3):
+            for ex in examples:
+                collected.append(net(ex))                                  # nothing is read here
+    assert all(isinstance(d, dropin.DeferredDetection) for r in collected for d in r)
+    assert eng.stats["deferred_calls"] == 9 and eng.stats["original_calls"] == 0
+    assert eng.stats["captures"] == 2                                      # one graph per lane
+    for i, got in enumerate(collected):
+        _same(got, want[i % 3])
+        assert got[0]["metadata"] == examples[i % 3]["metadata"][0]
+    assert eng.stats["fused_calls"] == 9 and eng.stats["deferred_redone"] == 0 and not eng._pending
+    blob = pickle.loads(pickle.dumps([{k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in d.items()} for d in collected[0]]))
+    assert type(blob[0]) is dict and set(blob[0]) == {"box3d_lidar", "scores", "label_preds", "metadata"}
+    assert type(pickle.loads(pickle.dumps(collected[1][0]))) is dict
+
+
+def test_deferred_calls_that_fail_a_check_are_redone_from_their_example(car):
+    """Overflow of a strided layer's capacity, another anchor table, weights changed through ``.data``: found when the call is
+    resolved, settled through the synchronous path, and the lanes take the larger capacities for the calls that follow."""
+    from reference_standin import example_of
+    from second_amd import compat
+    make, clouds, small = car
+    sync = compat.accelerate_model(make())
+    net = compat.accelerate_model(make(), deferred=True)
+    eng = net._second_amd_engine
+    ex_small, ex_big = example_of(net, small, "cuda"), example_of(net, clouds[:2], "cuda")
+    with torch.no_grad():
+        a = net(ex_small)
+        b = net(ex_small)
+        _same(a, sync(ex_small)); _same(b, sync(ex_small))
+        for sess in eng._sessions.values():                                  # squeeze the lanes: the next calls overflow
+            sess.grow_to = None
+            sess.caps = [256 for _ in sess.caps]
+            sess.build(True)
+        c = net(ex_small)
+        d = net(ex_small)
+        _same(c, sync(ex_small)); _same(d, sync(ex_small))
+        assert eng.stats["deferred_redone"] == 2
+        e = net(ex_small)                                                   # lanes rebuilt with the settled capacities: no redo any more
+        f = net(ex_small)
+        _same(e, sync(ex_small)); _same(f, sync(ex_small))
+        assert eng.stats["deferred_redone"] == 2
+        net.rpn.conv_cls.bias.data.add_(0.6)
+        sync.rpn.conv_cls.bias.data.add_(0.6)
+        g = net(ex_big)
+        _same(g, sync(ex_big))
+    assert eng.stats["original_calls"] == 0
