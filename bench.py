@@ -470,6 +470,12 @@ def build_inputs(rank, device, order="shuffle", scene="open"):
     clouds = _scene_clouds(scene, [rank * BATCH + s for s in range(WL["batch"])])
     if order == "sorted":   # experiment: points in spatial (z, y, x) order instead of the shuffled order of SURVEY 8d
         clouds = [c[np.lexsort((c[:, 0], c[:, 1], c[:, 2]))] for c in clouds]
+    elif order == "scan":   # firing order: azimuth step of 0.16 degrees (the generator's), then elevation (beam) -- real .bin files are un-shuffled
+        def scan(c):
+            az = np.round(np.degrees(np.arctan2(c[:, 1], c[:, 0])) / 0.16).astype(np.int64)
+            el = np.arctan2(c[:, 2], np.hypot(c[:, 0], c[:, 1]))
+            return c[np.lexsort((-el, az))]
+        clouds = [scan(c) for c in clouds]
     pts, offs = syn.batch_clouds(clouds)
     return clouds, torch.from_numpy(pts).to(device), torch.from_numpy(offs).to(device)
 
@@ -956,7 +962,7 @@ def time_dropin_train(iters_eager=6, iters_fused=40, batch=4):
     return out
 
 
-def time_scene_density(args, main_value, budget_s=150.0):
+def time_scene_density(args, main_value, budget_s=200.0):
     """How much of the headline depends on the BEV sparsity of the scene: the default path on a DENSE seeded scene
     (synthetic.syn_kitti_cloud(scene="dense"): 14-20 % of the 200 x 176 BEV cells occupied instead of 4-7 %, same 16 000 voxels /
     17 000 points per frame -- and, because its voxels are scattered instead of clustered, 2-3x the active rows in the strided
@@ -967,7 +973,7 @@ def time_scene_density(args, main_value, budget_s=150.0):
     res = {"sparse_scene": {"frames_per_s": main_value, "what": "the timed region of this line (SURVEY 8d clouds)"}}
     t0 = time.time()
     for key, extra in (("dense_scene", ["--scene", "dense"]), ("dense_scene_skip_off", ["--scene", "dense", "--background-skip", "0"]),
-                       ("sparse_scene_skip_off", ["--background-skip", "0"])):
+                       ("sparse_scene_skip_off", ["--background-skip", "0"]), ("sparse_scene_scan_order", ["--point-order", "scan"])):
         if time.time() - t0 > budget_s:
             res[key] = {"skipped": "time budget"}
             continue
@@ -984,8 +990,9 @@ def time_scene_density(args, main_value, budget_s=150.0):
         except Exception as e:  # noqa: BLE001
             res[key] = {"error": repr(e)[:300]}
     res["skip_off"] = {"sparse_scene": res["sparse_scene_skip_off"].get("frames_per_s"), "dense_scene": res["dense_scene_skip_off"].get("frames_per_s")}
-    res["what"] = ("frames/s of the default path on the bench's clouds (sparse_scene = `value`) and on a dense seeded scene, and of "
-                   "--background-skip 0 on both (fresh child processes of this command)")
+    res["what"] = ("frames/s of the default path on the bench's clouds (sparse_scene = `value`) and on a dense seeded scene, of "
+                   "--background-skip 0 on both, and of the bench's clouds in lidar firing order instead of shuffled (--point-order scan: real "
+                   ".bin files are un-shuffled; the shuffle of SURVEY 8d is the worst case for every gather); fresh child processes of this command")
     return res
 
 
@@ -1001,7 +1008,9 @@ def main():
     ap.add_argument("--mode", default="graph", choices=["graph", "static", "eager"],
                     help="graph: static-capacity forward captured in a hipGraph (default); static: same, eager "
                          "launches; eager: the dynamic-shape drop-in path (host syncs per strided layer)")
-    ap.add_argument("--point-order", default="shuffle", choices=["shuffle", "sorted"])
+    ap.add_argument("--point-order", default="shuffle", choices=["shuffle", "sorted", "scan"],
+                    help="shuffle = SURVEY 8d (worst case for every gather); sorted = cell (z, y, x) order; scan = firing order of a spinning "
+                         "lidar (azimuth step, then beam), the order of a KITTI velodyne .bin file")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-table", action="store_true", help="skip the per-launch roofline table (`kernels` key)")
     ap.add_argument("--no-extra-lines", action="store_true", help="skip config.e2e_from_pinned_host and config.batch1")
@@ -1294,6 +1303,11 @@ def main():
             "roofline_mfma": roof_mfma,     # second-largest consumer by kind: the dense RPN conv, MFMA bound
             "kernels": ktable,              # per-launch table of one step (SURVEY 8d formulas)
         }
+        if scenes is not None:
+            # the headline's dependence on the scene, at the TOP level of the record: the same command on the dense seeded scene and
+            # on the bench's clouds in lidar firing order (never `value`; details under config.rpn_background_tiles.frames_per_s)
+            res["value_dense_scene"] = (scenes.get("dense_scene") or {}).get("frames_per_s")
+            res["value_scan_order"] = (scenes.get("sparse_scene_scan_order") or {}).get("frames_per_s")
         if world == 1 and not args.no_cpu_baseline:
             out32 = None
             if args.workload == "car.fhd" and args.dtype in ("bf16", "fp16") and "boxes" in out:
