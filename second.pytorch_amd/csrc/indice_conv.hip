@@ -242,6 +242,14 @@ __device__ long long *g_timeline = nullptr;
 #endif
 
 static int conv_swizzle() { return 1; }      // XCD-aware tile order (round-1 A/B settled: on)
+static int rows_xcd_order() {                // the same for k_conv_rows_buf (round 6): SEC_CONV_ROWS_XCD=0 keeps the plain order (A/B)
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("SEC_CONV_ROWS_XCD");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v;
+}
   // profiling aid (tools/conv_microbench.py --timeline); null in production
 
 #ifndef SEC_SK_MIN_WAVES
@@ -657,8 +665,21 @@ SEC_PACKED_F32_OK __global__ __launch_bounds__(WAVES * 64, MINW) void k_conv_row
         rw = ((per_wg + WAVES - 1) / WAVES + 3) & ~3;
         rw = rw < 4 ? 4 : (rw > 32 ? 32 : rw);
     }
-    if ((long long)blockIdx.x * (rw * WAVES) >= n_out) return;
-    const long long row = (long long)blockIdx.x * (rw * WAVES) + w * rw + r;
+    // XCD-aware tile order (relu bit 16): workgroup b runs on XCD b % 8, and the rows of a batch are concatenated frame by frame, so
+    // giving XCD x the CONTIGUOUS range of tiles [x * per, (x + 1) * per) keeps a frame's feature rows, its slice of the gather table
+    // and its output rows in ONE XCD's 4 MB L2 -- with the plain order every XCD pulls every frame's rows through its own L2 (the
+    // 16-channel layers fetched 1.6-1.9x their algorithmic bytes from the fabric, L2 hit rate 0.5-0.7: profiles/r05_w_pmc.txt).
+    // The host launches a multiple of eight workgroups >= the live tile count; surplus workgroups exit.
+    int bid = blockIdx.x;
+    if (relu & 0x10000) {
+        const int nact = (int)(((long long)n_out + rw * WAVES - 1) / (rw * WAVES));
+        const int per = (nact + 7) >> 3;
+        bid = (bid & 7) * per + (bid >> 3);
+        if ((int)(blockIdx.x >> 3) >= per) return;
+    }
+    relu &= 1;
+    if ((long long)bid * (rw * WAVES) >= n_out) return;
+    const long long row = (long long)bid * (rw * WAVES) + w * rw + r;
     const bool valid = row < n_out && r < rw;
     SEC_RTL(long long *tl = g_timeline; long long tl0 = 0, tl1 = 0, tl2 = 0; if (tl) tl0 = clock64();)
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(feat), 0, (int)feat_bytes, 0x00020000);
@@ -667,7 +688,7 @@ SEC_PACKED_F32_OK __global__ __launch_bounds__(WAVES * 64, MINW) void k_conv_row
     // byte offset of this lane's first 16-byte chunk of every neighbour row; no neighbour -> beyond the buffer -> zeros
     unsigned off[KVOL];
     if constexpr (STAGE) {
-        const long long tile_row0 = (long long)blockIdx.x * (rw * WAVES) + w * rw;   // (32 rows are staged whatever rw is)
+        const long long tile_row0 = (long long)bid * (rw * WAVES) + w * rw;   // (32 rows are staged whatever rw is)
         const long long tbl_bytes = (long long)n_cap * KVOL * 4;
         const int *tile = nbr + tile_row0 * KVOL;
         // bytes of the table from this tile on: <= 0 for the waves of the last workgroup that start beyond the table (a table
@@ -923,9 +944,11 @@ static void launch_rows_buf(const void *feat, long long n_feat, const void *pack
     set_last_kernel("k_conv_rows_buf<%s, %d, %d, %d, %d, %d, %d, %d>", dtype_name<T>(), CIN, COUT, KVOL, DIST, WAVES, MINW, FL);
     int blocks = div_up(n_out, 32 * WAVES);
     if ((FL & 2048) != 0 && blocks < kBalWgs) blocks = kBalWgs;      // BAL: the kernel spreads the rows over up to kBalWgs workgroups
+    const int xcd = rows_xcd_order();
+    if (xcd) blocks = (blocks + 7) / 8 * 8 + 8;                      // the XCD-contiguous order needs ceil(live tiles / 8) workgroups per XCD
     hipLaunchKernelGGL((k_conv_rows_buf<T, CIN, COUT, KVOL, DIST, WAVES, MINW, FL>), dim3(blocks), dim3(WAVES * 64), 0, st,
                        (const T *)feat, n_feat * CIN * (long long)sizeof(T), (const T *)packed, nbr, n_out, num_out_dev, scale, shift,
-                       relu, (T *)out);
+                       (relu & 1) | (xcd << 16), (T *)out);
 }
 
 #ifdef SEC_CONV_EXPERIMENTS   // round-3 A/B forms: two row tiles per wave (k_conv_rows_m2), input planes in LDS windows (k_conv_rows_lds)
@@ -961,7 +984,13 @@ __global__ __launch_bounds__(kBlock) void k_conv_c4_mfma(const T *__restrict__ f
     if (num_out_dev) n_out = *num_out_dev;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const long long tile_row0 = (long long)blockIdx.x * 128 + w * 32;
+    int bid = blockIdx.x;
+    if (relu & 0x10000) {                                // XCD-contiguous tile order, as in k_conv_rows_buf: a frame's rows stay in one XCD's L2
+        const int per = (int)((((long long)n_out + 127) / 128 + 7) >> 3);
+        bid = (int)(blockIdx.x >> 3) < per ? (bid & 7) * per + (bid >> 3) : 0x3fffff;      // surplus workgroups: beyond every row
+    }
+    relu &= 1;
+    const long long tile_row0 = (long long)bid * 128 + w * 32;
     const long long row = tile_row0 + r;
     const bool valid = row < n_out;
     if (tile_row0 < n_out) {
@@ -2314,12 +2343,15 @@ SEC_API int sec_indice_conv_fwd(const void *features, int n_in, int cin, const v
     if (packed_weight && dtype != SEC_F32 && cin == 4 && cout == 16 && kvol == 27 && out_dtype == dtype && conv_variant() != 29 &&
         (long long)n_in * 8 < 0x7fffffffll) {
         const long long fb = (long long)n_in * 8;
+        const int c4_xcd = rows_xcd_order();
+        const int c4_blocks = c4_xcd ? (div_up(n_out, 128) + 7) / 8 * 8 : div_up(n_out, 128);
+        const int c4_relu = (relu & 1) | (c4_xcd << 16);
         if (dtype == SEC_BF16)
-            hipLaunchKernelGGL((k_conv_c4_mfma<__hip_bfloat16, 16>), dim3(div_up(n_out, 128)), dim3(kBlock), 0, st, (const __hip_bfloat16 *)features,
-                               fb, (const __hip_bfloat16 *)packed_weight, nbr_out, n_out, num_out_dev, scale, shift, relu, (__hip_bfloat16 *)out);
+            hipLaunchKernelGGL((k_conv_c4_mfma<__hip_bfloat16, 16>), dim3(c4_blocks), dim3(kBlock), 0, st, (const __hip_bfloat16 *)features,
+                               fb, (const __hip_bfloat16 *)packed_weight, nbr_out, n_out, num_out_dev, scale, shift, c4_relu, (__hip_bfloat16 *)out);
         else
-            hipLaunchKernelGGL((k_conv_c4_mfma<__half, 16>), dim3(div_up(n_out, 128)), dim3(kBlock), 0, st, (const __half *)features, fb,
-                               (const __half *)packed_weight, nbr_out, n_out, num_out_dev, scale, shift, relu, (__half *)out);
+            hipLaunchKernelGGL((k_conv_c4_mfma<__half, 16>), dim3(c4_blocks), dim3(kBlock), 0, st, (const __half *)features, fb,
+                               (const __half *)packed_weight, nbr_out, n_out, num_out_dev, scale, shift, c4_relu, (__half *)out);
         return check_launch();
     }
     if (packed_weight && dtype != SEC_F32 && cin % 16 == 0) {
