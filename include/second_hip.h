@@ -554,6 +554,22 @@ int sec_predict_decode(const void *box, const int64_t *h_box_strides5, const voi
                        int h, int w, int k, const float *anchors, const int *top_idx,
                        const float *top_score, int rotate, float *decoded, float *dets, int *dir_label,
                        int dtype, void *stream);
+/* LAZY heads: the producer of the head tensor (sec_conv1x1_chain_nhwc_tiles with background == NULL and SEC_CHAIN_X_LIVE_ONLY) wrote
+ * only the 8 x 16 tiles its live list names -- the copy of the other ~60 % of the map (22 MB per batch of 8 for car.fhd) never
+ * happens.  tile_live [batch][ceil(h/8) * ceil(w/16)] (row-major tiles): bit 4 set = the tile was written (the tile-indexed half of
+ * layer `convs` of sec_rpn_tile_live_masks called with convs + 1 layers); elements of any other tile are read from *_background =
+ * the same view (same sa / sy / sx / sc strides, ONE frame) of that producer's output for an empty frame -- exactly what the copy
+ * would have written.  Results identical, bit for bit, to the eager entry points on the materialised tensor. */
+int sec_predict_select_lazy(const void *cls, const int64_t *h_cls_strides5, int batch, int anchors_per_loc,
+                            int h, int w, int num_class, int k, float score_thr, unsigned *key_scratch, int *top_idx,
+                            float *top_score, int *top_label, int *counts, int dtype, const unsigned short *tile_live,
+                            const void *cls_background, void *stream);
+int sec_predict_decode_lazy(const void *box, const int64_t *h_box_strides5, const void *dir,
+                            const int64_t *h_dir_strides5, int num_dir_bins, int batch, int anchors_per_loc,
+                            int h, int w, int k, const float *anchors, const int *top_idx,
+                            const float *top_score, int rotate, float *decoded, float *dets, int *dir_label,
+                            int dtype, const unsigned short *tile_live, const void *box_background,
+                            const void *dir_background, void *stream);
 int sec_predict_finalize(const float *decoded, const float *top_score, const int *top_label,
                          const int *dir_label, const int *keep, const int *num_keep, int batch, int k,
                          int post_max, int use_direction, float dir_offset, float dir_limit_offset,

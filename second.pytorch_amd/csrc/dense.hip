@@ -1174,6 +1174,7 @@ __global__ __launch_bounds__(256, 3) void k_conv1x1_chain(const T *__restrict__ 
             item = 8 * per_live - n_live + (local - per_live) * 8 + xcd;
         }
         if (lists && !is_live) {
+            if (!background) return;                // lazy consumers (sec_predict_*_lazy): background tiles are never materialised
             constexpr int kCopyTiles = 4, NC = N2 / 8, PER = BM * NC / 256;      // 16-byte chunks per pixel / per thread and tile
             const int n_bg = ntile - n_live;
             const uint4 *e4 = reinterpret_cast<const uint4 *>(background);
@@ -1939,7 +1940,9 @@ SEC_API int sec_conv1x1_chain_x3(const void *x_hi, const void *x_lo, long long p
 SEC_API int sec_conv1x1_chain_nhwc_tiles(const void *x, int batch, int h, int w, const void *packed_w1, const float *bias1, int relu1,
                                          const void *packed_w2, const float *bias2, int cout2, const unsigned short *tile_order,
                                          const int *live_counts, const void *background, void *y, int dtype, void *stream) {
-    if (!x || !packed_w1 || !packed_w2 || !bias1 || !y || !tile_order || !live_counts || !background || batch <= 0 || h <= 0 || w <= 0)
+    // background == NULL: only with SEC_CHAIN_X_LIVE_ONLY (relu1 bit 1: the lists are used whatever the live share) -- the tiles
+    // outside the list are then NOT written, for consumers that read them from the empty frame's map (sec_predict_select_lazy)
+    if (!x || !packed_w1 || !packed_w2 || !bias1 || !y || !tile_order || !live_counts || (!background && !(relu1 & 2)) || batch <= 0 || h <= 0 || w <= 0)
         return SEC_E_INVALID;
     if ((cout2 != 64 && cout2 != 128) || (dtype != SEC_BF16 && dtype != SEC_F16)) return SEC_E_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;

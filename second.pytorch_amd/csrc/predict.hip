@@ -17,7 +17,22 @@ namespace sec {
 
 struct View5 {          // element strides of a [B, A, H, W, C] view
     long long sb, sa, sy, sx, sc;
+    // LAZY heads (sec_predict_select_lazy / _decode_lazy): the producer (sec_conv1x1_chain_nhwc_tiles with background == NULL) wrote
+    // only the tiles its live list names.  `live` [B][tiles] (8 x 16 tiles, row-major) holds bit 4 = "this tile was written"; for
+    // every other tile the element is read from the empty frame's head map instead -- `bg` = its element offset relative to the
+    // view's base pointer (same sa / sy / sx / sc, no frame stride): exactly the value the producer's copy would have put there.
+    long long bg;
+    const unsigned short *live;
+    int tiles_x, tpf;
 };
+// element offset of frame b as seen from pixel (y, x): the frame itself, or the empty frame's map for a tile that was never written
+__device__ __forceinline__ long long frame_off(const View5 &v, int b, int y, int x) {
+    if (v.live) {
+        const unsigned m = v.live[(long long)b * v.tpf + (y >> 3) * v.tiles_x + (x >> 4)];
+        if (!((m >> 4) & 1u)) return v.bg;
+    }
+    return (long long)b * v.sb;
+}
 struct PredGeom {
     int batch, A, H, W, nc;   // anchors per location, feature map, classes
 };
@@ -62,7 +77,7 @@ __device__ __forceinline__ unsigned anchor_key(const T *cls, const View5 &v, con
     int t = n / g.W;
     int y = t % g.H;
     int a = t / g.H;
-    const T *p = cls + b * v.sb + a * v.sa + y * v.sy + x * v.sx;
+    const T *p = cls + frame_off(v, b, y, x) + a * v.sa + y * v.sy + x * v.sx;
     float best = ldf(p);
     int lab = 0;
     for (int c = 1; c < g.nc; ++c) {
@@ -583,8 +598,8 @@ __global__ __launch_bounds__(kSelThreads) void k_predict_select_chunk(const T *_
             if (bx >= g.W) { bx = 0; if (++by >= g.H) { by = 0; ++ba; } }
             ok[2 * j] = a0 < N;
             ok[2 * j + 1] = a0 + 1 < N;                                 // slots beyond the frame hold key 0
-            off[2 * j] = ok[2 * j] ? (long long)b * v.sb + (long long)aa * v.sa + (long long)ay * v.sy + (long long)ax * v.sx : 0;
-            off[2 * j + 1] = ok[2 * j + 1] ? (long long)b * v.sb + (long long)ba * v.sa + (long long)by * v.sy + (long long)bx * v.sx : 0;
+            off[2 * j] = ok[2 * j] ? frame_off(v, b, ay, ax) + (long long)aa * v.sa + (long long)ay * v.sy + (long long)ax * v.sx : 0;
+            off[2 * j + 1] = ok[2 * j + 1] ? frame_off(v, b, by, bx) + (long long)ba * v.sa + (long long)by * v.sy + (long long)bx * v.sx : 0;
             ax += 128;
             while (ax >= g.W) { ax -= g.W; if (++ay >= g.H) { ay = 0; ++aa; } }
         }
@@ -696,7 +711,7 @@ __global__ __launch_bounds__(kBlock) void k_predict_decode(const T *__restrict__
     int q = n / g.W;
     int y = q % g.H;
     int a = q / g.H;
-    const T *pb = box + b * vb.sb + a * vb.sa + y * vb.sy + x * vb.sx;
+    const T *pb = box + frame_off(vb, b, y, x) + a * vb.sa + y * vb.sy + x * vb.sx;
     float e[7];
 #pragma unroll
     for (int c = 0; c < 7; ++c) e[c] = ldf(pb + c * vb.sc);
@@ -724,7 +739,7 @@ __global__ __launch_bounds__(kBlock) void k_predict_decode(const T *__restrict__
     }
     int dl = 0;
     if (dir) {
-        const T *pd = dir + b * vd.sb + a * vd.sa + y * vd.sy + x * vd.sx;
+        const T *pd = dir + frame_off(vd, b, y, x) + a * vd.sa + y * vd.sy + x * vd.sx;
         float best = ldf(pd);
         for (int c = 1; c < ndir; ++c) {
             float f = ldf(pd + c * vd.sc);
@@ -769,7 +784,19 @@ __global__ __launch_bounds__(kBlock) void k_predict_finalize(const float *__rest
 
 using namespace sec;
 
-static View5 mkview(const int64_t *s) { return View5{s[0], s[1], s[2], s[3], s[4]}; }
+static View5 mkview(const int64_t *s) { return View5{s[0], s[1], s[2], s[3], s[4], 0, nullptr, 0, 0}; }
+// the lazy form of a view: `base` is the view's pointer, `background` the same element of the empty frame's map
+static View5 mkview_lazy(const int64_t *s, const void *base, const void *background, const unsigned short *tile_live, int h, int w, int elt) {
+    View5 v = mkview(s);
+    if (tile_live && background) {
+        v.bg = (long long)((const char *)background - (const char *)base) / elt;
+        v.live = tile_live;
+        v.tiles_x = (w + 15) / 16;
+        v.tpf = ((h + 7) / 8) * v.tiles_x;
+    }
+    return v;
+}
+static int elt_bytes(int dtype) { return dtype == SEC_F32 ? 4 : 2; }
 
 // a 16-bit key no larger than the key of any bf16 logit whose sigmoid reaches `thr` (0 = no such bound): the logit of thr, lowered
 // by more than bf16's and sigmoidf's rounding, mapped like f2key() >> 16, minus one key step (truncation of a negative value's
@@ -792,15 +819,17 @@ static unsigned conservative_thr16(float thr, int dtype) {
     return k16 > 2u ? k16 - 2u : 0u;                 // two key steps down: covers the rounding of the conversions above
 }
 
-SEC_API int sec_predict_select(const void *cls, const int64_t *h_cls_strides5, int batch, int anchors_per_loc, int h, int w,
+static int predict_select_impl(const void *cls, const int64_t *h_cls_strides5, int batch, int anchors_per_loc, int h, int w,
                                int num_class, int k, float score_thr, unsigned *key_scratch, int *top_idx, float *top_score,
-                               int *top_label, int *counts, int dtype, void *stream) {
+                               int *top_label, int *counts, int dtype, void *stream, const unsigned short *tile_live,
+                               const void *cls_background) {
     if (!key_scratch) return SEC_E_WORKSPACE;
     if (!cls || !h_cls_strides5 || batch <= 0 || anchors_per_loc <= 0 || h <= 0 || w <= 0 || num_class <= 0 || k <= 0 ||
         k > kSelThreads || !top_idx || !top_score || !top_label || !counts)
         return SEC_E_INVALID;
+    if ((tile_live != nullptr) != (cls_background != nullptr) || dtype < SEC_F32 || dtype > SEC_BF16) return SEC_E_INVALID;
     PredGeom g{batch, anchors_per_loc, h, w, num_class};
-    View5 v = mkview(h_cls_strides5);
+    View5 v = mkview_lazy(h_cls_strides5, cls, cls_background, tile_live, h, w, elt_bytes(dtype));
     hipStream_t st = (hipStream_t)stream;
     const long long total = (long long)batch * anchors_per_loc * h * w;
 #define SEC_SEL(T, K16)                                                                                                         \
@@ -888,14 +917,32 @@ SEC_API int sec_predict_select(const void *cls, const int64_t *h_cls_strides5, i
     return check_launch();
 }
 
-SEC_API int sec_predict_decode(const void *box, const int64_t *h_box_strides5, const void *dir, const int64_t *h_dir_strides5,
+SEC_API int sec_predict_select(const void *cls, const int64_t *h_cls_strides5, int batch, int anchors_per_loc, int h, int w,
+                               int num_class, int k, float score_thr, unsigned *key_scratch, int *top_idx, float *top_score,
+                               int *top_label, int *counts, int dtype, void *stream) {
+    return predict_select_impl(cls, h_cls_strides5, batch, anchors_per_loc, h, w, num_class, k, score_thr, key_scratch, top_idx, top_score,
+                               top_label, counts, dtype, stream, nullptr, nullptr);
+}
+SEC_API int sec_predict_select_lazy(const void *cls, const int64_t *h_cls_strides5, int batch, int anchors_per_loc, int h, int w,
+                                    int num_class, int k, float score_thr, unsigned *key_scratch, int *top_idx, float *top_score,
+                                    int *top_label, int *counts, int dtype, const unsigned short *tile_live, const void *cls_background,
+                                    void *stream) {
+    if (!tile_live || !cls_background) return SEC_E_INVALID;
+    return predict_select_impl(cls, h_cls_strides5, batch, anchors_per_loc, h, w, num_class, k, score_thr, key_scratch, top_idx, top_score,
+                               top_label, counts, dtype, stream, tile_live, cls_background);
+}
+
+static int predict_decode_impl(const void *box, const int64_t *h_box_strides5, const void *dir, const int64_t *h_dir_strides5,
                                int num_dir_bins, int batch, int anchors_per_loc, int h, int w, int k, const float *anchors,
                                const int *top_idx, const float *top_score, int rotate, float *decoded, float *dets,
-                               int *dir_label, int dtype, void *stream) {
+                               int *dir_label, int dtype, void *stream, const unsigned short *tile_live, const void *box_background,
+                               const void *dir_background) {
     if (!box || !h_box_strides5 || batch <= 0 || k <= 0 || !anchors || !top_idx || !top_score || !decoded || !dets || !dir_label)
         return SEC_E_INVALID;
+    if (dtype < SEC_F32 || dtype > SEC_BF16 || (tile_live && (!box_background || (dir && !dir_background)))) return SEC_E_INVALID;
     PredGeom g{batch, anchors_per_loc, h, w, 1};
-    View5 vb = mkview(h_box_strides5), vd = dir ? mkview(h_dir_strides5) : View5{0, 0, 0, 0, 0};
+    View5 vb = mkview_lazy(h_box_strides5, box, box_background, tile_live, h, w, elt_bytes(dtype));
+    View5 vd = dir ? mkview_lazy(h_dir_strides5, dir, dir_background, tile_live, h, w, elt_bytes(dtype)) : View5{0, 0, 0, 0, 0, 0, nullptr, 0, 0};
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(div_up((long long)batch * k, kBlock));
 #define SEC_DEC(T) hipLaunchKernelGGL(k_predict_decode<T>, grid, dim3(kBlock), 0, st, (const T *)box, vb, (const T *)dir, vd, \
@@ -906,6 +953,22 @@ SEC_API int sec_predict_decode(const void *box, const int64_t *h_box_strides5, c
     else return SEC_E_UNSUPPORTED;
 #undef SEC_DEC
     return check_launch();
+}
+SEC_API int sec_predict_decode(const void *box, const int64_t *h_box_strides5, const void *dir, const int64_t *h_dir_strides5,
+                               int num_dir_bins, int batch, int anchors_per_loc, int h, int w, int k, const float *anchors,
+                               const int *top_idx, const float *top_score, int rotate, float *decoded, float *dets,
+                               int *dir_label, int dtype, void *stream) {
+    return predict_decode_impl(box, h_box_strides5, dir, h_dir_strides5, num_dir_bins, batch, anchors_per_loc, h, w, k, anchors, top_idx,
+                               top_score, rotate, decoded, dets, dir_label, dtype, stream, nullptr, nullptr, nullptr);
+}
+SEC_API int sec_predict_decode_lazy(const void *box, const int64_t *h_box_strides5, const void *dir, const int64_t *h_dir_strides5,
+                                    int num_dir_bins, int batch, int anchors_per_loc, int h, int w, int k, const float *anchors,
+                                    const int *top_idx, const float *top_score, int rotate, float *decoded, float *dets,
+                                    int *dir_label, int dtype, const unsigned short *tile_live, const void *box_background,
+                                    const void *dir_background, void *stream) {
+    if (!tile_live || !box_background) return SEC_E_INVALID;
+    return predict_decode_impl(box, h_box_strides5, dir, h_dir_strides5, num_dir_bins, batch, anchors_per_loc, h, w, k, anchors, top_idx,
+                               top_score, rotate, decoded, dets, dir_label, dtype, stream, tile_live, box_background, dir_background);
 }
 
 SEC_API int sec_predict_finalize(const float *decoded, const float *top_score, const int *top_label, const int *dir_label,

@@ -266,7 +266,8 @@ class _Session:
             feats = self.voxels[:, :, :nf].float().sum(1) / self.num_points.float().unsqueeze(1)
             if dt is not None:
                 feats = feats.to(dt)
-        preds = det.network_forward(feats, self.coors, b, num_active_dev=self.n_dev)
+        with det.lazy_heads():          # the head tensor's background tiles stay unwritten: predict_device reads them from the empty frame's map
+            preds = det.network_forward(feats, self.coors, b, num_active_dev=self.n_dev)
         out = det.predict_device(preds, b, self.anchors)
         checks = list(getattr(det.middle_feature_extractor, "last_overflow_checks", [])) if not det.pillars else []
         packed = torch.cat([out["boxes"].reshape(b, -1).float(), out["scores"].float(), out["labels"].float(),

@@ -679,6 +679,10 @@ class RPNInference(nn.Module):
         # empty-frame map (sec_conv2d_nhwc_tiles_lazy) -- no copy of the ~1 450 background tiles (47 MB read + 47 MB written) per layer;
         # the fused 1x1 tail then runs on the last conv's lists whatever the live share (x_live_only)
         self.lazy_background = True
+        # lazy_heads (set by SecondDetector around forwards whose consumer is the fused predict): the fused 1x1 tail writes the head
+        # tensor's live tiles ONLY and the select / decode kernels read every other tile from the empty frame's head map -- the copy
+        # of ~60 % of the [B, H, W, 64] head tensor (22 MB per batch of 8) disappears; forward() then adds preds["lazy_heads"]
+        self.lazy_heads = False
         self.last_live_counts = None       # [convs, B] int32 on the device: live tiles per conv and frame of the last forward (bench / tests)
         self._empty_maps = {}
         self.register_load_state_dict_post_hook(lambda module, incompatible: module._repack())
@@ -870,7 +874,7 @@ class RPNInference(nn.Module):
                     empty = self.empty_frame_maps(sm.shape[2], sm.shape[3])
                     lazy = self.lazy_background and self.background_convs >= 2
                     if lazy:
-                        live, self.last_live_counts, nbr = gather.tile_lists(self.background_convs, masks=True)
+                        live, self.last_live_counts, nbr = gather.tile_lists(self.list_layers(), masks=True)
                     else:
                         (live, self.last_live_counts), nbr = gather.tile_lists(self.background_convs), None
                     x = ops.conv2d_nhwc_gather(gather.features, sm, self.gather_packed, self.bs[i], self.ws[i].shape[0], relu=True,
@@ -892,11 +896,15 @@ class RPNInference(nn.Module):
                 ups.append(None)                     # single block: the deblock runs fused with the heads below
             else:
                 ups.append(self._conv(x, i))
+        lazy_heads = None
         if self.chain_tail and live is not None:
             last = self.background_convs - 1
+            want_lazy = self.lazy_heads and nbr is not None and nbr.shape[0] > self.background_convs
             y = ops.conv1x1_chain(x, self.packed[-1], self.bs[-1], self.head_packed, self.head_b64, self.head_cout,
-                                  tile_order=live[last], live_counts=self.last_live_counts[last], background=empty[last + 1],
-                                  x_live_only=nbr is not None)
+                                  tile_order=live[last], live_counts=self.last_live_counts[last],
+                                  background=None if want_lazy else empty[last + 1], x_live_only=nbr is not None)
+            if want_lazy:      # (tile-indexed masks of the layer BEHIND the last conv: bit 4 = the last conv's list holds the tile)
+                lazy_heads = (nbr[self.background_convs, 1], self._split_heads(empty[last + 1]))
         elif self.chain_tail:
             y = ops.conv1x1_chain(x, self.packed[-1], self.bs[-1], self.head_packed, self.head_b64, self.head_cout)
         else:
@@ -906,7 +914,15 @@ class RPNInference(nn.Module):
                                     self.head_cout, 1, 1, 0, relu=False)
             else:
                 y = ops.bias_act_(F.conv2d(f, self.head_w, None), self.head_b, relu=False)
-        return self._split_heads(y)
+        ret = self._split_heads(y)
+        if lazy_heads is not None:
+            ret["lazy_heads"] = lazy_heads          # consumed by SecondDetector._predict_fused (ops.predict_select / predict_decode lazy=)
+        return ret
+
+    def list_layers(self):
+        """Layers of live-tile lists / masks a forward asks rpn_tile_live for: one per 3x3 conv, plus one when the heads are lazy (its
+        tile-indexed masks say which tiles the LAST conv's list -- the fused tail's -- holds)."""
+        return self.background_convs + (1 if (self.lazy_heads and self.chain_tail and self.background_convs < 8) else 0)
 
 
 # ------------------------------------------------------------------------------------------ detector
@@ -1044,7 +1060,31 @@ class SecondDetector(nn.Module):
         finally:
             ops.set_rulebook_numbering(prev)
 
+    def lazy_heads(self):
+        """Context: forwards inside may leave the head tensor's background tiles unwritten (RPNInference.lazy_heads) because their
+        preds go straight to :meth:`predict_device`'s fused kernels, which read those tiles from the empty frame's map.  A no-op when
+        the prepared RPN / the predict path cannot do it (or SEC_RPN_LAZY_HEADS=0)."""
+        det = self
+
+        class _Ctx:
+            def __enter__(self_):
+                self_.prev = getattr(det.rpn, "lazy_heads", None)
+                if (self_.prev is not None and det.fused_predict and det.cfg["nms_pre_max_size"] <= 1024
+                        and os.environ.get("SEC_RPN_LAZY_HEADS", "1") != "0"):
+                    det.rpn.lazy_heads = True
+                return self_
+
+            def __exit__(self_, *exc):
+                if self_.prev is not None:
+                    det.rpn.lazy_heads = self_.prev
+                return False
+        return _Ctx()
+
     def _forward_points(self, points, point_offsets, static=False):
+        with self.lazy_heads():
+            return self._forward_points_impl(points, point_offsets, static)
+
+    def _forward_points_impl(self, points, point_offsets, static=False):
         batch_size = point_offsets.numel() - 1
         nf = self.cfg["num_point_features"]
         if self.pillars:
@@ -1186,10 +1226,13 @@ class SecondDetector(nn.Module):
                                                             bev_sparse=self._rpn_takes_rows())
                     self._branch_overflow = [list(getattr(self.middle_feature_extractor, "last_overflow_checks", []))]
                     if isinstance(spatial, SparseBEV) and getattr(self.rpn, "background_convs", 0) and self.rpn.skip_background:
-                        spatial.tile_lists(self.rpn.background_convs,      # the live-tile lists belong to the latency-bound segment
-                                           masks=self.rpn.lazy_background and self.rpn.background_convs >= 2)
+                        lazy_ = self.rpn.lazy_background and self.rpn.background_convs >= 2
+                        with self.lazy_heads():
+                            spatial.tile_lists(self.rpn.list_layers() if lazy_ else self.rpn.background_convs,   # the live-tile lists belong to the latency-bound segment
+                                               masks=lazy_)
                 with torch.cuda.graph(gb, pool=pool, capture_error_mode="thread_local"):
-                    preds = self.rpn(spatial)
+                    with self.lazy_heads():
+                        preds = self.rpn(spatial)
                 with torch.cuda.graph(gc, pool=pool, capture_error_mode="thread_local"):
                     out = self.predict_device(preds, batch_size)
         finally:
@@ -1280,8 +1323,14 @@ class SecondDetector(nn.Module):
         if anchors.dim() == 3:
             anchors = anchors[0]
         anchors = anchors.float().contiguous()
-        top_idx, top_score, top_label, counts = ops.predict_select(cls, cfg["nms_pre_max_size"], cfg["nms_score_threshold"])
-        dec, dets, dlab = ops.predict_decode(box, dirp, anchors, top_idx, top_score, rotate=cfg["use_rotate_nms"])
+        lz = preds.get("lazy_heads")       # (tile_live, empty-frame heads): background tiles of the head tensor were never written
+        lz_cls = lz_box = None
+        if lz is not None:
+            bg = lz[1]
+            lz_cls = (lz[0], view5(bg["cls_preds"], cfg["num_class"]))
+            lz_box = (lz[0], (view5(bg["box_preds"], 7), view5(bg["dir_cls_preds"], cfg["num_direction_bins"]) if dirp is not None else None))
+        top_idx, top_score, top_label, counts = ops.predict_select(cls, cfg["nms_pre_max_size"], cfg["nms_score_threshold"], lazy=lz_cls)
+        dec, dets, dlab = ops.predict_decode(box, dirp, anchors, top_idx, top_score, rotate=cfg["use_rotate_nms"], lazy=lz_box)
         if cfg["use_rotate_nms"]:
             keep, num_keep = ops.nms_sorted(dets, counts, cfg["nms_iou_threshold"], "rotate", "cpu", post_max=cfg["nms_post_max_size"])
         else:

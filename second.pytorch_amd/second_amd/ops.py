@@ -1085,16 +1085,25 @@ def conv1x1_chain(x, packed_w1, bias1, packed_w2, bias2, cout2, relu1=True, tile
     """y = W2 * act(W1 * x + bias1) + bias2 for two back-to-back 1x1 convs on a channels_last [B,128,H,W] tensor
     (the RPN deblock + merged heads, rpn.py:275-285,386-391); the 128-channel intermediate stays in LDS.
     ``tile_order`` / ``live_counts`` (the last 3x3 conv's lists of :func:`rpn_tile_live`) + ``background`` (this op's output for an
-    empty frame, [1, cout2, H, W]): only the live tiles are computed, the others copied (sec_conv1x1_chain_nhwc_tiles)."""
+    empty frame, [1, cout2, H, W]): only the live tiles are computed, the others copied (sec_conv1x1_chain_nhwc_tiles);
+    ``background=None`` (with ``x_live_only``): the others are not written at all -- 22 MB of copies per batch of 8 less -- and the
+    consumers read them from the empty frame's map (``lazy=`` of :func:`predict_select` / :func:`predict_decode`)."""
     rt.require_gpu(x, packed_w1, packed_w2, bias1)
     assert x.dim() == 4 and x.shape[1] == 128 and x.is_contiguous(memory_format=torch.channels_last)
     b, _, h, w = x.shape
     y = torch.empty((b, int(cout2), h, w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
     if tile_order is not None:
-        rt.require_gpu(tile_order, live_counts, background)
+        rt.require_gpu(tile_order, live_counts)
         assert tile_order.dtype == torch.int16 and tile_order.is_contiguous() and tuple(tile_order.shape) == (b, ((h + 7) // 8) * ((w + 15) // 16))
-        assert live_counts.dtype == torch.int32 and live_counts.numel() == b and background.dtype == x.dtype
-        assert background.numel() == h * w * int(cout2) and background.is_contiguous(memory_format=torch.channels_last)
+        assert live_counts.dtype == torch.int32 and live_counts.numel() == b
+        if background is None:
+            # lazy consumers (predict_select / predict_decode with ``lazy=``): the tiles outside the list stay UNWRITTEN
+            assert x_live_only, "conv1x1_chain without a background: the lists must be binding (x_live_only)"
+            if POISON_LAZY_OUTPUTS:
+                y.fill_(float("nan"))
+        else:
+            rt.require_gpu(background)
+            assert background.dtype == x.dtype and background.numel() == h * w * int(cout2) and background.is_contiguous(memory_format=torch.channels_last)
         # x_live_only (SEC_CHAIN_X_LIVE_ONLY): the producer of x wrote the live tiles of these lists only -- the lists are used whatever the live share
         rc = rt.lib().sec_conv1x1_chain_nhwc_tiles(rt.ptr(x), b, h, w, rt.ptr(packed_w1), rt.ptr(bias1), int(bool(relu1)) | (2 if x_live_only else 0), rt.ptr(packed_w2),
                                                    rt.ptr(bias2), int(cout2), rt.ptr(tile_order), rt.ptr(live_counts), rt.ptr(background),
@@ -1145,11 +1154,24 @@ def _strides5(t):
     return (ctypes.c_int64 * 5)(*[int(x) for x in t.stride()])
 
 
+def _lazy_args(view, lazy, pick):
+    """(tile_live pointer, background pointer of the same view) of a ``lazy=(tile_live [B, tiles] int16, pick-able background)``."""
+    tile_live, bg = lazy
+    b, a, h, w, _ = view.shape
+    assert tile_live.dtype == torch.int16 and tile_live.is_contiguous() and tuple(tile_live.shape) == (b, ((h + 7) // 8) * ((w + 15) // 16))
+    bgv = pick(bg)
+    assert bgv.dtype == view.dtype and tuple(bgv.shape[1:]) == tuple(view.shape[1:]) and tuple(bgv.stride()[1:]) == tuple(view.stride()[1:]), \
+        "the background view must have the strides of the head view (same channels-last layout)"
+    return tile_live, bgv
+
+
 @_traced("predict_select")
-def predict_select(cls, k, score_thr):
+def predict_select(cls, k, score_thr, lazy=None):
     """cls: [B, A, H, W, num_class] view (any strides).  -> (top_idx [B,k] int32 anchor ids sorted by descending
     score, top_score [B,k] sigmoid scores, top_label [B,k], counts [B] = entries with score >= score_thr).  The selection is
-    rows [0, counts[b]) of frame b (the reference masks by the threshold before its topk); rows behind them are unspecified."""
+    rows [0, counts[b]) of frame b (the reference masks by the threshold before its topk); rows behind them are unspecified.
+    ``lazy`` = (tile_live [B, tiles] int16 with bit 4 = "tile written", bg = the empty frame's view [1, A, H, W, num_class] with the
+    strides of ``cls``): elements of unwritten 8 x 16 tiles are read from ``bg`` (sec_predict_select_lazy)."""
     rt.require_gpu(cls)
     b, a, h, w, nc = cls.shape
     k = min(int(k), a * h * w, 1024)
@@ -1159,6 +1181,13 @@ def predict_select(cls, k, score_thr):
     top_label = torch.empty((b, k), dtype=torch.int32, device=dev)
     counts = torch.empty((b,), dtype=torch.int32, device=dev)
     keys = torch.empty((b * a * h * w,), dtype=torch.int32, device=dev)
+    if lazy is not None:
+        tile_live, bgv = _lazy_args(cls, lazy, lambda t: t)
+        rc = rt.lib().sec_predict_select_lazy(rt.ptr(cls), _strides5(cls), b, a, h, w, nc, k, float(score_thr), rt.ptr(keys), rt.ptr(top_idx),
+                                              rt.ptr(top_score), rt.ptr(top_label), rt.ptr(counts), rt.dtype_code(cls.dtype),
+                                              rt.ptr(tile_live), rt.ptr(bgv), rt.stream())
+        rt.check(rc, "sec_predict_select_lazy")
+        return top_idx, top_score, top_label, counts
     rc = rt.lib().sec_predict_select(rt.ptr(cls), _strides5(cls), b, a, h, w, nc, k, float(score_thr), rt.ptr(keys), rt.ptr(top_idx),
                                      rt.ptr(top_score), rt.ptr(top_label), rt.ptr(counts), rt.dtype_code(cls.dtype), rt.stream())
     rt.check(rc, "sec_predict_select")
@@ -1166,9 +1195,10 @@ def predict_select(cls, k, score_thr):
 
 
 @_traced("predict_decode")
-def predict_decode(box, dir_cls, anchors, top_idx, top_score, rotate=True):
+def predict_decode(box, dir_cls, anchors, top_idx, top_score, rotate=True, lazy=None):
     """box: [B,A,H,W,7] view, dir_cls: [B,A,H,W,bins] view or None, anchors [A*H*W,7] fp32.
-    -> (decoded [B,k,7] fp32, dets [B,k,6] fp32 NMS rows, dir_label [B,k] int32)."""
+    -> (decoded [B,k,7] fp32, dets [B,k,6] fp32 NMS rows, dir_label [B,k] int32).
+    ``lazy`` = (tile_live, (bg_box, bg_dir)): as in :func:`predict_select` (sec_predict_decode_lazy)."""
     rt.require_gpu(box, anchors, top_idx, top_score)
     b, a, h, w, code = box.shape
     assert code == 7 and anchors.dtype == torch.float32 and anchors.is_contiguous() and anchors.shape == (a * h * w, 7)
@@ -1179,6 +1209,15 @@ def predict_decode(box, dir_cls, anchors, top_idx, top_score, rotate=True):
     dlab = torch.empty((b, k), dtype=torch.int32, device=dev)
     if dir_cls is not None:
         assert dir_cls.dtype == box.dtype
+    if lazy is not None:
+        tile_live, bgb = _lazy_args(box, lazy, lambda t: t[0])
+        bgd = _lazy_args(dir_cls, lazy, lambda t: t[1])[1] if dir_cls is not None else None
+        rc = rt.lib().sec_predict_decode_lazy(rt.ptr(box), _strides5(box), rt.ptr(dir_cls), _strides5(dir_cls) if dir_cls is not None else None,
+                                              dir_cls.shape[-1] if dir_cls is not None else 0, b, a, h, w, k, rt.ptr(anchors),
+                                              rt.ptr(top_idx), rt.ptr(top_score), int(bool(rotate)), rt.ptr(dec), rt.ptr(dets), rt.ptr(dlab),
+                                              rt.dtype_code(box.dtype), rt.ptr(tile_live), rt.ptr(bgb), rt.ptr(bgd), rt.stream())
+        rt.check(rc, "sec_predict_decode_lazy")
+        return dec, dets, dlab
     rc = rt.lib().sec_predict_decode(rt.ptr(box), _strides5(box), rt.ptr(dir_cls),
                                      _strides5(dir_cls) if dir_cls is not None else None,
                                      dir_cls.shape[-1] if dir_cls is not None else 0, b, a, h, w, k, rt.ptr(anchors),

@@ -29,7 +29,7 @@ SYMBOLS = [
     "sec_pillar_scatter", "sec_pfn_fwd", "sec_pfn_fwd_slots", "sec_pfn_train_workspace_bytes", "sec_pfn_train_fwd", "sec_pfn_train_bwd", "sec_block_filter_workspace_bytes",
     "sec_voxel_block_filter_f32", "sec_bias_act_nhwc", "sec_conv2d_packed_weight_bytes",
     "sec_conv2d_pack_weight", "sec_conv2d_nhwc", "sec_split_f32_bf16x2", "sec_merge_bf16x2_f32", "sec_conv2d_nhwc_x3", "sec_conv2d_nhwc_x3_tiles", "sec_conv1x1_chain_x3", "sec_conv1x1_chain_nhwc", "sec_rotate_iou_f32", "sec_nms_workspace_bytes", "sec_nms_sorted_f32",
-    "sec_predict_select", "sec_predict_decode", "sec_predict_finalize",
+    "sec_predict_select", "sec_predict_select_lazy", "sec_predict_decode", "sec_predict_decode_lazy", "sec_predict_finalize",
     "sec_assign_targets_workspace_bytes", "sec_assign_targets_f32", "sec_assign_targets_per_class_f32",
     "sec_second_loss_workspace_bytes", "sec_second_loss_f32", "sec_heads_loss_supported", "sec_heads_loss_workspace_bytes",
     "sec_heads_loss_fwd", "sec_heads_loss_fwd_terms", "sec_heads_loss_bwd", "sec_set_fp32_mode", "sec_get_fp32_mode",
@@ -173,6 +173,8 @@ def lib():
         l.sec_nms_sorted_f32.argtypes = [vp, vp, ci, ci, ci, cf, ci, ci, cf, ci, vp, vp, vp, sz, vp]
         l.sec_predict_select.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, cf, vp, vp, vp, vp, vp, ci, vp]
         l.sec_predict_decode.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, ci, vp, vp, vp, ci, vp]
+        l.sec_predict_select_lazy.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, cf, vp, vp, vp, vp, vp, ci, vp, vp, vp]
+        l.sec_predict_decode_lazy.argtypes = [vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, ci, vp, vp, vp, ci, vp, vp, vp, vp]
         l.sec_predict_finalize.argtypes = [vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, cf, cf, ci, vp, vp, vp, vp, vp, vp]
         l.sec_assign_targets_workspace_bytes.argtypes = [ci, ci, ci]
         l.sec_assign_targets_f32.argtypes = [vp, ci, vp, vp, vp, vp, ci, ci, cf, cf, vp, vp, vp, vp, sz, vp]

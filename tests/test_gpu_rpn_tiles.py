@@ -213,6 +213,54 @@ def test_detector_with_and_without_background_tiles_gives_identical_detections()
         assert torch.equal(outs[1][k], outs[2][k]), k
 
 
+def test_lazy_heads_give_the_detections_of_the_materialised_head_tensor(monkeypatch):
+    """The fused 1x1 tail writes the head tensor's live tiles only (background == NULL) and select / decode read every other tile
+    from the empty frame's head map (sec_predict_select_lazy / _decode_lazy).  A network whose EMPTY regions score above the
+    threshold (random BatchNorm shifts, default heads: thousands of background candidates), unwritten tiles poisoned with NaN:
+    every output of the step must equal, bit for bit, the step that materialises the whole tensor (SEC_RPN_LAZY_HEADS=0)."""
+    from second_amd.models import SecondDetector, CAR_FHD
+    from second_amd import ops, synthetic as syn
+    clouds = [syn.syn_kitti_cloud(s) for s in range(3)]
+    pts, offs = syn.batch_clouds(clouds)
+    pts, offs = torch.from_numpy(pts).cuda(), torch.from_numpy(offs).cuda()
+    torch.manual_seed(0)
+    det = SecondDetector(dict(CAR_FHD, nms_score_threshold=0.3)).cuda().eval()
+    g = torch.Generator().manual_seed(2)
+    for m in det.modules():
+        if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+            m.running_mean.copy_(torch.empty(m.num_features).uniform_(-0.1, 0.1, generator=g))
+            m.running_var.copy_(torch.empty(m.num_features).uniform_(0.5, 1.5, generator=g))
+            m.bias.data.copy_(torch.empty(m.num_features).uniform_(-0.2, 0.3, generator=g))
+    det.rpn.conv_cls.bias.data.fill_(-0.2)                     # sigmoid(-0.2 + small) straddles 0.3 ... 0.5: background anchors are candidates
+    det.prepare_inference(torch.bfloat16)
+    det.calibrate(pts, offs)
+    with torch.no_grad():
+        with det.lazy_heads():                                   # the lazy form is really taken, and the head tensor really has holes
+            ops.POISON_LAZY_OUTPUTS = True
+            try:
+                vox = det.voxel_generator.generate_device(pts, offs, mean_features=4, sync=False, mean_dtype=torch.bfloat16)
+                preds = det.network_forward(vox["mean"], vox["coordinates"], 3, num_active_dev=vox["voxel_offsets"][3:])
+            finally:
+                ops.POISON_LAZY_OUTPUTS = False
+        assert "lazy_heads" in preds and torch.isnan(preds["cls_preds"].float()).any()
+        written = ((preds["lazy_heads"][0].int() >> 4) & 1).sum().item()
+        assert 0 < written < preds["lazy_heads"][0].numel()
+        ops.POISON_LAZY_OUTPUTS = True
+        try:
+            lazy = {k: v.clone() for k, v in det.forward_points(pts, offs, static=True).items() if isinstance(v, torch.Tensor)}
+        finally:
+            ops.POISON_LAZY_OUTPUTS = False
+        monkeypatch.setenv("SEC_RPN_LAZY_HEADS", "0")
+        eager = {k: v.clone() for k, v in det.forward_points(pts, offs, static=True).items() if isinstance(v, torch.Tensor)}
+        plain = det.network_forward(vox["mean"], vox["coordinates"], 3, num_active_dev=vox["voxel_offsets"][3:])
+        assert "lazy_heads" not in plain and not torch.isnan(plain["cls_preds"].float()).any()
+    assert int(eager["valid"].sum()) >= 20
+    bg_share = 1.0 - written / preds["lazy_heads"][0].numel()
+    assert bg_share > 0.3
+    for k in eager:
+        assert torch.equal(lazy[k], eager[k]), k
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 def test_prepared_rpn_follows_a_state_dict_loaded_later(dtype):
     """RPNInference keeps packed copies of its folded weights (MFMA slab order, gather permutation, hi | lo pairs of the fp32
