@@ -872,9 +872,13 @@ def time_dropin_fused(cpu_state, points, offsets, iters=60):
         compat.accelerate_model(net, dtype=forced, fp32_exact=exact, deferred=deferred)
         n_it = iters if not exact else max(10, iters // 4)
         with torch.no_grad():
-            for _ in range(30 if deferred else 5):        # (deferred: every lane captured, its pinned slots and allocator pools warm)
+            # warm-up by TIME, like the main harness: the network was just built on the host (GPU idle, clocks down); deferred mode
+            # also needs every lane captured, its pinned slots and allocator pools in place
+            tw, nw = time.perf_counter(), 0
+            while nw < (30 if deferred else 5) or time.perf_counter() - tw < (1.0 if not exact else 0.3):
                 res = net(example)
                 len(res[0])                               # (deferred results resolve when read)
+                nw += 1
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             if deferred:        # the reference's evaluate() loop: `detections += net(example)`, first read after the loop (train.py:519-539)

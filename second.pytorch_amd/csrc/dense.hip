@@ -1137,8 +1137,10 @@ __global__ __launch_bounds__(kBlock) void k_conv1x1_nhwc(const T *__restrict__ x
 // TILES: the workgroup's 128 pixels are an 8 x 16 tile of the [batch][h][w] map taken from the live-tile lists of sec_rpn_tile_live
 // (the last 3x3 conv's: a 1x1 conv reaches no farther), spread evenly over the XCDs; the workgroups behind them copy the other
 // tiles from `background` = this kernel's output for an empty frame ([h][w][N2]) -- the scheme of k_conv2d_halo_reg.
+// (64-channel heads, NT2 == 1: four workgroups per CU -- 1024 slots hold the 650-900 live tiles of a car.fhd batch of 8 in ONE round;
+// at three per CU the 862-tile list of the last conv left ~100 tiles for a second round on an otherwise empty chip)
 template <typename T, int NT2, bool TILES = false>    // NT2 = 32-wide cout tiles per wave in the second GEMM: cout2 = 64 * NT2
-__global__ __launch_bounds__(256, 3) void k_conv1x1_chain(const T *__restrict__ x, const T *__restrict__ w1pk,
+__global__ __launch_bounds__(256, NT2 == 1 ? 4 : 3) void k_conv1x1_chain(const T *__restrict__ x, const T *__restrict__ w1pk,
                                                           const float *__restrict__ b1, const T *__restrict__ w2pk,
                                                           const float *__restrict__ b2, T *__restrict__ y, long long m,
                                                           int relu1, int batch = 0, int h = 0, int w = 0, int per_xcd = 0,
