@@ -188,3 +188,25 @@ def test_training_outside_the_captured_step_keeps_the_original_forward():
     compat.accelerate_model(plain)                          # no train_dtype: training stays on the original forward
     plain(ex)
     assert plain._second_amd_engine.stats["original_calls"] == 1
+
+
+def test_fp16_features_with_a_scaled_loss():
+    """``train_dtype=torch.float16`` and a caller that scales its loss (apex ``amp.scale_loss``, train.py:318-320): the factor arrives at
+    the backward graph as the gradient of ``loss`` (a device scalar) and every parameter gradient carries it."""
+    from second_amd import compat
+    net = _net(5)
+    ex = _example(net, seeds=(6, 7))
+    compat.accelerate_model(net, train_dtype=torch.float16)
+    net(ex)["loss"].backward()
+    g1 = _grads(net)
+    for p in net.parameters():
+        p.grad = None
+    (net(ex)["loss"] * 64.0).backward()
+    g64 = _grads(net)
+    eng = net._second_amd_engine
+    assert eng.stats["train_calls"] == 2 and eng.stats["original_calls"] == 0 and eng.trainer.dtype == torch.float16
+    for n in g1:
+        assert torch.isfinite(g64[n]).all(), n
+        ref = 64.0 * g1[n]
+        # (the second forward saw BatchNorm statistics moved once by the first: a 1 % effect; fp16 rounding of the scaled gradients on top)
+        assert (g64[n] - ref).abs().max().item() <= 0.1 * ref.abs().max().item() + 1e-6, n
