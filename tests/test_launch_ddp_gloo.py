@@ -70,8 +70,10 @@ def _worker(rank, world, port, model_dir, q):
 
 
 def _worker_body(rank, world, port, model_dir, q):
+    # SEC_ACCELERATE_TRAIN: the launcher passes the REAL reference network through compat.accelerate_model(train_dtype=bf16).  On this
+    # CPU run every training call must be routed to the original forward (the captured step needs the GPU) without disturbing the loop
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                      SEC_LAUNCH_NO_ISOLATION="1")
+                      SEC_LAUNCH_NO_ISOLATION="1", SEC_ACCELERATE_TRAIN="bf16")
     for p in (ROOT, os.path.join(ROOT, "second.pytorch_amd"), os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
     torch.set_num_threads(4)
@@ -113,6 +115,10 @@ def _worker_body(rank, world, port, model_dir, q):
     gathered = [torch.zeros_like(flat) for _ in range(world)]
     dist.all_gather(gathered, flat)
     same = all(torch.equal(gathered[0], g) for g in gathered)
+    eng = getattr(net, "_second_amd_engine", None)
+    assert state.get("train_accelerated") and eng is not None and eng.train_dtype == torch.bfloat16
+    assert eng.trainer not in (None, False), eng.stats       # the real network's loss settings are inside the captured step's reach ...
+    assert eng.stats["original_calls"] == 3 and eng.stats["train_calls"] == 0, eng.stats      # ... and CPU examples take the original forward
     q.put((rank, same, state["allreduce_calls"], state["allreduce_bytes"], int(net.get_global_step()), built,
            T.torch.utils.data.DataLoader is torch.utils.data.DataLoader))
     dist.destroy_process_group()
