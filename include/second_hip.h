@@ -37,6 +37,12 @@ extern "C" {
 
 #define SEC_ABI_VERSION 7
 int sec_abi_version(void);
+/* Content checksum of `count` device tensors in one launch (+ one memset): sums [count][2] = (sum of the tensor's 32-bit words, sum of
+ * word * (index + 1)), both mod 2^64.  h_ptrs / h_nbytes are HOST arrays (4-byte aligned pointers, byte counts that are multiples of
+ * 4: SEC_E_UNSUPPORTED otherwise); the pointers become kernel arguments, so a captured launch keeps reading the same tensors.  What
+ * compat.accelerate_model compares every call against the values at adoption: the reference's own optimizers update weights through
+ * `.data` (torchplus/train/fastai_optim.py), which no version counter sees. */
+int sec_tensors_checksum(const void *const *h_ptrs, const long long *h_nbytes, int count, unsigned long long *sums, void *stream);
 /* last HIP error string seen by this library (thread-unsafe convenience for diagnostics) */
 const char *sec_last_error(void);
 /* measurement aid: the kernel instantiation (template arguments as rocprofv3 prints them, e.g.
@@ -66,6 +72,16 @@ const char *sec_last_kernel_name(void);
  *   dtype of the sparse stack that consumes it: the reference's `.to(dtype)` of example_convert_to_torch, train.py:36-38).
  * --------------------------------------------------------------------------------------------- */
 size_t sec_voxelize_workspace_bytes(int num_points, int batch, int max_voxels, int max_points);
+/* SimpleVoxel.forward alone (voxel_encoder.py:220-225), for callers that already HOLD the voxel tensor -- the example dict of
+ * VoxelNet.forward (voxelnet.py:339-375: voxels [n, max_points, num_features] fp32, num_points [n]): mean [n, mean_features] =
+ * sum over the point slots / num_points, stored as mean_dtype; same operation order as the fused epilogue of sec_voxelize_f32 (bit
+ * identical).  num_dev (optional device int): rows at or past it are written as zeros.
+ * sec_rows_differ_f32: flag[0] |= 1 if any of the `rows` rows of a [rows][n] differs (bit compare) from b [n]; the caller zeroes
+ * `flag`.  Used to compare the anchors an example carries (voxelnet.py:358, [B, A * 7]) with the table a captured pipeline decodes
+ * with, in one pass. */
+int sec_simple_voxel_f32(const float *voxels, const int *num_points, int n, const int *num_dev, int max_points, int num_features,
+                         int mean_features, void *mean, int mean_dtype, void *stream);
+int sec_rows_differ_f32(const float *a, long long rows, const float *b, long long n, int *flag, void *stream);
 int sec_voxelize_f32(const float *points, const int *point_offsets, int num_points, int num_features,
                      int batch, const float *h_range6, const float *h_voxel_size3, int max_points,
                      int max_voxels, int cap_mode, float *voxels, int *coors,

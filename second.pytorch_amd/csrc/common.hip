@@ -105,7 +105,7 @@ int exclusive_scan_i32(const int *in, int *out, long long n, int *total_out, int
         return check_launch();
     }
     if (n <= 0) {
-        if (total_out) return hip_ok(hipMemsetAsync(total_out, 0, sizeof(int), st));
+        if (total_out) return fill_words(total_out, sizeof(int), 0u, st);
         return SEC_OK;
     }
     int nblocks = div_up(n, kScanTile);
@@ -115,7 +115,80 @@ int exclusive_scan_i32(const int *in, int *out, long long n, int *total_out, int
     return check_launch();
 }
 
+__global__ __launch_bounds__(kBlock) void k_fill_words(unsigned *__restrict__ p, long long n, unsigned v) {
+    const long long stride = (long long)gridDim.x * kBlock;
+    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) p[i] = v;
+}
+int fill_words(void *p, size_t bytes, unsigned v, hipStream_t st) {
+    if (bytes == 0) return SEC_OK;
+    if ((bytes & 3) || ((size_t)p & 3)) return SEC_E_INVALID;
+    const long long n = (long long)(bytes / 4);
+    long long blocks = div_up(n, (long long)kBlock * 4);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_fill_words, dim3((unsigned)blocks), dim3(kBlock), 0, st, reinterpret_cast<unsigned *>(p), n, v);
+    return check_launch();
+}
+
+// ---- content checksum of a set of tensors (sec_tensors_checksum): sums[2 i] = sum of tensor i's 32-bit words, sums[2 i + 1] = sum of
+// word * (index + 1), both mod 2^64 -- order-independent accumulation (atomics), position-sensitive result.  One launch over all
+// tensors; the table of pointers travels as kernel arguments.
+constexpr int kCsumTensors = 168, kCsumChunk = 16384;       // words per workgroup
+struct CsumArgs {
+    const unsigned *p[kCsumTensors];
+    unsigned words[kCsumTensors];       // 32-bit words (a trailing 16-bit half, if any, is counted as one more word)
+    int blk0[kCsumTensors + 1];
+    int n;
+};
+__global__ __launch_bounds__(kBlock) void k_tensors_checksum(CsumArgs a, int slot0, unsigned long long *__restrict__ sums) {
+    int i = 0;
+    while (i + 1 < a.n && (int)blockIdx.x >= a.blk0[i + 1]) ++i;
+    const unsigned w0 = (unsigned)((int)blockIdx.x - a.blk0[i]) * kCsumChunk;
+    const unsigned w1 = w0 + kCsumChunk < a.words[i] ? w0 + kCsumChunk : a.words[i];
+    const unsigned *p = a.p[i];
+    unsigned long long s1 = 0ull, s2 = 0ull;
+    for (unsigned k = w0 + threadIdx.x; k < w1; k += kBlock) {
+        const unsigned long long v = p[k];
+        s1 += v;
+        s2 += v * (unsigned long long)(k + 1u);
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        s1 += __shfl_xor(s1, d, 64);
+        s2 += __shfl_xor(s2, d, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&sums[2 * (slot0 + i)], s1);
+        atomicAdd(&sums[2 * (slot0 + i) + 1], s2);
+    }
+}
+
 }  // namespace sec
+
+SEC_API int sec_tensors_checksum(const void *const *h_ptrs, const long long *h_nbytes, int count, unsigned long long *sums, void *stream) {
+    using namespace sec;
+    if (count < 0 || !sums || (count > 0 && (!h_ptrs || !h_nbytes))) return SEC_E_INVALID;
+    for (int i = 0; i < count; ++i)
+        if (!h_ptrs[i] || h_nbytes[i] < 0 || (h_nbytes[i] & 3) || ((size_t)h_ptrs[i] & 3) || h_nbytes[i] / 4 > 0xffffffffll) return SEC_E_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    // (zeroed by a kernel, not hipMemsetAsync: the memset NODE of a captured graph did not reliably precede the atomics on replay --
+    // the second replay of a drop-in session compared doubled sums)
+    int rc;
+    if ((rc = fill_words(sums, (size_t)count * 2 * sizeof(unsigned long long), 0u, st))) return rc;
+    for (int i0 = 0; i0 < count; i0 += kCsumTensors) {
+        CsumArgs a;
+        a.n = count - i0 < kCsumTensors ? count - i0 : kCsumTensors;
+        int blocks = 0;
+        for (int j = 0; j < a.n; ++j) {
+            a.p[j] = reinterpret_cast<const unsigned *>(h_ptrs[i0 + j]);
+            a.words[j] = (unsigned)(h_nbytes[i0 + j] / 4);
+            a.blk0[j] = blocks;
+            blocks += (int)div_up((long long)a.words[j], kCsumChunk);
+        }
+        a.blk0[a.n] = blocks;
+        if (blocks > 0) hipLaunchKernelGGL(k_tensors_checksum, dim3(blocks), dim3(kBlock), 0, st, a, i0, sums);
+    }
+    return check_launch();
+}
 
 SEC_API int sec_abi_version(void) { return SEC_ABI_VERSION; }
 SEC_API const char *sec_last_error(void) { return sec::g_last_error; }

@@ -193,6 +193,10 @@ constexpr int kScanItems = 8;                      // per thread
 constexpr int kScanTile = kBlock * kScanItems;     // 2048 per block
 inline size_t scan_scratch_ints(long long n) { return (size_t)div_up(n, kScanTile) + 8; }
 int exclusive_scan_i32(const int *in, int *out, long long n, int *total_out, int *scratch, hipStream_t st);
+// `bytes` (a multiple of 4) of `p` (4-byte aligned) := the 32-bit word `v`, by a KERNEL.  Use this, not hipMemsetAsync, in anything
+// that may be captured into a hipGraph: on ROCm 7.2 the runtime's memset NODE misbehaves on replay (scatter.hip: a non-zero pattern
+// after some tens of replays; round 6: atomics that followed it accumulated onto the previous replay's values).
+int fill_words(void *p, size_t bytes, unsigned v, hipStream_t st);
 
 // voxelize.hip: hash table left in the workspace of sec_voxelize_f32 (see sec_rulebook_subm3d_after_voxelize)
 bool vox_slots_of(const void *ws, size_t bytes, int n, int batch, int max_voxels, int max_points, const int **count,

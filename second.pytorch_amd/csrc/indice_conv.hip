@@ -2481,7 +2481,7 @@ static int run_bwd(const void *features, int n_in, int cin, const void *weight, 
     }
     if (dweight) {
         // (dweight_zeroed: the forward's sec_pack_conv_weight_train zeroed it -- one memset node per layer and step less)
-        if (!dweight_zeroed && (rc = hip_ok(hipMemsetAsync(dweight, 0, (size_t)kvol * cin * cout * sizeof(float), st)))) return rc;
+        if (!dweight_zeroed && (rc = fill_words(dweight, (size_t)kvol * cin * cout * sizeof(float), 0u, st))) return rc;
         if (n_out > 0 && !launch_wgrad_tiled<T>(features, dout, nbr_out, n_out, cin, cout, kvol, dweight, st)) {
             int rows_per_chunk = 512;
             hipLaunchKernelGGL(k_conv_wgrad<T>, dim3(div_up(n_out, rows_per_chunk), kvol), dim3(kBlock), 0, st,

@@ -564,9 +564,9 @@ SEC_API int sec_pfn_train_bwd(const float *voxels, const int *num_points, const 
     if (!workspace || workspace_bytes < sec_pfn_train_workspace_bytes(num_pillars, channels)) return SEC_E_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     if (num_pillars == 0) {
-        int rc = hip_ok(hipMemsetAsync(dweight_t, 0, sizeof(float) * kPfnIn * channels, st));
-        if (!rc) rc = hip_ok(hipMemsetAsync(dgamma, 0, sizeof(float) * channels, st));
-        if (!rc) rc = hip_ok(hipMemsetAsync(dbeta, 0, sizeof(float) * channels, st));
+        int rc = fill_words(dweight_t, sizeof(float) * kPfnIn * channels, 0u, st);
+        if (!rc) rc = fill_words(dgamma, sizeof(float) * channels, 0u, st);
+        if (!rc) rc = fill_words(dbeta, sizeof(float) * channels, 0u, st);
         return rc;
     }
     const int blocks = pfn_blocks(num_pillars);

@@ -1276,7 +1276,7 @@ SEC_API int sec_rulebook_conv3d_build(const int *indices, int n_in, const int *n
     const long long fill_b = prefill_nbr_in ? (long long)n_in * g.kvol : 0;
     if (nc == 0) {
         if (fill_a + fill_b > 0) rb_init(nullptr, 0, 0, prefill_nbr_out, fill_a, -1, prefill_nbr_in, fill_b, -1, st);
-        return hip_ok(hipMemsetAsync(num_out, 0, 2 * sizeof(int), st));
+        return fill_words(num_out, 2 * sizeof(int), 0u, st);
     }
     rb_init(w.keys, w.table, kEmptyKey, w.vals, w.table, kEmptyI32, w.ticket, w.ctl_words, 0, st);
     int nb = div_up(nc, kBlock);

@@ -670,7 +670,7 @@ SEC_API int sec_assign_targets_f32(const float *anchors, int n_anchor, const flo
     int *gt_max = ar.take<int>(n_gt > 0 ? n_gt : 1);
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    if ((rc = hip_ok(hipMemsetAsync(gt_max, 0, (size_t)(n_gt > 0 ? n_gt : 1) * sizeof(int), st)))) return rc;
+    if ((rc = fill_words(gt_max, (size_t)(n_gt > 0 ? n_gt : 1) * sizeof(int), 0u, st))) return rc;     // (a kernel: this runs inside captured training steps)
     dim3 grid(div_up(n_anchor, kBlock), batch);
     const AssignRange all{0, n_anchor, 0};
     hipLaunchKernelGGL(k_assign_max, grid, dim3(kBlock), 0, st, anchors, n_anchor, gt_boxes, gt_classes, gt_offsets, all, a_max,
@@ -703,7 +703,7 @@ SEC_API int sec_assign_targets_per_class_f32(const float *anchors, int n_anchor,
     // one best-overlap word per ground truth.  assign_per_class: a box belongs to one class, so the ranges touch disjoint
     // words; assign_all (class id 0 = every ground truth): the best overlap is taken over ALL anchors (target_ops.py:108-112),
     // hence every range's first pass before any second pass.
-    if ((rc = hip_ok(hipMemsetAsync(gt_max, 0, (size_t)(n_gt > 0 ? n_gt : 1) * sizeof(int), st)))) return rc;
+    if ((rc = fill_words(gt_max, (size_t)(n_gt > 0 ? n_gt : 1) * sizeof(int), 0u, st))) return rc;     // (a kernel: this runs inside captured training steps)
     for (int pass = 0; pass < 2; ++pass)
         for (int c = 0; c < n_class; ++c) {
             const AssignRange R{h_class_anchor_begin[c], h_class_anchor_begin[c + 1], h_class_ids[c]};

@@ -788,7 +788,7 @@ SEC_API int sec_voxelize_f32(const float *points, const int *point_offsets, int 
         hipLaunchKernelGGL(k_vox_hash, dim3(nb), dim3(kBlock), 0, st, points, point_offsets, p, w.keys, w.vals, w.pslot);
         hipLaunchKernelGGL(k_vox_flag_scan, dim3(div_up(num_points, kBlock * kFlagItems)), dim3(kBlock), 0, st, w.pslot, w.vals, num_points, w.rank,
                            reinterpret_cast<unsigned long long *>(w.ctl + 4), w.ctl, w.total);
-    } else if ((rc = hip_ok(hipMemsetAsync(w.total, 0, sizeof(int), st)))) return rc;
+    } else if ((rc = fill_words(w.total, sizeof(int), 0u, st))) return rc;
     if (!fused_frames)
         hipLaunchKernelGGL(k_vox_frames, dim3(1), dim3(64), 0, st, point_offsets, w.rank, w.total, p, w.base,
                            w.break_idx, voxel_offsets);
@@ -845,5 +845,81 @@ SEC_API int sec_voxelize_f32(const float *points, const int *point_offsets, int 
                                    (__hip_bfloat16 *)mean);
         }
     }
+    return check_launch();
+}
+
+namespace sec {
+// SimpleVoxel.forward (second/pytorch/models/voxel_encoder.py:220-225) on a voxel tensor that ARRIVES from the host side of the
+// boundary (the example dict of VoxelNet.forward: `voxels` [N, T, F], `num_points` [N]) -- the drop-in sessions' first step.  Same
+// arithmetic as k_vox_mean above (slot order, __fadd_rn / __fdiv_rn): the features equal the fused voxeliser epilogue's, bit for
+// bit.  Rows at or past the live count (`num_dev`) are written as zeros.
+template <typename OT>
+__global__ __launch_bounds__(kBlock) void k_simple_voxel(const float *__restrict__ voxels, const int *__restrict__ num_points, int n,
+                                                        const int *__restrict__ num_dev, int T, int F, int nf, OT *__restrict__ mean) {
+    const long long g = (long long)blockIdx.x * kBlock + threadIdx.x;
+    if (g >= (long long)n * nf) return;
+    const int vid = (int)(g / nf), f = (int)(g - (long long)vid * nf);
+    const int live = num_dev ? (*num_dev < n ? *num_dev : n) : n;
+    float m = 0.0f;
+    if (vid < live) {
+        const float *src = voxels + (size_t)vid * T * F + f;
+        float s = 0.0f;
+        for (int t = 0; t < T; ++t) s = __fadd_rn(s, src[(size_t)t * F]);
+        m = __fdiv_rn(s, (float)num_points[vid]);
+    }
+    if constexpr (std::is_same<OT, float>::value) mean[g] = m;
+    else if constexpr (std::is_same<OT, __half>::value) mean[g] = __float2half_rn(m);
+    else mean[g] = __float2bfloat16(m);
+}
+
+// flag[0] |= 1 when any of the `rows` rows of `a` [rows][n] differs from `b` [n] (bit compare: NaN equals the same NaN).  The drop-in
+// sessions' check of the example's anchors against the anchor table a graph was captured with -- one launch, one pass over `a`.
+__global__ __launch_bounds__(kBlock) void k_rows_differ(const unsigned *__restrict__ a, const unsigned *__restrict__ b, unsigned n,
+                                                       int *__restrict__ flag) {
+    // blockIdx.y = row; 16-byte loads where the row length allows it (no 64-bit modulo per element: the first form spent 25 us on it)
+    const unsigned *row = a + (size_t)blockIdx.y * n;
+    const unsigned stride = gridDim.x * kBlock;
+    unsigned diff = 0u;
+    if ((n & 3u) == 0u && ((((size_t)a) | ((size_t)b)) & 15) == 0) {
+        const uint4 *r4 = reinterpret_cast<const uint4 *>(row), *b4 = reinterpret_cast<const uint4 *>(b);
+        for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < (n >> 2); i += stride) {
+            const uint4 x = r4[i], y = b4[i];
+            diff |= (x.x ^ y.x) | (x.y ^ y.y) | (x.z ^ y.z) | (x.w ^ y.w);
+        }
+    } else {
+        for (unsigned i = blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) diff |= row[i] ^ b[i];
+    }
+    if (__ballot(diff != 0u) != 0ull && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+}  // namespace sec
+
+SEC_API int sec_simple_voxel_f32(const float *voxels, const int *num_points, int n, const int *num_dev, int max_points, int num_features,
+                                 int mean_features, void *mean, int mean_dtype, void *stream) {
+    if (n < 0 || max_points <= 0 || num_features <= 0 || mean_features <= 0 || mean_features > num_features || !mean ||
+        (n > 0 && (!voxels || !num_points)))
+        return SEC_E_INVALID;
+    if (mean_dtype < SEC_F32 || mean_dtype > SEC_BF16) return SEC_E_UNSUPPORTED;
+    if (n == 0) return SEC_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(div_up((long long)n * mean_features, kBlock));
+    if (mean_dtype == SEC_F32)
+        hipLaunchKernelGGL(k_simple_voxel<float>, grid, dim3(kBlock), 0, st, voxels, num_points, n, num_dev, max_points, num_features, mean_features, (float *)mean);
+    else if (mean_dtype == SEC_F16)
+        hipLaunchKernelGGL(k_simple_voxel<__half>, grid, dim3(kBlock), 0, st, voxels, num_points, n, num_dev, max_points, num_features, mean_features, (__half *)mean);
+    else
+        hipLaunchKernelGGL(k_simple_voxel<__hip_bfloat16>, grid, dim3(kBlock), 0, st, voxels, num_points, n, num_dev, max_points, num_features, mean_features,
+                           (__hip_bfloat16 *)mean);
+    return check_launch();
+}
+
+SEC_API int sec_rows_differ_f32(const float *a, long long rows, const float *b, long long n, int *flag, void *stream) {
+    if (rows < 0 || n <= 0 || n > 0x7fffffffll || rows > 65535 || !flag || (rows > 0 && (!a || !b))) return SEC_E_INVALID;
+    if (rows == 0) return SEC_OK;
+    // rows * n * 4 bytes must be 16-byte aligned per row for the vector path: n % 4 == 0 and a 16-byte aligned base (torch allocations are)
+    long long bx = div_up(n / 4 > 0 ? n / 4 : n, (long long)kBlock * 2);
+    if (bx > 256) bx = 256;
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(k_rows_differ, dim3((unsigned)bx, (unsigned)rows), dim3(kBlock), 0, (hipStream_t)stream, reinterpret_cast<const unsigned *>(a),
+                       reinterpret_cast<const unsigned *>(b), (unsigned)n, flag);
     return check_launch();
 }

@@ -226,8 +226,9 @@ class _Session:
         self.coors = torch.zeros((cap, 4), dtype=torch.int32, device=dev)
         self.n_dev = torch.zeros((1,), dtype=torch.int32, device=dev)
         self.anchors = anchors0.detach().float().contiguous().clone()
-        # the example's anchors [B, A, 7] land here every call (one copy) and are compared with the session's table INSIDE the graph
-        self.anchors_in = self.anchors.unsqueeze(0).repeat(batch, 1, 1)
+        # 1 when the anchors of the example in flight differ from the session's table: written by ONE compare launch per call
+        # (ops.rows_differ_, outside the graph: the example's tensor has no fixed address), read -- and cleared -- by the graph
+        self.anchor_flag = torch.zeros((1,), dtype=torch.int32, device=dev)
         self.caps = None            # static_out_rows of the strided layers, in module order
         self.graph = self.outs = None
         self.event = torch.cuda.Event()
@@ -259,13 +260,21 @@ class _Session:
         for m, c in zip(self._strided(), self.caps or []):
             m.static_out_rows = c
         dt = det._infer_dtype
+        # the content check of the network's tensors (FusedVoxelNet._checksum) at the head of the graph.  (Its first form, ~45 us of small
+        # torch launches, was tried on a side branch of the captured graph -- fork / join on a second stream: the synchronous call
+        # gained nothing and three asynchronous lanes LOST a fifth of their throughput, 16.8 k -> 13.2 k frames/s -- a branched hipGraph
+        # serialises against the other lanes' graphs.  Kept linear; the check itself became one launch instead.)
+        stale = self.eng.weights_changed_flag()
         if det.pillars:
             feats = det.voxel_feature_extractor(self.voxels, self.num_points, self.coors, out_dtype=dt, num_dev=self.n_dev)
         else:
             nf = det.cfg["num_point_features"]      # SimpleVoxel (voxel_encoder.py:207-225), summed in fp32 whatever the storage type
-            feats = self.voxels[:, :, :nf].float().sum(1) / self.num_points.float().unsqueeze(1)
-            if dt is not None:
-                feats = feats.to(dt)
+            if self.voxels.dtype == torch.float32 and self.voxels.is_cuda:
+                feats = ops.simple_voxel(self.voxels, self.num_points, nf, out_dtype=dt or torch.float32, num_dev=self.n_dev)   # one launch
+            else:
+                feats = self.voxels[:, :, :nf].float().sum(1) / self.num_points.float().unsqueeze(1)
+                if dt is not None:
+                    feats = feats.to(dt)
         with det.lazy_heads():          # the head tensor's background tiles stay unwritten: predict_device reads them from the empty frame's map
             preds = det.network_forward(feats, self.coors, b, num_active_dev=self.n_dev)
         out = det.predict_device(preds, b, self.anchors)
@@ -273,12 +282,10 @@ class _Session:
         packed = torch.cat([out["boxes"].reshape(b, -1).float(), out["scores"].float(), out["labels"].float(),
                             out["valid"].float()], 1)
         counters = torch.stack([num[1] for num, _ in checks]).int() if checks else torch.zeros((1,), dtype=torch.int32, device=packed.device)
-        # content check of the network's tensors (FusedVoxelNet._checksum): their norms now against the norms at adoption, inside the
-        # graph -- in-place updates that bump no version counter (`p.data.copy_()`, `p.data.mul_()`) show up here
-        stale = self.eng.weights_changed_flag()
-        # a freed-and-reallocated anchor tensor can reuse an address and a version counter (identity proves nothing): content, every call
-        other_anchors = (self.anchors_in != self.anchors.unsqueeze(0)).any().int().reshape(1)
-        flags = torch.cat([counters.reshape(-1), other_anchors, stale])         # [overflow counters..., anchors differ, weights changed]
+        # (the content check above: in-place updates that bump no version counter -- `p.data.copy_()`, `p.data.mul_()` -- show up in it)
+        # (the anchors: compared by content, every call -- a freed-and-reallocated tensor can reuse an address and a version counter)
+        flags = torch.cat([counters.reshape(-1), self.anchor_flag, stale])      # [overflow counters..., anchors differ, weights changed]
+        self.anchor_flag.zero_()                                                # ready for the next call's compare
         return {"packed": packed, "counters": counters, "limits": [int(c) for _, c in checks], "post": int(out["scores"].shape[1]), "flags": flags}
 
     def build(self, graph):
@@ -358,17 +365,29 @@ class FusedVoxelNet:
                 w[0].device)
 
     def _checksum(self):
-        """L2 norm of every floating-point tensor of the three sub-modules as one fp32 device vector (a multi-tensor launch per dtype)."""
-        groups = {}
+        """Content fingerprint of every non-empty tensor of the three sub-modules, on the device: a position-weighted 64-bit sum of the
+        bytes (ops.tensors_checksum: ONE launch over all ~140 tensors; the first form -- a multi-tensor L2 norm per dtype, stacked and
+        compared -- cost ~45 us of small launches per call).  Tensors whose byte size is not a multiple of 4 are padded views no network
+        here has; they fall back to their fp32 sum."""
+        ts, odd = [], []
         for t in self._watch:
-            if t.is_floating_point() and t.numel():
-                groups.setdefault(t.dtype, []).append(t.detach())
-        parts = [torch.stack(torch._foreach_norm(ts)).float() for ts in groups.values()]
+            if t.numel() == 0:
+                continue
+            t = t.detach()
+            if t.is_cuda and t.is_contiguous() and (t.numel() * t.element_size()) % 4 == 0 and t.data_ptr() % 4 == 0:
+                ts.append(t)
+            else:
+                odd.append(t)
+        parts = []
+        if ts:
+            parts.append(ops.tensors_checksum(ts).reshape(-1))
+        if odd:
+            parts.append(torch.stack([t.double().sum() for t in odd]).view(torch.int64))
         return torch.cat(parts) if len(parts) != 1 else parts[0]
 
     def weights_changed_flag(self):
-        """int32[1] on the device: 1 when any tensor's norm differs (bit pattern: NaN-safe) from its norm at adoption."""
-        return (self._checksum().view(torch.int32) != self._ref_sum.view(torch.int32)).any().int().reshape(1)
+        """int32[1] on the device: 1 when any tensor's fingerprint differs from its fingerprint at adoption."""
+        return (self._checksum() != self._ref_sum).any().int().reshape(1)
 
     def run_dtype(self):
         """None = fp32 pipeline; torch.float16 / torch.bfloat16 = 16-bit features (BatchNorm statistics, biases, box decode and
@@ -528,7 +547,10 @@ class FusedVoxelNet:
         sess.num_points[:n].copy_(example["num_points"], non_blocking=True)
         sess.coors[:n].copy_(example["coordinates"], non_blocking=True)
         sess.n_dev.fill_(n)
-        sess.anchors_in.copy_(example["anchors"].reshape(sess.anchors_in.shape), non_blocking=True)
+        anc = example["anchors"]
+        if anc.dtype != torch.float32 or not anc.is_contiguous():
+            anc = anc.float().contiguous()
+        ops.rows_differ_(sess.anchor_flag, anc, sess.anchors)
 
     def _static(self, det, example):
         batch = example["anchors"].shape[0]

@@ -152,6 +152,7 @@ class _TrainSession:
         self.reg_targets = torch.zeros((batch, n_anchor, 7), dtype=torch.float32, device=dev)
         self.importance = torch.ones((batch, n_anchor), dtype=torch.float32, device=dev)
         self.g_static = torch.ones((), dtype=torch.float32, device=dev)
+        self.anchor_flag = torch.zeros((1,), dtype=torch.int32, device=dev)
         self.caps = list(strided_caps)
         self.bucket = eng.bucket
         self.serial = 0
@@ -393,7 +394,10 @@ class FusedTrainStep:
             sess = self._session(det, example, batch)
             self._fill(sess, example)
             nc = sess.counters.numel()
-            sess.dev_flags[nc:].copy_((anchors != sess.anchors.unsqueeze(0)).any().int().reshape(1))
+            anc = anchors if (anchors.dtype == torch.float32 and anchors.is_contiguous()) else anchors.float().contiguous()
+            sess.anchor_flag.zero_()
+            ops.rows_differ_(sess.anchor_flag, anc, sess.anchors)               # one pass over the example's anchors
+            sess.dev_flags[nc:].copy_(sess.anchor_flag)
             sess.serial += 1
             loss, scalars = _Replay.apply(sess, *sess.bucket.params)
             sess.dev_flags[:nc].copy_(sess.counters.reshape(-1))

@@ -351,6 +351,48 @@ def rulebook_chain(indices0, batch_size, shape0, convs, n_dev=None, site_table=N
     return {"levels": out, "site_map": smap, "workspace": ws}
 
 
+def simple_voxel(voxels, num_points, mean_features, out_dtype=None, num_dev=None):
+    """SimpleVoxel.forward (voxel_encoder.py:220-225) of a voxel tensor the caller already holds ([N, T, F] fp32, num_points [N] int32):
+    -> [N, mean_features] in ``out_dtype`` (default fp32), one launch, the operation order of the voxeliser's fused epilogue
+    (sec_simple_voxel_f32).  ``num_dev``: device int32[1], rows at or past it come out as zeros."""
+    rt.require_gpu(voxels, num_points)
+    assert voxels.dtype == torch.float32 and voxels.dim() == 3 and voxels.is_contiguous()
+    assert num_points.dtype == torch.int32 and num_points.is_contiguous() and num_points.numel() == voxels.shape[0]
+    n, t, f = voxels.shape
+    out_dtype = out_dtype or torch.float32
+    mean = torch.empty((n, int(mean_features)), dtype=out_dtype, device=voxels.device)
+    rt.check(rt.lib().sec_simple_voxel_f32(rt.ptr(voxels), rt.ptr(num_points), n, rt.ptr(num_dev), t, f, int(mean_features), rt.ptr(mean),
+                                           rt.dtype_code(out_dtype), rt.stream()), "sec_simple_voxel_f32")
+    return mean
+
+
+def tensors_checksum(tensors):
+    """int64 [len(tensors), 2] on the device: (sum of 32-bit words, sum of word * (index + 1)) mod 2^64 of every tensor's bytes, ONE
+    launch for all of them (sec_tensors_checksum; contiguous CUDA tensors whose byte size is a multiple of 4).  Captured in a graph, the
+    launch keeps reading the same storages."""
+    import ctypes
+    n = len(tensors)
+    for t in tensors:
+        rt.require_gpu(t)
+        assert t.is_contiguous()
+    sums = torch.empty((n, 2), dtype=torch.int64, device=tensors[0].device)
+    ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in tensors])
+    nbytes = (ctypes.c_longlong * n)(*[t.numel() * t.element_size() for t in tensors])
+    rt.check(rt.lib().sec_tensors_checksum(ptrs, nbytes, n, rt.ptr(sums), rt.stream()), "sec_tensors_checksum")
+    return sums
+
+
+def rows_differ_(flag, a, b):
+    """flag[0] |= 1 (int32 device tensor, zeroed by the caller) when any row of ``a`` [rows, ...] differs from ``b`` [...] -- contiguous
+    fp32 tensors, bit compare, one launch (sec_rows_differ_f32)."""
+    rt.require_gpu(flag, a, b)
+    assert a.dtype == b.dtype == torch.float32 and a.is_contiguous() and b.is_contiguous() and flag.dtype == torch.int32
+    n = b.numel()
+    assert n > 0 and a.numel() % n == 0
+    rt.check(rt.lib().sec_rows_differ_f32(rt.ptr(a), a.numel() // n, rt.ptr(b), n, rt.ptr(flag), rt.stream()), "sec_rows_differ_f32")
+    return flag
+
+
 # ----------------------------------------------------------------------------- indice_conv
 _conv_profiler = None
 

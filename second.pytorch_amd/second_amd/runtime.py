@@ -19,7 +19,7 @@ _ERRORS = {-1: "SEC_E_INVALID (bad argument)", -2: "SEC_E_WORKSPACE (workspace t
 
 # every symbol include/second_hip.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
-    "sec_abi_version", "sec_last_error", "sec_last_kernel_name", "sec_voxelize_workspace_bytes", "sec_voxelize_f32",
+    "sec_abi_version", "sec_last_error", "sec_last_kernel_name", "sec_tensors_checksum", "sec_voxelize_workspace_bytes", "sec_voxelize_f32", "sec_simple_voxel_f32", "sec_rows_differ_f32",
     "sec_rulebook_workspace_bytes", "sec_rulebook_subm3d", "sec_rulebook_subm3d_after_conv", "sec_rulebook_subm3d_after_voxelize",
     "sec_rulebook_conv3d_build",
     "sec_rulebook_conv3d_tables", "sec_rulebook_sorted_workspace_bytes", "sec_rulebook_conv3d_build_sorted",
@@ -114,6 +114,9 @@ def lib():
         vp, ci, cf, sz, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_int64
         l.sec_voxelize_workspace_bytes.argtypes = [ci, ci, ci, ci]
         l.sec_voxelize_f32.argtypes = [vp, vp, ci, ci, ci, vp, vp, ci, ci, ci, vp, vp, vp, vp, vp, ci, ci, vp, sz, vp]
+        l.sec_tensors_checksum.argtypes = [vp, vp, ci, vp, vp]
+        l.sec_simple_voxel_f32.argtypes = [vp, vp, ci, vp, ci, ci, ci, vp, ci, vp]
+        l.sec_rows_differ_f32.argtypes = [vp, ctypes.c_longlong, vp, ctypes.c_longlong, vp, vp]
         l.sec_rulebook_workspace_bytes.argtypes = [ci, ci, ci]
         l.sec_rulebook_subm3d.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp, vp, vp, vp, sz, vp]
         l.sec_rulebook_subm3d_after_conv.argtypes = [vp, ci, vp, ci, vp, vp, vp, vp, vp, sz, ci, vp, vp, vp, ci, vp]

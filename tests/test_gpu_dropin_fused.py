@@ -99,7 +99,7 @@ def test_fp32_forward_example_is_served_by_one_graph_and_returns_the_module_path
     with torch.no_grad():
         got2 = net(ex2)
         want2 = net._second_amd_original_forward(ex2)
-    assert eng.stats["captures"] == 1 and eng.stats["fused_calls"] == 2 and len(eng._sessions) == 1
+    assert eng.stats["captures"] == 1 and eng.stats["fused_calls"] == 2 and len(eng._sessions) == 1, eng.stats
     _same(got2, want2)
     for g, k in zip(got, keep):
         assert torch.equal(g["box3d_lidar"], k), "a returned tensor aliases the session's static buffers"
