@@ -396,6 +396,38 @@ def test_whole_training_step_captured_in_one_graph_replays_and_learns():
         assert torch.isfinite(p).all()
 
 
+def test_captured_step_has_no_memory_of_the_previous_batch():
+    """Scratch that a step zeroes and then accumulates into with atomics (the target assigner's best-overlap word per ground truth)
+    must be zeroed by a KERNEL inside a captured graph: ROCm 7.2's memset node does not reliably run before the atomics on replay
+    (round 6: found on the drop-in sessions' checksum).  With the learning rate at zero the weights stand still, so the loss of a
+    batch must not depend on which batch was replayed before it -- ground truth A, then B (other boxes), then A again."""
+    from second_amd import synthetic as syn
+    from second_amd.models import SecondDetector, CAR_FHD
+    from second_amd.training import DeviceTrainer
+    pts, offs, gt_a, goffs = _train_inputs()
+    gt_b = torch.from_numpy(np.concatenate([syn.syn_kitti_boxes(s, 24)[12:] for s in (5, 6)]).astype(np.float32)).cuda()   # 12 other boxes per frame
+    torch.manual_seed(0)
+    tr = DeviceTrainer(SecondDetector(CAR_FHD).cuda(), amp_dtype=torch.bfloat16, lr=0.0, weight_decay=0.0)
+    replay = tr.capture_step(pts, offs, gt_a, goffs)
+    a1 = replay(pts, offs, gt_a, goffs).clone()
+    b1 = replay(pts, offs, gt_b, goffs).clone()
+    a2 = replay(pts, offs, gt_a, goffs).clone()
+    b2 = replay(pts, offs, gt_b, goffs).clone()
+    for _ in range(30):
+        replay(pts, offs, gt_b, goffs)
+    a3 = replay(pts, offs, gt_a, goffs).clone()
+    torch.cuda.synchronize()
+    assert not torch.allclose(a1, b1, rtol=1e-3), "the two ground-truth sets must give different losses"
+    torch.testing.assert_close(a2, a1, rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(b2, b1, rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(a3, a1, rtol=1e-5, atol=1e-7)
+    # and the eager step of a fresh trainer on the same weights agrees
+    torch.manual_seed(0)
+    tr2 = DeviceTrainer(SecondDetector(CAR_FHD).cuda(), amp_dtype=torch.bfloat16, lr=0.0, weight_decay=0.0)
+    _, e_a, _ = tr2.forward_loss(pts, offs, gt_a, goffs)
+    torch.testing.assert_close(a1.float(), e_a.float(), rtol=2e-3, atol=1e-5)
+
+
 def test_captured_step_follows_the_learning_rate_and_leaves_the_state_as_it_found_it():
     """The captured kernels read the optimizer's hyper-parameters from device memory: a one-cycle schedule (the reference changes
     lr every step, car.fhd.config:171-188) is followed by replays, no re-capture; lr = 0 leaves the weights alone.  capture_step
