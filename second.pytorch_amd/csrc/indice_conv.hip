@@ -1177,8 +1177,11 @@ static void launch_mfma(const void *feat, long long n_feat, const void *packed, 
                     // + one barrier per three offsets (FL 512, six-slot weight ring): 23.5 -> 22.1 us stand-alone
                     if (n_out < rows_min() && conv_variant() == 1) {      // mid-size layers: 128-row workgroups
                         if (rows_footprint() == 4) { SEC_BUF(4, 4, 3, 27); }          // the form with a barrier per offset (13.3 vs 12.65 us)
-                        else if (bal) { SEC_BUFM(3, 4, 3, 1 + 128 + 512 + 2048); }
-                        else { SEC_BUFM(3, 4, 3, 1 + 128 + 512); }
+                        // (two waves per SIMD asked for, not three: 63 KB of LDS per four-wave workgroup allow two workgroups per CU whatever
+                        // the registers do -- with MINW = 3 hipcc squeezed the kernel into 122 VGPRs + 32 AGPR spill slots for nothing and
+                        // warned that it could not meet the occupancy)
+                        else if (bal) { SEC_BUFM(3, 4, 2, 1 + 128 + 512 + 2048); }
+                        else { SEC_BUFM(3, 4, 2, 1 + 128 + 512); }
                     } else if (rows_footprint() == 1) { SEC_BUF(4, 8, 3, 27); }
                     else if (rows_footprint() == 3) { SEC_BUFM(3, 8, 3, 1 + 128); }
                     else if (bal) { SEC_BUFM(3, 8, 3, 1 + 128 + 512 + 2048); }
