@@ -859,9 +859,9 @@ def time_dropin_fused(cpu_state, points, offsets, iters=60):
         if os.environ.get("SEC_BENCH_DROPIN_VARIANTS") and tag not in os.environ["SEC_BENCH_DROPIN_VARIANTS"].split(","):
             continue                                       # (one variant alone: diagnostics, and the child process below)
         if deferred and not os.environ.get("SEC_BENCH_DROPIN_VARIANTS"):
-            # the asynchronous engine in a FRESH process -- what evaluate() is: one engine per process.  (In a process that ran another
-            # engine before, the same loop measures 11 k instead of 14-16 k frames/s; an earlier engine's buffers and graphs being
-            # collected does not change that -- not understood, so the leg measures the deployment case and says so.)
+            # the asynchronous engine in a FRESH process -- what evaluate() is: one engine per process.  (Until its lanes got
+            # high-priority streams -- models.lane_stream: a hardware queue each, whatever streams the process created before -- the same
+            # loop measured 11-13 k instead of 17 k frames/s in a process that had run another engine first.)
             import subprocess
             try:
                 r = subprocess.run([sys.executable, os.path.abspath(__file__), "--dropin-leg", tag], capture_output=True, text=True, timeout=240,

@@ -232,7 +232,8 @@ class _Session:
         self.caps = None            # static_out_rows of the strided layers, in module order
         self.graph = self.outs = None
         self.event = torch.cuda.Event()
-        self.stream = torch.cuda.Stream(device=dev) if eng.deferred else None     # asynchronous calls: this lane's own stream
+        from .models import lane_stream
+        self.stream = lane_stream(dev) if eng.deferred else None     # asynchronous calls: this lane's own (high-priority: own hardware queue) stream
         self.slots, self.grow_to = [], None
 
     def take_slot(self):
