@@ -123,7 +123,7 @@ def time_rpn_conv(det, batch, reps=100):
 
 
 PLAN_NAMES = {0: "k_conv_generic", 1: "k_conv_tiled", 2: "k_conv_c4", 3: "k_conv_mfma", 4: "k_conv_mfma_sk", 5: "k_conv_mfma_sks",
-              6: "k_conv_rows", 7: "k_conv_rows", 8: "k_conv_rows", 9: "k_conv_rows", 10: "k_conv_rows_reg", 11: "k_conv_rows_buf", 12: "k_conv_c4_mfma", 13: "k_conv_rows_m2", 14: "k_conv_rows_lds"}
+              6: "k_conv_rows", 7: "k_conv_rows", 8: "k_conv_rows", 9: "k_conv_rows", 10: "k_conv_rows_reg", 11: "k_conv_rows_buf", 12: "k_conv_c4_mfma", 13: "k_conv_rows_m2", 14: "k_conv_rows_lds", 15: "k_conv_rows_ks"}
 
 
 def kernel_table(det, points, offsets, reps=30):
@@ -235,7 +235,7 @@ def kernel_table(det, points, offsets, reps=30):
             s_ = elt(feat.dtype)
             plan = ops.indice_conv_plan(cin, cout, k, cap, feat.dtype, kw.get("out_dtype") or feat.dtype, kw.get("packed") is not None)
             ent.update(bytes=s_ * (p_ * cin + m * cout) + 8 * p_ + s_ * k * cin * cout, flop=2.0 * p_ * cin * cout,
-                       kernel=(ops.last_kernel_name() if plan in (11, 13, 14) else "") or PLAN_NAMES.get(plan, str(plan)),
+                       kernel=(ops.last_kernel_name() if plan in (11, 13, 14, 15) else "") or PLAN_NAMES.get(plan, str(plan)),
                        detail=f"{cin}->{cout} k{k} {m} rows {p_} pairs")
         elif name == "pfn_forward":
             if isinstance(a[1], dict):           # pfn_forward_slots(points, vox, ...): pillars read through the voxeliser's point lists

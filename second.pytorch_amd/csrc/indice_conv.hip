@@ -951,6 +951,10 @@ static void launch_rows_buf(const void *feat, long long n_feat, const void *pack
                        (relu & 1) | (xcd << 16), (T *)out);
 }
 
+#ifdef SEC_CONV_EXPERIMENTS   // round-6 A/B form: the offsets of a row tile split over three wave groups (k_conv_rows_ks): measured slower
+#include "../../tools/kernel_experiments/indice_conv_rows_r06.inc"
+#endif
+
 #ifdef SEC_CONV_EXPERIMENTS   // round-3 A/B forms: two row tiles per wave (k_conv_rows_m2), input planes in LDS windows (k_conv_rows_lds)
 #include "../../tools/kernel_experiments/indice_conv_rows_r03.inc"
 #endif
@@ -1045,7 +1049,7 @@ static int conv_variant() {
 
 // kernel ids reported by sec_indice_conv_fwd_plan
 enum { PLAN_GENERIC = 0, PLAN_TILED = 1, PLAN_C4 = 2, PLAN_MFMA_WAVE = 3, PLAN_MFMA_SK = 4, PLAN_MFMA_SKS = 5, PLAN_ROWS = 6,
-       PLAN_ROWS_COMPACT = 7, PLAN_ROWS_TOUCH = 8, PLAN_ROWS_COMPACT_TOUCH = 9, PLAN_ROWS_REG = 10, PLAN_ROWS_BUF = 11, PLAN_C4_MFMA = 12, PLAN_ROWS_M2 = 13, PLAN_ROWS_LDS = 14, PLAN_EXPERIMENT = 99 };
+       PLAN_ROWS_COMPACT = 7, PLAN_ROWS_TOUCH = 8, PLAN_ROWS_COMPACT_TOUCH = 9, PLAN_ROWS_REG = 10, PLAN_ROWS_BUF = 11, PLAN_C4_MFMA = 12, PLAN_ROWS_M2 = 13, PLAN_ROWS_LDS = 14, PLAN_ROWS_KS = 15, PLAN_EXPERIMENT = 99 };
 
 // Row count from which the buffer-load row-split kernel replaces split-K in the automatic choice (the
 // row-split chain of 27 offsets needs enough workgroups to fill the chip, split-K has a 4x shorter chain per wave)
@@ -1061,6 +1065,11 @@ static int rows_footprint() {
 }
 // 1: the automatic choice would take the two-tiles-per-wave kernel (k_conv_rows_m2, experiment builds) for the 64 -> 64 layers: measured slower
 static int m2_auto() { return 0; }
+static bool ks_auto() {                      // SEC_CONV_KS=1 (experiment builds): k_conv_rows_ks for the mid-size 64 -> 64 layers (A/B)
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("SEC_CONV_KS"); v = e ? atoi(e) != 0 : 0; }
+    return v != 0;
+}
 static bool rows_balance() { return true; }   // rows per wave chosen on the device so that a launch fills every CU once (round 3: kept)
 static bool buf_shape(int cin, int cout, int kvol) {
     if (kvol == 3) return cin == 64 && cout == 64;
@@ -1077,6 +1086,11 @@ static int rows_plan(int cin, int cout, int kvol, int n_out, bool same_dtype) {
         if (cin == 64 && cout == 64 && kvol == 27 && v == 46) return PLAN_ROWS_LDS;          // input planes staged in LDS (round 3)
         if (cin == 64 && cout == 64 && kvol == 27 && (v == 41 || v == 42 || v == 43 || (v == 1 && m2_auto() && n_out >= rows_min())))
             return PLAN_ROWS_M2;                                                           // two row tiles per wave (round 3)
+#endif
+        // offsets split over wave groups (k_conv_rows_ks, round 6, experiment builds): 50 forces it for any row count, SEC_CONV_KS=1 makes
+        // it the automatic choice of the mid-size 64 -> 64 layers (measured slower than the four-wave form of k_conv_rows_buf)
+#ifdef SEC_CONV_EXPERIMENTS
+        if (cin == 64 && cout == 64 && kvol == 27 && (v == 50 || (v == 1 && n_out >= kRowsMinSmall && n_out < rows_min() && ks_auto()))) return PLAN_ROWS_KS;
 #endif
         if (v == 22 || (((v >= 16 && v <= 28) || v == 44 || v == 45) && cin == 64 && cout == 64 && kvol == 27)) return PLAN_ROWS_BUF;
         if (v >= 36 && v <= 40) return PLAN_ROWS_BUF;
@@ -1122,6 +1136,14 @@ static void launch_mfma(const void *feat, long long n_feat, const void *packed, 
             }
             if (rp == PLAN_ROWS_LDS && n_feat * CIN * (long long)sizeof(T) < 0x7fffffffll) {
                 launch_rows_lds<T>(feat, n_feat, packed, nbr, n_out, num_out_dev, scale, shift, relu, out, st);
+                return;
+            }
+        }
+#endif
+#ifdef SEC_CONV_EXPERIMENTS
+        if constexpr (CIN == 64 && COUT == 64) {
+            if (rp == PLAN_ROWS_KS && n_feat * CIN * (long long)sizeof(T) < 0x7fffffffll) {
+                launch_rows_ks<T, 4, 3>(feat, n_feat, packed, nbr, n_out, num_out_dev, scale, shift, relu, out, st);
                 return;
             }
         }

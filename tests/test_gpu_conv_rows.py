@@ -20,8 +20,9 @@ PLAN_ROWS_BUF = 11
 ROW_VARIANTS = [(None, 11), (22, 11)]
 # Round 3 added 41 = two row tiles per wave (k_conv_rows_m2, plan 13) and 46 = input planes staged in LDS windows (k_conv_rows_lds,
 # plan 14: on the first-touch-ordered rows of the `layer` fixture its windows mostly MISS -- the exact gather fallback).
+# Round 6 added 50 = the offsets of a row tile split over three wave groups (k_conv_rows_ks, plan 15; measured slower, not shipped).
 EXPERIMENT_VARIANTS = [(9, 6), (10, 7), (11, 8), (12, 9), (13, 10), (14, 10), (15, 10), (16, 11), (17, 11), (18, 11), (19, 11),
-                       (20, 11), (21, 11), (23, 11), (27, 11), (28, 11), (41, 13), (46, 14)]
+                       (20, 11), (21, 11), (23, 11), (27, 11), (28, 11), (41, 13), (46, 14), (50, 15)]
 
 
 def dev(a, dtype=None):
@@ -167,6 +168,15 @@ def test_conv_rows_ragged_tail_device_count_and_empty_rows(ops, layer):
                                   num_out_dev=dev(np.array([m], np.int32)))
             np.testing.assert_array_equal(out[:m].float().cpu().numpy(), ref[:m], err_msg=f"variant {variant} static n_out {m}")
     ops.indice_conv_set_variant(-1)
+    # the mid-size form (four-wave workgroups, rows per wave chosen on the device): ragged counts, static capacity
+    for m in (8193, 20001, 24127, 39000):
+        assert ops.indice_conv_plan(64, 64, 27, m, dtype) == PLAN_ROWS_BUF
+        out = ops.indice_conv(f_t, w_t, dev(nbr[:m]), m, packed=packed, shift=dev(shift), relu=True)
+        np.testing.assert_array_equal(out.float().cpu().numpy(), ref[:m], err_msg=f"mid-size n_out {m}")
+        table = dev(np.concatenate([nbr[:m], garbage]))
+        out = ops.indice_conv(f_t, w_t, table, m + 512, packed=packed, shift=dev(shift), relu=True,
+                              num_out_dev=dev(np.array([m], np.int32)))
+        np.testing.assert_array_equal(out[:m].float().cpu().numpy(), ref[:m], err_msg=f"mid-size static n_out {m}")
     torch.cuda.synchronize()
 
 
