@@ -142,7 +142,10 @@ struct Conv2dParams {
 
 // Live share (of 256) up to which a conv / the fused tail follows its live-tile list; above it every tile is taken in the plain order
 // (computing a background tile is always correct).  SEC_RPN_LIST_MAX_LIVE=<percent> overrides (read once, before the first launch).
-__device__ int g_list_max_live_q8 = 192;
+// 225 / 256 = 88 % since round 6 (192 = 75 % before): on the bench's dense seeded scene, whose last two convs have 76-78 % of their tiles
+// live, 75 % gave 8 000 frames/s and 82 / 88 / 94 / 100 % 8 130-8 180 (gpurun r06_x, two runs each); with every tile live the lists
+// cost what they cannot save (480 instead of 427 us for the six convs + tail, round 4), so the switch stays below 100 %.
+__device__ int g_list_max_live_q8 = 225;
 
 static void apply_list_threshold_env() {
     static bool done = false;
@@ -577,7 +580,7 @@ __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(con
         if (tile_order)
             for (int f = 0; f < p.batch; ++f) n_live += live_counts[f];
         // A scene whose sites reach (almost) every tile gains nothing from the lists and would pay their dependent lookups in every
-        // workgroup's prologue (all tiles live: 480 instead of 427 us for the six convs + tail): above three quarters live, every
+        // workgroup's prologue (all tiles live: 480 instead of 427 us for the six convs + tail): above g_list_max_live_q8 / 256 live, every
         // tile is convolved in the plain order -- computing a background tile is always correct.
         if (tile_order && n_live * 256 <= ntile * g_list_max_live_q8) {
             listed = true;
@@ -1159,7 +1162,7 @@ __global__ __launch_bounds__(256, NT2 == 1 ? 4 : 3) void k_conv1x1_chain(const T
         if (local >= per_xcd) return;
         int n_live = 0;
         for (int f = 0; f < batch; ++f) n_live += live_counts[f];
-        // above three quarters live: every tile in the plain order (k_conv2d_halo_reg) -- unless x holds its live tiles ONLY (relu1 bit 1,
+        // above g_list_max_live_q8 / 256 live: every tile in the plain order (k_conv2d_halo_reg) -- unless x holds its live tiles ONLY (relu1 bit 1,
         // SEC_CHAIN_X_LIVE_ONLY: a lazy producer left the others unwritten; the lists name exactly the tiles that exist)
         const bool lists = (relu1 & 2) != 0 || n_live * 256 <= ntile * g_list_max_live_q8;
         const int per_live = (n_live + 7) >> 3;

@@ -823,6 +823,18 @@ SEC_PACKED_F32_OK __global__ __launch_bounds__(WAVES * 64, MINW) void k_conv_row
         if (C::KS > 2) areg[(k) % DIST][2 % C::KS] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o_ + 64, 0, 0);      \
         if (C::KS > 3) areg[(k) % DIST][3 % C::KS] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o_ + 96, 0, 0);      \
     }
+#ifdef SEC_CONV_ABLATIONS   // FL bit 12: the weight slices are not fetched (the ring holds whatever the registers do): what does the W stream cost?
+#define SEC_WLOAD(g)                                                                                                  \
+    {                                                                                                                 \
+        _Pragma("unroll") for (int j_ = 0; j_ < 3; ++j_) {                                                            \
+            if constexpr ((FL & 4096) != 0) { ww0[j_] = u32x4_t{(unsigned)lane, 0u, 0u, 0u}; if (NBW > 1) ww1[j_] = ww0[j_]; }  \
+            else {                                                                                                    \
+            ww0[j_] = wpv[(size_t)(3 * (g) + j_) * C::BSLOT];                                                         \
+            if (NBW > 1) ww1[j_] = wpv[(size_t)(3 * (g) + j_) * C::BSLOT + 64];                                       \
+            }                                                                                                         \
+        }                                                                                                             \
+    }
+#else
 #define SEC_WLOAD(g)                                                                                                  \
     {                                                                                                                 \
         _Pragma("unroll") for (int j_ = 0; j_ < 3; ++j_) {                                                            \
@@ -830,6 +842,7 @@ SEC_PACKED_F32_OK __global__ __launch_bounds__(WAVES * 64, MINW) void k_conv_row
             if (NBW > 1) ww1[j_] = wpv[(size_t)(3 * (g) + j_) * C::BSLOT + 64];                                       \
         }                                                                                                             \
     }
+#endif
 #define SEC_WSTORE(g)                                                                                                 \
     {                                                                                                                 \
         _Pragma("unroll") for (int j_ = 0; j_ < 3; ++j_) {                                                            \
@@ -1090,9 +1103,9 @@ static int rows_plan(int cin, int cout, int kvol, int n_out, bool same_dtype) {
         // offsets split over wave groups (k_conv_rows_ks, round 6, experiment builds): 50 forces it for any row count, SEC_CONV_KS=1 makes
         // it the automatic choice of the mid-size 64 -> 64 layers (measured slower than the four-wave form of k_conv_rows_buf)
 #ifdef SEC_CONV_EXPERIMENTS
-        if (cin == 64 && cout == 64 && kvol == 27 && (v == 50 || (v == 1 && n_out >= kRowsMinSmall && n_out < rows_min() && ks_auto()))) return PLAN_ROWS_KS;
+        if (cin == 64 && cout == 64 && kvol == 27 && (v == 50 || (v >= 71 && v <= 73) || (v == 1 && n_out >= kRowsMinSmall && n_out < rows_min() && ks_auto()))) return PLAN_ROWS_KS;
 #endif
-        if (v == 22 || (((v >= 16 && v <= 28) || v == 44 || v == 45) && cin == 64 && cout == 64 && kvol == 27)) return PLAN_ROWS_BUF;
+        if (v == 22 || (((v >= 16 && v <= 28) || v == 44 || v == 45 || (v >= 60 && v <= 67)) && cin == 64 && cout == 64 && kvol == 27)) return PLAN_ROWS_BUF;
         if (v >= 36 && v <= 40) return PLAN_ROWS_BUF;
         if (v == 1 && n_out >= rows_min()) return PLAN_ROWS_BUF;
         // 64 -> 64, 27 offsets, 8 k .. 40 k rows (the 23 k-row stage of car.fhd at batch 8): four-wave workgroups (128 rows) fill the
@@ -1143,6 +1156,11 @@ static void launch_mfma(const void *feat, long long n_feat, const void *packed, 
 #ifdef SEC_CONV_EXPERIMENTS
         if constexpr (CIN == 64 && COUT == 64) {
             if (rp == PLAN_ROWS_KS && n_feat * CIN * (long long)sizeof(T) < 0x7fffffffll) {
+#ifdef SEC_CONV_ABLATIONS
+                if (conv_variant() == 71) { launch_rows_ks<T, 4, 3, 2>(feat, n_feat, packed, nbr, n_out, num_out_dev, scale, shift, relu, out, st); return; }
+                if (conv_variant() == 72) { launch_rows_ks<T, 4, 3, 1>(feat, n_feat, packed, nbr, n_out, num_out_dev, scale, shift, relu, out, st); return; }
+                if (conv_variant() == 73) { launch_rows_ks<T, 4, 3, 3>(feat, n_feat, packed, nbr, n_out, num_out_dev, scale, shift, relu, out, st); return; }
+#endif
                 launch_rows_ks<T, 4, 3>(feat, n_feat, packed, nbr, n_out, num_out_dev, scale, shift, relu, out, st);
                 return;
             }
@@ -1179,6 +1197,16 @@ static void launch_mfma(const void *feat, long long n_feat, const void *packed, 
                     case 24: SEC_BUF(4, 8, 3 + 4, 27); return;
                     case 25: SEC_BUF(4, 8, 3 + 8, 27); return;
                     case 26: SEC_BUF(4, 8, 3 + 16, 27); return;
+                    // 60-65 (round 6): the shipped four-wave (23 k rows) and eight-wave (56 k rows) forms without the W stream (FL 4096), without
+                    // gathers that touch memory (FL 4), without both
+                    case 60: launch_rows_buf<T, CIN, COUT, 3, 4, 2, 1 + 128 + 512 + 2048 + 4096, 27>(feat, n_feat, packed, nbr, n_out, num_out_dev, scale, shift, relu, out, st); return;
+                    case 61: launch_rows_buf<T, CIN, COUT, 3, 4, 2, 1 + 128 + 512 + 2048 + 4, 27>(feat, n_feat, packed, nbr, n_out, num_out_dev, scale, shift, relu, out, st); return;
+                    case 62: launch_rows_buf<T, CIN, COUT, 3, 4, 2, 1 + 128 + 512 + 2048 + 4096 + 4, 27>(feat, n_feat, packed, nbr, n_out, num_out_dev, scale, shift, relu, out, st); return;
+                    case 63: launch_rows_buf<T, CIN, COUT, 3, 8, 3, 1 + 128 + 512 + 2048 + 4096, 27>(feat, n_feat, packed, nbr, n_out, num_out_dev, scale, shift, relu, out, st); return;
+                    case 64: launch_rows_buf<T, CIN, COUT, 3, 8, 3, 1 + 128 + 512 + 2048 + 4, 27>(feat, n_feat, packed, nbr, n_out, num_out_dev, scale, shift, relu, out, st); return;
+                    case 65: launch_rows_buf<T, CIN, COUT, 3, 8, 3, 1 + 128 + 512 + 2048 + 4096 + 4, 27>(feat, n_feat, packed, nbr, n_out, num_out_dev, scale, shift, relu, out, st); return;
+                    case 66: launch_rows_buf<T, CIN, COUT, 3, 4, 2, 1 + 128 + 512 + 2048, 27>(feat, n_feat, packed, nbr, n_out, num_out_dev, scale, shift, relu, out, st); return;   // the plain four-wave form, any row count
+                    case 67: launch_rows_buf<T, CIN, COUT, 3, 8, 3, 1 + 128 + 512 + 2048, 27>(feat, n_feat, packed, nbr, n_out, num_out_dev, scale, shift, relu, out, st); return;   // the plain eight-wave form, any row count
                     case 44: launch_rows_buf<T, CIN, COUT, 3, 8, 3, 1 + 128 + 512 + 4, 27>(feat, n_feat, packed, nbr, n_out, num_out_dev, scale, shift, relu, out, st); return;
                     case 45: launch_rows_buf<T, CIN, COUT, 3, 8, 3, 1 + 128 + 512 + 16, 27>(feat, n_feat, packed, nbr, n_out, num_out_dev, scale, shift, relu, out, st); return;
 #endif
