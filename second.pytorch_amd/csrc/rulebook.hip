@@ -1004,7 +1004,50 @@ __device__ __forceinline__ int chain_rank(const ChainLevel &L, int b, int z, int
     return r < L.out_cap ? r : -1;             // a rank past the capacity is not a row (overflow is reported by num_out[1])
 }
 
-constexpr int kTabU = 4;                       // table items per thread of k_chain_tables
+// Ranks of the THREE cells (z, y, x0), (z, y, x0 + 1), (z, y, x0 + 2) of level L in one round of loads: they are consecutive bits of
+// the bitmap, so one 32-byte block + its prefix answers all three (a second block when the triple straddles a 256-cell boundary:
+// 2 of 256 positions).  The tables of a 3x3x3 kernel ask for exactly such triples (dx = -1, 0, +1 of one (dz, dy)): a third of the
+// loads of three bm_rank1 calls, and k_chain_tables is bound by what its lookups put through the vector L1.
+__device__ __forceinline__ int rank_in_block(const uint4 &a, const uint4 &b, int prefix, unsigned lin) {
+    const unsigned wi = (lin >> 5) & 7u, bit = 1u << (lin & 31u);
+    const unsigned w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    unsigned word = 0u;
+    int r = prefix;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        word = wi == (unsigned)q ? w[q] : word;
+        r += wi > (unsigned)q ? __popc(w[q]) : 0;
+    }
+    return (word & bit) ? r + __popc(word & (bit - 1u)) : -1;
+}
+__device__ __forceinline__ void chain_rank3(const ChainLevel &L, int b, int z, int y, int x0, int (&out)[3]) {
+    out[0] = out[1] = out[2] = -1;
+    if ((unsigned)z >= (unsigned)L.shape[0] || (unsigned)y >= (unsigned)L.shape[1]) return;
+    const int xa = x0 < 0 ? 0 : x0, xb = x0 + 2 < L.shape[2] ? x0 + 2 : L.shape[2] - 1;
+    if (xa > xb) return;
+    const unsigned row = (((unsigned)b * L.shape[0] + z) * L.shape[1] + y) * L.shape[2];
+    const size_t blk_a = (row + (unsigned)xa) >> 8, blk_b = (row + (unsigned)xb) >> 8;
+    const uint4 a0 = *reinterpret_cast<const uint4 *>(L.bm + blk_a * kBmBlk), a1 = *reinterpret_cast<const uint4 *>(L.bm + blk_a * kBmBlk + 4);
+    const int pa = L.prefix8[blk_a];
+    uint4 b0 = a0, b1 = a1;
+    int pb = pa;
+    if (blk_b != blk_a) {
+        b0 = *reinterpret_cast<const uint4 *>(L.bm + blk_b * kBmBlk);
+        b1 = *reinterpret_cast<const uint4 *>(L.bm + blk_b * kBmBlk + 4);
+        pb = L.prefix8[blk_b];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int x = x0 + i;
+        if ((unsigned)x >= (unsigned)L.shape[2]) continue;
+        const unsigned lin = row + (unsigned)x;
+        const bool in_a = (lin >> 8) == blk_a;
+        const int r = rank_in_block(in_a ? a0 : b0, in_a ? a1 : b1, in_a ? pa : pb, lin);
+        out[i] = r < L.out_cap ? r : -1;           // a rank past the capacity is not a row (overflow is reported by num_out[1])
+    }
+}
+
+constexpr int kTabU = 4;                       // table items (kernel of 3 offsets) / x-triples (27 offsets) per thread of k_chain_tables
 __global__ __launch_bounds__(kBlock) void k_chain_tables(ChainParams P) {
     const int blk = blockIdx.x;
     if (blk < P.cand_blks) {
@@ -1045,6 +1088,49 @@ __global__ __launch_bounds__(kBlock) void k_chain_tables(ChainParams P) {
     const int kv = subm ? 27 : L.kvol;
     int *dst = subm ? L.subm_nbr : L.nbr_out;
     const long long t0 = (long long)(blk - (subm ? L.sblk0 : L.cblk0)) * (kBlock * kTabU) + threadIdx.x;
+    if (kv == 27) {
+        // 27 offsets: a thread takes kTabU x-TRIPLES (row, dz, dy) -- one bitmap block + one prefix per three table entries -- and the
+        // wave hands its 192 consecutive entries to memory through LDS as three full 256-byte stores (a thread's own three entries are
+        // 12 bytes apart from its neighbour's)
+        __shared__ int s_tri[kBlock / 64][192];
+        if (t0 - threadIdx.x >= (long long)live * 9) return;     // whole workgroups past the live rows leave here
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        const long long n_ent = (long long)live * 27;
+        int4 c3[kTabU];
+        int r3[kTabU], j3[kTabU];
+#pragma unroll
+        for (int u = 0; u < kTabU; ++u) {
+            const long long t = t0 + (long long)u * kBlock;
+            const int r = (int)(t / 9);
+            r3[u] = r; j3[u] = (int)(t - (long long)r * 9);
+            c3[u] = *reinterpret_cast<const int4 *>(L.out_indices + (size_t)(r < live ? r : 0) * 4);
+        }
+        int v3[kTabU][3];
+#pragma unroll
+        for (int u = 0; u < kTabU; ++u) {
+            const int dz = j3[u] / 3, dy = j3[u] - dz * 3;
+            int z, y, x0;
+            if (subm) { z = c3[u].y + dz - 1; y = c3[u].z + dy - 1; x0 = c3[u].w - 1; }
+            else { z = 2 * c3[u].y - L.pad[0] + dz; y = 2 * c3[u].z - L.pad[1] + dy; x0 = 2 * c3[u].w - L.pad[2]; }
+            if (r3[u] < live) chain_rank3(T, c3[u].x, z, y, x0, v3[u]);
+            else v3[u][0] = v3[u][1] = v3[u][2] = -1;
+            if (subm && j3[u] == 4) v3[u][1] = r3[u];              // the centre offset is the row itself
+        }
+#pragma unroll
+        for (int u = 0; u < kTabU; ++u) {
+            const long long e0 = (t0 - lane + (long long)u * kBlock) * 3;      // first entry of this wave's 192
+#pragma unroll
+            for (int i = 0; i < 3; ++i) s_tri[wv][3 * lane + i] = v3[u][i];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int v = s_tri[wv][i * 64 + lane];
+                if (e0 + i * 64 + lane < n_ent) dst[e0 + i * 64 + lane] = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        return;
+    }
     if (t0 >= (long long)live * kv) return;                      // (uniform enough: whole workgroups past the live rows leave here)
     int4 c[kTabU];
     int rr[kTabU], kk[kTabU];
@@ -1603,9 +1689,10 @@ SEC_API int sec_rulebook_chain_sorted(const int *indices0, int n0, const int *n0
         tile0 += w.ntiles[l];
         L.nbr_out = h_nbr_out[l - 1]; L.out_indices = h_out_indices[l - 1]; L.num_out = h_num_out[l - 1];
         // tables launch: SubM table of this level, then its conv table (levels >= 2 are built output side), sized for the capacity
-        L.sblk0 = blk0; L.sblks = L.subm_nbr ? div_up((long long)L.out_cap * 27, kBlock * kTabU) : 0;
+        // (27 offsets: a thread takes x-triples, nine per row; 3 offsets: single entries)
+        L.sblk0 = blk0; L.sblks = L.subm_nbr ? div_up((long long)L.out_cap * 9, kBlock * kTabU) : 0;
         blk0 += L.sblks;
-        L.cblk0 = blk0; L.cblks = l >= 2 ? div_up((long long)L.out_cap * L.kvol, kBlock * kTabU) : 0;
+        L.cblk0 = blk0; L.cblks = l >= 2 ? div_up((long long)L.out_cap * (L.kvol == 27 ? 9 : L.kvol), kBlock * kTabU) : 0;
         blk0 += L.cblks;
     }
     P.map_blk0 = blk0;
