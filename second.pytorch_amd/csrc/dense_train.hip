@@ -9,6 +9,7 @@
 //
 // replacing MIOpen's igemm_wrw / igemm_bwd kernels and ~8 torch kernels per BatchNorm + ReLU pair of the reference path.
 #include "common.hpp"
+#include <stdlib.h>
 #include <type_traits>
 
 namespace sec {
@@ -198,6 +199,178 @@ __global__ __launch_bounds__(256, 2) void k_conv2d_wgrad3x3(const T *__restrict_
             const int ci = cih + (t >> 1) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h, co = coh + (t & 1) * 32 + r;
             dst[(size_t)ci * C + co] = acc[t >> 1][t & 1][i];
         }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The same weight gradient with a whole KERNEL ROW per workgroup (round 6; 3x3, maps at least 16 pixels wide).  In the form above a
+// workgroup is one tap: every step moves 32 KB (64 pixels of x and of dy) through the L2 -> L1 path for 64 MFMAs -- 64 FLOP per byte,
+// and nine workgroups read the same pixels; the launch ran at what that path delivers (~10 TB/s: 62.9 us for 41.5 GFLOP at batch 4,
+// 0.26 of the matrix peak, MFMA busy 0.3).  Here a workgroup owns the three taps (ty, -1), (ty, 0), (ty, +1) of a pixel run: it loads
+// the run of x ONCE (66 pixels: the 64 of the step and one on either side) and dy once, keeps THREE images of x in LDS -- image tx
+// holds x[p + tx] at pixel p, zeros where p + tx leaves the row: a loaded chunk of pixel q goes to image 0 at q, to image -1 at q + 1
+// unless q ends a row, to image +1 at q - 1 unless q starts one, so every position has exactly one writer -- and multiplies each of
+// them with the same dy fragments: 192 MFMAs per 33 KB, 190 FLOP per byte.  Twelve 32 x 32 accumulators per wave (192 registers: one
+// wave per SIMD, one workgroup per CU, 128 KB of LDS double-buffered), same partial layout [slice][tap][ci][co], same reduce.
+// Taken from ~160 k pixels on (wgrad_row_form below: what it gains and why not more).
+template <typename T>
+__global__ __launch_bounds__(256, 1) void k_conv2d_wgrad3x3_row(const T *__restrict__ x, const T *__restrict__ dy, float *__restrict__ part,
+                                                                int B, int H, int W, int steps, long long P, int slices) {
+    constexpr int C = 128, PIXB = C * 2, IMG = 64 * PIXB;  // 256 bytes per pixel, 16 KB per 64-pixel image
+    extern __shared__ __attribute__((aligned(16))) char wg_smem[];   // [2 buffers][x(-1) | x(0) | x(+1) | dy][IMG]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    // workgroup id = (group of 8 slices) * 24 + row * 8 + xcd: the three rows of a slice on ONE XCD (they share dy and two thirds of x)
+    const int within = blockIdx.x % 24, slice = (blockIdx.x / 24) * 8 + within % 8;
+    const int trow = within / 8, ty = trow - 1;
+    if (slice >= slices) return;
+    const long long step0 = (long long)slice * steps;
+    const long long total_steps = (P + 63) / 64;
+    const int nst = (int)(step0 + steps <= total_steps ? steps : (total_steps > step0 ? total_steps - step0 : 0));
+    const unsigned tensor_bytes = (unsigned)(P * PIXB);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(x), 0, (int)tensor_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc(const_cast<T *>(dy), 0, (int)tensor_bytes, 0x00020000);
+    const int cq = tid & 15, pl = tid >> 4;                // chunk cq of the pixels pl, pl + 16, pl + 32, pl + 48 of a step
+    const bool ex_lo = pl == 0, ex_hi = pl == 15;          // ... and of the pixel in front of the step / behind it
+    unsigned fq;
+    int fx, fy, fb;
+    {
+        fq = (unsigned)(step0 * 64 + pl);
+        const unsigned HW = (unsigned)H * (unsigned)W;
+        fb = (int)(fq / HW);
+        const unsigned rem = fq - (unsigned)fb * HW;
+        fy = (int)(rem / (unsigned)W);
+        fx = (int)(rem - (unsigned)fy * (unsigned)W);
+    }
+    int fs = 0;
+    struct Stage { tu32x4 x[5], d[4]; unsigned edge; };    // edge bit i: pixel i starts its row, bit 4 + i: it ends it
+    Stage sa, sb, sc;
+    auto fetch = [&](Stage &s) {
+        const bool oks = fs < nst;
+        unsigned edge = 0u, extra = 0xfffffff0u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool okp = oks && (long long)fq < P;
+            s.d[i] = __builtin_amdgcn_raw_buffer_load_b128(drs, okp ? fq * (unsigned)PIXB + cq * 16u : 0xfffffff0u, 0, 0);
+            const int sy = fy + ty;
+            const bool okx = okp && (unsigned)sy < (unsigned)H;
+            const unsigned xo = (unsigned)((fb * H + sy) * W + fx) * (unsigned)PIXB + cq * 16u;
+            s.x[i] = __builtin_amdgcn_raw_buffer_load_b128(xrs, okx ? xo : 0xfffffff0u, 0, 0);
+            edge |= (unsigned)(fx == 0) << i | (unsigned)(fx == W - 1) << (4 + i);
+            if (i == 0 && ex_lo && okx && fx > 0) extra = xo - (unsigned)PIXB;         // x of the pixel in front of the step, same row
+            if (i == 3 && ex_hi && okx && fx < W - 1) extra = xo + (unsigned)PIXB;     // ... of the pixel behind it
+            fq += 16;
+            fx += 16;
+            const bool wrap = fx >= W;
+            fx = wrap ? fx - W : fx;
+            fy = wrap ? fy + 1 : fy;
+            const bool wrapy = fy == H;
+            fy = wrapy ? 0 : fy;
+            fb = wrapy ? fb + 1 : fb;
+        }
+        s.x[4] = __builtin_amdgcn_raw_buffer_load_b128(xrs, extra, 0, 0);
+        s.edge = edge;
+        ++fs;
+    };
+    // LDS image: [pixel][16 chunks], chunk index ^ 4 * (pixel & 3)
+    auto img_off = [&](int pix_lo2) { return (cq ^ ((pix_lo2 & 3) << 2)) << 4; };
+    const int off_c = pl * PIXB + img_off(pl), off_p = (pl + 1) * PIXB + img_off(pl + 1), off_m = (pl - 1) * PIXB + img_off(pl - 1);
+    const tu32x4 zero4 = {0u, 0u, 0u, 0u};
+    auto put = [&](int buf, const Stage &s) {
+        char *b = wg_smem + buf * 4 * IMG;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int o = i * 16 * PIXB;
+            *reinterpret_cast<tu32x4 *>(b + IMG + off_c + o) = s.x[i];                                               // tap 0 of this pixel
+            if (!(ex_hi && i == 3)) *reinterpret_cast<tu32x4 *>(b + off_p + o) = ((s.edge >> (4 + i)) & 1u) ? zero4 : s.x[i];   // tap -1 of the next one
+            if (!(ex_lo && i == 0)) *reinterpret_cast<tu32x4 *>(b + 2 * IMG + off_m + o) = ((s.edge >> i) & 1u) ? zero4 : s.x[i];  // tap +1 of the previous one
+            *reinterpret_cast<tu32x4 *>(b + 3 * IMG + off_c + o) = s.d[i];
+        }
+        if (ex_lo) *reinterpret_cast<tu32x4 *>(b + img_off(0)) = s.x[4];                                    // tap -1 of pixel 0
+        if (ex_hi) *reinterpret_cast<tu32x4 *>(b + 2 * IMG + 63 * PIXB + img_off(63)) = s.x[4];             // tap +1 of pixel 63
+    };
+    const int g = lane >> 4, li = lane & 15;
+    const int cih = (wv >> 1) * 64, coh = (wv & 1) * 64;
+    int ra_off[2], rb_off[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int prow = (g >> 1) * 8 + (li >> 2);
+        const int sw = (li >> 2) << 2;
+        const int ca = (cih / 8 + t * 4 + (g & 1) * 2 + ((li & 3) >> 1)) ^ sw;
+        const int cb = (coh / 8 + t * 4 + (g & 1) * 2 + ((li & 3) >> 1)) ^ sw;
+        ra_off[t] = prow * PIXB + (ca << 4) + (li & 1) * 8;
+        rb_off[t] = prow * PIXB + (cb << 4) + (li & 1) * 8;
+    }
+    tf32x16 acc[3][2][2];
+#pragma unroll
+    for (int t = 0; t < 12; ++t)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[t >> 2][(t >> 1) & 1][t & 1][i] = 0.0f;
+    auto frag = [&](const char *base, int off) {
+        const uint2 lo = lds_tr16_b64(base + off), hi = lds_tr16_b64(base + off + 4 * PIXB);
+        return make_uint4(lo.x, lo.y, hi.x, hi.y);
+    };
+    // one wave per SIMD: nothing but this wave's own instruction order hides an LDS round trip, so the eight fragments of k-step
+    // ks + 1 are read while the twelve MFMAs of k-step ks run (register double buffer; first form: reads right in front of their
+    // MFMAs, s_waitcnt lgkmcnt(2) sixteen times per step)
+    auto mfmas = [&](int buf) {
+        const char *b = wg_smem + buf * 4 * IMG;
+        uint4 fa[2][3][2], fb[2][2];
+        auto read_ks = [&](int ks, int q) {
+            const char *bd = b + 3 * IMG + ks * 16 * PIXB;
+            fb[q][0] = frag(bd, rb_off[0]);
+            fb[q][1] = frag(bd, rb_off[1]);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const char *bx = b + t * IMG + ks * 16 * PIXB;
+                fa[q][t][0] = frag(bx, ra_off[0]);
+                fa[q][t][1] = frag(bx, ra_off[1]);
+            }
+        };
+        read_ks(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int q = ks & 1;
+            if (ks + 1 < 4) read_ks(ks + 1, q ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                acc[t][0][0] = MfmaT<T>::run(fa[q][t][0], fb[q][0], acc[t][0][0]);
+                acc[t][0][1] = MfmaT<T>::run(fa[q][t][0], fb[q][1], acc[t][0][1]);
+                acc[t][1][0] = MfmaT<T>::run(fa[q][t][1], fb[q][0], acc[t][1][0]);
+                acc[t][1][1] = MfmaT<T>::run(fa[q][t][1], fb[q][1], acc[t][1][1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    if (nst > 0) {
+        fetch(sa);
+        fetch(sb);
+        fetch(sc);
+        put(0, sa);
+        __syncthreads();
+#define SEC_WGRAD_ROW_STEP(S, FS, PS)                                                                  \
+        mfmas((S) & 1);                                                                                \
+        fetch(FS);                                                                                     \
+        put(((S) + 1) & 1, PS);                                                                        \
+        __syncthreads();
+        for (int s = 0; s < nst; s += 3) {
+            SEC_WGRAD_ROW_STEP(s, sa, sb)
+            SEC_WGRAD_ROW_STEP(s + 1, sb, sc)
+            SEC_WGRAD_ROW_STEP(s + 2, sc, sa)
+        }
+#undef SEC_WGRAD_ROW_STEP
+    }
+#pragma unroll
+    for (int tt = 0; tt < 3; ++tt) {
+        float *dst = part + ((size_t)slice * 9 + trow * 3 + tt) * C * C;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int ci = cih + (t >> 1) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h, co = coh + (t & 1) * 32 + r;
+                dst[(size_t)ci * C + co] = acc[tt][t >> 1][t & 1][i];
+            }
+    }
 }
 
 // dw[co][ci][tap] (torch's [Cout][Cin][3][3]) = sum_g part[g][tap][ci][co], g ascending (fixed order: run-to-run identical)
@@ -509,12 +682,45 @@ __global__ __launch_bounds__(kBlock) void k_conv2d_pack_train_multi(Pack2dArgs a
 }
 
 constexpr int kBnGroups = 512;
+// slices of the row form: x 3 kernel rows = 240 workgroups.  The three rows of a slice go to ONE XCD (they share dy and most of x), eight
+// slices per group of 24 workgroups, so an XCD gets 3 * ceil(slices / 8) workgroups of 128 KB LDS each for its 32 CUs: 80 slices is the
+// most that fits one round (85 gave XCDs 0 and 1 a 33rd workgroup: a second round, the launch took twice as long)
+constexpr int kWgradRowSlices = 80;
+// Which maps take the row form.  Measured (gpurun r06_ab / r06_ac / r06_ad, us per weight gradient + reduce, tap form -> row form):
+// 4 x 200 x 176 (car.fhd training) 77 -> 81, 3 x 248 x 248 (nuScenes) 108 -> 92, 8 x 200 x 176 139 -> 123; with NO operand traffic the
+// row form still takes 71 us at 4 x 200 x 176 -- one wave per SIMD walks LDS stores (64 KB of images per step at the ~80 B/clk of
+// ds_write_b128), a barrier, fragment reads and 48 MFMAs in sequence -- so it wins only where the tap form's nine passes over x and dy
+// cost more than that: from ~160 k pixels.  SEC_WGRAD_ROW=0 / 1 (read per call) forces a form: tests run every shape through both.
+static bool wgrad_row_form(long long pixels) {
+    const char *e = getenv("SEC_WGRAD_ROW");
+    if (e && *e) return atoi(e) != 0;
+    return pixels >= 160000;
+}
 
 template <typename T>
 static int run_wgrad(const void *x, const void *dy, int B, int H, int W, float *dw, void *ws, size_t ws_bytes, hipStream_t st, int ntaps, int cout) {
     const long long P = (long long)B * H * W;
     if (P * 128 * 2 >= (1ll << 31)) return SEC_E_UNSUPPORTED;   // 32-bit buffer offsets (8.4 M pixels; the nuScenes maps hold 0.5 M)
     const long long total_steps = (P + 63) / 64;
+    if (ntaps == 9 && W >= 16 && wgrad_row_form(P)) {
+        // a kernel row per workgroup: one workgroup per CU (128 KB of LDS), slices x 3 rows ~ 256 workgroups
+        int steps = (int)((total_steps + kWgradRowSlices - 1) / kWgradRowSlices);
+        steps = (steps + 2) / 3 * 3;
+        if (steps < 3) steps = 3;
+        const long long gx = (total_steps + steps - 1) / steps;
+        const size_t need = (size_t)gx * 9 * 128 * 128 * sizeof(float);
+        if (ws_bytes < need) return SEC_E_WORKSPACE;
+        constexpr int lds = 2 * 4 * 64 * 256;
+        auto fn = k_conv2d_wgrad3x3_row<T>;
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(fn, dim3((unsigned)((gx + 7) / 8 * 8 * 3)), dim3(256), lds, st, (const T *)x, (const T *)dy, (float *)ws, B, H, W, steps, P, (int)gx);
+        hipLaunchKernelGGL(k_conv2d_wgrad_reduce, dim3(div_up(9 * 128 * 128, 256)), dim3(256), 0, st, (const float *)ws, (int)gx, dw, 9, cout);
+        return check_launch();
+    }
     int steps = ntaps == 1 ? 6 : 42;                         // multiples of 3 (the kernel's unrolled stage ring); ~2 workgroups per CU at batch 4 (2200 steps -> 53 runs x 9 taps)
     long long gx = (total_steps + steps - 1) / steps;
     if (gx > 256) { steps = (int)((total_steps + 255) / 256); steps = (steps + 2) / 3 * 3; gx = (total_steps + steps - 1) / steps; }
@@ -542,6 +748,7 @@ SEC_API size_t sec_conv2d_wgrad_workspace_bytes(int batch, int h, int w, int cin
     long long gx = (total_steps + steps0 - 1) / steps0;
     if (gx > 256) gx = 256;
     if (gx < 1) gx = 1;
+    if (ksize == 3 && gx < kWgradRowSlices) gx = kWgradRowSlices;     // the row form cuts the pixels into up to kWgradRowSlices slices
     return (size_t)gx * ksize * ksize * 128 * 128 * sizeof(float);
 }
 

@@ -22,12 +22,16 @@ def _cl(t):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("form", ["tap", "row"])
 @pytest.mark.parametrize("shape", [(1, 13, 17), (2, 21, 12), (2, 40, 48), (4, 200, 176)])
-def test_conv2d_wgrad_vs_torch(ops, dtype, shape):
+def test_conv2d_wgrad_vs_torch(ops, dtype, shape, form, monkeypatch):
     """dW of the 3x3 / s1 / p1 128 -> 128 conv: ragged pixel counts (221 pixels: not a multiple of the 64-pixel step), a map narrower
     than the 16-pixel stride of the kernel's staging (its NARROW instantiation), a mid size and
     the car.fhd training shape (batch 4 x 200 x 176 = 140 800 pixels); vs torch autograd in fp32 on the same rounded operands; the
     fixed-order reduction makes it run-to-run identical."""
+    # both forms of the kernel on every shape: a tap per workgroup (k_conv2d_wgrad3x3) and a kernel row per workgroup
+    # (k_conv2d_wgrad3x3_row: the automatic choice from ~160 k pixels; maps narrower than 16 pixels always take the tap form)
+    monkeypatch.setenv("SEC_WGRAD_ROW", "1" if form == "row" else "0")
     b, h, w = shape
     g = torch.Generator().manual_seed(b * 1000 + h)
     x = _cl(torch.randn(b, 128, h, w, generator=g).cuda().to(dtype))
