@@ -429,26 +429,42 @@ __global__ __launch_bounds__(256) void k_bn_partial(const T *__restrict__ y, con
         }
     }
     if (pl < ppi) {
-        for (long long p = (long long)blockIdx.x * ppi + pl; p < P; p += (long long)gridDim.x * ppi) {
-            const uint4 v = reinterpret_cast<const uint4 *>(y)[p * cg + chg];
-            const T *e = reinterpret_cast<const T *>(&v);
-            if (MODE == 0) {
+        // four pixels per trip with all their loads issued first (same pixels, same order of additions as one pixel per trip: the
+        // sums are bit-identical): one 16-byte load per tensor in flight per thread left the pass at 3.6-3.8 TB/s on activations the
+        // previous kernel had just written (19 us for the 72 MB of a backward pass at batch 4)
+        constexpr int U = 4;
+        const long long stride = (long long)gridDim.x * ppi;
+        const uint4 *y4 = reinterpret_cast<const uint4 *>(y), *d4 = reinterpret_cast<const uint4 *>(dz);
+        for (long long p0 = (long long)blockIdx.x * ppi + pl; p0 < P; p0 += U * stride) {
+            uint4 v[U], gq[U];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float f = t2f<T>(e[j]);
-                    a[j] += f;
-                    b2[j] += f * f;
-                }
-            } else {
-                const uint4 gq = reinterpret_cast<const uint4 *>(dz)[p * cg + chg];
-                const T *ge = reinterpret_cast<const T *>(&gq);
+            for (int u = 0; u < U; ++u) {
+                const long long p = p0 + u * stride;
+                const bool ok = p < P;
+                v[u] = ld_sel(y4, p * cg + chg, ok, make_uint4(0u, 0u, 0u, 0u));
+                if (MODE == 1) gq[u] = ld_sel(d4, p * cg + chg, ok, make_uint4(0u, 0u, 0u, 0u));
+            }
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float xh = (t2f<T>(e[j]) - mu[j]) * is[j];
-                    float g = t2f<T>(ge[j]);
-                    if (relu && !(xh * ga[j] + be[j] > 0.0f)) g = 0.0f;
-                    a[j] += g;
-                    b2[j] += g * xh;
+            for (int u = 0; u < U; ++u) {
+                if (p0 + u * stride >= P) break;
+                const T *e = reinterpret_cast<const T *>(&v[u]);
+                if (MODE == 0) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float f = t2f<T>(e[j]);
+                        a[j] += f;
+                        b2[j] += f * f;
+                    }
+                } else {
+                    const T *ge = reinterpret_cast<const T *>(&gq[u]);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float xh = (t2f<T>(e[j]) - mu[j]) * is[j];
+                        float g = t2f<T>(ge[j]);
+                        if (relu && !(xh * ga[j] + be[j] > 0.0f)) g = 0.0f;
+                        a[j] += g;
+                        b2[j] += g * xh;
+                    }
                 }
             }
         }
@@ -510,6 +526,46 @@ __global__ __launch_bounds__(256) void k_bn_bwd_finalize(const float *__restrict
     dgamma[c] = (float)s1;
 }
 
+// the element loop of both apply kernels: chunk q, q + qs, ... of 8 channels whose parameters the caller holds in registers
+template <typename T, int MODE>
+__device__ __forceinline__ void bn_apply_loop(const T *__restrict__ y, const T *__restrict__ dz, T *__restrict__ out, long long q0, long long qs,
+                                              long long n, const float (&mu)[8], const float (&is)[8], const float (&ga)[8],
+                                              const float (&be)[8], const float (&db)[8], const float (&dg)[8], float inv_p, int relu) {
+    constexpr int U = 4;
+    const uint4 *y4 = reinterpret_cast<const uint4 *>(y), *d4 = reinterpret_cast<const uint4 *>(dz);
+    for (long long qb = q0; qb < n; qb += U * qs) {
+        uint4 v[U], gq[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long q = qb + u * qs;
+            v[u] = ld_sel(y4, q, q < n, make_uint4(0u, 0u, 0u, 0u));
+            if (MODE == 1) gq[u] = ld_sel(d4, q, q < n, make_uint4(0u, 0u, 0u, 0u));
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long q = qb + u * qs;
+            if (q >= n) break;
+            const T *e = reinterpret_cast<const T *>(&v[u]);
+            const T *ge = reinterpret_cast<const T *>(&gq[u]);
+            uint4 o;
+            T *oe = reinterpret_cast<T *>(&o);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xh = (t2f<T>(e[j]) - mu[j]) * is[j];
+                const float zp = xh * ga[j] + be[j];
+                if (MODE == 0) {
+                    oe[j] = f2t<T>(relu ? (zp > 0.0f ? zp : 0.0f) : zp);
+                } else {
+                    float g = t2f<T>(ge[j]);
+                    if (relu && !(zp > 0.0f)) g = 0.0f;
+                    oe[j] = f2t<T>(ga[j] * is[j] * (g - db[j] * inv_p - xh * dg[j] * inv_p));
+                }
+            }
+            reinterpret_cast<uint4 *>(out)[q] = o;
+        }
+    }
+}
+
 // MODE 0: z = act((y - mean) * invstd * gamma + beta);  MODE 1: dy = gamma * invstd * (g - dbeta / P - xh * dgamma / P)
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void k_bn_apply(const T *__restrict__ y, const T *__restrict__ dz, long long P, int C,
@@ -521,30 +577,19 @@ __global__ __launch_bounds__(256) void k_bn_apply(const T *__restrict__ y, const
     const int cg = C / 8;
     const long long n = P * cg;
     const float inv_p = 1.0f / (float)(P > 0 ? P : 1);
-    for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < n; q += (long long)gridDim.x * 256) {
-        const int chg = (int)(q % cg);
-        const uint4 v = reinterpret_cast<const uint4 *>(y)[q];
-        const T *e = reinterpret_cast<const T *>(&v);
-        uint4 gq = make_uint4(0, 0, 0, 0);
-        if (MODE == 1) gq = reinterpret_cast<const uint4 *>(dz)[q];
-        const T *ge = reinterpret_cast<const T *>(&gq);
-        uint4 o;
-        T *oe = reinterpret_cast<T *>(&o);
+    // The grid stride is a multiple of 256 and cg divides 256, so a thread's channel group never changes: its 8 channels' parameters
+    // are read ONCE (the loop used to fetch six 4-byte values per channel and element from global memory: 48 loads for one 16-byte
+    // chunk), and four chunks per trip are loaded before any is used.  Same arithmetic per element: bit-identical outputs.
+    const long long q0 = (long long)blockIdx.x * 256 + threadIdx.x, qs = (long long)gridDim.x * 256;
+    const int chg = (int)(q0 % cg);
+    float mu[8], is[8], ga[8], be[8], db[8], dg[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int c = chg * 8 + j;
-            const float xh = (t2f<T>(e[j]) - mean[c]) * invstd[c];
-            const float zp = xh * gamma[c] + beta[c];
-            if (MODE == 0) {
-                oe[j] = f2t<T>(relu ? (zp > 0.0f ? zp : 0.0f) : zp);
-            } else {
-                float g = t2f<T>(ge[j]);
-                if (relu && !(zp > 0.0f)) g = 0.0f;
-                oe[j] = f2t<T>(gamma[c] * invstd[c] * (g - dbeta[c] * inv_p - xh * dgamma[c] * inv_p));
-            }
-        }
-        reinterpret_cast<uint4 *>(out)[q] = o;
+    for (int j = 0; j < 8; ++j) {
+        const int c = chg * 8 + j;
+        mu[j] = mean[c]; is[j] = invstd[c]; ga[j] = gamma[c]; be[j] = beta[c];
+        db[j] = MODE == 1 ? dbeta[c] : 0.0f; dg[j] = MODE == 1 ? dgamma[c] : 0.0f;
     }
+    bn_apply_loop<T, MODE>(y, dz, out, q0, qs, n, mu, is, ga, be, db, dg, inv_p, relu);
 }
 
 // Small activations (the sparse stack's BatchNorm1d rows: at most kBnSmallRows): the partial sums come from kBnSmallGroups workgroups
@@ -601,30 +646,16 @@ __global__ __launch_bounds__(256) void k_bn_apply_small(const T *__restrict__ y,
     const int cg = C / 8;
     const long long n = P * cg;
     const float inv_p = 1.0f / (float)(P > 0 ? P : 1);
-    for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < n; q += (long long)gridDim.x * 256) {
-        const int chg = (int)(q % cg);
-        const uint4 v = reinterpret_cast<const uint4 *>(y)[q];
-        const T *e = reinterpret_cast<const T *>(&v);
-        uint4 gq = make_uint4(0, 0, 0, 0);
-        if (MODE == 1) gq = reinterpret_cast<const uint4 *>(dz)[q];
-        const T *ge = reinterpret_cast<const T *>(&gq);
-        uint4 o;
-        T *oe = reinterpret_cast<T *>(&o);
+    const long long q0 = (long long)blockIdx.x * 256 + threadIdx.x, qs = (long long)gridDim.x * 256;
+    const int chg = (int)(q0 % cg);                    // (invariant per thread: see k_bn_apply)
+    float mu[8], is[8], ga[8], be[8], db[8], dg[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int c = chg * 8 + j;
-            const float xh = (t2f<T>(e[j]) - s_a[c]) * s_b[c];
-            const float zp = xh * s_g[c] + s_be[c];
-            if (MODE == 0) {
-                oe[j] = f2t<T>(relu ? (zp > 0.0f ? zp : 0.0f) : zp);
-            } else {
-                float g = t2f<T>(ge[j]);
-                if (relu && !(zp > 0.0f)) g = 0.0f;
-                oe[j] = f2t<T>(s_g[c] * s_b[c] * (g - s_b2[c] * inv_p - xh * s_g2[c] * inv_p));
-            }
-        }
-        reinterpret_cast<uint4 *>(out)[q] = o;
+    for (int j = 0; j < 8; ++j) {
+        const int c = chg * 8 + j;
+        mu[j] = s_a[c]; is[j] = s_b[c]; ga[j] = s_g[c]; be[j] = s_be[c];
+        db[j] = MODE == 1 ? s_b2[c] : 0.0f; dg[j] = MODE == 1 ? s_g2[c] : 0.0f;
     }
+    bn_apply_loop<T, MODE>(y, dz, out, q0, qs, n, mu, is, ga, be, db, dg, inv_p, relu);
 }
 
 // fp32 master weight [cout][cin][k][k] -> BOTH 16-bit MFMA slab images of a training step in one launch: `fwd` in the layout of
@@ -681,7 +712,7 @@ __global__ __launch_bounds__(kBlock) void k_conv2d_pack_train_multi(Pack2dArgs a
     conv2d_pack_train_at<T>((long long)(blockIdx.x - d.blk0) * kBlock + threadIdx.x, d.w, d.cout, d.cin, d.ks, (T *)d.fwd, (T *)d.dgrad);
 }
 
-constexpr int kBnGroups = 512;
+constexpr int kBnGroups = 512;                             // (2048 measured in round 6: the partial pass 10.6 -> 9.4 us, each finalize 6 -> 16 us)
 // slices of the row form: x 3 kernel rows = 240 workgroups.  The three rows of a slice go to ONE XCD (they share dy and most of x), eight
 // slices per group of 24 workgroups, so an XCD gets 3 * ceil(slices / 8) workgroups of 128 KB LDS each for its 32 CUs: 80 slices is the
 // most that fits one round (85 gave XCDs 0 and 1 a 33rd workgroup: a second round, the launch took twice as long)
