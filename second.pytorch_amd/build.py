@@ -12,7 +12,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = [os.path.join(HERE, "csrc", f) for f in
        ("common.hip", "voxelize.hip", "rulebook.hip", "indice_conv.hip", "scatter.hip", "nms.hip", "dense.hip", "pillars.hip", "predict.hip", "train.hip", "dense_train.hip")]
-HDR = [os.path.join(HERE, "csrc", "common.hpp"), os.path.join(HERE, "..", "include", "second_hip.h")]
+HDR = [os.path.join(HERE, "csrc", "common.hpp"), os.path.join(HERE, "csrc", "dense_patch.hpp"), os.path.join(HERE, "..", "include", "second_hip.h")]
 OUT = os.path.join(HERE, "lib", "libsecond_hip.so")
 # No packed fp32 VALU: `-Xclang -target-feature -Xclang -packed-fp32-ops` makes the backend split every <2 x float> operation, so no
 # v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32 is emitted (the vectorisers stay on: they also merge loads / stores, worth 9-15 % on the

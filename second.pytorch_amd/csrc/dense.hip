@@ -1488,9 +1488,25 @@ static int conv2d_variant() {
     return v;
 }
 
+#include "dense_patch.hpp"
+
+// SEC_CONV2D_PATCH=0: the strided / patch layers of the PointPillars RPN on the generic implicit GEMM (A/B; read once)
+static bool conv2d_patch_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("SEC_CONV2D_PATCH");
+        v = (e && *e == '0') ? 0 : 1;
+    }
+    return v != 0;
+}
+
 template <typename T>
 static int launch_conv2d(const void *x, const void *wpk, const float *bias, void *y, const Conv2dParams &p, hipStream_t st) {
     dim3 block(kBlock);
+    if (conv2d_variant() == 13 && conv2d_patch_enabled()) {
+        const int rc = patch::dispatch<T>(x, wpk, bias, y, p, p.cout, st);
+        if (rc != patch::kNotTaken) return rc;
+    }
     if (conv2d_variant() == 14 && p.ksize == 3 && p.stride == 1 && p.pad == 1 && p.cout % 128 == 0 && p.cin == 128)
         return launch_conv2d_halo_reg<T, 128, 8>(x, wpk, bias, y, p, st);   // A/B: the two-stage loop with per-m-tile halo addressing
     if (conv2d_variant() == 13 && p.ksize == 3 && p.stride == 1 && p.pad == 1 && p.cout % 128 == 0 && (p.cin == 128 || p.cin == 64))

@@ -923,7 +923,14 @@ def test_pointpillars_detector_runs_fused_equals_module_path(syn):
                                                      (128, 128, 3, 1, 1, (37, 29)), (128, 128, 3, 1, 1, (8, 16)), (128, 128, 3, 1, 1, (9, 17)),
                                                      (128, 256, 3, 1, 1, (23, 40)), (128, 128, 3, 1, 1, (1, 1)),
                                                      (256, 256, 3, 1, 1, (50, 50)), (256, 128, 3, 1, 1, (7, 19)),    # 4 x 16 tiles, 256 input channels
-                                                     (64, 64, 3, 1, 1, (200, 200)), (64, 64, 3, 1, 1, (13, 21))])     # 64 output channels per workgroup
+                                                     (64, 64, 3, 1, 1, (200, 200)), (64, 64, 3, 1, 1, (13, 21)),      # 64 output channels per workgroup
+                                                     # k_conv2d_patch (PointPillars RPN: stride-2 first convs, k == stride deblocks, 1x1 over 256 / 384 channels):
+                                                     # full-size and ragged maps, odd sizes (the last tap row / column falls into the padding or is dropped)
+                                                     (64, 64, 3, 2, 1, (400, 400)), (64, 64, 3, 2, 1, (101, 77)), (64, 128, 3, 2, 1, (200, 200)),
+                                                     (64, 128, 3, 2, 1, (50, 37)), (128, 256, 3, 2, 1, (100, 100)), (128, 128, 3, 2, 1, (23, 18)),
+                                                     (64, 128, 4, 4, 0, (200, 200)), (64, 128, 4, 4, 0, (37, 53)), (128, 128, 2, 2, 0, (100, 100)),
+                                                     (128, 128, 2, 2, 0, (31, 45)), (256, 128, 1, 1, 0, (50, 50)), (384, 256, 1, 1, 0, (50, 50)),
+                                                     (384, 128, 1, 1, 0, (7, 5)), (256, 256, 1, 1, 0, (3, 33))])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 def test_conv2d_nhwc_mfma_vs_torch(ops, cin, cout, k, stride, pad, hw, dtype):
     torch.manual_seed(cin + cout + k)
