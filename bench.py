@@ -268,6 +268,17 @@ def kernel_table(det, points, offsets, reps=30):
             b_, cin, _, _ = x.shape
             ent.update(flop=2.0 * b_ * res.shape[2] * res.shape[3] * cin * cout * ks * ks,
                        bytes=elt(x.dtype) * (x.numel() + res.numel()), detail=f"{cin}->{cout} k{ks} {tuple(x.shape[2:])}")
+        elif name == "pillar_site_map":
+            n = live(kw.get("num_dev"), a[0].shape[0])
+            ent.update(bytes=16 * n + 4 * n + 4 * res.numel(), detail=f"{n} pillars -> map {tuple(res.shape)} (zero fill included)")
+        elif name == "conv2d_nhwc_rows":
+            feat, smap, cout, ks = a[0], a[1], a[4], a[5]
+            n = int((smap > 0).sum().item())
+            cin = feat.shape[1]
+            # FLOPs of the dense-equivalent conv (empty tiles are skipped, not counted separately); bytes: map + pillar rows + output
+            ent.update(flop=2.0 * res.shape[0] * res.shape[2] * res.shape[3] * cin * cout * ks * ks,
+                       bytes=4 * smap.numel() + elt(feat.dtype) * n * cin + elt(res.dtype) * res.numel(),
+                       detail=f"{cin}->{cout} k{ks} {tuple(smap.shape[1:])} gathered from {n} pillar rows (no canvas)")
         elif name == "sparse_site_map":
             n = live(kw.get("num_dev"), a[0].shape[0])
             ent.update(bytes=16 * n + 4 * res.numel(), detail=f"{n} sites -> map {tuple(res.shape)}")

@@ -309,6 +309,16 @@ int sec_conv2d_nhwc_gather(const void *features, long long feature_rows, const i
                            const unsigned short *tile_order, const int *live_counts, const void *background, void *y,
                            int dtype, void *stream);   /* tile_order .. background: see sec_rpn_tile_live; tile_order NULL = every tile tests its own map entries; background NULL with lists = lazy consumers (below) */
 
+/* PointPillarsScatter + the first RPN conv without the canvas (second/pytorch/models/pointpillars.py:444-476 writes the pillar rows
+ * into a zeroed [B, C, ny, nx] image that rpn.py:484-486 `ZeroPad2d(1) + Conv2d(3, stride 2)` then reads): the convolution
+ * (+ bias + ReLU, as sec_conv2d_nhwc) of that image straight from the pillar feature rows `rows` [feature_rows][cin] (16-bit) and
+ * site_map [batch][h][w] = row + 1 of the cell's pillar, 0 = none (sec_sparse_site_map with d = 1).
+ * Shapes: cin 64, 3x3 / stride 2 / pad 1, cout 64 or a multiple of 128 (SEC_E_UNSUPPORTED otherwise).  Bit-identical to
+ * sec_conv2d_nhwc on the scattered image; tiles whose input cells hold no pillar write act(bias). */
+int sec_conv2d_nhwc_rows(const void *rows, long long feature_rows, const int *site_map, int batch, int h, int w, int cin,
+                         const void *packed_weight, const float *bias, int cout, int ksize, int stride, int pad, int relu, void *y,
+                         int dtype, void *stream);
+
 /* The dense RPN (rpn.py:486-497: Conv2d 3x3 + BatchNorm2d + ReLU, repeated) on a BEV image that is empty except at the sparse
  * middle's sites (middle.py:206-210): a pixel of the j-th conv's output sees the image only within j + 1 steps, so a tile
  * farther than that from every site holds exactly what the same network computes for an EMPTY frame at that position -- for

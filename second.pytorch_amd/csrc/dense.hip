@@ -1842,6 +1842,29 @@ SEC_API int sec_conv2d_nhwc(const void *x, int batch, int h, int w, int cin, con
     return launch_conv2d<__half>(x, packed_weight, bias, y, p, st);
 }
 
+SEC_API int sec_conv2d_nhwc_rows(const void *rows, long long feature_rows, const int *site_map, int batch, int h, int w, int cin,
+                                 const void *packed_weight, const float *bias, int cout, int ksize, int stride, int pad, int relu, void *y,
+                                 int dtype, void *stream) {
+    if (!rows || !site_map || !packed_weight || !y || batch <= 0 || h <= 0 || w <= 0 || feature_rows < 0 || ksize <= 0 || stride <= 0 || pad < 0)
+        return SEC_E_INVALID;
+    if (dtype != SEC_BF16 && dtype != SEC_F16) return SEC_E_UNSUPPORTED;
+    if (feature_rows * cin * 2 > 0x7fffffffll || (long long)h * w * 4 > 0x7fffffffll) return SEC_E_UNSUPPORTED;     // 32-bit buffer offsets
+    Conv2dParams p;
+    p.batch = batch; p.h = h; p.w = w; p.cin = cin; p.cout = cout; p.ksize = ksize; p.stride = stride; p.pad = pad;
+    p.relu = relu & 1;
+    p.zskip = 0;
+    p.stagger = 0;
+    p.ho = (h + 2 * pad - ksize) / stride + 1;
+    p.wo = (w + 2 * pad - ksize) / stride + 1;
+    if (p.ho <= 0 || p.wo <= 0) return SEC_E_INVALID;
+    p.m = (long long)batch * p.ho * p.wo;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned fb = (unsigned)(feature_rows * cin * 2);
+    const int rc = dtype == SEC_BF16 ? patch::dispatch_rows<__hip_bfloat16>(rows, fb, site_map, packed_weight, bias, y, p, st)
+                                     : patch::dispatch_rows<__half>(rows, fb, site_map, packed_weight, bias, y, p, st);
+    return rc == patch::kNotTaken ? SEC_E_UNSUPPORTED : rc;
+}
+
 // fp32 <-> two bf16 planes (hi = bf16(v), lo = bf16(v - hi)): the operand form of sec_conv2d_nhwc_x3.  Element-wise, HBM bound.
 __global__ __launch_bounds__(kBlock) void k_split_bf16x2(const float4 *__restrict__ x, long long n4, uint2 *__restrict__ hi, uint2 *__restrict__ lo) {
     for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (long long)gridDim.x * kBlock) {

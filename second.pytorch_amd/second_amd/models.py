@@ -330,6 +330,21 @@ class SparseBEV:
         return self.sp.dense_channels_last_2d()
 
 
+class PillarBEV:
+    """The PillarFeatureNet's rows handed to RPNInference WITHOUT PointPillarsScatter's canvas (pointpillars.py:444-476): rows + (b, z, y, x)
+    coordinates of an [ny, nx] grid.  ``dense()`` is the scatter's channels_last image for consumers that need it."""
+
+    def __init__(self, features, coords, batch_size, ny, nx, num_dev=None):
+        self.features, self.coords, self.num_dev = features.contiguous(), coords.int().contiguous(), num_dev
+        self.batch_size, self.ny, self.nx = int(batch_size), int(ny), int(nx)
+
+    def site_map(self):
+        return ops.pillar_site_map(self.coords, self.batch_size, self.ny, self.nx, num_dev=self.num_dev)
+
+    def dense(self):
+        return ops.pillar_scatter(self.features, self.coords, self.batch_size, self.ny, self.nx, channels_last=True, num_dev=self.num_dev)
+
+
 class RPNV2(nn.Module):
     """ZeroPad+Conv3x3+BN+ReLU, layer_num x (Conv3x3+BN+ReLU) per block; deconv (or strided conv) per
     block; three 1x1 heads.  Keys: blocks.<b>.<i>, deblocks.<b>.<i>, conv_cls, conv_box, conv_dir_cls."""
@@ -657,6 +672,7 @@ class RPNInference(nn.Module):
                         self.chain_x3 = [ops.conv2d_pack_weight_x3(wl_), ops.conv2d_pack_weight_x3(hw64), hb64]
         # deblock (1x1, stride 1, 128 -> 128) + heads (<= 128 padded channels) run as ONE kernel (sec_conv1x1_chain_nhwc)
         wl = self.ws[-1]
+        self.pillar_rows_first = True    # a PillarBEV input: the first conv reads the pillar rows through a site map when the shapes allow (False: the scattered canvas)
         self.sparse_input = True   # forward()'s input comes from SparseConvTensor.dense(): all-zero halo tiles skip their MFMA loop (bit-identical)
         # first conv straight from the sparse rows (sec_conv2d_nhwc_gather): 3x3 / s1 / p1 on 2 planes x 64 channels; its weights
         # are packed a second time with the input channels in plane-major order (gather_first=False: always the dense image)
@@ -857,7 +873,7 @@ class RPNInference(nn.Module):
 
     def forward(self, x):
         if self.packed_x3 is not None:
-            return self._forward_x3(x)
+            return self._forward_x3(x.dense() if isinstance(x, PillarBEV) else x)
         ups = []
         first = self.sparse_input     # x is the scattered sparse-middle output: mostly empty tiles
         gather = None
@@ -866,9 +882,24 @@ class RPNInference(nn.Module):
                 gather = x
             else:
                 x = x.dense()
+        if isinstance(x, PillarBEV):
+            kind0, i0 = self.plan[0]
+            w0, (s0, p0) = self.ws[i0], self.cfgs[i0]
+            if (self.use_hip and self.pillar_rows_first and kind0 == "c" and x.features.dtype == w0.dtype and w0.shape[2] == w0.shape[3]
+                    and ops.conv2d_rows_supported(x.features.shape[1], w0.shape[0], w0.shape[2], s0[0], p0[0], w0.dtype) and w0.shape[1] == x.features.shape[1]):
+                pillars, x = x, None
+            else:
+                x = x.dense()
+        else:
+            pillars = None
         live = nbr = None
         for kind, i in self.plan:
-            if kind == "c" and gather is not None:
+            if kind == "c" and x is None:
+                # the first conv straight from the pillar rows (sec_conv2d_nhwc_rows): no zero fill, no scatter, no 82 MB canvas
+                x = ops.conv2d_nhwc_rows(pillars.features, pillars.site_map(), self.packed[i], self.bs[i], self.ws[i].shape[0],
+                                         self.ws[i].shape[2], self.cfgs[i][0][0], self.cfgs[i][1][0], relu=True)
+                first = False
+            elif kind == "c" and gather is not None:
                 sm = gather.site_map()
                 if self.background_convs and self.skip_background:
                     empty = self.empty_frame_maps(sm.shape[2], sm.shape[3])
@@ -1018,8 +1049,13 @@ class SecondDetector(nn.Module):
     def _network_forward(self, voxel_features, coors, batch_size, num_active_dev=None, site_table=None):
         dt = self._infer_dtype
         if self.pillars:
-            spatial = self.middle_feature_extractor(voxel_features if dt is None else voxel_features.to(dt), coors,
-                                                    batch_size, channels_last=dt is not None, num_dev=num_active_dev)
+            mfe = self.middle_feature_extractor
+            if (dt in (torch.bfloat16, torch.float16) and isinstance(self.rpn, RPNInference) and self.rpn.use_hip and self.rpn.packed_x3 is None
+                    and isinstance(mfe, PointPillarsScatter) and not torch.is_grad_enabled()):
+                # no canvas: the RPN's first conv gathers the pillar rows (PillarBEV.dense() is the scatter for the shapes it does not take)
+                return self.rpn(PillarBEV(voxel_features.to(dt), coors, batch_size, mfe.ny, mfe.nx, num_dev=num_active_dev))
+            spatial = mfe(voxel_features if dt is None else voxel_features.to(dt), coors,
+                          batch_size, channels_last=dt is not None, num_dev=num_active_dev)
             return self.rpn(spatial)
         if dt is not None:
             spatial = self.middle_feature_extractor(voxel_features.to(dt), coors, batch_size, channels_last=True,

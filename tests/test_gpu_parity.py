@@ -1337,3 +1337,36 @@ def test_rulebook_subm_after_voxelize_reuses_the_voxel_hash_table(ops, syn):
         live = int(vox["voxel_offsets"][2].item())
         assert live == 16000 and torch.equal(reuse["nbr_out"][:live], plain["nbr_out"][:live])
         assert (reuse["nbr_out"][:live, 13] == torch.arange(live, device="cuda", dtype=torch.int32)).all()
+
+
+@pytest.mark.parametrize("cout,hw,npil", [(64, (400, 400), 60000), (64, (37, 53), 300), (128, (50, 70), 0), (128, (96, 40), 900)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_conv2d_nhwc_rows_equals_pillar_scatter_then_conv(ops, cout, hw, npil, dtype):
+    """sec_conv2d_nhwc_rows (PointPillarsScatter + the first RPN conv without the canvas; pointpillars.py:444-476, rpn.py:484-486): bit-identical
+    to sec_pillar_scatter followed by sec_conv2d_nhwc, including empty tiles (act(bias)), an empty frame, rows past the live count (static
+    capacity: the device-side pillar count) and ragged map sizes."""
+    torch.manual_seed(cout + npil)
+    b, (h, w), cap = (4 if hw == (400, 400) else 3), hw, npil + 37     # 4 x 400 x 400: the several-rounds launch (piece table form of the kernel)
+    cells = torch.randperm(2 * h * w, device="cuda")[:npil]            # frames 0 and 1 hold pillars, frame 2 is empty
+    if npil > 400:                                                       # clustered: leave whole tiles without pillars
+        cells = cells[(cells % w) < w // 2]
+    n = cells.numel()
+    coords = torch.zeros(cap, 4, dtype=torch.int32, device="cuda")
+    coords[:n, 0], coords[:n, 2], coords[:n, 3] = (cells // (h * w)).int(), ((cells // w) % h).int(), (cells % w).int()
+    coords[n:] = torch.tensor([1, 0, 2, 3], dtype=torch.int32, device="cuda")          # stale rows past the live count: must not be read
+    feats = torch.randn(cap, 64, device="cuda").to(dtype)
+    num_dev = torch.tensor([n], dtype=torch.int32, device="cuda")
+    wgt = (torch.randn(cout, 64, 3, 3, device="cuda") / 24).to(dtype)
+    bias = torch.randn(cout, device="cuda")
+    pk = ops.conv2d_pack_weight(wgt)
+    canvas = ops.pillar_scatter(feats, coords, b, h, w, channels_last=True, num_dev=num_dev)
+    smap = ops.pillar_site_map(coords, b, h, w, num_dev=num_dev)
+    assert int((smap > 0).sum()) == n and int(smap.max()) <= n
+    for relu in (True, False):
+        ref = ops.conv2d_nhwc(canvas, pk, bias, cout, 3, 2, 1, relu=relu)
+        out = ops.conv2d_nhwc_rows(feats, smap, pk, bias, cout, 3, 2, 1, relu=relu)
+        assert out.shape == ref.shape and torch.equal(out.view(torch.int16), ref.view(torch.int16))
+    tref = torch.relu(torch.nn.functional.conv2d(canvas.float(), wgt.float(), bias, 2, 1))
+    tol = 2 ** -7 if dtype == torch.bfloat16 else 2 ** -9
+    np.testing.assert_allclose(ops.conv2d_nhwc_rows(feats, smap, pk, bias, cout, 3, 2, 1, relu=True).float().cpu().numpy(),
+                               tref.cpu().numpy(), rtol=tol, atol=tol * tref.abs().max().item())

@@ -7,11 +7,11 @@ rows = list(csv.DictReader(open(glob.glob(d + "/*counter_collection.csv")[0])))
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in rows:
     if pat in r["Kernel_Name"]:
-        acc[r["Kernel_Name"][:70]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        acc[r["Kernel_Name"][:110]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 kt = list(csv.DictReader(open(glob.glob(d + "/*kernel_trace.csv")[0])))
 for k, cs in acc.items():
     m = {c: sum(v) / len(v) for c, v in cs.items()}
-    dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in kt if r["Kernel_Name"][:70] == k]
+    dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in kt if r["Kernel_Name"][:110] == k]
     print(k, f"launches={len(dur)} avg_us={sum(dur) / max(len(dur), 1):.1f}")
     for c, v in sorted(m.items()):
         print(f"  {c:28s} {v:.4g}")
