@@ -300,25 +300,34 @@ static int dispatch(const void *x, const void *wpk, const float *bias, void *y, 
     const bool c128 = p.cout % 128 == 0;
     if ((long long)p.h * p.w * p.cin * 2 > 0x7fffffffll) return kNotTaken;      // a frame is one buffer resource: 32-bit offsets
     if (p.ksize == 3 && p.stride == 2 && p.pad == 1) {
-        if (p.cin == 64 && p.cout == 64)
+        // (far larger maps than any PointPillars config of the reference -- 4 x 800 x 800: 5200 workgroups -- are better off on the generic
+        // implicit GEMM, 137 vs 166 us: a 74 KB footprint per 128 x 64 outputs is a lot of LDS fill when nothing hides it; r06 A/B)
+        if (p.cin == 64 && p.cout == 64 && (long long)p.batch * div_up(p.ho, 8) * div_up(p.wo, 16) <= 2560)
             return several_rounds(p, 8, 16, 64) ? launch<T, 64, 3, 2, 8, 16, 2, false, true>(x, wpk, bias, y, p, ldc, st)
                                                 : launch<T, 64, 3, 2, 8, 16, 2>(x, wpk, bias, y, p, ldc, st);
-        if (p.cin == 64 && c128) return launch<T, 64, 3, 2, 8, 16, 1>(x, wpk, bias, y, p, ldc, st);
-        if (p.cin == 128 && c128) return launch<T, 128, 3, 2, 4, 16, 1>(x, wpk, bias, y, p, ldc, st);
+        if (p.cin == 64 && c128)
+            return several_rounds(p, 8, 16, 128) ? launch<T, 64, 3, 2, 8, 16, 1, false, true>(x, wpk, bias, y, p, ldc, st)
+                                                 : launch<T, 64, 3, 2, 8, 16, 1>(x, wpk, bias, y, p, ldc, st);
+        if (p.cin == 128 && c128)
+            return several_rounds(p, 4, 16, 128) ? launch<T, 128, 3, 2, 4, 16, 1, false, true>(x, wpk, bias, y, p, ldc, st)
+                                                 : launch<T, 128, 3, 2, 4, 16, 1>(x, wpk, bias, y, p, ldc, st);
     }
     // stride-1 3x3 layers of the small PointPillars maps (batch 4: one round of workgroups, so a layer's time is one workgroup's time):
     // 256 channels at 50 x 50 and 64 -> 64 at 200 x 200 run 15 % / 12 % faster here than on k_conv2d_halo_reg's two-stage loop (steady
     // 8-deep B ring instead of 4-fragment double buffering; r06_pp3 / r06_pp4: 22.3 -> 19.0 us and 22.5 -> 18.6 us); the 128-channel
     // shared-row loop of k_conv2d_halo_reg stays ahead of this form (17.0 vs 18.3 us at 100 x 100) and keeps its layers.
     if (p.ksize == 3 && p.stride == 1 && p.pad == 1) {
-        if (p.cin == 64 && p.cout == 64) return launch<T, 64, 3, 1, 16, 16, 2>(x, wpk, bias, y, p, ldc, st);
-        if (p.cin == 256 && c128) return launch<T, 256, 3, 1, 4, 16, 1>(x, wpk, bias, y, p, ldc, st);
+        // (larger maps -- several rounds of workgroups, config 5's 124 x 124 -- stay on k_conv2d_halo_reg: -0.5 % on nusc.fhd with this form, r06_nusc_ab)
+        if (p.cin == 64 && p.cout == 64 && !several_rounds(p, 16, 16, 64)) return launch<T, 64, 3, 1, 16, 16, 2>(x, wpk, bias, y, p, ldc, st);
+        if (p.cin == 256 && c128 && !several_rounds(p, 4, 16, 128)) return launch<T, 256, 3, 1, 4, 16, 1>(x, wpk, bias, y, p, ldc, st);
 #ifdef SEC_PATCH_S1     // experiment builds: the 128-channel layers on this form too (A/B against k_conv2d_halo_reg)
         if (p.cin == 128 && c128) return launch<T, 128, 3, 1, 8, 16, 1>(x, wpk, bias, y, p, ldc, st);
 #endif
     }
     if (p.ksize == 4 && p.stride == 4 && p.pad == 0 && p.cin == 64 && c128) return launch<T, 64, 4, 4, 2, 16, 1>(x, wpk, bias, y, p, ldc, st);
-    if (p.ksize == 2 && p.stride == 2 && p.pad == 0 && p.cin == 128 && c128) return launch<T, 128, 2, 2, 2, 16, 1>(x, wpk, bias, y, p, ldc, st);
+    if (p.ksize == 2 && p.stride == 2 && p.pad == 0 && p.cin == 128 && c128)      // config 5's deblock (248 -> 124): 64-pixel tiles, half the weight re-reads
+        return several_rounds(p, 2, 16, 128) ? launch<T, 128, 2, 2, 4, 16, 1>(x, wpk, bias, y, p, ldc, st)
+                                             : launch<T, 128, 2, 2, 2, 16, 1>(x, wpk, bias, y, p, ldc, st);
     if (p.ksize == 1 && p.stride == 1 && p.pad == 0 && c128) {
         if (p.cin == 256) return launch<T, 256, 1, 1, 2, 16, 1>(x, wpk, bias, y, p, ldc, st);
         if (p.cin == 384) return launch<T, 384, 1, 1, 2, 16, 1>(x, wpk, bias, y, p, ldc, st);

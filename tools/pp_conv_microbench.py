@@ -11,6 +11,8 @@ B = int(os.environ.get("BATCH", "4"))
 LAYERS = [(64, 64, 3, 2, 1, 400), (64, 64, 3, 1, 1, 200), (64, 128, 4, 4, 0, 200), (64, 128, 3, 2, 1, 200), (128, 128, 3, 1, 1, 100),
           (128, 128, 2, 2, 0, 100), (128, 256, 3, 2, 1, 100), (256, 256, 3, 1, 1, 50), (256, 128, 1, 1, 0, 50), (384, 256, 1, 1, 0, 50)]
 GRAPH = int(os.environ.get("GRAPH", "1"))      # time launches replayed from a hipGraph (an eager launch through ctypes has a ~10 us floor)
+if os.environ.get("SHAPES") == "nusc.fhd":      # config 5's RPN (all.fhd: 248 x 248 BEV map, blocks of 128 and 256 channels)
+    LAYERS = [(128, 128, 3, 1, 1, 248), (128, 128, 2, 2, 0, 248), (128, 256, 3, 2, 1, 248), (256, 256, 3, 1, 1, 124), (64, 64, 3, 2, 1, 800)]
 def bench(fn, warm=200, n=200):
     if GRAPH:
         side = torch.cuda.Stream()
