@@ -27,7 +27,22 @@ struct VoxParams {
     int num_points, num_features, batch, max_points, max_voxels, cap_mode;
     int peek;        // k_vox_hash: look before the atomics (pays when most points share their cell with an earlier point)
     uint32_t table_mask;
+    // Pillar path (many points per voxel, small grid: sec_voxelize_f32 with voxels == NULL):
+    int stage;       // k_vox_cell_first: 0 = every point; 1 / 2 = the EARLY points of every cloud (in-cloud index < len / kStageDiv) / the others
+    int dense_cells; // > 0: cells per cloud of the DENSE slot numbering (slot = cloud * cells + linear cell; no key array, no probing)
 };
+
+// Staged first-point pass of a pillar config (dense numbering, from a quarter of a million points).  One device-scope atomicMin per
+// point runs at the fabric's atomic rate, ~11 G/s: 105 us for the 1.17 M points of config 4 (the hash form with its two device-scope
+// loads per point took 95).  The first eighth of every cloud's points is enough to settle most slots: after it -- a kernel boundary
+// later -- a slot that any early point touched holds an index below every later point's, so the later points look with a plain,
+// L2-cached load and skip the atomic (a stale value can only be LARGER: it costs the atomic it would have saved; slots no early point
+// touched still take their atomicMin).  13 + 37 us for the two launches (r06_stage*), exact.
+constexpr int kStageDiv = 8;
+__device__ __forceinline__ bool stage_early(const int *__restrict__ offs, int b, int i) {
+    const int q = i - offs[b], len = offs[b + 1] - offs[b];
+    return (long long)q * kStageDiv < len;
+}
 
 __device__ __forceinline__ int frame_of(const int *__restrict__ offs, int batch, int i) {
     int lo = 0, hi = batch;  // find b with offs[b] <= i < offs[b+1]
@@ -86,6 +101,31 @@ __global__ __launch_bounds__(kBlock) void k_vox_hash(const float *__restrict__ p
     pslot[i] = (int)s;
 }
 
+// DENSE numbering (pillar grids: batch * cells fits the table the workspace holds anyway): a cell's slot is its linear index, so the
+// first-point pass is ONE non-returning atomicMin per point (no key array, no compare-and-swap, no probing, nothing to wait for) and
+// vals[] is 2.5 MB for config 4 instead of the 48 MB hash table of 1.17 M points.  Stage 2 looks first (plain load, see above).
+__global__ __launch_bounds__(kBlock) void k_vox_cell_first(const float *__restrict__ points, const int *__restrict__ offs, VoxParams p,
+                                                          int *__restrict__ vals, int *__restrict__ pslot) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= p.num_points) return;
+    if (i >= offs[p.batch]) { if (p.stage != 2) pslot[i] = -1; return; }        // capacity rows beyond the live point count
+    const int b = frame_of(offs, p.batch, i);
+    if (p.stage && stage_early(offs, b, i) != (p.stage == 1)) return;           // the other launch's point
+    const float *pt = points + (size_t)i * p.num_features;
+    int c[3];
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        float q = floorf(__fdiv_rn(__fsub_rn(pt[j], p.lo[j]), p.vs[j]));       // as k_vox_hash: the reference loop's arithmetic
+        if (!(q >= 0.0f) || !(q < (float)p.grid[j])) ok = false;
+        c[j] = (int)q;
+    }
+    if (!ok) { pslot[i] = -1; return; }
+    const int s = b * p.dense_cells + (c[2] * p.grid[1] + c[1]) * p.grid[0] + c[0];
+    if (p.stage != 2 || __hip_atomic_load(&vals[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > i) atomicMin(&vals[s], i);
+    pslot[i] = s;
+}
+
 __global__ __launch_bounds__(kBlock) void k_vox_init(unsigned long long *__restrict__ keys, int *__restrict__ vals, long long table,
                                                     int *__restrict__ count, long long rows, int *__restrict__ slot_idx,
                                                     long long slots, int *__restrict__ ctl, long long ctl_words,
@@ -99,7 +139,10 @@ __global__ __launch_bounds__(kBlock) void k_vox_init(unsigned long long *__restr
     for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < ctl_words; i += stride) ctl[i] = 0;
     if (svid)      // fused scan: a point of a voxel spins on svid[slot] until the voxel's first point has numbered it
         for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < table; i += stride) svid[i] = kEmptyI32;
-    for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < table; i += stride) { keys[i] = kEmptyKey; vals[i] = kEmptyI32; }
+    if (keys)
+        for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < table; i += stride) { keys[i] = kEmptyKey; vals[i] = kEmptyI32; }
+    else       // dense numbering: `table` = batch * cells first-point words, no keys
+        for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < table; i += stride) vals[i] = kEmptyI32;
     for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < rows; i += stride) count[i] = 0;
     for (long long i = (long long)blockIdx.x * kBlock + threadIdx.x; i < slots; i += stride) slot_idx[i] = kEmptyI32;
 }
@@ -108,38 +151,49 @@ __global__ __launch_bounds__(kBlock) void k_vox_init(unsigned long long *__restr
 // (single-pass scan of common.hpp); *total = number of voxels over all clouds.  Four points per thread: a quarter of the tiles, so a
 // quarter of the same-address ticket atomics and status words on the look-back chain (round 3).
 constexpr int kFlagItems = 4;
+// ITEMS = 16 for the sweeps of the nuScenes configs (1.17 M points at batch 4): 286 tiles instead of 1146 -- the launch is as long as its
+// same-address ticket atomics take (~25 ns each: 30 us with four points per thread).
+constexpr int kFlagItemsBig = 16;
+template <int ITEMS>
 __global__ __launch_bounds__(kBlock) void k_vox_flag_scan(const int *__restrict__ pslot, const int *__restrict__ vals, int n,
                                                          int *__restrict__ rank, unsigned long long *__restrict__ status,
                                                          int *__restrict__ ticket, int *__restrict__ total) {
+    static_assert(ITEMS % 4 == 0, "int4 groups");
     __shared__ int smem[5];
     __shared__ int s_tile;
     const int tile = scan_take_tile(ticket, &s_tile);
-    const int i0 = (tile * kBlock + threadIdx.x) * kFlagItems;
-    int f[kFlagItems], v = 0;
-    int s4[kFlagItems];
-    if (i0 + kFlagItems <= n) {
-        const int4 q = *reinterpret_cast<const int4 *>(pslot + i0);
-        s4[0] = q.x; s4[1] = q.y; s4[2] = q.z; s4[3] = q.w;
+    const int i0 = (tile * kBlock + threadIdx.x) * ITEMS;
+    int f[ITEMS], v = 0;
+    int s4[ITEMS];
+    if (i0 + ITEMS <= n) {
+#pragma unroll
+        for (int g = 0; g < ITEMS / 4; ++g) {
+            const int4 q = *reinterpret_cast<const int4 *>(pslot + i0 + 4 * g);
+            s4[4 * g] = q.x; s4[4 * g + 1] = q.y; s4[4 * g + 2] = q.z; s4[4 * g + 3] = q.w;
+        }
     } else {
 #pragma unroll
-        for (int j = 0; j < kFlagItems; ++j) s4[j] = ld_sel(pslot, i0 + j, i0 + j < n, -1);
+        for (int j = 0; j < ITEMS; ++j) s4[j] = ld_sel(pslot, i0 + j, i0 + j < n, -1);
     }
 #pragma unroll
-    for (int j = 0; j < kFlagItems; ++j) {
+    for (int j = 0; j < ITEMS; ++j) {
         f[j] = (ld_sel(vals, s4[j], s4[j] >= 0, -1) == i0 + j) ? 1 : 0;      // unconditional loads: all ITEMS in flight at once
         v += f[j];
     }
     int ex = scan_lookback(v, tile, (int)gridDim.x, status, smem, total);
-    if (i0 + kFlagItems <= n) {
-        int4 r;
-        r.x = ex; ex += f[0];
-        r.y = ex; ex += f[1];
-        r.z = ex; ex += f[2];
-        r.w = ex;
-        *reinterpret_cast<int4 *>(rank + i0) = r;
+    if (i0 + ITEMS <= n) {
+#pragma unroll
+        for (int g = 0; g < ITEMS / 4; ++g) {
+            int4 r;
+            r.x = ex; ex += f[4 * g];
+            r.y = ex; ex += f[4 * g + 1];
+            r.z = ex; ex += f[4 * g + 2];
+            r.w = ex; ex += f[4 * g + 3];
+            *reinterpret_cast<int4 *>(rank + i0 + 4 * g) = r;
+        }
     } else {
 #pragma unroll
-        for (int j = 0; j < kFlagItems; ++j) {
+        for (int j = 0; j < ITEMS; ++j) {
             if (i0 + j < n) rank[i0 + j] = ex;
             ex += f[j];
         }
@@ -211,7 +265,7 @@ __global__ __launch_bounds__(kBlock) void k_vox_assign(const int *__restrict__ o
         int vid = (total ? s_voff[b] : voxel_offsets[b]) + r;
         svid[s] = vid;
         unsigned long long vol = (unsigned long long)p.grid[0] * p.grid[1] * p.grid[2];
-        unsigned long long lin = keys[s] - (unsigned long long)b * vol;
+        unsigned long long lin = p.dense_cells ? (unsigned long long)(s - b * p.dense_cells) : keys[s] - (unsigned long long)b * vol;
         int x = (int)(lin % p.grid[0]);
         unsigned long long t = lin / p.grid[0];
         int y = (int)(t % p.grid[1]);
@@ -420,6 +474,10 @@ __global__ __launch_bounds__(kRankBlock) void k_vox_group_rank(const int *__rest
     // The points of ONE voxel inside a workgroup are counted in LDS first (a small hash table keyed by the voxel row), so a voxel costs
     // one returning global atomic per WORKGROUP that touches it: the near pillars of a nuScenes sweep hold thousands of points, and a
     // returning atomic per point (or per wave) on their counters serialised the launch -- 116 us for 293 k points, 8 us this way.
+    // (Random point order -- the synthetic sweeps -- leaves ~1000 distinct voxels per 1024-point workgroup, i.e. about one returning atomic
+    // per point again: 78 us for 1.17 M points, the fabric's rate for atomics.  Placing the early eighth of every cloud first and dropping
+    // the later points of voxels it already fills was measured in round 6: only 2 % of the bench cloud's points live in such pillars
+    // (max 758 points per pillar), two launches 21 + 68 us -- rejected, DESIGN_APPENDIX.)
     __shared__ int t_key[kRankTable], t_cnt[kRankTable], t_base[kRankTable];
     const int tid = threadIdx.x, i = blockIdx.x * kRankBlock + tid;
     for (int j = tid; j < kRankTable; j += kRankBlock) { t_key[j] = -1; t_cnt[j] = 0; }
@@ -766,13 +824,22 @@ SEC_API int sec_voxelize_f32(const float *points, const int *point_offsets, int 
     int rc;
     // scan + numbering + slots in one launch (k_vox_scan_assign_cascade) for the shapes of the sparse-middle configs
     const bool fused_scan = num_points > 0 && batch <= kFusedFrames && max_points <= kCascadeMaxPoints;
+    // Pillar path (sort path + voxels == NULL: the consumers read the point lists, nobody looks cells up in the hash table afterwards --
+    // sec_rulebook_*_after_voxelize needs the voxel tensor's configs): dense slot numbering when batch * cells fits the carved table,
+    // and the staged first-point pass (kStageDiv) from a quarter of a million points.
+    const long long cells = (long long)p.grid[0] * p.grid[1] * p.grid[2];
+    const bool dense = w.sort_bits && !voxels && num_points > 0 && (long long)batch * cells <= (long long)w.table;
+    const bool staged_first = dense && num_points >= 256 * 1024;
+    p.dense_cells = dense ? (int)cells : 0;
+    p.stage = 0;
     {   // one init launch instead of four memset nodes; only the rows that can be live (#voxels <= #points) are touched
         long long cap_rows = (long long)batch * max_voxels;
         if (cap_rows > num_points) cap_rows = num_points > 0 ? num_points : 1;
-        int blocks = div_up((long long)w.table, kBlock);
+        const long long table = dense ? (long long)batch * cells : (long long)w.table;
+        int blocks = div_up(table, kBlock);
         if (blocks > 256 * 8) blocks = 256 * 8;
-        hipLaunchKernelGGL(k_vox_init, dim3(blocks), dim3(kBlock), 0, st, w.keys, w.vals, (long long)w.table, w.count, cap_rows,
-                           w.slot_idx, cap_rows * max_points, w.ctl, (long long)scan_ctl_words(num_points), w.break_idx, batch,
+        hipLaunchKernelGGL(k_vox_init, dim3(blocks), dim3(kBlock), 0, st, dense ? (unsigned long long *)nullptr : w.keys, w.vals, table, w.count, cap_rows,
+                           w.slot_idx, w.sort_bits ? 0ll : cap_rows * max_points /* the run path (k_vox_run_select) writes every slot a consumer reads (t < count): 29 MB of fill less for config 4 */, w.ctl, (long long)scan_ctl_words(num_points), w.break_idx, batch,
                            fused_scan ? w.svid : (int *)nullptr, fused_scan ? w.frame_words : (unsigned long long *)nullptr);
     }
     const bool fused_frames = num_points > 0 && batch <= kFusedFrames;
@@ -785,9 +852,21 @@ SEC_API int sec_voxelize_f32(const float *points, const int *point_offsets, int 
                            w.pslot, w.vals, num_points, p, reinterpret_cast<unsigned long long *>(w.ctl + 4), w.ctl, w.total,
                            w.frame_words, w.base, voxel_offsets, w.svid, w.break_idx, coors, w.count, w.slot_idx);
     } else if (num_points > 0) {
-        hipLaunchKernelGGL(k_vox_hash, dim3(nb), dim3(kBlock), 0, st, points, point_offsets, p, w.keys, w.vals, w.pslot);
-        hipLaunchKernelGGL(k_vox_flag_scan, dim3(div_up(num_points, kBlock * kFlagItems)), dim3(kBlock), 0, st, w.pslot, w.vals, num_points, w.rank,
-                           reinterpret_cast<unsigned long long *>(w.ctl + 4), w.ctl, w.total);
+        if (dense) {
+            for (int stg = staged_first ? 1 : 0; stg <= (staged_first ? 2 : 0); ++stg) {
+                p.stage = stg;
+                hipLaunchKernelGGL(k_vox_cell_first, dim3(nb), dim3(kBlock), 0, st, points, point_offsets, p, w.vals, w.pslot);
+            }
+            p.stage = 0;
+        } else {
+            hipLaunchKernelGGL(k_vox_hash, dim3(nb), dim3(kBlock), 0, st, points, point_offsets, p, w.keys, w.vals, w.pslot);
+        }
+        if (num_points >= 512 * 1024)
+            hipLaunchKernelGGL(k_vox_flag_scan<kFlagItemsBig>, dim3(div_up(num_points, kBlock * kFlagItemsBig)), dim3(kBlock), 0, st, w.pslot, w.vals, num_points,
+                               w.rank, reinterpret_cast<unsigned long long *>(w.ctl + 4), w.ctl, w.total);
+        else
+            hipLaunchKernelGGL(k_vox_flag_scan<kFlagItems>, dim3(div_up(num_points, kBlock * kFlagItems)), dim3(kBlock), 0, st, w.pslot, w.vals, num_points,
+                               w.rank, reinterpret_cast<unsigned long long *>(w.ctl + 4), w.ctl, w.total);
     } else if ((rc = fill_words(w.total, sizeof(int), 0u, st))) return rc;
     if (!fused_frames)
         hipLaunchKernelGGL(k_vox_frames, dim3(1), dim3(64), 0, st, point_offsets, w.rank, w.total, p, w.base,

@@ -1370,3 +1370,28 @@ def test_conv2d_nhwc_rows_equals_pillar_scatter_then_conv(ops, cout, hw, npil, d
     tol = 2 ** -7 if dtype == torch.bfloat16 else 2 ** -9
     np.testing.assert_allclose(ops.conv2d_nhwc_rows(feats, smap, pk, bias, cout, 3, 2, 1, relu=True).float().cpu().numpy(),
                                tref.cpu().numpy(), rtol=tol, atol=tol * tref.abs().max().item())
+
+
+@pytest.mark.parametrize("sizes", [(150000, 0, 210000), (60000, 0, 30000)])
+def test_voxelize_pillars_dense_numbering_and_staged_passes(ops, syn, sizes):
+    """The pillar path of sec_voxelize_f32 (csrc/voxelize.hip: voxels == NULL, max_points > 8): dense slot numbering (k_vox_cell_first) and,
+    from 256 k points, the staged first-point pass (early eighth of every cloud first, the others look before their atomicMin).  A ragged batch with an empty cloud, above and below the staging threshold, both cap modes, the voxel cap hit
+    and not hit: counts and coordinates equal the oracle-checked tensor path, and the PillarFeatureNet computed through the point lists
+    equals the one computed from the oracle-checked voxel tensor bit for bit (slot contents and slot order)."""
+    rng_, vs = [-50, -50, -10, 50, 50, 10], [0.25, 0.25, 20]
+    clouds = [syn.syn_nusc_cloud(7 + k, n, tuple(rng_), scene="urban") if n else np.zeros((0, 4), np.float32) for k, n in enumerate(sizes)]
+    pts, offs = syn.batch_clouds(clouds)
+    pts, offs = dev(pts), dev(offs)
+    rng = np.random.default_rng(11)
+    wt, sc, sh = dev((rng.standard_normal((9, 64)) / 3).astype(np.float32)), dev(rng.uniform(0.5, 1.5, 64).astype(np.float32)), dev(rng.uniform(-0.3, 0.3, 64).astype(np.float32))
+    xo, yo = vs[0] / 2 + rng_[0], vs[1] / 2 + rng_[1]
+    for cap_mode in ("break", "continue"):
+        for max_points, max_voxels in ((60, 30000), (60, 5000), (100, 30000)):
+            ref = _check_voxelize(ops, clouds, vs, rng_, max_points, max_voxels, cap_mode)       # tensor path (hash numbering) vs the oracle
+            p = ref["voxel_num"]
+            out = ops.pfn_forward(ref["voxels"][:p].contiguous(), ref["num_points_per_voxel"][:p].contiguous(), ref["coordinates"][:p].contiguous(),
+                                  wt, sc, sh, vs[0], vs[1], xo, yo)
+            v2 = ops.voxelize(pts, offs, rng_, vs, max_points, max_voxels, cap_mode, fill=False)
+            assert v2["voxels"] is None and v2["voxel_num"] == p and torch.equal(v2["voxel_offsets"], ref["voxel_offsets"])
+            assert torch.equal(v2["num_points_per_voxel"][:p], ref["num_points_per_voxel"][:p]) and torch.equal(v2["coordinates"][:p], ref["coordinates"][:p])
+            assert torch.equal(ops.pfn_forward_slots(pts, v2, wt, sc, sh, vs[0], vs[1], xo, yo)[:p], out)
