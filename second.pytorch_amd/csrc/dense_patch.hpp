@@ -75,9 +75,11 @@ __device__ constexpr typename PieceTable<CIN, KS, ST, TH, TW>::Arr g_piece_table
 // pieces are gathered from the rows (cells without a pillar and the padding read zeros through the buffer bounds check) -- what the
 // zero fill + scatter + this conv computed from the 82 MB canvas of config 4, without the canvas.  A tile whose footprint holds no
 // pillar skips the DMA and the K loop (its result is act(bias), exactly: 0 * w accumulates to 0).
-// TABLE: the footprint entries come from g_piece_table instead of being decoded in the kernel.  The table costs one more dependent load in
-// the prologue: it pays when the launch runs several rounds of workgroups (the VALU work of the decode is what a round waits for: first conv
-// of config 4, 1300 workgroups, 27.4 -> 22.9 us) and costs ~1 us when a layer is ONE round of workgroups (every other layer at batch 4).
+// TABLE: the footprint entries come from g_piece_table instead of being decoded in the kernel -- for the ROWS form on launches of several
+// rounds of workgroups only.  ROWS needs every entry before its first DMA anyway (map lookups first), so there the table replaces ~60 VALU
+// instructions per piece by one load (first conv of config 4, 1300 workgroups: 27.4 -> 22.9 us); on a ONE-round launch the extra dependent
+// load costs ~1 us, and the image form -- which decodes an entry right before issuing its piece, so its DMAs leave while the decode of the
+// next ones runs -- is 6-8 us SLOWER with the table at every size (29.3 vs 35.7 us at 4 x 400 x 400, 53.5 vs 61.7 us at config 5's 128 -> 256).
 template <typename T, int CIN, int KS, int ST, int TH, int TW, int PXS, bool ROWS = false, bool TABLE = false>
 __global__ __launch_bounds__(256, 2) void k_conv2d_patch(const T *__restrict__ x, const T *__restrict__ wpk, const float *__restrict__ bias,
                                                          T *__restrict__ y, Conv2dParams p, int tiles_y, int tiles_x, int per_xcd, int ldc,
@@ -303,14 +305,9 @@ static int dispatch(const void *x, const void *wpk, const float *bias, void *y, 
         // (far larger maps than any PointPillars config of the reference -- 4 x 800 x 800: 5200 workgroups -- are better off on the generic
         // implicit GEMM, 137 vs 166 us: a 74 KB footprint per 128 x 64 outputs is a lot of LDS fill when nothing hides it; r06 A/B)
         if (p.cin == 64 && p.cout == 64 && (long long)p.batch * div_up(p.ho, 8) * div_up(p.wo, 16) <= 2560)
-            return several_rounds(p, 8, 16, 64) ? launch<T, 64, 3, 2, 8, 16, 2, false, true>(x, wpk, bias, y, p, ldc, st)
-                                                : launch<T, 64, 3, 2, 8, 16, 2>(x, wpk, bias, y, p, ldc, st);
-        if (p.cin == 64 && c128)
-            return several_rounds(p, 8, 16, 128) ? launch<T, 64, 3, 2, 8, 16, 1, false, true>(x, wpk, bias, y, p, ldc, st)
-                                                 : launch<T, 64, 3, 2, 8, 16, 1>(x, wpk, bias, y, p, ldc, st);
-        if (p.cin == 128 && c128)
-            return several_rounds(p, 4, 16, 128) ? launch<T, 128, 3, 2, 4, 16, 1, false, true>(x, wpk, bias, y, p, ldc, st)
-                                                 : launch<T, 128, 3, 2, 4, 16, 1>(x, wpk, bias, y, p, ldc, st);
+            return launch<T, 64, 3, 2, 8, 16, 2>(x, wpk, bias, y, p, ldc, st);
+        if (p.cin == 64 && c128) return launch<T, 64, 3, 2, 8, 16, 1>(x, wpk, bias, y, p, ldc, st);
+        if (p.cin == 128 && c128) return launch<T, 128, 3, 2, 4, 16, 1>(x, wpk, bias, y, p, ldc, st);
     }
     // stride-1 3x3 layers of the small PointPillars maps (batch 4: one round of workgroups, so a layer's time is one workgroup's time):
     // 256 channels at 50 x 50 and 64 -> 64 at 200 x 200 run 15 % / 12 % faster here than on k_conv2d_halo_reg's two-stage loop (steady
