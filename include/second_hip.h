@@ -309,6 +309,14 @@ int sec_conv2d_nhwc_gather(const void *features, long long feature_rows, const i
                            const unsigned short *tile_order, const int *live_counts, const void *background, void *y,
                            int dtype, void *stream);   /* tile_order .. background: see sec_rpn_tile_live; tile_order NULL = every tile tests its own map entries; background NULL with lists = lazy consumers (below) */
 
+/* sec_conv2d_nhwc writing channels [y_channel_offset, y_channel_offset + cout) of a wider channels-last map [batch][ho][wo][y_channels]:
+ * the deblocks of a multi-block RPN deposit their outputs straight into the concatenated feature map the heads read (`torch.cat(ups, dim=1)`,
+ * rpn.py:386-391) -- no concat copy.  Shapes: those of the strided / patch conv kernel (3x3 s2 p1 from 64 or 128 channels; k == stride 4 from 64,
+ * 2 from 128 channels; 1x1 from 256 or 384 channels; cout a multiple of 128, or 64 -> 64 for the 3x3), SEC_E_UNSUPPORTED otherwise; offsets and
+ * widths multiples of 8 channels.  Same arithmetic as sec_conv2d_nhwc (bit-identical values). */
+int sec_conv2d_nhwc_into(const void *x, int batch, int h, int w, int cin, const void *packed_weight, const float *bias, int cout,
+                         int ksize, int stride, int pad, int relu, void *y, int y_channels, int y_channel_offset, int dtype, void *stream);
+
 /* PointPillarsScatter + the first RPN conv without the canvas (second/pytorch/models/pointpillars.py:444-476 writes the pillar rows
  * into a zeroed [B, C, ny, nx] image that rpn.py:484-486 `ZeroPad2d(1) + Conv2d(3, stride 2)` then reads): the convolution
  * (+ bias + ReLU, as sec_conv2d_nhwc) of that image straight from the pillar feature rows `rows` [feature_rows][cin] (16-bit) and

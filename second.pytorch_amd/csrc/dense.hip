@@ -1842,6 +1842,29 @@ SEC_API int sec_conv2d_nhwc(const void *x, int batch, int h, int w, int cin, con
     return launch_conv2d<__half>(x, packed_weight, bias, y, p, st);
 }
 
+SEC_API int sec_conv2d_nhwc_into(const void *x, int batch, int h, int w, int cin, const void *packed_weight, const float *bias, int cout,
+                                 int ksize, int stride, int pad, int relu, void *y, int y_channels, int y_channel_offset, int dtype, void *stream) {
+    if (!x || !packed_weight || !y || batch <= 0 || h <= 0 || w <= 0 || ksize <= 0 || stride <= 0 || pad < 0 || y_channel_offset < 0 ||
+        y_channel_offset + cout > y_channels)
+        return SEC_E_INVALID;
+    if (cin % 64 || cout % 64 || (y_channel_offset % 8) || (y_channels % 8) || (dtype != SEC_BF16 && dtype != SEC_F16)) return SEC_E_UNSUPPORTED;
+    Conv2dParams p;
+    p.batch = batch; p.h = h; p.w = w; p.cin = cin; p.cout = cout; p.ksize = ksize; p.stride = stride; p.pad = pad;
+    p.relu = relu & 1;
+    p.zskip = 0;
+    p.stagger = 0;
+    p.ho = (h + 2 * pad - ksize) / stride + 1;
+    p.wo = (w + 2 * pad - ksize) / stride + 1;
+    if (p.ho <= 0 || p.wo <= 0) return SEC_E_INVALID;
+    p.m = (long long)batch * p.ho * p.wo;
+    hipStream_t st = (hipStream_t)stream;
+    // only k_conv2d_patch writes with a channel pitch: the shapes of patch::dispatch (the deblocks of the multi-block RPNs among them)
+    const int rc = dtype == SEC_BF16
+                       ? patch::dispatch<__hip_bfloat16>(x, packed_weight, bias, (__hip_bfloat16 *)y + y_channel_offset, p, y_channels, st)
+                       : patch::dispatch<__half>(x, packed_weight, bias, (__half *)y + y_channel_offset, p, y_channels, st);
+    return rc == patch::kNotTaken ? SEC_E_UNSUPPORTED : rc;
+}
+
 SEC_API int sec_conv2d_nhwc_rows(const void *rows, long long feature_rows, const int *site_map, int batch, int h, int w, int cin,
                                  const void *packed_weight, const float *bias, int cout, int ksize, int stride, int pad, int relu, void *y,
                                  int dtype, void *stream) {

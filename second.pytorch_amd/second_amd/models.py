@@ -672,6 +672,7 @@ class RPNInference(nn.Module):
                         self.chain_x3 = [ops.conv2d_pack_weight_x3(wl_), ops.conv2d_pack_weight_x3(hw64), hb64]
         # deblock (1x1, stride 1, 128 -> 128) + heads (<= 128 padded channels) run as ONE kernel (sec_conv1x1_chain_nhwc)
         wl = self.ws[-1]
+        self.concat_in_place = True      # multi-block RPNs: the deblocks write into the concatenated map (False: torch.cat of their outputs)
         self.pillar_rows_first = True    # a PillarBEV input: the first conv reads the pillar rows through a site map when the shapes allow (False: the scattered canvas)
         self.sparse_input = True   # forward()'s input comes from SparseConvTensor.dense(): all-zero halo tiles skip their MFMA loop (bit-identical)
         # first conv straight from the sparse rows (sec_conv2d_nhwc_gather): 3x3 / s1 / p1 on 2 planes x 64 channels; its weights
@@ -893,6 +894,7 @@ class RPNInference(nn.Module):
         else:
             pillars = None
         live = nbr = None
+        catbuf, coff = None, 0
         for kind, i in self.plan:
             if kind == "c" and x is None:
                 # the first conv straight from the pillar rows (sec_conv2d_nhwc_rows): no zero fill, no scatter, no 82 MB canvas
@@ -925,6 +927,15 @@ class RPNInference(nn.Module):
                 first = False
             elif self.chain_tail:
                 ups.append(None)                     # single block: the deblock runs fused with the heads below
+            elif self._deblocks_write_into_the_concat():
+                # multi-block RPN: every deblock deposits its channels straight into the map the heads read (no torch.cat; sec_conv2d_nhwc_into)
+                w_, (s_, p_) = self.ws[i], self.cfgs[i]
+                if catbuf is None:
+                    ho, wo = (x.shape[2] + 2 * p_[0] - w_.shape[2]) // s_[0] + 1, (x.shape[3] + 2 * p_[1] - w_.shape[3]) // s_[1] + 1
+                    catbuf = torch.empty((x.shape[0], self._cat_channels, ho, wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+                    coff = 0
+                ups.append(ops.conv2d_nhwc_into(x, self.packed[i], self.bs[i], w_.shape[0], w_.shape[2], s_[0], p_[0], True, catbuf, coff))
+                coff += w_.shape[0]
             else:
                 ups.append(self._conv(x, i))
         lazy_heads = None
@@ -939,7 +950,7 @@ class RPNInference(nn.Module):
         elif self.chain_tail:
             y = ops.conv1x1_chain(x, self.packed[-1], self.bs[-1], self.head_packed, self.head_b64, self.head_cout)
         else:
-            f = ups[0] if len(ups) == 1 else torch.cat(ups, dim=1)    # channels_last in, channels_last out
+            f = catbuf if catbuf is not None else (ups[0] if len(ups) == 1 else torch.cat(ups, dim=1))    # channels_last in, channels_last out
             if self.use_hip:
                 y = ops.conv2d_nhwc(f.contiguous(memory_format=torch.channels_last), self.head_packed, self.head_b64,
                                     self.head_cout, 1, 1, 0, relu=False)
@@ -949,6 +960,19 @@ class RPNInference(nn.Module):
         if lazy_heads is not None:
             ret["lazy_heads"] = lazy_heads          # consumed by SecondDetector._predict_fused (ops.predict_select / predict_decode lazy=)
         return ret
+
+    def _deblocks_write_into_the_concat(self):
+        """Several deblocks, each a plain conv (no depth-to-space) of a shape sec_conv2d_nhwc_into serves: they fill one preallocated map."""
+        v = getattr(self, "_into_ok", None)
+        if v is None:
+            us = [i for kind, i in self.plan if kind == "u"]
+            v = bool(self.use_hip and self.concat_in_place and len(us) > 1 and all(
+                self.ups[i] == 1 and self.cfgs[i][0][0] == self.cfgs[i][0][1] and self.cfgs[i][1][0] == self.cfgs[i][1][1] and self.ws[i].shape[2] == self.ws[i].shape[3]
+                and ops.conv2d_into_supported(self.ws[i].shape[1], self.ws[i].shape[0], self.ws[i].shape[2], self.cfgs[i][0][0], self.cfgs[i][1][0], self.ws[i].dtype)
+                for i in us))
+            self._cat_channels = sum(self.ws[i].shape[0] for i in us)
+            self._into_ok = v
+        return v
 
     def list_layers(self):
         """Layers of live-tile lists / masks a forward asks rpn_tile_live for: one per 3x3 conv, plus one when the heads are lazy (its

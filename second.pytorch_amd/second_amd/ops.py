@@ -1083,6 +1083,32 @@ def conv2d_nhwc_rows(rows, site_map, packed, bias, cout, ksize, stride, pad, rel
     return y
 
 
+def conv2d_into_supported(cin, cout, ksize, stride, pad, dtype):
+    """Shapes :func:`conv2d_nhwc_into` serves (the strided / patch conv kernel, csrc/dense_patch.hpp patch::dispatch)."""
+    if dtype not in (torch.bfloat16, torch.float16):
+        return False
+    c128 = cout % 128 == 0
+    return ((ksize, stride, pad) == (3, 2, 1) and ((cin == 64 and (cout == 64 or c128)) or (cin == 128 and c128))
+            or (ksize, stride, pad, cin) == (4, 4, 0, 64) and c128 or (ksize, stride, pad, cin) == (2, 2, 0, 128) and c128
+            or (ksize, stride, pad) == (1, 1, 0) and cin in (256, 384) and c128)
+
+
+@_traced("conv2d_nhwc")
+def conv2d_nhwc_into(x, packed, bias, cout, ksize, stride, pad, relu, out, channel_offset):
+    """:func:`conv2d_nhwc` writing channels [channel_offset, channel_offset + cout) of the channels_last map ``out`` [B, C, Ho, Wo]
+    (sec_conv2d_nhwc_into): the deblocks of a multi-block RPN fill the concatenated map the heads read without a ``torch.cat``.
+    Returns the channel slice (a view)."""
+    rt.require_gpu(x, packed, out)
+    assert x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and out.is_contiguous(memory_format=torch.channels_last)
+    b, cin, h, w = x.shape
+    ho, wo = (h + 2 * pad - ksize) // stride + 1, (w + 2 * pad - ksize) // stride + 1
+    assert out.dtype == x.dtype and out.shape[0] == b and tuple(out.shape[2:]) == (ho, wo) and channel_offset + cout <= out.shape[1]
+    rc = rt.lib().sec_conv2d_nhwc_into(rt.ptr(x), b, h, w, cin, rt.ptr(packed), rt.ptr(bias), int(cout), int(ksize), int(stride), int(pad),
+                                       int(bool(relu)), rt.ptr(out), int(out.shape[1]), int(channel_offset), rt.dtype_code(x.dtype), rt.stream())
+    rt.check(rc, "sec_conv2d_nhwc_into")
+    return out[:, channel_offset:channel_offset + cout]
+
+
 def conv2d_rows_supported(cin, cout, ksize, stride, pad, dtype):
     return (dtype in (torch.bfloat16, torch.float16) and cin == 64 and ksize == 3 and stride == 2 and pad == 1
             and (cout == 64 or cout % 128 == 0))

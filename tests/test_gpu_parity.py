@@ -736,7 +736,16 @@ def test_rpn_inference_multi_block_pointpillars_shape():
         f32 = RPNInference(net, torch.float32)(x.contiguous(memory_format=torch.channels_last))
         inf = RPNInference(net, torch.bfloat16)
         assert inf.use_hip and not inf.chain_tail
-        bf = inf(x.bfloat16().contiguous(memory_format=torch.channels_last))
+        xb = x.bfloat16().contiguous(memory_format=torch.channels_last)
+        bf = inf(xb)
+        # the deblocks deposit their outputs straight into the concatenated map (sec_conv2d_nhwc_into): bit-identical to torch.cat of them
+        assert inf._deblocks_write_into_the_concat()
+        cat = RPNInference(net, torch.bfloat16)
+        cat.concat_in_place = False
+        bf_cat = cat(xb)
+        assert not cat._deblocks_write_into_the_concat()
+        for k in bf:
+            assert torch.equal(bf[k], bf_cat[k]), k
     for k in ref:
         assert f32[k].shape == ref[k].shape == bf[k].shape
         np.testing.assert_allclose(f32[k].cpu().numpy(), ref[k].cpu().numpy(), rtol=2e-3, atol=2e-4)
