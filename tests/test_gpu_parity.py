@@ -580,6 +580,21 @@ def test_rotate_nms_1000_boxes_vs_oracle(ops):
             np.testing.assert_array_equal(k[1], r1[:post] if post else r1)
 
 
+@pytest.mark.parametrize("n", [700, 1100, 1500])
+def test_rotate_nms_reduce_forms_vs_oracle(ops, n):
+    """Candidate counts off the usual 1000 (odd and even numbers of 64-bit mask words per row, up to 24): keep lists equal the sequential
+    oracle's, ragged batch (65 = one box into the second block, n - 1), with and without a post-NMS cap."""
+    rng = np.random.default_rng(n)
+    dets = np.concatenate([rng.uniform(0, 70, (n, 1)), rng.uniform(-40, 40, (n, 1)), rng.uniform(1.4, 1.8, (n, 1)),
+                           rng.uniform(3.5, 4.3, (n, 1)), rng.uniform(-3.2, 3.2, (n, 1)),
+                           np.sort(rng.uniform(0.3, 1, (n, 1)), 0)[::-1]], 1).astype(np.float32)
+    for post in (0, 83):
+        k = _nms_call(ops, [dets, dets[:65], dets[:n - 1]], 0.05, "rotate", "numba", post_max=post)
+        for kk, d in zip(k, (dets, dets[:65], dets[:n - 1])):
+            r = orc.rotate_nms_sorted(d, 0.05, "numba")
+            np.testing.assert_array_equal(kk, r[:post] if post else r)
+
+
 @pytest.mark.parametrize("thr", [0.01, 0.1, 0.3, 0.5])
 def test_rotate_nms_clustered_candidates_vs_oracle(ops, thr):
     """The candidates of a detector cluster on the objects (a few dozen jittered boxes per object): the regime where the mask
