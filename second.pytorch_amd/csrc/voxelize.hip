@@ -608,11 +608,13 @@ __device__ __forceinline__ void vox_select_wave(int v, int n, int s0, int nvalid
 template <int R>
 __global__ __launch_bounds__(kBlock) void k_vox_run_select(const int *__restrict__ voxel_offsets, int batch, const int *__restrict__ count,
                                                           const int *__restrict__ run_start, const int *__restrict__ run, int max_points,
-                                                          int *__restrict__ slot_idx) {
+                                                          int *__restrict__ slot_idx, int *__restrict__ num_points_per_voxel) {
     __shared__ int s_sorted[kBlock / 64][64 * R];
     const int v = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     if (v >= voxel_offsets[batch]) return;                    // (whole waves leave: no barrier below)
     const int n = count[v];
+    // callers without a voxel tensor (point lists only) get the capped counts here: one launch (k_vox_counts) less on the pillar path
+    if (num_points_per_voxel && (threadIdx.x & 63) == 0) num_points_per_voxel[v] = n > max_points ? max_points : n;
     vox_select_wave<R>(v, n, run_start[v], n, s_sorted, run, max_points, slot_idx);
 }
 
@@ -884,12 +886,13 @@ SEC_API int sec_voxelize_f32(const float *points, const int *point_offsets, int 
                                reinterpret_cast<unsigned long long *>(w.ctl2 + 4), w.ctl2);
             hipLaunchKernelGGL(k_vox_run_scatter, dim3(nb), dim3(kBlock), 0, st, w.sval_in, w.sval_out, num_points, w.run_start, w.run);
             const dim3 gs(div_up(rows, kBlock / 64));
+            int *counts_here = voxels ? (int *)nullptr : num_points_per_voxel;
             if (max_points <= 64)
-                hipLaunchKernelGGL(k_vox_run_select<1>, gs, dim3(kBlock), 0, st, voxel_offsets, batch, w.count, w.run_start, w.run, max_points, w.slot_idx);
+                hipLaunchKernelGGL(k_vox_run_select<1>, gs, dim3(kBlock), 0, st, voxel_offsets, batch, w.count, w.run_start, w.run, max_points, w.slot_idx, counts_here);
             else if (max_points <= 128)
-                hipLaunchKernelGGL(k_vox_run_select<2>, gs, dim3(kBlock), 0, st, voxel_offsets, batch, w.count, w.run_start, w.run, max_points, w.slot_idx);
+                hipLaunchKernelGGL(k_vox_run_select<2>, gs, dim3(kBlock), 0, st, voxel_offsets, batch, w.count, w.run_start, w.run, max_points, w.slot_idx, counts_here);
             else
-                hipLaunchKernelGGL(k_vox_run_select<4>, gs, dim3(kBlock), 0, st, voxel_offsets, batch, w.count, w.run_start, w.run, max_points, w.slot_idx);
+                hipLaunchKernelGGL(k_vox_run_select<4>, gs, dim3(kBlock), 0, st, voxel_offsets, batch, w.count, w.run_start, w.run, max_points, w.slot_idx, counts_here);
         } else {
             hipLaunchKernelGGL(k_vox_cascade, dim3(nb), dim3(kBlock), 0, st, point_offsets, w.pslot, w.svid,
                                w.break_idx, p, w.count, w.slot_idx);
@@ -899,7 +902,8 @@ SEC_API int sec_voxelize_f32(const float *points, const int *point_offsets, int 
     long long bound = num_points < cap ? num_points : cap;  // #voxels <= #points
     if (bound > 0 && !voxels) {
         // the caller consumes the point lists in the workspace directly (sec_pfn_fwd_slots): no [rows, max_points, F] tensor
-        hipLaunchKernelGGL(k_vox_counts, dim3(div_up(bound, kBlock)), dim3(kBlock), 0, st, voxel_offsets, w.count, p, num_points_per_voxel);
+        if (!w.sort_bits)      // (the run path wrote them in k_vox_run_select)
+            hipLaunchKernelGGL(k_vox_counts, dim3(div_up(bound, kBlock)), dim3(kBlock), 0, st, voxel_offsets, w.count, p, num_points_per_voxel);
     } else if (bound > 0 && mean && num_features == 4 && max_points <= kCascadeMaxPoints &&
         (reinterpret_cast<uintptr_t>(points) & 15) == 0 && (reinterpret_cast<uintptr_t>(voxels) & 15) == 0) {
         const dim3 gf(div_up(bound, kBlock));
