@@ -35,7 +35,7 @@ extern "C" {
 #define SEC_F16 1
 #define SEC_BF16 2
 
-#define SEC_ABI_VERSION 7
+#define SEC_ABI_VERSION 8
 int sec_abi_version(void);
 /* Content checksum of `count` device tensors in one launch (+ one memset): sums [count][2] = (sum of the tensor's 32-bit words, sum of
  * word * (index + 1)), both mod 2^64.  h_ptrs / h_nbytes are HOST arrays (4-byte aligned pointers, byte counts that are multiples of

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libsecond_hip.so")
 LIB_PATH = os.environ.get("SEC_HIP_LIB", LIB_PATH)   # A/B builds: point at another libsecond_hip.so
 
 SEC_F32, SEC_F16, SEC_BF16 = 0, 1, 2
-ABI_VERSION = 7          # include/second_hip.h SEC_ABI_VERSION the argtypes in lib() were written for
+ABI_VERSION = 8          # include/second_hip.h SEC_ABI_VERSION the argtypes in lib() were written for
 _DTYPES = {torch.float32: SEC_F32, torch.float16: SEC_F16, torch.bfloat16: SEC_BF16}
 _ERRORS = {-1: "SEC_E_INVALID (bad argument)", -2: "SEC_E_WORKSPACE (workspace too small)",
            -3: "SEC_E_UNSUPPORTED", -4: "SEC_E_LAUNCH (HIP error)"}
