@@ -830,7 +830,7 @@ SEC_API int sec_voxelize_f32(const float *points, const int *point_offsets, int 
     // sec_rulebook_*_after_voxelize needs the voxel tensor's configs): dense slot numbering when batch * cells fits the carved table,
     // and the staged first-point pass (kStageDiv) from a quarter of a million points.
     const long long cells = (long long)p.grid[0] * p.grid[1] * p.grid[2];
-    const bool dense = w.sort_bits && !voxels && num_points > 0 && (long long)batch * cells <= (long long)w.table;
+    const bool dense = w.sort_bits && !voxels && num_points > 0 && (long long)batch * cells <= (long long)w.table && (long long)batch * cells < 0x7fffffffll;   // slots are ints
     const bool staged_first = dense && num_points >= 256 * 1024;
     p.dense_cells = dense ? (int)cells : 0;
     p.stage = 0;
