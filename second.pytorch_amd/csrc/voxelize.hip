@@ -550,7 +550,7 @@ __device__ __forceinline__ void vox_select_wave(int v, int n, int s0, int nvalid
     for (int rr = 0; rr < R; ++rr) {                           // every element of the chunk, broadcast: smaller ones (or equal and earlier) count
         const int lim = m - rr * 64 < 64 ? m - rr * 64 : 64;   // elements of register rr
         for (int k = 0; k < lim; ++k) {
-            const int o = __shfl(x[rr], k, 64);
+            const int o = __builtin_amdgcn_readlane(x[rr], k);      // k is wave-uniform: one v_readlane instead of a ds_bpermute round trip per element
             const int pos = rr * 64 + k;
 #pragma unroll
             for (int r = 0; r < R; ++r) rk[r] += (o < x[r] || (o == x[r] && pos < r * 64 + lane)) ? 1 : 0;
@@ -568,13 +568,13 @@ __device__ __forceinline__ void vox_select_wave(int v, int n, int s0, int nvalid
 #pragma unroll
     for (int r = 0; r < R; ++r) S[r] = s_sorted[wv][r * 64 + lane];
     if (n > CAP) {
-        int T = __shfl(S[R - 1], 63, 64);                      // the largest kept index
+        int T = __builtin_amdgcn_readlane(S[R - 1], 63);       // the largest kept index
         for (int base = CAP; base < n; base += 64) {
             const int y = ld_sel(run, s0 + base + lane, base + lane < n, BIG);
             unsigned long long pend = __ballot(y < T);
             while (pend) {
                 const int l = __ffsll((long long)pend) - 1;
-                const int val = __shfl(y, l, 64);
+                const int val = __builtin_amdgcn_readlane(y, l);
                 pend &= pend - 1;
                 if (val >= T) continue;                        // T fell since the ballot
                 int pos = 0;
@@ -585,14 +585,14 @@ __device__ __forceinline__ void vox_select_wave(int v, int n, int s0, int nvalid
                 for (int r = 0; r < R; ++r) {
                     const int pr = pos - r * 64;               // insertion lane in this register: < 0 everything shifts, >= 64 nothing does
                     if (pr < 64) {
-                        const int last = __shfl(S[r], 63, 64);
+                        const int last = __builtin_amdgcn_readlane(S[r], 63);
                         const int up = __shfl_up(S[r], 1, 64);
                         const int at = pr < 0 ? 0 : pr;
                         S[r] = lane > at ? up : (lane == at ? carry : S[r]);
                         carry = last;
                     }
                 }
-                T = __shfl(S[R - 1], 63, 64);
+                T = __builtin_amdgcn_readlane(S[R - 1], 63);
             }
         }
     }
