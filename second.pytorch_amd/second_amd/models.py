@@ -1410,15 +1410,42 @@ class SecondDetector(nn.Module):
         return res
 
 
-def lane_stream(device=None):
+def lane_stream(device=None, index=None):
     """A stream for one lane of a serving loop.  HIP maps streams onto a handful of hardware queues (GPU_MAX_HW_QUEUES, default 4) per
     PRIORITY level, handing a new stream the least-shared queue: whether two lanes end up behind each other in one queue then depends
     on how many other streams the process created before (torch's capture / warm-up side streams included) -- measured on the same
     loop: 17.0 k, 13.3 k or 9.4 k frames/s depending on it.  High-priority streams come from a queue pool of their own that nothing
     else in the process uses, so a few lanes get a queue each whatever ran before.  SEC_LANE_PRIORITY=0: normal-priority streams."""
     import os
+    groups = int(os.environ.get("SEC_LANE_CU_GROUPS", "0") or 0)
+    if groups > 1 and index is not None:
+        return _cu_masked_stream(index % groups, groups)
     prio = -1 if os.environ.get("SEC_LANE_PRIORITY", "-1") != "0" else 0
     return torch.cuda.Stream(device=device, priority=prio)
+
+
+_masked_streams = []          # (hipStream_t, ExternalStream): kept alive for the life of the process
+
+
+def _cu_masked_stream(group, groups):
+    """EXPERIMENT (SEC_LANE_CU_GROUPS=g): a stream whose kernels run on the ``group``-th of ``groups`` equal slices of every XCD's CUs
+    (hipExtStreamCreateWithCUMask; mask bit i = CU slot i // 8 of XCD i % 8 on MI355X, ``tools/probes/cu_mask_probe.hip``), so that lanes of
+    different groups never share a CU and every chip-filling launch of a lane becomes several rounds on its own slice."""
+    import ctypes
+    path = next(l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l)
+    hip = ctypes.CDLL(path)
+    slots = 32 // groups                                   # CU slots per XCD and group
+    bits = 0
+    for slot in range(group * slots, (group + 1) * slots):
+        bits |= 0xff << (8 * slot)
+    words = (ctypes.c_uint32 * 8)(*[(bits >> (32 * w)) & 0xffffffff for w in range(8)])
+    st = ctypes.c_void_p()
+    rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), 8, words)
+    if rc != 0:
+        raise RuntimeError(f"hipExtStreamCreateWithCUMask -> {rc}")
+    ext = torch.cuda.ExternalStream(st.value)
+    _masked_streams.append((st, ext))
+    return ext
 
 
 class _NullCtx:
@@ -1483,7 +1510,7 @@ class InFlightRunner:
             self.replays.append(replay)
             self.outputs.append(outs)
             self._overflow += [c for lst in getattr(det, "_branch_overflow", []) for c in lst]
-        self.lanes = [lane_stream() for _ in self.replays] if len(self.replays) > 1 else [None]
+        self.lanes = [lane_stream(index=i) for i in range(len(self.replays))] if len(self.replays) > 1 else [None]
         self._k = 0
 
     def step(self, host_points=None, host_offsets=None, fetch=False):
