@@ -308,6 +308,16 @@ def kernel_table(det, points, offsets, reps=30):
                        detail=f"{cin}->{cout} k3 ({h_}, {w_}); {lv} of {tot} tiles are within reach of a site and are convolved, "
                               + ("the others are copied from the empty frame's output" if copied else
                                  "the others are not written (the next conv reads them from the empty frame's map)"))
+        elif name == "conv2d_nhwc_tiles_tail":
+            x, tl = a[0], a[3]
+            b_, cin, h_, w_ = x.shape
+            lv, tot = int(a[4].sum().item()), tl.numel()
+            # the last 3x3 conv with the 1x1 tail in its epilogue: FLOPs of both on the live tiles; the conv's output never reaches memory
+            ent.update(flop=2.0 * lv * 128 * (cin * 128 * 9 + 128 * (128 + res.shape[1])),
+                       bytes=elt(x.dtype) * (x.numel() * lv // tot + res.numel() * lv // tot), live_tiles=lv, tiles=tot,
+                       dense_equivalent_flop=2.0 * b_ * h_ * w_ * (cin * 128 * 9 + 128 * (128 + res.shape[1])),
+                       detail=f"{cin}->128 k3 ({h_}, {w_}) + fused 1x1 tail 128->128->{res.shape[1]} in the epilogue on {lv} of {tot} tiles; the conv's "
+                              "output stays in LDS, the other tiles of the head map are not written (select / decode read them from the empty frame's head map)")
         elif name == "rpn_tile_live":
             smap = a[0]
             ent.update(bytes=4 * smap.numel() + 2 * res[0].numel(), detail=f"site map {tuple(smap.shape)} -> live-tile maps of {a[1]} conv layers")

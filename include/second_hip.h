@@ -35,7 +35,7 @@ extern "C" {
 #define SEC_F16 1
 #define SEC_BF16 2
 
-#define SEC_ABI_VERSION 8
+#define SEC_ABI_VERSION 9
 int sec_abi_version(void);
 /* Content checksum of `count` device tensors in one launch (+ one memset): sums [count][2] = (sum of the tensor's 32-bit words, sum of
  * word * (index + 1)), both mod 2^64.  h_ptrs / h_nbytes are HOST arrays (4-byte aligned pointers, byte counts that are multiples of
@@ -372,6 +372,15 @@ int sec_rpn_tile_live_masks(const int *site_map, int batch, int h, int w, int la
 int sec_conv2d_nhwc_tiles_lazy(const void *x, int batch, int h, int w, const void *packed_weight, const float *bias, int cout,
                                int relu, const unsigned short *tile_order, const int *live_counts, const void *background,
                                const unsigned short *nbr_masks, const void *background_in, void *y, int dtype, void *stream);
+/* The LAST 3x3 conv of a single-block RPN with its 1x1 tail in the epilogue (round 6): sec_conv2d_nhwc_tiles_lazy (128 -> 128, background
+ * NULL) followed by sec_conv1x1_chain_nhwc_tiles (relu1 | SEC_CHAIN_X_LIVE_ONLY, background NULL, cout2 = 64) on the same lists, as ONE
+ * launch -- the conv's 16-bit output tile goes from LDS straight into the two 1x1 GEMMs (deblock rpn.py:275-285, merged heads
+ * rpn.py:386-391) and never reaches memory; y_heads [batch][h][w][64] holds the live tiles of the list (every tile when the conv falls
+ * back to the plain tile order), bit-identical to the two launches.  cout2 != 64 or a dtype other than bf16 / f16: SEC_E_UNSUPPORTED. */
+int sec_conv2d_nhwc_tiles_tail(const void *x, int batch, int h, int w, const void *packed_weight, const float *bias, int relu,
+                               const unsigned short *tile_order, const int *live_counts, const unsigned short *nbr_masks,
+                               const void *background_in, const void *packed_w1, const float *bias1, int relu1, const void *packed_w2,
+                               const float *bias2, int cout2, void *y_heads, int dtype, void *stream);
 
 /* Adjoint of sec_sparse_to_dense -- rows[i,:] = dense[indices[i]] -- i.e. the backward of
  * SparseConvTensor.dense() (upstream gets it from autograd through scatter_nd, spconv/__init__.py) and of

@@ -140,6 +140,15 @@ struct Conv2dParams {
     int stagger;  // profiling builds (-DSEC_CONV_TIMELINE): start delay in clocks per resident-slot index
 };
 
+// k_conv2d_halo_reg<..., TAIL>: the fused 1x1 tail (deblock 128 -> 128 + merged heads 128 -> 64, k_conv1x1_chain's two GEMMs) run on the
+// conv's output tile while it is still in LDS
+struct ConvTailArgs {
+    const void *w1, *w2;      // packed 1x1 weights ([cin8][cout] uint4, sec_conv2d_pack_weight with ksize 1)
+    const float *b1, *b2;
+    void *y;                  // [batch][h][w][64]
+    int relu1;
+};
+
 // Live share (of 256) up to which a conv / the fused tail follows its live-tile list; above it every tile is taken in the plain order
 // (computing a background tile is always correct).  SEC_RPN_LIST_MAX_LIVE=<percent> overrides (read once, before the first launch).
 // 225 / 256 = 88 % since round 6 (192 = 75 % before): on the bench's dense seeded scene, whose last two convs have 76-78 % of their tiles
@@ -365,7 +374,7 @@ template <int CH, int HW_, bool COLKEY> __device__ __forceinline__ int halo_key(
 // the fp32 result (bias + ReLU applied in fp32) into the two planes of the next layer's input.  18.4x the fp32 MFMA rate per
 // product / 3 passes: the matrix pipe's fp32 instruction (v_mfma_f32_32x32x2_f32, 256 FLOP/clk/CU) is what MIOpen's fp32
 // convolution runs at ~80 % of (0.65 ms per layer at batch 8).
-template <typename T, int CIN, int TH, int ROLL = 0, bool GATHER = false, int NSPLIT = 1, bool X3 = false>
+template <typename T, int CIN, int TH, int ROLL = 0, bool GATHER = false, int NSPLIT = 1, bool X3 = false, bool TAIL = false>
 __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(const T *__restrict__ x, const T *__restrict__ wpk,
                                                             const float *__restrict__ bias, T *__restrict__ y,
                                                             Conv2dParams p, int tiles_y, int tiles_x, int per_xcd,
@@ -377,8 +386,9 @@ __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(con
                                                             const T *__restrict__ bg_in = nullptr,
                                                             const T *__restrict__ x_lo = nullptr, T *__restrict__ y_lo = nullptr,
                                                             const T *__restrict__ background_lo = nullptr,
-                                                            const T *__restrict__ bg_in_lo = nullptr) {
+                                                            const T *__restrict__ bg_in_lo = nullptr, ConvTailArgs tail = ConvTailArgs{}) {
     static_assert(!GATHER || (ROLL == 2 && CIN == 128), "gather prologue: the shared-row loop on two 64-channel planes");
+    static_assert(!TAIL || (ROLL == 2 && CIN == 128 && TH == 8 && !GATHER && NSPLIT == 1 && !X3), "fused 1x1 tail: the lazy list form of the 128-channel conv");
     static_assert(!X3 || (ROLL == 2 && CIN == 128 && TH == 8 && !GATHER && NSPLIT == 1 && std::is_same<T, __hip_bfloat16>::value),
                   "three-pass split-fp32 form: the shared-row bf16 loop");
     constexpr int TW = 16, HW_ = TW + 2, HPIX = (TH + 2) * (TW + 2);
@@ -937,12 +947,83 @@ __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(con
                     }
                 }
             };
+            // TAIL: first-GEMM weights of the fused tail (this wave: all 128 pixels x mid channels [32 wv, 32 wv + 32)), in flight over the tile exchange
+            uint4 tq[TAIL ? 8 : 1];
+            if constexpr (TAIL) {
+                const uint4 *wl = reinterpret_cast<const uint4 *>(tail.w1) + (size_t)hh * 128 + wv * 32 + r;
+#pragma unroll
+                for (int s_ = 0; s_ < 8; ++s_) tq[s_] = wl[(size_t)s_ * 2 * 128];
+            }
             if (p.relu) put_tile(std::true_type{}, std::false_type{});
             else put_tile(std::false_type{}, std::false_type{});
             __syncthreads();
 #ifdef SEC_CONV_TIMELINE
             if (tl) tl_eb2 = clock64();
 #endif
+            if constexpr (TAIL) {
+                // The conv's 16-bit output tile [pixel q = ty * 16 + px][16 chunks of 8 channels] (pitch 17 uint4: the 16 lanes a ds_read_b128
+                // serves together hit 16 different 16-byte slots) is exactly k_conv1x1_chain's x tile: y = W2 relu(W1 x + b1) + b2 on it --
+                // same fragments, same k order, same roundings as the separate launch (bit-identical heads); the conv's output never
+                // reaches memory (28 MB written + 28 MB read per batch of 8) and the tail's launch, list lookups and lock-stepped round go.
+                f32x16d a1[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) a1[a][i] = 0.0f;
+#pragma unroll
+                for (int s_ = 0; s_ < 8; ++s_)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) a1[mt] = MfmaD<T>::run(tq[s_], ot[(mt * 32 + r) * PITCH + s_ * 2 + hh], a1[mt]);
+                // second-GEMM weights: wave = 64 pixels (wm) x 32 of the 64 head channels (wn)
+                const int wm = wv & 1, wn = wv >> 1;
+                uint4 cq[8];
+                {
+                    const uint4 *wl = reinterpret_cast<const uint4 *>(tail.w2) + (size_t)hh * 64 + wn * 32 + r;
+#pragma unroll
+                    for (int s_ = 0; s_ < 8; ++s_) cq[s_] = wl[(size_t)s_ * 2 * 64];
+                }
+                lds_barrier();                              // every wave has read all of the conv tile
+                {
+                    unsigned char *tb = reinterpret_cast<unsigned char *>(ot);
+                    auto put_mid = [&](auto relu_tag) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const float4 b1v = *reinterpret_cast<const float4 *>(tail.b1 + wv * 32 + 8 * g + 4 * hh);
+#pragma unroll
+                            for (int mt = 0; mt < 4; ++mt) {
+                                const int px = mt * 32 + r;
+                                float v[4] = {a1[mt][4 * g] + b1v.x, a1[mt][4 * g + 1] + b1v.y, a1[mt][4 * g + 2] + b1v.z, a1[mt][4 * g + 3] + b1v.w};
+                                if (decltype(relu_tag)::value) {
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j) v[j] = __builtin_fmaxf(v[j], 0.0f);
+                                }
+                                *reinterpret_cast<uint2 *>(tb + ((size_t)px * PITCH + (wv * 4 + g)) * 16 + hh * 8) = make_uint2(pack2<T>(v[0], v[1]), pack2<T>(v[2], v[3]));
+                            }
+                        }
+                    };
+                    if (tail.relu1 & 1) put_mid(std::true_type{});
+                    else put_mid(std::false_type{});
+                }
+                lds_barrier();
+                f32x16d a2[2];
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) a2[a][i] = 0.0f;
+#pragma unroll
+                for (int s_ = 0; s_ < 8; ++s_)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) a2[mt] = MfmaD<T>::run(cq[s_], ot[(wm * 64 + mt * 32 + r) * PITCH + s_ * 2 + hh], a2[mt]);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const int px = wm * 64 + mt * 32 + r;
+                    const int oy = y0 + (px >> 4), ox = x0 + (px & 15);
+                    const bool ok = oy < p.h && ox < p.w;
+                    T *ypix = reinterpret_cast<T *>(tail.y) + (ok ? (((size_t)b * p.h + oy) * p.w + ox) * 64 : 0);
+                    store_tile_t<T>(a2[mt], tail.b2, wn * 32, 0, ypix, ok, hh);
+                }
+                return;
+            }
             uint4 *y4 = reinterpret_cast<uint4 *>(y);
 #pragma unroll
             for (int ty_ = 0; ty_ < TH; ++ty_) {            // one tile row (16 pixels x 16 chunks) per instruction
@@ -1015,19 +1096,19 @@ extern "C" __attribute__((visibility("default"))) int sec__debug_timeline2(long 
 }
 #endif
 
-template <typename T, int CIN, int TH, int ROLL = 0, bool GATHER = false, int NSPLIT = 1, bool X3 = false>
+template <typename T, int CIN, int TH, int ROLL = 0, bool GATHER = false, int NSPLIT = 1, bool X3 = false, bool TAIL = false>
 static int launch_conv2d_halo_reg(const void *x, const void *wpk, const float *bias, void *y, const Conv2dParams &p, hipStream_t st,
                                   const int *site_map = nullptr, unsigned feat_bytes = 0, const unsigned short *tile_order = nullptr,
                                   const int *live_counts = nullptr, const void *background = nullptr,
                                   const unsigned short *nbr_masks = nullptr, const void *bg_in = nullptr,
                                   const void *x_lo = nullptr, void *y_lo = nullptr, const void *background_lo = nullptr,
-                                  const void *bg_in_lo = nullptr) {
+                                  const void *bg_in_lo = nullptr, const ConvTailArgs &tail = ConvTailArgs{}) {
     constexpr size_t lds_tile = (size_t)(TH + 2) * 18 * (CIN / 8) * 16;
     // (padding the dynamic LDS to hold 2 instead of 3 workgroups per CU was measured in round 3: slower in every combination)
     const long lds_pad = 0;
     const size_t lds = lds_tile + (size_t)lds_pad;
     static bool configured = false;
-    auto fn = k_conv2d_halo_reg<T, CIN, TH, ROLL, GATHER, NSPLIT, X3>;
+    auto fn = k_conv2d_halo_reg<T, CIN, TH, ROLL, GATHER, NSPLIT, X3, TAIL>;
     if (!configured) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         configured = true;
@@ -1035,12 +1116,13 @@ static int launch_conv2d_halo_reg(const void *x, const void *wpk, const float *b
     const int ty = div_up(p.h, TH), tx = div_up(p.w, 16);
     const int per_xcd = div_up(p.batch * ty * tx, 8);
     const int gx = per_xcd * 8;
-    if (X3) set_last_kernel("k_conv2d_halo_reg<%s, %d, %d, %d, false, 1, true>", dtype_name<T>(), CIN, TH, ROLL);
+    if (TAIL) set_last_kernel("k_conv2d_halo_reg<%s, %d, %d, %d, false, 1, false, true>", dtype_name<T>(), CIN, TH, ROLL);
+    else if (X3) set_last_kernel("k_conv2d_halo_reg<%s, %d, %d, %d, false, 1, true>", dtype_name<T>(), CIN, TH, ROLL);
     else if (NSPLIT == 1) set_last_kernel("k_conv2d_halo_reg<%s, %d, %d, %d, %s>", dtype_name<T>(), CIN, TH, ROLL, GATHER ? "true" : "false");
     else set_last_kernel("k_conv2d_halo_reg<%s, %d, %d, %d, %s, %d>", dtype_name<T>(), CIN, TH, ROLL, GATHER ? "true" : "false", NSPLIT);
     hipLaunchKernelGGL(fn, dim3(gx, p.cout / (128 / NSPLIT)), dim3(256), lds, st, (const T *)x, (const T *)wpk, bias, (T *)y, p, ty, tx, per_xcd,
                        site_map, feat_bytes, tile_order, live_counts, (const T *)background, nbr_masks, (const T *)bg_in, (const T *)x_lo, (T *)y_lo,
-                       (const T *)background_lo, (const T *)bg_in_lo);
+                       (const T *)background_lo, (const T *)bg_in_lo, tail);
     return check_launch();
 }
 
@@ -1803,6 +1885,31 @@ SEC_API int sec_conv2d_nhwc_tiles_lazy(const void *x, int batch, int h, int w, c
     if (!tile_order || !nbr_masks || !background_in) return SEC_E_INVALID;
     return conv2d_tiles_impl(x, batch, h, w, packed_weight, bias, cout, relu, tile_order, live_counts, background, nbr_masks, background_in, y,
                              dtype, stream);
+}
+
+// The last 3x3 conv of a single-block RPN with its 1x1 tail (deblock + merged heads) in the epilogue: see k_conv2d_halo_reg<..., TAIL>.
+SEC_API int sec_conv2d_nhwc_tiles_tail(const void *x, int batch, int h, int w, const void *packed_weight, const float *bias, int relu,
+                                       const unsigned short *tile_order, const int *live_counts, const unsigned short *nbr_masks,
+                                       const void *background_in, const void *packed_w1, const float *bias1, int relu1, const void *packed_w2,
+                                       const float *bias2, int cout2, void *y_heads, int dtype, void *stream) {
+    if (!x || !packed_weight || !tile_order || !live_counts || !nbr_masks || !background_in || !packed_w1 || !bias1 || !packed_w2 || !y_heads ||
+        batch <= 0 || h <= 0 || w <= 0)
+        return SEC_E_INVALID;
+    if (cout2 != 64 || (dtype != SEC_BF16 && dtype != SEC_F16)) return SEC_E_UNSUPPORTED;
+    apply_list_threshold_env();
+    Conv2dParams p;
+    p.batch = batch; p.h = h; p.w = w; p.cin = 128; p.cout = 128; p.ksize = 3; p.stride = 1; p.pad = 1;
+    p.relu = relu & 1; p.zskip = 0; p.stagger = 0;
+    p.ho = h; p.wo = w;
+    p.m = (long long)batch * h * w;
+    const ConvTailArgs tail{packed_w1, packed_w2, bias1, bias2, y_heads, relu1 & 1};
+    hipStream_t st = (hipStream_t)stream;
+    // y of the conv itself does not exist: the kernel's `y` is never dereferenced on the TAIL path (background == NULL: lazy form)
+    if (dtype == SEC_BF16)
+        return launch_conv2d_halo_reg<__hip_bfloat16, 128, 8, 2, false, 1, false, true>(x, packed_weight, bias, nullptr, p, st, nullptr, 0, tile_order, live_counts,
+                                                                                       nullptr, nbr_masks, background_in, nullptr, nullptr, nullptr, nullptr, tail);
+    return launch_conv2d_halo_reg<__half, 128, 8, 2, false, 1, false, true>(x, packed_weight, bias, nullptr, p, st, nullptr, 0, tile_order, live_counts, nullptr,
+                                                                           nbr_masks, background_in, nullptr, nullptr, nullptr, nullptr, tail);
 }
 
 SEC_API size_t sec_conv2d_packed_weight_bytes(int cout, int cin, int ksize, int dtype) {

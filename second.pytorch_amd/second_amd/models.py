@@ -700,6 +700,9 @@ class RPNInference(nn.Module):
         # tensor's live tiles ONLY and the select / decode kernels read every other tile from the empty frame's head map -- the copy
         # of ~60 % of the [B, H, W, 64] head tensor (22 MB per batch of 8) disappears; forward() then adds preds["lazy_heads"]
         self.lazy_heads = False
+        # fused_tail: with lazy heads the last 3x3 conv runs the 1x1 tail in its epilogue (sec_conv2d_nhwc_tiles_tail): one launch less, the
+        # conv's output never reaches memory
+        self.fused_tail = True
         self.last_live_counts = None       # [convs, B] int32 on the device: live tiles per conv and frame of the last forward (bench / tests)
         self._empty_maps = {}
         self.register_load_state_dict_post_hook(lambda module, incompatible: module._repack())
@@ -893,7 +896,7 @@ class RPNInference(nn.Module):
                 x = x.dense()
         else:
             pillars = None
-        live = nbr = None
+        live = nbr = fused_heads = None
         catbuf, coff = None, 0
         for kind, i in self.plan:
             if kind == "c" and x is None:
@@ -915,6 +918,11 @@ class RPNInference(nn.Module):
                 else:
                     x = ops.conv2d_nhwc_gather(gather.features, sm, self.gather_packed, self.bs[i], self.ws[i].shape[0], relu=True)
                 gather, first = None, False
+            elif kind == "c" and live is not None and nbr is not None and self._tail_in_last_conv(i, x, nbr):
+                # the last conv with the 1x1 tail (deblock + heads) in its epilogue: its output tile never leaves LDS (sec_conv2d_nhwc_tiles_tail)
+                fused_heads = ops.conv2d_nhwc_tiles_tail(x, self.packed[i], self.bs[i], live[i], self.last_live_counts[i], nbr[i], empty[i - 1],
+                                                         self.packed[-1], self.bs[-1], self.head_packed, self.head_b64, self.head_cout)
+                x = None
             elif kind == "c" and live is not None and nbr is not None:
                 # the last conv keeps its copies unless its consumer is the fused 1x1 tail on the same lists (x_live_only below)
                 keep = i == self.background_convs - 1 and not self.chain_tail
@@ -939,7 +947,10 @@ class RPNInference(nn.Module):
             else:
                 ups.append(self._conv(x, i))
         lazy_heads = None
-        if self.chain_tail and live is not None:
+        if fused_heads is not None:
+            y = fused_heads
+            lazy_heads = (nbr[self.background_convs, 1], self._split_heads(empty[self.background_convs]))
+        elif self.chain_tail and live is not None:
             last = self.background_convs - 1
             want_lazy = self.lazy_heads and nbr is not None and nbr.shape[0] > self.background_convs
             y = ops.conv1x1_chain(x, self.packed[-1], self.bs[-1], self.head_packed, self.head_b64, self.head_cout,
@@ -960,6 +971,14 @@ class RPNInference(nn.Module):
         if lazy_heads is not None:
             ret["lazy_heads"] = lazy_heads          # consumed by SecondDetector._predict_fused (ops.predict_select / predict_decode lazy=)
         return ret
+
+    def _tail_in_last_conv(self, i, x, nbr):
+        """Conv ``i`` is the last 3x3 conv of a single-block RPN whose consumers are all lazy (lazy heads on the same lists): it then runs
+        with the 1x1 tail in its epilogue.  SEC_RPN_FUSED_TAIL=0: the two launches (A/B, bit-identical)."""
+        import os
+        return (self.fused_tail and i == self.background_convs - 1 and self.chain_tail and self.lazy_heads and self.head_cout == 64
+                and nbr.shape[0] > self.background_convs and x is not None and x.shape[1] == 128
+                and x.dtype in (torch.bfloat16, torch.float16) and os.environ.get("SEC_RPN_FUSED_TAIL", "1") != "0")
 
     def _deblocks_write_into_the_concat(self):
         """Several deblocks, each a plain conv (no depth-to-space) of a shape sec_conv2d_nhwc_into serves: they fill one preallocated map."""

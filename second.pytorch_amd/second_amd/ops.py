@@ -1176,6 +1176,31 @@ def conv2d_nhwc_tiles(x, packed, bias, cout, tile_order, live_counts, background
     return y
 
 
+@_traced("conv2d_nhwc_tiles_tail")
+def conv2d_nhwc_tiles_tail(x, packed, bias, tile_order, live_counts, nbr_masks, background_in, packed_w1, bias1, packed_w2, bias2, cout2,
+                           relu=True, relu1=True):
+    """The lazy form of :func:`conv2d_nhwc_tiles` (128 -> 128) with the fused 1x1 tail of :func:`conv1x1_chain` (``x_live_only``, no
+    background) in its epilogue -- one launch, the conv's output never reaches memory (sec_conv2d_nhwc_tiles_tail).  Returns the head
+    tensor [B, cout2 = 64, H, W] channels_last; tiles outside the list are unwritten unless the conv took the plain tile order."""
+    rt.require_gpu(x, packed, tile_order, live_counts, nbr_masks, background_in, packed_w1, packed_w2, bias1)
+    assert x.dim() == 4 and x.shape[1] == 128 and x.is_contiguous(memory_format=torch.channels_last) and int(cout2) == 64
+    b, _, h, w = x.shape
+    tiles = ((h + 7) // 8) * ((w + 15) // 16)
+    assert tile_order.dtype == torch.int16 and tile_order.is_contiguous() and tuple(tile_order.shape) == (b, tiles)
+    assert live_counts.dtype == torch.int32 and live_counts.is_contiguous() and live_counts.numel() == b
+    assert nbr_masks.dtype == torch.int16 and nbr_masks.is_contiguous() and tuple(nbr_masks.shape) == (2, b, tiles)
+    assert background_in.dtype == x.dtype and background_in.numel() == h * w * 128 and background_in.is_contiguous(memory_format=torch.channels_last)
+    y = torch.empty((b, 64, h, w), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    if POISON_LAZY_OUTPUTS:
+        y.fill_(float("nan"))
+    rc = rt.lib().sec_conv2d_nhwc_tiles_tail(rt.ptr(x), b, h, w, rt.ptr(packed), rt.ptr(bias), int(bool(relu)), rt.ptr(tile_order), rt.ptr(live_counts),
+                                             rt.ptr(nbr_masks), rt.ptr(background_in), rt.ptr(packed_w1), rt.ptr(bias1), int(bool(relu1)),
+                                             rt.ptr(packed_w2), rt.ptr(bias2) if bias2 is not None else None, 64, rt.ptr(y),
+                                             rt.dtype_code(x.dtype), rt.stream())
+    rt.check(rc, "sec_conv2d_nhwc_tiles_tail")
+    return y
+
+
 # ----------------------------------------------------------------------------- IoU / NMS
 @_traced("conv1x1_chain")
 def conv1x1_chain(x, packed_w1, bias1, packed_w2, bias2, cout2, relu1=True, tile_order=None, live_counts=None, background=None, x_live_only=False):

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libsecond_hip.so")
 LIB_PATH = os.environ.get("SEC_HIP_LIB", LIB_PATH)   # A/B builds: point at another libsecond_hip.so
 
 SEC_F32, SEC_F16, SEC_BF16 = 0, 1, 2
-ABI_VERSION = 8          # include/second_hip.h SEC_ABI_VERSION the argtypes in lib() were written for
+ABI_VERSION = 9          # include/second_hip.h SEC_ABI_VERSION the argtypes in lib() were written for
 _DTYPES = {torch.float32: SEC_F32, torch.float16: SEC_F16, torch.bfloat16: SEC_BF16}
 _ERRORS = {-1: "SEC_E_INVALID (bad argument)", -2: "SEC_E_WORKSPACE (workspace too small)",
            -3: "SEC_E_UNSUPPORTED", -4: "SEC_E_LAUNCH (HIP error)"}
@@ -25,7 +25,7 @@ SYMBOLS = [
     "sec_rulebook_conv3d_tables", "sec_rulebook_sorted_workspace_bytes", "sec_rulebook_conv3d_build_sorted",
     "sec_rulebook_conv3d_tables_sorted", "sec_rulebook_subm3d_after_conv_sorted", "sec_rulebook_chain_workspace_bytes",
     "sec_rulebook_chain_sorted", "sec_conv_output_shape", "sec_packed_weight_bytes", "sec_packed_weight_x3_bytes",
-    "sec_pack_conv_weight", "sec_indice_conv_fwd", "sec_indice_conv_fwd_plan", "sec_indice_conv_set_variant", "sec_indice_conv_bwd_workspace_bytes", "sec_indice_conv_bwd", "sec_pack_conv_weight_train", "sec_sparse_to_dense", "sec_dense_to_sparse", "sec_sparse_site_map", "sec_sparse_site_map_sorted", "sec_conv2d_nhwc_gather", "sec_conv2d_nhwc_rows", "sec_conv2d_nhwc_into", "sec_rpn_tile_live_workspace_bytes", "sec_rpn_tile_live", "sec_rpn_tile_live_masks", "sec_conv2d_nhwc_tiles", "sec_conv2d_nhwc_tiles_lazy", "sec_conv1x1_chain_nhwc_tiles",
+    "sec_pack_conv_weight", "sec_indice_conv_fwd", "sec_indice_conv_fwd_plan", "sec_indice_conv_set_variant", "sec_indice_conv_bwd_workspace_bytes", "sec_indice_conv_bwd", "sec_pack_conv_weight_train", "sec_sparse_to_dense", "sec_dense_to_sparse", "sec_sparse_site_map", "sec_sparse_site_map_sorted", "sec_conv2d_nhwc_gather", "sec_conv2d_nhwc_rows", "sec_conv2d_nhwc_into", "sec_rpn_tile_live_workspace_bytes", "sec_rpn_tile_live", "sec_rpn_tile_live_masks", "sec_conv2d_nhwc_tiles", "sec_conv2d_nhwc_tiles_lazy", "sec_conv2d_nhwc_tiles_tail", "sec_conv1x1_chain_nhwc_tiles",
     "sec_pillar_scatter", "sec_pfn_fwd", "sec_pfn_fwd_slots", "sec_pfn_train_workspace_bytes", "sec_pfn_train_fwd", "sec_pfn_train_bwd", "sec_block_filter_workspace_bytes",
     "sec_voxel_block_filter_f32", "sec_bias_act_nhwc", "sec_conv2d_packed_weight_bytes",
     "sec_conv2d_pack_weight", "sec_conv2d_nhwc", "sec_split_f32_bf16x2", "sec_merge_bf16x2_f32", "sec_conv2d_nhwc_x3", "sec_conv2d_nhwc_x3_tiles", "sec_conv1x1_chain_x3", "sec_conv1x1_chain_nhwc", "sec_rotate_iou_f32", "sec_nms_workspace_bytes", "sec_nms_sorted_f32",
@@ -173,6 +173,7 @@ def lib():
         l.sec_conv2d_nhwc_tiles.argtypes = [vp, ci, ci, ci, vp, vp, ci, ci, vp, vp, vp, vp, ci, vp]
         l.sec_rpn_tile_live_masks.argtypes = [vp, ci, ci, ci, ci, vp, vp, vp, vp, sz, vp]
         l.sec_conv2d_nhwc_tiles_lazy.argtypes = [vp, ci, ci, ci, vp, vp, ci, ci, vp, vp, vp, vp, vp, vp, ci, vp]
+        l.sec_conv2d_nhwc_tiles_tail.argtypes = [vp, ci, ci, ci, vp, vp, ci, vp, vp, vp, vp, vp, vp, ci, vp, vp, ci, vp, ci, vp]
         l.sec_rotate_iou_f32.argtypes = [vp, ci, vp, ci, ci, vp, vp]
         l.sec_nms_workspace_bytes.argtypes = [ci, ci]
         l.sec_nms_sorted_f32.argtypes = [vp, vp, ci, ci, ci, cf, ci, ci, cf, ci, vp, vp, vp, sz, vp]

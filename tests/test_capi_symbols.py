@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(rt.LIB_PATH)
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.sec_abi_version() == rt.ABI_VERSION == 8
+    assert lib.sec_abi_version() == rt.ABI_VERSION == 9
 
 
 def test_workspace_queries_are_host_only():

@@ -261,6 +261,75 @@ def test_lazy_heads_give_the_detections_of_the_materialised_head_tensor(monkeypa
         assert torch.equal(lazy[k], eager[k]), k
 
 
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("list_pct", ["", "0"])
+def test_last_conv_with_the_tail_in_its_epilogue_is_bit_identical_to_the_two_launches(monkeypatch, dtype, list_pct):
+    """sec_conv2d_nhwc_tiles_tail (the last 3x3 conv with deblock + heads in its epilogue: its output tile goes from LDS into the two 1x1
+    GEMMs) against sec_conv2d_nhwc_tiles_lazy + sec_conv1x1_chain_nhwc_tiles (SEC_RPN_FUSED_TAIL=0): the head tensor's live tiles and
+    every output of the step, bit for bit; unwritten tiles poisoned.  list_pct "0": the conv falls back to the plain tile order
+    (every tile computed) while the consumers still follow the lists."""
+    import subprocess, sys, os
+    if list_pct:          # the list threshold is read once per process: its own interpreter
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        env = dict(os.environ, SEC_RPN_LIST_MAX_LIVE=list_pct, SEC_TAIL_TEST_DTYPE=str(dtype).split(".")[-1],
+                   PYTHONPATH=os.pathsep.join([root, os.path.join(root, "second.pytorch_amd"), os.environ.get("PYTHONPATH", "")]))
+        r = subprocess.run([sys.executable, __file__, "--tail-child"], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        return
+    _tail_vs_two_launches(dtype, monkeypatch.setenv)
+
+
+def _tail_vs_two_launches(dtype, setenv):
+    from second_amd.models import SecondDetector, CAR_FHD
+    from second_amd import ops, synthetic as syn
+    clouds = [syn.syn_kitti_cloud(s) for s in range(3)]
+    pts, offs = syn.batch_clouds(clouds)
+    pts, offs = torch.from_numpy(pts).cuda(), torch.from_numpy(offs).cuda()
+    torch.manual_seed(0)
+    det = SecondDetector(dict(CAR_FHD, nms_score_threshold=0.3)).cuda().eval()
+    g = torch.Generator().manual_seed(5)
+    for m in det.modules():
+        if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+            m.running_mean.copy_(torch.empty(m.num_features).uniform_(-0.1, 0.1, generator=g))
+            m.running_var.copy_(torch.empty(m.num_features).uniform_(0.5, 1.5, generator=g))
+            m.bias.data.copy_(torch.empty(m.num_features).uniform_(-0.2, 0.3, generator=g))
+    det.rpn.conv_cls.bias.data.fill_(-0.2)
+    det.prepare_inference(dtype)
+    det.calibrate(pts, offs)
+    seen = []
+    outs, heads = {}, {}
+    with torch.no_grad():
+        vox = det.voxel_generator.generate_device(pts, offs, mean_features=4, sync=False, mean_dtype=dtype)
+        for mode in ("1", "0"):
+            setenv("SEC_RPN_FUSED_TAIL", mode)
+            ops.set_op_hook(lambda name, fn, a, kw, res: seen.append((mode, name)))
+            ops.POISON_LAZY_OUTPUTS = True
+            try:
+                with det.lazy_heads():
+                    preds = det.network_forward(vox["mean"], vox["coordinates"], 3, num_active_dev=vox["voxel_offsets"][3:])
+                outs[mode] = {k: v.clone() for k, v in det.forward_points(pts, offs, static=True).items() if isinstance(v, torch.Tensor)}
+            finally:
+                ops.POISON_LAZY_OUTPUTS = False
+                ops.set_op_hook(None)
+            heads[mode] = preds
+    assert ("1", "conv2d_nhwc_tiles_tail") in seen and ("1", "conv1x1_chain") not in seen
+    assert ("0", "conv1x1_chain") in seen and ("0", "conv2d_nhwc_tiles_tail") not in seen
+    live = ((heads["0"]["lazy_heads"][0].int() >> 4) & 1).bool()                 # [B, tiles]: the last conv's list holds the tile
+    assert torch.equal(heads["1"]["lazy_heads"][0], heads["0"]["lazy_heads"][0]) and 0 < int(live.sum()) < live.numel()
+    for k in ("box_preds", "cls_preds", "dir_cls_preds"):
+        a, b = heads["1"][k], heads["0"][k]
+        assert a.shape == b.shape
+        # the tiles of the list, bit for bit (the fused conv may have written more: plain order); [B, A, H, W, code] views of the head map
+        bsz, hh, ww = a.shape[0], a.shape[2], a.shape[3]
+        th, tw = -(-hh // 8), -(-ww // 16)
+        m = live.view(bsz, th, tw).repeat_interleave(8, 1).repeat_interleave(16, 2)[:, :hh, :ww]
+        av, bv = a.permute(0, 2, 3, 1, 4)[m], b.permute(0, 2, 3, 1, 4)[m]
+        assert not torch.isnan(bv.float()).any() and torch.equal(av, bv), k
+    assert int(outs["0"]["valid"].sum()) >= 20
+    for k in outs["0"]:
+        assert torch.equal(outs["1"][k], outs["0"][k]), k
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
 def test_prepared_rpn_follows_a_state_dict_loaded_later(dtype):
     """RPNInference keeps packed copies of its folded weights (MFMA slab order, gather permutation, hi | lo pairs of the fp32
@@ -298,3 +367,9 @@ def test_prepared_rpn_follows_a_state_dict_loaded_later(dtype):
     got = run(a)
     for k in out_b:
         assert torch.equal(got[k], out_b[k]), k
+
+
+if __name__ == "__main__" and "--tail-child" in __import__("sys").argv:
+    import os as _os
+    _tail_vs_two_launches(getattr(torch, _os.environ["SEC_TAIL_TEST_DTYPE"]), lambda k, v: _os.environ.__setitem__(k, v))
+    print("ok")
