@@ -163,7 +163,7 @@ def kernel_table(det, points, offsets, reps=30):
         torch.cuda.synchronize()
         try:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            with ops.rt.capture_guard(), torch.cuda.graph(g, capture_error_mode="thread_local"):
                 for _ in range(reps):
                     fn(*a, **kw)
             g.replay()
@@ -1320,13 +1320,13 @@ def main():
     bg_tiles = None
     if rank == 0 and getattr(det.rpn, "background_convs", 0):
         if det.rpn.skip_background:
-            lt = [k for k in (ktable or []) if k["op"] in ("conv2d_nhwc_tiles", "conv2d_nhwc_gather")]
+            lt = [k for k in (ktable or []) if k["op"] in ("conv2d_nhwc_tiles", "conv2d_nhwc_gather", "conv2d_nhwc_tiles_tail")]
             bg_tiles = {"enabled": True, "lazy": bool(getattr(det.rpn, "lazy_background", False)), "live_tiles_per_conv": [k.get("live_tiles") for k in lt] or None, "tiles": lt[0].get("tiles") if lt else None,
                         "what": "conv j of the RPN (j = 0..5) convolves only the 8 x 16 tiles a site of the sparse middle can reach within j + 1 "
                                 "steps; the other tiles equal the network's output for an EMPTY frame at that position exactly (any weights) "
                                 "and are copied from it -- or, with lazy = true (--lazy-background 1, default), never written: the next conv reads the halo "
-                                "pixels that fall into such a tile from the empty frame's map, the fused 1x1 tail runs on the last conv's live "
-                                "list (bit-identical either way).  Data dependent: --background-skip 0 convolves every tile"}
+                                "pixels that fall into such a tile from the empty frame's map, the 1x1 tail runs in the epilogue of the last conv's live "
+                                "tiles (bit-identical either way).  Data dependent: --background-skip 0 convolves every tile"}
         else:
             bg_tiles = {"enabled": False}
         try:

@@ -304,7 +304,7 @@ class _Session:
                     torch.cuda.current_stream().wait_stream(s)
                     torch.cuda.synchronize()
                     self.graph = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                    with ops.rt.capture_guard(), torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
                         self.outs = self.body()
                     self.eng.stats["captures"] += 1
         finally:

@@ -216,9 +216,9 @@ class _TrainSession:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.g_fwd, self.g_bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_fwd, pool=pool, capture_error_mode="thread_local"):
+        with ops.rt.capture_guard(), torch.cuda.graph(self.g_fwd, pool=pool, capture_error_mode="thread_local"):
             out = self.body()
-        with torch.cuda.graph(self.g_bwd, pool=pool, capture_error_mode="thread_local"):
+        with ops.rt.capture_guard(), torch.cuda.graph(self.g_bwd, pool=pool, capture_error_mode="thread_local"):
             self._grads(out)
         with torch.no_grad():
             sd = det.state_dict()

@@ -1263,7 +1263,7 @@ class SecondDetector(nn.Module):
         graph = torch.cuda.CUDAGraph()
         outs, self._branch_overflow = [], []
         # thread_local: a RCCL watchdog / other host thread touching the runtime must not invalidate the capture
-        with torch.no_grad(), torch.cuda.graph(graph, capture_error_mode="thread_local"):
+        with ops.rt.capture_guard(), torch.no_grad(), torch.cuda.graph(graph, capture_error_mode="thread_local"):
             cur = torch.cuda.current_stream()
             side = [torch.cuda.Stream() for _ in parts[1:]]
             for st in side:
@@ -1296,7 +1296,7 @@ class SecondDetector(nn.Module):
         prev = ops.set_rulebook_numbering(self.rulebook_numbering)
         try:
             with torch.no_grad():
-                with torch.cuda.graph(ga, pool=pool, capture_error_mode="thread_local"):
+                with ops.rt.capture_guard(), torch.cuda.graph(ga, pool=pool, capture_error_mode="thread_local"):
                     vox = self.voxel_generator.generate_device(points, point_offsets, mean_features=nf, sync=False,
                                                                mean_dtype=self._infer_dtype)
                     spatial = self.middle_feature_extractor(vox["mean"].to(self._infer_dtype), vox["coordinates"], batch_size,
@@ -1309,10 +1309,10 @@ class SecondDetector(nn.Module):
                         with self.lazy_heads():
                             spatial.tile_lists(self.rpn.list_layers() if lazy_ else self.rpn.background_convs,   # the live-tile lists belong to the latency-bound segment
                                                masks=lazy_)
-                with torch.cuda.graph(gb, pool=pool, capture_error_mode="thread_local"):
+                with ops.rt.capture_guard(), torch.cuda.graph(gb, pool=pool, capture_error_mode="thread_local"):
                     with self.lazy_heads():
                         preds = self.rpn(spatial)
-                with torch.cuda.graph(gc, pool=pool, capture_error_mode="thread_local"):
+                with ops.rt.capture_guard(), torch.cuda.graph(gc, pool=pool, capture_error_mode="thread_local"):
                     out = self.predict_device(preds, batch_size)
         finally:
             ops.set_rulebook_numbering(prev)

@@ -2,6 +2,7 @@
 
 Fails loudly: no library -> RuntimeError at first use; no silent CPU path anywhere.
 """
+import contextlib
 import ctypes
 import os
 
@@ -230,6 +231,23 @@ def require_gpu(*tensors):
             raise SecondHipError(
                 "second_amd ops are GPU only (got a CPU tensor): there is no CPU path by decision (INTEGRATION.md section 1, CPU tensors); "
                 "move the tensors to the MI355X -- the reference does with example_convert_to_torch(..., device), train.py:24-55")
+
+
+@contextlib.contextmanager
+def capture_guard():
+    """No Python garbage collection inside a stream capture.  Destroying a hipGraph (``torch.cuda.CUDAGraph.__del__`` of an object an earlier
+    capture left in a reference cycle) while a stream of the process is capturing fails with hipErrorStreamCaptureUnsupported -- raised from
+    a destructor, i.e. ``terminate`` -- and the collector runs whenever an allocation crosses its threshold (torch >= 2.9 no longer collects
+    before a capture unless ``torch.compiler.config.force_cudagraph_gc``).  Collect first, then keep the collector off until the capture ends."""
+    import gc
+    gc.collect()
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
 
 
 def ptr(t):

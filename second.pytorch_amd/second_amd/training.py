@@ -293,7 +293,8 @@ class DeviceTrainer:
         ops._bn_counter_stack.append([[], False])   # throw-away frame: the three non-capturing warm-up iterations of make_graphed_callables
         try:                                    # must not queue num_batches_tracked increments into the step's deferred list
             sample = x.detach().clone().requires_grad_()
-            fn = torch.cuda.make_graphed_callables(_Mixed(), (sample,))
+            with ops.rt.capture_guard():        # (its captures use the global error mode: a collector run inside would abort the process)
+                fn = torch.cuda.make_graphed_callables(_Mixed(), (sample,))
         except Exception as e:  # noqa: BLE001 -- capture is an optimisation: the eager path is always correct
             import warnings
             warnings.warn(f"second_amd: hipGraph capture of the RPN training segment failed ({e!r}); running it eagerly")
@@ -386,7 +387,7 @@ class DeviceTrainer:
         if in_graph:
             try:
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                with ops.rt.capture_guard(), torch.cuda.graph(g, capture_error_mode="thread_local"):
                     out6 = self.step(*bufs)
                 graphs = (g,)
             except Exception as e:  # noqa: BLE001
@@ -400,11 +401,11 @@ class DeviceTrainer:
             g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             # graph 1 ends with the gradients PACKED into the flat bucket (the copies are captured: which tensors backward handed over
             # is host state of the capture, not of a replay); the collective runs on the bucket between the graphs
-            with torch.cuda.graph(g1, pool=pool, capture_error_mode="thread_local"):
+            with ops.rt.capture_guard(), torch.cuda.graph(g1, pool=pool, capture_error_mode="thread_local"):
                 out6 = self._step_backward(*bufs)
                 self.bucket.pack()
             self.bucket.reduce(average=True)
-            with torch.cuda.graph(g2, pool=pool, capture_error_mode="thread_local"):
+            with ops.rt.capture_guard(), torch.cuda.graph(g2, pool=pool, capture_error_mode="thread_local"):
                 self.bucket.unpack()
                 self._step_update()
             graphs = (g1, g2)

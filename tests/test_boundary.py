@@ -156,3 +156,36 @@ def test_fork_after_hip_init_on_hardware_raises_in_the_child():
         print("ok")
     """, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_capture_guard_keeps_the_collector_off_and_restores_it():
+    """runtime.capture_guard: garbage is collected BEFORE the guarded region (a hipGraph destroyed while a stream captures aborts the process),
+    the collector is off inside it -- also when the region raises -- and back in its previous state afterwards."""
+    import gc
+    import weakref
+    from second_amd import runtime as rt
+
+    class Node:
+        pass
+    a, b = Node(), Node()
+    a.other, b.other = b, a                  # a reference cycle: only the collector frees it
+    probe = weakref.ref(a)
+    del a, b
+    assert gc.isenabled()
+    with rt.capture_guard():
+        assert probe() is None               # collected on entry
+        assert not gc.isenabled()
+    assert gc.isenabled()
+    try:
+        with rt.capture_guard():
+            raise ValueError("inside")
+    except ValueError:
+        pass
+    assert gc.isenabled()
+    gc.disable()
+    try:
+        with rt.capture_guard():
+            assert not gc.isenabled()
+        assert not gc.isenabled()            # it was off before: stays off
+    finally:
+        gc.enable()

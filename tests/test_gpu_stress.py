@@ -82,7 +82,7 @@ def test_rotated_nms_keep_list_is_stable_over_500_replays_beside_the_rpn_conv():
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.stream(s_nms):
-        with torch.cuda.graph(g, stream=s_nms, capture_error_mode="thread_local"):
+        with ops.rt.capture_guard(), torch.cuda.graph(g, stream=s_nms, capture_error_mode="thread_local"):
             keep, nk = ops.nms_sorted(dets, counts, thr, kind, sem, **kw)
     torch.cuda.synchronize()
     n0 = nk0.tolist()
