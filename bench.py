@@ -752,12 +752,12 @@ def other_configs(budget_s=270.0):
 
 
 # ------------------------------------------------------------------------------------------ extra lines
-def time_e2e(det, points, offsets, inflight, steps, warmup, serialize_rpn=False):
+def time_e2e(det, points, offsets, inflight, steps, warmup, serialize_rpn=False, rpn_tokens=None):
     """SURVEY 8(d) "end-to-end": the same loop as the timed region, but every step's clouds start in PINNED HOST memory
     (copied into the step's own input buffers on its stream) and its detections end in pinned host memory.  Per-lane input
     buffers, so lane k's copy overlaps the other lanes' compute."""
     from second_amd.models import InFlightRunner
-    runner = InFlightRunner(det, points, offsets, inflight=inflight, private_inputs=True, serialize_rpn=serialize_rpn and not det.pillars)
+    runner = InFlightRunner(det, points, offsets, inflight=inflight, private_inputs=True, serialize_rpn=serialize_rpn and not det.pillars, rpn_tokens=rpn_tokens)
     hp, ho = points.cpu().pin_memory(), offsets.cpu().pin_memory()
     for _ in range(max(3, warmup)):
         runner.step(hp, ho, fetch=True)
@@ -1090,7 +1090,9 @@ def main():
     ap.add_argument("--profile-run", action="store_true",
                     help="for runs under rocprofv3: no self-warming beyond --warmup and ONE timed window (keeps the trace small); the "
                          "printed value is then not a benchmark figure")
-    ap.add_argument("--rpn-tokens", type=int, default=1, help="--serialize-rpn 1: RPN segments allowed to run at a time")
+    ap.add_argument("--rpn-tokens", type=int, default=0,
+                    help="--serialize-rpn 1: RPN segments allowed to run at a time; 0 = InFlightRunner's own rule (two when at most 60 %% of the last "
+                         "conv's tiles are live on the calibration scene, one on denser scenes)")
     ap.add_argument("--background-skip", type=int, default=1,
                     help="RPN convs after the first compute only the tiles a site (or the zero padding) can reach and fill the others "
                          "with the layer's background vector (bit-identical outputs; 0 = convolve every tile)")
@@ -1177,7 +1179,7 @@ def main():
             serialize = (bool(args.serialize_rpn) and not det.pillars and getattr(det, "_infer_dtype", None) is not None
                          and args.branches <= 1 and args.inflight > 1)
             runner = InFlightRunner(det, points, offsets, inflight=args.inflight, branches=args.branches, serialize_rpn=serialize,
-                                    rpn_tokens=args.rpn_tokens)
+                                    rpn_tokens=args.rpn_tokens or None)
             graph_parts = runner.parts      # branches > 1: the roofline probe below times one branch's launch
             replays = runner.replays
             outs = runner.outputs[-1]
@@ -1266,7 +1268,7 @@ def main():
             except Exception as e:  # noqa: BLE001
                 dtrain = {"error": repr(e)[:300]}
         if rank == 0 and args.mode == "graph" and args.branches == 1 and args.workload == "car.fhd" and not args.no_extra_lines:
-            e2e = time_e2e(det, points, offsets, max(1, args.inflight), min(args.steps, 200), args.warmup, serialize_rpn=serialize)
+            e2e = time_e2e(det, points, offsets, max(1, args.inflight), min(args.steps, 200), args.warmup, serialize_rpn=serialize, rpn_tokens=args.rpn_tokens or None)
             batch1 = time_batch1(det, points, offsets)      # last: it re-calibrates the static capacities for one frame
         if (rank == 0 and world == 1 and args.mode == "graph" and args.branches == 1 and args.workload == "car.fhd" and not args.no_extra_lines
                 and getattr(det.rpn, "background_convs", 0) and det.rpn.skip_background):
@@ -1359,6 +1361,7 @@ def main():
                        "graph_branches": args.branches if args.mode == "graph" else None,
                        "steps_in_flight": max(1, args.inflight) if args.mode == "graph" else 1,
                        "rpn_segments_serialized": bool(serialize) if args.mode == "graph" else None,
+                       "rpn_tokens": runner.rpn_tokens if (args.mode == "graph" and serialize) else None,
                        "single_step_latency_ms": latency_ms, "frames_per_s_one_step_at_a_time": one_at_a_time,
                        "rulebook_numbering": det.rulebook_numbering, "points_per_frame": int(points.shape[0]) // WL["batch"],
                        "rows_per_frame": rows_per_frame,

@@ -704,6 +704,7 @@ class RPNInference(nn.Module):
         # conv's output never reaches memory
         self.fused_tail = True
         self.last_live_counts = None       # [convs, B] int32 on the device: live tiles per conv and frame of the last forward (bench / tests)
+        self.last_tiles_per_frame = None   # tiles of one frame's map in that forward
         self._empty_maps = {}
         self.register_load_state_dict_post_hook(lambda module, incompatible: module._repack())
         convs = [i for kind, i in self.plan if kind == "c"]
@@ -913,6 +914,7 @@ class RPNInference(nn.Module):
                         live, self.last_live_counts, nbr = gather.tile_lists(self.list_layers(), masks=True)
                     else:
                         (live, self.last_live_counts), nbr = gather.tile_lists(self.background_convs), None
+                    self.last_tiles_per_frame = int(live.shape[-1])
                     x = ops.conv2d_nhwc_gather(gather.features, sm, self.gather_packed, self.bs[i], self.ws[i].shape[0], relu=True,
                                                tile_order=live[0], live_counts=self.last_live_counts[0], background=None if lazy else empty[0])
                 else:
@@ -1491,7 +1493,7 @@ class InFlightRunner:
     ``step()`` enqueues one full forward and returns (outputs, stream): the output tensors of that lane, valid once
     ``stream`` has been synchronised (or after :meth:`synchronize`) and until the lane is stepped again."""
 
-    def __init__(self, det, points, point_offsets, inflight=3, branches=1, private_inputs=False, serialize_rpn=False, rpn_tokens=1):
+    def __init__(self, det, points, point_offsets, inflight=3, branches=1, private_inputs=False, serialize_rpn=False, rpn_tokens=None):
         """``private_inputs``: every lane gets its OWN copy of the input buffers (``self.inputs[k]``) and pinned host
         mirrors of its outputs, so that :meth:`step` can take a host-resident batch: the pinned-host -> HBM copy of lane k's
         next clouds then overlaps the compute of the other lanes (the end-to-end serving form; with shared buffers a copy
@@ -1505,7 +1507,8 @@ class InFlightRunner:
         # segments fill the rest of the chip
         self.serialize_rpn = bool(serialize_rpn) and branches <= 1 and int(inflight) > 1
         self._rpn_token = None
-        self.rpn_tokens = max(1, int(rpn_tokens))   # RPN segments allowed at a time (a ring of that many events)
+        # RPN segments allowed at a time (a ring of that many events); None = decided after the captures from the scene (below)
+        self.rpn_tokens = None if rpn_tokens is None else max(1, int(rpn_tokens))
         self._rpn_events = []
         self._keepalive = []                      # per lane: the buffers its three graphs hand to each other
         assert not (private_inputs and branches > 1), "private input buffers are a single-chain feature"
@@ -1529,6 +1532,23 @@ class InFlightRunner:
             self.replays.append(replay)
             self.outputs.append(outs)
             self._overflow += [c for lst in getattr(det, "_branch_overflow", []) for c in lst]
+        if self.rpn_tokens is None:
+            # Two RPN segments at a time when the RPN is the light part of the step -- the calibration scene leaves most of the last conv's
+            # tiles to the background -- and one when the scene is dense.  Measured with four lanes, interleaved runs (gpurun r06_lanes3 /
+            # r06_tok2; round 6, since the last RPN conv carries the 1x1 tail): car.fhd (39 % of the tiles live) one token 20.2-20.3 k
+            # frames/s, two 20.9 k, three 20.4-20.5 k, unserialised 20.5 k; dense seeded scene (81 % live) 8.45 k with one, 8.38 k with two.
+            # (Before the tail moved, one and two tokens were level: 20.0 / 20.1 k, r05_j.)
+            self.rpn_tokens = 1
+            counts = getattr(det.rpn, "last_live_counts", None)
+            if self.serialize_rpn and counts is not None and getattr(det.rpn, "skip_background", False):
+                for seg in self.replays[-1]:          # the counts are the last capture's buffer: one replay of that lane fills it
+                    seg()
+                torch.cuda.synchronize()
+                tiles = getattr(det.rpn, "last_tiles_per_frame", None)
+                if tiles:
+                    last = min(det.rpn.background_convs, counts.shape[0]) - 1
+                    share = float(counts[last].sum().item()) / float(tiles * counts.shape[1])
+                    self.rpn_tokens = 2 if share <= 0.6 else 1
         self.lanes = [lane_stream(index=i) for i in range(len(self.replays))] if len(self.replays) > 1 else [None]
         self._k = 0
 

@@ -155,6 +155,47 @@ def test_rpn_with_background_tiles_is_bit_identical_to_the_full_convs(ops, dtype
         assert counts[1] < tiles, "nothing was skipped: the comparison would be vacuous"
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("batch,h,w,n", [(3, 50, 70, 200), (1, 40, 48, 1), (2, 33, 17, 0), (2, 96, 64, 4000), (2, 120, 112, 700), (1, 8, 16, 1)])
+def test_fused_tail_on_ragged_maps_matches_the_two_launches(ops, dtype, batch, h, w, n):
+    """sec_conv2d_nhwc_tiles_tail on maps that are not multiples of the 8 x 16 tile, empty frames, one-site frames and scenes that take the
+    plain tile order: the head tiles the last conv's list names equal, bit for bit, what sec_conv2d_nhwc_tiles_lazy +
+    sec_conv1x1_chain_nhwc_tiles write (RPNInference.fused_tail off); every other tile is poisoned in both."""
+    rng = np.random.default_rng(n + h + 1)
+    idx = np.zeros((0, 4), np.int32)
+    if n:
+        idx = np.stack([rng.integers(0, batch, n), rng.integers(0, 2, n), rng.integers(0, h, n), rng.integers(0, w, n)], 1)
+        idx[0, 2:] = [h - 1, w - 1]                                        # the ragged corner tile holds a site
+        idx = np.unique(idx, axis=0).astype(np.int32)
+    feat = torch.randn(max(len(idx), 1), 64, device="cuda").to(dtype)
+    smap = ops.sparse_site_map(torch.from_numpy(idx).cuda(), batch, [2, h, w])
+    rpn = _rpn_pair(dtype, 4)
+    bev = _bev(feat, smap)
+    seen, outs = [], {}
+    with torch.no_grad():
+        rpn.skip_background, rpn.lazy_background, rpn.lazy_heads = True, True, True
+        for fused in (True, False):
+            rpn.fused_tail = fused
+            ops.set_op_hook(lambda name, fn, a, kw, res: seen.append((fused, name)))
+            ops.POISON_LAZY_OUTPUTS = True
+            try:
+                outs[fused] = rpn(bev)
+            finally:
+                ops.POISON_LAZY_OUTPUTS = False
+                ops.set_op_hook(None)
+    assert (True, "conv2d_nhwc_tiles_tail") in seen and (False, "conv2d_nhwc_tiles_tail") not in seen and (False, "conv1x1_chain") in seen
+    mask_f, mask_u = outs[True]["lazy_heads"][0], outs[False]["lazy_heads"][0]
+    assert torch.equal(mask_f, mask_u)
+    live = ((mask_u.int() >> 4) & 1).bool()
+    th, tw = -(-h // 8), -(-w // 16)
+    m = live.view(batch, th, tw).repeat_interleave(8, 1).repeat_interleave(16, 2)[:, :h, :w]
+    if n:
+        assert bool(m.any())
+    for k in ("box_preds", "cls_preds", "dir_cls_preds"):
+        a, b = outs[True][k].permute(0, 2, 3, 1, 4)[m], outs[False][k].permute(0, 2, 3, 1, 4)[m]
+        assert not torch.isnan(b.float()).any() and torch.equal(a, b), k
+
+
 def test_lazy_background_across_a_change_from_lists_to_the_plain_order(ops):
     """A scene whose live share crosses the list threshold (225 / 256 of the tiles, csrc/dense.hip g_list_max_live_q8) between two layers: the early convs use their lists and write their live tiles
     only, a later conv takes the plain tile order and must read that output through the tile-indexed masks (every tile it computes, the
