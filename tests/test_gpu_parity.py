@@ -1234,6 +1234,9 @@ def test_detector_steps_in_flight_with_serialised_rpn_segments(syn):
         for private in (False, True):
             runner = InFlightRunner(det, pts, offs, inflight=4, serialize_rpn=True, private_inputs=private)
             assert runner.serialize_rpn and isinstance(runner.replays[0], tuple) and len(runner.replays[0]) == 3
+            # the runner's token rule: two RPN segments at a time up to 60 % live tiles in the last conv of the calibration scene, else one
+            share = float(det.rpn.last_live_counts[det.rpn.background_convs - 1].sum()) / (det.rpn.last_tiles_per_frame * 3)
+            assert runner.rpn_tokens == (2 if share <= 0.6 else 1), (runner.rpn_tokens, share)
             hp, ho = (pts.cpu().pin_memory(), offs.cpu().pin_memory()) if private else (None, None)
             for _ in range(11):
                 runner.step(hp, ho, fetch=private)
@@ -1245,6 +1248,7 @@ def test_detector_steps_in_flight_with_serialised_rpn_segments(syn):
             if private:
                 for h in runner.host_outputs:
                     assert torch.equal(h["valid"], m.cpu()) and torch.equal(h["boxes"][m.cpu()], e["boxes"][m].cpu())
+        assert InFlightRunner(det, pts, offs, inflight=2, serialize_rpn=True, rpn_tokens=3).rpn_tokens == 3        # an explicit count is kept
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
