@@ -1022,6 +1022,9 @@ __global__ __launch_bounds__(256, CIN == 128 ? 3 : 2) void k_conv2d_halo_reg(con
                     T *ypix = reinterpret_cast<T *>(tail.y) + (ok ? (((size_t)b * p.h + oy) * p.w + ox) * 64 : 0);
                     store_tile_t<T>(a2[mt], tail.b2, wn * 32, 0, ypix, ok, hh);
                 }
+#ifdef SEC_CONV_TIMELINE
+                if (tl && tid == 0) atomicSub(&g_cu_resident[cu_key], 1);     // (no timeline record for the tail form; keep the residency count right)
+#endif
                 return;
             }
             uint4 *y4 = reinterpret_cast<uint4 *>(y);
